@@ -55,6 +55,83 @@ def make_genome(total_bp: int, n_contigs: int = 3, seed: int = 11, repeat_frac: 
     return contigs
 
 
+def add_duplications(contigs, seg_len: int = 12000, copies: int = 3, div: float = 0.025, seed: int = 5):
+    """Copy one `seg_len` segment to `copies-1` other places at `div` divergence (substitutions):
+    reads drawn from it have several near-equal candidate windows -> lordFAST's fine mode."""
+    rng = np.random.default_rng(seed)
+    name, s0 = contigs[0]
+    src = int(rng.integers(0, len(s0) - seg_len))
+    seg = s0[src:src + seg_len].copy()
+    places = [(0, src)]
+    for k in range(copies - 1):
+        ci = (k + 1) % len(contigs)
+        _, s = contigs[ci]
+        p = int(rng.integers(0, len(s) - seg_len))
+        c = seg.copy()
+        mut = rng.random(seg_len) < div
+        cur = np.searchsorted(_ACGT, c[mut])
+        c[mut] = _ACGT[(cur + rng.integers(1, 4, size=int(mut.sum()))) % 4]
+        s[p:p + seg_len] = c
+        places.append((ci, p))
+    return places
+
+
+def special_reads(contigs, dup_places=None, seed: int = 77, err: float = 0.10):
+    """Reads engineered to reach the rare branches of the extension code:
+    big deletion / insertion (split + supplementary), inversion with indel (inverted middle segment),
+    junk head / tail (clip test), chimera, duplicated-segment read (fine mode), too short, N-rich,
+    lower case, unmappable."""
+    rng = np.random.default_rng(seed)
+    out = []
+
+    def frag(ci, p, ln):
+        return contigs[ci][1][p:p + ln].copy()
+
+    def rnd(n):
+        return _ACGT[rng.integers(0, 4, size=n, dtype=np.uint8)]
+
+    def emit(tag, arr, rc=False, e=err):
+        if rc:
+            arr = revcomp(arr)
+        out.append((f"s{len(out)}_{tag}", mutate(arr, e, rng).tobytes()))
+
+    big = max(range(len(contigs)), key=lambda i: len(contigs[i][1]))
+    n_big = len(contigs[big][1])
+    for rc in (False, True):
+        p = int(rng.integers(1000, n_big - 12000))
+        f = frag(big, p, 9000)
+        emit("del600", np.concatenate([f[:4000], f[4600:]]), rc)                       # 600 bp deletion in read
+        emit("ins600", np.concatenate([f[:4000], rnd(600), f[4000:]]), rc)             # 600 bp insertion in read
+        emit("ins2500", np.concatenate([f[:3000], rnd(2500), f[3000:]]), rc)           # long junk insertion
+        # inversion + deletion sized so that the gap fails the 0.40 identity test forward but its reverse
+        # complement passes the 0.60 test -> inverted middle segment (src/LordFAST.cpp:2033-2077)
+        emit("inv", np.concatenate([f[:3000], revcomp(f[3000:4500]), f[4850:]]), rc, 0.06)
+        emit("inv2", np.concatenate([f[:3000], revcomp(f[3000:5000]), rnd(900), f[5000:]]), rc, 0.05)
+        emit("inv3", np.concatenate([f[:3000], revcomp(f[3000:4500]), f[4700:]]), rc)  # aligned through
+        emit("junkhead", np.concatenate([rnd(1500), f[:6000]]), rc)
+        emit("junktail", np.concatenate([f[:6000], rnd(1500)]), rc)
+        emit("junkboth", np.concatenate([rnd(800), f[:5000], rnd(900)]), rc, 0.15)
+        q = int(rng.integers(1000, len(contigs[0][1]) - 6000))
+        emit("chimera", np.concatenate([f[:4000], frag(0, q, 4000)]), rc)
+    if dup_places:
+        for (ci, p) in dup_places:
+            for rc in (False, True):
+                emit("dup", frag(ci, p + 1500, 8000), rc, 0.12)
+    emit("short", frag(big, 500, 700))
+    emit("unmappable", rnd(4000), e=0.0)
+    nread = frag(big, 2000, 5000)
+    nread[rng.integers(0, 5000, size=150)] = ord("N")
+    emit("withN", nread)
+    low = mutate(frag(big, 8000, 4000), err, rng)
+    out.append((f"s{len(out)}_lower", low.tobytes().lower()))
+    emit("edge_start", frag(big, 0, 3000))
+    emit("edge_end", frag(big, n_big - 3000, 3000))
+    emit("edge_end_rc", frag(big, n_big - 3500, 3500), True)
+    last = len(contigs) - 1
+    emit("genome_end", frag(last, len(contigs[last][1]) - 3000, 3000))
+    return out
+
+
 def write_fasta(path: str, contigs, width: int = 80) -> None:
     with open(path, "wb") as fh:
         for name, s in contigs:

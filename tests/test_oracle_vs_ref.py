@@ -1,0 +1,160 @@
+"""Pin the oracle against the REAL reference (oracle/_ref/liblfref.so, compiled by oracle/Makefile from
+/root/reference) on seeded random inputs.  Skipped where that build is absent.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from lordfast_amd import synth
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def rseq(rng, n, alphabet=ACGT, p=None):
+    return bytes(rng.choice(alphabet, size=n, p=p))
+
+
+def test_edlib_fuzz(oracle_lib, ref):
+    orc = oracle_lib.Oracle()
+    rng = np.random.default_rng(1)
+    n_cases = 0
+    lens = list(range(1, 40)) + [62, 63, 64, 65, 66, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320, 500, 700]
+    for it in range(2600):
+        n = int(rng.choice(lens))
+        kind = it % 5
+        if kind == 0:
+            q = rseq(rng, n); t = rseq(rng, int(rng.choice(lens)))
+        elif kind == 1:
+            q = rseq(rng, n, ACGT[:2], [0.85, 0.15]); t = rseq(rng, int(rng.choice(lens)), ACGT[:2], [0.85, 0.15])
+        else:
+            q = rseq(rng, n)
+            t = synth.mutate(np.frombuffer(q, dtype=np.uint8), float(rng.uniform(0.0, 0.4)), rng).tobytes() or q
+        for mode in (0, 1):
+            tt = t + rseq(rng, int(rng.integers(0, 25))) if mode == 1 else t
+            a = ref.edlib(q, tt, mode)
+            b = orc.edlib(q, tt, mode)
+            assert a[0] == b[0] and a[1] == b[1], (n, len(tt), mode, a[:2], b[:2])
+            assert np.array_equal(a[2], b[2]), (n, len(tt), mode)
+            n_cases += 1
+    assert n_cases >= 5000
+
+
+def test_edlib_hirschberg_fuzz(oracle_lib, ref):
+    orc = oracle_lib.Oracle()
+    rng = np.random.default_rng(2)
+    for it in range(14):
+        n = int(rng.integers(1800, 4200))
+        q = np.frombuffer(rseq(rng, n), dtype=np.uint8)
+        t = synth.mutate(q, float(rng.uniform(0.05, 0.3)), rng)
+        if it % 3 == 0:      # low-complexity insert: many co-optimal paths across the split column
+            q = np.concatenate([q[:n // 2], np.frombuffer(b"AT" * 200, dtype=np.uint8), q[n // 2:]])
+        if it % 4 == 1:
+            t = np.concatenate([t[:500], t[900:]])
+        mode = it % 2
+        tt = t.tobytes() + (rseq(rng, 20) if mode else b"")
+        a = ref.edlib(q.tobytes(), tt, mode)
+        b = orc.edlib(q.tobytes(), tt, mode)
+        assert a[:2] == b[:2]
+        assert np.array_equal(a[2], b[2])
+
+
+def test_ksw_fuzz(oracle_lib, ref):
+    orc = oracle_lib.Oracle()
+    rng = np.random.default_rng(3)
+    for it in range(1500):
+        n = int(rng.integers(1, 700))
+        q = rng.integers(0, 4, size=n).astype(np.uint8)
+        if it % 3 == 0:
+            t = rng.integers(0, 4, size=int(rng.integers(1, 700))).astype(np.uint8)
+        else:
+            keep = int(rng.integers(1, n + 1))
+            t = np.concatenate([q[:keep], rng.integers(0, 4, size=int(rng.integers(0, 200))).astype(np.uint8)])
+            mut = rng.random(len(t)) < rng.uniform(0, 0.2)
+            t[mut] = rng.integers(0, 4, size=int(mut.sum())).astype(np.uint8)
+            if it % 2 and len(t) > 8:
+                t = np.delete(t, rng.integers(0, len(t), size=4))
+            if it % 7 == 0 and n > 8:
+                q = np.delete(q, rng.integers(0, n, size=4))
+        if it % 11 == 0:
+            q = q.copy(); q[rng.integers(0, len(q), size=2)] = 4
+        prm = (0, 1, 0, 1, 40, 40, len(q)) if it % 2 else (8, 1, 4, 1, 100, 200, len(q))
+        assert ref.ksw_extend2(q, t, *prm) == orc.ksw_extend2(q, t, *prm), it
+
+
+def test_chain_and_sort_fuzz(oracle_lib, ref):
+    orc = oracle_lib.Oracle()
+    ref.set_params(oracle_lib.default_params(), "t")
+    rng = np.random.default_rng(4)
+    for it in range(400):
+        n = int(rng.integers(0, 400)) if it % 10 else int(rng.integers(400, 3000))
+        nq = max(1, int(n * rng.uniform(0.05, 1.0)))
+        qpool = np.sort(rng.integers(0, 20000, size=nq))
+        q = qpool[rng.integers(0, nq, size=n)].astype(np.uint32)
+        if it % 4 == 0:   # near-collinear with tiny offsets: equal-score ties in the DP
+            t = (q.astype(np.int64) + rng.integers(-2, 3, size=n) + 100000).astype(np.uint32)
+        elif it % 4 == 1:  # several diagonals (repeat copies)
+            t = (q.astype(np.int64) + rng.choice([100000, 100003, 250000], size=n)).astype(np.uint32)
+        else:
+            t = rng.integers(50000, 90000, size=n).astype(np.uint32)
+        ln = rng.integers(14, 25, size=n).astype(np.uint32)
+        if it % 5 == 0 and n:   # organ-pipe / sorted / reversed patterns for the introsort paths
+            order = np.argsort(q, kind="stable")
+            if it % 2:
+                order = order[::-1]
+            q, t, ln = q[order], t[order], ln[order]
+        sd = np.stack([t, q, ln], axis=1) if n else np.zeros((0, 3), dtype=np.uint32)
+        a = ref.chain_n2(sd)
+        b = orc.chain_n2(sd)
+        assert np.array_equal(a[0], b[0]), f"sort order differs (n={n}, it={it})"
+        assert np.array_equal(a[1], b[1]), f"chain differs (n={n}, it={it})"
+        assert np.float32(a[2]) == np.float32(b[2])
+
+
+@pytest.fixture(scope="module")
+def big_case(tmp_path_factory, ref, oracle_lib):
+    d = tmp_path_factory.mktemp("g600k")
+    g = synth.make_genome(600000, 4, seed=21, n_families=40, repeat_frac=0.10)
+    dup = synth.add_duplications(g, 12000, 3, 0.025)
+    fa = os.path.join(str(d), "g.fa")
+    synth.write_fasta(fa, g)
+    ref.index_build(fa)
+    ref.load(fa)
+    reads = synth.special_reads(g, dup, seed=5) + synth.make_reads(g, 60, 7000, 0.15, seed=6) \
+        + synth.make_reads(g, 30, 3000, 0.10, seed=7, mix=(0.40, 0.25, 0.35))
+    return fa, reads
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(max_map=30), dict(min_anchor_len=17, sampling_count=2000),
+                                dict(min_anchor_len=12, sampling_count=400, max_ref_hits=30),
+                                dict(min_read_len=4000, gap_penalty=0.3, chain_reward=5.0, chain_penalty=8.0)])
+def test_sam_vs_reference(big_case, ref, oracle_lib, kw):
+    fa, reads = big_case
+    names = [r[0] for r in reads]
+    seqs = [r[1] for r in reads]
+    orc = oracle_lib.Oracle(fa)
+    p = oracle_lib.default_params(**kw)
+    ref.set_params(p, "t")
+    exp, _ = ref.map_mem(names, seqs)
+    got = orc.map_batch(names, seqs, params=oracle_lib.default_params(threads=4, **kw))
+    assert got == exp
+    # seeds too
+    for s in seqs[::7]:
+        if len(s) < 20:
+            continue
+        a = ref.seed(s); b = orc.seed(s, params=p)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    orc.close()
+
+
+def test_fastq_qualities(big_case, ref, oracle_lib):
+    fa, reads = big_case
+    names = [r[0] for r in reads[:25]]
+    seqs = [r[1] for r in reads[:25]]
+    rng = np.random.default_rng(8)
+    quals = [bytes(rng.integers(35, 74, size=len(s)).astype(np.uint8)) for s in seqs]
+    orc = oracle_lib.Oracle(fa)
+    p = oracle_lib.default_params()
+    ref.set_params(p, "t")
+    exp, _ = ref.map_mem(names, seqs, quals)
+    assert orc.map_batch(names, seqs, quals, params=p) == exp
+    orc.close()
