@@ -1,0 +1,213 @@
+/*
+ * lordfast_amd.h -- C ABI of liblfgpu.so: the MI355X (gfx950) implementation of lordFAST's per-read
+ * seed -> vote -> chain -> extend -> SAM hot path (reference: vpc-ccg/lordfast v0.0.10).
+ *
+ * Plain C: pointers and sizes only.  Two layers:
+ *
+ *   1. Batch API (lf_*)  -- what a GPU wants: one call per read batch / problem batch.
+ *   2. Drop-in entry points -- the reference's own internal function names and argument meaning
+ *      (bwt_load, getLocs_extend_whole_step, chain_seeds_n2, edlibAlign, ksw_extend2, mapSeqMT ...),
+ *      thin single-item wrappers over layer 1 that operate on one process-global index, exactly like
+ *      the reference's globals.  Each cites the reference declaration it replaces.
+ *
+ * All compute goes through HIP kernels; there is no CPU fallback: every entry point that needs the
+ * device returns LF_ERR_NO_DEVICE (or aborts with a message, for the void drop-in calls) when no
+ * gfx950 device / code object is available.
+ */
+#ifndef LORDFAST_AMD_H
+#define LORDFAST_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LF_OK             0
+#define LF_ERR_IO         1
+#define LF_ERR_NO_DEVICE  2
+#define LF_ERR_ARG        3
+#define LF_ERR_HIP        4
+#define LF_ERR_NOMEM      5
+
+/* ------------------------------------------------------------------------------------------------
+ * Data model (reference: src/LordFAST.h:30-75)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Seed_t (src/LordFAST.h:30-35): same 8-byte layout, qPos 20 bits / len 12 bits. */
+typedef struct {
+    uint32_t tPos;
+    uint32_t qPos : 20;
+    uint32_t len  : 12;
+} Seed_t;
+
+typedef struct { Seed_t *list; uint32_t num; } SeedList;                 /* src/LordFAST.h:37-41 */
+typedef struct { Seed_t *seeds; uint32_t chainLen; float score; } Chain_t; /* src/LordFAST.h:65-70 */
+
+/* option globals of src/CommandLineParser.cpp:41-55 gathered in one struct */
+typedef struct {
+    int    min_anchor_len;   /* -k MIN_ANCHOR_LEN   14   [12..20] */
+    int    sampling_count;   /* -c SAMPLING_COUNT   1000 */
+    int    max_map;          /* -n MAX_MAP          10   */
+    int    min_read_len;     /* -l MIN_READ_LEN     1000 (>= 100) */
+    int    max_ref_hits;     /* -m MAX_REF_HITS     1000 */
+    int    chain_alg;        /* -a 0 = dp-n2 (clasp: not available on this path yet) */
+    double chain_reward;     /* --chainReward  9.3  */
+    double chain_penalty;    /* --chainPenalty 11.4 */
+    double gap_penalty;      /* --gapPenalty   0.15 */
+    int    threads;          /* -t host glue threads (0 = all online CPUs, max 255) */
+    char   read_group_id[256]; /* -R ... ID, empty = none */
+} lf_params_t;
+
+void lf_params_default(lf_params_t *p);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device / index
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lf_index lf_index_t;      /* FM-index + pac + contigs, resident in HBM */
+
+/* number of usable gfx950 devices (0 = none; never throws) */
+int lf_device_count(void);
+const char *lf_last_error(void);
+
+/* Load <prefix>.bwt/.sa/.pac/.ann/.amb (formats: SURVEY App. A; lib/bwa/bwt.c:421-462,
+ * lib/bwa/bntseq.c:100-160) and put them in HBM of `device`.  The 256 MiB <prefix>.cache of
+ * src/BWT.cpp:159-187 is NOT read: the 12-mer table is rebuilt on the GPU (src/BWT.cpp:60-115).
+ * flags: LF_IDX_FULL_SA materialises the whole suffix array in HBM so that locate is one load
+ * instead of a ~31-step LF walk (results identical). */
+#define LF_IDX_FULL_SA 1u
+int  lf_index_load(const char *prefix, int device, unsigned flags, lf_index_t **out);
+void lf_index_free(lf_index_t *idx);
+uint32_t lf_index_genome_len(const lf_index_t *idx);          /* bwt_get_refGenLen, src/BWT.cpp:305 */
+int  lf_index_n_contigs(const lf_index_t *idx);
+const char *lf_index_contig(const lf_index_t *idx, int i, int64_t *offset, int32_t *len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage 1: seeding -- getLocs_extend_whole_step for a batch of reads (src/BWT.cpp:312-394)
+ *   reads: concatenated bases (ASCII, any case), read i = reads[off[i] .. off[i+1])
+ *   result: for read i the forward seeds F[offF[i]..offF[i+1]) and reverse seeds R[offR[i]..offR[i+1]),
+ *   same content and order as the reference's two SeedLists.  Buffers are owned by the result.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int       n_reads;
+    uint64_t *offF, *offR;        /* n_reads + 1 each */
+    Seed_t   *F, *R;
+    /* algorithmic-byte counters of SURVEY 8(d), summed over the batch */
+    uint64_t  n_cache, n_occblk, n_sa, n_readbytes;
+    /* kernel time (ms, HIP events on the launch stream): search, accept+scan, locate */
+    float     ms_search, ms_accept, ms_locate;
+} lf_seeds_t;
+
+int  lf_seed_batch(const lf_index_t *idx, const lf_params_t *p, int n_reads,
+                   const char *reads, const uint64_t *off, lf_seeds_t **out);
+void lf_seeds_free(lf_seeds_t *s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage 3: dp-n2 chaining for a batch of windows (src/Chain.cpp:232-310)
+ *   seeds of window w: seeds[off[w]..off[w+1]) -- REORDERED in place exactly as the reference's
+ *   std::sort by qPos does; chain indices (into the reordered window) are written to
+ *   chain_idx[off[w] .. off[w]+chain_len[w]) ; score[w] is the float the reference stores.
+ * ---------------------------------------------------------------------------------------------- */
+int lf_chain_n2_batch(const lf_params_t *p, int n_windows, Seed_t *seeds, const uint64_t *off,
+                      uint32_t *chain_idx, uint32_t *chain_len, float *score, int device);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage 4: edlib-equivalent alignment for a batch of problems (lib/edlib/edlib.cpp:101-221;
+ * output function: SURVEY App. F).  Raw-byte comparison, k = -1, task = PATH.
+ *   problem i: query q[qoff[i]..qoff[i+1]) vs target t[toff[i]..toff[i+1]), mode[i] 0 = NW, 1 = SHW
+ *   out: edit_distance[i], end_location[i] (may be -1 in SHW), ops of problem i at
+ *        ops[ops_off[i] .. ops_off[i] + ops_len[i]) with ops_off[i] = qoff[i] + toff[i]
+ *        (0 match, 1 insertion/query base, 2 deletion/target base, 3 mismatch).
+ * ---------------------------------------------------------------------------------------------- */
+int lf_edlib_batch(int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
+                   const uint8_t *mode, int32_t *edit_distance, int32_t *end_location,
+                   uint8_t *ops, uint32_t *ops_len, int device, float *kernel_ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * ksw_extend2 for a batch (lib/bwa/ksw.c:380-478), lordFAST's 5x5 clip matrix (+2 / -16 / N 0),
+ * end_bonus 0.  q/t hold codes 0..4.  prm[i] = {o_del,e_del,o_ins,e_ins,w,zdrop,h0}.
+ * ---------------------------------------------------------------------------------------------- */
+int lf_ksw_extend2_batch(int n, const uint8_t *q, const uint64_t *qoff, const uint8_t *t,
+                         const uint64_t *toff, const int32_t *prm, int32_t *score, int32_t *qle,
+                         int32_t *tle, int device);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole path: mapSeq over a batch (src/LordFAST.cpp:461-580) -> SAM records in read order.
+ *   names/seqs/quals: n NUL-terminated strings; quals may be NULL or quals[i] "" (FASTA -> "*").
+ *   *sam is malloc'd (free with lf_free), *sam_len bytes, no header.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    double ms_total, ms_seed, ms_vote, ms_chain, ms_extend, ms_sam;   /* wall, host clock */
+    float  ms_k_search, ms_k_accept, ms_k_locate, ms_k_chain, ms_k_edlib, ms_k_ksw; /* HIP events */
+    uint64_t n_reads, n_bases, n_seeds, n_chain_problems, n_edlib_problems, n_ksw_problems;
+    uint64_t n_cache, n_occblk, n_sa, n_readbytes;     /* SURVEY 8(d) seed counters */
+    uint64_t ext_bytes;                                /* sum over problems (q + ceil(t/4) + q + t) */
+    uint64_t edlib_launches, search_launches, locate_launches;
+} lf_stats_t;
+
+int  lf_map_batch(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,
+                  const char *const *seqs, const char *const *quals, char **sam, size_t *sam_len,
+                  lf_stats_t *stats);
+char *lf_sam_header(const lf_index_t *idx, const lf_params_t *p, const char *cmdline); /* src/BWT.cpp:668-681 */
+void lf_free(void *ptr);
+
+/* ------------------------------------------------------------------------------------------------
+ * Drop-in entry points: the reference's internal C/C++ functions with C linkage.
+ * They use one process-global index (like _fmd_index, src/BWT.cpp:32) and option set.
+ * ---------------------------------------------------------------------------------------------- */
+extern lf_params_t lf_global_params;      /* MIN_ANCHOR_LEN, SAMPLING_COUNT, ... (src/Common.h:76-81) */
+
+int      bwt_load(char *ref_path);                                        /* src/BWT.h:29  */
+uint32_t bwt_get_refGenLen(void);                                         /* src/BWT.h:31  */
+void     getLocs_extend_whole_step(char *qSeq, uint32_t qLen, uint32_t hash_count,
+                                   SeedList *seedForward, SeedList *seedReverse);   /* src/BWT.h:32 */
+void     bwt_get_intv_info(uint64_t beg, uint64_t end, char **chr_name, int32_t *chr_len,
+                           uint32_t *chr_beg, uint32_t *chr_end);         /* src/BWT.h:35 */
+void     bwt_get_chr_boundaries(uint64_t beg, uint64_t end, uint32_t *chr_beg, uint32_t *chr_end); /* src/BWT.h:36 */
+void     bwt_str_pac2int(uint32_t beg, uint32_t len, uint8_t *seq);       /* src/BWT.h:37 */
+void     bwt_str_pac2char(uint32_t beg, uint32_t len, char *seq);         /* src/BWT.h:38 */
+void     printSamHeader(FILE *fp);                                        /* src/BWT.h:39 */
+/* src/Chain.h:51 -- `Chain_t &bestChain` becomes a pointer in the C ABI */
+void     chain_seeds_n2(Seed_t *fragment_list, uint32_t nFragment, Chain_t *bestChain);
+
+/* lib/edlib/edlib.h:21-56,79-135,172,190 (same enum values and struct layouts) */
+typedef enum { EDLIB_MODE_NW, EDLIB_MODE_SHW, EDLIB_MODE_HW } EdlibAlignMode;
+typedef enum { EDLIB_TASK_DISTANCE, EDLIB_TASK_LOC, EDLIB_TASK_PATH } EdlibAlignTask;
+typedef struct { int k; EdlibAlignMode mode; EdlibAlignTask task; } EdlibAlignConfig;
+typedef struct {
+    int editDistance;
+    int *endLocations;
+    int *startLocations;
+    int numLocations;
+    unsigned char *alignment;
+    int alignmentLength;
+    int alphabetLength;
+} EdlibAlignResult;
+EdlibAlignConfig edlibNewAlignConfig(int k, EdlibAlignMode mode, EdlibAlignTask task);
+/* supports what lordFAST calls: k = -1, mode NW or SHW, task PATH (src/LordFAST.cpp:1833,1941,2168) */
+EdlibAlignResult edlibAlign(const char *query, int queryLength, const char *target, int targetLength,
+                            EdlibAlignConfig config);
+void edlibFreeAlignResult(EdlibAlignResult result);
+
+/* lib/bwa/ksw.h:108 -- m must be 5 and mat the clip matrix of src/LordFAST.cpp:178-187; end_bonus 0;
+ * _gtle/_gscore/_max_off must be NULL (lordFAST passes 0 for them) */
+int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat,
+                int o_del, int e_del, int o_ins, int e_ins, int w, int end_bonus, int zdrop, int h0,
+                int *qle, int *tle, int *gtle, int *gscore, int *max_off);
+
+/* src/LordFAST.h:122-126 -- the chunk driver. Read layout as src/Reads.h:28-35. */
+typedef struct { uint32_t *length; char *seq; char *qual; char *name; uint8_t *isFq; } Read;
+void initializeFAST(void);             /* opens lf_global_output (stdout if NULL), prints the header */
+void finalizeFAST(void);
+void initFASTChunk(Read *seqList, int seqListSize);
+void mapSeqMT(void);                   /* maps the chunk on the GPU, writes SAM records in read order */
+extern FILE *lf_global_output;
+extern int   lf_global_no_header;
+extern char  lf_global_cmdline[2000];
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LORDFAST_AMD_H */

@@ -1,0 +1,252 @@
+"""ctypes binding of liblfgpu.so (include/lordfast_amd.h).  No torch types cross this boundary."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class LfError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "liblfgpu.so")
+
+
+def build_library(quiet: bool = True) -> None:
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+class Params(C.Structure):
+    _fields_ = [("min_anchor_len", C.c_int), ("sampling_count", C.c_int), ("max_map", C.c_int),
+                ("min_read_len", C.c_int), ("max_ref_hits", C.c_int), ("chain_alg", C.c_int),
+                ("chain_reward", C.c_double), ("chain_penalty", C.c_double), ("gap_penalty", C.c_double),
+                ("threads", C.c_int), ("read_group_id", C.c_char * 256)]
+
+
+def default_params(**kw) -> Params:
+    p = Params(14, 1000, 10, 1000, 1000, 0, 9.3, 11.4, 0.15, 0, b"")
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class Seeds(C.Structure):
+    _fields_ = [("n_reads", C.c_int), ("offF", C.POINTER(C.c_uint64)), ("offR", C.POINTER(C.c_uint64)),
+                ("F", C.c_void_p), ("R", C.c_void_p),
+                ("n_cache", C.c_uint64), ("n_occblk", C.c_uint64), ("n_sa", C.c_uint64), ("n_readbytes", C.c_uint64),
+                ("ms_search", C.c_float), ("ms_accept", C.c_float), ("ms_locate", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("ms_total", "ms_seed", "ms_vote", "ms_chain", "ms_extend", "ms_sam")] + \
+               [(n, C.c_float) for n in ("ms_k_search", "ms_k_accept", "ms_k_locate", "ms_k_chain", "ms_k_edlib", "ms_k_ksw")] + \
+               [(n, C.c_uint64) for n in ("n_reads", "n_bases", "n_seeds", "n_chain_problems", "n_edlib_problems",
+                                          "n_ksw_problems", "n_cache", "n_occblk", "n_sa", "n_readbytes", "ext_bytes",
+                                          "edlib_launches", "search_launches", "locate_launches")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def lib():
+    """Load liblfgpu.so (fails loudly if it was not built: there is no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise LfError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(make -C lordfast_amd/csrc). There is no CPU fallback.")
+    L = C.CDLL(path)
+    L.lf_last_error.restype = C.c_char_p
+    L.lf_index_load.argtypes = [C.c_char_p, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
+    L.lf_index_free.argtypes = [C.c_void_p]
+    L.lf_index_genome_len.argtypes = [C.c_void_p]
+    L.lf_index_genome_len.restype = C.c_uint32
+    L.lf_seed_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_char_p, C.c_void_p,
+                                C.POINTER(C.POINTER(Seeds))]
+    L.lf_seeds_free.argtypes = [C.POINTER(Seeds)]
+    L.lf_free.argtypes = [C.c_void_p]
+    if hasattr(L, "lf_edlib_batch"):
+        L.lf_edlib_batch.argtypes = [C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    if hasattr(L, "lf_chain_n2_batch"):
+        L.lf_chain_n2_batch.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_int]
+    if hasattr(L, "lf_ksw_extend2_batch"):
+        L.lf_ksw_extend2_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    if hasattr(L, "lf_map_batch"):
+        L.lf_map_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_char_p),
+                                   C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_size_t), C.POINTER(Stats)]
+        L.lf_sam_header.restype = C.c_void_p
+        L.lf_sam_header.argtypes = [C.c_void_p, C.POINTER(Params), C.c_char_p]
+    _LIB = L
+    return L
+
+
+def device_count() -> int:
+    return lib().lf_device_count()
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise LfError(f"{what} failed (rc={rc}): {lib().lf_last_error().decode(errors='replace')}")
+
+
+def _seeds_to_triples(raw: np.ndarray) -> np.ndarray:
+    """Seed_t {u32 tPos; u32 qPos:20, len:12} -> (n,3) u32 [tPos,qPos,len]"""
+    raw = raw.reshape(-1, 2)
+    return np.stack([raw[:, 0], raw[:, 1] & 0xFFFFF, raw[:, 1] >> 20], axis=1).astype(np.uint32)
+
+
+def _triples_to_seeds(tr: np.ndarray) -> np.ndarray:
+    tr = np.ascontiguousarray(tr, dtype=np.uint32).reshape(-1, 3)
+    out = np.empty((len(tr), 2), dtype=np.uint32)
+    out[:, 0] = tr[:, 0]
+    out[:, 1] = (tr[:, 1] & 0xFFFFF) | ((tr[:, 2] & 0xFFF) << 20)
+    return out
+
+
+def _cstr_array(items):
+    arr = (C.c_char_p * len(items))()
+    arr[:] = [x if isinstance(x, bytes) else x.encode() for x in items]
+    return arr
+
+
+def _concat(seqs):
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if len(seqs):
+        off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    return b"".join(seqs), off
+
+
+class LordFast:
+    """An FM-index resident in one GPU's HBM + the batch entry points."""
+
+    FULL_SA = 1
+
+    def __init__(self, prefix: str, device: int = 0, full_sa: bool = True):
+        self.L = lib()
+        h = C.c_void_p()
+        _check(self.L.lf_index_load(prefix.encode(), device, self.FULL_SA if full_sa else 0, C.byref(h)), "lf_index_load")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.L.lf_index_free(self.h)
+            self.h = None
+
+    def genome_len(self) -> int:
+        return self.L.lf_index_genome_len(self.h)
+
+    # ---- stage 1
+    def seed_batch(self, seqs, params: Params | None = None):
+        """-> (list of F triples, list of R triples, info dict)"""
+        p = params or default_params()
+        cat, off = _concat(seqs)
+        out = C.POINTER(Seeds)()
+        _check(self.L.lf_seed_batch(self.h, C.byref(p), len(seqs), cat, off.ctypes.data, C.byref(out)), "lf_seed_batch")
+        s = out.contents
+        n = s.n_reads
+        offF = np.ctypeslib.as_array(s.offF, shape=(n + 1,)).copy()
+        offR = np.ctypeslib.as_array(s.offR, shape=(n + 1,)).copy()
+        F = np.frombuffer(C.string_at(s.F, int(offF[-1]) * 8), dtype=np.uint32) if offF[-1] else np.zeros(0, np.uint32)
+        R = np.frombuffer(C.string_at(s.R, int(offR[-1]) * 8), dtype=np.uint32) if offR[-1] else np.zeros(0, np.uint32)
+        Ft, Rt = _seeds_to_triples(F), _seeds_to_triples(R)
+        info = dict(n_cache=s.n_cache, n_occblk=s.n_occblk, n_sa=s.n_sa, n_readbytes=s.n_readbytes,
+                    ms_search=s.ms_search, ms_accept=s.ms_accept, ms_locate=s.ms_locate)
+        self.L.lf_seeds_free(out)
+        Fl = [Ft[int(offF[i]):int(offF[i + 1])] for i in range(n)]
+        Rl = [Rt[int(offR[i]):int(offR[i + 1])] for i in range(n)]
+        return Fl, Rl, info
+
+    # ---- whole path
+    def map_batch(self, names, seqs, quals=None, params: Params | None = None):
+        p = params or default_params()
+        sam = C.c_void_p()
+        ln = C.c_size_t()
+        st = Stats()
+        q = _cstr_array(quals) if quals is not None else None
+        _check(self.L.lf_map_batch(self.h, C.byref(p), len(names), _cstr_array(names), _cstr_array(seqs), q,
+                                   C.byref(sam), C.byref(ln), C.byref(st)), "lf_map_batch")
+        out = C.string_at(sam, ln.value)
+        self.L.lf_free(sam)
+        return out, st.as_dict()
+
+    def sam_header(self, cmdline: str, params: Params | None = None) -> bytes:
+        p = params or default_params()
+        ptr = self.L.lf_sam_header(self.h, C.byref(p), cmdline.encode())
+        out = C.string_at(ptr)
+        self.L.lf_free(ptr)
+        return out
+
+
+# ---- index-free batch primitives -------------------------------------------------------------
+
+def edlib_batch(qs, ts, modes, device: int = 0):
+    """-> list of (edit_distance, end_location, ops ndarray), kernel ms"""
+    L = lib()
+    n = len(qs)
+    qcat, qoff = _concat(qs)
+    tcat, toff = _concat(ts)
+    mode = np.ascontiguousarray(modes, dtype=np.uint8)
+    ed = np.zeros(n, dtype=np.int32)
+    end = np.zeros(n, dtype=np.int32)
+    ops = np.zeros(int(qoff[-1] + toff[-1]) + 1, dtype=np.uint8)
+    ops_len = np.zeros(n, dtype=np.uint32)
+    ms = C.c_float()
+    _check(L.lf_edlib_batch(n, qcat, qoff.ctypes.data, tcat, toff.ctypes.data, mode.ctypes.data, ed.ctypes.data,
+                            end.ctypes.data, ops.ctypes.data, ops_len.ctypes.data, device, C.byref(ms)), "lf_edlib_batch")
+    res = []
+    for i in range(n):
+        o = int(qoff[i] + toff[i])
+        res.append((int(ed[i]), int(end[i]), ops[o:o + int(ops_len[i])].copy()))
+    return res, ms.value
+
+
+def chain_n2_batch(windows, params: Params | None = None, device: int = 0):
+    """windows: list of (n,3) triples. -> list of (reordered triples, chain triples, score)"""
+    L = lib()
+    p = params or default_params()
+    off = np.zeros(len(windows) + 1, dtype=np.uint64)
+    if len(windows):
+        off[1:] = np.cumsum([len(w) for w in windows], dtype=np.uint64)
+    allw = np.concatenate([np.asarray(w, dtype=np.uint32).reshape(-1, 3) for w in windows]) if len(windows) else np.zeros((0, 3), np.uint32)
+    seeds = _triples_to_seeds(allw)
+    nt = max(1, len(allw))
+    chain_idx = np.zeros(nt, dtype=np.uint32)
+    chain_len = np.zeros(max(1, len(windows)), dtype=np.uint32)
+    score = np.zeros(max(1, len(windows)), dtype=np.float32)
+    _check(L.lf_chain_n2_batch(C.byref(p), len(windows), seeds.ctypes.data, off.ctypes.data, chain_idx.ctypes.data,
+                               chain_len.ctypes.data, score.ctypes.data, device), "lf_chain_n2_batch")
+    tr = _seeds_to_triples(seeds.reshape(-1))
+    out = []
+    for w in range(len(windows)):
+        a, b = int(off[w]), int(off[w + 1])
+        srt = tr[a:b]
+        idx = chain_idx[a:a + int(chain_len[w])]
+        out.append((srt, srt[idx], float(score[w])))
+    return out
+
+
+def ksw_extend2_batch(qs, ts, prms, device: int = 0):
+    L = lib()
+    n = len(qs)
+    qcat, qoff = _concat([np.ascontiguousarray(q, dtype=np.uint8).tobytes() for q in qs])
+    tcat, toff = _concat([np.ascontiguousarray(t, dtype=np.uint8).tobytes() for t in ts])
+    prm = np.ascontiguousarray(prms, dtype=np.int32).reshape(n, 7)
+    sc = np.zeros(n, np.int32); qle = np.zeros(n, np.int32); tle = np.zeros(n, np.int32)
+    _check(L.lf_ksw_extend2_batch(n, qcat, qoff.ctypes.data, tcat, toff.ctypes.data, prm.ctypes.data, sc.ctypes.data,
+                                  qle.ctypes.data, tle.ctypes.data, device), "lf_ksw_extend2_batch")
+    return [(int(sc[i]), int(qle[i]), int(tle[i])) for i in range(n)]

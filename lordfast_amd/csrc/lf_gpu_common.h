@@ -1,0 +1,101 @@
+/* lf_gpu_common.h -- shared by the HIP translation units of liblfgpu.so (gfx950 only). */
+#ifndef LF_GPU_COMMON_H
+#define LF_GPU_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "lf_internal.h"
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    lf_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); return LF_ERR_HIP; } } while (0)
+
+/* device view of the FM-index (all pointers in HBM) */
+struct lf_dev_index {
+    uint64_t primary, L2[5], seq_len;
+    int64_t  l_pac;
+    uint64_t n_sa;
+    const uint32_t *bwt;        /* reference layout: per 128 symbols 4 x u64 Occ + 8 x u32 (lib/bwa/bwt.h:72-73) */
+    const uint64_t *sa_sampled; /* every 32nd row (lib/bwa/bwt.c:62-84), sa[0] = -1 */
+    const uint64_t *sa_full;    /* seq_len + 1 rows, or NULL */
+    const uint64_t *cache;      /* 4^12 x (beg,end): SA interval of every 12-mer (src/BWT.cpp:60-115) */
+    const uint8_t  *pac;
+};
+
+struct lf_dev_state {           /* host-side owner of the device allocations */
+    lf_dev_index view;
+    void *bwt, *sa_sampled, *sa_full, *cache, *pac;
+    hipStream_t stream;
+};
+
+__device__ __forceinline__ int lf_nt4(unsigned char ch)
+{   /* nst_nt4_table (lib/bwa/bntseq.c:47-64): A/a C/c G/g T/t -> 0..3, everything else > 3 */
+    switch (ch) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+    }
+}
+
+/* symbols equal to c among the first r symbols (r <= 0: none, r >= 32: all) of a 32-symbol chunk held
+ * MSB-first in y */
+__device__ __forceinline__ uint32_t lf_count_sym(uint32_t hi, uint32_t lo, int c, int r)
+{
+    const uint64_t y = ((uint64_t)hi << 32) | lo;
+    const uint64_t rep = (c & 1 ? 0x5555555555555555ull : 0ull) | (c & 2 ? 0xAAAAAAAAAAAAAAAAull : 0ull);
+    const uint64_t eq = ~(y ^ rep);
+    uint64_t m = eq & (eq >> 1) & 0x5555555555555555ull;
+    const uint64_t keep = r >= 32 ? ~0ull : (r <= 0 ? 0ull : (~0ull << (64 - 2 * r)));
+    return (uint32_t)__popcll(m & keep);
+}
+
+/* Occ(k, c): occurrences of c in B[0..k] (bwt_occ, lib/bwa/bwt.c:107-127). One 64-byte block. */
+__device__ __forceinline__ uint64_t lf_occ(const lf_dev_index &ix, uint64_t k, int c)
+{
+    if (k == ix.seq_len) return ix.L2[c + 1] - ix.L2[c];
+    if (k == ~0ull) return 0;
+    k -= (k >= ix.primary);
+    const uint32_t *blk = ix.bwt + ((k >> 7) << 4);
+    uint64_t n = reinterpret_cast<const uint64_t *>(blk)[c];
+    const uint4 w0 = *reinterpret_cast<const uint4 *>(blk + 8);
+    const uint4 w1 = *reinterpret_cast<const uint4 *>(blk + 12);
+    const int rem = (int)(k & 127) + 1;
+    n += lf_count_sym(w0.x, w0.y, c, rem) + lf_count_sym(w0.z, w0.w, c, rem - 32)
+       + lf_count_sym(w1.x, w1.y, c, rem - 64) + lf_count_sym(w1.z, w1.w, c, rem - 96);
+    return n;
+}
+
+/* one backward-search step: [k,l] -> interval of c.P (src/BWT.cpp:290-293). touches counted like
+ * bwt_2occ (lib/bwa/bwt.c:132-139): 1 block if k-1 and l share one, else 2 */
+__device__ __forceinline__ void lf_backward_step(const lf_dev_index &ix, uint64_t &k, uint64_t &l, int c, uint32_t &blk_touches)
+{
+    const uint64_t km = k - 1;
+    const uint64_t _k = (km >= ix.primary) ? km - 1 : km, _l = (l >= ix.primary) ? l - 1 : l;
+    blk_touches += (km == ~0ull || l == ~0ull || (_k >> 7) != (_l >> 7)) ? 2u : 1u;
+    const uint64_t ok = lf_occ(ix, km, c), ol = lf_occ(ix, l, c);
+    k = ix.L2[c] + ok + 1;
+    l = ix.L2[c] + ol;
+}
+
+/* bwt_B0 (lib/bwa/bwt.h:78) + bwt_invPsi (lib/bwa/bwt.c:53-59) */
+__device__ __forceinline__ uint64_t lf_inv_psi(const lf_dev_index &ix, uint64_t k)
+{
+    if (k == ix.primary) return 0;
+    const uint64_t x = k - (k > ix.primary);
+    const uint32_t w = ix.bwt[((x >> 7) << 4) + 8 + ((x & 127) >> 4)];
+    const int c = (int)((w >> ((~x & 15) << 1)) & 3);
+    return ix.L2[c] + lf_occ(ix, k, c);
+}
+
+/* bwt_sa (lib/bwa/bwt.c:86-96) by LF walk to the next sampled row */
+__device__ __forceinline__ uint64_t lf_sa_walk(const lf_dev_index &ix, uint64_t k, uint32_t &steps)
+{
+    uint64_t off = 0;
+    while (k & 31) { ++off; k = lf_inv_psi(ix, k); }
+    steps += (uint32_t)off;
+    return off + ix.sa_sampled[k >> 5];
+}
+
+#endif

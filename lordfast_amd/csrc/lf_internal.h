@@ -1,0 +1,72 @@
+/* lf_internal.h -- private to liblfgpu.so (host C glue <-> HIP translation units). */
+#ifndef LF_INTERNAL_H
+#define LF_INTERNAL_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "lordfast_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { int64_t offset; int32_t len; char *name; } lf_contig_t;
+
+/* host copy of what the glue needs + opaque device handle */
+struct lf_index {
+    /* .bwt header */
+    uint64_t primary, L2[5], seq_len, bwt_size;
+    uint64_t sa_intv, n_sa;
+    int64_t  l_pac;
+    int32_t  n_seqs;
+    lf_contig_t *contigs;
+    uint8_t *pac;            /* host copy (glue: MD strings, SAM) */
+    int      device;
+    unsigned flags;
+    void    *dev;            /* struct lf_dev_index* (lf_gpu.hip) */
+};
+
+void lf_set_error(const char *fmt, ...);
+
+/* ---- lf_gpu.hip ---- */
+int  lfg_device_count(void);
+int  lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const uint64_t *sa_sampled);
+void lfg_index_free(struct lf_index *ix);
+
+typedef struct {        /* raw device results of the seed stage, copied to host */
+    uint64_t n_hits;
+    uint32_t *tpos;      /* n_hits */
+    uint32_t *qpl;       /* n_hits: qPos | len << 20  (Seed_t bit layout) */
+    uint8_t  *strand;    /* n_hits: 1 = reverse */
+    uint64_t *read_off;  /* n_reads + 1: first hit of each read */
+    uint64_t counters[4];
+    float ms_search, ms_accept, ms_locate;
+} lfg_hits_t;
+
+int  lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads,
+              const uint64_t *off, lfg_hits_t *out);
+void lfg_hits_free(lfg_hits_t *h);
+
+int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, const Seed_t *sorted_seeds,
+                 const uint64_t *off, uint32_t *chain_idx, uint32_t *chain_len, float *score, float *ms);
+
+/* edlib problems: sequences given as byte strings (host memory) */
+int lfg_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
+              const uint8_t *mode, const uint8_t *task, int32_t *ed, int32_t *endloc,
+              uint8_t *ops, uint32_t *ops_len, float *ms);
+/* last DP column: out[cs_off[i] + r] = dist(q[0..r), t) for r = 0..n_i ; rev[i] walks both strings backwards */
+int lfg_colscores(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
+                  const uint8_t *rev, int32_t *out, const uint64_t *cs_off, float *ms);
+int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff, const uint8_t *t, const uint64_t *toff,
+            const int32_t *prm, int32_t *score, int32_t *qle, int32_t *tle, float *ms);
+
+#define LF_TASK_PATH 0
+#define LF_TASK_DIST 1
+
+/* edlib's own leaf/Hirschberg switch (lib/edlib/edlib.cpp:1117-1119) */
+static inline int lf_is_leaf(int64_t n, int64_t m) { return 20LL * ((n + 63) / 64) * m + 8LL * m < 1024 * 1024; }
+
+#ifdef __cplusplus
+}
+#endif
+#endif

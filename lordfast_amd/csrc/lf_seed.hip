@@ -1,0 +1,350 @@
+/*
+ * lf_seed.hip -- FM-index residency in HBM and the seeding kernels (gfx950).
+ *
+ * Reference path replaced: getLocs_extend_whole_step (src/BWT.cpp:312-394) over
+ * bwt_count_exact_cached (src/BWT.cpp:265-298), bwt_2occ/bwt_occ (lib/bwa/bwt.c:107-163) and bwt_sa
+ * (lib/bwa/bwt.c:86-96).
+ *
+ * Formulation (results identical, see DESIGN.md "seed search"):
+ *   The reference restarts a whole backward search for every candidate length m+1.  Because the text is
+ *   forward + reverse complement, count(P) == count(revcomp(P)), and revcomp(q[pos..pos+m)) grows to the
+ *   LEFT as m grows -- so ONE backward search over the complemented read finds the maximal m, and one
+ *   more backward search over q[pos..pos+m) yields the exact [sp,ep] rows whose order the seed lists keep.
+ *   HBM-bound on random 64-byte Occ blocks: one lane per sample position, thousands of independent
+ *   dependent-load chains per CU in flight.
+ */
+#include <hipcub/hipcub.hpp>
+#include "lf_gpu_common.h"
+
+/* ---------------------------------------------------------------- index residency */
+
+/* src/BWT.cpp:60-115 -- one level of the 12-mer table: child (4i+j) = j prepended to k-mer i */
+__global__ void lf_cache_level_kernel(lf_dev_index ix, const uint64_t *__restrict__ parent, uint64_t *__restrict__ child, uint32_t n_parent)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parent) return;
+    const uint64_t bk = parent[2 * (size_t)i], bl = parent[2 * (size_t)i + 1];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const size_t ni = (size_t)i * 4 + j;
+        uint64_t k = bk, l = bl;
+        if (bk <= bl) { uint32_t dummy = 0; lf_backward_step(ix, k, l, j, dummy); }
+        child[2 * ni] = k; child[2 * ni + 1] = l;
+    }
+}
+
+/* full suffix array from the sampled one: SA[k] = steps + SA_sampled[row reached] (lib/bwa/bwt.c:86-96) */
+__global__ void lf_full_sa_kernel(lf_dev_index ix, uint64_t *__restrict__ sa_full, uint64_t n_rows)
+{
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_rows; k += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t steps = 0;
+        sa_full[k] = lf_sa_walk(ix, k, steps);
+    }
+}
+
+extern "C" int lfg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const uint64_t *sa_sampled)
+{
+    HIPCHK(hipSetDevice(ix->device));
+    lf_dev_state *st = new lf_dev_state();
+    memset(st, 0, sizeof(*st));
+    ix->dev = st;
+    HIPCHK(hipStreamCreate(&st->stream));
+    lf_dev_index &v = st->view;
+    v.primary = ix->primary; v.seq_len = ix->seq_len; v.l_pac = ix->l_pac; v.n_sa = ix->n_sa;
+    for (int i = 0; i < 5; i++) v.L2[i] = ix->L2[i];
+
+    const size_t bwt_bytes = ix->bwt_size * 4;
+    HIPCHK(hipMalloc(&st->bwt, bwt_bytes + 256));
+    HIPCHK(hipMemset(st->bwt, 0, bwt_bytes + 256));
+    HIPCHK(hipMemcpy(st->bwt, bwt, bwt_bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&st->sa_sampled, ix->n_sa * 8));
+    HIPCHK(hipMemcpy(st->sa_sampled, sa_sampled, ix->n_sa * 8, hipMemcpyHostToDevice));
+    const size_t pac_bytes = (size_t)(ix->l_pac / 4 + 1);
+    HIPCHK(hipMalloc(&st->pac, pac_bytes + 16));
+    HIPCHK(hipMemcpy(st->pac, ix->pac, pac_bytes, hipMemcpyHostToDevice));
+    v.bwt = (const uint32_t *)st->bwt; v.sa_sampled = (const uint64_t *)st->sa_sampled; v.pac = (const uint8_t *)st->pac;
+
+    /* 12-mer table, level by level, ping-pong between two buffers */
+    const int K = 12;
+    uint64_t *bufA, *bufB;
+    HIPCHK(hipMalloc(&bufA, ((size_t)1 << (2 * K)) * 16));
+    HIPCHK(hipMalloc(&bufB, ((size_t)1 << (2 * (K - 1))) * 16));
+    uint64_t *cur = (K % 2 == 0) ? bufA : bufB, *nxt = (K % 2 == 0) ? bufB : bufA;   /* level K lands in bufA */
+    const uint64_t root[2] = { 0, ix->seq_len };
+    HIPCHK(hipMemcpy(cur, root, 16, hipMemcpyHostToDevice));
+    for (int k = 0; k < K; k++) {
+        const uint32_t np = 1u << (2 * k);
+        hipLaunchKernelGGL(lf_cache_level_kernel, dim3((np + 255) / 256), dim3(256), 0, st->stream, v, cur, nxt, np);
+        uint64_t *t = cur; cur = nxt; nxt = t;
+    }
+    HIPCHK(hipStreamSynchronize(st->stream));
+    if (cur != bufA) { lf_set_error("cache table ended in the wrong buffer"); return LF_ERR_HIP; }
+    HIPCHK(hipFree(bufB));
+    st->cache = bufA;
+    v.cache = bufA;
+
+    if (ix->flags & LF_IDX_FULL_SA) {
+        const uint64_t rows = ix->seq_len + 1;
+        HIPCHK(hipMalloc(&st->sa_full, rows * 8));
+        hipLaunchKernelGGL(lf_full_sa_kernel, dim3(256 * 32), dim3(256), 0, st->stream, v, (uint64_t *)st->sa_full, rows);
+        HIPCHK(hipStreamSynchronize(st->stream));
+        v.sa_full = (const uint64_t *)st->sa_full;
+    }
+    HIPCHK(hipGetLastError());
+    return LF_OK;
+}
+
+extern "C" void lfg_index_free(struct lf_index *ix)
+{
+    lf_dev_state *st = (lf_dev_state *)ix->dev;
+    if (!st) return;
+    (void)hipSetDevice(ix->device);
+    if (st->bwt) (void)hipFree(st->bwt);
+    if (st->sa_sampled) (void)hipFree(st->sa_sampled);
+    if (st->sa_full) (void)hipFree(st->sa_full);
+    if (st->cache) (void)hipFree(st->cache);
+    if (st->pac) (void)hipFree(st->pac);
+    if (st->stream) (void)hipStreamDestroy(st->stream);
+    delete st;
+    ix->dev = NULL;
+}
+
+/* ---------------------------------------------------------------- seeding kernels */
+
+/* sample positions: seed_pos accumulates `step` in FP64 exactly like src/BWT.cpp:320-321,388-389
+ * (sequential adds, truncation), one lane per read. Layout pos[i * n_reads + r] (coalesced). */
+__global__ void lf_seed_pos_kernel(int n_reads, const uint64_t *__restrict__ off, uint32_t hash_count, uint32_t *__restrict__ pos)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t qLen = (uint32_t)(off[r + 1] - off[r]);
+    const double step = (double)qLen / hash_count;
+    double sp = 0;
+    uint32_t p = 0;
+    for (uint32_t i = 0; i < hash_count; i++) {
+        pos[(size_t)i * n_reads + r] = p;
+        sp += step;
+        p = (uint32_t)sp;
+    }
+}
+
+struct lf_sample_t { uint64_t sp; uint32_t occ; uint32_t m; };   /* occ saturates at 2^32-1; m = 0: no seed */
+
+/* one lane per (read, sample): maximal exact match starting at pos, >= k long */
+__global__ void __launch_bounds__(256)
+lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ reads, const uint64_t *__restrict__ off,
+                      uint32_t hash_count, int kmin, const uint32_t *__restrict__ pos, lf_sample_t *__restrict__ out,
+                      unsigned long long *__restrict__ counters)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n_reads * hash_count;
+    uint32_t n_cache = 0, n_blk = 0;
+    if (gid < total) {
+        const int r = (int)(gid / hash_count);
+        const uint32_t i = (uint32_t)(gid % hash_count);
+        const uint32_t qLen = (uint32_t)(off[r + 1] - off[r]);
+        const unsigned char *q = reinterpret_cast<const unsigned char *>(reads) + off[r];
+        const uint32_t p = pos[(size_t)i * n_reads + r];
+        lf_sample_t res; res.sp = 0; res.occ = 0; res.m = 0;
+
+        if ((uint64_t)p + (uint64_t)kmin <= qLen) {
+            /* phase 1: complemented strand, growing leftwards: 12-mer table then one step per base.
+             * table index: base-4 number with the LAST character of the pattern most significant
+             * (src/BWT.cpp:270-277); pattern = revcomp(q[p..p+m)) whose last 12 are comp(q[p+11..p]) */
+            uint32_t idx = 0; bool ok = true;
+#pragma unroll
+            for (int t = 0; t < 12; t++) { const int c = lf_nt4(q[p + t]); ok &= (c < 4); idx = idx * 4 + (uint32_t)(3 - c); }
+            uint32_t m = 0;
+            if (ok) {
+                n_cache++;
+                uint64_t k = ix.cache[2 * (size_t)idx], l = ix.cache[2 * (size_t)idx + 1];
+                if (k <= l) {
+                    m = 12;
+                    while (p + m < qLen) {
+                        const int c = lf_nt4(q[p + m]);
+                        if (c > 3) break;
+                        uint64_t k2 = k, l2 = l;
+                        lf_backward_step(ix, k2, l2, 3 - c, n_blk);
+                        if (k2 > l2) break;
+                        k = k2; l = l2; m++;
+                    }
+                    if ((int)m < kmin) m = 0;
+                }
+            }
+            if (m) {
+                /* phase 2: exact rows of q[p..p+m): table on its last 12 bases, then leftwards to q[p] */
+                uint32_t idf = 0;
+#pragma unroll
+                for (int t = 0; t < 12; t++) idf = idf * 4 + (uint32_t)lf_nt4(q[p + m - 1 - t]);
+                n_cache++;
+                uint64_t k = ix.cache[2 * (size_t)idf], l = ix.cache[2 * (size_t)idf + 1];
+                for (int t = (int)m - 13; t >= 0; t--) lf_backward_step(ix, k, l, lf_nt4(q[p + t]), n_blk);
+                const uint64_t occ = l - k + 1;
+                res.sp = k; res.m = m;
+                res.occ = occ > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)occ;
+            }
+        }
+        out[gid] = res;
+    }
+    /* SURVEY 8(d) counters: one atomic pair per wave */
+    for (int o = 32; o > 0; o >>= 1) { n_cache += __shfl_down(n_cache, o); n_blk += __shfl_down(n_blk, o); }
+    if ((threadIdx.x & 63) == 0 && (n_cache | n_blk)) { atomicAdd(&counters[0], (unsigned long long)n_cache); atomicAdd(&counters[1], (unsigned long long)n_blk); }
+}
+
+/* acceptance is sequential per read: 0 < occ < MAX_REF_HITS and not contained in the previous accepted
+ * seed (src/BWT.cpp:345,386).  One lane per read; writes the number of hits to locate per sample. */
+__global__ void lf_seed_accept_kernel(int n_reads, uint32_t hash_count, uint32_t max_ref_hits, const uint32_t *__restrict__ pos,
+                                      const lf_sample_t *__restrict__ smp, uint32_t *__restrict__ cnt)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    uint32_t last_pos = 0;
+    for (uint32_t i = 0; i < hash_count; i++) {
+        const lf_sample_t s = smp[(size_t)r * hash_count + i];
+        const uint32_t p = pos[(size_t)i * n_reads + r];
+        uint32_t c = 0;
+        if (s.m && s.occ > 0 && s.occ < max_ref_hits && (p + s.m) > last_pos) { c = s.occ; last_pos = p + s.m; }
+        cnt[(size_t)r * hash_count + i] = c;
+    }
+}
+
+/* locate: rows sp..sp+cnt-1 of every accepted sample -> (tPos, qPos|len<<20, strand) in sample order then
+ * SA-row order (src/BWT.cpp:348-384) */
+__global__ void __launch_bounds__(256)
+lf_seed_locate_kernel(lf_dev_index ix, int n_reads, const uint64_t *__restrict__ off, uint32_t hash_count,
+                      const uint32_t *__restrict__ pos, const lf_sample_t *__restrict__ smp, const uint32_t *__restrict__ cnt,
+                      const uint64_t *__restrict__ hit_off, uint32_t *__restrict__ tpos, uint32_t *__restrict__ qpl,
+                      uint8_t *__restrict__ strand, unsigned long long *__restrict__ counters)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)n_reads * hash_count;
+    uint32_t n_blk = 0, n_sa = 0;
+    if (gid < total) {
+        const uint32_t c = cnt[gid];
+        if (c) {
+            const int r = (int)(gid / hash_count);
+            const uint32_t i = (uint32_t)(gid % hash_count);
+            const uint32_t qLen = (uint32_t)(off[r + 1] - off[r]);
+            const uint32_t p = pos[(size_t)i * n_reads + r];
+            const lf_sample_t s = smp[gid];
+            const uint64_t o = hit_off[gid];
+            const uint64_t l_pac = (uint64_t)ix.l_pac;
+            for (uint32_t j = 0; j < c; j++) {
+                const uint64_t row = s.sp + j;
+                uint64_t sapos = ix.sa_full ? ix.sa_full[row] : lf_sa_walk(ix, row, n_blk);
+                n_sa++;
+                uint32_t t, qp; uint8_t rv;
+                if (sapos >= l_pac) { t = (uint32_t)((l_pac << 1) - sapos - s.m); qp = qLen - p - s.m; rv = 1; }
+                else { t = (uint32_t)sapos; qp = p; rv = 0; }
+                tpos[o + j] = t;
+                qpl[o + j] = (qp & 0xFFFFFu) | ((s.m & 0xFFFu) << 20);
+                strand[o + j] = rv;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { n_blk += __shfl_down(n_blk, o); n_sa += __shfl_down(n_sa, o); }
+    if ((threadIdx.x & 63) == 0 && (n_blk | n_sa)) { atomicAdd(&counters[1], (unsigned long long)n_blk); atomicAdd(&counters[2], (unsigned long long)n_sa); }
+}
+
+struct lf_widen_op { __host__ __device__ uint64_t operator()(uint32_t x) const { return (uint64_t)x; } };
+
+__global__ void lf_read_first_hit_kernel(int n_reads, uint32_t hash_count, const uint64_t *__restrict__ hit_off, uint64_t total_hits, uint64_t *__restrict__ read_off)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_reads) return;
+    read_off[r] = (r == n_reads) ? total_hits : hit_off[(size_t)r * hash_count];
+}
+
+extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads,
+                        const uint64_t *off, lfg_hits_t *out)
+{
+    memset(out, 0, sizeof(*out));
+    lf_dev_state *st = (lf_dev_state *)ix->dev;
+    if (!st) { lf_set_error("index is not on a device"); return LF_ERR_NO_DEVICE; }
+    HIPCHK(hipSetDevice(ix->device));
+    hipStream_t s = st->stream;
+    const uint32_t hc = (uint32_t)p->sampling_count;
+    const size_t total = (size_t)n_reads * hc;
+    const uint64_t n_bases = off[n_reads];
+
+    char *d_reads = nullptr; uint64_t *d_off = nullptr, *d_hit_off = nullptr, *d_read_off = nullptr;
+    uint32_t *d_pos = nullptr, *d_cnt = nullptr, *d_tpos = nullptr, *d_qpl = nullptr; uint8_t *d_strand = nullptr;
+    lf_sample_t *d_smp = nullptr; unsigned long long *d_counters = nullptr; void *d_tmp = nullptr;
+    hipEvent_t ev[6];
+    for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&ev[i]));
+
+    HIPCHK(hipMalloc(&d_reads, n_bases + 64));
+    HIPCHK(hipMalloc(&d_off, (size_t)(n_reads + 1) * 8));
+    HIPCHK(hipMalloc(&d_pos, total * 4 + 4));
+    HIPCHK(hipMalloc(&d_smp, total * sizeof(lf_sample_t) + 16));
+    HIPCHK(hipMalloc(&d_cnt, (total + 1) * 4));
+    HIPCHK(hipMalloc(&d_hit_off, (total + 1) * 8));
+    HIPCHK(hipMalloc(&d_read_off, (size_t)(n_reads + 1) * 8));
+    HIPCHK(hipMalloc(&d_counters, 4 * 8));
+    HIPCHK(hipMemsetAsync(d_counters, 0, 32, s));
+    HIPCHK(hipMemcpyAsync(d_reads, reads, n_bases, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+
+    hipLaunchKernelGGL(lf_seed_pos_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, d_off, hc, d_pos);
+    HIPCHK(hipEventRecord(ev[0], s));
+    hipLaunchKernelGGL(lf_seed_search_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, st->view, n_reads, d_reads,
+                       d_off, hc, p->min_anchor_len, d_pos, d_smp, d_counters);
+    HIPCHK(hipEventRecord(ev[1], s));
+    hipLaunchKernelGGL(lf_seed_accept_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, hc, (uint32_t)p->max_ref_hits, d_pos, d_smp, d_cnt);
+    HIPCHK(hipMemsetAsync(d_cnt + total, 0, 4, s));
+    size_t tmp_bytes = 0;
+    /* u32 counts summed into u64 offsets */
+    hipcub::TransformInputIterator<uint64_t, lf_widen_op, uint32_t *> cnt64(d_cnt, lf_widen_op());
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt64, d_hit_off, (int)(total + 1), s));
+    HIPCHK(hipMalloc(&d_tmp, tmp_bytes + 16));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, cnt64, d_hit_off, (int)(total + 1), s));
+    HIPCHK(hipEventRecord(ev[2], s));
+    uint64_t n_hits = 0;
+    HIPCHK(hipMemcpyAsync(&n_hits, d_hit_off + total, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+
+    HIPCHK(hipMalloc(&d_tpos, (n_hits + 1) * 4));
+    HIPCHK(hipMalloc(&d_qpl, (n_hits + 1) * 4));
+    HIPCHK(hipMalloc(&d_strand, n_hits + 16));
+    HIPCHK(hipEventRecord(ev[3], s));
+    hipLaunchKernelGGL(lf_seed_locate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, st->view, n_reads, d_off, hc,
+                       d_pos, d_smp, d_cnt, d_hit_off, d_tpos, d_qpl, d_strand, d_counters);
+    HIPCHK(hipEventRecord(ev[4], s));
+    hipLaunchKernelGGL(lf_read_first_hit_kernel, dim3((n_reads + 1 + 255) / 256), dim3(256), 0, s, n_reads, hc, d_hit_off, n_hits, d_read_off);
+
+    out->n_hits = n_hits;
+    out->tpos = (uint32_t *)malloc((n_hits + 1) * 4);
+    out->qpl = (uint32_t *)malloc((n_hits + 1) * 4);
+    out->strand = (uint8_t *)malloc(n_hits + 1);
+    out->read_off = (uint64_t *)malloc((size_t)(n_reads + 1) * 8);
+    HIPCHK(hipMemcpyAsync(out->tpos, d_tpos, n_hits * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out->qpl, d_qpl, n_hits * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out->strand, d_strand, n_hits, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out->read_off, d_read_off, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out->counters, d_counters, 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    out->counters[3] = n_bases;
+    HIPCHK(hipEventElapsedTime(&out->ms_search, ev[0], ev[1]));
+    HIPCHK(hipEventElapsedTime(&out->ms_accept, ev[1], ev[2]));
+    HIPCHK(hipEventElapsedTime(&out->ms_locate, ev[3], ev[4]));
+
+    for (int i = 0; i < 6; i++) (void)hipEventDestroy(ev[i]);
+    (void)hipFree(d_reads); (void)hipFree(d_off); (void)hipFree(d_pos); (void)hipFree(d_smp); (void)hipFree(d_cnt);
+    (void)hipFree(d_hit_off); (void)hipFree(d_read_off); (void)hipFree(d_counters); (void)hipFree(d_tmp);
+    (void)hipFree(d_tpos); (void)hipFree(d_qpl); (void)hipFree(d_strand);
+    return LF_OK;
+}
+
+extern "C" void lfg_hits_free(lfg_hits_t *h)
+{
+    free(h->tpos); free(h->qpl); free(h->strand); free(h->read_off);
+    memset(h, 0, sizeof(*h));
+}
