@@ -1,0 +1,474 @@
+/*
+ * lf_align.hip -- extension kernels (gfx950): edlib-equivalent edit-distance alignment and ksw_extend2.
+ *
+ * Reference replaced: edlibAlign (lib/edlib/edlib.cpp:101-221) with config {k=-1, NW|SHW, PATH}, and
+ * ksw_extend2 (lib/bwa/ksw.c:380-478).  Integer only; results bit-identical.
+ *
+ * edlib kernel: Myers/Hyyro bit-vector DP, 64 query rows per 64-bit word, ONE LANE PER PROBLEM (the DP of
+ * one problem is a dependent chain; parallelism comes from the ~10^2 independent gap problems per read).
+ * Problems are binned by ceil(n/64) into register-resident classes NB = 1,2,4,8 (template) and sorted by
+ * target length so that the 64 lanes of a wave run near-equal trip counts.  Per column and block the lane
+ * stores two words -- Pv (vertical +1) and Ph (horizontal +1) -- in a wave-transposed history in HBM
+ * (entry e of lane l at base + (e*64 + l)*16: every wave store is one contiguous 1 KiB line).  Traceback
+ * needs only those two bits per cell: Up if Pv, else Left if Ph, else Diagonal (match iff bytes equal),
+ * which is edlib's move priority (lib/edlib/edlib.cpp:950,984,1015).  No banding: the Ukkonen band of
+ * the reference only removes cells that cannot be on an optimal path.
+ */
+#include "lf_gpu_common.h"
+#include <algorithm>
+#include <string.h>
+#include <vector>
+#include <numeric>
+
+struct lf_aln_prob {
+    uint64_t qoff, toff;     /* into the uploaded byte strings */
+    uint64_t ops_off;        /* output ops region (capacity n + m) */
+    uint64_t hist_base;      /* 16-byte entries; wave-transposed (template classes) or private (generic) */
+    uint64_t aux_off;        /* generic kernel: private state words; colscores: output offset */
+    uint32_t n, m;
+    uint32_t id;             /* original problem index */
+    uint8_t  mode, task, rev, pad;
+};
+
+struct lf_hist_t { uint64_t pv, ph; };
+
+__device__ __forceinline__ int lf_hin_neg(int h) { return h < 0; }
+
+/* one Myers block step. Pv/Mv in-out; returns hout; ph_out = horizontal +1 bits (unshifted) */
+__device__ __forceinline__ int lf_myers_step(uint64_t &Pv, uint64_t &Mv, uint64_t Eq, int hin, uint64_t &ph_out, uint64_t &mh_out)
+{
+    const uint64_t hneg = hin < 0 ? 1ull : 0ull, hpos = hin > 0 ? 1ull : 0ull;
+    const uint64_t Xv = Eq | Mv;
+    Eq |= hneg;
+    const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+    uint64_t Ph = Mv | ~(Xh | Pv);
+    uint64_t Mh = Pv & Xh;
+    ph_out = Ph; mh_out = Mh;
+    const int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+    Ph = (Ph << 1) | hpos;
+    Mh = (Mh << 1) | hneg;
+    Pv = Mh | ~(Xv | Ph);
+    Mv = Ph & Xv;
+    return hout;
+}
+
+/* bit planes of 64 query bytes: uppercase A,C,G,T -> (lo,hi) code + valid; anything else never equals a
+ * target base (edlib compares raw bytes, lib/edlib/edlib.cpp:1367-1384; the target comes from the 2-bit
+ * reference and is upper case) */
+__device__ __forceinline__ void lf_plane_add(unsigned char ch, int bit, uint64_t &lo, uint64_t &hi, uint64_t &valid)
+{
+    int c;
+    switch (ch) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break; default: c = -1; }
+    if (c >= 0) { lo |= (uint64_t)(c & 1) << bit; hi |= (uint64_t)(c >> 1) << bit; valid |= 1ull << bit; }
+}
+
+/* Eq mask of target byte tc against a block; tc outside ACGT: exact byte compare (general alphabets) */
+__device__ __forceinline__ uint64_t lf_eq_mask(unsigned char tc, uint64_t lo, uint64_t hi, uint64_t valid,
+                                               const unsigned char *q, uint32_t n, uint32_t blk, bool rev)
+{
+    int c;
+    switch (tc) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break; default: c = -1; }
+    if (c >= 0) {
+        const uint64_t slo = (c & 1) ? ~0ull : 0ull, shi = (c & 2) ? ~0ull : 0ull;
+        return ~((lo ^ slo) | (hi ^ shi)) & valid;
+    }
+    uint64_t e = 0;
+    for (uint32_t i = 0; i < 64; i++) {
+        const uint32_t r = blk * 64 + i;
+        if (r < n && q[rev ? n - 1 - r : r] == tc) e |= 1ull << i;
+    }
+    return e;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * register-resident classes: NB blocks per column
+ * ---------------------------------------------------------------------------------------------- */
+template <int NB>
+__global__ void __launch_bounds__(64)
+lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, const unsigned char *__restrict__ qs,
+                const unsigned char *__restrict__ ts, lf_hist_t *__restrict__ hist, uint8_t *__restrict__ ops,
+                int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
+{
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    const int lane = threadIdx.x;
+    if (gid >= n_probs) return;
+    const lf_aln_prob pr = probs[gid];
+    const unsigned char *q = qs + pr.qoff, *t = ts + pr.toff;
+    const uint32_t n = pr.n, m = pr.m;
+
+    uint64_t lo[NB], hi[NB], valid[NB], Pv[NB], Mv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) { lo[b] = hi[b] = valid[b] = 0; Pv[b] = ~0ull; Mv[b] = 0; }
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+        for (int i = 0; i < 64; i++) { const uint32_t r = b * 64 + i; if (r < n) lf_plane_add(q[r], i, lo[b], hi[b], valid[b]); }
+
+    const int lastb = (int)((n - 1) >> 6), lastbit = (int)((n - 1) & 63);
+    int score = (int)n;                     /* D[n][0] */
+    /* SHW (lib/edlib/edlib.cpp:583-618): min over prefixes, smallest on ties; the empty prefix only exists
+     * through the wildcard padding of the last block, i.e. when n % 64 != 0 */
+    int best = (n & 63) ? (int)n : 0x7fffffff, best_c = 0;
+    lf_hist_t *h = hist + pr.hist_base + lane;
+    const bool want_path = pr.task == LF_TASK_PATH;
+
+    for (uint32_t c = 1; c <= m; c++) {
+        const unsigned char tc = t[c - 1];
+        int hin = 1;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const uint64_t Eq = lf_eq_mask(tc, lo[b], hi[b], valid[b], q, n, b, false);
+            uint64_t ph, mh;
+            hin = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
+            if (b == lastb) score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
+            if (want_path) { lf_hist_t e; e.pv = Pv[b]; e.ph = ph; h[((size_t)(c - 1) * NB + b) * 64] = e; }
+        }
+        if (score < best) { best = score; best_c = (int)c; }
+    }
+    int ed, tl;
+    if (pr.mode == 0) { ed = score; tl = (int)m; } else { ed = best; tl = best_c; }
+    out_ed[pr.id] = ed;
+    out_end[pr.id] = tl - 1;
+    if (!want_path) { out_len[pr.id] = 0; return; }
+
+    /* traceback from (n, tl); ops written backwards from the end of the region, then moved to its start */
+    uint8_t *o = ops + pr.ops_off;
+    const uint32_t cap = n + m;
+    uint32_t w = cap;
+    uint32_t r = n, c = (uint32_t)tl;
+    if (c == 0) { while (r) { o[--w] = 1; r--; } }
+    while (r > 0 && c > 0) {
+        const lf_hist_t e = h[((size_t)(c - 1) * NB + ((r - 1) >> 6)) * 64];
+        const int bit = (int)((r - 1) & 63);
+        if ((e.pv >> bit) & 1) { o[--w] = 1; r--; }
+        else if ((e.ph >> bit) & 1) { o[--w] = 2; c--; }
+        else { o[--w] = (q[r - 1] == t[c - 1]) ? 0 : 3; r--; c--; }
+    }
+    while (c > 0) { o[--w] = 2; c--; }
+    while (r > 0) { o[--w] = 1; r--; }
+    const uint32_t len = cap - w;
+    for (uint32_t i = 0; i < len; i++) o[i] = o[w + i];
+    out_len[pr.id] = len;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * generic kernel: any n; per-lane state in HBM (aux words), private history.  Used for n > 512 and for
+ * the column-score requests of the Hirschberg splits (lib/edlib/edlib.cpp:1161-1330).
+ *   aux layout per problem: nbk x {lo,hi,valid,Pv,Mv}
+ *   task LF_TASK_COLS: out_cols[aux2 + r] = D[r][m], r = 0..n, strings walked backwards when rev
+ * ---------------------------------------------------------------------------------------------- */
+#define LF_TASK_COLS 2
+__global__ void __launch_bounds__(64)
+lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, const unsigned char *__restrict__ qs,
+                        const unsigned char *__restrict__ ts, lf_hist_t *__restrict__ hist, uint64_t *__restrict__ aux,
+                        uint8_t *__restrict__ ops, int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end,
+                        uint32_t *__restrict__ out_len, int32_t *__restrict__ out_cols, const uint64_t *__restrict__ cols_off)
+{
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= n_probs) return;
+    const lf_aln_prob pr = probs[gid];
+    const unsigned char *q = qs + pr.qoff, *t = ts + pr.toff;
+    const uint32_t n = pr.n, m = pr.m;
+    const bool rev = pr.rev != 0;
+    const uint32_t nbk = (n + 63) >> 6;
+    uint64_t *st = aux + pr.aux_off;       /* [b*5 + {0 lo,1 hi,2 valid,3 Pv,4 Mv}] */
+    for (uint32_t b = 0; b < nbk; b++) {
+        uint64_t lo = 0, hi = 0, valid = 0;
+        for (int i = 0; i < 64; i++) { const uint32_t r = b * 64 + i; if (r < n) lf_plane_add(q[rev ? n - 1 - r : r], i, lo, hi, valid); }
+        st[b * 5 + 0] = lo; st[b * 5 + 1] = hi; st[b * 5 + 2] = valid; st[b * 5 + 3] = ~0ull; st[b * 5 + 4] = 0;
+    }
+    const uint32_t lastb = (n - 1) >> 6; const int lastbit = (int)((n - 1) & 63);
+    int score = (int)n;
+    int best = (n & 63) ? (int)n : 0x7fffffff, best_c = 0;
+    lf_hist_t *h = hist + pr.hist_base;
+    const bool want_path = pr.task == LF_TASK_PATH;
+    for (uint32_t c = 1; c <= m; c++) {
+        const unsigned char tc = t[rev ? m - c : c - 1];
+        int hin = 1;
+        for (uint32_t b = 0; b < nbk; b++) {
+            uint64_t Pv = st[b * 5 + 3], Mv = st[b * 5 + 4];
+            const uint64_t Eq = lf_eq_mask(tc, st[b * 5 + 0], st[b * 5 + 1], st[b * 5 + 2], q, n, b, rev);
+            uint64_t ph, mh;
+            hin = lf_myers_step(Pv, Mv, Eq, hin, ph, mh);
+            st[b * 5 + 3] = Pv; st[b * 5 + 4] = Mv;
+            if (b == lastb) score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
+            if (want_path) { lf_hist_t e; e.pv = Pv; e.ph = ph; h[(size_t)(c - 1) * nbk + b] = e; }
+        }
+        if (score < best) { best = score; best_c = (int)c; }
+    }
+    if (pr.task == LF_TASK_COLS) {
+        int32_t *oc = out_cols + cols_off[pr.id];
+        int v = (int)m;
+        oc[0] = v;
+        for (uint32_t r = 1; r <= n; r++) {
+            const uint32_t b = (r - 1) >> 6; const int bit = (int)((r - 1) & 63);
+            v += (int)((st[b * 5 + 3] >> bit) & 1) - (int)((st[b * 5 + 4] >> bit) & 1);
+            oc[r] = v;
+        }
+        return;
+    }
+    int ed, tl;
+    if (pr.mode == 0) { ed = score; tl = (int)m; } else { ed = best; tl = best_c; }
+    out_ed[pr.id] = ed;
+    out_end[pr.id] = tl - 1;
+    if (!want_path) { out_len[pr.id] = 0; return; }
+    uint8_t *o = ops + pr.ops_off;
+    const uint32_t cap = n + m;
+    uint32_t w = cap, r = n, c = (uint32_t)tl;
+    if (c == 0) { while (r) { o[--w] = 1; r--; } }
+    while (r > 0 && c > 0) {
+        const lf_hist_t e = h[(size_t)(c - 1) * nbk + ((r - 1) >> 6)];
+        const int bit = (int)((r - 1) & 63);
+        if ((e.pv >> bit) & 1) { o[--w] = 1; r--; }
+        else if ((e.ph >> bit) & 1) { o[--w] = 2; c--; }
+        else { o[--w] = (q[r - 1] == t[c - 1]) ? 0 : 3; r--; c--; }
+    }
+    while (c > 0) { o[--w] = 2; c--; }
+    while (r > 0) { o[--w] = 1; r--; }
+    const uint32_t len = cap - w;
+    for (uint32_t i = 0; i < len; i++) o[i] = o[w + i];
+    out_len[pr.id] = len;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * host launcher
+ * ---------------------------------------------------------------------------------------------- */
+struct lf_dev_buf {
+    void *p = nullptr;
+    ~lf_dev_buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T *as() { return (T *)p; }
+};
+
+static int class_nb(uint32_t n)
+{
+    const uint32_t nb = (n + 63) / 64;
+    if (nb <= 1) return 1;
+    if (nb <= 2) return 2;
+    if (nb <= 4) return 4;
+    if (nb <= 8) return 8;
+    return 0;              /* generic */
+}
+
+/* runs DIST/PATH problems (cols == nullptr) or COLS problems (cols != nullptr) */
+static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
+                     const uint8_t *mode, const uint8_t *task, const uint8_t *rev, int32_t *ed, int32_t *endloc,
+                     uint8_t *ops, uint32_t *ops_len, int32_t *cols, const uint64_t *cols_off, float *ms)
+{
+    if (ms) *ms = 0;
+    if (n == 0) return LF_OK;
+    if (lfg_device_count() <= device) { lf_set_error("no gfx950 device %d visible (no CPU path)", device); return LF_ERR_NO_DEVICE; }
+    HIPCHK(hipSetDevice(device));
+    const uint64_t qbytes = qoff[n], tbytes = toff[n];
+
+    /* bin + sort */
+    std::vector<lf_aln_prob> P[5];     /* 0 generic, 1..4 -> NB 1,2,4,8 */
+    std::vector<int> trivial;          /* n == 0 or m == 0: no DP (lib/edlib/edlib.cpp:1096-1104) */
+    for (int i = 0; i < n; i++) {
+        lf_aln_prob pr; memset(&pr, 0, sizeof pr);
+        pr.qoff = qoff[i]; pr.toff = toff[i]; pr.n = (uint32_t)(qoff[i + 1] - qoff[i]); pr.m = (uint32_t)(toff[i + 1] - toff[i]);
+        pr.ops_off = qoff[i] + toff[i]; pr.id = (uint32_t)i;
+        pr.mode = mode ? mode[i] : 0; pr.task = cols ? LF_TASK_COLS : (task ? task[i] : LF_TASK_PATH); pr.rev = rev ? rev[i] : 0;
+        if (pr.n == 0 || (pr.m == 0 && !cols)) { trivial.push_back(i); continue; }
+        const int cls = cols ? 0 : class_nb(pr.n);
+        P[cls == 0 ? 0 : (cls == 1 ? 1 : cls == 2 ? 2 : cls == 4 ? 3 : 4)].push_back(pr);
+    }
+    static const int NBS[5] = { 0, 1, 2, 4, 8 };
+    size_t hist_entries = 0, aux_words = 0;
+    for (int k = 1; k <= 4; k++) {
+        auto &v = P[k];
+        std::sort(v.begin(), v.end(), [](const lf_aln_prob &a, const lf_aln_prob &b) { return a.m < b.m || (a.m == b.m && a.id < b.id); });
+        for (size_t w = 0; w < v.size(); w += 64) {
+            uint32_t mx = 0; bool any = false;
+            for (size_t j = w; j < std::min(v.size(), w + 64); j++) { if (v[j].task == LF_TASK_PATH) { any = true; mx = std::max(mx, v[j].m); } v[j].hist_base = hist_entries; }
+            if (any) hist_entries += (size_t)64 * mx * NBS[k];
+        }
+    }
+    for (auto &pr : P[0]) {
+        const size_t nbk = (pr.n + 63) / 64;
+        pr.aux_off = aux_words; aux_words += nbk * 5;
+        pr.hist_base = hist_entries;
+        if (pr.task == LF_TASK_PATH) hist_entries += (size_t)pr.m * nbk;
+    }
+    std::sort(P[0].begin(), P[0].end(), [](const lf_aln_prob &a, const lf_aln_prob &b) {
+        const uint64_t wa = (uint64_t)((a.n + 63) / 64) * a.m, wb = (uint64_t)((b.n + 63) / 64) * b.m; return wa > wb; });
+
+    lf_dev_buf d_q, d_t, d_hist, d_aux, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off, d_prob[5];
+    HIPCHK(d_q.alloc(qbytes + 64)); HIPCHK(d_t.alloc(tbytes + 64));
+    HIPCHK(d_hist.alloc(hist_entries * sizeof(lf_hist_t) + 64));
+    HIPCHK(d_aux.alloc(aux_words * 8 + 64));
+    HIPCHK(d_ed.alloc((size_t)n * 4)); HIPCHK(d_end.alloc((size_t)n * 4)); HIPCHK(d_len.alloc((size_t)n * 4));
+    size_t cols_total = 0;
+    if (cols) {
+        for (int i = 0; i < n; i++) cols_total = std::max<size_t>(cols_total, cols_off[i] + (qoff[i + 1] - qoff[i]) + 1);
+        HIPCHK(d_cols.alloc(cols_total * 4 + 16)); HIPCHK(d_cols_off.alloc((size_t)n * 8));
+    } else HIPCHK(d_ops.alloc(qbytes + tbytes + 64));
+    hipStream_t s; HIPCHK(hipStreamCreate(&s));
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipMemcpyAsync(d_q.p, q, qbytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_t.p, t, tbytes, hipMemcpyHostToDevice, s));
+    if (cols) HIPCHK(hipMemcpyAsync(d_cols_off.p, cols_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(d_len.p, 0, (size_t)n * 4, s));
+    for (int k = 0; k < 5; k++) if (!P[k].empty()) {
+        HIPCHK(d_prob[k].alloc(P[k].size() * sizeof(lf_aln_prob)));
+        HIPCHK(hipMemcpyAsync(d_prob[k].p, P[k].data(), P[k].size() * sizeof(lf_aln_prob), hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(hipEventRecord(e0, s));
+#define LAUNCH_CLASS(K, NBV) if (!P[K].empty()) hipLaunchKernelGGL(lf_edlib_kernel<NBV>, dim3((unsigned)((P[K].size() + 63) / 64)), dim3(64), 0, s, \
+        d_prob[K].as<lf_aln_prob>(), (int)P[K].size(), d_q.as<unsigned char>(), d_t.as<unsigned char>(), d_hist.as<lf_hist_t>(), \
+        d_ops.as<uint8_t>(), d_ed.as<int32_t>(), d_end.as<int32_t>(), d_len.as<uint32_t>())
+    LAUNCH_CLASS(1, 1); LAUNCH_CLASS(2, 2); LAUNCH_CLASS(3, 4); LAUNCH_CLASS(4, 8);
+    if (!P[0].empty())
+        hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((P[0].size() + 63) / 64)), dim3(64), 0, s,
+                           d_prob[0].as<lf_aln_prob>(), (int)P[0].size(), d_q.as<unsigned char>(), d_t.as<unsigned char>(),
+                           d_hist.as<lf_hist_t>(), d_aux.as<uint64_t>(), d_ops.as<uint8_t>(), d_ed.as<int32_t>(), d_end.as<int32_t>(),
+                           d_len.as<uint32_t>(), d_cols.as<int32_t>(), d_cols_off.as<uint64_t>());
+    HIPCHK(hipEventRecord(e1, s));
+    if (cols) HIPCHK(hipMemcpyAsync(cols, d_cols.p, cols_total * 4, hipMemcpyDeviceToHost, s));
+    else {
+        HIPCHK(hipMemcpyAsync(ed, d_ed.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(endloc, d_end.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(ops_len, d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(ops, d_ops.p, qbytes + tbytes, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+
+    /* degenerate problems: one side empty -> pure insertion / deletion run (lib/edlib/edlib.cpp:1096-1104) */
+    for (int i : trivial) {
+        const uint32_t nn = (uint32_t)(qoff[i + 1] - qoff[i]), mm = (uint32_t)(toff[i + 1] - toff[i]);
+        if (cols) { int32_t *oc = cols + cols_off[i]; oc[0] = (int32_t)mm; continue; }   /* n == 0 */
+        const int md = mode ? mode[i] : 0;
+        uint8_t *o = ops + qoff[i] + toff[i];
+        if (nn == 0) {
+            /* NW: delete the whole target; SHW: the empty prefix is optimal */
+            const uint32_t tl = md == 0 ? mm : 0;
+            ed[i] = (int32_t)tl; endloc[i] = (int32_t)tl - 1; ops_len[i] = tl;
+            for (uint32_t j = 0; j < tl; j++) o[j] = 2;
+        } else { ed[i] = (int32_t)nn; endloc[i] = -1; ops_len[i] = nn; for (uint32_t j = 0; j < nn; j++) o[j] = 1; }
+        if (task && task[i] == LF_TASK_DIST) ops_len[i] = 0;
+    }
+    return LF_OK;
+}
+
+extern "C" int lfg_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
+                         const uint8_t *mode, const uint8_t *task, int32_t *ed, int32_t *endloc, uint8_t *ops,
+                         uint32_t *ops_len, float *ms)
+{
+    return run_edlib(device, n, q, qoff, t, toff, mode, task, nullptr, ed, endloc, ops, ops_len, nullptr, nullptr, ms);
+}
+
+extern "C" int lfg_colscores(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
+                             const uint8_t *rev, int32_t *out, const uint64_t *cs_off, float *ms)
+{
+    return run_edlib(device, n, q, qoff, t, toff, nullptr, nullptr, rev, nullptr, nullptr, nullptr, nullptr, out, cs_off, ms);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * ksw_extend2 (lib/bwa/ksw.c:380-478), clip matrix +2/-16/N=0 (src/LordFAST.cpp:82-85,178-187).
+ * Rare branch of the reference (clip / split tests): one lane per problem, H/E rows in HBM.
+ * ---------------------------------------------------------------------------------------------- */
+struct lf_ksw_prob { uint64_t qoff, toff, ws_off; int32_t qlen, tlen, o_del, e_del, o_ins, e_ins, w, zdrop, h0, id; };
+
+__global__ void __launch_bounds__(64)
+lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t *__restrict__ qs, const uint8_t *__restrict__ ts,
+              int32_t *__restrict__ ws, int32_t *__restrict__ out_score, int32_t *__restrict__ out_qle, int32_t *__restrict__ out_tle)
+{
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= n_probs) return;
+    const lf_ksw_prob pr = probs[gid];
+    const uint8_t *q = qs + pr.qoff, *t = ts + pr.toff;
+    const int qlen = pr.qlen, tlen = pr.tlen, o_del = pr.o_del, e_del = pr.e_del, o_ins = pr.o_ins, e_ins = pr.e_ins;
+    const int zdrop = pr.zdrop, h0 = pr.h0;
+    int w = pr.w;
+    int32_t *H = ws + pr.ws_off, *E = H + qlen + 2;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    for (int j = 0; j <= qlen + 1; j++) { H[j] = 0; E[j] = 0; }
+    H[0] = h0;
+    H[1] = h0 > oe_ins ? h0 - oe_ins : 0;
+    for (int j = 2; j <= qlen && H[j - 1] > e_ins; ++j) H[j] = H[j - 1] - e_ins;
+    int max_ins = (int)((double)(qlen * 2 - o_ins) / e_ins + 1.);
+    if (max_ins < 1) max_ins = 1;
+    if (w > max_ins) w = max_ins;
+    int max_del = (int)((double)(qlen * 2 - o_del) / e_del + 1.);
+    if (max_del < 1) max_del = 1;
+    if (w > max_del) w = max_del;
+    int mx = h0, max_i = -1, max_j = -1, beg = 0, end = qlen;
+    for (int i = 0; i < tlen; ++i) {
+        int f = 0, h1, m = 0, mj = -1, j;
+        const int tc = t[i];
+        if (beg < i - w) beg = i - w;
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
+        else h1 = 0;
+        for (j = beg; j < end; ++j) {
+            int M = H[j], e = E[j], h, tt;
+            H[j] = h1;
+            const int qc = q[j];
+            const int sc = (tc > 3 || qc > 3) ? 0 : (tc == qc ? 2 : -16);
+            M = M ? M + sc : 0;
+            h = M > e ? M : e;
+            h = h > f ? h : f;
+            h1 = h;
+            mj = m > h ? mj : j;
+            m = m > h ? m : h;
+            tt = M - oe_del; if (tt < 0) tt = 0;
+            e -= e_del; if (e < tt) e = tt;
+            E[j] = e;
+            tt = M - oe_ins; if (tt < 0) tt = 0;
+            f -= e_ins; if (f < tt) f = tt;
+        }
+        H[end] = h1; E[end] = 0;
+        if (m == 0) break;
+        if (m > mx) { mx = m; max_i = i; max_j = mj; }
+        else if (zdrop > 0) {
+            if (i - max_i > mj - max_j) { if (mx - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
+            else { if (mx - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
+        }
+        for (j = beg; j < end && H[j] == 0 && E[j] == 0; ++j) {}
+        beg = j;
+        for (j = end; j >= beg && H[j] == 0 && E[j] == 0; --j) {}
+        end = j + 2 < qlen ? j + 2 : qlen;
+    }
+    out_score[pr.id] = mx; out_qle[pr.id] = max_j + 1; out_tle[pr.id] = max_i + 1;
+}
+
+extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff, const uint8_t *t, const uint64_t *toff,
+                       const int32_t *prm, int32_t *score, int32_t *qle, int32_t *tle, float *ms)
+{
+    if (ms) *ms = 0;
+    if (n == 0) return LF_OK;
+    if (lfg_device_count() <= device) { lf_set_error("no gfx950 device %d visible (no CPU path)", device); return LF_ERR_NO_DEVICE; }
+    HIPCHK(hipSetDevice(device));
+    std::vector<lf_ksw_prob> P((size_t)n);
+    size_t ws = 0;
+    for (int i = 0; i < n; i++) {
+        lf_ksw_prob &p = P[i];
+        p.qoff = qoff[i]; p.toff = toff[i]; p.qlen = (int32_t)(qoff[i + 1] - qoff[i]); p.tlen = (int32_t)(toff[i + 1] - toff[i]);
+        p.o_del = prm[7 * i]; p.e_del = prm[7 * i + 1]; p.o_ins = prm[7 * i + 2]; p.e_ins = prm[7 * i + 3];
+        p.w = prm[7 * i + 4]; p.zdrop = prm[7 * i + 5]; p.h0 = prm[7 * i + 6]; p.id = i;
+        p.ws_off = ws; ws += 2 * ((size_t)p.qlen + 2);
+    }
+    lf_dev_buf d_q, d_t, d_p, d_ws, d_s, d_ql, d_tl;
+    HIPCHK(d_q.alloc(qoff[n] + 16)); HIPCHK(d_t.alloc(toff[n] + 16)); HIPCHK(d_p.alloc(P.size() * sizeof(lf_ksw_prob)));
+    HIPCHK(d_ws.alloc(ws * 4 + 16)); HIPCHK(d_s.alloc((size_t)n * 4)); HIPCHK(d_ql.alloc((size_t)n * 4)); HIPCHK(d_tl.alloc((size_t)n * 4));
+    hipStream_t s; HIPCHK(hipStreamCreate(&s));
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipMemcpyAsync(d_q.p, q, qoff[n], hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_t.p, t, toff[n], hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_p.p, P.data(), P.size() * sizeof(lf_ksw_prob), hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(lf_ksw_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_p.as<lf_ksw_prob>(), n, d_q.as<uint8_t>(),
+                       d_t.as<uint8_t>(), d_ws.as<int32_t>(), d_s.as<int32_t>(), d_ql.as<int32_t>(), d_tl.as<int32_t>());
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipMemcpyAsync(score, d_s.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(qle, d_ql.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(tle, d_tl.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    return LF_OK;
+}

@@ -1,0 +1,168 @@
+/*
+ * lf_chain.hip -- dp-n2 anchor chaining (gfx950).  Reference: chain_seeds_n2 (src/Chain.cpp:232-310).
+ *
+ * One wavefront per window.  Seeds arrive already in the reference's std::sort order (the introsort
+ * permutation is reproduced on the host, SURVEY 7 hard part 1).  The DP row i is sequential; its inner
+ * scan over j < i is spread over the 64 lanes, each keeping its best (value, largest j), followed by a
+ * wavefront max-reduction with the same tie rule -- the reference visits j downwards and updates on strict
+ * '>', so the winner is the LARGEST j attaining the maximum, and only if it beats dp[i] = len_i.
+ * FP64 throughout, evaluation order (dp[j] + reward) - pen, no contraction (-ffp-contract=off).
+ * pen[d] = 0.1*d + chainPenalty*log(d) comes from a host-built table (glibc log, the same libm the
+ * reference uses), so no device transcendental is involved.
+ * Seeds + dp + prev live in LDS (<= LF_CHAIN_LDS_MAX seeds) or in an HBM workspace for huge windows.
+ */
+#include "lf_gpu_common.h"
+#include <vector>
+#include <algorithm>
+#include <math.h>
+
+#define LF_CHAIN_LDS_MAX 4096
+
+struct lf_chain_win { uint64_t off; uint32_t n; uint32_t id; uint64_t ws_off; };
+
+__device__ __forceinline__ void lf_wave_argmax(double &v, int &j)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v2 = __shfl_xor(v, o);
+        const int j2 = __shfl_xor(j, o);
+        if (v2 > v || (v2 == v && j2 > j)) { v = v2; j = j2; }
+    }
+}
+
+__global__ void __launch_bounds__(64)
+lf_chain_n2_kernel(const lf_chain_win *__restrict__ wins, int n_wins, const uint32_t *__restrict__ seeds /* tPos, qpl pairs */,
+                   const double *__restrict__ pen, uint32_t pen_n, double reward, double chain_penalty, uint32_t cap,
+                   double *__restrict__ ws_dp, int *__restrict__ ws_prev,
+                   uint32_t *__restrict__ chain_idx, uint32_t *__restrict__ chain_len, float *__restrict__ score)
+{
+    /* dynamic LDS, carved for `cap` seeds (launch-time, per size class): dp | tPos | qPos | prev | len */
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *s_dp = reinterpret_cast<double *>(smem);
+    uint32_t *s_t = reinterpret_cast<uint32_t *>(smem + (size_t)cap * 8);
+    uint32_t *s_q = s_t + cap;
+    int *s_prev = reinterpret_cast<int *>(s_q + cap);
+    uint16_t *s_l = reinterpret_cast<uint16_t *>(s_prev + cap);
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= n_wins) return;
+    const lf_chain_win w = wins[blockIdx.x];
+    const int n = (int)w.n;
+    const uint32_t *sd = seeds + 2 * w.off;
+    const bool in_lds = n <= (int)cap;
+    double *dp = in_lds ? s_dp : ws_dp + w.ws_off;
+    int *prev = in_lds ? s_prev : ws_prev + w.ws_off;
+    if (in_lds) {
+        for (int i = lane; i < n; i += 64) { const uint32_t qpl = sd[2 * i + 1]; s_t[i] = sd[2 * i]; s_q[i] = qpl & 0xFFFFF; s_l[i] = (uint16_t)(qpl >> 20); }
+        __syncthreads();
+    }
+    double best = -1; int bestIdx = -1;
+    for (int i = 0; i < n; i++) {
+        uint32_t ti, qi, li;
+        if (in_lds) { ti = s_t[i]; qi = s_q[i]; li = s_l[i]; }
+        else { const uint32_t qpl = sd[2 * i + 1]; ti = sd[2 * i]; qi = qpl & 0xFFFFF; li = qpl >> 20; }
+        double bv = -1.0e300; int bj = -1;
+        for (int j = i - 1 - lane; j >= 0; j -= 64) {
+            uint32_t tj, qj, lj;
+            if (in_lds) { tj = s_t[j]; qj = s_q[j]; lj = s_l[j]; }
+            else { const uint32_t qpl = sd[2 * j + 1]; tj = sd[2 * j]; qj = qpl & 0xFFFFF; lj = qpl >> 20; }
+            const int distR = (int)qi - ((int)qj + (int)lj - 1);
+            if (distR <= 0) continue;
+            const int distT = (int)(ti - (tj + lj - 1));
+            if (distT <= 0) continue;
+            const uint32_t d = (uint32_t)(distR < distT ? distT - distR : distR - distT);
+            /* score_penalty (src/Chain.cpp:217-225); the table covers every distance a window can produce */
+            const double pn = d <= 1 ? 0.0 : (d < pen_n ? pen[d] : 0.1 * (double)(int)d + chain_penalty * log((double)(int)d));
+            const double cand = (dp[j] + reward) - pn;
+            if (cand > bv) { bv = cand; bj = j; }      /* j descends within a lane: first hit = largest j */
+        }
+        lf_wave_argmax(bv, bj);
+        double di = (double)li; int pi = -1;
+        if (bj >= 0 && bv > di) { di = bv; pi = bj; }
+        if (lane == 0) { dp[i] = di; prev[i] = pi; }
+        if (di > best) { best = di; bestIdx = i; }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        uint32_t len = 0;
+        for (int k = bestIdx; k != -1; k = prev[k]) len++;
+        uint32_t wpos = len;
+        uint32_t *out = chain_idx + w.off;
+        for (int k = bestIdx; k != -1; k = prev[k]) out[--wpos] = (uint32_t)k;
+        chain_len[w.id] = len;
+        score[w.id] = (float)best;
+    }
+}
+
+extern "C" int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, const Seed_t *sorted_seeds,
+                            const uint64_t *off, uint32_t *chain_idx, uint32_t *chain_len, float *score, float *ms)
+{
+    if (ms) *ms = 0;
+    if (n_windows == 0) return LF_OK;
+    if (lfg_device_count() <= device) { lf_set_error("no gfx950 device %d visible (no CPU path)", device); return LF_ERR_NO_DEVICE; }
+    HIPCHK(hipSetDevice(device));
+    const uint64_t total = off[n_windows];
+    std::vector<lf_chain_win> W((size_t)n_windows);
+    size_t ws = 0;
+    uint64_t max_d = 64;
+    const uint32_t *raw = (const uint32_t *)sorted_seeds;
+    for (int i = 0; i < n_windows; i++) {
+        W[i].off = off[i]; W[i].n = (uint32_t)(off[i + 1] - off[i]); W[i].id = (uint32_t)i; W[i].ws_off = ws;
+        if (W[i].n > LF_CHAIN_LDS_MAX) ws += W[i].n;
+        if (W[i].n) {
+            uint32_t tmin = 0xFFFFFFFFu, tmax = 0, qmax = 0;
+            for (uint64_t k = off[i]; k < off[i + 1]; k++) {
+                const uint32_t t = raw[2 * k], qv = raw[2 * k + 1] & 0xFFFFF;
+                if (t < tmin) tmin = t;
+                if (t > tmax) tmax = t;
+                if (qv > qmax) qmax = qv;
+            }
+            const uint64_t d = (uint64_t)(tmax - tmin) + qmax + 8192;
+            if (d > max_d) max_d = d;
+        }
+    }
+    std::sort(W.begin(), W.end(), [](const lf_chain_win &a, const lf_chain_win &b) { return a.n < b.n || (a.n == b.n && a.id < b.id); });
+    if (max_d > (64u << 20)) max_d = 64u << 20;      /* beyond the table the kernel evaluates the formula itself */
+    /* penalty table, evaluated exactly as score_penalty does (src/Chain.cpp:224) with the host libm */
+    std::vector<double> pen((size_t)max_d);
+    for (uint64_t d = 0; d < max_d; d++) pen[d] = d <= 1 ? 0.0 : 0.1 * (double)(int)d + p->chain_penalty * log((double)(int)d);
+    const double reward = p->chain_reward * (double)p->min_anchor_len;     /* score_reward, src/Chain.cpp:211-215 */
+
+    void *d_w = nullptr, *d_seeds = nullptr, *d_pen = nullptr, *d_dp = nullptr, *d_prev = nullptr, *d_idx = nullptr, *d_len = nullptr, *d_sc = nullptr;
+    HIPCHK(hipMalloc(&d_w, W.size() * sizeof(lf_chain_win)));
+    HIPCHK(hipMalloc(&d_seeds, total * 8 + 16));
+    HIPCHK(hipMalloc(&d_pen, pen.size() * 8));
+    HIPCHK(hipMalloc(&d_dp, ws * 8 + 16)); HIPCHK(hipMalloc(&d_prev, ws * 4 + 16));
+    HIPCHK(hipMalloc(&d_idx, total * 4 + 16)); HIPCHK(hipMalloc(&d_len, (size_t)n_windows * 4)); HIPCHK(hipMalloc(&d_sc, (size_t)n_windows * 4));
+    hipStream_t s; HIPCHK(hipStreamCreate(&s));
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipMemcpyAsync(d_w, W.data(), W.size() * sizeof(lf_chain_win), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_seeds, sorted_seeds, total * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_pen, pen.data(), pen.size() * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(e0, s));
+    /* windows are sorted by size; one launch per LDS size class so small windows keep the CU full */
+    static const uint32_t CAPS[5] = { 128, 512, 2048, LF_CHAIN_LDS_MAX, 0 };
+    size_t lo = 0;
+    for (int c = 0; c < 5; c++) {
+        size_t hi = lo;
+        while (hi < W.size() && (CAPS[c] == 0 || W[hi].n <= CAPS[c])) hi++;
+        if (hi > lo) {
+            const uint32_t cap = CAPS[c] ? CAPS[c] : 1;
+            const size_t smem = (size_t)cap * 22 + 16;
+            hipLaunchKernelGGL(lf_chain_n2_kernel, dim3((unsigned)(hi - lo)), dim3(64), smem, s, (const lf_chain_win *)d_w + lo, (int)(hi - lo),
+                               (const uint32_t *)d_seeds, (const double *)d_pen, (uint32_t)pen.size(), reward, p->chain_penalty, CAPS[c],
+                               (double *)d_dp, (int *)d_prev, (uint32_t *)d_idx, (uint32_t *)d_len, (float *)d_sc);
+        }
+        lo = hi;
+    }
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipMemcpyAsync(chain_idx, d_idx, total * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(chain_len, d_len, (size_t)n_windows * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(score, d_sc, (size_t)n_windows * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    (void)hipFree(d_w); (void)hipFree(d_seeds); (void)hipFree(d_pen); (void)hipFree(d_dp); (void)hipFree(d_prev);
+    (void)hipFree(d_idx); (void)hipFree(d_len); (void)hipFree(d_sc);
+    return LF_OK;
+}

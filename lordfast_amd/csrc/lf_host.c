@@ -154,6 +154,13 @@ int lf_seed_batch(const lf_index_t *ix, const lf_params_t *p, int n_reads, const
     if (!ix || !p || n_reads < 0 || p->min_anchor_len < 12 || p->min_anchor_len > 20 || p->sampling_count <= 0) {
         lf_set_error("lf_seed_batch: bad argument (k must be in [12,20], c > 0)"); return LF_ERR_ARG;
     }
+    if (n_reads == 0) {
+        lf_seeds_t *e = (lf_seeds_t *)calloc(1, sizeof *e);
+        e->offF = (uint64_t *)calloc(1, 8); e->offR = (uint64_t *)calloc(1, 8);
+        e->F = (Seed_t *)malloc(8); e->R = (Seed_t *)malloc(8);
+        *out = e;
+        return LF_OK;
+    }
     lfg_hits_t h;
     int rc = lfg_seed(ix, p, n_reads, reads, off, &h);
     if (rc != LF_OK) return rc;

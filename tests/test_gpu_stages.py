@@ -1,0 +1,137 @@
+"""GPU parity, stage level: lf_edlib_batch / lf_chain_n2_batch / lf_ksw_extend2_batch (HIP, through the
+C ABI) vs the golden vectors produced by the real reference, and vs the oracle on seeded random inputs."""
+import numpy as np
+import pytest
+
+from conftest import split_ragged
+from lordfast_amd import synth
+
+pytestmark = pytest.mark.gpu
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def rseq(rng, n, alphabet=ACGT, p=None):
+    return bytes(rng.choice(alphabet, size=n, p=p))
+
+
+def test_edlib_golden(stages):
+    import lordfast_amd as la
+    qs = split_ragged(stages["ed_q"].tobytes(), stages["ed_qn"])
+    ts = split_ragged(stages["ed_t"].tobytes(), stages["ed_tn"])
+    ops = split_ragged(stages["ed_ops"], stages["ed_opsn"])
+    res, ms = la.edlib_batch(qs, ts, stages["ed_mode"])
+    assert len(res) == len(qs)
+    for i, (r, ed, end, op) in enumerate(zip(res, stages["ed_dist"], stages["ed_end"], ops)):
+        assert (r[0], r[1]) == (int(ed), int(end)), (i, len(qs[i]), len(ts[i]), int(stages["ed_mode"][i]))
+        assert np.array_equal(r[2], op), i
+
+
+def test_edlib_fuzz_vs_oracle(oracle_lib):
+    import lordfast_amd as la
+    orc = oracle_lib.Oracle()
+    rng = np.random.default_rng(11)
+    qs, ts, modes = [], [], []
+    lens = list(range(1, 40)) + [62, 63, 64, 65, 66, 127, 128, 129, 191, 192, 193, 255, 256, 257, 320, 511, 512, 513, 700, 1100]
+    for it in range(1500):
+        n = int(rng.choice(lens))
+        kind = it % 5
+        if kind == 0:
+            q = rseq(rng, n); t = rseq(rng, int(rng.choice(lens)))
+        elif kind == 1:
+            q = rseq(rng, n, ACGT[:2], [0.85, 0.15]); t = rseq(rng, int(rng.choice(lens)), ACGT[:2], [0.85, 0.15])
+        else:
+            q = rseq(rng, n)
+            t = synth.mutate(np.frombuffer(q, dtype=np.uint8), float(rng.uniform(0.0, 0.4)), rng).tobytes() or q
+        if it % 37 == 0:
+            q = q.lower()                      # raw-byte comparison: lower case never matches the reference
+        if it % 41 == 0:
+            q = q[:len(q) // 2] + b"N" + q[len(q) // 2:]
+        for mode in (0, 1):
+            tt = t + rseq(rng, int(rng.integers(0, 25))) if mode == 1 else t
+            qs.append(q); ts.append(tt); modes.append(mode)
+    # Hirschberg regime and a skinny-but-long problem
+    for n, e in ((1900, 0.15), (3000, 0.1), (2400, 0.3)):
+        q = np.frombuffer(rseq(rng, n), dtype=np.uint8)
+        t = synth.mutate(q, e, rng)
+        q2 = np.concatenate([q[:n // 2], np.frombuffer(b"AT" * 150, dtype=np.uint8), q[n // 2:]])
+        qs += [q.tobytes(), q2.tobytes(), q.tobytes()]; ts += [t.tobytes(), t.tobytes(), t.tobytes() + rseq(rng, 20)]; modes += [0, 0, 1]
+    qs.append(rseq(rng, 90)); ts.append(rseq(rng, 40000)); modes.append(1)
+    res, ms = la.edlib_batch(qs, ts, modes)
+    for i, r in enumerate(res):
+        o = orc.edlib(qs[i], ts[i], modes[i])
+        assert (r[0], r[1]) == (o[0], o[1]), (i, len(qs[i]), len(ts[i]), modes[i])
+        assert np.array_equal(r[2], o[2]), (i, len(qs[i]), len(ts[i]), modes[i])
+
+
+def test_edlib_empty_batch():
+    import lordfast_amd as la
+    res, _ = la.edlib_batch([], [], [])
+    assert res == []
+
+
+def test_chain_golden(stages):
+    import lordfast_amd as la
+    ins = split_ragged(stages["chain_in"], stages["chain_n"])
+    srt = split_ragged(stages["chain_sorted"], stages["chain_n"])
+    outs = split_ragged(stages["chain_out"], stages["chain_out_n"])
+    res = la.chain_n2_batch(ins)
+    for r, ss, ch, sc in zip(res, srt, outs, stages["chain_score"]):
+        assert np.array_equal(r[0], ss), "introsort order differs from std::sort"
+        assert np.array_equal(r[1], ch)
+        assert np.float32(r[2]) == np.float32(sc)
+
+
+def test_chain_fuzz_vs_oracle(oracle_lib):
+    import lordfast_amd as la
+    orc = oracle_lib.Oracle()
+    rng = np.random.default_rng(4)
+    wins = []
+    for it in range(300):
+        n = int(rng.integers(0, 400)) if it % 10 else int(rng.integers(400, 6000))
+        nq = max(1, int(n * rng.uniform(0.05, 1.0)))
+        qpool = np.sort(rng.integers(0, 20000, size=nq))
+        q = qpool[rng.integers(0, nq, size=n)].astype(np.uint32) if n else np.zeros(0, np.uint32)
+        if it % 4 == 0:
+            t = (q.astype(np.int64) + rng.integers(-2, 3, size=n) + 100000).astype(np.uint32)
+        elif it % 4 == 1:
+            t = (q.astype(np.int64) + rng.choice([100000, 100003, 250000], size=n)).astype(np.uint32)
+        else:
+            t = rng.integers(50000, 90000, size=n).astype(np.uint32)
+        ln = rng.integers(14, 25, size=n).astype(np.uint32)
+        wins.append(np.stack([t, q, ln], axis=1) if n else np.zeros((0, 3), dtype=np.uint32))
+    for kw in (dict(), dict(chain_reward=5.0, chain_penalty=8.0, min_anchor_len=17)):
+        res = la.chain_n2_batch(wins, la.default_params(**kw))
+        for i, (w, r) in enumerate(zip(wins, res)):
+            o = orc.chain_n2(w, oracle_lib.default_params(**kw))
+            assert np.array_equal(r[0], o[0]), i
+            assert np.array_equal(r[1], o[1]), (i, len(w))
+            assert np.float32(r[2]) == np.float32(o[2]), i
+
+
+def test_ksw_golden_and_fuzz(stages, oracle_lib):
+    import lordfast_amd as la
+    qs = split_ragged(stages["ksw_q"], stages["ksw_qn"])
+    ts = split_ragged(stages["ksw_t"], stages["ksw_tn"])
+    res = la.ksw_extend2_batch(qs, ts, stages["ksw_prm"])
+    for r, exp in zip(res, stages["ksw_res"]):
+        assert tuple(r) == tuple(int(x) for x in exp)
+    orc = oracle_lib.Oracle()
+    rng = np.random.default_rng(3)
+    qs, ts, prms = [], [], []
+    for it in range(600):
+        n = int(rng.integers(1, 700))
+        q = rng.integers(0, 4, size=n).astype(np.uint8)
+        if it % 3 == 0:
+            t = rng.integers(0, 4, size=int(rng.integers(1, 700))).astype(np.uint8)
+        else:
+            keep = int(rng.integers(1, n + 1))
+            t = np.concatenate([q[:keep], rng.integers(0, 4, size=int(rng.integers(0, 200))).astype(np.uint8)])
+            mut = rng.random(len(t)) < rng.uniform(0, 0.2)
+            t[mut] = rng.integers(0, 4, size=int(mut.sum())).astype(np.uint8)
+        if it % 11 == 0:
+            q[rng.integers(0, len(q), size=2)] = 4
+        qs.append(q); ts.append(t)
+        prms.append((0, 1, 0, 1, 40, 40, len(q)) if it % 2 else (8, 1, 4, 1, 100, 200, len(q)))
+    res = la.ksw_extend2_batch(qs, ts, prms)
+    for i, r in enumerate(res):
+        assert tuple(r) == tuple(orc.ksw_extend2(qs[i], ts[i], *prms[i])), i
