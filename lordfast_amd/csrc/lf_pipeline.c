@@ -1,0 +1,1152 @@
+/*
+ * lf_pipeline.c -- lf_map_batch: mapSeq (src/LordFAST.cpp:461-580) for a whole read batch.
+ *
+ * The reference runs one read at a time through seed -> vote -> chain -> extend.  Here every stage is a
+ * batch over all reads of a chunk so that each HIP kernel sees 10^5..10^7 independent work items:
+ *
+ *   A  GPU   seeds of every read                                   lf_seed.hip
+ *   B  host  window vote (sparse, same counts/ties as the dense tagged array), coarse/fine decision,
+ *            seed selection + std::sort order per candidate window
+ *   C  GPU   dp-n2 chains of all candidate windows                 lf_chain.hip
+ *      host  fine mode: top-N heap replay on the chain scores
+ *   D  GPU   alignments.  alignChain_edlib (src/LordFAST.cpp:1765-2258) is data dependent (clip test,
+ *            split test), so it is written as a REPLAY: the host walks the reference's control flow,
+ *            every alignment it needs is looked up in a memo; a miss registers a request and the walk
+ *            continues speculatively on the common path.  Requests of all chains go to the GPU together
+ *            (lf_align.hip), then incomplete chains are replayed.  ~99 % finish after one GPU round.
+ *   E  host  CIGAR / MD / MAPQ / SAM text (src/LordFAST.cpp:318-459,1570-1763)
+ *
+ * The host never computes a DP cell: no CPU alignment, chaining or FM-index code exists in this library.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+#include "lf_internal.h"
+#include "lf_stdsort.h"
+
+int lf_edlib_solve(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
+                   const uint8_t *mode, int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len,
+                   float *kernel_ms, uint64_t *n_launch_rounds);
+void lf_sort_seeds_by_qpos(Seed_t *s, long n);
+
+/* src/LordFAST.cpp:88-92 */
+#define CLIP_LEN    500
+#define CLIP_SIM    0.75
+#define SPLIT_LEN   80
+#define SPLIT_SIM   0.40
+#define REVERSE_SIM 0.60
+
+static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+
+/* ---------------------------------------------------------------- small containers */
+typedef struct { char *s; size_t n, cap; } str_t;
+static void str_init(str_t *b) { b->cap = 256; b->s = (char *)malloc(b->cap); b->n = 0; b->s[0] = 0; }
+static void str_room(str_t *b, size_t extra)
+{
+    if (b->n + extra + 1 <= b->cap) return;
+    while (b->n + extra + 1 > b->cap) b->cap *= 2;
+    b->s = (char *)realloc(b->s, b->cap);
+}
+static void str_putn(str_t *b, const char *s, size_t l) { str_room(b, l); memcpy(b->s + b->n, s, l); b->n += l; b->s[b->n] = 0; }
+static void str_puts(str_t *b, const char *s) { str_putn(b, s, strlen(s)); }
+static void str_putc(str_t *b, char c) { str_room(b, 1); b->s[b->n++] = c; b->s[b->n] = 0; }
+static void str_putu(str_t *b, unsigned long long v)
+{
+    char tmp[24]; int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    str_room(b, (size_t)k);
+    while (k) b->s[b->n++] = tmp[--k];
+    b->s[b->n] = 0;
+}
+static void str_puti(str_t *b, long long v) { if (v < 0) { str_putc(b, '-'); str_putu(b, (unsigned long long)(-v)); } else str_putu(b, (unsigned long long)v); }
+
+/* per-base op track that grows at both ends (the reference uses std::deque<char>) */
+typedef struct { char *buf; size_t cap, beg, end; } track_t;
+static void tr_init(track_t *d, size_t hint) { d->cap = hint * 2 + 256; d->buf = (char *)malloc(d->cap); d->beg = d->end = d->cap / 2; }
+static void tr_clear(track_t *d) { d->beg = d->end = d->cap / 2; }
+static size_t tr_size(const track_t *d) { return d->end - d->beg; }
+static void tr_room(track_t *d, size_t front, size_t back)
+{
+    if (d->beg >= front && d->cap - d->end >= back) return;
+    size_t n = tr_size(d), ncap = (n + front + back) * 2 + 1024;
+    char *nb = (char *)malloc(ncap);
+    size_t nbeg = front + (ncap - n - front - back) / 2;
+    memcpy(nb + nbeg, d->buf + d->beg, n);
+    free(d->buf);
+    d->buf = nb; d->cap = ncap; d->beg = nbeg; d->end = nbeg + n;
+}
+static void tr_back_n(track_t *d, size_t n, char c) { tr_room(d, 0, n); memset(d->buf + d->end, c, n); d->end += n; }
+static void tr_front_n(track_t *d, size_t n, char c) { tr_room(d, n, 0); d->beg -= n; memset(d->buf + d->beg, c, n); }
+
+/* ---------------------------------------------------------------- data model (src/LordFAST.h:43-118) */
+typedef struct { uint32_t tStart, tEnd; uint8_t isReverse; float score; int req; } win_t;
+#define WIN_LESS(a, b) ((a)->score > (b)->score)              /* compareWin, src/LordFAST.cpp:981-984 */
+LF_DEFINE_STDSORT(winh, win_t, WIN_LESS)
+
+typedef struct {
+    uint32_t qStart, qEnd, pos, posEnd;
+    uint16_t flag;
+    int32_t alnScore, nmCount;
+    char *cigar, *md;
+} sam_t;
+typedef struct { sam_t *v; int n, cap; int32_t totalScore; } samlist_t;
+#define SAM_LESS(a, b) ((a)->totalScore > (b)->totalScore)    /* compareSam, src/LordFAST.cpp:986-992 */
+LF_DEFINE_STDSORT(samsort, samlist_t, SAM_LESS)
+
+static void samlist_clear(samlist_t *l) { for (int i = 0; i < l->n; i++) { free(l->v[i].cigar); free(l->v[i].md); } l->n = 0; }
+static void samlist_push(samlist_t *l, const sam_t *s, char *cigar, char *md)
+{
+    if (l->n == l->cap) { l->cap = l->cap ? l->cap * 2 : 2; l->v = (sam_t *)realloc(l->v, (size_t)l->cap * sizeof(sam_t)); }
+    l->v[l->n] = *s; l->v[l->n].cigar = cigar; l->v[l->n].md = md; l->n++;
+}
+
+/* ---------------------------------------------------------------- requests */
+typedef struct {           /* identity of one alignment request inside a chain walk */
+    uint8_t type;          /* 0 edlib, 1 ksw */
+    uint8_t qrc, trc;      /* sequence = reverse complement of the segment */
+    uint8_t mode;          /* edlib: 0 NW 1 SHW ; ksw: 0 clip set, 1 split set */
+    uint32_t qs, qseg, qn; /* query segment [qs, qs+qseg) of the walk's query string, first qn bases of it used */
+    uint32_t ts, tseg, tn; /* reference segment [ts, ts+tseg), first tn bases used */
+} rkey_t;
+
+typedef struct {
+    rkey_t key;
+    int round;             /* -1 = requested, not yet computed */
+    int64_t slot;          /* index in the round's result arrays */
+} memo_t;
+
+typedef struct { int32_t *ed, *end; uint32_t *ops_len; uint8_t *ops; uint64_t *ops_off; int n; } ed_round_t;
+typedef struct { int32_t *score, *qle, *tle; int n; } ksw_round_t;
+
+typedef struct {
+    /* staged edlib requests of one worker */
+    char *qb, *tb; uint64_t qn, qcap, tn, tcap;
+    uint64_t *qoff, *toff; uint8_t *mode; int n, cap;
+    memo_t **owner;        /* memo entry to patch */
+    /* staged ksw requests */
+    uint8_t *kq, *kt; uint64_t kqn, kqcap, ktn, ktcap;
+    uint64_t *kqoff, *ktoff; int32_t *kprm; int kn, kcap;
+    memo_t **kowner;
+    uint64_t ext_bytes;
+} stage_t;
+
+typedef struct job {
+    int read, widx;        /* owning read, slot in that read's mapping list */
+    int isRev;
+    Seed_t *chain; uint32_t chainLen;
+    memo_t *memo; int nmemo, capmemo;
+    int complete, hint;
+} job_t;
+
+typedef struct {
+    const char *name, *seq, *qual;
+    uint32_t len; int isFq;
+    char *seq_rev, *qual_rev;
+    Seed_t *F, *R; uint32_t nF, nR;
+    int mode;              /* 0 short, 1 no window, 2 coarse, 3 fine */
+    int vote_tid;          /* worker that voted this read (owns its chain requests) */
+    /* fine-mode candidates in scan order */
+    struct cand { uint32_t win; uint8_t isRev; int req; } *cands; int ncand, capcand;
+    win_t *wins; int nWins;
+    job_t *jobs;           /* one per kept window */
+    samlist_t *maps;
+    str_t out;
+} rd_t;
+
+typedef struct {           /* one chain request = (read, window) */
+    int read; uint8_t isRev; uint32_t tStart, tEnd;
+    uint64_t off; uint32_t n;
+} creq_t;
+
+typedef struct ctx {
+    const struct lf_index *ix;
+    const lf_params_t *p;
+    int n_threads;
+    rd_t *reads; int n_reads;
+    /* chain requests (built per worker, then merged) */
+    creq_t *creq; int n_creq;
+    Seed_t *cseeds; uint64_t n_cseeds;
+    uint32_t *chain_idx, *chain_len; float *chain_score;
+    /* extension rounds */
+    ed_round_t *ed_rounds; int n_ed_rounds;
+    ksw_round_t *ksw_rounds; int n_ksw_rounds;
+    stage_t *stages;       /* per worker */
+    lf_stats_t *st;
+} ctx_t;
+
+/* ---------------------------------------------------------------- parallel for */
+typedef void (*pf_fn)(ctx_t *cx, int tid, int i);
+typedef struct { ctx_t *cx; pf_fn fn; int n, tid; volatile int *next; } pf_arg_t;
+static void *pf_worker(void *a_)
+{
+    pf_arg_t *a = (pf_arg_t *)a_;
+    for (;;) {
+        int i = __sync_fetch_and_add(a->next, 1);
+        if (i >= a->n) break;
+        a->fn(a->cx, a->tid, i);
+    }
+    return NULL;
+}
+static void parallel_for(ctx_t *cx, int n, pf_fn fn)
+{
+    volatile int next = 0;
+    int nt = cx->n_threads;
+    if (nt > n) nt = n;
+    if (nt <= 1) { pf_arg_t a = { cx, fn, n, 0, &next }; pf_worker(&a); return; }
+    pthread_t th[256]; pf_arg_t args[256];
+    for (int t = 0; t < nt; t++) { args[t] = (pf_arg_t){ cx, fn, n, t, &next }; pthread_create(&th[t], NULL, pf_worker, &args[t]); }
+    for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
+}
+
+/* ---------------------------------------------------------------- reference fetch (src/BWT.cpp:593-666) */
+static inline int pac_base(const uint8_t *pac, uint32_t l) { return (pac[l >> 2] >> ((~l & 3) << 1)) & 3; }
+
+static int pos2rid(const struct lf_index *ix, int64_t pos)
+{   /* bns_pos2rid (lib/bwa/bntseq.c:349-363). pos >= l_pac is undefined in the reference (anns[-1],
+       SURVEY App. B #9); we clamp to the last contig. */
+    if (pos >= ix->l_pac) return ix->n_seqs - 1;
+    int lo = 0, hi = ix->n_seqs - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (ix->contigs[mid].offset <= pos) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+static void chr_boundaries(const struct lf_index *ix, uint64_t beg, uint64_t end, uint32_t *cb, uint32_t *ce)
+{   /* bwt_get_chr_boundaries: contig of the MIDPOINT */
+    int rid = pos2rid(ix, (int64_t)((beg + end) >> 1));
+    *cb = (uint32_t)ix->contigs[rid].offset;
+    *ce = (uint32_t)(ix->contigs[rid].offset + ix->contigs[rid].len - 1);
+}
+
+static char rc_char(char c)
+{   /* tableRev, src/Common.cpp:31-40: case kept, anything else 'N' */
+    switch (c) {
+    case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+    case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
+    default: return 'N';
+    }
+}
+static void revcomp_into(const char *s, char *out, uint32_t len) { for (uint32_t i = 0; i < len; i++) out[i] = rc_char(s[len - 1 - i]); out[len] = 0; }
+
+/* ================================================================ B: vote, candidates, selection */
+typedef struct { uint32_t win, cnt; } wc_t;
+static int wc_cmp(const void *a, const void *b) { uint32_t x = ((const wc_t *)a)->win, y = ((const wc_t *)b)->win; return x < y ? -1 : x > y; }
+
+/* sparse equivalent of the tagged dense array of src/LordFAST.cpp:588-620: every seed adds its weight to
+ * windows floor(tPos/L) and floor(tPos/L)-1; returns the touched windows in ascending order */
+static int vote(const lf_params_t *p, uint32_t L, const Seed_t *s, uint32_t n, wc_t **buf, size_t *cap)
+{
+    if (*cap < 2 * (size_t)n + 2) { *cap = 2 * (size_t)n + 2; *buf = (wc_t *)realloc(*buf, *cap * sizeof(wc_t)); }
+    wc_t *w = *buf; int m = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t id = s[i].tPos / L;
+        uint32_t weight = (uint32_t)(1 + ((int32_t)s[i].len - p->min_anchor_len));
+        w[m].win = id; w[m].cnt = weight; m++;
+        if (id >= 1) { w[m].win = id - 1; w[m].cnt = weight; m++; }
+    }
+    qsort(w, (size_t)m, sizeof(wc_t), wc_cmp);
+    int d = 0;
+    for (int i = 0; i < m; ) {
+        uint32_t id = w[i].win, c = 0;
+        while (i < m && w[i].win == id) c += w[i++].cnt;
+        w[d].win = id; w[d].cnt = c; d++;
+    }
+    return d;
+}
+
+/* local maximum test of src/LordFAST.cpp:630-632 on the sparse list (k = position of the window) */
+static inline int local_max(const wc_t *w, int d, int k, uint32_t refWinNum)
+{
+    const uint32_t id = w[k].win;
+    const int left_ok = (id == 0) || !(k > 0 && w[k - 1].win == id - 1) || w[k].cnt >= w[k - 1].cnt;
+    const int right_ok = (id == refWinNum - 1) || !(k + 1 < d && w[k + 1].win == id + 1) || w[k].cnt > w[k + 1].cnt;
+    return left_ok && right_ok;
+}
+
+static void top_push(win_t *l, int *n, int maxWin, uint32_t i, uint32_t L, float score, int isRev, int req)
+{   /* src/LordFAST.cpp:634-654 */
+    if (*n < maxWin) {
+        win_t *b = &l[*n];
+        b->tStart = i * L; b->tEnd = (i + 2) * L - 1; b->score = score; b->isReverse = (uint8_t)isRev; b->req = req;
+        (*n)++;
+        winh_push_heap(l, *n);
+    } else if (score > l[0].score) {
+        winh_pop_heap(l, *n);
+        win_t *b = &l[*n - 1];
+        b->tStart = i * L; b->tEnd = (i + 2) * L - 1; b->score = score; b->isReverse = (uint8_t)isRev; b->req = req;
+        winh_push_heap(l, *n);
+    }
+}
+
+typedef struct { creq_t *v; int n, cap; Seed_t *s; uint64_t ns, caps; wc_t *wbuf; size_t wcap; wc_t *wbuf2; size_t wcap2; } cstage_t;
+static cstage_t *g_cstage;      /* per worker, set up by lf_map_batch */
+
+/* selection of src/LordFAST.cpp:995-1018 (== :659-680) into the worker's chain-request stage */
+static int add_chain_request(ctx_t *cx, int tid, int ri, int isRev, uint32_t tStart, uint32_t tEnd)
+{
+    cstage_t *cs = &g_cstage[tid];
+    const rd_t *r = &cx->reads[ri];
+    const uint32_t L = r->len, margin = L >> 1;
+    uint32_t cb, ce;
+    chr_boundaries(cx->ix, tStart, tEnd, &cb, &ce);
+    const int64_t lo = ((int64_t)tStart - (int64_t)margin > (int64_t)cb) ? (int64_t)tStart - (int64_t)margin : (int64_t)cb;
+    const int64_t hi = ((int64_t)tEnd + (int64_t)margin < (int64_t)ce) ? (int64_t)tEnd + (int64_t)margin : (int64_t)ce;
+    const Seed_t *s = isRev ? r->R : r->F;
+    const uint32_t n = isRev ? r->nR : r->nF;
+    if (cs->ns + n + 1 > cs->caps) { cs->caps = (cs->ns + n + 1) * 2; cs->s = (Seed_t *)realloc(cs->s, cs->caps * sizeof(Seed_t)); }
+    const uint64_t off = cs->ns;
+    for (uint32_t i = 0; i < n; i++)
+        if ((int64_t)s[i].tPos >= lo && (int64_t)s[i].tPos <= hi) cs->s[cs->ns++] = s[i];
+    lf_sort_seeds_by_qpos(cs->s + off, (long)(cs->ns - off));               /* std::sort, src/Chain.cpp:244 */
+    if (cs->n == cs->cap) { cs->cap = cs->cap ? cs->cap * 2 : 256; cs->v = (creq_t *)realloc(cs->v, (size_t)cs->cap * sizeof(creq_t)); }
+    creq_t *q = &cs->v[cs->n];
+    q->read = ri; q->isRev = (uint8_t)isRev; q->tStart = tStart; q->tEnd = tEnd; q->off = off; q->n = (uint32_t)(cs->ns - off);
+    return cs->n++;         /* worker-local id; rebased after the merge */
+}
+
+static void phase_vote(ctx_t *cx, int tid, int ri)
+{
+    rd_t *r = &cx->reads[ri];
+    const lf_params_t *p = cx->p;
+    cstage_t *cs = &g_cstage[tid];
+    r->vote_tid = tid;
+    if ((int)r->len < p->min_read_len) { r->mode = 0; return; }
+    const uint32_t L = r->len;
+    const uint32_t refWinNum = (uint32_t)cx->ix->l_pac / (uint32_t)p->min_read_len;          /* src/LordFAST.cpp:130 */
+    uint32_t lim = (uint32_t)cx->ix->l_pac / L + 2;                                          /* :622-624 */
+    if (lim > refWinNum) lim = refWinNum;
+    const int maxWin = p->max_map;
+    r->wins = (win_t *)calloc((size_t)maxWin + 1, sizeof(win_t));
+    r->nWins = 0;
+    int dF = vote(p, L, r->F, r->nF, &cs->wbuf, &cs->wcap);
+    for (int k = 0; k < dF && cs->wbuf[k].win < lim; k++)
+        if (local_max(cs->wbuf, dF, k, refWinNum)) top_push(r->wins, &r->nWins, maxWin, cs->wbuf[k].win, L, (float)cs->wbuf[k].cnt, 0, -1);
+    int dR = vote(p, L, r->R, r->nR, &cs->wbuf2, &cs->wcap2);
+    for (int k = 0; k < dR && cs->wbuf2[k].win < lim; k++)
+        if (local_max(cs->wbuf2, dR, k, refWinNum)) top_push(r->wins, &r->nWins, maxWin, cs->wbuf2[k].win, L, (float)cs->wbuf2[k].cnt, 1, -1);
+    if (r->nWins == 0) { r->mode = 1; return; }
+    winh_sort_heap(r->wins, r->nWins);                                                        /* :528 */
+    const float scoreRatio = 4;
+    /* a single candidate is compared with a stale slot in the reference (App. B #1); both branches then
+     * align the same window and print the same record */
+    if (r->nWins == 1 || r->wins[0].score >= scoreRatio * r->wins[1].score) {
+        r->mode = 2;
+        r->nWins = 1;
+        r->wins[0].req = add_chain_request(cx, tid, ri, r->wins[0].isReverse, r->wins[0].tStart, r->wins[0].tEnd);
+    } else {
+        r->mode = 3;
+        const float minScore = (float)r->wins[0].score / scoreRatio;                          /* :553 */
+        r->nWins = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            const wc_t *w = pass ? cs->wbuf2 : cs->wbuf; const int d = pass ? dR : dF;
+            for (int k = 0; k < d && w[k].win < lim; k++) {
+                if ((float)w[k].cnt > minScore && local_max(w, d, k, refWinNum)) {                /* :875-877 */
+                    if (r->ncand == r->capcand) { r->capcand = r->capcand ? r->capcand * 2 : 8; r->cands = (struct cand *)realloc(r->cands, (size_t)r->capcand * sizeof(struct cand)); }
+                    r->cands[r->ncand].win = w[k].win; r->cands[r->ncand].isRev = (uint8_t)pass;
+                    r->cands[r->ncand].req = add_chain_request(cx, tid, ri, pass, w[k].win * L, (w[k].win + 2) * L - 1);
+                    r->ncand++;
+                }
+            }
+        }
+    }
+}
+
+/* fine mode, after the chain kernel: the heap of src/LordFAST.cpp:879-901 replayed on the chain scores */
+static void phase_fine_select(ctx_t *cx, int tid, int ri)
+{
+    (void)tid;
+    rd_t *r = &cx->reads[ri];
+    if (r->mode != 3) return;
+    for (int c = 0; c < r->ncand; c++)
+        top_push(r->wins, &r->nWins, cx->p->max_map, r->cands[c].win, r->len, cx->chain_score[r->cands[c].req], r->cands[c].isRev, r->cands[c].req);
+}
+
+/* ================================================================ D: alignChain_edlib as a replay */
+typedef struct {
+    int ed, end; const uint8_t *ops; uint32_t nops;
+    int have;
+} edres_t;
+
+typedef struct {
+    ctx_t *cx; int tid; job_t *job;
+    const char *query;        /* read forward or reverse complement */
+    uint32_t readLen;
+    int missing;              /* edlib results still to come */
+    int bail;                 /* a ksw result is missing: stop walking */
+    int build;                /* build strings (results complete so far) */
+} walk_t;
+
+static int key_eq(const rkey_t *a, const rkey_t *b) { return memcmp(a, b, sizeof(rkey_t)) == 0; }
+
+static memo_t *memo_find(job_t *j, const rkey_t *k)
+{
+    if (j->hint < j->nmemo && key_eq(&j->memo[j->hint].key, k)) return &j->memo[j->hint++];
+    for (int i = 0; i < j->nmemo; i++) if (key_eq(&j->memo[i].key, k)) { j->hint = i + 1; return &j->memo[i]; }
+    return NULL;
+}
+static memo_t *memo_add(job_t *j, const rkey_t *k)
+{
+    if (j->nmemo == j->capmemo) { j->capmemo = j->capmemo ? j->capmemo * 2 : 32; j->memo = (memo_t *)realloc(j->memo, (size_t)j->capmemo * sizeof(memo_t)); }
+    memo_t *m = &j->memo[j->nmemo++];
+    m->key = *k; m->round = -1; m->slot = -1;
+    j->hint = j->nmemo;
+    return m;
+}
+
+/* bytes of a request: query segment of the walk's query string (optionally reverse-complemented) */
+static void put_query(const walk_t *w, const rkey_t *k, char *dst)
+{
+    const char *src = w->query + k->qs;
+    if (!k->qrc) memcpy(dst, src, k->qn);
+    else for (uint32_t i = 0; i < k->qn; i++) dst[i] = rc_char(src[k->qseg - 1 - i]);
+}
+static void put_target(const walk_t *w, const rkey_t *k, char *dst)
+{
+    const uint8_t *pac = w->cx->ix->pac;
+    if (!k->trc) for (uint32_t i = 0; i < k->tn; i++) dst[i] = "ACGT"[pac_base(pac, k->ts + i)];
+    else for (uint32_t i = 0; i < k->tn; i++) dst[i] = "ACGT"[3 - pac_base(pac, k->ts + k->tseg - 1 - i)];
+}
+static uint8_t code_of(char c)
+{   /* _pf_char2int, src/LordFAST.cpp:158-164 */
+    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+
+static void stage_edlib(walk_t *w, memo_t *m)
+{
+    stage_t *s = &w->cx->stages[w->tid];
+    const rkey_t *k = &m->key;
+    if (s->n == s->cap) {
+        s->cap = s->cap ? s->cap * 2 : 1024;
+        s->qoff = (uint64_t *)realloc(s->qoff, ((size_t)s->cap + 1) * 8); s->toff = (uint64_t *)realloc(s->toff, ((size_t)s->cap + 1) * 8);
+        s->mode = (uint8_t *)realloc(s->mode, (size_t)s->cap); s->owner = (memo_t **)realloc(s->owner, (size_t)s->cap * sizeof(memo_t *));
+        if (s->n == 0) { s->qoff[0] = 0; s->toff[0] = 0; }
+    }
+    if (s->qn + k->qn + 1 > s->qcap) { s->qcap = (s->qn + k->qn + 1) * 2; s->qb = (char *)realloc(s->qb, s->qcap); }
+    if (s->tn + k->tn + 1 > s->tcap) { s->tcap = (s->tn + k->tn + 1) * 2; s->tb = (char *)realloc(s->tb, s->tcap); }
+    put_query(w, k, s->qb + s->qn); put_target(w, k, s->tb + s->tn);
+    s->qn += k->qn; s->tn += k->tn;
+    s->qoff[s->n + 1] = s->qn; s->toff[s->n + 1] = s->tn; s->mode[s->n] = k->mode;
+    /* the memo array may be reallocated later: remember (job, index) through a stable pointer instead */
+    s->owner[s->n] = (memo_t *)(uintptr_t)(((uint64_t)(uintptr_t)(m - w->job->memo)));
+    s->n++;
+    s->ext_bytes += (uint64_t)k->qn + (k->tn + 3) / 4 + k->qn + k->tn;      /* SURVEY 8(d) B_ext */
+}
+
+/* job owner bookkeeping: parallel arrays */
+typedef struct { job_t **job; int n, cap; } jobvec_t;
+static jobvec_t *g_ed_jobs, *g_ksw_jobs;   /* per worker */
+static void jv_push(jobvec_t *v, job_t *j) { if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 1024; v->job = (job_t **)realloc(v->job, (size_t)v->cap * sizeof(job_t *)); } v->job[v->n++] = j; }
+
+static void stage_ksw(walk_t *w, memo_t *m)
+{
+    stage_t *s = &w->cx->stages[w->tid];
+    const rkey_t *k = &m->key;
+    if (s->kn == s->kcap) {
+        s->kcap = s->kcap ? s->kcap * 2 : 64;
+        s->kqoff = (uint64_t *)realloc(s->kqoff, ((size_t)s->kcap + 1) * 8); s->ktoff = (uint64_t *)realloc(s->ktoff, ((size_t)s->kcap + 1) * 8);
+        s->kprm = (int32_t *)realloc(s->kprm, (size_t)s->kcap * 7 * 4); s->kowner = (memo_t **)realloc(s->kowner, (size_t)s->kcap * sizeof(memo_t *));
+        if (s->kn == 0) { s->kqoff[0] = 0; s->ktoff[0] = 0; }
+    }
+    if (s->kqn + k->qn + 1 > s->kqcap) { s->kqcap = (s->kqn + k->qn + 1) * 2; s->kq = (uint8_t *)realloc(s->kq, s->kqcap); }
+    if (s->ktn + k->tn + 1 > s->ktcap) { s->ktcap = (s->ktn + k->tn + 1) * 2; s->kt = (uint8_t *)realloc(s->kt, s->ktcap); }
+    /* codes: convertChar2int / reverseComplementIntStr (src/LordFAST.cpp:1191-1201): 3 - code, so an N (4)
+     * becomes 255 in the reference and indexes past its 5x5 matrix; we score any code > 3 as 0 */
+    const char *src = w->query + k->qs;
+    for (uint32_t i = 0; i < k->qn; i++) {
+        uint8_t c = k->qrc ? code_of(src[k->qseg - 1 - i]) : code_of(src[i]);
+        s->kq[s->kqn + i] = k->qrc ? (uint8_t)(c > 3 ? 4 : 3 - c) : c;
+    }
+    const uint8_t *pac = w->cx->ix->pac;
+    for (uint32_t i = 0; i < k->tn; i++)
+        s->kt[s->ktn + i] = (uint8_t)(k->trc ? 3 - pac_base(pac, k->ts + k->tseg - 1 - i) : pac_base(pac, k->ts + i));
+    s->kqn += k->qn; s->ktn += k->tn;
+    s->kqoff[s->kn + 1] = s->kqn; s->ktoff[s->kn + 1] = s->ktn;
+    int32_t *pr = s->kprm + 7 * s->kn;
+    if (k->mode == 0) { pr[0] = 0; pr[1] = 1; pr[2] = 0; pr[3] = 1; pr[4] = 40; pr[5] = 40; }        /* ksw_extend :1848,:2180 */
+    else { pr[0] = 8; pr[1] = 1; pr[2] = 4; pr[3] = 1; pr[4] = 100; pr[5] = 200; }                    /* ksw_extend2 :1971,:1981 */
+    pr[6] = (int32_t)k->qn;                                                                           /* h0 = readAlnLen */
+    s->kowner[s->kn] = (memo_t *)(uintptr_t)(((uint64_t)(uintptr_t)(m - w->job->memo)));
+    s->kn++;
+}
+
+/* edlibAlign(query segment, target segment, mode, PATH) through the memo */
+static edres_t need_edlib(walk_t *w, int qrc, uint32_t qs, uint32_t qseg, uint32_t qn, int trc, uint32_t ts, uint32_t tseg, uint32_t tn, int mode)
+{
+    edres_t r; memset(&r, 0, sizeof r);
+    rkey_t k; memset(&k, 0, sizeof k);
+    k.type = 0; k.qrc = (uint8_t)qrc; k.trc = (uint8_t)trc; k.mode = (uint8_t)mode;
+    k.qs = qs; k.qseg = qseg; k.qn = qn; k.ts = ts; k.tseg = tseg; k.tn = tn;
+    memo_t *m = memo_find(w->job, &k);
+    if (!m) { m = memo_add(w->job, &k); stage_edlib(w, m); jv_push(&g_ed_jobs[w->tid], w->job); }
+    if (m->round < 0) { w->missing++; w->build = 0; r.ed = 0; r.end = (mode == 0) ? (int)tn - 1 : (int)tn - 1; return r; }
+    const ed_round_t *R = &w->cx->ed_rounds[m->round];
+    r.have = 1; r.ed = R->ed[m->slot]; r.end = R->end[m->slot]; r.nops = R->ops_len[m->slot]; r.ops = R->ops + R->ops_off[m->slot];
+    return r;
+}
+
+static int need_ksw(walk_t *w, int set, int qrc, uint32_t qs, uint32_t qseg, int trc, uint32_t ts, uint32_t tseg, int *qle, int *tle)
+{
+    rkey_t k; memset(&k, 0, sizeof k);
+    k.type = 1; k.qrc = (uint8_t)qrc; k.trc = (uint8_t)trc; k.mode = (uint8_t)set;
+    k.qs = qs; k.qseg = qseg; k.qn = qseg; k.ts = ts; k.tseg = tseg; k.tn = tseg;
+    memo_t *m = memo_find(w->job, &k);
+    if (!m) { m = memo_add(w->job, &k); stage_ksw(w, m); jv_push(&g_ksw_jobs[w->tid], w->job); }
+    if (m->round < 0) { w->bail = 1; w->build = 0; return 0; }
+    const ksw_round_t *R = &w->cx->ksw_rounds[m->round];
+    *qle = R->qle[m->slot]; *tle = R->tle[m->slot];
+    return 1;
+}
+
+/* ---- CIGAR / MD tracks (src/LordFAST.cpp:1570-1763) ---- */
+static const char OP2CH[4] = { 'M', 'I', 'D', 'M' };
+static void ops_back(track_t *cg, track_t *md, const edres_t *r, const uint8_t *pac, int trc, uint32_t ts, uint32_t tseg)
+{   /* edlibCigar_pushback + edlibMD_pushback: target base for deletions / mismatches */
+    if (!r->have) return;
+    tr_room(cg, 0, r->nops); tr_room(md, 0, r->nops);
+    uint32_t ti = 0;
+    for (uint32_t i = 0; i < r->nops; i++) {
+        const uint8_t op = r->ops[i];
+        cg->buf[cg->end++] = OP2CH[op];
+        char m;
+        if (op == 0) { m = '='; ti++; }
+        else if (op == 1) m = '-';
+        else { m = "ACGT"[trc ? 3 - pac_base(pac, ts + tseg - 1 - ti) : pac_base(pac, ts + ti)]; ti++; }
+        md->buf[md->end++] = m;
+    }
+}
+static void ops_front(track_t *cg, track_t *md, const edres_t *r, const uint8_t *pac, uint32_t ts, uint32_t tseg)
+{   /* edlibCigar_pushfront + edlibMD_pushfront: the alignment was computed on reverse complements of
+       query prefix and reference [ts, ts+tseg); pushing each op to the front restores forward order and
+       the MD base is the complement of the (reverse-complemented) target base = the forward base */
+    if (!r->have) return;
+    tr_room(cg, r->nops, 0); tr_room(md, r->nops, 0);
+    uint32_t ti = 0;
+    for (uint32_t i = 0; i < r->nops; i++) {
+        const uint8_t op = r->ops[i];
+        cg->buf[--cg->beg] = OP2CH[op];
+        char m;
+        if (op == 0) { m = '='; ti++; }
+        else if (op == 1) m = '-';
+        else { m = "ACGT"[pac_base(pac, ts + tseg - 1 - ti)]; ti++; }   /* complement(rc target[ti]) */
+        md->buf[--md->beg] = m;
+    }
+}
+
+static char *cigar_string(const track_t *c)
+{   /* edlibCigar_toString: leading / trailing I runs print as S */
+    str_t sb; str_init(&sb);
+    char ch = 0; unsigned num = 0; int opn = 0;
+    const size_t n = tr_size(c);
+    for (size_t i = 0; i < n; i++) {
+        const char x = c->buf[c->beg + i];
+        if (x != ch) {
+            if (ch != 0) { str_putu(&sb, num); str_putc(&sb, (opn == 0 && ch == 'I') ? 'S' : ch); opn++; }
+            num = 1; ch = x;
+        } else num++;
+    }
+    if (num) { str_putu(&sb, num); str_putc(&sb, ch == 'I' ? 'S' : ch); }
+    return sb.s;
+}
+static char *md_string(const track_t *md, const track_t *cg)
+{   /* edlibMD_toString */
+    str_t sb; str_init(&sb);
+    unsigned num = 0; char last = '=';
+    const size_t n = tr_size(md);
+    for (size_t i = 0; i < n; i++) {
+        const char m = md->buf[md->beg + i], c = cg->buf[cg->beg + i];
+        if (m == '=') { num++; last = '='; }
+        else if (m == '-') last = 'I';
+        else if (c == 'M') { str_putu(&sb, num); num = 0; str_putc(&sb, m); last = 'X'; }
+        else if (c == 'D') { if (last != 'D') { str_putu(&sb, num); num = 0; str_putc(&sb, '^'); } str_putc(&sb, m); last = 'D'; }
+    }
+    str_putu(&sb, num);
+    return sb.s;
+}
+
+static void emit_sam(walk_t *w, samlist_t *map, const sam_t *tmp, const track_t *cg, const track_t *md)
+{
+    if (!w->build) return;
+    samlist_push(map, tmp, cigar_string(cg), md_string(md, cg));
+}
+
+/* the walk itself.  Returns 1 when every alignment it needed was available (map is then final). */
+static int walk_chain(ctx_t *cx, int tid, job_t *job, samlist_t *map)
+{
+    const struct lf_index *ix = cx->ix;
+    const uint8_t *pac = ix->pac;
+    rd_t *rd = &cx->reads[job->read];
+    const int isRev = job->isRev;
+    const Seed_t *s = job->chain;
+    const uint32_t chainLen = job->chainLen;
+    walk_t W; memset(&W, 0, sizeof W);
+    W.cx = cx; W.tid = tid; W.job = job; W.query = isRev ? rd->seq_rev : rd->seq; W.readLen = rd->len; W.build = 1;
+    job->hint = 0;
+    const int32_t readLen = (int32_t)rd->len;
+    track_t cg, md; tr_init(&cg, rd->len); tr_init(&md, rd->len);
+    sam_t tmp; memset(&tmp, 0, sizeof tmp);
+    uint32_t chrBeg, chrEnd, readAlnStart, refAlnStart, readAlnEnd, refAlnEnd, i;
+    int32_t readAlnLen, refAlnLen, editScore = 0;
+    int qle = 0, tle = 0;
+    samlist_clear(map);
+
+    chr_boundaries(ix, s[0].tPos, s[chainLen - 1].tPos, &chrBeg, &chrEnd);                   /* :1799 */
+    tmp.flag = isRev ? 16 : 0; tmp.pos = s[0].tPos; tmp.qStart = s[0].qPos;
+
+    /* ---- before the first anchor (:1820-1899) ---- */
+    readAlnLen = (int32_t)s[0].qPos; refAlnLen = readAlnLen + 20;
+    if (readAlnLen > 0) {
+        if ((int64_t)s[0].tPos - refAlnLen >= (int64_t)chrBeg) {
+            refAlnStart = s[0].tPos - (uint32_t)refAlnLen;
+            edres_t r = need_edlib(&W, 1, 0, (uint32_t)readAlnLen, (uint32_t)readAlnLen, 1, refAlnStart, (uint32_t)refAlnLen, (uint32_t)refAlnLen, 1);
+            int realigned = 0;
+            if (r.have && readAlnLen > CLIP_LEN && (1 - ((float)r.ed / readAlnLen)) < CLIP_SIM) {
+                if (!need_ksw(&W, 0, 1, 0, (uint32_t)readAlnLen, 1, refAlnStart, (uint32_t)refAlnLen, &qle, &tle)) goto bail;
+                if (qle > 0 && qle < readAlnLen) {
+                    edres_t r2 = need_edlib(&W, 1, 0, (uint32_t)readAlnLen, (uint32_t)qle, 1, refAlnStart, (uint32_t)refAlnLen, (uint32_t)tle, 0);
+                    ops_front(&cg, &md, &r2, pac, refAlnStart, (uint32_t)refAlnLen);
+                    editScore -= r2.ed;
+                    tmp.pos = s[0].tPos - (uint32_t)r2.end - 1;
+                    tmp.qStart = s[0].qPos - (uint32_t)qle;
+                    tr_front_n(&cg, (size_t)(readAlnLen - qle), 'I'); tr_front_n(&md, (size_t)(readAlnLen - qle), '-');
+                    realigned = 1;
+                }
+            }
+            if (!realigned) {
+                editScore -= r.ed;
+                ops_front(&cg, &md, &r, pac, refAlnStart, (uint32_t)refAlnLen);
+                tmp.pos = s[0].tPos - (uint32_t)r.end - 1;
+                tmp.qStart = 0;
+            }
+        } else { tr_front_n(&cg, (size_t)readAlnLen, 'I'); tr_front_n(&md, (size_t)readAlnLen, '-'); }
+    }
+
+    /* ---- between adjacent anchors (:1901-2137) ---- */
+    int numAnchorsSoFar = 1;
+    for (i = 0; i + 1 < chainLen; i++) {
+        tr_back_n(&cg, s[i].len, 'M'); tr_back_n(&md, s[i].len, '=');
+        readAlnStart = s[i].qPos + s[i].len; refAlnStart = s[i].tPos + s[i].len;
+        readAlnEnd = s[i + 1].qPos; refAlnEnd = s[i + 1].tPos;
+        readAlnLen = (int32_t)(readAlnEnd - readAlnStart); refAlnLen = (int32_t)(refAlnEnd - refAlnStart);
+        if (readAlnLen > 0 && refAlnLen > 0) {
+            edres_t r = need_edlib(&W, 0, readAlnStart, (uint32_t)readAlnLen, (uint32_t)readAlnLen, 0, refAlnStart, (uint32_t)refAlnLen, (uint32_t)refAlnLen, 0);
+            int handled = 0;
+            if (r.have && abs(readAlnLen - refAlnLen) >= SPLIT_LEN && (1 - ((float)r.ed / readAlnLen)) < SPLIT_SIM) {
+                /* split test: extension from both ends of the gap (:1967-1983) */
+                int q1, t1, q2, t2;
+                if (!need_ksw(&W, 1, 0, readAlnStart, (uint32_t)readAlnLen, 0, refAlnStart, (uint32_t)refAlnLen, &q1, &t1)) goto bail;
+                if (!need_ksw(&W, 1, 1, readAlnStart, (uint32_t)readAlnLen, 1, refAlnStart, (uint32_t)refAlnLen, &q2, &t2)) goto bail;
+                const uint32_t rs_new = readAlnStart + (uint32_t)q1, ts_new = refAlnStart + (uint32_t)t1;
+                const uint32_t re_new = readAlnEnd - (uint32_t)q2, te_new = refAlnEnd - (uint32_t)t2;
+                const int32_t tl_new = (int32_t)(te_new - ts_new), rl_new = (int32_t)(re_new - rs_new);
+                if (rs_new < re_new || ts_new < te_new) {                                    /* :1995 */
+                    handled = 1;
+                    if (rs_new > readAlnStart || ts_new > refAlnStart) {                     /* first part :1998-2007 */
+                        edres_t a = need_edlib(&W, 0, readAlnStart, (uint32_t)readAlnLen, rs_new - readAlnStart, 0, refAlnStart, (uint32_t)refAlnLen, ts_new - refAlnStart, 0);
+                        ops_back(&cg, &md, &a, pac, 0, refAlnStart, (uint32_t)refAlnLen);
+                        editScore -= a.ed;
+                    }
+                    tr_back_n(&cg, (size_t)((uint32_t)readLen - rs_new), 'I'); tr_back_n(&md, (size_t)((uint32_t)readLen - rs_new), '-');
+                    tmp.posEnd = ts_new; tmp.qEnd = rs_new; tmp.nmCount = editScore;
+                    if (numAnchorsSoFar > 1) emit_sam(&W, map, &tmp, &cg, &md);
+                    tr_clear(&cg); tr_clear(&md); editScore = 0;
+                    if (rs_new < re_new && ts_new < te_new) {                                /* middle part :2033-2077 */
+                        edres_t f = need_edlib(&W, 0, rs_new, (uint32_t)rl_new, (uint32_t)rl_new, 0, ts_new, (uint32_t)tl_new, (uint32_t)tl_new, 0);
+                        edres_t v = need_edlib(&W, 1, rs_new, (uint32_t)rl_new, (uint32_t)rl_new, 0, ts_new, (uint32_t)tl_new, (uint32_t)tl_new, 0);
+                        if (f.have && v.have && (1 - ((double)v.ed / rl_new)) > (1 - ((double)f.ed / rl_new)) && (1 - ((double)v.ed / rl_new)) > REVERSE_SIM) {
+                            tmp.flag = isRev ? 0 : 16;
+                            tmp.pos = ts_new; tmp.qStart = rs_new; tmp.posEnd = te_new; tmp.qEnd = re_new;
+                            tr_back_n(&cg, rs_new, 'I'); tr_back_n(&md, rs_new, '-');
+                            ops_back(&cg, &md, &v, pac, 0, ts_new, (uint32_t)tl_new);
+                            editScore -= v.ed;
+                            tr_back_n(&cg, (size_t)((uint32_t)readLen - re_new), 'I');
+                            tr_front_n(&md, (size_t)((uint32_t)readLen - re_new), '-');           /* sic :2057 (App. B #3) */
+                            tmp.nmCount = editScore;
+                            emit_sam(&W, map, &tmp, &cg, &md);
+                            tr_clear(&cg); tr_clear(&md); editScore = 0;
+                        }
+                    }
+                    if (re_new < readAlnEnd || te_new < refAlnEnd) {                          /* second part :2079-2090 */
+                        edres_t b = need_edlib(&W, 1, readAlnStart, (uint32_t)readAlnLen, readAlnEnd - re_new, 1, refAlnStart, (uint32_t)refAlnLen, refAlnEnd - te_new, 0);
+                        ops_front(&cg, &md, &b, pac, refAlnStart, (uint32_t)refAlnLen);
+                        editScore -= b.ed;
+                    }
+                    tr_front_n(&cg, re_new, 'I'); tr_front_n(&md, re_new, '-');
+                    tmp.flag = isRev ? 16 : 0; tmp.pos = te_new; tmp.qStart = re_new;
+                    numAnchorsSoFar = 0;
+                }
+            }
+            if (!handled) { editScore -= r.ed; ops_back(&cg, &md, &r, pac, 0, refAlnStart, (uint32_t)refAlnLen); }
+        } else if (readAlnLen > 0) {
+            tr_back_n(&cg, (size_t)readAlnLen, 'I'); tr_back_n(&md, (size_t)readAlnLen, '-');
+            editScore -= readAlnLen;
+        } else {
+            if (refAlnLen > 0) {
+                tr_back_n(&cg, (size_t)refAlnLen, 'D');
+                tr_room(&md, 0, (size_t)refAlnLen);
+                for (int32_t j = 0; j < refAlnLen; j++) md.buf[md.end++] = "ACGT"[pac_base(pac, refAlnStart + (uint32_t)j)];
+            }
+            editScore -= refAlnLen;
+        }
+        numAnchorsSoFar++;
+    }
+
+    /* ---- last anchor and the tail (:2149-2230) ---- */
+    tr_back_n(&cg, s[i].len, 'M'); tr_back_n(&md, s[i].len, '=');
+    tmp.posEnd = s[i].tPos + s[i].len - 1; tmp.qEnd = s[i].qPos + s[i].len - 1;
+    readAlnStart = s[i].qPos + s[i].len;
+    readAlnLen = readLen - (int32_t)readAlnStart; refAlnLen = readAlnLen + 20;
+    if (readAlnLen > 0) {
+        if (s[i].tPos + s[i].len + (uint32_t)refAlnLen - 1 <= chrEnd) {
+            refAlnStart = s[i].tPos + s[i].len;
+            edres_t r = need_edlib(&W, 0, readAlnStart, (uint32_t)readAlnLen, (uint32_t)readAlnLen, 0, refAlnStart, (uint32_t)refAlnLen, (uint32_t)refAlnLen, 1);
+            int realigned = 0;
+            if (r.have && readAlnLen > CLIP_LEN && (1 - ((float)r.ed / readAlnLen)) < CLIP_SIM) {
+                if (!need_ksw(&W, 0, 0, readAlnStart, (uint32_t)readAlnLen, 0, refAlnStart, (uint32_t)refAlnLen, &qle, &tle)) goto bail;
+                if (qle > 0 && qle < readAlnLen) {
+                    edres_t r2 = need_edlib(&W, 0, readAlnStart, (uint32_t)readAlnLen, (uint32_t)qle, 0, refAlnStart, (uint32_t)refAlnLen, (uint32_t)tle, 0);
+                    ops_back(&cg, &md, &r2, pac, 0, refAlnStart, (uint32_t)refAlnLen);
+                    editScore -= r2.ed;
+                    tmp.posEnd = refAlnStart + (uint32_t)r2.end;
+                    tmp.qEnd = readAlnStart + (uint32_t)qle;
+                    tr_back_n(&cg, (size_t)(readAlnLen - qle), 'I'); tr_back_n(&md, (size_t)(readAlnLen - qle), '-');
+                    realigned = 1;
+                }
+            }
+            if (!realigned) {
+                editScore -= r.ed;
+                ops_back(&cg, &md, &r, pac, 0, refAlnStart, (uint32_t)refAlnLen);
+                tmp.posEnd = refAlnStart + (uint32_t)r.end;
+                tmp.qEnd = (uint32_t)readLen;
+            }
+        } else { tr_back_n(&cg, (size_t)readAlnLen, 'I'); tr_back_n(&md, (size_t)readAlnLen, '-'); }
+    }
+    tmp.nmCount = editScore;
+    emit_sam(&W, map, &tmp, &cg, &md);
+bail:
+    free(cg.buf); free(md.buf);
+    job->complete = (W.missing == 0 && !W.bail);
+    if (!job->complete) samlist_clear(map);
+    return job->complete;
+}
+
+/* alignWin's scoring tail (src/LordFAST.cpp:1063-1090,1148-1175) */
+static void score_mapping(const lf_params_t *p, samlist_t *map, int isReverse, uint32_t rLen, uint32_t chainLen)
+{
+    if (chainLen > 1) {
+        map->totalScore = 0;
+        for (int i = 0; i < map->n; i++) {
+            map->v[i].alnScore = (int32_t)((uint32_t)map->v[i].nmCount + (map->v[i].qEnd - map->v[i].qStart));
+            map->totalScore += map->v[i].nmCount;
+        }
+        const double gp = isReverse ? p->gap_penalty : 0.15;                                  /* :1077 vs :1162 */
+        for (int i = 0; i + 1 < map->n; i++) {
+            int64_t a = (int64_t)map->v[i + 1].pos - (int64_t)map->v[i].posEnd, b = (int64_t)map->v[i + 1].qStart - (int64_t)map->v[i].qEnd;
+            uint32_t diff = (uint32_t)((a < 0 ? -a : a) + (b < 0 ? -b : b));
+            map->totalScore = (int32_t)((double)map->totalScore - gp * (double)diff);
+        }
+        map->totalScore = (int32_t)((uint32_t)map->totalScore - map->v[0].qStart);
+        map->totalScore = (int32_t)((uint32_t)map->totalScore - (rLen - map->v[map->n - 1].qEnd));
+    } else map->totalScore = (int32_t)((uint32_t)-2 * rLen);
+}
+
+/* ================================================================ E: printSamEntry (src/LordFAST.cpp:318-459) */
+static void intv_info(const struct lf_index *ix, uint32_t pos, uint32_t posEnd, const char **name, uint32_t *cbeg)
+{
+    int rid = pos2rid(ix, (int64_t)(((uint64_t)pos + (uint64_t)posEnd) >> 1));
+    *cbeg = (uint32_t)((uint64_t)pos - (uint64_t)ix->contigs[rid].offset);
+    *name = ix->contigs[rid].name;
+}
+
+static void sam_line(str_t *o, const ctx_t *cx, const rd_t *r, const sam_t *s, int flag, const char *rname, uint32_t rstart, int mapq)
+{
+    str_puts(o, r->name); str_putc(o, '\t'); str_puti(o, flag); str_putc(o, '\t'); str_puts(o, rname); str_putc(o, '\t');
+    str_putu(o, rstart + 1); str_putc(o, '\t'); str_puti(o, mapq >= 0 ? mapq : 0); str_putc(o, '\t');
+    str_puts(o, s->cigar); str_puts(o, "\t*\t0\t0\t");
+    if (s->flag & 16) { str_putn(o, r->seq_rev, r->len); str_putc(o, '\t'); str_puts(o, r->qual_rev); }
+    else { str_putn(o, r->seq, r->len); str_putc(o, '\t'); str_puts(o, r->qual); }
+    str_puts(o, "\tAS:i:"); str_puti(o, s->alnScore); str_puts(o, "\tXS:i:0\tNM:i:"); str_puti(o, abs(s->nmCount));
+    str_puts(o, "\tMD:Z:"); str_puts(o, s->md);
+    if (cx->p->read_group_id[0]) { str_puts(o, "\tRG:Z:"); str_puts(o, cx->p->read_group_id); }
+}
+
+static void print_sam_entry(ctx_t *cx, rd_t *r, int num)
+{
+    str_t *o = &r->out;
+    const samlist_t *mp = r->maps;
+    const int readLen = (int)r->len, maxWin = cx->p->max_map;
+    const double bestEdit = (num > 0 ? (double)(-1 * mp[0].totalScore) / readLen : 1);
+    const double mapqPortion = 50.0 / (maxWin - 1);
+    int x1 = 0, x2 = 0;
+    for (int i = 0; i < num; i++) if (mp[i].n > 0) { x1++; if ((double)(-1 * mp[i].totalScore) / readLen * 0.95 < bestEdit) x2++; }
+    const double mapq = (x2 > 1 ? 2.1 : (maxWin - x1) * mapqPortion);
+    int32_t mapq_int;
+    for (int i = 0; i < num; i++) {
+        if (i == 0) {
+            if (mp[0].n > 0) {
+                const double e0 = (double)(-1 * mp[0].totalScore) / readLen;
+                if (num == 1 || (num > 1 && e0 < 0.15 && e0 < 0.95 * (double)(-1 * mp[1].totalScore) / readLen)) mapq_int = 60;
+                else mapq_int = (int32_t)(mapq + 5 * (0.2 - e0) / 0.2);
+                const int ns = mp[0].n;
+                str_t *sa = (str_t *)calloc((size_t)ns, sizeof(str_t));
+                const char **rn = (const char **)calloc((size_t)ns, sizeof(char *));
+                uint32_t *rs = (uint32_t *)calloc((size_t)ns, sizeof(uint32_t));
+                for (int j = 0; j < ns; j++) {
+                    const sam_t *s = &mp[0].v[j];
+                    intv_info(cx->ix, s->pos, s->posEnd, &rn[j], &rs[j]);
+                    if (ns > 1) {
+                        str_init(&sa[j]);
+                        str_puts(&sa[j], rn[j]); str_putc(&sa[j], ','); str_putu(&sa[j], rs[j] + 1); str_putc(&sa[j], ',');
+                        str_puts(&sa[j], (s->flag & 16) ? "-," : "+,"); str_puts(&sa[j], s->cigar); str_putc(&sa[j], ',');
+                        str_puti(&sa[j], mapq_int); str_putc(&sa[j], ','); str_puti(&sa[j], abs(s->nmCount)); str_putc(&sa[j], ';');
+                    }
+                }
+                for (int j = 0; j < ns; j++) {
+                    const sam_t *s = &mp[0].v[j];
+                    sam_line(o, cx, r, s, j > 0 ? (s->flag | 2048) : s->flag, rn[j], rs[j], mapq_int);
+                    if (ns > 1) { str_puts(o, "\tSA:Z:"); for (int z = 0; z < ns; z++) if (z != j) str_putn(o, sa[z].s, sa[z].n); }
+                    str_putc(o, '\n');
+                }
+                if (ns > 1) for (int j = 0; j < ns; j++) free(sa[j].s);
+                free(sa); free(rn); free(rs);
+            } else {
+                str_puts(o, r->name); str_puts(o, "\t4\t*\t0\t0\t*\t*\t0\t0\t"); str_putn(o, r->seq, r->len); str_putc(o, '\t'); str_puts(o, r->qual);
+                if (cx->p->read_group_id[0]) { str_puts(o, "\tRG:Z:"); str_puts(o, cx->p->read_group_id); }
+                str_putc(o, '\n');
+            }
+        } else if (mp[i].n > 0) {
+            mapq_int = (int32_t)(mapq + 5 * (0.2 - (double)(-1 * mp[i].totalScore) / readLen) / 0.2);
+            for (int j = 0; j < mp[i].n; j++) {
+                const sam_t *s = &mp[i].v[j];
+                const char *rn; uint32_t rs;
+                intv_info(cx->ix, s->pos, s->posEnd, &rn, &rs);
+                sam_line(o, cx, r, s, s->flag | 256, rn, rs, mapq_int);
+                str_putc(o, '\n');
+            }
+        }
+    }
+}
+
+/* ================================================================ phases driven by lf_map_batch */
+static void phase_prepare(ctx_t *cx, int tid, int ri)
+{
+    (void)tid;
+    rd_t *r = &cx->reads[ri];
+    str_init(&r->out);
+    if ((int)r->len < cx->p->min_read_len) return;
+    r->seq_rev = (char *)malloc((size_t)r->len + 1);
+    revcomp_into(r->seq, r->seq_rev, r->len);                          /* reverseComplement :501 */
+    const uint32_t ql = r->isFq ? r->len : 1;
+    r->qual_rev = (char *)malloc((size_t)ql + 1);
+    for (uint32_t i = 0; i < ql; i++) r->qual_rev[i] = r->qual[ql - 1 - i];   /* reverse :502 */
+    r->qual_rev[ql] = 0;
+}
+
+static void phase_make_jobs(ctx_t *cx, int tid, int ri)
+{
+    (void)tid;
+    rd_t *r = &cx->reads[ri];
+    if (r->mode < 2) return;
+    r->jobs = (job_t *)calloc((size_t)r->nWins + 1, sizeof(job_t));
+    r->maps = (samlist_t *)calloc((size_t)cx->p->max_map + 1, sizeof(samlist_t));
+    for (int w = 0; w < r->nWins; w++) {
+        job_t *j = &r->jobs[w];
+        const int rq = r->wins[w].req;
+        j->read = ri; j->widx = w; j->isRev = r->wins[w].isReverse;
+        j->chainLen = cx->chain_len[rq];
+        j->chain = (Seed_t *)malloc(((size_t)j->chainLen + 1) * sizeof(Seed_t));
+        const creq_t *cq = &cx->creq[rq];
+        for (uint32_t k = 0; k < j->chainLen; k++) j->chain[k] = cx->cseeds[cq->off + cx->chain_idx[cq->off + k]];
+        j->complete = (j->chainLen <= 1);                   /* nothing to extend: totalScore = -2L (:1089) */
+    }
+}
+
+static void phase_walk(ctx_t *cx, int tid, int ri)
+{
+    rd_t *r = &cx->reads[ri];
+    if (r->mode < 2) return;
+    for (int w = 0; w < r->nWins; w++) {
+        job_t *j = &r->jobs[w];
+        if (j->complete) continue;
+        walk_chain(cx, tid, j, &r->maps[w]);
+    }
+}
+
+static void phase_sam(ctx_t *cx, int tid, int ri)
+{
+    (void)tid;
+    rd_t *r = &cx->reads[ri];
+    if (r->mode < 2) {
+        r->maps = (samlist_t *)calloc(2, sizeof(samlist_t));
+        print_sam_entry(cx, r, 1);
+        return;
+    }
+    for (int w = 0; w < r->nWins; w++) score_mapping(cx->p, &r->maps[w], r->wins[w].isReverse, r->len, r->jobs[w].chainLen);
+    if (r->mode == 3) samsort_sort(r->maps, r->nWins);                     /* std::sort(compareSam) :565 */
+    print_sam_entry(cx, r, r->mode == 2 ? 1 : r->nWins);
+}
+
+/* ---------------------------------------------------------------- one chunk of reads through all stages */
+static int map_chunk(ctx_t *cx)
+{
+    const int n = cx->n_reads, nt = cx->n_threads;
+    lf_stats_t *st = cx->st;
+    int rc = LF_OK;
+    double t0 = now_ms(), t1;
+
+    parallel_for(cx, n, phase_prepare);
+
+    /* ---- A: seeds ---- */
+    {
+        int *map = (int *)malloc((size_t)n * sizeof(int)); int m = 0;
+        uint64_t bases = 0;
+        for (int i = 0; i < n; i++) if ((int)cx->reads[i].len >= cx->p->min_read_len) { map[m++] = i; bases += cx->reads[i].len; }
+        if (m) {
+            char *cat = (char *)malloc(bases + 1); uint64_t *off = (uint64_t *)malloc(((size_t)m + 1) * 8);
+            uint64_t o = 0;
+            for (int k = 0; k < m; k++) { off[k] = o; memcpy(cat + o, cx->reads[map[k]].seq, cx->reads[map[k]].len); o += cx->reads[map[k]].len; }
+            off[m] = o;
+            lfg_hits_t h;
+            rc = lfg_seed(cx->ix, cx->p, m, cat, off, &h);
+            free(cat); free(off);
+            if (rc != LF_OK) { free(map); return rc; }
+            for (int k = 0; k < m; k++) {
+                rd_t *r = &cx->reads[map[k]];
+                const uint64_t a = h.read_off[k], b = h.read_off[k + 1];
+                uint32_t nr = 0;
+                for (uint64_t j = a; j < b; j++) nr += h.strand[j];
+                r->nR = nr; r->nF = (uint32_t)(b - a) - nr;
+                r->F = (Seed_t *)malloc(((size_t)r->nF + 1) * sizeof(Seed_t)); r->R = (Seed_t *)malloc(((size_t)r->nR + 1) * sizeof(Seed_t));
+                uint32_t f = 0, v = 0;
+                for (uint64_t j = a; j < b; j++) {
+                    Seed_t sd; sd.tPos = h.tpos[j]; sd.qPos = h.qpl[j] & 0xFFFFF; sd.len = h.qpl[j] >> 20;
+                    if (h.strand[j]) r->R[v++] = sd; else r->F[f++] = sd;
+                }
+            }
+            st->n_seeds += h.n_hits; st->n_cache += h.counters[0]; st->n_occblk += h.counters[1]; st->n_sa += h.counters[2]; st->n_readbytes += h.counters[3];
+            st->ms_k_search += h.ms_search; st->ms_k_accept += h.ms_accept; st->ms_k_locate += h.ms_locate;
+            st->search_launches++; st->locate_launches++;
+            lfg_hits_free(&h);
+        }
+        free(map);
+    }
+    t1 = now_ms(); st->ms_seed += t1 - t0; t0 = t1;
+
+    /* ---- B: vote + chain requests ---- */
+    g_cstage = (cstage_t *)calloc((size_t)nt, sizeof(cstage_t));
+    parallel_for(cx, n, phase_vote);
+    {   /* merge the per-worker chain requests; rebase request ids */
+        int total = 0; uint64_t seeds = 0;
+        int *base = (int *)malloc((size_t)nt * sizeof(int)); uint64_t *sbase = (uint64_t *)malloc((size_t)nt * 8);
+        for (int t = 0; t < nt; t++) { base[t] = total; sbase[t] = seeds; total += g_cstage[t].n; seeds += g_cstage[t].ns; }
+        cx->n_creq = total; cx->n_cseeds = seeds;
+        cx->creq = (creq_t *)malloc(((size_t)total + 1) * sizeof(creq_t));
+        cx->cseeds = (Seed_t *)malloc((seeds + 1) * sizeof(Seed_t));
+        for (int t = 0; t < nt; t++) {
+            memcpy(cx->cseeds + sbase[t], g_cstage[t].s, g_cstage[t].ns * sizeof(Seed_t));
+            for (int k = 0; k < g_cstage[t].n; k++) { creq_t q = g_cstage[t].v[k]; q.off += sbase[t]; cx->creq[base[t] + k] = q; }
+        }
+        /* request ids handed out during the vote were worker-local: rebase them */
+        for (int i = 0; i < n; i++) {
+            rd_t *r = &cx->reads[i];
+            if (r->mode == 2) r->wins[0].req += base[r->vote_tid];
+            else if (r->mode == 3) for (int c = 0; c < r->ncand; c++) r->cands[c].req += base[r->vote_tid];
+        }
+        free(base); free(sbase);
+        for (int t = 0; t < nt; t++) { free(g_cstage[t].v); free(g_cstage[t].s); free(g_cstage[t].wbuf); free(g_cstage[t].wbuf2); }
+        free(g_cstage); g_cstage = NULL;
+    }
+    t1 = now_ms(); st->ms_vote += t1 - t0; t0 = t1;
+
+    /* ---- C: chains ---- */
+    {
+        uint64_t *off = (uint64_t *)malloc(((size_t)cx->n_creq + 1) * 8);
+        for (int g = 0; g < cx->n_creq; g++) off[g] = cx->creq[g].off;
+        off[cx->n_creq] = cx->n_cseeds;
+        cx->chain_idx = (uint32_t *)malloc((cx->n_cseeds + 1) * 4);
+        cx->chain_len = (uint32_t *)calloc((size_t)cx->n_creq + 1, 4);
+        cx->chain_score = (float *)calloc((size_t)cx->n_creq + 1, 4);
+        float ms = 0;
+        rc = lfg_chain_n2(cx->ix->device, cx->p, cx->n_creq, cx->cseeds, off, cx->chain_idx, cx->chain_len, cx->chain_score, &ms);
+        free(off);
+        if (rc != LF_OK) return rc;
+        st->ms_k_chain += ms; st->n_chain_problems += (uint64_t)cx->n_creq;
+    }
+    parallel_for(cx, n, phase_fine_select);
+    parallel_for(cx, n, phase_make_jobs);
+    t1 = now_ms(); st->ms_chain += t1 - t0; t0 = t1;
+
+    /* ---- D: extension rounds ---- */
+    cx->stages = (stage_t *)calloc((size_t)nt, sizeof(stage_t));
+    g_ed_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
+    g_ksw_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
+    for (int round = 0; round < 64; round++) {
+        parallel_for(cx, n, phase_walk);
+        int ne = 0, nk = 0;
+        for (int t = 0; t < nt; t++) { ne += cx->stages[t].n; nk += cx->stages[t].kn; }
+        if (ne == 0 && nk == 0) break;
+        if (ne) {
+            uint64_t qn = 0, tn = 0;
+            for (int t = 0; t < nt; t++) { qn += cx->stages[t].qn; tn += cx->stages[t].tn; st->ext_bytes += cx->stages[t].ext_bytes; }
+            char *qb = (char *)malloc(qn + 1), *tb = (char *)malloc(tn + 1);
+            uint64_t *qoff = (uint64_t *)malloc(((size_t)ne + 1) * 8), *toff = (uint64_t *)malloc(((size_t)ne + 1) * 8);
+            uint8_t *mode = (uint8_t *)malloc((size_t)ne);
+            ed_round_t R; memset(&R, 0, sizeof R);
+            R.n = ne; R.ed = (int32_t *)malloc((size_t)ne * 4); R.end = (int32_t *)malloc((size_t)ne * 4);
+            R.ops_len = (uint32_t *)malloc((size_t)ne * 4); R.ops = (uint8_t *)malloc(qn + tn + 1); R.ops_off = (uint64_t *)malloc((size_t)ne * 8);
+            const int ridx = cx->n_ed_rounds;
+            int g = 0; uint64_t qo = 0, to = 0;
+            for (int t = 0; t < nt; t++) {
+                stage_t *s = &cx->stages[t];
+                memcpy(qb + qo, s->qb, s->qn); memcpy(tb + to, s->tb, s->tn);
+                for (int k = 0; k < s->n; k++, g++) {
+                    qoff[g] = qo + s->qoff[k]; toff[g] = to + s->toff[k]; mode[g] = s->mode[k];
+                    R.ops_off[g] = qoff[g] + toff[g];
+                    memo_t *m = &g_ed_jobs[t].job[k]->memo[(uintptr_t)s->owner[k]];
+                    m->round = ridx; m->slot = g;
+                }
+                qo += s->qn; to += s->tn;
+                s->n = 0; s->qn = 0; s->tn = 0; s->ext_bytes = 0; g_ed_jobs[t].n = 0;
+            }
+            qoff[ne] = qo; toff[ne] = to;
+            float ms = 0; uint64_t launches = 0;
+            rc = lf_edlib_solve(cx->ix->device, ne, qb, qoff, tb, toff, mode, R.ed, R.end, R.ops, R.ops_len, &ms, &launches);
+            free(qb); free(tb); free(qoff); free(toff); free(mode);
+            cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
+            cx->ed_rounds[cx->n_ed_rounds++] = R;
+            if (rc != LF_OK) return rc;
+            st->ms_k_edlib += ms; st->n_edlib_problems += (uint64_t)ne; st->edlib_launches += launches;
+        }
+        if (nk) {
+            uint64_t qn = 0, tn = 0;
+            for (int t = 0; t < nt; t++) { qn += cx->stages[t].kqn; tn += cx->stages[t].ktn; }
+            uint8_t *qb = (uint8_t *)malloc(qn + 1), *tb = (uint8_t *)malloc(tn + 1);
+            uint64_t *qoff = (uint64_t *)malloc(((size_t)nk + 1) * 8), *toff = (uint64_t *)malloc(((size_t)nk + 1) * 8);
+            int32_t *prm = (int32_t *)malloc((size_t)nk * 7 * 4);
+            ksw_round_t R; memset(&R, 0, sizeof R);
+            R.n = nk; R.score = (int32_t *)malloc((size_t)nk * 4); R.qle = (int32_t *)malloc((size_t)nk * 4); R.tle = (int32_t *)malloc((size_t)nk * 4);
+            const int ridx = cx->n_ksw_rounds;
+            int g = 0; uint64_t qo = 0, to = 0;
+            for (int t = 0; t < nt; t++) {
+                stage_t *s = &cx->stages[t];
+                memcpy(qb + qo, s->kq, s->kqn); memcpy(tb + to, s->kt, s->ktn);
+                for (int k = 0; k < s->kn; k++, g++) {
+                    qoff[g] = qo + s->kqoff[k]; toff[g] = to + s->ktoff[k];
+                    memcpy(prm + 7 * g, s->kprm + 7 * k, 28);
+                    memo_t *m = &g_ksw_jobs[t].job[k]->memo[(uintptr_t)s->kowner[k]];
+                    m->round = ridx; m->slot = g;
+                }
+                qo += s->kqn; to += s->ktn;
+                s->kn = 0; s->kqn = 0; s->ktn = 0; g_ksw_jobs[t].n = 0;
+            }
+            qoff[nk] = qo; toff[nk] = to;
+            float ms = 0;
+            rc = lfg_ksw(cx->ix->device, nk, qb, qoff, tb, toff, prm, R.score, R.qle, R.tle, &ms);
+            free(qb); free(tb); free(qoff); free(toff); free(prm);
+            cx->ksw_rounds = (ksw_round_t *)realloc(cx->ksw_rounds, ((size_t)cx->n_ksw_rounds + 1) * sizeof(ksw_round_t));
+            cx->ksw_rounds[cx->n_ksw_rounds++] = R;
+            if (rc != LF_OK) return rc;
+            st->ms_k_ksw += ms; st->n_ksw_problems += (uint64_t)nk;
+        }
+    }
+    t1 = now_ms(); st->ms_extend += t1 - t0; t0 = t1;
+
+    /* ---- E: SAM ---- */
+    parallel_for(cx, n, phase_sam);
+    t1 = now_ms(); st->ms_sam += t1 - t0;
+    return LF_OK;
+}
+
+static void chunk_free(ctx_t *cx)
+{
+    for (int i = 0; i < cx->n_reads; i++) {
+        rd_t *r = &cx->reads[i];
+        free(r->seq_rev); free(r->qual_rev); free(r->F); free(r->R); free(r->cands); free(r->wins);
+        if (r->jobs) { for (int w = 0; w < r->nWins; w++) { free(r->jobs[w].chain); free(r->jobs[w].memo); } free(r->jobs); }
+        if (r->maps) { for (int w = 0; w <= cx->p->max_map && (r->mode >= 2 || w < 2); w++) { samlist_clear(&r->maps[w]); free(r->maps[w].v); } free(r->maps); }
+    }
+    free(cx->creq); free(cx->cseeds); free(cx->chain_idx); free(cx->chain_len); free(cx->chain_score);
+    for (int k = 0; k < cx->n_ed_rounds; k++) { ed_round_t *R = &cx->ed_rounds[k]; free(R->ed); free(R->end); free(R->ops_len); free(R->ops); free(R->ops_off); }
+    for (int k = 0; k < cx->n_ksw_rounds; k++) { ksw_round_t *R = &cx->ksw_rounds[k]; free(R->score); free(R->qle); free(R->tle); }
+    free(cx->ed_rounds); free(cx->ksw_rounds);
+    if (cx->stages) {
+        for (int t = 0; t < cx->n_threads; t++) {
+            stage_t *s = &cx->stages[t];
+            free(s->qb); free(s->tb); free(s->qoff); free(s->toff); free(s->mode); free(s->owner);
+            free(s->kq); free(s->kt); free(s->kqoff); free(s->ktoff); free(s->kprm); free(s->kowner);
+            free(g_ed_jobs[t].job); free(g_ksw_jobs[t].job);
+        }
+        free(cx->stages); free(g_ed_jobs); free(g_ksw_jobs); g_ed_jobs = g_ksw_jobs = NULL;
+    }
+    cx->creq = NULL; cx->cseeds = NULL; cx->chain_idx = NULL; cx->chain_len = NULL; cx->chain_score = NULL;
+    cx->ed_rounds = NULL; cx->ksw_rounds = NULL; cx->n_ed_rounds = cx->n_ksw_rounds = 0; cx->stages = NULL;
+}
+
+static pthread_mutex_t g_map_lock = PTHREAD_MUTEX_INITIALIZER;     /* worker-stage globals: one batch at a time */
+
+int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *const *names,
+                 const char *const *seqs, const char *const *quals, char **sam, size_t *sam_len, lf_stats_t *stats)
+{
+    if (!ix || !p || n < 0 || !sam) { lf_set_error("lf_map_batch: bad argument"); return LF_ERR_ARG; }
+    if (p->chain_alg != 0) { lf_set_error("lf_map_batch: --chainAlg clasp is not implemented on the GPU path yet"); return LF_ERR_ARG; }
+    if (p->min_anchor_len < 12 || p->min_anchor_len > 20 || p->sampling_count <= 0 || p->max_map < 2 || p->max_ref_hits <= 0 || p->min_read_len < 100) {
+        lf_set_error("lf_map_batch: option out of range (k in [12,20], c > 0, n >= 2, m > 0, l >= 100)"); return LF_ERR_ARG;
+    }
+    lf_stats_t local; memset(&local, 0, sizeof local);
+    lf_stats_t *st = stats ? stats : &local;
+    memset(st, 0, sizeof *st);
+    int nt = p->threads;
+    long online = sysconf(_SC_NPROCESSORS_ONLN);
+    if (nt <= 0 || nt > online) nt = (int)online;                      /* src/CommandLineParser.cpp:181-185 */
+    if (nt > 255) nt = 255;
+    if (nt < 1) nt = 1;
+    const double T0 = now_ms();
+    pthread_mutex_lock(&g_map_lock);
+
+    str_t all; str_init(&all);
+    int rc = LF_OK;
+    /* chunks bound the device + host working set; reads stay in input order */
+    const uint64_t CHUNK_BASES = 400ull << 20; const int CHUNK_READS = 32768;
+    int i0 = 0;
+    while (i0 < n && rc == LF_OK) {
+        int i1 = i0; uint64_t bases = 0;
+        while (i1 < n && i1 - i0 < CHUNK_READS && bases < CHUNK_BASES) { bases += strlen(seqs[i1]); i1++; }
+        ctx_t cx; memset(&cx, 0, sizeof cx);
+        cx.ix = ix; cx.p = p; cx.n_threads = nt; cx.st = st;
+        cx.n_reads = i1 - i0;
+        cx.reads = (rd_t *)calloc((size_t)cx.n_reads, sizeof(rd_t));
+        for (int i = i0; i < i1; i++) {
+            rd_t *r = &cx.reads[i - i0];
+            r->name = names[i]; r->seq = seqs[i]; r->len = (uint32_t)strlen(seqs[i]);
+            r->isFq = (quals && quals[i] && quals[i][0]);
+            r->qual = r->isFq ? quals[i] : "*";
+            st->n_bases += r->len;
+        }
+        st->n_reads += (uint64_t)cx.n_reads;
+        rc = map_chunk(&cx);
+        if (rc == LF_OK) for (int i = 0; i < cx.n_reads; i++) str_putn(&all, cx.reads[i].out.s, cx.reads[i].out.n);
+        for (int i = 0; i < cx.n_reads; i++) free(cx.reads[i].out.s);
+        chunk_free(&cx);
+        free(cx.reads);
+        i0 = i1;
+    }
+    pthread_mutex_unlock(&g_map_lock);
+    st->ms_total = now_ms() - T0;
+    if (rc != LF_OK) { free(all.s); return rc; }
+    *sam = all.s;
+    if (sam_len) *sam_len = all.n;
+    return LF_OK;
+}
+
+/* printSamHeader (src/BWT.cpp:668-681) */
+char *lf_sam_header(const lf_index_t *ix, const lf_params_t *p, const char *cmdline)
+{
+    (void)p;
+    str_t sb; str_init(&sb);
+    str_puts(&sb, "@HD\tVN:1.5\tSO:unsorted\n");
+    for (int i = 0; i < ix->n_seqs; i++) { str_puts(&sb, "@SQ\tSN:"); str_puts(&sb, ix->contigs[i].name); str_puts(&sb, "\tLN:"); str_puti(&sb, ix->contigs[i].len); str_putc(&sb, '\n'); }
+    str_puts(&sb, "@PG\tID:lordfast\tPN:lordfast\tVN:0.0.10\tCL:"); str_puts(&sb, cmdline ? cmdline : ""); str_putc(&sb, '\n');
+    return sb.s;
+}

@@ -1,0 +1,104 @@
+"""GPU parity, whole path: lf_map_batch (HIP kernels + host glue, through the C ABI) must print the very
+SAM records the reference prints (golden vectors), and the oracle's on larger seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CONFIGS, golden_sam
+from lordfast_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lf(golden_dir):
+    import lordfast_amd as la
+    h = la.LordFast(os.path.join(golden_dir, "genome.fa"), device=0, full_sa=True)
+    yield h
+    h.close()
+
+
+def first_diff(a: bytes, b: bytes) -> str:
+    la_, lb = a.split(b"\n"), b.split(b"\n")
+    for i, (x, y) in enumerate(zip(la_, lb)):
+        if x != y:
+            fx, fy = x.split(b"\t"), y.split(b"\t")
+            for j, (u, v) in enumerate(zip(fx, fy)):
+                if u != v:
+                    return f"line {i} ({fx[0].decode()}) field {j}: {u[:80]!r} != {v[:80]!r}"
+            return f"line {i}: field count {len(fx)} vs {len(fy)}"
+    return f"line count {len(la_)} vs {len(lb)}"
+
+
+@pytest.mark.parametrize("cfg", list(GOLDEN_CONFIGS))
+def test_sam_golden(lf, golden_reads, cfg):
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    sam, st = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
+    exp = golden_sam(cfg)
+    assert sam == exp, first_diff(sam, exp)
+    assert st["n_reads"] == len(seqs) and st["n_edlib_problems"] > 0 and st["n_chain_problems"] > 0
+    assert st["n_ksw_problems"] > 0, "fixture must reach the ksw clip/split branch"
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_sam_thread_counts(lf, golden_reads, threads):
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    sam, _ = lf.map_batch(names, seqs, params=la.default_params(threads=threads))
+    assert sam == golden_sam("default")
+
+
+def test_sam_fastq_and_readgroup(lf, oracle, oracle_lib, golden_reads):
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    names, seqs = names[:30], seqs[:30]
+    rng = np.random.default_rng(5)
+    quals = [bytes(rng.integers(35, 74, size=len(s)).astype(np.uint8)) for s in seqs]
+    sam, _ = lf.map_batch(names, seqs, quals, params=la.default_params(read_group_id=b"grp1"))
+    exp = oracle.map_batch(names, seqs, quals, params=oracle_lib.default_params(read_group_id=b"grp1"))
+    assert sam == exp, first_diff(sam, exp)
+
+
+def test_empty_and_tiny(lf, oracle):
+    sam, _ = lf.map_batch([], [])
+    assert sam == b""
+    names = [b"a", b"b"]
+    seqs = [b"ACGT", b"N" * 1500]
+    sam, _ = lf.map_batch(names, seqs)
+    assert sam == oracle.map_batch(names, seqs)
+
+
+@pytest.fixture(scope="module")
+def big_case(tmp_path_factory, oracle_lib):
+    """1.2 Mbp genome with repeat families; index built by the compiled reference (checker side)"""
+    from conftest import have_ref
+    if not have_ref():
+        pytest.skip("needs oracle/_ref/liblfref.so to build an index")
+    d = tmp_path_factory.mktemp("g1m")
+    g = synth.make_genome(1200000, 4, seed=31, n_families=60, repeat_frac=0.12)
+    dup = synth.add_duplications(g, 15000, 4, 0.02)
+    fa = os.path.join(str(d), "g.fa")
+    synth.write_fasta(fa, g)
+    ref = oracle_lib.Ref()
+    ref.index_build(fa)
+    os.remove(fa + ".cache")
+    reads = synth.special_reads(g, dup, seed=9) + synth.make_reads(g, 300, 6000, 0.15, seed=10) \
+        + synth.make_reads(g, 60, 12000, 0.15, seed=11) + synth.make_reads(g, 40, 3000, 0.10, seed=12, mix=(0.40, 0.25, 0.35))
+    return fa, reads
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(max_map=30), dict(min_anchor_len=17, sampling_count=2000)])
+def test_sam_vs_oracle_big(big_case, oracle_lib, kw):
+    import lordfast_amd as la
+    fa, reads = big_case
+    names = [r[0] for r in reads]
+    seqs = [r[1] for r in reads]
+    h = la.LordFast(fa, device=0)
+    sam, st = h.map_batch(names, seqs, params=la.default_params(**kw))
+    h.close()
+    orc = oracle_lib.Oracle(fa)
+    exp = orc.map_batch(names, seqs, params=oracle_lib.default_params(threads=8, **kw))
+    orc.close()
+    assert sam == exp, first_diff(sam, exp)
