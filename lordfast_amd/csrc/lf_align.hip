@@ -230,6 +230,117 @@ lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, cons
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * wave kernel: ONE WAVEFRONT PER PROBLEM for long queries (n > 512) and for the Hirschberg column requests.
+ * Lane l owns KB consecutive 64-row blocks; the 64 lanes sweep the DP matrix as an anti-diagonal wavefront:
+ * at step s lane l computes column s - l + 1, taking the horizontal carry (hout) that lane l-1 produced
+ * one step earlier through a lane shuffle.  m + lanes - 1 steps instead of m * blocks dependent ones.
+ * State lives in registers; history layout = the generic kernel's (private, (c-1)*nbk + block).
+ * ---------------------------------------------------------------------------------------------- */
+template <int KB>
+__global__ void __launch_bounds__(64)
+lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, const unsigned char *__restrict__ qs,
+                     const unsigned char *__restrict__ ts, lf_hist_t *__restrict__ hist,
+                     uint8_t *__restrict__ ops, int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end,
+                     uint32_t *__restrict__ out_len, int32_t *__restrict__ out_cols, const uint64_t *__restrict__ cols_off)
+{
+    if ((int)blockIdx.x >= n_probs) return;
+    const int lane = threadIdx.x;
+    const lf_aln_prob pr = probs[blockIdx.x];
+    const unsigned char *q = qs + pr.qoff, *t = ts + pr.toff;
+    const uint32_t n = pr.n, m = pr.m;
+    const bool rev = pr.rev != 0;
+    const uint32_t nbk = (n + 63) >> 6;
+    const int nl = (int)((nbk + KB - 1) / KB);            /* lanes that own at least one block */
+    uint64_t lo[KB], hi[KB], valid[KB], Pv[KB], Mv[KB];
+#pragma unroll
+    for (int k = 0; k < KB; k++) {
+        lo[k] = hi[k] = valid[k] = 0; Pv[k] = ~0ull; Mv[k] = 0;
+        const uint32_t b = (uint32_t)lane * KB + k;
+        if (b < nbk) for (int i = 0; i < 64; i++) { const uint32_t r = b * 64 + i; if (r < n) lf_plane_add(q[rev ? n - 1 - r : r], i, lo[k], hi[k], valid[k]); }
+    }
+    const uint32_t lastb = (n - 1) >> 6; const int lastbit = (int)((n - 1) & 63);
+    const int lane_last = (int)(lastb / KB);
+    int score = (int)n, best = (n & 63) ? (int)n : 0x7fffffff, best_c = 0;
+    lf_hist_t *h = hist + pr.hist_base;
+    const bool want_path = pr.task == LF_TASK_PATH;
+    int hout_prev = 1;
+    const int steps = (int)m + nl - 1;
+    for (int s = 0; s < steps; s++) {
+        const int from_left = __shfl_up(hout_prev, 1);
+        const int c = s - lane + 1;
+        if (lane < nl && c >= 1 && c <= (int)m) {
+            const unsigned char tc = t[rev ? (int)m - c : c - 1];
+            int hin = lane == 0 ? 1 : from_left;
+#pragma unroll
+            for (int k = 0; k < KB; k++) {
+                const uint32_t b = (uint32_t)lane * KB + k;
+                if (b < nbk) {
+                    const uint64_t Eq = lf_eq_mask(tc, lo[k], hi[k], valid[k], q, n, b, rev);
+                    uint64_t ph, mh;
+                    hin = lf_myers_step(Pv[k], Mv[k], Eq, hin, ph, mh);
+                    if (b == lastb) score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
+                    if (want_path) { lf_hist_t e; e.pv = Pv[k]; e.ph = ph; h[(size_t)(c - 1) * nbk + b] = e; }
+                }
+            }
+            hout_prev = hin;
+            if (lane == lane_last && score < best) { best = score; best_c = c; }
+        }
+    }
+    if (pr.task == LF_TASK_COLS) {
+        /* D[r][m] for r = 0..n from the final vertical deltas: lane-local sums + exclusive scan over lanes */
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+            const uint32_t b = (uint32_t)lane * KB + k;
+            if (b < nbk) {
+                const uint32_t rows = (b == lastb) ? (uint32_t)lastbit + 1 : 64;
+                const uint64_t msk = rows >= 64 ? ~0ull : ((1ull << rows) - 1);
+                mine += __popcll(Pv[k] & msk) - __popcll(Mv[k] & msk);
+            }
+        }
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        int v = (int)m + incl - mine;
+        int32_t *oc = out_cols + cols_off[pr.id];
+        if (lane == 0) oc[0] = (int)m;
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+            const uint32_t b = (uint32_t)lane * KB + k;
+            if (b < nbk) for (int i = 0; i < 64; i++) {
+                const uint32_t r = b * 64 + i + 1;
+                if (r <= n) { v += (int)((Pv[k] >> i) & 1) - (int)((Mv[k] >> i) & 1); oc[r] = v; }
+            }
+        }
+        return;
+    }
+    const int ed_nw = __shfl(score, lane_last), ed_shw = __shfl(best, lane_last), c_shw = __shfl(best_c, lane_last);
+    int ed, tl;
+    if (pr.mode == 0) { ed = ed_nw; tl = (int)m; } else { ed = ed_shw; tl = c_shw; }
+    __syncthreads();                      /* history written by all lanes is read back by lane 0 */
+    if (lane != 0) return;
+    out_ed[pr.id] = ed;
+    out_end[pr.id] = tl - 1;
+    if (!want_path) { out_len[pr.id] = 0; return; }
+    uint8_t *o = ops + pr.ops_off;
+    const uint32_t cap = n + m;
+    uint32_t w = cap, r = n, c = (uint32_t)tl;
+    if (c == 0) { while (r) { o[--w] = 1; r--; } }
+    while (r > 0 && c > 0) {
+        const lf_hist_t e = h[(size_t)(c - 1) * nbk + ((r - 1) >> 6)];
+        const int bit = (int)((r - 1) & 63);
+        if ((e.pv >> bit) & 1) { o[--w] = 1; r--; }
+        else if ((e.ph >> bit) & 1) { o[--w] = 2; c--; }
+        else { o[--w] = (q[r - 1] == t[c - 1]) ? 0 : 3; r--; c--; }
+    }
+    while (c > 0) { o[--w] = 2; c--; }
+    while (r > 0) { o[--w] = 1; r--; }
+    const uint32_t len = cap - w;
+    for (uint32_t i = 0; i < len; i++) o[i] = o[w + i];
+    out_len[pr.id] = len;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * host launcher
  * ---------------------------------------------------------------------------------------------- */
 struct lf_dev_buf {
@@ -261,7 +372,7 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     const uint64_t qbytes = qoff[n], tbytes = toff[n];
 
     /* bin + sort */
-    std::vector<lf_aln_prob> P[5];     /* 0 generic, 1..4 -> NB 1,2,4,8 */
+    std::vector<lf_aln_prob> P[7];     /* 0 generic lane kernel, 1..4 -> NB 1,2,4,8 lane classes, 5/6 wave kernel KB 1/4 */
     std::vector<int> trivial;          /* n == 0 or m == 0: no DP (lib/edlib/edlib.cpp:1096-1104) */
     for (int i = 0; i < n; i++) {
         lf_aln_prob pr; memset(&pr, 0, sizeof pr);
@@ -270,7 +381,9 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
         pr.mode = mode ? mode[i] : 0; pr.task = cols ? LF_TASK_COLS : (task ? task[i] : LF_TASK_PATH); pr.rev = rev ? rev[i] : 0;
         if (pr.n == 0 || (pr.m == 0 && !cols)) { trivial.push_back(i); continue; }
         const int cls = cols ? 0 : class_nb(pr.n);
-        P[cls == 0 ? 0 : (cls == 1 ? 1 : cls == 2 ? 2 : cls == 4 ? 3 : 4)].push_back(pr);
+        int slot = cls == 0 ? 0 : (cls == 1 ? 1 : cls == 2 ? 2 : cls == 4 ? 3 : 4);
+        if (slot == 0) slot = pr.n <= 4096 ? 5 : (pr.n <= 16384 ? 6 : 0);
+        P[slot].push_back(pr);
     }
     static const int NBS[5] = { 0, 1, 2, 4, 8 };
     size_t hist_entries = 0, aux_words = 0;
@@ -283,16 +396,17 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
             if (any) hist_entries += (size_t)64 * mx * NBS[k];
         }
     }
-    for (auto &pr : P[0]) {
+    for (int k : {0, 5, 6}) for (auto &pr : P[k]) {
         const size_t nbk = (pr.n + 63) / 64;
-        pr.aux_off = aux_words; aux_words += nbk * 5;
+        if (k == 0) { pr.aux_off = aux_words; aux_words += nbk * 5; }
         pr.hist_base = hist_entries;
         if (pr.task == LF_TASK_PATH) hist_entries += (size_t)pr.m * nbk;
     }
+    for (int k : {5, 6}) std::sort(P[k].begin(), P[k].end(), [](const lf_aln_prob &a, const lf_aln_prob &b) { return a.m > b.m; });
     std::sort(P[0].begin(), P[0].end(), [](const lf_aln_prob &a, const lf_aln_prob &b) {
         const uint64_t wa = (uint64_t)((a.n + 63) / 64) * a.m, wb = (uint64_t)((b.n + 63) / 64) * b.m; return wa > wb; });
 
-    lf_dev_buf d_q, d_t, d_hist, d_aux, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off, d_prob[5];
+    lf_dev_buf d_q, d_t, d_hist, d_aux, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off, d_prob[7];
     HIPCHK(d_q.alloc(qbytes + 64)); HIPCHK(d_t.alloc(tbytes + 64));
     HIPCHK(d_hist.alloc(hist_entries * sizeof(lf_hist_t) + 64));
     HIPCHK(d_aux.alloc(aux_words * 8 + 64));
@@ -308,7 +422,7 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     HIPCHK(hipMemcpyAsync(d_t.p, t, tbytes, hipMemcpyHostToDevice, s));
     if (cols) HIPCHK(hipMemcpyAsync(d_cols_off.p, cols_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(d_len.p, 0, (size_t)n * 4, s));
-    for (int k = 0; k < 5; k++) if (!P[k].empty()) {
+    for (int k = 0; k < 7; k++) if (!P[k].empty()) {
         HIPCHK(d_prob[k].alloc(P[k].size() * sizeof(lf_aln_prob)));
         HIPCHK(hipMemcpyAsync(d_prob[k].p, P[k].data(), P[k].size() * sizeof(lf_aln_prob), hipMemcpyHostToDevice, s));
     }
@@ -322,6 +436,10 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
                            d_prob[0].as<lf_aln_prob>(), (int)P[0].size(), d_q.as<unsigned char>(), d_t.as<unsigned char>(),
                            d_hist.as<lf_hist_t>(), d_aux.as<uint64_t>(), d_ops.as<uint8_t>(), d_ed.as<int32_t>(), d_end.as<int32_t>(),
                            d_len.as<uint32_t>(), d_cols.as<int32_t>(), d_cols_off.as<uint64_t>());
+#define LAUNCH_WAVE(K, KBV) if (!P[K].empty()) hipLaunchKernelGGL(lf_edlib_wave_kernel<KBV>, dim3((unsigned)P[K].size()), dim3(64), 0, s, \
+        d_prob[K].as<lf_aln_prob>(), (int)P[K].size(), d_q.as<unsigned char>(), d_t.as<unsigned char>(), d_hist.as<lf_hist_t>(), \
+        d_ops.as<uint8_t>(), d_ed.as<int32_t>(), d_end.as<int32_t>(), d_len.as<uint32_t>(), d_cols.as<int32_t>(), d_cols_off.as<uint64_t>())
+    LAUNCH_WAVE(5, 1); LAUNCH_WAVE(6, 4);
     HIPCHK(hipEventRecord(e1, s));
     if (cols) HIPCHK(hipMemcpyAsync(cols, d_cols.p, cols_total * 4, hipMemcpyDeviceToHost, s));
     else {
