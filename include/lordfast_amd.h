@@ -80,6 +80,9 @@ const char *lf_last_error(void);
 #define LF_IDX_FULL_SA 1u
 int  lf_index_load(const char *prefix, int device, unsigned flags, lf_index_t **out);
 void lf_index_free(lf_index_t *idx);
+/* bwt_index (src/BWT.cpp:140-157 over lib/bwa/bwtindex.c:187-293): build <fasta>.pac/.ann/.amb/.bwt/.sa/.cache on
+ * the GPU, byte-identical to the reference's indexer (plain or gzip FASTA). */
+int  lf_index_build(const char *fasta_path, int device);
 uint32_t lf_index_genome_len(const lf_index_t *idx);          /* bwt_get_refGenLen, src/BWT.cpp:305 */
 int  lf_index_n_contigs(const lf_index_t *idx);
 const char *lf_index_contig(const lf_index_t *idx, int i, int64_t *offset, int32_t *len);
@@ -159,6 +162,7 @@ void lf_free(void *ptr);
  * ---------------------------------------------------------------------------------------------- */
 extern lf_params_t lf_global_params;      /* MIN_ANCHOR_LEN, SAMPLING_COUNT, ... (src/Common.h:76-81) */
 
+int      bwt_index(char *ref_path);                                       /* src/BWT.h:28  */
 int      bwt_load(char *ref_path);                                        /* src/BWT.h:29  */
 uint32_t bwt_get_refGenLen(void);                                         /* src/BWT.h:31  */
 void     getLocs_extend_whole_step(char *qSeq, uint32_t qLen, uint32_t hash_count,

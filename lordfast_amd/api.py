@@ -75,6 +75,8 @@ def lib():
                                 C.POINTER(C.POINTER(Seeds))]
     L.lf_seeds_free.argtypes = [C.POINTER(Seeds)]
     L.lf_free.argtypes = [C.c_void_p]
+    if hasattr(L, "lf_index_build"):
+        L.lf_index_build.argtypes = [C.c_char_p, C.c_int]
     if hasattr(L, "lf_edlib_batch"):
         L.lf_edlib_batch.argtypes = [C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)]
@@ -128,6 +130,19 @@ def _concat(seqs):
     if len(seqs):
         off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
     return b"".join(seqs), off
+
+
+def index_build(contigs_or_fasta, fasta_path: str | None = None, device: int = 0) -> str:
+    """Build the reference's index files next to a FASTA on the GPU.  `contigs_or_fasta` is either a path or a
+    list of (name, uint8 array) that is first written to `fasta_path`."""
+    if isinstance(contigs_or_fasta, (str, bytes)):
+        fa = contigs_or_fasta if isinstance(contigs_or_fasta, str) else contigs_or_fasta.decode()
+    else:
+        from . import synth
+        fa = fasta_path
+        synth.write_fasta(fa, contigs_or_fasta)
+    _check(lib().lf_index_build(fa.encode(), device), "lf_index_build")
+    return fa
 
 
 class LordFast:

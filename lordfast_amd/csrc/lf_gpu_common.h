@@ -28,6 +28,8 @@ struct lf_dev_state {           /* host-side owner of the device allocations */
     hipStream_t stream;
 };
 
+int lfg_build_cache_table(const lf_dev_index *v, hipStream_t stream, uint64_t **table);
+
 __device__ __forceinline__ int lf_nt4(unsigned char ch)
 {   /* nst_nt4_table (lib/bwa/bntseq.c:47-64): A/a C/c G/g T/t -> 0..3, everything else > 3 */
     switch (ch) {

@@ -42,6 +42,28 @@ __global__ void lf_full_sa_kernel(lf_dev_index ix, uint64_t *__restrict__ sa_ful
     }
 }
 
+/* 12-mer table (src/BWT.cpp:60-115), level by level, ping-pong between two buffers; *table = 4^12 pairs */
+int lfg_build_cache_table(const lf_dev_index *v, hipStream_t stream, uint64_t **table)
+{
+    const int K = 12;
+    uint64_t *bufA, *bufB;
+    HIPCHK(hipMalloc(&bufA, ((size_t)1 << (2 * K)) * 16));
+    HIPCHK(hipMalloc(&bufB, ((size_t)1 << (2 * (K - 1))) * 16));
+    uint64_t *cur = (K % 2 == 0) ? bufA : bufB, *nxt = (K % 2 == 0) ? bufB : bufA;   /* level K lands in bufA */
+    const uint64_t root[2] = { 0, v->seq_len };
+    HIPCHK(hipMemcpy(cur, root, 16, hipMemcpyHostToDevice));
+    for (int k = 0; k < K; k++) {
+        const uint32_t np = 1u << (2 * k);
+        hipLaunchKernelGGL(lf_cache_level_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, *v, cur, nxt, np);
+        uint64_t *t = cur; cur = nxt; nxt = t;
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    if (cur != bufA) { lf_set_error("cache table ended in the wrong buffer"); return LF_ERR_HIP; }
+    HIPCHK(hipFree(bufB));
+    *table = bufA;
+    return LF_OK;
+}
+
 extern "C" int lfg_device_count(void)
 {
     int n = 0;
@@ -71,24 +93,13 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
     HIPCHK(hipMemcpy(st->pac, ix->pac, pac_bytes, hipMemcpyHostToDevice));
     v.bwt = (const uint32_t *)st->bwt; v.sa_sampled = (const uint64_t *)st->sa_sampled; v.pac = (const uint8_t *)st->pac;
 
-    /* 12-mer table, level by level, ping-pong between two buffers */
-    const int K = 12;
-    uint64_t *bufA, *bufB;
-    HIPCHK(hipMalloc(&bufA, ((size_t)1 << (2 * K)) * 16));
-    HIPCHK(hipMalloc(&bufB, ((size_t)1 << (2 * (K - 1))) * 16));
-    uint64_t *cur = (K % 2 == 0) ? bufA : bufB, *nxt = (K % 2 == 0) ? bufB : bufA;   /* level K lands in bufA */
-    const uint64_t root[2] = { 0, ix->seq_len };
-    HIPCHK(hipMemcpy(cur, root, 16, hipMemcpyHostToDevice));
-    for (int k = 0; k < K; k++) {
-        const uint32_t np = 1u << (2 * k);
-        hipLaunchKernelGGL(lf_cache_level_kernel, dim3((np + 255) / 256), dim3(256), 0, st->stream, v, cur, nxt, np);
-        uint64_t *t = cur; cur = nxt; nxt = t;
+    {
+        uint64_t *tab = nullptr;
+        int rc = lfg_build_cache_table(&v, st->stream, &tab);
+        if (rc != LF_OK) return rc;
+        st->cache = tab;
+        v.cache = tab;
     }
-    HIPCHK(hipStreamSynchronize(st->stream));
-    if (cur != bufA) { lf_set_error("cache table ended in the wrong buffer"); return LF_ERR_HIP; }
-    HIPCHK(hipFree(bufB));
-    st->cache = bufA;
-    v.cache = bufA;
 
     if (ix->flags & LF_IDX_FULL_SA) {
         const uint64_t rows = ix->seq_len + 1;
