@@ -169,9 +169,9 @@ def main():
             my_names, my_seqs, _ = lfd.scatter_reads(dist, torch, names, seqs, dev)
         else:
             my_names, my_seqs = names, seqs
-        sam, st = lf.map_batch(my_names, my_seqs, params=params)
+        sam, st = lf.map_batch(my_names, my_seqs, params=params, copy=False)
         if dist:
-            sam = lfd.gather_sam(dist, torch, sam, dev)
+            sam = lfd.gather_sam(dist, torch, sam.view(), dev)
         return sam, st
 
     for _ in range(args.warmup):
@@ -241,7 +241,9 @@ def main():
                 out["cpu_baseline"] = base
                 out["speedup_vs_cpu_baseline"] = value / base["value"]
                 # CIGAR bit-match rate against the reference on the sampled reads (primary records)
-                mine = [l for l in sam.split(b"\n") if l]
+                # the reference sample is a prefix of the batch: compare the head of our SAM (records are in read order)
+                head = sam.head(4 * len(ref_sam) + (1 << 20)) if hasattr(sam, "head") else sam[:4 * len(ref_sam) + (1 << 20)]
+                mine = [l for l in head.split(b"\n")[:-1] if l]
                 want = {}
                 for l in ref_sam.split(b"\n"):
                     f = l.split(b"\t")

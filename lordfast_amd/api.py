@@ -145,6 +145,35 @@ def index_build(contigs_or_fasta, fasta_path: str | None = None, device: int = 0
     return fa
 
 
+class SamBuffer:
+    """SAM text owned by the C library (malloc'd by lf_map_batch)."""
+
+    def __init__(self, L, ptr, n):
+        self.L, self.ptr, self.n = L, ptr, n
+
+    def __len__(self):
+        return self.n
+
+    def view(self) -> memoryview:
+        if self.n == 0:
+            return memoryview(b"")
+        return memoryview((C.c_char * self.n).from_address(self.ptr.value)).cast("B")
+
+    def tobytes(self) -> bytes:
+        return bytes(self.view())
+
+    def head(self, n_bytes: int) -> bytes:
+        return bytes(self.view()[:min(n_bytes, self.n)])
+
+    def free(self):
+        if self.ptr:
+            self.L.lf_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.free()
+
+
 class LordFast:
     """An FM-index resident in one GPU's HBM + the batch entry points."""
 
@@ -187,7 +216,9 @@ class LordFast:
         return Fl, Rl, info
 
     # ---- whole path
-    def map_batch(self, names, seqs, quals=None, params: Params | None = None):
+    def map_batch(self, names, seqs, quals=None, params: Params | None = None, copy: bool = True):
+        """-> (SAM records, stats dict).  copy=False returns a SamBuffer (zero-copy view of the C buffer; SAM text of a
+        100k-read batch is > 2 GiB)."""
         p = params or default_params()
         sam = C.c_void_p()
         ln = C.c_size_t()
@@ -195,9 +226,12 @@ class LordFast:
         q = _cstr_array(quals) if quals is not None else None
         _check(self.L.lf_map_batch(self.h, C.byref(p), len(names), _cstr_array(names), _cstr_array(seqs), q,
                                    C.byref(sam), C.byref(ln), C.byref(st)), "lf_map_batch")
-        out = C.string_at(sam, ln.value)
-        self.L.lf_free(sam)
-        return out, st.as_dict()
+        buf = SamBuffer(self.L, sam, ln.value)
+        if copy:
+            out = buf.tobytes()
+            buf.free()
+            return out, st.as_dict()
+        return buf, st.as_dict()
 
     def sam_header(self, cmdline: str, params: Params | None = None) -> bytes:
         p = params or default_params()

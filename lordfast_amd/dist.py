@@ -66,7 +66,7 @@ def scatter_reads(dist, torch, names, seqs, device, src: int = 0):
     return my_names, my_seqs, bounds
 
 
-def gather_sam(dist, torch, sam: bytes, device, dst: int = 0) -> bytes | None:
+def gather_sam(dist, torch, sam, device, dst: int = 0) -> bytes | None:
     """concatenate the per-rank SAM blobs on rank dst in rank order (= input order)."""
     rank, world = dist.get_rank(), dist.get_world_size()
     ln = torch.tensor([len(sam)], dtype=torch.int64, device=device)
@@ -76,7 +76,8 @@ def gather_sam(dist, torch, sam: bytes, device, dst: int = 0) -> bytes | None:
     mx = max(sizes + [1])
     mine = torch.zeros(mx, dtype=torch.uint8, device=device)
     if len(sam):
-        mine[:len(sam)] = torch.frombuffer(bytearray(sam), dtype=torch.uint8).to(device)
+        src = sam if isinstance(sam, (bytearray, memoryview)) else bytearray(sam)
+        mine[:len(sam)] = torch.frombuffer(src, dtype=torch.uint8).to(device)
     bufs = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world)]
     dist.all_gather(bufs, mine)
     if rank != dst:
