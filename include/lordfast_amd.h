@@ -201,6 +201,10 @@ int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
                 int o_del, int e_del, int o_ins, int e_ins, int w, int end_bonus, int zdrop, int h0,
                 int *qle, int *tle, int *gtle, int *gscore, int *max_off);
 
+/* lib/bwa/ksw.h:107 -- ksw_extend = ksw_extend2 with equal insertion / deletion costs (lib/bwa/ksw.c:480-483) */
+int ksw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat, int gapo, int gape,
+               int w, int end_bonus, int zdrop, int h0, int *qle, int *tle, int *gtle, int *gscore, int *max_off);
+
 /* src/LordFAST.h:122-126 -- the chunk driver. Read layout as src/Reads.h:28-35. */
 typedef struct { uint32_t *length; char *seq; char *qual; char *name; uint8_t *isFq; } Read;
 void initializeFAST(void);             /* opens lf_global_output (stdout if NULL), prints the header */

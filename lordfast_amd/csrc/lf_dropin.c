@@ -178,6 +178,12 @@ int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
     return sc;
 }
 
+int ksw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat, int gapo, int gape,
+               int w, int end_bonus, int zdrop, int h0, int *qle, int *tle, int *gtle, int *gscore, int *max_off)
+{   /* lib/bwa/ksw.c:480-483 */
+    return ksw_extend2(qlen, query, tlen, target, m, mat, gapo, gape, gapo, gape, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore, max_off);
+}
+
 /* ---- the chunk driver of src/LordFAST.h:122-126 ---- */
 void initializeFAST(void)
 {   /* src/LordFAST.cpp:110-215: output + header */
