@@ -360,6 +360,25 @@ static int class_nb(uint32_t n)
     return 0;              /* generic */
 }
 
+/* stable counting sort of problems by target length (ascending or descending): O(n), replaces std::sort */
+static void sort_by_m(std::vector<lf_aln_prob> &v, bool descending)
+{
+    if (v.size() < 2) return;
+    uint32_t mx = 0;
+    for (auto &p : v) mx = std::max(mx, p.m);
+    if ((size_t)mx > 8 * v.size() + 65536) {        /* sparse lengths: comparison sort */
+        if (descending) std::stable_sort(v.begin(), v.end(), [](const lf_aln_prob &a, const lf_aln_prob &b) { return a.m > b.m; });
+        else std::stable_sort(v.begin(), v.end(), [](const lf_aln_prob &a, const lf_aln_prob &b) { return a.m < b.m; });
+        return;
+    }
+    std::vector<uint32_t> cnt((size_t)mx + 2, 0);
+    for (auto &p : v) cnt[(descending ? mx - p.m : p.m) + 1]++;
+    for (size_t i = 1; i < cnt.size(); i++) cnt[i] += cnt[i - 1];
+    std::vector<lf_aln_prob> o(v.size());
+    for (auto &p : v) o[cnt[descending ? mx - p.m : p.m]++] = p;
+    v.swap(o);
+}
+
 /* runs DIST/PATH problems (cols == nullptr) or COLS problems (cols != nullptr) */
 static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
                      const uint8_t *mode, const uint8_t *task, const uint8_t *rev, int32_t *ed, int32_t *endloc,
@@ -371,9 +390,21 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     HIPCHK(hipSetDevice(device));
     const uint64_t qbytes = qoff[n], tbytes = toff[n];
 
-    /* bin + sort */
+    /* bin + order */
     std::vector<lf_aln_prob> P[7];     /* 0 generic lane kernel, 1..4 -> NB 1,2,4,8 lane classes, 5/6 wave kernel KB 1/4 */
     std::vector<int> trivial;          /* n == 0 or m == 0: no DP (lib/edlib/edlib.cpp:1096-1104) */
+    {
+        size_t c[7] = { 0, 0, 0, 0, 0, 0, 0 };
+        for (int i = 0; i < n; i++) {
+            const uint32_t nn = (uint32_t)(qoff[i + 1] - qoff[i]), mm = (uint32_t)(toff[i + 1] - toff[i]);
+            if (nn == 0 || (mm == 0 && !cols)) continue;
+            const int cls = cols ? 0 : class_nb(nn);
+            int slot = cls == 0 ? 0 : (cls == 1 ? 1 : cls == 2 ? 2 : cls == 4 ? 3 : 4);
+            if (slot == 0) slot = nn <= 4096 ? 5 : (nn <= 16384 ? 6 : 0);
+            c[slot]++;
+        }
+        for (int k = 0; k < 7; k++) P[k].reserve(c[k]);
+    }
     for (int i = 0; i < n; i++) {
         lf_aln_prob pr; memset(&pr, 0, sizeof pr);
         pr.qoff = qoff[i]; pr.toff = toff[i]; pr.n = (uint32_t)(qoff[i + 1] - qoff[i]); pr.m = (uint32_t)(toff[i + 1] - toff[i]);
@@ -389,7 +420,7 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     size_t hist_entries = 0, aux_words = 0;
     for (int k = 1; k <= 4; k++) {
         auto &v = P[k];
-        std::sort(v.begin(), v.end(), [](const lf_aln_prob &a, const lf_aln_prob &b) { return a.m < b.m || (a.m == b.m && a.id < b.id); });
+        sort_by_m(v, false);
         for (size_t w = 0; w < v.size(); w += 64) {
             uint32_t mx = 0; bool any = false;
             for (size_t j = w; j < std::min(v.size(), w + 64); j++) { if (v[j].task == LF_TASK_PATH) { any = true; mx = std::max(mx, v[j].m); } v[j].hist_base = hist_entries; }
@@ -402,56 +433,56 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
         pr.hist_base = hist_entries;
         if (pr.task == LF_TASK_PATH) hist_entries += (size_t)pr.m * nbk;
     }
-    for (int k : {5, 6}) std::sort(P[k].begin(), P[k].end(), [](const lf_aln_prob &a, const lf_aln_prob &b) { return a.m > b.m; });
+    for (int k : {5, 6}) sort_by_m(P[k], true);
     std::sort(P[0].begin(), P[0].end(), [](const lf_aln_prob &a, const lf_aln_prob &b) {
         const uint64_t wa = (uint64_t)((a.n + 63) / 64) * a.m, wb = (uint64_t)((b.n + 63) / 64) * b.m; return wa > wb; });
 
-    lf_dev_buf d_q, d_t, d_hist, d_aux, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off, d_prob[7];
-    HIPCHK(d_q.alloc(qbytes + 64)); HIPCHK(d_t.alloc(tbytes + 64));
-    HIPCHK(d_hist.alloc(hist_entries * sizeof(lf_hist_t) + 64));
-    HIPCHK(d_aux.alloc(aux_words * 8 + 64));
-    HIPCHK(d_ed.alloc((size_t)n * 4)); HIPCHK(d_end.alloc((size_t)n * 4)); HIPCHK(d_len.alloc((size_t)n * 4));
     size_t cols_total = 0;
-    if (cols) {
-        for (int i = 0; i < n; i++) cols_total = std::max<size_t>(cols_total, cols_off[i] + (qoff[i + 1] - qoff[i]) + 1);
-        HIPCHK(d_cols.alloc(cols_total * 4 + 16)); HIPCHK(d_cols_off.alloc((size_t)n * 8));
-    } else HIPCHK(d_ops.alloc(qbytes + tbytes + 64));
-    hipStream_t s; HIPCHK(hipStreamCreate(&s));
+    if (cols) for (int i = 0; i < n; i++) cols_total = std::max<size_t>(cols_total, cols_off[i] + (qoff[i + 1] - qoff[i]) + 1);
+#define DSLOT(T, k, bytes) (T *)lfg_dev_slot(device, LF_DS_ALN0 + (k), (bytes))
+    unsigned char *d_q = DSLOT(unsigned char, 0, qbytes + 64), *d_t = DSLOT(unsigned char, 1, tbytes + 64);
+    lf_hist_t *d_hist = DSLOT(lf_hist_t, 2, hist_entries * sizeof(lf_hist_t) + 64);
+    uint64_t *d_aux = DSLOT(uint64_t, 3, aux_words * 8 + 64);
+    int32_t *d_ed = DSLOT(int32_t, 4, (size_t)n * 4), *d_end = DSLOT(int32_t, 5, (size_t)n * 4);
+    uint32_t *d_len = DSLOT(uint32_t, 6, (size_t)n * 4);
+    uint8_t *d_ops = cols ? nullptr : DSLOT(uint8_t, 7, qbytes + tbytes + 64);
+    int32_t *d_cols = cols ? DSLOT(int32_t, 8, cols_total * 4 + 16) : nullptr;
+    uint64_t *d_cols_off = cols ? DSLOT(uint64_t, 9, (size_t)n * 8) : nullptr;
+    if (!d_q || !d_t || !d_hist || !d_aux || !d_ed || !d_end || !d_len || (!cols && !d_ops) || (cols && (!d_cols || !d_cols_off))) return LF_ERR_NOMEM;
+    lf_aln_prob *d_prob[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    for (int k = 0; k < 7; k++) if (!P[k].empty()) { d_prob[k] = DSLOT(lf_aln_prob, 10 + k, P[k].size() * sizeof(lf_aln_prob)); if (!d_prob[k]) return LF_ERR_NOMEM; }
+#undef DSLOT
+    static hipStream_t s = nullptr;
+    if (!s) HIPCHK(hipStreamCreate(&s));
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipMemcpyAsync(d_q.p, q, qbytes, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_t.p, t, tbytes, hipMemcpyHostToDevice, s));
-    if (cols) HIPCHK(hipMemcpyAsync(d_cols_off.p, cols_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(d_len.p, 0, (size_t)n * 4, s));
-    for (int k = 0; k < 7; k++) if (!P[k].empty()) {
-        HIPCHK(d_prob[k].alloc(P[k].size() * sizeof(lf_aln_prob)));
-        HIPCHK(hipMemcpyAsync(d_prob[k].p, P[k].data(), P[k].size() * sizeof(lf_aln_prob), hipMemcpyHostToDevice, s));
-    }
+    HIPCHK(hipMemcpyAsync(d_q, q, qbytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_t, t, tbytes, hipMemcpyHostToDevice, s));
+    if (cols) HIPCHK(hipMemcpyAsync(d_cols_off, cols_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(d_len, 0, (size_t)n * 4, s));
+    for (int k = 0; k < 7; k++) if (!P[k].empty())
+        HIPCHK(hipMemcpyAsync(d_prob[k], P[k].data(), P[k].size() * sizeof(lf_aln_prob), hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(e0, s));
 #define LAUNCH_CLASS(K, NBV) if (!P[K].empty()) hipLaunchKernelGGL(lf_edlib_kernel<NBV>, dim3((unsigned)((P[K].size() + 63) / 64)), dim3(64), 0, s, \
-        d_prob[K].as<lf_aln_prob>(), (int)P[K].size(), d_q.as<unsigned char>(), d_t.as<unsigned char>(), d_hist.as<lf_hist_t>(), \
-        d_ops.as<uint8_t>(), d_ed.as<int32_t>(), d_end.as<int32_t>(), d_len.as<uint32_t>())
+        d_prob[K], (int)P[K].size(), d_q, d_t, d_hist, d_ops, d_ed, d_end, d_len)
     LAUNCH_CLASS(1, 1); LAUNCH_CLASS(2, 2); LAUNCH_CLASS(3, 4); LAUNCH_CLASS(4, 8);
     if (!P[0].empty())
         hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((P[0].size() + 63) / 64)), dim3(64), 0, s,
-                           d_prob[0].as<lf_aln_prob>(), (int)P[0].size(), d_q.as<unsigned char>(), d_t.as<unsigned char>(),
-                           d_hist.as<lf_hist_t>(), d_aux.as<uint64_t>(), d_ops.as<uint8_t>(), d_ed.as<int32_t>(), d_end.as<int32_t>(),
-                           d_len.as<uint32_t>(), d_cols.as<int32_t>(), d_cols_off.as<uint64_t>());
+                           d_prob[0], (int)P[0].size(), d_q, d_t, d_hist, d_aux, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off);
 #define LAUNCH_WAVE(K, KBV) if (!P[K].empty()) hipLaunchKernelGGL(lf_edlib_wave_kernel<KBV>, dim3((unsigned)P[K].size()), dim3(64), 0, s, \
-        d_prob[K].as<lf_aln_prob>(), (int)P[K].size(), d_q.as<unsigned char>(), d_t.as<unsigned char>(), d_hist.as<lf_hist_t>(), \
-        d_ops.as<uint8_t>(), d_ed.as<int32_t>(), d_end.as<int32_t>(), d_len.as<uint32_t>(), d_cols.as<int32_t>(), d_cols_off.as<uint64_t>())
+        d_prob[K], (int)P[K].size(), d_q, d_t, d_hist, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off)
     LAUNCH_WAVE(5, 1); LAUNCH_WAVE(6, 4);
     HIPCHK(hipEventRecord(e1, s));
-    if (cols) HIPCHK(hipMemcpyAsync(cols, d_cols.p, cols_total * 4, hipMemcpyDeviceToHost, s));
+    if (cols) HIPCHK(hipMemcpyAsync(cols, d_cols, cols_total * 4, hipMemcpyDeviceToHost, s));
     else {
-        HIPCHK(hipMemcpyAsync(ed, d_ed.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(endloc, d_end.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(ops_len, d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(ops, d_ops.p, qbytes + tbytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(ed, d_ed, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(endloc, d_end, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(ops_len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(ops, d_ops, qbytes + tbytes, hipMemcpyDeviceToHost, s));
     }
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 
     /* degenerate problems: one side empty -> pure insertion / deletion run (lib/edlib/edlib.cpp:1096-1104) */
     for (int i : trivial) {

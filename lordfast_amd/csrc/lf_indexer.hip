@@ -312,11 +312,11 @@ extern "C" int lf_index_build(const char *fasta_path, int device)
     size_t tmp_bytes = 0; void *d_tmp = nullptr;
     {   /* one temp buffer big enough for every hipCUB call below */
         size_t a = 0, b = 0, c = 0, d = 0, e = 0;
-        hipcub::DeviceRadixSort::SortPairs(nullptr, a, d_key, d_key2, d_pos, d_pos2, (int)maxb, 0, 64, s);
-        hipcub::DeviceRadixSort::SortPairs(nullptr, b, d_key, d_key2, d_idx, d_idx2, (int)maxb, 0, 64, s);
-        hipcub::DeviceRadixSort::SortPairs(nullptr, c, d_gid, d_gid2, d_idx, d_idx2, (int)maxb, 0, 32, s);
-        hipcub::DeviceScan::InclusiveScan(nullptr, d, d_u32a, d_gid, lf_max_op(), (int)maxb, s);
-        hipcub::DeviceSelect::Flagged(nullptr, e, d_pos, d_tied, d_pos2, d_nsel, (int)maxb, s);
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, d_key, d_key2, d_pos, d_pos2, (int)maxb, 0, 64, s);
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, d_key, d_key2, d_idx, d_idx2, (int)maxb, 0, 64, s);
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, c, d_gid, d_gid2, d_idx, d_idx2, (int)maxb, 0, 32, s);
+        (void)hipcub::DeviceScan::InclusiveScan(nullptr, d, d_u32a, d_gid, lf_max_op(), (int)maxb, s);
+        (void)hipcub::DeviceSelect::Flagged(nullptr, e, d_pos, d_tied, d_pos2, d_nsel, (int)maxb, s);
         tmp_bytes = std::max({ a, b, c, d, e }) + (64u << 20);
         HIPCHK(hipMalloc(&d_tmp, tmp_bytes));
     }

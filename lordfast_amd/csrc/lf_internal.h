@@ -60,6 +60,16 @@ int lfg_colscores(int device, int n, const char *q, const uint64_t *qoff, const 
 int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff, const uint8_t *t, const uint64_t *toff,
             const int32_t *prm, int32_t *score, int32_t *qle, int32_t *tle, float *ms);
 
+/* ---- lf_mem.hip: persistent grow-only buffers ---- */
+void *lfg_dev_slot(int device, int slot, size_t bytes);
+void *lfg_pin_slot(int slot, size_t bytes);
+void  lfg_slots_release(void);
+/* slot ids */
+enum { LF_DS_SEED0 = 0 /* ..15 */, LF_DS_CHAIN0 = 16 /* ..23 */, LF_DS_ALN0 = 24 /* ..47 */, LF_DS_KSW0 = 48 /* ..55 */ };
+enum { LF_PS_READS = 0, LF_PS_READOFF = 1, LF_PS_HITS_T = 2, LF_PS_HITS_Q = 3, LF_PS_HITS_S = 4, LF_PS_HITS_OFF = 5,
+       LF_PS_CHAIN_SEEDS = 6, LF_PS_CHAIN_IDX = 7, LF_PS_ALN_Q = 8, LF_PS_ALN_T = 9, LF_PS_ALN_PROB = 10 /* ..16 */,
+       LF_PS_ROUND0 = 20 /* 4 per round: ed, end, len, ops ; up to 16 rounds */ };
+
 #define LF_TASK_PATH 0
 #define LF_TASK_DIST 1
 

@@ -120,7 +120,7 @@ typedef struct {
     int64_t slot;          /* index in the round's result arrays */
 } memo_t;
 
-typedef struct { int32_t *ed, *end; uint32_t *ops_len; uint8_t *ops; uint64_t *ops_off; int n; } ed_round_t;
+typedef struct { int32_t *ed, *end; uint32_t *ops_len; uint8_t *ops; uint64_t *ops_off; int n, pinned; } ed_round_t;
 typedef struct { int32_t *score, *qle, *tle; int n; } ksw_round_t;
 
 typedef struct {
@@ -150,6 +150,7 @@ typedef struct {
     Seed_t *F, *R; uint32_t nF, nR;
     int mode;              /* 0 short, 1 no window, 2 coarse, 3 fine */
     int vote_tid;          /* worker that voted this read (owns its chain requests) */
+    int seed_idx;          /* position in the seed batch */
     /* fine-mode candidates in scan order */
     struct cand { uint32_t win; uint8_t isRev; int req; } *cands; int ncand, capcand;
     win_t *wins; int nWins;
@@ -177,30 +178,81 @@ typedef struct ctx {
     ksw_round_t *ksw_rounds; int n_ksw_rounds;
     stage_t *stages;       /* per worker */
     lf_stats_t *st;
+    const lfg_hits_t *hits;
+    /* scratch for the parallel merge of staged alignment requests */
+    char *mg_qb, *mg_tb; uint64_t *mg_qoff, *mg_toff, *mg_qbase, *mg_tbase; uint8_t *mg_mode; int *mg_gbase; ed_round_t *mg_R; int mg_round;
+    /* output assembly */
+    char *out_base; uint64_t *out_off;
+    int *seed_map; char *cat; uint64_t *cat_off;
 } ctx_t;
 
-/* ---------------------------------------------------------------- parallel for */
+/* ---------------------------------------------------------------- parallel for on a persistent thread pool */
 typedef void (*pf_fn)(ctx_t *cx, int tid, int i);
-typedef struct { ctx_t *cx; pf_fn fn; int n, tid; volatile int *next; } pf_arg_t;
-static void *pf_worker(void *a_)
+typedef struct {
+    pthread_t th[256]; int nt, started;
+    pthread_mutex_t mu; pthread_cond_t cv_start, cv_done;
+    unsigned gen; int running, stop;
+    pf_fn fn; ctx_t *cx; int n, grain; volatile int next;
+} pool_t;
+static pool_t g_pool = { .mu = PTHREAD_MUTEX_INITIALIZER, .cv_start = PTHREAD_COND_INITIALIZER, .cv_done = PTHREAD_COND_INITIALIZER };
+
+static void pool_run(pool_t *P, int tid)
 {
-    pf_arg_t *a = (pf_arg_t *)a_;
     for (;;) {
-        int i = __sync_fetch_and_add(a->next, 1);
-        if (i >= a->n) break;
-        a->fn(a->cx, a->tid, i);
+        int i = __sync_fetch_and_add(&P->next, P->grain);
+        if (i >= P->n) break;
+        int e = i + P->grain < P->n ? i + P->grain : P->n;
+        for (; i < e; i++) P->fn(P->cx, tid, i);
     }
+}
+static void *pool_worker(void *arg)
+{
+    pool_t *P = &g_pool;
+    const int tid = (int)(intptr_t)arg;
+    unsigned seen = 0;
+    pthread_mutex_lock(&P->mu);
+    for (;;) {
+        while (P->gen == seen && !P->stop) pthread_cond_wait(&P->cv_start, &P->mu);
+        if (P->stop) break;
+        seen = P->gen;
+        pthread_mutex_unlock(&P->mu);
+        pool_run(P, tid);
+        pthread_mutex_lock(&P->mu);
+        if (--P->running == 0) pthread_cond_signal(&P->cv_done);
+    }
+    pthread_mutex_unlock(&P->mu);
     return NULL;
+}
+static void pool_ensure(int nt)
+{
+    pool_t *P = &g_pool;
+    if (P->started && P->nt == nt) return;
+    if (P->started) {                                   /* thread count changed: restart the pool */
+        pthread_mutex_lock(&P->mu); P->stop = 1; pthread_cond_broadcast(&P->cv_start); pthread_mutex_unlock(&P->mu);
+        for (int t = 1; t < P->nt; t++) pthread_join(P->th[t], NULL);
+        P->stop = 0; P->started = 0;
+    }
+    P->nt = nt; P->gen = 0;
+    pthread_attr_t at; pthread_attr_init(&at); pthread_attr_setstacksize(&at, 4u << 20);
+    for (int t = 1; t < nt; t++) pthread_create(&P->th[t], &at, pool_worker, (void *)(intptr_t)t);   /* tid 0 = caller */
+    P->started = 1;
 }
 static void parallel_for(ctx_t *cx, int n, pf_fn fn)
 {
-    volatile int next = 0;
-    int nt = cx->n_threads;
-    if (nt > n) nt = n;
-    if (nt <= 1) { pf_arg_t a = { cx, fn, n, 0, &next }; pf_worker(&a); return; }
-    pthread_t th[256]; pf_arg_t args[256];
-    for (int t = 0; t < nt; t++) { args[t] = (pf_arg_t){ cx, fn, n, t, &next }; pthread_create(&th[t], NULL, pf_worker, &args[t]); }
-    for (int t = 0; t < nt; t++) pthread_join(th[t], NULL);
+    pool_t *P = &g_pool;
+    if (n <= 0) return;
+    pool_ensure(cx->n_threads);
+    P->fn = fn; P->cx = cx; P->n = n; P->next = 0;
+    P->grain = n / (P->nt * 16) + 1; if (P->grain > 64) P->grain = 64;
+    if (P->nt <= 1) { pool_run(P, 0); return; }
+    pthread_mutex_lock(&P->mu);
+    P->running = P->nt - 1; P->gen++;
+    pthread_cond_broadcast(&P->cv_start);
+    pthread_mutex_unlock(&P->mu);
+    pool_run(P, 0);
+    pthread_mutex_lock(&P->mu);
+    while (P->running) pthread_cond_wait(&P->cv_done, &P->mu);
+    pthread_mutex_unlock(&P->mu);
 }
 
 /* ---------------------------------------------------------------- reference fetch (src/BWT.cpp:593-666) */
@@ -233,27 +285,41 @@ static void revcomp_into(const char *s, char *out, uint32_t len) { for (uint32_t
 
 /* ================================================================ B: vote, candidates, selection */
 typedef struct { uint32_t win, cnt; } wc_t;
-static int wc_cmp(const void *a, const void *b) { uint32_t x = ((const wc_t *)a)->win, y = ((const wc_t *)b)->win; return x < y ? -1 : x > y; }
+
+/* LSD radix sort of (window, weight) pairs by window id, 11 bits per pass */
+static wc_t *radix_sort_wc(wc_t *a, wc_t *tmp, int n, uint32_t maxkey)
+{
+    for (int shift = 0; shift < 32 && (maxkey >> shift); shift += 11) {
+        uint32_t cnt[2049]; memset(cnt, 0, sizeof cnt);
+        for (int i = 0; i < n; i++) cnt[((a[i].win >> shift) & 2047) + 1]++;
+        for (int i = 1; i <= 2048; i++) cnt[i] += cnt[i - 1];
+        for (int i = 0; i < n; i++) tmp[cnt[(a[i].win >> shift) & 2047]++] = a[i];
+        wc_t *t = a; a = tmp; tmp = t;
+    }
+    return a;
+}
 
 /* sparse equivalent of the tagged dense array of src/LordFAST.cpp:588-620: every seed adds its weight to
- * windows floor(tPos/L) and floor(tPos/L)-1; returns the touched windows in ascending order */
-static int vote(const lf_params_t *p, uint32_t L, const Seed_t *s, uint32_t n, wc_t **buf, size_t *cap)
+ * windows floor(tPos/L) and floor(tPos/L)-1; returns the touched windows in ascending order in *out */
+static int vote(const lf_params_t *p, uint32_t L, const Seed_t *s, uint32_t n, wc_t **buf, size_t *cap, wc_t **out)
 {
-    if (*cap < 2 * (size_t)n + 2) { *cap = 2 * (size_t)n + 2; *buf = (wc_t *)realloc(*buf, *cap * sizeof(wc_t)); }
-    wc_t *w = *buf; int m = 0;
+    if (*cap < 4 * (size_t)n + 4) { *cap = 4 * (size_t)n + 4; *buf = (wc_t *)realloc(*buf, *cap * sizeof(wc_t)); }
+    wc_t *w = *buf; int m = 0; uint32_t mx = 0;
     for (uint32_t i = 0; i < n; i++) {
         uint32_t id = s[i].tPos / L;
         uint32_t weight = (uint32_t)(1 + ((int32_t)s[i].len - p->min_anchor_len));
+        if (id > mx) mx = id;
         w[m].win = id; w[m].cnt = weight; m++;
         if (id >= 1) { w[m].win = id - 1; w[m].cnt = weight; m++; }
     }
-    qsort(w, (size_t)m, sizeof(wc_t), wc_cmp);
+    w = radix_sort_wc(w, *buf + 2 * (size_t)n + 2, m, mx ? mx : 1);
     int d = 0;
     for (int i = 0; i < m; ) {
         uint32_t id = w[i].win, c = 0;
         while (i < m && w[i].win == id) c += w[i++].cnt;
         w[d].win = id; w[d].cnt = c; d++;
     }
+    *out = w;
     return d;
 }
 
@@ -314,6 +380,19 @@ static void phase_vote(ctx_t *cx, int tid, int ri)
     cstage_t *cs = &g_cstage[tid];
     r->vote_tid = tid;
     if ((int)r->len < p->min_read_len) { r->mode = 0; return; }
+    {   /* this read's hits -> the two SeedLists of the reference (forward / reverse), order kept */
+        const lfg_hits_t *h = cx->hits;
+        const uint64_t a = h->read_off[r->seed_idx], b = h->read_off[r->seed_idx + 1];
+        uint32_t nr = 0;
+        for (uint64_t j = a; j < b; j++) nr += h->strand[j];
+        r->nR = nr; r->nF = (uint32_t)(b - a) - nr;
+        r->F = (Seed_t *)malloc(((size_t)(b - a) + 2) * sizeof(Seed_t)); r->R = r->F + r->nF + 1;
+        uint32_t f = 0, v = 0;
+        for (uint64_t j = a; j < b; j++) {
+            Seed_t sd; sd.tPos = h->tpos[j]; sd.qPos = h->qpl[j] & 0xFFFFF; sd.len = h->qpl[j] >> 20;
+            if (h->strand[j]) r->R[v++] = sd; else r->F[f++] = sd;
+        }
+    }
     const uint32_t L = r->len;
     const uint32_t refWinNum = (uint32_t)cx->ix->l_pac / (uint32_t)p->min_read_len;          /* src/LordFAST.cpp:130 */
     uint32_t lim = (uint32_t)cx->ix->l_pac / L + 2;                                          /* :622-624 */
@@ -321,12 +400,13 @@ static void phase_vote(ctx_t *cx, int tid, int ri)
     const int maxWin = p->max_map;
     r->wins = (win_t *)calloc((size_t)maxWin + 1, sizeof(win_t));
     r->nWins = 0;
-    int dF = vote(p, L, r->F, r->nF, &cs->wbuf, &cs->wcap);
-    for (int k = 0; k < dF && cs->wbuf[k].win < lim; k++)
-        if (local_max(cs->wbuf, dF, k, refWinNum)) top_push(r->wins, &r->nWins, maxWin, cs->wbuf[k].win, L, (float)cs->wbuf[k].cnt, 0, -1);
-    int dR = vote(p, L, r->R, r->nR, &cs->wbuf2, &cs->wcap2);
-    for (int k = 0; k < dR && cs->wbuf2[k].win < lim; k++)
-        if (local_max(cs->wbuf2, dR, k, refWinNum)) top_push(r->wins, &r->nWins, maxWin, cs->wbuf2[k].win, L, (float)cs->wbuf2[k].cnt, 1, -1);
+    wc_t *wF, *wR;
+    int dF = vote(p, L, r->F, r->nF, &cs->wbuf, &cs->wcap, &wF);
+    for (int k = 0; k < dF && wF[k].win < lim; k++)
+        if (local_max(wF, dF, k, refWinNum)) top_push(r->wins, &r->nWins, maxWin, wF[k].win, L, (float)wF[k].cnt, 0, -1);
+    int dR = vote(p, L, r->R, r->nR, &cs->wbuf2, &cs->wcap2, &wR);
+    for (int k = 0; k < dR && wR[k].win < lim; k++)
+        if (local_max(wR, dR, k, refWinNum)) top_push(r->wins, &r->nWins, maxWin, wR[k].win, L, (float)wR[k].cnt, 1, -1);
     if (r->nWins == 0) { r->mode = 1; return; }
     winh_sort_heap(r->wins, r->nWins);                                                        /* :528 */
     const float scoreRatio = 4;
@@ -341,7 +421,7 @@ static void phase_vote(ctx_t *cx, int tid, int ri)
         const float minScore = (float)r->wins[0].score / scoreRatio;                          /* :553 */
         r->nWins = 0;
         for (int pass = 0; pass < 2; pass++) {
-            const wc_t *w = pass ? cs->wbuf2 : cs->wbuf; const int d = pass ? dR : dF;
+            const wc_t *w = pass ? wR : wF; const int d = pass ? dR : dF;
             for (int k = 0; k < d && w[k].win < lim; k++) {
                 if ((float)w[k].cnt > minScore && local_max(w, d, k, refWinNum)) {                /* :875-877 */
                     if (r->ncand == r->capcand) { r->capcand = r->capcand ? r->capcand * 2 : 8; r->cands = (struct cand *)realloc(r->cands, (size_t)r->capcand * sizeof(struct cand)); }
@@ -844,6 +924,13 @@ static void phase_prepare(ctx_t *cx, int tid, int ri)
     r->qual_rev[ql] = 0;
 }
 
+static void phase_concat(ctx_t *cx, int tid, int k)
+{
+    (void)tid;
+    const rd_t *r = &cx->reads[cx->seed_map[k]];
+    memcpy(cx->cat + cx->cat_off[k], r->seq, r->len);
+}
+
 static void phase_make_jobs(ctx_t *cx, int tid, int ri)
 {
     (void)tid;
@@ -874,6 +961,30 @@ static void phase_walk(ctx_t *cx, int tid, int ri)
     }
 }
 
+static void phase_merge_edlib(ctx_t *cx, int tid, int t)
+{
+    (void)tid;
+    stage_t *s = &cx->stages[t];
+    const uint64_t qo = cx->mg_qbase[t], to = cx->mg_tbase[t];
+    if (s->qn) memcpy(cx->mg_qb + qo, s->qb, s->qn);
+    if (s->tn) memcpy(cx->mg_tb + to, s->tb, s->tn);
+    int g = cx->mg_gbase[t];
+    for (int k = 0; k < s->n; k++, g++) {
+        cx->mg_qoff[g] = qo + s->qoff[k]; cx->mg_toff[g] = to + s->toff[k]; cx->mg_mode[g] = s->mode[k];
+        cx->mg_R->ops_off[g] = cx->mg_qoff[g] + cx->mg_toff[g];
+        memo_t *m = &g_ed_jobs[t].job[k]->memo[(uintptr_t)s->owner[k]];
+        m->round = cx->mg_round; m->slot = g;
+    }
+    s->n = 0; s->qn = 0; s->tn = 0; s->ext_bytes = 0; g_ed_jobs[t].n = 0;
+}
+
+static void phase_copy_out(ctx_t *cx, int tid, int ri)
+{
+    (void)tid;
+    memcpy(cx->out_base + cx->out_off[ri], cx->reads[ri].out.s, cx->reads[ri].out.n);
+    free(cx->reads[ri].out.s); cx->reads[ri].out.s = NULL;
+}
+
 static void phase_sam(ctx_t *cx, int tid, int ri)
 {
     (void)tid;
@@ -897,40 +1008,35 @@ static int map_chunk(ctx_t *cx)
     double t0 = now_ms(), t1;
 
     parallel_for(cx, n, phase_prepare);
+    if (getenv("LF_TIMING")) fprintf(stderr, "[lf] prepare %.1f ms\n", now_ms() - t0);
 
     /* ---- A: seeds ---- */
+    lfg_hits_t hits; memset(&hits, 0, sizeof hits);
     {
         int *map = (int *)malloc((size_t)n * sizeof(int)); int m = 0;
         uint64_t bases = 0;
-        for (int i = 0; i < n; i++) if ((int)cx->reads[i].len >= cx->p->min_read_len) { map[m++] = i; bases += cx->reads[i].len; }
+        for (int i = 0; i < n; i++) if ((int)cx->reads[i].len >= cx->p->min_read_len) { cx->reads[i].seed_idx = m; map[m++] = i; bases += cx->reads[i].len; }
         if (m) {
-            char *cat = (char *)malloc(bases + 1); uint64_t *off = (uint64_t *)malloc(((size_t)m + 1) * 8);
+            char *cat = (char *)lfg_pin_slot(LF_PS_READS, bases + 64);
+            uint64_t *off = (uint64_t *)lfg_pin_slot(LF_PS_READOFF, ((size_t)m + 1) * 8);
+            if (!cat || !off) { free(map); return LF_ERR_NOMEM; }
             uint64_t o = 0;
-            for (int k = 0; k < m; k++) { off[k] = o; memcpy(cat + o, cx->reads[map[k]].seq, cx->reads[map[k]].len); o += cx->reads[map[k]].len; }
+            for (int k = 0; k < m; k++) { off[k] = o; o += cx->reads[map[k]].len; }
             off[m] = o;
-            lfg_hits_t h;
-            rc = lfg_seed(cx->ix, cx->p, m, cat, off, &h);
-            free(cat); free(off);
+            cx->seed_map = map; cx->cat = cat; cx->cat_off = off;
+            double tc0 = now_ms();
+            parallel_for(cx, m, phase_concat);
+            if (getenv("LF_TIMING")) fprintf(stderr, "[lf] concat %.1f ms\n", now_ms() - tc0);
+            tc0 = now_ms();
+            rc = lfg_seed(cx->ix, cx->p, m, cat, off, &hits);
+            if (getenv("LF_TIMING")) fprintf(stderr, "[lf] lfg_seed %.1f ms (search %.1f locate %.1f), %llu hits\n", now_ms() - tc0, hits.ms_search, hits.ms_locate, (unsigned long long)hits.n_hits);
             if (rc != LF_OK) { free(map); return rc; }
-            for (int k = 0; k < m; k++) {
-                rd_t *r = &cx->reads[map[k]];
-                const uint64_t a = h.read_off[k], b = h.read_off[k + 1];
-                uint32_t nr = 0;
-                for (uint64_t j = a; j < b; j++) nr += h.strand[j];
-                r->nR = nr; r->nF = (uint32_t)(b - a) - nr;
-                r->F = (Seed_t *)malloc(((size_t)r->nF + 1) * sizeof(Seed_t)); r->R = (Seed_t *)malloc(((size_t)r->nR + 1) * sizeof(Seed_t));
-                uint32_t f = 0, v = 0;
-                for (uint64_t j = a; j < b; j++) {
-                    Seed_t sd; sd.tPos = h.tpos[j]; sd.qPos = h.qpl[j] & 0xFFFFF; sd.len = h.qpl[j] >> 20;
-                    if (h.strand[j]) r->R[v++] = sd; else r->F[f++] = sd;
-                }
-            }
-            st->n_seeds += h.n_hits; st->n_cache += h.counters[0]; st->n_occblk += h.counters[1]; st->n_sa += h.counters[2]; st->n_readbytes += h.counters[3];
-            st->ms_k_search += h.ms_search; st->ms_k_accept += h.ms_accept; st->ms_k_locate += h.ms_locate;
+            st->n_seeds += hits.n_hits; st->n_cache += hits.counters[0]; st->n_occblk += hits.counters[1]; st->n_sa += hits.counters[2]; st->n_readbytes += hits.counters[3];
+            st->ms_k_search += hits.ms_search; st->ms_k_accept += hits.ms_accept; st->ms_k_locate += hits.ms_locate;
             st->search_launches++; st->locate_launches++;
-            lfg_hits_free(&h);
         }
-        free(map);
+        free(map); cx->seed_map = NULL;
+        cx->hits = &hits;
     }
     t1 = now_ms(); st->ms_seed += t1 - t0; t0 = t1;
 
@@ -982,38 +1088,46 @@ static int map_chunk(ctx_t *cx)
     cx->stages = (stage_t *)calloc((size_t)nt, sizeof(stage_t));
     g_ed_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
     g_ksw_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
+    const int timing = getenv("LF_TIMING") != NULL;
     for (int round = 0; round < 64; round++) {
+        double tw0 = now_ms();
         parallel_for(cx, n, phase_walk);
+        if (timing) fprintf(stderr, "[lf] round %d walk %.1f ms\n", round, now_ms() - tw0);
         int ne = 0, nk = 0;
         for (int t = 0; t < nt; t++) { ne += cx->stages[t].n; nk += cx->stages[t].kn; }
         if (ne == 0 && nk == 0) break;
         if (ne) {
             uint64_t qn = 0, tn = 0;
-            for (int t = 0; t < nt; t++) { qn += cx->stages[t].qn; tn += cx->stages[t].tn; st->ext_bytes += cx->stages[t].ext_bytes; }
-            char *qb = (char *)malloc(qn + 1), *tb = (char *)malloc(tn + 1);
+            uint64_t *qbase = (uint64_t *)malloc((size_t)nt * 8), *tbase = (uint64_t *)malloc((size_t)nt * 8); int *gbase = (int *)malloc((size_t)nt * sizeof(int));
+            { int g0 = 0; for (int t = 0; t < nt; t++) { qbase[t] = qn; tbase[t] = tn; gbase[t] = g0; qn += cx->stages[t].qn; tn += cx->stages[t].tn; g0 += cx->stages[t].n; st->ext_bytes += cx->stages[t].ext_bytes; } }
+            const int ridx = cx->n_ed_rounds;
+            const int pin = ridx < 16;                       /* persistent pinned slots for the first rounds */
+            char *qb = (char *)lfg_pin_slot(LF_PS_ALN_Q, qn + 1), *tb = (char *)lfg_pin_slot(LF_PS_ALN_T, tn + 1);
             uint64_t *qoff = (uint64_t *)malloc(((size_t)ne + 1) * 8), *toff = (uint64_t *)malloc(((size_t)ne + 1) * 8);
             uint8_t *mode = (uint8_t *)malloc((size_t)ne);
             ed_round_t R; memset(&R, 0, sizeof R);
-            R.n = ne; R.ed = (int32_t *)malloc((size_t)ne * 4); R.end = (int32_t *)malloc((size_t)ne * 4);
-            R.ops_len = (uint32_t *)malloc((size_t)ne * 4); R.ops = (uint8_t *)malloc(qn + tn + 1); R.ops_off = (uint64_t *)malloc((size_t)ne * 8);
-            const int ridx = cx->n_ed_rounds;
-            int g = 0; uint64_t qo = 0, to = 0;
-            for (int t = 0; t < nt; t++) {
-                stage_t *s = &cx->stages[t];
-                memcpy(qb + qo, s->qb, s->qn); memcpy(tb + to, s->tb, s->tn);
-                for (int k = 0; k < s->n; k++, g++) {
-                    qoff[g] = qo + s->qoff[k]; toff[g] = to + s->toff[k]; mode[g] = s->mode[k];
-                    R.ops_off[g] = qoff[g] + toff[g];
-                    memo_t *m = &g_ed_jobs[t].job[k]->memo[(uintptr_t)s->owner[k]];
-                    m->round = ridx; m->slot = g;
-                }
-                qo += s->qn; to += s->tn;
-                s->n = 0; s->qn = 0; s->tn = 0; s->ext_bytes = 0; g_ed_jobs[t].n = 0;
+            R.n = ne; R.pinned = pin;
+            if (pin) {
+                R.ed = (int32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx, (size_t)ne * 4); R.end = (int32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 1, (size_t)ne * 4);
+                R.ops_len = (uint32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 2, (size_t)ne * 4); R.ops = (uint8_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 3, qn + tn + 1);
+            } else {
+                R.ed = (int32_t *)malloc((size_t)ne * 4); R.end = (int32_t *)malloc((size_t)ne * 4);
+                R.ops_len = (uint32_t *)malloc((size_t)ne * 4); R.ops = (uint8_t *)malloc(qn + tn + 1);
             }
-            qoff[ne] = qo; toff[ne] = to;
+            R.ops_off = (uint64_t *)malloc((size_t)ne * 8);
+            if (!qb || !tb || !R.ed || !R.end || !R.ops_len || !R.ops) return LF_ERR_NOMEM;
+            cx->mg_qb = qb; cx->mg_tb = tb; cx->mg_qoff = qoff; cx->mg_toff = toff; cx->mg_mode = mode; cx->mg_R = &R;
+            cx->mg_qbase = qbase; cx->mg_tbase = tbase; cx->mg_gbase = gbase; cx->mg_round = ridx;
+            double tm0 = now_ms();
+            parallel_for(cx, nt, phase_merge_edlib);         /* every worker copies its own staged requests */
+            if (timing) fprintf(stderr, "[lf] round %d merge %.1f ms (%d problems, %.1f MB)\n", round, now_ms() - tm0, ne, (qn + tn) / 1e6);
+            qoff[ne] = qn; toff[ne] = tn;
+            free(qbase); free(tbase); free(gbase);
             float ms = 0; uint64_t launches = 0;
+            double ts0 = now_ms();
             rc = lf_edlib_solve(cx->ix->device, ne, qb, qoff, tb, toff, mode, R.ed, R.end, R.ops, R.ops_len, &ms, &launches);
-            free(qb); free(tb); free(qoff); free(toff); free(mode);
+            if (timing) fprintf(stderr, "[lf] round %d edlib solve %.1f ms (kernels %.1f ms)\n", round, now_ms() - ts0, ms);
+            free(qoff); free(toff); free(mode);
             cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
             cx->ed_rounds[cx->n_ed_rounds++] = R;
             if (rc != LF_OK) return rc;
@@ -1063,12 +1177,12 @@ static void chunk_free(ctx_t *cx)
 {
     for (int i = 0; i < cx->n_reads; i++) {
         rd_t *r = &cx->reads[i];
-        free(r->seq_rev); free(r->qual_rev); free(r->F); free(r->R); free(r->cands); free(r->wins);
+        free(r->seq_rev); free(r->qual_rev); free(r->F); free(r->cands); free(r->wins);
         if (r->jobs) { for (int w = 0; w < r->nWins; w++) { free(r->jobs[w].chain); free(r->jobs[w].memo); } free(r->jobs); }
         if (r->maps) { for (int w = 0; w <= cx->p->max_map && (r->mode >= 2 || w < 2); w++) { samlist_clear(&r->maps[w]); free(r->maps[w].v); } free(r->maps); }
     }
     free(cx->creq); free(cx->cseeds); free(cx->chain_idx); free(cx->chain_len); free(cx->chain_score);
-    for (int k = 0; k < cx->n_ed_rounds; k++) { ed_round_t *R = &cx->ed_rounds[k]; free(R->ed); free(R->end); free(R->ops_len); free(R->ops); free(R->ops_off); }
+    for (int k = 0; k < cx->n_ed_rounds; k++) { ed_round_t *R = &cx->ed_rounds[k]; if (!R->pinned) { free(R->ed); free(R->end); free(R->ops_len); free(R->ops); } free(R->ops_off); }
     for (int k = 0; k < cx->n_ksw_rounds; k++) { ksw_round_t *R = &cx->ksw_rounds[k]; free(R->score); free(R->qle); free(R->tle); }
     free(cx->ed_rounds); free(cx->ksw_rounds);
     if (cx->stages) {
@@ -1126,7 +1240,15 @@ int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *
         }
         st->n_reads += (uint64_t)cx.n_reads;
         rc = map_chunk(&cx);
-        if (rc == LF_OK) for (int i = 0; i < cx.n_reads; i++) str_putn(&all, cx.reads[i].out.s, cx.reads[i].out.n);
+        if (rc == LF_OK) {
+            uint64_t *ooff = (uint64_t *)malloc(((size_t)cx.n_reads + 1) * 8), tot = 0;
+            for (int i = 0; i < cx.n_reads; i++) { ooff[i] = tot; tot += cx.reads[i].out.n; }
+            str_room(&all, tot);
+            cx.out_base = all.s + all.n; cx.out_off = ooff;
+            parallel_for(&cx, cx.n_reads, phase_copy_out);
+            all.n += tot; all.s[all.n] = 0;
+            free(ooff);
+        }
         for (int i = 0; i < cx.n_reads; i++) free(cx.reads[i].out.s);
         chunk_free(&cx);
         free(cx.reads);

@@ -281,24 +281,26 @@ extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_r
     if (!st) { lf_set_error("index is not on a device"); return LF_ERR_NO_DEVICE; }
     HIPCHK(hipSetDevice(ix->device));
     hipStream_t s = st->stream;
+    const int dv = ix->device;
     const uint32_t hc = (uint32_t)p->sampling_count;
     const size_t total = (size_t)n_reads * hc;
     const uint64_t n_bases = off[n_reads];
+    if (total + 1 >= (1ull << 31)) { lf_set_error("seed batch too large (%zu samples): split the batch", total); return LF_ERR_ARG; }
 
-    char *d_reads = nullptr; uint64_t *d_off = nullptr, *d_hit_off = nullptr, *d_read_off = nullptr;
-    uint32_t *d_pos = nullptr, *d_cnt = nullptr, *d_tpos = nullptr, *d_qpl = nullptr; uint8_t *d_strand = nullptr;
-    lf_sample_t *d_smp = nullptr; unsigned long long *d_counters = nullptr; void *d_tmp = nullptr;
+    /* persistent device buffers (lf_mem.hip): no hipMalloc in the steady state */
+#define DSLOT(T, k, bytes) (T *)lfg_dev_slot(dv, LF_DS_SEED0 + (k), (bytes))
+    char *d_reads = DSLOT(char, 0, n_bases + 64);
+    uint64_t *d_off = DSLOT(uint64_t, 1, (size_t)(n_reads + 1) * 8);
+    uint32_t *d_pos = DSLOT(uint32_t, 2, total * 4 + 4);
+    lf_sample_t *d_smp = DSLOT(lf_sample_t, 3, total * sizeof(lf_sample_t) + 16);
+    uint32_t *d_cnt = DSLOT(uint32_t, 4, (total + 1) * 4);
+    uint64_t *d_hit_off = DSLOT(uint64_t, 5, (total + 1) * 8);
+    uint64_t *d_read_off = DSLOT(uint64_t, 6, (size_t)(n_reads + 1) * 8);
+    unsigned long long *d_counters = DSLOT(unsigned long long, 7, 64);
+    if (!d_reads || !d_off || !d_pos || !d_smp || !d_cnt || !d_hit_off || !d_read_off || !d_counters) return LF_ERR_NOMEM;
     hipEvent_t ev[6];
     for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&ev[i]));
 
-    HIPCHK(hipMalloc(&d_reads, n_bases + 64));
-    HIPCHK(hipMalloc(&d_off, (size_t)(n_reads + 1) * 8));
-    HIPCHK(hipMalloc(&d_pos, total * 4 + 4));
-    HIPCHK(hipMalloc(&d_smp, total * sizeof(lf_sample_t) + 16));
-    HIPCHK(hipMalloc(&d_cnt, (total + 1) * 4));
-    HIPCHK(hipMalloc(&d_hit_off, (total + 1) * 8));
-    HIPCHK(hipMalloc(&d_read_off, (size_t)(n_reads + 1) * 8));
-    HIPCHK(hipMalloc(&d_counters, 4 * 8));
     HIPCHK(hipMemsetAsync(d_counters, 0, 32, s));
     HIPCHK(hipMemcpyAsync(d_reads, reads, n_bases, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
@@ -314,27 +316,33 @@ extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_r
     /* u32 counts summed into u64 offsets */
     hipcub::TransformInputIterator<uint64_t, lf_widen_op, uint32_t *> cnt64(d_cnt, lf_widen_op());
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt64, d_hit_off, (int)(total + 1), s));
-    HIPCHK(hipMalloc(&d_tmp, tmp_bytes + 16));
+    void *d_tmp = lfg_dev_slot(dv, LF_DS_SEED0 + 8, tmp_bytes + 16);
+    if (!d_tmp) return LF_ERR_NOMEM;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, cnt64, d_hit_off, (int)(total + 1), s));
     HIPCHK(hipEventRecord(ev[2], s));
-    uint64_t n_hits = 0;
-    HIPCHK(hipMemcpyAsync(&n_hits, d_hit_off + total, 8, hipMemcpyDeviceToHost, s));
+    uint64_t *h_nhits = (uint64_t *)lfg_pin_slot(LF_PS_HITS_OFF, (size_t)(n_reads + 2) * 8);
+    if (!h_nhits) return LF_ERR_NOMEM;
+    HIPCHK(hipMemcpyAsync(h_nhits, d_hit_off + total, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    const uint64_t n_hits = h_nhits[0];
 
-    HIPCHK(hipMalloc(&d_tpos, (n_hits + 1) * 4));
-    HIPCHK(hipMalloc(&d_qpl, (n_hits + 1) * 4));
-    HIPCHK(hipMalloc(&d_strand, n_hits + 16));
+    uint32_t *d_tpos = DSLOT(uint32_t, 9, (n_hits + 1) * 4);
+    uint32_t *d_qpl = DSLOT(uint32_t, 10, (n_hits + 1) * 4);
+    uint8_t *d_strand = DSLOT(uint8_t, 11, n_hits + 16);
+    if (!d_tpos || !d_qpl || !d_strand) return LF_ERR_NOMEM;
     HIPCHK(hipEventRecord(ev[3], s));
     hipLaunchKernelGGL(lf_seed_locate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, st->view, n_reads, d_off, hc,
                        d_pos, d_smp, d_cnt, d_hit_off, d_tpos, d_qpl, d_strand, d_counters);
     HIPCHK(hipEventRecord(ev[4], s));
     hipLaunchKernelGGL(lf_read_first_hit_kernel, dim3((n_reads + 1 + 255) / 256), dim3(256), 0, s, n_reads, hc, d_hit_off, n_hits, d_read_off);
 
+    /* results land in pinned host slots (valid until the next lfg_seed call) */
     out->n_hits = n_hits;
-    out->tpos = (uint32_t *)malloc((n_hits + 1) * 4);
-    out->qpl = (uint32_t *)malloc((n_hits + 1) * 4);
-    out->strand = (uint8_t *)malloc(n_hits + 1);
-    out->read_off = (uint64_t *)malloc((size_t)(n_reads + 1) * 8);
+    out->tpos = (uint32_t *)lfg_pin_slot(LF_PS_HITS_T, (n_hits + 1) * 4);
+    out->qpl = (uint32_t *)lfg_pin_slot(LF_PS_HITS_Q, (n_hits + 1) * 4);
+    out->strand = (uint8_t *)lfg_pin_slot(LF_PS_HITS_S, n_hits + 1);
+    out->read_off = h_nhits;
+    if (!out->tpos || !out->qpl || !out->strand) return LF_ERR_NOMEM;
     HIPCHK(hipMemcpyAsync(out->tpos, d_tpos, n_hits * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out->qpl, d_qpl, n_hits * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out->strand, d_strand, n_hits, hipMemcpyDeviceToHost, s));
@@ -346,16 +354,12 @@ extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_r
     HIPCHK(hipEventElapsedTime(&out->ms_search, ev[0], ev[1]));
     HIPCHK(hipEventElapsedTime(&out->ms_accept, ev[1], ev[2]));
     HIPCHK(hipEventElapsedTime(&out->ms_locate, ev[3], ev[4]));
-
     for (int i = 0; i < 6; i++) (void)hipEventDestroy(ev[i]);
-    (void)hipFree(d_reads); (void)hipFree(d_off); (void)hipFree(d_pos); (void)hipFree(d_smp); (void)hipFree(d_cnt);
-    (void)hipFree(d_hit_off); (void)hipFree(d_read_off); (void)hipFree(d_counters); (void)hipFree(d_tmp);
-    (void)hipFree(d_tpos); (void)hipFree(d_qpl); (void)hipFree(d_strand);
+#undef DSLOT
     return LF_OK;
 }
 
 extern "C" void lfg_hits_free(lfg_hits_t *h)
 {
-    free(h->tpos); free(h->qpl); free(h->strand); free(h->read_off);
-    memset(h, 0, sizeof(*h));
+    memset(h, 0, sizeof(*h));      /* the arrays live in persistent pinned slots */
 }
