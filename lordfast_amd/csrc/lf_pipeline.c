@@ -1173,14 +1173,18 @@ static int map_chunk(ctx_t *cx)
     return LF_OK;
 }
 
+static void phase_free_read(ctx_t *cx, int tid, int i)
+{
+    (void)tid;
+    rd_t *r = &cx->reads[i];
+    free(r->seq_rev); free(r->qual_rev); free(r->F); free(r->cands); free(r->wins);
+    if (r->jobs) { for (int w = 0; w < r->nWins; w++) { free(r->jobs[w].chain); free(r->jobs[w].memo); } free(r->jobs); }
+    if (r->maps) { for (int w = 0; w <= cx->p->max_map && (r->mode >= 2 || w < 2); w++) { samlist_clear(&r->maps[w]); free(r->maps[w].v); } free(r->maps); }
+}
+
 static void chunk_free(ctx_t *cx)
 {
-    for (int i = 0; i < cx->n_reads; i++) {
-        rd_t *r = &cx->reads[i];
-        free(r->seq_rev); free(r->qual_rev); free(r->F); free(r->cands); free(r->wins);
-        if (r->jobs) { for (int w = 0; w < r->nWins; w++) { free(r->jobs[w].chain); free(r->jobs[w].memo); } free(r->jobs); }
-        if (r->maps) { for (int w = 0; w <= cx->p->max_map && (r->mode >= 2 || w < 2); w++) { samlist_clear(&r->maps[w]); free(r->maps[w].v); } free(r->maps); }
-    }
+    parallel_for(cx, cx->n_reads, phase_free_read);
     free(cx->creq); free(cx->cseeds); free(cx->chain_idx); free(cx->chain_len); free(cx->chain_score);
     for (int k = 0; k < cx->n_ed_rounds; k++) { ed_round_t *R = &cx->ed_rounds[k]; if (!R->pinned) { free(R->ed); free(R->end); free(R->ops_len); free(R->ops); } free(R->ops_off); }
     for (int k = 0; k < cx->n_ksw_rounds; k++) { ksw_round_t *R = &cx->ksw_rounds[k]; free(R->score); free(R->qle); free(R->tle); }
@@ -1213,13 +1217,32 @@ int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *
     memset(st, 0, sizeof *st);
     int nt = p->threads;
     long online = sysconf(_SC_NPROCESSORS_ONLN);
-    if (nt <= 0 || nt > online) nt = (int)online;                      /* src/CommandLineParser.cpp:181-185 */
+    if (nt <= 0 || nt > online) {                                      /* "all CPUs", src/CommandLineParser.cpp:181-185 ... */
+        nt = (int)online;
+        /* ... but not more than the cgroup CPU quota grants: oversubscribing a throttled container only adds
+         * context switches (cpu.max = "<quota> <period>" on cgroup v2) */
+        FILE *fq = fopen("/sys/fs/cgroup/cpu.max", "r");
+        if (fq) {
+            long long quota = 0, period = 0; char qs[64];
+            if (fscanf(fq, "%63s %lld", qs, &period) == 2 && strcmp(qs, "max") != 0 && period > 0) {
+                quota = atoll(qs);
+                int lim = (int)((quota + period - 1) / period);
+                if (lim >= 1 && lim < nt) nt = lim;
+            }
+            fclose(fq);
+        }
+    }
     if (nt > 255) nt = 255;
     if (nt < 1) nt = 1;
     const double T0 = now_ms();
     pthread_mutex_lock(&g_map_lock);
 
     str_t all; str_init(&all);
+    {   /* one allocation for the SAM text: ~2 x bases (SEQ + CIGAR/MD) + per-record overhead */
+        uint64_t est = 4096;
+        for (int i = 0; i < n; i++) est += 2 * strlen(seqs[i]) + strlen(names[i]) + 512;
+        str_room(&all, est + est / 8);
+    }
     int rc = LF_OK;
     /* chunks bound the device + host working set; reads stay in input order */
     const uint64_t CHUNK_BASES = 400ull << 20; const int CHUNK_READS = 32768;
