@@ -21,13 +21,42 @@
 #include <numeric>
 
 struct lf_aln_prob {
-    uint64_t qoff, toff;     /* into the uploaded byte strings */
+    int64_t  qstart, tstart; /* element 0 of query / target: byte index (ASCII buffers) or pac coordinate */
     uint64_t ops_off;        /* output ops region (capacity n + m) */
     uint64_t hist_base;      /* 16-byte entries; wave-transposed (template classes) or private (generic) */
-    uint64_t aux_off;        /* generic kernel: private state words; colscores: output offset */
+    uint64_t aux_off;        /* generic kernel: private state words */
     uint32_t n, m;
     uint32_t id;             /* original problem index */
-    uint8_t  mode, task, rev, pad;
+    uint8_t  mode, task, flags, pad;
+};
+/* flags: how element i of a sequence is fetched -- index start +/- i, optionally complemented.  Requests of the
+ * mapping pipeline are DESCRIPTORS into the read batch and the 2-bit reference already resident in HBM
+ * (no byte staging, no H2D of sequences); the stage API uploads byte strings and uses the same accessors. */
+
+struct lf_seqs { const unsigned char *q; const unsigned char *t; const uint8_t *pac; };
+
+__device__ __forceinline__ unsigned char lf_rc_char(unsigned char c)
+{
+    switch (c) {
+    case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+    case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
+    default: return 'N';
+    }
+}
+struct lf_qacc {
+    const unsigned char *b; int64_t start; int dir; bool comp;
+    __device__ __forceinline__ lf_qacc(const lf_seqs &S, const lf_aln_prob &p) : b(S.q), start(p.qstart), dir((p.flags & LF_F_QREV) ? -1 : 1), comp(p.flags & LF_F_QCOMP) {}
+    __device__ __forceinline__ unsigned char get(uint32_t i) const { const unsigned char c = b[start + (int64_t)dir * (int64_t)i]; return comp ? lf_rc_char(c) : c; }
+};
+struct lf_tacc {
+    const unsigned char *b; const uint8_t *pac; int64_t start; int dir; bool comp, is_pac;
+    __device__ __forceinline__ lf_tacc(const lf_seqs &S, const lf_aln_prob &p) : b(S.t), pac(S.pac), start(p.tstart), dir((p.flags & LF_F_TREV) ? -1 : 1), comp(p.flags & LF_F_TCOMP), is_pac(p.flags & LF_F_TPAC) {}
+    __device__ __forceinline__ unsigned char get(uint32_t i) const {
+        const int64_t x = start + (int64_t)dir * (int64_t)i;
+        if (is_pac) { int c = (pac[x >> 2] >> ((~x & 3) << 1)) & 3; if (comp) c = 3 - c; return (unsigned char)"ACGT"[c]; }
+        const unsigned char c = b[x];
+        return comp ? lf_rc_char(c) : c;
+    }
 };
 
 struct lf_hist_t { uint64_t pv, ph; };
@@ -64,7 +93,7 @@ __device__ __forceinline__ void lf_plane_add(unsigned char ch, int bit, uint64_t
 
 /* Eq mask of target byte tc against a block; tc outside ACGT: exact byte compare (general alphabets) */
 __device__ __forceinline__ uint64_t lf_eq_mask(unsigned char tc, uint64_t lo, uint64_t hi, uint64_t valid,
-                                               const unsigned char *q, uint32_t n, uint32_t blk, bool rev)
+                                               const lf_qacc &Q, uint32_t n, uint32_t blk)
 {
     int c;
     switch (tc) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break; default: c = -1; }
@@ -75,7 +104,7 @@ __device__ __forceinline__ uint64_t lf_eq_mask(unsigned char tc, uint64_t lo, ui
     uint64_t e = 0;
     for (uint32_t i = 0; i < 64; i++) {
         const uint32_t r = blk * 64 + i;
-        if (r < n && q[rev ? n - 1 - r : r] == tc) e |= 1ull << i;
+        if (r < n && Q.get(r) == tc) e |= 1ull << i;
     }
     return e;
 }
@@ -85,15 +114,14 @@ __device__ __forceinline__ uint64_t lf_eq_mask(unsigned char tc, uint64_t lo, ui
  * ---------------------------------------------------------------------------------------------- */
 template <int NB>
 __global__ void __launch_bounds__(64)
-lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, const unsigned char *__restrict__ qs,
-                const unsigned char *__restrict__ ts, lf_hist_t *__restrict__ hist, uint8_t *__restrict__ ops,
+lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ hist, uint8_t *__restrict__ ops,
                 int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
 {
     const int gid = blockIdx.x * 64 + threadIdx.x;
     const int lane = threadIdx.x;
     if (gid >= n_probs) return;
     const lf_aln_prob pr = probs[gid];
-    const unsigned char *q = qs + pr.qoff, *t = ts + pr.toff;
+    const lf_qacc Q(S, pr); const lf_tacc T(S, pr);
     const uint32_t n = pr.n, m = pr.m;
 
     uint64_t lo[NB], hi[NB], valid[NB], Pv[NB], Mv[NB];
@@ -101,7 +129,7 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, const unsign
     for (int b = 0; b < NB; b++) { lo[b] = hi[b] = valid[b] = 0; Pv[b] = ~0ull; Mv[b] = 0; }
 #pragma unroll
     for (int b = 0; b < NB; b++)
-        for (int i = 0; i < 64; i++) { const uint32_t r = b * 64 + i; if (r < n) lf_plane_add(q[r], i, lo[b], hi[b], valid[b]); }
+        for (int i = 0; i < 64; i++) { const uint32_t r = b * 64 + i; if (r < n) lf_plane_add(Q.get(r), i, lo[b], hi[b], valid[b]); }
 
     const int lastb = (int)((n - 1) >> 6), lastbit = (int)((n - 1) & 63);
     int score = (int)n;                     /* D[n][0] */
@@ -112,11 +140,11 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, const unsign
     const bool want_path = pr.task == LF_TASK_PATH;
 
     for (uint32_t c = 1; c <= m; c++) {
-        const unsigned char tc = t[c - 1];
+        const unsigned char tc = T.get(c - 1);
         int hin = 1;
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-            const uint64_t Eq = lf_eq_mask(tc, lo[b], hi[b], valid[b], q, n, b, false);
+            const uint64_t Eq = lf_eq_mask(tc, lo[b], hi[b], valid[b], Q, n, b);
             uint64_t ph, mh;
             hin = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
             if (b == lastb) score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
@@ -141,7 +169,7 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, const unsign
         const int bit = (int)((r - 1) & 63);
         if ((e.pv >> bit) & 1) { o[--w] = 1; r--; }
         else if ((e.ph >> bit) & 1) { o[--w] = 2; c--; }
-        else { o[--w] = (q[r - 1] == t[c - 1]) ? 0 : 3; r--; c--; }
+        else { o[--w] = (Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
     }
     while (c > 0) { o[--w] = 2; c--; }
     while (r > 0) { o[--w] = 1; r--; }
@@ -158,22 +186,20 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, const unsign
  * ---------------------------------------------------------------------------------------------- */
 #define LF_TASK_COLS 2
 __global__ void __launch_bounds__(64)
-lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, const unsigned char *__restrict__ qs,
-                        const unsigned char *__restrict__ ts, lf_hist_t *__restrict__ hist, uint64_t *__restrict__ aux,
+lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ hist, uint64_t *__restrict__ aux,
                         uint8_t *__restrict__ ops, int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end,
                         uint32_t *__restrict__ out_len, int32_t *__restrict__ out_cols, const uint64_t *__restrict__ cols_off)
 {
     const int gid = blockIdx.x * 64 + threadIdx.x;
     if (gid >= n_probs) return;
     const lf_aln_prob pr = probs[gid];
-    const unsigned char *q = qs + pr.qoff, *t = ts + pr.toff;
+    const lf_qacc Q(S, pr); const lf_tacc T(S, pr);
     const uint32_t n = pr.n, m = pr.m;
-    const bool rev = pr.rev != 0;
     const uint32_t nbk = (n + 63) >> 6;
     uint64_t *st = aux + pr.aux_off;       /* [b*5 + {0 lo,1 hi,2 valid,3 Pv,4 Mv}] */
     for (uint32_t b = 0; b < nbk; b++) {
         uint64_t lo = 0, hi = 0, valid = 0;
-        for (int i = 0; i < 64; i++) { const uint32_t r = b * 64 + i; if (r < n) lf_plane_add(q[rev ? n - 1 - r : r], i, lo, hi, valid); }
+        for (int i = 0; i < 64; i++) { const uint32_t r = b * 64 + i; if (r < n) lf_plane_add(Q.get(r), i, lo, hi, valid); }
         st[b * 5 + 0] = lo; st[b * 5 + 1] = hi; st[b * 5 + 2] = valid; st[b * 5 + 3] = ~0ull; st[b * 5 + 4] = 0;
     }
     const uint32_t lastb = (n - 1) >> 6; const int lastbit = (int)((n - 1) & 63);
@@ -182,11 +208,11 @@ lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, cons
     lf_hist_t *h = hist + pr.hist_base;
     const bool want_path = pr.task == LF_TASK_PATH;
     for (uint32_t c = 1; c <= m; c++) {
-        const unsigned char tc = t[rev ? m - c : c - 1];
+        const unsigned char tc = T.get(c - 1);
         int hin = 1;
         for (uint32_t b = 0; b < nbk; b++) {
             uint64_t Pv = st[b * 5 + 3], Mv = st[b * 5 + 4];
-            const uint64_t Eq = lf_eq_mask(tc, st[b * 5 + 0], st[b * 5 + 1], st[b * 5 + 2], q, n, b, rev);
+            const uint64_t Eq = lf_eq_mask(tc, st[b * 5 + 0], st[b * 5 + 1], st[b * 5 + 2], Q, n, b);
             uint64_t ph, mh;
             hin = lf_myers_step(Pv, Mv, Eq, hin, ph, mh);
             st[b * 5 + 3] = Pv; st[b * 5 + 4] = Mv;
@@ -220,7 +246,7 @@ lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, cons
         const int bit = (int)((r - 1) & 63);
         if ((e.pv >> bit) & 1) { o[--w] = 1; r--; }
         else if ((e.ph >> bit) & 1) { o[--w] = 2; c--; }
-        else { o[--w] = (q[r - 1] == t[c - 1]) ? 0 : 3; r--; c--; }
+        else { o[--w] = (Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
     }
     while (c > 0) { o[--w] = 2; c--; }
     while (r > 0) { o[--w] = 1; r--; }
@@ -238,17 +264,15 @@ lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, cons
  * ---------------------------------------------------------------------------------------------- */
 template <int KB>
 __global__ void __launch_bounds__(64)
-lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, const unsigned char *__restrict__ qs,
-                     const unsigned char *__restrict__ ts, lf_hist_t *__restrict__ hist,
+lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ hist,
                      uint8_t *__restrict__ ops, int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end,
                      uint32_t *__restrict__ out_len, int32_t *__restrict__ out_cols, const uint64_t *__restrict__ cols_off)
 {
     if ((int)blockIdx.x >= n_probs) return;
     const int lane = threadIdx.x;
     const lf_aln_prob pr = probs[blockIdx.x];
-    const unsigned char *q = qs + pr.qoff, *t = ts + pr.toff;
+    const lf_qacc Q(S, pr); const lf_tacc T(S, pr);
     const uint32_t n = pr.n, m = pr.m;
-    const bool rev = pr.rev != 0;
     const uint32_t nbk = (n + 63) >> 6;
     const int nl = (int)((nbk + KB - 1) / KB);            /* lanes that own at least one block */
     uint64_t lo[KB], hi[KB], valid[KB], Pv[KB], Mv[KB];
@@ -256,7 +280,7 @@ lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, const u
     for (int k = 0; k < KB; k++) {
         lo[k] = hi[k] = valid[k] = 0; Pv[k] = ~0ull; Mv[k] = 0;
         const uint32_t b = (uint32_t)lane * KB + k;
-        if (b < nbk) for (int i = 0; i < 64; i++) { const uint32_t r = b * 64 + i; if (r < n) lf_plane_add(q[rev ? n - 1 - r : r], i, lo[k], hi[k], valid[k]); }
+        if (b < nbk) for (int i = 0; i < 64; i++) { const uint32_t r = b * 64 + i; if (r < n) lf_plane_add(Q.get(r), i, lo[k], hi[k], valid[k]); }
     }
     const uint32_t lastb = (n - 1) >> 6; const int lastbit = (int)((n - 1) & 63);
     const int lane_last = (int)(lastb / KB);
@@ -269,13 +293,13 @@ lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, const u
         const int from_left = __shfl_up(hout_prev, 1);
         const int c = s - lane + 1;
         if (lane < nl && c >= 1 && c <= (int)m) {
-            const unsigned char tc = t[rev ? (int)m - c : c - 1];
+            const unsigned char tc = T.get((uint32_t)(c - 1));
             int hin = lane == 0 ? 1 : from_left;
 #pragma unroll
             for (int k = 0; k < KB; k++) {
                 const uint32_t b = (uint32_t)lane * KB + k;
                 if (b < nbk) {
-                    const uint64_t Eq = lf_eq_mask(tc, lo[k], hi[k], valid[k], q, n, b, rev);
+                    const uint64_t Eq = lf_eq_mask(tc, lo[k], hi[k], valid[k], Q, n, b);
                     uint64_t ph, mh;
                     hin = lf_myers_step(Pv[k], Mv[k], Eq, hin, ph, mh);
                     if (b == lastb) score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
@@ -331,7 +355,7 @@ lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, const u
         const int bit = (int)((r - 1) & 63);
         if ((e.pv >> bit) & 1) { o[--w] = 1; r--; }
         else if ((e.ph >> bit) & 1) { o[--w] = 2; c--; }
-        else { o[--w] = (q[r - 1] == t[c - 1]) ? 0 : 3; r--; c--; }
+        else { o[--w] = (Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
     }
     while (c > 0) { o[--w] = 2; c--; }
     while (r > 0) { o[--w] = 1; r--; }
@@ -380,15 +404,22 @@ static void sort_by_m(std::vector<lf_aln_prob> &v, bool descending)
 }
 
 /* runs DIST/PATH problems (cols == nullptr) or COLS problems (cols != nullptr) */
+struct lf_desc_src { const lf_aln_desc_t *d; const uint64_t *ops_off; uint64_t ops_total; const unsigned char *d_reads; const uint8_t *d_pac; };
+
 static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
                      const uint8_t *mode, const uint8_t *task, const uint8_t *rev, int32_t *ed, int32_t *endloc,
-                     uint8_t *ops, uint32_t *ops_len, int32_t *cols, const uint64_t *cols_off, float *ms)
+                     uint8_t *ops, uint32_t *ops_len, int32_t *cols, const uint64_t *cols_off, float *ms,
+                     const lf_desc_src *D = nullptr)
 {
     if (ms) *ms = 0;
     if (n == 0) return LF_OK;
     if (lfg_device_count() <= device) { lf_set_error("no gfx950 device %d visible (no CPU path)", device); return LF_ERR_NO_DEVICE; }
     HIPCHK(hipSetDevice(device));
-    const uint64_t qbytes = qoff[n], tbytes = toff[n];
+    const uint64_t qbytes = D ? 0 : qoff[n], tbytes = D ? 0 : toff[n];
+    const uint64_t ops_bytes = D ? D->ops_total : qbytes + tbytes;
+#define PN(i) (D ? D->d[i].n : (uint32_t)(qoff[(i) + 1] - qoff[i]))
+#define PM(i) (D ? D->d[i].m : (uint32_t)(toff[(i) + 1] - toff[i]))
+#define POPS(i) (D ? D->ops_off[i] : qoff[i] + toff[i])
 
     /* bin + order */
     std::vector<lf_aln_prob> P[7];     /* 0 generic lane kernel, 1..4 -> NB 1,2,4,8 lane classes, 5/6 wave kernel KB 1/4 */
@@ -396,7 +427,7 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     {
         size_t c[7] = { 0, 0, 0, 0, 0, 0, 0 };
         for (int i = 0; i < n; i++) {
-            const uint32_t nn = (uint32_t)(qoff[i + 1] - qoff[i]), mm = (uint32_t)(toff[i + 1] - toff[i]);
+            const uint32_t nn = PN(i), mm = PM(i);
             if (nn == 0 || (mm == 0 && !cols)) continue;
             const int cls = cols ? 0 : class_nb(nn);
             int slot = cls == 0 ? 0 : (cls == 1 ? 1 : cls == 2 ? 2 : cls == 4 ? 3 : 4);
@@ -407,9 +438,14 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     }
     for (int i = 0; i < n; i++) {
         lf_aln_prob pr; memset(&pr, 0, sizeof pr);
-        pr.qoff = qoff[i]; pr.toff = toff[i]; pr.n = (uint32_t)(qoff[i + 1] - qoff[i]); pr.m = (uint32_t)(toff[i + 1] - toff[i]);
-        pr.ops_off = qoff[i] + toff[i]; pr.id = (uint32_t)i;
-        pr.mode = mode ? mode[i] : 0; pr.task = cols ? LF_TASK_COLS : (task ? task[i] : LF_TASK_PATH); pr.rev = rev ? rev[i] : 0;
+        pr.n = PN(i); pr.m = PM(i); pr.ops_off = POPS(i); pr.id = (uint32_t)i;
+        if (D) { pr.qstart = D->d[i].qstart; pr.tstart = D->d[i].tstart; pr.flags = (uint8_t)(D->d[i].flags | LF_F_TPAC); pr.mode = D->d[i].mode; pr.task = LF_TASK_PATH; }
+        else {
+            const bool rv = rev && rev[i];                    /* Hirschberg right half: both strings walked backwards */
+            pr.qstart = (int64_t)qoff[i] + (rv ? (int64_t)pr.n - 1 : 0); pr.tstart = (int64_t)toff[i] + (rv ? (int64_t)pr.m - 1 : 0);
+            pr.flags = rv ? (LF_F_QREV | LF_F_TREV) : 0;
+            pr.mode = mode ? mode[i] : 0; pr.task = cols ? LF_TASK_COLS : (task ? task[i] : LF_TASK_PATH);
+        }
         if (pr.n == 0 || (pr.m == 0 && !cols)) { trivial.push_back(i); continue; }
         const int cls = cols ? 0 : class_nb(pr.n);
         int slot = cls == 0 ? 0 : (cls == 1 ? 1 : cls == 2 ? 2 : cls == 4 ? 3 : 4);
@@ -438,14 +474,15 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
         const uint64_t wa = (uint64_t)((a.n + 63) / 64) * a.m, wb = (uint64_t)((b.n + 63) / 64) * b.m; return wa > wb; });
 
     size_t cols_total = 0;
-    if (cols) for (int i = 0; i < n; i++) cols_total = std::max<size_t>(cols_total, cols_off[i] + (qoff[i + 1] - qoff[i]) + 1);
+    if (cols) for (int i = 0; i < n; i++) cols_total = std::max<size_t>(cols_total, cols_off[i] + PN(i) + 1);
 #define DSLOT(T, k, bytes) (T *)lfg_dev_slot(device, LF_DS_ALN0 + (k), (bytes))
-    unsigned char *d_q = DSLOT(unsigned char, 0, qbytes + 64), *d_t = DSLOT(unsigned char, 1, tbytes + 64);
+    unsigned char *d_q = D ? const_cast<unsigned char *>(D->d_reads) : DSLOT(unsigned char, 0, qbytes + 64);
+    unsigned char *d_t = DSLOT(unsigned char, 1, tbytes + 64);
     lf_hist_t *d_hist = DSLOT(lf_hist_t, 2, hist_entries * sizeof(lf_hist_t) + 64);
     uint64_t *d_aux = DSLOT(uint64_t, 3, aux_words * 8 + 64);
     int32_t *d_ed = DSLOT(int32_t, 4, (size_t)n * 4), *d_end = DSLOT(int32_t, 5, (size_t)n * 4);
     uint32_t *d_len = DSLOT(uint32_t, 6, (size_t)n * 4);
-    uint8_t *d_ops = cols ? nullptr : DSLOT(uint8_t, 7, qbytes + tbytes + 64);
+    uint8_t *d_ops = cols ? nullptr : DSLOT(uint8_t, 7, ops_bytes + 64);
     int32_t *d_cols = cols ? DSLOT(int32_t, 8, cols_total * 4 + 16) : nullptr;
     uint64_t *d_cols_off = cols ? DSLOT(uint64_t, 9, (size_t)n * 8) : nullptr;
     if (!d_q || !d_t || !d_hist || !d_aux || !d_ed || !d_end || !d_len || (!cols && !d_ops) || (cols && (!d_cols || !d_cols_off))) return LF_ERR_NOMEM;
@@ -455,21 +492,24 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     static hipStream_t s = nullptr;
     if (!s) HIPCHK(hipStreamCreate(&s));
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipMemcpyAsync(d_q, q, qbytes, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_t, t, tbytes, hipMemcpyHostToDevice, s));
+    if (!D) {
+        HIPCHK(hipMemcpyAsync(d_q, q, qbytes, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_t, t, tbytes, hipMemcpyHostToDevice, s));
+    }
+    lf_seqs S; S.q = d_q; S.t = d_t; S.pac = D ? D->d_pac : nullptr;
     if (cols) HIPCHK(hipMemcpyAsync(d_cols_off, cols_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(d_len, 0, (size_t)n * 4, s));
     for (int k = 0; k < 7; k++) if (!P[k].empty())
         HIPCHK(hipMemcpyAsync(d_prob[k], P[k].data(), P[k].size() * sizeof(lf_aln_prob), hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(e0, s));
 #define LAUNCH_CLASS(K, NBV) if (!P[K].empty()) hipLaunchKernelGGL(lf_edlib_kernel<NBV>, dim3((unsigned)((P[K].size() + 63) / 64)), dim3(64), 0, s, \
-        d_prob[K], (int)P[K].size(), d_q, d_t, d_hist, d_ops, d_ed, d_end, d_len)
+        d_prob[K], (int)P[K].size(), S, d_hist, d_ops, d_ed, d_end, d_len)
     LAUNCH_CLASS(1, 1); LAUNCH_CLASS(2, 2); LAUNCH_CLASS(3, 4); LAUNCH_CLASS(4, 8);
     if (!P[0].empty())
         hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((P[0].size() + 63) / 64)), dim3(64), 0, s,
-                           d_prob[0], (int)P[0].size(), d_q, d_t, d_hist, d_aux, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off);
+                           d_prob[0], (int)P[0].size(), S, d_hist, d_aux, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off);
 #define LAUNCH_WAVE(K, KBV) if (!P[K].empty()) hipLaunchKernelGGL(lf_edlib_wave_kernel<KBV>, dim3((unsigned)P[K].size()), dim3(64), 0, s, \
-        d_prob[K], (int)P[K].size(), d_q, d_t, d_hist, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off)
+        d_prob[K], (int)P[K].size(), S, d_hist, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off)
     LAUNCH_WAVE(5, 1); LAUNCH_WAVE(6, 4);
     HIPCHK(hipEventRecord(e1, s));
     if (cols) HIPCHK(hipMemcpyAsync(cols, d_cols, cols_total * 4, hipMemcpyDeviceToHost, s));
@@ -477,7 +517,7 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
         HIPCHK(hipMemcpyAsync(ed, d_ed, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(endloc, d_end, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(ops_len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(ops, d_ops, qbytes + tbytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(ops, d_ops, ops_bytes, hipMemcpyDeviceToHost, s));
     }
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
@@ -486,10 +526,10 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
 
     /* degenerate problems: one side empty -> pure insertion / deletion run (lib/edlib/edlib.cpp:1096-1104) */
     for (int i : trivial) {
-        const uint32_t nn = (uint32_t)(qoff[i + 1] - qoff[i]), mm = (uint32_t)(toff[i + 1] - toff[i]);
+        const uint32_t nn = PN(i), mm = PM(i);
         if (cols) { int32_t *oc = cols + cols_off[i]; oc[0] = (int32_t)mm; continue; }   /* n == 0 */
-        const int md = mode ? mode[i] : 0;
-        uint8_t *o = ops + qoff[i] + toff[i];
+        const int md = D ? D->d[i].mode : (mode ? mode[i] : 0);
+        uint8_t *o = ops + POPS(i);
         if (nn == 0) {
             /* NW: delete the whole target; SHW: the empty prefix is optimal */
             const uint32_t tl = md == 0 ? mm : 0;
@@ -498,7 +538,23 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
         } else { ed[i] = (int32_t)nn; endloc[i] = -1; ops_len[i] = nn; for (uint32_t j = 0; j < nn; j++) o[j] = 1; }
         if (task && task[i] == LF_TASK_DIST) ops_len[i] = 0;
     }
+#undef PN
+#undef PM
+#undef POPS
     return LF_OK;
+}
+
+extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_desc_t *d, const uint64_t *ops_off, uint64_t ops_total,
+                              int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, float *ms)
+{
+    lf_dev_state *st = (lf_dev_state *)ix->dev;
+    if (!st) { lf_set_error("index is not on a device"); return LF_ERR_NO_DEVICE; }
+    lf_desc_src D;
+    D.d = d; D.ops_off = ops_off; D.ops_total = ops_total;
+    D.d_reads = (const unsigned char *)lfg_dev_slot(ix->device, LF_DS_SEED0 + 0, 0);      /* read batch left in HBM by lfg_seed */
+    D.d_pac = st->view.pac;
+    if (!D.d_reads) { lf_set_error("lfg_edlib_desc: no resident read batch"); return LF_ERR_ARG; }
+    return run_edlib(ix->device, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ed, endloc, ops, ops_len, nullptr, nullptr, ms, &D);
 }
 
 extern "C" int lfg_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,

@@ -70,6 +70,17 @@ enum { LF_PS_READS = 0, LF_PS_READOFF = 1, LF_PS_HITS_T = 2, LF_PS_HITS_Q = 3, L
        LF_PS_CHAIN_SEEDS = 6, LF_PS_CHAIN_IDX = 7, LF_PS_ALN_Q = 8, LF_PS_ALN_T = 9, LF_PS_ALN_PROB = 10 /* ..16 */,
        LF_PS_ROUND0 = 20 /* 4 per round: ed, end, len, ops ; up to 16 rounds */ };
 
+/* alignment request as a DESCRIPTOR into HBM-resident data: query = the read batch uploaded by the seed stage,
+ * target = the 2-bit reference.  Element i = base[start +/- i], optionally complemented (flags LF_F_*). */
+typedef struct { int64_t qstart, tstart; uint32_t n, m; uint8_t flags, mode, pad[6]; } lf_aln_desc_t;
+int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_desc_t *d, const uint64_t *ops_off, uint64_t ops_total,
+                   int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, float *ms);
+#define LF_F_QREV  1u
+#define LF_F_QCOMP 2u
+#define LF_F_TREV  4u
+#define LF_F_TCOMP 8u
+#define LF_F_TPAC  16u
+
 #define LF_TASK_PATH 0
 #define LF_TASK_DIST 1
 

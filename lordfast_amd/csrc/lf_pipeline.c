@@ -133,6 +133,8 @@ typedef struct {
     uint64_t *kqoff, *ktoff; int32_t *kprm; int kn, kcap;
     memo_t **kowner;
     uint64_t ext_bytes;
+    /* staged edlib requests as descriptors into HBM-resident reads / pac (leaf-size problems: the common case) */
+    lf_aln_desc_t *dd; uint64_t *dops; uintptr_t *downer; int dn, dcap; uint64_t dops_total;
 } stage_t;
 
 typedef struct job {
@@ -180,9 +182,10 @@ typedef struct ctx {
     lf_stats_t *st;
     const lfg_hits_t *hits;
     /* scratch for the parallel merge of staged alignment requests */
-    char *mg_qb, *mg_tb; uint64_t *mg_qoff, *mg_toff, *mg_qbase, *mg_tbase; uint8_t *mg_mode; int *mg_gbase; ed_round_t *mg_R; int mg_round;
+    lf_aln_desc_t *mg_desc; char *mg_qb, *mg_tb; uint64_t *mg_qoff, *mg_toff, *mg_qbase, *mg_tbase; uint8_t *mg_mode; int *mg_gbase; ed_round_t *mg_R; int mg_round;
     /* output assembly */
     char *out_base; uint64_t *out_off;
+    const char *const *len_seqs; uint32_t *len_out;
     int *seed_map; char *cat; uint64_t *cat_off;
 } ctx_t;
 
@@ -517,7 +520,7 @@ static void stage_edlib(walk_t *w, memo_t *m)
 
 /* job owner bookkeeping: parallel arrays */
 typedef struct { job_t **job; int n, cap; } jobvec_t;
-static jobvec_t *g_ed_jobs, *g_ksw_jobs;   /* per worker */
+static jobvec_t *g_ed_jobs, *g_ksw_jobs, *g_edd_jobs;   /* per worker */
 static void jv_push(jobvec_t *v, job_t *j) { if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 1024; v->job = (job_t **)realloc(v->job, (size_t)v->cap * sizeof(job_t *)); } v->job[v->n++] = j; }
 
 static void stage_ksw(walk_t *w, memo_t *m)
@@ -552,6 +555,38 @@ static void stage_ksw(walk_t *w, memo_t *m)
     s->kn++;
 }
 
+/* leaf-size request -> descriptor (no bytes are copied: the GPU reads the resident read batch and the 2-bit reference) */
+static void stage_edlib_desc(walk_t *w, memo_t *m)
+{
+    stage_t *s = &w->cx->stages[w->tid];
+    const rkey_t *k = &m->key;
+    const rd_t *rd = &w->cx->reads[w->job->read];
+    if (s->dn == s->dcap) {
+        s->dcap = s->dcap ? s->dcap * 2 : 1024;
+        s->dd = (lf_aln_desc_t *)realloc(s->dd, (size_t)s->dcap * sizeof(lf_aln_desc_t));
+        s->dops = (uint64_t *)realloc(s->dops, (size_t)s->dcap * 8);
+        s->downer = (uintptr_t *)realloc(s->downer, (size_t)s->dcap * sizeof(uintptr_t));
+    }
+    lf_aln_desc_t *d = &s->dd[s->dn];
+    memset(d, 0, sizeof *d);
+    const int64_t roff = (int64_t)w->cx->cat_off[rd->seed_idx], L = (int64_t)rd->len;
+    /* the walk's query string is the read (forward chains) or its reverse complement (reverse chains);
+     * a request may itself ask for the reverse complement of a segment: compose into (start, direction, complement).
+     * complementing twice is the identity for every byte that can match the upper-case reference */
+    const int rev_q = (w->job->isRev ? 1 : 0) ^ (k->qrc ? 1 : 0);
+    int64_t qstart;
+    if (!w->job->isRev) qstart = k->qrc ? roff + k->qs + k->qseg - 1 : roff + k->qs;
+    else qstart = k->qrc ? roff + L - k->qs - k->qseg : roff + L - 1 - k->qs;
+    d->qstart = qstart;
+    d->tstart = k->trc ? (int64_t)k->ts + k->tseg - 1 : (int64_t)k->ts;
+    d->n = k->qn; d->m = k->tn; d->mode = k->mode;
+    d->flags = (uint8_t)((rev_q ? (LF_F_QREV | LF_F_QCOMP) : 0) | (k->trc ? (LF_F_TREV | LF_F_TCOMP) : 0));
+    s->dops[s->dn] = s->dops_total; s->dops_total += (uint64_t)k->qn + k->tn;
+    s->downer[s->dn] = (uintptr_t)(m - w->job->memo);
+    s->dn++;
+    s->ext_bytes += (uint64_t)k->qn + (k->tn + 3) / 4 + k->qn + k->tn;      /* SURVEY 8(d) B_ext */
+}
+
 /* edlibAlign(query segment, target segment, mode, PATH) through the memo */
 static edres_t need_edlib(walk_t *w, int qrc, uint32_t qs, uint32_t qseg, uint32_t qn, int trc, uint32_t ts, uint32_t tseg, uint32_t tn, int mode)
 {
@@ -560,7 +595,11 @@ static edres_t need_edlib(walk_t *w, int qrc, uint32_t qs, uint32_t qseg, uint32
     k.type = 0; k.qrc = (uint8_t)qrc; k.trc = (uint8_t)trc; k.mode = (uint8_t)mode;
     k.qs = qs; k.qseg = qseg; k.qn = qn; k.ts = ts; k.tseg = tseg; k.tn = tn;
     memo_t *m = memo_find(w->job, &k);
-    if (!m) { m = memo_add(w->job, &k); stage_edlib(w, m); jv_push(&g_ed_jobs[w->tid], w->job); }
+    if (!m) {
+        m = memo_add(w->job, &k);
+        if (lf_is_leaf(qn, tn) && qn > 0 && tn > 0) { stage_edlib_desc(w, m); jv_push(&g_edd_jobs[w->tid], w->job); }
+        else { stage_edlib(w, m); jv_push(&g_ed_jobs[w->tid], w->job); }      /* Hirschberg-size: byte strings */
+    }
     if (m->round < 0) { w->missing++; w->build = 0; r.ed = 0; r.end = (mode == 0) ? (int)tn - 1 : (int)tn - 1; return r; }
     const ed_round_t *R = &w->cx->ed_rounds[m->round];
     r.have = 1; r.ed = R->ed[m->slot]; r.end = R->end[m->slot]; r.nops = R->ops_len[m->slot]; r.ops = R->ops + R->ops_off[m->slot];
@@ -978,6 +1017,23 @@ static void phase_merge_edlib(ctx_t *cx, int tid, int t)
     s->n = 0; s->qn = 0; s->tn = 0; s->ext_bytes = 0; g_ed_jobs[t].n = 0;
 }
 
+static void phase_strlen(ctx_t *cx, int tid, int i) { (void)tid; cx->len_out[i] = (uint32_t)strlen(cx->len_seqs[i]); }
+
+static void phase_merge_desc(ctx_t *cx, int tid, int t)
+{
+    (void)tid;
+    stage_t *s = &cx->stages[t];
+    int g = cx->mg_gbase[t];
+    const uint64_t ob = cx->mg_qbase[t];
+    for (int k = 0; k < s->dn; k++, g++) {
+        cx->mg_desc[g] = s->dd[k];
+        cx->mg_R->ops_off[g] = ob + s->dops[k];
+        memo_t *m = &g_edd_jobs[t].job[k]->memo[s->downer[k]];
+        m->round = cx->mg_round; m->slot = g;
+    }
+    s->dn = 0; s->dops_total = 0; g_edd_jobs[t].n = 0;
+}
+
 static void phase_copy_out(ctx_t *cx, int tid, int ri)
 {
     (void)tid;
@@ -1088,14 +1144,46 @@ static int map_chunk(ctx_t *cx)
     cx->stages = (stage_t *)calloc((size_t)nt, sizeof(stage_t));
     g_ed_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
     g_ksw_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
+    g_edd_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
     const int timing = getenv("LF_TIMING") != NULL;
     for (int round = 0; round < 64; round++) {
         double tw0 = now_ms();
         parallel_for(cx, n, phase_walk);
         if (timing) fprintf(stderr, "[lf] round %d walk %.1f ms\n", round, now_ms() - tw0);
-        int ne = 0, nk = 0;
-        for (int t = 0; t < nt; t++) { ne += cx->stages[t].n; nk += cx->stages[t].kn; }
-        if (ne == 0 && nk == 0) break;
+        int ne = 0, nk = 0, nd = 0;
+        for (int t = 0; t < nt; t++) { ne += cx->stages[t].n; nk += cx->stages[t].kn; nd += cx->stages[t].dn; }
+        if (ne == 0 && nk == 0 && nd == 0) break;
+        if (nd) {
+            /* descriptor requests: nothing but 32-byte descriptors goes to the GPU */
+            uint64_t *obase = (uint64_t *)malloc((size_t)nt * 8); int *gbase = (int *)malloc((size_t)nt * sizeof(int));
+            uint64_t ops_total = 0;
+            { int g0 = 0; for (int t = 0; t < nt; t++) { obase[t] = ops_total; gbase[t] = g0; ops_total += cx->stages[t].dops_total; g0 += cx->stages[t].dn; st->ext_bytes += cx->stages[t].ext_bytes; cx->stages[t].ext_bytes = 0; } }
+            const int ridx = cx->n_ed_rounds;
+            const int pin = ridx < 16;
+            ed_round_t R; memset(&R, 0, sizeof R);
+            R.n = nd; R.pinned = pin;
+            if (pin) {
+                R.ed = (int32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx, (size_t)nd * 4); R.end = (int32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 1, (size_t)nd * 4);
+                R.ops_len = (uint32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 2, (size_t)nd * 4); R.ops = (uint8_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 3, ops_total + 1);
+            } else {
+                R.ed = (int32_t *)malloc((size_t)nd * 4); R.end = (int32_t *)malloc((size_t)nd * 4);
+                R.ops_len = (uint32_t *)malloc((size_t)nd * 4); R.ops = (uint8_t *)malloc(ops_total + 1);
+            }
+            R.ops_off = (uint64_t *)malloc((size_t)nd * 8);
+            lf_aln_desc_t *desc = (lf_aln_desc_t *)lfg_pin_slot(LF_PS_ALN_PROB, (size_t)nd * sizeof(lf_aln_desc_t));
+            if (!desc || !R.ed || !R.end || !R.ops_len || !R.ops) return LF_ERR_NOMEM;
+            cx->mg_desc = desc; cx->mg_R = &R; cx->mg_qbase = obase; cx->mg_gbase = gbase; cx->mg_round = ridx;
+            double tm0 = now_ms();
+            parallel_for(cx, nt, phase_merge_desc);
+            free(obase); free(gbase);
+            float ms = 0;
+            rc = lfg_edlib_desc(cx->ix, nd, desc, R.ops_off, ops_total, R.ed, R.end, R.ops, R.ops_len, &ms);
+            if (timing) fprintf(stderr, "[lf] round %d: %d descriptor problems, merge+solve %.1f ms (kernels %.1f ms), ops %.1f MB\n", round, nd, now_ms() - tm0, ms, ops_total / 1e6);
+            cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
+            cx->ed_rounds[cx->n_ed_rounds++] = R;
+            if (rc != LF_OK) return rc;
+            st->ms_k_edlib += ms; st->n_edlib_problems += (uint64_t)nd; st->edlib_launches += 1;
+        }
         if (ne) {
             uint64_t qn = 0, tn = 0;
             uint64_t *qbase = (uint64_t *)malloc((size_t)nt * 8), *tbase = (uint64_t *)malloc((size_t)nt * 8); int *gbase = (int *)malloc((size_t)nt * sizeof(int));
@@ -1194,9 +1282,10 @@ static void chunk_free(ctx_t *cx)
             stage_t *s = &cx->stages[t];
             free(s->qb); free(s->tb); free(s->qoff); free(s->toff); free(s->mode); free(s->owner);
             free(s->kq); free(s->kt); free(s->kqoff); free(s->ktoff); free(s->kprm); free(s->kowner);
-            free(g_ed_jobs[t].job); free(g_ksw_jobs[t].job);
+            free(s->dd); free(s->dops); free(s->downer);
+            free(g_ed_jobs[t].job); free(g_ksw_jobs[t].job); free(g_edd_jobs[t].job);
         }
-        free(cx->stages); free(g_ed_jobs); free(g_ksw_jobs); g_ed_jobs = g_ksw_jobs = NULL;
+        free(cx->stages); free(g_ed_jobs); free(g_ksw_jobs); free(g_edd_jobs); g_ed_jobs = g_ksw_jobs = g_edd_jobs = NULL;
     }
     cx->creq = NULL; cx->cseeds = NULL; cx->chain_idx = NULL; cx->chain_len = NULL; cx->chain_score = NULL;
     cx->ed_rounds = NULL; cx->ksw_rounds = NULL; cx->n_ed_rounds = cx->n_ksw_rounds = 0; cx->stages = NULL;
@@ -1236,11 +1325,14 @@ int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *
     if (nt < 1) nt = 1;
     const double T0 = now_ms();
     pthread_mutex_lock(&g_map_lock);
-
     str_t all; str_init(&all);
-    {   /* one allocation for the SAM text: ~2 x bases (SEQ + CIGAR/MD) + per-record overhead */
+    uint32_t *lens = (uint32_t *)malloc(((size_t)n + 1) * 4);
+    {   /* read lengths once, in parallel; one allocation for the SAM text (~2 x bases + per-record overhead) */
+        ctx_t c0; memset(&c0, 0, sizeof c0);
+        c0.n_threads = nt; c0.len_seqs = seqs; c0.len_out = lens;
+        parallel_for(&c0, n, phase_strlen);
         uint64_t est = 4096;
-        for (int i = 0; i < n; i++) est += 2 * strlen(seqs[i]) + strlen(names[i]) + 512;
+        for (int i = 0; i < n; i++) est += 2 * (uint64_t)lens[i] + 640;
         str_room(&all, est + est / 8);
     }
     int rc = LF_OK;
@@ -1249,14 +1341,14 @@ int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *
     int i0 = 0;
     while (i0 < n && rc == LF_OK) {
         int i1 = i0; uint64_t bases = 0;
-        while (i1 < n && i1 - i0 < CHUNK_READS && bases < CHUNK_BASES) { bases += strlen(seqs[i1]); i1++; }
+        while (i1 < n && i1 - i0 < CHUNK_READS && bases < CHUNK_BASES) { bases += lens[i1]; i1++; }
         ctx_t cx; memset(&cx, 0, sizeof cx);
         cx.ix = ix; cx.p = p; cx.n_threads = nt; cx.st = st;
         cx.n_reads = i1 - i0;
         cx.reads = (rd_t *)calloc((size_t)cx.n_reads, sizeof(rd_t));
         for (int i = i0; i < i1; i++) {
             rd_t *r = &cx.reads[i - i0];
-            r->name = names[i]; r->seq = seqs[i]; r->len = (uint32_t)strlen(seqs[i]);
+            r->name = names[i]; r->seq = seqs[i]; r->len = lens[i];
             r->isFq = (quals && quals[i] && quals[i][0]);
             r->qual = r->isFq ? quals[i] : "*";
             st->n_bases += r->len;
@@ -1278,6 +1370,7 @@ int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *
         i0 = i1;
     }
     pthread_mutex_unlock(&g_map_lock);
+    free(lens);
     st->ms_total = now_ms() - T0;
     if (rc != LF_OK) { free(all.s); return rc; }
     *sam = all.s;
