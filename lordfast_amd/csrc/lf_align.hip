@@ -158,7 +158,7 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
     out_end[pr.id] = tl - 1;
     if (!want_path) { out_len[pr.id] = 0; return; }
 
-    /* traceback from (n, tl); ops written backwards from the end of the region, then moved to its start */
+    /* traceback from (n, tl); ops written backwards from the end of the region (they stay end-aligned) */
     uint8_t *o = ops + pr.ops_off;
     const uint32_t cap = n + m;
     uint32_t w = cap;
@@ -173,9 +173,7 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
     }
     while (c > 0) { o[--w] = 2; c--; }
     while (r > 0) { o[--w] = 1; r--; }
-    const uint32_t len = cap - w;
-    for (uint32_t i = 0; i < len; i++) o[i] = o[w + i];
-    out_len[pr.id] = len;
+    out_len[pr.id] = cap - w;            /* ops are END-aligned: o[cap - len .. cap) */
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -250,9 +248,7 @@ lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_s
     }
     while (c > 0) { o[--w] = 2; c--; }
     while (r > 0) { o[--w] = 1; r--; }
-    const uint32_t len = cap - w;
-    for (uint32_t i = 0; i < len; i++) o[i] = o[w + i];
-    out_len[pr.id] = len;
+    out_len[pr.id] = cap - w;            /* ops are END-aligned: o[cap - len .. cap) */
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -359,9 +355,7 @@ lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs
     }
     while (c > 0) { o[--w] = 2; c--; }
     while (r > 0) { o[--w] = 1; r--; }
-    const uint32_t len = cap - w;
-    for (uint32_t i = 0; i < len; i++) o[i] = o[w + i];
-    out_len[pr.id] = len;
+    out_len[pr.id] = cap - w;            /* ops are END-aligned: o[cap - len .. cap) */
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -489,8 +483,11 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     lf_aln_prob *d_prob[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     for (int k = 0; k < 7; k++) if (!P[k].empty()) { d_prob[k] = DSLOT(lf_aln_prob, 10 + k, P[k].size() * sizeof(lf_aln_prob)); if (!d_prob[k]) return LF_ERR_NOMEM; }
 #undef DSLOT
-    static hipStream_t s = nullptr;
-    if (!s) HIPCHK(hipStreamCreate(&s));
+    /* the size classes run CONCURRENTLY on their own streams: the long-query classes have few, long waves and
+     * would leave most CUs idle if the kernels ran back to back */
+    static hipStream_t s = nullptr, cs[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    static hipEvent_t cdone[7];
+    if (!s) { HIPCHK(hipStreamCreate(&s)); for (int k = 0; k < 7; k++) { HIPCHK(hipStreamCreate(&cs[k])); HIPCHK(hipEventCreateWithFlags(&cdone[k], hipEventDisableTiming)); } }
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     if (!D) {
         HIPCHK(hipMemcpyAsync(d_q, q, qbytes, hipMemcpyHostToDevice, s));
@@ -502,15 +499,18 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     for (int k = 0; k < 7; k++) if (!P[k].empty())
         HIPCHK(hipMemcpyAsync(d_prob[k], P[k].data(), P[k].size() * sizeof(lf_aln_prob), hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(e0, s));
-#define LAUNCH_CLASS(K, NBV) if (!P[K].empty()) hipLaunchKernelGGL(lf_edlib_kernel<NBV>, dim3((unsigned)((P[K].size() + 63) / 64)), dim3(64), 0, s, \
-        d_prob[K], (int)P[K].size(), S, d_hist, d_ops, d_ed, d_end, d_len)
-    LAUNCH_CLASS(1, 1); LAUNCH_CLASS(2, 2); LAUNCH_CLASS(3, 4); LAUNCH_CLASS(4, 8);
-    if (!P[0].empty())
-        hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((P[0].size() + 63) / 64)), dim3(64), 0, s,
-                           d_prob[0], (int)P[0].size(), S, d_hist, d_aux, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off);
-#define LAUNCH_WAVE(K, KBV) if (!P[K].empty()) hipLaunchKernelGGL(lf_edlib_wave_kernel<KBV>, dim3((unsigned)P[K].size()), dim3(64), 0, s, \
+    for (int k = 0; k < 7; k++) if (!P[k].empty()) HIPCHK(hipStreamWaitEvent(cs[k], e0, 0));
+    /* longest-running classes first */
+#define LAUNCH_WAVE(K, KBV) if (!P[K].empty()) hipLaunchKernelGGL(lf_edlib_wave_kernel<KBV>, dim3((unsigned)P[K].size()), dim3(64), 0, cs[K], \
         d_prob[K], (int)P[K].size(), S, d_hist, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off)
-    LAUNCH_WAVE(5, 1); LAUNCH_WAVE(6, 4);
+    LAUNCH_WAVE(6, 4); LAUNCH_WAVE(5, 1);
+    if (!P[0].empty())
+        hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((P[0].size() + 63) / 64)), dim3(64), 0, cs[0],
+                           d_prob[0], (int)P[0].size(), S, d_hist, d_aux, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off);
+#define LAUNCH_CLASS(K, NBV) if (!P[K].empty()) hipLaunchKernelGGL(lf_edlib_kernel<NBV>, dim3((unsigned)((P[K].size() + 63) / 64)), dim3(64), 0, cs[K], \
+        d_prob[K], (int)P[K].size(), S, d_hist, d_ops, d_ed, d_end, d_len)
+    LAUNCH_CLASS(4, 8); LAUNCH_CLASS(3, 4); LAUNCH_CLASS(2, 2); LAUNCH_CLASS(1, 1);
+    for (int k = 0; k < 7; k++) if (!P[k].empty()) { HIPCHK(hipEventRecord(cdone[k], cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
     HIPCHK(hipEventRecord(e1, s));
     if (cols) HIPCHK(hipMemcpyAsync(cols, d_cols, cols_total * 4, hipMemcpyDeviceToHost, s));
     else {
@@ -530,12 +530,13 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
         if (cols) { int32_t *oc = cols + cols_off[i]; oc[0] = (int32_t)mm; continue; }   /* n == 0 */
         const int md = D ? D->d[i].mode : (mode ? mode[i] : 0);
         uint8_t *o = ops + POPS(i);
+        const uint32_t cap = nn + mm;
         if (nn == 0) {
             /* NW: delete the whole target; SHW: the empty prefix is optimal */
             const uint32_t tl = md == 0 ? mm : 0;
             ed[i] = (int32_t)tl; endloc[i] = (int32_t)tl - 1; ops_len[i] = tl;
-            for (uint32_t j = 0; j < tl; j++) o[j] = 2;
-        } else { ed[i] = (int32_t)nn; endloc[i] = -1; ops_len[i] = nn; for (uint32_t j = 0; j < nn; j++) o[j] = 1; }
+            for (uint32_t j = 0; j < tl; j++) o[cap - tl + j] = 2;
+        } else { ed[i] = (int32_t)nn; endloc[i] = -1; ops_len[i] = nn; for (uint32_t j = 0; j < nn; j++) o[cap - nn + j] = 1; }
         if (task && task[i] == LF_TASK_DIST) ops_len[i] = 0;
     }
 #undef PN

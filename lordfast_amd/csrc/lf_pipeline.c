@@ -602,7 +602,8 @@ static edres_t need_edlib(walk_t *w, int qrc, uint32_t qs, uint32_t qseg, uint32
     }
     if (m->round < 0) { w->missing++; w->build = 0; r.ed = 0; r.end = (mode == 0) ? (int)tn - 1 : (int)tn - 1; return r; }
     const ed_round_t *R = &w->cx->ed_rounds[m->round];
-    r.have = 1; r.ed = R->ed[m->slot]; r.end = R->end[m->slot]; r.nops = R->ops_len[m->slot]; r.ops = R->ops + R->ops_off[m->slot];
+    r.have = 1; r.ed = R->ed[m->slot]; r.end = R->end[m->slot]; r.nops = R->ops_len[m->slot];
+    r.ops = R->ops + R->ops_off[m->slot] + ((uint64_t)qn + tn - r.nops);            /* end-aligned in its region */
     return r;
 }
 

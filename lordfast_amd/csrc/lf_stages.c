@@ -121,7 +121,7 @@ int lf_edlib_solve(int device, int n, const char *q, const uint64_t *qoff, const
                 hnode_t *x = &H.v[who[j]];
                 if (e2[j] != x->best) { lf_set_error("hirschberg: leaf distance %d != expected %d", e2[j], x->best); rc = LF_ERR_HIP; break; }
                 x->nops = len2[j]; x->ops = (uint8_t *)malloc(x->nops + 1);
-                memcpy(x->ops, ops2 + qo[j] + to[j], x->nops);
+                memcpy(x->ops, ops2 + qo[j] + to[j] + (x->n + x->m - x->nops), x->nops);     /* kernel output is end-aligned */
                 x->state = 3;
             }
             free(qo); free(to); free(who); free(qb); free(tb); free(e2); free(l2); free(len2); free(ops2);
@@ -175,8 +175,12 @@ int lf_edlib_solve(int device, int n, const char *q, const uint64_t *qoff, const
             if (rc != LF_OK) break;
         }
     }
-    if (rc == LF_OK) for (int i = 0; i < n; i++) if (root[i] >= 0)
-        ops_len[i] = emit_tree(&H, root[i], ops + qoff[i] + toff[i]);
+    if (rc == LF_OK) for (int i = 0; i < n; i++) if (root[i] >= 0) {
+        uint8_t *o = ops + qoff[i] + toff[i];
+        const uint64_t cap = (qoff[i + 1] - qoff[i]) + (toff[i + 1] - toff[i]);
+        ops_len[i] = emit_tree(&H, root[i], o);
+        memmove(o + cap - ops_len[i], o, ops_len[i]);                                       /* same convention: end-aligned */
+    }
     for (int k = 0; k < H.n; k++) free(H.v[k].ops);
     free(H.v); free(root); free(task);
     if (kernel_ms) *kernel_ms = ms_acc;
@@ -189,5 +193,13 @@ int lf_edlib_batch(int n, const char *q, const uint64_t *qoff, const char *t, co
 {
     if (n < 0 || !qoff || !toff) { lf_set_error("lf_edlib_batch: bad argument"); return LF_ERR_ARG; }
     if (mode) for (int i = 0; i < n; i++) if (mode[i] > 1) { lf_set_error("lf_edlib_batch: only NW (0) and SHW (1) are implemented"); return LF_ERR_ARG; }
-    return lf_edlib_solve(device, n, q, qoff, t, toff, mode, edit_distance, end_location, ops, ops_len, kernel_ms, NULL);
+    int rc = lf_edlib_solve(device, n, q, qoff, t, toff, mode, edit_distance, end_location, ops, ops_len, kernel_ms, NULL);
+    if (rc != LF_OK) return rc;
+    /* the kernels leave each ops run END-aligned in its region; the public contract is start-aligned */
+    for (int i = 0; i < n; i++) {
+        uint8_t *o = ops + qoff[i] + toff[i];
+        const uint64_t cap = (qoff[i + 1] - qoff[i]) + (toff[i + 1] - toff[i]);
+        if (ops_len[i] && ops_len[i] < cap) memmove(o, o + cap - ops_len[i], ops_len[i]);
+    }
+    return LF_OK;
 }
