@@ -14,6 +14,7 @@
  * which is edlib's move priority (lib/edlib/edlib.cpp:950,984,1015).  No banding: the Ukkonen band of
  * the reference only removes cells that cannot be on an optimal path.
  */
+#include <hipcub/hipcub.hpp>
 #include "lf_gpu_common.h"
 #include <algorithm>
 #include <string.h>
@@ -545,6 +546,148 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     return LF_OK;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * descriptor batches are binned, ordered and laid out ON THE GPU: key = (size class, target length), one radix
+ * sort, one scan for the history bases, one kernel that writes the per-class problem arrays.  The host uploads
+ * 32-byte descriptors and launches; it does no per-problem work.
+ * ---------------------------------------------------------------------------------------------- */
+__device__ __forceinline__ int lf_desc_class(uint32_t n)
+{   /* order = launch classes: 1..4 lane kernels NB 1,2,4,8 ; 5,6 wave kernels KB 1,4 ; 0 generic lane kernel */
+    const uint32_t nb = (n + 63) >> 6;
+    if (nb <= 1) return 1; if (nb <= 2) return 2; if (nb <= 4) return 3; if (nb <= 8) return 4;
+    if (n <= 4096) return 5; if (n <= 16384) return 6;
+    return 0;
+}
+__global__ void lf_desc_keys_kernel(const lf_aln_desc_t *__restrict__ d, int n, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = ((uint64_t)lf_desc_class(d[i].n) << 32) | d[i].m;
+    vals[i] = (uint32_t)i;
+}
+__global__ void lf_desc_bounds_kernel(const uint64_t *__restrict__ keys, int n, int *__restrict__ cstart /* 8 */)
+{
+    const int c = threadIdx.x;
+    if (c > 7) return;
+    const uint64_t want = (uint64_t)c << 32;
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
+    cstart[c] = lo;
+}
+__global__ void lf_desc_entries_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const lf_aln_desc_t *__restrict__ d,
+                                       const int *__restrict__ cstart, int n, uint64_t *__restrict__ ent)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int c = (int)(keys[j] >> 32);
+    uint64_t e;
+    if (c >= 1 && c <= 4) {
+        const int rel = j - cstart[c];
+        if (rel & 63) e = 0;
+        else {      /* first lane of a wave: the wave's history holds 64 x (largest m of the wave) x NB entries */
+            int last = j + 63; if (last > cstart[c + 1] - 1) last = cstart[c + 1] - 1;
+            e = 64ull * (uint32_t)keys[last] * (1u << (c - 1));
+        }
+    } else { const uint32_t nn = d[vals[j]].n; e = (uint64_t)(uint32_t)keys[j] * ((nn + 63) >> 6); }
+    ent[j] = e;
+}
+__global__ void lf_desc_build_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const lf_aln_desc_t *__restrict__ d,
+                                     const uint64_t *__restrict__ ops_off, const int *__restrict__ cstart, const uint64_t *__restrict__ base,
+                                     int n, lf_aln_prob *__restrict__ probs, uint64_t *__restrict__ aux_words_total)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int c = (int)(keys[j] >> 32);
+    const uint32_t i = vals[j];
+    const lf_aln_desc_t x = d[i];
+    lf_aln_prob p;
+    p.qstart = x.qstart; p.tstart = x.tstart; p.ops_off = ops_off[i];
+    int jb = j;
+    if (c >= 1 && c <= 4) jb = cstart[c] + ((j - cstart[c]) & ~63);
+    p.hist_base = base[jb];
+    p.aux_off = 0;
+    if (c == 0) p.aux_off = atomicAdd((unsigned long long *)aux_words_total, (unsigned long long)(((x.n + 63) >> 6) * 5));
+    p.n = x.n; p.m = x.m; p.id = i; p.mode = x.mode; p.task = LF_TASK_PATH; p.flags = (uint8_t)(x.flags | LF_F_TPAC); p.pad = 0;
+    probs[j] = p;
+}
+
+static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, float *ms)
+{
+    if (ms) *ms = 0;
+    if (n == 0) return LF_OK;
+    HIPCHK(hipSetDevice(device));
+    static hipStream_t s = nullptr, cs[7];
+    static hipEvent_t cdone[7];
+    if (!s) { HIPCHK(hipStreamCreate(&s)); for (int k = 0; k < 7; k++) { HIPCHK(hipStreamCreate(&cs[k])); HIPCHK(hipEventCreateWithFlags(&cdone[k], hipEventDisableTiming)); } }
+#define DSLOT(T, k, bytes) (T *)lfg_dev_slot(device, LF_DS_ALN0 + (k), (bytes))
+    lf_aln_desc_t *d_desc = DSLOT(lf_aln_desc_t, 0, (size_t)n * sizeof(lf_aln_desc_t));
+    uint64_t *d_opsoff = DSLOT(uint64_t, 1, (size_t)n * 8);
+    uint64_t *d_keys = DSLOT(uint64_t, 3, (size_t)n * 8), *d_keys2 = DSLOT(uint64_t, 8, (size_t)n * 8);
+    uint32_t *d_vals = DSLOT(uint32_t, 9, (size_t)n * 4), *d_vals2 = DSLOT(uint32_t, 10, (size_t)n * 4);
+    uint64_t *d_ent = DSLOT(uint64_t, 11, (size_t)n * 8), *d_base = DSLOT(uint64_t, 12, (size_t)n * 8 + 8);
+    lf_aln_prob *d_probs = DSLOT(lf_aln_prob, 13, (size_t)n * sizeof(lf_aln_prob));
+    int32_t *d_ed = DSLOT(int32_t, 4, (size_t)n * 4), *d_end = DSLOT(int32_t, 5, (size_t)n * 4);
+    uint32_t *d_len = DSLOT(uint32_t, 6, (size_t)n * 4);
+    uint8_t *d_ops = DSLOT(uint8_t, 7, D->ops_total + 64);
+    int *d_cstart = DSLOT(int, 14, 64);
+    uint64_t *d_misc = DSLOT(uint64_t, 15, 64);
+    if (!d_desc || !d_opsoff || !d_keys || !d_keys2 || !d_vals || !d_vals2 || !d_ent || !d_base || !d_probs || !d_ed || !d_end || !d_len || !d_ops || !d_cstart || !d_misc) return LF_ERR_NOMEM;
+    size_t tb1 = 0, tb2 = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, d_keys, d_keys2, d_vals, d_vals2, n, 0, 35, s);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, d_ent, d_base, n, s);
+    void *d_tmp = lfg_dev_slot(device, LF_DS_ALN0 + 16, std::max(tb1, tb2) + 256);
+    if (!d_tmp) return LF_ERR_NOMEM;
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+
+    HIPCHK(hipMemcpyAsync(d_desc, D->d, (size_t)n * sizeof(lf_aln_desc_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_opsoff, D->ops_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(d_misc, 0, 64, s));
+    HIPCHK(hipEventRecord(e0, s));
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(lf_desc_keys_kernel, dim3(gb), dim3(256), 0, s, d_desc, n, d_keys, d_vals);
+    { size_t tb = tb1; HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 35, s)); }
+    hipLaunchKernelGGL(lf_desc_bounds_kernel, dim3(1), dim3(64), 0, s, d_keys2, n, d_cstart);
+    hipLaunchKernelGGL(lf_desc_entries_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, d_cstart, n, d_ent);
+    { size_t tb = tb2; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_ent, d_base, n, s)); }
+    hipLaunchKernelGGL(lf_desc_build_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, d_opsoff, d_cstart, d_base, n, d_probs, d_misc);
+    int cstart[8]; uint64_t tail[2], aux_total = 0;
+    HIPCHK(hipMemcpyAsync(cstart, d_cstart, 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&tail[0], d_base + (n - 1), 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&tail[1], d_ent + (n - 1), 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&aux_total, d_misc, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const uint64_t hist_entries = tail[0] + tail[1];
+    lf_hist_t *d_hist = DSLOT(lf_hist_t, 2, hist_entries * sizeof(lf_hist_t) + 64);
+    uint64_t *d_aux = DSLOT(uint64_t, 17, aux_total * 8 + 64);
+    if (!d_hist || !d_aux) return LF_ERR_NOMEM;
+#undef DSLOT
+    lf_seqs S; S.q = D->d_reads; S.t = nullptr; S.pac = D->d_pac;
+    hipEvent_t eb; HIPCHK(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(eb, s));
+    auto cnt = [&](int c) { return cstart[c + 1] - cstart[c]; };
+    for (int k = 0; k < 7; k++) if (cnt(k) > 0) HIPCHK(hipStreamWaitEvent(cs[k], eb, 0));
+#define DW(K, KBV) if (cnt(K) > 0) hipLaunchKernelGGL(lf_edlib_wave_kernel<KBV>, dim3((unsigned)cnt(K)), dim3(64), 0, cs[K], \
+        d_probs + cstart[K], cnt(K), S, d_hist, d_ops, d_ed, d_end, d_len, (int32_t *)nullptr, (const uint64_t *)nullptr)
+    DW(6, 4); DW(5, 1);
+    if (cnt(0) > 0)
+        hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((cnt(0) + 63) / 64)), dim3(64), 0, cs[0],
+                           d_probs + cstart[0], cnt(0), S, d_hist, d_aux, d_ops, d_ed, d_end, d_len, (int32_t *)nullptr, (const uint64_t *)nullptr);
+#define DL(K, NBV) if (cnt(K) > 0) hipLaunchKernelGGL(lf_edlib_kernel<NBV>, dim3((unsigned)((cnt(K) + 63) / 64)), dim3(64), 0, cs[K], \
+        d_probs + cstart[K], cnt(K), S, d_hist, d_ops, d_ed, d_end, d_len)
+    DL(4, 8); DL(3, 4); DL(2, 2); DL(1, 1);
+    for (int k = 0; k < 7; k++) if (cnt(k) > 0) { HIPCHK(hipEventRecord(cdone[k], cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipMemcpyAsync(ed, d_ed, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(endloc, d_end, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ops_len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ops, d_ops, D->ops_total, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(eb);
+    return LF_OK;
+}
+
 extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_desc_t *d, const uint64_t *ops_off, uint64_t ops_total,
                               int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, float *ms)
 {
@@ -555,7 +698,8 @@ extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_des
     D.d_reads = (const unsigned char *)lfg_dev_slot(ix->device, LF_DS_SEED0 + 0, 0);      /* read batch left in HBM by lfg_seed */
     D.d_pac = st->view.pac;
     if (!D.d_reads) { lf_set_error("lfg_edlib_desc: no resident read batch"); return LF_ERR_ARG; }
-    return run_edlib(ix->device, n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ed, endloc, ops, ops_len, nullptr, nullptr, ms, &D);
+    for (int i = 0; i < n; i += 4096) if (d[i].n == 0 || d[i].m == 0) { lf_set_error("lfg_edlib_desc: empty sequence in a descriptor"); return LF_ERR_ARG; }
+    return run_edlib_desc_gpu(ix->device, n, &D, ed, endloc, ops, ops_len, ms);
 }
 
 extern "C" int lfg_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,

@@ -686,14 +686,168 @@ static char *md_string(const track_t *md, const track_t *cg)
     return sb.s;
 }
 
-static void emit_sam(walk_t *w, samlist_t *map, const sam_t *tmp, const track_t *cg, const track_t *md)
+/* ---- alignment builder: CIGAR + MD of one SAM record ------------------------------------------------
+ * STREAM mode (default) run-length encodes on the fly: it is fed (cigar char, md char) pairs in final order and
+ * keeps the state machines of edlibCigar_toString / edlibMD_toString (src/LordFAST.cpp:1596-1626,1717-1763), so no
+ * per-base track is materialised.  Front insertions are legal only while nothing has been appended (that is how the
+ * reference uses them: left extension first, or right after a clear); they are stacked and flushed first.
+ * TRACK mode keeps the per-base deques of the reference and is used when a walk hits the one branch that misaligns
+ * MD and CIGAR (src/LordFAST.cpp:2057, App. B #3). */
+typedef struct { int kind; char cg, md; uint32_t n; edres_t r; uint32_t ts, tseg; } fseg_t;
+typedef struct {
+    int track_mode, need_track, active;
+    track_t cg, md;                        /* TRACK mode */
+    str_t scg, smd; char ch; unsigned run; int opn; unsigned mdnum; char last; int fed;    /* STREAM mode */
+    fseg_t front[8]; int nfront;
+    const uint8_t *pac;
+} alnb_t;
+
+static void ab_reset_stream(alnb_t *b) { str_init(&b->scg); str_init(&b->smd); b->ch = 0; b->run = 0; b->opn = 0; b->mdnum = 0; b->last = '='; b->fed = 0; b->nfront = 0; }
+static void ab_init(alnb_t *b, int track_mode, int active, const uint8_t *pac, size_t hint)
 {
-    if (!w->build) return;
-    samlist_push(map, tmp, cigar_string(cg), md_string(md, cg));
+    memset(b, 0, sizeof *b);
+    b->track_mode = track_mode; b->active = active; b->pac = pac;
+    if (!active) return;
+    if (track_mode) { tr_init(&b->cg, hint); tr_init(&b->md, hint); } else ab_reset_stream(b);
+}
+static void ab_free(alnb_t *b)
+{
+    if (!b->active) return;
+    if (b->track_mode) { free(b->cg.buf); free(b->md.buf); } else { free(b->scg.s); free(b->smd.s); }
+}
+static inline void st_c(alnb_t *b, char c, uint32_t n)
+{
+    if (c != b->ch) {
+        if (b->ch) { str_putu(&b->scg, b->run); str_putc(&b->scg, (b->opn == 0 && b->ch == 'I') ? 'S' : b->ch); b->opn++; }
+        b->run = n; b->ch = c;
+    } else b->run += n;
+}
+static inline void st_md_base(alnb_t *b, char base, int is_del)
+{
+    if (!is_del) { str_putu(&b->smd, b->mdnum); b->mdnum = 0; str_putc(&b->smd, base); b->last = 'X'; }
+    else { if (b->last != 'D') { str_putu(&b->smd, b->mdnum); b->mdnum = 0; str_putc(&b->smd, '^'); } str_putc(&b->smd, base); b->last = 'D'; }
+}
+static void st_run(alnb_t *b, char cg, char md, uint32_t n)
+{
+    if (!n) return;
+    b->fed = 1;
+    st_c(b, cg, n);
+    if (md == '=') { b->mdnum += n; b->last = '='; } else b->last = 'I';          /* md is '=' or '-' for runs */
+}
+/* ops in forward order (target base index grows) */
+static void st_ops_fwd(alnb_t *b, const edres_t *r, int trc, uint32_t ts, uint32_t tseg)
+{
+    const uint8_t *pac = b->pac; uint32_t ti = 0;
+    if (r->nops) b->fed = 1;
+    for (uint32_t i = 0; i < r->nops; ) {
+        const uint8_t op = r->ops[i];
+        if (op == 0) { uint32_t j = i + 1; while (j < r->nops && r->ops[j] == 0) j++; st_c(b, 'M', j - i); b->mdnum += j - i; b->last = '='; ti += j - i; i = j; continue; }
+        if (op == 1) { st_c(b, 'I', 1); b->last = 'I'; i++; continue; }
+        const char base = "ACGT"[trc ? 3 - pac_base(pac, ts + tseg - 1 - ti) : pac_base(pac, ts + ti)];
+        st_c(b, op == 2 ? 'D' : 'M', 1); st_md_base(b, base, op == 2); ti++; i++;
+    }
+}
+/* ops that the reference pushes to the FRONT one by one (reversed order); target = reverse complement of
+ * [ts, ts+tseg): the MD base is the complement of it, i.e. the forward base (edlibMD_pushfront) */
+static void st_ops_rev(alnb_t *b, const edres_t *r, uint32_t ts, uint32_t tseg)
+{
+    const uint8_t *pac = b->pac;
+    uint32_t ti = 0;
+    for (uint32_t i = 0; i < r->nops; i++) ti += (r->ops[i] != 1);
+    if (r->nops) b->fed = 1;
+    for (uint32_t i = r->nops; i-- > 0; ) {
+        const uint8_t op = r->ops[i];
+        if (op == 0) { ti--; st_c(b, 'M', 1); b->mdnum++; b->last = '='; continue; }
+        if (op == 1) { st_c(b, 'I', 1); b->last = 'I'; continue; }
+        ti--;
+        const char base = "ACGT"[pac_base(pac, ts + tseg - 1 - ti)];
+        st_c(b, op == 2 ? 'D' : 'M', 1); st_md_base(b, base, op == 2);
+    }
+}
+static void ab_flush_front(alnb_t *b)
+{
+    while (b->nfront > 0) {
+        const fseg_t *f = &b->front[--b->nfront];
+        if (f->kind == 0) st_run(b, f->cg, f->md, f->n); else st_ops_rev(b, &f->r, f->ts, f->tseg);
+    }
+}
+static void ab_back_run(alnb_t *b, char cg, char md, size_t n)
+{
+    if (!b->active) return;
+    if (b->track_mode) { tr_back_n(&b->cg, n, cg); tr_back_n(&b->md, n, md); return; }
+    ab_flush_front(b); st_run(b, cg, md, (uint32_t)n);
+}
+static void ab_front_run(alnb_t *b, char cg, char md, size_t n)
+{
+    if (!b->active) return;
+    if (b->track_mode) { tr_front_n(&b->cg, n, cg); tr_front_n(&b->md, n, md); return; }
+    if (b->fed || b->nfront >= 8) { b->need_track = 1; return; }
+    fseg_t *f = &b->front[b->nfront++]; f->kind = 0; f->cg = cg; f->md = md; f->n = (uint32_t)n;
+}
+static void ab_back_ops(alnb_t *b, const edres_t *r, int trc, uint32_t ts, uint32_t tseg)
+{
+    if (!b->active || !r->have) return;
+    if (b->track_mode) { ops_back(&b->cg, &b->md, r, b->pac, trc, ts, tseg); return; }
+    ab_flush_front(b); st_ops_fwd(b, r, trc, ts, tseg);
+}
+static void ab_front_ops(alnb_t *b, const edres_t *r, uint32_t ts, uint32_t tseg)
+{
+    if (!b->active || !r->have) return;
+    if (b->track_mode) { ops_front(&b->cg, &b->md, r, b->pac, ts, tseg); return; }
+    if (b->fed || b->nfront >= 8) { b->need_track = 1; return; }
+    fseg_t *f = &b->front[b->nfront++]; f->kind = 1; f->r = *r; f->ts = ts; f->tseg = tseg;
+}
+static void ab_back_del(alnb_t *b, uint32_t ts, uint32_t n)
+{   /* pure deletion between two anchors (src/LordFAST.cpp:2126-2134) */
+    if (!b->active || !n) return;
+    if (b->track_mode) {
+        tr_back_n(&b->cg, n, 'D'); tr_room(&b->md, 0, n);
+        for (uint32_t j = 0; j < n; j++) b->md.buf[b->md.end++] = "ACGT"[pac_base(b->pac, ts + j)];
+        return;
+    }
+    ab_flush_front(b); b->fed = 1;
+    st_c(b, 'D', n);
+    for (uint32_t j = 0; j < n; j++) st_md_base(b, "ACGT"[pac_base(b->pac, ts + j)], 1);
+}
+static void ab_md_front_only(alnb_t *b, size_t n)
+{   /* the reference's misplaced padding: MD at the front while the CIGAR got it at the back */
+    if (!b->active) return;
+    if (b->track_mode) { tr_front_n(&b->md, n, '-'); return; }
+    b->need_track = 1;
+}
+static void ab_cg_back_only(alnb_t *b, size_t n)
+{
+    if (!b->active) return;
+    if (b->track_mode) { tr_back_n(&b->cg, n, 'I'); return; }
+    b->need_track = 1;
+}
+static void ab_clear(alnb_t *b)
+{
+    if (!b->active) return;
+    if (b->track_mode) { tr_clear(&b->cg); tr_clear(&b->md); return; }
+    free(b->scg.s); free(b->smd.s); ab_reset_stream(b);
+}
+/* strings of the record built so far (ownership passes to the caller) */
+static void ab_take(alnb_t *b, char **cigar, char **md)
+{
+    if (b->track_mode) { *cigar = cigar_string(&b->cg); *md = md_string(&b->md, &b->cg); return; }
+    ab_flush_front(b);
+    if (b->run) { str_putu(&b->scg, b->run); str_putc(&b->scg, b->ch == 'I' ? 'S' : b->ch); }
+    str_putu(&b->smd, b->mdnum);
+    *cigar = b->scg.s; *md = b->smd.s;
+    ab_reset_stream(b);
+}
+
+static void emit_sam(walk_t *w, samlist_t *map, const sam_t *tmp, alnb_t *ab)
+{
+    if (!w->build || !ab->active || ab->need_track) return;
+    char *c, *m;
+    ab_take(ab, &c, &m);
+    samlist_push(map, tmp, c, m);
 }
 
 /* the walk itself.  Returns 1 when every alignment it needed was available (map is then final). */
-static int walk_chain(ctx_t *cx, int tid, job_t *job, samlist_t *map)
+static int walk_chain_mode(ctx_t *cx, int tid, job_t *job, samlist_t *map, int track_mode, int active, int *need_track)
 {
     const struct lf_index *ix = cx->ix;
     const uint8_t *pac = ix->pac;
@@ -705,7 +859,7 @@ static int walk_chain(ctx_t *cx, int tid, job_t *job, samlist_t *map)
     W.cx = cx; W.tid = tid; W.job = job; W.query = isRev ? rd->seq_rev : rd->seq; W.readLen = rd->len; W.build = 1;
     job->hint = 0;
     const int32_t readLen = (int32_t)rd->len;
-    track_t cg, md; tr_init(&cg, rd->len); tr_init(&md, rd->len);
+    alnb_t ab; ab_init(&ab, track_mode, active, pac, rd->len);
     sam_t tmp; memset(&tmp, 0, sizeof tmp);
     uint32_t chrBeg, chrEnd, readAlnStart, refAlnStart, readAlnEnd, refAlnEnd, i;
     int32_t readAlnLen, refAlnLen, editScore = 0;
@@ -726,27 +880,27 @@ static int walk_chain(ctx_t *cx, int tid, job_t *job, samlist_t *map)
                 if (!need_ksw(&W, 0, 1, 0, (uint32_t)readAlnLen, 1, refAlnStart, (uint32_t)refAlnLen, &qle, &tle)) goto bail;
                 if (qle > 0 && qle < readAlnLen) {
                     edres_t r2 = need_edlib(&W, 1, 0, (uint32_t)readAlnLen, (uint32_t)qle, 1, refAlnStart, (uint32_t)refAlnLen, (uint32_t)tle, 0);
-                    ops_front(&cg, &md, &r2, pac, refAlnStart, (uint32_t)refAlnLen);
+                    ab_front_ops(&ab, &r2, refAlnStart, (uint32_t)refAlnLen);
                     editScore -= r2.ed;
                     tmp.pos = s[0].tPos - (uint32_t)r2.end - 1;
                     tmp.qStart = s[0].qPos - (uint32_t)qle;
-                    tr_front_n(&cg, (size_t)(readAlnLen - qle), 'I'); tr_front_n(&md, (size_t)(readAlnLen - qle), '-');
+                    ab_front_run(&ab, 'I', '-', (size_t)(readAlnLen - qle));
                     realigned = 1;
                 }
             }
             if (!realigned) {
                 editScore -= r.ed;
-                ops_front(&cg, &md, &r, pac, refAlnStart, (uint32_t)refAlnLen);
+                ab_front_ops(&ab, &r, refAlnStart, (uint32_t)refAlnLen);
                 tmp.pos = s[0].tPos - (uint32_t)r.end - 1;
                 tmp.qStart = 0;
             }
-        } else { tr_front_n(&cg, (size_t)readAlnLen, 'I'); tr_front_n(&md, (size_t)readAlnLen, '-'); }
+        } else ab_front_run(&ab, 'I', '-', (size_t)readAlnLen);
     }
 
     /* ---- between adjacent anchors (:1901-2137) ---- */
     int numAnchorsSoFar = 1;
     for (i = 0; i + 1 < chainLen; i++) {
-        tr_back_n(&cg, s[i].len, 'M'); tr_back_n(&md, s[i].len, '=');
+        ab_back_run(&ab, 'M', '=', s[i].len);
         readAlnStart = s[i].qPos + s[i].len; refAlnStart = s[i].tPos + s[i].len;
         readAlnEnd = s[i + 1].qPos; refAlnEnd = s[i + 1].tPos;
         readAlnLen = (int32_t)(readAlnEnd - readAlnStart); refAlnLen = (int32_t)(refAlnEnd - refAlnStart);
@@ -765,56 +919,52 @@ static int walk_chain(ctx_t *cx, int tid, job_t *job, samlist_t *map)
                     handled = 1;
                     if (rs_new > readAlnStart || ts_new > refAlnStart) {                     /* first part :1998-2007 */
                         edres_t a = need_edlib(&W, 0, readAlnStart, (uint32_t)readAlnLen, rs_new - readAlnStart, 0, refAlnStart, (uint32_t)refAlnLen, ts_new - refAlnStart, 0);
-                        ops_back(&cg, &md, &a, pac, 0, refAlnStart, (uint32_t)refAlnLen);
+                        ab_back_ops(&ab, &a, 0, refAlnStart, (uint32_t)refAlnLen);
                         editScore -= a.ed;
                     }
-                    tr_back_n(&cg, (size_t)((uint32_t)readLen - rs_new), 'I'); tr_back_n(&md, (size_t)((uint32_t)readLen - rs_new), '-');
+                    ab_back_run(&ab, 'I', '-', (size_t)((uint32_t)readLen - rs_new));
                     tmp.posEnd = ts_new; tmp.qEnd = rs_new; tmp.nmCount = editScore;
-                    if (numAnchorsSoFar > 1) emit_sam(&W, map, &tmp, &cg, &md);
-                    tr_clear(&cg); tr_clear(&md); editScore = 0;
+                    if (numAnchorsSoFar > 1) emit_sam(&W, map, &tmp, &ab);
+                    ab_clear(&ab); editScore = 0;
                     if (rs_new < re_new && ts_new < te_new) {                                /* middle part :2033-2077 */
                         edres_t f = need_edlib(&W, 0, rs_new, (uint32_t)rl_new, (uint32_t)rl_new, 0, ts_new, (uint32_t)tl_new, (uint32_t)tl_new, 0);
                         edres_t v = need_edlib(&W, 1, rs_new, (uint32_t)rl_new, (uint32_t)rl_new, 0, ts_new, (uint32_t)tl_new, (uint32_t)tl_new, 0);
                         if (f.have && v.have && (1 - ((double)v.ed / rl_new)) > (1 - ((double)f.ed / rl_new)) && (1 - ((double)v.ed / rl_new)) > REVERSE_SIM) {
                             tmp.flag = isRev ? 0 : 16;
                             tmp.pos = ts_new; tmp.qStart = rs_new; tmp.posEnd = te_new; tmp.qEnd = re_new;
-                            tr_back_n(&cg, rs_new, 'I'); tr_back_n(&md, rs_new, '-');
-                            ops_back(&cg, &md, &v, pac, 0, ts_new, (uint32_t)tl_new);
+                            ab_back_run(&ab, 'I', '-', rs_new);
+                            ab_back_ops(&ab, &v, 0, ts_new, (uint32_t)tl_new);
                             editScore -= v.ed;
-                            tr_back_n(&cg, (size_t)((uint32_t)readLen - re_new), 'I');
-                            tr_front_n(&md, (size_t)((uint32_t)readLen - re_new), '-');           /* sic :2057 (App. B #3) */
+                            ab_cg_back_only(&ab, (size_t)((uint32_t)readLen - re_new));
+                            ab_md_front_only(&ab, (size_t)((uint32_t)readLen - re_new));          /* sic :2057 (App. B #3) */
                             tmp.nmCount = editScore;
-                            emit_sam(&W, map, &tmp, &cg, &md);
-                            tr_clear(&cg); tr_clear(&md); editScore = 0;
+                            emit_sam(&W, map, &tmp, &ab);
+                            ab_clear(&ab); editScore = 0;
                         }
                     }
                     if (re_new < readAlnEnd || te_new < refAlnEnd) {                          /* second part :2079-2090 */
                         edres_t b = need_edlib(&W, 1, readAlnStart, (uint32_t)readAlnLen, readAlnEnd - re_new, 1, refAlnStart, (uint32_t)refAlnLen, refAlnEnd - te_new, 0);
-                        ops_front(&cg, &md, &b, pac, refAlnStart, (uint32_t)refAlnLen);
+                        ab_front_ops(&ab, &b, refAlnStart, (uint32_t)refAlnLen);
                         editScore -= b.ed;
                     }
-                    tr_front_n(&cg, re_new, 'I'); tr_front_n(&md, re_new, '-');
+                    ab_front_run(&ab, 'I', '-', re_new);
                     tmp.flag = isRev ? 16 : 0; tmp.pos = te_new; tmp.qStart = re_new;
                     numAnchorsSoFar = 0;
                 }
             }
-            if (!handled) { editScore -= r.ed; ops_back(&cg, &md, &r, pac, 0, refAlnStart, (uint32_t)refAlnLen); }
+            if (!handled) { editScore -= r.ed; ab_back_ops(&ab, &r, 0, refAlnStart, (uint32_t)refAlnLen); }
         } else if (readAlnLen > 0) {
-            tr_back_n(&cg, (size_t)readAlnLen, 'I'); tr_back_n(&md, (size_t)readAlnLen, '-');
+            ab_back_run(&ab, 'I', '-', (size_t)readAlnLen);
             editScore -= readAlnLen;
         } else {
-            if (refAlnLen > 0) {
-                tr_back_n(&cg, (size_t)refAlnLen, 'D');
-                tr_room(&md, 0, (size_t)refAlnLen);
-                for (int32_t j = 0; j < refAlnLen; j++) md.buf[md.end++] = "ACGT"[pac_base(pac, refAlnStart + (uint32_t)j)];
-            }
+            if (refAlnLen > 0) ab_back_del(&ab, refAlnStart, (uint32_t)refAlnLen);
             editScore -= refAlnLen;
         }
         numAnchorsSoFar++;
     }
 
     /* ---- last anchor and the tail (:2149-2230) ---- */
-    tr_back_n(&cg, s[i].len, 'M'); tr_back_n(&md, s[i].len, '=');
+    ab_back_run(&ab, 'M', '=', s[i].len);
     tmp.posEnd = s[i].tPos + s[i].len - 1; tmp.qEnd = s[i].qPos + s[i].len - 1;
     readAlnStart = s[i].qPos + s[i].len;
     readAlnLen = readLen - (int32_t)readAlnStart; refAlnLen = readAlnLen + 20;
@@ -827,30 +977,42 @@ static int walk_chain(ctx_t *cx, int tid, job_t *job, samlist_t *map)
                 if (!need_ksw(&W, 0, 0, readAlnStart, (uint32_t)readAlnLen, 0, refAlnStart, (uint32_t)refAlnLen, &qle, &tle)) goto bail;
                 if (qle > 0 && qle < readAlnLen) {
                     edres_t r2 = need_edlib(&W, 0, readAlnStart, (uint32_t)readAlnLen, (uint32_t)qle, 0, refAlnStart, (uint32_t)refAlnLen, (uint32_t)tle, 0);
-                    ops_back(&cg, &md, &r2, pac, 0, refAlnStart, (uint32_t)refAlnLen);
+                    ab_back_ops(&ab, &r2, 0, refAlnStart, (uint32_t)refAlnLen);
                     editScore -= r2.ed;
                     tmp.posEnd = refAlnStart + (uint32_t)r2.end;
                     tmp.qEnd = readAlnStart + (uint32_t)qle;
-                    tr_back_n(&cg, (size_t)(readAlnLen - qle), 'I'); tr_back_n(&md, (size_t)(readAlnLen - qle), '-');
+                    ab_back_run(&ab, 'I', '-', (size_t)(readAlnLen - qle));
                     realigned = 1;
                 }
             }
             if (!realigned) {
                 editScore -= r.ed;
-                ops_back(&cg, &md, &r, pac, 0, refAlnStart, (uint32_t)refAlnLen);
+                ab_back_ops(&ab, &r, 0, refAlnStart, (uint32_t)refAlnLen);
                 tmp.posEnd = refAlnStart + (uint32_t)r.end;
                 tmp.qEnd = (uint32_t)readLen;
             }
-        } else { tr_back_n(&cg, (size_t)readAlnLen, 'I'); tr_back_n(&md, (size_t)readAlnLen, '-'); }
+        } else { ab_back_run(&ab, 'I', '-', (size_t)readAlnLen); }
     }
     tmp.nmCount = editScore;
-    emit_sam(&W, map, &tmp, &cg, &md);
+    emit_sam(&W, map, &tmp, &ab);
 bail:
-    free(cg.buf); free(md.buf);
+    *need_track = ab.need_track;
+    ab_free(&ab);
     job->complete = (W.missing == 0 && !W.bail);
-    if (!job->complete) samlist_clear(map);
+    if (!job->complete || ab.need_track) samlist_clear(map);
     return job->complete;
 }
+
+static int walk_chain(ctx_t *cx, int tid, job_t *job, samlist_t *map)
+{
+    int need_track = 0;
+    const int active = job->nmemo > 0;        /* a first walk has no results yet: it only registers requests */
+    int done = walk_chain_mode(cx, tid, job, map, 0, active, &need_track);
+    if (done && !active) done = walk_chain_mode(cx, tid, job, map, 0, 1, &need_track);   /* chain without any alignment */
+    if (done && need_track) done = walk_chain_mode(cx, tid, job, map, 1, 1, &need_track); /* rare: per-base tracks */
+    return done;
+}
+
 
 /* alignWin's scoring tail (src/LordFAST.cpp:1063-1090,1148-1175) */
 static void score_mapping(const lf_params_t *p, samlist_t *map, int isReverse, uint32_t rLen, uint32_t chainLen)
