@@ -184,7 +184,9 @@ def main():
             my_names, my_seqs, _ = lfd.scatter_reads(dist, torch, names, seqs, dev)
         else:
             my_names, my_seqs = names, seqs
+        t_call = time.perf_counter()
         sam, st = lf.map_batch(my_names, my_seqs, params=params, copy=False)
+        st["ms_python_call"] = (time.perf_counter() - t_call) * 1e3
         if dist:
             sam = lfd.gather_sam(dist, torch, sam.view(), dev)
         return sam, st
@@ -240,7 +242,7 @@ def main():
                        "reads_per_gpu": args.reads, "mean_read_len": bases / max(1, n_total), "genome_mbp": args.genome_mbp,
                        "parallelism": f"read-sharded x{world}", "index": "FM-index + full SA resident in HBM"},
             "gbp_per_s": bases * K / elapsed / 1e9,
-            "host_ms_per_step": {k: agg[k] / K for k in ("ms_seed", "ms_vote", "ms_chain", "ms_extend", "ms_sam")},
+            "host_ms_per_step": {k: agg[k] / K for k in ("ms_total", "ms_python_call", "ms_seed", "ms_vote", "ms_chain", "ms_extend", "ms_sam")},
             "per_read": {"seeds": agg["n_seeds"] / (n_total * K / world), "edlib_problems": agg["n_edlib_problems"] / (n_total * K / world),
                          "seed_bytes": (16 * agg["n_cache"] + 64 * agg["n_occblk"] + 8 * agg["n_sa"] + agg["n_readbytes"]) / (n_total * K / world)},
             "roofline": roofline,

@@ -338,25 +338,38 @@ lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs
     const int ed_nw = __shfl(score, lane_last), ed_shw = __shfl(best, lane_last), c_shw = __shfl(best_c, lane_last);
     int ed, tl;
     if (pr.mode == 0) { ed = ed_nw; tl = (int)m; } else { ed = ed_shw; tl = c_shw; }
-    __syncthreads();                      /* history written by all lanes is read back by lane 0 */
-    if (lane != 0) return;
-    out_ed[pr.id] = ed;
-    out_end[pr.id] = tl - 1;
-    if (!want_path) { out_len[pr.id] = 0; return; }
+    __syncthreads();                      /* history written by all lanes is read back below */
+    if (lane == 0) { out_ed[pr.id] = ed; out_end[pr.id] = tl - 1; }
+    if (!want_path) { if (lane == 0) out_len[pr.id] = 0; return; }
+    /* cooperative traceback: the 64 lanes fetch the history of 64 consecutive columns of the current 64-row block
+     * in one round trip (lane l holds column c-l); the walk then runs out of registers via lane broadcasts -- every
+     * lane replays the same moves (uniform control flow), lane 0 writes the ops.  One HBM/L2 round trip per ~64
+     * steps instead of one per step. */
     uint8_t *o = ops + pr.ops_off;
     const uint32_t cap = n + m;
     uint32_t w = cap, r = n, c = (uint32_t)tl;
-    if (c == 0) { while (r) { o[--w] = 1; r--; } }
+    if (c == 0) { if (lane == 0) for (uint32_t i = 0; i < r; i++) o[cap - 1 - i] = 1; w -= r; r = 0; }
     while (r > 0 && c > 0) {
-        const lf_hist_t e = h[(size_t)(c - 1) * nbk + ((r - 1) >> 6)];
-        const int bit = (int)((r - 1) & 63);
-        if ((e.pv >> bit) & 1) { o[--w] = 1; r--; }
-        else if ((e.ph >> bit) & 1) { o[--w] = 2; c--; }
-        else { o[--w] = (Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
+        const uint32_t blk = (r - 1) >> 6, c0 = c;
+        const int col = (int)c0 - lane;
+        lf_hist_t e; e.pv = 0; e.ph = 0;
+        if (col >= 1) e = h[(size_t)(col - 1) * nbk + blk];
+        while (r > 0 && c > 0 && ((r - 1) >> 6) == blk && (c0 - c) < 64) {
+            const int src = (int)(c0 - c);
+            const uint64_t pv = __shfl(e.pv, src), ph = __shfl(e.ph, src);
+            const int bit = (int)((r - 1) & 63);
+            uint8_t op;
+            if ((pv >> bit) & 1) { op = 1; if (lane == 0) o[w - 1] = op; r--; }
+            else if ((ph >> bit) & 1) { op = 2; if (lane == 0) o[w - 1] = op; c--; }
+            else { if (lane == 0) o[w - 1] = (Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
+            w--;
+        }
     }
-    while (c > 0) { o[--w] = 2; c--; }
-    while (r > 0) { o[--w] = 1; r--; }
-    out_len[pr.id] = cap - w;            /* ops are END-aligned: o[cap - len .. cap) */
+    if (lane == 0) {
+        while (c > 0) { o[--w] = 2; c--; }
+        while (r > 0) { o[--w] = 1; r--; }
+        out_len[pr.id] = cap - w;            /* ops are END-aligned: o[cap - len .. cap) */
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -723,16 +736,19 @@ struct lf_ksw_prob { uint64_t qoff, toff, ws_off; int32_t qlen, tlen, o_del, e_d
 
 __global__ void __launch_bounds__(64)
 lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t *__restrict__ qs, const uint8_t *__restrict__ ts,
-              int32_t *__restrict__ ws, int32_t *__restrict__ out_score, int32_t *__restrict__ out_qle, int32_t *__restrict__ out_tle)
+              int32_t *__restrict__ ws, int32_t *__restrict__ out_score, int32_t *__restrict__ out_qle, int32_t *__restrict__ out_tle, int lds_q)
 {
-    const int gid = blockIdx.x * 64 + threadIdx.x;
-    if (gid >= n_probs) return;
+    /* one workgroup per problem; the H/E rows live in LDS when the query fits (lds_q), else in the HBM workspace.
+     * The recurrence is sequential along the row (F carries), so one lane walks it; the branch is rare. */
+    extern __shared__ __attribute__((aligned(16))) int32_t s_he[];
+    const int gid = blockIdx.x;
+    if (gid >= n_probs || threadIdx.x != 0) return;
     const lf_ksw_prob pr = probs[gid];
     const uint8_t *q = qs + pr.qoff, *t = ts + pr.toff;
     const int qlen = pr.qlen, tlen = pr.tlen, o_del = pr.o_del, e_del = pr.e_del, o_ins = pr.o_ins, e_ins = pr.e_ins;
     const int zdrop = pr.zdrop, h0 = pr.h0;
     int w = pr.w;
-    int32_t *H = ws + pr.ws_off, *E = H + qlen + 2;
+    int32_t *H = (qlen <= lds_q) ? s_he : ws + pr.ws_off, *E = H + qlen + 2;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     for (int j = 0; j <= qlen + 1; j++) { H[j] = 0; E[j] = 0; }
     H[0] = h0;
@@ -810,8 +826,11 @@ extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff
     HIPCHK(hipMemcpyAsync(d_t.p, t, toff[n], hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_p.p, P.data(), P.size() * sizeof(lf_ksw_prob), hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(lf_ksw_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_p.as<lf_ksw_prob>(), n, d_q.as<uint8_t>(),
-                       d_t.as<uint8_t>(), d_ws.as<int32_t>(), d_s.as<int32_t>(), d_ql.as<int32_t>(), d_tl.as<int32_t>());
+    int qmax = 0;
+    for (int i = 0; i < n; i++) qmax = std::max(qmax, P[i].qlen);
+    const int lds_q = std::min(qmax, 6000);
+    hipLaunchKernelGGL(lf_ksw_kernel, dim3((unsigned)n), dim3(64), (size_t)(2 * (lds_q + 2)) * 4, s, d_p.as<lf_ksw_prob>(), n, d_q.as<uint8_t>(),
+                       d_t.as<uint8_t>(), d_ws.as<int32_t>(), d_s.as<int32_t>(), d_ql.as<int32_t>(), d_tl.as<int32_t>(), lds_q);
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipMemcpyAsync(score, d_s.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(qle, d_ql.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));

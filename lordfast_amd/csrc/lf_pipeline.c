@@ -1499,6 +1499,7 @@ int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *
         str_room(&all, est + est / 8);
     }
     int rc = LF_OK;
+    if (getenv("LF_TIMING")) fprintf(stderr, "[lf] setup (strlen + SAM buffer) %.1f ms\n", now_ms() - T0);
     /* chunks bound the device + host working set; reads stay in input order */
     const uint64_t CHUNK_BASES = 400ull << 20; const int CHUNK_READS = 32768;
     int i0 = 0;
@@ -1517,7 +1518,10 @@ int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *
             st->n_bases += r->len;
         }
         st->n_reads += (uint64_t)cx.n_reads;
+        double tch = now_ms();
         rc = map_chunk(&cx);
+        if (getenv("LF_TIMING")) fprintf(stderr, "[lf] chunk of %d reads: map_chunk %.1f ms\n", cx.n_reads, now_ms() - tch);
+        tch = now_ms();
         if (rc == LF_OK) {
             uint64_t *ooff = (uint64_t *)malloc(((size_t)cx.n_reads + 1) * 8), tot = 0;
             for (int i = 0; i < cx.n_reads; i++) { ooff[i] = tot; tot += cx.reads[i].out.n; }
@@ -1528,13 +1532,17 @@ int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *
             free(ooff);
         }
         for (int i = 0; i < cx.n_reads; i++) free(cx.reads[i].out.s);
+        if (getenv("LF_TIMING")) fprintf(stderr, "[lf] output assembly %.1f ms\n", now_ms() - tch);
+        tch = now_ms();
         chunk_free(&cx);
         free(cx.reads);
+        if (getenv("LF_TIMING")) fprintf(stderr, "[lf] chunk_free %.1f ms\n", now_ms() - tch);
         i0 = i1;
     }
     pthread_mutex_unlock(&g_map_lock);
     free(lens);
     st->ms_total = now_ms() - T0;
+    if (getenv("LF_TIMING")) fprintf(stderr, "[lf] lf_map_batch total %.1f ms\n", st->ms_total);
     if (rc != LF_OK) { free(all.s); return rc; }
     *sam = all.s;
     if (sam_len) *sam_len = all.n;
