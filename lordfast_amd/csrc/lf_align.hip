@@ -140,18 +140,27 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
     lf_hist_t *h = hist + pr.hist_base + lane;
     const bool want_path = pr.task == LF_TASK_PATH;
 
-    for (uint32_t c = 1; c <= m; c++) {
-        const unsigned char tc = T.get(c - 1);
-        int hin = 1;
+    for (uint32_t c0 = 1; c0 <= m; c0 += 8) {
+        /* the 8 target bases of this trip are fetched together: their latency is paid once, not per column */
+        unsigned char tcs[8];
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const uint64_t Eq = lf_eq_mask(tc, lo[b], hi[b], valid[b], Q, n, b);
-            uint64_t ph, mh;
-            hin = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
-            if (b == lastb) score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
-            if (want_path) { lf_hist_t e; e.pv = Pv[b]; e.ph = ph; h[((size_t)(c - 1) * NB + b) * 64] = e; }
+        for (int k = 0; k < 8; k++) tcs[k] = (c0 + k <= m) ? T.get(c0 + k - 1) : (unsigned char)0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t c = c0 + k;
+            if (c > m) break;
+            const unsigned char tc = tcs[k];
+            int hin = 1;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const uint64_t Eq = lf_eq_mask(tc, lo[b], hi[b], valid[b], Q, n, b);
+                uint64_t ph, mh;
+                hin = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
+                if (b == lastb) score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
+                if (want_path) { lf_hist_t e; e.pv = Pv[b]; e.ph = ph; h[((size_t)(c - 1) * NB + b) * 64] = e; }
+            }
+            if (score < best) { best = score; best_c = (int)c; }
         }
-        if (score < best) { best = score; best_c = (int)c; }
     }
     int ed, tl;
     if (pr.mode == 0) { ed = score; tl = (int)m; } else { ed = best; tl = best_c; }
@@ -259,6 +268,7 @@ lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_s
  * one step earlier through a lane shuffle.  m + lanes - 1 steps instead of m * blocks dependent ones.
  * State lives in registers; history layout = the generic kernel's (private, (c-1)*nbk + block).
  * ---------------------------------------------------------------------------------------------- */
+#define LF_WAVE_LDS_T 8192
 template <int KB>
 __global__ void __launch_bounds__(64)
 lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ hist,
@@ -274,11 +284,25 @@ lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs
     const int nl = (int)((nbk + KB - 1) / KB);            /* lanes that own at least one block */
     uint64_t lo[KB], hi[KB], valid[KB], Pv[KB], Mv[KB];
 #pragma unroll
-    for (int k = 0; k < KB; k++) {
-        lo[k] = hi[k] = valid[k] = 0; Pv[k] = ~0ull; Mv[k] = 0;
-        const uint32_t b = (uint32_t)lane * KB + k;
-        if (b < nbk) for (int i = 0; i < 64; i++) { const uint32_t r = b * 64 + i; if (r < n) lf_plane_add(Q.get(r), i, lo[k], hi[k], valid[k]); }
+    for (int k = 0; k < KB; k++) { lo[k] = hi[k] = valid[k] = 0; Pv[k] = ~0ull; Mv[k] = 0; }
+    /* bit planes by ballot: for block b the 64 lanes fetch its 64 query bytes in one coalesced load and three
+     * wave ballots give lo / hi / valid; the lane that owns block b keeps them */
+    for (uint32_t b = 0; b < nbk; b++) {
+        const uint32_t r = b * 64 + (uint32_t)lane;
+        int code = -1;
+        if (r < n) { switch (Q.get(r)) { case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break; default: code = -1; } }
+        const uint64_t bl = __ballot(code >= 0 && (code & 1)), bh = __ballot(code >= 0 && (code & 2)), bv = __ballot(code >= 0);
+        const int owner = (int)(b / KB), slot = (int)(b % KB);
+        if (lane == owner) {
+#pragma unroll
+            for (int k = 0; k < KB; k++) if (k == slot) { lo[k] = bl; hi[k] = bh; valid[k] = bv; }
+        }
     }
+    /* target staged once into LDS (coalesced), then read from LDS inside the dependent step loop */
+    __shared__ unsigned char s_t[LF_WAVE_LDS_T];
+    const bool t_lds = m <= LF_WAVE_LDS_T;
+    if (t_lds) { for (uint32_t j = (uint32_t)lane; j < m; j += 64) s_t[j] = T.get(j); }
+    __syncthreads();
     const uint32_t lastb = (n - 1) >> 6; const int lastbit = (int)((n - 1) & 63);
     const int lane_last = (int)(lastb / KB);
     int score = (int)n, best = (n & 63) ? (int)n : 0x7fffffff, best_c = 0;
@@ -290,7 +314,7 @@ lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs
         const int from_left = __shfl_up(hout_prev, 1);
         const int c = s - lane + 1;
         if (lane < nl && c >= 1 && c <= (int)m) {
-            const unsigned char tc = T.get((uint32_t)(c - 1));
+            const unsigned char tc = t_lds ? s_t[c - 1] : T.get((uint32_t)(c - 1));
             int hin = lane == 0 ? 1 : from_left;
 #pragma unroll
             for (int k = 0; k < KB; k++) {

@@ -44,24 +44,29 @@ void lf_sort_seeds_by_qpos(Seed_t *s, long n);
 static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
 /* ---------------------------------------------------------------- small containers */
-typedef struct { char *s; size_t n, cap; } str_t;
-static void str_init(str_t *b) { b->cap = 256; b->s = (char *)malloc(b->cap); b->n = 0; b->s[0] = 0; }
+/* mode 0: owned, growable, NUL-terminated; mode 1: count only (nothing is written); mode 2: fixed external window */
+typedef struct { char *s; size_t n, cap; int mode; } str_t;
+static void str_init(str_t *b) { b->cap = 256; b->s = (char *)malloc(b->cap); b->n = 0; b->s[0] = 0; b->mode = 0; }
 static void str_room(str_t *b, size_t extra)
 {
-    if (b->n + extra + 1 <= b->cap) return;
+    if (b->mode || b->n + extra + 1 <= b->cap) return;
     while (b->n + extra + 1 > b->cap) b->cap *= 2;
     b->s = (char *)realloc(b->s, b->cap);
 }
-static void str_putn(str_t *b, const char *s, size_t l) { str_room(b, l); memcpy(b->s + b->n, s, l); b->n += l; b->s[b->n] = 0; }
+static inline void str_putn(str_t *b, const char *s, size_t l)
+{
+    str_room(b, l);
+    if (b->mode != 1) memcpy(b->s + b->n, s, l);
+    b->n += l;
+    if (b->mode == 0) b->s[b->n] = 0;
+}
 static void str_puts(str_t *b, const char *s) { str_putn(b, s, strlen(s)); }
-static void str_putc(str_t *b, char c) { str_room(b, 1); b->s[b->n++] = c; b->s[b->n] = 0; }
+static inline void str_putc(str_t *b, char c) { str_putn(b, &c, 1); }
 static void str_putu(str_t *b, unsigned long long v)
 {
     char tmp[24]; int k = 0;
-    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
-    str_room(b, (size_t)k);
-    while (k) b->s[b->n++] = tmp[--k];
-    b->s[b->n] = 0;
+    do { tmp[23 - k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    str_putn(b, tmp + 24 - k, (size_t)k);
 }
 static void str_puti(str_t *b, long long v) { if (v < 0) { str_putc(b, '-'); str_putu(b, (unsigned long long)(-v)); } else str_putu(b, (unsigned long long)v); }
 
@@ -1116,7 +1121,7 @@ static void phase_prepare(ctx_t *cx, int tid, int ri)
 {
     (void)tid;
     rd_t *r = &cx->reads[ri];
-    str_init(&r->out);
+    memset(&r->out, 0, sizeof r->out);
     if ((int)r->len < cx->p->min_read_len) return;
     r->seq_rev = (char *)malloc((size_t)r->len + 1);
     revcomp_into(r->seq, r->seq_rev, r->len);                          /* reverseComplement :501 */
@@ -1197,25 +1202,24 @@ static void phase_merge_desc(ctx_t *cx, int tid, int t)
     s->dn = 0; s->dops_total = 0; g_edd_jobs[t].n = 0;
 }
 
-static void phase_copy_out(ctx_t *cx, int tid, int ri)
-{
-    (void)tid;
-    memcpy(cx->out_base + cx->out_off[ri], cx->reads[ri].out.s, cx->reads[ri].out.n);
-    free(cx->reads[ri].out.s); cx->reads[ri].out.s = NULL;
-}
 
-static void phase_sam(ctx_t *cx, int tid, int ri)
+/* E is three passes so that the SAM text is formatted straight into its final place:
+ * score + order the mappings; print in COUNT mode (exact record sizes); print again into the final buffer */
+static void phase_sam_score(ctx_t *cx, int tid, int ri)
 {
     (void)tid;
     rd_t *r = &cx->reads[ri];
-    if (r->mode < 2) {
-        r->maps = (samlist_t *)calloc(2, sizeof(samlist_t));
-        print_sam_entry(cx, r, 1);
-        return;
-    }
+    if (r->mode < 2) { r->maps = (samlist_t *)calloc(2, sizeof(samlist_t)); return; }
     for (int w = 0; w < r->nWins; w++) score_mapping(cx->p, &r->maps[w], r->wins[w].isReverse, r->len, r->jobs[w].chainLen);
     if (r->mode == 3) samsort_sort(r->maps, r->nWins);                     /* std::sort(compareSam) :565 */
-    print_sam_entry(cx, r, r->mode == 2 ? 1 : r->nWins);
+}
+static void phase_sam_print(ctx_t *cx, int tid, int ri)
+{
+    (void)tid;
+    rd_t *r = &cx->reads[ri];
+    if (cx->out_base) { r->out.s = cx->out_base + cx->out_off[ri]; r->out.cap = r->out.n; r->out.n = 0; r->out.mode = 2; }
+    else { r->out.s = NULL; r->out.cap = 0; r->out.n = 0; r->out.mode = 1; }
+    print_sam_entry(cx, r, r->mode < 2 ? 1 : (r->mode == 2 ? 1 : r->nWins));
 }
 
 /* ---------------------------------------------------------------- one chunk of reads through all stages */
@@ -1418,8 +1422,10 @@ static int map_chunk(ctx_t *cx)
     }
     t1 = now_ms(); st->ms_extend += t1 - t0; t0 = t1;
 
-    /* ---- E: SAM ---- */
-    parallel_for(cx, n, phase_sam);
+    /* ---- E: SAM (score + count here; the text is written by lf_map_batch straight into the output buffer) ---- */
+    parallel_for(cx, n, phase_sam_score);
+    cx->out_base = NULL;
+    parallel_for(cx, n, phase_sam_print);
     t1 = now_ms(); st->ms_sam += t1 - t0;
     return LF_OK;
 }
@@ -1501,7 +1507,9 @@ int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *
     int rc = LF_OK;
     if (getenv("LF_TIMING")) fprintf(stderr, "[lf] setup (strlen + SAM buffer) %.1f ms\n", now_ms() - T0);
     /* chunks bound the device + host working set; reads stay in input order */
-    const uint64_t CHUNK_BASES = 400ull << 20; const int CHUNK_READS = 32768;
+    const uint64_t CHUNK_BASES = 400ull << 20;
+    int CHUNK_READS = 32768;
+    if (getenv("LF_CHUNK_READS")) { CHUNK_READS = atoi(getenv("LF_CHUNK_READS")); if (CHUNK_READS < 1) CHUNK_READS = 1; }   /* test hook */
     int i0 = 0;
     while (i0 < n && rc == LF_OK) {
         int i1 = i0; uint64_t bases = 0;
@@ -1527,11 +1535,11 @@ int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *
             for (int i = 0; i < cx.n_reads; i++) { ooff[i] = tot; tot += cx.reads[i].out.n; }
             str_room(&all, tot);
             cx.out_base = all.s + all.n; cx.out_off = ooff;
-            parallel_for(&cx, cx.n_reads, phase_copy_out);
+            parallel_for(&cx, cx.n_reads, phase_sam_print);
             all.n += tot; all.s[all.n] = 0;
             free(ooff);
+            st->ms_sam += now_ms() - tch;
         }
-        for (int i = 0; i < cx.n_reads; i++) free(cx.reads[i].out.s);
         if (getenv("LF_TIMING")) fprintf(stderr, "[lf] output assembly %.1f ms\n", now_ms() - tch);
         tch = now_ms();
         chunk_free(&cx);

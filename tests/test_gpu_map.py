@@ -50,6 +50,15 @@ def test_sam_thread_counts(lf, golden_reads, threads):
     assert sam == golden_sam("default")
 
 
+def test_sam_many_chunks(lf, golden_reads, monkeypatch):
+    """reads are processed in chunks; chunk boundaries must not show in the output"""
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    monkeypatch.setenv("LF_CHUNK_READS", "7")
+    sam, st = lf.map_batch(names, seqs, params=la.default_params(threads=2))
+    assert sam == golden_sam("default")
+
+
 def test_sam_fastq_and_readgroup(lf, oracle, oracle_lib, golden_reads):
     import lordfast_amd as la
     names, seqs = golden_reads
