@@ -523,9 +523,13 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
 #undef DSLOT
     /* the size classes run CONCURRENTLY on their own streams: the long-query classes have few, long waves and
      * would leave most CUs idle if the kernels ran back to back */
-    static hipStream_t s = nullptr, cs[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-    static hipEvent_t cdone[7];
-    if (!s) { HIPCHK(hipStreamCreate(&s)); for (int k = 0; k < 7; k++) { HIPCHK(hipStreamCreate(&cs[k])); HIPCHK(hipEventCreateWithFlags(&cdone[k], hipEventDisableTiming)); } }
+    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1), cs[7];
+    static hipEvent_t cdone_all[2][7]; static bool cdone_init[2] = { false, false };
+    const int lane_id = lfg_get_lane();
+    if (!s) return LF_ERR_HIP;
+    for (int k = 0; k < 7; k++) { cs[k] = (hipStream_t)lfg_lane_stream(device, 2 + k); if (!cs[k]) return LF_ERR_HIP; }
+    if (!cdone_init[lane_id]) { for (int k = 0; k < 7; k++) HIPCHK(hipEventCreateWithFlags(&cdone_all[lane_id][k], hipEventDisableTiming)); cdone_init[lane_id] = true; }
+    hipEvent_t *cdone = cdone_all[lane_id];
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     if (!D) {
         HIPCHK(hipMemcpyAsync(d_q, q, qbytes, hipMemcpyHostToDevice, s));
@@ -653,9 +657,13 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     if (ms) *ms = 0;
     if (n == 0) return LF_OK;
     HIPCHK(hipSetDevice(device));
-    static hipStream_t s = nullptr, cs[7];
-    static hipEvent_t cdone[7];
-    if (!s) { HIPCHK(hipStreamCreate(&s)); for (int k = 0; k < 7; k++) { HIPCHK(hipStreamCreate(&cs[k])); HIPCHK(hipEventCreateWithFlags(&cdone[k], hipEventDisableTiming)); } }
+    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1), cs[7];
+    static hipEvent_t cdone_all[2][7]; static bool cdone_init[2] = { false, false };
+    const int lane_id = lfg_get_lane();
+    if (!s) return LF_ERR_HIP;
+    for (int k = 0; k < 7; k++) { cs[k] = (hipStream_t)lfg_lane_stream(device, 2 + k); if (!cs[k]) return LF_ERR_HIP; }
+    if (!cdone_init[lane_id]) { for (int k = 0; k < 7; k++) HIPCHK(hipEventCreateWithFlags(&cdone_all[lane_id][k], hipEventDisableTiming)); cdone_init[lane_id] = true; }
+    hipEvent_t *cdone = cdone_all[lane_id];
 #define DSLOT(T, k, bytes) (T *)lfg_dev_slot(device, LF_DS_ALN0 + (k), (bytes))
     lf_aln_desc_t *d_desc = DSLOT(lf_aln_desc_t, 0, (size_t)n * sizeof(lf_aln_desc_t));
     uint64_t *d_opsoff = DSLOT(uint64_t, 1, (size_t)n * 8);

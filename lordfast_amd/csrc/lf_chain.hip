@@ -127,13 +127,14 @@ extern "C" int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, con
     for (uint64_t d = 0; d < max_d; d++) pen[d] = d <= 1 ? 0.0 : 0.1 * (double)(int)d + p->chain_penalty * log((double)(int)d);
     const double reward = p->chain_reward * (double)p->min_anchor_len;     /* score_reward, src/Chain.cpp:211-215 */
 
-    void *d_w = nullptr, *d_seeds = nullptr, *d_pen = nullptr, *d_dp = nullptr, *d_prev = nullptr, *d_idx = nullptr, *d_len = nullptr, *d_sc = nullptr;
-    HIPCHK(hipMalloc(&d_w, W.size() * sizeof(lf_chain_win)));
-    HIPCHK(hipMalloc(&d_seeds, total * 8 + 16));
-    HIPCHK(hipMalloc(&d_pen, pen.size() * 8));
-    HIPCHK(hipMalloc(&d_dp, ws * 8 + 16)); HIPCHK(hipMalloc(&d_prev, ws * 4 + 16));
-    HIPCHK(hipMalloc(&d_idx, total * 4 + 16)); HIPCHK(hipMalloc(&d_len, (size_t)n_windows * 4)); HIPCHK(hipMalloc(&d_sc, (size_t)n_windows * 4));
-    hipStream_t s; HIPCHK(hipStreamCreate(&s));
+#define CSLOT(k, bytes) lfg_dev_slot(device, LF_DS_CHAIN0 + (k), (bytes))
+    void *d_w = CSLOT(0, W.size() * sizeof(lf_chain_win)), *d_seeds = CSLOT(1, total * 8 + 16), *d_pen = CSLOT(2, pen.size() * 8);
+    void *d_dp = CSLOT(3, ws * 8 + 16), *d_prev = CSLOT(4, ws * 4 + 16), *d_idx = CSLOT(5, total * 4 + 16);
+    void *d_len = CSLOT(6, (size_t)n_windows * 4), *d_sc = CSLOT(7, (size_t)n_windows * 4);
+#undef CSLOT
+    if (!d_w || !d_seeds || !d_pen || !d_dp || !d_prev || !d_idx || !d_len || !d_sc) return LF_ERR_NOMEM;
+    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 9);
+    if (!s) return LF_ERR_HIP;
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipMemcpyAsync(d_w, W.data(), W.size() * sizeof(lf_chain_win), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_seeds, sorted_seeds, total * 8, hipMemcpyHostToDevice, s));
@@ -161,8 +162,6 @@ extern "C" int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, con
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
-    (void)hipFree(d_w); (void)hipFree(d_seeds); (void)hipFree(d_pen); (void)hipFree(d_dp); (void)hipFree(d_prev);
-    (void)hipFree(d_idx); (void)hipFree(d_len); (void)hipFree(d_sc);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return LF_OK;
 }

@@ -64,6 +64,9 @@ int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff, const uin
 void *lfg_dev_slot(int device, int slot, size_t bytes);
 void *lfg_pin_slot(int slot, size_t bytes);
 void  lfg_slots_release(void);
+void  lfg_set_lane(int lane);          /* calling thread drives lane 0 or 1 (own slots + streams) */
+int   lfg_get_lane(void);
+void *lfg_lane_stream(int device, int which);   /* persistent hipStream_t of the calling thread's lane */
 /* slot ids */
 enum { LF_DS_SEED0 = 0 /* ..15 */, LF_DS_CHAIN0 = 16 /* ..23 */, LF_DS_ALN0 = 24 /* ..47 */, LF_DS_KSW0 = 48 /* ..55 */ };
 enum { LF_PS_READS = 0, LF_PS_READOFF = 1, LF_PS_HITS_T = 2, LF_PS_HITS_Q = 3, LF_PS_HITS_S = 4, LF_PS_HITS_OFF = 5,

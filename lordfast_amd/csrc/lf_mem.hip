@@ -8,14 +8,30 @@
 
 namespace {
 struct slot_t { void *p = nullptr; size_t cap = 0; };
-constexpr int MAX_DEV = 16, MAX_SLOT = 96;
+constexpr int MAX_DEV = 16, MAX_SLOT = 256, LANE_STRIDE = 112, MAX_LANE = 2;
+thread_local int t_lane = 0;
+hipStream_t g_streams[MAX_DEV][MAX_LANE][16];
 slot_t g_dev[MAX_DEV][MAX_SLOT];
 slot_t g_pin[MAX_SLOT];
 std::mutex g_mu;
 }
 
+/* two batches ("lanes") may be in flight at once, each driven by its own host thread: a lane owns its own
+ * set of slots and streams, so nothing is shared between them but the index */
+extern "C" void lfg_set_lane(int lane) { t_lane = (lane >= 0 && lane < MAX_LANE) ? lane : 0; }
+extern "C" int lfg_get_lane(void) { return t_lane; }
+extern "C" void *lfg_lane_stream(int device, int which)
+{
+    if (device < 0 || device >= MAX_DEV || which < 0 || which >= 16) return nullptr;
+    std::lock_guard<std::mutex> g(g_mu);
+    hipStream_t &st = g_streams[device][t_lane][which];
+    if (!st) { if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&st) != hipSuccess) { lf_set_error("hipStreamCreate failed"); return nullptr; } }
+    return (void *)st;
+}
+
 extern "C" void *lfg_dev_slot(int device, int slot, size_t bytes)
 {
+    slot += t_lane * LANE_STRIDE;
     if (device < 0 || device >= MAX_DEV || slot < 0 || slot >= MAX_SLOT) { lf_set_error("bad device slot %d/%d", device, slot); return nullptr; }
     std::lock_guard<std::mutex> g(g_mu);
     slot_t &s = g_dev[device][slot];
@@ -32,6 +48,7 @@ extern "C" void *lfg_dev_slot(int device, int slot, size_t bytes)
 
 extern "C" void *lfg_pin_slot(int slot, size_t bytes)
 {
+    slot += t_lane * LANE_STRIDE;
     if (slot < 0 || slot >= MAX_SLOT) { lf_set_error("bad pinned slot %d", slot); return nullptr; }
     std::lock_guard<std::mutex> g(g_mu);
     slot_t &s = g_pin[slot];

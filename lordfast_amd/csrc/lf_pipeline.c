@@ -44,21 +44,56 @@ void lf_sort_seeds_by_qpos(Seed_t *s, long n);
 static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
 /* ---------------------------------------------------------------- small containers */
-/* mode 0: owned, growable, NUL-terminated; mode 1: count only (nothing is written); mode 2: fixed external window */
-typedef struct { char *s; size_t n, cap; int mode; } str_t;
-static void str_init(str_t *b) { b->cap = 256; b->s = (char *)malloc(b->cap); b->n = 0; b->s[0] = 0; b->mode = 0; }
+/* ---- per-worker bump arenas: every chunk-lifetime object of the host glue (seed lists, jobs, memos, CIGAR/MD strings,
+ * ...) is carved from the arena of the thread that creates it and released by ONE reset at the end of the chunk.
+ * With two chunks in flight, malloc/free pairs that cross threads contend on glibc's arena locks; a bump allocator
+ * has no locks and no per-object free at all. ---- */
+typedef struct { char **blk; size_t *bsz; int nblk, cur; size_t off; } arena_t;
+#define AR_BLOCK ((size_t)8 << 20)
+static void *ar_alloc(arena_t *a, size_t n)
+{
+    n = (n + 15) & ~(size_t)15;
+    for (;;) {
+        if (a->cur < a->nblk && a->off + n <= a->bsz[a->cur]) { void *p = a->blk[a->cur] + a->off; a->off += n; return p; }
+        if (a->cur + 1 < a->nblk && n <= a->bsz[a->cur + 1]) { a->cur++; a->off = 0; continue; }
+        /* new block (inserted after the current one so that larger requests do not strand the rest) */
+        size_t sz = n > AR_BLOCK ? n : AR_BLOCK;
+        a->blk = (char **)realloc(a->blk, ((size_t)a->nblk + 1) * sizeof(char *)); a->bsz = (size_t *)realloc(a->bsz, ((size_t)a->nblk + 1) * sizeof(size_t));
+        int at = a->nblk ? a->cur + 1 : 0;
+        for (int i = a->nblk; i > at; i--) { a->blk[i] = a->blk[i - 1]; a->bsz[i] = a->bsz[i - 1]; }
+        a->blk[at] = (char *)malloc(sz); a->bsz[at] = sz; a->nblk++;
+        a->cur = at; a->off = 0;
+    }
+}
+static void *ar_zalloc(arena_t *a, size_t n) { void *p = ar_alloc(a, n); memset(p, 0, n); return p; }
+static void *ar_grow(arena_t *a, void *old, size_t old_bytes, size_t new_bytes)
+{
+    void *p = ar_alloc(a, new_bytes);
+    if (old && old_bytes) memcpy(p, old, old_bytes);
+    return p;
+}
+static void ar_reset(arena_t *a) { a->cur = 0; a->off = 0; }
+static arena_t g_arena[2][258];          /* [lane][worker]; blocks are kept across chunks and batches */
+
+/* mode 0: owned, growable, NUL-terminated; mode 1: count only (nothing is written); mode 2: fixed external window;
+ * mode 3: growable inside an arena (never freed individually) */
+typedef struct { char *s; size_t n, cap; int mode; arena_t *ar; } str_t;
+static void str_init(str_t *b) { b->cap = 256; b->s = (char *)malloc(b->cap); b->n = 0; b->s[0] = 0; b->mode = 0; b->ar = NULL; }
+static void str_init_ar(str_t *b, arena_t *ar, size_t cap0) { b->cap = cap0 < 64 ? 64 : cap0; b->s = (char *)ar_alloc(ar, b->cap); b->n = 0; b->s[0] = 0; b->mode = 3; b->ar = ar; }
 static void str_room(str_t *b, size_t extra)
 {
-    if (b->mode || b->n + extra + 1 <= b->cap) return;
-    while (b->n + extra + 1 > b->cap) b->cap *= 2;
-    b->s = (char *)realloc(b->s, b->cap);
+    if (b->mode == 1 || b->mode == 2 || b->n + extra + 1 <= b->cap) return;
+    size_t nc = b->cap;
+    while (b->n + extra + 1 > nc) nc *= 2;
+    if (b->mode == 3) b->s = (char *)ar_grow(b->ar, b->s, b->n + 1, nc); else b->s = (char *)realloc(b->s, nc);
+    b->cap = nc;
 }
 static inline void str_putn(str_t *b, const char *s, size_t l)
 {
     str_room(b, l);
     if (b->mode != 1) memcpy(b->s + b->n, s, l);
     b->n += l;
-    if (b->mode == 0) b->s[b->n] = 0;
+    if (b->mode == 0 || b->mode == 3) b->s[b->n] = 0;
 }
 static void str_puts(str_t *b, const char *s) { str_putn(b, s, strlen(s)); }
 static inline void str_putc(str_t *b, char c) { str_putn(b, &c, 1); }
@@ -103,10 +138,10 @@ typedef struct { sam_t *v; int n, cap; int32_t totalScore; } samlist_t;
 #define SAM_LESS(a, b) ((a)->totalScore > (b)->totalScore)    /* compareSam, src/LordFAST.cpp:986-992 */
 LF_DEFINE_STDSORT(samsort, samlist_t, SAM_LESS)
 
-static void samlist_clear(samlist_t *l) { for (int i = 0; i < l->n; i++) { free(l->v[i].cigar); free(l->v[i].md); } l->n = 0; }
-static void samlist_push(samlist_t *l, const sam_t *s, char *cigar, char *md)
+static void samlist_clear(samlist_t *l) { l->n = 0; }                 /* strings and the array live in an arena */
+static void samlist_push(samlist_t *l, const sam_t *s, char *cigar, char *md, arena_t *ar)
 {
-    if (l->n == l->cap) { l->cap = l->cap ? l->cap * 2 : 2; l->v = (sam_t *)realloc(l->v, (size_t)l->cap * sizeof(sam_t)); }
+    if (l->n == l->cap) { int nc = l->cap ? l->cap * 2 : 2; l->v = (sam_t *)ar_grow(ar, l->v, (size_t)l->cap * sizeof(sam_t), (size_t)nc * sizeof(sam_t)); l->cap = nc; }
     l->v[l->n] = *s; l->v[l->n].cigar = cigar; l->v[l->n].md = md; l->n++;
 }
 
@@ -185,6 +220,9 @@ typedef struct ctx {
     ksw_round_t *ksw_rounds; int n_ksw_rounds;
     stage_t *stages;       /* per worker */
     lf_stats_t *st;
+    int lane;                       /* 0 / 1: which of the two in-flight chunks this is */
+    arena_t *arena;                 /* g_arena[lane]: one per worker */
+    struct cstage *cstage; struct jobvec *ed_jobs, *ksw_jobs, *edd_jobs;      /* per worker thread */
     const lfg_hits_t *hits;
     /* scratch for the parallel merge of staged alignment requests */
     lf_aln_desc_t *mg_desc; char *mg_qb, *mg_tb; uint64_t *mg_qoff, *mg_toff, *mg_qbase, *mg_tbase; uint8_t *mg_mode; int *mg_gbase; ed_round_t *mg_R; int mg_round;
@@ -194,72 +232,84 @@ typedef struct ctx {
     int *seed_map; char *cat; uint64_t *cat_off;
 } ctx_t;
 
-/* ---------------------------------------------------------------- parallel for on a persistent thread pool */
+/* ---------------------------------------------------------------- parallel for on a persistent thread pool
+ * Two chunks ("lanes") are in flight at once so that the host phases of one overlap the GPU phases of the other.
+ * The pool therefore serves up to two jobs concurrently; each lane's driver thread also works on its own job.
+ * Worker ids: pool threads 0..nw-1, lane drivers nw and nw+1 (per-worker scratch arrays have nw+2 entries). */
 typedef void (*pf_fn)(ctx_t *cx, int tid, int i);
+typedef struct { pf_fn fn; ctx_t *cx; int n, grain; volatile int next; int active, inflight; } pjob_t;
 typedef struct {
-    pthread_t th[256]; int nt, started;
-    pthread_mutex_t mu; pthread_cond_t cv_start, cv_done;
-    unsigned gen; int running, stop;
-    pf_fn fn; ctx_t *cx; int n, grain; volatile int next;
+    pthread_t th[256]; int nw, started, stop;
+    pthread_mutex_t mu; pthread_cond_t cv_work, cv_done[2];
+    pjob_t job[2];
 } pool_t;
-static pool_t g_pool = { .mu = PTHREAD_MUTEX_INITIALIZER, .cv_start = PTHREAD_COND_INITIALIZER, .cv_done = PTHREAD_COND_INITIALIZER };
+static pool_t g_pool = { .mu = PTHREAD_MUTEX_INITIALIZER, .cv_work = PTHREAD_COND_INITIALIZER,
+                         .cv_done = { PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER } };
 
-static void pool_run(pool_t *P, int tid)
+static void pool_run(pjob_t *J, int tid)
 {
     for (;;) {
-        int i = __sync_fetch_and_add(&P->next, P->grain);
-        if (i >= P->n) break;
-        int e = i + P->grain < P->n ? i + P->grain : P->n;
-        for (; i < e; i++) P->fn(P->cx, tid, i);
+        int i = __sync_fetch_and_add(&J->next, J->grain);
+        if (i >= J->n) break;
+        int e = i + J->grain < J->n ? i + J->grain : J->n;
+        for (; i < e; i++) J->fn(J->cx, tid, i);
     }
 }
 static void *pool_worker(void *arg)
 {
     pool_t *P = &g_pool;
     const int tid = (int)(intptr_t)arg;
-    unsigned seen = 0;
     pthread_mutex_lock(&P->mu);
     for (;;) {
-        while (P->gen == seen && !P->stop) pthread_cond_wait(&P->cv_start, &P->mu);
+        int pick = -1;
+        for (int k = 0; k < 2; k++) { const int j = (tid + k) & 1; if (P->job[j].active && P->job[j].next < P->job[j].n) { pick = j; break; } }
+        if (pick >= 0) {
+            pjob_t *J = &P->job[pick];
+            J->inflight++;
+            pthread_mutex_unlock(&P->mu);
+            pool_run(J, tid);
+            pthread_mutex_lock(&P->mu);
+            if (--J->inflight == 0) pthread_cond_signal(&P->cv_done[pick]);
+            continue;
+        }
         if (P->stop) break;
-        seen = P->gen;
-        pthread_mutex_unlock(&P->mu);
-        pool_run(P, tid);
-        pthread_mutex_lock(&P->mu);
-        if (--P->running == 0) pthread_cond_signal(&P->cv_done);
+        pthread_cond_wait(&P->cv_work, &P->mu);
     }
     pthread_mutex_unlock(&P->mu);
     return NULL;
 }
-static void pool_ensure(int nt)
+static void pool_ensure(int nw)
 {
     pool_t *P = &g_pool;
-    if (P->started && P->nt == nt) return;
-    if (P->started) {                                   /* thread count changed: restart the pool */
-        pthread_mutex_lock(&P->mu); P->stop = 1; pthread_cond_broadcast(&P->cv_start); pthread_mutex_unlock(&P->mu);
-        for (int t = 1; t < P->nt; t++) pthread_join(P->th[t], NULL);
+    if (P->started && P->nw == nw) return;
+    if (P->started) {                                   /* worker count changed: restart the pool */
+        pthread_mutex_lock(&P->mu); P->stop = 1; pthread_cond_broadcast(&P->cv_work); pthread_mutex_unlock(&P->mu);
+        for (int t = 0; t < P->nw; t++) pthread_join(P->th[t], NULL);
         P->stop = 0; P->started = 0;
     }
-    P->nt = nt; P->gen = 0;
+    P->nw = nw;
     pthread_attr_t at; pthread_attr_init(&at); pthread_attr_setstacksize(&at, 4u << 20);
-    for (int t = 1; t < nt; t++) pthread_create(&P->th[t], &at, pool_worker, (void *)(intptr_t)t);   /* tid 0 = caller */
+    for (int t = 0; t < nw; t++) pthread_create(&P->th[t], &at, pool_worker, (void *)(intptr_t)t);
     P->started = 1;
 }
+/* called by a lane driver (cx->lane); returns when every item ran */
 static void parallel_for(ctx_t *cx, int n, pf_fn fn)
 {
     pool_t *P = &g_pool;
     if (n <= 0) return;
-    pool_ensure(cx->n_threads);
-    P->fn = fn; P->cx = cx; P->n = n; P->next = 0;
-    P->grain = n / (P->nt * 16) + 1; if (P->grain > 64) P->grain = 64;
-    if (P->nt <= 1) { pool_run(P, 0); return; }
+    pjob_t *J = &P->job[cx->lane];
+    const int self = P->nw + cx->lane;
     pthread_mutex_lock(&P->mu);
-    P->running = P->nt - 1; P->gen++;
-    pthread_cond_broadcast(&P->cv_start);
+    J->fn = fn; J->cx = cx; J->n = n; J->next = 0;
+    J->grain = n / ((P->nw + 1) * 16) + 1; if (J->grain > 64) J->grain = 64;
+    J->inflight = 1; J->active = 1;
+    pthread_cond_broadcast(&P->cv_work);
     pthread_mutex_unlock(&P->mu);
-    pool_run(P, 0);
+    pool_run(J, self);
     pthread_mutex_lock(&P->mu);
-    while (P->running) pthread_cond_wait(&P->cv_done, &P->mu);
+    J->inflight--;
+    while (J->inflight > 0) pthread_cond_wait(&P->cv_done[cx->lane], &P->mu);
+    J->active = 0;
     pthread_mutex_unlock(&P->mu);
 }
 
@@ -355,13 +405,12 @@ static void top_push(win_t *l, int *n, int maxWin, uint32_t i, uint32_t L, float
     }
 }
 
-typedef struct { creq_t *v; int n, cap; Seed_t *s; uint64_t ns, caps; wc_t *wbuf; size_t wcap; wc_t *wbuf2; size_t wcap2; } cstage_t;
-static cstage_t *g_cstage;      /* per worker, set up by lf_map_batch */
+typedef struct cstage { creq_t *v; int n, cap; Seed_t *s; uint64_t ns, caps; wc_t *wbuf; size_t wcap; wc_t *wbuf2; size_t wcap2; } cstage_t;
 
 /* selection of src/LordFAST.cpp:995-1018 (== :659-680) into the worker's chain-request stage */
 static int add_chain_request(ctx_t *cx, int tid, int ri, int isRev, uint32_t tStart, uint32_t tEnd)
 {
-    cstage_t *cs = &g_cstage[tid];
+    cstage_t *cs = &cx->cstage[tid];
     const rd_t *r = &cx->reads[ri];
     const uint32_t L = r->len, margin = L >> 1;
     uint32_t cb, ce;
@@ -385,7 +434,7 @@ static void phase_vote(ctx_t *cx, int tid, int ri)
 {
     rd_t *r = &cx->reads[ri];
     const lf_params_t *p = cx->p;
-    cstage_t *cs = &g_cstage[tid];
+    cstage_t *cs = &cx->cstage[tid];
     r->vote_tid = tid;
     if ((int)r->len < p->min_read_len) { r->mode = 0; return; }
     {   /* this read's hits -> the two SeedLists of the reference (forward / reverse), order kept */
@@ -394,7 +443,7 @@ static void phase_vote(ctx_t *cx, int tid, int ri)
         uint32_t nr = 0;
         for (uint64_t j = a; j < b; j++) nr += h->strand[j];
         r->nR = nr; r->nF = (uint32_t)(b - a) - nr;
-        r->F = (Seed_t *)malloc(((size_t)(b - a) + 2) * sizeof(Seed_t)); r->R = r->F + r->nF + 1;
+        r->F = (Seed_t *)ar_alloc(&cx->arena[tid], ((size_t)(b - a) + 2) * sizeof(Seed_t)); r->R = r->F + r->nF + 1;
         uint32_t f = 0, v = 0;
         for (uint64_t j = a; j < b; j++) {
             Seed_t sd; sd.tPos = h->tpos[j]; sd.qPos = h->qpl[j] & 0xFFFFF; sd.len = h->qpl[j] >> 20;
@@ -406,7 +455,7 @@ static void phase_vote(ctx_t *cx, int tid, int ri)
     uint32_t lim = (uint32_t)cx->ix->l_pac / L + 2;                                          /* :622-624 */
     if (lim > refWinNum) lim = refWinNum;
     const int maxWin = p->max_map;
-    r->wins = (win_t *)calloc((size_t)maxWin + 1, sizeof(win_t));
+    r->wins = (win_t *)ar_zalloc(&cx->arena[tid], ((size_t)maxWin + 1) * sizeof(win_t));
     r->nWins = 0;
     wc_t *wF, *wR;
     int dF = vote(p, L, r->F, r->nF, &cs->wbuf, &cs->wcap, &wF);
@@ -432,7 +481,7 @@ static void phase_vote(ctx_t *cx, int tid, int ri)
             const wc_t *w = pass ? wR : wF; const int d = pass ? dR : dF;
             for (int k = 0; k < d && w[k].win < lim; k++) {
                 if ((float)w[k].cnt > minScore && local_max(w, d, k, refWinNum)) {                /* :875-877 */
-                    if (r->ncand == r->capcand) { r->capcand = r->capcand ? r->capcand * 2 : 8; r->cands = (struct cand *)realloc(r->cands, (size_t)r->capcand * sizeof(struct cand)); }
+                    if (r->ncand == r->capcand) { int nc = r->capcand ? r->capcand * 2 : 8; r->cands = (struct cand *)ar_grow(&cx->arena[tid], r->cands, (size_t)r->capcand * sizeof(struct cand), (size_t)nc * sizeof(struct cand)); r->capcand = nc; }
                     r->cands[r->ncand].win = w[k].win; r->cands[r->ncand].isRev = (uint8_t)pass;
                     r->cands[r->ncand].req = add_chain_request(cx, tid, ri, pass, w[k].win * L, (w[k].win + 2) * L - 1);
                     r->ncand++;
@@ -475,9 +524,9 @@ static memo_t *memo_find(job_t *j, const rkey_t *k)
     for (int i = 0; i < j->nmemo; i++) if (key_eq(&j->memo[i].key, k)) { j->hint = i + 1; return &j->memo[i]; }
     return NULL;
 }
-static memo_t *memo_add(job_t *j, const rkey_t *k)
+static memo_t *memo_add(job_t *j, const rkey_t *k, arena_t *ar)
 {
-    if (j->nmemo == j->capmemo) { j->capmemo = j->capmemo ? j->capmemo * 2 : 32; j->memo = (memo_t *)realloc(j->memo, (size_t)j->capmemo * sizeof(memo_t)); }
+    if (j->nmemo == j->capmemo) { int nc = j->capmemo ? j->capmemo * 2 : 32; j->memo = (memo_t *)ar_grow(ar, j->memo, (size_t)j->capmemo * sizeof(memo_t), (size_t)nc * sizeof(memo_t)); j->capmemo = nc; }
     memo_t *m = &j->memo[j->nmemo++];
     m->key = *k; m->round = -1; m->slot = -1;
     j->hint = j->nmemo;
@@ -524,8 +573,7 @@ static void stage_edlib(walk_t *w, memo_t *m)
 }
 
 /* job owner bookkeeping: parallel arrays */
-typedef struct { job_t **job; int n, cap; } jobvec_t;
-static jobvec_t *g_ed_jobs, *g_ksw_jobs, *g_edd_jobs;   /* per worker */
+typedef struct jobvec { job_t **job; int n, cap; } jobvec_t;
 static void jv_push(jobvec_t *v, job_t *j) { if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 1024; v->job = (job_t **)realloc(v->job, (size_t)v->cap * sizeof(job_t *)); } v->job[v->n++] = j; }
 
 static void stage_ksw(walk_t *w, memo_t *m)
@@ -601,9 +649,9 @@ static edres_t need_edlib(walk_t *w, int qrc, uint32_t qs, uint32_t qseg, uint32
     k.qs = qs; k.qseg = qseg; k.qn = qn; k.ts = ts; k.tseg = tseg; k.tn = tn;
     memo_t *m = memo_find(w->job, &k);
     if (!m) {
-        m = memo_add(w->job, &k);
-        if (lf_is_leaf(qn, tn) && qn > 0 && tn > 0) { stage_edlib_desc(w, m); jv_push(&g_edd_jobs[w->tid], w->job); }
-        else { stage_edlib(w, m); jv_push(&g_ed_jobs[w->tid], w->job); }      /* Hirschberg-size: byte strings */
+        m = memo_add(w->job, &k, &w->cx->arena[w->tid]);
+        if (lf_is_leaf(qn, tn) && qn > 0 && tn > 0) { stage_edlib_desc(w, m); jv_push(&w->cx->edd_jobs[w->tid], w->job); }
+        else { stage_edlib(w, m); jv_push(&w->cx->ed_jobs[w->tid], w->job); }      /* Hirschberg-size: byte strings */
     }
     if (m->round < 0) { w->missing++; w->build = 0; r.ed = 0; r.end = (mode == 0) ? (int)tn - 1 : (int)tn - 1; return r; }
     const ed_round_t *R = &w->cx->ed_rounds[m->round];
@@ -618,7 +666,7 @@ static int need_ksw(walk_t *w, int set, int qrc, uint32_t qs, uint32_t qseg, int
     k.type = 1; k.qrc = (uint8_t)qrc; k.trc = (uint8_t)trc; k.mode = (uint8_t)set;
     k.qs = qs; k.qseg = qseg; k.qn = qseg; k.ts = ts; k.tseg = tseg; k.tn = tseg;
     memo_t *m = memo_find(w->job, &k);
-    if (!m) { m = memo_add(w->job, &k); stage_ksw(w, m); jv_push(&g_ksw_jobs[w->tid], w->job); }
+    if (!m) { m = memo_add(w->job, &k, &w->cx->arena[w->tid]); stage_ksw(w, m); jv_push(&w->cx->ksw_jobs[w->tid], w->job); }
     if (m->round < 0) { w->bail = 1; w->build = 0; return 0; }
     const ksw_round_t *R = &w->cx->ksw_rounds[m->round];
     *qle = R->qle[m->slot]; *tle = R->tle[m->slot];
@@ -660,9 +708,9 @@ static void ops_front(track_t *cg, track_t *md, const edres_t *r, const uint8_t 
     }
 }
 
-static char *cigar_string(const track_t *c)
+static char *cigar_string(const track_t *c, arena_t *ar)
 {   /* edlibCigar_toString: leading / trailing I runs print as S */
-    str_t sb; str_init(&sb);
+    str_t sb; str_init_ar(&sb, ar, 512);
     char ch = 0; unsigned num = 0; int opn = 0;
     const size_t n = tr_size(c);
     for (size_t i = 0; i < n; i++) {
@@ -675,9 +723,9 @@ static char *cigar_string(const track_t *c)
     if (num) { str_putu(&sb, num); str_putc(&sb, ch == 'I' ? 'S' : ch); }
     return sb.s;
 }
-static char *md_string(const track_t *md, const track_t *cg)
+static char *md_string(const track_t *md, const track_t *cg, arena_t *ar)
 {   /* edlibMD_toString */
-    str_t sb; str_init(&sb);
+    str_t sb; str_init_ar(&sb, ar, 512);
     unsigned num = 0; char last = '=';
     const size_t n = tr_size(md);
     for (size_t i = 0; i < n; i++) {
@@ -704,21 +752,21 @@ typedef struct {
     track_t cg, md;                        /* TRACK mode */
     str_t scg, smd; char ch; unsigned run; int opn; unsigned mdnum; char last; int fed;    /* STREAM mode */
     fseg_t front[8]; int nfront;
-    const uint8_t *pac;
+    const uint8_t *pac; arena_t *ar; size_t hint;
 } alnb_t;
 
-static void ab_reset_stream(alnb_t *b) { str_init(&b->scg); str_init(&b->smd); b->ch = 0; b->run = 0; b->opn = 0; b->mdnum = 0; b->last = '='; b->fed = 0; b->nfront = 0; }
-static void ab_init(alnb_t *b, int track_mode, int active, const uint8_t *pac, size_t hint)
+static void ab_reset_stream(alnb_t *b) { str_init_ar(&b->scg, b->ar, b->hint); str_init_ar(&b->smd, b->ar, b->hint); b->ch = 0; b->run = 0; b->opn = 0; b->mdnum = 0; b->last = '='; b->fed = 0; b->nfront = 0; }
+static void ab_init(alnb_t *b, int track_mode, int active, const uint8_t *pac, size_t hint, arena_t *ar)
 {
     memset(b, 0, sizeof *b);
-    b->track_mode = track_mode; b->active = active; b->pac = pac;
+    b->track_mode = track_mode; b->active = active; b->pac = pac; b->ar = ar; b->hint = hint / 2 + 128;
     if (!active) return;
     if (track_mode) { tr_init(&b->cg, hint); tr_init(&b->md, hint); } else ab_reset_stream(b);
 }
 static void ab_free(alnb_t *b)
 {
     if (!b->active) return;
-    if (b->track_mode) { free(b->cg.buf); free(b->md.buf); } else { free(b->scg.s); free(b->smd.s); }
+    if (b->track_mode) { free(b->cg.buf); free(b->md.buf); }
 }
 static inline void st_c(alnb_t *b, char c, uint32_t n)
 {
@@ -830,12 +878,12 @@ static void ab_clear(alnb_t *b)
 {
     if (!b->active) return;
     if (b->track_mode) { tr_clear(&b->cg); tr_clear(&b->md); return; }
-    free(b->scg.s); free(b->smd.s); ab_reset_stream(b);
+    ab_reset_stream(b);
 }
 /* strings of the record built so far (ownership passes to the caller) */
 static void ab_take(alnb_t *b, char **cigar, char **md)
 {
-    if (b->track_mode) { *cigar = cigar_string(&b->cg); *md = md_string(&b->md, &b->cg); return; }
+    if (b->track_mode) { *cigar = cigar_string(&b->cg, b->ar); *md = md_string(&b->md, &b->cg, b->ar); return; }
     ab_flush_front(b);
     if (b->run) { str_putu(&b->scg, b->run); str_putc(&b->scg, b->ch == 'I' ? 'S' : b->ch); }
     str_putu(&b->smd, b->mdnum);
@@ -848,7 +896,7 @@ static void emit_sam(walk_t *w, samlist_t *map, const sam_t *tmp, alnb_t *ab)
     if (!w->build || !ab->active || ab->need_track) return;
     char *c, *m;
     ab_take(ab, &c, &m);
-    samlist_push(map, tmp, c, m);
+    samlist_push(map, tmp, c, m, ab->ar);
 }
 
 /* the walk itself.  Returns 1 when every alignment it needed was available (map is then final). */
@@ -864,7 +912,7 @@ static int walk_chain_mode(ctx_t *cx, int tid, job_t *job, samlist_t *map, int t
     W.cx = cx; W.tid = tid; W.job = job; W.query = isRev ? rd->seq_rev : rd->seq; W.readLen = rd->len; W.build = 1;
     job->hint = 0;
     const int32_t readLen = (int32_t)rd->len;
-    alnb_t ab; ab_init(&ab, track_mode, active, pac, rd->len);
+    alnb_t ab; ab_init(&ab, track_mode, active, pac, rd->len, &cx->arena[tid]);
     sam_t tmp; memset(&tmp, 0, sizeof tmp);
     uint32_t chrBeg, chrEnd, readAlnStart, refAlnStart, readAlnEnd, refAlnEnd, i;
     int32_t readAlnLen, refAlnLen, editScore = 0;
@@ -1123,10 +1171,10 @@ static void phase_prepare(ctx_t *cx, int tid, int ri)
     rd_t *r = &cx->reads[ri];
     memset(&r->out, 0, sizeof r->out);
     if ((int)r->len < cx->p->min_read_len) return;
-    r->seq_rev = (char *)malloc((size_t)r->len + 1);
+    r->seq_rev = (char *)ar_alloc(&cx->arena[tid], (size_t)r->len + 1);
     revcomp_into(r->seq, r->seq_rev, r->len);                          /* reverseComplement :501 */
     const uint32_t ql = r->isFq ? r->len : 1;
-    r->qual_rev = (char *)malloc((size_t)ql + 1);
+    r->qual_rev = (char *)ar_alloc(&cx->arena[tid], (size_t)ql + 1);
     for (uint32_t i = 0; i < ql; i++) r->qual_rev[i] = r->qual[ql - 1 - i];   /* reverse :502 */
     r->qual_rev[ql] = 0;
 }
@@ -1143,14 +1191,14 @@ static void phase_make_jobs(ctx_t *cx, int tid, int ri)
     (void)tid;
     rd_t *r = &cx->reads[ri];
     if (r->mode < 2) return;
-    r->jobs = (job_t *)calloc((size_t)r->nWins + 1, sizeof(job_t));
-    r->maps = (samlist_t *)calloc((size_t)cx->p->max_map + 1, sizeof(samlist_t));
+    r->jobs = (job_t *)ar_zalloc(&cx->arena[tid], ((size_t)r->nWins + 1) * sizeof(job_t));
+    r->maps = (samlist_t *)ar_zalloc(&cx->arena[tid], ((size_t)cx->p->max_map + 1) * sizeof(samlist_t));
     for (int w = 0; w < r->nWins; w++) {
         job_t *j = &r->jobs[w];
         const int rq = r->wins[w].req;
         j->read = ri; j->widx = w; j->isRev = r->wins[w].isReverse;
         j->chainLen = cx->chain_len[rq];
-        j->chain = (Seed_t *)malloc(((size_t)j->chainLen + 1) * sizeof(Seed_t));
+        j->chain = (Seed_t *)ar_alloc(&cx->arena[tid], ((size_t)j->chainLen + 1) * sizeof(Seed_t));
         const creq_t *cq = &cx->creq[rq];
         for (uint32_t k = 0; k < j->chainLen; k++) j->chain[k] = cx->cseeds[cq->off + cx->chain_idx[cq->off + k]];
         j->complete = (j->chainLen <= 1);                   /* nothing to extend: totalScore = -2L (:1089) */
@@ -1179,10 +1227,10 @@ static void phase_merge_edlib(ctx_t *cx, int tid, int t)
     for (int k = 0; k < s->n; k++, g++) {
         cx->mg_qoff[g] = qo + s->qoff[k]; cx->mg_toff[g] = to + s->toff[k]; cx->mg_mode[g] = s->mode[k];
         cx->mg_R->ops_off[g] = cx->mg_qoff[g] + cx->mg_toff[g];
-        memo_t *m = &g_ed_jobs[t].job[k]->memo[(uintptr_t)s->owner[k]];
+        memo_t *m = &cx->ed_jobs[t].job[k]->memo[(uintptr_t)s->owner[k]];
         m->round = cx->mg_round; m->slot = g;
     }
-    s->n = 0; s->qn = 0; s->tn = 0; s->ext_bytes = 0; g_ed_jobs[t].n = 0;
+    s->n = 0; s->qn = 0; s->tn = 0; s->ext_bytes = 0; cx->ed_jobs[t].n = 0;
 }
 
 static void phase_strlen(ctx_t *cx, int tid, int i) { (void)tid; cx->len_out[i] = (uint32_t)strlen(cx->len_seqs[i]); }
@@ -1196,10 +1244,10 @@ static void phase_merge_desc(ctx_t *cx, int tid, int t)
     for (int k = 0; k < s->dn; k++, g++) {
         cx->mg_desc[g] = s->dd[k];
         cx->mg_R->ops_off[g] = ob + s->dops[k];
-        memo_t *m = &g_edd_jobs[t].job[k]->memo[s->downer[k]];
+        memo_t *m = &cx->edd_jobs[t].job[k]->memo[s->downer[k]];
         m->round = cx->mg_round; m->slot = g;
     }
-    s->dn = 0; s->dops_total = 0; g_edd_jobs[t].n = 0;
+    s->dn = 0; s->dops_total = 0; cx->edd_jobs[t].n = 0;
 }
 
 
@@ -1209,7 +1257,7 @@ static void phase_sam_score(ctx_t *cx, int tid, int ri)
 {
     (void)tid;
     rd_t *r = &cx->reads[ri];
-    if (r->mode < 2) { r->maps = (samlist_t *)calloc(2, sizeof(samlist_t)); return; }
+    if (r->mode < 2) { r->maps = (samlist_t *)ar_zalloc(&cx->arena[tid], 2 * sizeof(samlist_t)); return; }
     for (int w = 0; w < r->nWins; w++) score_mapping(cx->p, &r->maps[w], r->wins[w].isReverse, r->len, r->jobs[w].chainLen);
     if (r->mode == 3) samsort_sort(r->maps, r->nWins);                     /* std::sort(compareSam) :565 */
 }
@@ -1264,18 +1312,18 @@ static int map_chunk(ctx_t *cx)
     t1 = now_ms(); st->ms_seed += t1 - t0; t0 = t1;
 
     /* ---- B: vote + chain requests ---- */
-    g_cstage = (cstage_t *)calloc((size_t)nt, sizeof(cstage_t));
+    cx->cstage = (cstage_t *)calloc((size_t)nt, sizeof(cstage_t));
     parallel_for(cx, n, phase_vote);
     {   /* merge the per-worker chain requests; rebase request ids */
         int total = 0; uint64_t seeds = 0;
         int *base = (int *)malloc((size_t)nt * sizeof(int)); uint64_t *sbase = (uint64_t *)malloc((size_t)nt * 8);
-        for (int t = 0; t < nt; t++) { base[t] = total; sbase[t] = seeds; total += g_cstage[t].n; seeds += g_cstage[t].ns; }
+        for (int t = 0; t < nt; t++) { base[t] = total; sbase[t] = seeds; total += cx->cstage[t].n; seeds += cx->cstage[t].ns; }
         cx->n_creq = total; cx->n_cseeds = seeds;
         cx->creq = (creq_t *)malloc(((size_t)total + 1) * sizeof(creq_t));
         cx->cseeds = (Seed_t *)malloc((seeds + 1) * sizeof(Seed_t));
         for (int t = 0; t < nt; t++) {
-            memcpy(cx->cseeds + sbase[t], g_cstage[t].s, g_cstage[t].ns * sizeof(Seed_t));
-            for (int k = 0; k < g_cstage[t].n; k++) { creq_t q = g_cstage[t].v[k]; q.off += sbase[t]; cx->creq[base[t] + k] = q; }
+            memcpy(cx->cseeds + sbase[t], cx->cstage[t].s, cx->cstage[t].ns * sizeof(Seed_t));
+            for (int k = 0; k < cx->cstage[t].n; k++) { creq_t q = cx->cstage[t].v[k]; q.off += sbase[t]; cx->creq[base[t] + k] = q; }
         }
         /* request ids handed out during the vote were worker-local: rebase them */
         for (int i = 0; i < n; i++) {
@@ -1284,8 +1332,8 @@ static int map_chunk(ctx_t *cx)
             else if (r->mode == 3) for (int c = 0; c < r->ncand; c++) r->cands[c].req += base[r->vote_tid];
         }
         free(base); free(sbase);
-        for (int t = 0; t < nt; t++) { free(g_cstage[t].v); free(g_cstage[t].s); free(g_cstage[t].wbuf); free(g_cstage[t].wbuf2); }
-        free(g_cstage); g_cstage = NULL;
+        for (int t = 0; t < nt; t++) { free(cx->cstage[t].v); free(cx->cstage[t].s); free(cx->cstage[t].wbuf); free(cx->cstage[t].wbuf2); }
+        free(cx->cstage); cx->cstage = NULL;
     }
     t1 = now_ms(); st->ms_vote += t1 - t0; t0 = t1;
 
@@ -1309,9 +1357,9 @@ static int map_chunk(ctx_t *cx)
 
     /* ---- D: extension rounds ---- */
     cx->stages = (stage_t *)calloc((size_t)nt, sizeof(stage_t));
-    g_ed_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
-    g_ksw_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
-    g_edd_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
+    cx->ed_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
+    cx->ksw_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
+    cx->edd_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
     const int timing = getenv("LF_TIMING") != NULL;
     for (int round = 0; round < 64; round++) {
         double tw0 = now_ms();
@@ -1404,11 +1452,11 @@ static int map_chunk(ctx_t *cx)
                 for (int k = 0; k < s->kn; k++, g++) {
                     qoff[g] = qo + s->kqoff[k]; toff[g] = to + s->ktoff[k];
                     memcpy(prm + 7 * g, s->kprm + 7 * k, 28);
-                    memo_t *m = &g_ksw_jobs[t].job[k]->memo[(uintptr_t)s->kowner[k]];
+                    memo_t *m = &cx->ksw_jobs[t].job[k]->memo[(uintptr_t)s->kowner[k]];
                     m->round = ridx; m->slot = g;
                 }
                 qo += s->kqn; to += s->ktn;
-                s->kn = 0; s->kqn = 0; s->ktn = 0; g_ksw_jobs[t].n = 0;
+                s->kn = 0; s->kqn = 0; s->ktn = 0; cx->ksw_jobs[t].n = 0;
             }
             qoff[nk] = qo; toff[nk] = to;
             float ms = 0;
@@ -1430,18 +1478,9 @@ static int map_chunk(ctx_t *cx)
     return LF_OK;
 }
 
-static void phase_free_read(ctx_t *cx, int tid, int i)
-{
-    (void)tid;
-    rd_t *r = &cx->reads[i];
-    free(r->seq_rev); free(r->qual_rev); free(r->F); free(r->cands); free(r->wins);
-    if (r->jobs) { for (int w = 0; w < r->nWins; w++) { free(r->jobs[w].chain); free(r->jobs[w].memo); } free(r->jobs); }
-    if (r->maps) { for (int w = 0; w <= cx->p->max_map && (r->mode >= 2 || w < 2); w++) { samlist_clear(&r->maps[w]); free(r->maps[w].v); } free(r->maps); }
-}
-
 static void chunk_free(ctx_t *cx)
 {
-    parallel_for(cx, cx->n_reads, phase_free_read);
+    for (int t = 0; t < cx->n_threads; t++) ar_reset(&cx->arena[t]);      /* every per-read object at once */
     free(cx->creq); free(cx->cseeds); free(cx->chain_idx); free(cx->chain_len); free(cx->chain_score);
     for (int k = 0; k < cx->n_ed_rounds; k++) { ed_round_t *R = &cx->ed_rounds[k]; if (!R->pinned) { free(R->ed); free(R->end); free(R->ops_len); free(R->ops); } free(R->ops_off); }
     for (int k = 0; k < cx->n_ksw_rounds; k++) { ksw_round_t *R = &cx->ksw_rounds[k]; free(R->score); free(R->qle); free(R->tle); }
@@ -1452,15 +1491,103 @@ static void chunk_free(ctx_t *cx)
             free(s->qb); free(s->tb); free(s->qoff); free(s->toff); free(s->mode); free(s->owner);
             free(s->kq); free(s->kt); free(s->kqoff); free(s->ktoff); free(s->kprm); free(s->kowner);
             free(s->dd); free(s->dops); free(s->downer);
-            free(g_ed_jobs[t].job); free(g_ksw_jobs[t].job); free(g_edd_jobs[t].job);
+            free(cx->ed_jobs[t].job); free(cx->ksw_jobs[t].job); free(cx->edd_jobs[t].job);
         }
-        free(cx->stages); free(g_ed_jobs); free(g_ksw_jobs); free(g_edd_jobs); g_ed_jobs = g_ksw_jobs = g_edd_jobs = NULL;
+        free(cx->stages); free(cx->ed_jobs); free(cx->ksw_jobs); free(cx->edd_jobs); cx->ed_jobs = cx->ksw_jobs = cx->edd_jobs = NULL;
     }
     cx->creq = NULL; cx->cseeds = NULL; cx->chain_idx = NULL; cx->chain_len = NULL; cx->chain_score = NULL;
     cx->ed_rounds = NULL; cx->ksw_rounds = NULL; cx->n_ed_rounds = cx->n_ksw_rounds = 0; cx->stages = NULL;
 }
 
-static pthread_mutex_t g_map_lock = PTHREAD_MUTEX_INITIALIZER;     /* worker-stage globals: one batch at a time */
+static pthread_mutex_t g_map_lock = PTHREAD_MUTEX_INITIALIZER;     /* the worker pool and the lanes serve one batch at a time */
+
+/* ---- a batch is cut into chunks; two lane threads pull chunks and run them through map_chunk.  While one lane waits
+ * for the GPU the other lane's host phases keep the cores busy.  SAM text is written in chunk order. ---- */
+typedef struct { int i0, i1; uint64_t size; int sized; } chunk_t;
+typedef struct {
+    const lf_index_t *ix; const lf_params_t *p;
+    const char *const *names, *const *seqs, *const *quals; const uint32_t *lens;
+    int slots;                                  /* per-worker scratch slots = pool workers + 2 drivers */
+    chunk_t *chunks; int n_chunks; volatile int next_chunk;
+    pthread_mutex_t mu; pthread_cond_t cv;      /* chunk sizes become known in any order */
+    pthread_rwlock_t grow;                      /* writers of SAM text hold it shared; growing the buffer exclusive */
+    str_t all;
+    volatile int rc; char err[1024];
+    lf_stats_t st[2];
+} batch_t;
+
+static void merge_stats(lf_stats_t *d, const lf_stats_t *a)
+{
+    d->ms_seed += a->ms_seed; d->ms_vote += a->ms_vote; d->ms_chain += a->ms_chain; d->ms_extend += a->ms_extend; d->ms_sam += a->ms_sam;
+    d->ms_k_search += a->ms_k_search; d->ms_k_accept += a->ms_k_accept; d->ms_k_locate += a->ms_k_locate; d->ms_k_chain += a->ms_k_chain;
+    d->ms_k_edlib += a->ms_k_edlib; d->ms_k_ksw += a->ms_k_ksw;
+    d->n_reads += a->n_reads; d->n_bases += a->n_bases; d->n_seeds += a->n_seeds; d->n_chain_problems += a->n_chain_problems;
+    d->n_edlib_problems += a->n_edlib_problems; d->n_ksw_problems += a->n_ksw_problems; d->n_cache += a->n_cache; d->n_occblk += a->n_occblk;
+    d->n_sa += a->n_sa; d->n_readbytes += a->n_readbytes; d->ext_bytes += a->ext_bytes; d->edlib_launches += a->edlib_launches;
+    d->search_launches += a->search_launches; d->locate_launches += a->locate_launches;
+}
+
+static void *lane_main(void *arg_)
+{
+    batch_t *B = (batch_t *)((void **)arg_)[0];
+    const int lane = (int)(intptr_t)((void **)arg_)[1];
+    const int timing = getenv("LF_TIMING") != NULL;
+    lfg_set_lane(lane);
+    lf_stats_t *st = &B->st[lane];
+    for (;;) {
+        const int k = __sync_fetch_and_add(&B->next_chunk, 1);
+        if (k >= B->n_chunks || B->rc != LF_OK) break;
+        chunk_t *C = &B->chunks[k];
+        ctx_t cx; memset(&cx, 0, sizeof cx);
+        cx.ix = B->ix; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane];
+        cx.n_reads = C->i1 - C->i0;
+        cx.reads = (rd_t *)calloc((size_t)cx.n_reads, sizeof(rd_t));
+        for (int i = C->i0; i < C->i1; i++) {
+            rd_t *r = &cx.reads[i - C->i0];
+            r->name = B->names[i]; r->seq = B->seqs[i]; r->len = B->lens[i];
+            r->isFq = (B->quals && B->quals[i] && B->quals[i][0]);
+            r->qual = r->isFq ? B->quals[i] : "*";
+            st->n_bases += r->len;
+        }
+        st->n_reads += (uint64_t)cx.n_reads;
+        double tch = now_ms();
+        int rc = map_chunk(&cx);
+        if (timing) fprintf(stderr, "[lf] lane %d chunk %d (%d reads): map_chunk %.1f ms\n", lane, k, cx.n_reads, now_ms() - tch);
+        uint64_t tot = 0, *ooff = NULL;
+        if (rc == LF_OK) {
+            ooff = (uint64_t *)malloc(((size_t)cx.n_reads + 1) * 8);
+            for (int i = 0; i < cx.n_reads; i++) { ooff[i] = tot; tot += cx.reads[i].out.n; }
+        } else { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = rc; }
+        /* publish this chunk's size, then wait for the sizes of all earlier chunks: base offset of our text */
+        pthread_mutex_lock(&B->mu);
+        C->size = tot; C->sized = 1;
+        pthread_cond_broadcast(&B->cv);
+        uint64_t base = 0;
+        for (int j = 0; j < k; j++) { while (!B->chunks[j].sized) pthread_cond_wait(&B->cv, &B->mu); base += B->chunks[j].size; }
+        pthread_mutex_unlock(&B->mu);
+        if (rc == LF_OK && B->rc == LF_OK) {
+            tch = now_ms();
+            pthread_rwlock_rdlock(&B->grow);
+            if (base + tot + 1 > B->all.cap) {          /* rare: the up-front estimate was too small */
+                pthread_rwlock_unlock(&B->grow);
+                pthread_rwlock_wrlock(&B->grow);
+                if (base + tot + 1 > B->all.cap) { size_t nc = (size_t)((base + tot + 1) * 1.25) + 4096; B->all.s = (char *)realloc(B->all.s, nc); B->all.cap = nc; }
+                pthread_rwlock_unlock(&B->grow);
+                pthread_rwlock_rdlock(&B->grow);
+            }
+            cx.out_base = B->all.s + base; cx.out_off = ooff;
+            parallel_for(&cx, cx.n_reads, phase_sam_print);
+            pthread_rwlock_unlock(&B->grow);
+            st->ms_sam += now_ms() - tch;
+        }
+        free(ooff);
+        tch = now_ms();
+        chunk_free(&cx);
+        free(cx.reads);
+        if (timing) fprintf(stderr, "[lf] lane %d chunk %d: chunk_free %.1f ms\n", lane, k, now_ms() - tch);
+    }
+    return NULL;
+}
 
 int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *const *names,
                  const char *const *seqs, const char *const *quals, char **sam, size_t *sam_len, lf_stats_t *stats)
@@ -1494,66 +1621,59 @@ int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *
     if (nt < 1) nt = 1;
     const double T0 = now_ms();
     pthread_mutex_lock(&g_map_lock);
-    str_t all; str_init(&all);
+    const int n_lanes = (nt >= 3 && !getenv("LF_ONE_LANE")) ? 2 : 1;
+    const int nw = nt - n_lanes;                       /* pool workers; the lane drivers work too */
+    pool_ensure(nw);
+
+    batch_t B; memset(&B, 0, sizeof B);
+    B.ix = ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + 2; B.rc = LF_OK;
+    pthread_mutex_init(&B.mu, NULL); pthread_cond_init(&B.cv, NULL); pthread_rwlock_init(&B.grow, NULL);
+    str_init(&B.all);
     uint32_t *lens = (uint32_t *)malloc(((size_t)n + 1) * 4);
+    B.lens = lens;
     {   /* read lengths once, in parallel; one allocation for the SAM text (~2 x bases + per-record overhead) */
         ctx_t c0; memset(&c0, 0, sizeof c0);
-        c0.n_threads = nt; c0.len_seqs = seqs; c0.len_out = lens;
+        c0.n_threads = nw + 2; c0.lane = 0; c0.len_seqs = seqs; c0.len_out = lens;
         parallel_for(&c0, n, phase_strlen);
         uint64_t est = 4096;
         for (int i = 0; i < n; i++) est += 2 * (uint64_t)lens[i] + 640;
-        str_room(&all, est + est / 8);
+        str_room(&B.all, est + est / 8);
     }
-    int rc = LF_OK;
-    if (getenv("LF_TIMING")) fprintf(stderr, "[lf] setup (strlen + SAM buffer) %.1f ms\n", now_ms() - T0);
+    if (getenv("LF_TIMING")) fprintf(stderr, "[lf] setup (strlen + SAM buffer) %.1f ms, %d lanes, %d pool workers\n", now_ms() - T0, n_lanes, nw);
     /* chunks bound the device + host working set; reads stay in input order */
     const uint64_t CHUNK_BASES = 400ull << 20;
     int CHUNK_READS = 32768;
     if (getenv("LF_CHUNK_READS")) { CHUNK_READS = atoi(getenv("LF_CHUNK_READS")); if (CHUNK_READS < 1) CHUNK_READS = 1; }   /* test hook */
-    int i0 = 0;
-    while (i0 < n && rc == LF_OK) {
+    else if (n_lanes == 2 && n > 2048) {               /* at least ~4 chunks so that the two lanes interleave */
+        int want = (n + 3) / 4; if (want < 1024) want = 1024;
+        if (want < CHUNK_READS) CHUNK_READS = want;
+    }
+    B.chunks = (chunk_t *)calloc((size_t)n + 1, sizeof(chunk_t));
+    for (int i0 = 0; i0 < n; ) {
         int i1 = i0; uint64_t bases = 0;
         while (i1 < n && i1 - i0 < CHUNK_READS && bases < CHUNK_BASES) { bases += lens[i1]; i1++; }
-        ctx_t cx; memset(&cx, 0, sizeof cx);
-        cx.ix = ix; cx.p = p; cx.n_threads = nt; cx.st = st;
-        cx.n_reads = i1 - i0;
-        cx.reads = (rd_t *)calloc((size_t)cx.n_reads, sizeof(rd_t));
-        for (int i = i0; i < i1; i++) {
-            rd_t *r = &cx.reads[i - i0];
-            r->name = names[i]; r->seq = seqs[i]; r->len = lens[i];
-            r->isFq = (quals && quals[i] && quals[i][0]);
-            r->qual = r->isFq ? quals[i] : "*";
-            st->n_bases += r->len;
-        }
-        st->n_reads += (uint64_t)cx.n_reads;
-        double tch = now_ms();
-        rc = map_chunk(&cx);
-        if (getenv("LF_TIMING")) fprintf(stderr, "[lf] chunk of %d reads: map_chunk %.1f ms\n", cx.n_reads, now_ms() - tch);
-        tch = now_ms();
-        if (rc == LF_OK) {
-            uint64_t *ooff = (uint64_t *)malloc(((size_t)cx.n_reads + 1) * 8), tot = 0;
-            for (int i = 0; i < cx.n_reads; i++) { ooff[i] = tot; tot += cx.reads[i].out.n; }
-            str_room(&all, tot);
-            cx.out_base = all.s + all.n; cx.out_off = ooff;
-            parallel_for(&cx, cx.n_reads, phase_sam_print);
-            all.n += tot; all.s[all.n] = 0;
-            free(ooff);
-            st->ms_sam += now_ms() - tch;
-        }
-        if (getenv("LF_TIMING")) fprintf(stderr, "[lf] output assembly %.1f ms\n", now_ms() - tch);
-        tch = now_ms();
-        chunk_free(&cx);
-        free(cx.reads);
-        if (getenv("LF_TIMING")) fprintf(stderr, "[lf] chunk_free %.1f ms\n", now_ms() - tch);
+        B.chunks[B.n_chunks].i0 = i0; B.chunks[B.n_chunks].i1 = i1; B.n_chunks++;
         i0 = i1;
     }
+    void *a0[2] = { &B, (void *)(intptr_t)0 }, *a1[2] = { &B, (void *)(intptr_t)1 };
+    pthread_t t1; int have_t1 = 0;
+    if (n_lanes == 2 && B.n_chunks > 1) { have_t1 = pthread_create(&t1, NULL, lane_main, a1) == 0; }
+    lane_main(a0);
+    if (have_t1) pthread_join(t1, NULL);
+    lfg_set_lane(0);
     pthread_mutex_unlock(&g_map_lock);
-    free(lens);
+
+    uint64_t total = 0;
+    for (int k = 0; k < B.n_chunks; k++) total += B.chunks[k].size;
+    merge_stats(st, &B.st[0]); merge_stats(st, &B.st[1]);
+    free(lens); free(B.chunks);
+    pthread_mutex_destroy(&B.mu); pthread_cond_destroy(&B.cv); pthread_rwlock_destroy(&B.grow);
     st->ms_total = now_ms() - T0;
     if (getenv("LF_TIMING")) fprintf(stderr, "[lf] lf_map_batch total %.1f ms\n", st->ms_total);
-    if (rc != LF_OK) { free(all.s); return rc; }
-    *sam = all.s;
-    if (sam_len) *sam_len = all.n;
+    if (B.rc != LF_OK) { lf_set_error("%s", B.err); free(B.all.s); return B.rc; }
+    B.all.n = total; B.all.s[total] = 0;
+    *sam = B.all.s;
+    if (sam_len) *sam_len = total;
     return LF_OK;
 }
 

@@ -280,7 +280,8 @@ extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_r
     lf_dev_state *st = (lf_dev_state *)ix->dev;
     if (!st) { lf_set_error("index is not on a device"); return LF_ERR_NO_DEVICE; }
     HIPCHK(hipSetDevice(ix->device));
-    hipStream_t s = st->stream;
+    hipStream_t s = (hipStream_t)lfg_lane_stream(ix->device, 0);
+    if (!s) return LF_ERR_HIP;
     const int dv = ix->device;
     const uint32_t hc = (uint32_t)p->sampling_count;
     const size_t total = (size_t)n_reads * hc;
