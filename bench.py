@@ -5,8 +5,8 @@
 
 A "step" maps one batch of synthetic reads (inputs in host memory -> SAM records in host memory, index
 resident in HBM, index load excluded -- the reference's own timer, src/baseFAST.cpp:69-75).  Weak scaling:
-every GPU gets the same number of reads; rank 0 scatters the packed batch and gathers the SAM records over
-RCCL.  Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the dominant
+reads are independent, so every GPU maps its own shard (--reads per GPU) against its own replica of the index
+and keeps its SAM records in its own host buffer: no data-path collective (--single-output adds the gather).  Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the dominant
 kernel and `cpu_baseline` (the real reference, compiled into oracle/_ref, on all host cores, bounded sample).
 """
 from __future__ import annotations
@@ -36,12 +36,25 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workdir", default=os.environ.get("LF_BENCH_DIR", "/tmp/lf_bench"))
-    ap.add_argument("--check", action="store_true", help="also compare a sample of the SAM with the oracle")
+    ap.add_argument("--single-output", action="store_true",
+                    help="N>1: also gather every rank's SAM records behind rank 0's (point-to-point over RCCL) inside the timed region")
     return ap.parse_args()
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def genome_recipe(args):
+    total = int(args.genome_mbp * 1e6)
+    return total, max(2, min(24, total // 2_000_000)), max(0, min(1000, total // 100_000))
+
+
+def make_contigs(args):
+    """the synthetic genome is a pure function of its recipe: any rank can regenerate it instead of parsing the FASTA"""
+    from lordfast_amd import synth
+    total, n_contigs, fams = genome_recipe(args)
+    return synth.make_genome(total, n_contigs, seed=11, repeat_frac=0.10, n_families=fams)
 
 
 def ensure_index(args, rank):
@@ -54,21 +67,13 @@ def ensure_index(args, rank):
     if rank == 0 and not os.path.exists(done):
         os.makedirs(d, exist_ok=True)
         t0 = time.time()
-        total = int(args.genome_mbp * 1e6)
-        n_contigs = max(2, min(24, total // 2_000_000))
-        fams = max(0, min(1000, total // 100_000))
-        contigs = synth.make_genome(total, n_contigs, seed=11, repeat_frac=0.10, n_families=fams)
+        total, n_contigs, fams = genome_recipe(args)
+        contigs = make_contigs(args)
         log(f"genome {total} bp, {n_contigs} contigs, {fams} repeat families: {time.time() - t0:.1f}s")
         t0 = time.time()
         import lordfast_amd as la
-        if hasattr(la.lib(), "lf_index_build"):
-            la.index_build(contigs, fa)                       # GPU indexer (writes the reference's formats)
-        else:
-            synth.write_fasta(fa, contigs)
-            from oracle import pyoracle as po                 # checker-side indexer (the reference's own)
-            po.Ref().index_build(fa)
+        la.index_build(contigs, fa)                           # GPU indexer (writes the reference's file formats)
         log(f"index built in {time.time() - t0:.1f}s")
-        np.save(os.path.join(d, "contig_lens.npy"), np.array([len(s) for _, s in contigs]))
         open(done, "w").write("ok")
         return fa, contigs
     while not os.path.exists(done):
@@ -76,10 +81,11 @@ def ensure_index(args, rank):
     return fa, None
 
 
-def make_reads(args, contigs, fa, n_total):
-    """seeded reads; cached on disk so that repeated bench runs on one box skip generation"""
+def make_reads(args, contigs, fa, rank):
+    """this rank's seeded reads (seed 2024 + rank: every GPU maps DIFFERENT reads); cached on disk so that repeated
+    bench runs on one box skip generation"""
     from lordfast_amd import synth
-    key = hashlib.md5(f"{fa}|{n_total}|{args.read_len}|{args.err}".encode()).hexdigest()[:12]
+    key = hashlib.md5(f"{fa}|{args.reads}|{args.read_len}|{args.err}|{rank}".encode()).hexdigest()[:12]
     path = os.path.join(os.path.dirname(fa), f"reads_{key}.npz")
     if os.path.exists(path):
         z = np.load(path)
@@ -88,18 +94,18 @@ def make_reads(args, contigs, fa, n_total):
         names = [nblob[int(noff[i]):int(noff[i + 1])] for i in range(len(noff) - 1)]
         return names, seqs
     if contigs is None:
-        from tests.conftest import read_fasta
-        cn, cs = read_fasta(fa)
-        contigs = [(a.decode(), np.frombuffer(b, dtype=np.uint8)) for a, b in zip(cn, cs)]
+        contigs = make_contigs(args)
     t0 = time.time()
-    reads = synth.make_reads(contigs, n_total, args.read_len, args.err, seed=2024)
-    names = [r[0].encode() for r in reads]
+    reads = synth.make_reads(contigs, args.reads, args.read_len, args.err, seed=2024 + rank)
+    names = [(r[0] if rank == 0 else f"g{rank}_{r[0]}").encode() for r in reads]
     seqs = [r[1] for r in reads]
-    log(f"{n_total} reads generated in {time.time() - t0:.1f}s")
+    log(f"rank {rank}: {args.reads} reads generated in {time.time() - t0:.1f}s")
     off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.int64)
     noff = np.concatenate([[0], np.cumsum([len(s) for s in names])]).astype(np.int64)
-    np.savez(path, blob=np.frombuffer(b"".join(seqs), dtype=np.uint8), off=off,
+    tmp = path + f".tmp{os.getpid()}.npz"
+    np.savez(tmp, blob=np.frombuffer(b"".join(seqs), dtype=np.uint8), off=off,
              nblob=np.frombuffer(b"".join(names), dtype=np.uint8), noff=noff)
+    os.replace(tmp, path)
     return names, seqs
 
 
@@ -174,22 +180,52 @@ def main():
     params = la.default_params(min_anchor_len=14, sampling_count=1000)       # -k 14 -c 1000 --chainAlg dp-n2
 
     n_total = args.reads * world
-    if rank == 0:
-        names, seqs = make_reads(args, contigs, fa, n_total)
-    else:
-        names, seqs = None, None
+    names, seqs = make_reads(args, contigs, fa, rank)        # reads shard by rank: no data-path collective
+    contigs = None
+    bases_local = sum(len(s) for s in seqs)
+
+    # host thread budget: the cgroup quota (or the online CPUs) split between the ranks of this node
+    budget = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            budget = min(budget, max(1, -(-int(q) // int(per))))
+    except Exception:                                                    # noqa: BLE001
+        pass
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    params.threads = max(2, min(255, budget // max(1, local_world)))
+    log(f"rank {rank}: {params.threads} host threads (budget {budget}, {local_world} ranks on this node)")
+
+    # caller-owned SAM buffer, pinned and reused by every step (rank 0's holds the whole job's SAM: the other ranks'
+    # records are gathered behind its own, so the output order is the input order)
+    est_bases = args.reads * args.read_len * 1.15
+    cap_one = int(2.6 * est_bases) + args.reads * 2048 + (1 << 20)
+    cap = cap_one * (world if (rank == 0 and args.single_output) else 1)
+    try:
+        out_buf = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+    except RuntimeError:
+        out_buf = torch.empty(cap, dtype=torch.uint8)
+    out_ptr = out_buf.data_ptr()
+    fixed_arrays = (la.api._cstr_array(names), la.api._cstr_array(seqs))
+
+    class _Sam:                                                          # head()/len() like api.SamBuffer
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def head(self, k):
+            return bytes(out_buf[:min(k, self.n)].numpy().tobytes())
 
     def step():
-        if dist:
-            my_names, my_seqs, _ = lfd.scatter_reads(dist, torch, names, seqs, dev)
-        else:
-            my_names, my_seqs = names, seqs
+        na, sa = fixed_arrays
         t_call = time.perf_counter()
-        sam, st = lf.map_batch(my_names, my_seqs, params=params, copy=False)
+        ln, st = lf.map_batch_into(names, seqs, out_ptr, cap_one, params=params, name_arr=na, seq_arr=sa)
         st["ms_python_call"] = (time.perf_counter() - t_call) * 1e3
-        if dist:
-            sam = lfd.gather_sam(dist, torch, sam.view(), dev)
-        return sam, st
+        if dist and args.single_output:                      # optional: one SAM stream on rank 0, input order
+            ln = lfd.gather_sam_p2p(dist, torch, out_buf, ln, dev)
+        return _Sam(ln or 0), st
 
     for _ in range(args.warmup):
         step()
@@ -210,29 +246,49 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    bases_total = bases_local
     if dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        bsum = torch.tensor([bases_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(bsum, op=dist.ReduceOp.SUM)
+        bases_total = int(bsum.item())
 
     if rank == 0:
         K = args.steps
-        bases = sum(len(s) for s in seqs)
+        bases = bases_total
         value = n_total * K / elapsed
-        # ---- roofline of the dominant kernel (HIP-event time summed over the timed steps, rank 0) ----
+        # ---- roofline: algorithmic bytes (SURVEY 8d counters emitted by the kernels) / HIP-event kernel time, rank 0 ----
         kernels = {
             "lf_seed_search_kernel": (agg["ms_k_search"], 16 * agg["n_cache"] + 64 * agg["n_occblk"] + agg["n_readbytes"], agg["search_launches"]),
             "lf_seed_locate_kernel": (agg["ms_k_locate"], 8 * agg["n_sa"] + 9 * agg["n_sa"], agg["locate_launches"]),
+            # the edlib size classes (lf_edlib_kernel<1,2,4,8>, lf_edlib_wave_kernel<1,4>) run concurrently as ONE launch group
             "lf_edlib_kernel": (agg["ms_k_edlib"], agg["ext_bytes"], max(1, agg["edlib_launches"])),
-            "lf_chain_n2_kernel": (agg["ms_k_chain"], 16 * agg["n_chain_problems"], max(1, K)),
+            "lf_chain_n2_kernel": (agg["ms_k_chain"], 16 * agg["n_chain_problems"], max(1, agg["search_launches"])),
         }
+        by_kernel = {}
+        for kname, (kms, kbytes, kl) in kernels.items():
+            gbs = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+            by_kernel[kname] = dict(ms_per_step=kms / K, launches_per_step=kl / K, algorithmic_GB_per_step=kbytes / K / 1e9,
+                                    achieved_GBps=gbs, frac_of_8TBps=gbs / 8000.0)
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms, alg_bytes, launches = kernels[dom]
         achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        # HBM traffic from the committed PMC passes of the same command (profiles/r01_c2), per launch; null otherwise
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_c2", "pmc_fetch_write_summary.json")
+        if os.path.exists(pmc_path) and args.genome_mbp == 3100 and args.reads == 100000 and world == 1:
+            pmc = json.load(open(pmc_path))
+            fam = [v for k, v in pmc.items() if k.startswith(dom.replace("_kernel", ""))] if dom == "lf_edlib_kernel" else [pmc[dom]] if dom in pmc else []
+            if fam:
+                # one profiled step = the same 100k reads; FETCH_SIZE / WRITE_SIZE are in KB; raw (no gfx950 x2 correction: random 64-B reads)
+                traffic = sum(v["fetch_kb"] + v["write_kb"] for v in fam) * 1024.0 / max(1.0, launches / K)
         roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
-                        traffic=None, launches=int(launches), avg_launch_ms=ms / max(1, launches),
+                        traffic=traffic, launches=int(launches), avg_launch_ms=ms / max(1, launches),
                         algorithmic_bytes_per_launch=alg_bytes / max(1, launches),
-                        per_kernel_ms={k: round(v[0], 3) for k, v in kernels.items()})
+                        per_kernel_ms={k: round(v[0], 3) for k, v in kernels.items()}, by_kernel=by_kernel,
+                        note="edlib classes are integer-ALU/latency bound; their HBM traffic is traceback history (see profiles/r01_c2/README.md)")
         out = {
             "metric": "aligned reads/s", "value": value, "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -240,7 +296,8 @@ def main():
             "config": {"workload": f"{args.reads} synthetic PacBio reads per GPU (~{args.read_len} bp, {args.err:.0%} err) vs "
                                    f"{args.genome_mbp:g} Mbp synthetic genome, -k 14 -c 1000 --chainAlg dp-n2",
                        "reads_per_gpu": args.reads, "mean_read_len": bases / max(1, n_total), "genome_mbp": args.genome_mbp,
-                       "parallelism": f"read-sharded x{world}", "index": "FM-index + full SA resident in HBM"},
+                       "parallelism": f"reads sharded over {world} GPU(s), index replicated, no data-path collective"
+                                      + (" + SAM gather to rank 0" if (dist and args.single_output) else ""), "index": "FM-index + full SA resident in HBM"},
             "gbp_per_s": bases * K / elapsed / 1e9,
             "host_ms_per_step": {k: agg[k] / K for k in ("ms_total", "ms_python_call", "ms_seed", "ms_vote", "ms_chain", "ms_extend", "ms_sam")},
             "per_read": {"seeds": agg["n_seeds"] / (n_total * K / world), "edlib_problems": agg["n_edlib_problems"] / (n_total * K / world),

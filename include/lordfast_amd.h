@@ -153,6 +153,10 @@ typedef struct {
 int  lf_map_batch(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,
                   const char *const *seqs, const char *const *quals, char **sam, size_t *sam_len,
                   lf_stats_t *stats);
+/* same, SAM text written into a caller-owned buffer (reusable / pinned); LF_ERR_NOMEM when out_cap is too small */
+int  lf_map_batch_into(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,
+                       const char *const *seqs, const char *const *quals, char *out, size_t out_cap, size_t *sam_len,
+                       lf_stats_t *stats);
 char *lf_sam_header(const lf_index_t *idx, const lf_params_t *p, const char *cmdline); /* src/BWT.cpp:668-681 */
 void lf_free(void *ptr);
 

@@ -90,6 +90,9 @@ def lib():
         L.lf_map_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_char_p),
                                    C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_size_t), C.POINTER(Stats)]
+        L.lf_map_batch_into.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_char_p),
+                                        C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p, C.c_size_t,
+                                        C.POINTER(C.c_size_t), C.POINTER(Stats)]
         L.lf_sam_header.restype = C.c_void_p
         L.lf_sam_header.argtypes = [C.c_void_p, C.POINTER(Params), C.c_char_p]
     _LIB = L
@@ -232,6 +235,20 @@ class LordFast:
             buf.free()
             return out, st.as_dict()
         return buf, st.as_dict()
+
+    def map_batch_into(self, names, seqs, out_ptr: int, out_cap: int, quals=None, params: Params | None = None,
+                       name_arr=None, seq_arr=None):
+        """SAM text into a caller-owned buffer (address + capacity), e.g. a pinned torch tensor reused across batches.
+        -> (length, stats).  name_arr / seq_arr: pre-built ctypes arrays (saves rebuilding them per call)."""
+        p = params or default_params()
+        ln = C.c_size_t()
+        st = Stats()
+        q = _cstr_array(quals) if quals is not None else None
+        na = name_arr if name_arr is not None else _cstr_array(names)
+        sa = seq_arr if seq_arr is not None else _cstr_array(seqs)
+        _check(self.L.lf_map_batch_into(self.h, C.byref(p), len(names), na, sa, q, C.c_void_p(out_ptr), out_cap,
+                                        C.byref(ln), C.byref(st)), "lf_map_batch_into")
+        return ln.value, st.as_dict()
 
     def sam_header(self, cmdline: str, params: Params | None = None) -> bytes:
         p = params or default_params()

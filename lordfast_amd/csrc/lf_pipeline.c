@@ -1511,7 +1511,7 @@ typedef struct {
     chunk_t *chunks; int n_chunks; volatile int next_chunk;
     pthread_mutex_t mu; pthread_cond_t cv;      /* chunk sizes become known in any order */
     pthread_rwlock_t grow;                      /* writers of SAM text hold it shared; growing the buffer exclusive */
-    str_t all;
+    str_t all; int fixed_out;                   /* fixed_out: caller-provided buffer, never reallocated */
     volatile int rc; char err[1024];
     lf_stats_t st[2];
 } batch_t;
@@ -1571,12 +1571,17 @@ static void *lane_main(void *arg_)
             if (base + tot + 1 > B->all.cap) {          /* rare: the up-front estimate was too small */
                 pthread_rwlock_unlock(&B->grow);
                 pthread_rwlock_wrlock(&B->grow);
-                if (base + tot + 1 > B->all.cap) { size_t nc = (size_t)((base + tot + 1) * 1.25) + 4096; B->all.s = (char *)realloc(B->all.s, nc); B->all.cap = nc; }
+                if (base + tot + 1 > B->all.cap) {
+                    if (B->fixed_out) { snprintf(B->err, sizeof B->err, "lf_map_batch_into: output buffer too small (need more than %llu bytes)", (unsigned long long)(base + tot + 1)); B->rc = LF_ERR_NOMEM; }
+                    else { size_t nc = (size_t)((base + tot + 1) * 1.25) + 4096; B->all.s = (char *)realloc(B->all.s, nc); B->all.cap = nc; }
+                }
                 pthread_rwlock_unlock(&B->grow);
                 pthread_rwlock_rdlock(&B->grow);
             }
-            cx.out_base = B->all.s + base; cx.out_off = ooff;
-            parallel_for(&cx, cx.n_reads, phase_sam_print);
+            if (B->rc == LF_OK) {
+                cx.out_base = B->all.s + base; cx.out_off = ooff;
+                parallel_for(&cx, cx.n_reads, phase_sam_print);
+            }
             pthread_rwlock_unlock(&B->grow);
             st->ms_sam += now_ms() - tch;
         }
@@ -1589,10 +1594,11 @@ static void *lane_main(void *arg_)
     return NULL;
 }
 
-int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *const *names,
-                 const char *const *seqs, const char *const *quals, char **sam, size_t *sam_len, lf_stats_t *stats)
+static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, const char *const *names,
+                          const char *const *seqs, const char *const *quals, char *ext_buf, size_t ext_cap,
+                          char **sam, size_t *sam_len, lf_stats_t *stats)
 {
-    if (!ix || !p || n < 0 || !sam) { lf_set_error("lf_map_batch: bad argument"); return LF_ERR_ARG; }
+    if (!ix || !p || n < 0 || (!sam && !ext_buf)) { lf_set_error("lf_map_batch: bad argument"); return LF_ERR_ARG; }
     if (p->chain_alg != 0) { lf_set_error("lf_map_batch: --chainAlg clasp is not implemented on the GPU path yet"); return LF_ERR_ARG; }
     if (p->min_anchor_len < 12 || p->min_anchor_len > 20 || p->sampling_count <= 0 || p->max_map < 2 || p->max_ref_hits <= 0 || p->min_read_len < 100) {
         lf_set_error("lf_map_batch: option out of range (k in [12,20], c > 0, n >= 2, m > 0, l >= 100)"); return LF_ERR_ARG;
@@ -1628,7 +1634,8 @@ int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *
     batch_t B; memset(&B, 0, sizeof B);
     B.ix = ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + 2; B.rc = LF_OK;
     pthread_mutex_init(&B.mu, NULL); pthread_cond_init(&B.cv, NULL); pthread_rwlock_init(&B.grow, NULL);
-    str_init(&B.all);
+    if (ext_buf) { B.all.s = ext_buf; B.all.cap = ext_cap; B.all.n = 0; B.all.mode = 2; B.fixed_out = 1; }
+    else str_init(&B.all);
     uint32_t *lens = (uint32_t *)malloc(((size_t)n + 1) * 4);
     B.lens = lens;
     {   /* read lengths once, in parallel; one allocation for the SAM text (~2 x bases + per-record overhead) */
@@ -1637,7 +1644,7 @@ int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *
         parallel_for(&c0, n, phase_strlen);
         uint64_t est = 4096;
         for (int i = 0; i < n; i++) est += 2 * (uint64_t)lens[i] + 640;
-        str_room(&B.all, est + est / 8);
+        if (!ext_buf) str_room(&B.all, est + est / 8);
     }
     if (getenv("LF_TIMING")) fprintf(stderr, "[lf] setup (strlen + SAM buffer) %.1f ms, %d lanes, %d pool workers\n", now_ms() - T0, n_lanes, nw);
     /* chunks bound the device + host working set; reads stay in input order */
@@ -1670,11 +1677,27 @@ int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *
     pthread_mutex_destroy(&B.mu); pthread_cond_destroy(&B.cv); pthread_rwlock_destroy(&B.grow);
     st->ms_total = now_ms() - T0;
     if (getenv("LF_TIMING")) fprintf(stderr, "[lf] lf_map_batch total %.1f ms\n", st->ms_total);
-    if (B.rc != LF_OK) { lf_set_error("%s", B.err); free(B.all.s); return B.rc; }
-    B.all.n = total; B.all.s[total] = 0;
-    *sam = B.all.s;
+    if (B.rc != LF_OK) { lf_set_error("%s", B.err); if (!ext_buf) free(B.all.s); return B.rc; }
+    B.all.s[total] = 0;
+    if (sam) *sam = B.all.s;
     if (sam_len) *sam_len = total;
     return LF_OK;
+}
+
+int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *const *names,
+                 const char *const *seqs, const char *const *quals, char **sam, size_t *sam_len, lf_stats_t *stats)
+{
+    return map_batch_core(ix, p, n, names, seqs, quals, NULL, 0, sam, sam_len, stats);
+}
+
+/* same, into a caller-owned buffer (e.g. pinned and reused across batches: a fresh multi-GB malloc per batch costs
+ * page faults on first touch and an munmap on free).  LF_ERR_NOMEM if it is too small; 2.5 x bases + 1 KiB per read
+ * is a safe size for error rates up to ~20 %. */
+int lf_map_batch_into(const lf_index_t *ix, const lf_params_t *p, int n, const char *const *names,
+                      const char *const *seqs, const char *const *quals, char *out, size_t out_cap, size_t *sam_len, lf_stats_t *stats)
+{
+    if (!out || out_cap < 2) { lf_set_error("lf_map_batch_into: no output buffer"); return LF_ERR_ARG; }
+    return map_batch_core(ix, p, n, names, seqs, quals, out, out_cap, NULL, sam_len, stats);
 }
 
 /* printSamHeader (src/BWT.cpp:668-681) */

@@ -83,3 +83,78 @@ def gather_sam(dist, torch, sam, device, dst: int = 0) -> bytes | None:
     if rank != dst:
         return None
     return b"".join(bytes(b[:s].cpu().numpy().tobytes()) for b, s in zip(bufs, sizes))
+
+
+# ---- point-to-point variants: rank `src` talks to every other rank directly (one xGMI link per peer); nothing is
+# ---- broadcast to ranks that do not need it and nothing is padded.  Work with "nccl" (device tensors) and "gloo".
+
+def _send_bytes(dist, torch, data, device, dst):
+    n = len(data)
+    dist.send(torch.tensor([n], dtype=torch.int64, device=device), dst)
+    if n:
+        t = data if isinstance(data, torch.Tensor) else torch.frombuffer(data if isinstance(data, (bytearray, memoryview)) else bytearray(data), dtype=torch.uint8)
+        dist.send(t.to(device), dst)
+
+
+def _recv_tensor(dist, torch, device, src):
+    ln = torch.zeros(1, dtype=torch.int64, device=device)
+    dist.recv(ln, src)
+    n = int(ln.item())
+    buf = torch.empty(n, dtype=torch.uint8, device=device)
+    if n:
+        dist.recv(buf, src)
+    return buf
+
+
+def scatter_reads_p2p(dist, torch, names, seqs, device, src: int = 0):
+    """rank `src` holds the batch; every rank gets ITS shard only. -> (names, seqs, bounds)"""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if rank == src:
+        lens = np.array([len(s) for s in seqs], dtype=np.int64)
+        bounds = shard_bounds(lens, world)
+        for r in range(world):
+            if r == src:
+                continue
+            lo, hi = bounds[r]
+            sl = lens[lo:hi]
+            nl = np.array([len(x) for x in names[lo:hi]], dtype=np.int64)
+            meta = np.concatenate([[hi - lo, lo], [b for ab in bounds for b in ab], sl, nl]).astype(np.int64).tobytes()
+            _send_bytes(dist, torch, meta, device, r)
+            _send_bytes(dist, torch, b"".join(seqs[lo:hi]) + b"".join(names[lo:hi]), device, r)
+        lo, hi = bounds[src]
+        return names[lo:hi], seqs[lo:hi], bounds
+    meta = np.frombuffer(_recv_tensor(dist, torch, device, src).cpu().numpy().tobytes(), dtype=np.int64)
+    payload = _recv_tensor(dist, torch, device, src).cpu().numpy().tobytes()
+    n = int(meta[0])
+    bounds = [(int(meta[2 + 2 * r]), int(meta[3 + 2 * r])) for r in range(world)]
+    sl = meta[2 + 2 * world:2 + 2 * world + n]
+    nl = meta[2 + 2 * world + n:2 + 2 * world + 2 * n]
+    so = np.concatenate([[0], np.cumsum(sl)])
+    no = np.concatenate([[0], np.cumsum(nl)]) + int(so[-1])
+    my_seqs = [payload[int(so[i]):int(so[i + 1])] for i in range(n)]
+    my_names = [payload[int(no[i]):int(no[i + 1])] for i in range(n)]
+    return my_names, my_seqs, bounds
+
+
+def gather_sam_p2p(dist, torch, my_buf, my_len: int, device, dst: int = 0):
+    """Concatenate the per-rank SAM texts on rank `dst` in rank order.  `my_buf` is a uint8 CPU tensor (ideally pinned);
+    on `dst` it must be large enough for ALL ranks and already hold dst's own text at offset 0 (dst must be rank 0 so
+    that its shard comes first).  Returns the total length on dst, None elsewhere."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if rank != dst:
+        _send_bytes(dist, torch, my_buf[:my_len], device, dst)
+        return None
+    assert dst == 0
+    off = my_len
+    for r in range(world):
+        if r == dst:
+            continue
+        t = _recv_tensor(dist, torch, device, r)
+        n = t.numel()
+        if off + n > my_buf.numel():
+            raise RuntimeError("gather_sam_p2p: destination buffer too small")
+        my_buf[off:off + n].copy_(t, non_blocking=True)
+        off += n
+    if device.type != "cpu":
+        torch.cuda.synchronize()
+    return off

@@ -24,9 +24,16 @@ lo, hi = bounds[rank]
 assert my_names == names[lo:hi] and my_seqs == seqs[lo:hi]
 fake_sam = b"".join(n + b"\t" + hashlib.md5(s).hexdigest().encode() + b"\n" for n, s in zip(my_names, my_seqs))
 out = lfd.gather_sam(dist, torch, fake_sam, dev)
+# point-to-point variants (what bench.py uses)
+n2, s2, b2 = lfd.scatter_reads_p2p(dist, torch, names if rank == 0 else None, seqs if rank == 0 else None, dev)
+assert b2 == bounds and n2 == my_names and s2 == my_seqs
+buf = torch.zeros(1 << 16, dtype=torch.uint8)
+buf[:len(fake_sam)] = torch.frombuffer(bytearray(fake_sam), dtype=torch.uint8)
+tot = lfd.gather_sam_p2p(dist, torch, buf, len(fake_sam), dev)
 if rank == 0:
     exp = b"".join(n + b"\t" + hashlib.md5(s).hexdigest().encode() + b"\n" for n, s in zip(names, seqs))
     assert out == exp
+    assert bytes(buf[:tot].numpy().tobytes()) == exp
     print("DIST_OK", bounds)
 dist.destroy_process_group()
 '''

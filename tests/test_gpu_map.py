@@ -42,6 +42,24 @@ def test_sam_golden(lf, golden_reads, cfg):
     assert st["n_ksw_problems"] > 0, "fixture must reach the ksw clip/split branch"
 
 
+def test_map_batch_into_caller_buffer(lf, golden_reads):
+    """lf_map_batch_into: same records into a caller-owned buffer; a buffer that is too small is an error, not a truncation"""
+    import ctypes as C
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    exp = golden_sam("default")
+    buf = np.zeros(len(exp) + 4096, dtype=np.uint8)
+    ln, st = lf.map_batch_into(names, seqs, buf.ctypes.data, buf.size, params=la.default_params(**GOLDEN_CONFIGS["default"]))
+    assert ln == len(exp) and buf[:ln].tobytes() == exp
+    ln2, _ = lf.map_batch_into(names, seqs, buf.ctypes.data, buf.size)            # buffer reuse
+    assert buf[:ln2].tobytes() == exp
+    small = np.zeros(len(exp) // 2, dtype=np.uint8)
+    with pytest.raises(RuntimeError, match="too small"):
+        lf.map_batch_into(names, seqs, small.ctypes.data, small.size)
+    sam, _ = lf.map_batch(names, seqs)                                           # the handle survives the error
+    assert sam == exp
+
+
 @pytest.mark.parametrize("threads", [1, 3])
 def test_sam_thread_counts(lf, golden_reads, threads):
     import lordfast_amd as la
