@@ -652,7 +652,8 @@ __global__ void lf_desc_build_kernel(const uint64_t *__restrict__ keys, const ui
     probs[j] = p;
 }
 
-static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, float *ms)
+static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len,
+                              int ops_slot, void **ops_dev, float *ms)
 {
     if (ms) *ms = 0;
     if (n == 0) return LF_OK;
@@ -673,7 +674,8 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     lf_aln_prob *d_probs = DSLOT(lf_aln_prob, 13, (size_t)n * sizeof(lf_aln_prob));
     int32_t *d_ed = DSLOT(int32_t, 4, (size_t)n * 4), *d_end = DSLOT(int32_t, 5, (size_t)n * 4);
     uint32_t *d_len = DSLOT(uint32_t, 6, (size_t)n * 4);
-    uint8_t *d_ops = DSLOT(uint8_t, 7, D->ops_total + 64);
+    uint8_t *d_ops = ops ? DSLOT(uint8_t, 7, D->ops_total + 64) : (uint8_t *)lfg_dev_slot(device, ops_slot, D->ops_total + 64);
+    if (ops_dev) *ops_dev = d_ops;
     int *d_cstart = DSLOT(int, 14, 64);
     uint64_t *d_misc = DSLOT(uint64_t, 15, 64);
     if (!d_desc || !d_opsoff || !d_keys || !d_keys2 || !d_vals || !d_vals2 || !d_ent || !d_base || !d_probs || !d_ed || !d_end || !d_len || !d_ops || !d_cstart || !d_misc) return LF_ERR_NOMEM;
@@ -725,7 +727,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     HIPCHK(hipMemcpyAsync(ed, d_ed, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(endloc, d_end, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(ops_len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(ops, d_ops, D->ops_total, hipMemcpyDeviceToHost, s));
+    if (ops) HIPCHK(hipMemcpyAsync(ops, d_ops, D->ops_total, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
@@ -734,7 +736,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
 }
 
 extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_desc_t *d, const uint64_t *ops_off, uint64_t ops_total,
-                              int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, float *ms)
+                              int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, int ops_slot, void **ops_dev, float *ms)
 {
     lf_dev_state *st = (lf_dev_state *)ix->dev;
     if (!st) { lf_set_error("index is not on a device"); return LF_ERR_NO_DEVICE; }
@@ -744,7 +746,7 @@ extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_des
     D.d_pac = st->view.pac;
     if (!D.d_reads) { lf_set_error("lfg_edlib_desc: no resident read batch"); return LF_ERR_ARG; }
     for (int i = 0; i < n; i += 4096) if (d[i].n == 0 || d[i].m == 0) { lf_set_error("lfg_edlib_desc: empty sequence in a descriptor"); return LF_ERR_ARG; }
-    return run_edlib_desc_gpu(ix->device, n, &D, ed, endloc, ops, ops_len, ms);
+    return run_edlib_desc_gpu(ix->device, n, &D, ed, endloc, ops, ops_len, ops_slot, ops_dev, ms);
 }
 
 extern "C" int lfg_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,

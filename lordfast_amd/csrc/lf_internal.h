@@ -68,16 +68,33 @@ void  lfg_set_lane(int lane);          /* calling thread drives lane 0 or 1 (own
 int   lfg_get_lane(void);
 void *lfg_lane_stream(int device, int which);   /* persistent hipStream_t of the calling thread's lane */
 /* slot ids */
-enum { LF_DS_SEED0 = 0 /* ..15 */, LF_DS_CHAIN0 = 16 /* ..23 */, LF_DS_ALN0 = 24 /* ..47 */, LF_DS_KSW0 = 48 /* ..55 */ };
+enum { LF_DS_SEED0 = 0 /* ..15 */, LF_DS_CHAIN0 = 16 /* ..23 */, LF_DS_ALN0 = 24 /* ..47 */, LF_DS_KSW0 = 48 /* ..55 */,
+       LF_DS_RND0 = 56 /* ..87: 2 per extension round (ops, spare) */, LF_DS_RENDER0 = 88 /* ..95 */ };
+#define LF_MAX_ED_ROUNDS 16
 enum { LF_PS_READS = 0, LF_PS_READOFF = 1, LF_PS_HITS_T = 2, LF_PS_HITS_Q = 3, LF_PS_HITS_S = 4, LF_PS_HITS_OFF = 5,
        LF_PS_CHAIN_SEEDS = 6, LF_PS_CHAIN_IDX = 7, LF_PS_ALN_Q = 8, LF_PS_ALN_T = 9, LF_PS_ALN_PROB = 10 /* ..16 */,
-       LF_PS_ROUND0 = 20 /* 4 per round: ed, end, len, ops ; up to 16 rounds */ };
+       LF_PS_ROUND0 = 20 /* 4 per round: ed, end, len, ops ; up to 16 rounds */, LF_PS_RENDER0 = 84 /* ..91 */ };
 
 /* alignment request as a DESCRIPTOR into HBM-resident data: query = the read batch uploaded by the seed stage,
  * target = the 2-bit reference.  Element i = base[start +/- i], optionally complemented (flags LF_F_*). */
 typedef struct { int64_t qstart, tstart; uint32_t n, m; uint8_t flags, mode, pad[6]; } lf_aln_desc_t;
+/* ops == NULL: the edit paths stay in HBM, in the device slot `ops_slot` (address returned in *ops_dev) */
 int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_desc_t *d, const uint64_t *ops_off, uint64_t ops_total,
-                   int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, float *ms);
+                   int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, int ops_slot, void **ops_dev, float *ms);
+
+/* ---- lf_render.hip: CIGAR / MD text from the paths in HBM ---- */
+enum { LF_RI_RUN_M = 0, LF_RI_RUN_I = 1, LF_RI_OPS_FWD = 2, LF_RI_OPS_FWD_TRC = 3, LF_RI_OPS_REV = 4, LF_RI_DEL = 5 };
+typedef struct {            /* one piece of a record, in output order */
+    uint64_t ops_begin;     /* OPS_*: first op of the path inside its round's ops buffer */
+    uint32_t n;             /* elements: ops of the path / length of the run / deleted bases */
+    uint32_t tpos;          /* reference position of the first non-insert element (OPS_FWD_TRC: walks downwards, complemented) */
+    uint8_t kind, round, pad[6];
+} lf_ritem_t;
+typedef struct { uint32_t item0, nitems; } lf_rrecord_t;
+int lfg_render(const struct lf_index *ix, int n_recs, const lf_rrecord_t *recs, uint64_t n_items, const lf_ritem_t *items,
+               const void *const *round_ops, char **text_out, uint64_t **offs_out, uint64_t *text_bytes, float *ms);
+int lfg_fetch(int device, void *dst, const void *src_dev, size_t bytes);
+int lfg_upload(int device, void *dst_dev, const void *src, size_t bytes);
 #define LF_F_QREV  1u
 #define LF_F_QCOMP 2u
 #define LF_F_TREV  4u

@@ -133,6 +133,7 @@ typedef struct {
     uint16_t flag;
     int32_t alnScore, nmCount;
     char *cigar, *md;
+    int rec, rtid;             /* >= 0: CIGAR / MD are rendered on the GPU (record `rec` of worker `rtid`) */
 } sam_t;
 typedef struct { sam_t *v; int n, cap; int32_t totalScore; } samlist_t;
 #define SAM_LESS(a, b) ((a)->totalScore > (b)->totalScore)    /* compareSam, src/LordFAST.cpp:986-992 */
@@ -142,7 +143,7 @@ static void samlist_clear(samlist_t *l) { l->n = 0; }                 /* strings
 static void samlist_push(samlist_t *l, const sam_t *s, char *cigar, char *md, arena_t *ar)
 {
     if (l->n == l->cap) { int nc = l->cap ? l->cap * 2 : 2; l->v = (sam_t *)ar_grow(ar, l->v, (size_t)l->cap * sizeof(sam_t), (size_t)nc * sizeof(sam_t)); l->cap = nc; }
-    l->v[l->n] = *s; l->v[l->n].cigar = cigar; l->v[l->n].md = md; l->n++;
+    l->v[l->n] = *s; l->v[l->n].cigar = cigar; l->v[l->n].md = md; l->v[l->n].rec = -1; l->n++;
 }
 
 /* ---------------------------------------------------------------- requests */
@@ -158,9 +159,15 @@ typedef struct {
     rkey_t key;
     int round;             /* -1 = requested, not yet computed */
     int64_t slot;          /* index in the round's result arrays */
+    uint8_t *hops;         /* host copy of the ops region, fetched on demand (per-base fallback only) */
 } memo_t;
 
-typedef struct { int32_t *ed, *end; uint32_t *ops_len; uint8_t *ops; uint64_t *ops_off; int n, pinned; } ed_round_t;
+typedef struct {
+    int32_t *ed, *end; uint32_t *ops_len; uint64_t *ops_off; int n, pinned;
+    uint8_t *ops;          /* host copy of the edit paths, or NULL when they stay in HBM ... */
+    uint8_t *d_ops;        /* ... at this device address */
+    uint64_t ops_bytes;
+} ed_round_t;
 typedef struct { int32_t *score, *qle, *tle; int n; } ksw_round_t;
 
 typedef struct {
@@ -175,6 +182,8 @@ typedef struct {
     uint64_t ext_bytes;
     /* staged edlib requests as descriptors into HBM-resident reads / pac (leaf-size problems: the common case) */
     lf_aln_desc_t *dd; uint64_t *dops; uintptr_t *downer; int dn, dcap; uint64_t dops_total;
+    /* CIGAR / MD recipes of the finished records (rendered by lf_render.hip after the last round) */
+    lf_ritem_t *ri; uint64_t rin, ricap; lf_rrecord_t *rr; int rrn, rrcap;
 } stage_t;
 
 typedef struct job {
@@ -226,6 +235,8 @@ typedef struct ctx {
     const lfg_hits_t *hits;
     /* scratch for the parallel merge of staged alignment requests */
     lf_aln_desc_t *mg_desc; char *mg_qb, *mg_tb; uint64_t *mg_qoff, *mg_toff, *mg_qbase, *mg_tbase; uint8_t *mg_mode; int *mg_gbase; ed_round_t *mg_R; int mg_round;
+    int host_cigar;                 /* LF_HOST_CIGAR=1: build CIGAR / MD on the host from copied-back paths (cross-check) */
+    char *rtext; uint64_t *roffs; int *rrbase;      /* rendered text, per-record offsets, first record of each worker */
     /* output assembly */
     char *out_base; uint64_t *out_off;
     const char *const *len_seqs; uint32_t *len_out;
@@ -237,7 +248,7 @@ typedef struct ctx {
  * The pool therefore serves up to two jobs concurrently; each lane's driver thread also works on its own job.
  * Worker ids: pool threads 0..nw-1, lane drivers nw and nw+1 (per-worker scratch arrays have nw+2 entries). */
 typedef void (*pf_fn)(ctx_t *cx, int tid, int i);
-typedef struct { pf_fn fn; ctx_t *cx; int n, grain; volatile int next; int active, inflight; } pjob_t;
+typedef struct { pf_fn fn; ctx_t *cx; int n, grain; volatile int next; int active, inflight; int timed; volatile long long cpu_ns; } pjob_t;
 typedef struct {
     pthread_t th[256]; int nw, started, stop;
     pthread_mutex_t mu; pthread_cond_t cv_work, cv_done[2];
@@ -246,8 +257,40 @@ typedef struct {
 static pool_t g_pool = { .mu = PTHREAD_MUTEX_INITIALIZER, .cv_work = PTHREAD_COND_INITIALIZER,
                          .cv_done = { PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER } };
 
+/* LF_TIMING=1: per-phase CPU time (summed over workers) and wall time, printed at the end of each batch */
+static struct { const char *name; double cpu_ms, wall_ms; long calls; } g_phase[32];
+static int g_phase_n, g_phase_on;
+static pthread_mutex_t g_phase_mu = PTHREAD_MUTEX_INITIALIZER;
+static inline long long thread_cpu_ns(void) { struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec * 1000000000LL + ts.tv_nsec; }
+static void phase_account(const char *name, double cpu_ms, double wall_ms)
+{
+    pthread_mutex_lock(&g_phase_mu);
+    int k = 0;
+    for (; k < g_phase_n; k++) if (g_phase[k].name == name) break;
+    if (k == g_phase_n && g_phase_n < 32) { g_phase[k].name = name; g_phase[k].cpu_ms = g_phase[k].wall_ms = 0; g_phase[k].calls = 0; g_phase_n++; }
+    if (k < 32) { g_phase[k].cpu_ms += cpu_ms; g_phase[k].wall_ms += wall_ms; g_phase[k].calls++; }
+    pthread_mutex_unlock(&g_phase_mu);
+}
+static void phase_report(void)
+{
+    for (int k = 0; k < g_phase_n; k++)
+        fprintf(stderr, "[lf] phase %-20s cpu %9.1f ms  wall %8.1f ms  calls %ld\n", g_phase[k].name, g_phase[k].cpu_ms, g_phase[k].wall_ms, g_phase[k].calls);
+    g_phase_n = 0;
+}
+
 static void pool_run(pjob_t *J, int tid)
 {
+    if (J->timed) {
+        const long long c0 = thread_cpu_ns();
+        for (;;) {
+            int i = __sync_fetch_and_add(&J->next, J->grain);
+            if (i >= J->n) break;
+            int e = i + J->grain < J->n ? i + J->grain : J->n;
+            for (; i < e; i++) J->fn(J->cx, tid, i);
+        }
+        __sync_fetch_and_add(&J->cpu_ns, thread_cpu_ns() - c0);
+        return;
+    }
     for (;;) {
         int i = __sync_fetch_and_add(&J->next, J->grain);
         if (i >= J->n) break;
@@ -293,14 +336,16 @@ static void pool_ensure(int nw)
     P->started = 1;
 }
 /* called by a lane driver (cx->lane); returns when every item ran */
-static void parallel_for(ctx_t *cx, int n, pf_fn fn)
+#define parallel_for(cx, n, fn) parallel_for_named(cx, n, fn, #fn)
+static void parallel_for_named(ctx_t *cx, int n, pf_fn fn, const char *name)
 {
     pool_t *P = &g_pool;
     if (n <= 0) return;
     pjob_t *J = &P->job[cx->lane];
     const int self = P->nw + cx->lane;
+    const double w0 = g_phase_on ? now_ms() : 0;
     pthread_mutex_lock(&P->mu);
-    J->fn = fn; J->cx = cx; J->n = n; J->next = 0;
+    J->fn = fn; J->cx = cx; J->n = n; J->next = 0; J->timed = g_phase_on; J->cpu_ns = 0;
     J->grain = n / ((P->nw + 1) * 16) + 1; if (J->grain > 64) J->grain = 64;
     J->inflight = 1; J->active = 1;
     pthread_cond_broadcast(&P->cv_work);
@@ -311,6 +356,7 @@ static void parallel_for(ctx_t *cx, int n, pf_fn fn)
     while (J->inflight > 0) pthread_cond_wait(&P->cv_done[cx->lane], &P->mu);
     J->active = 0;
     pthread_mutex_unlock(&P->mu);
+    if (g_phase_on) phase_account(name, J->cpu_ns / 1e6, now_ms() - w0);
 }
 
 /* ---------------------------------------------------------------- reference fetch (src/BWT.cpp:593-666) */
@@ -505,6 +551,7 @@ static void phase_fine_select(ctx_t *cx, int tid, int ri)
 typedef struct {
     int ed, end; const uint8_t *ops; uint32_t nops;
     int have;
+    int round; uint64_t ops_begin; uint32_t tcons;      /* where the path lives in HBM; reference bases it consumes */
 } edres_t;
 
 typedef struct {
@@ -528,7 +575,7 @@ static memo_t *memo_add(job_t *j, const rkey_t *k, arena_t *ar)
 {
     if (j->nmemo == j->capmemo) { int nc = j->capmemo ? j->capmemo * 2 : 32; j->memo = (memo_t *)ar_grow(ar, j->memo, (size_t)j->capmemo * sizeof(memo_t), (size_t)nc * sizeof(memo_t)); j->capmemo = nc; }
     memo_t *m = &j->memo[j->nmemo++];
-    m->key = *k; m->round = -1; m->slot = -1;
+    m->key = *k; m->round = -1; m->slot = -1; m->hops = NULL;
     j->hint = j->nmemo;
     return m;
 }
@@ -656,7 +703,9 @@ static edres_t need_edlib(walk_t *w, int qrc, uint32_t qs, uint32_t qseg, uint32
     if (m->round < 0) { w->missing++; w->build = 0; r.ed = 0; r.end = (mode == 0) ? (int)tn - 1 : (int)tn - 1; return r; }
     const ed_round_t *R = &w->cx->ed_rounds[m->round];
     r.have = 1; r.ed = R->ed[m->slot]; r.end = R->end[m->slot]; r.nops = R->ops_len[m->slot];
-    r.ops = R->ops + R->ops_off[m->slot] + ((uint64_t)qn + tn - r.nops);            /* end-aligned in its region */
+    r.round = m->round; r.ops_begin = R->ops_off[m->slot] + ((uint64_t)qn + tn - r.nops);     /* end-aligned in its region */
+    r.tcons = mode == 0 ? tn : (uint32_t)(r.end + 1);                               /* NW: all of it; SHW: up to the end column */
+    r.ops = R->ops ? R->ops + r.ops_begin : (m->hops ? m->hops + ((uint64_t)qn + tn - r.nops) : NULL);
     return r;
 }
 
@@ -748,7 +797,8 @@ static char *md_string(const track_t *md, const track_t *cg, arena_t *ar)
  * MD and CIGAR (src/LordFAST.cpp:2057, App. B #3). */
 typedef struct { int kind; char cg, md; uint32_t n; edres_t r; uint32_t ts, tseg; } fseg_t;
 typedef struct {
-    int track_mode, need_track, active;
+    int track_mode, need_track, active;    /* track_mode: 0 STREAM (host strings), 1 TRACK (per-base), 2 RECIPE (GPU renders) */
+    stage_t *rs; uint64_t item_mark;       /* RECIPE mode: the worker's item list; first item of the open record */
     track_t cg, md;                        /* TRACK mode */
     str_t scg, smd; char ch; unsigned run; int opn; unsigned mdnum; char last; int fed;    /* STREAM mode */
     fseg_t front[8]; int nfront;
@@ -756,17 +806,40 @@ typedef struct {
 } alnb_t;
 
 static void ab_reset_stream(alnb_t *b) { str_init_ar(&b->scg, b->ar, b->hint); str_init_ar(&b->smd, b->ar, b->hint); b->ch = 0; b->run = 0; b->opn = 0; b->mdnum = 0; b->last = '='; b->fed = 0; b->nfront = 0; }
-static void ab_init(alnb_t *b, int track_mode, int active, const uint8_t *pac, size_t hint, arena_t *ar)
+static void ab_init(alnb_t *b, int track_mode, int active, const uint8_t *pac, size_t hint, arena_t *ar, stage_t *rs)
 {
     memset(b, 0, sizeof *b);
     b->track_mode = track_mode; b->active = active; b->pac = pac; b->ar = ar; b->hint = hint / 2 + 128;
     if (!active) return;
-    if (track_mode) { tr_init(&b->cg, hint); tr_init(&b->md, hint); } else ab_reset_stream(b);
+    if (track_mode == 2) { b->rs = rs; b->item_mark = rs->rin; b->last = '='; }
+    else if (track_mode) { tr_init(&b->cg, hint); tr_init(&b->md, hint); } else ab_reset_stream(b);
 }
 static void ab_free(alnb_t *b)
 {
     if (!b->active) return;
-    if (b->track_mode) { free(b->cg.buf); free(b->md.buf); }
+    if (b->track_mode == 1) { free(b->cg.buf); free(b->md.buf); }
+}
+/* ---- RECIPE mode: the order of the pieces is all the host records ---- */
+static inline lf_ritem_t *rc_item(alnb_t *b)
+{
+    stage_t *s = b->rs;
+    if (s->rin == s->ricap) { s->ricap = s->ricap ? s->ricap * 2 : 4096; s->ri = (lf_ritem_t *)realloc(s->ri, s->ricap * sizeof(lf_ritem_t)); }
+    lf_ritem_t *it = &s->ri[s->rin++];
+    memset(it, 0, sizeof *it);
+    return it;
+}
+static void rc_run(alnb_t *b, int kind, uint32_t n, uint32_t tpos)
+{
+    if (!n) return;
+    b->fed = 1;
+    lf_ritem_t *it = rc_item(b); it->kind = (uint8_t)kind; it->n = n; it->tpos = tpos;
+}
+static void rc_ops(alnb_t *b, const edres_t *r, int kind, uint32_t tpos)
+{
+    if (r->round >= LF_MAX_ED_ROUNDS) { b->need_track = 1; return; }      /* beyond the rounds kept in HBM: host fallback */
+    if (!r->nops) return;
+    b->fed = 1;
+    lf_ritem_t *it = rc_item(b); it->kind = (uint8_t)kind; it->n = r->nops; it->tpos = tpos; it->round = (uint8_t)r->round; it->ops_begin = r->ops_begin;
 }
 static inline void st_c(alnb_t *b, char c, uint32_t n)
 {
@@ -821,69 +894,80 @@ static void ab_flush_front(alnb_t *b)
 {
     while (b->nfront > 0) {
         const fseg_t *f = &b->front[--b->nfront];
+        if (b->track_mode == 2) {
+            if (f->kind == 0) rc_run(b, f->cg == 'M' ? LF_RI_RUN_M : LF_RI_RUN_I, f->n, 0);
+            else rc_ops(b, &f->r, LF_RI_OPS_REV, f->ts + f->tseg - f->r.tcons);
+            continue;
+        }
         if (f->kind == 0) st_run(b, f->cg, f->md, f->n); else st_ops_rev(b, &f->r, f->ts, f->tseg);
     }
 }
 static void ab_back_run(alnb_t *b, char cg, char md, size_t n)
 {
     if (!b->active) return;
-    if (b->track_mode) { tr_back_n(&b->cg, n, cg); tr_back_n(&b->md, n, md); return; }
-    ab_flush_front(b); st_run(b, cg, md, (uint32_t)n);
+    if (b->track_mode == 1) { tr_back_n(&b->cg, n, cg); tr_back_n(&b->md, n, md); return; }
+    ab_flush_front(b);
+    if (b->track_mode == 2) { rc_run(b, cg == 'M' ? LF_RI_RUN_M : LF_RI_RUN_I, (uint32_t)n, 0); return; }
+    st_run(b, cg, md, (uint32_t)n);
 }
 static void ab_front_run(alnb_t *b, char cg, char md, size_t n)
 {
     if (!b->active) return;
-    if (b->track_mode) { tr_front_n(&b->cg, n, cg); tr_front_n(&b->md, n, md); return; }
+    if (b->track_mode == 1) { tr_front_n(&b->cg, n, cg); tr_front_n(&b->md, n, md); return; }
     if (b->fed || b->nfront >= 8) { b->need_track = 1; return; }
     fseg_t *f = &b->front[b->nfront++]; f->kind = 0; f->cg = cg; f->md = md; f->n = (uint32_t)n;
 }
 static void ab_back_ops(alnb_t *b, const edres_t *r, int trc, uint32_t ts, uint32_t tseg)
 {
     if (!b->active || !r->have) return;
-    if (b->track_mode) { ops_back(&b->cg, &b->md, r, b->pac, trc, ts, tseg); return; }
-    ab_flush_front(b); st_ops_fwd(b, r, trc, ts, tseg);
+    if (b->track_mode == 1) { ops_back(&b->cg, &b->md, r, b->pac, trc, ts, tseg); return; }
+    ab_flush_front(b);
+    if (b->track_mode == 2) { rc_ops(b, r, trc ? LF_RI_OPS_FWD_TRC : LF_RI_OPS_FWD, trc ? ts + tseg - 1 : ts); return; }
+    st_ops_fwd(b, r, trc, ts, tseg);
 }
 static void ab_front_ops(alnb_t *b, const edres_t *r, uint32_t ts, uint32_t tseg)
 {
     if (!b->active || !r->have) return;
-    if (b->track_mode) { ops_front(&b->cg, &b->md, r, b->pac, ts, tseg); return; }
+    if (b->track_mode == 1) { ops_front(&b->cg, &b->md, r, b->pac, ts, tseg); return; }
     if (b->fed || b->nfront >= 8) { b->need_track = 1; return; }
     fseg_t *f = &b->front[b->nfront++]; f->kind = 1; f->r = *r; f->ts = ts; f->tseg = tseg;
 }
 static void ab_back_del(alnb_t *b, uint32_t ts, uint32_t n)
 {   /* pure deletion between two anchors (src/LordFAST.cpp:2126-2134) */
     if (!b->active || !n) return;
-    if (b->track_mode) {
+    if (b->track_mode == 1) {
         tr_back_n(&b->cg, n, 'D'); tr_room(&b->md, 0, n);
         for (uint32_t j = 0; j < n; j++) b->md.buf[b->md.end++] = "ACGT"[pac_base(b->pac, ts + j)];
         return;
     }
     ab_flush_front(b); b->fed = 1;
+    if (b->track_mode == 2) { rc_run(b, LF_RI_DEL, n, ts); return; }
     st_c(b, 'D', n);
     for (uint32_t j = 0; j < n; j++) st_md_base(b, "ACGT"[pac_base(b->pac, ts + j)], 1);
 }
 static void ab_md_front_only(alnb_t *b, size_t n)
 {   /* the reference's misplaced padding: MD at the front while the CIGAR got it at the back */
     if (!b->active) return;
-    if (b->track_mode) { tr_front_n(&b->md, n, '-'); return; }
+    if (b->track_mode == 1) { tr_front_n(&b->md, n, '-'); return; }
     b->need_track = 1;
 }
 static void ab_cg_back_only(alnb_t *b, size_t n)
 {
     if (!b->active) return;
-    if (b->track_mode) { tr_back_n(&b->cg, n, 'I'); return; }
+    if (b->track_mode == 1) { tr_back_n(&b->cg, n, 'I'); return; }
     b->need_track = 1;
 }
 static void ab_clear(alnb_t *b)
 {
     if (!b->active) return;
-    if (b->track_mode) { tr_clear(&b->cg); tr_clear(&b->md); return; }
+    if (b->track_mode == 1) { tr_clear(&b->cg); tr_clear(&b->md); return; }
+    if (b->track_mode == 2) { b->rs->rin = b->item_mark; b->fed = 0; b->nfront = 0; return; }
     ab_reset_stream(b);
 }
 /* strings of the record built so far (ownership passes to the caller) */
 static void ab_take(alnb_t *b, char **cigar, char **md)
 {
-    if (b->track_mode) { *cigar = cigar_string(&b->cg, b->ar); *md = md_string(&b->md, &b->cg, b->ar); return; }
+    if (b->track_mode == 1) { *cigar = cigar_string(&b->cg, b->ar); *md = md_string(&b->md, &b->cg, b->ar); return; }
     ab_flush_front(b);
     if (b->run) { str_putu(&b->scg, b->run); str_putc(&b->scg, b->ch == 'I' ? 'S' : b->ch); }
     str_putu(&b->smd, b->mdnum);
@@ -894,6 +978,17 @@ static void ab_take(alnb_t *b, char **cigar, char **md)
 static void emit_sam(walk_t *w, samlist_t *map, const sam_t *tmp, alnb_t *ab)
 {
     if (!w->build || !ab->active || ab->need_track) return;
+    if (ab->track_mode == 2) {                       /* close the record: its pieces are items [item_mark, rin) */
+        ab_flush_front(ab);
+        if (ab->need_track) return;
+        stage_t *s = ab->rs;
+        if (s->rrn == s->rrcap) { s->rrcap = s->rrcap ? s->rrcap * 2 : 1024; s->rr = (lf_rrecord_t *)realloc(s->rr, (size_t)s->rrcap * sizeof(lf_rrecord_t)); }
+        s->rr[s->rrn].item0 = (uint32_t)ab->item_mark; s->rr[s->rrn].nitems = (uint32_t)(s->rin - ab->item_mark);
+        samlist_push(map, tmp, NULL, NULL, ab->ar);
+        map->v[map->n - 1].rec = s->rrn++; map->v[map->n - 1].rtid = w->tid;
+        ab->item_mark = s->rin; ab->fed = 0; ab->nfront = 0;
+        return;
+    }
     char *c, *m;
     ab_take(ab, &c, &m);
     samlist_push(map, tmp, c, m, ab->ar);
@@ -912,7 +1007,9 @@ static int walk_chain_mode(ctx_t *cx, int tid, job_t *job, samlist_t *map, int t
     W.cx = cx; W.tid = tid; W.job = job; W.query = isRev ? rd->seq_rev : rd->seq; W.readLen = rd->len; W.build = 1;
     job->hint = 0;
     const int32_t readLen = (int32_t)rd->len;
-    alnb_t ab; ab_init(&ab, track_mode, active, pac, rd->len, &cx->arena[tid]);
+    stage_t *const rs = &cx->stages[tid];
+    const uint64_t rin0 = rs->rin; const int rrn0 = rs->rrn;
+    alnb_t ab; ab_init(&ab, track_mode, active, pac, rd->len, &cx->arena[tid], rs);
     sam_t tmp; memset(&tmp, 0, sizeof tmp);
     uint32_t chrBeg, chrEnd, readAlnStart, refAlnStart, readAlnEnd, refAlnEnd, i;
     int32_t readAlnLen, refAlnLen, editScore = 0;
@@ -1052,7 +1149,8 @@ bail:
     *need_track = ab.need_track;
     ab_free(&ab);
     job->complete = (W.missing == 0 && !W.bail);
-    if (!job->complete || ab.need_track) samlist_clear(map);
+    if (!job->complete || ab.need_track) { samlist_clear(map); rs->rin = rin0; rs->rrn = rrn0; }
+    else if (track_mode == 2 && active) rs->rin = ab.item_mark;          /* pieces after the last record are dropped */
     return job->complete;
 }
 
@@ -1060,9 +1158,21 @@ static int walk_chain(ctx_t *cx, int tid, job_t *job, samlist_t *map)
 {
     int need_track = 0;
     const int active = job->nmemo > 0;        /* a first walk has no results yet: it only registers requests */
-    int done = walk_chain_mode(cx, tid, job, map, 0, active, &need_track);
-    if (done && !active) done = walk_chain_mode(cx, tid, job, map, 0, 1, &need_track);   /* chain without any alignment */
-    if (done && need_track) done = walk_chain_mode(cx, tid, job, map, 1, 1, &need_track); /* rare: per-base tracks */
+    const int mode = cx->host_cigar ? 0 : 2;
+    int done = walk_chain_mode(cx, tid, job, map, mode, active, &need_track);
+    if (done && !active) done = walk_chain_mode(cx, tid, job, map, mode, 1, &need_track);   /* chain without any alignment */
+    if (done && need_track) {                                                               /* rare: per-base tracks on the host */
+        for (int k = 0; k < job->nmemo; k++) {          /* bring this job's edit paths back from HBM */
+            memo_t *m = &job->memo[k];
+            if (m->key.type != 0 || m->round < 0 || m->hops) continue;
+            const ed_round_t *R = &cx->ed_rounds[m->round];
+            if (R->ops || !R->d_ops) continue;
+            const size_t region = (size_t)m->key.qn + m->key.tn;
+            m->hops = (uint8_t *)ar_alloc(&cx->arena[tid], region + 1);
+            if (lfg_fetch(cx->ix->device, m->hops, R->d_ops + R->ops_off[m->slot], region) != LF_OK) { m->hops = NULL; return 0; }
+        }
+        done = walk_chain_mode(cx, tid, job, map, 1, 1, &need_track);
+    }
     return done;
 }
 
@@ -1214,6 +1324,21 @@ static void phase_walk(ctx_t *cx, int tid, int ri)
         if (j->complete) continue;
         walk_chain(cx, tid, j, &r->maps[w]);
     }
+}
+
+/* the records' strings are in the rendered text now */
+static void phase_bind_text(ctx_t *cx, int tid, int ri)
+{
+    (void)tid;
+    rd_t *r = &cx->reads[ri];
+    if (r->mode < 2) return;
+    for (int w = 0; w < r->nWins; w++)
+        for (int j = 0; j < r->maps[w].n; j++) {
+            sam_t *s = &r->maps[w].v[j];
+            if (s->rec < 0) continue;
+            const size_t g = (size_t)cx->rrbase[s->rtid] + (size_t)s->rec;
+            s->cigar = cx->rtext + cx->roffs[2 * g]; s->md = cx->rtext + cx->roffs[2 * g + 1];
+        }
 }
 
 static void phase_merge_edlib(ctx_t *cx, int tid, int t)
@@ -1376,23 +1501,29 @@ static int map_chunk(ctx_t *cx)
             const int ridx = cx->n_ed_rounds;
             const int pin = ridx < 16;
             ed_round_t R; memset(&R, 0, sizeof R);
-            R.n = nd; R.pinned = pin;
+            R.n = nd; R.pinned = pin; R.ops_bytes = ops_total;
+            /* the edit paths stay in HBM (slot of this round) unless the host builds the strings itself */
+            const int host_ops = cx->host_cigar || ridx >= LF_MAX_ED_ROUNDS;
             if (pin) {
                 R.ed = (int32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx, (size_t)nd * 4); R.end = (int32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 1, (size_t)nd * 4);
-                R.ops_len = (uint32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 2, (size_t)nd * 4); R.ops = (uint8_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 3, ops_total + 1);
+                R.ops_len = (uint32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 2, (size_t)nd * 4);
+                if (host_ops) R.ops = (uint8_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 3, ops_total + 1);
             } else {
                 R.ed = (int32_t *)malloc((size_t)nd * 4); R.end = (int32_t *)malloc((size_t)nd * 4);
                 R.ops_len = (uint32_t *)malloc((size_t)nd * 4); R.ops = (uint8_t *)malloc(ops_total + 1);
             }
             R.ops_off = (uint64_t *)malloc((size_t)nd * 8);
             lf_aln_desc_t *desc = (lf_aln_desc_t *)lfg_pin_slot(LF_PS_ALN_PROB, (size_t)nd * sizeof(lf_aln_desc_t));
-            if (!desc || !R.ed || !R.end || !R.ops_len || !R.ops) return LF_ERR_NOMEM;
+            if (!desc || !R.ed || !R.end || !R.ops_len || (host_ops && !R.ops)) return LF_ERR_NOMEM;
             cx->mg_desc = desc; cx->mg_R = &R; cx->mg_qbase = obase; cx->mg_gbase = gbase; cx->mg_round = ridx;
             double tm0 = now_ms();
             parallel_for(cx, nt, phase_merge_desc);
             free(obase); free(gbase);
             float ms = 0;
-            rc = lfg_edlib_desc(cx->ix, nd, desc, R.ops_off, ops_total, R.ed, R.end, R.ops, R.ops_len, &ms);
+            void *dops = NULL;
+            rc = lfg_edlib_desc(cx->ix, nd, desc, R.ops_off, ops_total, R.ed, R.end, R.ops, R.ops_len,
+                                LF_DS_RND0 + 2 * (ridx < LF_MAX_ED_ROUNDS ? ridx : 0), &dops, &ms);
+            if (!host_ops) R.d_ops = (uint8_t *)dops;
             if (timing) fprintf(stderr, "[lf] round %d: %d descriptor problems, merge+solve %.1f ms (kernels %.1f ms), ops %.1f MB\n", round, nd, now_ms() - tm0, ms, ops_total / 1e6);
             cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
             cx->ed_rounds[cx->n_ed_rounds++] = R;
@@ -1409,7 +1540,7 @@ static int map_chunk(ctx_t *cx)
             uint64_t *qoff = (uint64_t *)malloc(((size_t)ne + 1) * 8), *toff = (uint64_t *)malloc(((size_t)ne + 1) * 8);
             uint8_t *mode = (uint8_t *)malloc((size_t)ne);
             ed_round_t R; memset(&R, 0, sizeof R);
-            R.n = ne; R.pinned = pin;
+            R.n = ne; R.pinned = pin; R.ops_bytes = qn + tn;
             if (pin) {
                 R.ed = (int32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx, (size_t)ne * 4); R.end = (int32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 1, (size_t)ne * 4);
                 R.ops_len = (uint32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 2, (size_t)ne * 4); R.ops = (uint8_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 3, qn + tn + 1);
@@ -1470,6 +1601,46 @@ static int map_chunk(ctx_t *cx)
     }
     t1 = now_ms(); st->ms_extend += t1 - t0; t0 = t1;
 
+    /* ---- D': CIGAR / MD text of every record, rendered on the GPU from the paths in HBM ---- */
+    if (!cx->host_cigar) {
+        uint64_t n_items = 0; int n_recs = 0;
+        cx->rrbase = (int *)malloc((size_t)nt * sizeof(int));
+        uint64_t *ibase = (uint64_t *)malloc((size_t)nt * 8);
+        for (int t = 0; t < nt; t++) { cx->rrbase[t] = n_recs; ibase[t] = n_items; n_recs += cx->stages[t].rrn; n_items += cx->stages[t].rin; }
+        if (n_recs) {
+            if (n_items >= 0xffffffffull) { lf_set_error("lf_map_batch: too many CIGAR pieces in one chunk"); free(ibase); return LF_ERR_ARG; }
+            lf_ritem_t *items = (lf_ritem_t *)lfg_pin_slot(LF_PS_RENDER0 + 3, (n_items + 1) * sizeof(lf_ritem_t));
+            lf_rrecord_t *recs = (lf_rrecord_t *)lfg_pin_slot(LF_PS_RENDER0 + 4, ((size_t)n_recs + 1) * sizeof(lf_rrecord_t));
+            if (!items || !recs) { free(ibase); return LF_ERR_NOMEM; }
+            for (int t = 0; t < nt; t++) {
+                const stage_t *s = &cx->stages[t];
+                if (s->rin) memcpy(items + ibase[t], s->ri, s->rin * sizeof(lf_ritem_t));
+                for (int k = 0; k < s->rrn; k++) { lf_rrecord_t q = s->rr[k]; q.item0 += (uint32_t)ibase[t]; recs[cx->rrbase[t] + k] = q; }
+            }
+            /* rounds whose paths were computed through the host (Hirschberg-size problems): put them into HBM too */
+            const void *round_ops[LF_MAX_ED_ROUNDS]; memset(round_ops, 0, sizeof round_ops);
+            for (int k = 0; k < cx->n_ed_rounds && k < LF_MAX_ED_ROUNDS; k++) {
+                ed_round_t *Rk = &cx->ed_rounds[k];
+                if (!Rk->d_ops && Rk->ops && Rk->ops_bytes) {
+                    void *dp = lfg_dev_slot(cx->ix->device, LF_DS_RND0 + 2 * k, Rk->ops_bytes + 64);
+                    if (!dp) { free(ibase); return LF_ERR_NOMEM; }
+                    rc = lfg_upload(cx->ix->device, dp, Rk->ops, Rk->ops_bytes);
+                    if (rc != LF_OK) { free(ibase); return rc; }
+                    Rk->d_ops = (uint8_t *)dp;
+                }
+                round_ops[k] = Rk->d_ops;
+            }
+            float ms = 0; uint64_t tbytes = 0;
+            rc = lfg_render(cx->ix, n_recs, recs, n_items, items, round_ops, &cx->rtext, &cx->roffs, &tbytes, &ms);
+            if (timing) fprintf(stderr, "[lf] render: %d records, %llu pieces, %.1f MB text, kernels %.1f ms, total %.1f ms\n", n_recs, (unsigned long long)n_items, tbytes / 1e6, ms, now_ms() - t0);
+            if (rc != LF_OK) { free(ibase); return rc; }
+            st->ms_k_render += ms; st->render_bytes += tbytes; st->render_launches += 1;
+            parallel_for(cx, n, phase_bind_text);
+        }
+        free(ibase);
+    }
+    t1 = now_ms(); st->ms_render += t1 - t0; t0 = t1;
+
     /* ---- E: SAM (score + count here; the text is written by lf_map_batch straight into the output buffer) ---- */
     parallel_for(cx, n, phase_sam_score);
     cx->out_base = NULL;
@@ -1490,13 +1661,14 @@ static void chunk_free(ctx_t *cx)
             stage_t *s = &cx->stages[t];
             free(s->qb); free(s->tb); free(s->qoff); free(s->toff); free(s->mode); free(s->owner);
             free(s->kq); free(s->kt); free(s->kqoff); free(s->ktoff); free(s->kprm); free(s->kowner);
-            free(s->dd); free(s->dops); free(s->downer);
+            free(s->dd); free(s->dops); free(s->downer); free(s->ri); free(s->rr);
             free(cx->ed_jobs[t].job); free(cx->ksw_jobs[t].job); free(cx->edd_jobs[t].job);
         }
         free(cx->stages); free(cx->ed_jobs); free(cx->ksw_jobs); free(cx->edd_jobs); cx->ed_jobs = cx->ksw_jobs = cx->edd_jobs = NULL;
     }
     cx->creq = NULL; cx->cseeds = NULL; cx->chain_idx = NULL; cx->chain_len = NULL; cx->chain_score = NULL;
     cx->ed_rounds = NULL; cx->ksw_rounds = NULL; cx->n_ed_rounds = cx->n_ksw_rounds = 0; cx->stages = NULL;
+    free(cx->rrbase); cx->rrbase = NULL; cx->rtext = NULL; cx->roffs = NULL;
 }
 
 static pthread_mutex_t g_map_lock = PTHREAD_MUTEX_INITIALIZER;     /* the worker pool and the lanes serve one batch at a time */
@@ -1511,7 +1683,7 @@ typedef struct {
     chunk_t *chunks; int n_chunks; volatile int next_chunk;
     pthread_mutex_t mu; pthread_cond_t cv;      /* chunk sizes become known in any order */
     pthread_rwlock_t grow;                      /* writers of SAM text hold it shared; growing the buffer exclusive */
-    str_t all; int fixed_out;                   /* fixed_out: caller-provided buffer, never reallocated */
+    int host_cigar; str_t all; int fixed_out;                   /* fixed_out: caller-provided buffer, never reallocated */
     volatile int rc; char err[1024];
     lf_stats_t st[2];
 } batch_t;
@@ -1525,6 +1697,7 @@ static void merge_stats(lf_stats_t *d, const lf_stats_t *a)
     d->n_edlib_problems += a->n_edlib_problems; d->n_ksw_problems += a->n_ksw_problems; d->n_cache += a->n_cache; d->n_occblk += a->n_occblk;
     d->n_sa += a->n_sa; d->n_readbytes += a->n_readbytes; d->ext_bytes += a->ext_bytes; d->edlib_launches += a->edlib_launches;
     d->search_launches += a->search_launches; d->locate_launches += a->locate_launches;
+    d->ms_render += a->ms_render; d->ms_k_render += a->ms_k_render; d->render_bytes += a->render_bytes; d->render_launches += a->render_launches;
 }
 
 static void *lane_main(void *arg_)
@@ -1539,7 +1712,7 @@ static void *lane_main(void *arg_)
         if (k >= B->n_chunks || B->rc != LF_OK) break;
         chunk_t *C = &B->chunks[k];
         ctx_t cx; memset(&cx, 0, sizeof cx);
-        cx.ix = B->ix; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane];
+        cx.ix = B->ix; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane]; cx.host_cigar = B->host_cigar;
         cx.n_reads = C->i1 - C->i0;
         cx.reads = (rd_t *)calloc((size_t)cx.n_reads, sizeof(rd_t));
         for (int i = C->i0; i < C->i1; i++) {
@@ -1627,11 +1800,13 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
     if (nt < 1) nt = 1;
     const double T0 = now_ms();
     pthread_mutex_lock(&g_map_lock);
+    g_phase_on = getenv("LF_PHASES") != NULL;
     const int n_lanes = (nt >= 3 && !getenv("LF_ONE_LANE")) ? 2 : 1;
     const int nw = nt - n_lanes;                       /* pool workers; the lane drivers work too */
     pool_ensure(nw);
 
     batch_t B; memset(&B, 0, sizeof B);
+    B.host_cigar = getenv("LF_HOST_CIGAR") != NULL;
     B.ix = ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + 2; B.rc = LF_OK;
     pthread_mutex_init(&B.mu, NULL); pthread_cond_init(&B.cv, NULL); pthread_rwlock_init(&B.grow, NULL);
     if (ext_buf) { B.all.s = ext_buf; B.all.cap = ext_cap; B.all.n = 0; B.all.mode = 2; B.fixed_out = 1; }
@@ -1668,6 +1843,7 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
     lane_main(a0);
     if (have_t1) pthread_join(t1, NULL);
     lfg_set_lane(0);
+    if (g_phase_on) { fprintf(stderr, "[lf] batch of %d reads: %.1f ms wall, %d threads\n", n, now_ms() - T0, nt); phase_report(); }
     pthread_mutex_unlock(&g_map_lock);
 
     uint64_t total = 0;

@@ -1,0 +1,258 @@
+/*
+ * lf_render.hip -- CIGAR and MD:Z text of every SAM record, written on the GPU from the alignment paths that the
+ * edlib kernels left in HBM.
+ *
+ * The reference builds both strings base by base while it walks a chain (alignChain_edlib, src/LordFAST.cpp:1570-1763
+ * for the per-base tracks and :1799-2230 for the order of the pieces).  Here the host's chain walk only records the
+ * ORDER of the pieces as 24-byte items (anchor run, clipped run, edlib path forward / reversed, pure deletion); one
+ * wavefront per record then turns the pieces into text:
+ *
+ *   CIGAR  run-length encoding of M / I / D over the concatenated pieces; a leading or trailing I is printed as S
+ *          (src/LordFAST.cpp:1691-1708)
+ *   MD     <matches><mismatched reference base> ... ^<deleted reference bases> ...; an insertion breaks a deletion run
+ *          (src/LordFAST.cpp:1717-1760)
+ *
+ * Per 64-element tile the lanes classify their element, find run starts with one ballot, get the run lengths from
+ * the position of the previous set bit, and place their tokens with a wave prefix sum; only the open run, the match
+ * counter and the output cursors are carried from tile to tile.  The kernel runs twice: a counting pass (exact
+ * sizes -> one exclusive scan -> offsets), then the writing pass.  The edit paths never leave the device.
+ *
+ * Traffic per record: ops bytes read twice, text written once, a few 2-bit reference bases.
+ */
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include <string.h>
+#include <mutex>
+#include "lf_internal.h"
+#include "lf_gpu_common.h"
+
+struct lf_rrounds { const uint8_t *ops[LF_MAX_ED_ROUNDS]; };
+
+__device__ __forceinline__ int lf_ndigits(uint32_t v)
+{
+    return v < 10u ? 1 : v < 100u ? 2 : v < 1000u ? 3 : v < 10000u ? 4 : v < 100000u ? 5 : v < 1000000u ? 6
+         : v < 10000000u ? 7 : v < 100000000u ? 8 : v < 1000000000u ? 9 : 10;
+}
+/* decimal digits of v followed by up to two characters */
+__device__ __forceinline__ void lf_put_token(char *dst, uint32_t v, int nd, char c1, char c2)
+{
+    for (int k = nd - 1; k >= 0; k--) { dst[k] = (char)('0' + v % 10u); v /= 10u; }
+    dst[nd] = c1;
+    if (c2) dst[nd + 1] = c2;
+}
+__device__ __forceinline__ uint32_t lf_wave_excl_sum(uint32_t v, uint32_t *total)
+{
+    uint32_t x = v;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    *total = __shfl(x, 63, 64);
+    return x - v;
+}
+__device__ __forceinline__ char lf_pac_char(const uint8_t *pac, uint32_t pos, int comp)
+{
+    int b = (pac[pos >> 2] >> ((~pos & 3u) << 1)) & 3;
+    if (comp) b = 3 - b;
+    return "ACGT"[b];
+}
+
+/* element types */
+#define T_EQ 0
+#define T_X  1
+#define T_I  2
+#define T_D  3
+
+template <bool WRITE>
+__global__ void __launch_bounds__(64)
+lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_ritem_t *__restrict__ items, lf_rrounds R,
+                 const uint8_t *__restrict__ pac, uint32_t *__restrict__ lens /* 2 per record */,
+                 const uint64_t *__restrict__ offs /* 2 per record (WRITE) */, char *__restrict__ text)
+{
+    const int rec = blockIdx.x;
+    if (rec >= n_recs) return;
+    const int lane = threadIdx.x;
+    const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const lf_rrecord_t rr = recs[rec];
+    char *cg = WRITE ? text + offs[2 * rec] : nullptr, *md = WRITE ? text + offs[2 * rec + 1] : nullptr;
+    /* carried state (wave-uniform) */
+    int c_ch = 0; uint32_t c_run = 0; int c_first = 1; uint32_t c_out = 0;
+    uint32_t m_num = 0; int m_last = T_EQ; uint32_t m_out = 0;
+
+    /* close the open CIGAR run and open a new one (wave-uniform path, lane 0 writes) */
+    auto cigar_run = [&](int ch, uint32_t n) {
+        if (ch == c_ch) { c_run += n; return; }
+        if (c_ch) {
+            const int nd = lf_ndigits(c_run);
+            if (WRITE && lane == 0) lf_put_token(cg + c_out, c_run, nd, (c_first && c_ch == 'I') ? 'S' : (char)c_ch, 0);
+            c_out += nd + 1; c_first = 0;
+        }
+        c_ch = ch; c_run = n;
+    };
+
+    for (uint32_t it = 0; it < rr.nitems; it++) {
+        const lf_ritem_t I = items[rr.item0 + it];
+        if (I.n == 0) continue;
+        if (I.kind == LF_RI_RUN_M) { cigar_run('M', I.n); m_num += I.n; m_last = T_EQ; continue; }
+        if (I.kind == LF_RI_RUN_I) { cigar_run('I', I.n); m_last = T_I; continue; }
+        if (I.kind == LF_RI_DEL) {
+            cigar_run('D', I.n);
+            if (m_last != T_D) {
+                const int nd = lf_ndigits(m_num);
+                if (WRITE && lane == 0) lf_put_token(md + m_out, m_num, nd, '^', 0);
+                m_out += nd + 1; m_num = 0;
+            }
+            if (WRITE) for (uint32_t j = lane; j < I.n; j += 64) md[m_out + j] = lf_pac_char(pac, I.tpos + j, 0);
+            m_out += I.n; m_last = T_D;
+            continue;
+        }
+        /* an edit path: I.n ops at R.ops[round] + ops_begin, forward or reversed */
+        const uint8_t *ops = R.ops[I.round] + I.ops_begin;
+        const int rev = (I.kind == LF_RI_OPS_REV), trc = (I.kind == LF_RI_OPS_FWD_TRC);
+        uint32_t tcarry = 0;
+        for (uint32_t base = 0; base < I.n; base += 64) {
+            const uint32_t k = base + lane;
+            const bool act = k < I.n;
+            const uint32_t cnt = (I.n - base < 64u) ? I.n - base : 64u;
+            int ty = T_EQ;
+            if (act) { const uint8_t op = ops[rev ? I.n - 1 - k : k]; ty = op == 0 ? T_EQ : op == 1 ? T_I : op == 2 ? T_D : T_X; }
+            const int ch = !act ? 0 : (ty == T_I ? 'I' : ty == T_D ? 'D' : 'M');
+            /* ---- CIGAR ---- */
+            int pch = __shfl_up(ch, 1, 64); if (lane == 0) pch = c_ch;
+            const bool start = act && ch != pch;
+            const uint64_t smask = __ballot(start);
+            const bool emits = start && pch != 0;
+            const uint64_t emask = __ballot(emits);
+            uint32_t tlen = 0, rl = 0; int nd = 0;
+            if (emits) {
+                const uint64_t sb = smask & below;
+                rl = sb ? (uint32_t)(lane - (63 - __clzll((long long)sb))) : c_run + (uint32_t)lane;
+                nd = lf_ndigits(rl); tlen = (uint32_t)nd + 1;
+            }
+            uint32_t tot; const uint32_t pos = lf_wave_excl_sum(tlen, &tot);
+            if (WRITE && emits) lf_put_token(cg + c_out + pos, rl, nd, (c_first && !(emask & below) && pch == 'I') ? 'S' : (char)pch, 0);
+            c_out += tot;
+            if (emask) c_first = 0;
+            const int lastch = __shfl(ch, (int)cnt - 1, 64);
+            if (smask) c_run = cnt - (uint32_t)(63 - __clzll((long long)smask)); else c_run += cnt;
+            c_ch = lastch;
+            /* ---- MD ---- */
+            int pty = __shfl_up(ty, 1, 64); if (lane == 0) pty = m_last;
+            const bool isx = act && ty == T_X, isd = act && ty == T_D;
+            const bool flush = isx || (isd && pty != T_D);
+            const uint64_t eqmask = __ballot(act && ty == T_EQ), fmask = __ballot(flush), nimask = __ballot(act && ty != T_I);
+            uint32_t mlen = 0, num = 0; int mnd = 0; char bch = 0;
+            if (isx || isd) {
+                const uint32_t ti = tcarry + (uint32_t)__popcll(nimask & below);
+                bch = lf_pac_char(pac, trc ? I.tpos - ti : I.tpos + ti, trc);
+                if (flush) {
+                    const uint64_t fb = fmask & below;
+                    if (fb) { const int p = 63 - __clzll((long long)fb); num = (uint32_t)__popcll(eqmask & below & ~(~0ull >> (63 - p))); }
+                    else num = m_num + (uint32_t)__popcll(eqmask & below);
+                    mnd = lf_ndigits(num); mlen = (uint32_t)mnd + (isd ? 2u : 1u);
+                } else mlen = 1;
+            }
+            uint32_t mtot; const uint32_t mpos = lf_wave_excl_sum(mlen, &mtot);
+            if (WRITE && (isx || isd)) {
+                if (flush) lf_put_token(md + m_out + mpos, num, mnd, isd ? '^' : bch, isd ? bch : 0);
+                else md[m_out + mpos] = bch;
+            }
+            m_out += mtot;
+            if (fmask) { const int p = 63 - __clzll((long long)fmask); m_num = (uint32_t)__popcll(eqmask & ~(~0ull >> (63 - p))); }
+            else m_num += (uint32_t)__popcll(eqmask);
+            m_last = __shfl(ty, (int)cnt - 1, 64);
+            tcarry += (uint32_t)__popcll(nimask);
+        }
+    }
+    /* close the record (src/LordFAST.cpp:1704-1708, :1756-1760): the last CIGAR run (I -> S), the match counter */
+    if (c_ch) {
+        const int nd = lf_ndigits(c_run);
+        if (WRITE && lane == 0) lf_put_token(cg + c_out, c_run, nd, c_ch == 'I' ? 'S' : (char)c_ch, 0);
+        c_out += nd + 1;
+    }
+    {
+        const int nd = lf_ndigits(m_num);
+        if (WRITE && lane == 0) { lf_put_token(md + m_out, m_num, nd, 0, 0); cg[c_out] = 0; }
+        m_out += nd;
+    }
+    if (!WRITE && lane == 0) { lens[2 * rec] = c_out + 1; lens[2 * rec + 1] = m_out + 1; }      /* + NUL */
+}
+
+struct lf_widen32 { __host__ __device__ uint64_t operator()(uint32_t v) const { return v; } };
+
+/* host entry: items / records in (pinned) host memory; rounds[r] = device address of round r's ops (or NULL);
+ * text comes back in a pinned slot, offs[2*rec], offs[2*rec+1] = start of the record's CIGAR / MD (NUL-terminated). */
+extern "C" int lfg_render(const struct lf_index *ix, int n_recs, const lf_rrecord_t *recs, uint64_t n_items, const lf_ritem_t *items,
+                          const void *const *round_ops, char **text_out, uint64_t **offs_out, uint64_t *text_bytes, float *ms)
+{
+    if (ms) *ms = 0;
+    *text_out = nullptr; *offs_out = nullptr; *text_bytes = 0;
+    if (n_recs == 0) return LF_OK;
+    lf_dev_state *st = (lf_dev_state *)ix->dev;
+    if (!st) { lf_set_error("index is not on a device"); return LF_ERR_NO_DEVICE; }
+    const int device = ix->device;
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
+    if (!s) return LF_ERR_HIP;
+    lf_rrecord_t *d_recs = (lf_rrecord_t *)lfg_dev_slot(device, LF_DS_RENDER0 + 0, (size_t)n_recs * sizeof(lf_rrecord_t));
+    lf_ritem_t *d_items = (lf_ritem_t *)lfg_dev_slot(device, LF_DS_RENDER0 + 1, (size_t)n_items * sizeof(lf_ritem_t) + 64);
+    uint32_t *d_lens = (uint32_t *)lfg_dev_slot(device, LF_DS_RENDER0 + 2, (size_t)n_recs * 8);
+    uint64_t *d_offs = (uint64_t *)lfg_dev_slot(device, LF_DS_RENDER0 + 3, (size_t)n_recs * 16 + 16);
+    uint64_t *h_offs = (uint64_t *)lfg_pin_slot(LF_PS_RENDER0 + 0, (size_t)n_recs * 16 + 16);
+    uint32_t *h_tail = (uint32_t *)lfg_pin_slot(LF_PS_RENDER0 + 1, 64);
+    if (!d_recs || !d_items || !d_lens || !d_offs || !h_offs || !h_tail) return LF_ERR_NOMEM;
+    size_t tb = 0;
+    hipcub::TransformInputIterator<uint64_t, lf_widen32, uint32_t *> in(d_lens, lf_widen32());
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, d_offs, 2 * n_recs, s);
+    void *d_tmp = lfg_dev_slot(device, LF_DS_RENDER0 + 4, tb + 256);
+    if (!d_tmp) return LF_ERR_NOMEM;
+    lf_rrounds R;
+    for (int r = 0; r < LF_MAX_ED_ROUNDS; r++) R.ops[r] = (const uint8_t *)round_ops[r];
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipMemcpyAsync(d_recs, recs, (size_t)n_recs * sizeof(lf_rrecord_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_items, items, (size_t)n_items * sizeof(lf_ritem_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(lf_render_kernel<false>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac,
+                       d_lens, (const uint64_t *)nullptr, (char *)nullptr);
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, in, d_offs, 2 * n_recs, s));
+    HIPCHK(hipMemcpyAsync(h_offs, d_offs, (size_t)n_recs * 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_tail, d_lens + 2 * (size_t)n_recs - 1, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const uint64_t total = h_offs[2 * (size_t)n_recs - 1] + h_tail[0];
+    char *d_text = (char *)lfg_dev_slot(device, LF_DS_RENDER0 + 5, total + 64);
+    char *h_text = (char *)lfg_pin_slot(LF_PS_RENDER0 + 2, total + 64);
+    if (!d_text || !h_text) return LF_ERR_NOMEM;
+    hipLaunchKernelGGL(lf_render_kernel<true>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac,
+                       d_lens, (const uint64_t *)d_offs, d_text);
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipMemcpyAsync(h_text, d_text, total, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *text_out = h_text; *offs_out = h_offs; *text_bytes = total;
+    return LF_OK;
+}
+
+/* small synchronous device -> host copy (rare per-base fallback of the chain walk) */
+extern "C" int lfg_fetch(int device, void *dst, const void *src_dev, size_t bytes)
+{
+    /* called from pool workers: own non-blocking stream, so that the copy does not serialise with the lanes' kernels */
+    static std::mutex mu; static hipStream_t fs[16];
+    if (device < 0 || device >= 16) return LF_ERR_ARG;
+    std::lock_guard<std::mutex> g(mu);
+    HIPCHK(hipSetDevice(device));
+    if (!fs[device]) HIPCHK(hipStreamCreateWithFlags(&fs[device], hipStreamNonBlocking));
+    HIPCHK(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, fs[device]));
+    HIPCHK(hipStreamSynchronize(fs[device]));
+    return LF_OK;
+}
+extern "C" int lfg_upload(int device, void *dst_dev, const void *src, size_t bytes)
+{
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
+    if (!s) return LF_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return LF_OK;
+}

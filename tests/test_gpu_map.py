@@ -42,6 +42,22 @@ def test_sam_golden(lf, golden_reads, cfg):
     assert st["n_ksw_problems"] > 0, "fixture must reach the ksw clip/split branch"
 
 
+def test_sam_host_cigar_crosscheck(lf, golden_reads, monkeypatch):
+    """LF_HOST_CIGAR=1 builds CIGAR / MD on the host from copied-back edit paths instead of lf_render_kernel: both
+    must print the reference's records"""
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    monkeypatch.setenv("LF_HOST_CIGAR", "1")
+    sam, st = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS["default"]))
+    assert st["render_launches"] == 0
+    exp = golden_sam("default")
+    assert sam == exp, first_diff(sam, exp)
+    monkeypatch.delenv("LF_HOST_CIGAR")
+    sam, st = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS["default"]))
+    assert st["render_launches"] >= 1 and st["render_bytes"] > 0
+    assert sam == exp, first_diff(sam, exp)
+
+
 def test_map_batch_into_caller_buffer(lf, golden_reads):
     """lf_map_batch_into: same records into a caller-owned buffer; a buffer that is too small is an error, not a truncation"""
     import ctypes as C
