@@ -73,7 +73,8 @@ static void *ar_grow(arena_t *a, void *old, size_t old_bytes, size_t new_bytes)
     return p;
 }
 static void ar_reset(arena_t *a) { a->cur = 0; a->off = 0; }
-static arena_t g_arena[2][258];          /* [lane][worker]; blocks are kept across chunks and batches */
+#define LF_MAX_LANES 4
+static arena_t g_arena[LF_MAX_LANES][260];          /* [lane][worker]; blocks are kept across chunks and batches */
 
 /* mode 0: owned, growable, NUL-terminated; mode 1: count only (nothing is written); mode 2: fixed external window;
  * mode 3: growable inside an arena (never freed individually) */
@@ -251,11 +252,11 @@ typedef void (*pf_fn)(ctx_t *cx, int tid, int i);
 typedef struct { pf_fn fn; ctx_t *cx; int n, grain; volatile int next; int active, inflight; int timed; volatile long long cpu_ns; } pjob_t;
 typedef struct {
     pthread_t th[256]; int nw, started, stop;
-    pthread_mutex_t mu; pthread_cond_t cv_work, cv_done[2];
-    pjob_t job[2];
+    pthread_mutex_t mu; pthread_cond_t cv_work, cv_done[LF_MAX_LANES];
+    pjob_t job[LF_MAX_LANES];
 } pool_t;
 static pool_t g_pool = { .mu = PTHREAD_MUTEX_INITIALIZER, .cv_work = PTHREAD_COND_INITIALIZER,
-                         .cv_done = { PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER } };
+                         .cv_done = { PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER } };
 
 /* LF_TIMING=1: per-phase CPU time (summed over workers) and wall time, printed at the end of each batch */
 static struct { const char *name; double cpu_ms, wall_ms; long calls; } g_phase[32];
@@ -305,7 +306,7 @@ static void *pool_worker(void *arg)
     pthread_mutex_lock(&P->mu);
     for (;;) {
         int pick = -1;
-        for (int k = 0; k < 2; k++) { const int j = (tid + k) & 1; if (P->job[j].active && P->job[j].next < P->job[j].n) { pick = j; break; } }
+        for (int k = 0; k < LF_MAX_LANES; k++) { const int j = (tid + k) % LF_MAX_LANES; if (P->job[j].active && P->job[j].next < P->job[j].n) { pick = j; break; } }
         if (pick >= 0) {
             pjob_t *J = &P->job[pick];
             J->inflight++;
@@ -1434,7 +1435,8 @@ static int map_chunk(ctx_t *cx)
         free(map); cx->seed_map = NULL;
         cx->hits = &hits;
     }
-    t1 = now_ms(); st->ms_seed += t1 - t0; t0 = t1;
+    double tstage[8] = { 0 };
+    t1 = now_ms(); st->ms_seed += t1 - t0; tstage[0] = t1 - t0; t0 = t1;
 
     /* ---- B: vote + chain requests ---- */
     cx->cstage = (cstage_t *)calloc((size_t)nt, sizeof(cstage_t));
@@ -1460,7 +1462,7 @@ static int map_chunk(ctx_t *cx)
         for (int t = 0; t < nt; t++) { free(cx->cstage[t].v); free(cx->cstage[t].s); free(cx->cstage[t].wbuf); free(cx->cstage[t].wbuf2); }
         free(cx->cstage); cx->cstage = NULL;
     }
-    t1 = now_ms(); st->ms_vote += t1 - t0; t0 = t1;
+    t1 = now_ms(); st->ms_vote += t1 - t0; tstage[1] = t1 - t0; t0 = t1;
 
     /* ---- C: chains ---- */
     {
@@ -1478,7 +1480,7 @@ static int map_chunk(ctx_t *cx)
     }
     parallel_for(cx, n, phase_fine_select);
     parallel_for(cx, n, phase_make_jobs);
-    t1 = now_ms(); st->ms_chain += t1 - t0; t0 = t1;
+    t1 = now_ms(); st->ms_chain += t1 - t0; tstage[2] = t1 - t0; t0 = t1;
 
     /* ---- D: extension rounds ---- */
     cx->stages = (stage_t *)calloc((size_t)nt, sizeof(stage_t));
@@ -1599,7 +1601,7 @@ static int map_chunk(ctx_t *cx)
             st->ms_k_ksw += ms; st->n_ksw_problems += (uint64_t)nk;
         }
     }
-    t1 = now_ms(); st->ms_extend += t1 - t0; t0 = t1;
+    t1 = now_ms(); st->ms_extend += t1 - t0; tstage[3] = t1 - t0; t0 = t1;
 
     /* ---- D': CIGAR / MD text of every record, rendered on the GPU from the paths in HBM ---- */
     if (!cx->host_cigar) {
@@ -1639,13 +1641,15 @@ static int map_chunk(ctx_t *cx)
         }
         free(ibase);
     }
-    t1 = now_ms(); st->ms_render += t1 - t0; t0 = t1;
+    t1 = now_ms(); st->ms_render += t1 - t0; tstage[4] = t1 - t0; t0 = t1;
 
     /* ---- E: SAM (score + count here; the text is written by lf_map_batch straight into the output buffer) ---- */
     parallel_for(cx, n, phase_sam_score);
     cx->out_base = NULL;
     parallel_for(cx, n, phase_sam_print);
-    t1 = now_ms(); st->ms_sam += t1 - t0;
+    t1 = now_ms(); st->ms_sam += t1 - t0; tstage[5] = t1 - t0;
+    if (timing) fprintf(stderr, "[lf] lane %d chunk of %d reads: seed %.1f vote %.1f chain %.1f extend %.1f render %.1f sam-count %.1f ms (t=%.1f)\n",
+                        cx->lane, n, tstage[0], tstage[1], tstage[2], tstage[3], tstage[4], tstage[5], now_ms());
     return LF_OK;
 }
 
@@ -1685,7 +1689,7 @@ typedef struct {
     pthread_rwlock_t grow;                      /* writers of SAM text hold it shared; growing the buffer exclusive */
     int host_cigar; str_t all; int fixed_out;                   /* fixed_out: caller-provided buffer, never reallocated */
     volatile int rc; char err[1024];
-    lf_stats_t st[2];
+    lf_stats_t st[LF_MAX_LANES];
 } batch_t;
 
 static void merge_stats(lf_stats_t *d, const lf_stats_t *a)
@@ -1801,13 +1805,16 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
     const double T0 = now_ms();
     pthread_mutex_lock(&g_map_lock);
     g_phase_on = getenv("LF_PHASES") != NULL;
-    const int n_lanes = (nt >= 3 && !getenv("LF_ONE_LANE")) ? 2 : 1;
+    /* chunks in flight: the host phases of one overlap the GPU phases of the others */
+    int n_lanes = nt >= 8 ? 3 : (nt >= 3 ? 2 : 1);
+    if (getenv("LF_LANES")) { n_lanes = atoi(getenv("LF_LANES")); if (n_lanes < 1) n_lanes = 1; if (n_lanes > LF_MAX_LANES) n_lanes = LF_MAX_LANES; if (n_lanes > 1 && nt < n_lanes + 1) n_lanes = 1; }
+    if (getenv("LF_ONE_LANE")) n_lanes = 1;
     const int nw = nt - n_lanes;                       /* pool workers; the lane drivers work too */
     pool_ensure(nw);
 
     batch_t B; memset(&B, 0, sizeof B);
     B.host_cigar = getenv("LF_HOST_CIGAR") != NULL;
-    B.ix = ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + 2; B.rc = LF_OK;
+    B.ix = ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + n_lanes; B.rc = LF_OK;
     pthread_mutex_init(&B.mu, NULL); pthread_cond_init(&B.cv, NULL); pthread_rwlock_init(&B.grow, NULL);
     if (ext_buf) { B.all.s = ext_buf; B.all.cap = ext_cap; B.all.n = 0; B.all.mode = 2; B.fixed_out = 1; }
     else str_init(&B.all);
@@ -1815,7 +1822,7 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
     B.lens = lens;
     {   /* read lengths once, in parallel; one allocation for the SAM text (~2 x bases + per-record overhead) */
         ctx_t c0; memset(&c0, 0, sizeof c0);
-        c0.n_threads = nw + 2; c0.lane = 0; c0.len_seqs = seqs; c0.len_out = lens;
+        c0.n_threads = nw + n_lanes; c0.lane = 0; c0.len_seqs = seqs; c0.len_out = lens;
         parallel_for(&c0, n, phase_strlen);
         uint64_t est = 4096;
         for (int i = 0; i < n; i++) est += 2 * (uint64_t)lens[i] + 640;
@@ -1826,8 +1833,8 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
     const uint64_t CHUNK_BASES = 400ull << 20;
     int CHUNK_READS = 32768;
     if (getenv("LF_CHUNK_READS")) { CHUNK_READS = atoi(getenv("LF_CHUNK_READS")); if (CHUNK_READS < 1) CHUNK_READS = 1; }   /* test hook */
-    else if (n_lanes == 2 && n > 2048) {               /* at least ~4 chunks so that the two lanes interleave */
-        int want = (n + 3) / 4; if (want < 1024) want = 1024;
+    else if (n_lanes >= 2 && n > 2048) {               /* at least two chunks per lane so that the lanes interleave */
+        int want = (n + 2 * n_lanes - 1) / (2 * n_lanes); if (want < 1024) want = 1024;
         if (want < CHUNK_READS) CHUNK_READS = want;
     }
     B.chunks = (chunk_t *)calloc((size_t)n + 1, sizeof(chunk_t));
@@ -1837,18 +1844,18 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
         B.chunks[B.n_chunks].i0 = i0; B.chunks[B.n_chunks].i1 = i1; B.n_chunks++;
         i0 = i1;
     }
-    void *a0[2] = { &B, (void *)(intptr_t)0 }, *a1[2] = { &B, (void *)(intptr_t)1 };
-    pthread_t t1; int have_t1 = 0;
-    if (n_lanes == 2 && B.n_chunks > 1) { have_t1 = pthread_create(&t1, NULL, lane_main, a1) == 0; }
-    lane_main(a0);
-    if (have_t1) pthread_join(t1, NULL);
+    void *la[LF_MAX_LANES][2]; pthread_t lt[LF_MAX_LANES]; int have[LF_MAX_LANES] = { 0 };
+    for (int l = 0; l < LF_MAX_LANES; l++) { la[l][0] = &B; la[l][1] = (void *)(intptr_t)l; }
+    for (int l = 1; l < n_lanes && l < B.n_chunks; l++) have[l] = pthread_create(&lt[l], NULL, lane_main, la[l]) == 0;
+    lane_main(la[0]);
+    for (int l = 1; l < n_lanes; l++) if (have[l]) pthread_join(lt[l], NULL);
     lfg_set_lane(0);
     if (g_phase_on) { fprintf(stderr, "[lf] batch of %d reads: %.1f ms wall, %d threads\n", n, now_ms() - T0, nt); phase_report(); }
     pthread_mutex_unlock(&g_map_lock);
 
     uint64_t total = 0;
     for (int k = 0; k < B.n_chunks; k++) total += B.chunks[k].size;
-    merge_stats(st, &B.st[0]); merge_stats(st, &B.st[1]);
+    for (int l = 0; l < LF_MAX_LANES; l++) merge_stats(st, &B.st[l]);
     free(lens); free(B.chunks);
     pthread_mutex_destroy(&B.mu); pthread_cond_destroy(&B.cv); pthread_rwlock_destroy(&B.grow);
     st->ms_total = now_ms() - T0;
