@@ -149,7 +149,7 @@ typedef struct {
     uint64_t ext_bytes;                                /* sum over problems (q + ceil(t/4) + q + t) */
     uint64_t edlib_launches, search_launches, locate_launches;
     /* CIGAR / MD rendering (lf_render_kernel): wall, HIP events, text bytes written, launches */
-    double ms_render; float ms_k_render, pad_; uint64_t render_bytes, render_launches;
+    double ms_render; float ms_k_render, ms_k_vote; uint64_t render_bytes, render_launches;
 } lf_stats_t;
 
 int  lf_map_batch(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,

@@ -51,7 +51,7 @@ class Stats(C.Structure):
                [(n, C.c_uint64) for n in ("n_reads", "n_bases", "n_seeds", "n_chain_problems", "n_edlib_problems",
                                           "n_ksw_problems", "n_cache", "n_occblk", "n_sa", "n_readbytes", "ext_bytes",
                                           "edlib_launches", "search_launches", "locate_launches")] + \
-               [("ms_render", C.c_double), ("ms_k_render", C.c_float), ("pad_", C.c_float),
+               [("ms_render", C.c_double), ("ms_k_render", C.c_float), ("ms_k_vote", C.c_float),
                 ("render_bytes", C.c_uint64), ("render_launches", C.c_uint64)]
 
     def as_dict(self):

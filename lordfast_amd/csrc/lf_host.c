@@ -162,7 +162,7 @@ int lf_seed_batch(const lf_index_t *ix, const lf_params_t *p, int n_reads, const
         return LF_OK;
     }
     lfg_hits_t h;
-    int rc = lfg_seed(ix, p, n_reads, reads, off, &h);
+    int rc = lfg_seed(ix, p, n_reads, reads, off, 1, &h);
     if (rc != LF_OK) return rc;
     lf_seeds_t *s = (lf_seeds_t *)calloc(1, sizeof *s);
     s->n_reads = n_reads;

@@ -43,8 +43,22 @@ typedef struct {        /* raw device results of the seed stage, copied to host 
     float ms_search, ms_accept, ms_locate;
 } lfg_hits_t;
 
+/* want_hits == 0: the hits stay in HBM for lfg_vote_chain (out gets n_hits, read_off and the counters only) */
 int  lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads,
-              const uint64_t *off, lfg_hits_t *out);
+              const uint64_t *off, int want_hits, lfg_hits_t *out);
+
+/* ---- lf_vote.hip: votes -> candidate windows -> chains, on the hits that lfg_seed left in HBM ---- */
+typedef struct {
+    int n_reads, n_req;
+    uint8_t *mode;            /* per read: 1 no window, 2 coarse (one request), 3 fine (nreq candidate requests) */
+    uint64_t *req0;           /* n_reads + 1: first request of each read */
+    uint32_t *nreq; float *vscore;
+    uint32_t *req_win;        /* per request: window id | isReverse << 31 */
+    uint32_t *chain_len; float *chain_score; uint64_t *chain_off; Seed_t *chain_seeds;
+    uint64_t n_req_seeds, n_chain_seeds;
+    float ms_vote, ms_chain;
+} lfg_vc_t;
+int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, int n_reads, uint64_t n_hits, uint32_t max_read_len, lfg_vc_t *out);
 void lfg_hits_free(lfg_hits_t *h);
 
 int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, const Seed_t *sorted_seeds,
@@ -69,11 +83,11 @@ int   lfg_get_lane(void);
 void *lfg_lane_stream(int device, int which);   /* persistent hipStream_t of the calling thread's lane */
 /* slot ids */
 enum { LF_DS_SEED0 = 0 /* ..15 */, LF_DS_CHAIN0 = 16 /* ..23 */, LF_DS_ALN0 = 24 /* ..47 */, LF_DS_KSW0 = 48 /* ..55 */,
-       LF_DS_RND0 = 56 /* ..87: 2 per extension round (ops, spare) */, LF_DS_RENDER0 = 88 /* ..95 */ };
+       LF_DS_RND0 = 56 /* ..87: 2 per extension round (ops, spare) */, LF_DS_RENDER0 = 88 /* ..95 */, LF_DS_VOTE0 = 96 /* ..127 */ };
 #define LF_MAX_ED_ROUNDS 16
 enum { LF_PS_READS = 0, LF_PS_READOFF = 1, LF_PS_HITS_T = 2, LF_PS_HITS_Q = 3, LF_PS_HITS_S = 4, LF_PS_HITS_OFF = 5,
        LF_PS_CHAIN_SEEDS = 6, LF_PS_CHAIN_IDX = 7, LF_PS_ALN_Q = 8, LF_PS_ALN_T = 9, LF_PS_ALN_PROB = 10 /* ..16 */,
-       LF_PS_ROUND0 = 20 /* 4 per round: ed, end, len, ops ; up to 16 rounds */, LF_PS_RENDER0 = 84 /* ..91 */ };
+       LF_PS_ROUND0 = 20 /* 4 per round: ed, end, len, ops ; up to 16 rounds */, LF_PS_RENDER0 = 84 /* ..91 */, LF_PS_VOTE0 = 92 /* ..107 */ };
 
 /* alignment request as a DESCRIPTOR into HBM-resident data: query = the read batch uploaded by the seed stage,
  * target = the 2-bit reference.  Element i = base[start +/- i], optionally complemented (flags LF_F_*). */

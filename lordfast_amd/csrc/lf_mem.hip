@@ -8,7 +8,7 @@
 
 namespace {
 struct slot_t { void *p = nullptr; size_t cap = 0; };
-constexpr int MAX_DEV = 16, MAX_SLOT = 512, LANE_STRIDE = 112, MAX_LANE = 4;
+constexpr int MAX_DEV = 16, MAX_SLOT = 640, LANE_STRIDE = 160, MAX_LANE = 4;
 thread_local int t_lane = 0;
 hipStream_t g_streams[MAX_DEV][MAX_LANE][16];
 slot_t g_dev[MAX_DEV][MAX_SLOT];

@@ -236,6 +236,8 @@ typedef struct ctx {
     const lfg_hits_t *hits;
     /* scratch for the parallel merge of staged alignment requests */
     lf_aln_desc_t *mg_desc; char *mg_qb, *mg_tb; uint64_t *mg_qoff, *mg_toff, *mg_qbase, *mg_tbase; uint8_t *mg_mode; int *mg_gbase; ed_round_t *mg_R; int mg_round;
+    int host_vote;                  /* LF_HOST_VOTE=1: vote / select / sort on the host from copied-back hits (cross-check) */
+    lfg_vc_t vc;                    /* device path: modes, requests and chains of this chunk */
     int host_cigar;                 /* LF_HOST_CIGAR=1: build CIGAR / MD on the host from copied-back paths (cross-check) */
     char *rtext; uint64_t *roffs; int *rrbase;      /* rendered text, per-record offsets, first record of each worker */
     /* output assembly */
@@ -534,6 +536,37 @@ static void phase_vote(ctx_t *cx, int tid, int ri)
                     r->ncand++;
                 }
             }
+        }
+    }
+}
+
+/* device path: the read's mode, windows and fine-mode candidates as lf_vote_select_kernel decided them */
+static void phase_select(ctx_t *cx, int tid, int ri)
+{
+    rd_t *r = &cx->reads[ri];
+    const lf_params_t *p = cx->p;
+    r->vote_tid = tid;
+    if ((int)r->len < p->min_read_len) { r->mode = 0; return; }
+    const lfg_vc_t *vc = &cx->vc;
+    const int k = r->seed_idx;
+    const uint32_t L = r->len;
+    r->wins = (win_t *)ar_zalloc(&cx->arena[tid], ((size_t)p->max_map + 1) * sizeof(win_t));
+    r->nWins = 0;
+    r->mode = vc->mode[k];
+    if (r->mode == 2) {
+        const int rq = (int)vc->req0[k];
+        const uint32_t w = vc->req_win[rq], id = w & 0x7fffffffu;
+        win_t *b = &r->wins[0];
+        b->tStart = id * L; b->tEnd = (id + 2) * L - 1; b->score = vc->vscore[k]; b->isReverse = (uint8_t)(w >> 31); b->req = rq;
+        r->nWins = 1;
+    } else if (r->mode == 3) {
+        const uint32_t nc = vc->nreq[k];
+        r->cands = (struct cand *)ar_alloc(&cx->arena[tid], ((size_t)nc + 1) * sizeof(struct cand));
+        r->ncand = (int)nc; r->capcand = (int)nc + 1;
+        for (uint32_t c = 0; c < nc; c++) {
+            const int rq = (int)(vc->req0[k] + c);
+            const uint32_t w = vc->req_win[rq];
+            r->cands[c].win = w & 0x7fffffffu; r->cands[c].isRev = (uint8_t)(w >> 31); r->cands[c].req = rq;
         }
     }
 }
@@ -1310,8 +1343,11 @@ static void phase_make_jobs(ctx_t *cx, int tid, int ri)
         j->read = ri; j->widx = w; j->isRev = r->wins[w].isReverse;
         j->chainLen = cx->chain_len[rq];
         j->chain = (Seed_t *)ar_alloc(&cx->arena[tid], ((size_t)j->chainLen + 1) * sizeof(Seed_t));
-        const creq_t *cq = &cx->creq[rq];
-        for (uint32_t k = 0; k < j->chainLen; k++) j->chain[k] = cx->cseeds[cq->off + cx->chain_idx[cq->off + k]];
+        if (!cx->host_vote) memcpy(j->chain, cx->vc.chain_seeds + cx->vc.chain_off[rq], (size_t)j->chainLen * sizeof(Seed_t));
+        else {
+            const creq_t *cq = &cx->creq[rq];
+            for (uint32_t k = 0; k < j->chainLen; k++) j->chain[k] = cx->cseeds[cq->off + cx->chain_idx[cq->off + k]];
+        }
         j->complete = (j->chainLen <= 1);                   /* nothing to extend: totalScore = -2L (:1089) */
     }
 }
@@ -1403,6 +1439,7 @@ static int map_chunk(ctx_t *cx)
     lf_stats_t *st = cx->st;
     int rc = LF_OK;
     double t0 = now_ms(), t1;
+    const int timing = getenv("LF_TIMING") != NULL, timing0 = timing;
 
     parallel_for(cx, n, phase_prepare);
     if (getenv("LF_TIMING")) fprintf(stderr, "[lf] prepare %.1f ms\n", now_ms() - t0);
@@ -1425,7 +1462,7 @@ static int map_chunk(ctx_t *cx)
             parallel_for(cx, m, phase_concat);
             if (getenv("LF_TIMING")) fprintf(stderr, "[lf] concat %.1f ms\n", now_ms() - tc0);
             tc0 = now_ms();
-            rc = lfg_seed(cx->ix, cx->p, m, cat, off, &hits);
+            rc = lfg_seed(cx->ix, cx->p, m, cat, off, cx->host_vote, &hits);
             if (getenv("LF_TIMING")) fprintf(stderr, "[lf] lfg_seed %.1f ms (search %.1f locate %.1f), %llu hits\n", now_ms() - tc0, hits.ms_search, hits.ms_locate, (unsigned long long)hits.n_hits);
             if (rc != LF_OK) { free(map); return rc; }
             st->n_seeds += hits.n_hits; st->n_cache += hits.counters[0]; st->n_occblk += hits.counters[1]; st->n_sa += hits.counters[2]; st->n_readbytes += hits.counters[3];
@@ -1438,6 +1475,25 @@ static int map_chunk(ctx_t *cx)
     double tstage[8] = { 0 };
     t1 = now_ms(); st->ms_seed += t1 - t0; tstage[0] = t1 - t0; t0 = t1;
 
+    if (!cx->host_vote) {
+        /* ---- B + C on the device: votes -> candidate windows -> sorted requests -> chains; only chains come back ---- */
+        uint32_t max_len = 0;
+        for (int i = 0; i < n; i++) if (cx->reads[i].len > max_len) max_len = cx->reads[i].len;
+        int m = 0;
+        for (int i = 0; i < n; i++) if ((int)cx->reads[i].len >= cx->p->min_read_len) m++;
+        rc = lfg_vote_chain(cx->ix, cx->p, m, hits.n_hits, max_len, &cx->vc);
+        if (timing0) fprintf(stderr, "[lf] lfg_vote_chain %.1f ms (vote %.1f chain %.1f), %d requests, %llu request seeds, %llu chain seeds\n", now_ms() - t0,
+                             cx->vc.ms_vote, cx->vc.ms_chain, cx->vc.n_req, (unsigned long long)cx->vc.n_req_seeds, (unsigned long long)cx->vc.n_chain_seeds);
+        if (rc != LF_OK) return rc;
+        cx->n_creq = cx->vc.n_req; cx->chain_len = cx->vc.chain_len; cx->chain_score = cx->vc.chain_score;
+        st->ms_k_vote += cx->vc.ms_vote; st->ms_k_chain += cx->vc.ms_chain; st->n_chain_problems += (uint64_t)cx->vc.n_req;
+        parallel_for(cx, n, phase_select);
+        t1 = now_ms(); st->ms_vote += t1 - t0; tstage[1] = t1 - t0; t0 = t1;
+        parallel_for(cx, n, phase_fine_select);
+        parallel_for(cx, n, phase_make_jobs);
+        t1 = now_ms(); st->ms_chain += t1 - t0; tstage[2] = t1 - t0; t0 = t1;
+        goto extend;
+    }
     /* ---- B: vote + chain requests ---- */
     cx->cstage = (cstage_t *)calloc((size_t)nt, sizeof(cstage_t));
     parallel_for(cx, n, phase_vote);
@@ -1482,12 +1538,12 @@ static int map_chunk(ctx_t *cx)
     parallel_for(cx, n, phase_make_jobs);
     t1 = now_ms(); st->ms_chain += t1 - t0; tstage[2] = t1 - t0; t0 = t1;
 
+extend:
     /* ---- D: extension rounds ---- */
     cx->stages = (stage_t *)calloc((size_t)nt, sizeof(stage_t));
     cx->ed_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
     cx->ksw_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
     cx->edd_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
-    const int timing = getenv("LF_TIMING") != NULL;
     for (int round = 0; round < 64; round++) {
         double tw0 = now_ms();
         parallel_for(cx, n, phase_walk);
@@ -1656,7 +1712,8 @@ static int map_chunk(ctx_t *cx)
 static void chunk_free(ctx_t *cx)
 {
     for (int t = 0; t < cx->n_threads; t++) ar_reset(&cx->arena[t]);      /* every per-read object at once */
-    free(cx->creq); free(cx->cseeds); free(cx->chain_idx); free(cx->chain_len); free(cx->chain_score);
+    free(cx->creq); free(cx->cseeds); free(cx->chain_idx);
+    if (cx->host_vote) { free(cx->chain_len); free(cx->chain_score); }          /* device path: pinned slots of lfg_vote_chain */
     for (int k = 0; k < cx->n_ed_rounds; k++) { ed_round_t *R = &cx->ed_rounds[k]; if (!R->pinned) { free(R->ed); free(R->end); free(R->ops_len); free(R->ops); } free(R->ops_off); }
     for (int k = 0; k < cx->n_ksw_rounds; k++) { ksw_round_t *R = &cx->ksw_rounds[k]; free(R->score); free(R->qle); free(R->tle); }
     free(cx->ed_rounds); free(cx->ksw_rounds);
@@ -1687,7 +1744,7 @@ typedef struct {
     chunk_t *chunks; int n_chunks; volatile int next_chunk;
     pthread_mutex_t mu; pthread_cond_t cv;      /* chunk sizes become known in any order */
     pthread_rwlock_t grow;                      /* writers of SAM text hold it shared; growing the buffer exclusive */
-    int host_cigar; str_t all; int fixed_out;                   /* fixed_out: caller-provided buffer, never reallocated */
+    int host_cigar, host_vote; str_t all; int fixed_out;                   /* fixed_out: caller-provided buffer, never reallocated */
     volatile int rc; char err[1024];
     lf_stats_t st[LF_MAX_LANES];
 } batch_t;
@@ -1701,7 +1758,7 @@ static void merge_stats(lf_stats_t *d, const lf_stats_t *a)
     d->n_edlib_problems += a->n_edlib_problems; d->n_ksw_problems += a->n_ksw_problems; d->n_cache += a->n_cache; d->n_occblk += a->n_occblk;
     d->n_sa += a->n_sa; d->n_readbytes += a->n_readbytes; d->ext_bytes += a->ext_bytes; d->edlib_launches += a->edlib_launches;
     d->search_launches += a->search_launches; d->locate_launches += a->locate_launches;
-    d->ms_render += a->ms_render; d->ms_k_render += a->ms_k_render; d->render_bytes += a->render_bytes; d->render_launches += a->render_launches;
+    d->ms_render += a->ms_render; d->ms_k_render += a->ms_k_render; d->ms_k_vote += a->ms_k_vote; d->render_bytes += a->render_bytes; d->render_launches += a->render_launches;
 }
 
 static void *lane_main(void *arg_)
@@ -1716,7 +1773,7 @@ static void *lane_main(void *arg_)
         if (k >= B->n_chunks || B->rc != LF_OK) break;
         chunk_t *C = &B->chunks[k];
         ctx_t cx; memset(&cx, 0, sizeof cx);
-        cx.ix = B->ix; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane]; cx.host_cigar = B->host_cigar;
+        cx.ix = B->ix; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane]; cx.host_cigar = B->host_cigar; cx.host_vote = B->host_vote;
         cx.n_reads = C->i1 - C->i0;
         cx.reads = (rd_t *)calloc((size_t)cx.n_reads, sizeof(rd_t));
         for (int i = C->i0; i < C->i1; i++) {
@@ -1814,6 +1871,7 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
 
     batch_t B; memset(&B, 0, sizeof B);
     B.host_cigar = getenv("LF_HOST_CIGAR") != NULL;
+    B.host_vote = getenv("LF_HOST_VOTE") != NULL || p->max_map > 64;     /* the selection kernel keeps the top-N heap in 64 LDS slots */
     B.ix = ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + n_lanes; B.rc = LF_OK;
     pthread_mutex_init(&B.mu, NULL); pthread_cond_init(&B.cv, NULL); pthread_rwlock_init(&B.grow, NULL);
     if (ext_buf) { B.all.s = ext_buf; B.all.cap = ext_cap; B.all.n = 0; B.all.mode = 2; B.fixed_out = 1; }

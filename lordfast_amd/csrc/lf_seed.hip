@@ -274,7 +274,7 @@ __global__ void lf_read_first_hit_kernel(int n_reads, uint32_t hash_count, const
 }
 
 extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads,
-                        const uint64_t *off, lfg_hits_t *out)
+                        const uint64_t *off, int want_hits, lfg_hits_t *out)
 {
     memset(out, 0, sizeof(*out));
     lf_dev_state *st = (lf_dev_state *)ix->dev;
@@ -339,14 +339,16 @@ extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_r
 
     /* results land in pinned host slots (valid until the next lfg_seed call) */
     out->n_hits = n_hits;
-    out->tpos = (uint32_t *)lfg_pin_slot(LF_PS_HITS_T, (n_hits + 1) * 4);
-    out->qpl = (uint32_t *)lfg_pin_slot(LF_PS_HITS_Q, (n_hits + 1) * 4);
-    out->strand = (uint8_t *)lfg_pin_slot(LF_PS_HITS_S, n_hits + 1);
     out->read_off = h_nhits;
-    if (!out->tpos || !out->qpl || !out->strand) return LF_ERR_NOMEM;
-    HIPCHK(hipMemcpyAsync(out->tpos, d_tpos, n_hits * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out->qpl, d_qpl, n_hits * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out->strand, d_strand, n_hits, hipMemcpyDeviceToHost, s));
+    if (want_hits) {
+        out->tpos = (uint32_t *)lfg_pin_slot(LF_PS_HITS_T, (n_hits + 1) * 4);
+        out->qpl = (uint32_t *)lfg_pin_slot(LF_PS_HITS_Q, (n_hits + 1) * 4);
+        out->strand = (uint8_t *)lfg_pin_slot(LF_PS_HITS_S, n_hits + 1);
+        if (!out->tpos || !out->qpl || !out->strand) return LF_ERR_NOMEM;
+        HIPCHK(hipMemcpyAsync(out->tpos, d_tpos, n_hits * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(out->qpl, d_qpl, n_hits * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(out->strand, d_strand, n_hits, hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(hipMemcpyAsync(out->read_off, d_read_off, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out->counters, d_counters, 32, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

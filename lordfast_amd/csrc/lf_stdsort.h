@@ -10,13 +10,17 @@
 #define LF_STDSORT_H
 #include <stddef.h>
 
+#ifndef LF_STDSORT_FN
+#define LF_STDSORT_FN static            /* HIP translation units set this to `static __device__` */
+#endif
+
 #define LF_DEFINE_STDSORT(NAME, T, LESS)                                                                  \
-static void NAME##_sift_up(T *a, long hole, long top, T v) {                                              \
+LF_STDSORT_FN void NAME##_sift_up(T *a, long hole, long top, T v) {                                              \
     long parent = (hole - 1) / 2;                                                                         \
     while (hole > top && LESS(&a[parent], &v)) { a[hole] = a[parent]; hole = parent; parent = (hole - 1) / 2; } \
     a[hole] = v;                                                                                          \
 }                                                                                                         \
-static void NAME##_sift_down(T *a, long hole, long len, T v) {                                            \
+LF_STDSORT_FN void NAME##_sift_down(T *a, long hole, long len, T v) {                                            \
     const long top = hole; long child = hole;                                                             \
     while (child < (len - 1) / 2) {                                                                       \
         child = 2 * (child + 1);                                                                          \
@@ -26,26 +30,26 @@ static void NAME##_sift_down(T *a, long hole, long len, T v) {                  
     if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); a[hole] = a[child - 1]; hole = child - 1; } \
     NAME##_sift_up(a, hole, top, v);                                                                      \
 }                                                                                                         \
-static void NAME##_push_heap(T *a, long n) { T v = a[n - 1]; NAME##_sift_up(a, n - 1, 0, v); }            \
-static void NAME##_pop_heap(T *a, long n) { if (n > 1) { T v = a[n - 1]; a[n - 1] = a[0]; NAME##_sift_down(a, 0, n - 1, v); } } \
-static void NAME##_sort_heap(T *a, long n) { while (n > 1) { NAME##_pop_heap(a, n); n--; } }              \
-static void NAME##_make_heap(T *a, long n) {                                                              \
+LF_STDSORT_FN void NAME##_push_heap(T *a, long n) { T v = a[n - 1]; NAME##_sift_up(a, n - 1, 0, v); }            \
+LF_STDSORT_FN void NAME##_pop_heap(T *a, long n) { if (n > 1) { T v = a[n - 1]; a[n - 1] = a[0]; NAME##_sift_down(a, 0, n - 1, v); } } \
+LF_STDSORT_FN void NAME##_sort_heap(T *a, long n) { while (n > 1) { NAME##_pop_heap(a, n); n--; } }              \
+LF_STDSORT_FN void NAME##_make_heap(T *a, long n) {                                                              \
     if (n < 2) return;                                                                                    \
     for (long parent = (n - 2) / 2;; parent--) { T v = a[parent]; NAME##_sift_down(a, parent, n, v); if (parent == 0) return; } \
 }                                                                                                         \
-static void NAME##_linear_insert(T *a, long last) {                                                       \
+LF_STDSORT_FN void NAME##_linear_insert(T *a, long last) {                                                       \
     T v = a[last]; long next = last - 1;                                                                  \
     while (LESS(&v, &a[next])) { a[last] = a[next]; last = next; next--; }                                \
     a[last] = v;                                                                                          \
 }                                                                                                         \
-static void NAME##_insertion(T *a, long first, long last) {                                               \
+LF_STDSORT_FN void NAME##_insertion(T *a, long first, long last) {                                               \
     if (first == last) return;                                                                            \
     for (long i = first + 1; i != last; i++) {                                                            \
         if (LESS(&a[i], &a[first])) { T v = a[i]; for (long k = i; k > first; k--) a[k] = a[k - 1]; a[first] = v; } \
         else NAME##_linear_insert(a, i);                                                                  \
     }                                                                                                     \
 }                                                                                                         \
-static void NAME##_intro(T *a, long first, long last, long depth) {                                       \
+LF_STDSORT_FN void NAME##_intro(T *a, long first, long last, long depth) {                                       \
     while (last - first > 16) {                                                                           \
         if (depth == 0) { NAME##_make_heap(a + first, last - first); NAME##_sort_heap(a + first, last - first); return; } \
         depth--;                                                                                          \
@@ -66,7 +70,7 @@ static void NAME##_intro(T *a, long first, long last, long depth) {             
         last = lo;                                                                                        \
     }                                                                                                     \
 }                                                                                                         \
-static void NAME##_sort(T *a, long n) {                                                                   \
+LF_STDSORT_FN void NAME##_sort(T *a, long n) {                                                                   \
     if (n <= 0) return;                                                                                   \
     long lg = 0; for (long t_ = n; t_ > 1; t_ >>= 1) lg++;                                                \
     NAME##_intro(a, 0, n, 2 * lg);                                                                        \

@@ -1,0 +1,488 @@
+/*
+ * lf_vote.hip -- candidate selection and chaining without leaving HBM (gfx950).
+ *
+ * The seed stage leaves every hit of the chunk in device memory (tPos, qPos|len, strand; hits of one read are
+ * contiguous).  This stage turns them into chains; only the chains (a few dozen seeds per read) go to the host.
+ *
+ *   1 keys      every hit votes, with weight 1 + (len - k), for the windows floor(tPos/L) and floor(tPos/L) - 1 of its
+ *               read and strand (src/LordFAST.cpp:588-620): key = (read, strand, window)
+ *   2 sort + reduce-by-key (hipCUB): the sparse equivalent of the reference's dense per-thread vote array, windows of a
+ *               (read, strand) in ascending order -- the order the reference scans them in
+ *   3 select    one wavefront per read: local-maximum test (:630-632), the top-N min-heap with libstdc++'s
+ *               push_heap / pop_heap / sort_heap element order (:634-654, :528), coarse / fine decision (:531-553),
+ *               fine-mode candidate list (:875-877)
+ *   4 requests  window -> [lo, hi] reference range clipped to the contig of the window's midpoint (:995-1003)
+ *   5 gather    the read's hits of that strand inside the range, original order kept (:1004-1012)
+ *   6 sort      by qPos (src/Chain.cpp:244 std::sort(compare_seed)).  A radix sort gives the unique order whenever all
+ *               qPos of a request differ; requests with equal qPos get libstdc++'s introsort replayed by one lane on the
+ *               original order (lf_stdsort.h), because the reference's tie order reaches the chain DP
+ *   7 chain     lf_chain_n2_kernel (lf_chain.hip) on the device-resident requests; chains gathered and copied back
+ *
+ * Integer work, HBM-bound: two radix sorts dominate (16-24 B per hit and pass).
+ */
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <mutex>
+#include "lf_internal.h"
+#include "lf_gpu_common.h"
+#include "lf_chain_kernel.h"
+
+#define LF_STDSORT_FN static __device__
+#include "lf_stdsort.h"
+
+#define VK_WIN_BITS 26
+#define VK_INVALID (~0ull)
+__host__ __device__ __forceinline__ uint64_t vk_make(uint32_t read, uint32_t strand, uint32_t win)
+{
+    return ((uint64_t)read << (VK_WIN_BITS + 1)) | ((uint64_t)strand << VK_WIN_BITS) | win;
+}
+
+/* ---- 1: votes ---- */
+__global__ void __launch_bounds__(256)
+lf_vote_keys_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_t *__restrict__ read_off,
+                    const uint32_t *__restrict__ tpos, const uint32_t *__restrict__ qpl, const uint8_t *__restrict__ strand,
+                    uint32_t min_anchor_len, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t L = (uint32_t)(off[r + 1] - off[r]);
+    const uint64_t a = read_off[r], b = read_off[r + 1];
+    for (uint64_t j = a + threadIdx.x; j < b; j += blockDim.x) {
+        const uint32_t id = tpos[j] / L;
+        const uint32_t weight = (uint32_t)(1 + ((int32_t)(qpl[j] >> 20) - (int32_t)min_anchor_len));
+        const uint32_t s = strand[j];
+        keys[2 * j] = vk_make((uint32_t)r, s, id); vals[2 * j] = weight;
+        keys[2 * j + 1] = id >= 1 ? vk_make((uint32_t)r, s, id - 1) : VK_INVALID; vals[2 * j + 1] = weight;
+    }
+}
+
+/* ---- 3: selection ---- */
+struct lf_hwin { float score; uint32_t win; };        /* win | isReverse << 31 */
+#define HWIN_LESS(a, b) ((a)->score > (b)->score)      /* compareWin (src/LordFAST.cpp:981-984) */
+LF_DEFINE_STDSORT(dwinh, lf_hwin, HWIN_LESS)
+
+__device__ __forceinline__ int64_t lf_lower_bound(const uint64_t *__restrict__ k, int64_t n, uint64_t want)
+{
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (k[mid] < want) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__global__ void __launch_bounds__(64)
+lf_vote_select_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ ucnt,
+                      const int *__restrict__ n_runs_p, uint32_t l_pac, uint32_t min_read_len, int max_win,
+                      uint8_t *__restrict__ mode, uint32_t *__restrict__ nreq, int64_t *__restrict__ seg0,
+                      uint32_t *__restrict__ stage /* n_runs */, float *__restrict__ vscore)
+{
+    __shared__ lf_hwin heap[64];
+    __shared__ uint32_t s_win[64], s_cnt[64];
+    __shared__ int s_n; __shared__ float s_min;
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= n_reads) return;
+    const int64_t n_runs = *n_runs_p;
+    const uint32_t L = (uint32_t)(off[r + 1] - off[r]);
+    const uint32_t refWinNum = l_pac / min_read_len;                       /* src/LordFAST.cpp:130 */
+    uint32_t lim = l_pac / L + 2; if (lim > refWinNum) lim = refWinNum;     /* :622-624 */
+    const uint64_t WMASK = (1ull << VK_WIN_BITS) - 1;
+    const int64_t fa = lf_lower_bound(ukeys, n_runs, vk_make((uint32_t)r, 0, 0));
+    const int64_t fb = lf_lower_bound(ukeys, n_runs, vk_make((uint32_t)r, 1, 0));
+    const int64_t rb = lf_lower_bound(ukeys, n_runs, vk_make((uint32_t)r + 1, 0, 0));
+    if (lane == 0) { s_n = 0; s_min = 0; seg0[r] = fa; }
+    __syncthreads();
+    const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+
+    auto is_local_max = [&](int64_t k, int64_t sa, int64_t sb, uint32_t id, uint32_t c) -> bool {
+        const bool left_ok = (id == 0) || !(k > sa && (uint32_t)(ukeys[k - 1] & WMASK) == id - 1) || c >= ucnt[k - 1];
+        const bool right_ok = (id == refWinNum - 1) || !(k + 1 < sb && (uint32_t)(ukeys[k + 1] & WMASK) == id + 1) || c > ucnt[k + 1];
+        return left_ok && right_ok;
+    };
+    /* pass 0: the top-N heap, windows of the forward list first, then the reverse list, ascending (:626-656) */
+    for (int pass = 0; pass < 2; pass++) {
+        const int64_t sa = pass ? fb : fa, sb = pass ? rb : fb;
+        for (int64_t base = sa; base < sb; base += 64) {
+            const int64_t k = base + lane;
+            uint32_t id = 0, c = 0; bool cand = false;
+            if (k < sb) {
+                id = (uint32_t)(ukeys[k] & WMASK); c = ucnt[k];
+                if (id < lim && is_local_max(k, sa, sb, id, c)) cand = (s_n < max_win) || ((float)c > s_min);
+            }
+            s_win[lane] = id; s_cnt[lane] = c;
+            uint64_t m = __ballot(cand);
+            __syncthreads();
+            if (lane == 0 && m) {
+                int n = s_n;
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1; m &= m - 1;
+                    const float sc = (float)s_cnt[b];
+                    lf_hwin e; e.score = sc; e.win = s_win[b] | ((uint32_t)pass << 31);
+                    if (n < max_win) { heap[n] = e; n++; dwinh_push_heap(heap, n); }
+                    else if (sc > heap[0].score) { dwinh_pop_heap(heap, n); heap[n - 1] = e; dwinh_push_heap(heap, n); }
+                }
+                s_n = n; s_min = heap[0].score;
+            }
+            __syncthreads();
+        }
+    }
+    const int n = s_n;
+    if (n == 0) { if (lane == 0) { mode[r] = 1; nreq[r] = 0; vscore[r] = 0; } return; }
+    if (lane == 0) dwinh_sort_heap(heap, n);                                                   /* :528 */
+    __syncthreads();
+    const float scoreRatio = 4;
+    if (n == 1 || heap[0].score >= scoreRatio * heap[1].score) {                                /* coarse (:531) */
+        if (lane == 0) { mode[r] = 2; nreq[r] = 1; stage[fa] = heap[0].win; vscore[r] = heap[0].score; }
+        return;
+    }
+    /* fine: every local maximum above best/4, forward list then reverse list (:553, :875-877) */
+    const float minScore = heap[0].score / scoreRatio;
+    uint32_t ncand = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const int64_t sa = pass ? fb : fa, sb = pass ? rb : fb;
+        for (int64_t base = sa; base < sb; base += 64) {
+            const int64_t k = base + lane;
+            uint32_t id = 0; bool cand = false;
+            if (k < sb) {
+                id = (uint32_t)(ukeys[k] & WMASK); const uint32_t c = ucnt[k];
+                cand = id < lim && (float)c > minScore && is_local_max(k, sa, sb, id, c);
+            }
+            const uint64_t m = __ballot(cand);
+            /* the list is written over windows already scanned (ncand never overtakes the scan position) -- but lanes of
+             * this tile still read ukeys/ucnt, which are separate arrays: stage[] is write-only here */
+            if (cand) stage[fa + ncand + (uint32_t)__popcll(m & below)] = id | ((uint32_t)pass << 31);
+            ncand += (uint32_t)__popcll(m);
+        }
+    }
+    if (lane == 0) { mode[r] = 3; nreq[r] = ncand; vscore[r] = heap[0].score; }
+}
+
+/* ---- 4: requests ---- */
+__global__ void lf_req_build_kernel(int n_reads, const uint64_t *__restrict__ off, const uint32_t *__restrict__ nreq, const uint64_t *__restrict__ req0,
+                                    const int64_t *__restrict__ seg0, const uint32_t *__restrict__ stage,
+                                    const int64_t *__restrict__ ctg_off, const int64_t *__restrict__ ctg_len, int n_ctg, int64_t l_pac,
+                                    uint32_t *__restrict__ req_read, uint32_t *__restrict__ req_win, int64_t *__restrict__ req_lo, int64_t *__restrict__ req_hi)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t L = (uint32_t)(off[r + 1] - off[r]), margin = L >> 1;
+    const uint32_t n = nreq[r];
+    const uint64_t q0 = req0[r];
+    for (uint32_t c = 0; c < n; c++) {
+        const uint32_t w = stage[seg0[r] + c], id = w & 0x7fffffffu;
+        const uint32_t tStart = id * L, tEnd = (id + 2) * L - 1;                 /* uint32 arithmetic as in top_push */
+        const int64_t mid = (int64_t)(((uint64_t)tStart + (uint64_t)tEnd) >> 1);  /* bwt_get_chr_boundaries: contig of the midpoint */
+        int rid;
+        if (mid >= l_pac) rid = n_ctg - 1;
+        else { int lo = 0, hi = n_ctg - 1; while (lo < hi) { const int m = (lo + hi + 1) >> 1; if (ctg_off[m] <= mid) lo = m; else hi = m - 1; } rid = lo; }
+        const int64_t cb = (int64_t)(uint32_t)ctg_off[rid], ce = (int64_t)(uint32_t)(ctg_off[rid] + ctg_len[rid] - 1);
+        const int64_t lo = ((int64_t)tStart - (int64_t)margin > cb) ? (int64_t)tStart - (int64_t)margin : cb;
+        const int64_t hi = ((int64_t)tEnd + (int64_t)margin < ce) ? (int64_t)tEnd + (int64_t)margin : ce;
+        req_read[q0 + c] = (uint32_t)r; req_win[q0 + c] = w; req_lo[q0 + c] = lo; req_hi[q0 + c] = hi;
+    }
+}
+
+/* ---- 5: count / gather the hits of a request (one wavefront per request, order kept) ---- */
+template <bool WRITE>
+__global__ void __launch_bounds__(64)
+lf_req_gather_kernel(int n_req, const uint32_t *__restrict__ req_read, const uint32_t *__restrict__ req_win, const int64_t *__restrict__ req_lo,
+                     const int64_t *__restrict__ req_hi, const uint64_t *__restrict__ read_off, const uint32_t *__restrict__ tpos,
+                     const uint32_t *__restrict__ qpl, const uint8_t *__restrict__ strand, uint32_t *__restrict__ req_n,
+                     const uint64_t *__restrict__ req_off, uint2 *__restrict__ gathered, uint64_t *__restrict__ skeys)
+{
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q >= n_req) return;
+    const uint32_t r = req_read[q], s = req_win[q] >> 31;
+    const int64_t lo = req_lo[q], hi = req_hi[q];
+    const uint64_t a = read_off[r], b = read_off[r + 1];
+    const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    uint64_t out = WRITE ? req_off[q] : 0; uint32_t cnt = 0;
+    for (uint64_t base = a; base < b; base += 64) {
+        const uint64_t j = base + lane;
+        bool in = false; uint32_t t = 0, ql = 0;
+        if (j < b && strand[j] == s) { t = tpos[j]; in = (int64_t)t >= lo && (int64_t)t <= hi; if (WRITE && in) ql = qpl[j]; }
+        const uint64_t m = __ballot(in);
+        if (WRITE && in) {
+            const uint64_t p = out + cnt + (uint32_t)__popcll(m & below);
+            gathered[p] = make_uint2(t, ql);
+            skeys[p] = ((uint64_t)(uint32_t)q << 20) | (ql & 0xFFFFFu);
+        }
+        cnt += (uint32_t)__popcll(m);
+    }
+    if (!WRITE && lane == 0) req_n[q] = cnt;
+}
+
+/* ---- 6: equal qPos inside a request -> replay std::sort on the original order ---- */
+__global__ void lf_tie_flag_kernel(uint64_t n, const uint64_t *__restrict__ skeys_sorted, uint8_t *__restrict__ flag)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 || i >= n) return;
+    if (skeys_sorted[i] == skeys_sorted[i - 1]) flag[skeys_sorted[i] >> 20] = 1;
+}
+struct lf_dseed { uint32_t tPos, qpl; };
+#define DSEED_QLESS(a, b) (((a)->qpl & 0xFFFFFu) < ((b)->qpl & 0xFFFFFu))     /* compare_seed (src/Chain.cpp:227-230) */
+LF_DEFINE_STDSORT(dseedq, lf_dseed, DSEED_QLESS)
+__global__ void __launch_bounds__(64)
+lf_tie_sort_kernel(int n_req, const uint8_t *__restrict__ flag, const uint64_t *__restrict__ req_off, const uint32_t *__restrict__ req_n,
+                   const uint2 *__restrict__ gathered, uint2 *__restrict__ sorted)
+{
+    const int q = blockIdx.x;
+    if (q >= n_req || !flag[q]) return;
+    const uint64_t o = req_off[q]; const uint32_t n = req_n[q];
+    for (uint32_t i = threadIdx.x; i < n; i += 64) sorted[o + i] = gathered[o + i];
+    __syncthreads();
+    if (threadIdx.x == 0) dseedq_sort(reinterpret_cast<lf_dseed *>(sorted + o), (long)n);
+}
+
+/* ---- 7: chain descriptors, chain gather ---- */
+__global__ void lf_req_wins_kernel(int n_req, const uint64_t *__restrict__ req_off, const uint32_t *__restrict__ req_n, const uint64_t *__restrict__ ws_off,
+                                   lf_chain_win *__restrict__ wins)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_req) return;
+    lf_chain_win w; w.off = req_off[q]; w.n = req_n[q]; w.id = (uint32_t)q; w.ws_off = ws_off[q];
+    wins[q] = w;
+}
+__global__ void lf_chain_gather_kernel(int n_req, const uint64_t *__restrict__ req_off, const uint32_t *__restrict__ chain_idx, const uint32_t *__restrict__ chain_len,
+                                       const uint64_t *__restrict__ chain_off, const uint2 *__restrict__ sorted, uint2 *__restrict__ chain_seeds)
+{
+    const int q = blockIdx.x;
+    if (q >= n_req) return;
+    const uint32_t n = chain_len[q];
+    const uint64_t o = req_off[q], co = chain_off[q];
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) chain_seeds[co + k] = sorted[o + chain_idx[o + k]];
+}
+struct lf_big_op { __host__ __device__ uint64_t operator()(uint32_t n) const { return n > LF_CHAIN_LDS_MAX ? (uint64_t)n : 0ull; } };
+struct lf_w32 { __host__ __device__ uint64_t operator()(uint32_t v) const { return v; } };
+
+/* penalty table, evaluated exactly as score_penalty does (src/Chain.cpp:224) with the host libm; cached per device */
+static int pen_table(int device, const lf_params_t *p, uint64_t want, hipStream_t s, const double **d_pen, uint32_t *pen_n)
+{
+    static std::mutex mu; static double *tab[16]; static uint64_t tab_n[16]; static double tab_cp[16];
+    std::lock_guard<std::mutex> g(mu);
+    if (want > (64u << 20)) want = 64u << 20;
+    if (!tab[device] || tab_n[device] < want || tab_cp[device] != p->chain_penalty) {
+        uint64_t n = 2 * want; if (n < (1u << 20)) n = 1u << 20;
+        std::vector<double> pen((size_t)n);
+        for (uint64_t d = 0; d < n; d++) pen[d] = d <= 1 ? 0.0 : 0.1 * (double)(int)d + p->chain_penalty * log((double)(int)d);
+        /* an outgrown table is not freed: another lane may still have a launch in flight that reads it (rare, small) */
+        HIPCHK(hipMalloc((void **)&tab[device], n * 8));
+        HIPCHK(hipMemcpy(tab[device], pen.data(), n * 8, hipMemcpyHostToDevice));
+        tab_n[device] = n; tab_cp[device] = p->chain_penalty;
+    }
+    (void)s;
+    *d_pen = tab[device]; *pen_n = (uint32_t)tab_n[device];
+    return LF_OK;
+}
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, int n_reads, uint64_t n_hits, uint32_t max_read_len, lfg_vc_t *out)
+{
+    memset(out, 0, sizeof *out);
+    if (n_reads == 0) return LF_OK;
+    const int dv = ix->device;
+    HIPCHK(hipSetDevice(dv));
+    hipStream_t s = (hipStream_t)lfg_lane_stream(dv, 0);
+    if (!s) return LF_ERR_HIP;
+    if (n_reads >= (1 << 20)) { lf_set_error("lfg_vote_chain: too many reads in one chunk"); return LF_ERR_ARG; }
+    /* left in HBM by lfg_seed */
+    const uint64_t *d_off = (const uint64_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 1, 0), *d_read_off = (const uint64_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 6, 0);
+    const uint32_t *d_tpos = (const uint32_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 9, 0), *d_qpl = (const uint32_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 10, 0);
+    const uint8_t *d_strand = (const uint8_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 11, 0);
+    if (!d_off || !d_read_off || !d_tpos || !d_qpl || !d_strand) { lf_set_error("lfg_vote_chain: no resident seed batch"); return LF_ERR_ARG; }
+#define VSLOT(k, bytes) lfg_dev_slot(dv, LF_DS_VOTE0 + (k), (bytes))
+    hipEvent_t e0, e1, e2; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
+    HIPCHK(hipEventRecord(e0, s));
+
+    /* per-read arrays, one allocation */
+    const size_t R = (size_t)n_reads;
+    char *pr = (char *)VSLOT(0, al256(R) + al256(R * 4) + al256((R + 1) * 8) + al256(R * 8) + al256(R * 4) + 1024);
+    if (!pr) return LF_ERR_NOMEM;
+    uint8_t *d_mode = (uint8_t *)pr; pr += al256(R);
+    uint32_t *d_nreq = (uint32_t *)pr; pr += al256(R * 4);
+    uint64_t *d_req0 = (uint64_t *)pr; pr += al256((R + 1) * 8);
+    int64_t *d_seg0 = (int64_t *)pr; pr += al256(R * 8);
+    float *d_vscore = (float *)pr; pr += al256(R * 4);
+    int *d_nruns = (int *)pr;
+    uint64_t *h_small = (uint64_t *)lfg_pin_slot(LF_PS_VOTE0 + 0, 256);
+    if (!h_small) return LF_ERR_NOMEM;
+
+    uint32_t n_req = 0;
+    uint32_t *d_stage = nullptr;
+    if (n_hits) {
+        const uint64_t E = 2 * n_hits;
+        if (E >= (1ull << 31)) { lf_set_error("lfg_vote_chain: too many hits in one chunk (%llu)", (unsigned long long)n_hits); return LF_ERR_ARG; }
+        uint64_t *d_keys = (uint64_t *)VSLOT(1, E * 8), *d_keys2 = (uint64_t *)VSLOT(2, E * 8);
+        uint32_t *d_vals = (uint32_t *)VSLOT(3, E * 4), *d_vals2 = (uint32_t *)VSLOT(4, E * 4);
+        if (!d_keys || !d_keys2 || !d_vals || !d_vals2) return LF_ERR_NOMEM;
+        int rbits = 1; while ((1 << rbits) < n_reads + 1) rbits++;
+        const int end_bit = VK_WIN_BITS + 1 + rbits;
+        size_t tb1 = 0, tb2 = 0, tb3 = 0;
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, d_keys, d_keys2, d_vals, d_vals2, (int)E, 0, end_bit, s);
+        (void)hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, d_keys2, d_keys, d_vals2, d_vals, d_nruns, hipcub::Sum(), (int)E, s);
+        hipcub::TransformInputIterator<uint64_t, lf_w32, uint32_t *> nreq64(d_nreq, lf_w32());
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, nreq64, d_req0, n_reads + 1, s);
+        void *d_tmp = VSLOT(5, std::max(tb1, std::max(tb2, tb3)) + 256);
+        if (!d_tmp) return LF_ERR_NOMEM;
+        hipLaunchKernelGGL(lf_vote_keys_kernel, dim3((unsigned)n_reads), dim3(256), 0, s, n_reads, d_off, d_read_off, d_tpos, d_qpl, d_strand,
+                           (uint32_t)p->min_anchor_len, d_keys, d_vals);
+        { size_t tb = tb1; HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, (int)E, 0, end_bit, s)); }
+        /* unique (read, strand, window) keys -> d_keys, summed weights -> d_vals (the invalid key sorts last; it is never looked up) */
+        { size_t tb = tb2; HIPCHK(hipcub::DeviceReduce::ReduceByKey(d_tmp, tb, d_keys2, d_keys, d_vals2, d_vals, d_nruns, hipcub::Sum(), (int)E, s)); }
+        d_stage = (uint32_t *)d_vals2;                      /* free again: candidate windows per read, at most one per unique key */
+        hipLaunchKernelGGL(lf_vote_select_kernel, dim3((unsigned)n_reads), dim3(64), 0, s, n_reads, d_off, d_keys, d_vals, d_nruns,
+                           (uint32_t)ix->l_pac, (uint32_t)p->min_read_len, p->max_map, d_mode, d_nreq, d_seg0, d_stage, d_vscore);
+        /* request ids: exclusive scan over n_reads + 1 counts (the last one is a zero pad) */
+        { size_t tb = tb3; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, nreq64, d_req0, n_reads, s)); }
+        HIPCHK(hipMemcpyAsync(h_small, d_req0 + (R - 1), 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h_small + 1, d_nreq + (R - 1), 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const uint64_t nr = h_small[0] + (uint32_t)h_small[1];
+        if (nr >= (1ull << 31)) { lf_set_error("lfg_vote_chain: too many candidate windows"); return LF_ERR_ARG; }
+        n_req = (uint32_t)nr;
+    } else {
+        HIPCHK(hipMemsetAsync(d_mode, 1, R, s));
+        HIPCHK(hipMemsetAsync(d_nreq, 0, R * 4, s));
+        HIPCHK(hipMemsetAsync(d_req0, 0, (R + 1) * 8, s));
+    }
+    HIPCHK(hipEventRecord(e1, s));
+
+    /* host-side result arrays (pinned, valid until this lane's next call) */
+    out->n_reads = n_reads; out->n_req = (int)n_req;
+    out->mode = (uint8_t *)lfg_pin_slot(LF_PS_VOTE0 + 1, R + 16);
+    out->req0 = (uint64_t *)lfg_pin_slot(LF_PS_VOTE0 + 2, (R + 1) * 8);
+    out->nreq = (uint32_t *)lfg_pin_slot(LF_PS_VOTE0 + 3, R * 4 + 16);
+    out->vscore = (float *)lfg_pin_slot(LF_PS_VOTE0 + 4, R * 4 + 16);
+    if (!out->mode || !out->req0 || !out->nreq || !out->vscore) return LF_ERR_NOMEM;
+    HIPCHK(hipMemcpyAsync(out->mode, d_mode, R, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out->req0, d_req0, R * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out->nreq, d_nreq, R * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out->vscore, d_vscore, R * 4, hipMemcpyDeviceToHost, s));
+    if (n_req == 0) {
+        HIPCHK(hipStreamSynchronize(s));
+        out->req0[R] = 0;
+        HIPCHK(hipEventElapsedTime(&out->ms_vote, e0, e1));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+        return LF_OK;
+    }
+
+    /* ---- requests ---- */
+    const size_t Q = (size_t)n_req;
+    char *pq = (char *)VSLOT(6, al256(Q * 4) * 4 + al256(Q * 8) * 2 + al256((Q + 1) * 8) * 3 + al256(Q) + al256(Q * sizeof(lf_chain_win)) + 1024);
+    int64_t *d_ctg = (int64_t *)VSLOT(7, (size_t)ix->n_seqs * 16 + 64);
+    if (!pq || !d_ctg) return LF_ERR_NOMEM;
+    uint32_t *d_req_read = (uint32_t *)pq; pq += al256(Q * 4);
+    uint32_t *d_req_win = (uint32_t *)pq; pq += al256(Q * 4);
+    uint32_t *d_req_n = (uint32_t *)pq; pq += al256(Q * 4);
+    uint32_t *d_clen = (uint32_t *)pq; pq += al256(Q * 4);
+    int64_t *d_req_lo = (int64_t *)pq; pq += al256(Q * 8);
+    int64_t *d_req_hi = (int64_t *)pq; pq += al256(Q * 8);
+    uint64_t *d_req_off = (uint64_t *)pq; pq += al256((Q + 1) * 8);
+    uint64_t *d_ws_off = (uint64_t *)pq; pq += al256((Q + 1) * 8);
+    uint64_t *d_coff = (uint64_t *)pq; pq += al256((Q + 1) * 8);
+    uint8_t *d_flag = (uint8_t *)pq; pq += al256(Q);
+    lf_chain_win *d_wins = (lf_chain_win *)pq;
+    float *d_cscore = (float *)VSLOT(8, Q * 4 + 64);
+    if (!d_cscore) return LF_ERR_NOMEM;
+    {
+        int64_t *h_ctg = (int64_t *)lfg_pin_slot(LF_PS_VOTE0 + 5, (size_t)ix->n_seqs * 16 + 64);
+        if (!h_ctg) return LF_ERR_NOMEM;
+        for (int i = 0; i < ix->n_seqs; i++) { h_ctg[i] = ix->contigs[i].offset; h_ctg[ix->n_seqs + i] = ix->contigs[i].len; }
+        HIPCHK(hipMemcpyAsync(d_ctg, h_ctg, (size_t)ix->n_seqs * 16, hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(lf_req_build_kernel, dim3((unsigned)((n_reads + 127) / 128)), dim3(128), 0, s, n_reads, d_off, d_nreq, d_req0, d_seg0, d_stage,
+                       d_ctg, d_ctg + ix->n_seqs, ix->n_seqs, (int64_t)ix->l_pac, d_req_read, d_req_win, d_req_lo, d_req_hi);
+    hipLaunchKernelGGL(lf_req_gather_kernel<false>, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_req_read, d_req_win, d_req_lo, d_req_hi, d_read_off,
+                       d_tpos, d_qpl, d_strand, d_req_n, (const uint64_t *)nullptr, (uint2 *)nullptr, (uint64_t *)nullptr);
+    size_t tbs = 0, tbs2 = 0;
+    hipcub::TransformInputIterator<uint64_t, lf_w32, uint32_t *> n64(d_req_n, lf_w32());
+    hipcub::TransformInputIterator<uint64_t, lf_big_op, uint32_t *> big64(d_req_n, lf_big_op());
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tbs, n64, d_req_off, (int)n_req, s);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tbs2, big64, d_ws_off, (int)n_req, s);
+    void *d_tmp2 = VSLOT(9, std::max(tbs, tbs2) + 256);
+    if (!d_tmp2) return LF_ERR_NOMEM;
+    { size_t tb = tbs; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp2, tb, n64, d_req_off, (int)n_req, s)); }
+    { size_t tb = tbs2; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp2, tb, big64, d_ws_off, (int)n_req, s)); }
+    HIPCHK(hipMemcpyAsync(h_small + 2, d_req_off + (Q - 1), 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_small + 3, d_ws_off + (Q - 1), 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_small + 4, d_req_n + (Q - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const uint32_t last_n = (uint32_t)h_small[4];
+    const uint64_t S = h_small[2] + last_n, WS = h_small[3] + (last_n > LF_CHAIN_LDS_MAX ? last_n : 0);
+    if (S >= (1ull << 31)) { lf_set_error("lfg_vote_chain: too many seeds in candidate windows (%llu)", (unsigned long long)S); return LF_ERR_ARG; }
+    out->n_req_seeds = S;
+
+    uint2 *d_gath = (uint2 *)VSLOT(10, S * 8 + 64), *d_sorted = (uint2 *)VSLOT(11, S * 8 + 64);
+    uint64_t *d_sk = (uint64_t *)VSLOT(12, S * 8 + 64), *d_sk2 = (uint64_t *)VSLOT(13, S * 8 + 64);
+    uint32_t *d_cidx = (uint32_t *)VSLOT(14, S * 4 + 64);
+    double *d_dp = (double *)VSLOT(15, WS * 8 + 64); int *d_prev = (int *)VSLOT(16, WS * 4 + 64);
+    if (!d_gath || !d_sorted || !d_sk || !d_sk2 || !d_cidx || !d_dp || !d_prev) return LF_ERR_NOMEM;
+    if (S) {
+        hipLaunchKernelGGL(lf_req_gather_kernel<true>, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_req_read, d_req_win, d_req_lo, d_req_hi, d_read_off,
+                           d_tpos, d_qpl, d_strand, d_req_n, (const uint64_t *)d_req_off, d_gath, d_sk);
+        int qbits = 1; while ((1ull << qbits) < (uint64_t)n_req + 1) qbits++;
+        size_t tb4 = 0;
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb4, d_sk, d_sk2, (uint64_t *)d_gath, (uint64_t *)d_sorted, (int)S, 0, 20 + qbits, s);
+        void *d_tmp3 = VSLOT(17, tb4 + 256);
+        if (!d_tmp3) return LF_ERR_NOMEM;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp3, tb4, d_sk, d_sk2, (uint64_t *)d_gath, (uint64_t *)d_sorted, (int)S, 0, 20 + qbits, s));
+        HIPCHK(hipMemsetAsync(d_flag, 0, Q, s));
+        hipLaunchKernelGGL(lf_tie_flag_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, S, d_sk2, d_flag);
+        hipLaunchKernelGGL(lf_tie_sort_kernel, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_flag, d_req_off, d_req_n, d_gath, d_sorted);
+    }
+    /* ---- chains ---- */
+    uint64_t max_d = 4ull * max_read_len + 8192;
+    const double *d_pen; uint32_t pen_n;
+    { int rc = pen_table(dv, p, max_d, s, &d_pen, &pen_n); if (rc != LF_OK) return rc; }
+    const double reward = p->chain_reward * (double)p->min_anchor_len;     /* score_reward, src/Chain.cpp:211-215 */
+    hipLaunchKernelGGL(lf_req_wins_kernel, dim3((unsigned)((n_req + 255) / 256)), dim3(256), 0, s, (int)n_req, d_req_off, d_req_n, d_ws_off, d_wins);
+    {
+        static const uint32_t CAPS[5] = { 128, 512, 2048, LF_CHAIN_LDS_MAX, 0 };
+        uint32_t lo = 0;                                     /* one launch per LDS size class; a block outside its class exits */
+        for (int c = 0; c < 5; c++) {
+            const uint32_t hi = CAPS[c] ? CAPS[c] : 0xFFFFFFFFu;
+            if (c == 4 && WS == 0) break;
+            const uint32_t cap = CAPS[c] ? CAPS[c] : 1;
+            const size_t smem = (size_t)cap * 22 + 16;
+            hipLaunchKernelGGL(lf_chain_n2_kernel, dim3((unsigned)n_req), dim3(64), smem, s, (const lf_chain_win *)d_wins, (int)n_req,
+                               (const uint32_t *)d_sorted, d_pen, pen_n, reward, p->chain_penalty, CAPS[c], d_dp, d_prev, d_cidx, d_clen, d_cscore, lo, hi);
+            lo = hi + 1;
+        }
+    }
+    size_t tb5 = 0;
+    hipcub::TransformInputIterator<uint64_t, lf_w32, uint32_t *> cl64(d_clen, lf_w32());
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb5, cl64, d_coff, (int)n_req, s);
+    void *d_tmp4 = VSLOT(18, tb5 + 256);
+    if (!d_tmp4) return LF_ERR_NOMEM;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp4, tb5, cl64, d_coff, (int)n_req, s));
+    HIPCHK(hipMemcpyAsync(h_small + 5, d_coff + (Q - 1), 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_small + 6, d_clen + (Q - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const uint64_t C = h_small[5] + (uint32_t)h_small[6];
+    uint2 *d_cseeds = (uint2 *)VSLOT(19, C * 8 + 64);
+    if (!d_cseeds) return LF_ERR_NOMEM;
+    hipLaunchKernelGGL(lf_chain_gather_kernel, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_req_off, d_cidx, d_clen, d_coff, d_sorted, d_cseeds);
+    HIPCHK(hipEventRecord(e2, s));
+    out->req_win = (uint32_t *)lfg_pin_slot(LF_PS_VOTE0 + 6, Q * 4 + 16);
+    out->chain_len = (uint32_t *)lfg_pin_slot(LF_PS_VOTE0 + 7, Q * 4 + 16);
+    out->chain_score = (float *)lfg_pin_slot(LF_PS_VOTE0 + 8, Q * 4 + 16);
+    out->chain_off = (uint64_t *)lfg_pin_slot(LF_PS_VOTE0 + 9, (Q + 1) * 8);
+    out->chain_seeds = (Seed_t *)lfg_pin_slot(LF_PS_VOTE0 + 10, C * 8 + 16);
+    if (!out->req_win || !out->chain_len || !out->chain_score || !out->chain_off || !out->chain_seeds) return LF_ERR_NOMEM;
+    HIPCHK(hipMemcpyAsync(out->req_win, d_req_win, Q * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out->chain_len, d_clen, Q * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out->chain_score, d_cscore, Q * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out->chain_off, d_coff, Q * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out->chain_seeds, d_cseeds, C * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    out->chain_off[Q] = C; out->req0[R] = n_req;
+    out->n_chain_seeds = C;
+    HIPCHK(hipEventElapsedTime(&out->ms_vote, e0, e1));
+    HIPCHK(hipEventElapsedTime(&out->ms_chain, e1, e2));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+#undef VSLOT
+    return LF_OK;
+}

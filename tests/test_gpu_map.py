@@ -58,6 +58,17 @@ def test_sam_host_cigar_crosscheck(lf, golden_reads, monkeypatch):
     assert sam == exp, first_diff(sam, exp)
 
 
+@pytest.mark.parametrize("cfg", ["default", "n30"])
+def test_sam_host_vote_crosscheck(lf, golden_reads, monkeypatch, cfg):
+    """LF_HOST_VOTE=1 votes / selects / sorts on the host from copied-back hits instead of lf_vote.hip: same records"""
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    monkeypatch.setenv("LF_HOST_VOTE", "1")
+    sam, st = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
+    exp = golden_sam(cfg)
+    assert sam == exp, first_diff(sam, exp)
+
+
 def test_map_batch_into_caller_buffer(lf, golden_reads):
     """lf_map_batch_into: same records into a caller-owned buffer; a buffer that is too small is an error, not a truncation"""
     import ctypes as C
