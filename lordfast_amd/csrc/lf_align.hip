@@ -157,7 +157,8 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
                 uint64_t ph, mh;
                 hin = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
                 if (b == lastb) score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
-                if (want_path) { lf_hist_t e; e.pv = Pv[b]; e.ph = ph; h[((size_t)(c - 1) * NB + b) * 64] = e; }
+                /* blocks above the problem's last one are padding of the size class: never read back, not stored */
+                if (want_path && b <= lastb) { lf_hist_t e; e.pv = Pv[b]; e.ph = ph; h[((size_t)(c - 1) * NB + b) * 64] = e; }
             }
             if (score < best) { best = score; best_c = (int)c; }
         }
@@ -168,18 +169,38 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
     out_end[pr.id] = tl - 1;
     if (!want_path) { out_len[pr.id] = 0; return; }
 
-    /* traceback from (n, tl); ops written backwards from the end of the region (they stay end-aligned) */
+    /* traceback from (n, tl); ops written backwards from the end of the region (they stay end-aligned).
+     * The 64 lanes walk their paths COLUMN-LOCKSTEP: in iteration cc every lane whose path is in column cc makes all of
+     * its moves there (any Up moves, then one Left or Diagonal).  Problems of a wave are sorted by target length and
+     * their paths hug the diagonal, so in one iteration the lanes read the same few 1 KiB history rows (entry index
+     * (cc-1)*NB + block): the wave-transposed rows are fetched whole instead of 16 bytes per 128-byte line. */
+    __shared__ uint32_t s_cmax;
+    s_cmax = 0;                          /* every live lane (lane 0 may have left already) */
+    __syncthreads();
+    atomicMax(&s_cmax, (uint32_t)tl);
+    __syncthreads();
+    const uint32_t cmax = s_cmax;
     uint8_t *o = ops + pr.ops_off;
     const uint32_t cap = n + m;
     uint32_t w = cap;
     uint32_t r = n, c = (uint32_t)tl;
-    if (c == 0) { while (r) { o[--w] = 1; r--; } }
-    while (r > 0 && c > 0) {
-        const lf_hist_t e = h[((size_t)(c - 1) * NB + ((r - 1) >> 6)) * 64];
-        const int bit = (int)((r - 1) & 63);
-        if ((e.pv >> bit) & 1) { o[--w] = 1; r--; }
-        else if ((e.ph >> bit) & 1) { o[--w] = 2; c--; }
-        else { o[--w] = (Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
+    for (uint32_t cc = cmax; cc >= 1; cc--) {
+        if (c != cc || r == 0) continue;
+        uint32_t b = (r - 1) >> 6;
+        lf_hist_t e = h[((size_t)(cc - 1) * NB + b) * 64];
+        for (;;) {
+            const int bit = (int)((r - 1) & 63);
+            if ((e.pv >> bit) & 1) {                                   /* Up: stays in this column */
+                o[--w] = 1; r--;
+                if (r == 0) break;
+                const uint32_t b2 = (r - 1) >> 6;
+                if (b2 != b) { b = b2; e = h[((size_t)(cc - 1) * NB + b) * 64]; }
+                continue;
+            }
+            if ((e.ph >> bit) & 1) { o[--w] = 2; c--; break; }          /* Left */
+            o[--w] = (Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--;   /* Diagonal */
+            break;
+        }
     }
     while (c > 0) { o[--w] = 2; c--; }
     while (r > 0) { o[--w] = 1; r--; }
@@ -397,6 +418,102 @@ lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * group kernel: the wave kernel's anti-diagonal sweep with G = 16 or 32 lanes per problem, 64/G problems per
+ * wavefront.  Queries of 513..2048 bases have 9..32 blocks: one problem per wave would leave most lanes idle.
+ * One block per lane; carries cross lanes by shuffle, never a group boundary (group lane 0 takes hin = 1);
+ * wave-wide ballots build the bit planes of all groups at once; each group tracebacks cooperatively (G history
+ * columns per round trip).  Loop bounds are wave-uniform maxima, work is predicated per group.
+ * ---------------------------------------------------------------------------------------------- */
+template <int G>
+__global__ void __launch_bounds__(64)
+lf_edlib_group_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ hist,
+                      uint8_t *__restrict__ ops, int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
+{
+    constexpr int P = 64 / G;                      /* problems per wave = sub-iterations per 64-row block */
+    constexpr int TCAP = LF_WAVE_LDS_T / P;
+    const int lane = threadIdx.x, g = lane / G, gl = lane % G;
+    const int pi = (int)blockIdx.x * P + g;
+    const bool live = pi < n_probs;
+    const lf_aln_prob pr = probs[live ? pi : n_probs - 1];      /* a dead group shadows the last problem and stores nothing */
+    const lf_qacc Q(S, pr); const lf_tacc T(S, pr);
+    const uint32_t n = pr.n, m = pr.m;
+    const uint32_t nbk = (n + 63) >> 6;            /* <= G */
+    uint32_t nbk_max = nbk, steps_max = m + nbk - 1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(nbk_max, o), b2 = __shfl_xor(steps_max, o);
+        nbk_max = a > nbk_max ? a : nbk_max; steps_max = b2 > steps_max ? b2 : steps_max;
+    }
+    uint64_t lo = 0, hi = 0, valid = 0, Pv = ~0ull, Mv = 0;
+    const uint64_t gmask = (1ull << G) - 1;
+    for (uint32_t b = 0; b < nbk_max; b++) {
+#pragma unroll
+        for (int sub = 0; sub < P; sub++) {
+            const uint32_t r = b * 64 + (uint32_t)(sub * G + gl);
+            int code = -1;
+            if (b < nbk && r < n) { switch (Q.get(r)) { case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break; default: code = -1; } }
+            const uint64_t bl = __ballot(code >= 0 && (code & 1)), bh = __ballot(code >= 0 && (code & 2)), bv = __ballot(code >= 0);
+            if ((uint32_t)gl == b) {
+                lo |= ((bl >> (g * G)) & gmask) << (sub * G); hi |= ((bh >> (g * G)) & gmask) << (sub * G); valid |= ((bv >> (g * G)) & gmask) << (sub * G);
+            }
+        }
+    }
+    __shared__ unsigned char s_t[LF_WAVE_LDS_T];
+    unsigned char *my_t = s_t + g * TCAP;
+    const bool t_lds = m <= (uint32_t)TCAP;
+    if (t_lds) { for (uint32_t j = (uint32_t)gl; j < m; j += G) my_t[j] = T.get(j); }
+    __syncthreads();
+    const uint32_t lastb = (n - 1) >> 6; const int lastbit = (int)((n - 1) & 63);
+    int score = (int)n, best = (n & 63) ? (int)n : 0x7fffffff, best_c = 0;
+    lf_hist_t *h = hist + pr.hist_base;
+    int hout_prev = 1;
+    for (uint32_t s = 0; s < steps_max; s++) {
+        const int from_left = __shfl_up(hout_prev, 1);
+        const int c = (int)s - gl + 1;
+        if ((uint32_t)gl < nbk && c >= 1 && c <= (int)m) {
+            const unsigned char tc = t_lds ? my_t[c - 1] : T.get((uint32_t)(c - 1));
+            const uint64_t Eq = lf_eq_mask(tc, lo, hi, valid, Q, n, (uint32_t)gl);
+            uint64_t ph, mh;
+            const int hin = gl == 0 ? 1 : from_left;
+            hout_prev = lf_myers_step(Pv, Mv, Eq, hin, ph, mh);
+            if ((uint32_t)gl == lastb) { score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1); if (score < best) { best = score; best_c = c; } }
+            if (live) { lf_hist_t e; e.pv = Pv; e.ph = ph; h[(size_t)(c - 1) * nbk + gl] = e; }
+        }
+    }
+    const int src_last = g * G + (int)lastb;
+    const int ed_nw = __shfl(score, src_last), ed_shw = __shfl(best, src_last), c_shw = __shfl(best_c, src_last);
+    int ed, tl;
+    if (pr.mode == 0) { ed = ed_nw; tl = (int)m; } else { ed = ed_shw; tl = c_shw; }
+    __syncthreads();                      /* history written by all lanes is read back below */
+    if (!live) return;
+    if (gl == 0) { out_ed[pr.id] = ed; out_end[pr.id] = tl - 1; }
+    uint8_t *o = ops + pr.ops_off;
+    const uint32_t cap = n + m;
+    uint32_t w = cap, r = n, c = (uint32_t)tl;
+    if (c == 0) { if (gl == 0) for (uint32_t i = 0; i < r; i++) o[cap - 1 - i] = 1; w -= r; r = 0; }
+    while (r > 0 && c > 0) {
+        const uint32_t blk = (r - 1) >> 6, c0 = c;
+        const int col = (int)c0 - gl;
+        lf_hist_t e; e.pv = 0; e.ph = 0;
+        if (col >= 1) e = h[(size_t)(col - 1) * nbk + blk];
+        while (r > 0 && c > 0 && ((r - 1) >> 6) == blk && (c0 - c) < (uint32_t)G) {
+            const int src = g * G + (int)(c0 - c);
+            const uint64_t pv = __shfl(e.pv, src), ph = __shfl(e.ph, src);
+            const int bit = (int)((r - 1) & 63);
+            if ((pv >> bit) & 1) { if (gl == 0) o[w - 1] = 1; r--; }
+            else if ((ph >> bit) & 1) { if (gl == 0) o[w - 1] = 2; c--; }
+            else { if (gl == 0) o[w - 1] = (Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
+            w--;
+        }
+    }
+    if (gl == 0) {
+        while (c > 0) { o[--w] = 2; c--; }
+        while (r > 0) { o[--w] = 1; r--; }
+        out_len[pr.id] = cap - w;            /* ops are END-aligned: o[cap - len .. cap) */
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * host launcher
  * ---------------------------------------------------------------------------------------------- */
 struct lf_dev_buf {
@@ -592,11 +709,15 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
  * sort, one scan for the history bases, one kernel that writes the per-class problem arrays.  The host uploads
  * 32-byte descriptors and launches; it does no per-problem work.
  * ---------------------------------------------------------------------------------------------- */
+#define LF_NCLASS 11
+/* launch classes: 0 generic lane kernel ; 1..6 lane kernels NB 1,2,3,4,6,8 ; 7,8 group kernels G 16,32 ; 9,10 wave kernels KB 1,4 */
+__host__ __device__ __forceinline__ int lf_class_nb(int c) { return c == 1 ? 1 : c == 2 ? 2 : c == 3 ? 3 : c == 4 ? 4 : c == 5 ? 6 : 8; }
 __device__ __forceinline__ int lf_desc_class(uint32_t n)
-{   /* order = launch classes: 1..4 lane kernels NB 1,2,4,8 ; 5,6 wave kernels KB 1,4 ; 0 generic lane kernel */
+{
     const uint32_t nb = (n + 63) >> 6;
-    if (nb <= 1) return 1; if (nb <= 2) return 2; if (nb <= 4) return 3; if (nb <= 8) return 4;
-    if (n <= 4096) return 5; if (n <= 16384) return 6;
+    if (nb <= 1) return 1; if (nb <= 2) return 2; if (nb <= 3) return 3; if (nb <= 4) return 4; if (nb <= 6) return 5; if (nb <= 8) return 6;
+    if (nb <= 16) return 7; if (nb <= 32) return 8;
+    if (n <= 4096) return 9; if (n <= 16384) return 10;
     return 0;
 }
 __global__ void lf_desc_keys_kernel(const lf_aln_desc_t *__restrict__ d, int n, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
@@ -606,10 +727,10 @@ __global__ void lf_desc_keys_kernel(const lf_aln_desc_t *__restrict__ d, int n, 
     keys[i] = ((uint64_t)lf_desc_class(d[i].n) << 32) | d[i].m;
     vals[i] = (uint32_t)i;
 }
-__global__ void lf_desc_bounds_kernel(const uint64_t *__restrict__ keys, int n, int *__restrict__ cstart /* 8 */)
+__global__ void lf_desc_bounds_kernel(const uint64_t *__restrict__ keys, int n, int *__restrict__ cstart /* LF_NCLASS + 1 */)
 {
     const int c = threadIdx.x;
-    if (c > 7) return;
+    if (c > LF_NCLASS) return;
     const uint64_t want = (uint64_t)c << 32;
     int lo = 0, hi = n;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
@@ -622,12 +743,12 @@ __global__ void lf_desc_entries_kernel(const uint64_t *__restrict__ keys, const 
     if (j >= n) return;
     const int c = (int)(keys[j] >> 32);
     uint64_t e;
-    if (c >= 1 && c <= 4) {
+    if (c >= 1 && c <= 6) {
         const int rel = j - cstart[c];
         if (rel & 63) e = 0;
         else {      /* first lane of a wave: the wave's history holds 64 x (largest m of the wave) x NB entries */
             int last = j + 63; if (last > cstart[c + 1] - 1) last = cstart[c + 1] - 1;
-            e = 64ull * (uint32_t)keys[last] * (1u << (c - 1));
+            e = 64ull * (uint32_t)keys[last] * (uint32_t)lf_class_nb(c);
         }
     } else { const uint32_t nn = d[vals[j]].n; e = (uint64_t)(uint32_t)keys[j] * ((nn + 63) >> 6); }
     ent[j] = e;
@@ -644,7 +765,7 @@ __global__ void lf_desc_build_kernel(const uint64_t *__restrict__ keys, const ui
     lf_aln_prob p;
     p.qstart = x.qstart; p.tstart = x.tstart; p.ops_off = ops_off[i];
     int jb = j;
-    if (c >= 1 && c <= 4) jb = cstart[c] + ((j - cstart[c]) & ~63);
+    if (c >= 1 && c <= 6) jb = cstart[c] + ((j - cstart[c]) & ~63);
     p.hist_base = base[jb];
     p.aux_off = 0;
     if (c == 0) p.aux_off = atomicAdd((unsigned long long *)aux_words_total, (unsigned long long)(((x.n + 63) >> 6) * 5));
@@ -658,12 +779,13 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     if (ms) *ms = 0;
     if (n == 0) return LF_OK;
     HIPCHK(hipSetDevice(device));
-    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1), cs[7];
-    static hipEvent_t cdone_all[4][7]; static bool cdone_init[4] = { false, false, false, false };
+    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1), cs[LF_NCLASS];
+    static hipEvent_t cdone_all[4][LF_NCLASS]; static bool cdone_init[4] = { false, false, false, false };
     const int lane_id = lfg_get_lane();
     if (!s) return LF_ERR_HIP;
-    for (int k = 0; k < 7; k++) { cs[k] = (hipStream_t)lfg_lane_stream(device, 2 + k); if (!cs[k]) return LF_ERR_HIP; }
-    if (!cdone_init[lane_id]) { for (int k = 0; k < 7; k++) HIPCHK(hipEventCreateWithFlags(&cdone_all[lane_id][k], hipEventDisableTiming)); cdone_init[lane_id] = true; }
+    static const bool serial_classes = getenv("LF_SERIAL_CLASSES") != nullptr;     /* profiling aid: one class at a time */
+    for (int k = 0; k < LF_NCLASS; k++) { cs[k] = serial_classes ? s : (hipStream_t)lfg_lane_stream(device, 2 + k); if (!cs[k]) return LF_ERR_HIP; }
+    if (!cdone_init[lane_id]) { for (int k = 0; k < LF_NCLASS; k++) HIPCHK(hipEventCreateWithFlags(&cdone_all[lane_id][k], hipEventDisableTiming)); cdone_init[lane_id] = true; }
     hipEvent_t *cdone = cdone_all[lane_id];
 #define DSLOT(T, k, bytes) (T *)lfg_dev_slot(device, LF_DS_ALN0 + (k), (bytes))
     lf_aln_desc_t *d_desc = DSLOT(lf_aln_desc_t, 0, (size_t)n * sizeof(lf_aln_desc_t));
@@ -680,7 +802,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     uint64_t *d_misc = DSLOT(uint64_t, 15, 64);
     if (!d_desc || !d_opsoff || !d_keys || !d_keys2 || !d_vals || !d_vals2 || !d_ent || !d_base || !d_probs || !d_ed || !d_end || !d_len || !d_ops || !d_cstart || !d_misc) return LF_ERR_NOMEM;
     size_t tb1 = 0, tb2 = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, d_keys, d_keys2, d_vals, d_vals2, n, 0, 35, s);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, d_keys, d_keys2, d_vals, d_vals2, n, 0, 36, s);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, d_ent, d_base, n, s);
     void *d_tmp = lfg_dev_slot(device, LF_DS_ALN0 + 16, std::max(tb1, tb2) + 256);
     if (!d_tmp) return LF_ERR_NOMEM;
@@ -692,13 +814,13 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     HIPCHK(hipEventRecord(e0, s));
     const unsigned gb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(lf_desc_keys_kernel, dim3(gb), dim3(256), 0, s, d_desc, n, d_keys, d_vals);
-    { size_t tb = tb1; HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 35, s)); }
+    { size_t tb = tb1; HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 36, s)); }
     hipLaunchKernelGGL(lf_desc_bounds_kernel, dim3(1), dim3(64), 0, s, d_keys2, n, d_cstart);
     hipLaunchKernelGGL(lf_desc_entries_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, d_cstart, n, d_ent);
     { size_t tb = tb2; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_ent, d_base, n, s)); }
     hipLaunchKernelGGL(lf_desc_build_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, d_opsoff, d_cstart, d_base, n, d_probs, d_misc);
-    int cstart[8]; uint64_t tail[2], aux_total = 0;
-    HIPCHK(hipMemcpyAsync(cstart, d_cstart, 32, hipMemcpyDeviceToHost, s));
+    int cstart[LF_NCLASS + 1]; uint64_t tail[2], aux_total = 0;
+    HIPCHK(hipMemcpyAsync(cstart, d_cstart, sizeof cstart, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&tail[0], d_base + (n - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&tail[1], d_ent + (n - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&aux_total, d_misc, 8, hipMemcpyDeviceToHost, s));
@@ -712,17 +834,21 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     hipEvent_t eb; HIPCHK(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
     HIPCHK(hipEventRecord(eb, s));
     auto cnt = [&](int c) { return cstart[c + 1] - cstart[c]; };
-    for (int k = 0; k < 7; k++) if (cnt(k) > 0) HIPCHK(hipStreamWaitEvent(cs[k], eb, 0));
+    for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0) HIPCHK(hipStreamWaitEvent(cs[k], eb, 0));
+    /* largest problems first: their few long-running waves start while the small classes fill the rest of the chip */
 #define DW(K, KBV) if (cnt(K) > 0) hipLaunchKernelGGL(lf_edlib_wave_kernel<KBV>, dim3((unsigned)cnt(K)), dim3(64), 0, cs[K], \
         d_probs + cstart[K], cnt(K), S, d_hist, d_ops, d_ed, d_end, d_len, (int32_t *)nullptr, (const uint64_t *)nullptr)
-    DW(6, 4); DW(5, 1);
+    DW(10, 4); DW(9, 1);
     if (cnt(0) > 0)
         hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((cnt(0) + 63) / 64)), dim3(64), 0, cs[0],
                            d_probs + cstart[0], cnt(0), S, d_hist, d_aux, d_ops, d_ed, d_end, d_len, (int32_t *)nullptr, (const uint64_t *)nullptr);
+#define DG(K, GV) if (cnt(K) > 0) hipLaunchKernelGGL(lf_edlib_group_kernel<GV>, dim3((unsigned)((cnt(K) + (64 / GV) - 1) / (64 / GV))), dim3(64), 0, cs[K], \
+        d_probs + cstart[K], cnt(K), S, d_hist, d_ops, d_ed, d_end, d_len)
+    DG(8, 32); DG(7, 16);
 #define DL(K, NBV) if (cnt(K) > 0) hipLaunchKernelGGL(lf_edlib_kernel<NBV>, dim3((unsigned)((cnt(K) + 63) / 64)), dim3(64), 0, cs[K], \
         d_probs + cstart[K], cnt(K), S, d_hist, d_ops, d_ed, d_end, d_len)
-    DL(4, 8); DL(3, 4); DL(2, 2); DL(1, 1);
-    for (int k = 0; k < 7; k++) if (cnt(k) > 0) { HIPCHK(hipEventRecord(cdone[k], cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
+    DL(6, 8); DL(5, 6); DL(4, 4); DL(3, 3); DL(2, 2); DL(1, 1);
+    for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0) { HIPCHK(hipEventRecord(cdone[k], cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipMemcpyAsync(ed, d_ed, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(endloc, d_end, (size_t)n * 4, hipMemcpyDeviceToHost, s));
@@ -746,6 +872,15 @@ extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_des
     D.d_pac = st->view.pac;
     if (!D.d_reads) { lf_set_error("lfg_edlib_desc: no resident read batch"); return LF_ERR_ARG; }
     for (int i = 0; i < n; i += 4096) if (d[i].n == 0 || d[i].m == 0) { lf_set_error("lfg_edlib_desc: empty sequence in a descriptor"); return LF_ERR_ARG; }
+    if (getenv("LF_HIST_STATS")) {       /* debug: where the traceback-history bytes are (by ceil(n/64)) */
+        uint64_t cnt[12] = { 0 }, cells[12] = { 0 }, hist[12] = { 0 };
+        static const uint32_t edge[12] = { 1, 2, 3, 4, 5, 6, 8, 12, 16, 32, 64, 256 };
+        for (int i = 0; i < n; i++) {
+            const uint32_t nb = (d[i].n + 63) >> 6; int c = 0; while (c < 11 && nb > edge[c]) c++;
+            cnt[c]++; cells[c] += (uint64_t)d[i].n * d[i].m; hist[c] += (uint64_t)nb * d[i].m * 16;
+        }
+        for (int c = 0; c < 12; c++) if (cnt[c]) fprintf(stderr, "[lf] hist nb<=%u: %llu problems, %.1f Mcells, %.1f MB exact history\n", edge[c], (unsigned long long)cnt[c], cells[c] / 1e6, hist[c] / 1e6);
+    }
     return run_edlib_desc_gpu(ix->device, n, &D, ed, endloc, ops, ops_len, ops_slot, ops_dev, ms);
 }
 

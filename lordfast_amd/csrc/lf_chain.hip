@@ -58,7 +58,7 @@ extern "C" int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, con
     void *d_len = CSLOT(6, (size_t)n_windows * 4), *d_sc = CSLOT(7, (size_t)n_windows * 4);
 #undef CSLOT
     if (!d_w || !d_seeds || !d_pen || !d_dp || !d_prev || !d_idx || !d_len || !d_sc) return LF_ERR_NOMEM;
-    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 9);
+    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 15);
     if (!s) return LF_ERR_HIP;
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipMemcpyAsync(d_w, W.data(), W.size() * sizeof(lf_chain_win), hipMemcpyHostToDevice, s));
