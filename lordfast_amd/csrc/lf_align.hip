@@ -140,27 +140,43 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
     lf_hist_t *h = hist + pr.hist_base + lane;
     const bool want_path = pr.task == LF_TASK_PATH;
 
-    for (uint32_t c0 = 1; c0 <= m; c0 += 8) {
+    /* The blocks of one column depend on each other through the horizontal carry, and a block depends on itself one
+     * column earlier: one lane alone is a single dependent chain.  Walking the lane's OWN blocks as an anti-diagonal
+     * (time step t: block b works on column t - b, taking the carry block b-1 produced one time step earlier) makes
+     * the NB block steps of a time step independent, so the VALU pipeline sees NB-way ILP per lane even at the 2-4
+     * waves/SIMD these register-heavy classes get.  Blocks above the problem's last one (padding of the size class)
+     * are neither computed nor stored. */
+    int hout[NB]; unsigned char win[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) { hout[b] = 0; win[b] = 0; }
+    const uint32_t steps = m + (uint32_t)lastb;
+    for (uint32_t t0 = 1; t0 <= steps; t0 += 8) {
         /* the 8 target bases of this trip are fetched together: their latency is paid once, not per column */
         unsigned char tcs[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) tcs[k] = (c0 + k <= m) ? T.get(c0 + k - 1) : (unsigned char)0;
+        for (int k = 0; k < 8; k++) tcs[k] = (t0 + k <= m) ? T.get(t0 + k - 1) : (unsigned char)0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const uint32_t c = c0 + k;
-            if (c > m) break;
-            const unsigned char tc = tcs[k];
-            int hin = 1;
+            const uint32_t t = t0 + k;
+            if (t > steps) break;
 #pragma unroll
-            for (int b = 0; b < NB; b++) {
-                const uint64_t Eq = lf_eq_mask(tc, lo[b], hi[b], valid[b], Q, n, b);
-                uint64_t ph, mh;
-                hin = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
-                if (b == lastb) score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
-                /* blocks above the problem's last one are padding of the size class: never read back, not stored */
-                if (want_path && b <= lastb) { lf_hist_t e; e.pv = Pv[b]; e.ph = ph; h[((size_t)(c - 1) * NB + b) * 64] = e; }
+            for (int b = NB - 1; b >= 1; b--) win[b] = win[b - 1];
+            win[0] = tcs[k];
+#pragma unroll
+            for (int b = NB - 1; b >= 0; b--) {
+                const int c = (int)t - b;
+                if (b <= lastb && c >= 1 && c <= (int)m) {
+                    const int hin = b == 0 ? 1 : hout[b > 0 ? b - 1 : 0];
+                    const uint64_t Eq = lf_eq_mask(win[b], lo[b], hi[b], valid[b], Q, n, b);
+                    uint64_t ph, mh;
+                    hout[b] = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
+                    if (b == lastb) {
+                        score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
+                        if (score < best) { best = score; best_c = c; }
+                    }
+                    if (want_path) { lf_hist_t e; e.pv = Pv[b]; e.ph = ph; h[((size_t)(c - 1) * NB + b) * 64] = e; }
+                }
             }
-            if (score < best) { best = score; best_c = (int)c; }
         }
     }
     int ed, tl;
@@ -345,7 +361,8 @@ lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs
                     uint64_t ph, mh;
                     hin = lf_myers_step(Pv[k], Mv[k], Eq, hin, ph, mh);
                     if (b == lastb) score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
-                    if (want_path) { lf_hist_t e; e.pv = Pv[k]; e.ph = ph; h[(size_t)(c - 1) * nbk + b] = e; }
+                    /* history rows follow the sweep: at step s the lanes write ONE contiguous row (s * nbk + block) */
+                    if (want_path) { lf_hist_t e; e.pv = Pv[k]; e.ph = ph; h[(size_t)s * nbk + b] = e; }
                 }
             }
             hout_prev = hin;
@@ -398,7 +415,7 @@ lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs
         const uint32_t blk = (r - 1) >> 6, c0 = c;
         const int col = (int)c0 - lane;
         lf_hist_t e; e.pv = 0; e.ph = 0;
-        if (col >= 1) e = h[(size_t)(col - 1) * nbk + blk];
+        if (col >= 1) e = h[(size_t)(col - 1 + (int)(blk / KB)) * nbk + blk];
         while (r > 0 && c > 0 && ((r - 1) >> 6) == blk && (c0 - c) < 64) {
             const int src = (int)(c0 - c);
             const uint64_t pv = __shfl(e.pv, src), ph = __shfl(e.ph, src);
@@ -430,7 +447,7 @@ lf_edlib_group_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
                       uint8_t *__restrict__ ops, int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
 {
     constexpr int P = 64 / G;                      /* problems per wave = sub-iterations per 64-row block */
-    constexpr int TCAP = LF_WAVE_LDS_T / P;
+    constexpr int TCAP = G * 72;                   /* LDS bytes of target per group: covers m <= 1.125 n; longer targets read HBM */
     const int lane = threadIdx.x, g = lane / G, gl = lane % G;
     const int pi = (int)blockIdx.x * P + g;
     const bool live = pi < n_probs;
@@ -458,7 +475,7 @@ lf_edlib_group_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
             }
         }
     }
-    __shared__ unsigned char s_t[LF_WAVE_LDS_T];
+    __shared__ unsigned char s_t[64 * 72];
     unsigned char *my_t = s_t + g * TCAP;
     const bool t_lds = m <= (uint32_t)TCAP;
     if (t_lds) { for (uint32_t j = (uint32_t)gl; j < m; j += G) my_t[j] = T.get(j); }
@@ -477,7 +494,7 @@ lf_edlib_group_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
             const int hin = gl == 0 ? 1 : from_left;
             hout_prev = lf_myers_step(Pv, Mv, Eq, hin, ph, mh);
             if ((uint32_t)gl == lastb) { score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1); if (score < best) { best = score; best_c = c; } }
-            if (live) { lf_hist_t e; e.pv = Pv; e.ph = ph; h[(size_t)(c - 1) * nbk + gl] = e; }
+            if (live) { lf_hist_t e; e.pv = Pv; e.ph = ph; h[(size_t)s * nbk + gl] = e; }      /* row s = column - 1 + block: contiguous per group */
         }
     }
     const int src_last = g * G + (int)lastb;
@@ -495,7 +512,7 @@ lf_edlib_group_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
         const uint32_t blk = (r - 1) >> 6, c0 = c;
         const int col = (int)c0 - gl;
         lf_hist_t e; e.pv = 0; e.ph = 0;
-        if (col >= 1) e = h[(size_t)(col - 1) * nbk + blk];
+        if (col >= 1) e = h[(size_t)(col - 1 + (int)blk) * nbk + blk];
         while (r > 0 && c > 0 && ((r - 1) >> 6) == blk && (c0 - c) < (uint32_t)G) {
             const int src = g * G + (int)(c0 - c);
             const uint64_t pv = __shfl(e.pv, src), ph = __shfl(e.ph, src);
@@ -616,7 +633,7 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
         const size_t nbk = (pr.n + 63) / 64;
         if (k == 0) { pr.aux_off = aux_words; aux_words += nbk * 5; }
         pr.hist_base = hist_entries;
-        if (pr.task == LF_TASK_PATH) hist_entries += (size_t)pr.m * nbk;
+        if (pr.task == LF_TASK_PATH) hist_entries += ((size_t)pr.m + nbk) * nbk;     /* wave kernels: m + lanes - 1 rows */
     }
     for (int k : {5, 6}) sort_by_m(P[k], true);
     std::sort(P[0].begin(), P[0].end(), [](const lf_aln_prob &a, const lf_aln_prob &b) {
@@ -750,7 +767,7 @@ __global__ void lf_desc_entries_kernel(const uint64_t *__restrict__ keys, const 
             int last = j + 63; if (last > cstart[c + 1] - 1) last = cstart[c + 1] - 1;
             e = 64ull * (uint32_t)keys[last] * (uint32_t)lf_class_nb(c);
         }
-    } else { const uint32_t nn = d[vals[j]].n; e = (uint64_t)(uint32_t)keys[j] * ((nn + 63) >> 6); }
+    } else { const uint32_t nb = (d[vals[j]].n + 63) >> 6; e = ((uint64_t)(uint32_t)keys[j] + nb) * nb; }      /* m + lanes - 1 rows of nb entries */
     ent[j] = e;
 }
 __global__ void lf_desc_build_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const lf_aln_desc_t *__restrict__ d,

@@ -1863,7 +1863,7 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
     pthread_mutex_lock(&g_map_lock);
     g_phase_on = getenv("LF_PHASES") != NULL;
     /* chunks in flight: the host phases of one overlap the GPU phases of the others */
-    int n_lanes = nt >= 8 ? 3 : (nt >= 3 ? 2 : 1);
+    int n_lanes = nt >= 8 ? 4 : (nt >= 3 ? 2 : 1);
     if (getenv("LF_LANES")) { n_lanes = atoi(getenv("LF_LANES")); if (n_lanes < 1) n_lanes = 1; if (n_lanes > LF_MAX_LANES) n_lanes = LF_MAX_LANES; if (n_lanes > 1 && nt < n_lanes + 1) n_lanes = 1; }
     if (getenv("LF_ONE_LANE")) n_lanes = 1;
     const int nw = nt - n_lanes;                       /* pool workers; the lane drivers work too */

@@ -227,41 +227,55 @@ __global__ void lf_seed_accept_kernel(int n_reads, uint32_t hash_count, uint32_t
 }
 
 /* locate: rows sp..sp+cnt-1 of every accepted sample -> (tPos, qPos|len<<20, strand) in sample order then
- * SA-row order (src/BWT.cpp:348-384) */
+ * SA-row order (src/BWT.cpp:348-384).
+ * A wavefront owns 64 consecutive samples and spreads ITS HITS (not its samples) over the lanes: hit h of the wave
+ * belongs to the last sample whose first hit is <= h (hit_off is the global exclusive scan, so the wave's output is
+ * one contiguous range).  Output writes are fully coalesced, suffix-array reads are contiguous within a sample, and
+ * a repeat with 999 hits no longer serialises 63 idle lanes behind it. */
 __global__ void __launch_bounds__(256)
 lf_seed_locate_kernel(lf_dev_index ix, int n_reads, const uint64_t *__restrict__ off, uint32_t hash_count,
                       const uint32_t *__restrict__ pos, const lf_sample_t *__restrict__ smp, const uint32_t *__restrict__ cnt,
                       const uint64_t *__restrict__ hit_off, uint32_t *__restrict__ tpos, uint32_t *__restrict__ qpl,
                       uint8_t *__restrict__ strand, unsigned long long *__restrict__ counters)
 {
+    __shared__ uint64_t s_sp[256]; __shared__ uint32_t s_rel[256], s_m[256], s_p[256], s_ql[256];
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)n_reads * hash_count;
+    const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
     uint32_t n_blk = 0, n_sa = 0;
-    if (gid < total) {
-        const uint32_t c = cnt[gid];
-        if (c) {
-            const int r = (int)(gid / hash_count);
-            const uint32_t i = (uint32_t)(gid % hash_count);
-            const uint32_t qLen = (uint32_t)(off[r + 1] - off[r]);
-            const uint32_t p = pos[(size_t)i * n_reads + r];
-            const lf_sample_t s = smp[gid];
-            const uint64_t o = hit_off[gid];
-            const uint64_t l_pac = (uint64_t)ix.l_pac;
-            for (uint32_t j = 0; j < c; j++) {
-                const uint64_t row = s.sp + j;
-                uint64_t sapos = ix.sa_full ? ix.sa_full[row] : lf_sa_walk(ix, row, n_blk);
-                n_sa++;
-                uint32_t t, qp; uint8_t rv;
-                if (sapos >= l_pac) { t = (uint32_t)((l_pac << 1) - sapos - s.m); qp = qLen - p - s.m; rv = 1; }
-                else { t = (uint32_t)sapos; qp = p; rv = 0; }
-                tpos[o + j] = t;
-                qpl[o + j] = (qp & 0xFFFFFu) | ((s.m & 0xFFFu) << 20);
-                strand[o + j] = rv;
-            }
-        }
+    const uint64_t l_pac = (uint64_t)ix.l_pac;
+    uint32_t c = 0; uint64_t o = 0;
+    if (gid < total) { c = cnt[gid]; o = hit_off[gid]; }
+    else o = hit_off[total];
+    const uint64_t o0 = __shfl(o, 0);
+    const uint32_t Tw = (uint32_t)(__shfl(o, 63) - o0) + __shfl(c, 63);
+    if (Tw == 0) return;
+    if (c) {
+        const int r = (int)(gid / hash_count);
+        const uint32_t i = (uint32_t)(gid % hash_count);
+        const lf_sample_t s = smp[gid];
+        s_sp[threadIdx.x] = s.sp; s_m[threadIdx.x] = s.m; s_p[threadIdx.x] = pos[(size_t)i * n_reads + r]; s_ql[threadIdx.x] = (uint32_t)(off[r + 1] - off[r]);
     }
-    for (int o = 32; o > 0; o >>= 1) { n_blk += __shfl_down(n_blk, o); n_sa += __shfl_down(n_sa, o); }
-    if ((threadIdx.x & 63) == 0 && (n_blk | n_sa)) { atomicAdd(&counters[1], (unsigned long long)n_blk); atomicAdd(&counters[2], (unsigned long long)n_sa); }
+    s_rel[threadIdx.x] = (uint32_t)(o - o0);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (uint32_t h = (uint32_t)lane; h < Tw; h += 64) {
+        int lo = 0, hi = 63;                         /* last sample of the wave whose first hit is <= h */
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_rel[wbase + mid] <= h) lo = mid; else hi = mid - 1; }
+        const int k = wbase + lo;
+        const uint32_t j = h - s_rel[k], m = s_m[k], p = s_p[k], qLen = s_ql[k];
+        const uint64_t row = s_sp[k] + j;
+        const uint64_t sapos = ix.sa_full ? ix.sa_full[row] : lf_sa_walk(ix, row, n_blk);
+        n_sa++;
+        uint32_t t, qp; uint8_t rv;
+        if (sapos >= l_pac) { t = (uint32_t)((l_pac << 1) - sapos - m); qp = qLen - p - m; rv = 1; }
+        else { t = (uint32_t)sapos; qp = p; rv = 0; }
+        tpos[o0 + h] = t;
+        qpl[o0 + h] = (qp & 0xFFFFFu) | ((m & 0xFFFu) << 20);
+        strand[o0 + h] = rv;
+    }
+    for (int d = 32; d > 0; d >>= 1) { n_blk += __shfl_down(n_blk, d); n_sa += __shfl_down(n_sa, d); }
+    if (lane == 0 && (n_blk | n_sa)) { atomicAdd(&counters[1], (unsigned long long)n_blk); atomicAdd(&counters[2], (unsigned long long)n_sa); }
 }
 
 struct lf_widen_op { __host__ __device__ uint64_t operator()(uint32_t x) const { return (uint64_t)x; } };
