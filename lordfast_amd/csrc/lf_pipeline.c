@@ -1475,7 +1475,13 @@ static int map_chunk(ctx_t *cx)
     double tstage[8] = { 0 };
     t1 = now_ms(); st->ms_seed += t1 - t0; tstage[0] = t1 - t0; t0 = t1;
 
-    if (!cx->host_vote) {
+    /* a chunk whose hit count does not fit the device stage's 32-bit sort sizes votes on the host (pathological input) */
+    int host_vote = cx->host_vote;
+    if (!host_vote && (hits.n_hits >= (1ull << 30) || getenv("LF_TEST_VOTE_FALLBACK"))) {
+        if (hits.n_hits) { rc = lfg_seed_fetch_hits(cx->ix, &hits); if (rc != LF_OK) return rc; }
+        host_vote = 1; cx->host_vote = 1;           /* this chunk only: lane_main resets it */
+    }
+    if (!host_vote) {
         /* ---- B + C on the device: votes -> candidate windows -> sorted requests -> chains; only chains come back ---- */
         uint32_t max_len = 0;
         for (int i = 0; i < n; i++) if (cx->reads[i].len > max_len) max_len = cx->reads[i].len;
@@ -1487,6 +1493,7 @@ static int map_chunk(ctx_t *cx)
         if (rc != LF_OK) return rc;
         cx->n_creq = cx->vc.n_req; cx->chain_len = cx->vc.chain_len; cx->chain_score = cx->vc.chain_score;
         st->ms_k_vote += cx->vc.ms_vote; st->ms_k_chain += cx->vc.ms_chain; st->n_chain_problems += (uint64_t)cx->vc.n_req;
+        st->n_req_seeds += cx->vc.n_req_seeds; st->n_tie_requests += cx->vc.n_tie_req;
         parallel_for(cx, n, phase_select);
         t1 = now_ms(); st->ms_vote += t1 - t0; tstage[1] = t1 - t0; t0 = t1;
         parallel_for(cx, n, phase_fine_select);
@@ -1758,7 +1765,7 @@ static void merge_stats(lf_stats_t *d, const lf_stats_t *a)
     d->n_edlib_problems += a->n_edlib_problems; d->n_ksw_problems += a->n_ksw_problems; d->n_cache += a->n_cache; d->n_occblk += a->n_occblk;
     d->n_sa += a->n_sa; d->n_readbytes += a->n_readbytes; d->ext_bytes += a->ext_bytes; d->edlib_launches += a->edlib_launches;
     d->search_launches += a->search_launches; d->locate_launches += a->locate_launches;
-    d->ms_render += a->ms_render; d->ms_k_render += a->ms_k_render; d->ms_k_vote += a->ms_k_vote; d->render_bytes += a->render_bytes; d->render_launches += a->render_launches;
+    d->ms_render += a->ms_render; d->ms_k_render += a->ms_k_render; d->ms_k_vote += a->ms_k_vote; d->n_req_seeds += a->n_req_seeds; d->n_tie_requests += a->n_tie_requests; d->render_bytes += a->render_bytes; d->render_launches += a->render_launches;
 }
 
 static void *lane_main(void *arg_)

@@ -255,6 +255,7 @@ __global__ void lf_chain_gather_kernel(int n_req, const uint64_t *__restrict__ r
 }
 struct lf_big_op { __host__ __device__ uint64_t operator()(uint32_t n) const { return n > LF_CHAIN_LDS_MAX ? (uint64_t)n : 0ull; } };
 struct lf_w32 { __host__ __device__ uint64_t operator()(uint32_t v) const { return v; } };
+struct lf_w8 { __host__ __device__ uint64_t operator()(uint8_t v) const { return v; } };
 
 /* penalty table, evaluated exactly as score_penalty does (src/Chain.cpp:224) with the host libm; cached per device */
 static int pen_table(int device, const lf_params_t *p, uint64_t want, hipStream_t s, const double **d_pen, uint32_t *pen_n)
@@ -419,6 +420,7 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     uint32_t *d_cidx = (uint32_t *)VSLOT(14, S * 4 + 64);
     double *d_dp = (double *)VSLOT(15, WS * 8 + 64); int *d_prev = (int *)VSLOT(16, WS * 4 + 64);
     if (!d_gath || !d_sorted || !d_sk || !d_sk2 || !d_cidx || !d_dp || !d_prev) return LF_ERR_NOMEM;
+    bool have_ties = false;
     if (S) {
         hipLaunchKernelGGL(lf_req_gather_kernel<true>, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_req_read, d_req_win, d_req_lo, d_req_hi, d_read_off,
                            d_tpos, d_qpl, d_strand, d_req_n, (const uint64_t *)d_req_off, d_gath, d_sk);
@@ -431,6 +433,12 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
         HIPCHK(hipMemsetAsync(d_flag, 0, Q, s));
         hipLaunchKernelGGL(lf_tie_flag_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, S, d_sk2, d_flag);
         hipLaunchKernelGGL(lf_tie_sort_kernel, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_flag, d_req_off, d_req_n, d_gath, d_sorted);
+        {   /* how many requests needed the introsort replay (statistics) */
+            size_t tbf = 0; uint64_t *d_nt = (uint64_t *)d_nruns + 1;
+            hipcub::TransformInputIterator<uint64_t, lf_w8, uint8_t *> f64(d_flag, lf_w8());
+            (void)hipcub::DeviceReduce::Sum(nullptr, tbf, f64, d_nt, (int)n_req, s);
+            if (tbf <= tb4) { HIPCHK(hipcub::DeviceReduce::Sum(d_tmp3, tbf, f64, d_nt, (int)n_req, s)); HIPCHK(hipMemcpyAsync(h_small + 8, d_nt, 8, hipMemcpyDeviceToHost, s)); have_ties = true; }
+        }
     }
     /* ---- chains ---- */
     uint64_t max_d = 4ull * max_read_len + 8192;
@@ -479,6 +487,7 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     out->chain_off[Q] = C; out->req0[R] = n_req;
+    out->n_tie_req = have_ties ? h_small[8] : 0;
     out->n_chain_seeds = C;
     HIPCHK(hipEventElapsedTime(&out->ms_vote, e0, e1));
     HIPCHK(hipEventElapsedTime(&out->ms_chain, e1, e2));

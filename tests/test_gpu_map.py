@@ -40,6 +40,7 @@ def test_sam_golden(lf, golden_reads, cfg):
     assert sam == exp, first_diff(sam, exp)
     assert st["n_reads"] == len(seqs) and st["n_edlib_problems"] > 0 and st["n_chain_problems"] > 0
     assert st["n_ksw_problems"] > 0, "fixture must reach the ksw clip/split branch"
+    print("tie requests:", st["n_tie_requests"], "of", st["n_chain_problems"])
 
 
 def test_sam_host_cigar_crosscheck(lf, golden_reads, monkeypatch):
@@ -67,6 +68,14 @@ def test_sam_host_vote_crosscheck(lf, golden_reads, monkeypatch, cfg):
     sam, st = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
     exp = golden_sam(cfg)
     assert sam == exp, first_diff(sam, exp)
+
+
+def test_sam_vote_fallback_after_device_seeding(lf, golden_reads, monkeypatch):
+    """a chunk with too many hits for the device vote stage copies its hits back and votes on the host"""
+    names, seqs = golden_reads
+    monkeypatch.setenv("LF_TEST_VOTE_FALLBACK", "1")
+    sam, st = lf.map_batch(names, seqs)
+    assert sam == golden_sam("default")
 
 
 def test_map_batch_into_caller_buffer(lf, golden_reads):
@@ -155,4 +164,39 @@ def test_sam_vs_oracle_big(big_case, oracle_lib, kw):
     orc = oracle_lib.Oracle(fa)
     exp = orc.map_batch(names, seqs, params=oracle_lib.default_params(threads=8, **kw))
     orc.close()
+    assert sam == exp, first_diff(sam, exp)
+
+
+def test_sam_tandem_repeats_tie_order(tmp_path, oracle_lib):
+    """Tandem duplications make one read sample hit two places of the same candidate window: equal qPos inside a chain
+    request.  std::sort's (unstable) order of those ties reaches the chain DP, so the GPU path must replay libstdc++'s
+    introsort for such requests (lf_tie_sort_kernel) -- checked against the oracle, and the replay must really run."""
+    import lordfast_amd as la
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    contigs = []
+    for ci in range(2):
+        parts = []
+        for _ in range(12):
+            parts.append(acgt[rng.integers(0, 4, size=int(rng.integers(6000, 9000)))])
+            unit = acgt[rng.integers(0, 4, size=int(rng.integers(400, 1500)))]
+            copies = int(rng.integers(2, 4))
+            for k in range(copies):
+                u = unit.copy()
+                nmut = max(1, len(u) // 200)                       # copies differ a little, like real tandem repeats
+                u[rng.integers(0, len(u), size=nmut)] = acgt[rng.integers(0, 4, size=nmut)]
+                parts.append(u)
+        parts.append(acgt[rng.integers(0, 4, size=7000)])
+        contigs.append((f"tr{ci}", np.concatenate(parts)))
+    fa = la.index_build(contigs, str(tmp_path / "tandem.fa"))
+    reads = synth.make_reads(contigs, 120, 5000, 0.12, seed=3) + synth.make_reads(contigs, 40, 9000, 0.15, seed=4)
+    names = [r[0].encode() for r in reads]
+    seqs = [r[1] for r in reads]
+    h = la.LordFast(fa, device=0)
+    sam, st = h.map_batch(names, seqs)
+    h.close()
+    orc = oracle_lib.Oracle(fa)
+    exp = orc.map_batch(names, seqs, params=oracle_lib.default_params(threads=8))
+    orc.close()
+    assert st["n_tie_requests"] > 0, "the fixture must produce chain requests with equal qPos"
     assert sam == exp, first_diff(sam, exp)
