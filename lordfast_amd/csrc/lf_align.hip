@@ -1003,27 +1003,33 @@ extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff
         p.w = prm[7 * i + 4]; p.zdrop = prm[7 * i + 5]; p.h0 = prm[7 * i + 6]; p.id = i;
         p.ws_off = ws; ws += 2 * ((size_t)p.qlen + 2);
     }
-    lf_dev_buf d_q, d_t, d_p, d_ws, d_s, d_ql, d_tl;
-    HIPCHK(d_q.alloc(qoff[n] + 16)); HIPCHK(d_t.alloc(toff[n] + 16)); HIPCHK(d_p.alloc(P.size() * sizeof(lf_ksw_prob)));
-    HIPCHK(d_ws.alloc(ws * 4 + 16)); HIPCHK(d_s.alloc((size_t)n * 4)); HIPCHK(d_ql.alloc((size_t)n * 4)); HIPCHK(d_tl.alloc((size_t)n * 4));
-    hipStream_t s; HIPCHK(hipStreamCreate(&s));
+    /* persistent slots and the lane's stream: no hipMalloc / hipFree (hipFree synchronises the whole device, which
+     * would stall the other chunks in flight) */
+#define KSLOT(T, k, bytes) (T *)lfg_dev_slot(device, LF_DS_KSW0 + (k), (bytes))
+    uint8_t *d_q = KSLOT(uint8_t, 0, qoff[n] + 16), *d_t = KSLOT(uint8_t, 1, toff[n] + 16);
+    lf_ksw_prob *d_p = KSLOT(lf_ksw_prob, 2, P.size() * sizeof(lf_ksw_prob));
+    int32_t *d_ws = KSLOT(int32_t, 3, ws * 4 + 16), *d_s = KSLOT(int32_t, 4, (size_t)n * 4), *d_ql = KSLOT(int32_t, 5, (size_t)n * 4), *d_tl = KSLOT(int32_t, 6, (size_t)n * 4);
+#undef KSLOT
+    if (!d_q || !d_t || !d_p || !d_ws || !d_s || !d_ql || !d_tl) return LF_ERR_NOMEM;
+    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 14);
+    if (!s) return LF_ERR_HIP;
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipMemcpyAsync(d_q.p, q, qoff[n], hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_t.p, t, toff[n], hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_p.p, P.data(), P.size() * sizeof(lf_ksw_prob), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_q, q, qoff[n], hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_t, t, toff[n], hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_p, P.data(), P.size() * sizeof(lf_ksw_prob), hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(e0, s));
     int qmax = 0;
     for (int i = 0; i < n; i++) qmax = std::max(qmax, P[i].qlen);
     const int lds_q = std::min(qmax, 6000);
-    hipLaunchKernelGGL(lf_ksw_kernel, dim3((unsigned)n), dim3(64), (size_t)(2 * (lds_q + 2)) * 4, s, d_p.as<lf_ksw_prob>(), n, d_q.as<uint8_t>(),
-                       d_t.as<uint8_t>(), d_ws.as<int32_t>(), d_s.as<int32_t>(), d_ql.as<int32_t>(), d_tl.as<int32_t>(), lds_q);
+    hipLaunchKernelGGL(lf_ksw_kernel, dim3((unsigned)n), dim3(64), (size_t)(2 * (lds_q + 2)) * 4, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
+                       (const uint8_t *)d_t, d_ws, d_s, d_ql, d_tl, lds_q);
     HIPCHK(hipEventRecord(e1, s));
-    HIPCHK(hipMemcpyAsync(score, d_s.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(qle, d_ql.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(tle, d_tl.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(score, d_s, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(qle, d_ql, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(tle, d_tl, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return LF_OK;
 }

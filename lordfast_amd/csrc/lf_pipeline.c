@@ -236,6 +236,7 @@ typedef struct ctx {
     const lfg_hits_t *hits;
     /* scratch for the parallel merge of staged alignment requests */
     lf_aln_desc_t *mg_desc; char *mg_qb, *mg_tb; uint64_t *mg_qoff, *mg_toff, *mg_qbase, *mg_tbase; uint8_t *mg_mode; int *mg_gbase; ed_round_t *mg_R; int mg_round;
+    struct { const char *label; double t; } marks[96]; int n_marks; int timing;     /* LF_TIMING=1: per-chunk timeline */
     int host_vote;                  /* LF_HOST_VOTE=1: vote / select / sort on the host from copied-back hits (cross-check) */
     lfg_vc_t vc;                    /* device path: modes, requests and chains of this chunk */
     int host_cigar;                 /* LF_HOST_CIGAR=1: build CIGAR / MD on the host from copied-back paths (cross-check) */
@@ -1432,6 +1433,18 @@ static void phase_sam_print(ctx_t *cx, int tid, int ri)
     print_sam_entry(cx, r, r->mode < 2 ? 1 : (r->mode == 2 ? 1 : r->nWins));
 }
 
+static inline void tmark(ctx_t *cx, const char *label)
+{
+    if (cx->timing && cx->n_marks < 96) { cx->marks[cx->n_marks].label = label; cx->marks[cx->n_marks].t = now_ms(); cx->n_marks++; }
+}
+static void tmark_dump(ctx_t *cx, double t_begin)
+{
+    if (!cx->timing) return;
+    char line[4096]; int o = 0; double prev = t_begin;
+    for (int k = 0; k < cx->n_marks && o < 3900; k++) { o += snprintf(line + o, sizeof line - (size_t)o, " %s %.1f", cx->marks[k].label, cx->marks[k].t - prev); prev = cx->marks[k].t; }
+    fprintf(stderr, "[lf] lane %d timeline (ms per step, start t=%.1f):%s\n", cx->lane, t_begin, line);
+}
+
 /* ---------------------------------------------------------------- one chunk of reads through all stages */
 static int map_chunk(ctx_t *cx)
 {
@@ -1440,8 +1453,11 @@ static int map_chunk(ctx_t *cx)
     int rc = LF_OK;
     double t0 = now_ms(), t1;
     const int timing = getenv("LF_TIMING") != NULL, timing0 = timing;
+    cx->timing = timing; cx->n_marks = 0;
+    const double t_begin = t0;
 
     parallel_for(cx, n, phase_prepare);
+    tmark(cx, "prepare");
     if (getenv("LF_TIMING")) fprintf(stderr, "[lf] prepare %.1f ms\n", now_ms() - t0);
 
     /* ---- A: seeds ---- */
@@ -1460,9 +1476,11 @@ static int map_chunk(ctx_t *cx)
             cx->seed_map = map; cx->cat = cat; cx->cat_off = off;
             double tc0 = now_ms();
             parallel_for(cx, m, phase_concat);
+            tmark(cx, "concat");
             if (getenv("LF_TIMING")) fprintf(stderr, "[lf] concat %.1f ms\n", now_ms() - tc0);
             tc0 = now_ms();
             rc = lfg_seed(cx->ix, cx->p, m, cat, off, cx->host_vote, &hits);
+            tmark(cx, "SEED");
             if (getenv("LF_TIMING")) fprintf(stderr, "[lf] lfg_seed %.1f ms (search %.1f locate %.1f), %llu hits\n", now_ms() - tc0, hits.ms_search, hits.ms_locate, (unsigned long long)hits.n_hits);
             if (rc != LF_OK) { free(map); return rc; }
             st->n_seeds += hits.n_hits; st->n_cache += hits.counters[0]; st->n_occblk += hits.counters[1]; st->n_sa += hits.counters[2]; st->n_readbytes += hits.counters[3];
@@ -1490,6 +1508,7 @@ static int map_chunk(ctx_t *cx)
         rc = lfg_vote_chain(cx->ix, cx->p, m, hits.n_hits, max_len, &cx->vc);
         if (timing0) fprintf(stderr, "[lf] lfg_vote_chain %.1f ms (vote %.1f chain %.1f), %d requests, %llu request seeds, %llu chain seeds\n", now_ms() - t0,
                              cx->vc.ms_vote, cx->vc.ms_chain, cx->vc.n_req, (unsigned long long)cx->vc.n_req_seeds, (unsigned long long)cx->vc.n_chain_seeds);
+        tmark(cx, "VOTECHAIN");
         if (rc != LF_OK) return rc;
         cx->n_creq = cx->vc.n_req; cx->chain_len = cx->vc.chain_len; cx->chain_score = cx->vc.chain_score;
         st->ms_k_vote += cx->vc.ms_vote; st->ms_k_chain += cx->vc.ms_chain; st->n_chain_problems += (uint64_t)cx->vc.n_req;
@@ -1498,6 +1517,7 @@ static int map_chunk(ctx_t *cx)
         t1 = now_ms(); st->ms_vote += t1 - t0; tstage[1] = t1 - t0; t0 = t1;
         parallel_for(cx, n, phase_fine_select);
         parallel_for(cx, n, phase_make_jobs);
+        tmark(cx, "select+jobs");
         t1 = now_ms(); st->ms_chain += t1 - t0; tstage[2] = t1 - t0; t0 = t1;
         goto extend;
     }
@@ -1554,6 +1574,7 @@ extend:
     for (int round = 0; round < 64; round++) {
         double tw0 = now_ms();
         parallel_for(cx, n, phase_walk);
+        tmark(cx, "walk");
         if (timing) fprintf(stderr, "[lf] round %d walk %.1f ms\n", round, now_ms() - tw0);
         int ne = 0, nk = 0, nd = 0;
         for (int t = 0; t < nt; t++) { ne += cx->stages[t].n; nk += cx->stages[t].kn; nd += cx->stages[t].dn; }
@@ -1583,12 +1604,14 @@ extend:
             cx->mg_desc = desc; cx->mg_R = &R; cx->mg_qbase = obase; cx->mg_gbase = gbase; cx->mg_round = ridx;
             double tm0 = now_ms();
             parallel_for(cx, nt, phase_merge_desc);
+            tmark(cx, "merge");
             free(obase); free(gbase);
             float ms = 0;
             void *dops = NULL;
             rc = lfg_edlib_desc(cx->ix, nd, desc, R.ops_off, ops_total, R.ed, R.end, R.ops, R.ops_len,
                                 LF_DS_RND0 + 2 * (ridx < LF_MAX_ED_ROUNDS ? ridx : 0), &dops, &ms);
             if (!host_ops) R.d_ops = (uint8_t *)dops;
+            tmark(cx, "EDLIB");
             if (timing) fprintf(stderr, "[lf] round %d: %d descriptor problems, merge+solve %.1f ms (kernels %.1f ms), ops %.1f MB\n", round, nd, now_ms() - tm0, ms, ops_total / 1e6);
             cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
             cx->ed_rounds[cx->n_ed_rounds++] = R;
@@ -1625,6 +1648,7 @@ extend:
             float ms = 0; uint64_t launches = 0;
             double ts0 = now_ms();
             rc = lf_edlib_solve(cx->ix->device, ne, qb, qoff, tb, toff, mode, R.ed, R.end, R.ops, R.ops_len, &ms, &launches);
+            tmark(cx, "HIRSCH");
             if (timing) fprintf(stderr, "[lf] round %d edlib solve %.1f ms (kernels %.1f ms)\n", round, now_ms() - ts0, ms);
             free(qoff); free(toff); free(mode);
             cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
@@ -1657,6 +1681,7 @@ extend:
             qoff[nk] = qo; toff[nk] = to;
             float ms = 0;
             rc = lfg_ksw(cx->ix->device, nk, qb, qoff, tb, toff, prm, R.score, R.qle, R.tle, &ms);
+            tmark(cx, "KSW");
             free(qb); free(tb); free(qoff); free(toff); free(prm);
             cx->ksw_rounds = (ksw_round_t *)realloc(cx->ksw_rounds, ((size_t)cx->n_ksw_rounds + 1) * sizeof(ksw_round_t));
             cx->ksw_rounds[cx->n_ksw_rounds++] = R;
@@ -1696,7 +1721,9 @@ extend:
                 round_ops[k] = Rk->d_ops;
             }
             float ms = 0; uint64_t tbytes = 0;
+            tmark(cx, "recipe");
             rc = lfg_render(cx->ix, n_recs, recs, n_items, items, round_ops, &cx->rtext, &cx->roffs, &tbytes, &ms);
+            tmark(cx, "RENDER");
             if (timing) fprintf(stderr, "[lf] render: %d records, %llu pieces, %.1f MB text, kernels %.1f ms, total %.1f ms\n", n_recs, (unsigned long long)n_items, tbytes / 1e6, ms, now_ms() - t0);
             if (rc != LF_OK) { free(ibase); return rc; }
             st->ms_k_render += ms; st->render_bytes += tbytes; st->render_launches += 1;
@@ -1711,6 +1738,8 @@ extend:
     cx->out_base = NULL;
     parallel_for(cx, n, phase_sam_print);
     t1 = now_ms(); st->ms_sam += t1 - t0; tstage[5] = t1 - t0;
+    tmark(cx, "samcount");
+    tmark_dump(cx, t_begin);
     if (timing) fprintf(stderr, "[lf] lane %d chunk of %d reads: seed %.1f vote %.1f chain %.1f extend %.1f render %.1f sam-count %.1f ms (t=%.1f)\n",
                         cx->lane, n, tstage[0], tstage[1], tstage[2], tstage[3], tstage[4], tstage[5], now_ms());
     return LF_OK;
