@@ -1433,6 +1433,23 @@ static void phase_sam_print(ctx_t *cx, int tid, int ri)
     print_sam_entry(cx, r, r->mode < 2 ? 1 : (r->mode == 2 ? 1 : r->nWins));
 }
 
+/* Hirschberg-size problems of one round, solved by lf_edlib_solve on the calling thread or on a helper thread */
+typedef struct {
+    int device, lane, n; const char *q, *t; const uint64_t *qoff, *toff; const uint8_t *mode;
+    int32_t *ed, *end; uint8_t *ops; uint32_t *ops_len;
+    int rc; float ms; uint64_t launches; char err[512];
+} hsolve_t;
+static void *hsolve_main(void *arg)
+{
+    hsolve_t *H = (hsolve_t *)arg;
+    const int prev = lfg_get_lane();
+    lfg_set_lane(H->lane);
+    H->rc = lf_edlib_solve(H->device, H->n, H->q, H->qoff, H->t, H->toff, H->mode, H->ed, H->end, H->ops, H->ops_len, &H->ms, &H->launches);
+    if (H->rc != LF_OK) snprintf(H->err, sizeof H->err, "%s", lf_last_error());
+    lfg_set_lane(prev);
+    return NULL;
+}
+
 static inline void tmark(ctx_t *cx, const char *label)
 {
     if (cx->timing && cx->n_marks < 96) { cx->marks[cx->n_marks].label = label; cx->marks[cx->n_marks].t = now_ms(); cx->n_marks++; }
@@ -1579,45 +1596,13 @@ extend:
         int ne = 0, nk = 0, nd = 0;
         for (int t = 0; t < nt; t++) { ne += cx->stages[t].n; nk += cx->stages[t].kn; nd += cx->stages[t].dn; }
         if (ne == 0 && nk == 0 && nd == 0) break;
-        if (nd) {
-            /* descriptor requests: nothing but 32-byte descriptors goes to the GPU */
-            uint64_t *obase = (uint64_t *)malloc((size_t)nt * 8); int *gbase = (int *)malloc((size_t)nt * sizeof(int));
-            uint64_t ops_total = 0;
-            { int g0 = 0; for (int t = 0; t < nt; t++) { obase[t] = ops_total; gbase[t] = g0; ops_total += cx->stages[t].dops_total; g0 += cx->stages[t].dn; st->ext_bytes += cx->stages[t].ext_bytes; cx->stages[t].ext_bytes = 0; } }
-            const int ridx = cx->n_ed_rounds;
-            const int pin = ridx < 16;
-            ed_round_t R; memset(&R, 0, sizeof R);
-            R.n = nd; R.pinned = pin; R.ops_bytes = ops_total;
-            /* the edit paths stay in HBM (slot of this round) unless the host builds the strings itself */
-            const int host_ops = cx->host_cigar || ridx >= LF_MAX_ED_ROUNDS;
-            if (pin) {
-                R.ed = (int32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx, (size_t)nd * 4); R.end = (int32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 1, (size_t)nd * 4);
-                R.ops_len = (uint32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 2, (size_t)nd * 4);
-                if (host_ops) R.ops = (uint8_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 3, ops_total + 1);
-            } else {
-                R.ed = (int32_t *)malloc((size_t)nd * 4); R.end = (int32_t *)malloc((size_t)nd * 4);
-                R.ops_len = (uint32_t *)malloc((size_t)nd * 4); R.ops = (uint8_t *)malloc(ops_total + 1);
-            }
-            R.ops_off = (uint64_t *)malloc((size_t)nd * 8);
-            lf_aln_desc_t *desc = (lf_aln_desc_t *)lfg_pin_slot(LF_PS_ALN_PROB, (size_t)nd * sizeof(lf_aln_desc_t));
-            if (!desc || !R.ed || !R.end || !R.ops_len || (host_ops && !R.ops)) return LF_ERR_NOMEM;
-            cx->mg_desc = desc; cx->mg_R = &R; cx->mg_qbase = obase; cx->mg_gbase = gbase; cx->mg_round = ridx;
-            double tm0 = now_ms();
-            parallel_for(cx, nt, phase_merge_desc);
-            tmark(cx, "merge");
-            free(obase); free(gbase);
-            float ms = 0;
-            void *dops = NULL;
-            rc = lfg_edlib_desc(cx->ix, nd, desc, R.ops_off, ops_total, R.ed, R.end, R.ops, R.ops_len,
-                                LF_DS_RND0 + 2 * (ridx < LF_MAX_ED_ROUNDS ? ridx : 0), &dops, &ms);
-            if (!host_ops) R.d_ops = (uint8_t *)dops;
-            tmark(cx, "EDLIB");
-            if (timing) fprintf(stderr, "[lf] round %d: %d descriptor problems, merge+solve %.1f ms (kernels %.1f ms), ops %.1f MB\n", round, nd, now_ms() - tm0, ms, ops_total / 1e6);
-            cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
-            cx->ed_rounds[cx->n_ed_rounds++] = R;
-            if (rc != LF_OK) return rc;
-            st->ms_k_edlib += ms; st->n_edlib_problems += (uint64_t)nd; st->edlib_launches += 1;
-        }
+        /* the few problems above edlib's leaf size go through the host-orchestrated Hirschberg splits; they are
+         * independent of this round's descriptor problems, so a helper thread (own slots and streams: lane + 4)
+         * drives them while this thread runs the descriptor round */
+        hsolve_t HS; memset(&HS, 0, sizeof HS);
+        pthread_t hs_thread; int hs_spawned = 0;
+        uint64_t *hs_qoff = NULL, *hs_toff = NULL; uint8_t *hs_mode = NULL;
+        double ts0 = 0;
         if (ne) {
             uint64_t qn = 0, tn = 0;
             uint64_t *qbase = (uint64_t *)malloc((size_t)nt * 8), *tbase = (uint64_t *)malloc((size_t)nt * 8); int *gbase = (int *)malloc((size_t)nt * sizeof(int));
@@ -1645,16 +1630,60 @@ extend:
             if (timing) fprintf(stderr, "[lf] round %d merge %.1f ms (%d problems, %.1f MB)\n", round, now_ms() - tm0, ne, (qn + tn) / 1e6);
             qoff[ne] = qn; toff[ne] = tn;
             free(qbase); free(tbase); free(gbase);
-            float ms = 0; uint64_t launches = 0;
-            double ts0 = now_ms();
-            rc = lf_edlib_solve(cx->ix->device, ne, qb, qoff, tb, toff, mode, R.ed, R.end, R.ops, R.ops_len, &ms, &launches);
-            tmark(cx, "HIRSCH");
-            if (timing) fprintf(stderr, "[lf] round %d edlib solve %.1f ms (kernels %.1f ms)\n", round, now_ms() - ts0, ms);
-            free(qoff); free(toff); free(mode);
+            cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
+            cx->ed_rounds[cx->n_ed_rounds++] = R;            /* the result arrays are filled by the solver below */
+            HS.device = cx->ix->device; HS.lane = cx->lane + LF_MAX_LANES; HS.n = ne; HS.q = qb; HS.qoff = qoff; HS.t = tb; HS.toff = toff; HS.mode = mode;
+            HS.ed = R.ed; HS.end = R.end; HS.ops = R.ops; HS.ops_len = R.ops_len;
+            hs_qoff = qoff; hs_toff = toff; hs_mode = mode;
+            ts0 = now_ms();
+            if (nd && !getenv("LF_NO_HELPER")) hs_spawned = pthread_create(&hs_thread, NULL, hsolve_main, &HS) == 0;
+            if (!hs_spawned) { HS.lane = cx->lane; hsolve_main(&HS); tmark(cx, "HIRSCH"); }
+        }
+        if (nd) {
+            /* descriptor requests: nothing but 32-byte descriptors goes to the GPU */
+            uint64_t *obase = (uint64_t *)malloc((size_t)nt * 8); int *gbase = (int *)malloc((size_t)nt * sizeof(int));
+            uint64_t ops_total = 0;
+            { int g0 = 0; for (int t = 0; t < nt; t++) { obase[t] = ops_total; gbase[t] = g0; ops_total += cx->stages[t].dops_total; g0 += cx->stages[t].dn; st->ext_bytes += cx->stages[t].ext_bytes; cx->stages[t].ext_bytes = 0; } }
+            const int ridx = cx->n_ed_rounds;
+            const int pin = ridx < 16;
+            ed_round_t R; memset(&R, 0, sizeof R);
+            R.n = nd; R.pinned = pin; R.ops_bytes = ops_total;
+            /* the edit paths stay in HBM (slot of this round) unless the host builds the strings itself */
+            const int host_ops = cx->host_cigar || ridx >= LF_MAX_ED_ROUNDS;
+            if (pin) {
+                R.ed = (int32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx, (size_t)nd * 4); R.end = (int32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 1, (size_t)nd * 4);
+                R.ops_len = (uint32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 2, (size_t)nd * 4);
+                if (host_ops) R.ops = (uint8_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 3, ops_total + 1);
+            } else {
+                R.ed = (int32_t *)malloc((size_t)nd * 4); R.end = (int32_t *)malloc((size_t)nd * 4);
+                R.ops_len = (uint32_t *)malloc((size_t)nd * 4); R.ops = (uint8_t *)malloc(ops_total + 1);
+            }
+            R.ops_off = (uint64_t *)malloc((size_t)nd * 8);
+            lf_aln_desc_t *desc = (lf_aln_desc_t *)lfg_pin_slot(LF_PS_ALN_PROB, (size_t)nd * sizeof(lf_aln_desc_t));
+            if (!desc || !R.ed || !R.end || !R.ops_len || (host_ops && !R.ops)) { if (hs_spawned) pthread_join(hs_thread, NULL); return LF_ERR_NOMEM; }
+            cx->mg_desc = desc; cx->mg_R = &R; cx->mg_qbase = obase; cx->mg_gbase = gbase; cx->mg_round = ridx;
+            double tm0 = now_ms();
+            parallel_for(cx, nt, phase_merge_desc);
+            tmark(cx, "merge");
+            free(obase); free(gbase);
+            float ms = 0;
+            void *dops = NULL;
+            rc = lfg_edlib_desc(cx->ix, nd, desc, R.ops_off, ops_total, R.ed, R.end, R.ops, R.ops_len,
+                                LF_DS_RND0 + 2 * (ridx < LF_MAX_ED_ROUNDS ? ridx : 0), &dops, &ms);
+            if (!host_ops) R.d_ops = (uint8_t *)dops;
+            tmark(cx, "EDLIB");
+            if (timing) fprintf(stderr, "[lf] round %d: %d descriptor problems, merge+solve %.1f ms (kernels %.1f ms), ops %.1f MB\n", round, nd, now_ms() - tm0, ms, ops_total / 1e6);
             cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
             cx->ed_rounds[cx->n_ed_rounds++] = R;
-            if (rc != LF_OK) return rc;
-            st->ms_k_edlib += ms; st->n_edlib_problems += (uint64_t)ne; st->edlib_launches += launches;
+            if (rc != LF_OK) { if (hs_spawned) pthread_join(hs_thread, NULL); return rc; }
+            st->ms_k_edlib += ms; st->n_edlib_problems += (uint64_t)nd; st->edlib_launches += 1;
+        }
+        if (ne) {
+            if (hs_spawned) { pthread_join(hs_thread, NULL); tmark(cx, "hirsch-join"); }
+            if (timing) fprintf(stderr, "[lf] round %d edlib solve %.1f ms (kernels %.1f ms)%s\n", round, now_ms() - ts0, HS.ms, hs_spawned ? " [helper thread]" : "");
+            free(hs_qoff); free(hs_toff); free(hs_mode);
+            if (HS.rc != LF_OK) { lf_set_error("%s", HS.err); return HS.rc; }
+            st->ms_k_edlib += HS.ms; st->n_edlib_problems += (uint64_t)ne; st->edlib_launches += HS.launches;
         }
         if (nk) {
             uint64_t qn = 0, tn = 0;
