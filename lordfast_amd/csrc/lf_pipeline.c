@@ -390,6 +390,22 @@ static char rc_char(char c)
     }
 }
 static void revcomp_into(const char *s, char *out, uint32_t len) { for (uint32_t i = 0; i < len; i++) out[i] = rc_char(s[len - 1 - i]); out[len] = 0; }
+/* reverse complement / reversed copy written straight into the SAM text (src/LordFAST.cpp:501-502 build both strings
+ * for every read; only records on the reverse strand ever print them) */
+static void str_put_rc(str_t *b, const char *s, size_t l)
+{
+    str_room(b, l);
+    if (b->mode != 1) { char *d = b->s + b->n; for (size_t i = 0; i < l; i++) d[i] = rc_char(s[l - 1 - i]); }
+    b->n += l;
+    if (b->mode == 0 || b->mode == 3) b->s[b->n] = 0;
+}
+static void str_put_rev(str_t *b, const char *s, size_t l)
+{
+    str_room(b, l);
+    if (b->mode != 1) { char *d = b->s + b->n; for (size_t i = 0; i < l; i++) d[i] = s[l - 1 - i]; }
+    b->n += l;
+    if (b->mode == 0 || b->mode == 3) b->s[b->n] = 0;
+}
 
 /* ================================================================ B: vote, candidates, selection */
 typedef struct { uint32_t win, cnt; } wc_t;
@@ -615,10 +631,20 @@ static memo_t *memo_add(job_t *j, const rkey_t *k, arena_t *ar)
     return m;
 }
 
-/* bytes of a request: query segment of the walk's query string (optionally reverse-complemented) */
-static void put_query(const walk_t *w, const rkey_t *k, char *dst)
+/* the walk's query string; the reverse complement of a read is only materialised if a byte-string request needs it */
+static const char *walk_query(walk_t *w)
 {
-    const char *src = w->query + k->qs;
+    if (!w->query) {
+        rd_t *rd = &w->cx->reads[w->job->read];
+        if (!rd->seq_rev) { rd->seq_rev = (char *)ar_alloc(&w->cx->arena[w->tid], (size_t)rd->len + 1); revcomp_into(rd->seq, rd->seq_rev, rd->len); }
+        w->query = rd->seq_rev;
+    }
+    return w->query;
+}
+/* bytes of a request: query segment of the walk's query string (optionally reverse-complemented) */
+static void put_query(walk_t *w, const rkey_t *k, char *dst)
+{
+    const char *src = walk_query(w) + k->qs;
     if (!k->qrc) memcpy(dst, src, k->qn);
     else for (uint32_t i = 0; i < k->qn; i++) dst[i] = rc_char(src[k->qseg - 1 - i]);
 }
@@ -672,7 +698,7 @@ static void stage_ksw(walk_t *w, memo_t *m)
     if (s->ktn + k->tn + 1 > s->ktcap) { s->ktcap = (s->ktn + k->tn + 1) * 2; s->kt = (uint8_t *)realloc(s->kt, s->ktcap); }
     /* codes: convertChar2int / reverseComplementIntStr (src/LordFAST.cpp:1191-1201): 3 - code, so an N (4)
      * becomes 255 in the reference and indexes past its 5x5 matrix; we score any code > 3 as 0 */
-    const char *src = w->query + k->qs;
+    const char *src = walk_query(w) + k->qs;
     for (uint32_t i = 0; i < k->qn; i++) {
         uint8_t c = k->qrc ? code_of(src[k->qseg - 1 - i]) : code_of(src[i]);
         s->kq[s->kqn + i] = k->qrc ? (uint8_t)(c > 3 ? 4 : 3 - c) : c;
@@ -1245,7 +1271,7 @@ static void sam_line(str_t *o, const ctx_t *cx, const rd_t *r, const sam_t *s, i
     str_puts(o, r->name); str_putc(o, '\t'); str_puti(o, flag); str_putc(o, '\t'); str_puts(o, rname); str_putc(o, '\t');
     str_putu(o, rstart + 1); str_putc(o, '\t'); str_puti(o, mapq >= 0 ? mapq : 0); str_putc(o, '\t');
     str_puts(o, s->cigar); str_puts(o, "\t*\t0\t0\t");
-    if (s->flag & 16) { str_putn(o, r->seq_rev, r->len); str_putc(o, '\t'); str_puts(o, r->qual_rev); }
+    if (s->flag & 16) { str_put_rc(o, r->seq, r->len); str_putc(o, '\t'); str_put_rev(o, r->qual, r->isFq ? r->len : 1); }
     else { str_putn(o, r->seq, r->len); str_putc(o, '\t'); str_puts(o, r->qual); }
     str_puts(o, "\tAS:i:"); str_puti(o, s->alnScore); str_puts(o, "\tXS:i:0\tNM:i:"); str_puti(o, abs(s->nmCount));
     str_puts(o, "\tMD:Z:"); str_puts(o, s->md);
@@ -1316,12 +1342,7 @@ static void phase_prepare(ctx_t *cx, int tid, int ri)
     rd_t *r = &cx->reads[ri];
     memset(&r->out, 0, sizeof r->out);
     if ((int)r->len < cx->p->min_read_len) return;
-    r->seq_rev = (char *)ar_alloc(&cx->arena[tid], (size_t)r->len + 1);
-    revcomp_into(r->seq, r->seq_rev, r->len);                          /* reverseComplement :501 */
-    const uint32_t ql = r->isFq ? r->len : 1;
-    r->qual_rev = (char *)ar_alloc(&cx->arena[tid], (size_t)ql + 1);
-    for (uint32_t i = 0; i < ql; i++) r->qual_rev[i] = r->qual[ql - 1 - i];   /* reverse :502 */
-    r->qual_rev[ql] = 0;
+    r->seq_rev = NULL; r->qual_rev = NULL;     /* built on demand: walk_query (rare byte-string requests); SAM prints them in place */
 }
 
 static void phase_concat(ctx_t *cx, int tid, int k)
