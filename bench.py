@@ -163,9 +163,15 @@ def main():
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # LF_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 code path run on a box with fewer GPUs than ranks
+        # (ranks then share devices); the driver's runs use RCCL ("nccl"), one rank per GPU
+        backend = os.environ.get("LF_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
+        dist.init_process_group(backend)
     dev = torch.device("cuda", local)
+    rdev = dev if (not dist or dist.get_backend() == "nccl") else torch.device("cpu")     # where the reduced scalars live
 
     import lordfast_amd as la
     from lordfast_amd import dist as lfd
@@ -225,7 +231,7 @@ def main():
         ln, st = lf.map_batch_into(names, seqs, out_ptr, cap_one, params=params, name_arr=na, seq_arr=sa)
         st["ms_python_call"] = (time.perf_counter() - t_call) * 1e3
         if dist and args.single_output:                      # optional: one SAM stream on rank 0, input order
-            ln = lfd.gather_sam_p2p(dist, torch, out_buf, ln, dev)
+            ln = lfd.gather_sam_p2p(dist, torch, out_buf, ln, rdev)
         return _Sam(ln or 0), st
 
     for _ in range(args.warmup):
@@ -249,10 +255,10 @@ def main():
     elapsed = time.perf_counter() - t0
     bases_total = bases_local
     if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        bsum = torch.tensor([bases_local], dtype=torch.int64, device=dev)
+        bsum = torch.tensor([bases_local], dtype=torch.int64, device=rdev)
         dist.all_reduce(bsum, op=dist.ReduceOp.SUM)
         bases_total = int(bsum.item())
 
@@ -261,12 +267,21 @@ def main():
         bases = bases_total
         value = n_total * K / elapsed
         # ---- roofline: algorithmic bytes (SURVEY 8d counters emitted by the kernels) / HIP-event kernel time, rank 0 ----
+        # HIP events bracket each kernel (or launch group) on the stream it runs on.  Four chunks are in flight, so a
+        # bracket also contains time the kernel spent sharing the GPU with the other chunks' kernels.
+        n_hits = agg["n_seeds"]
         kernels = {
             "lf_seed_search_kernel": (agg["ms_k_search"], 16 * agg["n_cache"] + 64 * agg["n_occblk"] + agg["n_readbytes"], agg["search_launches"]),
             "lf_seed_locate_kernel": (agg["ms_k_locate"], 8 * agg["n_sa"] + 9 * agg["n_sa"], agg["locate_launches"]),
-            # the edlib size classes (lf_edlib_kernel<1,2,4,8>, lf_edlib_wave_kernel<1,4>) run concurrently as ONE launch group
-            "lf_edlib_kernel": (agg["ms_k_edlib"], agg["ext_bytes"], max(1, agg["edlib_launches"])),
-            "lf_chain_n2_kernel": (agg["ms_k_chain"], 16 * agg["n_chain_problems"], max(1, agg["search_launches"])),
+            # lf_vote_keys_kernel + radix sort + reduce-by-key + lf_vote_select_kernel: 9 B/hit read, 2 x 12 B (key, weight) per hit
+            "lf_vote_* (keys, sort, reduce, select)": (agg["ms_k_vote"], 33 * n_hits, agg["search_launches"]),
+            # request gather + sort by qPos + lf_chain_n2_kernel + chain gather: 16 B per request seed, 8 B per chain seed
+            "lf_chain_* (gather, sort, dp-n2)": (agg["ms_k_chain"], 16 * agg["n_req_seeds"], agg["search_launches"]),
+            # the edlib size classes (lf_edlib_kernel<1,2,3,4,6,8>, lf_edlib_group_kernel<16,32>, lf_edlib_wave_kernel<1,4>)
+            # run concurrently on their own streams as ONE launch group; the events bracket the group
+            "lf_edlib_* (size-class launch group)": (agg["ms_k_edlib"], agg["ext_bytes"], max(1, agg["edlib_launches"])),
+            # CIGAR / MD: every op byte read twice (count pass, write pass), text written once
+            "lf_render_kernel": (agg["ms_k_render"], 2 * agg["ops_bytes"] + agg["render_bytes"], max(1, agg["render_launches"])),
         }
         by_kernel = {}
         for kname, (kms, kbytes, kl) in kernels.items():
@@ -281,15 +296,19 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "r01_c2", "pmc_fetch_write_summary.json")
         if os.path.exists(pmc_path) and args.genome_mbp == 3100 and args.reads == 100000 and world == 1:
             pmc = json.load(open(pmc_path))
-            fam = [v for k, v in pmc.items() if k.startswith(dom.replace("_kernel", ""))] if dom == "lf_edlib_kernel" else [pmc[dom]] if dom in pmc else []
+            prefix = dom.split("*")[0].split(" ")[0]
+            fam = [v for k, v in pmc.items() if k.startswith(prefix)]
             if fam:
-                # one profiled step = the same 100k reads; FETCH_SIZE / WRITE_SIZE are in KB; raw (no gfx950 x2 correction: random 64-B reads)
-                traffic = sum(v["fetch_kb"] + v["write_kb"] for v in fam) * 1024.0 / max(1.0, launches / K)
+                # one profiled step = the same 100k reads; FETCH_SIZE / WRITE_SIZE in KB, raw (the gfx950 "x2 for wide
+                # coalesced reads" correction is NOT applied: see profiles/r01_c2/README.md)
+                traffic = sum(v.get("fetch_kb", 0.0) + v.get("write_kb", 0.0) for v in fam) * 1024.0 / max(1.0, launches / K)
         roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
                         traffic=traffic, launches=int(launches), avg_launch_ms=ms / max(1, launches),
                         algorithmic_bytes_per_launch=alg_bytes / max(1, launches),
                         per_kernel_ms={k: round(v[0], 3) for k, v in kernels.items()}, by_kernel=by_kernel,
-                        note="edlib classes are integer-ALU/latency bound; their HBM traffic is traceback history (see profiles/r01_c2/README.md)")
+                        chunks_in_flight=4,
+                        note="edlib kernels are integer-ALU / latency bound, their HBM traffic is traceback history; durations are "
+                             "HIP-event brackets with 4 chunks in flight (profiles/r01_c2/README.md has the one-chunk-at-a-time figures)")
         out = {
             "metric": "aligned reads/s", "value": value, "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -300,9 +319,10 @@ def main():
                        "parallelism": f"reads sharded over {world} GPU(s), index replicated, no data-path collective"
                                       + (" + SAM gather to rank 0" if (dist and args.single_output) else ""), "index": "FM-index + full SA resident in HBM"},
             "gbp_per_s": bases * K / elapsed / 1e9,
-            "host_ms_per_step": {k: agg[k] / K for k in ("ms_total", "ms_python_call", "ms_seed", "ms_vote", "ms_chain", "ms_extend", "ms_sam")},
+            "host_ms_per_step": {k: agg[k] / K for k in ("ms_total", "ms_python_call", "ms_seed", "ms_vote", "ms_chain", "ms_extend", "ms_render", "ms_sam")},
             "per_read": {"seeds": agg["n_seeds"] / (n_total * K / world), "edlib_problems": agg["n_edlib_problems"] / (n_total * K / world),
-                         "seed_bytes": (16 * agg["n_cache"] + 64 * agg["n_occblk"] + 8 * agg["n_sa"] + agg["n_readbytes"]) / (n_total * K / world)},
+                         "seed_bytes": (16 * agg["n_cache"] + 64 * agg["n_occblk"] + 8 * agg["n_sa"] + agg["n_readbytes"]) / (n_total * K / world),
+                         "ext_bytes": agg["ext_bytes"] / (n_total * K / world), "cigar_md_text_bytes": agg["render_bytes"] / (n_total * K / world)},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

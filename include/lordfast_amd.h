@@ -150,6 +150,7 @@ typedef struct {
     uint64_t edlib_launches, search_launches, locate_launches;
     /* CIGAR / MD rendering (lf_render_kernel): wall, HIP events, text bytes written, launches */
     double ms_render; float ms_k_render, ms_k_vote; uint64_t render_bytes, render_launches;
+    uint64_t ops_bytes;                                 /* edit-path bytes left in HBM for the renderer */
     uint64_t n_req_seeds, n_tie_requests;              /* seeds gathered into chain requests; requests whose equal qPos needed the std::sort replay */
 } lf_stats_t;
 

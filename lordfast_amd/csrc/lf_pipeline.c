@@ -1697,7 +1697,7 @@ extend:
             cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
             cx->ed_rounds[cx->n_ed_rounds++] = R;
             if (rc != LF_OK) { if (hs_spawned) pthread_join(hs_thread, NULL); return rc; }
-            st->ms_k_edlib += ms; st->n_edlib_problems += (uint64_t)nd; st->edlib_launches += 1;
+            st->ms_k_edlib += ms; st->n_edlib_problems += (uint64_t)nd; st->edlib_launches += 1; st->ops_bytes += ops_total;
         }
         if (ne) {
             if (hs_spawned) { pthread_join(hs_thread, NULL); tmark(cx, "hirsch-join"); }
@@ -1844,7 +1844,7 @@ static void merge_stats(lf_stats_t *d, const lf_stats_t *a)
     d->n_edlib_problems += a->n_edlib_problems; d->n_ksw_problems += a->n_ksw_problems; d->n_cache += a->n_cache; d->n_occblk += a->n_occblk;
     d->n_sa += a->n_sa; d->n_readbytes += a->n_readbytes; d->ext_bytes += a->ext_bytes; d->edlib_launches += a->edlib_launches;
     d->search_launches += a->search_launches; d->locate_launches += a->locate_launches;
-    d->ms_render += a->ms_render; d->ms_k_render += a->ms_k_render; d->ms_k_vote += a->ms_k_vote; d->n_req_seeds += a->n_req_seeds; d->n_tie_requests += a->n_tie_requests; d->render_bytes += a->render_bytes; d->render_launches += a->render_launches;
+    d->ms_render += a->ms_render; d->ms_k_render += a->ms_k_render; d->ms_k_vote += a->ms_k_vote; d->ops_bytes += a->ops_bytes; d->n_req_seeds += a->n_req_seeds; d->n_tie_requests += a->n_tie_requests; d->render_bytes += a->render_bytes; d->render_launches += a->render_launches;
 }
 
 static void *lane_main(void *arg_)

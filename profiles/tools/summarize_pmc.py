@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""summarize_pmc.py <out.json> <counter_collection.csv> [<counter_collection.csv> ...]
+Per kernel (template arguments kept, parameter lists dropped): dispatches and the SUM over dispatches of every counter
+found in the rocprofv3 --pmc CSVs (FETCH_SIZE / WRITE_SIZE are in KB as rocprofv3 reports them)."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+out = defaultdict(lambda: {"launches": 0})
+for path in sys.argv[2:]:
+    seen = defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"].split("(")[0]
+        if name.startswith("void "):
+            name = name[5:]
+        if len(name) > 80:
+            name = name[:80]
+        ctr = r["Counter_Name"]
+        key = ctr.lower().replace("_size", "_kb")
+        out[name][key] = out[name].get(key, 0.0) + float(r["Counter_Value"])
+        seen[name].add(r["Dispatch_Id"])
+    for name, ids in seen.items():
+        out[name]["launches"] = max(out[name]["launches"], len(ids))
+json.dump(dict(sorted(out.items(), key=lambda kv: -(kv[1].get("fetch_kb", 0) + kv[1].get("write_kb", 0)))), open(sys.argv[1], "w"), indent=1)
+print("wrote", sys.argv[1], len(out), "kernels")
