@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""busy.py <kernel_trace.csv> [t0_frac t1_frac] -- union of kernel execution intervals from a rocprofv3 --kernel-trace CSV:
+"""busy.py <kernel_trace.csv> [t0_frac t1_frac | --last-step <chunks per step>] -- union of kernel execution intervals from a rocprofv3 --kernel-trace CSV:
 how much of the wall time had at least one kernel running, and each kernel family's share of the summed durations."""
 import csv
 import sys
@@ -8,7 +8,12 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 lo, hi = iv[0][0], max(e for _, e, _ in iv)
-if len(sys.argv) > 3:
+if len(sys.argv) > 3 and sys.argv[2] == "--last-step":
+    # window = the last K launches of the seed search kernel (K = chunks per step) up to the last kernel of the trace
+    k = int(sys.argv[3])
+    starts = [s for s, _, n in iv if n.startswith("lf_seed_search_kernel")]
+    lo = starts[-k]
+elif len(sys.argv) > 3:
     a, b = float(sys.argv[2]), float(sys.argv[3])
     lo, hi = lo + int((hi - lo) * a), lo + int((hi - lo) * b)
 busy = 0

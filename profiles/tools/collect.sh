@@ -11,7 +11,7 @@ $B --steps 3 --warmup 1 > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.er
 rm -rf /tmp/lfp_kt /tmp/lfp_ser /tmp/lfp_f /tmp/lfp_w
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lfp_kt -- $B --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof_kernel_trace.json 2> /tmp/lfp_kt.err
 python3 profiles/tools/trim_stats.py $(ls /tmp/lfp_kt/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
-python3 profiles/tools/busy.py $(ls /tmp/lfp_kt/*/*kernel_trace.csv | head -1) 0.70 0.99 > $OUT/gpu_busy_last_step.txt
+python3 profiles/tools/busy.py $(ls /tmp/lfp_kt/*/*kernel_trace.csv | head -1) --last-step 8 > $OUT/gpu_busy_last_step.txt
 cp $(ls /tmp/lfp_kt/*/*agent_info.csv | head -1) $OUT/agent_info.csv 2>/dev/null
 LF_SERIAL_CLASSES=1 LF_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lfp_ser -- $B --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_serialized.json 2> /tmp/lfp_ser.err
 python3 profiles/tools/trim_stats.py $(ls /tmp/lfp_ser/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_one_chunk_at_a_time_classes_serialized.csv
