@@ -18,7 +18,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime initialises (see lf_host.c)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # before the HIP runtime initialises (see lf_host.c)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -201,6 +201,8 @@ def main():
         pass
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     params.threads = max(2, min(255, budget // max(1, local_world)))
+    if os.environ.get("LF_BENCH_THREADS"):
+        params.threads = int(os.environ["LF_BENCH_THREADS"])
     log(f"rank {rank}: {params.threads} host threads (budget {budget}, {local_world} ranks on this node)")
 
     # caller-owned SAM buffer, pinned and reused by every step (rank 0's holds the whole job's SAM: the other ranks'
@@ -310,8 +312,8 @@ def main():
 
         dom = max(single, key=lambda k: kernels[k][0])
         roofline = roof(dom, dom)
-        roofline.update(per_kernel_ms={k: round(v[0], 3) for k, v in kernels.items()}, by_kernel=by_kernel, chunks_in_flight=4,
-                        note="HIP-event brackets with 4 chunks in flight: a bracket contains time shared with the other chunks' kernels; "
+        roofline.update(per_kernel_ms={k: round(v[0], 3) for k, v in kernels.items()}, by_kernel=by_kernel, chunks_in_flight=8,
+                        note="HIP-event brackets with up to 8 chunks in flight: a bracket contains time shared with the other chunks' kernels; "
                              "profiles/r01_c2/README.md has the one-chunk-at-a-time figures (search: ~12 ms/launch, ~2 TB/s)")
         roofline_edlib = roof("lf_edlib_* (size-class launch group)", "lf_edlib_")
         roofline_edlib["note"] = ("integer-ALU / latency bound; HBM traffic is the 2-bit-per-cell traceback history (16 B per column and "

@@ -73,7 +73,7 @@ static void *ar_grow(arena_t *a, void *old, size_t old_bytes, size_t new_bytes)
     return p;
 }
 static void ar_reset(arena_t *a) { a->cur = 0; a->off = 0; }
-#define LF_MAX_LANES 4
+#define LF_MAX_LANES 8
 static arena_t g_arena[LF_MAX_LANES][260];          /* [lane][worker]; blocks are kept across chunks and batches */
 
 /* mode 0: owned, growable, NUL-terminated; mode 1: count only (nothing is written); mode 2: fixed external window;
@@ -259,7 +259,8 @@ typedef struct {
     pjob_t job[LF_MAX_LANES];
 } pool_t;
 static pool_t g_pool = { .mu = PTHREAD_MUTEX_INITIALIZER, .cv_work = PTHREAD_COND_INITIALIZER,
-                         .cv_done = { PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER } };
+                         .cv_done = { PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
+                                      PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER } };
 
 /* LF_TIMING=1: per-phase CPU time (summed over workers) and wall time, printed at the end of each batch */
 static struct { const char *name; double cpu_ms, wall_ms; long calls; } g_phase[32];
@@ -1949,7 +1950,7 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
     pthread_mutex_lock(&g_map_lock);
     g_phase_on = getenv("LF_PHASES") != NULL;
     /* chunks in flight: the host phases of one overlap the GPU phases of the others */
-    int n_lanes = nt >= 8 ? 4 : (nt >= 3 ? 2 : 1);
+    int n_lanes = nt >= 16 ? 8 : (nt >= 8 ? 4 : (nt >= 3 ? 2 : 1));
     if (getenv("LF_LANES")) { n_lanes = atoi(getenv("LF_LANES")); if (n_lanes < 1) n_lanes = 1; if (n_lanes > LF_MAX_LANES) n_lanes = LF_MAX_LANES; if (n_lanes > 1 && nt < n_lanes + 1) n_lanes = 1; }
     if (getenv("LF_ONE_LANE")) n_lanes = 1;
     const int nw = nt - n_lanes;                       /* pool workers; the lane drivers work too */
