@@ -81,6 +81,46 @@ __device__ __forceinline__ void lf_backward_step(const lf_dev_index &ix, uint64_
     l = ix.L2[c] + ol;
 }
 
+/* Occ(k, c) for all four symbols at once (bwt_occ4, lib/bwa/bwt.c:169-186): the same 64-byte block, four counts */
+__device__ __forceinline__ void lf_occ4(const lf_dev_index &ix, uint64_t k, uint64_t cnt[4])
+{
+    if (k == ~0ull) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; return; }
+    if (k == ix.seq_len) { for (int c = 0; c < 4; c++) cnt[c] = ix.L2[c + 1] - ix.L2[c]; return; }
+    k -= (k >= ix.primary);
+    const uint32_t *blk = ix.bwt + ((k >> 7) << 4);
+    const uint4 w0 = *reinterpret_cast<const uint4 *>(blk + 8);
+    const uint4 w1 = *reinterpret_cast<const uint4 *>(blk + 12);
+    const ulonglong2 c01 = *reinterpret_cast<const ulonglong2 *>(blk), c23 = *reinterpret_cast<const ulonglong2 *>(blk + 4);
+    const int rem = (int)(k & 127) + 1;
+    cnt[0] = c01.x; cnt[1] = c01.y; cnt[2] = c23.x; cnt[3] = c23.y;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        cnt[c] += lf_count_sym(w0.x, w0.y, c, rem) + lf_count_sym(w0.z, w0.w, c, rem - 32)
+                + lf_count_sym(w1.x, w1.y, c, rem - 64) + lf_count_sym(w1.z, w1.w, c, rem - 96);
+}
+
+/* Bidirectional step (bwt_extend with is_back = 0, lib/bwa/bwt.c:262-275).  The text is forward + reverse complement,
+ * so a pattern P and revcomp(P) have intervals of the same size s; (x0, x1, s) = (first row of P, first row of
+ * revcomp(P), size).  Appending base c to P = prepending (3 - c) to revcomp(P): one backward step on x1 with all four
+ * counts, and x0 moves past the rows of the patterns P.d with d > c.  Returns false (state untouched) if P.c does not occur. */
+__device__ __forceinline__ bool lf_extend_right(const lf_dev_index &ix, uint64_t &x0, uint64_t &x1, uint64_t &s, int c, uint32_t &blk_touches)
+{
+    const uint64_t km = x1 - 1, l = x1 - 1 + s;
+    const uint64_t _k = (km >= ix.primary) ? km - 1 : km, _l = (l >= ix.primary) ? l - 1 : l;
+    blk_touches += (km == ~0ull || l == ~0ull || (_k >> 7) != (_l >> 7)) ? 2u : 1u;
+    uint64_t tk[4], tl[4];
+    lf_occ4(ix, km, tk); lf_occ4(ix, l, tl);
+    const int a = 3 - c;                                   /* symbol prepended on the complement strand */
+    const uint64_t ns = tl[a] - tk[a];
+    if (ns == 0) return false;
+    /* rows of P.d for d = 0..3 follow each other inside P's interval in the order of d; on the complement strand d
+     * appears as 3 - d, so P.c starts after the sentinel row (if P's complement interval spans it) and all a' > a */
+    uint64_t nx0 = x0 + ((x1 <= ix.primary && x1 + s - 1 >= ix.primary) ? 1u : 0u);
+    for (int j = 3; j > a; j--) nx0 += tl[j] - tk[j];
+    x0 = nx0; x1 = ix.L2[a] + 1 + tk[a]; s = ns;
+    return true;
+}
+
 /* bwt_B0 (lib/bwa/bwt.h:78) + bwt_invPsi (lib/bwa/bwt.c:53-59) */
 __device__ __forceinline__ uint64_t lf_inv_psi(const lf_dev_index &ix, uint64_t k)
 {

@@ -166,40 +166,38 @@ lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ rea
         lf_sample_t res; res.sp = 0; res.occ = 0; res.m = 0;
 
         if ((uint64_t)p + (uint64_t)kmin <= qLen) {
-            /* phase 1: complemented strand, growing leftwards: 12-mer table then one step per base.
-             * table index: base-4 number with the LAST character of the pattern most significant
-             * (src/BWT.cpp:270-277); pattern = revcomp(q[p..p+m)) whose last 12 are comp(q[p+11..p]) */
-            uint32_t idx = 0; bool ok = true;
+            /* Bidirectional search (the index holds forward + reverse-complement text, like bwa mem's SMEM search):
+             * (x0, x1, s) = first row of P = q[p..p+m), first row of revcomp(P), interval size.  Start from the two
+             * 12-mer table entries, then append one base at a time while P still occurs.  The maximal m AND the exact
+             * rows of P come out of the same pass: m - 12 steps instead of the reference's restart per m.
+             * table index: base-4 number with the LAST character of the pattern most significant (src/BWT.cpp:270-277);
+             * pattern P12 = q[p..p+12), pattern revcomp(P12) whose last 12 characters are comp(q[p+11..p]) */
+            uint32_t idc = 0, idf = 0; bool ok = true;
 #pragma unroll
-            for (int t = 0; t < 12; t++) { const int c = lf_nt4(q[p + t]); ok &= (c < 4); idx = idx * 4 + (uint32_t)(3 - c); }
+            for (int t = 0; t < 12; t++) {
+                const int c = lf_nt4(q[p + t]); ok &= (c < 4); idc = idc * 4 + (uint32_t)(3 - c);
+                idf = idf * 4 + (uint32_t)lf_nt4(q[p + 11 - t]);
+            }
             uint32_t m = 0;
             if (ok) {
-                n_cache++;
-                uint64_t k = ix.cache[2 * (size_t)idx], l = ix.cache[2 * (size_t)idx + 1];
-                if (k <= l) {
+                n_cache += 2;
+                uint64_t x1 = ix.cache[2 * (size_t)idc];
+                const uint64_t l1 = ix.cache[2 * (size_t)idc + 1];
+                if (x1 <= l1) {
+                    uint64_t x0 = ix.cache[2 * (size_t)idf], sz = l1 - x1 + 1;
                     m = 12;
                     while (p + m < qLen) {
                         const int c = lf_nt4(q[p + m]);
                         if (c > 3) break;
-                        uint64_t k2 = k, l2 = l;
-                        lf_backward_step(ix, k2, l2, 3 - c, n_blk);
-                        if (k2 > l2) break;
-                        k = k2; l = l2; m++;
+                        if (!lf_extend_right(ix, x0, x1, sz, c, n_blk)) break;
+                        m++;
                     }
                     if ((int)m < kmin) m = 0;
+                    if (m) {
+                        res.sp = x0; res.m = m;
+                        res.occ = sz > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sz;
+                    }
                 }
-            }
-            if (m) {
-                /* phase 2: exact rows of q[p..p+m): table on its last 12 bases, then leftwards to q[p] */
-                uint32_t idf = 0;
-#pragma unroll
-                for (int t = 0; t < 12; t++) idf = idf * 4 + (uint32_t)lf_nt4(q[p + m - 1 - t]);
-                n_cache++;
-                uint64_t k = ix.cache[2 * (size_t)idf], l = ix.cache[2 * (size_t)idf + 1];
-                for (int t = (int)m - 13; t >= 0; t--) lf_backward_step(ix, k, l, lf_nt4(q[p + t]), n_blk);
-                const uint64_t occ = l - k + 1;
-                res.sp = k; res.m = m;
-                res.occ = occ > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)occ;
             }
         }
         out[gid] = res;
