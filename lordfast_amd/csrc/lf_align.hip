@@ -34,32 +34,6 @@ struct lf_aln_prob {
  * mapping pipeline are DESCRIPTORS into the read batch and the 2-bit reference already resident in HBM
  * (no byte staging, no H2D of sequences); the stage API uploads byte strings and uses the same accessors. */
 
-struct lf_seqs { const unsigned char *q; const unsigned char *t; const uint8_t *pac; };
-
-__device__ __forceinline__ unsigned char lf_rc_char(unsigned char c)
-{
-    switch (c) {
-    case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
-    case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
-    default: return 'N';
-    }
-}
-struct lf_qacc {
-    const unsigned char *b; int64_t start; int dir; bool comp;
-    __device__ __forceinline__ lf_qacc(const lf_seqs &S, const lf_aln_prob &p) : b(S.q), start(p.qstart), dir((p.flags & LF_F_QREV) ? -1 : 1), comp(p.flags & LF_F_QCOMP) {}
-    __device__ __forceinline__ unsigned char get(uint32_t i) const { const unsigned char c = b[start + (int64_t)dir * (int64_t)i]; return comp ? lf_rc_char(c) : c; }
-};
-struct lf_tacc {
-    const unsigned char *b; const uint8_t *pac; int64_t start; int dir; bool comp, is_pac;
-    __device__ __forceinline__ lf_tacc(const lf_seqs &S, const lf_aln_prob &p) : b(S.t), pac(S.pac), start(p.tstart), dir((p.flags & LF_F_TREV) ? -1 : 1), comp(p.flags & LF_F_TCOMP), is_pac(p.flags & LF_F_TPAC) {}
-    __device__ __forceinline__ unsigned char get(uint32_t i) const {
-        const int64_t x = start + (int64_t)dir * (int64_t)i;
-        if (is_pac) { int c = (pac[x >> 2] >> ((~x & 3) << 1)) & 3; if (comp) c = 3 - c; return (unsigned char)"ACGT"[c]; }
-        const unsigned char c = b[x];
-        return comp ? lf_rc_char(c) : c;
-    }
-};
-
 struct lf_hist_t { uint64_t pv, ph; };
 
 __device__ __forceinline__ int lf_hin_neg(int h) { return h < 0; }
@@ -122,7 +96,8 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
     const int lane = threadIdx.x;
     if (gid >= n_probs) return;
     const lf_aln_prob pr = probs[gid];
-    const lf_qacc Q(S, pr); const lf_tacc T(S, pr);
+    const lf_qacc Q(S.q, pr.qstart, pr.flags); const lf_tacc T(S.t, S.pac, pr.tstart, pr.flags);
+    const bool lazy = (pr.flags & LF_F_LAZYX) != 0;      /* diagonal moves are not classified here (lf_render_kernel does it) */
     const uint32_t n = pr.n, m = pr.m;
 
     uint64_t lo[NB], hi[NB], valid[NB], Pv[NB], Mv[NB];
@@ -200,6 +175,17 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
     const uint32_t cap = n + m;
     uint32_t w = cap;
     uint32_t r = n, c = (uint32_t)tl;
+    /* ops leave in 8-byte words: bytes are collected in `acc` and stored when the (descending) address reaches an 8-byte
+     * boundary; only the bytes above the first boundary and below the last one are single-byte stores (the neighbouring
+     * problems' regions start right there) */
+    uint64_t acc = 0; bool packed = false;
+    auto emit = [&](uint8_t op) {
+        --w;
+        const uintptr_t A = (uintptr_t)(o + w);
+        if (!packed) { o[w] = op; packed = (A & 7) == 0; return; }
+        acc |= (uint64_t)op << ((A & 7) * 8);
+        if ((A & 7) == 0) { *reinterpret_cast<uint64_t *>(o + w) = acc; acc = 0; }
+    };
     for (uint32_t cc = cmax; cc >= 1; cc--) {
         if (c != cc || r == 0) continue;
         uint32_t b = (r - 1) >> 6;
@@ -207,19 +193,23 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
         for (;;) {
             const int bit = (int)((r - 1) & 63);
             if ((e.pv >> bit) & 1) {                                   /* Up: stays in this column */
-                o[--w] = 1; r--;
+                emit(1); r--;
                 if (r == 0) break;
                 const uint32_t b2 = (r - 1) >> 6;
                 if (b2 != b) { b = b2; e = h[((size_t)(cc - 1) * NB + b) * 64]; }
                 continue;
             }
-            if ((e.ph >> bit) & 1) { o[--w] = 2; c--; break; }          /* Left */
-            o[--w] = (Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--;   /* Diagonal */
+            if ((e.ph >> bit) & 1) { emit(2); c--; break; }             /* Left */
+            emit((lazy || Q.get(r - 1) == T.get(c - 1)) ? 0 : 3); r--; c--;   /* Diagonal */
             break;
         }
     }
-    while (c > 0) { o[--w] = 2; c--; }
-    while (r > 0) { o[--w] = 1; r--; }
+    while (c > 0) { emit(2); c--; }
+    while (r > 0) { emit(1); r--; }
+    if (packed) {                        /* bytes collected above the last boundary reached */
+        const uintptr_t A = (uintptr_t)(o + w);
+        for (uintptr_t x = A; (x & 7) != 0; x++) *reinterpret_cast<uint8_t *>(x) = (uint8_t)(acc >> ((x & 7) * 8));
+    }
     out_len[pr.id] = cap - w;            /* ops are END-aligned: o[cap - len .. cap) */
 }
 
@@ -238,7 +228,8 @@ lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_s
     const int gid = blockIdx.x * 64 + threadIdx.x;
     if (gid >= n_probs) return;
     const lf_aln_prob pr = probs[gid];
-    const lf_qacc Q(S, pr); const lf_tacc T(S, pr);
+    const lf_qacc Q(S.q, pr.qstart, pr.flags); const lf_tacc T(S.t, S.pac, pr.tstart, pr.flags);
+    const bool lazy = (pr.flags & LF_F_LAZYX) != 0;      /* diagonal moves are not classified here (lf_render_kernel does it) */
     const uint32_t n = pr.n, m = pr.m;
     const uint32_t nbk = (n + 63) >> 6;
     uint64_t *st = aux + pr.aux_off;       /* [b*5 + {0 lo,1 hi,2 valid,3 Pv,4 Mv}] */
@@ -291,7 +282,7 @@ lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_s
         const int bit = (int)((r - 1) & 63);
         if ((e.pv >> bit) & 1) { o[--w] = 1; r--; }
         else if ((e.ph >> bit) & 1) { o[--w] = 2; c--; }
-        else { o[--w] = (Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
+        else { o[--w] = (lazy || Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
     }
     while (c > 0) { o[--w] = 2; c--; }
     while (r > 0) { o[--w] = 1; r--; }
@@ -315,7 +306,8 @@ lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs
     if ((int)blockIdx.x >= n_probs) return;
     const int lane = threadIdx.x;
     const lf_aln_prob pr = probs[blockIdx.x];
-    const lf_qacc Q(S, pr); const lf_tacc T(S, pr);
+    const lf_qacc Q(S.q, pr.qstart, pr.flags); const lf_tacc T(S.t, S.pac, pr.tstart, pr.flags);
+    const bool lazy = (pr.flags & LF_F_LAZYX) != 0;      /* diagonal moves are not classified here (lf_render_kernel does it) */
     const uint32_t n = pr.n, m = pr.m;
     const uint32_t nbk = (n + 63) >> 6;
     const int nl = (int)((nbk + KB - 1) / KB);            /* lanes that own at least one block */
@@ -423,7 +415,7 @@ lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs
             uint8_t op;
             if ((pv >> bit) & 1) { op = 1; if (lane == 0) o[w - 1] = op; r--; }
             else if ((ph >> bit) & 1) { op = 2; if (lane == 0) o[w - 1] = op; c--; }
-            else { if (lane == 0) o[w - 1] = (Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
+            else { if (lane == 0) o[w - 1] = (lazy || Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
             w--;
         }
     }
@@ -452,7 +444,8 @@ lf_edlib_group_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     const int pi = (int)blockIdx.x * P + g;
     const bool live = pi < n_probs;
     const lf_aln_prob pr = probs[live ? pi : n_probs - 1];      /* a dead group shadows the last problem and stores nothing */
-    const lf_qacc Q(S, pr); const lf_tacc T(S, pr);
+    const lf_qacc Q(S.q, pr.qstart, pr.flags); const lf_tacc T(S.t, S.pac, pr.tstart, pr.flags);
+    const bool lazy = (pr.flags & LF_F_LAZYX) != 0;      /* diagonal moves are not classified here (lf_render_kernel does it) */
     const uint32_t n = pr.n, m = pr.m;
     const uint32_t nbk = (n + 63) >> 6;            /* <= G */
     uint32_t nbk_max = nbk, steps_max = m + nbk - 1;
@@ -519,7 +512,7 @@ lf_edlib_group_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
             const int bit = (int)((r - 1) & 63);
             if ((pv >> bit) & 1) { if (gl == 0) o[w - 1] = 1; r--; }
             else if ((ph >> bit) & 1) { if (gl == 0) o[w - 1] = 2; c--; }
-            else { if (gl == 0) o[w - 1] = (Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
+            else { if (gl == 0) o[w - 1] = (lazy || Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
             w--;
         }
     }
@@ -791,7 +784,7 @@ __global__ void lf_desc_build_kernel(const uint64_t *__restrict__ keys, const ui
 }
 
 static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len,
-                              int ops_slot, void **ops_dev, float *ms)
+                              int ops_slot, void **ops_dev, void **desc_dev, float *ms)
 {
     if (ms) *ms = 0;
     if (n == 0) return LF_OK;
@@ -805,7 +798,10 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     if (!cdone_init[lane_id]) { for (int k = 0; k < LF_NCLASS; k++) HIPCHK(hipEventCreateWithFlags(&cdone_all[lane_id][k], hipEventDisableTiming)); cdone_init[lane_id] = true; }
     hipEvent_t *cdone = cdone_all[lane_id];
 #define DSLOT(T, k, bytes) (T *)lfg_dev_slot(device, LF_DS_ALN0 + (k), (bytes))
-    lf_aln_desc_t *d_desc = DSLOT(lf_aln_desc_t, 0, (size_t)n * sizeof(lf_aln_desc_t));
+    /* the descriptors stay with the round's paths when those stay in HBM (lazy paths are resolved against them later) */
+    lf_aln_desc_t *d_desc = ops ? DSLOT(lf_aln_desc_t, 0, (size_t)n * sizeof(lf_aln_desc_t))
+                                : (lf_aln_desc_t *)lfg_dev_slot(device, ops_slot + 1, (size_t)n * sizeof(lf_aln_desc_t));
+    if (desc_dev) *desc_dev = d_desc;
     uint64_t *d_opsoff = DSLOT(uint64_t, 1, (size_t)n * 8);
     uint64_t *d_keys = DSLOT(uint64_t, 3, (size_t)n * 8), *d_keys2 = DSLOT(uint64_t, 8, (size_t)n * 8);
     uint32_t *d_vals = DSLOT(uint32_t, 9, (size_t)n * 4), *d_vals2 = DSLOT(uint32_t, 10, (size_t)n * 4);
@@ -879,7 +875,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
 }
 
 extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_desc_t *d, const uint64_t *ops_off, uint64_t ops_total,
-                              int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, int ops_slot, void **ops_dev, float *ms)
+                              int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, int ops_slot, void **ops_dev, void **desc_dev, float *ms)
 {
     lf_dev_state *st = (lf_dev_state *)ix->dev;
     if (!st) { lf_set_error("index is not on a device"); return LF_ERR_NO_DEVICE; }
@@ -898,7 +894,7 @@ extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_des
         }
         for (int c = 0; c < 12; c++) if (cnt[c]) fprintf(stderr, "[lf] hist nb<=%u: %llu problems, %.1f Mcells, %.1f MB exact history\n", edge[c], (unsigned long long)cnt[c], cells[c] / 1e6, hist[c] / 1e6);
     }
-    return run_edlib_desc_gpu(ix->device, n, &D, ed, endloc, ops, ops_len, ops_slot, ops_dev, ms);
+    return run_edlib_desc_gpu(ix->device, n, &D, ed, endloc, ops, ops_len, ops_slot, ops_dev, desc_dev, ms);
 }
 
 extern "C" int lfg_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,

@@ -41,6 +41,34 @@ __device__ __forceinline__ int lf_nt4(unsigned char ch)
     }
 }
 
+struct lf_seqs { const unsigned char *q; const unsigned char *t; const uint8_t *pac; };
+
+__device__ __forceinline__ unsigned char lf_rc_char(unsigned char c)
+{
+    switch (c) {
+    case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+    case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
+    default: return 'N';
+    }
+}
+/* element i of a sequence = base[start +/- i], optionally complemented (flags LF_F_*): requests of the mapping pipeline
+ * are DESCRIPTORS into the read batch and the 2-bit reference already resident in HBM */
+struct lf_qacc {
+    const unsigned char *b; int64_t start; int dir; bool comp;
+    __device__ __forceinline__ lf_qacc(const unsigned char *base, int64_t st, unsigned flags) : b(base), start(st), dir((flags & LF_F_QREV) ? -1 : 1), comp(flags & LF_F_QCOMP) {}
+    __device__ __forceinline__ unsigned char get(uint32_t i) const { const unsigned char c = b[start + (int64_t)dir * (int64_t)i]; return comp ? lf_rc_char(c) : c; }
+};
+struct lf_tacc {
+    const unsigned char *b; const uint8_t *pac; int64_t start; int dir; bool comp, is_pac;
+    __device__ __forceinline__ lf_tacc(const unsigned char *base, const uint8_t *pc, int64_t st, unsigned flags) : b(base), pac(pc), start(st), dir((flags & LF_F_TREV) ? -1 : 1), comp(flags & LF_F_TCOMP), is_pac(flags & LF_F_TPAC) {}
+    __device__ __forceinline__ unsigned char get(uint32_t i) const {
+        const int64_t x = start + (int64_t)dir * (int64_t)i;
+        if (is_pac) { int c = (pac[x >> 2] >> ((~x & 3) << 1)) & 3; if (comp) c = 3 - c; return (unsigned char)"ACGT"[c]; }
+        const unsigned char c = b[x];
+        return comp ? lf_rc_char(c) : c;
+    }
+};
+
 /* symbols equal to c among the first r symbols (r <= 0: none, r >= 32: all) of a 32-symbol chunk held
  * MSB-first in y */
 __device__ __forceinline__ uint32_t lf_count_sym(uint32_t hi, uint32_t lo, int c, int r)

@@ -95,19 +95,21 @@ enum { LF_PS_READS = 0, LF_PS_READOFF = 1, LF_PS_HITS_T = 2, LF_PS_HITS_Q = 3, L
 typedef struct { int64_t qstart, tstart; uint32_t n, m; uint8_t flags, mode, pad[6]; } lf_aln_desc_t;
 /* ops == NULL: the edit paths stay in HBM, in the device slot `ops_slot` (address returned in *ops_dev) */
 int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_desc_t *d, const uint64_t *ops_off, uint64_t ops_total,
-                   int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, int ops_slot, void **ops_dev, float *ms);
+                   int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, int ops_slot, void **ops_dev, void **desc_dev, float *ms);
 
 /* ---- lf_render.hip: CIGAR / MD text from the paths in HBM ---- */
 enum { LF_RI_RUN_M = 0, LF_RI_RUN_I = 1, LF_RI_OPS_FWD = 2, LF_RI_OPS_FWD_TRC = 3, LF_RI_OPS_REV = 4, LF_RI_DEL = 5 };
-typedef struct {            /* one piece of a record, in output order */
+typedef struct {            /* one piece of a record, in output order (32 bytes) */
     uint64_t ops_begin;     /* OPS_*: first op of the path inside its round's ops buffer */
     uint32_t n;             /* elements: ops of the path / length of the run / deleted bases */
     uint32_t tpos;          /* reference position of the first non-insert element (OPS_FWD_TRC: walks downwards, complemented) */
-    uint8_t kind, round, pad[6];
+    uint32_t slot;          /* OPS_*: the problem's descriptor in its round (lazy paths: where its query / target bases are) */
+    uint32_t qn, tcons;     /* OPS_*: query bases / reference bases the path consumes */
+    uint8_t kind, round, lazy, pad;
 } lf_ritem_t;
 typedef struct { uint32_t item0, nitems; } lf_rrecord_t;
 int lfg_render(const struct lf_index *ix, int n_recs, const lf_rrecord_t *recs, uint64_t n_items, const lf_ritem_t *items,
-               const void *const *round_ops, char **text_out, uint64_t **offs_out, uint64_t *text_bytes, float *ms);
+               const void *const *round_ops, const void *const *round_desc, char **text_out, uint64_t **offs_out, uint64_t *text_bytes, float *ms);
 int lfg_fetch(int device, void *dst, const void *src_dev, size_t bytes);
 int lfg_upload(int device, void *dst_dev, const void *src, size_t bytes);
 #define LF_F_QREV  1u
@@ -115,6 +117,7 @@ int lfg_upload(int device, void *dst_dev, const void *src, size_t bytes);
 #define LF_F_TREV  4u
 #define LF_F_TCOMP 8u
 #define LF_F_TPAC  16u
+#define LF_F_LAZYX 32u   /* diagonal moves are written as op 0 without comparing the bases; lf_render_kernel resolves match / mismatch */
 
 #define LF_TASK_PATH 0
 #define LF_TASK_DIST 1

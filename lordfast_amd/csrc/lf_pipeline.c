@@ -167,6 +167,8 @@ typedef struct {
     int32_t *ed, *end; uint32_t *ops_len; uint64_t *ops_off; int n, pinned;
     uint8_t *ops;          /* host copy of the edit paths, or NULL when they stay in HBM ... */
     uint8_t *d_ops;        /* ... at this device address */
+    void *d_desc;          /* the round's descriptors in HBM */
+    int lazy;              /* its paths carry op 0 for every diagonal move (LF_F_LAZYX) */
     uint64_t ops_bytes;
 } ed_round_t;
 typedef struct { int32_t *score, *qle, *tle; int n; } ksw_round_t;
@@ -237,6 +239,7 @@ typedef struct ctx {
     /* scratch for the parallel merge of staged alignment requests */
     lf_aln_desc_t *mg_desc; char *mg_qb, *mg_tb; uint64_t *mg_qoff, *mg_toff, *mg_qbase, *mg_tbase; uint8_t *mg_mode; int *mg_gbase; ed_round_t *mg_R; int mg_round;
     struct { const char *label; double t; } marks[96]; int n_marks; int timing;     /* LF_TIMING=1: per-chunk timeline */
+    int lazy;                       /* paths leave the edlib kernels with unclassified diagonal moves (resolved by the renderer) */
     int host_vote;                  /* LF_HOST_VOTE=1: vote / select / sort on the host from copied-back hits (cross-check) */
     lfg_vc_t vc;                    /* device path: modes, requests and chains of this chunk */
     int host_cigar;                 /* LF_HOST_CIGAR=1: build CIGAR / MD on the host from copied-back paths (cross-check) */
@@ -604,6 +607,7 @@ typedef struct {
     int ed, end; const uint8_t *ops; uint32_t nops;
     int have;
     int round; uint64_t ops_begin; uint32_t tcons;      /* where the path lives in HBM; reference bases it consumes */
+    uint32_t slot, qn; int lazy;
 } edres_t;
 
 typedef struct {
@@ -742,7 +746,7 @@ static void stage_edlib_desc(walk_t *w, memo_t *m)
     d->qstart = qstart;
     d->tstart = k->trc ? (int64_t)k->ts + k->tseg - 1 : (int64_t)k->ts;
     d->n = k->qn; d->m = k->tn; d->mode = k->mode;
-    d->flags = (uint8_t)((rev_q ? (LF_F_QREV | LF_F_QCOMP) : 0) | (k->trc ? (LF_F_TREV | LF_F_TCOMP) : 0));
+    d->flags = (uint8_t)((rev_q ? (LF_F_QREV | LF_F_QCOMP) : 0) | (k->trc ? (LF_F_TREV | LF_F_TCOMP) : 0) | (w->cx->lazy ? LF_F_LAZYX : 0));
     s->dops[s->dn] = s->dops_total; s->dops_total += (uint64_t)k->qn + k->tn;
     s->downer[s->dn] = (uintptr_t)(m - w->job->memo);
     s->dn++;
@@ -767,7 +771,8 @@ static edres_t need_edlib(walk_t *w, int qrc, uint32_t qs, uint32_t qseg, uint32
     r.have = 1; r.ed = R->ed[m->slot]; r.end = R->end[m->slot]; r.nops = R->ops_len[m->slot];
     r.round = m->round; r.ops_begin = R->ops_off[m->slot] + ((uint64_t)qn + tn - r.nops);     /* end-aligned in its region */
     r.tcons = mode == 0 ? tn : (uint32_t)(r.end + 1);                               /* NW: all of it; SHW: up to the end column */
-    r.ops = R->ops ? R->ops + r.ops_begin : (m->hops ? m->hops + ((uint64_t)qn + tn - r.nops) : NULL);
+    r.slot = (uint32_t)m->slot; r.qn = qn; r.lazy = R->lazy;
+    r.ops = m->hops ? m->hops + ((uint64_t)qn + tn - r.nops) : (R->ops ? R->ops + r.ops_begin : NULL);
     return r;
 }
 
@@ -902,6 +907,7 @@ static void rc_ops(alnb_t *b, const edres_t *r, int kind, uint32_t tpos)
     if (!r->nops) return;
     b->fed = 1;
     lf_ritem_t *it = rc_item(b); it->kind = (uint8_t)kind; it->n = r->nops; it->tpos = tpos; it->round = (uint8_t)r->round; it->ops_begin = r->ops_begin;
+    it->slot = r->slot; it->qn = r->qn; it->tcons = r->tcons; it->lazy = (uint8_t)r->lazy;
 }
 static inline void st_c(alnb_t *b, char c, uint32_t n)
 {
@@ -1216,6 +1222,27 @@ bail:
     return job->complete;
 }
 
+/* per-base fallback only: a lazy path (op 0 on every diagonal move) copied back from HBM gets its mismatches here,
+ * by the comparison the edlib kernels make: raw bytes of the request's query and target strings */
+static void resolve_lazy_ops(ctx_t *cx, int tid, job_t *job, memo_t *m, uint32_t nops)
+{
+    const rkey_t *k = &m->key;
+    rd_t *rd = &cx->reads[job->read];
+    walk_t W; memset(&W, 0, sizeof W);
+    W.cx = cx; W.tid = tid; W.job = job; W.query = job->isRev ? rd->seq_rev : rd->seq; W.readLen = rd->len;
+    char *q = (char *)ar_alloc(&cx->arena[tid], (size_t)k->qn + k->tn + 2), *t = q + k->qn + 1;
+    put_query(&W, k, q); put_target(&W, k, t);
+    uint8_t *ops = m->hops + ((size_t)k->qn + k->tn - nops);
+    uint32_t qi = 0, ti = 0;
+    for (uint32_t i = 0; i < nops; i++) {
+        const uint8_t op = ops[i];
+        if (op == 1) { qi++; continue; }
+        if (op == 2) { ti++; continue; }
+        if (op == 0 && q[qi] != t[ti]) ops[i] = 3;
+        qi++; ti++;
+    }
+}
+
 static int walk_chain(ctx_t *cx, int tid, job_t *job, samlist_t *map)
 {
     int need_track = 0;
@@ -1228,10 +1255,12 @@ static int walk_chain(ctx_t *cx, int tid, job_t *job, samlist_t *map)
             memo_t *m = &job->memo[k];
             if (m->key.type != 0 || m->round < 0 || m->hops) continue;
             const ed_round_t *R = &cx->ed_rounds[m->round];
-            if (R->ops || !R->d_ops) continue;
+            if (!R->lazy && (R->ops || !R->d_ops)) continue;
             const size_t region = (size_t)m->key.qn + m->key.tn;
             m->hops = (uint8_t *)ar_alloc(&cx->arena[tid], region + 1);
-            if (lfg_fetch(cx->ix->device, m->hops, R->d_ops + R->ops_off[m->slot], region) != LF_OK) { m->hops = NULL; return 0; }
+            if (R->ops) memcpy(m->hops, R->ops + R->ops_off[m->slot], region);
+            else if (lfg_fetch(cx->ix->device, m->hops, R->d_ops + R->ops_off[m->slot], region) != LF_OK) { m->hops = NULL; return 0; }
+            if (R->lazy) resolve_lazy_ops(cx, tid, job, m, R->ops_len[m->slot]);
         }
         done = walk_chain_mode(cx, tid, job, map, 1, 1, &need_track);
     }
@@ -1689,10 +1718,11 @@ extend:
             tmark(cx, "merge");
             free(obase); free(gbase);
             float ms = 0;
-            void *dops = NULL;
+            void *dops = NULL, *ddesc = NULL;
             rc = lfg_edlib_desc(cx->ix, nd, desc, R.ops_off, ops_total, R.ed, R.end, R.ops, R.ops_len,
-                                LF_DS_RND0 + 2 * (ridx < LF_MAX_ED_ROUNDS ? ridx : 0), &dops, &ms);
-            if (!host_ops) R.d_ops = (uint8_t *)dops;
+                                LF_DS_RND0 + 2 * (ridx < LF_MAX_ED_ROUNDS ? ridx : 0), &dops, &ddesc, &ms);
+            if (!host_ops) { R.d_ops = (uint8_t *)dops; R.d_desc = ddesc; }
+            R.lazy = cx->lazy;
             tmark(cx, "EDLIB");
             if (timing) fprintf(stderr, "[lf] round %d: %d descriptor problems, merge+solve %.1f ms (kernels %.1f ms), ops %.1f MB\n", round, nd, now_ms() - tm0, ms, ops_total / 1e6);
             cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
@@ -1759,7 +1789,7 @@ extend:
                 for (int k = 0; k < s->rrn; k++) { lf_rrecord_t q = s->rr[k]; q.item0 += (uint32_t)ibase[t]; recs[cx->rrbase[t] + k] = q; }
             }
             /* rounds whose paths were computed through the host (Hirschberg-size problems): put them into HBM too */
-            const void *round_ops[LF_MAX_ED_ROUNDS]; memset(round_ops, 0, sizeof round_ops);
+            const void *round_ops[LF_MAX_ED_ROUNDS], *round_desc[LF_MAX_ED_ROUNDS]; memset(round_ops, 0, sizeof round_ops); memset(round_desc, 0, sizeof round_desc);
             for (int k = 0; k < cx->n_ed_rounds && k < LF_MAX_ED_ROUNDS; k++) {
                 ed_round_t *Rk = &cx->ed_rounds[k];
                 if (!Rk->d_ops && Rk->ops && Rk->ops_bytes) {
@@ -1769,11 +1799,11 @@ extend:
                     if (rc != LF_OK) { free(ibase); return rc; }
                     Rk->d_ops = (uint8_t *)dp;
                 }
-                round_ops[k] = Rk->d_ops;
+                round_ops[k] = Rk->d_ops; round_desc[k] = Rk->d_desc;
             }
             float ms = 0; uint64_t tbytes = 0;
             tmark(cx, "recipe");
-            rc = lfg_render(cx->ix, n_recs, recs, n_items, items, round_ops, &cx->rtext, &cx->roffs, &tbytes, &ms);
+            rc = lfg_render(cx->ix, n_recs, recs, n_items, items, round_ops, round_desc, &cx->rtext, &cx->roffs, &tbytes, &ms);
             tmark(cx, "RENDER");
             if (timing) fprintf(stderr, "[lf] render: %d records, %llu pieces, %.1f MB text, kernels %.1f ms, total %.1f ms\n", n_recs, (unsigned long long)n_items, tbytes / 1e6, ms, now_ms() - t0);
             if (rc != LF_OK) { free(ibase); return rc; }
@@ -1860,7 +1890,7 @@ static void *lane_main(void *arg_)
         if (k >= B->n_chunks || B->rc != LF_OK) break;
         chunk_t *C = &B->chunks[k];
         ctx_t cx; memset(&cx, 0, sizeof cx);
-        cx.ix = B->ix; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane]; cx.host_cigar = B->host_cigar; cx.host_vote = B->host_vote;
+        cx.ix = B->ix; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane]; cx.host_cigar = B->host_cigar; cx.host_vote = B->host_vote; cx.lazy = !B->host_cigar && !getenv("LF_NO_LAZY");
         cx.n_reads = C->i1 - C->i0;
         cx.reads = (rd_t *)calloc((size_t)cx.n_reads, sizeof(rd_t));
         for (int i = C->i0; i < C->i1; i++) {

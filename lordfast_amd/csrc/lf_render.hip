@@ -27,7 +27,7 @@
 #include "lf_internal.h"
 #include "lf_gpu_common.h"
 
-struct lf_rrounds { const uint8_t *ops[LF_MAX_ED_ROUNDS]; };
+struct lf_rrounds { const uint8_t *ops[LF_MAX_ED_ROUNDS]; const lf_aln_desc_t *desc[LF_MAX_ED_ROUNDS]; };
 
 __device__ __forceinline__ int lf_ndigits(uint32_t v)
 {
@@ -66,7 +66,7 @@ __device__ __forceinline__ char lf_pac_char(const uint8_t *pac, uint32_t pos, in
 template <bool WRITE>
 __global__ void __launch_bounds__(64)
 lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_ritem_t *__restrict__ items, lf_rrounds R,
-                 const uint8_t *__restrict__ pac, uint32_t *__restrict__ lens /* 2 per record */,
+                 const uint8_t *__restrict__ pac, const unsigned char *__restrict__ reads, uint32_t *__restrict__ lens /* 2 per record */,
                  const uint64_t *__restrict__ offs /* 2 per record (WRITE) */, char *__restrict__ text)
 {
     const int rec = blockIdx.x;
@@ -109,13 +109,27 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
         /* an edit path: I.n ops at R.ops[round] + ops_begin, forward or reversed */
         const uint8_t *ops = R.ops[I.round] + I.ops_begin;
         const int rev = (I.kind == LF_RI_OPS_REV), trc = (I.kind == LF_RI_OPS_FWD_TRC);
-        uint32_t tcarry = 0;
+        uint32_t tcarry = 0, qcarry = 0;
+        /* a lazy path has op 0 for EVERY diagonal move: match / mismatch is decided here, by the comparison the edlib
+         * kernels would have made (same accessors, same indices in the problem's own orientation) -- but coalesced */
+        lf_aln_desc_t dsc; dsc.qstart = 0; dsc.tstart = 0; dsc.flags = 0;
+        if (I.lazy) dsc = R.desc[I.round][I.slot];
+        const lf_qacc QA(reads, dsc.qstart, dsc.flags); const lf_tacc TA(nullptr, pac, dsc.tstart, dsc.flags | LF_F_TPAC);
         for (uint32_t base = 0; base < I.n; base += 64) {
             const uint32_t k = base + lane;
             const bool act = k < I.n;
             const uint32_t cnt = (I.n - base < 64u) ? I.n - base : 64u;
             int ty = T_EQ;
             if (act) { const uint8_t op = ops[rev ? I.n - 1 - k : k]; ty = op == 0 ? T_EQ : op == 1 ? T_I : op == 2 ? T_D : T_X; }
+            if (I.lazy) {
+                const uint64_t nd_mask = __ballot(act && ty != T_D), ni_mask = __ballot(act && ty != T_I);
+                if (act && ty == T_EQ) {
+                    const uint32_t qe = qcarry + (uint32_t)__popcll(nd_mask & below), te = tcarry + (uint32_t)__popcll(ni_mask & below);
+                    const uint32_t qi = rev ? I.qn - 1 - qe : qe, ti2 = rev ? I.tcons - 1 - te : te;
+                    if (QA.get(qi) != TA.get(ti2)) ty = T_X;
+                }
+                qcarry += (uint32_t)__popcll(nd_mask);
+            }
             const int ch = !act ? 0 : (ty == T_I ? 'I' : ty == T_D ? 'D' : 'M');
             /* ---- CIGAR ---- */
             int pch = __shfl_up(ch, 1, 64); if (lane == 0) pch = c_ch;
@@ -183,7 +197,7 @@ struct lf_widen32 { __host__ __device__ uint64_t operator()(uint32_t v) const { 
 /* host entry: items / records in (pinned) host memory; rounds[r] = device address of round r's ops (or NULL);
  * text comes back in a pinned slot, offs[2*rec], offs[2*rec+1] = start of the record's CIGAR / MD (NUL-terminated). */
 extern "C" int lfg_render(const struct lf_index *ix, int n_recs, const lf_rrecord_t *recs, uint64_t n_items, const lf_ritem_t *items,
-                          const void *const *round_ops, char **text_out, uint64_t **offs_out, uint64_t *text_bytes, float *ms)
+                          const void *const *round_ops, const void *const *round_desc, char **text_out, uint64_t **offs_out, uint64_t *text_bytes, float *ms)
 {
     if (ms) *ms = 0;
     *text_out = nullptr; *offs_out = nullptr; *text_bytes = 0;
@@ -207,12 +221,13 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_recs, const lf_rrecor
     void *d_tmp = lfg_dev_slot(device, LF_DS_RENDER0 + 4, tb + 256);
     if (!d_tmp) return LF_ERR_NOMEM;
     lf_rrounds R;
-    for (int r = 0; r < LF_MAX_ED_ROUNDS; r++) R.ops[r] = (const uint8_t *)round_ops[r];
+    for (int r = 0; r < LF_MAX_ED_ROUNDS; r++) { R.ops[r] = (const uint8_t *)round_ops[r]; R.desc[r] = (const lf_aln_desc_t *)round_desc[r]; }
+    const unsigned char *d_reads = (const unsigned char *)lfg_dev_slot(device, LF_DS_SEED0 + 0, 0);      /* read batch left in HBM by lfg_seed */
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipMemcpyAsync(d_recs, recs, (size_t)n_recs * sizeof(lf_rrecord_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_items, items, (size_t)n_items * sizeof(lf_ritem_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(lf_render_kernel<false>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac,
+    hipLaunchKernelGGL(lf_render_kernel<false>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac, d_reads,
                        d_lens, (const uint64_t *)nullptr, (char *)nullptr);
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, in, d_offs, 2 * n_recs, s));
     HIPCHK(hipMemcpyAsync(h_offs, d_offs, (size_t)n_recs * 16, hipMemcpyDeviceToHost, s));
@@ -222,7 +237,7 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_recs, const lf_rrecor
     char *d_text = (char *)lfg_dev_slot(device, LF_DS_RENDER0 + 5, total + 64);
     char *h_text = (char *)lfg_pin_slot(LF_PS_RENDER0 + 2, total + 64);
     if (!d_text || !h_text) return LF_ERR_NOMEM;
-    hipLaunchKernelGGL(lf_render_kernel<true>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac,
+    hipLaunchKernelGGL(lf_render_kernel<true>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac, d_reads,
                        d_lens, (const uint64_t *)d_offs, d_text);
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipMemcpyAsync(h_text, d_text, total, hipMemcpyDeviceToHost, s));
