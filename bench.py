@@ -242,6 +242,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    cpu0 = sum(os.times()[:4])
     agg = None
     sam = None
     for _ in range(args.steps):
@@ -255,6 +256,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    cpu_s = sum(os.times()[:4]) - cpu0
     bases_total = bases_local
     if dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
@@ -327,7 +329,7 @@ def main():
                        "reads_per_gpu": args.reads, "mean_read_len": bases / max(1, n_total), "genome_mbp": args.genome_mbp,
                        "parallelism": f"reads sharded over {world} GPU(s), index replicated, no data-path collective"
                                       + (" + SAM gather to rank 0" if (dist and args.single_output) else ""), "index": "FM-index + full SA resident in HBM"},
-            "gbp_per_s": bases * K / elapsed / 1e9,
+            "gbp_per_s": bases * K / elapsed / 1e9, "host_cpu_seconds_per_step": cpu_s / K,
             "host_ms_per_step": {k: agg[k] / K for k in ("ms_total", "ms_python_call", "ms_seed", "ms_vote", "ms_chain", "ms_extend", "ms_render", "ms_sam")},
             "per_read": {"seeds": agg["n_seeds"] / (n_total * K / world), "edlib_problems": agg["n_edlib_problems"] / (n_total * K / world),
                          "seed_bytes": (16 * agg["n_cache"] + 64 * agg["n_occblk"] + 8 * agg["n_sa"] + agg["n_readbytes"]) / (n_total * K / world),

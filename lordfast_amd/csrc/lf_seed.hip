@@ -73,6 +73,11 @@ extern "C" int lfg_device_count(void)
 
 extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const uint64_t *sa_sampled)
 {
+    /* The chunk drivers wait for the GPU many times per chunk.  HIP's default wait spins on the CPU; with eight drivers
+     * that burns half of a 16-CPU quota.  Blocking waits give those cores to the worker pool (LF_SPIN_WAIT=1 keeps
+     * the default). */
+    if (!getenv("LF_SPIN_WAIT")) { (void)hipSetDevice(ix->device); (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
+
     HIPCHK(hipSetDevice(ix->device));
     lf_dev_state *st = new lf_dev_state();
     memset(st, 0, sizeof(*st));
