@@ -157,6 +157,25 @@ typedef struct {
 int  lf_map_batch(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,
                   const char *const *seqs, const char *const *quals, char **sam, size_t *sam_len,
                   lf_stats_t *stats);
+/* ------------------------------------------------------------------------------------------------
+ * Either side of the path: FASTA / FASTQ (plain or gzip) reader with the reference's record grammar
+ * (src/Reads.cpp:43-131, kseq over gzFile) and the `--search` loop of src/baseFAST.cpp:56-81 as one call.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lf_reads lf_reads_t;
+typedef struct lf_read_batch lf_read_batch_t;
+int  lf_reads_open(const char *path, lf_reads_t **out);
+/* up to max_reads records / max_bases sequence bytes (0 = no limit); *out = NULL at end of input */
+int  lf_reads_next(lf_reads_t *r, int max_reads, uint64_t max_bases, lf_read_batch_t **out);
+void lf_reads_close(lf_reads_t *r);
+int  lf_read_batch_size(const lf_read_batch_t *b);
+const char *const *lf_read_batch_names(const lf_read_batch_t *b);
+const char *const *lf_read_batch_seqs(const lf_read_batch_t *b);
+const char *const *lf_read_batch_quals(const lf_read_batch_t *b);     /* "" for FASTA records (printed as "*") */
+void lf_read_batch_free(lf_read_batch_t *b);
+/* reads_path -> SAM at out_path (NULL or "-": stdout); the next batch is read while the current one is on the GPU */
+int  lf_map_file(const lf_index_t *idx, const lf_params_t *p, const char *reads_path, const char *out_path, int no_header,
+                 const char *cmdline, int batch_reads, lf_stats_t *total);
+
 /* same, SAM text written into a caller-owned buffer (reusable / pinned); LF_ERR_NOMEM when out_cap is too small */
 int  lf_map_batch_into(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,
                        const char *const *seqs, const char *const *quals, char *out, size_t out_cap, size_t *sam_len,

@@ -102,6 +102,36 @@ def lib():
     return L
 
 
+def read_file(path: str, batch_reads: int = 0, batch_bases: int = 0):
+    """FASTA / FASTQ (plain or gzip) -> list of batches [(names, seqs, quals)] parsed by the library's reader
+    (quals: b"" for FASTA records)."""
+    L = lib()
+    L.lf_reads_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    L.lf_reads_next.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.lf_reads_close.argtypes = [C.c_void_p]
+    L.lf_read_batch_free.argtypes = [C.c_void_p]
+    L.lf_read_batch_size.argtypes = [C.c_void_p]
+    for f in ("lf_read_batch_names", "lf_read_batch_seqs", "lf_read_batch_quals"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = C.POINTER(C.c_char_p)
+    h = C.c_void_p()
+    _check(L.lf_reads_open(path.encode(), C.byref(h)), "lf_reads_open")
+    out = []
+    try:
+        while True:
+            b = C.c_void_p()
+            _check(L.lf_reads_next(h, batch_reads, batch_bases, C.byref(b)), "lf_reads_next")
+            if not b.value:
+                break
+            n = L.lf_read_batch_size(b)
+            na, sa, qa = L.lf_read_batch_names(b), L.lf_read_batch_seqs(b), L.lf_read_batch_quals(b)
+            out.append(([na[i] for i in range(n)], [sa[i] for i in range(n)], [qa[i] for i in range(n)]))
+            L.lf_read_batch_free(b)
+    finally:
+        L.lf_reads_close(h)
+    return out
+
+
 def device_count() -> int:
     return lib().lf_device_count()
 
@@ -252,6 +282,16 @@ class LordFast:
         _check(self.L.lf_map_batch_into(self.h, C.byref(p), len(names), na, sa, q, C.c_void_p(out_ptr), out_cap,
                                         C.byref(ln), C.byref(st)), "lf_map_batch_into")
         return ln.value, st.as_dict()
+
+    def map_file(self, reads_path: str, out_path: str, params: Params | None = None, header: bool = True, cmdline: str = "",
+                 batch_reads: int = 0):
+        """reads file -> SAM file (lf_map_file): the reader runs ahead of the GPU.  -> stats dict"""
+        p = params or default_params()
+        st = Stats()
+        self.L.lf_map_file.argtypes = [C.c_void_p, C.POINTER(Params), C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(Stats)]
+        _check(self.L.lf_map_file(self.h, C.byref(p), reads_path.encode(), out_path.encode(), 0 if header else 1, cmdline.encode(),
+                                  batch_reads, C.byref(st)), "lf_map_file")
+        return st.as_dict()
 
     def sam_header(self, cmdline: str, params: Params | None = None) -> bytes:
         p = params or default_params()

@@ -200,3 +200,20 @@ def test_sam_tandem_repeats_tie_order(tmp_path, oracle_lib):
     orc.close()
     assert st["n_tie_requests"] > 0, "the fixture must produce chain requests with equal qPos"
     assert sam == exp, first_diff(sam, exp)
+
+
+def test_map_file_fasta_gz(lf, golden_dir, tmp_path):
+    """lf_map_file: gzip FASTA in (the reference's reader grammar), SAM with header out, batches read ahead of the GPU"""
+    import lordfast_amd as la
+    out = str(tmp_path / "out.sam")
+    reads = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reads.fa.gz")
+    p = la.default_params(**GOLDEN_CONFIGS["default"])
+    st = lf.map_file(reads, out, params=p, cmdline="lordfast --search x", batch_reads=25)
+    got = open(out, "rb").read()
+    hdr = lf.sam_header("lordfast --search x", p)
+    assert got.startswith(hdr)
+    assert got[len(hdr):] == golden_sam("default"), first_diff(got[len(hdr):], golden_sam("default"))
+    assert st["n_reads"] > 0
+    out2 = str(tmp_path / "out2.sam")
+    lf.map_file(reads, out2, params=p, header=False)
+    assert open(out2, "rb").read() == golden_sam("default")

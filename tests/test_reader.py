@@ -1,0 +1,136 @@
+"""The library's FASTA/FASTQ(.gz) reader must yield what the reference's reader (kseq over gzFile, src/Reads.cpp) yields.
+CPU only: parsing needs no device.  Pinned two ways: a pure-Python statement of kseq's record grammar, and the compiled
+reference itself (mapping a file through its own reader == mapping our parsed records from memory)."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from conftest import have_ref
+
+
+def kseq_python(data: bytes):
+    """kseq_read (lib/bwa/kseq.h:176-215), restated; returns [(name, seq, qual)] and stops at the first malformed record"""
+    recs, i, n = [], 0, len(data)
+
+    def line(j):                      # -> (text without newline / trailing CR as kseq trims it, next index, hit_eof)
+        k = data.find(b"\n", j)
+        if k < 0:
+            return data[j:], n, True
+        return data[j:k], k + 1, False
+    last = 0
+    while True:
+        if not last:
+            while i < n and data[i:i + 1] not in (b">", b"@"):
+                i += 1
+            if i >= n:
+                break
+            i += 1
+        j = i
+        while j < n and data[j:j + 1] not in (b" ", b"\t", b"\n", b"\v", b"\f", b"\r"):
+            j += 1
+        name = data[i:j]
+        if j >= n and not name:
+            break
+        delim = data[j:j + 1]
+        i = j + 1
+        if delim != b"\n" and j < n:
+            _, i, _ = line(i)
+        seq = b""
+        last = 0
+        c = b""
+        while i < n:
+            c = data[i:i + 1]
+            i += 1
+            if c in (b">", b"+", b"@"):
+                break
+            if c == b"\n":
+                c = b""
+                continue
+            rest, i, _ = line(i)
+            seq += c + rest
+            if len(seq) > 1 and seq.endswith(b"\r"):
+                seq = seq[:-1]
+            c = b""
+        if c in (b">", b"@"):
+            last = 1
+        if c != b"+":
+            recs.append((name, seq, b""))
+            if i >= n and not last:
+                break
+            continue
+        if i >= n:
+            break
+        _, i, eof = line(i)
+        if eof:
+            break
+        qual = b""
+        while len(qual) < len(seq) and i < n:
+            rest, i, _ = line(i)
+            qual += rest
+            if len(qual) > 1 and qual.endswith(b"\r"):
+                qual = qual[:-1]
+        if len(qual) != len(seq):
+            break
+        recs.append((name, seq, qual))
+    return recs
+
+
+CASES = {
+    "fasta_multiline": b">r1 some comment\nACGT\nAC\n\nGG\n>r2\tx\nTTTT\n>empty\n>r3\nA\n",
+    "fasta_crlf": b">r1 c\r\nACGT\r\nGG\r\n>r2\r\nTT\r\n",
+    "fastq": b"@q1 desc\nACGTAC\n+\nIIIIII\n@q2\nAC\nGT\n+q2\nII\nII\n",
+    "fastq_at_in_qual": b"@q1\nACGT\n+\n@III\n@q2\nAA\n+\n>>\n",
+    "mixed": b"junk before\n>r1\nACGT\n@q1\nAC\n+\nII\n>r2\nGG",
+    "no_trailing_newline": b">r1\nACGT",
+    "truncated_quality": b"@q1\nACGT\n+\nIIII\n@q2\nACGT\n+\nII\n",
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("gz", [False, True])
+def test_reader_matches_kseq_grammar(tmp_path, name, gz):
+    import lordfast_amd as la
+    data = CASES[name]
+    path = str(tmp_path / (name + (".gz" if gz else ".txt")))
+    with (gzip.open(path, "wb") if gz else open(path, "wb")) as fh:
+        fh.write(data)
+    got = [(n, s, q) for names, seqs, quals in la.read_file(path) for n, s, q in zip(names, seqs, quals)]
+    assert got == kseq_python(data)
+    # batching does not change the record stream
+    got2 = [(n, s, q) for names, seqs, quals in la.read_file(path, batch_reads=1) for n, s, q in zip(names, seqs, quals)]
+    assert got2 == got
+
+
+def test_reader_vs_reference_reader(tmp_path, golden_dir, golden_reads):
+    """the compiled reference reading the file itself == the compiled reference fed with OUR parse of that file"""
+    if not have_ref():
+        pytest.skip("needs oracle/_ref/liblfref.so")
+    import lordfast_amd as la
+    from oracle import pyoracle as po
+    names, seqs = golden_reads
+    names, seqs = names[:24], seqs[:24]
+    rng = np.random.default_rng(3)
+    path = str(tmp_path / "reads.fq.gz")
+    with gzip.open(path, "wb") as fh:
+        for i, (n, s) in enumerate(zip(names, seqs)):
+            if i % 3 == 0:                              # FASTA record, wrapped lines, a comment
+                fh.write(b">" + n + b" comment text\n" + b"\n".join(s[k:k + 70] for k in range(0, len(s), 70)) + b"\n")
+            else:                                       # FASTQ record (qualities without '@' / '+' line starts are not required by kseq)
+                q = bytes(rng.integers(35, 74, size=len(s)).astype(np.uint8))
+                fh.write(b"@" + n + b"\n" + s + b"\n+\n" + q + b"\n")
+    batches = la.read_file(path)
+    pn = [x for b in batches for x in b[0]]
+    ps = [x for b in batches for x in b[1]]
+    pq = [x if x else b"*" for b in batches for x in b[2]]
+    assert pn == list(names) and ps == list(seqs)
+    ref = po.Ref()
+    fa = os.path.join(golden_dir, "genome.fa")
+    if not os.path.exists(fa + ".cache"):
+        ref.index_build(fa)                              # the reference's loader wants its 12-mer cache file
+    ref.load(fa)
+    ref.set_params(po.default_params(threads=1), "reader-test")
+    sam_file, _ = ref.map_file(path, header=False)
+    sam_mem, _ = ref.map_mem(pn, ps, [q if q != b"*" else b"" for q in pq])
+    assert sam_file == sam_mem
