@@ -28,7 +28,7 @@ import numpy as np  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("LF_BENCH_GENOME_MBP", "3100")))
     ap.add_argument("--reads", type=int, default=int(os.environ.get("LF_BENCH_READS", "100000")), help="reads per GPU per step")

@@ -113,7 +113,7 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
         /* a lazy path has op 0 for EVERY diagonal move: match / mismatch is decided here, by the comparison the edlib
          * kernels would have made (same accessors, same indices in the problem's own orientation) -- but coalesced */
         lf_aln_desc_t dsc; dsc.qstart = 0; dsc.tstart = 0; dsc.flags = 0;
-        if (I.lazy) dsc = R.desc[I.round][I.slot];
+        if (I.lazy && !WRITE) dsc = R.desc[I.round][I.slot];
         const lf_qacc QA(reads, dsc.qstart, dsc.flags); const lf_tacc TA(nullptr, pac, dsc.tstart, dsc.flags | LF_F_TPAC);
         for (uint32_t base = 0; base < I.n; base += 64) {
             const uint32_t k = base + lane;
@@ -121,12 +121,12 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
             const uint32_t cnt = (I.n - base < 64u) ? I.n - base : 64u;
             int ty = T_EQ;
             if (act) { const uint8_t op = ops[rev ? I.n - 1 - k : k]; ty = op == 0 ? T_EQ : op == 1 ? T_I : op == 2 ? T_D : T_X; }
-            if (I.lazy) {
+            if (I.lazy && !WRITE) {          /* the counting pass resolves and writes the mismatches back: the writing pass reads final ops */
                 const uint64_t nd_mask = __ballot(act && ty != T_D), ni_mask = __ballot(act && ty != T_I);
                 if (act && ty == T_EQ) {
                     const uint32_t qe = qcarry + (uint32_t)__popcll(nd_mask & below), te = tcarry + (uint32_t)__popcll(ni_mask & below);
                     const uint32_t qi = rev ? I.qn - 1 - qe : qe, ti2 = rev ? I.tcons - 1 - te : te;
-                    if (QA.get(qi) != TA.get(ti2)) ty = T_X;
+                    if (QA.get(qi) != TA.get(ti2)) { ty = T_X; const_cast<uint8_t *>(ops)[rev ? I.n - 1 - k : k] = 3; }
                 }
                 qcarry += (uint32_t)__popcll(nd_mask);
             }
