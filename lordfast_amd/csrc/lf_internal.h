@@ -59,7 +59,6 @@ typedef struct {
     float ms_vote, ms_chain;
 } lfg_vc_t;
 int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, int n_reads, uint64_t n_hits, uint32_t max_read_len, lfg_vc_t *out);
-int  lfg_seed_fetch_hits(const struct lf_index *ix, lfg_hits_t *out);
 void lfg_hits_free(lfg_hits_t *h);
 
 int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, const Seed_t *sorted_seeds,

@@ -5,18 +5,21 @@
  * batch over all reads of a chunk so that each HIP kernel sees 10^5..10^7 independent work items:
  *
  *   A  GPU   seeds of every read                                   lf_seed.hip
- *   B  host  window vote (sparse, same counts/ties as the dense tagged array), coarse/fine decision,
- *            seed selection + std::sort order per candidate window
- *   C  GPU   dp-n2 chains of all candidate windows                 lf_chain.hip
+ *   B  GPU   window vote (sparse, same counts/ties as the dense tagged array), local maxima, top-N heap,
+ *            coarse/fine decision, seed selection + std::sort order per candidate window   lf_vote.hip
+ *   C  GPU   dp-n2 chains of all candidate windows                 lf_chain_kernel.h
  *      host  fine mode: top-N heap replay on the chain scores
  *   D  GPU   alignments.  alignChain_edlib (src/LordFAST.cpp:1765-2258) is data dependent (clip test,
  *            split test), so it is written as a REPLAY: the host walks the reference's control flow,
  *            every alignment it needs is looked up in a memo; a miss registers a request and the walk
  *            continues speculatively on the common path.  Requests of all chains go to the GPU together
  *            (lf_align.hip), then incomplete chains are replayed.  ~99 % finish after one GPU round.
- *   E  host  CIGAR / MD / MAPQ / SAM text (src/LordFAST.cpp:318-459,1570-1763)
+ *   D' GPU   CIGAR / MD text of every record from the paths left in HBM (src/LordFAST.cpp:1570-1763)   lf_render.hip
+ *   E  host  MAPQ, SAM line assembly (src/LordFAST.cpp:318-459)
  *
  * The host never computes a DP cell: no CPU alignment, chaining or FM-index code exists in this library.
+ * LF_HOST_VOTE=1 / LF_HOST_CIGAR=1 switch stage B resp. D' to host implementations that work on data copied back
+ * from the device: diagnostic cross-checks for the tests, never selected automatically.
  */
 #include <math.h>
 #include <pthread.h>
@@ -46,7 +49,7 @@ static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, 
 /* ---------------------------------------------------------------- small containers */
 /* ---- per-worker bump arenas: every chunk-lifetime object of the host glue (seed lists, jobs, memos, CIGAR/MD strings,
  * ...) is carved from the arena of the thread that creates it and released by ONE reset at the end of the chunk.
- * With two chunks in flight, malloc/free pairs that cross threads contend on glibc's arena locks; a bump allocator
+ * With several chunks in flight, malloc/free pairs that cross threads contend on glibc's arena locks; a bump allocator
  * has no locks and no per-object free at all. ---- */
 typedef struct { char **blk; size_t *bsz; int nblk, cur; size_t off; } arena_t;
 #define AR_BLOCK ((size_t)8 << 20)
@@ -251,9 +254,9 @@ typedef struct ctx {
 } ctx_t;
 
 /* ---------------------------------------------------------------- parallel for on a persistent thread pool
- * Two chunks ("lanes") are in flight at once so that the host phases of one overlap the GPU phases of the other.
- * The pool therefore serves up to two jobs concurrently; each lane's driver thread also works on its own job.
- * Worker ids: pool threads 0..nw-1, lane drivers nw and nw+1 (per-worker scratch arrays have nw+2 entries). */
+ * Up to eight chunks ("lanes") are in flight at once so that the host phases of one overlap the GPU phases of the others.
+ * The pool therefore serves one job per lane concurrently; each lane's driver thread also works on its own job.
+ * Worker ids: pool threads 0..nw-1, lane drivers nw..nw+lanes-1 (per-worker scratch arrays have nw+lanes entries). */
 typedef void (*pf_fn)(ctx_t *cx, int tid, int i);
 typedef struct { pf_fn fn; ctx_t *cx; int n, grain; volatile int next; int active, inflight; int timed; volatile long long cpu_ns; } pjob_t;
 typedef struct {
@@ -1561,12 +1564,7 @@ static int map_chunk(ctx_t *cx)
     double tstage[8] = { 0 };
     t1 = now_ms(); st->ms_seed += t1 - t0; tstage[0] = t1 - t0; t0 = t1;
 
-    /* a chunk whose hit count does not fit the device stage's 32-bit sort sizes votes on the host (pathological input) */
-    int host_vote = cx->host_vote;
-    if (!host_vote && (hits.n_hits >= (1ull << 30) || getenv("LF_TEST_VOTE_FALLBACK"))) {
-        if (hits.n_hits) { rc = lfg_seed_fetch_hits(cx->ix, &hits); if (rc != LF_OK) return rc; }
-        host_vote = 1; cx->host_vote = 1;           /* this chunk only: lane_main resets it */
-    }
+    const int host_vote = cx->host_vote;
     if (!host_vote) {
         /* ---- B + C on the device: votes -> candidate windows -> sorted requests -> chains; only chains come back ---- */
         uint32_t max_len = 0;
@@ -1988,7 +1986,7 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
 
     batch_t B; memset(&B, 0, sizeof B);
     B.host_cigar = getenv("LF_HOST_CIGAR") != NULL;
-    B.host_vote = getenv("LF_HOST_VOTE") != NULL || p->max_map > 64;     /* the selection kernel keeps the top-N heap in 64 LDS slots */
+    B.host_vote = getenv("LF_HOST_VOTE") != NULL;          /* diagnostic cross-check only; the device stage is the product path */
     B.ix = ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + n_lanes; B.rc = LF_OK;
     pthread_mutex_init(&B.mu, NULL); pthread_cond_init(&B.cv, NULL); pthread_rwlock_init(&B.grow, NULL);
     if (ext_buf) { B.all.s = ext_buf; B.all.cap = ext_cap; B.all.n = 0; B.all.mode = 2; B.fixed_out = 1; }

@@ -379,28 +379,6 @@ extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_r
     return LF_OK;
 }
 
-/* the hits of the last lfg_seed(want_hits = 0) call of this lane, copied to the host after all (fallback of the
- * device vote stage when a chunk has more hits than its 32-bit sort sizes take) */
-extern "C" int lfg_seed_fetch_hits(const struct lf_index *ix, lfg_hits_t *out)
-{
-    const int dv = ix->device;
-    HIPCHK(hipSetDevice(dv));
-    hipStream_t s = (hipStream_t)lfg_lane_stream(dv, 0);
-    if (!s) return LF_ERR_HIP;
-    const uint64_t n_hits = out->n_hits;
-    const uint32_t *d_tpos = (const uint32_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 9, 0), *d_qpl = (const uint32_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 10, 0);
-    const uint8_t *d_strand = (const uint8_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 11, 0);
-    out->tpos = (uint32_t *)lfg_pin_slot(LF_PS_HITS_T, (n_hits + 1) * 4);
-    out->qpl = (uint32_t *)lfg_pin_slot(LF_PS_HITS_Q, (n_hits + 1) * 4);
-    out->strand = (uint8_t *)lfg_pin_slot(LF_PS_HITS_S, n_hits + 1);
-    if (!d_tpos || !d_qpl || !d_strand || !out->tpos || !out->qpl || !out->strand) return LF_ERR_NOMEM;
-    HIPCHK(hipMemcpyAsync(out->tpos, d_tpos, n_hits * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out->qpl, d_qpl, n_hits * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out->strand, d_strand, n_hits, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    return LF_OK;
-}
-
 extern "C" void lfg_hits_free(lfg_hits_t *h)
 {
     memset(h, 0, sizeof(*h));      /* the arrays live in persistent pinned slots */

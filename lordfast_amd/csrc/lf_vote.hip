@@ -61,6 +61,7 @@ lf_vote_keys_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_
 }
 
 /* ---- 3: selection ---- */
+#define LF_VOTE_MAX_WIN 1024                            /* -n / max_map bound of the selection kernel (LDS heap) */
 struct lf_hwin { float score; uint32_t win; };        /* win | isReverse << 31 */
 #define HWIN_LESS(a, b) ((a)->score > (b)->score)      /* compareWin (src/LordFAST.cpp:981-984) */
 LF_DEFINE_STDSORT(dwinh, lf_hwin, HWIN_LESS)
@@ -78,7 +79,7 @@ lf_vote_select_kernel(int n_reads, const uint64_t *__restrict__ off, const uint6
                       uint8_t *__restrict__ mode, uint32_t *__restrict__ nreq, int64_t *__restrict__ seg0,
                       uint32_t *__restrict__ stage /* n_runs */, float *__restrict__ vscore)
 {
-    __shared__ lf_hwin heap[64];
+    __shared__ lf_hwin heap[LF_VOTE_MAX_WIN];
     __shared__ uint32_t s_win[64], s_cnt[64];
     __shared__ int s_n; __shared__ float s_min;
     const int r = blockIdx.x, lane = threadIdx.x;
@@ -288,6 +289,7 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     hipStream_t s = (hipStream_t)lfg_lane_stream(dv, 0);
     if (!s) return LF_ERR_HIP;
     if (n_reads >= (1 << 20)) { lf_set_error("lfg_vote_chain: too many reads in one chunk"); return LF_ERR_ARG; }
+    if (p->max_map > LF_VOTE_MAX_WIN) { lf_set_error("lfg_vote_chain: -n %d exceeds the %d candidate windows the selection kernel keeps", p->max_map, LF_VOTE_MAX_WIN); return LF_ERR_ARG; }
     /* left in HBM by lfg_seed */
     const uint64_t *d_off = (const uint64_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 1, 0), *d_read_off = (const uint64_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 6, 0);
     const uint32_t *d_tpos = (const uint32_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 9, 0), *d_qpl = (const uint32_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 10, 0);
@@ -314,7 +316,7 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     uint32_t *d_stage = nullptr;
     if (n_hits) {
         const uint64_t E = 2 * n_hits;
-        if (E >= (1ull << 31)) { lf_set_error("lfg_vote_chain: too many hits in one chunk (%llu)", (unsigned long long)n_hits); return LF_ERR_ARG; }
+        if (E >= (1ull << 31)) { lf_set_error("lfg_vote_chain: %llu seed hits in one chunk exceed the 2^30 the vote sort takes; use smaller chunks (LF_CHUNK_READS)", (unsigned long long)n_hits); return LF_ERR_ARG; }
         uint64_t *d_keys = (uint64_t *)VSLOT(1, E * 8), *d_keys2 = (uint64_t *)VSLOT(2, E * 8);
         uint32_t *d_vals = (uint32_t *)VSLOT(3, E * 4), *d_vals2 = (uint32_t *)VSLOT(4, E * 4);
         if (!d_keys || !d_keys2 || !d_vals || !d_vals2) return LF_ERR_NOMEM;

@@ -70,14 +70,6 @@ def test_sam_host_vote_crosscheck(lf, golden_reads, monkeypatch, cfg):
     assert sam == exp, first_diff(sam, exp)
 
 
-def test_sam_vote_fallback_after_device_seeding(lf, golden_reads, monkeypatch):
-    """a chunk with too many hits for the device vote stage copies its hits back and votes on the host"""
-    names, seqs = golden_reads
-    monkeypatch.setenv("LF_TEST_VOTE_FALLBACK", "1")
-    sam, st = lf.map_batch(names, seqs)
-    assert sam == golden_sam("default")
-
-
 def test_map_batch_into_caller_buffer(lf, golden_reads):
     """lf_map_batch_into: same records into a caller-owned buffer; a buffer that is too small is an error, not a truncation"""
     import ctypes as C
@@ -152,7 +144,7 @@ def big_case(tmp_path_factory, oracle_lib):
     return fa, reads
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(max_map=30), dict(min_anchor_len=17, sampling_count=2000)])
+@pytest.mark.parametrize("kw", [dict(), dict(max_map=30), dict(max_map=100), dict(min_anchor_len=17, sampling_count=2000)])
 def test_sam_vs_oracle_big(big_case, oracle_lib, kw):
     import lordfast_amd as la
     fa, reads = big_case
