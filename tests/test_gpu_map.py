@@ -209,3 +209,46 @@ def test_map_file_fasta_gz(lf, golden_dir, tmp_path):
     out2 = str(tmp_path / "out2.sam")
     lf.map_file(reads, out2, params=p, header=False)
     assert open(out2, "rb").read() == golden_sam("default")
+
+
+def test_sam_very_long_reads(tmp_path, oracle_lib):
+    """55-125 kbp reads: chains of hundreds of anchors, gap problems above edlib's leaf size (host-orchestrated Hirschberg
+    splits on the helper thread), the n > 2048 wave classes and records of > 10^5 CIGAR pieces"""
+    import lordfast_amd as la
+    g = synth.make_genome(1200000, 4, seed=31, n_families=60, repeat_frac=0.12)
+    fa = la.index_build(g, str(tmp_path / "g.fa"))
+    reads = synth.make_reads(g, 3, 130000, 0.12, seed=13, sigma=0.1) + synth.make_reads(g, 2, 60000, 0.15, seed=14, sigma=0.1) \
+        + synth.make_reads(g, 2, 90000, 0.20, seed=15, sigma=0.1)
+    names = [r[0].encode() for r in reads]
+    seqs = [r[1] for r in reads]
+    assert max(len(x) for x in seqs) > 100000
+    h = la.LordFast(fa, device=0)
+    sam, st = h.map_batch(names, seqs)
+    h.close()
+    orc = oracle_lib.Oracle(fa)
+    exp = orc.map_batch(names, seqs, params=oracle_lib.default_params(threads=8))
+    orc.close()
+    assert sam == exp, first_diff(sam, exp)
+
+
+def test_sam_lowercase_and_n_bases(lf, oracle, golden_reads):
+    """seeding is case-insensitive (nst_nt4_table) but edlib compares raw bytes: lower-case read bases never match the
+    upper-case reference (SURVEY App. B #11); N never seeds and never matches"""
+    names, seqs = golden_reads
+    rng = np.random.default_rng(123)
+    out_names, out_seqs = [], []
+    for i, (n, s) in enumerate(zip(names[:40], seqs[:40])):
+        b = bytearray(s)
+        L = len(b)
+        if i % 3 == 0:                                  # a lower-case stretch
+            a = int(rng.integers(0, max(1, L - 400))); b[a:a + 300] = bytes(b[a:a + 300]).lower()
+        if i % 3 == 1:                                  # runs of N
+            for _ in range(3):
+                a = int(rng.integers(0, max(1, L - 60))); b[a:a + int(rng.integers(1, 40))] = b"N" * len(b[a:a + int(rng.integers(1, 40))])
+        if i % 3 == 2:                                  # scattered lower case + IUPAC codes
+            for p in rng.integers(0, L, size=25):
+                b[int(p)] = ord("acgtRYn"[int(rng.integers(0, 7))])
+        out_names.append(n); out_seqs.append(bytes(b))
+    sam, _ = lf.map_batch(out_names, out_seqs)
+    exp = oracle.map_batch(out_names, out_seqs)
+    assert sam == exp, first_diff(sam, exp)
