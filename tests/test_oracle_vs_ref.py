@@ -158,3 +158,42 @@ def test_fastq_qualities(big_case, ref, oracle_lib):
     exp, _ = ref.map_mem(names, seqs, quals)
     assert orc.map_batch(names, seqs, quals, params=p) == exp
     orc.close()
+
+
+def test_special_inputs_vs_reference(golden_dir, golden_reads, ref, oracle_lib, tmp_path):
+    """the oracle against the compiled reference on inputs the GPU parity tests use: lower-case / N / IUPAC bases,
+    and 50-130 kbp reads (Hirschberg-size gap problems)"""
+    names, seqs = golden_reads
+    rng = np.random.default_rng(123)
+    on, os_ = [], []
+    for i, (n, s) in enumerate(zip(names[:40], seqs[:40])):
+        b = bytearray(s)
+        L = len(b)
+        if i % 3 == 0:
+            a = int(rng.integers(0, max(1, L - 400))); b[a:a + 300] = bytes(b[a:a + 300]).lower()
+        if i % 3 == 1:
+            for _ in range(3):
+                a = int(rng.integers(0, max(1, L - 60))); b[a:a + int(rng.integers(1, 40))] = b"N" * len(b[a:a + int(rng.integers(1, 40))])
+        if i % 3 == 2:
+            for p in rng.integers(0, L, size=25):
+                b[int(p)] = ord("acgtRYn"[int(rng.integers(0, 7))])
+        on.append(n); os_.append(bytes(b))
+    fa = os.path.join(golden_dir, "genome.fa")
+    if not os.path.exists(fa + ".cache"):
+        ref.index_build(fa)
+    ref.load(fa)
+    ref.set_params(oracle_lib.default_params(threads=1), "special")
+    orc = oracle_lib.Oracle(fa)
+    assert ref.map_mem(on, os_)[0] == orc.map_batch(on, os_, params=oracle_lib.default_params(threads=1))
+    orc.close()
+    g = synth.make_genome(1200000, 4, seed=31, n_families=60, repeat_frac=0.12)
+    fa2 = str(tmp_path / "g.fa")
+    synth.write_fasta(fa2, g)
+    ref.index_build(fa2)
+    ref.load(fa2)
+    reads = synth.make_reads(g, 2, 130000, 0.12, seed=13, sigma=0.1) + synth.make_reads(g, 2, 60000, 0.15, seed=14, sigma=0.1)
+    ln = [r[0].encode() for r in reads]
+    ls = [r[1] for r in reads]
+    orc = oracle_lib.Oracle(fa2)
+    assert ref.map_mem(ln, ls)[0] == orc.map_batch(ln, ls, params=oracle_lib.default_params(threads=1))
+    orc.close()
