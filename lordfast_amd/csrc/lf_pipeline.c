@@ -388,14 +388,15 @@ static void chr_boundaries(const struct lf_index *ix, uint64_t beg, uint64_t end
     *ce = (uint32_t)(ix->contigs[rid].offset + ix->contigs[rid].len - 1);
 }
 
-static char rc_char(char c)
-{   /* tableRev, src/Common.cpp:31-40: case kept, anything else 'N' */
-    switch (c) {
-    case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
-    case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
-    default: return 'N';
-    }
+/* tableRev, src/Common.cpp:31-40: case kept, anything else 'N' */
+static char g_rc_tab[256]; static pthread_once_t g_rc_once = PTHREAD_ONCE_INIT;
+static void rc_tab_init(void)
+{
+    memset(g_rc_tab, 'N', sizeof g_rc_tab);
+    g_rc_tab['A'] = 'T'; g_rc_tab['C'] = 'G'; g_rc_tab['G'] = 'C'; g_rc_tab['T'] = 'A';
+    g_rc_tab['a'] = 't'; g_rc_tab['c'] = 'g'; g_rc_tab['g'] = 'c'; g_rc_tab['t'] = 'a';
 }
+static inline char rc_char(char c) { return g_rc_tab[(unsigned char)c]; }
 static void revcomp_into(const char *s, char *out, uint32_t len) { for (uint32_t i = 0; i < len; i++) out[i] = rc_char(s[len - 1 - i]); out[len] = 0; }
 /* reverse complement / reversed copy written straight into the SAM text (src/LordFAST.cpp:501-502 build both strings
  * for every read; only records on the reverse strand ever print them) */
@@ -1498,7 +1499,9 @@ static void *hsolve_main(void *arg)
     hsolve_t *H = (hsolve_t *)arg;
     const int prev = lfg_get_lane();
     lfg_set_lane(H->lane);
+    const long long c0 = g_phase_on ? thread_cpu_ns() : 0;
     H->rc = lf_edlib_solve(H->device, H->n, H->q, H->qoff, H->t, H->toff, H->mode, H->ed, H->end, H->ops, H->ops_len, &H->ms, &H->launches);
+    if (g_phase_on) phase_account("(hirschberg solve thread)", (thread_cpu_ns() - c0) / 1e6, 0);
     if (H->rc != LF_OK) snprintf(H->err, sizeof H->err, "%s", lf_last_error());
     lfg_set_lane(prev);
     return NULL;
@@ -1882,6 +1885,7 @@ static void *lane_main(void *arg_)
     const int lane = (int)(intptr_t)((void **)arg_)[1];
     const int timing = getenv("LF_TIMING") != NULL;
     lfg_set_lane(lane);
+    const long long lane_c0 = g_phase_on ? thread_cpu_ns() : 0;
     lf_stats_t *st = &B->st[lane];
     for (;;) {
         const int k = __sync_fetch_and_add(&B->next_chunk, 1);
@@ -1940,6 +1944,7 @@ static void *lane_main(void *arg_)
         free(cx.reads);
         if (timing) fprintf(stderr, "[lf] lane %d chunk %d: chunk_free %.1f ms\n", lane, k, now_ms() - tch);
     }
+    if (g_phase_on) phase_account("(lane driver threads, incl. their share of the phases)", (thread_cpu_ns() - lane_c0) / 1e6, 0);
     return NULL;
 }
 
@@ -1977,6 +1982,7 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
     const double T0 = now_ms();
     pthread_mutex_lock(&g_map_lock);
     g_phase_on = getenv("LF_PHASES") != NULL;
+    pthread_once(&g_rc_once, rc_tab_init);
     /* chunks in flight: the host phases of one overlap the GPU phases of the others */
     int n_lanes = nt >= 16 ? 8 : (nt >= 8 ? 4 : (nt >= 3 ? 2 : 1));
     if (getenv("LF_LANES")) { n_lanes = atoi(getenv("LF_LANES")); if (n_lanes < 1) n_lanes = 1; if (n_lanes > LF_MAX_LANES) n_lanes = LF_MAX_LANES; if (n_lanes > 1 && nt < n_lanes + 1) n_lanes = 1; }
