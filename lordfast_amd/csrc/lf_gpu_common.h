@@ -19,16 +19,17 @@ struct lf_dev_index {
     const uint64_t *sa_sampled; /* every 32nd row (lib/bwa/bwt.c:62-84), sa[0] = -1 */
     const uint64_t *sa_full;    /* seq_len + 1 rows, or NULL */
     const uint64_t *cache;      /* 4^12 x (beg,end): SA interval of every 12-mer (src/BWT.cpp:60-115) */
+    const uint64_t *cache14;    /* 4^14 x (beg,end), or NULL: two search steps saved per sample when -k >= 14 (4.3 GB; large genomes) */
     const uint8_t  *pac;
 };
 
 struct lf_dev_state {           /* host-side owner of the device allocations */
     lf_dev_index view;
-    void *bwt, *sa_sampled, *sa_full, *cache, *pac;
+    void *bwt, *sa_sampled, *sa_full, *cache, *cache14, *pac;
     hipStream_t stream;
 };
 
-int lfg_build_cache_table(const lf_dev_index *v, hipStream_t stream, uint64_t **table);
+int lfg_build_cache_table(const lf_dev_index *v, hipStream_t stream, int K, uint64_t **table);
 
 __device__ __forceinline__ int lf_nt4(unsigned char ch)
 {   /* nst_nt4_table (lib/bwa/bntseq.c:47-64): A/a C/c G/g T/t -> 0..3, everything else > 3 */

@@ -440,7 +440,7 @@ extern "C" int lf_index_build(const char *fasta_path, int device)
         v.L2[0] = 0; for (int i = 1; i <= 4; i++) v.L2[i] = hdr[i];
         const int K = 12;
         uint64_t *cur = nullptr;
-        if ((rc = lfg_build_cache_table(&v, s, &cur)) != LF_OK) return rc;
+        if ((rc = lfg_build_cache_table(&v, s, 12, &cur)) != LF_OK) return rc;
         std::vector<uint64_t> tab(((size_t)1 << (2 * K)) * 2);
         HIPCHK(hipMemcpy(tab.data(), cur, tab.size() * 8, hipMemcpyDeviceToHost));
         int32_t ch[2] = { K, 1 << (2 * K) };

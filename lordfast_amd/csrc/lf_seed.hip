@@ -43,9 +43,8 @@ __global__ void lf_full_sa_kernel(lf_dev_index ix, uint64_t *__restrict__ sa_ful
 }
 
 /* 12-mer table (src/BWT.cpp:60-115), level by level, ping-pong between two buffers; *table = 4^12 pairs */
-int lfg_build_cache_table(const lf_dev_index *v, hipStream_t stream, uint64_t **table)
+int lfg_build_cache_table(const lf_dev_index *v, hipStream_t stream, int K, uint64_t **table)
 {
-    const int K = 12;
     uint64_t *bufA, *bufB;
     HIPCHK(hipMalloc(&bufA, ((size_t)1 << (2 * K)) * 16));
     HIPCHK(hipMalloc(&bufB, ((size_t)1 << (2 * (K - 1))) * 16));
@@ -100,10 +99,17 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
 
     {
         uint64_t *tab = nullptr;
-        int rc = lfg_build_cache_table(&v, st->stream, &tab);
+        int rc = lfg_build_cache_table(&v, st->stream, 12, &tab);
         if (rc != LF_OK) return rc;
         st->cache = tab;
         v.cache = tab;
+        /* a 14-mer table pays when it is not larger than the text itself (LF_WIDE_TABLE=0/1 overrides) */
+        const char *wt = getenv("LF_WIDE_TABLE");
+        if (wt ? atoi(wt) != 0 : ix->seq_len >= (1ull << 28)) {
+            rc = lfg_build_cache_table(&v, st->stream, 14, &tab);
+            if (rc != LF_OK) return rc;
+            st->cache14 = tab; v.cache14 = tab;
+        }
     }
 
     if (ix->flags & LF_IDX_FULL_SA) {
@@ -126,6 +132,7 @@ extern "C" void lfg_index_free(struct lf_index *ix)
     if (st->sa_sampled) (void)hipFree(st->sa_sampled);
     if (st->sa_full) (void)hipFree(st->sa_full);
     if (st->cache) (void)hipFree(st->cache);
+    if (st->cache14) (void)hipFree(st->cache14);
     if (st->pac) (void)hipFree(st->pac);
     if (st->stream) (void)hipStreamDestroy(st->stream);
     delete st;
@@ -177,20 +184,27 @@ lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ rea
              * rows of P come out of the same pass: m - 12 steps instead of the reference's restart per m.
              * table index: base-4 number with the LAST character of the pattern most significant (src/BWT.cpp:270-277);
              * pattern P12 = q[p..p+12), pattern revcomp(P12) whose last 12 characters are comp(q[p+11..p]) */
+            /* table width W: 14 when the wide table exists and -k >= 14 (a match shorter than k is dropped anyway, so
+             * nothing is lost by starting at 14), else the reference's 12 */
+            const bool wide = ix.cache14 != nullptr && kmin >= 14;
+            const uint32_t W = wide ? 14u : 12u;
+            const uint64_t *__restrict__ tab = wide ? ix.cache14 : ix.cache;
             uint32_t idc = 0, idf = 0; bool ok = true;
 #pragma unroll
-            for (int t = 0; t < 12; t++) {
-                const int c = lf_nt4(q[p + t]); ok &= (c < 4); idc = idc * 4 + (uint32_t)(3 - c);
-                idf = idf * 4 + (uint32_t)lf_nt4(q[p + 11 - t]);
+            for (int t = 0; t < 14; t++) {
+                if ((uint32_t)t < W) {
+                    const int c = lf_nt4(q[p + t]); ok &= (c < 4); idc = idc * 4 + (uint32_t)(3 - c);
+                    idf = idf * 4 + (uint32_t)lf_nt4(q[p + W - 1 - t]);
+                }
             }
             uint32_t m = 0;
             if (ok) {
                 n_cache += 2;
-                uint64_t x1 = ix.cache[2 * (size_t)idc];
-                const uint64_t l1 = ix.cache[2 * (size_t)idc + 1];
+                uint64_t x1 = tab[2 * (size_t)idc];
+                const uint64_t l1 = tab[2 * (size_t)idc + 1];
                 if (x1 <= l1) {
-                    uint64_t x0 = ix.cache[2 * (size_t)idf], sz = l1 - x1 + 1;
-                    m = 12;
+                    uint64_t x0 = tab[2 * (size_t)idf], sz = l1 - x1 + 1;
+                    m = W;
                     while (p + m < qLen) {
                         const int c = lf_nt4(q[p + m]);
                         if (c > 3) break;
