@@ -64,7 +64,7 @@ struct lf_tacc {
     __device__ __forceinline__ lf_tacc(const unsigned char *base, const uint8_t *pc, int64_t st, unsigned flags) : b(base), pac(pc), start(st), dir((flags & LF_F_TREV) ? -1 : 1), comp(flags & LF_F_TCOMP), is_pac(flags & LF_F_TPAC) {}
     __device__ __forceinline__ unsigned char get(uint32_t i) const {
         const int64_t x = start + (int64_t)dir * (int64_t)i;
-        if (is_pac) { int c = (pac[x >> 2] >> ((~x & 3) << 1)) & 3; if (comp) c = 3 - c; return (unsigned char)"ACGT"[c]; }
+        if (is_pac) { int c = (pac[x >> 2] >> ((~x & 3) << 1)) & 3; if (comp) c = 3 - c; return (unsigned char)(0x54474341u >> (c << 3)); }   /* "ACGT"[c] without a table load */
         const unsigned char c = b[x];
         return comp ? lf_rc_char(c) : c;
     }

@@ -54,7 +54,7 @@ __device__ __forceinline__ char lf_pac_char(const uint8_t *pac, uint32_t pos, in
 {
     int b = (pac[pos >> 2] >> ((~pos & 3u) << 1)) & 3;
     if (comp) b = 3 - b;
-    return "ACGT"[b];
+    return (char)(0x54474341u >> (b << 3));          /* "ACGT"[b] without a table load */
 }
 
 /* element types */

@@ -143,7 +143,8 @@ extern "C" void lfg_index_free(struct lf_index *ix)
 
 /* sample positions: seed_pos accumulates `step` in FP64 exactly like src/BWT.cpp:320-321,388-389
  * (sequential adds, truncation), one lane per read. Layout pos[i * n_reads + r] (coalesced). */
-__global__ void lf_seed_pos_kernel(int n_reads, const uint64_t *__restrict__ off, uint32_t hash_count, uint32_t *__restrict__ pos)
+__global__ void lf_seed_pos_kernel(int n_reads, const uint64_t *__restrict__ off, uint32_t hash_count, uint32_t *__restrict__ pos,
+                                   uint32_t *__restrict__ pos_by_sample /* [r * hash_count + i]: coalesced for the per-sample kernels */)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
@@ -153,6 +154,7 @@ __global__ void lf_seed_pos_kernel(int n_reads, const uint64_t *__restrict__ off
     uint32_t p = 0;
     for (uint32_t i = 0; i < hash_count; i++) {
         pos[(size_t)i * n_reads + r] = p;
+        pos_by_sample[(size_t)r * hash_count + i] = p;
         sp += step;
         p = (uint32_t)sp;
     }
@@ -160,70 +162,98 @@ __global__ void lf_seed_pos_kernel(int n_reads, const uint64_t *__restrict__ off
 
 struct lf_sample_t { uint64_t sp; uint32_t occ; uint32_t m; };   /* occ saturates at 2^32-1; m = 0: no seed */
 
-/* one lane per (read, sample): maximal exact match starting at pos, >= k long */
+/* Maximal exact match of every (read, sample) starting at its sample position, >= k long.
+ * Match lengths are very uneven (a sample inside an error-free stretch extends for dozens of steps, most stop after a
+ * few), so a lane is not tied to one sample: a wavefront owns LF_SEARCH_SPAN consecutive samples and every lane that
+ * finishes its sample takes the next unassigned one (ballot + prefix count on a wave-uniform cursor).  The wave's trip
+ * count is then the SUM of the chain lengths / 64 instead of 64 x the longest chain. */
+#define LF_SEARCH_SPAN 512
 __global__ void __launch_bounds__(256)
 lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ reads, const uint64_t *__restrict__ off,
                       uint32_t hash_count, int kmin, const uint32_t *__restrict__ pos, lf_sample_t *__restrict__ out,
                       unsigned long long *__restrict__ counters)
 {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)n_reads * hash_count;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    size_t nxt = wave * LF_SEARCH_SPAN;
+    const size_t end = nxt + LF_SEARCH_SPAN < total ? nxt + LF_SEARCH_SPAN : total;
     uint32_t n_cache = 0, n_blk = 0;
-    if (gid < total) {
-        const int r = (int)(gid / hash_count);
-        const uint32_t i = (uint32_t)(gid % hash_count);
-        const uint32_t qLen = (uint32_t)(off[r + 1] - off[r]);
-        const unsigned char *q = reinterpret_cast<const unsigned char *>(reads) + off[r];
-        const uint32_t p = pos[(size_t)i * n_reads + r];
-        lf_sample_t res; res.sp = 0; res.occ = 0; res.m = 0;
+    /* table width W: 14 when the wide table exists and -k >= 14 (a match shorter than k is dropped anyway, so nothing
+     * is lost by starting at 14), else the reference's 12 */
+    const bool wide = ix.cache14 != nullptr && kmin >= 14;
+    const uint32_t W = wide ? 14u : 12u;
+    const uint64_t *__restrict__ tab = wide ? ix.cache14 : ix.cache;
 
-        if ((uint64_t)p + (uint64_t)kmin <= qLen) {
-            /* Bidirectional search (the index holds forward + reverse-complement text, like bwa mem's SMEM search):
-             * (x0, x1, s) = first row of P = q[p..p+m), first row of revcomp(P), interval size.  Start from the two
-             * 12-mer table entries, then append one base at a time while P still occurs.  The maximal m AND the exact
-             * rows of P come out of the same pass: m - 12 steps instead of the reference's restart per m.
-             * table index: base-4 number with the LAST character of the pattern most significant (src/BWT.cpp:270-277);
-             * pattern P12 = q[p..p+12), pattern revcomp(P12) whose last 12 characters are comp(q[p+11..p]) */
-            /* table width W: 14 when the wide table exists and -k >= 14 (a match shorter than k is dropped anyway, so
-             * nothing is lost by starting at 14), else the reference's 12 */
-            const bool wide = ix.cache14 != nullptr && kmin >= 14;
-            const uint32_t W = wide ? 14u : 12u;
-            const uint64_t *__restrict__ tab = wide ? ix.cache14 : ix.cache;
-            uint32_t idc = 0, idf = 0; bool ok = true;
+    bool active = false;                      /* this lane is in the middle of a sample */
+    size_t gid = 0; const unsigned char *q = nullptr; uint32_t p = 0, qLen = 0, m = 0;
+    uint64_t x0 = 0, x1 = 0, sz = 0;
+    for (;;) {
+        const uint64_t idle = __ballot(!active);
+        if (idle && nxt < end) {
+            const size_t cand = nxt + (size_t)__popcll(idle & below);
+            if (!active && cand < end) {
+                /* Bidirectional search (the index holds forward + reverse-complement text, like bwa mem's SMEM search):
+                 * (x0, x1, s) = first row of P = q[p..p+m), first row of revcomp(P), interval size.  Start from the two
+                 * table entries, then append one base at a time while P still occurs: the maximal m AND the exact rows
+                 * of P come out of the same pass.  Table index: base-4 number with the LAST character of the pattern
+                 * most significant (src/BWT.cpp:270-277); pattern P_W = q[p..p+W), and revcomp(P_W) whose last W
+                 * characters are comp(q[p+W-1..p]) */
+                gid = cand;
+                const int r = (int)(gid / hash_count);
+                const uint32_t i = (uint32_t)(gid % hash_count);
+                qLen = (uint32_t)(off[r + 1] - off[r]);
+                q = reinterpret_cast<const unsigned char *>(reads) + off[r];
+                p = pos[gid];                              /* pos_by_sample layout */
+                lf_sample_t res; res.sp = 0; res.occ = 0; res.m = 0;
+                bool started = false;
+                if ((uint64_t)p + (uint64_t)kmin <= qLen) {
+                    /* the first W <= 14 bases in two (unaligned) 8-byte loads; the batch buffer has 64 bytes of slack */
+                    uint64_t w0, w1;
+                    __builtin_memcpy(&w0, q + p, 8); __builtin_memcpy(&w1, q + p + 8, 8);
+                    uint32_t idc = 0, idf = 0; bool ok = true;
 #pragma unroll
-            for (int t = 0; t < 14; t++) {
-                if ((uint32_t)t < W) {
-                    const int c = lf_nt4(q[p + t]); ok &= (c < 4); idc = idc * 4 + (uint32_t)(3 - c);
-                    idf = idf * 4 + (uint32_t)lf_nt4(q[p + W - 1 - t]);
+                    for (int t = 0; t < 14; t++) {
+                        if ((uint32_t)t < W) {
+                            const int c = lf_nt4((unsigned char)((t < 8 ? w0 >> (8 * t) : w1 >> (8 * (t - 8))) & 0xff));
+                            ok &= (c < 4); idc = idc * 4 + (uint32_t)(3 - c);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 13; t >= 0; t--) {
+                        if ((uint32_t)t < W) idf = idf * 4 + (uint32_t)lf_nt4((unsigned char)((t < 8 ? w0 >> (8 * t) : w1 >> (8 * (t - 8))) & 0xff));
+                    }
+                    if (ok) {
+                        n_cache += 2;
+                        x1 = tab[2 * (size_t)idc];
+                        const uint64_t l1 = tab[2 * (size_t)idc + 1];
+                        if (x1 <= l1) { x0 = tab[2 * (size_t)idf]; sz = l1 - x1 + 1; m = W; started = true; }
+                    }
                 }
+                if (started) active = true; else out[gid] = res;
             }
-            uint32_t m = 0;
-            if (ok) {
-                n_cache += 2;
-                uint64_t x1 = tab[2 * (size_t)idc];
-                const uint64_t l1 = tab[2 * (size_t)idc + 1];
-                if (x1 <= l1) {
-                    uint64_t x0 = tab[2 * (size_t)idf], sz = l1 - x1 + 1;
-                    m = W;
-                    while (p + m < qLen) {
-                        const int c = lf_nt4(q[p + m]);
-                        if (c > 3) break;
-                        if (!lf_extend_right(ix, x0, x1, sz, c, n_blk)) break;
-                        m++;
-                    }
-                    if ((int)m < kmin) m = 0;
-                    if (m) {
-                        res.sp = x0; res.m = m;
-                        res.occ = sz > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sz;
-                    }
-                }
+            nxt += (size_t)__popcll(idle);
+            if (nxt > end) nxt = end;
+        }
+        if (!__ballot(active)) { if (nxt >= end) break; continue; }
+        if (active) {
+            bool more = false;
+            if (p + m < qLen) {
+                const int c = lf_nt4(q[p + m]);
+                if (c <= 3 && lf_extend_right(ix, x0, x1, sz, c, n_blk)) { m++; more = true; }
+            }
+            if (!more) {
+                lf_sample_t res; res.sp = 0; res.occ = 0; res.m = 0;
+                if ((int)m >= kmin) { res.sp = x0; res.m = m; res.occ = sz > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sz; }
+                out[gid] = res;
+                active = false;
             }
         }
-        out[gid] = res;
     }
     /* SURVEY 8(d) counters: one atomic pair per wave */
     for (int o = 32; o > 0; o >>= 1) { n_cache += __shfl_down(n_cache, o); n_blk += __shfl_down(n_blk, o); }
-    if ((threadIdx.x & 63) == 0 && (n_cache | n_blk)) { atomicAdd(&counters[0], (unsigned long long)n_cache); atomicAdd(&counters[1], (unsigned long long)n_blk); }
+    if (lane == 0 && (n_cache | n_blk)) { atomicAdd(&counters[0], (unsigned long long)n_cache); atomicAdd(&counters[1], (unsigned long long)n_blk); }
 }
 
 /* acceptance is sequential per read: 0 < occ < MAX_REF_HITS and not contained in the previous accepted
@@ -271,7 +301,7 @@ lf_seed_locate_kernel(lf_dev_index ix, int n_reads, const uint64_t *__restrict__
         const int r = (int)(gid / hash_count);
         const uint32_t i = (uint32_t)(gid % hash_count);
         const lf_sample_t s = smp[gid];
-        s_sp[threadIdx.x] = s.sp; s_m[threadIdx.x] = s.m; s_p[threadIdx.x] = pos[(size_t)i * n_reads + r]; s_ql[threadIdx.x] = (uint32_t)(off[r + 1] - off[r]);
+        s_sp[threadIdx.x] = s.sp; s_m[threadIdx.x] = s.m; s_p[threadIdx.x] = pos[gid]; s_ql[threadIdx.x] = (uint32_t)(off[r + 1] - off[r]);
     }
     s_rel[threadIdx.x] = (uint32_t)(o - o0);
     __builtin_amdgcn_wave_barrier();
@@ -323,13 +353,13 @@ extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_r
 #define DSLOT(T, k, bytes) (T *)lfg_dev_slot(dv, LF_DS_SEED0 + (k), (bytes))
     char *d_reads = DSLOT(char, 0, n_bases + 64);
     uint64_t *d_off = DSLOT(uint64_t, 1, (size_t)(n_reads + 1) * 8);
-    uint32_t *d_pos = DSLOT(uint32_t, 2, total * 4 + 4);
+    uint32_t *d_pos = DSLOT(uint32_t, 2, total * 4 + 4), *d_pos2 = DSLOT(uint32_t, 12, total * 4 + 4);
     lf_sample_t *d_smp = DSLOT(lf_sample_t, 3, total * sizeof(lf_sample_t) + 16);
     uint32_t *d_cnt = DSLOT(uint32_t, 4, (total + 1) * 4);
     uint64_t *d_hit_off = DSLOT(uint64_t, 5, (total + 1) * 8);
     uint64_t *d_read_off = DSLOT(uint64_t, 6, (size_t)(n_reads + 1) * 8);
     unsigned long long *d_counters = DSLOT(unsigned long long, 7, 64);
-    if (!d_reads || !d_off || !d_pos || !d_smp || !d_cnt || !d_hit_off || !d_read_off || !d_counters) return LF_ERR_NOMEM;
+    if (!d_reads || !d_off || !d_pos || !d_pos2 || !d_smp || !d_cnt || !d_hit_off || !d_read_off || !d_counters) return LF_ERR_NOMEM;
     hipEvent_t ev[6];
     for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&ev[i]));
 
@@ -337,10 +367,10 @@ extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_r
     HIPCHK(hipMemcpyAsync(d_reads, reads, n_bases, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
 
-    hipLaunchKernelGGL(lf_seed_pos_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, d_off, hc, d_pos);
+    hipLaunchKernelGGL(lf_seed_pos_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, d_off, hc, d_pos, d_pos2);
     HIPCHK(hipEventRecord(ev[0], s));
-    hipLaunchKernelGGL(lf_seed_search_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, st->view, n_reads, d_reads,
-                       d_off, hc, p->min_anchor_len, d_pos, d_smp, d_counters);
+    hipLaunchKernelGGL(lf_seed_search_kernel, dim3((unsigned)((total + 4 * LF_SEARCH_SPAN - 1) / (4 * LF_SEARCH_SPAN))), dim3(256), 0, s, st->view, n_reads, d_reads,
+                       d_off, hc, p->min_anchor_len, d_pos2, d_smp, d_counters);
     HIPCHK(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lf_seed_accept_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, hc, (uint32_t)p->max_ref_hits, d_pos, d_smp, d_cnt);
     HIPCHK(hipMemsetAsync(d_cnt + total, 0, 4, s));
@@ -364,7 +394,7 @@ extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_r
     if (!d_tpos || !d_qpl || !d_strand) return LF_ERR_NOMEM;
     HIPCHK(hipEventRecord(ev[3], s));
     hipLaunchKernelGGL(lf_seed_locate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, st->view, n_reads, d_off, hc,
-                       d_pos, d_smp, d_cnt, d_hit_off, d_tpos, d_qpl, d_strand, d_counters);
+                       d_pos2, d_smp, d_cnt, d_hit_off, d_tpos, d_qpl, d_strand, d_counters);
     HIPCHK(hipEventRecord(ev[4], s));
     hipLaunchKernelGGL(lf_read_first_hit_kernel, dim3((n_reads + 1 + 255) / 256), dim3(256), 0, s, n_reads, hc, d_hit_off, n_hits, d_read_off);
 
