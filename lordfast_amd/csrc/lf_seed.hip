@@ -251,9 +251,14 @@ lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ rea
             }
         }
     }
-    /* SURVEY 8(d) counters: one atomic pair per wave */
+    /* SURVEY 8(d) counters: one atomic pair per BLOCK (same-address atomics serialise) */
+    __shared__ unsigned long long s_cnt[2];
+    if (threadIdx.x == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+    __syncthreads();
     for (int o = 32; o > 0; o >>= 1) { n_cache += __shfl_down(n_cache, o); n_blk += __shfl_down(n_blk, o); }
-    if (lane == 0 && (n_cache | n_blk)) { atomicAdd(&counters[0], (unsigned long long)n_cache); atomicAdd(&counters[1], (unsigned long long)n_blk); }
+    if (lane == 0 && (n_cache | n_blk)) { atomicAdd(&s_cnt[0], (unsigned long long)n_cache); atomicAdd(&s_cnt[1], (unsigned long long)n_blk); }
+    __syncthreads();
+    if (threadIdx.x == 0 && (s_cnt[0] | s_cnt[1])) { atomicAdd(&counters[0], s_cnt[0]); atomicAdd(&counters[1], s_cnt[1]); }
 }
 
 /* acceptance is sequential per read: 0 < occ < MAX_REF_HITS and not contained in the previous accepted
@@ -321,8 +326,13 @@ lf_seed_locate_kernel(lf_dev_index ix, int n_reads, const uint64_t *__restrict__
         qpl[o0 + h] = (qp & 0xFFFFFu) | ((m & 0xFFFu) << 20);
         strand[o0 + h] = rv;
     }
-    for (int d = 32; d > 0; d >>= 1) { n_blk += __shfl_down(n_blk, d); n_sa += __shfl_down(n_sa, d); }
-    if (lane == 0 && (n_blk | n_sa)) { atomicAdd(&counters[1], (unsigned long long)n_blk); atomicAdd(&counters[2], (unsigned long long)n_sa); }
+    /* N_sa of SURVEY 8(d) is the hit count (the host adds it); only the sampled-SA walk variant has block touches to
+     * report -- 4 x 10^5 waves hammering one counter address were most of this kernel's time */
+    (void)n_sa;
+    if (!ix.sa_full) {
+        for (int d = 32; d > 0; d >>= 1) n_blk += __shfl_down(n_blk, d);
+        if (lane == 0 && n_blk) atomicAdd(&counters[1], (unsigned long long)n_blk);
+    }
 }
 
 struct lf_widen_op { __host__ __device__ uint64_t operator()(uint32_t x) const { return (uint64_t)x; } };
@@ -415,6 +425,7 @@ extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_r
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     out->counters[3] = n_bases;
+    out->counters[2] = n_hits;                 /* N_sa: one suffix-array read per hit */
     HIPCHK(hipEventElapsedTime(&out->ms_search, ev[0], ev[1]));
     HIPCHK(hipEventElapsedTime(&out->ms_accept, ev[1], ev[2]));
     HIPCHK(hipEventElapsedTime(&out->ms_locate, ev[3], ev[4]));
