@@ -266,6 +266,11 @@ def main():
         dist.all_reduce(bsum, op=dist.ReduceOp.SUM)
         bases_total = int(bsum.item())
 
+    try:
+        free_b, total_b = torch.cuda.mem_get_info(local)
+        hbm_used_gb = (total_b - free_b) / 1e9
+    except Exception:                                                    # noqa: BLE001
+        hbm_used_gb = None
     if rank == 0:
         K = args.steps
         bases = bases_total
@@ -329,7 +334,7 @@ def main():
                        "reads_per_gpu": args.reads, "mean_read_len": bases / max(1, n_total), "genome_mbp": args.genome_mbp,
                        "parallelism": f"reads sharded over {world} GPU(s), index replicated, no data-path collective"
                                       + (" + SAM gather to rank 0" if (dist and args.single_output) else ""), "index": "FM-index + full SA resident in HBM"},
-            "gbp_per_s": bases * K / elapsed / 1e9, "host_cpu_seconds_per_step": cpu_s / K,
+            "gbp_per_s": bases * K / elapsed / 1e9, "host_cpu_seconds_per_step": cpu_s / K, "hbm_used_gb": hbm_used_gb,
             "host_ms_per_step": {k: agg[k] / K for k in ("ms_total", "ms_python_call", "ms_seed", "ms_vote", "ms_chain", "ms_extend", "ms_render", "ms_sam")},
             "per_read": {"seeds": agg["n_seeds"] / (n_total * K / world), "edlib_problems": agg["n_edlib_problems"] / (n_total * K / world),
                          "seed_bytes": (16 * agg["n_cache"] + 64 * agg["n_occblk"] + 8 * agg["n_sa"] + agg["n_readbytes"]) / (n_total * K / world),
