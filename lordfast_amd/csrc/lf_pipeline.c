@@ -1984,8 +1984,9 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
     g_phase_on = getenv("LF_PHASES") != NULL;
     pthread_once(&g_rc_once, rc_tab_init);
     /* chunks in flight: the host phases of one overlap the GPU phases of the others */
-    int n_lanes = nt >= 16 ? 8 : (nt >= 8 ? 4 : (nt >= 3 ? 2 : 1));
-    if (getenv("LF_LANES")) { n_lanes = atoi(getenv("LF_LANES")); if (n_lanes < 1) n_lanes = 1; if (n_lanes > LF_MAX_LANES) n_lanes = LF_MAX_LANES; if (n_lanes > 1 && nt < n_lanes + 1) n_lanes = 1; }
+    /* drivers sleep while they wait for the GPU (blocking waits), so small thread budgets still get several chunks in flight */
+    int n_lanes = nt >= 12 ? 8 : (nt >= 4 ? 4 : nt);
+    if (getenv("LF_LANES")) { n_lanes = atoi(getenv("LF_LANES")); if (n_lanes < 1) n_lanes = 1; if (n_lanes > LF_MAX_LANES) n_lanes = LF_MAX_LANES; if (n_lanes > nt) n_lanes = nt; }
     if (getenv("LF_ONE_LANE")) n_lanes = 1;
     const int nw = nt - n_lanes;                       /* pool workers; the lane drivers work too */
     pool_ensure(nw);
