@@ -47,7 +47,7 @@ typedef struct {
     int max_map;          /* -n  MAX_MAP 10 */
     int min_read_len;     /* -l  MIN_READ_LEN 1000 */
     int max_ref_hits;     /* -m  MAX_REF_HITS 1000 */
-    int chain_alg;        /* 0 dp-n2, 1 clasp (clasp not restated yet) */
+    int chain_alg;        /* 0 dp-n2, 1 clasp */
     double chain_reward, chain_penalty, gap_penalty; /* 9.3, 11.4, 0.15 */
     int threads;
     char read_group_id[256];
@@ -72,6 +72,10 @@ void lfo_seed(const lfo_index_t *idx, const lfo_params_t *p, const char *seq, ui
 /* chain_seeds_n2 (src/Chain.cpp:232-310): reorders `seeds`, writes chain (capacity n). */
 void lfo_chain_n2(const lfo_params_t *p, lfo_seed_t *seeds, uint32_t n,
                   lfo_seed_t *chain, uint32_t *chainLen, float *score);
+
+/* chain_seeds_clasp (src/Chain.cpp:39-209; lib/clasp SOP chaining, lambda 0.15): `seeds` untouched, chain in
+ * target order (capacity n). n == 0: score -1, chainLen 0 (the reference leaves chainLen stale). */
+void lfo_chain_clasp(const lfo_seed_t *seeds, uint32_t n, lfo_seed_t *chain, uint32_t *chainLen, float *score);
 
 /* edlibAlign(q,t,{k=-1,mode,PATH}) as a pure function (lib/edlib/edlib.cpp:101-221).
  * mode 0 = NW, 1 = SHW. ops: capacity n+m. Returns edit distance; *endLoc may be -1 in SHW. */

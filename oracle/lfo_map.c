@@ -89,7 +89,7 @@ typedef struct {
     int chunkSize;
     wincount_t *winCnt; uint32_t refWinNum;
     lfo_seed_t *F, *R, *sel, *chain;
-    uint32_t nF, nR, nSel, chainLen; float chainScore;
+    uint32_t nF, nR, nSel, chainLen; float chainScore; int64_t selLow;
     win_t *topWins; int nWins;
     samlist_t *mappings;
 } ctx_t;
@@ -183,11 +183,19 @@ static void select_seeds(ctx_t *cx, uint32_t L, uint32_t tStart, uint32_t tEnd, 
     cx->nSel = 0;
     for (uint32_t i = 0; i < n; i++)
         if ((int64_t)s[i].tPos >= lo && (int64_t)s[i].tPos <= hi) cx->sel[cx->nSel++] = s[i];
+    cx->selLow = lo;
 }
 
 static void chain_selected(ctx_t *cx)
 {
-    if (cx->p->chain_alg != 0) { fprintf(stderr, "[lfo] clasp chaining is not restated\n"); abort(); }
+    if (cx->p->chain_alg != 0) {
+        /* src/LordFAST.cpp:682-692, 1028-1046: clasp keeps positions in `int`, so windows above 2e9 are shifted */
+        int shift = cx->selLow > 2000000000;
+        if (shift) for (uint32_t i = 0; i < cx->nSel; i++) cx->sel[i].tPos -= 2000000000u;
+        lfo_chain_clasp(cx->sel, cx->nSel, cx->chain, &cx->chainLen, &cx->chainScore);
+        if (shift) for (uint32_t i = 0; i < cx->chainLen; i++) cx->chain[i].tPos += 2000000000u;
+        return;
+    }
     lfo_chain_n2(cx->p, cx->sel, cx->nSel, cx->chain, &cx->chainLen, &cx->chainScore);
 }
 

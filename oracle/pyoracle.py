@@ -63,6 +63,7 @@ class Oracle:
                                C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]
         L.lfo_chain_n2.argtypes = [C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_void_p,
                                    C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+        L.lfo_chain_clasp.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
         L.lfo_edlib.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int),
                                 C.c_void_p, C.POINTER(C.c_int)]
         L.lfo_ksw_extend2.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 7 + \
@@ -122,6 +123,14 @@ class Oracle:
         self.L.lfo_chain_n2(C.byref(p), s.ctypes.data, n, out.ctypes.data, C.byref(cl), C.byref(sc))
         return s, out[:cl.value].copy(), sc.value
 
+    def chain_clasp(self, seeds: np.ndarray):
+        s = np.ascontiguousarray(seeds, dtype=np.uint32).copy()
+        n = len(s)
+        out = np.zeros((max(n, 1), 3), dtype=np.uint32)
+        cl, sc = C.c_uint32(), C.c_float()
+        self.L.lfo_chain_clasp(s.ctypes.data, n, out.ctypes.data, C.byref(cl), C.byref(sc))
+        return out[:cl.value].copy(), sc.value
+
     def edlib(self, q: bytes, t: bytes, mode: int):
         ops = np.zeros(len(q) + len(t) + 1, dtype=np.uint8)
         end, nops = C.c_int(), C.c_int()
@@ -163,6 +172,7 @@ class Ref:
         L.ref_seed.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32),
                                C.c_void_p, C.POINTER(C.c_uint32)]
         L.ref_chain_n2.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+        L.ref_chain_clasp.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
         L.ref_edlib.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int),
                                 C.c_void_p, C.POINTER(C.c_int)]
         L.ref_ksw_extend2.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 7 + \
@@ -229,6 +239,14 @@ class Ref:
         cl, sc = C.c_uint32(), C.c_float()
         self.L.ref_chain_n2(s.ctypes.data, n, out.ctypes.data, C.byref(cl), C.byref(sc))
         return s, out[:cl.value].copy(), sc.value
+
+    def chain_clasp(self, seeds: np.ndarray):
+        s = np.ascontiguousarray(seeds, dtype=np.uint32).copy()
+        n = len(s)
+        out = np.zeros((max(n, 1), 3), dtype=np.uint32)
+        cl, sc = C.c_uint32(), C.c_float()
+        self.L.ref_chain_clasp(s.ctypes.data, n, out.ctypes.data, C.byref(cl), C.byref(sc))
+        return out[:cl.value].copy(), sc.value
 
     def edlib(self, q: bytes, t: bytes, mode: int):
         ops = np.zeros(len(q) + len(t) + 1, dtype=np.uint8)
