@@ -53,7 +53,7 @@ typedef struct {
     int    max_map;          /* -n MAX_MAP          10   */
     int    min_read_len;     /* -l MIN_READ_LEN     1000 (>= 100) */
     int    max_ref_hits;     /* -m MAX_REF_HITS     1000 */
-    int    chain_alg;        /* -a 0 = dp-n2 (clasp: not available on this path yet) */
+    int    chain_alg;        /* -a 0 = dp-n2, 1 = clasp */
     double chain_reward;     /* --chainReward  9.3  */
     double chain_penalty;    /* --chainPenalty 11.4 */
     double gap_penalty;      /* --gapPenalty   0.15 */
@@ -115,6 +115,17 @@ void lf_seeds_free(lf_seeds_t *s);
  * ---------------------------------------------------------------------------------------------- */
 int lf_chain_n2_batch(const lf_params_t *p, int n_windows, Seed_t *seeds, const uint64_t *off,
                       uint32_t *chain_idx, uint32_t *chain_len, float *score, int device);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage 3b: clasp chaining (`-a clasp`) for a batch of windows: chain_seeds_clasp (src/Chain.cpp:39-209) over
+ *   lib/clasp's SOP-gap-cost chaining (lib/clasp/slchain.c:568-974), lambda 0.15, eps 0.
+ *   seeds of window w: seeds[off[w]..off[w+1]) in the caller's order (not modified); the chain, in target
+ *   order, is written to chain_out[off[w] .. off[w]+chain_len[w]); score[w] is the float the reference stores
+ *   (-1 and chain_len 0 for an empty window).  Like clasp itself, positions must fit `int` (the reference's
+ *   caller subtracts 2e9 first, src/LordFAST.cpp:684-692) and a window must be narrower than 2^28.
+ * ---------------------------------------------------------------------------------------------- */
+int lf_chain_clasp_batch(int n_windows, const Seed_t *seeds, const uint64_t *off,
+                         Seed_t *chain_out, uint32_t *chain_len, float *score, int device);
 
 /* ------------------------------------------------------------------------------------------------
  * Stage 4: edlib-equivalent alignment for a batch of problems (lib/edlib/edlib.cpp:101-221;
@@ -202,6 +213,7 @@ void     bwt_str_pac2char(uint32_t beg, uint32_t len, char *seq);         /* src
 void     printSamHeader(FILE *fp);                                        /* src/BWT.h:39 */
 /* src/Chain.h:51 -- `Chain_t &bestChain` becomes a pointer in the C ABI */
 void     chain_seeds_n2(Seed_t *fragment_list, uint32_t nFragment, Chain_t *bestChain);
+int      chain_seeds_clasp(Seed_t *fragment_list, uint32_t nFragment, Chain_t *bestChain);   /* src/Chain.h:51 */
 
 /* lib/edlib/edlib.h:21-56,79-135,172,190 (same enum values and struct layouts) */
 typedef enum { EDLIB_MODE_NW, EDLIB_MODE_SHW, EDLIB_MODE_HW } EdlibAlignMode;

@@ -86,6 +86,8 @@ def lib():
     if hasattr(L, "lf_chain_n2_batch"):
         L.lf_chain_n2_batch.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_int]
+    if hasattr(L, "lf_chain_clasp_batch"):
+        L.lf_chain_clasp_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     if hasattr(L, "lf_ksw_extend2_batch"):
         L.lf_ksw_extend2_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -347,6 +349,23 @@ def chain_n2_batch(windows, params: Params | None = None, device: int = 0):
         idx = chain_idx[a:a + int(chain_len[w])]
         out.append((srt, srt[idx], float(score[w])))
     return out
+
+
+def chain_clasp_batch(windows, device: int = 0):
+    """windows: list of (n,3) triples (tPos, qPos, len) in selection order. -> list of (chain triples, score)"""
+    L = lib()
+    off = np.zeros(len(windows) + 1, dtype=np.uint64)
+    if len(windows):
+        off[1:] = np.cumsum([len(w) for w in windows], dtype=np.uint64)
+    allw = np.concatenate([np.asarray(w, dtype=np.uint32).reshape(-1, 3) for w in windows]) if len(windows) else np.zeros((0, 3), np.uint32)
+    seeds = _triples_to_seeds(allw)
+    out_seeds = np.zeros_like(seeds) if len(seeds) else np.zeros(1, dtype=seeds.dtype)
+    chain_len = np.zeros(max(1, len(windows)), dtype=np.uint32)
+    score = np.zeros(max(1, len(windows)), dtype=np.float32)
+    _check(L.lf_chain_clasp_batch(len(windows), seeds.ctypes.data, off.ctypes.data, out_seeds.ctypes.data,
+                                  chain_len.ctypes.data, score.ctypes.data, device), "lf_chain_clasp_batch")
+    tr = _seeds_to_triples(out_seeds.reshape(-1))
+    return [(tr[int(off[w]):int(off[w]) + int(chain_len[w])], float(score[w])) for w in range(len(windows))]
 
 
 def ksw_extend2_batch(qs, ts, prms, device: int = 0):

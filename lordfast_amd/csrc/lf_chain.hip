@@ -90,3 +90,97 @@ extern "C" int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, con
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return LF_OK;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * clasp chaining for host-supplied windows (stage API / drop-in chain_seeds_clasp).  Seeds arrive in the caller's
+ * order; the stable sort by target start that the reference's qsort performs (src/Chain.cpp:94) is one device radix
+ * sort on (window, tPos).  Kernel: lf_clasp_kernel.h.  chain_out[off[w] .. off[w] + chain_len[w]) receives the chain.
+ * ------------------------------------------------------------------------------------------------------------- */
+#include <hipcub/hipcub.hpp>
+#include "lf_clasp_kernel.h"
+
+static __global__ void lf_clasp_keys_kernel(int n_windows, const uint64_t *__restrict__ off, const uint2 *__restrict__ seeds, uint64_t *__restrict__ keys)
+{
+    const int w = blockIdx.x;
+    if (w >= n_windows) return;
+    for (uint64_t k = off[w] + threadIdx.x; k < off[w + 1]; k += blockDim.x) keys[k] = ((uint64_t)(uint32_t)w << 32) | seeds[k].x;
+}
+static __global__ void lf_clasp_gather_kernel(int n_windows, const uint64_t *__restrict__ off, const uint32_t *__restrict__ chain_idx,
+                                              const uint32_t *__restrict__ chain_len, const uint2 *__restrict__ sorted, uint2 *__restrict__ chain_out)
+{
+    const int w = blockIdx.x;
+    if (w >= n_windows) return;
+    const uint64_t o = off[w];
+    for (uint32_t k = threadIdx.x; k < chain_len[w]; k += blockDim.x) chain_out[o + k] = sorted[o + chain_idx[o + k]];
+}
+
+extern "C" int lfg_chain_clasp(int device, int n_windows, const Seed_t *seeds, const uint64_t *off,
+                               Seed_t *chain_out, uint32_t *chain_len, float *score, float *ms)
+{
+    if (ms) *ms = 0;
+    if (n_windows == 0) return LF_OK;
+    if (lfg_device_count() <= device) { lf_set_error("no gfx950 device %d visible (no CPU path)", device); return LF_ERR_NO_DEVICE; }
+    HIPCHK(hipSetDevice(device));
+    const uint64_t total = off[n_windows];
+    if (total >= (1ull << 31)) { lf_set_error("lfg_chain_clasp: too many seeds"); return LF_ERR_ARG; }
+    std::vector<lf_chain_win> W((size_t)n_windows);
+    uint64_t ws = 0;
+    const uint32_t *raw = (const uint32_t *)seeds;
+    for (int i = 0; i < n_windows; i++) {
+        W[i].off = off[i]; W[i].n = (uint32_t)(off[i + 1] - off[i]); W[i].id = (uint32_t)i; W[i].ws_off = ws;
+        if (W[i].n > LF_CLASP_LDS_MAX) ws += W[i].n;
+        uint32_t tmin = 0xFFFFFFFFu, tmax = 0;
+        for (uint64_t k = off[i]; k < off[i + 1]; k++) { const uint32_t t = raw[2 * k]; if (t < tmin) tmin = t; if (t > tmax) tmax = t; }
+        /* clasp itself keeps positions in `int` (lib/clasp/slchain.c:65-72); the sort keys here need span + qPos < 2^29 */
+        if (W[i].n && (tmax >= 0x7FFFF000u || tmax - tmin >= (1u << 28))) {
+            lf_set_error("lfg_chain_clasp: window %d spans [%u, %u]: positions must be < 2^31 and a window narrower than 2^28", i, tmin, tmax);
+            return LF_ERR_ARG;
+        }
+    }
+#define CSLOT(k, bytes) lfg_dev_slot(device, LF_DS_CHAIN0 + (k), (bytes))
+    int wbits = 1; while ((1ull << wbits) < (uint64_t)n_windows + 1) wbits++;
+    size_t tb = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (int)total, 0, 32 + wbits, (hipStream_t)0);
+    void *d_w = CSLOT(0, W.size() * sizeof(lf_chain_win)), *d_seeds = CSLOT(1, total * 8 + 16), *d_sorted = CSLOT(2, total * 8 + 16);
+    void *d_ws = CSLOT(3, ws * LF_CLASP_BYTES_PER_FRAG + 16), *d_keys = CSLOT(4, total * 16 + 16), *d_idx = CSLOT(5, total * 4 + 16);
+    /* the chain stage owns 8 slots: the three per-window arrays share one, sort scratch and output another */
+    const size_t wpad = (((size_t)n_windows + 1) * 4 + 255) & ~(size_t)255, tpad = (tb + 511) & ~(size_t)255;
+    char *d_small = (char *)CSLOT(6, 2 * wpad + ((size_t)n_windows + 1) * 8), *d_big = (char *)CSLOT(7, tpad + total * 8 + 16);
+#undef CSLOT
+    if (!d_w || !d_seeds || !d_sorted || !d_ws || !d_keys || !d_idx || !d_small || !d_big) return LF_ERR_NOMEM;
+    void *d_len = d_small, *d_sc = d_small + wpad, *d_off = d_small + 2 * wpad, *d_tmp = d_big, *d_out = d_big + tpad;
+    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 15);
+    if (!s) return LF_ERR_HIP;
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipMemcpyAsync(d_w, W.data(), W.size() * sizeof(lf_chain_win), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_seeds, seeds, total * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_off, off, ((size_t)n_windows + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(e0, s));
+    if (total) {
+        uint64_t *k1 = (uint64_t *)d_keys, *k2 = k1 + total;
+        hipLaunchKernelGGL(lf_clasp_keys_kernel, dim3((unsigned)n_windows), dim3(64), 0, s, n_windows, (const uint64_t *)d_off, (const uint2 *)d_seeds, k1);
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, k1, k2, (uint64_t *)d_seeds, (uint64_t *)d_sorted, (int)total, 0, 32 + wbits, s));
+    }
+    static const uint32_t CCAPS[3] = { 128, LF_CLASP_LDS_MAX, 0 };
+    uint32_t lo = 0;
+    for (int c = 0; c < 3; c++) {
+        const uint32_t hi = CCAPS[c] ? CCAPS[c] : 0xFFFFFFFFu;
+        if (c == 2 && ws == 0) break;
+        const size_t smem = CCAPS[c] ? (size_t)CCAPS[c] * LF_CLASP_BYTES_PER_FRAG : 16;
+        hipLaunchKernelGGL(lf_clasp_kernel, dim3((unsigned)n_windows), dim3(64), smem, s, (const lf_chain_win *)d_w, n_windows,
+                           (const uint32_t *)d_sorted, (const uint32_t *)nullptr, CCAPS[c], (unsigned char *)d_ws,
+                           (uint32_t *)d_idx, (uint32_t *)d_len, (float *)d_sc, lo, hi);
+        lo = hi + 1;
+    }
+    hipLaunchKernelGGL(lf_clasp_gather_kernel, dim3((unsigned)n_windows), dim3(64), 0, s, n_windows, (const uint64_t *)d_off, (const uint32_t *)d_idx,
+                       (const uint32_t *)d_len, (const uint2 *)d_sorted, (uint2 *)d_out);
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipMemcpyAsync(chain_out, d_out, total * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(chain_len, d_len, (size_t)n_windows * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(score, d_sc, (size_t)n_windows * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return LF_OK;
+}

@@ -128,6 +128,20 @@ void chain_seeds_n2(Seed_t *fragment_list, uint32_t nFragment, Chain_t *bestChai
     free(idx);
 }
 
+int chain_seeds_clasp(Seed_t *fragment_list, uint32_t nFragment, Chain_t *bestChain)
+{   /* src/Chain.cpp:39-209: fragment_list is left untouched, bestChain->seeds (caller-allocated) gets the chain in
+     * target order, returns 1.  nFragment == 0: score -1; the reference leaves chainLen stale, we set it to 0. */
+    uint64_t off[2] = { 0, nFragment };
+    uint32_t len = 0; float score = -1;
+    if (nFragment == 0) { bestChain->chainLen = 0; bestChain->score = -1; return 1; }
+    Seed_t *out = (Seed_t *)malloc((size_t)nFragment * sizeof(Seed_t));
+    if (lf_chain_clasp_batch(1, fragment_list, off, out, &len, &score, g_ix ? g_ix->device : 0) != LF_OK) die("chain_seeds_clasp");
+    memcpy(bestChain->seeds, out, (size_t)len * sizeof(Seed_t));
+    bestChain->chainLen = len; bestChain->score = score;
+    free(out);
+    return 1;
+}
+
 EdlibAlignConfig edlibNewAlignConfig(int k, EdlibAlignMode mode, EdlibAlignTask task)
 {
     EdlibAlignConfig c; c.k = k; c.mode = mode; c.task = task; return c;

@@ -63,6 +63,9 @@ void lfg_hits_free(lfg_hits_t *h);
 
 int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, const Seed_t *sorted_seeds,
                  const uint64_t *off, uint32_t *chain_idx, uint32_t *chain_len, float *score, float *ms);
+/* clasp (lf_clasp_kernel.h): seeds in the caller's order; chain seeds land at chain_out[off[w] ..] */
+int lfg_chain_clasp(int device, int n_windows, const Seed_t *seeds, const uint64_t *off,
+                    Seed_t *chain_out, uint32_t *chain_len, float *score, float *ms);
 
 /* edlib problems: sequences given as byte strings (host memory) */
 int lfg_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,

@@ -1953,7 +1953,8 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
                           char **sam, size_t *sam_len, lf_stats_t *stats)
 {
     if (!ix || !p || n < 0 || (!sam && !ext_buf)) { lf_set_error("lf_map_batch: bad argument"); return LF_ERR_ARG; }
-    if (p->chain_alg != 0) { lf_set_error("lf_map_batch: --chainAlg clasp is not implemented on the GPU path yet"); return LF_ERR_ARG; }
+    if (p->chain_alg != 0 && p->chain_alg != 1) { lf_set_error("lf_map_batch: chain_alg must be 0 (dp-n2) or 1 (clasp)"); return LF_ERR_ARG; }
+    if (p->chain_alg == 1 && getenv("LF_HOST_VOTE") && atoi(getenv("LF_HOST_VOTE"))) { lf_set_error("lf_map_batch: the LF_HOST_VOTE diagnostic path only knows dp-n2; clasp runs on the device vote path"); return LF_ERR_ARG; }
     if (p->min_anchor_len < 12 || p->min_anchor_len > 20 || p->sampling_count <= 0 || p->max_map < 2 || p->max_ref_hits <= 0 || p->min_read_len < 100) {
         lf_set_error("lf_map_batch: option out of range (k in [12,20], c > 0, n >= 2, m > 0, l >= 100)"); return LF_ERR_ARG;
     }

@@ -24,6 +24,13 @@ int lf_chain_n2_batch(const lf_params_t *p, int n_windows, Seed_t *seeds, const 
     return lfg_chain_n2(device, p, n_windows, seeds, off, chain_idx, chain_len, score, NULL);
 }
 
+int lf_chain_clasp_batch(int n_windows, const Seed_t *seeds, const uint64_t *off,
+                         Seed_t *chain_out, uint32_t *chain_len, float *score, int device)
+{
+    if (n_windows < 0 || (n_windows && (!seeds || !off || !chain_out || !chain_len || !score))) { lf_set_error("lf_chain_clasp_batch: bad argument"); return LF_ERR_ARG; }
+    return lfg_chain_clasp(device, n_windows, seeds, off, chain_out, chain_len, score, NULL);
+}
+
 int lf_ksw_extend2_batch(int n, const uint8_t *q, const uint64_t *qoff, const uint8_t *t, const uint64_t *toff,
                          const int32_t *prm, int32_t *score, int32_t *qle, int32_t *tle, int device)
 {

@@ -30,6 +30,7 @@
 #include "lf_internal.h"
 #include "lf_gpu_common.h"
 #include "lf_chain_kernel.h"
+#include "lf_clasp_kernel.h"
 
 #define LF_STDSORT_FN static __device__
 #include "lf_stdsort.h"
@@ -190,7 +191,7 @@ __global__ void __launch_bounds__(64)
 lf_req_gather_kernel(int n_req, const uint32_t *__restrict__ req_read, const uint32_t *__restrict__ req_win, const int64_t *__restrict__ req_lo,
                      const int64_t *__restrict__ req_hi, const uint64_t *__restrict__ read_off, const uint32_t *__restrict__ tpos,
                      const uint32_t *__restrict__ qpl, const uint8_t *__restrict__ strand, uint32_t *__restrict__ req_n,
-                     const uint64_t *__restrict__ req_off, uint2 *__restrict__ gathered, uint64_t *__restrict__ skeys)
+                     const uint64_t *__restrict__ req_off, uint2 *__restrict__ gathered, uint64_t *__restrict__ skeys, int key_by_tpos)
 {
     const int q = blockIdx.x, lane = threadIdx.x;
     if (q >= n_req) return;
@@ -207,7 +208,8 @@ lf_req_gather_kernel(int n_req, const uint32_t *__restrict__ req_read, const uin
         if (WRITE && in) {
             const uint64_t p = out + cnt + (uint32_t)__popcll(m & below);
             gathered[p] = make_uint2(t, ql);
-            skeys[p] = ((uint64_t)(uint32_t)q << 20) | (ql & 0xFFFFFu);
+            /* dp-n2 sorts a request by qPos (std::sort), clasp by target start (qsort = stable merge sort) */
+            skeys[p] = key_by_tpos ? (((uint64_t)(uint32_t)q << 32) | t) : (((uint64_t)(uint32_t)q << 20) | (ql & 0xFFFFFu));
         }
         cnt += (uint32_t)__popcll(m);
     }
@@ -254,7 +256,13 @@ __global__ void lf_chain_gather_kernel(int n_req, const uint64_t *__restrict__ r
     const uint64_t o = req_off[q], co = chain_off[q];
     for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) chain_seeds[co + k] = sorted[o + chain_idx[o + k]];
 }
-struct lf_big_op { __host__ __device__ uint64_t operator()(uint32_t n) const { return n > LF_CHAIN_LDS_MAX ? (uint64_t)n : 0ull; } };
+struct lf_big_op { uint32_t lim; __host__ __device__ uint64_t operator()(uint32_t n) const { return n > lim ? (uint64_t)n : 0ull; } };
+/* clasp keeps positions in `int`: windows above 2e9 are shifted down (src/LordFAST.cpp:684-692, 1030-1046) */
+__global__ void lf_req_shift_kernel(int n_req, const int64_t *__restrict__ req_lo, uint32_t *__restrict__ shift)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n_req) shift[q] = req_lo[q] > 2000000000ll ? 2000000000u : 0u;
+}
 struct lf_w32 { __host__ __device__ uint64_t operator()(uint32_t v) const { return v; } };
 struct lf_w8 { __host__ __device__ uint64_t operator()(uint8_t v) const { return v; } };
 
@@ -398,10 +406,12 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     hipLaunchKernelGGL(lf_req_build_kernel, dim3((unsigned)((n_reads + 127) / 128)), dim3(128), 0, s, n_reads, d_off, d_nreq, d_req0, d_seg0, d_stage,
                        d_ctg, d_ctg + ix->n_seqs, ix->n_seqs, (int64_t)ix->l_pac, d_req_read, d_req_win, d_req_lo, d_req_hi);
     hipLaunchKernelGGL(lf_req_gather_kernel<false>, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_req_read, d_req_win, d_req_lo, d_req_hi, d_read_off,
-                       d_tpos, d_qpl, d_strand, d_req_n, (const uint64_t *)nullptr, (uint2 *)nullptr, (uint64_t *)nullptr);
+                       d_tpos, d_qpl, d_strand, d_req_n, (const uint64_t *)nullptr, (uint2 *)nullptr, (uint64_t *)nullptr, 0);
     size_t tbs = 0, tbs2 = 0;
     hipcub::TransformInputIterator<uint64_t, lf_w32, uint32_t *> n64(d_req_n, lf_w32());
-    hipcub::TransformInputIterator<uint64_t, lf_big_op, uint32_t *> big64(d_req_n, lf_big_op());
+    const bool clasp = p->chain_alg == 1;
+    const uint32_t big_lim = clasp ? LF_CLASP_LDS_MAX : LF_CHAIN_LDS_MAX;
+    hipcub::TransformInputIterator<uint64_t, lf_big_op, uint32_t *> big64(d_req_n, lf_big_op{big_lim});
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tbs, n64, d_req_off, (int)n_req, s);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tbs2, big64, d_ws_off, (int)n_req, s);
     void *d_tmp2 = VSLOT(9, std::max(tbs, tbs2) + 256);
@@ -413,26 +423,28 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     HIPCHK(hipMemcpyAsync(h_small + 4, d_req_n + (Q - 1), 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const uint32_t last_n = (uint32_t)h_small[4];
-    const uint64_t S = h_small[2] + last_n, WS = h_small[3] + (last_n > LF_CHAIN_LDS_MAX ? last_n : 0);
+    const uint64_t S = h_small[2] + last_n, WS = h_small[3] + (last_n > big_lim ? last_n : 0);
     if (S >= (1ull << 31)) { lf_set_error("lfg_vote_chain: too many seeds in candidate windows (%llu)", (unsigned long long)S); return LF_ERR_ARG; }
     out->n_req_seeds = S;
 
     uint2 *d_gath = (uint2 *)VSLOT(10, S * 8 + 64), *d_sorted = (uint2 *)VSLOT(11, S * 8 + 64);
     uint64_t *d_sk = (uint64_t *)VSLOT(12, S * 8 + 64), *d_sk2 = (uint64_t *)VSLOT(13, S * 8 + 64);
     uint32_t *d_cidx = (uint32_t *)VSLOT(14, S * 4 + 64);
-    double *d_dp = (double *)VSLOT(15, WS * 8 + 64); int *d_prev = (int *)VSLOT(16, WS * 4 + 64);
+    double *d_dp = (double *)VSLOT(15, WS * (clasp ? (uint64_t)LF_CLASP_BYTES_PER_FRAG : 8) + 64); int *d_prev = (int *)VSLOT(16, clasp ? Q * 4 + 64 : WS * 4 + 64);
     if (!d_gath || !d_sorted || !d_sk || !d_sk2 || !d_cidx || !d_dp || !d_prev) return LF_ERR_NOMEM;
     bool have_ties = false;
     if (S) {
         hipLaunchKernelGGL(lf_req_gather_kernel<true>, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_req_read, d_req_win, d_req_lo, d_req_hi, d_read_off,
-                           d_tpos, d_qpl, d_strand, d_req_n, (const uint64_t *)d_req_off, d_gath, d_sk);
+                           d_tpos, d_qpl, d_strand, d_req_n, (const uint64_t *)d_req_off, d_gath, d_sk, clasp ? 1 : 0);
         int qbits = 1; while ((1ull << qbits) < (uint64_t)n_req + 1) qbits++;
         size_t tb4 = 0;
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb4, d_sk, d_sk2, (uint64_t *)d_gath, (uint64_t *)d_sorted, (int)S, 0, 20 + qbits, s);
+        const int kbits = (clasp ? 32 : 20) + qbits;        /* the radix sort is stable: equal keys keep the gathered order */
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb4, d_sk, d_sk2, (uint64_t *)d_gath, (uint64_t *)d_sorted, (int)S, 0, kbits, s);
         void *d_tmp3 = VSLOT(17, tb4 + 256);
         if (!d_tmp3) return LF_ERR_NOMEM;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp3, tb4, d_sk, d_sk2, (uint64_t *)d_gath, (uint64_t *)d_sorted, (int)S, 0, 20 + qbits, s));
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp3, tb4, d_sk, d_sk2, (uint64_t *)d_gath, (uint64_t *)d_sorted, (int)S, 0, kbits, s));
         HIPCHK(hipMemsetAsync(d_flag, 0, Q, s));
+        if (!clasp) {
         hipLaunchKernelGGL(lf_tie_flag_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, S, d_sk2, d_flag);
         hipLaunchKernelGGL(lf_tie_sort_kernel, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_flag, d_req_off, d_req_n, d_gath, d_sorted);
         {   /* how many requests needed the introsort replay (statistics) */
@@ -441,6 +453,7 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
             (void)hipcub::DeviceReduce::Sum(nullptr, tbf, f64, d_nt, (int)n_req, s);
             if (tbf <= tb4) { HIPCHK(hipcub::DeviceReduce::Sum(d_tmp3, tbf, f64, d_nt, (int)n_req, s)); HIPCHK(hipMemcpyAsync(h_small + 8, d_nt, 8, hipMemcpyDeviceToHost, s)); have_ties = true; }
         }
+        }
     }
     /* ---- chains ---- */
     uint64_t max_d = 4ull * max_read_len + 8192;
@@ -448,7 +461,20 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     { int rc = pen_table(dv, p, max_d, s, &d_pen, &pen_n); if (rc != LF_OK) return rc; }
     const double reward = p->chain_reward * (double)p->min_anchor_len;     /* score_reward, src/Chain.cpp:211-215 */
     hipLaunchKernelGGL(lf_req_wins_kernel, dim3((unsigned)((n_req + 255) / 256)), dim3(256), 0, s, (int)n_req, d_req_off, d_req_n, d_ws_off, d_wins);
-    {
+    if (clasp) {
+        uint32_t *d_shift = (uint32_t *)d_prev;
+        hipLaunchKernelGGL(lf_req_shift_kernel, dim3((unsigned)((n_req + 255) / 256)), dim3(256), 0, s, (int)n_req, d_req_lo, d_shift);
+        static const uint32_t CCAPS[3] = { 128, LF_CLASP_LDS_MAX, 0 };
+        uint32_t lo = 0;
+        for (int c = 0; c < 3; c++) {
+            const uint32_t hi = CCAPS[c] ? CCAPS[c] : 0xFFFFFFFFu;
+            if (c == 2 && WS == 0) break;
+            const size_t smem = CCAPS[c] ? (size_t)CCAPS[c] * LF_CLASP_BYTES_PER_FRAG : 16;
+            hipLaunchKernelGGL(lf_clasp_kernel, dim3((unsigned)n_req), dim3(64), smem, s, (const lf_chain_win *)d_wins, (int)n_req,
+                               (const uint32_t *)d_sorted, (const uint32_t *)d_shift, CCAPS[c], (unsigned char *)d_dp, d_cidx, d_clen, d_cscore, lo, hi);
+            lo = hi + 1;
+        }
+    } else {
         static const uint32_t CAPS[5] = { 128, 512, 2048, LF_CHAIN_LDS_MAX, 0 };
         uint32_t lo = 0;                                     /* one launch per LDS size class; a block outside its class exits */
         for (int c = 0; c < 5; c++) {

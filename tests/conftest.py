@@ -64,6 +64,11 @@ def stages():
     return np.load(os.path.join(GOLDEN, "stages.npz"))
 
 
+@pytest.fixture(scope="session")
+def stages_clasp():
+    return np.load(os.path.join(GOLDEN, "stages_clasp.npz"))
+
+
 def golden_sam(cfg):
     with gzip.open(os.path.join(GOLDEN, f"expected_{cfg}.sam.gz"), "rb") as fh:
         return fh.read()
@@ -74,6 +79,8 @@ GOLDEN_CONFIGS = {
     "n30": dict(max_map=30),
     "k17c2000": dict(min_anchor_len=17, sampling_count=2000),
     "k12c300m20": dict(min_anchor_len=12, sampling_count=300, max_ref_hits=20),
+    "clasp": dict(chain_alg=1),
+    "clasp_n30": dict(chain_alg=1, max_map=30),
 }
 
 

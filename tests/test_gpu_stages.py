@@ -14,6 +14,36 @@ def rseq(rng, n, alphabet=ACGT, p=None):
     return bytes(rng.choice(alphabet, size=n, p=p))
 
 
+def test_chain_clasp_golden(stages_clasp):
+    """lf_chain_clasp_batch (lf_clasp_kernel.h) vs chain_seeds_clasp of the compiled reference"""
+    import lordfast_amd as la
+    st = stages_clasp
+    ins = split_ragged(st["clasp_in"], st["clasp_n"])
+    outs = split_ragged(st["clasp_out"], st["clasp_out_n"])
+    res = la.chain_clasp_batch(ins)
+    for i, ((ch, sc), exp, esc) in enumerate(zip(res, outs, st["clasp_score"])):
+        assert np.array_equal(ch, exp), (i, len(ins[i]), len(ch), len(exp))
+        assert np.float32(sc) == np.float32(esc), i
+
+
+def test_chain_clasp_fuzz_vs_oracle(oracle_lib):
+    import lordfast_amd as la
+    from test_oracle_vs_ref import clasp_window
+    orc = oracle_lib.Oracle()
+    rng = np.random.default_rng(21)
+    wins = [clasp_window(rng, it % 5) for it in range(1200)]
+    wins += [np.zeros((0, 3), dtype=np.uint32)]                                 # empty window: score -1, no chain
+    for n in (513, 700, 1500):                                                  # beyond the LDS classes: HBM workspace
+        q = np.sort(rng.integers(0, 30000, size=n))
+        t = q + rng.choice([100000, 100004, 160000], size=n) + rng.integers(-2, 3, size=n)
+        wins.append(np.stack([t, q, rng.integers(14, 22, size=n)], axis=1).astype(np.uint32)[rng.permutation(n)])
+    res = la.chain_clasp_batch(wins)
+    for i, (w, (ch, sc)) in enumerate(zip(wins, res)):
+        ech, esc = orc.chain_clasp(w)
+        assert np.array_equal(ch, ech), (i, len(w), len(ch), len(ech))
+        assert np.float32(sc) == np.float32(esc), i
+
+
 def test_edlib_golden(stages):
     import lordfast_amd as la
     qs = split_ragged(stages["ed_q"].tobytes(), stages["ed_qn"])

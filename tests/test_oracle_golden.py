@@ -63,6 +63,17 @@ def test_chain_n2(oracle, stages):
         assert np.float32(score) == np.float32(sc)
 
 
+def test_chain_clasp(oracle, stages_clasp):
+    st = stages_clasp
+    ins = split_ragged(st["clasp_in"], st["clasp_n"])
+    outs = split_ragged(st["clasp_out"], st["clasp_out_n"])
+    assert max(st["clasp_out_n"]) > 20
+    for sd, ch, sc in zip(ins, outs, st["clasp_score"]):
+        c2, score = oracle.chain_clasp(sd)
+        assert np.array_equal(c2, ch)
+        assert np.float32(score) == np.float32(sc)
+
+
 def test_edlib(oracle, stages):
     qs = split_ragged(stages["ed_q"].tobytes(), stages["ed_qn"])
     ts = split_ragged(stages["ed_t"].tobytes(), stages["ed_tn"])

@@ -110,6 +110,45 @@ def test_chain_and_sort_fuzz(oracle_lib, ref):
         assert np.float32(a[2]) == np.float32(b[2])
 
 
+def clasp_window(rng, kind):
+    """seed sets for the clasp chainer: a few diagonals with jitter, random background, repeated qPos"""
+    n = int(rng.integers(1, 40 if kind < 3 else 300))
+    L = int(rng.integers(200, 20000))
+    base = int(rng.integers(0, 1 << 27))
+    diags = rng.integers(0, 3 * L, size=int(rng.integers(1, 4)))
+    seeds = []
+    for _ in range(n):
+        ln = int(rng.integers(14, 40)) if kind != 2 else 15
+        q = int(rng.integers(0, L)) if kind != 2 else int(rng.integers(0, L // 10 + 1)) * 10
+        if rng.random() < 0.8:
+            d = int(diags[rng.integers(0, len(diags))])
+            jit = int(rng.integers(-3, 4)) if kind % 2 == 0 else int(rng.integers(-60, 61))
+            t = base + max(0, q + d + jit)
+        else:
+            t = base + int(rng.integers(0, 4 * L))
+        seeds.append((t, q, ln))
+    if kind == 4 and n > 2:
+        for _ in range(n // 4):
+            a = seeds[int(rng.integers(0, n))]
+            seeds.append((a[0] + int(rng.integers(0, 3)) * 50, a[1], a[2]))
+    return np.array(seeds, dtype=np.uint32)
+
+
+def test_chain_clasp_fuzz(oracle_lib, ref):
+    """lfo_chain_clasp (ordered maps replayed literally) vs the reference's chain_seeds_clasp over lib/clasp"""
+    orc = oracle_lib.Oracle()
+    rng = np.random.default_rng(8)
+    longest = 0
+    for it in range(1500):
+        sd = clasp_window(rng, it % 5)
+        a = ref.chain_clasp(sd)
+        b = orc.chain_clasp(sd)
+        assert np.array_equal(a[0], b[0]), f"chain differs (n={len(sd)}, it={it})"
+        assert np.float32(a[1]) == np.float32(b[1])
+        longest = max(longest, len(a[0]))
+    assert longest > 20
+
+
 @pytest.fixture(scope="module")
 def big_case(tmp_path_factory, ref, oracle_lib):
     d = tmp_path_factory.mktemp("g600k")
@@ -126,7 +165,8 @@ def big_case(tmp_path_factory, ref, oracle_lib):
 
 @pytest.mark.parametrize("kw", [dict(), dict(max_map=30), dict(min_anchor_len=17, sampling_count=2000),
                                 dict(min_anchor_len=12, sampling_count=400, max_ref_hits=30),
-                                dict(min_read_len=4000, gap_penalty=0.3, chain_reward=5.0, chain_penalty=8.0)])
+                                dict(min_read_len=4000, gap_penalty=0.3, chain_reward=5.0, chain_penalty=8.0),
+                                dict(chain_alg=1), dict(chain_alg=1, max_map=30, min_anchor_len=12, sampling_count=400)])
 def test_sam_vs_reference(big_case, ref, oracle_lib, kw):
     fa, reads = big_case
     names = [r[0] for r in reads]
