@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workdir", default=os.environ.get("LF_BENCH_DIR", "/tmp/lf_bench"))
+    ap.add_argument("--chain-alg", choices=["dp-n2", "clasp"], default="dp-n2",
+                    help="BASELINE config C2 (the headline) is dp-n2; clasp + --max-map 30 is config C4's option set")
+    ap.add_argument("--max-map", type=int, default=10, help="-n (config C4: 30)")
     ap.add_argument("--single-output", action="store_true",
                     help="N>1: also gather every rank's SAM records behind rank 0's (point-to-point over RCCL) inside the timed region")
     return ap.parse_args()
@@ -130,7 +133,7 @@ def cpu_baseline(args, fa, names, seqs):
         pass
     best = None
     for th in cands:
-        ref.set_params(po.default_params(threads=th), "bench")
+        ref.set_params(po.default_params(threads=th, chain_alg=1 if args.chain_alg == 'clasp' else 0, max_map=args.max_map), "bench")
         c = ref.threads()
         pilot = min(len(seqs), max(4 * c, 256))
         _, secs = ref.map_mem(names[:pilot], seqs[:pilot])
@@ -139,7 +142,7 @@ def cpu_baseline(args, fa, names, seqs):
         if best is None or r > best[0]:
             best = (r, th, c)
     rate, th, cores = best
-    ref.set_params(po.default_params(threads=th), "bench")
+    ref.set_params(po.default_params(threads=th, chain_alg=1 if args.chain_alg == 'clasp' else 0, max_map=args.max_map), "bench")
     n = int(min(len(seqs), max(pilot, rate * args.cpu_seconds)))
     sam, secs = ref.map_mem(names[:n], seqs[:n])
     bases = sum(len(s) for s in seqs[:n])
@@ -184,7 +187,8 @@ def main():
     t0 = time.time()
     lf = la.LordFast(fa, device=local, full_sa=True)
     log(f"rank {rank}: index resident in HBM after {time.time() - t0:.1f}s")
-    params = la.default_params(min_anchor_len=14, sampling_count=1000)       # -k 14 -c 1000 --chainAlg dp-n2
+    params = la.default_params(min_anchor_len=14, sampling_count=1000,       # -k 14 -c 1000 --chainAlg dp-n2 (C2)
+                               chain_alg=1 if args.chain_alg == "clasp" else 0, max_map=args.max_map)
 
     n_total = args.reads * world
     names, seqs = make_reads(args, contigs, fa, rank)        # reads shard by rank: no data-path collective
@@ -330,7 +334,7 @@ def main():
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{args.reads} synthetic PacBio reads per GPU (~{args.read_len} bp, {args.err:.0%} err) vs "
-                                   f"{args.genome_mbp:g} Mbp synthetic genome, -k 14 -c 1000 --chainAlg dp-n2",
+                                   f"{args.genome_mbp:g} Mbp synthetic genome, -k 14 -c 1000 --chainAlg {args.chain_alg}" + (f" -n {args.max_map}" if args.max_map != 10 else ""),
                        "reads_per_gpu": args.reads, "mean_read_len": bases / max(1, n_total), "genome_mbp": args.genome_mbp,
                        "parallelism": f"reads sharded over {world} GPU(s), index replicated, no data-path collective"
                                       + (" + SAM gather to rank 0" if (dist and args.single_output) else ""), "index": "FM-index + full SA resident in HBM"},

@@ -59,9 +59,13 @@ typedef struct {
     double gap_penalty;      /* --gapPenalty   0.15 */
     int    threads;          /* -t host glue threads (0 = all online CPUs, max 255) */
     char   read_group_id[256]; /* -R ... ID, empty = none */
+    char   read_group[1000];   /* -R: the whole @RG header line (escapes resolved), printed by lf_sam_header */
 } lf_params_t;
 
 void lf_params_default(lf_params_t *p);
+/* set_read_group (src/CommandLineParser.cpp:85-124): `rg_line` must start with "@RG", contain no literal tab and an
+ * "ID:" field; \t \n \r \\ escapes are resolved. Fills read_group and read_group_id. Non-zero + lf_last_error on error. */
+int  lf_params_set_read_group(lf_params_t *p, const char *rg_line);
 
 /* ------------------------------------------------------------------------------------------------
  * Device / index

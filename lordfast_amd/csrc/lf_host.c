@@ -36,6 +36,33 @@ void lf_params_default(lf_params_t *p)
     p->gap_penalty = 0.15; p->threads = 0;
 }
 
+int lf_params_set_read_group(lf_params_t *P, const char *rg_line)
+{   /* src/CommandLineParser.cpp:85-124 */
+    if (!P || !rg_line) { lf_set_error("lf_params_set_read_group: bad argument"); return LF_ERR_ARG; }
+    if (strstr(rg_line, "@RG") != rg_line) { lf_set_error("SAM read group line does not start with @RG"); return LF_ERR_ARG; }
+    if (strstr(rg_line, "\t") != NULL) { lf_set_error("the read group line contained literal <tab> characters. Please replace with escaped tabs: \\t"); return LF_ERR_ARG; }
+    if (strlen(rg_line) >= sizeof P->read_group) { lf_set_error("read group line too long"); return LF_ERR_ARG; }
+    const char *p; char *q;
+    for (p = rg_line, q = P->read_group; *p; p++) {
+        if (*p != '\\') *q++ = *p;
+        else {
+            p++;
+            if (*p == 't') *q++ = '\t';
+            else if (*p == 'n') *q++ = '\n';
+            else if (*p == 'r') *q++ = '\r';
+            else if (*p == '\\') *q++ = '\\';
+            else if (*p == 0) break;
+        }
+    }
+    *q = 0;
+    const char *id = strstr(P->read_group, "ID:");
+    if (!id) { lf_set_error("no ID within the read group line"); P->read_group[0] = 0; return LF_ERR_ARG; }
+    size_t k = 0;
+    for (id += 3; *id && *id != '\n' && *id != '\t' && k + 1 < sizeof P->read_group_id; ) P->read_group_id[k++] = *id++;
+    P->read_group_id[k] = 0;
+    return LF_OK;
+}
+
 void lf_free(void *ptr) { free(ptr); }
 
 static void *read_file(const char *path, size_t *n_out)

@@ -2067,10 +2067,10 @@ int lf_map_batch_into(const lf_index_t *ix, const lf_params_t *p, int n, const c
 /* printSamHeader (src/BWT.cpp:668-681) */
 char *lf_sam_header(const lf_index_t *ix, const lf_params_t *p, const char *cmdline)
 {
-    (void)p;
     str_t sb; str_init(&sb);
     str_puts(&sb, "@HD\tVN:1.5\tSO:unsorted\n");
     for (int i = 0; i < ix->n_seqs; i++) { str_puts(&sb, "@SQ\tSN:"); str_puts(&sb, ix->contigs[i].name); str_puts(&sb, "\tLN:"); str_puti(&sb, ix->contigs[i].len); str_putc(&sb, '\n'); }
+    if (p && p->read_group_id[0] && p->read_group[0]) { str_puts(&sb, p->read_group); str_putc(&sb, '\n'); }      /* src/BWT.cpp:676-679 */
     str_puts(&sb, "@PG\tID:lordfast\tPN:lordfast\tVN:0.0.10\tCL:"); str_puts(&sb, cmdline ? cmdline : ""); str_putc(&sb, '\n');
     return sb.s;
 }

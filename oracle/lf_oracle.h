@@ -51,6 +51,7 @@ typedef struct {
     double chain_reward, chain_penalty, gap_penalty; /* 9.3, 11.4, 0.15 */
     int threads;
     char read_group_id[256];
+    char read_group[1000];   /* the @RG header line (readGroup, src/CommandLineParser.cpp:42) */
 } lfo_params_t;
 
 void lfo_params_default(lfo_params_t *p);

@@ -804,7 +804,7 @@ char *lfo_sam_header(const lfo_index_t *ix, const lfo_params_t *p, const char *c
         sb_puts(&sb, "@SQ\tSN:"); sb_puts(&sb, ix->contigs[i].name);
         sb_printf(&sb, "\tLN:%d\n", ix->contigs[i].len);
     }
-    (void)p;
+    if (p && p->read_group_id[0] && p->read_group[0]) { sb_puts(&sb, p->read_group); sb_putc(&sb, '\n'); }   /* src/BWT.cpp:676-679 */
     sb_puts(&sb, "@PG\tID:lordfast\tPN:lordfast\tVN:0.0.10\tCL:"); sb_puts(&sb, cmdline ? cmdline : ""); sb_putc(&sb, '\n');
     return sb.s;
 }

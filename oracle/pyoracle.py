@@ -29,11 +29,11 @@ class Params(C.Structure):
     _fields_ = [("min_anchor_len", C.c_int), ("sampling_count", C.c_int), ("max_map", C.c_int),
                 ("min_read_len", C.c_int), ("max_ref_hits", C.c_int), ("chain_alg", C.c_int),
                 ("chain_reward", C.c_double), ("chain_penalty", C.c_double), ("gap_penalty", C.c_double),
-                ("threads", C.c_int), ("read_group_id", C.c_char * 256)]
+                ("threads", C.c_int), ("read_group_id", C.c_char * 256), ("read_group", C.c_char * 1000)]
 
 
 def default_params(**kw) -> Params:
-    p = Params(14, 1000, 10, 1000, 1000, 0, 9.3, 11.4, 0.15, 1, b"")
+    p = Params(14, 1000, 10, 1000, 1000, 0, 9.3, 11.4, 0.15, 1, b"", b"")
     for k, v in kw.items():
         setattr(p, k, v)
     return p

@@ -1,0 +1,96 @@
+"""The `lordfast` front end (lordfast_amd/cli/lordfast.c): the reference's process interface (SURVEY 8b,
+src/CommandLineParser.cpp:126-310, src/baseFAST.cpp:30-95) over the C ABI.  Option handling is checked on CPU
+(it fails before any device call); the end-to-end run is a GPU test against the golden SAM of the compiled reference."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, golden_sam
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "lordfast_amd", "lordfast")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    if not os.path.exists(CLI):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "lordfast_amd", "csrc"), "-j4"], check=True, stdout=subprocess.DEVNULL)
+    return CLI
+
+
+def run(cli, *args):
+    return subprocess.run([cli, *args], capture_output=True, timeout=600)
+
+
+def test_usage_and_validation(cli):
+    r = run(cli)
+    assert r.returncode == 1 and b"usage: lordfast --index ref.fa" in r.stderr
+    r = run(cli, "-v")
+    assert r.returncode == 0 and r.stdout == b"lordFAST 0.0.10\n"
+    r = run(cli, "--seq", "x.fa")
+    assert r.returncode == 1 and b"indexing / searching mode should be selected" in r.stderr
+    r = run(cli, "--search", "x.fa")
+    assert r.returncode == 1 and b"please indicate a sequence file for searching" in r.stderr
+    for opt, msg in (("-k 11", b"-k/--minAnchorLen requires an argument in [12..20]"), ("-k 21", b"-k/--minAnchorLen"),
+                     ("-c 0", b"-c/--anchorCount requires a positive integer"), ("-n 0", b"-n/--numMap requires a positive integer"),
+                     ("-m 0", b"-m/--maxRefHit requires a positive integer")):
+        r = run(cli, "--search", "x.fa", "--seq", "y.fa", *opt.split())
+        assert r.returncode == 1 and msg in r.stderr, opt
+    r = run(cli, "--search", "x.fa", "--seq", "y.fa", "-R", "RG\\tID:a")
+    assert r.returncode == 1 and b"does not start with @RG" in r.stderr
+    r = run(cli, "--search", "x.fa", "--seq", "y.fa", "-R", "@RG\\tSM:a")
+    assert r.returncode == 1 and b"no ID within the read group line" in r.stderr
+    r = run(cli, "--search", "x.fa", "--seq", "y.fa", "-Z")
+    assert r.returncode == 1 and b"usage:" in r.stderr
+
+
+def test_no_device_is_loud(cli):
+    import lordfast_amd as la
+    if la.device_count() > 0:
+        pytest.skip("a device is visible")
+    r = run(cli, "--search", "x.fa", "--seq", "y.fa")
+    assert r.returncode == 1 and b"no gfx950 device" in r.stderr and b"no CPU path" in r.stderr
+
+
+@pytest.mark.gpu
+def test_search_end_to_end(cli, golden_dir, oracle, oracle_lib, tmp_path):
+    reads = str(tmp_path / "reads.fa")
+    with gzip.open(os.path.join(GOLDEN, "reads.fa.gz"), "rb") as fi, open(reads, "wb") as fo:
+        fo.write(fi.read())
+    fa = os.path.join(golden_dir, "genome.fa")
+    out = str(tmp_path / "out.sam")
+    args = ["--search", fa, "--seq", reads, "-o", out, "-t", "4"]
+    r = run(cli, *args)
+    assert r.returncode == 0, r.stderr.decode()
+    cmdline = " ".join([cli] + args) + " "
+    exp = oracle.sam_header(cmdline) + golden_sam("default")
+    assert open(out, "rb").read() == exp
+    # stdout, no header, clasp + -n 30, read group
+    args = ["--search", fa, "--seq", os.path.join(GOLDEN, "reads.fa.gz"), "--noSamHeader", "-a", "clasp", "-n", "30", "-t", "0"]
+    r = run(cli, *args)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == golden_sam("clasp_n30")
+    args = ["--search", fa, "--seq", reads, "-R", "@RG\\tID:grp1\\tSM:x", "-k", "17", "-c", "2000"]
+    r = run(cli, *args)
+    assert r.returncode == 0, r.stderr.decode()
+    p = oracle_lib.default_params(min_anchor_len=17, sampling_count=2000, read_group_id=b"grp1", read_group=b"@RG\tID:grp1\tSM:x")
+    names, seqs = [], []
+    from conftest import read_fasta
+    names, seqs = read_fasta(reads)
+    exp = oracle.sam_header(" ".join([cli] + args) + " ", params=p) + oracle.map_batch(names, seqs, params=p)
+    assert r.stdout == exp
+    assert b"@RG\tID:grp1\tSM:x\n@PG" in r.stdout and b"\tRG:Z:grp1" in r.stdout
+
+
+@pytest.mark.gpu
+def test_index_mode_builds_reference_files(cli, tmp_path):
+    """--index writes the reference's index files; --search on a FASTA without index builds it first (src/BWT.cpp:203-208)"""
+    fa = str(tmp_path / "genome.fa")
+    with gzip.open(os.path.join(GOLDEN, "genome.fa.gz"), "rb") as fi, open(fa, "wb") as fo:
+        fo.write(fi.read())
+    r = run(cli, "--index", fa)
+    assert r.returncode == 0, r.stderr.decode()
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        assert open(f"{fa}.{ext}", "rb").read() == open(os.path.join(GOLDEN, f"genome.fa.{ext}"), "rb").read(), ext
