@@ -167,7 +167,10 @@ extern "C" int lfg_chain_clasp(int device, int n_windows, const Seed_t *seeds, c
         const uint32_t hi = CCAPS[c] ? CCAPS[c] : 0xFFFFFFFFu;
         if (c == 2 && ws == 0) break;
         const size_t smem = CCAPS[c] ? (size_t)CCAPS[c] * LF_CLASP_BYTES_PER_FRAG : 16;
-        hipLaunchKernelGGL(lf_clasp_kernel, dim3((unsigned)n_windows), dim3(64), smem, s, (const lf_chain_win *)d_w, n_windows,
+        if (CCAPS[c]) hipLaunchKernelGGL(lf_clasp_kernel<true>, dim3((unsigned)n_windows), dim3(64), smem, s, (const lf_chain_win *)d_w, n_windows,
+                           (const uint32_t *)d_sorted, (const uint32_t *)nullptr, CCAPS[c], (unsigned char *)d_ws,
+                           (uint32_t *)d_idx, (uint32_t *)d_len, (float *)d_sc, lo, hi);
+        else hipLaunchKernelGGL(lf_clasp_kernel<false>, dim3((unsigned)n_windows), dim3(64), smem, s, (const lf_chain_win *)d_w, n_windows,
                            (const uint32_t *)d_sorted, (const uint32_t *)nullptr, CCAPS[c], (unsigned char *)d_ws,
                            (uint32_t *)d_idx, (uint32_t *)d_len, (float *)d_sc, lo, hi);
         lo = hi + 1;

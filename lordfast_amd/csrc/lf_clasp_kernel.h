@@ -70,7 +70,7 @@ __device__ __forceinline__ double lf_clasp_gsop(int cs, int cq, int fend_s, int 
 }
 
 /* clasp's quickSort (lib/clasp/sort.c:164-225) on an index array; comparator = the int key (equal keys compare 0) */
-__device__ inline void lf_clasp_qsort(uint32_t *sorted, const int *keys, int size)
+__device__ __forceinline__ void lf_clasp_qsort(uint32_t *sorted, const int *keys, int size)
 {
     int stk[96]; int top = 0;
     stk[0] = 0; stk[1] = size - 1; top = 1;
@@ -107,7 +107,7 @@ __device__ __forceinline__ void lf_clasp_argmax(double &pr, uint32_t &ey, uint32
 
 /* bl_slChainSopRMQ (slchain.c:841-912) for the start point of fragment `cur`; returns the chosen chain or -1.
  * All lanes scan; lane 0 applies the side effects and owns the result. */
-__device__ inline int lf_clasp_rmq(const lf_clasp_mem &m, const uint32_t *enty, const uint32_t *entf, const double *prio,
+__device__ __forceinline__ int lf_clasp_rmq(const lf_clasp_mem &m, const uint32_t *enty, const uint32_t *entf, const double *prio,
                                    int N, uint32_t x, uint32_t y, int cur, int lane)
 {
     int res = -1; double resprio = -DBL_MAX;
@@ -150,7 +150,7 @@ __device__ inline int lf_clasp_rmq(const lf_clasp_mem &m, const uint32_t *enty, 
 }
 
 /* bl_slChainSop (slchain.c:668-826) over the cluster of fragments [cb, cb + cm) */
-__device__ inline void lf_clasp_chain_sop(const lf_clasp_mem &m, int cb, int cm, int lane)
+__device__ __forceinline__ void lf_clasp_chain_sop(const lf_clasp_mem &m, int cb, int cm, int lane)
 {
     const int N = 2 * cm;
     const int xmin = m.fp[cb];
@@ -239,6 +239,10 @@ __device__ inline void lf_clasp_chain_sop(const lf_clasp_mem &m, int cb, int cm,
     }
 }
 
+/* LDS = true: the window's working set is carved from dynamic LDS (windows up to `cap` fragments); every pointer is
+ * then derived from the LDS base alone, so the compiler emits ds_read / ds_write instead of FLAT accesses.
+ * LDS = false: windows above LF_CLASP_LDS_MAX work in their slice of the HBM workspace. */
+template <bool LDS>
 static __global__ void __launch_bounds__(64)
 lf_clasp_kernel(const lf_chain_win *__restrict__ wins, int n_wins, const uint32_t *__restrict__ seeds /* (tPos, qPos:20|len:12), by target start */,
                 const uint32_t *__restrict__ shift /* per window id: value subtracted from tPos (0 or 2000000000), may be null */,
@@ -254,8 +258,8 @@ lf_clasp_kernel(const lf_chain_win *__restrict__ wins, int n_wins, const uint32_
     const int n = (int)w.n;
     if (n == 0) { if (lane == 0) { chain_len[w.id] = 0; score[w.id] = -1.0f; } return; }
     lf_clasp_mem m;
-    const bool in_lds = w.n <= cap;
-    lf_clasp_carve(m, in_lds ? smem : ws + w.ws_off * (uint64_t)LF_CLASP_BYTES_PER_FRAG, in_lds ? cap : w.n);
+    if (LDS) lf_clasp_carve(m, smem, cap);
+    else lf_clasp_carve(m, ws + w.ws_off * (uint64_t)LF_CLASP_BYTES_PER_FRAG, w.n);
     const uint32_t sh = shift ? shift[w.id] : 0u;
     const uint32_t *sd = seeds + 2 * w.off;
     for (int i = lane; i < n; i += 64) { const uint32_t qpl = sd[2 * i + 1]; m.fp[i] = (int)(sd[2 * i] - sh); m.fq[i] = (int)(qpl & 0xFFFFF); m.fl[i] = (int)(qpl >> 20); }
