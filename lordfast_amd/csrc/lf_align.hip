@@ -651,7 +651,7 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     /* the size classes run CONCURRENTLY on their own streams: the long-query classes have few, long waves and
      * would leave most CUs idle if the kernels ran back to back */
     hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1), cs[7];
-    static hipEvent_t cdone_all[16][7]; static bool cdone_init[16] = { false };
+    static hipEvent_t cdone_all[32][7]; static bool cdone_init[32] = { false };
     const int lane_id = lfg_get_lane();
     if (!s) return LF_ERR_HIP;
     for (int k = 0; k < 7; k++) { cs[k] = (hipStream_t)lfg_lane_stream(device, 2 + k); if (!cs[k]) return LF_ERR_HIP; }
@@ -790,7 +790,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     if (n == 0) return LF_OK;
     HIPCHK(hipSetDevice(device));
     hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1), cs[LF_NCLASS];
-    static hipEvent_t cdone_all[16][LF_NCLASS]; static bool cdone_init[16] = { false };
+    static hipEvent_t cdone_all[32][LF_NCLASS]; static bool cdone_init[32] = { false };
     const int lane_id = lfg_get_lane();
     if (!s) return LF_ERR_HIP;
     static const bool serial_classes = getenv("LF_SERIAL_CLASSES") != nullptr;     /* profiling aid: one class at a time */

@@ -8,7 +8,7 @@
 
 namespace {
 struct slot_t { void *p = nullptr; size_t cap = 0; };
-constexpr int MAX_DEV = 16, MAX_SLOT = 2560, LANE_STRIDE = 160, MAX_LANE = 16;
+constexpr int MAX_DEV = 16, LANE_STRIDE = 160, MAX_LANE = 32, MAX_SLOT = MAX_LANE * LANE_STRIDE;
 thread_local int t_lane = 0;
 hipStream_t g_streams[MAX_DEV][MAX_LANE][16];
 slot_t g_dev[MAX_DEV][MAX_SLOT];
@@ -16,7 +16,7 @@ slot_t g_pin[MAX_SLOT];
 std::mutex g_mu;
 }
 
-/* up to eight chunks ("lanes") may be in flight at once (lanes 8..15 belong to the chunks' helper threads), each driven by its own host thread: a lane owns its own
+/* up to sixteen chunks ("lanes") may be in flight at once (lanes 16..31 belong to the chunks' helper threads), each driven by its own host thread: a lane owns its own
  * set of slots and streams, so nothing is shared between them but the index */
 extern "C" void lfg_set_lane(int lane) { t_lane = (lane >= 0 && lane < MAX_LANE) ? lane : 0; }
 extern "C" int lfg_get_lane(void) { return t_lane; }

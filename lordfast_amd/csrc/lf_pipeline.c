@@ -76,7 +76,7 @@ static void *ar_grow(arena_t *a, void *old, size_t old_bytes, size_t new_bytes)
     return p;
 }
 static void ar_reset(arena_t *a) { a->cur = 0; a->off = 0; }
-#define LF_MAX_LANES 8
+#define LF_MAX_LANES 16
 static arena_t g_arena[LF_MAX_LANES][260];          /* [lane][worker]; blocks are kept across chunks and batches */
 
 /* mode 0: owned, growable, NUL-terminated; mode 1: count only (nothing is written); mode 2: fixed external window;
