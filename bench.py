@@ -321,7 +321,10 @@ def main():
             return dict(bound="hbm", kernel=kname, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=traffic,
                         launches=int(launches), avg_launch_ms=ms / max(1, launches), algorithmic_bytes_per_launch=alg_bytes / max(1, launches))
 
-        dom = max(single, key=lambda k: kernels[k][0])
+        # pinned, not picked per run: with eight chunks in flight the brackets of search and render swap places from
+        # run to run; lf_seed_search_kernel is the HBM-bound kernel of the path (random 64-byte index reads) and
+        # rocprofv3's top single kernel outside the alignment group
+        dom = single[0]
         roofline = roof(dom, dom)
         roofline.update(per_kernel_ms={k: round(v[0], 3) for k, v in kernels.items()}, by_kernel=by_kernel, chunks_in_flight=8,
                         note="HIP-event brackets with up to 8 chunks in flight: a bracket contains time shared with the other chunks' kernels; "

@@ -161,12 +161,12 @@ extern "C" int lfg_chain_clasp(int device, int n_windows, const Seed_t *seeds, c
         hipLaunchKernelGGL(lf_clasp_keys_kernel, dim3((unsigned)n_windows), dim3(64), 0, s, n_windows, (const uint64_t *)d_off, (const uint2 *)d_seeds, k1);
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, k1, k2, (uint64_t *)d_seeds, (uint64_t *)d_sorted, (int)total, 0, 32 + wbits, s));
     }
-    static const uint32_t CCAPS[3] = { 128, LF_CLASP_LDS_MAX, 0 };
+    static const uint32_t CCAPS[5] = { 128, 256, 512, LF_CLASP_LDS_MAX, 0 };
     uint32_t lo = 0;
-    for (int c = 0; c < 3; c++) {
+    for (int c = 0; c < 5; c++) {
         const uint32_t hi = CCAPS[c] ? CCAPS[c] : 0xFFFFFFFFu;
-        if (c == 2 && ws == 0) break;
-        const size_t smem = CCAPS[c] ? (size_t)CCAPS[c] * LF_CLASP_BYTES_PER_FRAG : 16;
+        if (c == 4 && ws == 0) break;
+        const size_t smem = CCAPS[c] ? (size_t)CCAPS[c] * LF_CLASP_LDS_BYTES_PER_FRAG : 16;
         if (CCAPS[c]) hipLaunchKernelGGL(lf_clasp_kernel<true>, dim3((unsigned)n_windows), dim3(64), smem, s, (const lf_chain_win *)d_w, n_windows,
                            (const uint32_t *)d_sorted, (const uint32_t *)nullptr, CCAPS[c], (unsigned char *)d_ws,
                            (uint32_t *)d_idx, (uint32_t *)d_len, (float *)d_sc, lo, hi);

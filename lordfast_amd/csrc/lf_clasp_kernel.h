@@ -28,22 +28,29 @@
 #include "lf_gpu_common.h"
 #include "lf_chain_kernel.h"
 #include <float.h>
+#include <hipcub/hipcub.hpp>
+#include <type_traits>
 
-#define LF_CLASP_BYTES_PER_FRAG 200u       /* working set per fragment, see lf_clasp_carve */
-#define LF_CLASP_LDS_MAX 512u              /* windows up to this many fragments work in LDS (100 KiB) */
+#define LF_CLASP_BYTES_PER_FRAG 200u       /* HBM working set per fragment (32-bit ranks), see lf_clasp_carve */
+#define LF_CLASP_LDS_BYTES_PER_FRAG 136u   /* LDS working set per fragment (16-bit ranks, keys aliased) */
+#define LF_CLASP_LDS_MAX 1024u             /* windows up to this many fragments work in LDS (136 KiB) */
 #define LF_CLASP_NONE 0xFFFFFFFFu
 
+/* R = type of a rank / point index: uint16_t in the LDS instantiation (at most 2 * LF_CLASP_LDS_MAX points), uint32_t in
+ * the HBM-workspace one */
+template <class R>
 struct lf_clasp_mem {
     double *chain_scr, *best_scr, *prioA, *prioB;
     int *fp, *fq, *fl, *chain_first, *chain_prev, *best_base, *best_extra, *prev;
     int *px, *py, *pidx;
-    uint32_t *tr;                 /* tr[k * N + point] = rank of the point in order k */
-    uint32_t *entyA, *entfA, *entyB, *entfB;
-    int *keys;                    /* keys[k * N + point] */
-    uint32_t *sorted;             /* sorted[k * N + rank] = point; aliases prioA/prioB (dead before the time loop) */
+    R *tr;                        /* tr[k * N + point] = rank of the point in order k */
+    R *entyA, *entfA, *entyB, *entfB;
+    int *keys;                    /* keys[k * N + point]; 16-bit ranks: aliases tr + ent* (dead once the ranks exist) */
+    R *sorted;                    /* sorted[k * N + rank] = point; aliases prioA/prioB (dead before the sweep) */
 };
 
-__device__ __forceinline__ void lf_clasp_carve(lf_clasp_mem &m, unsigned char *base, size_t cap)
+template <class R>
+__device__ __forceinline__ void lf_clasp_carve(lf_clasp_mem<R> &m, unsigned char *base, size_t cap)
 {
     const size_t N = 2 * cap;
     m.chain_scr = reinterpret_cast<double *>(base);
@@ -54,10 +61,16 @@ __device__ __forceinline__ void lf_clasp_carve(lf_clasp_mem &m, unsigned char *b
     m.fq = m.fp + cap; m.fl = m.fq + cap; m.chain_first = m.fl + cap; m.chain_prev = m.chain_first + cap;
     m.best_base = m.chain_prev + cap; m.best_extra = m.best_base + cap; m.prev = m.best_extra + cap;
     m.px = m.prev + cap; m.py = m.px + N; m.pidx = m.py + N;
-    m.tr = reinterpret_cast<uint32_t *>(m.pidx + N);
-    m.entyA = m.tr + 4 * N; m.entfA = m.entyA + N; m.entyB = m.entfA + N; m.entfB = m.entyB + N;
-    m.keys = reinterpret_cast<int *>(m.entfB + N);
-    m.sorted = reinterpret_cast<uint32_t *>(m.prioA);
+    m.keys = m.pidx + N;                                              /* 4N ints */
+    if (sizeof(R) == 2) {                                             /* 136 B per fragment */
+        m.tr = reinterpret_cast<R *>(m.keys);                         /* 4N + 4N 16-bit entries == the 4N ints of keys */
+        m.entyA = m.tr + 4 * N;
+    } else {                                                          /* 200 B per fragment */
+        m.tr = reinterpret_cast<R *>(m.keys + 4 * N);
+        m.entyA = m.tr + 4 * N;
+    }
+    m.entfA = m.entyA + N; m.entyB = m.entfA + N; m.entfB = m.entyB + N;
+    m.sorted = reinterpret_cast<R *>(m.prioA);
 }
 
 /* D(a,b) of lib/clasp/slchain.h:40 */
@@ -70,7 +83,8 @@ __device__ __forceinline__ double lf_clasp_gsop(int cs, int cq, int fend_s, int 
 }
 
 /* clasp's quickSort (lib/clasp/sort.c:164-225) on an index array; comparator = the int key (equal keys compare 0) */
-__device__ __forceinline__ void lf_clasp_qsort(uint32_t *sorted, const int *keys, int size)
+template <class R>
+__device__ __forceinline__ void lf_clasp_qsort(R *sorted, const int *keys, int size)
 {
     int stk[96]; int top = 0;
     stk[0] = 0; stk[1] = size - 1; top = 1;
@@ -83,7 +97,7 @@ __device__ __forceinline__ void lf_clasp_qsort(uint32_t *sorted, const int *keys
             do {
                 while (keys[sorted[l2]] < xk) l2++;
                 while (keys[sorted[r2]] > xk) r2--;
-                if (l2 <= r2) { const uint32_t t = sorted[r2]; sorted[r2] = sorted[l2]; sorted[l2] = t; l2++; r2--; }
+                if (l2 <= r2) { const R t = sorted[r2]; sorted[r2] = sorted[l2]; sorted[l2] = t; l2++; r2--; }
             } while (r2 >= l2);
             if (top < 47) {
                 if ((l2 - left) > (right - l2)) { stk[2 * top] = left; stk[2 * top + 1] = r2; top++; left = l2; }
@@ -95,20 +109,24 @@ __device__ __forceinline__ void lf_clasp_qsort(uint32_t *sorted, const int *keys
     }
 }
 
-__device__ __forceinline__ void lf_clasp_argmax(double &pr, uint32_t &ey, uint32_t &ix)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double pr2 = __shfl_xor(pr, o);
-        const uint32_t ey2 = __shfl_xor(ey, o), ix2 = __shfl_xor(ix, o);
-        if (ey2 != LF_CLASP_NONE && (ey == LF_CLASP_NONE || pr2 > pr || (pr2 == pr && ey2 > ey))) { pr = pr2; ey = ey2; ix = ix2; }
+/* one candidate of a range-tree node: the entry with the greatest (prio, y-rank) below the query's y-rank */
+struct lf_clasp_cand { double pr; uint32_t ey, ix; };
+struct lf_clasp_better {
+    __device__ __forceinline__ lf_clasp_cand operator()(const lf_clasp_cand &a, const lf_clasp_cand &b) const
+    {
+        const bool take_b = b.ey != LF_CLASP_NONE && (a.ey == LF_CLASP_NONE || b.pr > a.pr || (b.pr == a.pr && b.ey > a.ey));
+        return take_b ? b : a;
     }
-}
+};
+/* wavefront arg-max, result valid in lane 0 (rocPRIM moves the four dwords with DPP row shifts / broadcasts instead of
+ * LDS-crossbar permutes) */
+typedef hipcub::WarpReduce<lf_clasp_cand, 64> lf_clasp_wreduce;
 
 /* bl_slChainSopRMQ (slchain.c:841-912) for the start point of fragment `cur`; returns the chosen chain or -1.
  * All lanes scan; lane 0 applies the side effects and owns the result. */
-__device__ __forceinline__ int lf_clasp_rmq(const lf_clasp_mem &m, const uint32_t *enty, const uint32_t *entf, const double *prio,
-                                   int N, uint32_t x, uint32_t y, int cur, int lane)
+template <class R>
+__device__ __forceinline__ int lf_clasp_rmq(const lf_clasp_mem<R> &m, const R *enty, const R *entf, const double *prio,
+                                   int N, uint32_t x, uint32_t y, int cur, int lane, lf_clasp_wreduce::TempStorage *wr_tmp)
 {
     int res = -1; double resprio = -DBL_MAX;
     const int cs = m.fp[cur], cq = m.fq[cur]; const double cscr = (double)m.fl[cur];
@@ -125,15 +143,17 @@ __device__ __forceinline__ int lf_clasp_rmq(const lf_clasp_mem &m, const uint32_
         }
         double pr = 0; uint32_t ey = LF_CLASP_NONE, ix = 0;
         for (int k = lo + lane; k < lo + len; k += 64) {
-            const uint32_t e = enty[k];
+            const uint32_t e = enty[k];            /* an unset entry is (R)~0: never below a rank */
             if (e < y) {
                 const double p2 = prio[k];
                 if (ey == LF_CLASP_NONE || p2 > pr || (p2 == pr && e > ey)) { pr = p2; ey = e; ix = (uint32_t)k; }
             }
         }
         if (__ballot(ey != LF_CLASP_NONE) == 0) continue;
-        lf_clasp_argmax(pr, ey, ix);
+        lf_clasp_cand cd; cd.pr = pr; cd.ey = ey; cd.ix = ix;
+        cd = lf_clasp_wreduce(*wr_tmp).Reduce(cd, lf_clasp_better());
         if (lane == 0) {
+            pr = cd.pr; ix = cd.ix;
             const int tf = (int)entf[ix];
             const double g = lf_clasp_gsop(cs, cq, m.fp[tf] + m.fl[tf] - 1, m.fq[tf] + m.fl[tf] - 1);
             if (cscr >= g) {                                                           /* :877 */
@@ -150,12 +170,13 @@ __device__ __forceinline__ int lf_clasp_rmq(const lf_clasp_mem &m, const uint32_
 }
 
 /* bl_slChainSop (slchain.c:668-826) over the cluster of fragments [cb, cb + cm) */
-__device__ __forceinline__ void lf_clasp_chain_sop(const lf_clasp_mem &m, int cb, int cm, int lane)
+template <class R>
+__device__ __forceinline__ void lf_clasp_chain_sop(const lf_clasp_mem<R> &m, int cb, int cm, int lane, lf_clasp_wreduce::TempStorage *wr_tmp)
 {
     const int N = 2 * cm;
     const int xmin = m.fp[cb];
     /* ---- bl_slExtractPoints: fragment ends sorted with clasp's quickSort, merged with the starts ---- */
-    for (int i = lane; i < cm; i += 64) { m.sorted[i] = (uint32_t)i; m.keys[i] = m.fp[cb + i] + m.fl[cb + i] - 1 - xmin; m.best_base[cb + i] = -1; m.prev[cb + i] = -1; }
+    for (int i = lane; i < cm; i += 64) { m.sorted[i] = (R)i; m.keys[i] = m.fp[cb + i] + m.fl[cb + i] - 1 - xmin; m.best_base[cb + i] = -1; m.prev[cb + i] = -1; }
     __syncthreads();
     if (lane == 0) {
         lf_clasp_qsort(m.sorted, m.keys, cm);
@@ -181,26 +202,29 @@ __device__ __forceinline__ void lf_clasp_chain_sop(const lf_clasp_mem &m, int cb
         m.keys[N + i] = y * 2 + (1 - st);           /* T1.y = y, start points first */
         m.keys[2 * N + i] = x * 2 + (1 - st);       /* T2.x = x, start points first */
         m.keys[3 * N + i] = (y - x) * 2 + st;       /* T2.y = y - x, end points first */
-        m.sorted[i] = m.sorted[N + i] = m.sorted[2 * N + i] = m.sorted[3 * N + i] = (uint32_t)i;
+        m.sorted[i] = m.sorted[N + i] = m.sorted[2 * N + i] = m.sorted[3 * N + i] = (R)i;
     }
     __syncthreads();
     if (lane < 4) lf_clasp_qsort(m.sorted + lane * N, m.keys + lane * N, N);
     __syncthreads();
     for (int r = lane; r < N; r += 64) {
+        uint32_t rk[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) m.tr[k * N + m.sorted[k * N + r]] = (uint32_t)r;
+        for (int k = 0; k < 4; k++) rk[k] = m.sorted[k * N + r];
+#pragma unroll
+        for (int k = 0; k < 4; k++) m.tr[k * N + rk[k]] = (R)r;
     }
     const int ta = m.px[m.sorted[2 * N + N - 1]], tb = m.py[m.sorted[N + N - 1]];     /* t.a, t.b :703-706 */
     __syncthreads();
-    for (int i = lane; i < N; i += 64) { m.entyA[i] = LF_CLASP_NONE; m.entyB[i] = LF_CLASP_NONE; }
+    for (int i = lane; i < N; i += 64) { m.entyA[i] = (R)~(R)0; m.entyB[i] = (R)~(R)0; }
     __syncthreads();
     /* ---- the sweep over the points ---- */
     for (int t = 0; t < N; t++) {
         const int pi = m.pidx[t], cur = pi >> 1;
         const uint32_t t0 = m.tr[t], t1 = m.tr[N + t], t2 = m.tr[2 * N + t], t3 = m.tr[3 * N + t];
         if (pi & 1) {
-            const int ap = lf_clasp_rmq(m, m.entyA, m.entfA, m.prioA, N, t0, t1, cur, lane);
-            const int bp = lf_clasp_rmq(m, m.entyB, m.entfB, m.prioB, N, t2, t3, cur, lane);
+            const int ap = lf_clasp_rmq(m, m.entyA, m.entfA, m.prioA, N, t0, t1, cur, lane, wr_tmp);
+            const int bp = lf_clasp_rmq(m, m.entyB, m.entfB, m.prioB, N, t2, t3, cur, lane, wr_tmp);
             if (lane == 0) {
                 const int cs = m.fp[cur], cq = m.fq[cur];
                 int pv;
@@ -232,8 +256,8 @@ __device__ __forceinline__ void lf_clasp_chain_sop(const lf_clasp_mem &m, int cb
             const int ds = lf_clasp_d(ta, fe_s), dq = lf_clasp_d(tb, fe_q);
             const double g1 = 0.15 * (double)ds + (0.0 - 0.15) * (double)dq;                           /* GCSOP1 */
             const double g2 = 0.15 * (double)dq + (0.0 - 0.15) * (double)ds;                           /* GCSOP2 */
-            m.prioA[t0] = scr - g1; m.entfA[t0] = (uint32_t)cur; m.entyA[t0] = t1;
-            m.prioB[t2] = scr - g2; m.entfB[t2] = (uint32_t)cur; m.entyB[t2] = t3;
+            m.prioA[t0] = scr - g1; m.entfA[t0] = (R)cur; m.entyA[t0] = (R)t1;
+            m.prioB[t2] = scr - g2; m.entfB[t2] = (R)cur; m.entyB[t2] = (R)t3;
         }
         __syncthreads();
     }
@@ -251,13 +275,15 @@ lf_clasp_kernel(const lf_chain_win *__restrict__ wins, int n_wins, const uint32_
                 uint32_t n_min, uint32_t n_max)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ lf_clasp_wreduce::TempStorage wr_tmp;
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= n_wins) return;
     const lf_chain_win w = wins[blockIdx.x];
     if (w.n < n_min || w.n > n_max) return;
     const int n = (int)w.n;
     if (n == 0) { if (lane == 0) { chain_len[w.id] = 0; score[w.id] = -1.0f; } return; }
-    lf_clasp_mem m;
+    typedef typename std::conditional<LDS, uint16_t, uint32_t>::type R;
+    lf_clasp_mem<R> m;
     if (LDS) lf_clasp_carve(m, smem, cap);
     else lf_clasp_carve(m, ws + w.ws_off * (uint64_t)LF_CLASP_BYTES_PER_FRAG, w.n);
     const uint32_t sh = shift ? shift[w.id] : 0u;
@@ -297,7 +323,7 @@ lf_clasp_kernel(const lf_chain_win *__restrict__ wins, int n_wins, const uint32_
                 m.chain_scr[begin] = (double)m.fl[begin]; m.chain_first[begin] = begin; m.chain_prev[begin] = -1;
                 m.best_scr[begin] = (double)m.fl[begin]; m.best_base[begin] = begin; m.best_extra[begin] = -1;
             }
-        } else lf_clasp_chain_sop(m, begin, cm, lane);
+        } else lf_clasp_chain_sop(m, begin, cm, lane, &wr_tmp);
         if (lane == 0) {      /* src/Chain.cpp:128-147: first strictly greater, compared with the float kept so far */
             for (int j = begin; j <= end; j++)
                 if (m.best_base[j] >= 0 && m.best_scr[j] > (double)bestScore) { bestScore = (float)m.best_scr[j]; bestFrag = j; }

@@ -474,17 +474,30 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     if (clasp) {
         uint32_t *d_shift = (uint32_t *)d_prev;
         hipLaunchKernelGGL(lf_req_shift_kernel, dim3((unsigned)((n_req + 255) / 256)), dim3(256), 0, s, (int)n_req, d_req_lo, d_shift);
-        static const uint32_t CCAPS[3] = { 128, LF_CLASP_LDS_MAX, 0 };
-        uint32_t lo = 0;
-        for (int c = 0; c < 3; c++) {
-            const uint32_t hi = CCAPS[c] ? CCAPS[c] : 0xFFFFFFFFu;
-            if (c == 2 && WS == 0) break;
-            const size_t smem = CCAPS[c] ? (size_t)CCAPS[c] * LF_CLASP_BYTES_PER_FRAG : 16;
-            if (CCAPS[c]) hipLaunchKernelGGL(lf_clasp_kernel<true>, dim3((unsigned)n_req), dim3(64), smem, s, (const lf_chain_win *)d_wins, (int)n_req,
+        /* LDS size classes (136 B per fragment: 18 / 9 / 6 / 4 / 3 / 2 / 1 / 1 windows per CU), the HBM-workspace class last.
+         * A window is one wavefront with a long dependent chain, so the classes run CONCURRENTLY on their own streams
+         * (the ones the alignment stage of this lane uses later), largest first: back to back on one stream the 512 class
+         * -- one window per CU -- would hold the whole stage up. */
+        enum { NCC = 9 };
+        static const uint32_t CCAPS[NCC] = { 64, 128, 192, 256, 384, 512, 768, LF_CLASP_LDS_MAX, 0 };
+        static hipEvent_t ev_all[32][NCC + 1]; static bool ev_init[32] = { false };
+        const int lane_id = lfg_get_lane();
+        if (!ev_init[lane_id]) { for (int k = 0; k <= NCC; k++) HIPCHK(hipEventCreateWithFlags(&ev_all[lane_id][k], hipEventDisableTiming)); ev_init[lane_id] = true; }
+        hipEvent_t *ev = ev_all[lane_id];
+        HIPCHK(hipEventRecord(ev[NCC], s));
+        for (int c = NCC - 1; c >= 0; c--) {
+            const uint32_t lo = c == 0 ? 0u : CCAPS[c - 1] + 1u, hi = CCAPS[c] ? CCAPS[c] : 0xFFFFFFFFu;
+            if (c == NCC - 1 && WS == 0) continue;
+            hipStream_t cs = (hipStream_t)lfg_lane_stream(dv, 2 + c);
+            if (!cs) return LF_ERR_HIP;
+            HIPCHK(hipStreamWaitEvent(cs, ev[NCC], 0));
+            const size_t smem = CCAPS[c] ? (size_t)CCAPS[c] * LF_CLASP_LDS_BYTES_PER_FRAG : 16;
+            if (CCAPS[c]) hipLaunchKernelGGL(lf_clasp_kernel<true>, dim3((unsigned)n_req), dim3(64), smem, cs, (const lf_chain_win *)d_wins, (int)n_req,
                                (const uint32_t *)d_sorted, (const uint32_t *)d_shift, CCAPS[c], (unsigned char *)d_dp, d_cidx, d_clen, d_cscore, lo, hi);
-            else hipLaunchKernelGGL(lf_clasp_kernel<false>, dim3((unsigned)n_req), dim3(64), smem, s, (const lf_chain_win *)d_wins, (int)n_req,
+            else hipLaunchKernelGGL(lf_clasp_kernel<false>, dim3((unsigned)n_req), dim3(64), smem, cs, (const lf_chain_win *)d_wins, (int)n_req,
                                (const uint32_t *)d_sorted, (const uint32_t *)d_shift, CCAPS[c], (unsigned char *)d_dp, d_cidx, d_clen, d_cscore, lo, hi);
-            lo = hi + 1;
+            HIPCHK(hipEventRecord(ev[c], cs));
+            HIPCHK(hipStreamWaitEvent(s, ev[c], 0));
         }
     } else {
         static const uint32_t CAPS[5] = { 128, 512, 2048, LF_CHAIN_LDS_MAX, 0 };

@@ -77,3 +77,26 @@ def test_host_introsort_order_matches_std_sort(stages, oracle_lib):
         s = _triples_to_seeds(tr)
         L.lf_sort_seeds_by_qpos(s.ctypes.data, len(s))
         assert np.array_equal(_seeds_to_triples(s.reshape(-1)), orc.sort_seeds(tr)), it
+
+
+def test_read_group_line_like_set_read_group():
+    """lf_params_set_read_group follows set_read_group (src/CommandLineParser.cpp:85-124): escapes, ID field, errors"""
+    import lordfast_amd as la
+    L = la.lib()
+    L.lf_params_set_read_group.argtypes = [C.POINTER(la.Params), C.c_char_p]
+    p = la.default_params()
+    assert L.lf_params_set_read_group(C.byref(p), b"@RG\\tID:grp1\\tSM:x\\\\y") == 0
+    assert p.read_group == b"@RG\tID:grp1\tSM:x\\y" and p.read_group_id == b"grp1"
+    for bad, msg in ((b"RG\\tID:a", b"does not start with @RG"), (b"@RG\tID:a", b"literal <tab>"), (b"@RG\\tSM:a", b"no ID within")):
+        q = la.default_params()
+        assert L.lf_params_set_read_group(C.byref(q), bad) != 0
+        assert msg in L.lf_last_error()
+    assert C.sizeof(la.Params) == C.sizeof(C.c_int) * 6 + 8 * 3 + 4 + 256 + 1000 + 4    # the C struct incl. tail padding
+
+
+def test_clasp_entry_points_need_a_device():
+    import lordfast_amd as la
+    if la.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(la.LfError, match="no gfx950 device"):
+        la.chain_clasp_batch([np.array([[100, 0, 20], [130, 30, 20]], dtype=np.uint32)])
