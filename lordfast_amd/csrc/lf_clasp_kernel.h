@@ -122,14 +122,24 @@ struct lf_clasp_better {
  * LDS-crossbar permutes) */
 typedef hipcub::WarpReduce<lf_clasp_cand, 64> lf_clasp_wreduce;
 
-/* bl_slChainSopRMQ (slchain.c:841-912) for the start point of fragment `cur`; returns the chosen chain or -1.
- * All lanes scan; lane 0 applies the side effects and owns the result. */
+/* per-query scratch of one tree walk: the winners of the canonical nodes, root to leaf (at most ~log2 N + 1) */
+#define LF_CLASP_MAX_NODES 40
+struct lf_clasp_nodes {
+    double pr[LF_CLASP_MAX_NODES], cmp[LF_CLASP_MAX_NODES], nw[LF_CLASP_MAX_NODES];
+    int ix[LF_CLASP_MAX_NODES], tf[LF_CLASP_MAX_NODES], first[LF_CLASP_MAX_NODES];
+    lf_clasp_wreduce::TempStorage wr;
+};
+
+/* bl_slChainSopRMQ (slchain.c:841-912) for the start point of fragment `cur`; returns the chosen chain or -1 (lane 0).
+ * Three phases: (A) every canonical node, root to leaf: strided scan + wavefront arg-max, winner parked in LDS;
+ * (B) lane k evaluates node k's winner -- gap cost, the test of :877 and both score expressions -- all nodes at once;
+ * (C) lane 0 applies the side effects and picks the result in node order, which is all that has to be sequential. */
 template <class R>
 __device__ __forceinline__ int lf_clasp_rmq(const lf_clasp_mem<R> &m, const R *enty, const R *entf, const double *prio,
-                                   int N, uint32_t x, uint32_t y, int cur, int lane, lf_clasp_wreduce::TempStorage *wr_tmp)
+                                   int N, uint32_t x, uint32_t y, int cur, int lane, lf_clasp_nodes *nd)
 {
-    int res = -1; double resprio = -DBL_MAX;
     const int cs = m.fp[cur], cq = m.fq[cur]; const double cscr = (double)m.fl[cur];
+    int K = 0;
     int s = 0, cnt = N;
     while (cnt > 0) {
         int lo, len;
@@ -151,19 +161,29 @@ __device__ __forceinline__ int lf_clasp_rmq(const lf_clasp_mem<R> &m, const R *e
         }
         if (__ballot(ey != LF_CLASP_NONE) == 0) continue;
         lf_clasp_cand cd; cd.pr = pr; cd.ey = ey; cd.ix = ix;
-        cd = lf_clasp_wreduce(*wr_tmp).Reduce(cd, lf_clasp_better());
-        if (lane == 0) {
-            pr = cd.pr; ix = cd.ix;
-            const int tf = (int)entf[ix];
-            const double g = lf_clasp_gsop(cs, cq, m.fp[tf] + m.fl[tf] - 1, m.fq[tf] + m.fl[tf] - 1);
-            if (cscr >= g) {                                                           /* :877 */
-                const int first = m.chain_first[tf];
-                if (m.best_scr[first] < cscr + m.chain_scr[tf] - g) {                  /* :884 */
-                    m.best_scr[first] = m.chain_scr[tf] + (cscr - g);                  /* :890 */
-                    m.best_base[first] = tf; m.best_extra[first] = cur;
-                }
-            }
-            if (pr > resprio) { res = tf; resprio = pr; }                              /* :898 */
+        cd = lf_clasp_wreduce(nd->wr).Reduce(cd, lf_clasp_better());
+        if (lane == 0) { nd->pr[K] = cd.pr; nd->ix[K] = (int)cd.ix; }
+        K++;
+    }
+    if (K == 0) return -1;
+    __syncthreads();
+    if (lane < K) {
+        const int tf = (int)entf[nd->ix[lane]];
+        const double g = lf_clasp_gsop(cs, cq, m.fp[tf] + m.fl[tf] - 1, m.fq[tf] + m.fl[tf] - 1);
+        const double cscr_tf = m.chain_scr[tf];
+        nd->tf[lane] = tf;
+        nd->first[lane] = (cscr >= g) ? m.chain_first[tf] : -1;                        /* :877 */
+        nd->cmp[lane] = cscr + cscr_tf - g;                                            /* :884 */
+        nd->nw[lane] = cscr_tf + (cscr - g);                                           /* :890 */
+    }
+    __syncthreads();
+    int res = -1;
+    if (lane == 0) {
+        double resprio = -DBL_MAX;
+        for (int k = 0; k < K; k++) {
+            const int tf = nd->tf[k], first = nd->first[k];
+            if (first >= 0 && m.best_scr[first] < nd->cmp[k]) { m.best_scr[first] = nd->nw[k]; m.best_base[first] = tf; m.best_extra[first] = cur; }
+            if (nd->pr[k] > resprio) { res = tf; resprio = nd->pr[k]; }                /* :898 */
         }
     }
     return res;
@@ -171,7 +191,7 @@ __device__ __forceinline__ int lf_clasp_rmq(const lf_clasp_mem<R> &m, const R *e
 
 /* bl_slChainSop (slchain.c:668-826) over the cluster of fragments [cb, cb + cm) */
 template <class R>
-__device__ __forceinline__ void lf_clasp_chain_sop(const lf_clasp_mem<R> &m, int cb, int cm, int lane, lf_clasp_wreduce::TempStorage *wr_tmp)
+__device__ __forceinline__ void lf_clasp_chain_sop(const lf_clasp_mem<R> &m, int cb, int cm, int lane, lf_clasp_nodes *wr_tmp)
 {
     const int N = 2 * cm;
     const int xmin = m.fp[cb];
@@ -275,7 +295,7 @@ lf_clasp_kernel(const lf_chain_win *__restrict__ wins, int n_wins, const uint32_
                 uint32_t n_min, uint32_t n_max)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ lf_clasp_wreduce::TempStorage wr_tmp;
+    __shared__ lf_clasp_nodes wr_tmp;
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= n_wins) return;
     const lf_chain_win w = wins[blockIdx.x];
