@@ -297,6 +297,15 @@ lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_s
  * State lives in registers; history layout = the generic kernel's (private, (c-1)*nbk + block).
  * ---------------------------------------------------------------------------------------------- */
 #define LF_WAVE_LDS_T 8192
+/* lane l receives lane l-1's value (lane 0: 0): the horizontal carry of the anti-diagonal sweeps.  DPP wave_shr:1 is a
+ * VALU move; __shfl_up goes through the LDS crossbar (ds_bpermute) and sits on the per-step dependency chain. */
+__device__ __forceinline__ int lf_wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+/* broadcast of a 64-bit value from a lane that is the same for the whole wavefront (v_readlane instead of ds_bpermute) */
+__device__ __forceinline__ uint64_t lf_readlane64(uint64_t v, int src_uniform)
+{
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src_uniform), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src_uniform);
+    return ((uint64_t)hi << 32) | lo;
+}
 template <int KB>
 __global__ void __launch_bounds__(64)
 lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ hist,
@@ -340,7 +349,7 @@ lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs
     int hout_prev = 1;
     const int steps = (int)m + nl - 1;
     for (int s = 0; s < steps; s++) {
-        const int from_left = __shfl_up(hout_prev, 1);
+        const int from_left = lf_wave_shr1(hout_prev);
         const int c = s - lane + 1;
         if (lane < nl && c >= 1 && c <= (int)m) {
             const unsigned char tc = t_lds ? s_t[c - 1] : T.get((uint32_t)(c - 1));
@@ -409,8 +418,8 @@ lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs
         lf_hist_t e; e.pv = 0; e.ph = 0;
         if (col >= 1) e = h[(size_t)(col - 1 + (int)(blk / KB)) * nbk + blk];
         while (r > 0 && c > 0 && ((r - 1) >> 6) == blk && (c0 - c) < 64) {
-            const int src = (int)(c0 - c);
-            const uint64_t pv = __shfl(e.pv, src), ph = __shfl(e.ph, src);
+            const int src = __builtin_amdgcn_readfirstlane((int)(c0 - c));      /* every lane replays the same walk */
+            const uint64_t pv = lf_readlane64(e.pv, src), ph = lf_readlane64(e.ph, src);
             const int bit = (int)((r - 1) & 63);
             uint8_t op;
             if ((pv >> bit) & 1) { op = 1; if (lane == 0) o[w - 1] = op; r--; }
@@ -478,7 +487,7 @@ lf_edlib_group_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     lf_hist_t *h = hist + pr.hist_base;
     int hout_prev = 1;
     for (uint32_t s = 0; s < steps_max; s++) {
-        const int from_left = __shfl_up(hout_prev, 1);
+        const int from_left = lf_wave_shr1(hout_prev);
         const int c = (int)s - gl + 1;
         if ((uint32_t)gl < nbk && c >= 1 && c <= (int)m) {
             const unsigned char tc = t_lds ? my_t[c - 1] : T.get((uint32_t)(c - 1));

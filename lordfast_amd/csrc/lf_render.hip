@@ -41,15 +41,19 @@ __device__ __forceinline__ void lf_put_token(char *dst, uint32_t v, int nd, char
     dst[nd] = c1;
     if (c2) dst[nd + 1] = c2;
 }
+/* exclusive prefix sum over the wavefront + total: rocPRIM's DPP scan (row shifts / broadcasts on the VALU) -- the
+ * shuffle version was six dependent LDS-crossbar permutes per call, two calls per 64-op tile */
 __device__ __forceinline__ uint32_t lf_wave_excl_sum(uint32_t v, uint32_t *total)
 {
-    uint32_t x = v;
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
-    *total = __shfl(x, 63, 64);
-    return x - v;
+    typedef hipcub::WarpScan<uint32_t, 64> scan_t;
+    __shared__ typename scan_t::TempStorage tmp;
+    uint32_t excl, tot;
+    scan_t(tmp).ExclusiveSum(v, excl, tot);
+    *total = tot;
+    return excl;
 }
+/* lane l receives lane l-1's value (lane 0: 0): DPP wave_shr:1 */
+__device__ __forceinline__ int lf_wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ char lf_pac_char(const uint8_t *pac, uint32_t pos, int comp)
 {
     int b = (pac[pos >> 2] >> ((~pos & 3u) << 1)) & 3;
@@ -132,7 +136,7 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
             }
             const int ch = !act ? 0 : (ty == T_I ? 'I' : ty == T_D ? 'D' : 'M');
             /* ---- CIGAR ---- */
-            int pch = __shfl_up(ch, 1, 64); if (lane == 0) pch = c_ch;
+            int pch = lf_wave_shr1(ch); if (lane == 0) pch = c_ch;
             const bool start = act && ch != pch;
             const uint64_t smask = __ballot(start);
             const bool emits = start && pch != 0;
@@ -147,11 +151,11 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
             if (WRITE && emits) lf_put_token(cg + c_out + pos, rl, nd, (c_first && !(emask & below) && pch == 'I') ? 'S' : (char)pch, 0);
             c_out += tot;
             if (emask) c_first = 0;
-            const int lastch = __shfl(ch, (int)cnt - 1, 64);
+            const int lastch = __builtin_amdgcn_readlane(ch, __builtin_amdgcn_readfirstlane((int)cnt - 1));
             if (smask) c_run = cnt - (uint32_t)(63 - __clzll((long long)smask)); else c_run += cnt;
             c_ch = lastch;
             /* ---- MD ---- */
-            int pty = __shfl_up(ty, 1, 64); if (lane == 0) pty = m_last;
+            int pty = lf_wave_shr1(ty); if (lane == 0) pty = m_last;
             const bool isx = act && ty == T_X, isd = act && ty == T_D;
             const bool flush = isx || (isd && pty != T_D);
             const uint64_t eqmask = __ballot(act && ty == T_EQ), fmask = __ballot(flush), nimask = __ballot(act && ty != T_I);
@@ -174,7 +178,7 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
             m_out += mtot;
             if (fmask) { const int p = 63 - __clzll((long long)fmask); m_num = (uint32_t)__popcll(eqmask & ~(~0ull >> (63 - p))); }
             else m_num += (uint32_t)__popcll(eqmask);
-            m_last = __shfl(ty, (int)cnt - 1, 64);
+            m_last = __builtin_amdgcn_readlane(ty, __builtin_amdgcn_readfirstlane((int)cnt - 1));
             tcarry += (uint32_t)__popcll(nimask);
         }
     }
