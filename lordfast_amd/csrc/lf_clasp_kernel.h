@@ -22,6 +22,12 @@
  * What has to be replayed literally is clasp's own quickSort: it is unstable, and the tie order of equal
  * diagonals / equal positions decides the ranks.  Lane 0 sorts the fragment ends, lanes 0-3 the four point orders.
  * All arithmetic is integer or FP64 in the reference's evaluation order (-ffp-contract=off).
+ *
+ * Working set: 136 B per fragment in LDS (16-bit ranks, sort keys aliased with the rank / entry arrays they are dead
+ * before), 200 B in the HBM workspace (32-bit ranks) for windows above LF_CLASP_LDS_MAX fragments.  The kernel is a
+ * template on that choice so that the LDS instantiation addresses LDS directly (ds_read / ds_write, no FLAT).
+ * A tree walk runs in three phases (lf_clasp_rmq): scans + DPP arg-max per node, one lane per node winner for the gap
+ * costs, lane 0 for the ordered side effects.
  */
 #ifndef LF_CLASP_KERNEL_H
 #define LF_CLASP_KERNEL_H
