@@ -20,6 +20,7 @@
 #include <string.h>
 #include <vector>
 #include <numeric>
+#include <limits.h>
 
 struct lf_aln_prob {
     int64_t  qstart, tstart; /* element 0 of query / target: byte index (ASCII buffers) or pac coordinate */
@@ -921,30 +922,48 @@ extern "C" int lfg_colscores(int device, int n, const char *q, const uint64_t *q
 
 /* ------------------------------------------------------------------------------------------------
  * ksw_extend2 (lib/bwa/ksw.c:380-478), clip matrix +2/-16/N=0 (src/LordFAST.cpp:82-85,178-187).
- * Rare branch of the reference (clip / split tests): one lane per problem, H/E rows in HBM.
+ * Rare branch of the reference (clip / split tests), but its problems are long (band 40 / 100, up to thousands of rows).
+ * One wavefront per problem; rows stay sequential, the band of a row (<= 2w + 1 columns) is processed 64 columns at a
+ * time:
+ *   - M(i,j) and E(i,j) depend on the previous row only: one lane per column;
+ *   - F runs along the row:  f(j+1) = max(f(j) - e_ins, max(M(j) - oe_ins, 0)).  With B(l) = t(l) + (l+1) e_ins this is
+ *     f(k) = max(carry, max_{l<k} B(l)) - k e_ins: one exclusive max-scan (DPP) per tile;
+ *   - the row maximum with the reference's tie rule (the LAST column attaining it: `mj = m > h ? mj : j`) is a wave
+ *     max of (h << 32 | j);
+ *   - H(i,j) is stored one column to the right (the reference's eh[j].h = h1 trick): a wave_shr:1 move.
+ * The band trimming, z-drop and maximum bookkeeping are the reference's scalar code on wave-uniform values.
  * ---------------------------------------------------------------------------------------------- */
 struct lf_ksw_prob { uint64_t qoff, toff, ws_off; int32_t qlen, tlen, o_del, e_del, o_ins, e_ins, w, zdrop, h0, id; };
 
+template <bool LDS>
 __global__ void __launch_bounds__(64)
 lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t *__restrict__ qs, const uint8_t *__restrict__ ts,
               int32_t *__restrict__ ws, int32_t *__restrict__ out_score, int32_t *__restrict__ out_qle, int32_t *__restrict__ out_tle, int lds_q)
 {
-    /* one workgroup per problem; the H/E rows live in LDS when the query fits (lds_q), else in the HBM workspace.
-     * The recurrence is sequential along the row (F carries), so one lane walks it; the branch is rare. */
     extern __shared__ __attribute__((aligned(16))) int32_t s_he[];
-    const int gid = blockIdx.x;
-    if (gid >= n_probs || threadIdx.x != 0) return;
+    typedef hipcub::WarpScan<int, 64> scan_t;
+    typedef hipcub::WarpReduce<unsigned long long, 64> red_t;
+    __shared__ typename scan_t::TempStorage scan_tmp;
+    __shared__ typename red_t::TempStorage red_tmp;
+    const int gid = blockIdx.x, lane = threadIdx.x;
+    if (gid >= n_probs) return;
     const lf_ksw_prob pr = probs[gid];
+    if (LDS != (pr.qlen <= lds_q)) return;            /* the other instantiation serves this problem */
     const uint8_t *q = qs + pr.qoff, *t = ts + pr.toff;
     const int qlen = pr.qlen, tlen = pr.tlen, o_del = pr.o_del, e_del = pr.e_del, o_ins = pr.o_ins, e_ins = pr.e_ins;
     const int zdrop = pr.zdrop, h0 = pr.h0;
     int w = pr.w;
-    int32_t *H = (qlen <= lds_q) ? s_he : ws + pr.ws_off, *E = H + qlen + 2;
+    int32_t *H, *E;
+    if (LDS) { H = s_he; E = s_he + qlen + 2; } else { H = ws + pr.ws_off; E = H + qlen + 2; }
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    for (int j = 0; j <= qlen + 1; j++) { H[j] = 0; E[j] = 0; }
-    H[0] = h0;
-    H[1] = h0 > oe_ins ? h0 - oe_ins : 0;
-    for (int j = 2; j <= qlen && H[j - 1] > e_ins; ++j) H[j] = H[j - 1] - e_ins;
+    /* first row (lib/bwa/ksw.c:404-407): h0, h0 - oe_ins, then -e_ins per column while positive */
+    for (int j = lane; j <= qlen + 1; j += 64) {
+        int v = 0;
+        if (j == 0) v = h0;
+        else if (j <= qlen && h0 > oe_ins) { const long long x = (long long)h0 - oe_ins - (long long)(j - 1) * e_ins; v = (j == 1 || x + e_ins > e_ins) ? (int)(x > 0 ? x : 0) : 0; }
+        H[j] = v; E[j] = 0;
+    }
+    __syncthreads();
     int max_ins = (int)((double)(qlen * 2 - o_ins) / e_ins + 1.);
     if (max_ins < 1) max_ins = 1;
     if (w > max_ins) w = max_ins;
@@ -953,43 +972,79 @@ lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t 
     if (w > max_del) w = max_del;
     int mx = h0, max_i = -1, max_j = -1, beg = 0, end = qlen;
     for (int i = 0; i < tlen; ++i) {
-        int f = 0, h1, m = 0, mj = -1, j;
         const int tc = t[i];
         if (beg < i - w) beg = i - w;
         if (end > i + w + 1) end = i + w + 1;
         if (end > qlen) end = qlen;
+        int h1;
         if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
         else h1 = 0;
-        for (j = beg; j < end; ++j) {
-            int M = H[j], e = E[j], h, tt;
-            H[j] = h1;
-            const int qc = q[j];
-            const int sc = (tc > 3 || qc > 3) ? 0 : (tc == qc ? 2 : -16);
-            M = M ? M + sc : 0;
-            h = M > e ? M : e;
-            h = h > f ? h : f;
-            h1 = h;
-            mj = m > h ? mj : j;
-            m = m > h ? m : h;
-            tt = M - oe_del; if (tt < 0) tt = 0;
-            e -= e_del; if (e < tt) e = tt;
-            E[j] = e;
-            tt = M - oe_ins; if (tt < 0) tt = 0;
-            f -= e_ins; if (f < tt) f = tt;
+        int f = 0, m = 0, mj = -1;
+        for (int base = beg; base < end; base += 64) {
+            const int j = base + lane;
+            const bool act = j < end;
+            const int cnt = end - base < 64 ? end - base : 64;
+            int M = 0, e = 0, tins = 0;
+            if (act) {
+                M = H[j]; e = E[j];
+                const int qc = q[j];
+                const int sc = (tc > 3 || qc > 3) ? 0 : (tc == qc ? 2 : -16);
+                M = M ? M + sc : 0;
+                tins = M - oe_ins; if (tins < 0) tins = 0;
+            }
+            /* f entering column base + k: max(carry, max_{l<k} B(l)) - k e_ins */
+            const int Bv = act ? tins + (lane + 1) * e_ins : INT_MIN / 2;
+            int G;
+            scan_t(scan_tmp).ExclusiveScan(Bv, G, f, hipcub::Max());
+            const int fin = G - lane * e_ins;
+            int h = M > e ? M : e;
+            h = h > fin ? h : fin;
+            if (!act) h = 0;
+            /* H(i, j) goes to slot j + 1 of the next row: slot j takes the h of column j - 1 (h1 for the first column) */
+            int hleft = lf_wave_shr1(h); if (lane == 0) hleft = h1;
+            if (act) {
+                H[j] = hleft;
+                int tt = M - oe_del; if (tt < 0) tt = 0;
+                int e2 = e - e_del; if (e2 < tt) e2 = tt;
+                E[j] = e2;
+            }
+            /* row maximum, last column on ties */
+            unsigned long long key = act ? (((unsigned long long)(unsigned)h << 32) | (unsigned)j) : 0ull;
+            key = red_t(red_tmp).Reduce(key, hipcub::Max());
+            const int tm = __builtin_amdgcn_readfirstlane((int)(key >> 32)), tj = __builtin_amdgcn_readfirstlane((int)(key & 0xFFFFFFFFu));
+            if (tm >= m) { m = tm; mj = tj; }
+            /* carries into the next tile */
+            const int last = __builtin_amdgcn_readfirstlane(cnt - 1);
+            h1 = __builtin_amdgcn_readlane(h, last);
+            int fout = fin - e_ins; if (fout < tins) fout = tins;
+            f = __builtin_amdgcn_readlane(fout, last);
         }
-        H[end] = h1; E[end] = 0;
+        if (lane == 0) { H[end] = h1; E[end] = 0; }
+        __syncthreads();
         if (m == 0) break;
         if (m > mx) { mx = m; max_i = i; max_j = mj; }
         else if (zdrop > 0) {
             if (i - max_i > mj - max_j) { if (mx - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
             else { if (mx - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
         }
-        for (j = beg; j < end && H[j] == 0 && E[j] == 0; ++j) {}
-        beg = j;
-        for (j = end; j >= beg && H[j] == 0 && E[j] == 0; --j) {}
-        end = j + 2 < qlen ? j + 2 : qlen;
+        /* trim the band: first / last column of [beg, end] that is not all zero (lib/bwa/ksw.c:462-465) */
+        int nb = end;
+        for (int base = beg; base < end; base += 64) {
+            const int j = base + lane;
+            const unsigned long long nz = __ballot(j < end && (H[j] != 0 || E[j] != 0));
+            if (nz) { nb = base + (__ffsll((long long)nz) - 1); break; }
+        }
+        int ne = nb - 1;
+        for (int top = end; top >= nb; top -= 64) {
+            const int j = top - lane;
+            const unsigned long long nz = __ballot(j >= nb && (H[j] != 0 || E[j] != 0));
+            if (nz) { ne = top - (__ffsll((long long)nz) - 1); break; }
+        }
+        beg = nb;
+        end = ne + 2 < qlen ? ne + 2 : qlen;
+        __syncthreads();
     }
-    out_score[pr.id] = mx; out_qle[pr.id] = max_j + 1; out_tle[pr.id] = max_i + 1;
+    if (lane == 0) { out_score[pr.id] = mx; out_qle[pr.id] = max_j + 1; out_tle[pr.id] = max_i + 1; }
 }
 
 extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff, const uint8_t *t, const uint64_t *toff,
@@ -1026,7 +1081,9 @@ extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff
     int qmax = 0;
     for (int i = 0; i < n; i++) qmax = std::max(qmax, P[i].qlen);
     const int lds_q = std::min(qmax, 6000);
-    hipLaunchKernelGGL(lf_ksw_kernel, dim3((unsigned)n), dim3(64), (size_t)(2 * (lds_q + 2)) * 4, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
+    hipLaunchKernelGGL(lf_ksw_kernel<true>, dim3((unsigned)n), dim3(64), (size_t)(2 * (lds_q + 2)) * 4, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
+                       (const uint8_t *)d_t, d_ws, d_s, d_ql, d_tl, lds_q);
+    if (qmax > lds_q) hipLaunchKernelGGL(lf_ksw_kernel<false>, dim3((unsigned)n), dim3(64), 0, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
                        (const uint8_t *)d_t, d_ws, d_s, d_ql, d_tl, lds_q);
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipMemcpyAsync(score, d_s, (size_t)n * 4, hipMemcpyDeviceToHost, s));
