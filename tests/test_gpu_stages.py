@@ -162,6 +162,19 @@ def test_ksw_golden_and_fuzz(stages, oracle_lib):
             q[rng.integers(0, len(q), size=2)] = 4
         qs.append(q); ts.append(t)
         prms.append((0, 1, 0, 1, 40, 40, len(q)) if it % 2 else (8, 1, 4, 1, 100, 200, len(q)))
+    # long problems with indels: several 64-column tiles per band row, band trimming and z-drop at work, queries beyond
+    # the LDS limit of the kernel (6000) in the HBM-workspace instantiation, small and large h0
+    code = np.zeros(256, dtype=np.uint8); code[ord("C")] = 1; code[ord("G")] = 2; code[ord("T")] = 3
+    for it in range(60):
+        n = int(rng.integers(800, 7500 if it % 6 == 0 else 3000))
+        qa = np.frombuffer(rseq(rng, n), dtype=np.uint8)
+        ta = synth.mutate(qa, float(rng.uniform(0.02, 0.3)), rng)
+        if it % 5 == 0:
+            ta = np.concatenate([ta[:len(ta) // 2], np.frombuffer(rseq(rng, int(rng.integers(50, 400))), dtype=np.uint8), ta[len(ta) // 2:]])
+        q, t = code[qa], code[ta]
+        h0 = len(q) if it % 3 else int(rng.integers(1, 200))
+        qs.append(q); ts.append(t)
+        prms.append((0, 1, 0, 1, 40, 40, h0) if it % 2 else (8, 1, 4, 1, 100, 200, h0))
     res = la.ksw_extend2_batch(qs, ts, prms)
     for i, r in enumerate(res):
-        assert tuple(r) == tuple(orc.ksw_extend2(qs[i], ts[i], *prms[i])), i
+        assert tuple(r) == tuple(orc.ksw_extend2(qs[i], ts[i], *prms[i])), (i, len(qs[i]), len(ts[i]), prms[i])
