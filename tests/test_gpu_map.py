@@ -144,7 +144,8 @@ def big_case(tmp_path_factory, oracle_lib):
     return fa, reads
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(max_map=30), dict(max_map=100), dict(min_anchor_len=17, sampling_count=2000)])
+@pytest.mark.parametrize("kw", [dict(), dict(max_map=30), dict(max_map=100), dict(min_anchor_len=17, sampling_count=2000),
+                                dict(chain_alg=1), dict(chain_alg=1, max_map=30, min_anchor_len=12, sampling_count=500)])
 def test_sam_vs_oracle_big(big_case, oracle_lib, kw):
     import lordfast_amd as la
     fa, reads = big_case
