@@ -220,6 +220,7 @@ def main():
         out_buf = torch.empty(cap, dtype=torch.uint8)
     out_ptr = out_buf.data_ptr()
     fixed_arrays = (la.api._cstr_array(names), la.api._cstr_array(seqs))
+    seq_lens = np.array([len(x) for x in seqs], dtype=np.uint32)          # Read.length of the reference's records
 
     class _Sam:                                                          # head()/len() like api.SamBuffer
         def __init__(self, n):
@@ -234,7 +235,7 @@ def main():
     def step():
         na, sa = fixed_arrays
         t_call = time.perf_counter()
-        ln, st = lf.map_batch_into(names, seqs, out_ptr, cap_one, params=params, name_arr=na, seq_arr=sa)
+        ln, st = lf.map_batch_into(names, seqs, out_ptr, cap_one, params=params, name_arr=na, seq_arr=sa, seq_lens=seq_lens)
         st["ms_python_call"] = (time.perf_counter() - t_call) * 1e3
         if dist and args.single_output:                      # optional: one SAM stream on rank 0, input order
             ln = lfd.gather_sam_p2p(dist, torch, out_buf, ln, rdev)

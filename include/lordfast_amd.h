@@ -195,6 +195,11 @@ int  lf_map_file(const lf_index_t *idx, const lf_params_t *p, const char *reads_
 int  lf_map_batch_into(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,
                        const char *const *seqs, const char *const *quals, char *out, size_t out_cap, size_t *sam_len,
                        lf_stats_t *stats);
+/* same with seq_lens[i] == strlen(seqs[i]) supplied by the caller (the reference's Read records carry `length`,
+ * src/Reads.h): saves the library one pass over the bases.  The strings must still be NUL-terminated. */
+int  lf_map_batch_into_lens(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,
+                            const char *const *seqs, const char *const *quals, const uint32_t *seq_lens,
+                            char *out, size_t out_cap, size_t *sam_len, lf_stats_t *stats);
 char *lf_sam_header(const lf_index_t *idx, const lf_params_t *p, const char *cmdline); /* src/BWT.cpp:668-681 */
 void lf_free(void *ptr);
 

@@ -272,7 +272,7 @@ class LordFast:
         return buf, st.as_dict()
 
     def map_batch_into(self, names, seqs, out_ptr: int, out_cap: int, quals=None, params: Params | None = None,
-                       name_arr=None, seq_arr=None):
+                       name_arr=None, seq_arr=None, seq_lens=None):
         """SAM text into a caller-owned buffer (address + capacity), e.g. a pinned torch tensor reused across batches.
         -> (length, stats).  name_arr / seq_arr: pre-built ctypes arrays (saves rebuilding them per call)."""
         p = params or default_params()
@@ -281,6 +281,13 @@ class LordFast:
         q = _cstr_array(quals) if quals is not None else None
         na = name_arr if name_arr is not None else _cstr_array(names)
         sa = seq_arr if seq_arr is not None else _cstr_array(seqs)
+        if seq_lens is not None:              # uint32 numpy array of len(seqs[i]): the library skips its strlen pass
+            sl = np.ascontiguousarray(seq_lens, dtype=np.uint32)
+            self.L.lf_map_batch_into_lens.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Stats)]
+            _check(self.L.lf_map_batch_into_lens(self.h, C.byref(p), len(names), na, sa, q, sl.ctypes.data, C.c_void_p(out_ptr), out_cap,
+                                                 C.byref(ln), C.byref(st)), "lf_map_batch_into_lens")
+            return ln.value, st.as_dict()
         _check(self.L.lf_map_batch_into(self.h, C.byref(p), len(names), na, sa, q, C.c_void_p(out_ptr), out_cap,
                                         C.byref(ln), C.byref(st)), "lf_map_batch_into")
         return ln.value, st.as_dict()

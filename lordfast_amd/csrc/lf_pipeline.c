@@ -1949,7 +1949,7 @@ static void *lane_main(void *arg_)
 }
 
 static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, const char *const *names,
-                          const char *const *seqs, const char *const *quals, char *ext_buf, size_t ext_cap,
+                          const char *const *seqs, const char *const *quals, const uint32_t *seq_lens, char *ext_buf, size_t ext_cap,
                           char **sam, size_t *sam_len, lf_stats_t *stats)
 {
     if (!ix || !p || n < 0 || (!sam && !ext_buf)) { lf_set_error("lf_map_batch: bad argument"); return LF_ERR_ARG; }
@@ -2004,7 +2004,8 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
     {   /* read lengths once, in parallel; one allocation for the SAM text (~2 x bases + per-record overhead) */
         ctx_t c0; memset(&c0, 0, sizeof c0);
         c0.n_threads = nw + n_lanes; c0.lane = 0; c0.len_seqs = seqs; c0.len_out = lens;
-        parallel_for(&c0, n, phase_strlen);
+        if (seq_lens) memcpy(lens, seq_lens, (size_t)n * 4);          /* the caller knows them (Read.length, src/Reads.h): no pass over the bases */
+        else parallel_for(&c0, n, phase_strlen);
         uint64_t est = 4096;
         for (int i = 0; i < n; i++) est += 2 * (uint64_t)lens[i] + 640;
         if (!ext_buf) str_room(&B.all, est + est / 8);
@@ -2055,7 +2056,7 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
 int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *const *names,
                  const char *const *seqs, const char *const *quals, char **sam, size_t *sam_len, lf_stats_t *stats)
 {
-    return map_batch_core(ix, p, n, names, seqs, quals, NULL, 0, sam, sam_len, stats);
+    return map_batch_core(ix, p, n, names, seqs, quals, NULL, NULL, 0, sam, sam_len, stats);
 }
 
 /* same, into a caller-owned buffer (e.g. pinned and reused across batches: a fresh multi-GB malloc per batch costs
@@ -2065,7 +2066,18 @@ int lf_map_batch_into(const lf_index_t *ix, const lf_params_t *p, int n, const c
                       const char *const *seqs, const char *const *quals, char *out, size_t out_cap, size_t *sam_len, lf_stats_t *stats)
 {
     if (!out || out_cap < 2) { lf_set_error("lf_map_batch_into: no output buffer"); return LF_ERR_ARG; }
-    return map_batch_core(ix, p, n, names, seqs, quals, out, out_cap, NULL, sam_len, stats);
+    return map_batch_core(ix, p, n, names, seqs, quals, NULL, out, out_cap, NULL, sam_len, stats);
+}
+
+/* same with the read lengths supplied (seq_lens[i] == strlen(seqs[i]); the strings stay NUL-terminated): the reference's
+ * Read records carry `length` (src/Reads.h), so its callers never measure a read twice either */
+int lf_map_batch_into_lens(const lf_index_t *ix, const lf_params_t *p, int n, const char *const *names,
+                           const char *const *seqs, const char *const *quals, const uint32_t *seq_lens,
+                           char *out, size_t out_cap, size_t *sam_len, lf_stats_t *stats)
+{
+    if (!out || out_cap < 2) { lf_set_error("lf_map_batch_into_lens: no output buffer"); return LF_ERR_ARG; }
+    if (!seq_lens && n > 0) { lf_set_error("lf_map_batch_into_lens: no lengths"); return LF_ERR_ARG; }
+    return map_batch_core(ix, p, n, names, seqs, quals, seq_lens, out, out_cap, NULL, sam_len, stats);
 }
 
 /* printSamHeader (src/BWT.cpp:668-681) */

@@ -81,6 +81,9 @@ def test_map_batch_into_caller_buffer(lf, golden_reads):
     assert ln == len(exp) and buf[:ln].tobytes() == exp
     ln2, _ = lf.map_batch_into(names, seqs, buf.ctypes.data, buf.size)            # buffer reuse
     assert buf[:ln2].tobytes() == exp
+    buf[:] = 0                                                                    # lf_map_batch_into_lens: lengths supplied
+    ln3, _ = lf.map_batch_into(names, seqs, buf.ctypes.data, buf.size, seq_lens=np.array([len(x) for x in seqs], dtype=np.uint32))
+    assert ln3 == len(exp) and buf[:ln3].tobytes() == exp
     small = np.zeros(len(exp) // 2, dtype=np.uint8)
     with pytest.raises(RuntimeError, match="too small"):
         lf.map_batch_into(names, seqs, small.ctypes.data, small.size)
