@@ -283,6 +283,8 @@ class LordFast:
         sa = seq_arr if seq_arr is not None else _cstr_array(seqs)
         if seq_lens is not None:              # uint32 numpy array of len(seqs[i]): the library skips its strlen pass
             sl = np.ascontiguousarray(seq_lens, dtype=np.uint32)
+            if sl.shape != (len(names),):
+                raise LfError(f"seq_lens has shape {sl.shape}, expected ({len(names)},)")
             self.L.lf_map_batch_into_lens.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Stats)]
             _check(self.L.lf_map_batch_into_lens(self.h, C.byref(p), len(names), na, sa, q, sl.ctypes.data, C.c_void_p(out_ptr), out_cap,

@@ -98,6 +98,9 @@ int main(int argc, char *argv[])
     if (P.min_anchor_len < 12 || P.min_anchor_len > 20) { fprintf(stderr, "[ERROR] (parseCommandLine) -k/--minAnchorLen requires an argument in [12..20]\n"); return EXIT_FAILURE; }
     if (P.sampling_count <= 0) { fprintf(stderr, "[ERROR] (parseCommandLine) -c/--anchorCount requires a positive integer argument\n"); return EXIT_FAILURE; }
     if (P.max_map <= 0) { fprintf(stderr, "[ERROR] (parseCommandLine) -n/--numMap requires a positive integer argument\n"); return EXIT_FAILURE; }
+    /* -n 1 divides by zero in the reference's MAPQ formula (src/LordFAST.cpp:326); refused here, at parse
+     * time, instead of after the index has been loaded */
+    if (searching && P.max_map < 2) { fprintf(stderr, "[ERROR] (parseCommandLine) -n/--numMap 1 is not supported (the reference's MAPQ formula divides by numMap - 1); use -n 2 or more\n"); return EXIT_FAILURE; }
     if (P.max_ref_hits <= 0) { fprintf(stderr, "[ERROR] (parseCommandLine) -m/--maxRefHit requires a positive integer argument\n"); return EXIT_FAILURE; }
     for (int i = 0; i < argc; i++) {               /* opt_commandAll: every argument followed by a blank (:303-307) */
         if (strlen(cmdline) + strlen(argv[i]) + 2 >= sizeof cmdline) break;
@@ -110,7 +113,8 @@ int main(int argc, char *argv[])
         if (lf_index_build(ref_file, device) != LF_OK) { fprintf(stderr, "[ERROR] (bwt_index) %s\n", lf_last_error()); return EXIT_FAILURE; }
         return EXIT_SUCCESS;
     }
-    fprintf(stderr, "[NOTE] number of threads: %d\n", P.threads);
+    /* 0 / out of range = all CPUs (src/CommandLineParser.cpp:181-185); the NOTE prints the resolved count (:296) */
+    fprintf(stderr, "[NOTE] number of threads: %d\n", P.threads > 0 ? P.threads : (int)sysconf(_SC_NPROCESSORS_ONLN));
     {   /* bwt_load builds the index first when <ref>.bwt is missing (src/BWT.cpp:203-208) */
         char path[4096]; snprintf(path, sizeof path, "%s.bwt", ref_file);
         if (access(path, R_OK) != 0) {

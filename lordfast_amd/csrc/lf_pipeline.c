@@ -44,6 +44,7 @@ void lf_sort_seeds_by_qpos(Seed_t *s, long n);
 #define SPLIT_SIM   0.40
 #define REVERSE_SIM 0.60
 
+#define LF_RC_SPLIT 100        /* internal: map_chunk wants its chunk cut in two (too many seed hits for one vote sort) */
 static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
 /* ---------------------------------------------------------------- small containers */
@@ -245,6 +246,7 @@ typedef struct ctx {
     int lazy;                       /* paths leave the edlib kernels with unclassified diagonal moves (resolved by the renderer) */
     int host_vote;                  /* LF_HOST_VOTE=1: vote / select / sort on the host from copied-back hits (cross-check) */
     lfg_vc_t vc;                    /* device path: modes, requests and chains of this chunk */
+    uint64_t max_chunk_hits;        /* more seed hits than this in one chunk: map_chunk asks for a split (LF_RC_SPLIT) */
     int host_cigar;                 /* LF_HOST_CIGAR=1: build CIGAR / MD on the host from copied-back paths (cross-check) */
     char *rtext; uint64_t *roffs; int *rrbase;      /* rendered text, per-record offsets, first record of each worker */
     /* output assembly */
@@ -1557,6 +1559,9 @@ static int map_chunk(ctx_t *cx)
             tmark(cx, "SEED");
             if (getenv("LF_TIMING")) fprintf(stderr, "[lf] lfg_seed %.1f ms (search %.1f locate %.1f), %llu hits\n", now_ms() - tc0, hits.ms_search, hits.ms_locate, (unsigned long long)hits.n_hits);
             if (rc != LF_OK) { free(map); return rc; }
+            /* the vote stage sorts 2 keys per hit with 31-bit indices: a chunk above the limit is cut in two by the
+             * caller and mapped again (the reference has no such limit; it must stay an implementation detail) */
+            if (hits.n_hits >= cx->max_chunk_hits && n > 1) { free(map); cx->seed_map = NULL; return LF_RC_SPLIT; }
             st->n_seeds += hits.n_hits; st->n_cache += hits.counters[0]; st->n_occblk += hits.counters[1]; st->n_sa += hits.counters[2]; st->n_readbytes += hits.counters[3];
             st->ms_k_search += hits.ms_search; st->ms_k_accept += hits.ms_accept; st->ms_k_locate += hits.ms_locate;
             st->search_launches++; st->locate_launches++;
@@ -1859,7 +1864,7 @@ typedef struct {
     const lf_index_t *ix; const lf_params_t *p;
     const char *const *names, *const *seqs, *const *quals; const uint32_t *lens;
     int slots;                                  /* per-worker scratch slots = pool workers + 2 drivers */
-    chunk_t *chunks; int n_chunks; volatile int next_chunk;
+    chunk_t *chunks; int n_chunks, n_chunks0; volatile int next_chunk;   /* n_chunks0: entries cut up front; n_chunks grows when a lane cuts a chunk */
     pthread_mutex_t mu; pthread_cond_t cv;      /* chunk sizes become known in any order */
     pthread_rwlock_t grow;                      /* writers of SAM text hold it shared; growing the buffer exclusive */
     int host_cigar, host_vote; str_t all; int fixed_out;                   /* fixed_out: caller-provided buffer, never reallocated */
@@ -1887,36 +1892,80 @@ static void *lane_main(void *arg_)
     lfg_set_lane(lane);
     const long long lane_c0 = g_phase_on ? thread_cpu_ns() : 0;
     lf_stats_t *st = &B->st[lane];
+    uint64_t max_hits = 1ull << 30;
+    if (getenv("LF_MAX_CHUNK_HITS")) { max_hits = strtoull(getenv("LF_MAX_CHUNK_HITS"), NULL, 10); if (max_hits < 1) max_hits = 1; }   /* test hook */
+    int todo[64], n_todo = 0;                       /* second halves of chunks this lane had to cut */
     for (;;) {
-        const int k = __sync_fetch_and_add(&B->next_chunk, 1);
-        if (k >= B->n_chunks || B->rc != LF_OK) break;
+        int k;
+        if (n_todo > 0) k = todo[--n_todo];
+        else {
+            k = __sync_fetch_and_add(&B->next_chunk, 1);
+            if (k >= B->n_chunks0) break;
+        }
         chunk_t *C = &B->chunks[k];
+        if (B->rc != LF_OK) {
+            /* another lane failed after this chunk was claimed: publish it as empty, or a lane that claimed a later chunk
+             * just before the error would wait for this chunk's size forever */
+            pthread_mutex_lock(&B->mu);
+            C->size = 0; C->sized = 1;
+            pthread_cond_broadcast(&B->cv);
+            pthread_mutex_unlock(&B->mu);
+            continue;                               /* drain the remaining chunk ids the same way */
+        }
         ctx_t cx; memset(&cx, 0, sizeof cx);
         cx.ix = B->ix; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane]; cx.host_cigar = B->host_cigar; cx.host_vote = B->host_vote; cx.lazy = !B->host_cigar && !getenv("LF_NO_LAZY");
+        cx.max_chunk_hits = max_hits;
         cx.n_reads = C->i1 - C->i0;
         cx.reads = (rd_t *)calloc((size_t)cx.n_reads, sizeof(rd_t));
+        uint64_t chunk_bases = 0;
         for (int i = C->i0; i < C->i1; i++) {
             rd_t *r = &cx.reads[i - C->i0];
             r->name = B->names[i]; r->seq = B->seqs[i]; r->len = B->lens[i];
             r->isFq = (B->quals && B->quals[i] && B->quals[i][0]);
             r->qual = r->isFq ? B->quals[i] : "*";
-            st->n_bases += r->len;
+            chunk_bases += r->len;
         }
-        st->n_reads += (uint64_t)cx.n_reads;
         double tch = now_ms();
         int rc = map_chunk(&cx);
+        if (rc == LF_RC_SPLIT) {
+            /* cut the chunk: this entry keeps the first half, the second half becomes a new entry that this lane maps
+             * next.  The new entry is registered before the first half publishes its size, so every chunk behind it
+             * sees it when it adds up its base offset. */
+            chunk_free(&cx); free(cx.reads);
+            if (n_todo >= 63) { snprintf(B->err, sizeof B->err, "lf_map_batch: a chunk could not be cut below the seed-hit limit"); B->rc = LF_ERR_ARG; n_todo = 0; todo[n_todo++] = k; continue; }
+            pthread_mutex_lock(&B->mu);
+            const int mid = C->i0 + (C->i1 - C->i0) / 2, nk = B->n_chunks++;
+            B->chunks[nk].i0 = mid; B->chunks[nk].i1 = C->i1; B->chunks[nk].size = 0; B->chunks[nk].sized = 0;
+            C->i1 = mid;
+            pthread_mutex_unlock(&B->mu);
+            if (timing) fprintf(stderr, "[lf] lane %d chunk %d: too many seed hits, cut at read %d\n", lane, k, mid);
+            todo[n_todo++] = nk; todo[n_todo++] = k;    /* first half first */
+            continue;
+        }
+        st->n_bases += chunk_bases;
+        st->n_reads += (uint64_t)cx.n_reads;
         if (timing) fprintf(stderr, "[lf] lane %d chunk %d (%d reads): map_chunk %.1f ms\n", lane, k, cx.n_reads, now_ms() - tch);
         uint64_t tot = 0, *ooff = NULL;
         if (rc == LF_OK) {
             ooff = (uint64_t *)malloc(((size_t)cx.n_reads + 1) * 8);
             for (int i = 0; i < cx.n_reads; i++) { ooff[i] = tot; tot += cx.reads[i].out.n; }
         } else { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = rc; }
-        /* publish this chunk's size, then wait for the sizes of all earlier chunks: base offset of our text */
+        /* publish this chunk's size, then wait for the sizes of all chunks of earlier reads: base offset of our text.
+         * (entries can be added while we wait: rescan after every wake-up) */
         pthread_mutex_lock(&B->mu);
         C->size = tot; C->sized = 1;
         pthread_cond_broadcast(&B->cv);
-        uint64_t base = 0;
-        for (int j = 0; j < k; j++) { while (!B->chunks[j].sized) pthread_cond_wait(&B->cv, &B->mu); base += B->chunks[j].size; }
+        uint64_t base;
+        for (;;) {
+            int waiting = 0; base = 0;
+            for (int j = 0; j < B->n_chunks; j++) {
+                if (B->chunks[j].i1 > C->i0) continue;
+                if (!B->chunks[j].sized) { waiting = 1; break; }
+                base += B->chunks[j].size;
+            }
+            if (!waiting) break;
+            pthread_cond_wait(&B->cv, &B->mu);
+        }
         pthread_mutex_unlock(&B->mu);
         if (rc == LF_OK && B->rc == LF_OK) {
             tch = now_ms();
@@ -2004,7 +2053,17 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
     {   /* read lengths once, in parallel; one allocation for the SAM text (~2 x bases + per-record overhead) */
         ctx_t c0; memset(&c0, 0, sizeof c0);
         c0.n_threads = nw + n_lanes; c0.lane = 0; c0.len_seqs = seqs; c0.len_out = lens;
-        if (seq_lens) memcpy(lens, seq_lens, (size_t)n * 4);          /* the caller knows them (Read.length, src/Reads.h): no pass over the bases */
+        if (seq_lens) {                                               /* the caller knows them (Read.length, src/Reads.h): no pass over the bases */
+            memcpy(lens, seq_lens, (size_t)n * 4);
+            /* a wrong length would make the device read past a string: one byte per read is checked */
+            for (int i = 0; i < n; i++) if (seqs[i][lens[i]] != 0 || (lens[i] > 0 && seqs[i][lens[i] - 1] == 0)) {
+                lf_set_error("lf_map_batch_into_lens: seq_lens[%d] = %u is not the length of seqs[%d]", i, lens[i], i);
+                free(lens); pthread_rwlock_destroy(&B.grow); pthread_mutex_destroy(&B.mu); pthread_cond_destroy(&B.cv);
+                if (!ext_buf) free(B.all.s);
+                pthread_mutex_unlock(&g_map_lock);
+                return LF_ERR_ARG;
+            }
+        }
         else parallel_for(&c0, n, phase_strlen);
         uint64_t est = 4096;
         for (int i = 0; i < n; i++) est += 2 * (uint64_t)lens[i] + 640;
@@ -2023,6 +2082,8 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
         int want = (n + 3 * n_lanes - 1) / (3 * n_lanes); if (want < 1024) want = 1024;
         if (want < CHUNK_READS) CHUNK_READS = want;
     }
+    /* reads x sampling positions is a 31-bit index in the seed stage */
+    { const long long cap = (1ll << 30) / (p->sampling_count > 0 ? p->sampling_count : 1); if (cap < CHUNK_READS) CHUNK_READS = cap < 1 ? 1 : (int)cap; }
     B.chunks = (chunk_t *)calloc((size_t)n + 1, sizeof(chunk_t));
     for (int i0 = 0; i0 < n; ) {
         int i1 = i0; uint64_t bases = 0;
@@ -2030,6 +2091,7 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
         B.chunks[B.n_chunks].i0 = i0; B.chunks[B.n_chunks].i1 = i1; B.n_chunks++;
         i0 = i1;
     }
+    B.n_chunks0 = B.n_chunks;
     void *la[LF_MAX_LANES][2]; pthread_t lt[LF_MAX_LANES]; int have[LF_MAX_LANES] = { 0 };
     for (int l = 0; l < LF_MAX_LANES; l++) { la[l][0] = &B; la[l][1] = (void *)(intptr_t)l; }
     for (int l = 1; l < n_lanes && l < B.n_chunks; l++) have[l] = pthread_create(&lt[l], NULL, lane_main, la[l]) == 0;

@@ -256,3 +256,18 @@ def test_sam_lowercase_and_n_bases(lf, oracle, golden_reads):
     sam, _ = lf.map_batch(out_names, out_seqs)
     exp = oracle.map_batch(out_names, out_seqs)
     assert sam == exp, first_diff(sam, exp)
+
+
+@pytest.mark.parametrize("limit,lanes", [(3000, 8), (20000, 2), (1, 4)])
+def test_chunk_is_cut_when_it_has_too_many_seed_hits(lf, golden_reads, monkeypatch, limit, lanes):
+    """The vote sort's 2^30-hit limit per chunk is an implementation detail (the reference has none): a chunk above it is
+    cut in two and mapped again (LF_MAX_CHUNK_HITS is the test hook).  Same records, same order, any number of lanes."""
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    monkeypatch.setenv("LF_MAX_CHUNK_HITS", str(limit))
+    monkeypatch.setenv("LF_LANES", str(lanes))
+    monkeypatch.setenv("LF_CHUNK_READS", "16")
+    sam, st = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS["default"]))
+    exp = golden_sam("default")
+    assert sam == exp, first_diff(sam, exp)
+    assert st["n_reads"] == len(seqs)
