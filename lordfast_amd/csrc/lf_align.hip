@@ -4,15 +4,15 @@
  * Reference replaced: edlibAlign (lib/edlib/edlib.cpp:101-221) with config {k=-1, NW|SHW, PATH}, and
  * ksw_extend2 (lib/bwa/ksw.c:380-478).  Integer only; results bit-identical.
  *
- * edlib kernel: Myers/Hyyro bit-vector DP, 64 query rows per 64-bit word, ONE LANE PER PROBLEM (the DP of
- * one problem is a dependent chain; parallelism comes from the ~10^2 independent gap problems per read).
- * Problems are binned by ceil(n/64) into register-resident classes NB = 1,2,4,8 (template) and sorted by
- * target length so that the 64 lanes of a wave run near-equal trip counts.  Per column and block the lane
- * stores two words -- Pv (vertical +1) and Ph (horizontal +1) -- in a wave-transposed history in HBM
- * (entry e of lane l at base + (e*64 + l)*16: every wave store is one contiguous 1 KiB line).  Traceback
- * needs only those two bits per cell: Up if Pv, else Left if Ph, else Diagonal (match iff bytes equal),
- * which is edlib's move priority (lib/edlib/edlib.cpp:950,984,1015).  No banding: the Ukkonen band of
- * the reference only removes cells that cannot be on an optimal path.
+ * edlib kernels: Myers/Hyyro bit-vector DP, 64 query rows per 64-bit word.  Problems are binned by ceil(n/64):
+ * ONE LANE PER PROBLEM with NB = 1,2,3,4,6,8 register-resident blocks for n <= 512 (the ~10^2 gap problems per read
+ * are what fills the lanes), G = 16 / 32 / 64 lanes per problem sweeping the matrix as an anti-diagonal above that,
+ * with edlib's Hirschberg recursion on the device for problems over its 1 MiB traceback switch.  Traceback needs two
+ * bits per cell -- Pv (vertical +1 => Up) and Ph (horizontal +1 => Left), else Diagonal (match iff bytes equal), which
+ * is edlib's move priority (lib/edlib/edlib.cpp:950,984,1015) -- and gets them by RECOMPUTING tiles from checkpoints
+ * into LDS instead of streaming them through HBM (see "TRACEBACK WITHOUT A HISTORY STREAM" below).  No banding: the
+ * Ukkonen band of the reference only removes cells that cannot be on an optimal path, and a lane (or a group of
+ * lanes) that skips out-of-band blocks saves no time, because its neighbours in the wavefront do not.
  */
 #include <hipcub/hipcub.hpp>
 #include "lf_gpu_common.h"
@@ -88,15 +88,94 @@ __device__ __forceinline__ uint64_t lf_eq_mask(unsigned char tc, uint64_t lo, ui
 /* ------------------------------------------------------------------------------------------------
  * register-resident classes: NB blocks per column
  * ---------------------------------------------------------------------------------------------- */
+
+/* edlib's own leaf / Hirschberg switch (lib/edlib/edlib.cpp:1117-1119), callable on the device */
+__host__ __device__ __forceinline__ bool lf_leaf(int64_t n, int64_t m) { return 20LL * ((n + 63) / 64) * m + 8LL * m < 1024 * 1024; }
+/* ================================================================================================
+ * TRACEBACK WITHOUT A HISTORY STREAM
+ *
+ * Round 1 wrote two bits per DP cell (Pv, Ph: 16 B per column and 64-row block) to HBM and read them back:
+ * 140 GB per 100 k reads for 4.4 GB of algorithmic bytes.  Now the forward pass keeps only CHECKPOINTS -- the
+ * bit-vector state (Pv, Mv) of every block every K columns (lane classes) or every K sweep steps (group / wave
+ * classes) -- and the traceback walks the matrix tile by tile from the end: the tile's K columns (steps) are
+ * recomputed from the checkpoint in front of it, their (Pv, Ph) words go to LDS, the path is followed through
+ * the tile, then the next tile to the left.  HBM sees 1/K of the old stream, the DP work doubles (integer ALU,
+ * of which the old kernels used ~5 %), results are identical: the same cells are visited with the same
+ * Up -> Left -> Diagonal priority (lib/edlib/edlib.cpp:950,984,1015).
+ * ================================================================================================ */
+
+#define LF_LANE_K   8        /* lane classes: columns per tile (tile in LDS: K x W blocks x 64 lanes x 16 B) */
+
+__device__ __forceinline__ uint32_t lf_wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(v, o); v = x > v ? x : v; }
+    return v;
+}
+__device__ __forceinline__ int lf_wave_max_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(v, o); v = x > v ? x : v; }
+    return v;
+}
+
+/* ops leave in 8-byte words: bytes are collected in `acc` and stored when the (descending) address reaches an 8-byte
+ * boundary; only the bytes above the first boundary and below the last one are single-byte stores (the neighbouring
+ * problems' regions start right there).  `store` = this lane owns the output. */
+struct lf_emitter {
+    uint8_t *o; uint32_t w; uint64_t acc; bool packed, store;
+    __device__ __forceinline__ void init(uint8_t *base, uint32_t cap, bool st) { o = base; w = cap; acc = 0; packed = false; store = st; }
+    __device__ __forceinline__ void put(uint8_t op)
+    {
+        --w;
+        const uintptr_t A = (uintptr_t)(o + w);
+        if (!packed) { if (store) o[w] = op; packed = (A & 7) == 0; return; }
+        acc |= (uint64_t)op << ((A & 7) * 8);
+        if ((A & 7) == 0) { if (store) *reinterpret_cast<uint64_t *>(o + w) = acc; acc = 0; }
+    }
+    __device__ __forceinline__ void flush()
+    {   /* bytes collected above the last boundary reached; the collector stays usable (the next put() is byte-wise) */
+        if (packed) {
+            const uintptr_t A = (uintptr_t)(o + w);
+            if (store) for (uintptr_t x = A; (x & 7) != 0; x++) *reinterpret_cast<uint8_t *>(x) = (uint8_t)(acc >> ((x & 7) * 8));
+        }
+        acc = 0; packed = false;
+    }
+};
+
+/* Eq mask with the query given by a functor (sub-problems of the Hirschberg recursion walk offset / reversed strings) */
+template <class QG>
+__device__ __forceinline__ uint64_t lf_eq_mask_f(unsigned char tc, uint64_t lo, uint64_t hi, uint64_t valid, const QG &qget, uint32_t n, uint32_t blk)
+{
+    int c;
+    switch (tc) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break; default: c = -1; }
+    if (c >= 0) {
+        const uint64_t slo = (c & 1) ? ~0ull : 0ull, shi = (c & 2) ? ~0ull : 0ull;
+        return ~((lo ^ slo) | (hi ^ shi)) & valid;
+    }
+    uint64_t e = 0;
+    for (uint32_t i = 0; i < 64; i++) {
+        const uint32_t r = blk * 64 + i;
+        if (r < n && qget(r) == tc) e |= 1ull << i;
+    }
+    return e;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * register-resident classes: ONE LANE PER PROBLEM, NB blocks per column (n <= 64 NB)
+ * ---------------------------------------------------------------------------------------------- */
 template <int NB>
 __global__ void __launch_bounds__(64)
-lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ hist, uint8_t *__restrict__ ops,
+lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ ckpt, uint8_t *__restrict__ ops,
                 int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
 {
+    constexpr int K = LF_LANE_K;
+    constexpr int W = NB < 2 ? 1 : 2;               /* blocks of a tile kept in LDS: the path's block and the one above */
+    __shared__ lf_hist_t s_tile[K * W * 64];
     const int gid = blockIdx.x * 64 + threadIdx.x;
     const int lane = threadIdx.x;
-    if (gid >= n_probs) return;
-    const lf_aln_prob pr = probs[gid];
+    const bool live = gid < n_probs;
+    const lf_aln_prob pr = probs[live ? gid : n_probs - 1];      /* a dead lane shadows the last problem and stores nothing */
     const lf_qacc Q(S.q, pr.qstart, pr.flags); const lf_tacc T(S.t, S.pac, pr.tstart, pr.flags);
     const bool lazy = (pr.flags & LF_F_LAZYX) != 0;      /* diagonal moves are not classified here (lf_render_kernel does it) */
     const uint32_t n = pr.n, m = pr.m;
@@ -113,15 +192,14 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
     /* SHW (lib/edlib/edlib.cpp:583-618): min over prefixes, smallest on ties; the empty prefix only exists
      * through the wildcard padding of the last block, i.e. when n % 64 != 0 */
     int best = (n & 63) ? (int)n : 0x7fffffff, best_c = 0;
-    lf_hist_t *h = hist + pr.hist_base + lane;
+    lf_hist_t *ck = ckpt + pr.hist_base + lane;     /* wave-transposed: checkpoint (j, block b) of lane l at ((j * NB + b) * 64 + l) */
     const bool want_path = pr.task == LF_TASK_PATH;
 
     /* The blocks of one column depend on each other through the horizontal carry, and a block depends on itself one
      * column earlier: one lane alone is a single dependent chain.  Walking the lane's OWN blocks as an anti-diagonal
      * (time step t: block b works on column t - b, taking the carry block b-1 produced one time step earlier) makes
-     * the NB block steps of a time step independent, so the VALU pipeline sees NB-way ILP per lane even at the 2-4
-     * waves/SIMD these register-heavy classes get.  Blocks above the problem's last one (padding of the size class)
-     * are neither computed nor stored. */
+     * the NB block steps of a time step independent, so the VALU pipeline sees NB-way ILP per lane.  Blocks above the
+     * problem's last one (padding of the size class) are not computed. */
     int hout[NB]; unsigned char win[NB];
 #pragma unroll
     for (int b = 0; b < NB; b++) { hout[b] = 0; win[b] = 0; }
@@ -150,73 +228,95 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
                         score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
                         if (score < best) { best = score; best_c = c; }
                     }
-                    if (want_path) { lf_hist_t e; e.pv = Pv[b]; e.ph = ph; h[((size_t)(c - 1) * NB + b) * 64] = e; }
+                    /* checkpoint: the state after every K-th column (one 1 KiB line per wave, block and checkpoint) */
+                    if (want_path && live && (c & (K - 1)) == 0) { lf_hist_t e; e.pv = Pv[b]; e.ph = Mv[b]; ck[((size_t)(c / K - 1) * NB + b) * 64] = e; }
                 }
             }
         }
     }
     int ed, tl;
     if (pr.mode == 0) { ed = score; tl = (int)m; } else { ed = best; tl = best_c; }
-    out_ed[pr.id] = ed;
-    out_end[pr.id] = tl - 1;
-    if (!want_path) { out_len[pr.id] = 0; return; }
+    if (live) { out_ed[pr.id] = ed; out_end[pr.id] = tl - 1; }
+    if (!__any(want_path)) { if (live) out_len[pr.id] = 0; return; }
 
     /* traceback from (n, tl); ops written backwards from the end of the region (they stay end-aligned).
-     * The 64 lanes walk their paths COLUMN-LOCKSTEP: in iteration cc every lane whose path is in column cc makes all of
-     * its moves there (any Up moves, then one Left or Diagonal).  Problems of a wave are sorted by target length and
-     * their paths hug the diagonal, so in one iteration the lanes read the same few 1 KiB history rows (entry index
-     * (cc-1)*NB + block): the wave-transposed rows are fetched whole instead of 16 bytes per 128-byte line. */
-    __shared__ uint32_t s_cmax;
-    s_cmax = 0;                          /* every live lane (lane 0 may have left already) */
-    __syncthreads();
-    atomicMax(&s_cmax, (uint32_t)tl);
-    __syncthreads();
-    const uint32_t cmax = s_cmax;
-    uint8_t *o = ops + pr.ops_off;
-    const uint32_t cap = n + m;
-    uint32_t w = cap;
-    uint32_t r = n, c = (uint32_t)tl;
-    /* ops leave in 8-byte words: bytes are collected in `acc` and stored when the (descending) address reaches an 8-byte
-     * boundary; only the bytes above the first boundary and below the last one are single-byte stores (the neighbouring
-     * problems' regions start right there) */
-    uint64_t acc = 0; bool packed = false;
-    auto emit = [&](uint8_t op) {
-        --w;
-        const uintptr_t A = (uintptr_t)(o + w);
-        if (!packed) { o[w] = op; packed = (A & 7) == 0; return; }
-        acc |= (uint64_t)op << ((A & 7) * 8);
-        if ((A & 7) == 0) { *reinterpret_cast<uint64_t *>(o + w) = acc; acc = 0; }
-    };
-    for (uint32_t cc = cmax; cc >= 1; cc--) {
-        if (c != cc || r == 0) continue;
-        uint32_t b = (r - 1) >> 6;
-        lf_hist_t e = h[((size_t)(cc - 1) * NB + b) * 64];
+     * Tiles of K columns, last tile first.  A lane whose path is inside the tile restores the checkpoint in front of it,
+     * recomputes the tile's columns for blocks 0 .. (block of its row) -- the same anti-diagonal order as above --
+     * keeps (Pv, Ph) of the W = 2 lowest of those blocks in LDS and follows its path until it leaves the tile on
+     * the left.  A path that climbs out of the LDS window inside one tile (> 64 insertions within K columns)
+     * re-enters the same tile with the window moved up. */
+    lf_emitter em; em.init(ops + pr.ops_off, n + m, live && want_path);
+    uint32_t r = want_path ? n : 0, c = want_path ? (uint32_t)tl : 0;
+    const uint32_t cmax = lf_wave_max_u32(c);
+    for (int ti = cmax ? (int)((cmax - 1) / K) : -1; ti >= 0; ti--) {
+        const uint32_t c0 = (uint32_t)ti * K;
         for (;;) {
-            const int bit = (int)((r - 1) & 63);
-            if ((e.pv >> bit) & 1) {                                   /* Up: stays in this column */
-                emit(1); r--;
-                if (r == 0) break;
-                const uint32_t b2 = (r - 1) >> 6;
-                if (b2 != b) { b = b2; e = h[((size_t)(cc - 1) * NB + b) * 64]; }
-                continue;
+            const bool act = r > 0 && c > c0;
+            if (!__any(act)) break;
+            if (act) {
+                const int br = (int)((r - 1) >> 6);
+                const int bw = (W == 2 && br > 0) ? br - 1 : br;
+#pragma unroll
+                for (int b = 0; b < NB; b++) if (b <= br) {
+                    if (ti == 0) { Pv[b] = ~0ull; Mv[b] = 0; }
+                    else { const lf_hist_t e = ck[((size_t)(ti - 1) * NB + b) * 64]; Pv[b] = e.pv; Mv[b] = e.ph; }
+                }
+                const uint32_t ncol = c - c0;                  /* 1 .. K columns of this tile are on or left of the path */
+                uint64_t tw = 0;
+#pragma unroll
+                for (int k = 0; k < K; k++) if ((uint32_t)k < ncol) tw |= (uint64_t)T.get(c0 + k) << (k * 8);
+#pragma unroll
+                for (int b = 0; b < NB; b++) { hout[b] = 0; win[b] = 0; }
+                const uint32_t tsteps = ncol + (uint32_t)br;
+                for (uint32_t t = 1; t <= tsteps; t++) {
+#pragma unroll
+                    for (int b = NB - 1; b >= 1; b--) win[b] = win[b - 1];
+                    win[0] = t <= ncol ? (unsigned char)(tw >> ((t - 1) * 8)) : (unsigned char)0;
+#pragma unroll
+                    for (int b = NB - 1; b >= 0; b--) {
+                        const int cc = (int)t - b;             /* column of the tile, 1-based */
+                        if (b <= br && cc >= 1 && cc <= (int)ncol) {
+                            const int hin = b == 0 ? 1 : hout[b > 0 ? b - 1 : 0];
+                            const uint64_t Eq = lf_eq_mask(win[b], lo[b], hi[b], valid[b], Q, n, b);
+                            uint64_t ph, mh;
+                            hout[b] = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
+                            if (b >= bw) { lf_hist_t e; e.pv = Pv[b]; e.ph = ph; s_tile[((cc - 1) * W + (b - bw)) * 64 + lane] = e; }
+                        }
+                    }
+                }
+                /* follow the path through the tile */
+                while (r > 0 && c > c0) {
+                    int b = (int)((r - 1) >> 6);
+                    if (b < bw) break;                          /* above the window: recompute with the window moved up */
+                    lf_hist_t e = s_tile[((c - c0 - 1) * W + (b - bw)) * 64 + lane];
+                    for (;;) {
+                        const int bit = (int)((r - 1) & 63);
+                        if ((e.pv >> bit) & 1) {                                   /* Up: stays in this column */
+                            em.put(1); r--;
+                            if (r == 0) break;
+                            const int b2 = (int)((r - 1) >> 6);
+                            if (b2 != b) { if (b2 < bw) break; b = b2; e = s_tile[((c - c0 - 1) * W + (b - bw)) * 64 + lane]; }
+                            continue;
+                        }
+                        if ((e.ph >> bit) & 1) { em.put(2); c--; break; }             /* Left */
+                        em.put((lazy || Q.get(r - 1) == T.get(c - 1)) ? 0 : 3); r--; c--;   /* Diagonal */
+                        break;
+                    }
+                }
             }
-            if ((e.ph >> bit) & 1) { emit(2); c--; break; }             /* Left */
-            emit((lazy || Q.get(r - 1) == T.get(c - 1)) ? 0 : 3); r--; c--;   /* Diagonal */
-            break;
         }
     }
-    while (c > 0) { emit(2); c--; }
-    while (r > 0) { emit(1); r--; }
-    if (packed) {                        /* bytes collected above the last boundary reached */
-        const uintptr_t A = (uintptr_t)(o + w);
-        for (uintptr_t x = A; (x & 7) != 0; x++) *reinterpret_cast<uint8_t *>(x) = (uint8_t)(acc >> ((x & 7) * 8));
-    }
-    out_len[pr.id] = cap - w;            /* ops are END-aligned: o[cap - len .. cap) */
+    if (want_path) {
+        while (c > 0) { em.put(2); c--; }
+        while (r > 0) { em.put(1); r--; }
+        em.flush();
+        if (live) out_len[pr.id] = n + m - em.w;            /* ops are END-aligned: o[cap - len .. cap) */
+    } else if (live) out_len[pr.id] = 0;
 }
 
 /* ------------------------------------------------------------------------------------------------
- * generic kernel: any n; per-lane state in HBM (aux words), private history.  Used for n > 512 and for
- * the column-score requests of the Hirschberg splits (lib/edlib/edlib.cpp:1161-1330).
+ * generic kernel: any n; per-lane state in HBM (aux words), private FULL history in HBM.  Only for queries longer
+ * than the sweep classes take (n > 32768) and for the column-score requests of their host-driven Hirschberg splits.
  *   aux layout per problem: nbk x {lo,hi,valid,Pv,Mv}
  *   task LF_TASK_COLS: out_cols[aux2 + r] = D[r][m], r = 0..n, strings walked backwards when rev
  * ---------------------------------------------------------------------------------------------- */
@@ -291,251 +391,319 @@ lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_s
 }
 
 /* ------------------------------------------------------------------------------------------------
- * wave kernel: ONE WAVEFRONT PER PROBLEM for long queries (n > 512) and for the Hirschberg column requests.
- * Lane l owns KB consecutive 64-row blocks; the 64 lanes sweep the DP matrix as an anti-diagonal wavefront:
- * at step s lane l computes column s - l + 1, taking the horizontal carry (hout) that lane l-1 produced
- * one step earlier through a lane shuffle.  m + lanes - 1 steps instead of m * blocks dependent ones.
- * State lives in registers; history layout = the generic kernel's (private, (c-1)*nbk + block).
+ * sweep classes: G = 16 / 32 / 64 LANES PER PROBLEM (64 / G problems per wavefront), KB blocks per lane.
+ *
+ * The lanes of a group sweep the DP matrix as an anti-diagonal: at step s lane l works on column s - l + 1 of its
+ * KB blocks and takes the horizontal carry lane l-1 produced one step earlier (DPP wave_shr:1).  m + lanes - 1 steps
+ * instead of m * blocks dependent ones.  Loop bounds are wave-uniform maxima, work is predicated per group.
+ *
+ *   forward    ed / end column; every K steps the state of all lanes (Pv, Mv per block, pending carry) is
+ *              checkpointed: one (KB + 1/16) KiB line per wave instead of K x KB KiB of history
+ *   traceback  tiles of K steps, last first: restore the checkpoint, replay the K steps with (Pv, Ph) going to LDS,
+ *              follow the path through the tile (position (r, c) lives at step c - 1 + owner(r), which only decreases)
+ *   G = 64     adds obtainAlignmentHirschberg (lib/edlib/edlib.cpp:1161-1330) ON THE DEVICE for problems above
+ *              edlib's 1 MiB traceback switch (:1117-1119): a depth-first walk over (query range, target range, distance)
+ *              triples on an LDS stack, right child first, so that the leaves' paths land end-aligned in one piece.
+ *              A split = forward sweep over the left half of the target, backward sweep over the right half (both
+ *              write their last DP column to HBM scratch), split row = first hit in the order rows 0..n-2, then -1,
+ *              then n-1 (:1263-1289) found with one ballot per 64 rows.  No host round trip, no byte staging.
+ * The target is staged through an LDS ring (refilled every TC/2 steps), so any target length runs out of LDS.
  * ---------------------------------------------------------------------------------------------- */
-#define LF_WAVE_LDS_T 8192
 /* lane l receives lane l-1's value (lane 0: 0): the horizontal carry of the anti-diagonal sweeps.  DPP wave_shr:1 is a
  * VALU move; __shfl_up goes through the LDS crossbar (ds_bpermute) and sits on the per-step dependency chain. */
 __device__ __forceinline__ int lf_wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
-/* broadcast of a 64-bit value from a lane that is the same for the whole wavefront (v_readlane instead of ds_bpermute) */
-__device__ __forceinline__ uint64_t lf_readlane64(uint64_t v, int src_uniform)
-{
-    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src_uniform), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src_uniform);
-    return ((uint64_t)hi << 32) | lo;
-}
-template <int KB>
-__global__ void __launch_bounds__(64)
-lf_edlib_wave_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ hist,
-                     uint8_t *__restrict__ ops, int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end,
-                     uint32_t *__restrict__ out_len, int32_t *__restrict__ out_cols, const uint64_t *__restrict__ cols_off)
-{
-    if ((int)blockIdx.x >= n_probs) return;
-    const int lane = threadIdx.x;
-    const lf_aln_prob pr = probs[blockIdx.x];
-    const lf_qacc Q(S.q, pr.qstart, pr.flags); const lf_tacc T(S.t, S.pac, pr.tstart, pr.flags);
-    const bool lazy = (pr.flags & LF_F_LAZYX) != 0;      /* diagonal moves are not classified here (lf_render_kernel does it) */
-    const uint32_t n = pr.n, m = pr.m;
-    const uint32_t nbk = (n + 63) >> 6;
-    const int nl = (int)((nbk + KB - 1) / KB);            /* lanes that own at least one block */
-    uint64_t lo[KB], hi[KB], valid[KB], Pv[KB], Mv[KB];
-#pragma unroll
-    for (int k = 0; k < KB; k++) { lo[k] = hi[k] = valid[k] = 0; Pv[k] = ~0ull; Mv[k] = 0; }
-    /* bit planes by ballot: for block b the 64 lanes fetch its 64 query bytes in one coalesced load and three
-     * wave ballots give lo / hi / valid; the lane that owns block b keeps them */
-    for (uint32_t b = 0; b < nbk; b++) {
-        const uint32_t r = b * 64 + (uint32_t)lane;
-        int code = -1;
-        if (r < n) { switch (Q.get(r)) { case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break; default: code = -1; } }
-        const uint64_t bl = __ballot(code >= 0 && (code & 1)), bh = __ballot(code >= 0 && (code & 2)), bv = __ballot(code >= 0);
-        const int owner = (int)(b / KB), slot = (int)(b % KB);
-        if (lane == owner) {
-#pragma unroll
-            for (int k = 0; k < KB; k++) if (k == slot) { lo[k] = bl; hi[k] = bh; valid[k] = bv; }
-        }
-    }
-    /* target staged once into LDS (coalesced), then read from LDS inside the dependent step loop */
-    __shared__ unsigned char s_t[LF_WAVE_LDS_T];
-    const bool t_lds = m <= LF_WAVE_LDS_T;
-    if (t_lds) { for (uint32_t j = (uint32_t)lane; j < m; j += 64) s_t[j] = T.get(j); }
-    __syncthreads();
-    const uint32_t lastb = (n - 1) >> 6; const int lastbit = (int)((n - 1) & 63);
-    const int lane_last = (int)(lastb / KB);
-    int score = (int)n, best = (n & 63) ? (int)n : 0x7fffffff, best_c = 0;
-    lf_hist_t *h = hist + pr.hist_base;
-    const bool want_path = pr.task == LF_TASK_PATH;
-    int hout_prev = 1;
-    const int steps = (int)m + nl - 1;
-    for (int s = 0; s < steps; s++) {
-        const int from_left = lf_wave_shr1(hout_prev);
-        const int c = s - lane + 1;
-        if (lane < nl && c >= 1 && c <= (int)m) {
-            const unsigned char tc = t_lds ? s_t[c - 1] : T.get((uint32_t)(c - 1));
-            int hin = lane == 0 ? 1 : from_left;
-#pragma unroll
-            for (int k = 0; k < KB; k++) {
-                const uint32_t b = (uint32_t)lane * KB + k;
-                if (b < nbk) {
-                    const uint64_t Eq = lf_eq_mask(tc, lo[k], hi[k], valid[k], Q, n, b);
-                    uint64_t ph, mh;
-                    hin = lf_myers_step(Pv[k], Mv[k], Eq, hin, ph, mh);
-                    if (b == lastb) score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
-                    /* history rows follow the sweep: at step s the lanes write ONE contiguous row (s * nbk + block) */
-                    if (want_path) { lf_hist_t e; e.pv = Pv[k]; e.ph = ph; h[(size_t)s * nbk + b] = e; }
-                }
-            }
-            hout_prev = hin;
-            if (lane == lane_last && score < best) { best = score; best_c = c; }
-        }
-    }
-    if (pr.task == LF_TASK_COLS) {
-        /* D[r][m] for r = 0..n from the final vertical deltas: lane-local sums + exclusive scan over lanes */
-        int mine = 0;
-#pragma unroll
-        for (int k = 0; k < KB; k++) {
-            const uint32_t b = (uint32_t)lane * KB + k;
-            if (b < nbk) {
-                const uint32_t rows = (b == lastb) ? (uint32_t)lastbit + 1 : 64;
-                const uint64_t msk = rows >= 64 ? ~0ull : ((1ull << rows) - 1);
-                mine += __popcll(Pv[k] & msk) - __popcll(Mv[k] & msk);
-            }
-        }
-        int incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-        int v = (int)m + incl - mine;
-        int32_t *oc = out_cols + cols_off[pr.id];
-        if (lane == 0) oc[0] = (int)m;
-#pragma unroll
-        for (int k = 0; k < KB; k++) {
-            const uint32_t b = (uint32_t)lane * KB + k;
-            if (b < nbk) for (int i = 0; i < 64; i++) {
-                const uint32_t r = b * 64 + i + 1;
-                if (r <= n) { v += (int)((Pv[k] >> i) & 1) - (int)((Mv[k] >> i) & 1); oc[r] = v; }
-            }
-        }
-        return;
-    }
-    const int ed_nw = __shfl(score, lane_last), ed_shw = __shfl(best, lane_last), c_shw = __shfl(best_c, lane_last);
-    int ed, tl;
-    if (pr.mode == 0) { ed = ed_nw; tl = (int)m; } else { ed = ed_shw; tl = c_shw; }
-    __syncthreads();                      /* history written by all lanes is read back below */
-    if (lane == 0) { out_ed[pr.id] = ed; out_end[pr.id] = tl - 1; }
-    if (!want_path) { if (lane == 0) out_len[pr.id] = 0; return; }
-    /* cooperative traceback: the 64 lanes fetch the history of 64 consecutive columns of the current 64-row block
-     * in one round trip (lane l holds column c-l); the walk then runs out of registers via lane broadcasts -- every
-     * lane replays the same moves (uniform control flow), lane 0 writes the ops.  One HBM/L2 round trip per ~64
-     * steps instead of one per step. */
-    uint8_t *o = ops + pr.ops_off;
-    const uint32_t cap = n + m;
-    uint32_t w = cap, r = n, c = (uint32_t)tl;
-    if (c == 0) { if (lane == 0) for (uint32_t i = 0; i < r; i++) o[cap - 1 - i] = 1; w -= r; r = 0; }
-    while (r > 0 && c > 0) {
-        const uint32_t blk = (r - 1) >> 6, c0 = c;
-        const int col = (int)c0 - lane;
-        lf_hist_t e; e.pv = 0; e.ph = 0;
-        if (col >= 1) e = h[(size_t)(col - 1 + (int)(blk / KB)) * nbk + blk];
-        while (r > 0 && c > 0 && ((r - 1) >> 6) == blk && (c0 - c) < 64) {
-            const int src = __builtin_amdgcn_readfirstlane((int)(c0 - c));      /* every lane replays the same walk */
-            const uint64_t pv = lf_readlane64(e.pv, src), ph = lf_readlane64(e.ph, src);
-            const int bit = (int)((r - 1) & 63);
-            uint8_t op;
-            if ((pv >> bit) & 1) { op = 1; if (lane == 0) o[w - 1] = op; r--; }
-            else if ((ph >> bit) & 1) { op = 2; if (lane == 0) o[w - 1] = op; c--; }
-            else { if (lane == 0) o[w - 1] = (lazy || Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
-            w--;
-        }
-    }
-    if (lane == 0) {
-        while (c > 0) { o[--w] = 2; c--; }
-        while (r > 0) { o[--w] = 1; r--; }
-        out_len[pr.id] = cap - w;            /* ops are END-aligned: o[cap - len .. cap) */
-    }
-}
 
-/* ------------------------------------------------------------------------------------------------
- * group kernel: the wave kernel's anti-diagonal sweep with G = 16 or 32 lanes per problem, 64/G problems per
- * wavefront.  Queries of 513..2048 bases have 9..32 blocks: one problem per wave would leave most lanes idle.
- * One block per lane; carries cross lanes by shuffle, never a group boundary (group lane 0 takes hin = 1);
- * wave-wide ballots build the bit planes of all groups at once; each group tracebacks cooperatively (G history
- * columns per round trip).  Loop bounds are wave-uniform maxima, work is predicated per group.
- * ---------------------------------------------------------------------------------------------- */
-template <int G>
+#define LF_HSTACK 48
+template <int G, int KB, int K>
 __global__ void __launch_bounds__(64)
-lf_edlib_group_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ hist,
+lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ ckpt, uint64_t *__restrict__ aux,
                       uint8_t *__restrict__ ops, int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
 {
-    constexpr int P = 64 / G;                      /* problems per wave = sub-iterations per 64-row block */
-    constexpr int TCAP = G * 72;                   /* LDS bytes of target per group: covers m <= 1.125 n; longer targets read HBM */
+    constexpr int P = 64 / G;                      /* problems per wave */
+    constexpr int TC = G * 64;                     /* LDS ring of target bytes per group (power of two) */
+    constexpr int H = TC / 2;
+    __shared__ lf_hist_t s_tile[K * KB * 64];
+    __shared__ unsigned char s_t[P * TC];
+    __shared__ uint32_t s_stack[G == 64 ? LF_HSTACK * 5 : 1];
     const int lane = threadIdx.x, g = lane / G, gl = lane % G;
     const int pi = (int)blockIdx.x * P + g;
     const bool live = pi < n_probs;
     const lf_aln_prob pr = probs[live ? pi : n_probs - 1];      /* a dead group shadows the last problem and stores nothing */
     const lf_qacc Q(S.q, pr.qstart, pr.flags); const lf_tacc T(S.t, S.pac, pr.tstart, pr.flags);
     const bool lazy = (pr.flags & LF_F_LAZYX) != 0;      /* diagonal moves are not classified here (lf_render_kernel does it) */
-    const uint32_t n = pr.n, m = pr.m;
-    const uint32_t nbk = (n + 63) >> 6;            /* <= G */
-    uint32_t nbk_max = nbk, steps_max = m + nbk - 1;
+    const bool want_path = pr.task == LF_TASK_PATH;
+    unsigned char *my_t = s_t + g * TC;
+    /* all groups of a wave share one checkpoint area (base of the wave's first problem) */
+    lf_hist_t *ck = ckpt + probs[(int)blockIdx.x * P].hist_base;
+    const uint64_t gmask = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1);
+
+    /* geometry of the (sub)problem being swept: query rows [qlo, qlo + n), target columns [tlo, tlo + m), both walked
+     * backwards when rev (right halves of the Hirschberg splits) */
+    uint32_t qlo = 0, n = pr.n, tlo = 0, m = pr.m; bool rev = false;
+    auto qget = [&](uint32_t i) -> unsigned char { return Q.get(rev ? qlo + n - 1 - i : qlo + i); };
+    auto tget = [&](uint32_t j) -> unsigned char { return T.get(rev ? tlo + m - 1 - j : tlo + j); };
+
+    uint64_t lo[KB], hi[KB], valid[KB], Pv[KB], Mv[KB];
+    uint32_t nbk = 0, lastb = 0; int lastbit = 0, nl = 0, lane_last = 0;
+    int hout_prev = 1;
+
+    /* bit planes by ballot: for block b the lanes fetch its 64 query bytes (G at a time per group) and three wave
+     * ballots give lo / hi / valid; the lane that owns block b keeps them */
+    auto build_planes = [&]() {
+        nbk = (n + 63) >> 6; lastb = (n - 1) >> 6; lastbit = (int)((n - 1) & 63);
+        nl = (int)((nbk + KB - 1) / KB); lane_last = (int)(lastb / KB);
+        const uint32_t nbk_max = G == 64 ? nbk : lf_wave_max_u32(nbk);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t a = __shfl_xor(nbk_max, o), b2 = __shfl_xor(steps_max, o);
-        nbk_max = a > nbk_max ? a : nbk_max; steps_max = b2 > steps_max ? b2 : steps_max;
-    }
-    uint64_t lo = 0, hi = 0, valid = 0, Pv = ~0ull, Mv = 0;
-    const uint64_t gmask = (1ull << G) - 1;
-    for (uint32_t b = 0; b < nbk_max; b++) {
+        for (int k = 0; k < KB; k++) { lo[k] = hi[k] = valid[k] = 0; }
+        for (uint32_t b = 0; b < nbk_max; b++) {
 #pragma unroll
-        for (int sub = 0; sub < P; sub++) {
-            const uint32_t r = b * 64 + (uint32_t)(sub * G + gl);
-            int code = -1;
-            if (b < nbk && r < n) { switch (Q.get(r)) { case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break; default: code = -1; } }
-            const uint64_t bl = __ballot(code >= 0 && (code & 1)), bh = __ballot(code >= 0 && (code & 2)), bv = __ballot(code >= 0);
-            if ((uint32_t)gl == b) {
-                lo |= ((bl >> (g * G)) & gmask) << (sub * G); hi |= ((bh >> (g * G)) & gmask) << (sub * G); valid |= ((bv >> (g * G)) & gmask) << (sub * G);
+            for (int sub = 0; sub < P; sub++) {
+                const uint32_t r = b * 64 + (uint32_t)(sub * G + gl);
+                int code = -1;
+                if (b < nbk && r < n) { switch (qget(r)) { case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break; default: code = -1; } }
+                const uint64_t bl = __ballot(code >= 0 && (code & 1)), bh = __ballot(code >= 0 && (code & 2)), bv = __ballot(code >= 0);
+                if ((uint32_t)gl == b / KB) {
+                    const int slot = (int)(b % KB);
+                    const uint64_t xl = ((bl >> (g * G)) & gmask) << (sub * G), xh = ((bh >> (g * G)) & gmask) << (sub * G), xv = ((bv >> (g * G)) & gmask) << (sub * G);
+#pragma unroll
+                    for (int k = 0; k < KB; k++) if (k == slot) { lo[k] |= xl; hi[k] |= xh; valid[k] |= xv; }
+                }
             }
         }
-    }
-    __shared__ unsigned char s_t[64 * 72];
-    unsigned char *my_t = s_t + g * TCAP;
-    const bool t_lds = m <= (uint32_t)TCAP;
-    if (t_lds) { for (uint32_t j = (uint32_t)gl; j < m; j += G) my_t[j] = T.get(j); }
-    __syncthreads();
-    const uint32_t lastb = (n - 1) >> 6; const int lastbit = (int)((n - 1) & 63);
-    int score = (int)n, best = (n & 63) ? (int)n : 0x7fffffff, best_c = 0;
-    lf_hist_t *h = hist + pr.hist_base;
-    int hout_prev = 1;
-    for (uint32_t s = 0; s < steps_max; s++) {
+    };
+    /* target columns [first, first + count) into the group's LDS ring */
+    auto stage_window = [&](int first, int count) {
+        for (int j = first + gl; j < first + count; j += G) if (j >= 0 && (uint32_t)j < m) my_t[j & (TC - 1)] = tget((uint32_t)j);
+    };
+    /* one sweep step s (TILE: (Pv, Ph) of the step go to LDS row s - s0) */
+    int score = 0, best = 0, best_c = 0;
+    auto sweep_step = [&](int s, bool track, bool tile, int s0) {
         const int from_left = lf_wave_shr1(hout_prev);
-        const int c = (int)s - gl + 1;
-        if ((uint32_t)gl < nbk && c >= 1 && c <= (int)m) {
-            const unsigned char tc = t_lds ? my_t[c - 1] : T.get((uint32_t)(c - 1));
-            const uint64_t Eq = lf_eq_mask(tc, lo, hi, valid, Q, n, (uint32_t)gl);
-            uint64_t ph, mh;
-            const int hin = gl == 0 ? 1 : from_left;
-            hout_prev = lf_myers_step(Pv, Mv, Eq, hin, ph, mh);
-            if ((uint32_t)gl == lastb) { score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1); if (score < best) { best = score; best_c = c; } }
-            if (live) { lf_hist_t e; e.pv = Pv; e.ph = ph; h[(size_t)s * nbk + gl] = e; }      /* row s = column - 1 + block: contiguous per group */
+        const int c = s - gl + 1;
+        if (gl < nl && c >= 1 && c <= (int)m) {
+            const unsigned char tc = my_t[(c - 1) & (TC - 1)];
+            int hin = gl == 0 ? 1 : from_left;
+#pragma unroll
+            for (int k = 0; k < KB; k++) {
+                const uint32_t b = (uint32_t)gl * KB + k;
+                if (b < nbk) {
+                    const uint64_t Eq = lf_eq_mask_f(tc, lo[k], hi[k], valid[k], qget, n, b);
+                    uint64_t ph, mh;
+                    hin = lf_myers_step(Pv[k], Mv[k], Eq, hin, ph, mh);
+                    if (track && b == lastb) score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
+                    if (tile) { lf_hist_t e; e.pv = Pv[k]; e.ph = ph; s_tile[((s - s0) * KB + k) * 64 + lane] = e; }
+                }
+            }
+            hout_prev = hin;
+            if (track && gl == lane_last && score < best) { best = score; best_c = c; }
         }
-    }
-    const int src_last = g * G + (int)lastb;
+    };
+    /* forward pass of the current geometry; want_ck: checkpoint every K steps.  Leaves score (NW distance at lane_last),
+     * best / best_c (SHW) behind; returns the wave-uniform number of steps. */
+    auto forward = [&](bool want_ck) -> int {
+#pragma unroll
+        for (int k = 0; k < KB; k++) { Pv[k] = ~0ull; Mv[k] = 0; }
+        hout_prev = 1;
+        score = (int)n; best = (n & 63) ? (int)n : 0x7fffffff; best_c = 0;
+        const int steps = (int)m + nl - 1;
+        const int steps_max = G == 64 ? steps : lf_wave_max_i32(steps);
+        for (int s = 0; s < steps_max; s++) {
+            if ((s & (H - 1)) == 0) { __syncthreads(); stage_window(s, H); __syncthreads(); }
+            sweep_step(s, true, false, 0);
+            if (want_ck && ((s + 1) & (K - 1)) == 0) {
+                const size_t j = (size_t)((s + 1) / K - 1);
+                lf_hist_t *row = ck + j * (64 * KB + 4);
+#pragma unroll
+                for (int k = 0; k < KB; k++) { lf_hist_t e; e.pv = Pv[k]; e.ph = Mv[k]; row[k * 64 + lane] = e; }
+                reinterpret_cast<signed char *>(row + 64 * KB)[lane] = (signed char)hout_prev;
+            }
+        }
+        return steps_max;
+    };
+    /* traceback of the current geometry from (r = n, c = tl) through checkpointed tiles; ops go to `em` backwards */
+    lf_emitter em; em.init(ops + pr.ops_off, pr.n + pr.m, live && want_path && gl == 0);
+    auto traceback = [&](uint32_t tl, int steps_max, bool active) {
+        uint32_t r = active ? n : 0, c = active ? tl : 0;
+        auto step_of = [&](uint32_t rr, uint32_t cc) -> int { return (rr > 0 && cc > 0) ? (int)(cc - 1 + ((rr - 1) >> 6) / KB) : -1; };
+        int scur = step_of(r, c);
+        const int jmax = lf_wave_max_i32(scur >= 0 ? scur / K : -1);
+        for (int j = jmax; j >= 0; j--) {
+            const int s0 = j * K;
+            /* restore the state in front of the tile */
+            if (j == 0) {
+#pragma unroll
+                for (int k = 0; k < KB; k++) { Pv[k] = ~0ull; Mv[k] = 0; }
+                hout_prev = 1;
+            } else {
+                const lf_hist_t *row = ck + (size_t)(j - 1) * (64 * KB + 4);
+#pragma unroll
+                for (int k = 0; k < KB; k++) { const lf_hist_t e = row[k * 64 + lane]; Pv[k] = e.pv; Mv[k] = e.ph; }
+                hout_prev = (int)reinterpret_cast<const signed char *>(row + 64 * KB)[lane];
+            }
+            __syncthreads();                                   /* the previous tile's LDS rows have been read */
+            stage_window(s0 - G + 1, K + G - 1);
+            __syncthreads();
+            const int s1 = s0 + K < steps_max ? s0 + K : steps_max;
+            for (int s = s0; s < s1; s++) sweep_step(s, false, true, s0);
+            __syncthreads();
+            for (;;) {
+                const bool act = scur >= s0;
+                if (!__any(act)) break;
+                if (act) {
+                    const uint32_t blk = (r - 1) >> 6;
+                    const lf_hist_t e = s_tile[((scur - s0) * KB + (int)(blk % KB)) * 64 + g * G + (int)(blk / KB)];
+                    const int bit = (int)((r - 1) & 63);
+                    if ((e.pv >> bit) & 1) { em.put(1); r--; }
+                    else if ((e.ph >> bit) & 1) { em.put(2); c--; }
+                    else { em.put((lazy || qget(r - 1) == tget(c - 1)) ? 0 : 3); r--; c--; }
+                    scur = step_of(r, c);
+                }
+            }
+        }
+        if (active) {
+            while (c > 0) { em.put(2); c--; }
+            while (r > 0) { em.put(1); r--; }
+        }
+    };
+
+    /* ---- the root problem ---- */
+    const bool root_leaf = G < 64 || lf_leaf(pr.n, pr.m);
+    build_planes();
+    int steps_max = forward(want_path && root_leaf);
+    const int src_last = g * G + lane_last;
     const int ed_nw = __shfl(score, src_last), ed_shw = __shfl(best, src_last), c_shw = __shfl(best_c, src_last);
     int ed, tl;
     if (pr.mode == 0) { ed = ed_nw; tl = (int)m; } else { ed = ed_shw; tl = c_shw; }
-    __syncthreads();                      /* history written by all lanes is read back below */
-    if (!live) return;
-    if (gl == 0) { out_ed[pr.id] = ed; out_end[pr.id] = tl - 1; }
-    uint8_t *o = ops + pr.ops_off;
-    const uint32_t cap = n + m;
-    uint32_t w = cap, r = n, c = (uint32_t)tl;
-    if (c == 0) { if (gl == 0) for (uint32_t i = 0; i < r; i++) o[cap - 1 - i] = 1; w -= r; r = 0; }
-    while (r > 0 && c > 0) {
-        const uint32_t blk = (r - 1) >> 6, c0 = c;
-        const int col = (int)c0 - gl;
-        lf_hist_t e; e.pv = 0; e.ph = 0;
-        if (col >= 1) e = h[(size_t)(col - 1 + (int)blk) * nbk + blk];
-        while (r > 0 && c > 0 && ((r - 1) >> 6) == blk && (c0 - c) < (uint32_t)G) {
-            const int src = g * G + (int)(c0 - c);
-            const uint64_t pv = __shfl(e.pv, src), ph = __shfl(e.ph, src);
-            const int bit = (int)((r - 1) & 63);
-            if ((pv >> bit) & 1) { if (gl == 0) o[w - 1] = 1; r--; }
-            else if ((ph >> bit) & 1) { if (gl == 0) o[w - 1] = 2; c--; }
-            else { if (gl == 0) o[w - 1] = (lazy || Q.get(r - 1) == T.get(c - 1)) ? 0 : 3; r--; c--; }
-            w--;
+    if (live && gl == 0) { out_ed[pr.id] = ed; out_end[pr.id] = tl - 1; }
+    if (!__any(want_path)) { if (live && gl == 0) out_len[pr.id] = 0; return; }
+    if (root_leaf) {
+        traceback((uint32_t)tl, steps_max, want_path);
+    } else if (G == 64) {
+        /* obtainAlignment (lib/edlib/edlib.cpp:1090-1143) on (q, t[0 .. tl)) with the known distance: depth-first, right
+         * child first.  Everything below is wave-uniform (one problem per wavefront). */
+        const uint32_t n_root = pr.n;
+        int32_t *Fb = reinterpret_cast<int32_t *>(aux + pr.aux_off), *Rb = Fb + (n_root + 1);
+        int sp = 0;
+        auto push = [&](uint32_t a, uint32_t b, uint32_t c2, uint32_t d, uint32_t e) {
+            if (lane == 0) { s_stack[sp * 5 + 0] = a; s_stack[sp * 5 + 1] = b; s_stack[sp * 5 + 2] = c2; s_stack[sp * 5 + 3] = d; s_stack[sp * 5 + 4] = e; }
+            sp++;
+        };
+        /* D[r][m] for r = 0..n of the sweep that just ended: lane-local sums + exclusive scan over lanes */
+        auto colscores = [&](int32_t *oc) {
+            int mine = 0;
+#pragma unroll
+            for (int k = 0; k < KB; k++) {
+                const uint32_t b = (uint32_t)lane * KB + k;
+                if (b < nbk) {
+                    const uint32_t rows = (b == lastb) ? (uint32_t)lastbit + 1 : 64;
+                    const uint64_t msk = rows >= 64 ? ~0ull : ((1ull << rows) - 1);
+                    mine += __popcll(Pv[k] & msk) - __popcll(Mv[k] & msk);
+                }
+            }
+            int incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            int v = (int)m + incl - mine;
+            if (lane == 0) oc[0] = (int)m;
+#pragma unroll
+            for (int k = 0; k < KB; k++) {
+                const uint32_t b = (uint32_t)lane * KB + k;
+                if (b < nbk) for (int i = 0; i < 64; i++) {
+                    const uint32_t r = b * 64 + i + 1;
+                    if (r <= n) { v += (int)((Pv[k] >> i) & 1) - (int)((Mv[k] >> i) & 1); oc[r] = v; }
+                }
+            }
+        };
+        if (tl == 0) { for (uint32_t i = 0; i < n_root; i++) em.put(1); }
+        else push(0, n_root, 0, (uint32_t)tl, (uint32_t)ed);
+        bool failed = false;
+        while (sp > 0 && !failed) {
+            sp--;
+            __syncthreads();
+            const uint32_t a_q = s_stack[sp * 5 + 0], a_n = s_stack[sp * 5 + 1], a_t = s_stack[sp * 5 + 2], a_m = s_stack[sp * 5 + 3];
+            const int a_best = (int)s_stack[sp * 5 + 4];
+            __syncthreads();
+            if (a_n == 0) { for (uint32_t i = 0; i < a_m; i++) em.put(2); continue; }          /* :1096-1104 */
+            if (a_m == 0) { for (uint32_t i = 0; i < a_n; i++) em.put(1); continue; }
+            if (lf_leaf(a_n, a_m)) {
+                qlo = a_q; n = a_n; tlo = a_t; m = a_m; rev = false;
+                build_planes();
+                steps_max = forward(true);
+                traceback(a_m, steps_max, true);
+                continue;
+            }
+            const uint32_t lw = a_m / 2, rw = a_m - lw;
+            /* F[x] = dist(q[0..x), t[0..lw)) */
+            qlo = a_q; n = a_n; tlo = a_t; m = lw; rev = false;
+            build_planes(); (void)forward(false); colscores(Fb);
+            /* R[x] = dist(last x of q, t[lw..m)): both strings walked backwards */
+            qlo = a_q; n = a_n; tlo = a_t + lw; m = rw; rev = true;
+            build_planes(); (void)forward(false); colscores(Rb);
+            __syncthreads();
+            /* split row (:1263-1289): first qi in 0..n-2 with F[qi+1] + R[n-qi-1] == best, else -1, else n-1 */
+            int split = -2, ls = 0, rs = 0;
+            for (uint32_t base = 0; base + 2 <= a_n && split == -2; base += 64) {
+                const uint32_t qi = base + (uint32_t)lane;
+                const bool hit = qi + 2 <= a_n && Fb[qi + 1] + Rb[a_n - qi - 1] == a_best;
+                const uint64_t bm = __ballot(hit);
+                if (bm) split = (int)(base + (uint32_t)(__ffsll((long long)bm) - 1));
+            }
+            if (split >= 0) { ls = Fb[split + 1]; rs = Rb[a_n - (uint32_t)split - 1]; }
+            else if ((int)lw + Rb[a_n] == a_best) { split = -1; ls = (int)lw; rs = Rb[a_n]; }
+            else if (Fb[a_n] + (int)rw == a_best) { split = (int)a_n - 1; ls = Fb[a_n]; rs = (int)rw; }
+            else { failed = true; break; }
+            __syncthreads();                                   /* Fb / Rb are overwritten by the children */
+            const uint32_t ul = (uint32_t)(split + 1);
+            if (sp + 2 > LF_HSTACK) { failed = true; break; }
+            push(a_q, ul, a_t, lw, (uint32_t)ls);                             /* left child: popped second */
+            push(a_q + ul, a_n - ul, a_t + lw, rw, (uint32_t)rs);             /* right child: popped first */
         }
+        if (failed && live && lane == 0) out_ed[pr.id] = -2;      /* cannot happen for a consistent distance; the host reports it */
     }
-    if (gl == 0) {
-        while (c > 0) { o[--w] = 2; c--; }
-        while (r > 0) { o[--w] = 1; r--; }
-        out_len[pr.id] = cap - w;            /* ops are END-aligned: o[cap - len .. cap) */
-    }
+    em.flush();
+    if (live && gl == 0) out_len[pr.id] = want_path ? pr.n + pr.m - em.w : 0;            /* ops are END-aligned: o[cap - len .. cap) */
 }
 
 /* ------------------------------------------------------------------------------------------------
- * host launcher
+ * size classes and checkpoint layout (shared by the host binning of the byte-string API and the device binning of
+ * the descriptor batches)
+ *   1..6   lane kernels NB 1,2,3,4,6,8 (n <= 512): 64 problems per wave, checkpoint every LF_LANE_K columns
+ *   7,8    sweep kernels G 16 / 32, one block per lane (n <= 1024 / 2048): 4 / 2 problems per wave
+ *   9..11  sweep kernels G 64, KB 1 / 4 / 8 blocks per lane (n <= 4096 / 16384 / 32768), with device Hirschberg
+ *   0      generic lane kernel (n > 32768; full history in HBM; Hirschberg driven by the host)
+ * A wave's checkpoints start at the hist_base of its first problem (16-byte entries).
  * ---------------------------------------------------------------------------------------------- */
+#define LF_NCLASS 12
+/* LF_SWEEP_MAX_N: lf_internal.h */
+__host__ __device__ __forceinline__ int lf_class_nb(int c) { return c == 1 ? 1 : c == 2 ? 2 : c == 3 ? 3 : c == 4 ? 4 : c == 5 ? 6 : 8; }
+__host__ __device__ __forceinline__ int lf_class_of(uint32_t n)
+{
+    const uint32_t nb = (n + 63) >> 6;
+    if (nb <= 1) return 1; if (nb <= 2) return 2; if (nb <= 3) return 3; if (nb <= 4) return 4; if (nb <= 6) return 5; if (nb <= 8) return 6;
+    if (nb <= 16) return 7; if (nb <= 32) return 8;
+    if (n <= 4096) return 9; if (n <= 16384) return 10; if (n <= LF_SWEEP_MAX_N) return 11;
+    return 0;
+}
+/* problems per wave, blocks per lane, steps per tile of the sweep classes */
+__host__ __device__ __forceinline__ int lf_class_ppw(int c) { return c >= 1 && c <= 6 ? 64 : c == 7 ? 4 : c == 8 ? 2 : 1; }      /* class 0: 1 (own history) */
+__host__ __device__ __forceinline__ int lf_class_kb(int c) { return c == 10 ? 4 : c == 11 ? 8 : 1; }
+__host__ __device__ __forceinline__ int lf_class_k(int c) { return c == 10 ? 4 : c == 11 ? 2 : 16; }
+/* checkpoint entries of one wave whose longest target is m_max (the wave's last problem: problems are sorted by m) */
+__host__ __device__ __forceinline__ uint64_t lf_class_wave_entries(int c, uint32_t m_max)
+{
+    if (c >= 1 && c <= 6) return 64ull * (m_max / LF_LANE_K) * (uint32_t)lf_class_nb(c);
+    if (c == 0) return 0;
+    const uint64_t rows = ((uint64_t)m_max + 64) / (uint32_t)lf_class_k(c) + 1;
+    return rows * (64ull * (uint32_t)lf_class_kb(c) + 4);
+}
+/* Hirschberg scratch of a sweep-class problem above edlib's traceback switch: two columns of n + 1 scores (in u64 words) */
+__host__ __device__ __forceinline__ uint64_t lf_class_aux_words(int c, uint32_t n, uint32_t m)
+{
+    if (c == 0) return (uint64_t)((n + 63) >> 6) * 5;
+    if (c >= 9 && !lf_leaf(n, m)) return (uint64_t)n + 2;
+    return 0;
+}
+
 struct lf_dev_buf {
     void *p = nullptr;
     ~lf_dev_buf() { if (p) (void)hipFree(p); }
@@ -543,109 +711,99 @@ struct lf_dev_buf {
     template <class T> T *as() { return (T *)p; }
 };
 
-static int class_nb(uint32_t n)
-{
-    const uint32_t nb = (n + 63) / 64;
-    if (nb <= 1) return 1;
-    if (nb <= 2) return 2;
-    if (nb <= 4) return 4;
-    if (nb <= 8) return 8;
-    return 0;              /* generic */
-}
-
-/* stable counting sort of problems by target length (ascending or descending): O(n), replaces std::sort */
-static void sort_by_m(std::vector<lf_aln_prob> &v, bool descending)
+/* stable counting sort of problems by target length (ascending): O(n), replaces std::sort */
+static void sort_by_m(std::vector<lf_aln_prob> &v)
 {
     if (v.size() < 2) return;
     uint32_t mx = 0;
     for (auto &p : v) mx = std::max(mx, p.m);
     if ((size_t)mx > 8 * v.size() + 65536) {        /* sparse lengths: comparison sort */
-        if (descending) std::stable_sort(v.begin(), v.end(), [](const lf_aln_prob &a, const lf_aln_prob &b) { return a.m > b.m; });
-        else std::stable_sort(v.begin(), v.end(), [](const lf_aln_prob &a, const lf_aln_prob &b) { return a.m < b.m; });
+        std::stable_sort(v.begin(), v.end(), [](const lf_aln_prob &a, const lf_aln_prob &b) { return a.m < b.m; });
         return;
     }
     std::vector<uint32_t> cnt((size_t)mx + 2, 0);
-    for (auto &p : v) cnt[(descending ? mx - p.m : p.m) + 1]++;
+    for (auto &p : v) cnt[p.m + 1]++;
     for (size_t i = 1; i < cnt.size(); i++) cnt[i] += cnt[i - 1];
     std::vector<lf_aln_prob> o(v.size());
-    for (auto &p : v) o[cnt[descending ? mx - p.m : p.m]++] = p;
+    for (auto &p : v) o[cnt[p.m]++] = p;
     v.swap(o);
 }
 
-/* runs DIST/PATH problems (cols == nullptr) or COLS problems (cols != nullptr) */
-struct lf_desc_src { const lf_aln_desc_t *d; const uint64_t *ops_off; uint64_t ops_total; const unsigned char *d_reads; const uint8_t *d_pac; };
+/* the launches of one binned batch: class k = probs[cstart[k] .. cstart[k + 1]) */
+struct lf_launch_ctx {
+    hipStream_t cs[LF_NCLASS]; const lf_aln_prob *d_probs; const int *cstart; lf_seqs S; lf_hist_t *d_hist; uint64_t *d_aux;
+    uint8_t *d_ops; int32_t *d_ed, *d_end; uint32_t *d_len; int32_t *d_cols; const uint64_t *d_cols_off;
+};
+static void launch_classes(const lf_launch_ctx &L)
+{
+    auto cnt = [&](int c) { return L.cstart[c + 1] - L.cstart[c]; };
+    /* largest problems first: their few long-running waves start while the small classes fill the rest of the chip */
+#define DS(C, GV, KBV, KV) if (cnt(C) > 0) hipLaunchKernelGGL((lf_edlib_sweep_kernel<GV, KBV, KV>), dim3((unsigned)((cnt(C) + (64 / GV) - 1) / (64 / GV))), dim3(64), 0, L.cs[C], \
+        L.d_probs + L.cstart[C], cnt(C), L.S, L.d_hist, L.d_aux, L.d_ops, L.d_ed, L.d_end, L.d_len)
+    DS(11, 64, 8, 2); DS(10, 64, 4, 4); DS(9, 64, 1, 16);
+    if (cnt(0) > 0)
+        hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((cnt(0) + 63) / 64)), dim3(64), 0, L.cs[0],
+                           L.d_probs + L.cstart[0], cnt(0), L.S, L.d_hist, L.d_aux, L.d_ops, L.d_ed, L.d_end, L.d_len, L.d_cols, L.d_cols_off);
+    DS(8, 32, 1, 16); DS(7, 16, 1, 16);
+#undef DS
+#define DL(C, NBV) if (cnt(C) > 0) hipLaunchKernelGGL(lf_edlib_kernel<NBV>, dim3((unsigned)((cnt(C) + 63) / 64)), dim3(64), 0, L.cs[C], \
+        L.d_probs + L.cstart[C], cnt(C), L.S, L.d_hist, L.d_ops, L.d_ed, L.d_end, L.d_len)
+    DL(6, 8); DL(5, 6); DL(4, 4); DL(3, 3); DL(2, 2); DL(1, 1);
+#undef DL
+}
 
+/* runs DIST/PATH problems (cols == nullptr) or COLS problems (cols != nullptr; generic kernel only) given as byte strings */
 static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
                      const uint8_t *mode, const uint8_t *task, const uint8_t *rev, int32_t *ed, int32_t *endloc,
-                     uint8_t *ops, uint32_t *ops_len, int32_t *cols, const uint64_t *cols_off, float *ms,
-                     const lf_desc_src *D = nullptr)
+                     uint8_t *ops, uint32_t *ops_len, int32_t *cols, const uint64_t *cols_off, float *ms)
 {
     if (ms) *ms = 0;
     if (n == 0) return LF_OK;
     if (lfg_device_count() <= device) { lf_set_error("no gfx950 device %d visible (no CPU path)", device); return LF_ERR_NO_DEVICE; }
     HIPCHK(hipSetDevice(device));
-    const uint64_t qbytes = D ? 0 : qoff[n], tbytes = D ? 0 : toff[n];
-    const uint64_t ops_bytes = D ? D->ops_total : qbytes + tbytes;
-#define PN(i) (D ? D->d[i].n : (uint32_t)(qoff[(i) + 1] - qoff[i]))
-#define PM(i) (D ? D->d[i].m : (uint32_t)(toff[(i) + 1] - toff[i]))
-#define POPS(i) (D ? D->ops_off[i] : qoff[i] + toff[i])
+    const uint64_t qbytes = qoff[n], tbytes = toff[n];
+    const uint64_t ops_bytes = qbytes + tbytes;
+#define PN(i) ((uint32_t)(qoff[(i) + 1] - qoff[i]))
+#define PM(i) ((uint32_t)(toff[(i) + 1] - toff[i]))
 
-    /* bin + order */
-    std::vector<lf_aln_prob> P[7];     /* 0 generic lane kernel, 1..4 -> NB 1,2,4,8 lane classes, 5/6 wave kernel KB 1/4 */
+    /* bin + order (the descriptor path does the same on the device) */
+    std::vector<lf_aln_prob> P[LF_NCLASS];
     std::vector<int> trivial;          /* n == 0 or m == 0: no DP (lib/edlib/edlib.cpp:1096-1104) */
-    {
-        size_t c[7] = { 0, 0, 0, 0, 0, 0, 0 };
-        for (int i = 0; i < n; i++) {
-            const uint32_t nn = PN(i), mm = PM(i);
-            if (nn == 0 || (mm == 0 && !cols)) continue;
-            const int cls = cols ? 0 : class_nb(nn);
-            int slot = cls == 0 ? 0 : (cls == 1 ? 1 : cls == 2 ? 2 : cls == 4 ? 3 : 4);
-            if (slot == 0) slot = nn <= 4096 ? 5 : (nn <= 16384 ? 6 : 0);
-            c[slot]++;
-        }
-        for (int k = 0; k < 7; k++) P[k].reserve(c[k]);
-    }
     for (int i = 0; i < n; i++) {
         lf_aln_prob pr; memset(&pr, 0, sizeof pr);
-        pr.n = PN(i); pr.m = PM(i); pr.ops_off = POPS(i); pr.id = (uint32_t)i;
-        if (D) { pr.qstart = D->d[i].qstart; pr.tstart = D->d[i].tstart; pr.flags = (uint8_t)(D->d[i].flags | LF_F_TPAC); pr.mode = D->d[i].mode; pr.task = LF_TASK_PATH; }
-        else {
-            const bool rv = rev && rev[i];                    /* Hirschberg right half: both strings walked backwards */
-            pr.qstart = (int64_t)qoff[i] + (rv ? (int64_t)pr.n - 1 : 0); pr.tstart = (int64_t)toff[i] + (rv ? (int64_t)pr.m - 1 : 0);
-            pr.flags = rv ? (LF_F_QREV | LF_F_TREV) : 0;
-            pr.mode = mode ? mode[i] : 0; pr.task = cols ? LF_TASK_COLS : (task ? task[i] : LF_TASK_PATH);
-        }
+        pr.n = PN(i); pr.m = PM(i); pr.ops_off = qoff[i] + toff[i]; pr.id = (uint32_t)i;
+        const bool rv = rev && rev[i];                    /* Hirschberg right half: both strings walked backwards */
+        pr.qstart = (int64_t)qoff[i] + (rv ? (int64_t)pr.n - 1 : 0); pr.tstart = (int64_t)toff[i] + (rv ? (int64_t)pr.m - 1 : 0);
+        pr.flags = rv ? (LF_F_QREV | LF_F_TREV) : 0;
+        pr.mode = mode ? mode[i] : 0; pr.task = cols ? LF_TASK_COLS : (task ? task[i] : LF_TASK_PATH);
         if (pr.n == 0 || (pr.m == 0 && !cols)) { trivial.push_back(i); continue; }
-        const int cls = cols ? 0 : class_nb(pr.n);
-        int slot = cls == 0 ? 0 : (cls == 1 ? 1 : cls == 2 ? 2 : cls == 4 ? 3 : 4);
-        if (slot == 0) slot = pr.n <= 4096 ? 5 : (pr.n <= 16384 ? 6 : 0);
-        P[slot].push_back(pr);
+        P[cols ? 0 : lf_class_of(pr.n)].push_back(pr);
     }
-    static const int NBS[5] = { 0, 1, 2, 4, 8 };
+    int cstart[LF_NCLASS + 1]; cstart[0] = 0;
     size_t hist_entries = 0, aux_words = 0;
-    for (int k = 1; k <= 4; k++) {
+    for (int k = 0; k < LF_NCLASS; k++) {
         auto &v = P[k];
-        sort_by_m(v, false);
-        for (size_t w = 0; w < v.size(); w += 64) {
-            uint32_t mx = 0; bool any = false;
-            for (size_t j = w; j < std::min(v.size(), w + 64); j++) { if (v[j].task == LF_TASK_PATH) { any = true; mx = std::max(mx, v[j].m); } v[j].hist_base = hist_entries; }
-            if (any) hist_entries += (size_t)64 * mx * NBS[k];
+        sort_by_m(v);
+        cstart[k + 1] = cstart[k] + (int)v.size();
+        const size_t ppw = (size_t)lf_class_ppw(k);
+        for (size_t w = 0; w < v.size(); w += ppw) {
+            const size_t e = std::min(v.size(), w + ppw);
+            for (size_t j = w; j < e; j++) {
+                v[j].hist_base = hist_entries;
+                const uint64_t aw = lf_class_aux_words(k, v[j].n, v[j].m);
+                if (aw) { v[j].aux_off = aux_words; aux_words += aw; }
+            }
+            if (k == 0) { if (v[w].task == LF_TASK_PATH) hist_entries += (size_t)v[w].m * ((v[w].n + 63) / 64); }      /* one problem per "wave": full history */
+            else hist_entries += lf_class_wave_entries(k, v[e - 1].m);
         }
     }
-    for (int k : {0, 5, 6}) for (auto &pr : P[k]) {
-        const size_t nbk = (pr.n + 63) / 64;
-        if (k == 0) { pr.aux_off = aux_words; aux_words += nbk * 5; }
-        pr.hist_base = hist_entries;
-        if (pr.task == LF_TASK_PATH) hist_entries += ((size_t)pr.m + nbk) * nbk;     /* wave kernels: m + lanes - 1 rows */
-    }
-    for (int k : {5, 6}) sort_by_m(P[k], true);
-    std::sort(P[0].begin(), P[0].end(), [](const lf_aln_prob &a, const lf_aln_prob &b) {
-        const uint64_t wa = (uint64_t)((a.n + 63) / 64) * a.m, wb = (uint64_t)((b.n + 63) / 64) * b.m; return wa > wb; });
+    std::vector<lf_aln_prob> all; all.reserve((size_t)cstart[LF_NCLASS]);
+    for (int k = 0; k < LF_NCLASS; k++) all.insert(all.end(), P[k].begin(), P[k].end());
 
     size_t cols_total = 0;
     if (cols) for (int i = 0; i < n; i++) cols_total = std::max<size_t>(cols_total, cols_off[i] + PN(i) + 1);
 #define DSLOT(T, k, bytes) (T *)lfg_dev_slot(device, LF_DS_ALN0 + (k), (bytes))
-    unsigned char *d_q = D ? const_cast<unsigned char *>(D->d_reads) : DSLOT(unsigned char, 0, qbytes + 64);
+    unsigned char *d_q = DSLOT(unsigned char, 0, qbytes + 64);
     unsigned char *d_t = DSLOT(unsigned char, 1, tbytes + 64);
     lf_hist_t *d_hist = DSLOT(lf_hist_t, 2, hist_entries * sizeof(lf_hist_t) + 64);
     uint64_t *d_aux = DSLOT(uint64_t, 3, aux_words * 8 + 64);
@@ -654,42 +812,34 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     uint8_t *d_ops = cols ? nullptr : DSLOT(uint8_t, 7, ops_bytes + 64);
     int32_t *d_cols = cols ? DSLOT(int32_t, 8, cols_total * 4 + 16) : nullptr;
     uint64_t *d_cols_off = cols ? DSLOT(uint64_t, 9, (size_t)n * 8) : nullptr;
-    if (!d_q || !d_t || !d_hist || !d_aux || !d_ed || !d_end || !d_len || (!cols && !d_ops) || (cols && (!d_cols || !d_cols_off))) return LF_ERR_NOMEM;
-    lf_aln_prob *d_prob[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-    for (int k = 0; k < 7; k++) if (!P[k].empty()) { d_prob[k] = DSLOT(lf_aln_prob, 10 + k, P[k].size() * sizeof(lf_aln_prob)); if (!d_prob[k]) return LF_ERR_NOMEM; }
+    lf_aln_prob *d_probs = DSLOT(lf_aln_prob, 13, (all.size() + 1) * sizeof(lf_aln_prob));
+    if (!d_q || !d_t || !d_hist || !d_aux || !d_ed || !d_end || !d_len || !d_probs || (!cols && !d_ops) || (cols && (!d_cols || !d_cols_off))) return LF_ERR_NOMEM;
 #undef DSLOT
     /* the size classes run CONCURRENTLY on their own streams: the long-query classes have few, long waves and
      * would leave most CUs idle if the kernels ran back to back */
-    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1), cs[7];
-    static hipEvent_t cdone_all[32][7]; static bool cdone_init[32] = { false };
+    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
+    static hipEvent_t cdone_all[32][LF_NCLASS], tev_all[32][2]; static bool cdone_init[32] = { false };
     const int lane_id = lfg_get_lane();
     if (!s) return LF_ERR_HIP;
-    for (int k = 0; k < 7; k++) { cs[k] = (hipStream_t)lfg_lane_stream(device, 2 + k); if (!cs[k]) return LF_ERR_HIP; }
-    if (!cdone_init[lane_id]) { for (int k = 0; k < 7; k++) HIPCHK(hipEventCreateWithFlags(&cdone_all[lane_id][k], hipEventDisableTiming)); cdone_init[lane_id] = true; }
-    hipEvent_t *cdone = cdone_all[lane_id];
-    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    if (!D) {
-        HIPCHK(hipMemcpyAsync(d_q, q, qbytes, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(d_t, t, tbytes, hipMemcpyHostToDevice, s));
+    lf_launch_ctx L;
+    for (int k = 0; k < LF_NCLASS; k++) { L.cs[k] = (hipStream_t)lfg_lane_stream(device, 2 + k); if (!L.cs[k]) return LF_ERR_HIP; }
+    if (!cdone_init[lane_id]) {
+        for (int k = 0; k < LF_NCLASS; k++) HIPCHK(hipEventCreateWithFlags(&cdone_all[lane_id][k], hipEventDisableTiming));
+        HIPCHK(hipEventCreate(&tev_all[lane_id][0])); HIPCHK(hipEventCreate(&tev_all[lane_id][1]));
+        cdone_init[lane_id] = true;
     }
-    lf_seqs S; S.q = d_q; S.t = d_t; S.pac = D ? D->d_pac : nullptr;
+    hipEvent_t *cdone = cdone_all[lane_id], e0 = tev_all[lane_id][0], e1 = tev_all[lane_id][1];
+    HIPCHK(hipMemcpyAsync(d_q, q, qbytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_t, t, tbytes, hipMemcpyHostToDevice, s));
     if (cols) HIPCHK(hipMemcpyAsync(d_cols_off, cols_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(d_len, 0, (size_t)n * 4, s));
-    for (int k = 0; k < 7; k++) if (!P[k].empty())
-        HIPCHK(hipMemcpyAsync(d_prob[k], P[k].data(), P[k].size() * sizeof(lf_aln_prob), hipMemcpyHostToDevice, s));
+    if (!all.empty()) HIPCHK(hipMemcpyAsync(d_probs, all.data(), all.size() * sizeof(lf_aln_prob), hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(e0, s));
-    for (int k = 0; k < 7; k++) if (!P[k].empty()) HIPCHK(hipStreamWaitEvent(cs[k], e0, 0));
-    /* longest-running classes first */
-#define LAUNCH_WAVE(K, KBV) if (!P[K].empty()) hipLaunchKernelGGL(lf_edlib_wave_kernel<KBV>, dim3((unsigned)P[K].size()), dim3(64), 0, cs[K], \
-        d_prob[K], (int)P[K].size(), S, d_hist, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off)
-    LAUNCH_WAVE(6, 4); LAUNCH_WAVE(5, 1);
-    if (!P[0].empty())
-        hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((P[0].size() + 63) / 64)), dim3(64), 0, cs[0],
-                           d_prob[0], (int)P[0].size(), S, d_hist, d_aux, d_ops, d_ed, d_end, d_len, d_cols, d_cols_off);
-#define LAUNCH_CLASS(K, NBV) if (!P[K].empty()) hipLaunchKernelGGL(lf_edlib_kernel<NBV>, dim3((unsigned)((P[K].size() + 63) / 64)), dim3(64), 0, cs[K], \
-        d_prob[K], (int)P[K].size(), S, d_hist, d_ops, d_ed, d_end, d_len)
-    LAUNCH_CLASS(4, 8); LAUNCH_CLASS(3, 4); LAUNCH_CLASS(2, 2); LAUNCH_CLASS(1, 1);
-    for (int k = 0; k < 7; k++) if (!P[k].empty()) { HIPCHK(hipEventRecord(cdone[k], cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
+    for (int k = 0; k < LF_NCLASS; k++) if (!P[k].empty()) HIPCHK(hipStreamWaitEvent(L.cs[k], e0, 0));
+    L.d_probs = d_probs; L.cstart = cstart; L.S.q = d_q; L.S.t = d_t; L.S.pac = nullptr; L.d_hist = d_hist; L.d_aux = d_aux;
+    L.d_ops = d_ops; L.d_ed = d_ed; L.d_end = d_end; L.d_len = d_len; L.d_cols = d_cols; L.d_cols_off = d_cols_off;
+    launch_classes(L);
+    for (int k = 0; k < LF_NCLASS; k++) if (!P[k].empty()) { HIPCHK(hipEventRecord(cdone[k], L.cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
     HIPCHK(hipEventRecord(e1, s));
     if (cols) HIPCHK(hipMemcpyAsync(cols, d_cols, cols_total * 4, hipMemcpyDeviceToHost, s));
     else {
@@ -701,14 +851,13 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 
     /* degenerate problems: one side empty -> pure insertion / deletion run (lib/edlib/edlib.cpp:1096-1104) */
     for (int i : trivial) {
         const uint32_t nn = PN(i), mm = PM(i);
         if (cols) { int32_t *oc = cols + cols_off[i]; oc[0] = (int32_t)mm; continue; }   /* n == 0 */
-        const int md = D ? D->d[i].mode : (mode ? mode[i] : 0);
-        uint8_t *o = ops + POPS(i);
+        const int md = mode ? mode[i] : 0;
+        uint8_t *o = ops + qoff[i] + toff[i];
         const uint32_t cap = nn + mm;
         if (nn == 0) {
             /* NW: delete the whole target; SHW: the empty prefix is optimal */
@@ -718,33 +867,24 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
         } else { ed[i] = (int32_t)nn; endloc[i] = -1; ops_len[i] = nn; for (uint32_t j = 0; j < nn; j++) o[cap - nn + j] = 1; }
         if (task && task[i] == LF_TASK_DIST) ops_len[i] = 0;
     }
+    if (!cols) for (int i = 0; i < n; i++) if (ed[i] == -2) { lf_set_error("edlib kernel: no Hirschberg split row for problem %d (n %u, m %u)", i, PN(i), PM(i)); return LF_ERR_HIP; }
 #undef PN
 #undef PM
-#undef POPS
     return LF_OK;
 }
 
 /* ------------------------------------------------------------------------------------------------
  * descriptor batches are binned, ordered and laid out ON THE GPU: key = (size class, target length), one radix
- * sort, one scan for the history bases, one kernel that writes the per-class problem arrays.  The host uploads
+ * sort, one scan for the checkpoint bases, one kernel that writes the per-class problem arrays.  The host uploads
  * 32-byte descriptors and launches; it does no per-problem work.
  * ---------------------------------------------------------------------------------------------- */
-#define LF_NCLASS 11
-/* launch classes: 0 generic lane kernel ; 1..6 lane kernels NB 1,2,3,4,6,8 ; 7,8 group kernels G 16,32 ; 9,10 wave kernels KB 1,4 */
-__host__ __device__ __forceinline__ int lf_class_nb(int c) { return c == 1 ? 1 : c == 2 ? 2 : c == 3 ? 3 : c == 4 ? 4 : c == 5 ? 6 : 8; }
-__device__ __forceinline__ int lf_desc_class(uint32_t n)
-{
-    const uint32_t nb = (n + 63) >> 6;
-    if (nb <= 1) return 1; if (nb <= 2) return 2; if (nb <= 3) return 3; if (nb <= 4) return 4; if (nb <= 6) return 5; if (nb <= 8) return 6;
-    if (nb <= 16) return 7; if (nb <= 32) return 8;
-    if (n <= 4096) return 9; if (n <= 16384) return 10;
-    return 0;
-}
+struct lf_desc_src { const lf_aln_desc_t *d; const uint64_t *ops_off; uint64_t ops_total; const unsigned char *d_reads; const uint8_t *d_pac; };
+
 __global__ void lf_desc_keys_kernel(const lf_aln_desc_t *__restrict__ d, int n, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    keys[i] = ((uint64_t)lf_desc_class(d[i].n) << 32) | d[i].m;
+    keys[i] = ((uint64_t)lf_class_of(d[i].n) << 32) | d[i].m;
     vals[i] = (uint32_t)i;
 }
 __global__ void lf_desc_bounds_kernel(const uint64_t *__restrict__ keys, int n, int *__restrict__ cstart /* LF_NCLASS + 1 */)
@@ -756,21 +896,22 @@ __global__ void lf_desc_bounds_kernel(const uint64_t *__restrict__ keys, int n, 
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
     cstart[c] = lo;
 }
+/* checkpoint entries are charged to the first problem of every wave */
 __global__ void lf_desc_entries_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const lf_aln_desc_t *__restrict__ d,
                                        const int *__restrict__ cstart, int n, uint64_t *__restrict__ ent)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int c = (int)(keys[j] >> 32);
-    uint64_t e;
-    if (c >= 1 && c <= 6) {
-        const int rel = j - cstart[c];
-        if (rel & 63) e = 0;
-        else {      /* first lane of a wave: the wave's history holds 64 x (largest m of the wave) x NB entries */
-            int last = j + 63; if (last > cstart[c + 1] - 1) last = cstart[c + 1] - 1;
-            e = 64ull * (uint32_t)keys[last] * (uint32_t)lf_class_nb(c);
+    uint64_t e = 0;
+    if (c == 0) { const uint32_t nb = (d[vals[j]].n + 63) >> 6; e = (uint64_t)(uint32_t)keys[j] * nb; }      /* full history: m rows of nb entries */
+    else {
+        const int ppw = lf_class_ppw(c), rel = j - cstart[c];
+        if (rel % ppw == 0) {
+            int last = j + ppw - 1; if (last > cstart[c + 1] - 1) last = cstart[c + 1] - 1;
+            e = lf_class_wave_entries(c, (uint32_t)keys[last]);
         }
-    } else { const uint32_t nb = (d[vals[j]].n + 63) >> 6; e = ((uint64_t)(uint32_t)keys[j] + nb) * nb; }      /* m + lanes - 1 rows of nb entries */
+    }
     ent[j] = e;
 }
 __global__ void lf_desc_build_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const lf_aln_desc_t *__restrict__ d,
@@ -785,10 +926,11 @@ __global__ void lf_desc_build_kernel(const uint64_t *__restrict__ keys, const ui
     lf_aln_prob p;
     p.qstart = x.qstart; p.tstart = x.tstart; p.ops_off = ops_off[i];
     int jb = j;
-    if (c >= 1 && c <= 6) jb = cstart[c] + ((j - cstart[c]) & ~63);
+    if (c != 0) { const int ppw = lf_class_ppw(c); jb = cstart[c] + ((j - cstart[c]) / ppw) * ppw; }
     p.hist_base = base[jb];
     p.aux_off = 0;
-    if (c == 0) p.aux_off = atomicAdd((unsigned long long *)aux_words_total, (unsigned long long)(((x.n + 63) >> 6) * 5));
+    const uint64_t aw = lf_class_aux_words(c, x.n, x.m);
+    if (aw) p.aux_off = atomicAdd((unsigned long long *)aux_words_total, (unsigned long long)aw);
     p.n = x.n; p.m = x.m; p.id = i; p.mode = x.mode; p.task = LF_TASK_PATH; p.flags = (uint8_t)(x.flags | LF_F_TPAC); p.pad = 0;
     probs[j] = p;
 }
@@ -799,14 +941,20 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     if (ms) *ms = 0;
     if (n == 0) return LF_OK;
     HIPCHK(hipSetDevice(device));
-    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1), cs[LF_NCLASS];
-    static hipEvent_t cdone_all[32][LF_NCLASS]; static bool cdone_init[32] = { false };
+    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
+    static hipEvent_t cdone_all[32][LF_NCLASS], tev_all[32][3]; static bool cdone_init[32] = { false };
     const int lane_id = lfg_get_lane();
     if (!s) return LF_ERR_HIP;
     static const bool serial_classes = getenv("LF_SERIAL_CLASSES") != nullptr;     /* profiling aid: one class at a time */
-    for (int k = 0; k < LF_NCLASS; k++) { cs[k] = serial_classes ? s : (hipStream_t)lfg_lane_stream(device, 2 + k); if (!cs[k]) return LF_ERR_HIP; }
-    if (!cdone_init[lane_id]) { for (int k = 0; k < LF_NCLASS; k++) HIPCHK(hipEventCreateWithFlags(&cdone_all[lane_id][k], hipEventDisableTiming)); cdone_init[lane_id] = true; }
-    hipEvent_t *cdone = cdone_all[lane_id];
+    lf_launch_ctx L;
+    for (int k = 0; k < LF_NCLASS; k++) { L.cs[k] = serial_classes ? s : (hipStream_t)lfg_lane_stream(device, 2 + k); if (!L.cs[k]) return LF_ERR_HIP; }
+    if (!cdone_init[lane_id]) {
+        for (int k = 0; k < LF_NCLASS; k++) HIPCHK(hipEventCreateWithFlags(&cdone_all[lane_id][k], hipEventDisableTiming));
+        HIPCHK(hipEventCreate(&tev_all[lane_id][0])); HIPCHK(hipEventCreate(&tev_all[lane_id][1]));
+        HIPCHK(hipEventCreateWithFlags(&tev_all[lane_id][2], hipEventDisableTiming));
+        cdone_init[lane_id] = true;
+    }
+    hipEvent_t *cdone = cdone_all[lane_id], e0 = tev_all[lane_id][0], e1 = tev_all[lane_id][1], eb = tev_all[lane_id][2];
 #define DSLOT(T, k, bytes) (T *)lfg_dev_slot(device, LF_DS_ALN0 + (k), (bytes))
     /* the descriptors stay with the round's paths when those stay in HBM (lazy paths are resolved against them later) */
     lf_aln_desc_t *d_desc = ops ? DSLOT(lf_aln_desc_t, 0, (size_t)n * sizeof(lf_aln_desc_t))
@@ -829,7 +977,6 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, d_ent, d_base, n, s);
     void *d_tmp = lfg_dev_slot(device, LF_DS_ALN0 + 16, std::max(tb1, tb2) + 256);
     if (!d_tmp) return LF_ERR_NOMEM;
-    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
 
     HIPCHK(hipMemcpyAsync(d_desc, D->d, (size_t)n * sizeof(lf_aln_desc_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_opsoff, D->ops_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
@@ -853,25 +1000,13 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     uint64_t *d_aux = DSLOT(uint64_t, 17, aux_total * 8 + 64);
     if (!d_hist || !d_aux) return LF_ERR_NOMEM;
 #undef DSLOT
-    lf_seqs S; S.q = D->d_reads; S.t = nullptr; S.pac = D->d_pac;
-    hipEvent_t eb; HIPCHK(hipEventCreateWithFlags(&eb, hipEventDisableTiming));
     HIPCHK(hipEventRecord(eb, s));
     auto cnt = [&](int c) { return cstart[c + 1] - cstart[c]; };
-    for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0) HIPCHK(hipStreamWaitEvent(cs[k], eb, 0));
-    /* largest problems first: their few long-running waves start while the small classes fill the rest of the chip */
-#define DW(K, KBV) if (cnt(K) > 0) hipLaunchKernelGGL(lf_edlib_wave_kernel<KBV>, dim3((unsigned)cnt(K)), dim3(64), 0, cs[K], \
-        d_probs + cstart[K], cnt(K), S, d_hist, d_ops, d_ed, d_end, d_len, (int32_t *)nullptr, (const uint64_t *)nullptr)
-    DW(10, 4); DW(9, 1);
-    if (cnt(0) > 0)
-        hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((cnt(0) + 63) / 64)), dim3(64), 0, cs[0],
-                           d_probs + cstart[0], cnt(0), S, d_hist, d_aux, d_ops, d_ed, d_end, d_len, (int32_t *)nullptr, (const uint64_t *)nullptr);
-#define DG(K, GV) if (cnt(K) > 0) hipLaunchKernelGGL(lf_edlib_group_kernel<GV>, dim3((unsigned)((cnt(K) + (64 / GV) - 1) / (64 / GV))), dim3(64), 0, cs[K], \
-        d_probs + cstart[K], cnt(K), S, d_hist, d_ops, d_ed, d_end, d_len)
-    DG(8, 32); DG(7, 16);
-#define DL(K, NBV) if (cnt(K) > 0) hipLaunchKernelGGL(lf_edlib_kernel<NBV>, dim3((unsigned)((cnt(K) + 63) / 64)), dim3(64), 0, cs[K], \
-        d_probs + cstart[K], cnt(K), S, d_hist, d_ops, d_ed, d_end, d_len)
-    DL(6, 8); DL(5, 6); DL(4, 4); DL(3, 3); DL(2, 2); DL(1, 1);
-    for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0) { HIPCHK(hipEventRecord(cdone[k], cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
+    for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && L.cs[k] != s) HIPCHK(hipStreamWaitEvent(L.cs[k], eb, 0));
+    L.d_probs = d_probs; L.cstart = cstart; L.S.q = D->d_reads; L.S.t = nullptr; L.S.pac = D->d_pac; L.d_hist = d_hist; L.d_aux = d_aux;
+    L.d_ops = d_ops; L.d_ed = d_ed; L.d_end = d_end; L.d_len = d_len; L.d_cols = nullptr; L.d_cols_off = nullptr;
+    launch_classes(L);
+    for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && L.cs[k] != s) { HIPCHK(hipEventRecord(cdone[k], L.cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipMemcpyAsync(ed, d_ed, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(endloc, d_end, (size_t)n * 4, hipMemcpyDeviceToHost, s));
@@ -880,7 +1015,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(eb);
+    if (cnt(9) + cnt(10) + cnt(11) > 0) for (int i = 0; i < n; i++) if (ed[i] == -2) { lf_set_error("edlib kernel: no Hirschberg split row for descriptor %d (n %u, m %u)", i, D->d[i].n, D->d[i].m); return LF_ERR_HIP; }
     return LF_OK;
 }
 
@@ -895,14 +1030,14 @@ extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_des
     D.d_pac = st->view.pac;
     if (!D.d_reads) { lf_set_error("lfg_edlib_desc: no resident read batch"); return LF_ERR_ARG; }
     for (int i = 0; i < n; i += 4096) if (d[i].n == 0 || d[i].m == 0) { lf_set_error("lfg_edlib_desc: empty sequence in a descriptor"); return LF_ERR_ARG; }
-    if (getenv("LF_HIST_STATS")) {       /* debug: where the traceback-history bytes are (by ceil(n/64)) */
+    if (getenv("LF_HIST_STATS")) {       /* debug: where the DP cells are (by ceil(n/64)) */
         uint64_t cnt[12] = { 0 }, cells[12] = { 0 }, hist[12] = { 0 };
         static const uint32_t edge[12] = { 1, 2, 3, 4, 5, 6, 8, 12, 16, 32, 64, 256 };
         for (int i = 0; i < n; i++) {
             const uint32_t nb = (d[i].n + 63) >> 6; int c = 0; while (c < 11 && nb > edge[c]) c++;
-            cnt[c]++; cells[c] += (uint64_t)d[i].n * d[i].m; hist[c] += (uint64_t)nb * d[i].m * 16;
+            cnt[c]++; cells[c] += (uint64_t)d[i].n * d[i].m; hist[c] += (uint64_t)nb * d[i].m;
         }
-        for (int c = 0; c < 12; c++) if (cnt[c]) fprintf(stderr, "[lf] hist nb<=%u: %llu problems, %.1f Mcells, %.1f MB exact history\n", edge[c], (unsigned long long)cnt[c], cells[c] / 1e6, hist[c] / 1e6);
+        for (int c = 0; c < 12; c++) if (cnt[c]) fprintf(stderr, "[lf] dp nb<=%u: %llu problems, %.1f Mcells, %.2f M block steps\n", edge[c], (unsigned long long)cnt[c], cells[c] / 1e6, hist[c] / 1e6);
     }
     return run_edlib_desc_gpu(ix->device, n, &D, ed, endloc, ops, ops_len, ops_slot, ops_dev, desc_dev, ms);
 }

@@ -124,6 +124,9 @@ int lfg_upload(int device, void *dst_dev, const void *src, size_t bytes);
 #define LF_TASK_PATH 0
 #define LF_TASK_DIST 1
 
+/* longest query the sweep kernels of lf_align.hip take (64 lanes x 8 blocks x 64 rows); they run edlib's Hirschberg
+ * recursion on the device.  Longer queries use the generic kernel and the host-driven splits of lf_stages.c. */
+#define LF_SWEEP_MAX_N 32768
 /* edlib's own leaf/Hirschberg switch (lib/edlib/edlib.cpp:1117-1119) */
 static inline int lf_is_leaf(int64_t n, int64_t m) { return 20LL * ((n + 63) / 64) * m + 8LL * m < 1024 * 1024; }
 

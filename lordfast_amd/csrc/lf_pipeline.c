@@ -769,8 +769,10 @@ static edres_t need_edlib(walk_t *w, int qrc, uint32_t qs, uint32_t qseg, uint32
     memo_t *m = memo_find(w->job, &k);
     if (!m) {
         m = memo_add(w->job, &k, &w->cx->arena[w->tid]);
-        if (lf_is_leaf(qn, tn) && qn > 0 && tn > 0) { stage_edlib_desc(w, m); jv_push(&w->cx->edd_jobs[w->tid], w->job); }
-        else { stage_edlib(w, m); jv_push(&w->cx->ed_jobs[w->tid], w->job); }      /* Hirschberg-size: byte strings */
+        /* every request is a descriptor (Hirschberg-size ones included: the sweep kernels recurse on the device);
+         * only queries beyond LF_SWEEP_MAX_N fall back to byte strings and the host-driven splits */
+        if (qn > 0 && tn > 0 && qn <= LF_SWEEP_MAX_N) { stage_edlib_desc(w, m); jv_push(&w->cx->edd_jobs[w->tid], w->job); }
+        else { stage_edlib(w, m); jv_push(&w->cx->ed_jobs[w->tid], w->job); }
     }
     if (m->round < 0) { w->missing++; w->build = 0; r.ed = 0; r.end = (mode == 0) ? (int)tn - 1 : (int)tn - 1; return r; }
     const ed_round_t *R = &w->cx->ed_rounds[m->round];

@@ -82,7 +82,9 @@ int lf_edlib_solve(int device, int n, const char *q, const uint64_t *qoff, const
     int n_big = 0;
     for (int i = 0; i < n; i++) {
         int64_t nn = (int64_t)(qoff[i + 1] - qoff[i]), mm = (int64_t)(toff[i + 1] - toff[i]);
-        task[i] = lf_is_leaf(nn, mm) ? LF_TASK_PATH : LF_TASK_DIST;
+        /* the kernels run edlib's Hirschberg recursion themselves for queries up to LF_SWEEP_MAX_N; only longer ones
+         * are split from here (distance first, then column-score requests level by level) */
+        task[i] = (nn <= LF_SWEEP_MAX_N || lf_is_leaf(nn, mm)) ? LF_TASK_PATH : LF_TASK_DIST;
         n_big += task[i] == LF_TASK_DIST;
     }
     rc = lfg_edlib(device, n, q, qoff, t, toff, mode, task, ed, endloc, ops, ops_len, &ms);

@@ -93,6 +93,52 @@ def test_edlib_fuzz_vs_oracle(oracle_lib):
         assert np.array_equal(r[2], o[2]), (i, len(qs[i]), len(ts[i]), modes[i])
 
 
+def test_edlib_checkpoint_tiles_and_device_hirschberg(oracle_lib):
+    """shapes aimed at the recompute-from-checkpoint traceback and the on-device Hirschberg recursion of lf_align.hip:
+    tile boundaries (m around multiples of 8 / 16), paths that climb > 64 rows inside one 8-column tile (the LDS window of
+    the lane classes moves), every size class (lane NB 1..8, groups of 16 / 32 lanes, wave KB 1 / 4 / 8), targets longer
+    than the LDS ring, tall-and-thin / short-and-wide leaves, several recursion levels, SHW roots whose prefix is a leaf"""
+    import lordfast_amd as la
+    orc = oracle_lib.Oracle()
+    rng = np.random.default_rng(77)
+    qs, ts, modes = [], [], []
+
+    def add(q, t, both=True):
+        for mode in ((0, 1) if both else (0,)):
+            qs.append(bytes(q)); ts.append(bytes(t) + (rseq(rng, 7) if mode else b"")); modes.append(mode)
+
+    for m in list(range(1, 20)) + [23, 24, 25, 31, 32, 33, 63, 64, 65, 127, 128, 129]:          # tile edges, lane classes
+        for n in (5, 64, 65, 130, 200, 300, 420, 512):
+            q = rseq(rng, n); t = synth.mutate(np.frombuffer(q, dtype=np.uint8), 0.2, rng).tobytes()[:m] or b"A"
+            add(q, t)
+    for n, ins_at, ins_len in ((300, 10, 180), (500, 3, 400), (200, 100, 90), (512, 250, 200), (128, 5, 100)):   # big insertions: window exits
+        t = rseq(rng, n - ins_len)
+        q = t[:ins_at] + rseq(rng, ins_len) + t[ins_at:]
+        add(q, t)
+        add(t, q)                                                                                  # and big deletions
+    for n in (513, 640, 1000, 1024, 1025, 1500, 2048, 2049, 3000, 4096, 4097, 6000):               # group / wave classes, leaf size
+        q = np.frombuffer(rseq(rng, n), dtype=np.uint8)
+        m_cap = max(40, (1 << 20) // (20 * ((n + 63) // 64) + 8) - 30)                             # stay below edlib's traceback switch
+        t = synth.mutate(q, float(rng.uniform(0.05, 0.3)), rng)[:m_cap]
+        add(q.tobytes(), t.tobytes())
+    add(rseq(rng, 3000), rseq(rng, 45))                                                            # tall and thin
+    add(rseq(rng, 45), rseq(rng, 5000))                                                            # short and wide (target longer than the LDS ring of its class)
+    add(rseq(rng, 700), rseq(rng, 3000))                                                           # group class, ring refills
+    for n, e in ((2500, 0.12), (5000, 0.15), (5000, 0.45), (9000, 0.1), (17000, 0.08)):            # Hirschberg on the device: 1-4 levels, KB 1 / 4 / 8
+        q = np.frombuffer(rseq(rng, n), dtype=np.uint8)
+        t = synth.mutate(q, e, rng)
+        add(q.tobytes(), t.tobytes(), both=(n <= 5000))
+    q = rseq(rng, 2600)                                                                             # SHW: (n, m) above the switch, (n, end) below it
+    qs.append(q); ts.append(synth.mutate(np.frombuffer(q[:900], dtype=np.uint8), 0.1, rng).tobytes() + rseq(rng, 3000)); modes.append(1)
+    q = rseq(rng, 2100); t = b"AC" * 1200 + q[1000:] + b"GT" * 900                                  # low complexity: many co-optimal paths, tie rules decide
+    add(q, t)
+    res, ms = la.edlib_batch(qs, ts, modes)
+    for i, r in enumerate(res):
+        o = orc.edlib(qs[i], ts[i], modes[i])
+        assert (r[0], r[1]) == (o[0], o[1]), (i, len(qs[i]), len(ts[i]), modes[i])
+        assert np.array_equal(r[2], o[2]), (i, len(qs[i]), len(ts[i]), modes[i])
+
+
 def test_edlib_empty_batch():
     import lordfast_amd as la
     res, _ = la.edlib_batch([], [], [])
