@@ -17,6 +17,7 @@
 #include <hipcub/hipcub.hpp>
 #include "lf_gpu_common.h"
 #include <algorithm>
+#include <type_traits>
 #include <string.h>
 #include <vector>
 #include <numeric>
@@ -37,57 +38,76 @@ struct lf_aln_prob {
 
 struct lf_hist_t { uint64_t pv, ph; };
 
-__device__ __forceinline__ int lf_hin_neg(int h) { return h < 0; }
-
-/* one Myers block step. Pv/Mv in-out; returns hout; ph_out = horizontal +1 bits (unshifted) */
-__device__ __forceinline__ int lf_myers_step(uint64_t &Pv, uint64_t &Mv, uint64_t Eq, int hin, uint64_t &ph_out, uint64_t &mh_out)
+/* one Myers block step. Pv/Mv in-out.  The horizontal delta entering / leaving the block travels as two bits:
+ * bit 0 = +1, bit 1 = -1 (no compares, no sign handling on the per-step dependency chain).  ph_out / mh_out =
+ * horizontal +1 / -1 bits of the block's rows (unshifted). */
+__device__ __forceinline__ uint32_t lf_myers_step(uint64_t &Pv, uint64_t &Mv, uint64_t Eq, uint32_t hin, uint64_t &ph_out, uint64_t &mh_out)
 {
-    const uint64_t hneg = hin < 0 ? 1ull : 0ull, hpos = hin > 0 ? 1ull : 0ull;
+    const uint64_t hpos = hin & 1u, hneg = hin >> 1;
     const uint64_t Xv = Eq | Mv;
     Eq |= hneg;
     const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
     uint64_t Ph = Mv | ~(Xh | Pv);
     uint64_t Mh = Pv & Xh;
     ph_out = Ph; mh_out = Mh;
-    const int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+    const uint32_t hout = (uint32_t)(Ph >> 63) | ((uint32_t)(Mh >> 63) << 1);
     Ph = (Ph << 1) | hpos;
     Mh = (Mh << 1) | hneg;
     Pv = Mh | ~(Xv | Ph);
     Mv = Ph & Xv;
     return hout;
 }
+#define LF_HIN_PLUS1 1u          /* first block of a column: the row above the matrix grows by one per column */
+/* +1 / 0 / -1 of a two-bit delta at bit `bit` of (ph, mh) */
+__device__ __forceinline__ int lf_delta_at(uint64_t ph, uint64_t mh, int bit) { return (int)((ph >> bit) & 1) - (int)((mh >> bit) & 1); }
 
 /* bit planes of 64 query bytes: uppercase A,C,G,T -> (lo,hi) code + valid; anything else never equals a
  * target base (edlib compares raw bytes, lib/edlib/edlib.cpp:1367-1384; the target comes from the 2-bit
- * reference and is upper case) */
+ * reference and is upper case).  Branch-free (lf_code_upper). */
 __device__ __forceinline__ void lf_plane_add(unsigned char ch, int bit, uint64_t &lo, uint64_t &hi, uint64_t &valid)
 {
-    int c;
-    switch (ch) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break; default: c = -1; }
-    if (c >= 0) { lo |= (uint64_t)(c & 1) << bit; hi |= (uint64_t)(c >> 1) << bit; valid |= 1ull << bit; }
+    bool ok;
+    const uint32_t c = lf_code_upper(ch, ok);
+    const uint64_t v = ok ? 1ull : 0ull;
+    lo |= (v & (c & 1u)) << bit; hi |= (v & (c >> 1)) << bit; valid |= v << bit;
 }
 
-/* Eq mask of target byte tc against a block; tc outside ACGT: exact byte compare (general alphabets) */
-__device__ __forceinline__ uint64_t lf_eq_mask(unsigned char tc, uint64_t lo, uint64_t hi, uint64_t valid,
-                                               const lf_qacc &Q, uint32_t n, uint32_t blk)
+/* A target symbol inside the DP loops is a 32-bit token: bits 1:0 = code, bit 8 = "not one of ACGT", bits 23:16 = the raw
+ * byte.  Targets of the mapping pipeline come from the 2-bit reference: always a bare code (template PAC). */
+__device__ __forceinline__ uint32_t lf_tok_of_byte(unsigned char ch)
 {
-    int c;
-    switch (tc) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break; default: c = -1; }
-    if (c >= 0) {
-        const uint64_t slo = (c & 1) ? ~0ull : 0ull, shi = (c & 2) ? ~0ull : 0ull;
-        return ~((lo ^ slo) | (hi ^ shi)) & valid;
-    }
-    uint64_t e = 0;
-    for (uint32_t i = 0; i < 64; i++) {
-        const uint32_t r = blk * 64 + i;
-        if (r < n && Q.get(r) == tc) e |= 1ull << i;
+    bool ok;
+    const uint32_t c = lf_code_upper(ch, ok);
+    return c | (ok ? 0u : 0x100u) | ((uint32_t)ch << 16);
+}
+template <bool PAC>
+__device__ __forceinline__ uint32_t lf_tok(const lf_tacc &T, uint32_t i) { return PAC ? T.pac_code(i) : lf_tok_of_byte(T.get(i)); }
+/* Eq mask of a token against a block: three ops per word from the bit planes; a byte outside ACGT takes the exact
+ * compare (general alphabets of the stage API; never on the pipeline path) */
+template <bool PAC, class QG>
+__device__ __forceinline__ uint64_t lf_eq_tok(uint32_t tok, uint64_t lo, uint64_t hi, uint64_t valid, const QG &qget, uint32_t n, uint32_t blk)
+{
+    const uint64_t slo = 0ull - (uint64_t)(tok & 1u), shi = 0ull - (uint64_t)((tok >> 1) & 1u);
+    uint64_t e = ~((lo ^ slo) | (hi ^ shi)) & valid;
+    if (!PAC) {
+        if (tok & 0x100u) {
+            const unsigned char tc = (unsigned char)(tok >> 16);
+            e = 0;
+            for (uint32_t i = 0; i < 64; i++) {
+                const uint32_t r = blk * 64 + i;
+                if (r < n && qget(r) == tc) e |= 1ull << i;
+            }
+        }
     }
     return e;
 }
-
-/* ------------------------------------------------------------------------------------------------
- * register-resident classes: NB blocks per column
- * ---------------------------------------------------------------------------------------------- */
+/* the generic kernel's form: raw byte */
+__device__ __forceinline__ uint64_t lf_eq_mask(unsigned char tc, uint64_t lo, uint64_t hi, uint64_t valid,
+                                               const lf_qacc &Q, uint32_t n, uint32_t blk)
+{
+    auto qg = [&](uint32_t r) -> unsigned char { return Q.get(r); };
+    return lf_eq_tok<false>(lf_tok_of_byte(tc), lo, hi, valid, qg, n, blk);
+}
 
 /* edlib's own leaf / Hirschberg switch (lib/edlib/edlib.cpp:1117-1119), callable on the device */
 __host__ __device__ __forceinline__ bool lf_leaf(int64_t n, int64_t m) { return 20LL * ((n + 63) / 64) * m + 8LL * m < 1024 * 1024; }
@@ -110,13 +130,13 @@ __device__ __forceinline__ uint32_t lf_wave_max_u32(uint32_t v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(v, o); v = x > v ? x : v; }
-    return v;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);        /* the same in every lane: let loop bounds live in SGPRs */
 }
 __device__ __forceinline__ int lf_wave_max_i32(int v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(v, o); v = x > v ? x : v; }
-    return v;
+    return __builtin_amdgcn_readfirstlane(v);
 }
 
 /* ops leave in 8-byte words: bytes are collected in `acc` and stored when the (descending) address reaches an 8-byte
@@ -143,28 +163,22 @@ struct lf_emitter {
     }
 };
 
-/* Eq mask with the query given by a functor (sub-problems of the Hirschberg recursion walk offset / reversed strings) */
-template <class QG>
-__device__ __forceinline__ uint64_t lf_eq_mask_f(unsigned char tc, uint64_t lo, uint64_t hi, uint64_t valid, const QG &qget, uint32_t n, uint32_t blk)
-{
-    int c;
-    switch (tc) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break; default: c = -1; }
-    if (c >= 0) {
-        const uint64_t slo = (c & 1) ? ~0ull : 0ull, shi = (c & 2) ? ~0ull : 0ull;
-        return ~((lo ^ slo) | (hi ^ shi)) & valid;
-    }
-    uint64_t e = 0;
-    for (uint32_t i = 0; i < 64; i++) {
-        const uint32_t r = blk * 64 + i;
-        if (r < n && qget(r) == tc) e |= 1ull << i;
-    }
-    return e;
-}
-
 /* ------------------------------------------------------------------------------------------------
  * register-resident classes: ONE LANE PER PROBLEM, NB blocks per column (n <= 64 NB)
+ *
+ * The blocks of one column depend on each other through the horizontal carry, and a block depends on itself one
+ * column earlier: one lane alone is a single dependent chain.  Walking the lane's OWN blocks as an anti-diagonal
+ * (time step t: block b works on column t - b, taking the carry block b-1 produced one time step earlier) makes the
+ * NB block steps of a time step independent: NB-way ILP per lane.
+ *
+ * The time loop carries NO per-lane control flow.  t and b are wave-uniform, so "block b has not started yet"
+ * (t - b < 1) is a scalar branch; everything that differs between lanes -- the number of blocks a problem really has,
+ * its target length -- is handled by letting a lane compute on: steps beyond its last block or its last column only
+ * write its own dead registers and feed other dead steps, and the three places where validity matters (distance
+ * bookkeeping, checkpoint stores, LDS tile stores) are selects / predicated stores.  The loop runs to the wavefront's
+ * longest problem (problems are sorted by target length).
  * ---------------------------------------------------------------------------------------------- */
-template <int NB>
+template <int NB, bool PAC>
 __global__ void __launch_bounds__(64)
 lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ ckpt, uint8_t *__restrict__ ops,
                 int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
@@ -177,6 +191,7 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
     const bool live = gid < n_probs;
     const lf_aln_prob pr = probs[live ? gid : n_probs - 1];      /* a dead lane shadows the last problem and stores nothing */
     const lf_qacc Q(S.q, pr.qstart, pr.flags); const lf_tacc T(S.t, S.pac, pr.tstart, pr.flags);
+    auto qget = [&](uint32_t r) -> unsigned char { return Q.get(r); };
     const bool lazy = (pr.flags & LF_F_LAZYX) != 0;      /* diagonal moves are not classified here (lf_render_kernel does it) */
     const uint32_t n = pr.n, m = pr.m;
 
@@ -184,8 +199,12 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
 #pragma unroll
     for (int b = 0; b < NB; b++) { lo[b] = hi[b] = valid[b] = 0; Pv[b] = ~0ull; Mv[b] = 0; }
 #pragma unroll
-    for (int b = 0; b < NB; b++)
-        for (int i = 0; i < 64; i++) { const uint32_t r = b * 64 + i; if (r < n) lf_plane_add(Q.get(r), i, lo[b], hi[b], valid[b]); }
+    for (int b = 0; b < NB; b++) {
+        if ((uint32_t)b * 64 < n) {
+#pragma unroll 8
+            for (int i = 0; i < 64; i++) { const uint32_t r = b * 64 + i; const unsigned char ch = r < n ? Q.get(r) : (unsigned char)0; lf_plane_add(ch, i, lo[b], hi[b], valid[b]); }
+        }
+    }
 
     const int lastb = (int)((n - 1) >> 6), lastbit = (int)((n - 1) & 63);
     int score = (int)n;                     /* D[n][0] */
@@ -194,43 +213,43 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
     int best = (n & 63) ? (int)n : 0x7fffffff, best_c = 0;
     lf_hist_t *ck = ckpt + pr.hist_base + lane;     /* wave-transposed: checkpoint (j, block b) of lane l at ((j * NB + b) * 64 + l) */
     const bool want_path = pr.task == LF_TASK_PATH;
+    const bool ck_on = want_path && live;
 
-    /* The blocks of one column depend on each other through the horizontal carry, and a block depends on itself one
-     * column earlier: one lane alone is a single dependent chain.  Walking the lane's OWN blocks as an anti-diagonal
-     * (time step t: block b works on column t - b, taking the carry block b-1 produced one time step earlier) makes
-     * the NB block steps of a time step independent, so the VALU pipeline sees NB-way ILP per lane.  Blocks above the
-     * problem's last one (padding of the size class) are not computed. */
-    int hout[NB]; unsigned char win[NB];
+    uint32_t hout[NB], win[NB];
 #pragma unroll
     for (int b = 0; b < NB; b++) { hout[b] = 0; win[b] = 0; }
-    const uint32_t steps = m + (uint32_t)lastb;
-    for (uint32_t t0 = 1; t0 <= steps; t0 += 8) {
+    const uint32_t steps_w = lf_wave_max_u32(m + (uint32_t)lastb);
+    for (uint32_t t0 = 1; t0 <= steps_w; t0 += 8) {
         /* the 8 target bases of this trip are fetched together: their latency is paid once, not per column */
-        unsigned char tcs[8];
+        uint32_t tcs[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) tcs[k] = (t0 + k <= m) ? T.get(t0 + k - 1) : (unsigned char)0;
+        for (int k = 0; k < 8; k++) tcs[k] = (t0 + k <= m) ? lf_tok<PAC>(T, t0 + k - 1) : 0u;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t t = t0 + k;
-            if (t > steps) break;
 #pragma unroll
             for (int b = NB - 1; b >= 1; b--) win[b] = win[b - 1];
             win[0] = tcs[k];
 #pragma unroll
             for (int b = NB - 1; b >= 0; b--) {
-                const int c = (int)t - b;
-                if (b <= lastb && c >= 1 && c <= (int)m) {
-                    const int hin = b == 0 ? 1 : hout[b > 0 ? b - 1 : 0];
-                    const uint64_t Eq = lf_eq_mask(win[b], lo[b], hi[b], valid[b], Q, n, b);
+                if (t > (uint32_t)b) {                                      /* wave-uniform: block b has reached column 1 */
+                    const uint32_t c = t - (uint32_t)b;
+                    const uint32_t hin = b == 0 ? LF_HIN_PLUS1 : hout[b > 0 ? b - 1 : 0];
+                    const uint64_t Eq = lf_eq_tok<PAC>(win[b], lo[b], hi[b], valid[b], qget, n, b);
                     uint64_t ph, mh;
                     hout[b] = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
-                    if (b == lastb) {
-                        score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
-                        if (score < best) { best = score; best_c = c; }
-                    }
+                    const bool inr = c <= m;
+                    score += (b == lastb && inr) ? lf_delta_at(ph, mh, lastbit) : 0;
                     /* checkpoint: the state after every K-th column (one 1 KiB line per wave, block and checkpoint) */
-                    if (want_path && live && (c & (K - 1)) == 0) { lf_hist_t e; e.pv = Pv[b]; e.ph = Mv[b]; ck[((size_t)(c / K - 1) * NB + b) * 64] = e; }
+                    if ((c & (K - 1)) == 0) {                               /* wave-uniform */
+                        if (ck_on && inr && b <= lastb) { lf_hist_t e; e.pv = Pv[b]; e.ph = Mv[b]; ck[((size_t)(c / K - 1) * NB + b) * 64] = e; }
+                    }
                 }
+            }
+            {   /* the last block has just finished column t - lastb */
+                const int cl = (int)t - lastb;
+                const bool upd = cl >= 1 && cl <= (int)m && score < best;
+                best = upd ? score : best; best_c = upd ? cl : best_c;
             }
         }
     }
@@ -253,55 +272,59 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
         for (;;) {
             const bool act = r > 0 && c > c0;
             if (!__any(act)) break;
-            if (act) {
-                const int br = (int)((r - 1) >> 6);
-                const int bw = (W == 2 && br > 0) ? br - 1 : br;
+            /* per lane: the block of the path's row, the LDS window, the columns of this tile left of the path */
+            const int br = act ? (int)((r - 1) >> 6) : -1;
+            const int bw = (W == 2 && br > 0) ? br - 1 : br;
+            const uint32_t ncol = act ? c - c0 : 0;                /* 1 .. K */
 #pragma unroll
-                for (int b = 0; b < NB; b++) if (b <= br) {
-                    if (ti == 0) { Pv[b] = ~0ull; Mv[b] = 0; }
-                    else { const lf_hist_t e = ck[((size_t)(ti - 1) * NB + b) * 64]; Pv[b] = e.pv; Mv[b] = e.ph; }
-                }
-                const uint32_t ncol = c - c0;                  /* 1 .. K columns of this tile are on or left of the path */
-                uint64_t tw = 0;
+            for (int b = 0; b < NB; b++) {
+                Pv[b] = ~0ull; Mv[b] = 0;
+                if (ti > 0 && b <= br) { const lf_hist_t e = ck[((size_t)(ti - 1) * NB + b) * 64]; Pv[b] = e.pv; Mv[b] = e.ph; }
+            }
+            uint32_t tcs[K];
 #pragma unroll
-                for (int k = 0; k < K; k++) if ((uint32_t)k < ncol) tw |= (uint64_t)T.get(c0 + k) << (k * 8);
+            for (int k = 0; k < K; k++) tcs[k] = ((uint32_t)k < ncol) ? lf_tok<PAC>(T, c0 + k) : 0u;
 #pragma unroll
-                for (int b = 0; b < NB; b++) { hout[b] = 0; win[b] = 0; }
-                const uint32_t tsteps = ncol + (uint32_t)br;
-                for (uint32_t t = 1; t <= tsteps; t++) {
+            for (int b = 0; b < NB; b++) { hout[b] = 0; win[b] = 0; }
+            const int br_w = lf_wave_max_i32(br);
+            const uint32_t tsteps = (uint32_t)K + (uint32_t)(br_w < 0 ? 0 : br_w);      /* wave-uniform */
+#pragma unroll 1
+            for (uint32_t t = 1; t <= tsteps; t++) {
 #pragma unroll
-                    for (int b = NB - 1; b >= 1; b--) win[b] = win[b - 1];
-                    win[0] = t <= ncol ? (unsigned char)(tw >> ((t - 1) * 8)) : (unsigned char)0;
+                for (int b = NB - 1; b >= 1; b--) win[b] = win[b - 1];
+                uint32_t w0 = 0;
 #pragma unroll
-                    for (int b = NB - 1; b >= 0; b--) {
-                        const int cc = (int)t - b;             /* column of the tile, 1-based */
-                        if (b <= br && cc >= 1 && cc <= (int)ncol) {
-                            const int hin = b == 0 ? 1 : hout[b > 0 ? b - 1 : 0];
-                            const uint64_t Eq = lf_eq_mask(win[b], lo[b], hi[b], valid[b], Q, n, b);
-                            uint64_t ph, mh;
-                            hout[b] = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
-                            if (b >= bw) { lf_hist_t e; e.pv = Pv[b]; e.ph = ph; s_tile[((cc - 1) * W + (b - bw)) * 64 + lane] = e; }
-                        }
+                for (int k = 0; k < K; k++) w0 = (t == (uint32_t)(k + 1)) ? tcs[k] : w0;       /* t is uniform: scalar selects */
+                win[0] = w0;
+#pragma unroll
+                for (int b = NB - 1; b >= 0; b--) {
+                    if (t > (uint32_t)b && t <= (uint32_t)(K + b)) {       /* wave-uniform: column t - b of the tile, 1 .. K */
+                        const uint32_t cc = t - (uint32_t)b;
+                        const uint32_t hin = b == 0 ? LF_HIN_PLUS1 : hout[b > 0 ? b - 1 : 0];
+                        const uint64_t Eq = lf_eq_tok<PAC>(win[b], lo[b], hi[b], valid[b], qget, n, b);
+                        uint64_t ph, mh;
+                        hout[b] = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
+                        if (b >= bw && b <= br && cc <= ncol) { lf_hist_t e; e.pv = Pv[b]; e.ph = ph; s_tile[((cc - 1) * W + (b - bw)) * 64 + lane] = e; }
                     }
                 }
-                /* follow the path through the tile */
-                while (r > 0 && c > c0) {
-                    int b = (int)((r - 1) >> 6);
-                    if (b < bw) break;                          /* above the window: recompute with the window moved up */
-                    lf_hist_t e = s_tile[((c - c0 - 1) * W + (b - bw)) * 64 + lane];
-                    for (;;) {
-                        const int bit = (int)((r - 1) & 63);
-                        if ((e.pv >> bit) & 1) {                                   /* Up: stays in this column */
-                            em.put(1); r--;
-                            if (r == 0) break;
-                            const int b2 = (int)((r - 1) >> 6);
-                            if (b2 != b) { if (b2 < bw) break; b = b2; e = s_tile[((c - c0 - 1) * W + (b - bw)) * 64 + lane]; }
-                            continue;
-                        }
-                        if ((e.ph >> bit) & 1) { em.put(2); c--; break; }             /* Left */
-                        em.put((lazy || Q.get(r - 1) == T.get(c - 1)) ? 0 : 3); r--; c--;   /* Diagonal */
-                        break;
+            }
+            /* follow the path through the tile */
+            while (r > 0 && c > c0) {
+                int b = (int)((r - 1) >> 6);
+                if (b < bw) break;                          /* above the window: recompute with the window moved up */
+                lf_hist_t e = s_tile[((c - c0 - 1) * W + (b - bw)) * 64 + lane];
+                for (;;) {
+                    const int bit = (int)((r - 1) & 63);
+                    if ((e.pv >> bit) & 1) {                                   /* Up: stays in this column */
+                        em.put(1); r--;
+                        if (r == 0) break;
+                        const int b2 = (int)((r - 1) >> 6);
+                        if (b2 != b) { if (b2 < bw) break; b = b2; e = s_tile[((c - c0 - 1) * W + (b - bw)) * 64 + lane]; }
+                        continue;
                     }
+                    if ((e.ph >> bit) & 1) { em.put(2); c--; break; }             /* Left */
+                    em.put((lazy || Q.get(r - 1) == T.get(c - 1)) ? 0 : 3); r--; c--;   /* Diagonal */
+                    break;
                 }
             }
         }
@@ -346,7 +369,7 @@ lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_s
     const bool want_path = pr.task == LF_TASK_PATH;
     for (uint32_t c = 1; c <= m; c++) {
         const unsigned char tc = T.get(c - 1);
-        int hin = 1;
+        uint32_t hin = LF_HIN_PLUS1;
         for (uint32_t b = 0; b < nbk; b++) {
             uint64_t Pv = st[b * 5 + 3], Mv = st[b * 5 + 4];
             const uint64_t Eq = lf_eq_mask(tc, st[b * 5 + 0], st[b * 5 + 1], st[b * 5 + 2], Q, n, b);
@@ -411,10 +434,10 @@ lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_s
  * ---------------------------------------------------------------------------------------------- */
 /* lane l receives lane l-1's value (lane 0: 0): the horizontal carry of the anti-diagonal sweeps.  DPP wave_shr:1 is a
  * VALU move; __shfl_up goes through the LDS crossbar (ds_bpermute) and sits on the per-step dependency chain. */
-__device__ __forceinline__ int lf_wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t lf_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
 
 #define LF_HSTACK 48
-template <int G, int KB, int K>
+template <int G, int KB, int K, bool PAC>
 __global__ void __launch_bounds__(64)
 lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ ckpt, uint64_t *__restrict__ aux,
                       uint8_t *__restrict__ ops, int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
@@ -445,7 +468,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
 
     uint64_t lo[KB], hi[KB], valid[KB], Pv[KB], Mv[KB];
     uint32_t nbk = 0, lastb = 0; int lastbit = 0, nl = 0, lane_last = 0;
-    int hout_prev = 1;
+    uint32_t hout_prev = LF_HIN_PLUS1;               /* carry bits (lf_myers_step) this lane hands to its right neighbour */
 
     /* bit planes by ballot: for block b the lanes fetch its 64 query bytes (G at a time per group) and three wave
      * ballots give lo / hi / valid; the lane that owns block b keeps them */
@@ -460,7 +483,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
             for (int sub = 0; sub < P; sub++) {
                 const uint32_t r = b * 64 + (uint32_t)(sub * G + gl);
                 int code = -1;
-                if (b < nbk && r < n) { switch (qget(r)) { case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break; default: code = -1; } }
+                if (b < nbk && r < n) { bool ok; const uint32_t cd = lf_code_upper(qget(r), ok); code = ok ? (int)cd : -1; }
                 const uint64_t bl = __ballot(code >= 0 && (code & 1)), bh = __ballot(code >= 0 && (code & 2)), bv = __ballot(code >= 0);
                 if ((uint32_t)gl == b / KB) {
                     const int slot = (int)(b % KB);
@@ -473,29 +496,32 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     };
     /* target columns [first, first + count) into the group's LDS ring */
     auto stage_window = [&](int first, int count) {
-        for (int j = first + gl; j < first + count; j += G) if (j >= 0 && (uint32_t)j < m) my_t[j & (TC - 1)] = tget((uint32_t)j);
+        for (int j = first + gl; j < first + count; j += G) if (j >= 0 && (uint32_t)j < m)
+            my_t[j & (TC - 1)] = PAC ? (unsigned char)T.pac_code(rev ? tlo + m - 1 - (uint32_t)j : tlo + (uint32_t)j) : tget((uint32_t)j);
     };
     /* one sweep step s (TILE: (Pv, Ph) of the step go to LDS row s - s0) */
     int score = 0, best = 0, best_c = 0;
-    auto sweep_step = [&](int s, bool track, bool tile, int s0) {
-        const int from_left = lf_wave_shr1(hout_prev);
+    auto sweep_step = [&](int s, auto track_c, auto tile_c, int s0) {
+        constexpr bool track = decltype(track_c)::value, tile = decltype(tile_c)::value;
+        const uint32_t from_left = lf_wave_shr1(hout_prev);
         const int c = s - gl + 1;
         if (gl < nl && c >= 1 && c <= (int)m) {
-            const unsigned char tc = my_t[(c - 1) & (TC - 1)];
-            int hin = gl == 0 ? 1 : from_left;
+            const uint32_t byte = my_t[(c - 1) & (TC - 1)];
+            const uint32_t tok = PAC ? byte : lf_tok_of_byte((unsigned char)byte);
+            uint32_t hin = gl == 0 ? LF_HIN_PLUS1 : from_left;
 #pragma unroll
             for (int k = 0; k < KB; k++) {
                 const uint32_t b = (uint32_t)gl * KB + k;
-                if (b < nbk) {
-                    const uint64_t Eq = lf_eq_mask_f(tc, lo[k], hi[k], valid[k], qget, n, b);
-                    uint64_t ph, mh;
-                    hin = lf_myers_step(Pv[k], Mv[k], Eq, hin, ph, mh);
-                    if (track && b == lastb) score += (int)((ph >> lastbit) & 1) - (int)((mh >> lastbit) & 1);
-                    if (tile) { lf_hist_t e; e.pv = Pv[k]; e.ph = ph; s_tile[((s - s0) * KB + k) * 64 + lane] = e; }
-                }
+                /* blocks past the problem's last one (padding of the lane's KB) compute on dead registers: no branch */
+                const uint64_t Eq = lf_eq_tok<PAC>(tok, lo[k], hi[k], valid[k], qget, n, b);
+                uint64_t ph, mh;
+                const uint32_t ho = lf_myers_step(Pv[k], Mv[k], Eq, hin, ph, mh);
+                hin = (KB == 1 || b < nbk) ? ho : hin;
+                if (track) score += (b == lastb) ? lf_delta_at(ph, mh, lastbit) : 0;
+                if (tile) { lf_hist_t e; e.pv = Pv[k]; e.ph = ph; s_tile[((s - s0) * KB + k) * 64 + lane] = e; }
             }
             hout_prev = hin;
-            if (track && gl == lane_last && score < best) { best = score; best_c = c; }
+            if (track) { const bool upd = gl == lane_last && score < best; best = upd ? score : best; best_c = upd ? c : best_c; }
         }
     };
     /* forward pass of the current geometry; want_ck: checkpoint every K steps.  Leaves score (NW distance at lane_last),
@@ -503,19 +529,19 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     auto forward = [&](bool want_ck) -> int {
 #pragma unroll
         for (int k = 0; k < KB; k++) { Pv[k] = ~0ull; Mv[k] = 0; }
-        hout_prev = 1;
+        hout_prev = LF_HIN_PLUS1;
         score = (int)n; best = (n & 63) ? (int)n : 0x7fffffff; best_c = 0;
         const int steps = (int)m + nl - 1;
         const int steps_max = G == 64 ? steps : lf_wave_max_i32(steps);
         for (int s = 0; s < steps_max; s++) {
             if ((s & (H - 1)) == 0) { __syncthreads(); stage_window(s, H); __syncthreads(); }
-            sweep_step(s, true, false, 0);
+            sweep_step(s, std::true_type(), std::false_type(), 0);
             if (want_ck && ((s + 1) & (K - 1)) == 0) {
                 const size_t j = (size_t)((s + 1) / K - 1);
                 lf_hist_t *row = ck + j * (64 * KB + 4);
 #pragma unroll
                 for (int k = 0; k < KB; k++) { lf_hist_t e; e.pv = Pv[k]; e.ph = Mv[k]; row[k * 64 + lane] = e; }
-                reinterpret_cast<signed char *>(row + 64 * KB)[lane] = (signed char)hout_prev;
+                reinterpret_cast<unsigned char *>(row + 64 * KB)[lane] = (unsigned char)hout_prev;
             }
         }
         return steps_max;
@@ -533,18 +559,18 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
             if (j == 0) {
 #pragma unroll
                 for (int k = 0; k < KB; k++) { Pv[k] = ~0ull; Mv[k] = 0; }
-                hout_prev = 1;
+                hout_prev = LF_HIN_PLUS1;
             } else {
                 const lf_hist_t *row = ck + (size_t)(j - 1) * (64 * KB + 4);
 #pragma unroll
                 for (int k = 0; k < KB; k++) { const lf_hist_t e = row[k * 64 + lane]; Pv[k] = e.pv; Mv[k] = e.ph; }
-                hout_prev = (int)reinterpret_cast<const signed char *>(row + 64 * KB)[lane];
+                hout_prev = (uint32_t)reinterpret_cast<const unsigned char *>(row + 64 * KB)[lane];
             }
             __syncthreads();                                   /* the previous tile's LDS rows have been read */
             stage_window(s0 - G + 1, K + G - 1);
             __syncthreads();
             const int s1 = s0 + K < steps_max ? s0 + K : steps_max;
-            for (int s = s0; s < s1; s++) sweep_step(s, false, true, s0);
+            for (int s = s0; s < s1; s++) sweep_step(s, std::false_type(), std::true_type(), s0);
             __syncthreads();
             for (;;) {
                 const bool act = scur >= s0;
@@ -567,7 +593,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     };
 
     /* ---- the root problem ---- */
-    const bool root_leaf = G < 64 || lf_leaf(pr.n, pr.m);
+    const bool root_leaf = G < 64 || lf_leaf(pr.n, pr.m);      /* G < 64: the binning sends only leaf-size problems */
     build_planes();
     int steps_max = forward(want_path && root_leaf);
     const int src_last = g * G + lane_last;
@@ -676,9 +702,11 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
 #define LF_NCLASS 12
 /* LF_SWEEP_MAX_N: lf_internal.h */
 __host__ __device__ __forceinline__ int lf_class_nb(int c) { return c == 1 ? 1 : c == 2 ? 2 : c == 3 ? 3 : c == 4 ? 4 : c == 5 ? 6 : 8; }
-__host__ __device__ __forceinline__ int lf_class_of(uint32_t n)
+__host__ __device__ __forceinline__ int lf_class_of(uint32_t n, uint32_t m)
 {
     const uint32_t nb = (n + 63) >> 6;
+    /* above edlib's traceback switch the path is Hirschberg's, whatever the query length: the classes that recurse */
+    if (!lf_leaf(n, m)) return n <= 4096 ? 9 : n <= 16384 ? 10 : n <= LF_SWEEP_MAX_N ? 11 : 0;
     if (nb <= 1) return 1; if (nb <= 2) return 2; if (nb <= 3) return 3; if (nb <= 4) return 4; if (nb <= 6) return 5; if (nb <= 8) return 6;
     if (nb <= 16) return 7; if (nb <= 32) return 8;
     if (n <= 4096) return 9; if (n <= 16384) return 10; if (n <= LF_SWEEP_MAX_N) return 11;
@@ -734,11 +762,12 @@ struct lf_launch_ctx {
     hipStream_t cs[LF_NCLASS]; const lf_aln_prob *d_probs; const int *cstart; lf_seqs S; lf_hist_t *d_hist; uint64_t *d_aux;
     uint8_t *d_ops; int32_t *d_ed, *d_end; uint32_t *d_len; int32_t *d_cols; const uint64_t *d_cols_off;
 };
+template <bool PAC>
 static void launch_classes(const lf_launch_ctx &L)
 {
     auto cnt = [&](int c) { return L.cstart[c + 1] - L.cstart[c]; };
     /* largest problems first: their few long-running waves start while the small classes fill the rest of the chip */
-#define DS(C, GV, KBV, KV) if (cnt(C) > 0) hipLaunchKernelGGL((lf_edlib_sweep_kernel<GV, KBV, KV>), dim3((unsigned)((cnt(C) + (64 / GV) - 1) / (64 / GV))), dim3(64), 0, L.cs[C], \
+#define DS(C, GV, KBV, KV) if (cnt(C) > 0) hipLaunchKernelGGL((lf_edlib_sweep_kernel<GV, KBV, KV, PAC>), dim3((unsigned)((cnt(C) + (64 / GV) - 1) / (64 / GV))), dim3(64), 0, L.cs[C], \
         L.d_probs + L.cstart[C], cnt(C), L.S, L.d_hist, L.d_aux, L.d_ops, L.d_ed, L.d_end, L.d_len)
     DS(11, 64, 8, 2); DS(10, 64, 4, 4); DS(9, 64, 1, 16);
     if (cnt(0) > 0)
@@ -746,7 +775,7 @@ static void launch_classes(const lf_launch_ctx &L)
                            L.d_probs + L.cstart[0], cnt(0), L.S, L.d_hist, L.d_aux, L.d_ops, L.d_ed, L.d_end, L.d_len, L.d_cols, L.d_cols_off);
     DS(8, 32, 1, 16); DS(7, 16, 1, 16);
 #undef DS
-#define DL(C, NBV) if (cnt(C) > 0) hipLaunchKernelGGL(lf_edlib_kernel<NBV>, dim3((unsigned)((cnt(C) + 63) / 64)), dim3(64), 0, L.cs[C], \
+#define DL(C, NBV) if (cnt(C) > 0) hipLaunchKernelGGL((lf_edlib_kernel<NBV, PAC>), dim3((unsigned)((cnt(C) + 63) / 64)), dim3(64), 0, L.cs[C], \
         L.d_probs + L.cstart[C], cnt(C), L.S, L.d_hist, L.d_ops, L.d_ed, L.d_end, L.d_len)
     DL(6, 8); DL(5, 6); DL(4, 4); DL(3, 3); DL(2, 2); DL(1, 1);
 #undef DL
@@ -777,7 +806,7 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
         pr.flags = rv ? (LF_F_QREV | LF_F_TREV) : 0;
         pr.mode = mode ? mode[i] : 0; pr.task = cols ? LF_TASK_COLS : (task ? task[i] : LF_TASK_PATH);
         if (pr.n == 0 || (pr.m == 0 && !cols)) { trivial.push_back(i); continue; }
-        P[cols ? 0 : lf_class_of(pr.n)].push_back(pr);
+        P[cols ? 0 : lf_class_of(pr.n, pr.m)].push_back(pr);
     }
     int cstart[LF_NCLASS + 1]; cstart[0] = 0;
     size_t hist_entries = 0, aux_words = 0;
@@ -838,7 +867,7 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     for (int k = 0; k < LF_NCLASS; k++) if (!P[k].empty()) HIPCHK(hipStreamWaitEvent(L.cs[k], e0, 0));
     L.d_probs = d_probs; L.cstart = cstart; L.S.q = d_q; L.S.t = d_t; L.S.pac = nullptr; L.d_hist = d_hist; L.d_aux = d_aux;
     L.d_ops = d_ops; L.d_ed = d_ed; L.d_end = d_end; L.d_len = d_len; L.d_cols = d_cols; L.d_cols_off = d_cols_off;
-    launch_classes(L);
+    launch_classes<false>(L);
     for (int k = 0; k < LF_NCLASS; k++) if (!P[k].empty()) { HIPCHK(hipEventRecord(cdone[k], L.cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
     HIPCHK(hipEventRecord(e1, s));
     if (cols) HIPCHK(hipMemcpyAsync(cols, d_cols, cols_total * 4, hipMemcpyDeviceToHost, s));
@@ -884,7 +913,7 @@ __global__ void lf_desc_keys_kernel(const lf_aln_desc_t *__restrict__ d, int n, 
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    keys[i] = ((uint64_t)lf_class_of(d[i].n) << 32) | d[i].m;
+    keys[i] = ((uint64_t)lf_class_of(d[i].n, d[i].m) << 32) | d[i].m;
     vals[i] = (uint32_t)i;
 }
 __global__ void lf_desc_bounds_kernel(const uint64_t *__restrict__ keys, int n, int *__restrict__ cstart /* LF_NCLASS + 1 */)
@@ -1005,7 +1034,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && L.cs[k] != s) HIPCHK(hipStreamWaitEvent(L.cs[k], eb, 0));
     L.d_probs = d_probs; L.cstart = cstart; L.S.q = D->d_reads; L.S.t = nullptr; L.S.pac = D->d_pac; L.d_hist = d_hist; L.d_aux = d_aux;
     L.d_ops = d_ops; L.d_ed = d_ed; L.d_end = d_end; L.d_len = d_len; L.d_cols = nullptr; L.d_cols_off = nullptr;
-    launch_classes(L);
+    launch_classes<true>(L);         /* targets of descriptors are the 2-bit reference */
     for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && L.cs[k] != s) { HIPCHK(hipEventRecord(cdone[k], L.cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipMemcpyAsync(ed, d_ed, (size_t)n * 4, hipMemcpyDeviceToHost, s));

@@ -31,26 +31,32 @@ struct lf_dev_state {           /* host-side owner of the device allocations */
 
 int lfg_build_cache_table(const lf_dev_index *v, hipStream_t stream, int K, uint64_t **table);
 
+/* ---- branch-free base classification.  A `switch` on a base compiles to a tree of exec-mask branches (dozens of scalar
+ * instructions and s_cbranch per call); these sit inside the DP and search loops, so they are arithmetic instead:
+ * for 'A' 'C' 'G' 'T' (0x41 0x43 0x47 0x54) bits 2:1 are 0 1 3 2, and x ^ (x >> 1) turns that into 0 1 2 3. ---- */
+__device__ __forceinline__ uint32_t lf_code2(uint32_t ch) { const uint32_t x = (ch >> 1) & 3u; return x ^ (x >> 1); }
+/* upper case only (edlib compares raw bytes): ok = ch is one of "ACGT" */
+__device__ __forceinline__ uint32_t lf_code_upper(uint32_t ch, bool &ok)
+{
+    const uint32_t c = lf_code2(ch);
+    ok = ch == ((0x54474341u >> (c << 3)) & 0xffu);
+    return c;
+}
 __device__ __forceinline__ int lf_nt4(unsigned char ch)
 {   /* nst_nt4_table (lib/bwa/bntseq.c:47-64): A/a C/c G/g T/t -> 0..3, everything else > 3 */
-    switch (ch) {
-    case 'A': case 'a': return 0;
-    case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2;
-    case 'T': case 't': return 3;
-    default: return 4;
-    }
+    bool ok;
+    const uint32_t c = lf_code_upper((uint32_t)ch & 0xDFu, ok);
+    return ok ? (int)c : 4;
 }
 
 struct lf_seqs { const unsigned char *q; const unsigned char *t; const uint8_t *pac; };
 
-__device__ __forceinline__ unsigned char lf_rc_char(unsigned char c)
-{
-    switch (c) {
-    case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
-    case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
-    default: return 'N';
-    }
+__device__ __forceinline__ unsigned char lf_rc_char(unsigned char ch)
+{   /* tableRev (src/Common.cpp:31-40): complement with the case kept, anything else 'N' */
+    bool ok;
+    const uint32_t c = lf_code_upper((uint32_t)ch & 0xDFu, ok);
+    const uint32_t r = ((0x41434754u >> (c << 3)) & 0xffu) | ((uint32_t)ch & 0x20u);      /* "TGCA"[c], case bit of ch */
+    return (unsigned char)(ok ? r : (uint32_t)'N');
 }
 /* element i of a sequence = base[start +/- i], optionally complemented (flags LF_F_*): requests of the mapping pipeline
  * are DESCRIPTORS into the read batch and the 2-bit reference already resident in HBM */
@@ -62,10 +68,15 @@ struct lf_qacc {
 struct lf_tacc {
     const unsigned char *b; const uint8_t *pac; int64_t start; int dir; bool comp, is_pac;
     __device__ __forceinline__ lf_tacc(const unsigned char *base, const uint8_t *pc, int64_t st, unsigned flags) : b(base), pac(pc), start(st), dir((flags & LF_F_TREV) ? -1 : 1), comp(flags & LF_F_TCOMP), is_pac(flags & LF_F_TPAC) {}
-    __device__ __forceinline__ unsigned char get(uint32_t i) const {
+    /* 2-bit code straight from the packed reference (targets of the mapping pipeline) */
+    __device__ __forceinline__ uint32_t pac_code(uint32_t i) const {
         const int64_t x = start + (int64_t)dir * (int64_t)i;
-        if (is_pac) { int c = (pac[x >> 2] >> ((~x & 3) << 1)) & 3; if (comp) c = 3 - c; return (unsigned char)(0x54474341u >> (c << 3)); }   /* "ACGT"[c] without a table load */
-        const unsigned char c = b[x];
+        const uint32_t c = ((uint32_t)pac[x >> 2] >> ((~(uint32_t)x & 3u) << 1)) & 3u;
+        return comp ? 3u - c : c;
+    }
+    __device__ __forceinline__ unsigned char get(uint32_t i) const {
+        if (is_pac) return (unsigned char)(0x54474341u >> (pac_code(i) << 3));   /* "ACGT"[c] without a table load */
+        const unsigned char c = b[start + (int64_t)dir * (int64_t)i];
         return comp ? lf_rc_char(c) : c;
     }
 };

@@ -130,6 +130,10 @@ def test_edlib_checkpoint_tiles_and_device_hirschberg(oracle_lib):
         add(q.tobytes(), t.tobytes(), both=(n <= 5000))
     q = rseq(rng, 2600)                                                                             # SHW: (n, m) above the switch, (n, end) below it
     qs.append(q); ts.append(synth.mutate(np.frombuffer(q[:900], dtype=np.uint8), 0.1, rng).tobytes() + rseq(rng, 3000)); modes.append(1)
+    for n, m in ((1900, 1900), (2040, 2100), (1000, 3400), (500, 6500), (60, 38000)):             # short queries above the switch: Hirschberg too
+        q = np.frombuffer(rseq(rng, n, ACGT[:2], [0.7, 0.3]), dtype=np.uint8)                      # two-letter strings: ties everywhere
+        t = np.concatenate([synth.mutate(q, 0.2, rng), np.frombuffer(rseq(rng, max(0, m - n), ACGT[:2], [0.7, 0.3]), dtype=np.uint8)])[:m]
+        add(q.tobytes(), t.tobytes())
     q = rseq(rng, 2100); t = b"AC" * 1200 + q[1000:] + b"GT" * 900                                  # low complexity: many co-optimal paths, tie rules decide
     add(q, t)
     res, ms = la.edlib_batch(qs, ts, modes)
