@@ -139,28 +139,27 @@ __device__ __forceinline__ int lf_wave_max_i32(int v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-/* ops leave in 8-byte words: bytes are collected in `acc` and stored when the (descending) address reaches an 8-byte
- * boundary; only the bytes above the first boundary and below the last one are single-byte stores (the neighbouring
- * problems' regions start right there).  `store` = this lane owns the output. */
+/* ops are produced back to front and leave in 8-byte words: bytes are shifted into `acc` and stored when the (descending)
+ * address reaches an 8-byte boundary; only the bytes above the first boundary and below the last one are single-byte
+ * stores (the neighbouring problems' regions start right there).  `store` = this lane owns the output. */
 struct lf_emitter {
-    uint8_t *o; uint32_t w; uint64_t acc; bool packed, store;
-    __device__ __forceinline__ void init(uint8_t *base, uint32_t cap, bool st) { o = base; w = cap; acc = 0; packed = false; store = st; }
-    __device__ __forceinline__ void put(uint8_t op)
+    uint8_t *o; uint32_t w, mis, cnt; uint64_t acc; bool store;
+    __device__ __forceinline__ void init(uint8_t *base, uint32_t cap, bool st) { o = base; w = cap; mis = (uint32_t)((uintptr_t)base & 7); cnt = 0; acc = 0; store = st; }
+    __device__ __forceinline__ void spill()
+    {   /* the collected bytes start at o + w, lowest address in the lowest byte */
+        if (store) {
+            if (cnt == 8) *reinterpret_cast<uint64_t *>(o + w) = acc;
+            else for (uint32_t i = 0; i < cnt; i++) o[w + i] = (uint8_t)(acc >> (8 * i));
+        }
+        cnt = 0;
+    }
+    __device__ __forceinline__ void put(uint32_t op)
     {
         --w;
-        const uintptr_t A = (uintptr_t)(o + w);
-        if (!packed) { if (store) o[w] = op; packed = (A & 7) == 0; return; }
-        acc |= (uint64_t)op << ((A & 7) * 8);
-        if ((A & 7) == 0) { if (store) *reinterpret_cast<uint64_t *>(o + w) = acc; acc = 0; }
+        acc = (acc << 8) | op; cnt++;
+        if (((mis + w) & 7) == 0) spill();
     }
-    __device__ __forceinline__ void flush()
-    {   /* bytes collected above the last boundary reached; the collector stays usable (the next put() is byte-wise) */
-        if (packed) {
-            const uintptr_t A = (uintptr_t)(o + w);
-            if (store) for (uintptr_t x = A; (x & 7) != 0; x++) *reinterpret_cast<uint8_t *>(x) = (uint8_t)(acc >> ((x & 7) * 8));
-        }
-        acc = 0; packed = false;
-    }
+    __device__ __forceinline__ void flush() { if (cnt) spill(); }
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -308,23 +307,19 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
                     }
                 }
             }
-            /* follow the path through the tile */
-            while (r > 0 && c > c0) {
-                int b = (int)((r - 1) >> 6);
-                if (b < bw) break;                          /* above the window: recompute with the window moved up */
-                lf_hist_t e = s_tile[((c - c0 - 1) * W + (b - bw)) * 64 + lane];
-                for (;;) {
+            /* follow the path through the tile: one (Pv, Ph) word pair per (column, block), re-read only when either changes */
+            {
+                uint32_t ec = 0xffffffffu; int eb = -1; lf_hist_t e; e.pv = e.ph = 0;
+                while (r > 0 && c > c0) {
+                    const int b = (int)((r - 1) >> 6);
+                    if (b < bw) break;                          /* above the window: recompute with the window moved up */
+                    if (c != ec || b != eb) { e = s_tile[((c - c0 - 1) * W + (b - bw)) * 64 + lane]; ec = c; eb = b; }
                     const int bit = (int)((r - 1) & 63);
-                    if ((e.pv >> bit) & 1) {                                   /* Up: stays in this column */
-                        em.put(1); r--;
-                        if (r == 0) break;
-                        const int b2 = (int)((r - 1) >> 6);
-                        if (b2 != b) { if (b2 < bw) break; b = b2; e = s_tile[((c - c0 - 1) * W + (b - bw)) * 64 + lane]; }
-                        continue;
-                    }
-                    if ((e.ph >> bit) & 1) { em.put(2); c--; break; }             /* Left */
-                    em.put((lazy || Q.get(r - 1) == T.get(c - 1)) ? 0 : 3); r--; c--;   /* Diagonal */
-                    break;
+                    const uint32_t up = (uint32_t)(e.pv >> bit) & 1u, lf = ((uint32_t)(e.ph >> bit) & 1u) & ~up, dg = (up | lf) ^ 1u;
+                    uint32_t op = up ? 1u : (lf ? 2u : 0u);      /* Up -> Left -> Diagonal (lib/edlib/edlib.cpp:950,984,1015) */
+                    if (!lazy) { if (dg && Q.get(r - 1) != T.get(c - 1)) op = 3u; }
+                    em.put(op);
+                    r -= up | dg; c -= lf | dg;
                 }
             }
         }
@@ -469,6 +464,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     uint64_t lo[KB], hi[KB], valid[KB], Pv[KB], Mv[KB];
     uint32_t nbk = 0, lastb = 0; int lastbit = 0, nl = 0, lane_last = 0;
     uint32_t hout_prev = LF_HIN_PLUS1;               /* carry bits (lf_myers_step) this lane hands to its right neighbour */
+    int ring_lo = 0;                                 /* the LDS ring holds target columns [ring_lo, ring_lo + TC) (wave-uniform) */
 
     /* bit planes by ballot: for block b the lanes fetch its 64 query bytes (G at a time per group) and three wave
      * ballots give lo / hi / valid; the lane that owns block b keeps them */
@@ -534,7 +530,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
         const int steps = (int)m + nl - 1;
         const int steps_max = G == 64 ? steps : lf_wave_max_i32(steps);
         for (int s = 0; s < steps_max; s++) {
-            if ((s & (H - 1)) == 0) { __syncthreads(); stage_window(s, H); __syncthreads(); }
+            if ((s & (H - 1)) == 0) { __syncthreads(); stage_window(s, H); __syncthreads(); ring_lo = s >= H ? s - H : 0; }
             sweep_step(s, std::true_type(), std::false_type(), 0);
             if (want_ck && ((s + 1) & (K - 1)) == 0) {
                 const size_t j = (size_t)((s + 1) / K - 1);
@@ -553,22 +549,30 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
         auto step_of = [&](uint32_t rr, uint32_t cc) -> int { return (rr > 0 && cc > 0) ? (int)(cc - 1 + ((rr - 1) >> 6) / KB) : -1; };
         int scur = step_of(r, c);
         const int jmax = lf_wave_max_i32(scur >= 0 ? scur / K : -1);
-        for (int j = jmax; j >= 0; j--) {
-            const int s0 = j * K;
-            /* restore the state in front of the tile */
-            if (j == 0) {
+        /* the checkpoint in front of tile j is loaded while tile j + 1 is replayed and walked (HBM latency off the chain) */
+        uint64_t nPv[KB], nMv[KB]; uint32_t nh = LF_HIN_PLUS1;
+        auto fetch_ck = [&](int j) {
+            if (j <= 0) {
 #pragma unroll
-                for (int k = 0; k < KB; k++) { Pv[k] = ~0ull; Mv[k] = 0; }
-                hout_prev = LF_HIN_PLUS1;
+                for (int k = 0; k < KB; k++) { nPv[k] = ~0ull; nMv[k] = 0; }
+                nh = LF_HIN_PLUS1;
             } else {
                 const lf_hist_t *row = ck + (size_t)(j - 1) * (64 * KB + 4);
 #pragma unroll
-                for (int k = 0; k < KB; k++) { const lf_hist_t e = row[k * 64 + lane]; Pv[k] = e.pv; Mv[k] = e.ph; }
-                hout_prev = (uint32_t)reinterpret_cast<const unsigned char *>(row + 64 * KB)[lane];
+                for (int k = 0; k < KB; k++) { const lf_hist_t e = row[k * 64 + lane]; nPv[k] = e.pv; nMv[k] = e.ph; }
+                nh = (uint32_t)reinterpret_cast<const unsigned char *>(row + 64 * KB)[lane];
             }
+        };
+        if (jmax >= 0) fetch_ck(jmax);
+        for (int j = jmax; j >= 0; j--) {
+            const int s0 = j * K;
+#pragma unroll
+            for (int k = 0; k < KB; k++) { Pv[k] = nPv[k]; Mv[k] = nMv[k]; }
+            hout_prev = nh;
+            if (j > 0) fetch_ck(j - 1);
             __syncthreads();                                   /* the previous tile's LDS rows have been read */
-            stage_window(s0 - G + 1, K + G - 1);
-            __syncthreads();
+            /* target columns of this tile: the ring still holds them unless the walk has moved left of it */
+            if (s0 - G + 1 < ring_lo) { ring_lo = s0 + K > H ? s0 + K - H : 0; stage_window(ring_lo, H); __syncthreads(); }      /* H >= G + K - 1 columns: the tile's and the next ones' */
             const int s1 = s0 + K < steps_max ? s0 + K : steps_max;
             for (int s = s0; s < s1; s++) sweep_step(s, std::false_type(), std::true_type(), s0);
             __syncthreads();
@@ -579,9 +583,11 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
                     const uint32_t blk = (r - 1) >> 6;
                     const lf_hist_t e = s_tile[((scur - s0) * KB + (int)(blk % KB)) * 64 + g * G + (int)(blk / KB)];
                     const int bit = (int)((r - 1) & 63);
-                    if ((e.pv >> bit) & 1) { em.put(1); r--; }
-                    else if ((e.ph >> bit) & 1) { em.put(2); c--; }
-                    else { em.put((lazy || qget(r - 1) == tget(c - 1)) ? 0 : 3); r--; c--; }
+                    const uint32_t up = (uint32_t)(e.pv >> bit) & 1u, lf = ((uint32_t)(e.ph >> bit) & 1u) & ~up, dg = (up | lf) ^ 1u;
+                    uint32_t op = up ? 1u : (lf ? 2u : 0u);      /* Up -> Left -> Diagonal (lib/edlib/edlib.cpp:950,984,1015) */
+                    if (!lazy) { if (dg && qget(r - 1) != tget(c - 1)) op = 3u; }
+                    em.put(op);
+                    r -= up | dg; c -= lf | dg;
                     scur = step_of(r, c);
                 }
             }
@@ -715,7 +721,7 @@ __host__ __device__ __forceinline__ int lf_class_of(uint32_t n, uint32_t m)
 /* problems per wave, blocks per lane, steps per tile of the sweep classes */
 __host__ __device__ __forceinline__ int lf_class_ppw(int c) { return c >= 1 && c <= 6 ? 64 : c == 7 ? 4 : c == 8 ? 2 : 1; }      /* class 0: 1 (own history) */
 __host__ __device__ __forceinline__ int lf_class_kb(int c) { return c == 10 ? 4 : c == 11 ? 8 : 1; }
-__host__ __device__ __forceinline__ int lf_class_k(int c) { return c == 10 ? 4 : c == 11 ? 2 : 16; }
+__host__ __device__ __forceinline__ int lf_class_k(int c) { return c == 10 ? 4 : c == 11 ? 2 : 8; }
 /* checkpoint entries of one wave whose longest target is m_max (the wave's last problem: problems are sorted by m) */
 __host__ __device__ __forceinline__ uint64_t lf_class_wave_entries(int c, uint32_t m_max)
 {
@@ -769,11 +775,11 @@ static void launch_classes(const lf_launch_ctx &L)
     /* largest problems first: their few long-running waves start while the small classes fill the rest of the chip */
 #define DS(C, GV, KBV, KV) if (cnt(C) > 0) hipLaunchKernelGGL((lf_edlib_sweep_kernel<GV, KBV, KV, PAC>), dim3((unsigned)((cnt(C) + (64 / GV) - 1) / (64 / GV))), dim3(64), 0, L.cs[C], \
         L.d_probs + L.cstart[C], cnt(C), L.S, L.d_hist, L.d_aux, L.d_ops, L.d_ed, L.d_end, L.d_len)
-    DS(11, 64, 8, 2); DS(10, 64, 4, 4); DS(9, 64, 1, 16);
+    DS(11, 64, 8, 2); DS(10, 64, 4, 4); DS(9, 64, 1, 8);
     if (cnt(0) > 0)
         hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((cnt(0) + 63) / 64)), dim3(64), 0, L.cs[0],
                            L.d_probs + L.cstart[0], cnt(0), L.S, L.d_hist, L.d_aux, L.d_ops, L.d_ed, L.d_end, L.d_len, L.d_cols, L.d_cols_off);
-    DS(8, 32, 1, 16); DS(7, 16, 1, 16);
+    DS(8, 32, 1, 8); DS(7, 16, 1, 8);
 #undef DS
 #define DL(C, NBV) if (cnt(C) > 0) hipLaunchKernelGGL((lf_edlib_kernel<NBV, PAC>), dim3((unsigned)((cnt(C) + 63) / 64)), dim3(64), 0, L.cs[C], \
         L.d_probs + L.cstart[C], cnt(C), L.S, L.d_hist, L.d_ops, L.d_ed, L.d_end, L.d_len)
