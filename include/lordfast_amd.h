@@ -200,6 +200,19 @@ int  lf_map_batch_into(const lf_index_t *idx, const lf_params_t *p, int n, const
 int  lf_map_batch_into_lens(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,
                             const char *const *seqs, const char *const *quals, const uint32_t *seq_lens,
                             char *out, size_t out_cap, size_t *sam_len, lf_stats_t *stats);
+/* ------------------------------------------------------------------------------------------------
+ * Several GPUs in one process: idx[d] = the same index loaded on device d (lf_index_load(prefix, d, ...)).
+ * Reads are independent, so the batch is cut into chunks that the devices pull from one counter -- the reference's
+ * pthread pool takes reads from a shared cursor the same way (src/LordFAST.cpp:295-303) -- and the SAM records are
+ * written in input order: the output is byte-identical to the one-device output.  seq_lens may be NULL.
+ * out == NULL: *sam is malloc'd (lf_free); otherwise the text goes to out[0 .. out_cap).
+ * (One process per GPU with torch.distributed / RCCL is the other deployment: lordfast_amd/dist.py, bench.py.)
+ * ---------------------------------------------------------------------------------------------- */
+int  lf_map_batch_multi(const lf_index_t *const *idx, int n_idx, const lf_params_t *p, int n, const char *const *names,
+                        const char *const *seqs, const char *const *quals, const uint32_t *seq_lens,
+                        char *out, size_t out_cap, char **sam, size_t *sam_len, lf_stats_t *stats);
+int  lf_map_file_multi(const lf_index_t *const *idx, int n_idx, const lf_params_t *p, const char *reads_path, const char *out_path,
+                       int no_header, const char *cmdline, int batch_reads, lf_stats_t *total);
 char *lf_sam_header(const lf_index_t *idx, const lf_params_t *p, const char *cmdline); /* src/BWT.cpp:668-681 */
 void lf_free(void *ptr);
 

@@ -387,3 +387,22 @@ def ksw_extend2_batch(qs, ts, prms, device: int = 0):
     _check(L.lf_ksw_extend2_batch(n, qcat, qoff.ctypes.data, tcat, toff.ctypes.data, prm.ctypes.data, sc.ctypes.data,
                                   qle.ctypes.data, tle.ctypes.data, device), "lf_ksw_extend2_batch")
     return [(int(sc[i]), int(qle[i]), int(tle[i])) for i in range(n)]
+
+
+def map_batch_multi(handles, names, seqs, quals=None, params: Params | None = None):
+    """lf_map_batch_multi: one batch spread over several LordFast handles (index replicas, normally one per GPU).
+    -> (SAM records in input order, stats dict)"""
+    L = lib()
+    L.lf_map_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params), C.c_int, C.POINTER(C.c_char_p),
+                                     C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(Stats)]
+    p = params or default_params()
+    hs = (C.c_void_p * len(handles))(*[h.h for h in handles])
+    na, sa = _cstr_array(names), _cstr_array(seqs)
+    qa = _cstr_array(quals) if quals is not None else None
+    out, ln, st = C.c_void_p(), C.c_size_t(), Stats()
+    _check(L.lf_map_batch_multi(hs, len(handles), C.byref(p), len(seqs), na, sa, qa, None, None, 0,
+                                C.byref(out), C.byref(ln), C.byref(st)), "lf_map_batch_multi")
+    sam = C.string_at(out, ln.value) if ln.value else b""
+    L.lf_free(out)
+    return sam, st.as_dict()

@@ -106,8 +106,22 @@ int main(int argc, char *argv[])
         if (strlen(cmdline) + strlen(argv[i]) + 2 >= sizeof cmdline) break;
         strcat(cmdline, argv[i]); strcat(cmdline, " ");
     }
-    const int device = getenv("LF_DEVICE") ? atoi(getenv("LF_DEVICE")) : 0;
-    if (lf_device_count() <= device) { fprintf(stderr, "[ERROR] no gfx950 device %d visible (this build has no CPU path)\n", device); return EXIT_FAILURE; }
+    /* LF_DEVICES="0-3" / "0,2,5": the read batches are spread over these GPUs (one index replica each); LF_DEVICE=d: one GPU */
+    int devs[16], n_devs = 0;
+    if (getenv("LF_DEVICES")) {
+        const char *q = getenv("LF_DEVICES");
+        while (*q && n_devs < 16) {
+            char *e; long a = strtol(q, &e, 10), b = a;
+            if (e == q) break;
+            if (*e == '-') { q = e + 1; b = strtol(q, &e, 10); }
+            for (long d = a; d <= b && n_devs < 16; d++) devs[n_devs++] = (int)d;
+            q = *e == ',' ? e + 1 : e;
+        }
+        if (n_devs == 0) { fprintf(stderr, "[ERROR] LF_DEVICES: expected a list like 0-3 or 0,2,5\n"); return EXIT_FAILURE; }
+    } else devs[n_devs++] = getenv("LF_DEVICE") ? atoi(getenv("LF_DEVICE")) : 0;
+    const int device = devs[0];
+    for (int d = 0; d < n_devs; d++)
+        if (devs[d] < 0 || lf_device_count() <= devs[d]) { fprintf(stderr, "[ERROR] no gfx950 device %d visible (this build has no CPU path)\n", devs[d]); return EXIT_FAILURE; }
 
     if (indexing) {
         if (lf_index_build(ref_file, device) != LF_OK) { fprintf(stderr, "[ERROR] (bwt_index) %s\n", lf_last_error()); return EXIT_FAILURE; }
@@ -122,13 +136,14 @@ int main(int argc, char *argv[])
             if (lf_index_build(ref_file, device) != LF_OK) { fprintf(stderr, "[ERROR] (bwt_index) %s\n", lf_last_error()); return EXIT_FAILURE; }
         }
     }
-    lf_index_t *ix = NULL;
+    lf_index_t *ixs[16] = { NULL };
     const unsigned flags = (getenv("LF_SAMPLED_SA") && atoi(getenv("LF_SAMPLED_SA"))) ? 0u : LF_IDX_FULL_SA;
-    if (lf_index_load(ref_file, device, flags, &ix) != LF_OK) { fprintf(stderr, "[ERROR] (bwt_load) %s\n", lf_last_error()); return EXIT_FAILURE; }
+    for (int d = 0; d < n_devs; d++)
+        if (lf_index_load(ref_file, devs[d], flags, &ixs[d]) != LF_OK) { fprintf(stderr, "[ERROR] (bwt_load) %s\n", lf_last_error()); return EXIT_FAILURE; }
     lf_stats_t st;
-    const int rc = lf_map_file(ix, &P, seq_file, out_file, no_header, cmdline, 0, &st);
+    const int rc = lf_map_file_multi((const lf_index_t *const *)ixs, n_devs, &P, seq_file, out_file, no_header, cmdline, 0, &st);
     if (rc != LF_OK) fprintf(stderr, "[ERROR] %s\n", lf_last_error());
     else fprintf(stderr, "[NOTE] processed %llu reads in %.2f seconds\n", (unsigned long long)st.n_reads, st.ms_total / 1000.0);
-    lf_index_free(ix);
+    for (int d = 0; d < n_devs; d++) lf_index_free(ixs[d]);
     return rc == LF_OK ? EXIT_SUCCESS : EXIT_FAILURE;
 }

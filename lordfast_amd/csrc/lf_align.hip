@@ -853,17 +853,12 @@ static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, con
     /* the size classes run CONCURRENTLY on their own streams: the long-query classes have few, long waves and
      * would leave most CUs idle if the kernels ran back to back */
     hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
-    static hipEvent_t cdone_all[32][LF_NCLASS], tev_all[32][2]; static bool cdone_init[32] = { false };
-    const int lane_id = lfg_get_lane();
     if (!s) return LF_ERR_HIP;
     lf_launch_ctx L;
     for (int k = 0; k < LF_NCLASS; k++) { L.cs[k] = (hipStream_t)lfg_lane_stream(device, 2 + k); if (!L.cs[k]) return LF_ERR_HIP; }
-    if (!cdone_init[lane_id]) {
-        for (int k = 0; k < LF_NCLASS; k++) HIPCHK(hipEventCreateWithFlags(&cdone_all[lane_id][k], hipEventDisableTiming));
-        HIPCHK(hipEventCreate(&tev_all[lane_id][0])); HIPCHK(hipEventCreate(&tev_all[lane_id][1]));
-        cdone_init[lane_id] = true;
-    }
-    hipEvent_t *cdone = cdone_all[lane_id], e0 = tev_all[lane_id][0], e1 = tev_all[lane_id][1];
+    hipEvent_t cdone[LF_NCLASS], e0 = (hipEvent_t)lfg_lane_event(device, 12), e1 = (hipEvent_t)lfg_lane_event(device, 13);
+    for (int k = 0; k < LF_NCLASS; k++) { cdone[k] = (hipEvent_t)lfg_lane_event(device, k); if (!cdone[k]) return LF_ERR_HIP; }
+    if (!e0 || !e1) return LF_ERR_HIP;
     HIPCHK(hipMemcpyAsync(d_q, q, qbytes, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_t, t, tbytes, hipMemcpyHostToDevice, s));
     if (cols) HIPCHK(hipMemcpyAsync(d_cols_off, cols_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
@@ -977,19 +972,13 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     if (n == 0) return LF_OK;
     HIPCHK(hipSetDevice(device));
     hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
-    static hipEvent_t cdone_all[32][LF_NCLASS], tev_all[32][3]; static bool cdone_init[32] = { false };
-    const int lane_id = lfg_get_lane();
     if (!s) return LF_ERR_HIP;
-    static const bool serial_classes = getenv("LF_SERIAL_CLASSES") != nullptr;     /* profiling aid: one class at a time */
+    const bool serial_classes = getenv("LF_SERIAL_CLASSES") != nullptr;     /* profiling aid: one class at a time (read per call: bench.py switches it) */
     lf_launch_ctx L;
     for (int k = 0; k < LF_NCLASS; k++) { L.cs[k] = serial_classes ? s : (hipStream_t)lfg_lane_stream(device, 2 + k); if (!L.cs[k]) return LF_ERR_HIP; }
-    if (!cdone_init[lane_id]) {
-        for (int k = 0; k < LF_NCLASS; k++) HIPCHK(hipEventCreateWithFlags(&cdone_all[lane_id][k], hipEventDisableTiming));
-        HIPCHK(hipEventCreate(&tev_all[lane_id][0])); HIPCHK(hipEventCreate(&tev_all[lane_id][1]));
-        HIPCHK(hipEventCreateWithFlags(&tev_all[lane_id][2], hipEventDisableTiming));
-        cdone_init[lane_id] = true;
-    }
-    hipEvent_t *cdone = cdone_all[lane_id], e0 = tev_all[lane_id][0], e1 = tev_all[lane_id][1], eb = tev_all[lane_id][2];
+    hipEvent_t cdone[LF_NCLASS], e0 = (hipEvent_t)lfg_lane_event(device, 12), e1 = (hipEvent_t)lfg_lane_event(device, 13), eb = (hipEvent_t)lfg_lane_event(device, 14);
+    for (int k = 0; k < LF_NCLASS; k++) { cdone[k] = (hipEvent_t)lfg_lane_event(device, k); if (!cdone[k]) return LF_ERR_HIP; }
+    if (!e0 || !e1 || !eb) return LF_ERR_HIP;
 #define DSLOT(T, k, bytes) (T *)lfg_dev_slot(device, LF_DS_ALN0 + (k), (bytes))
     /* the descriptors stay with the round's paths when those stay in HBM (lazy paths are resolved against them later) */
     lf_aln_desc_t *d_desc = ops ? DSLOT(lf_aln_desc_t, 0, (size_t)n * sizeof(lf_aln_desc_t))
@@ -1241,9 +1230,10 @@ extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff
     int32_t *d_ws = KSLOT(int32_t, 3, ws * 4 + 16), *d_s = KSLOT(int32_t, 4, (size_t)n * 4), *d_ql = KSLOT(int32_t, 5, (size_t)n * 4), *d_tl = KSLOT(int32_t, 6, (size_t)n * 4);
 #undef KSLOT
     if (!d_q || !d_t || !d_p || !d_ws || !d_s || !d_ql || !d_tl) return LF_ERR_NOMEM;
-    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 14);
+    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 15);
     if (!s) return LF_ERR_HIP;
-    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    hipEvent_t e0 = (hipEvent_t)lfg_lane_event(device, 40), e1 = (hipEvent_t)lfg_lane_event(device, 41);
+    if (!e0 || !e1) return LF_ERR_HIP;
     HIPCHK(hipMemcpyAsync(d_q, q, qoff[n], hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_t, t, toff[n], hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_p, P.data(), P.size() * sizeof(lf_ksw_prob), hipMemcpyHostToDevice, s));
@@ -1262,6 +1252,5 @@ extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return LF_OK;
 }

@@ -60,7 +60,8 @@ extern "C" int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, con
     if (!d_w || !d_seeds || !d_pen || !d_dp || !d_prev || !d_idx || !d_len || !d_sc) return LF_ERR_NOMEM;
     hipStream_t s = (hipStream_t)lfg_lane_stream(device, 15);
     if (!s) return LF_ERR_HIP;
-    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    hipEvent_t e0 = (hipEvent_t)lfg_lane_event(device, 30), e1 = (hipEvent_t)lfg_lane_event(device, 31);
+    if (!e0 || !e1) return LF_ERR_HIP;
     HIPCHK(hipMemcpyAsync(d_w, W.data(), W.size() * sizeof(lf_chain_win), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_seeds, sorted_seeds, total * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_pen, pen.data(), pen.size() * 8, hipMemcpyHostToDevice, s));
@@ -87,7 +88,6 @@ extern "C" int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, con
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return LF_OK;
 }
 
@@ -151,7 +151,8 @@ extern "C" int lfg_chain_clasp(int device, int n_windows, const Seed_t *seeds, c
     void *d_len = d_small, *d_sc = d_small + wpad, *d_off = d_small + 2 * wpad, *d_tmp = d_big, *d_out = d_big + tpad;
     hipStream_t s = (hipStream_t)lfg_lane_stream(device, 15);
     if (!s) return LF_ERR_HIP;
-    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    hipEvent_t e0 = (hipEvent_t)lfg_lane_event(device, 30), e1 = (hipEvent_t)lfg_lane_event(device, 31);
+    if (!e0 || !e1) return LF_ERR_HIP;
     HIPCHK(hipMemcpyAsync(d_w, W.data(), W.size() * sizeof(lf_chain_win), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_seeds, seeds, total * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_off, off, ((size_t)n_windows + 1) * 8, hipMemcpyHostToDevice, s));
@@ -184,6 +185,5 @@ extern "C" int lfg_chain_clasp(int device, int n_windows, const Seed_t *seeds, c
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return LF_OK;
 }

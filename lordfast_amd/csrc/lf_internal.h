@@ -84,6 +84,7 @@ void  lfg_slots_release(void);
 void  lfg_set_lane(int lane);          /* calling thread drives lane 0 or 1 (own slots + streams) */
 int   lfg_get_lane(void);
 void *lfg_lane_stream(int device, int which);   /* persistent hipStream_t of the calling thread's lane */
+void *lfg_lane_event(int device, int which);    /* persistent hipEvent_t (timing enabled) of the calling thread's lane; which < 48 */
 /* slot ids */
 enum { LF_DS_SEED0 = 0 /* ..15 */, LF_DS_CHAIN0 = 16 /* ..23 */, LF_DS_ALN0 = 24 /* ..47 */, LF_DS_KSW0 = 48 /* ..55 */,
        LF_DS_RND0 = 56 /* ..87: 2 per extension round (ops, spare) */, LF_DS_RENDER0 = 88 /* ..95 */, LF_DS_VOTE0 = 96 /* ..127 */ };

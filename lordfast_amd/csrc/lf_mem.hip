@@ -8,15 +8,16 @@
 
 namespace {
 struct slot_t { void *p = nullptr; size_t cap = 0; };
-constexpr int MAX_DEV = 16, LANE_STRIDE = 160, MAX_LANE = 32, MAX_SLOT = MAX_LANE * LANE_STRIDE;
+constexpr int MAX_DEV = 16, LANE_STRIDE = 160, MAX_LANE = 64, MAX_SLOT = MAX_LANE * LANE_STRIDE;
 thread_local int t_lane = 0;
 hipStream_t g_streams[MAX_DEV][MAX_LANE][16];
+hipEvent_t g_events[MAX_DEV][MAX_LANE][48];
 slot_t g_dev[MAX_DEV][MAX_SLOT];
 slot_t g_pin[MAX_SLOT];
 std::mutex g_mu;
 }
 
-/* up to sixteen chunks ("lanes") may be in flight at once (lanes 16..31 belong to the chunks' helper threads), each driven by its own host thread: a lane owns its own
+/* up to 32 chunks ("lanes") may be in flight at once, spread over the devices of the process (lanes 32..63 belong to the chunks' helper threads), each driven by its own host thread: a lane owns its own
  * set of slots and streams, so nothing is shared between them but the index */
 extern "C" void lfg_set_lane(int lane) { t_lane = (lane >= 0 && lane < MAX_LANE) ? lane : 0; }
 extern "C" int lfg_get_lane(void) { return t_lane; }
@@ -27,6 +28,17 @@ extern "C" void *lfg_lane_stream(int device, int which)
     hipStream_t &st = g_streams[device][t_lane][which];
     if (!st) { if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&st) != hipSuccess) { lf_set_error("hipStreamCreate failed"); return nullptr; } }
     return (void *)st;
+}
+
+/* persistent events of the calling thread's lane on `device` (created on first use, never destroyed: an error path
+ * cannot leak them, and nothing is created or destroyed in the steady state) */
+extern "C" void *lfg_lane_event(int device, int which)
+{
+    if (device < 0 || device >= MAX_DEV || which < 0 || which >= 48) return nullptr;
+    std::lock_guard<std::mutex> g(g_mu);
+    hipEvent_t &ev = g_events[device][t_lane][which];
+    if (!ev) { if (hipSetDevice(device) != hipSuccess || hipEventCreate(&ev) != hipSuccess) { lf_set_error("hipEventCreate failed"); return nullptr; } }
+    return (void *)ev;
 }
 
 extern "C" void *lfg_dev_slot(int device, int slot, size_t bytes)

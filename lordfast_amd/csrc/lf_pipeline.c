@@ -77,7 +77,7 @@ static void *ar_grow(arena_t *a, void *old, size_t old_bytes, size_t new_bytes)
     return p;
 }
 static void ar_reset(arena_t *a) { a->cur = 0; a->off = 0; }
-#define LF_MAX_LANES 16
+#define LF_MAX_LANES 32
 static arena_t g_arena[LF_MAX_LANES][260];          /* [lane][worker]; blocks are kept across chunks and batches */
 
 /* mode 0: owned, growable, NUL-terminated; mode 1: count only (nothing is written); mode 2: fixed external window;
@@ -1863,7 +1863,8 @@ static pthread_mutex_t g_map_lock = PTHREAD_MUTEX_INITIALIZER;     /* the worker
  * for the GPU the other lane's host phases keep the cores busy.  SAM text is written in chunk order. ---- */
 typedef struct { int i0, i1; uint64_t size; int sized; } chunk_t;
 typedef struct {
-    const lf_index_t *ix; const lf_params_t *p;
+    const lf_index_t *const *ixs; int n_ix;       /* one replica of the index per device; lane l works on device l % n_ix */
+    const lf_params_t *p;
     const char *const *names, *const *seqs, *const *quals; const uint32_t *lens;
     int slots;                                  /* per-worker scratch slots = pool workers + 2 drivers */
     chunk_t *chunks; int n_chunks, n_chunks0; volatile int next_chunk;   /* n_chunks0: entries cut up front; n_chunks grows when a lane cuts a chunk */
@@ -1915,7 +1916,7 @@ static void *lane_main(void *arg_)
             continue;                               /* drain the remaining chunk ids the same way */
         }
         ctx_t cx; memset(&cx, 0, sizeof cx);
-        cx.ix = B->ix; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane]; cx.host_cigar = B->host_cigar; cx.host_vote = B->host_vote; cx.lazy = !B->host_cigar && !getenv("LF_NO_LAZY");
+        cx.ix = B->ixs[lane % B->n_ix]; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane]; cx.host_cigar = B->host_cigar; cx.host_vote = B->host_vote; cx.lazy = !B->host_cigar && !getenv("LF_NO_LAZY");
         cx.max_chunk_hits = max_hits;
         cx.n_reads = C->i1 - C->i0;
         cx.reads = (rd_t *)calloc((size_t)cx.n_reads, sizeof(rd_t));
@@ -1999,11 +2000,15 @@ static void *lane_main(void *arg_)
     return NULL;
 }
 
-static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, const char *const *names,
+static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_params_t *p, int n, const char *const *names,
                           const char *const *seqs, const char *const *quals, const uint32_t *seq_lens, char *ext_buf, size_t ext_cap,
                           char **sam, size_t *sam_len, lf_stats_t *stats)
 {
-    if (!ix || !p || n < 0 || (!sam && !ext_buf)) { lf_set_error("lf_map_batch: bad argument"); return LF_ERR_ARG; }
+    if (!ixs || n_ix < 1 || n_ix > 16 || !p || n < 0 || (!sam && !ext_buf)) { lf_set_error("lf_map_batch: bad argument"); return LF_ERR_ARG; }
+    for (int d = 0; d < n_ix; d++) {
+        if (!ixs[d]) { lf_set_error("lf_map_batch: bad argument"); return LF_ERR_ARG; }
+        if (ixs[d]->l_pac != ixs[0]->l_pac || ixs[d]->seq_len != ixs[0]->seq_len || ixs[d]->n_seqs != ixs[0]->n_seqs) { lf_set_error("lf_map_batch_multi: the index replicas differ"); return LF_ERR_ARG; }
+    }
     if (p->chain_alg != 0 && p->chain_alg != 1) { lf_set_error("lf_map_batch: chain_alg must be 0 (dp-n2) or 1 (clasp)"); return LF_ERR_ARG; }
     if (p->chain_alg == 1 && getenv("LF_HOST_VOTE") && atoi(getenv("LF_HOST_VOTE"))) { lf_set_error("lf_map_batch: the LF_HOST_VOTE diagnostic path only knows dp-n2; clasp runs on the device vote path"); return LF_ERR_ARG; }
     if (p->min_anchor_len < 12 || p->min_anchor_len > 20 || p->sampling_count <= 0 || p->max_map < 2 || p->max_ref_hits <= 0 || p->min_read_len < 100) {
@@ -2040,13 +2045,20 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
     int n_lanes = nt >= 12 ? 8 : (nt >= 4 ? 4 : nt);
     if (getenv("LF_LANES")) { n_lanes = atoi(getenv("LF_LANES")); if (n_lanes < 1) n_lanes = 1; if (n_lanes > LF_MAX_LANES) n_lanes = LF_MAX_LANES; if (n_lanes > nt) n_lanes = nt; }
     if (getenv("LF_ONE_LANE")) n_lanes = 1;
+    if (n_ix > 1) {
+        /* several devices: LF_LANES / the default is per device (capped by LF_MAX_LANES and the thread budget); every
+         * device gets at least one lane.  Lanes pull chunks from one shared counter, so the devices balance themselves. */
+        int per = n_lanes; if (per * n_ix > LF_MAX_LANES) per = LF_MAX_LANES / n_ix; if (per * n_ix > nt && nt >= n_ix) per = nt / n_ix; if (per < 1) per = 1;
+        n_lanes = per * n_ix;
+        if (nt < n_lanes) nt = n_lanes;
+    }
     const int nw = nt - n_lanes;                       /* pool workers; the lane drivers work too */
     pool_ensure(nw);
 
     batch_t B; memset(&B, 0, sizeof B);
     B.host_cigar = getenv("LF_HOST_CIGAR") != NULL;
     B.host_vote = getenv("LF_HOST_VOTE") != NULL;          /* diagnostic cross-check only; the device stage is the product path */
-    B.ix = ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + n_lanes; B.rc = LF_OK;
+    B.ixs = ixs; B.n_ix = n_ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + n_lanes; B.rc = LF_OK;
     pthread_mutex_init(&B.mu, NULL); pthread_cond_init(&B.cv, NULL); pthread_rwlock_init(&B.grow, NULL);
     if (ext_buf) { B.all.s = ext_buf; B.all.cap = ext_cap; B.all.n = 0; B.all.mode = 2; B.fixed_out = 1; }
     else str_init(&B.all);
@@ -2120,7 +2132,7 @@ static int map_batch_core(const lf_index_t *ix, const lf_params_t *p, int n, con
 int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *const *names,
                  const char *const *seqs, const char *const *quals, char **sam, size_t *sam_len, lf_stats_t *stats)
 {
-    return map_batch_core(ix, p, n, names, seqs, quals, NULL, NULL, 0, sam, sam_len, stats);
+    return map_batch_core(&ix, 1, p, n, names, seqs, quals, NULL, NULL, 0, sam, sam_len, stats);
 }
 
 /* same, into a caller-owned buffer (e.g. pinned and reused across batches: a fresh multi-GB malloc per batch costs
@@ -2130,7 +2142,7 @@ int lf_map_batch_into(const lf_index_t *ix, const lf_params_t *p, int n, const c
                       const char *const *seqs, const char *const *quals, char *out, size_t out_cap, size_t *sam_len, lf_stats_t *stats)
 {
     if (!out || out_cap < 2) { lf_set_error("lf_map_batch_into: no output buffer"); return LF_ERR_ARG; }
-    return map_batch_core(ix, p, n, names, seqs, quals, NULL, out, out_cap, NULL, sam_len, stats);
+    return map_batch_core(&ix, 1, p, n, names, seqs, quals, NULL, out, out_cap, NULL, sam_len, stats);
 }
 
 /* same with the read lengths supplied (seq_lens[i] == strlen(seqs[i]); the strings stay NUL-terminated): the reference's
@@ -2141,7 +2153,21 @@ int lf_map_batch_into_lens(const lf_index_t *ix, const lf_params_t *p, int n, co
 {
     if (!out || out_cap < 2) { lf_set_error("lf_map_batch_into_lens: no output buffer"); return LF_ERR_ARG; }
     if (!seq_lens && n > 0) { lf_set_error("lf_map_batch_into_lens: no lengths"); return LF_ERR_ARG; }
-    return map_batch_core(ix, p, n, names, seqs, quals, seq_lens, out, out_cap, NULL, sam_len, stats);
+    return map_batch_core(&ix, 1, p, n, names, seqs, quals, seq_lens, out, out_cap, NULL, sam_len, stats);
+}
+
+/* one batch over SEVERAL devices of this process: idx[d] is a replica of the same index on its own device
+ * (lf_index_load(prefix, device d, ...)).  The batch is cut into chunks that the devices' lanes pull from one counter
+ * (the reference's pthread pool pulls reads from a shared cursor the same way, src/LordFAST.cpp:295-303), so the
+ * devices balance themselves; SAM records come out in input order -- byte-identical to the one-device output.
+ * (Two replicas may share a device -- that is how the one-GPU test box exercises this path.)
+ * seq_lens may be NULL; out == NULL: *sam is malloc'd. */
+int lf_map_batch_multi(const lf_index_t *const *idx, int n_idx, const lf_params_t *p, int n, const char *const *names,
+                       const char *const *seqs, const char *const *quals, const uint32_t *seq_lens,
+                       char *out, size_t out_cap, char **sam, size_t *sam_len, lf_stats_t *stats)
+{
+    if (out && out_cap < 2) { lf_set_error("lf_map_batch_multi: output buffer too small"); return LF_ERR_ARG; }
+    return map_batch_core(idx, n_idx, p, n, names, seqs, quals, seq_lens, out, out ? out_cap : 0, out ? NULL : sam, sam_len, stats);
 }
 
 /* printSamHeader (src/BWT.cpp:668-681) */

@@ -187,7 +187,16 @@ static void *ahead_main(void *arg)
 int lf_map_file(const lf_index_t *ix, const lf_params_t *p, const char *reads_path, const char *out_path, int no_header,
                 const char *cmdline, int batch_reads, lf_stats_t *total)
 {
-    if (!ix || !p || !reads_path) { lf_set_error("lf_map_file: bad argument"); return LF_ERR_ARG; }
+    return lf_map_file_multi(&ix, 1, p, reads_path, out_path, no_header, cmdline, batch_reads, total);
+}
+
+/* the same loop over several devices of this process (idx[d]: replica of the index on device d): every batch is
+ * spread over all of them by lf_map_batch_multi; the output is the one-device output, byte for byte */
+int lf_map_file_multi(const lf_index_t *const *idx, int n_idx, const lf_params_t *p, const char *reads_path, const char *out_path, int no_header,
+                      const char *cmdline, int batch_reads, lf_stats_t *total)
+{
+    if (!idx || n_idx < 1 || !idx[0] || !p || !reads_path) { lf_set_error("lf_map_file: bad argument"); return LF_ERR_ARG; }
+    const lf_index_t *ix = idx[0];
     lf_reads_t *rd = NULL;
     int rc = lf_reads_open(reads_path, &rd);
     if (rc != LF_OK) return rc;
@@ -196,7 +205,7 @@ int lf_map_file(const lf_index_t *ix, const lf_params_t *p, const char *reads_pa
     if (!no_header) { char *h = lf_sam_header(ix, p, cmdline ? cmdline : ""); if (h) { fputs(h, fo); lf_free(h); } }
     if (total) memset(total, 0, sizeof *total);
     ahead_t A; memset(&A, 0, sizeof A);
-    A.rd = rd; A.max_reads = batch_reads > 0 ? batch_reads : 100000; A.max_bases = 3ull << 30;
+    A.rd = rd; A.max_reads = batch_reads > 0 ? batch_reads : 100000 * n_idx; A.max_bases = (3ull << 30) * (unsigned)n_idx;
     pthread_mutex_init(&A.mu, NULL); pthread_cond_init(&A.cv, NULL);
     pthread_t th;
     if (pthread_create(&th, NULL, ahead_main, &A) != 0) { lf_set_error("lf_map_file: pthread_create failed"); rc = LF_ERR_NOMEM; goto out; }
@@ -210,7 +219,7 @@ int lf_map_file(const lf_index_t *ix, const lf_params_t *p, const char *reads_pa
         if (rrc != LF_OK) { rc = rrc; lf_set_error("%s", A.err); lf_read_batch_free(b); break; }
         if (!b) break;
         char *sam = NULL; size_t len = 0; lf_stats_t st;
-        rc = lf_map_batch(ix, p, b->n, b->names, b->seqs, b->quals, &sam, &len, &st);       /* the reader is already on the next batch */
+        rc = lf_map_batch_multi(idx, n_idx, p, b->n, b->names, b->seqs, b->quals, NULL, NULL, 0, &sam, &len, &st);       /* the reader is already on the next batch */
         if (rc == LF_OK) {
             if (fwrite(sam, 1, len, fo) != len) { lf_set_error("lf_map_file: short write"); rc = LF_ERR_IO; }
             lf_free(sam);

@@ -227,7 +227,8 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_recs, const lf_rrecor
     lf_rrounds R;
     for (int r = 0; r < LF_MAX_ED_ROUNDS; r++) { R.ops[r] = (const uint8_t *)round_ops[r]; R.desc[r] = (const lf_aln_desc_t *)round_desc[r]; }
     const unsigned char *d_reads = (const unsigned char *)lfg_dev_slot(device, LF_DS_SEED0 + 0, 0);      /* read batch left in HBM by lfg_seed */
-    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    hipEvent_t e0 = (hipEvent_t)lfg_lane_event(device, 32), e1 = (hipEvent_t)lfg_lane_event(device, 33);
+    if (!e0 || !e1) return LF_ERR_HIP;
     HIPCHK(hipMemcpyAsync(d_recs, recs, (size_t)n_recs * sizeof(lf_rrecord_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_items, items, (size_t)n_items * sizeof(lf_ritem_t), hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(e0, s));
@@ -248,7 +249,6 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_recs, const lf_rrecor
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *text_out = h_text; *offs_out = h_offs; *text_bytes = total;
     return LF_OK;
 }

@@ -33,12 +33,30 @@ __global__ void lf_cache_level_kernel(lf_dev_index ix, const uint64_t *__restric
     }
 }
 
-/* full suffix array from the sampled one: SA[k] = steps + SA_sampled[row reached] (lib/bwa/bwt.c:86-96) */
-__global__ void lf_full_sa_kernel(lf_dev_index ix, uint64_t *__restrict__ sa_full, uint64_t n_rows)
+/* Full suffix array from the sampled one.  bwt_sa (lib/bwa/bwt.c:86-96) walks every row to the next sampled row:
+ * SA[k] = steps + SA[row reached], ~31 LF steps per row.  Read the other way the same identity, SA[invPsi(k)] = SA[k] - 1,
+ * lets the rows be filled FROM the sampled ones: a chain starts at a sampled row (value known) and every LF step reaches
+ * the row of the text position just before, until the next sampled row.  Every row is written exactly once: n LF steps
+ * in total instead of ~31 n (4.7 s and 11.5 TB of index reads for a 3.1 Gbp genome before; the values are the same).
+ * Chains have geometric lengths (mean 32, max in the hundreds), so a lane is not tied to one chain: each loop iteration
+ * is ONE LF step of whatever chain the lane is on, and a lane that reaches a sampled row takes its next chain.
+ * Row 0 (the sentinel suffix) is stored as -1 like the reference does (sa[0] = -1) but precedes text position seq_len - 1. */
+__global__ void lf_full_sa_kernel(lf_dev_index ix, uint64_t *__restrict__ sa_full)
 {
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_rows; k += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t steps = 0;
-        sa_full[k] = lf_sa_walk(ix, k, steps);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ix.n_sa) return;
+    uint64_t k = i << 5, v = ix.sa_sampled[i];
+    sa_full[k] = v;
+    if (i == 0) v = ix.seq_len;
+    for (;;) {
+        k = lf_inv_psi(ix, k);
+        if ((k & 31) == 0) {                       /* the next sampled row: this chain is complete */
+            i += stride;
+            if (i >= ix.n_sa) break;
+            k = i << 5; v = ix.sa_sampled[i];
+            sa_full[k] = v;
+        } else { --v; sa_full[k] = v; }
     }
 }
 
@@ -115,7 +133,7 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
     if (ix->flags & LF_IDX_FULL_SA) {
         const uint64_t rows = ix->seq_len + 1;
         HIPCHK(hipMalloc(&st->sa_full, rows * 8));
-        hipLaunchKernelGGL(lf_full_sa_kernel, dim3(256 * 32), dim3(256), 0, st->stream, v, (uint64_t *)st->sa_full, rows);
+        hipLaunchKernelGGL(lf_full_sa_kernel, dim3(256 * 16), dim3(256), 0, st->stream, v, (uint64_t *)st->sa_full);
         HIPCHK(hipStreamSynchronize(st->stream));
         v.sa_full = (const uint64_t *)st->sa_full;
     }
@@ -371,7 +389,7 @@ extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_r
     unsigned long long *d_counters = DSLOT(unsigned long long, 7, 64);
     if (!d_reads || !d_off || !d_pos || !d_pos2 || !d_smp || !d_cnt || !d_hit_off || !d_read_off || !d_counters) return LF_ERR_NOMEM;
     hipEvent_t ev[6];
-    for (int i = 0; i < 6; i++) HIPCHK(hipEventCreate(&ev[i]));
+    for (int i = 0; i < 6; i++) { ev[i] = (hipEvent_t)lfg_lane_event(dv, 34 + i); if (!ev[i]) return LF_ERR_HIP; }
 
     HIPCHK(hipMemsetAsync(d_counters, 0, 32, s));
     HIPCHK(hipMemcpyAsync(d_reads, reads, n_bases, hipMemcpyHostToDevice, s));
@@ -429,7 +447,6 @@ extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_r
     HIPCHK(hipEventElapsedTime(&out->ms_search, ev[0], ev[1]));
     HIPCHK(hipEventElapsedTime(&out->ms_accept, ev[1], ev[2]));
     HIPCHK(hipEventElapsedTime(&out->ms_locate, ev[3], ev[4]));
-    for (int i = 0; i < 6; i++) (void)hipEventDestroy(ev[i]);
 #undef DSLOT
     return LF_OK;
 }

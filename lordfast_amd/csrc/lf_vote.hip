@@ -306,7 +306,8 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     const uint8_t *d_strand = (const uint8_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 11, 0);
     if (!d_off || !d_read_off || !d_tpos || !d_qpl || !d_strand) { lf_set_error("lfg_vote_chain: no resident seed batch"); return LF_ERR_ARG; }
 #define VSLOT(k, bytes) lfg_dev_slot(dv, LF_DS_VOTE0 + (k), (bytes))
-    hipEvent_t e0, e1, e2; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
+    hipEvent_t e0 = (hipEvent_t)lfg_lane_event(dv, 16), e1 = (hipEvent_t)lfg_lane_event(dv, 17), e2 = (hipEvent_t)lfg_lane_event(dv, 18);
+    if (!e0 || !e1 || !e2) return LF_ERR_HIP;
     HIPCHK(hipEventRecord(e0, s));
 
     /* per-read arrays, one allocation */
@@ -385,7 +386,6 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
         HIPCHK(hipStreamSynchronize(s));
         out->req0[R] = 0;
         HIPCHK(hipEventElapsedTime(&out->ms_vote, e0, e1));
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
         return LF_OK;
     }
 
@@ -480,10 +480,8 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
          * -- one window per CU -- would hold the whole stage up. */
         enum { NCC = 9 };
         static const uint32_t CCAPS[NCC] = { 64, 128, 192, 256, 384, 512, 768, LF_CLASP_LDS_MAX, 0 };
-        static hipEvent_t ev_all[32][NCC + 1]; static bool ev_init[32] = { false };
-        const int lane_id = lfg_get_lane();
-        if (!ev_init[lane_id]) { for (int k = 0; k <= NCC; k++) HIPCHK(hipEventCreateWithFlags(&ev_all[lane_id][k], hipEventDisableTiming)); ev_init[lane_id] = true; }
-        hipEvent_t *ev = ev_all[lane_id];
+        hipEvent_t ev[NCC + 1];
+        for (int k = 0; k <= NCC; k++) { ev[k] = (hipEvent_t)lfg_lane_event(dv, 20 + k); if (!ev[k]) return LF_ERR_HIP; }
         HIPCHK(hipEventRecord(ev[NCC], s));
         for (int c = NCC - 1; c >= 0; c--) {
             const uint32_t lo = c == 0 ? 0u : CCAPS[c - 1] + 1u, hi = CCAPS[c] ? CCAPS[c] : 0xFFFFFFFFu;
@@ -544,7 +542,6 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     out->n_chain_seeds = C;
     HIPCHK(hipEventElapsedTime(&out->ms_vote, e0, e1));
     HIPCHK(hipEventElapsedTime(&out->ms_chain, e1, e2));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
 #undef VSLOT
     return LF_OK;
 }

@@ -20,8 +20,8 @@ def cli():
     return CLI
 
 
-def run(cli, *args):
-    return subprocess.run([cli, *args], capture_output=True, timeout=600)
+def run(cli, *args, env=None):
+    return subprocess.run([cli, *args], capture_output=True, timeout=600, env=env)
 
 
 def test_usage_and_validation(cli):
@@ -82,6 +82,13 @@ def test_search_end_to_end(cli, golden_dir, oracle, oracle_lib, tmp_path):
     exp = oracle.sam_header(" ".join([cli] + args) + " ", params=p) + oracle.map_batch(names, seqs, params=p)
     assert r.stdout == exp
     assert b"@RG\tID:grp1\tSM:x\n@PG" in r.stdout and b"\tRG:Z:grp1" in r.stdout
+    # LF_DEVICES: the batches are spread over several index replicas (here two on device 0); same records, same order
+    args = ["--search", fa, "--seq", reads, "--noSamHeader", "-t", "4"]
+    r = run(cli, *args, env=dict(os.environ, LF_DEVICES="0,0", LF_CHUNK_READS="9"))
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == golden_sam("default")
+    r = run(cli, *args, env=dict(os.environ, LF_DEVICES="0-99"))
+    assert r.returncode != 0 and b"no gfx950 device" in r.stderr
 
 
 @pytest.mark.gpu

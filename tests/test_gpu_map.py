@@ -271,3 +271,22 @@ def test_chunk_is_cut_when_it_has_too_many_seed_hits(lf, golden_reads, monkeypat
     exp = golden_sam("default")
     assert sam == exp, first_diff(sam, exp)
     assert st["n_reads"] == len(seqs)
+
+
+@pytest.mark.parametrize("cfg,chunk", [("default", 7), ("clasp_n30", 16), ("default", 0)])
+def test_map_batch_multi_replicas_same_output(golden_dir, golden_reads, monkeypatch, cfg, chunk):
+    """lf_map_batch_multi over three index replicas (on the one GPU of the test box; normally one per GPU): chunks are
+    pulled by the replicas' lanes from one counter, records come out in input order -- the one-device SAM, byte for byte"""
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    hs = [la.LordFast(os.path.join(golden_dir, "genome.fa"), device=0, full_sa=(k != 1)) for k in range(3)]   # one replica locates by LF walk
+    try:
+        if chunk:
+            monkeypatch.setenv("LF_CHUNK_READS", str(chunk))
+        sam, st = la.map_batch_multi(hs, names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
+    finally:
+        for h in hs:
+            h.close()
+    exp = golden_sam(cfg)
+    assert sam == exp, first_diff(sam, exp)
+    assert st["n_reads"] == len(seqs)
