@@ -40,9 +40,29 @@ def parse():
     ap.add_argument("--chain-alg", choices=["dp-n2", "clasp"], default="dp-n2",
                     help="BASELINE config C2 (the headline) is dp-n2; clasp + --max-map 30 is config C4's option set")
     ap.add_argument("--max-map", type=int, default=10, help="-n (config C4: 30)")
-    ap.add_argument("--single-output", action="store_true",
-                    help="N>1: also gather every rank's SAM records behind rank 0's (point-to-point over RCCL) inside the timed region")
-    return ap.parse_args()
+    ap.add_argument("--single-output", action="store_true", help="(kept for round-1 command lines) same as --exchange on")
+    ap.add_argument("--exchange", choices=["auto", "on", "off"], default="auto",
+                    help="N>1: rank 0 owns the whole read batch; scatter it to the ranks and gather their SAM records back inside "
+                         "the timed region (RCCL point-to-point).  auto = on for N>1.  The rate without the exchange is reported too")
+    ap.add_argument("--repeat-profile", choices=["default", "grch38like"], default="default",
+                    help="default: 10 %% of the genome from 1000 low-copy families (SURVEY 8d); grch38like: ~50 %% repeats incl. a "
+                         "300 bp family with ~10^6 copies per 3 Gbp and truncated 1-6 kbp families")
+    ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2",
+                    help="BASELINE.json config: c2 = 15 kbp / 15 %% PacBio, -k 14 -c 1000 dp-n2 (headline); c4 = clasp -n 30; "
+                         "c5 = 50 kbp / 10 %% ONT error mix, -k 17 -c 2000")
+    a = ap.parse_args()
+    if a.single_output:
+        a.exchange = "on"
+    if a.config == "c4":
+        a.chain_alg, a.max_map = "clasp", 30
+    if a.config == "c5":
+        if a.read_len == 15000:
+            a.read_len = 50000
+        if a.err == 0.15:
+            a.err = 0.10
+        if "LF_BENCH_READS" not in os.environ and a.reads == 100000:
+            a.reads = 30000
+    return a
 
 
 def log(*a):
@@ -58,13 +78,13 @@ def make_contigs(args):
     """the synthetic genome is a pure function of its recipe: any rank can regenerate it instead of parsing the FASTA"""
     from lordfast_amd import synth
     total, n_contigs, fams = genome_recipe(args)
-    return synth.make_genome(total, n_contigs, seed=11, repeat_frac=0.10, n_families=fams)
+    return synth.make_genome(total, n_contigs, seed=11, repeat_frac=0.10, n_families=fams, profile=args.repeat_profile)
 
 
 def ensure_index(args, rank):
     """synthetic genome + index files under workdir (rank 0 builds, others wait on the done marker)"""
     from lordfast_amd import synth
-    tag = f"g{args.genome_mbp:g}"
+    tag = f"g{args.genome_mbp:g}" + ("" if args.repeat_profile == "default" else "_" + args.repeat_profile)
     d = os.path.join(args.workdir, tag)
     fa = os.path.join(d, "genome.fa")
     done = os.path.join(d, "DONE")
@@ -89,7 +109,7 @@ def make_reads(args, contigs, fa, rank):
     """this rank's seeded reads (seed 2024 + rank: every GPU maps DIFFERENT reads); cached on disk so that repeated
     bench runs on one box skip generation"""
     from lordfast_amd import synth
-    key = hashlib.md5(f"{fa}|{args.reads}|{args.read_len}|{args.err}|{rank}".encode()).hexdigest()[:12]
+    key = hashlib.md5(f"{fa}|{args.reads}|{args.read_len}|{args.err}|{rank}|{args.config == 'c5'}".encode()).hexdigest()[:12]
     path = os.path.join(os.path.dirname(fa), f"reads_{key}.npz")
     if os.path.exists(path):
         z = np.load(path)
@@ -100,7 +120,8 @@ def make_reads(args, contigs, fa, rank):
     if contigs is None:
         contigs = make_contigs(args)
     t0 = time.time()
-    reads = synth.make_reads(contigs, args.reads, args.read_len, args.err, seed=2024 + rank)
+    mix = (0.40, 0.25, 0.35) if args.config == "c5" else (0.15, 0.50, 0.35)          # ONT / PacBio CLR profile
+    reads = synth.make_reads(contigs, args.reads, args.read_len, args.err, seed=2024 + rank, mix=mix)
     names = [(r[0] if rank == 0 else f"g{rank}_{r[0]}").encode() for r in reads]
     seqs = [r[1] for r in reads]
     log(f"rank {rank}: {args.reads} reads generated in {time.time() - t0:.1f}s")
@@ -133,7 +154,9 @@ def cpu_baseline(args, fa, names, seqs):
         pass
     best = None
     for th in cands:
-        ref.set_params(po.default_params(threads=th, chain_alg=1 if args.chain_alg == 'clasp' else 0, max_map=args.max_map), "bench")
+        kk, cc = (17, 2000) if args.config == "c5" else (14, 1000)
+        ref.set_params(po.default_params(threads=th, chain_alg=1 if args.chain_alg == 'clasp' else 0, max_map=args.max_map,
+                                         min_anchor_len=kk, sampling_count=cc), "bench")
         c = ref.threads()
         pilot = min(len(seqs), max(4 * c, 256))
         _, secs = ref.map_mem(names[:pilot], seqs[:pilot])
@@ -142,13 +165,23 @@ def cpu_baseline(args, fa, names, seqs):
         if best is None or r > best[0]:
             best = (r, th, c)
     rate, th, cores = best
-    ref.set_params(po.default_params(threads=th, chain_alg=1 if args.chain_alg == 'clasp' else 0, max_map=args.max_map), "bench")
+    ref.set_params(po.default_params(threads=th, chain_alg=1 if args.chain_alg == 'clasp' else 0, max_map=args.max_map,
+                                     min_anchor_len=kk, sampling_count=cc), "bench")
     n = int(min(len(seqs), max(pilot, rate * args.cpu_seconds)))
     sam, secs = ref.map_mem(names[:n], seqs[:n])
     bases = sum(len(s) for s in seqs[:n])
-    return dict(value=n / secs, unit="reads/s", cores=cores, kind="reference",
+    granted = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            granted = min(granted, max(1, -(-int(q) // int(per))))
+    except Exception:                                                    # noqa: BLE001
+        pass
+    # `cores` = the CPUs this container may use (cgroup quota), `threads` = the reference's --threads value that was fastest
+    return dict(value=n / secs, unit="reads/s", cores=granted, cpus_granted=granted, cpus_online=os.cpu_count(), threads=cores,
+                kind="reference",
                 sample=f"first {n} reads of the same batch ({bases / 1e6:.1f} Mbp), mapSeqMT only, {secs:.1f}s, "
-                       f"--threads {cores}", bp_per_s=bases / secs), sam, n
+                       f"--threads {cores} on {granted} granted CPUs", bp_per_s=bases / secs), sam, n
 
 
 def main():
@@ -187,11 +220,24 @@ def main():
     t0 = time.time()
     lf = la.LordFast(fa, device=local, full_sa=True)
     log(f"rank {rank}: index resident in HBM after {time.time() - t0:.1f}s")
-    params = la.default_params(min_anchor_len=14, sampling_count=1000,       # -k 14 -c 1000 --chainAlg dp-n2 (C2)
+    kk, cc = (17, 2000) if args.config == "c5" else (14, 1000)             # -k 14 -c 1000 --chainAlg dp-n2 (C2); -k 17 -c 2000 (C5)
+    params = la.default_params(min_anchor_len=kk, sampling_count=cc,
                                chain_alg=1 if args.chain_alg == "clasp" else 0, max_map=args.max_map)
 
     n_total = args.reads * world
-    names, seqs = make_reads(args, contigs, fa, rank)        # reads shard by rank: no data-path collective
+    exchange = world > 1 and args.exchange in ("auto", "on")
+    names, seqs = make_reads(args, contigs, fa, rank)        # this rank's shard (seed 2024 + rank)
+    packed_all = None
+    if exchange and rank == 0:
+        # rank 0 OWNS the whole job's read batch (shard r = the reads rank r would generate itself), packed once, outside
+        # the timed region, the way a reader thread leaves a chunk in host memory (one blob + offsets)
+        all_names, all_seqs = list(names), list(seqs)
+        for r in range(1, world):
+            nr, sr = make_reads(args, contigs, fa, r)
+            all_names += nr; all_seqs += sr
+        packed_all = lfd.pack_reads(all_names, all_seqs)
+        del all_names, all_seqs
+        log(f"rank 0 owns the batch: {len(packed_all)} reads, {packed_all.blob.nbytes / 1e9:.2f} GB packed")
     contigs = None
     bases_local = sum(len(s) for s in seqs)
 
@@ -213,7 +259,7 @@ def main():
     # records are gathered behind its own, so the output order is the input order)
     est_bases = args.reads * args.read_len * 1.15
     cap_one = int(2.6 * est_bases) + args.reads * 2048 + (1 << 20)
-    cap = cap_one * (world if (rank == 0 and args.single_output) else 1)
+    cap = cap_one * (world if (rank == 0 and exchange) else 1)
     try:
         out_buf = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
     except RuntimeError:
@@ -232,44 +278,82 @@ def main():
         def head(self, k):
             return bytes(out_buf[:min(k, self.n)].numpy().tobytes())
 
-    def step():
-        na, sa = fixed_arrays
+    def step(with_exchange=False):
+        t_x0 = time.perf_counter()
+        if with_exchange:
+            # scatter: every rank receives its shard (two byte ranges + offsets) and maps it straight out of the receive buffer
+            shard, _ = lfd.scatter_packed_p2p(dist, torch, packed_all, rdev)
+            na, sa, sl = shard.arrays()
+            nn = shard
+        else:
+            (na, sa), sl, nn = fixed_arrays, seq_lens, names
         t_call = time.perf_counter()
-        ln, st = lf.map_batch_into(names, seqs, out_ptr, cap_one, params=params, name_arr=na, seq_arr=sa, seq_lens=seq_lens)
+        ln, st = lf.map_batch_into(nn, None, out_ptr, cap_one, params=params, name_arr=na, seq_arr=sa, seq_lens=sl)
         st["ms_python_call"] = (time.perf_counter() - t_call) * 1e3
-        if dist and args.single_output:                      # optional: one SAM stream on rank 0, input order
+        t_g0 = time.perf_counter()
+        if with_exchange:                                    # gather: one SAM stream on rank 0, input order
             ln = lfd.gather_sam_p2p(dist, torch, out_buf, ln, rdev)
+        st["ms_scatter"] = (t_call - t_x0) * 1e3
+        st["ms_gather"] = (time.perf_counter() - t_g0) * 1e3
         return _Sam(ln or 0), st
 
+    def timed(n_steps, with_exchange):
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cpu0 = sum(os.times()[:4])
+        agg, sam = None, None
+        for _ in range(n_steps):
+            sam, st = step(with_exchange)
+            if agg is None:
+                agg = dict(st)
+            else:
+                for k, v in st.items():
+                    agg[k] += v
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        cpu_s = sum(os.times()[:4]) - cpu0
+        if dist:
+            tmax = torch.tensor([el], dtype=torch.float64, device=rdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el, cpu_s, agg, sam
+
     for _ in range(args.warmup):
-        step()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    cpu0 = sum(os.times()[:4])
-    agg = None
-    sam = None
-    for _ in range(args.steps):
-        sam, st = step()
-        if agg is None:
-            agg = dict(st)
-        else:
-            for k, v in st.items():
-                agg[k] += v
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    cpu_s = sum(os.times()[:4]) - cpu0
+        step(exchange)
+    # the timed region: EXACTLY --steps steps between barrier + synchronize, max over ranks.  With N > 1 the exchange
+    # (scatter of the read batch from rank 0, gather of the SAM records) is INSIDE it; the same number of steps is then
+    # timed again without it (every rank maps the shard it already holds) and reported as value_without_exchange.
+    elapsed, cpu_s, agg, sam = timed(args.steps, exchange)
+    elapsed_nx = None
+    if exchange:
+        elapsed_nx, _, _, _ = timed(args.steps, False)
     bases_total = bases_local
     if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
         bsum = torch.tensor([bases_local], dtype=torch.int64, device=rdev)
         dist.all_reduce(bsum, op=dist.ReduceOp.SUM)
         bases_total = int(bsum.item())
+
+    # ---- exclusive pass (rank 0, outside the timed region): ONE step with one chunk at a time and the alignment size classes
+    # on one stream, so that every HIP-event bracket is the kernel (group) ALONE on the GPU.  The timed steps above keep
+    # eight chunks in flight: their brackets overlap and are only reported as `overlapped_bracket_ms`.
+    excl = None
+    if rank == 0:
+        saved = {k: os.environ.get(k) for k in ("LF_LANES", "LF_SERIAL_CLASSES")}
+        os.environ["LF_LANES"] = "1"; os.environ["LF_SERIAL_CLASSES"] = "1"
+        try:
+            _, excl = step(False)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    if dist:
+        dist.barrier()
 
     try:
         free_b, total_b = torch.cuda.mem_get_info(local)
@@ -280,75 +364,83 @@ def main():
         K = args.steps
         bases = bases_total
         value = n_total * K / elapsed
-        # ---- roofline: algorithmic bytes (SURVEY 8d counters emitted by the kernels) / HIP-event kernel time, rank 0 ----
-        # HIP events bracket each kernel (or launch group) on the stream it runs on.  Eight chunks are in flight, so a
-        # bracket also contains time the kernel spent sharing the GPU with the other chunks' kernels.
-        n_hits = agg["n_seeds"]
-        kernels = {
-            "lf_seed_search_kernel": (agg["ms_k_search"], 16 * agg["n_cache"] + 64 * agg["n_occblk"] + agg["n_readbytes"], agg["search_launches"]),
-            "lf_seed_locate_kernel": (agg["ms_k_locate"], 8 * agg["n_sa"] + 9 * agg["n_sa"], agg["locate_launches"]),
-            # lf_vote_keys_kernel + radix sort + reduce-by-key + lf_vote_select_kernel: 9 B/hit read, 2 x 12 B (key, weight) per hit
-            "lf_vote_* (keys, sort, reduce, select)": (agg["ms_k_vote"], 33 * n_hits, agg["search_launches"]),
-            # request gather + sort by qPos + lf_chain_n2_kernel + chain gather: 16 B per request seed, 8 B per chain seed
-            "lf_chain_* (gather, sort, dp-n2)": (agg["ms_k_chain"], 16 * agg["n_req_seeds"], agg["search_launches"]),
-            # the edlib size classes (lf_edlib_kernel<1,2,3,4,6,8>, lf_edlib_group_kernel<16,32>, lf_edlib_wave_kernel<1,4>)
-            # run concurrently on their own streams as ONE launch group; the events bracket the group
-            "lf_edlib_* (size-class launch group)": (agg["ms_k_edlib"], agg["ext_bytes"], max(1, agg["edlib_launches"])),
-            # CIGAR / MD: every op byte read twice (count pass, write pass), text written once
-            "lf_render_kernel": (agg["ms_k_render"], 2 * agg["ops_bytes"] + agg["render_bytes"], max(1, agg["render_launches"])),
-        }
+        # ---- roofline: algorithmic bytes (SURVEY 8d counters emitted by the kernels) / EXCLUSIVE kernel time ----
+        # Durations come from the exclusive pass (one step = one launch sequence per chunk; HIP events on the launch
+        # streams; nothing else on the GPU).  Their sum is below ms_per_step; profiles/r02_c2 holds the rocprofv3
+        # --kernel-trace --stats summary of the same serialized command.
+        def kernel_table(a):
+            n_hits = a["n_seeds"]
+            return {
+                "lf_seed_search_kernel": (a["ms_k_search"], 16 * a["n_cache"] + 64 * a["n_occblk"] + a["n_readbytes"], a["search_launches"]),
+                "lf_seed_locate_kernel": (a["ms_k_locate"], 8 * a["n_sa"] + 9 * a["n_sa"], a["locate_launches"]),
+                # lf_vote_hash_kernel (+ request-count scan): 9 B per hit read; votes live in LDS
+                "lf_vote_hash_kernel (+ scan)": (a["ms_k_vote"], 9 * n_hits, a["search_launches"]),
+                # request gather + sort by qPos + lf_chain_n2_kernel + chain gather: 16 B per request seed, 8 B per chain seed
+                "lf_chain_* (gather, sort, dp-n2 | clasp)": (a["ms_k_chain"], 16 * a["n_req_seeds"], a["search_launches"]),
+                # the alignment size classes lf_edlib_kernel<1,2,3,4,6,8>, lf_edlib_sweep_kernel<16|32|64, ...>: one launch group per round
+                "lf_edlib_* (size-class launch group)": (a["ms_k_edlib"], a["ext_bytes"], max(1, a["edlib_launches"])),
+                # CIGAR / MD: every op byte read twice (count pass, write pass), text written once
+                "lf_render_kernel": (a["ms_k_render"], 2 * a["ops_bytes"] + a["render_bytes"], max(1, a["render_launches"])),
+                "lf_ksw_kernel": (a["ms_k_ksw"], 0, max(1, a["n_ksw_problems"] and 1)),
+            }
+        kx = kernel_table(excl)
         by_kernel = {}
-        for kname, (kms, kbytes, kl) in kernels.items():
+        for kname, (kms, kbytes, kl) in kx.items():
             gbs = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-            by_kernel[kname] = dict(ms_per_step=kms / K, launches_per_step=kl / K, algorithmic_GB_per_step=kbytes / K / 1e9,
+            by_kernel[kname] = dict(ms_per_step=kms, launches_per_step=kl, avg_launch_ms=kms / max(1, kl), algorithmic_GB_per_step=kbytes / 1e9,
                                     achieved_GBps=gbs, frac_of_8TBps=gbs / 8000.0)
-        # `roofline` is quoted on the dominant SINGLE kernel (rocprofv3's top row after the one-off index residency kernel:
-        # one name, one launch per chunk, HIP-event average comparable with the profiler's); the extension stage as a whole
-        # is larger but is a group of ten kernels run concurrently -- it gets the same fields under `roofline_edlib_group`
-        single = ["lf_seed_search_kernel", "lf_seed_locate_kernel", "lf_render_kernel"]
+        excl_sum = sum(v[0] for v in kx.values())
+        dom = max(kx, key=lambda k: kx[k][0])                 # the dominant kernel (group) by exclusive time
         pmc = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_c2", "pmc_fetch_write_summary.json")
-        if os.path.exists(pmc_path) and args.genome_mbp == 3100 and args.reads == 100000 and world == 1:
+        pmc_path = os.path.join(ROOT, "profiles", "r02_c2", "pmc_fetch_write_summary.json")
+        if os.path.exists(pmc_path) and args.genome_mbp == 3100 and args.reads == 100000 and world == 1 and args.config == "c2" and args.repeat_profile == "default":
             pmc = json.load(open(pmc_path))           # one profiled step of the same command (FETCH_SIZE / WRITE_SIZE passes)
-
-        def roof(kname, prefix):
-            ms, alg_bytes, launches = kernels[kname]
-            achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            traffic = None
-            if pmc:
-                fam = [v for k, v in pmc.items() if k.startswith(prefix)]
-                if fam:    # KB, raw (the gfx950 "x2 for wide coalesced reads" correction is NOT applied: profiles/r01_c2/README.md)
-                    traffic = sum(v.get("fetch_kb", 0.0) + v.get("write_kb", 0.0) for v in fam) * 1024.0 / max(1.0, launches / K)
-            return dict(bound="hbm", kernel=kname, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=traffic,
-                        launches=int(launches), avg_launch_ms=ms / max(1, launches), algorithmic_bytes_per_launch=alg_bytes / max(1, launches))
-
-        # pinned, not picked per run: with eight chunks in flight the brackets of search and render swap places from
-        # run to run; lf_seed_search_kernel is the HBM-bound kernel of the path (random 64-byte index reads) and
-        # rocprofv3's top single kernel outside the alignment group
-        dom = single[0]
-        roofline = roof(dom, dom)
-        roofline.update(per_kernel_ms={k: round(v[0], 3) for k, v in kernels.items()}, by_kernel=by_kernel, chunks_in_flight=8,
-                        note="HIP-event brackets with up to 8 chunks in flight: a bracket contains time shared with the other chunks' kernels; "
-                             "profiles/r01_c2/README.md has the one-chunk-at-a-time figures (search alone: 8.4 ms per 25 k reads = 0.88 TB/s of algorithmic bytes)")
-        roofline_edlib = roof("lf_edlib_* (size-class launch group)", "lf_edlib_")
-        roofline_edlib["note"] = ("integer-ALU / latency bound; HBM traffic is the 2-bit-per-cell traceback history (16 B per column and "
-                                  "64-row block), ~60x the algorithmic bytes")
+        dms, dbytes, dl = kx[dom]
+        achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
+        traffic = None
+        if pmc:
+            prefix = dom.split(" ")[0].rstrip("*")
+            fam = [v for k, v in pmc.items() if k.startswith(prefix)]
+            if fam:    # bytes per launch; FETCH_SIZE x2 for the wide coalesced reads is NOT applied (profiles/r02_c2/README.md)
+                traffic = sum(v.get("fetch_kb", 0.0) + v.get("write_kb", 0.0) for v in fam) * 1024.0 / max(1.0, dl)
+        roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=traffic,
+                        launches_per_step=int(dl), avg_launch_ms=dms / max(1, dl), algorithmic_bytes_per_launch=dbytes / max(1, dl),
+                        exclusive_ms_per_step=dms, exclusive_ms_sum_all_kernels=excl_sum, by_kernel=by_kernel,
+                        measured="exclusive pass inside bench.py: LF_LANES=1 LF_SERIAL_CLASSES=1, HIP events on the launch streams, one step "
+                                 "after the timed region; the rocprofv3 summary of the same mode is profiles/r02_c2/kernel_stats_serialized.csv",
+                        overlapped_bracket_ms_per_step={k: round(v[0] / K, 2) for k, v in kernel_table(agg).items()},
+                        chunks_in_flight_timed_region=8)
+        if dom.startswith("lf_edlib"):
+            # the alignment kernels are integer-ALU work, not HBM work: one Myers block step (64 DP cells) is ~55 32-bit lane
+            # operations; the chip issues 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s
+            lane_ops = excl["dp_block_steps"] * 55.0
+            roofline["alu"] = dict(bound="int32 VALU", achieved=lane_ops / (dms * 1e-3) / 1e12, peak=78.6, unit="T lane-ops/s",
+                                   frac=lane_ops / (dms * 1e-3) / 1e12 / 78.6, dp_block_steps_per_step=excl["dp_block_steps"],
+                                   note="forward pass only (algorithmic work); the traceback recomputes tiles from checkpoints on top of it")
         out = {
             "metric": "aligned reads/s", "value": value, "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{args.reads} synthetic PacBio reads per GPU (~{args.read_len} bp, {args.err:.0%} err) vs "
-                                   f"{args.genome_mbp:g} Mbp synthetic genome, -k 14 -c 1000 --chainAlg {args.chain_alg}" + (f" -n {args.max_map}" if args.max_map != 10 else ""),
+            "config": {"workload": f"{args.config}: {args.reads} synthetic {'ONT' if args.config == 'c5' else 'PacBio'} reads per GPU (~{args.read_len} bp, {args.err:.0%} err) vs "
+                                   f"{args.genome_mbp:g} Mbp synthetic genome ({args.repeat_profile} repeats), -k {kk} -c {cc} --chainAlg {args.chain_alg}" + (f" -n {args.max_map}" if args.max_map != 10 else ""),
                        "reads_per_gpu": args.reads, "mean_read_len": bases / max(1, n_total), "genome_mbp": args.genome_mbp,
-                       "parallelism": f"reads sharded over {world} GPU(s), index replicated, no data-path collective"
-                                      + (" + SAM gather to rank 0" if (dist and args.single_output) else ""), "index": "FM-index + full SA resident in HBM"},
+                       "parallelism": (f"rank 0 owns the {n_total}-read batch: RCCL point-to-point scatter of the packed reads + gather of the SAM "
+                                       f"records inside the timed region; {world} GPUs, index replicated" if exchange else
+                                       f"reads sharded over {world} GPU(s), index replicated, no data-path collective"),
+                       "index": "FM-index + full SA resident in HBM"},
             "gbp_per_s": bases * K / elapsed / 1e9, "host_cpu_seconds_per_step": cpu_s / K, "hbm_used_gb": hbm_used_gb,
-            "host_ms_per_step": {k: agg[k] / K for k in ("ms_total", "ms_python_call", "ms_seed", "ms_vote", "ms_chain", "ms_extend", "ms_render", "ms_sam")},
+            "host_ms_per_step": {k: agg[k] / K for k in ("ms_total", "ms_python_call", "ms_seed", "ms_vote", "ms_chain", "ms_extend", "ms_render", "ms_sam", "ms_scatter", "ms_gather")},
             "per_read": {"seeds": agg["n_seeds"] / (n_total * K / world), "edlib_problems": agg["n_edlib_problems"] / (n_total * K / world),
                          "seed_bytes": (16 * agg["n_cache"] + 64 * agg["n_occblk"] + 8 * agg["n_sa"] + agg["n_readbytes"]) / (n_total * K / world),
-                         "ext_bytes": agg["ext_bytes"] / (n_total * K / world), "cigar_md_text_bytes": agg["render_bytes"] / (n_total * K / world)},
-            "roofline": roofline, "roofline_edlib_group": roofline_edlib,
+                         "ext_bytes": agg["ext_bytes"] / (n_total * K / world), "cigar_md_text_bytes": agg["render_bytes"] / (n_total * K / world),
+                         "dp_block_steps": agg["dp_block_steps"] / (n_total * K / world),
+                         "chain_requests": agg["n_chain_problems"] / (n_total * K / world), "tie_requests": agg["n_tie_requests"] / (n_total * K / world),
+                         "ksw_problems": agg["n_ksw_problems"] / (n_total * K / world)},
+            "roofline": roofline,
         }
+        if elapsed_nx is not None:
+            out["value_without_exchange"] = n_total * K / elapsed_nx
+            out["ms_per_step_without_exchange"] = elapsed_nx / K * 1e3
         if not args.no_cpu_baseline and world == 1:
             try:
                 cb = cpu_baseline(args, fa, names, seqs)
@@ -358,24 +450,32 @@ def main():
             if cb:
                 base, ref_sam, n = cb
                 out["cpu_baseline"] = base
-                out["speedup_vs_cpu_baseline"] = value / base["value"]
-                # CIGAR bit-match rate against the reference on the sampled reads (primary records)
-                # the reference sample is a prefix of the batch: compare the head of our SAM (records are in read order)
-                head = sam.head(4 * len(ref_sam) + (1 << 20)) if hasattr(sam, "head") else sam[:4 * len(ref_sam) + (1 << 20)]
-                mine = [l for l in head.split(b"\n")[:-1] if l]
-                want = {}
-                for l in ref_sam.split(b"\n"):
-                    f = l.split(b"\t")
-                    if len(f) > 5 and not (int(f[1]) & (256 | 2048)):
-                        want[f[0]] = l
-                hit = tot = 0
-                for l in mine:
-                    f = l.split(b"\t")
-                    if f[0] in want and not (int(f[1]) & (256 | 2048)):
-                        tot += 1
-                        hit += (l == want[f[0]])
+                out["speedup_vs_cpu_baseline"] = value / base["value"]          # vs `cpus_granted` host CPUs (not an optimisation target)
+                # bit-match against the reference on the sampled reads: the sample is a prefix of the batch and records are in
+                # read order, so the head of our SAM holds the same reads.  Primary records (the BASELINE metric) and ALL
+                # records of a read (secondaries, supplementaries: same lines, same order) are compared.
+                head = sam.head(6 * len(ref_sam) + (1 << 20)) if hasattr(sam, "head") else sam[:6 * len(ref_sam) + (1 << 20)]
+                def by_read(txt):
+                    d = {}
+                    for l in txt.split(b"\n"):
+                        if l:
+                            d.setdefault(l.split(b"\t", 1)[0], []).append(l)
+                    return d
+                want, mine = by_read(ref_sam), by_read(head[:head.rfind(b"\n") + 1])
+                hit = tot = hit_all = 0
+                for nm, lines in want.items():
+                    got = mine.get(nm)
+                    if got is None:
+                        continue
+                    tot += 1
+                    hit_all += (got == lines)
+                    pw = [l for l in lines if not (int(l.split(b"\t")[1]) & (256 | 2048))]
+                    pg = [l for l in got if not (int(l.split(b"\t")[1]) & (256 | 2048))]
+                    hit += (pw == pg)
                 out["primary_record_match_rate"] = hit / max(1, tot)
-                out["primary_records_compared"] = tot
+                out["all_records_match_rate"] = hit_all / max(1, tot)
+                out["reads_compared"] = tot
+                out["records_compared"] = sum(len(v) for k, v in want.items() if k in mine)
         print(json.dumps(out), flush=True)
     lf.close()
     if dist:

@@ -167,6 +167,7 @@ typedef struct {
     double ms_render; float ms_k_render, ms_k_vote; uint64_t render_bytes, render_launches;
     uint64_t ops_bytes;                                 /* edit-path bytes left in HBM for the renderer */
     uint64_t n_req_seeds, n_tie_requests;              /* seeds gathered into chain requests; requests whose equal qPos needed the std::sort replay */
+    uint64_t dp_block_steps;                            /* sum over alignment problems of ceil(q / 64) * t: Myers block steps of one forward pass */
 } lf_stats_t;
 
 int  lf_map_batch(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,

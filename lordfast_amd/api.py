@@ -53,7 +53,7 @@ class Stats(C.Structure):
                                           "edlib_launches", "search_launches", "locate_launches")] + \
                [("ms_render", C.c_double), ("ms_k_render", C.c_float), ("ms_k_vote", C.c_float),
                 ("render_bytes", C.c_uint64), ("render_launches", C.c_uint64),
-                ("ops_bytes", C.c_uint64), ("n_req_seeds", C.c_uint64), ("n_tie_requests", C.c_uint64)]
+                ("ops_bytes", C.c_uint64), ("n_req_seeds", C.c_uint64), ("n_tie_requests", C.c_uint64), ("dp_block_steps", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

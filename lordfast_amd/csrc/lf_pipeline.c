@@ -186,7 +186,7 @@ typedef struct {
     uint8_t *kq, *kt; uint64_t kqn, kqcap, ktn, ktcap;
     uint64_t *kqoff, *ktoff; int32_t *kprm; int kn, kcap;
     memo_t **kowner;
-    uint64_t ext_bytes;
+    uint64_t ext_bytes, blk_steps;
     /* staged edlib requests as descriptors into HBM-resident reads / pac (leaf-size problems: the common case) */
     lf_aln_desc_t *dd; uint64_t *dops; uintptr_t *downer; int dn, dcap; uint64_t dops_total;
     /* CIGAR / MD recipes of the finished records (rendered by lf_render.hip after the last round) */
@@ -689,6 +689,7 @@ static void stage_edlib(walk_t *w, memo_t *m)
     s->owner[s->n] = (memo_t *)(uintptr_t)(((uint64_t)(uintptr_t)(m - w->job->memo)));
     s->n++;
     s->ext_bytes += (uint64_t)k->qn + (k->tn + 3) / 4 + k->qn + k->tn;      /* SURVEY 8(d) B_ext */
+    s->blk_steps += (uint64_t)((k->qn + 63) / 64) * k->tn;
 }
 
 /* job owner bookkeeping: parallel arrays */
@@ -757,6 +758,7 @@ static void stage_edlib_desc(walk_t *w, memo_t *m)
     s->downer[s->dn] = (uintptr_t)(m - w->job->memo);
     s->dn++;
     s->ext_bytes += (uint64_t)k->qn + (k->tn + 3) / 4 + k->qn + k->tn;      /* SURVEY 8(d) B_ext */
+    s->blk_steps += (uint64_t)((k->qn + 63) / 64) * k->tn;
 }
 
 /* edlibAlign(query segment, target segment, mode, PATH) through the memo */
@@ -1665,7 +1667,7 @@ extend:
         if (ne) {
             uint64_t qn = 0, tn = 0;
             uint64_t *qbase = (uint64_t *)malloc((size_t)nt * 8), *tbase = (uint64_t *)malloc((size_t)nt * 8); int *gbase = (int *)malloc((size_t)nt * sizeof(int));
-            { int g0 = 0; for (int t = 0; t < nt; t++) { qbase[t] = qn; tbase[t] = tn; gbase[t] = g0; qn += cx->stages[t].qn; tn += cx->stages[t].tn; g0 += cx->stages[t].n; st->ext_bytes += cx->stages[t].ext_bytes; } }
+            { int g0 = 0; for (int t = 0; t < nt; t++) { qbase[t] = qn; tbase[t] = tn; gbase[t] = g0; qn += cx->stages[t].qn; tn += cx->stages[t].tn; g0 += cx->stages[t].n; st->ext_bytes += cx->stages[t].ext_bytes; cx->stages[t].ext_bytes = 0; st->dp_block_steps += cx->stages[t].blk_steps; cx->stages[t].blk_steps = 0; } }
             const int ridx = cx->n_ed_rounds;
             const int pin = ridx < 16;                       /* persistent pinned slots for the first rounds */
             char *qb = (char *)lfg_pin_slot(LF_PS_ALN_Q, qn + 1), *tb = (char *)lfg_pin_slot(LF_PS_ALN_T, tn + 1);
@@ -1702,7 +1704,7 @@ extend:
             /* descriptor requests: nothing but 32-byte descriptors goes to the GPU */
             uint64_t *obase = (uint64_t *)malloc((size_t)nt * 8); int *gbase = (int *)malloc((size_t)nt * sizeof(int));
             uint64_t ops_total = 0;
-            { int g0 = 0; for (int t = 0; t < nt; t++) { obase[t] = ops_total; gbase[t] = g0; ops_total += cx->stages[t].dops_total; g0 += cx->stages[t].dn; st->ext_bytes += cx->stages[t].ext_bytes; cx->stages[t].ext_bytes = 0; } }
+            { int g0 = 0; for (int t = 0; t < nt; t++) { obase[t] = ops_total; gbase[t] = g0; ops_total += cx->stages[t].dops_total; g0 += cx->stages[t].dn; st->ext_bytes += cx->stages[t].ext_bytes; cx->stages[t].ext_bytes = 0; st->dp_block_steps += cx->stages[t].blk_steps; cx->stages[t].blk_steps = 0; } }
             const int ridx = cx->n_ed_rounds;
             const int pin = ridx < 16;
             ed_round_t R; memset(&R, 0, sizeof R);
@@ -1884,7 +1886,7 @@ static void merge_stats(lf_stats_t *d, const lf_stats_t *a)
     d->n_edlib_problems += a->n_edlib_problems; d->n_ksw_problems += a->n_ksw_problems; d->n_cache += a->n_cache; d->n_occblk += a->n_occblk;
     d->n_sa += a->n_sa; d->n_readbytes += a->n_readbytes; d->ext_bytes += a->ext_bytes; d->edlib_launches += a->edlib_launches;
     d->search_launches += a->search_launches; d->locate_launches += a->locate_launches;
-    d->ms_render += a->ms_render; d->ms_k_render += a->ms_k_render; d->ms_k_vote += a->ms_k_vote; d->ops_bytes += a->ops_bytes; d->n_req_seeds += a->n_req_seeds; d->n_tie_requests += a->n_tie_requests; d->render_bytes += a->render_bytes; d->render_launches += a->render_launches;
+    d->dp_block_steps += a->dp_block_steps; d->ms_render += a->ms_render; d->ms_k_render += a->ms_k_render; d->ms_k_vote += a->ms_k_vote; d->ops_bytes += a->ops_bytes; d->n_req_seeds += a->n_req_seeds; d->n_tie_requests += a->n_tie_requests; d->render_bytes += a->render_bytes; d->render_launches += a->render_launches;
 }
 
 static void *lane_main(void *arg_)

@@ -4,13 +4,10 @@
  * The seed stage leaves every hit of the chunk in device memory (tPos, qPos|len, strand; hits of one read are
  * contiguous).  This stage turns them into chains; only the chains (a few dozen seeds per read) go to the host.
  *
- *   1 keys      every hit votes, with weight 1 + (len - k), for the windows floor(tPos/L) and floor(tPos/L) - 1 of its
- *               read and strand (src/LordFAST.cpp:588-620): key = (read, strand, window)
- *   2 sort + reduce-by-key (hipCUB): the sparse equivalent of the reference's dense per-thread vote array, windows of a
- *               (read, strand) in ascending order -- the order the reference scans them in
- *   3 select    one wavefront per read: local-maximum test (:630-632), the top-N min-heap with libstdc++'s
- *               push_heap / pop_heap / sort_heap element order (:634-654, :528), coarse / fine decision (:531-553),
- *               fine-mode candidate list (:875-877)
+ *   1-3 vote    one block per read, in LDS: every hit votes, with weight 1 + (len - k), for the windows floor(tPos/L) and
+ *               floor(tPos/L) - 1 of its strand (src/LordFAST.cpp:588-620) into a hash table; local-maximum test (:630-632),
+ *               best / second-best score, coarse / fine decision (:531-553), fine-mode candidate list (:875-877)
+ *               (lf_vote_hash_kernel; no sort of the votes, see the comment there)
  *   4 requests  window -> [lo, hi] reference range clipped to the contig of the window's midpoint (:995-1003)
  *   5 gather    the read's hits of that strand inside the range, original order kept (:1004-1012)
  *   6 sort      by qPos (src/Chain.cpp:244 std::sort(compare_seed)).  A radix sort gives the unique order whenever all
@@ -18,7 +15,7 @@
  *               original order (lf_stdsort.h), because the reference's tie order reaches the chain DP
  *   7 chain     lf_chain_n2_kernel (lf_chain.hip) on the device-resident requests; chains gathered and copied back
  *
- * Integer work, HBM-bound: two radix sorts dominate (16-24 B per hit and pass).
+ * Integer work; the hits are read once (9 B per hit) by the vote and once per request by the gather.
  */
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -36,129 +33,165 @@
 #include "lf_stdsort.h"
 
 #define VK_WIN_BITS 26
-__host__ __device__ __forceinline__ uint64_t vk_make(uint32_t read, uint32_t strand, uint32_t win)
-{
-    return ((uint64_t)read << (VK_WIN_BITS + 1)) | ((uint64_t)strand << VK_WIN_BITS) | win;
-}
+#define VK_WMASK ((1u << VK_WIN_BITS) - 1u)
 
-/* ---- 1: votes ---- */
+/* ---- 1-3: votes, local maxima, coarse / fine decision: ONE BLOCK PER READ, all in LDS ----
+ * The reference adds every seed's weight to a dense per-thread array indexed by window (src/LordFAST.cpp:588-620), scans it
+ * for local maxima (:630-632), keeps the best max_map of them in a min-heap (:634-654), sorts the heap (:528) and decides:
+ * coarse if the best window scores >= 4 x the second (:531-549), else every local maximum above best / 4 is a fine-mode
+ * candidate, forward list first, ascending (:553, :875-877).
+ *
+ * What reaches the output of that procedure is order-free: the largest and second-largest scores (a heap of >= 2
+ * elements never evicts either), the window of the largest when it is unique (a tie can never be >= 4 x the second),
+ * the number of candidates (0 / 1 / more), and the SET of local maxima above best / 4 -- whose order is the scan order,
+ * i.e. ascending (strand, window).  So no sort of the votes is needed at all: a read's ~4 k votes go into an open-addressing
+ * hash table in LDS (atomicAdd of the weight), the local-maximum test looks its two neighbours up in the same table, two
+ * atomicMax passes find best and second, and only the handful of fine-mode candidates is ordered (rank by counting).
+ * Round 1 radix-sorted and reduced all votes through HBM (hipCUB, 55 GB of traffic per 100 k reads for 7 GB of votes).
+ * Reads with more votes than the largest LDS table keep theirs in a global scratch area (same code, GTAB). */
+__device__ __forceinline__ uint32_t vk_hash(uint32_t key, uint32_t mask) { return (key * 2654435761u) >> 7 & mask; }
+#define LF_VOTE_FILTER_WORDS 1024u
+__device__ __forceinline__ uint32_t vk_hash2(uint32_t key) { return ((key ^ (key >> 15)) * 0x9E3779B1u) >> 17; }      /* 15 bits */
+
+template <bool GTAB>
 __global__ void __launch_bounds__(256)
-lf_vote_keys_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_t *__restrict__ read_off,
+lf_vote_hash_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_t *__restrict__ read_off,
                     const uint32_t *__restrict__ tpos, const uint32_t *__restrict__ qpl, const uint8_t *__restrict__ strand,
-                    uint32_t min_anchor_len, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+                    uint32_t min_anchor_len, uint32_t l_pac, uint32_t min_read_len,
+                    uint64_t votes_lo, uint64_t votes_hi, uint32_t lds_cap,
+                    const uint64_t *__restrict__ gtab_off, uint32_t *__restrict__ gtab,
+                    uint8_t *__restrict__ mode, uint32_t *__restrict__ nreq, int64_t *__restrict__ seg0,
+                    uint32_t *__restrict__ stage, uint32_t *__restrict__ tmp_list, float *__restrict__ vscore)
 {
-    const int r = blockIdx.x;
+    extern __shared__ uint32_t s_tab[];
+    __shared__ unsigned long long s_best;
+    __shared__ uint32_t s_second, s_ncand, s_nlist;
+    const int r = blockIdx.x, tid = threadIdx.x;
     if (r >= n_reads) return;
-    const uint32_t L = (uint32_t)(off[r + 1] - off[r]);
-    const uint64_t a = read_off[r], b = read_off[r + 1];
-    for (uint64_t j = a + threadIdx.x; j < b; j += blockDim.x) {
-        const uint32_t id = tpos[j] / L;
-        const uint32_t weight = (uint32_t)(1 + ((int32_t)(qpl[j] >> 20) - (int32_t)min_anchor_len));
-        const uint32_t s = strand[j];
-        keys[2 * j] = vk_make((uint32_t)r, s, id); vals[2 * j] = weight;
-        /* window 0 has no left neighbour: its second vote goes to a per-read dummy key (strand 1, window 2^26 - 1) that
-         * sorts last inside the read's own key range and is never a candidate (>= the window limit) */
-        keys[2 * j + 1] = id >= 1 ? vk_make((uint32_t)r, s, id - 1) : vk_make((uint32_t)r, 1u, (1u << VK_WIN_BITS) - 1u); vals[2 * j + 1] = weight;
-    }
-}
-
-/* ---- 3: selection ---- */
-#define LF_VOTE_MAX_WIN 1024                            /* -n / max_map bound of the selection kernel (LDS heap) */
-struct lf_hwin { float score; uint32_t win; };        /* win | isReverse << 31 */
-#define HWIN_LESS(a, b) ((a)->score > (b)->score)      /* compareWin (src/LordFAST.cpp:981-984) */
-LF_DEFINE_STDSORT(dwinh, lf_hwin, HWIN_LESS)
-
-__device__ __forceinline__ int64_t lf_lower_bound(const uint64_t *__restrict__ k, int64_t n, uint64_t want)
-{
-    int64_t lo = 0, hi = n;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (k[mid] < want) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-
-__global__ void __launch_bounds__(64)
-lf_vote_select_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ ucnt,
-                      const int *__restrict__ n_runs_p, uint32_t l_pac, uint32_t min_read_len, int max_win,
-                      uint8_t *__restrict__ mode, uint32_t *__restrict__ nreq, int64_t *__restrict__ seg0,
-                      uint32_t *__restrict__ stage /* n_runs */, float *__restrict__ vscore)
-{
-    __shared__ lf_hwin heap[LF_VOTE_MAX_WIN];
-    __shared__ uint32_t s_win[64], s_cnt[64];
-    __shared__ int s_n; __shared__ float s_min;
-    const int r = blockIdx.x, lane = threadIdx.x;
-    if (r >= n_reads) return;
-    const int64_t n_runs = *n_runs_p;
-    const uint32_t L = (uint32_t)(off[r + 1] - off[r]);
-    const uint32_t refWinNum = l_pac / min_read_len;                       /* src/LordFAST.cpp:130 */
-    uint32_t lim = l_pac / L + 2; if (lim > refWinNum) lim = refWinNum;     /* :622-624 */
-    const uint64_t WMASK = (1ull << VK_WIN_BITS) - 1;
-    const int64_t fa = lf_lower_bound(ukeys, n_runs, vk_make((uint32_t)r, 0, 0));
-    const int64_t fb = lf_lower_bound(ukeys, n_runs, vk_make((uint32_t)r, 1, 0));
-    const int64_t rb = lf_lower_bound(ukeys, n_runs, vk_make((uint32_t)r + 1, 0, 0));
-    if (lane == 0) { s_n = 0; s_min = 0; seg0[r] = fa; }
+    const uint64_t a = read_off[r], b = read_off[r + 1], votes = 2 * (b - a);
+    if (votes < votes_lo || votes > votes_hi) return;                       /* another launch's size class */
+    uint32_t cap = lds_cap;
+    if (GTAB) { cap = 4096; while ((uint64_t)cap < 2 * votes) cap <<= 1; }
+    uint32_t *keys = GTAB ? gtab + gtab_off[r] : s_tab, *cnts = keys + cap, *bits = cnts + cap;
+    const uint32_t mask = cap - 1;
+    /* bits: a 32 Kbit presence filter over a second hash of the key.  Most windows are isolated, so most neighbour lookups
+     * ask for a window that was never touched; the filter answers those with one LDS read instead of a probe sequence whose
+     * length -- the longest among the 64 lanes -- the whole wavefront would walk */
+    for (uint32_t i = tid; i < 2 * cap + LF_VOTE_FILTER_WORDS; i += 256) keys[i] = 0;
+    if (tid == 0) { s_best = 0; s_second = 0; s_ncand = 0; s_nlist = 0; seg0[r] = (int64_t)(2 * a); }
     __syncthreads();
-    const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-
-    auto is_local_max = [&](int64_t k, int64_t sa, int64_t sb, uint32_t id, uint32_t c) -> bool {
-        const bool left_ok = (id == 0) || !(k > sa && (uint32_t)(ukeys[k - 1] & WMASK) == id - 1) || c >= ucnt[k - 1];
-        const bool right_ok = (id == refWinNum - 1) || !(k + 1 < sb && (uint32_t)(ukeys[k + 1] & WMASK) == id + 1) || c > ucnt[k + 1];
-        return left_ok && right_ok;
+    const uint32_t L = (uint32_t)(off[r + 1] - off[r]);
+    auto insert = [&](uint32_t key, uint32_t w) {
+        uint32_t h = vk_hash(key, mask);
+        for (;;) {
+            const uint32_t old = atomicCAS(&keys[h], 0u, key + 1u);
+            if (old == 0u) { const uint32_t fb = vk_hash2(key); atomicOr(&bits[fb >> 5], 1u << (fb & 31)); }
+            if (old == 0u || old == key + 1u) { atomicAdd(&cnts[h], w); return; }
+            h = (h + 1) & mask;
+        }
     };
-    /* pass 0: the top-N heap, windows of the forward list first, then the reverse list, ascending (:626-656) */
-    for (int pass = 0; pass < 2; pass++) {
-        const int64_t sa = pass ? fb : fa, sb = pass ? rb : fb;
-        for (int64_t base = sa; base < sb; base += 64) {
-            const int64_t k = base + lane;
-            uint32_t id = 0, c = 0; bool cand = false;
-            if (k < sb) {
-                id = (uint32_t)(ukeys[k] & WMASK); c = ucnt[k];
-                if (id < lim && is_local_max(k, sa, sb, id, c)) cand = (s_n < max_win) || ((float)c > s_min);
-            }
-            s_win[lane] = id; s_cnt[lane] = c;
-            uint64_t m = __ballot(cand);
-            __syncthreads();
-            if (lane == 0 && m) {
-                int n = s_n;
-                while (m) {
-                    const int b = __ffsll((long long)m) - 1; m &= m - 1;
-                    const float sc = (float)s_cnt[b];
-                    lf_hwin e; e.score = sc; e.win = s_win[b] | ((uint32_t)pass << 31);
-                    if (n < max_win) { heap[n] = e; n++; dwinh_push_heap(heap, n); }
-                    else if (sc > heap[0].score) { dwinh_pop_heap(heap, n); heap[n - 1] = e; dwinh_push_heap(heap, n); }
-                }
-                s_n = n; s_min = heap[0].score;
-            }
-            __syncthreads();
+    for (uint64_t j = a + tid; j < b; j += 256) {
+        const uint32_t id = tpos[j] / L;
+        const uint32_t w = (uint32_t)(1 + ((int32_t)(qpl[j] >> 20) - (int32_t)min_anchor_len));
+        const uint32_t sk = (uint32_t)strand[j] << VK_WIN_BITS;
+        insert(sk | id, w);
+        if (id >= 1) insert(sk | (id - 1), w);                              /* windows are 2L wide, stride L (:612-619) */
+    }
+    __syncthreads();
+    auto lookup = [&](uint32_t key) -> int64_t {                           /* count of a window, -1 if it was never touched */
+        const uint32_t fb = vk_hash2(key);
+        if (!((bits[fb >> 5] >> (fb & 31)) & 1u)) return -1;
+        uint32_t h = vk_hash(key, mask);
+        for (;;) {
+            const uint32_t k = keys[h];
+            if (k == 0u) return -1;
+            if (k == key + 1u) return (int64_t)(cnts[h] & 0x7fffffffu);
+            h = (h + 1) & mask;
+        }
+    };
+    const uint32_t refWinNum = l_pac / min_read_len;                        /* src/LordFAST.cpp:130 */
+    uint32_t lim = l_pac / L + 2; if (lim > refWinNum) lim = refWinNum;     /* :622-624 */
+    /* pass A: local maxima below the window limit (:630-632); flagged in the top bit of their count.  Per-thread best /
+     * count first, one atomic per wavefront (thousands of same-address LDS atomics serialise) */
+    unsigned long long lbest = 0; uint32_t lcnt = 0;
+    for (uint32_t i = tid; i < cap; i += 256) {
+        const uint32_t k = keys[i];
+        if (k == 0u) continue;
+        const uint32_t key = k - 1u, id = key & VK_WMASK, c = cnts[i] & 0x7fffffffu;
+        if (id >= lim) continue;
+        bool ok = true;
+        if (id != 0) { const int64_t cl = lookup(key - 1u); ok = cl < 0 || (int64_t)c >= cl; }
+        if (ok && id != refWinNum - 1) { const int64_t cr = lookup(key + 1u); ok = cr < 0 || (int64_t)c > cr; }
+        if (ok) {
+            atomicOr(&cnts[i], 0x80000000u);
+            const unsigned long long v = ((unsigned long long)c << 32) | key;
+            lbest = v > lbest ? v : lbest; lcnt++;
         }
     }
-    const int n = s_n;
-    if (n == 0) { if (lane == 0) { mode[r] = 1; nreq[r] = 0; vscore[r] = 0; } return; }
-    if (lane == 0) dwinh_sort_heap(heap, n);                                                   /* :528 */
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long x = __shfl_xor(lbest, o); lbest = x > lbest ? x : lbest;
+        lcnt += __shfl_xor(lcnt, o);
+    }
+    if ((tid & 63) == 0 && lcnt) { atomicMax(&s_best, lbest); atomicAdd(&s_ncand, lcnt); }
     __syncthreads();
-    const float scoreRatio = 4;
-    if (n == 1 || heap[0].score >= scoreRatio * heap[1].score) {                                /* coarse (:531) */
-        if (lane == 0) { mode[r] = 2; nreq[r] = 1; stage[fa] = heap[0].win; vscore[r] = heap[0].score; }
+    const uint32_t n_cand = s_ncand;
+    if (n_cand == 0) { if (tid == 0) { mode[r] = 1; nreq[r] = 0; vscore[r] = 0; } return; }
+    const uint32_t best_c = (uint32_t)(s_best >> 32), best_key = (uint32_t)s_best;
+    /* pass B: the second-largest score among the local maxima (the largest one itself excluded once) */
+    if (n_cand > 1) {
+        uint32_t lsec = 0;
+        for (uint32_t i = tid; i < cap; i += 256) {
+            const uint32_t k = keys[i], cc = cnts[i];
+            if (k != 0u && (cc & 0x80000000u) && k - 1u != best_key) { const uint32_t v = cc & 0x7fffffffu; lsec = v > lsec ? v : lsec; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(lsec, o); lsec = x > lsec ? x : lsec; }
+        if ((tid & 63) == 0 && lsec) atomicMax(&s_second, lsec);
+        __syncthreads();
+    }
+    const float top = (float)best_c, second = (float)s_second, scoreRatio = 4;
+    const uint64_t sg = 2 * a;
+    if (n_cand == 1 || top >= scoreRatio * second) {                         /* coarse (:531): one request, the best window */
+        if (tid == 0) { mode[r] = 2; nreq[r] = 1; stage[sg] = (best_key & VK_WMASK) | ((best_key >> VK_WIN_BITS) << 31); vscore[r] = top; }
         return;
     }
-    /* fine: every local maximum above best/4, forward list then reverse list (:553, :875-877) */
-    const float minScore = heap[0].score / scoreRatio;
-    uint32_t ncand = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        const int64_t sa = pass ? fb : fa, sb = pass ? rb : fb;
-        for (int64_t base = sa; base < sb; base += 64) {
-            const int64_t k = base + lane;
-            uint32_t id = 0; bool cand = false;
-            if (k < sb) {
-                id = (uint32_t)(ukeys[k] & WMASK); const uint32_t c = ucnt[k];
-                cand = id < lim && (float)c > minScore && is_local_max(k, sa, sb, id, c);
-            }
-            const uint64_t m = __ballot(cand);
-            /* the list is written over windows already scanned (ncand never overtakes the scan position) -- but lanes of
-             * this tile still read ukeys/ucnt, which are separate arrays: stage[] is write-only here */
-            if (cand) stage[fa + ncand + (uint32_t)__popcll(m & below)] = id | ((uint32_t)pass << 31);
-            ncand += (uint32_t)__popcll(m);
-        }
+    /* fine: every local maximum above best / 4 (:553, :875-877), in scan order = ascending (strand, window) */
+    const float minScore = top / scoreRatio;
+    for (uint32_t i = tid; i < cap; i += 256) {
+        const uint32_t k = keys[i], cc = cnts[i];
+        if (k != 0u && (cc & 0x80000000u) && (float)(cc & 0x7fffffffu) > minScore) tmp_list[sg + atomicAdd(&s_nlist, 1u)] = k - 1u;
     }
-    if (lane == 0) { mode[r] = 3; nreq[r] = ncand; vscore[r] = heap[0].score; }
+    __syncthreads();
+    const uint32_t nl = s_nlist;
+    if (nl <= 64) {                                                          /* the usual handful: rank by counting */
+        for (uint32_t e = tid; e < nl; e += 256) {
+            const uint32_t key = tmp_list[sg + e];
+            uint32_t rank = 0;
+            for (uint32_t f = 0; f < nl; f++) rank += tmp_list[sg + f] < key;
+            stage[sg + rank] = (key & VK_WMASK) | ((key >> VK_WIN_BITS) << 31);
+        }
+    } else {
+        /* a read without a dominant window (best score of a few votes) makes every local maximum a candidate: thousands.
+         * The table is not needed any more: its memory holds the list for a bitonic sort (nl <= 2/3 cap, so the next
+         * power of two fits into the 2 cap words) */
+        uint32_t P = 128; while (P < nl) P <<= 1;
+        for (uint32_t i = tid; i < P; i += 256) keys[i] = i < nl ? tmp_list[sg + i] : 0xffffffffu;
+        __syncthreads();
+        for (uint32_t k = 2; k <= P; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = tid; i < P; i += 256) {
+                    const uint32_t x = i ^ j;
+                    if (x > i) {
+                        const uint32_t va = keys[i], vb = keys[x];
+                        if ((va > vb) == ((i & k) == 0)) { keys[i] = vb; keys[x] = va; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t e = tid; e < nl; e += 256) { const uint32_t key = keys[e]; stage[sg + e] = (key & VK_WMASK) | ((key >> VK_WIN_BITS) << 31); }
+    }
+    if (tid == 0) { mode[r] = 3; nreq[r] = nl; vscore[r] = top; }
 }
 
 /* ---- 4: requests ---- */
@@ -299,7 +332,6 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     hipStream_t s = (hipStream_t)lfg_lane_stream(dv, 0);
     if (!s) return LF_ERR_HIP;
     if (n_reads >= (1 << 20)) { lf_set_error("lfg_vote_chain: too many reads in one chunk"); return LF_ERR_ARG; }
-    if (p->max_map > LF_VOTE_MAX_WIN) { lf_set_error("lfg_vote_chain: -n %d exceeds the %d candidate windows the selection kernel keeps", p->max_map, LF_VOTE_MAX_WIN); return LF_ERR_ARG; }
     /* left in HBM by lfg_seed */
     const uint64_t *d_off = (const uint64_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 1, 0), *d_read_off = (const uint64_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 6, 0);
     const uint32_t *d_tpos = (const uint32_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 9, 0), *d_qpl = (const uint32_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 10, 0);
@@ -327,35 +359,54 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     uint32_t *d_stage = nullptr;
     if (n_hits) {
         const uint64_t E = 2 * n_hits;
-        if (E >= (1ull << 31)) { lf_set_error("lfg_vote_chain: %llu seed hits in one chunk exceed the 2^30 the vote sort takes; use smaller chunks (LF_CHUNK_READS)", (unsigned long long)n_hits); return LF_ERR_ARG; }
-        uint64_t *d_keys = (uint64_t *)VSLOT(1, E * 8), *d_keys2 = (uint64_t *)VSLOT(2, E * 8);
-        uint32_t *d_vals = (uint32_t *)VSLOT(3, E * 4), *d_vals2 = (uint32_t *)VSLOT(4, E * 4);
-        if (!d_keys || !d_keys2 || !d_vals || !d_vals2) return LF_ERR_NOMEM;
-        int rbits = 1; while ((1 << rbits) < n_reads + 1) rbits++;
-        const int end_bit = VK_WIN_BITS + 1 + rbits;
-        size_t tb1 = 0, tb2 = 0, tb3 = 0;
-        /* The votes of a read are contiguous (2 per hit) and its read id is the key's high part, so sorting every read's
-         * segment on the low (strand, window) bits gives the globally sorted array: 27 key bits instead of 40, and a
-         * segment (~4 k votes, 50 kB) is sorted out of L2 instead of being streamed through HBM five times.
-         * LF_VOTE_GLOBAL_SORT=1 keeps the device-wide sort (diagnostic). */
-        static const bool seg_sort = !(getenv("LF_VOTE_GLOBAL_SORT") && atoi(getenv("LF_VOTE_GLOBAL_SORT")));
-        hipcub::TransformInputIterator<int, lf_twice, const uint64_t *> seg_begin(d_read_off, lf_twice()), seg_end(d_read_off + 1, lf_twice());
-        if (seg_sort) (void)hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tb1, d_keys, d_keys2, d_vals, d_vals2, (int)E, n_reads, seg_begin, seg_end, 0, VK_WIN_BITS + 1, s);
-        else (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, d_keys, d_keys2, d_vals, d_vals2, (int)E, 0, end_bit, s);
-        (void)hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, d_keys2, d_keys, d_vals2, d_vals, d_nruns, hipcub::Sum(), (int)E, s);
+        if (E >= (1ull << 31)) { lf_set_error("lfg_vote_chain: %llu seed hits in one chunk exceed the 2^30 the vote sort takes; use smaller chunks (LF_CHUNK_READS)", (unsigned long long)n_hits); return LF_ERR_ARG; }      /* 2 votes per hit are indexed with 32 bits; lf_map_batch cuts a chunk in two before this can happen */
+        d_stage = (uint32_t *)VSLOT(1, E * 4 + 16);
+        uint32_t *d_tmp_list = (uint32_t *)VSLOT(2, E * 4 + 16);
+        if (!d_stage || !d_tmp_list) return LF_ERR_NOMEM;
+        size_t tb3 = 0;
         hipcub::TransformInputIterator<uint64_t, lf_w32, uint32_t *> nreq64(d_nreq, lf_w32());
         (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, nreq64, d_req0, n_reads + 1, s);
-        void *d_tmp = VSLOT(5, std::max(tb1, std::max(tb2, tb3)) + 256);
+        void *d_tmp = VSLOT(5, tb3 + 256);
         if (!d_tmp) return LF_ERR_NOMEM;
-        hipLaunchKernelGGL(lf_vote_keys_kernel, dim3((unsigned)n_reads), dim3(256), 0, s, n_reads, d_off, d_read_off, d_tpos, d_qpl, d_strand,
-                           (uint32_t)p->min_anchor_len, d_keys, d_vals);
-        if (seg_sort) { size_t tb = tb1; HIPCHK(hipcub::DeviceSegmentedRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, (int)E, n_reads, seg_begin, seg_end, 0, VK_WIN_BITS + 1, s)); }
-        else { size_t tb = tb1; HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, (int)E, 0, end_bit, s)); }
-        /* unique (read, strand, window) keys -> d_keys, summed weights -> d_vals (a read's dummy key sorts last in its range; it is never a candidate) */
-        { size_t tb = tb2; HIPCHK(hipcub::DeviceReduce::ReduceByKey(d_tmp, tb, d_keys2, d_keys, d_vals2, d_vals, d_nruns, hipcub::Sum(), (int)E, s)); }
-        d_stage = (uint32_t *)d_vals2;                      /* free again: candidate windows per read, at most one per unique key */
-        hipLaunchKernelGGL(lf_vote_select_kernel, dim3((unsigned)n_reads), dim3(64), 0, s, n_reads, d_off, d_keys, d_vals, d_nruns,
-                           (uint32_t)ix->l_pac, (uint32_t)p->min_read_len, p->max_map, d_mode, d_nreq, d_seg0, d_stage, d_vscore);
+        /* LDS table classes (load factor <= 2/3); reads above the largest keep their table in a global scratch area */
+        static const uint32_t caps[3] = { 4096, 8192, 16384 };
+        uint64_t v_max_lds = (uint64_t)caps[2] * 2 / 3;
+        if (getenv("LF_VOTE_LDS_MAX_VOTES")) { const uint64_t x = strtoull(getenv("LF_VOTE_LDS_MAX_VOTES"), nullptr, 10); if (x < v_max_lds) v_max_lds = x; }   /* test hook: push reads to the global-table path */
+        const uint64_t *h_read_off = (const uint64_t *)lfg_pin_slot(LF_PS_HITS_OFF, 0);      /* lfg_seed left it there */
+        uint64_t gtab_words = 0; std::vector<uint64_t> gtab_off;
+        uint64_t v_max = 0;
+        if (h_read_off) {
+            for (int r = 0; r < n_reads; r++) {
+                const uint64_t v = 2 * (h_read_off[r + 1] - h_read_off[r]);
+                if (v > v_max) v_max = v;
+                if (v > v_max_lds) {
+                    if (gtab_off.empty()) gtab_off.assign((size_t)n_reads, 0);
+                    uint64_t cap = 4096; while (cap < 2 * v) cap <<= 1;
+                    gtab_off[(size_t)r] = gtab_words; gtab_words += 2 * cap + LF_VOTE_FILTER_WORDS;
+                }
+            }
+        } else { lf_set_error("lfg_vote_chain: no resident seed batch (host offsets)"); return LF_ERR_ARG; }
+        static bool attr_set[16] = { false };
+        if (!attr_set[dv]) { HIPCHK(hipFuncSetAttribute((const void *)lf_vote_hash_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8 + LF_VOTE_FILTER_WORDS * 4)); attr_set[dv] = true; }
+        uint64_t lo = 0;
+        for (int k = 0; k < 3 && lo <= v_max_lds; k++) {
+            uint64_t hi = (uint64_t)caps[k] * 2 / 3; if (hi > v_max_lds) hi = v_max_lds;
+            if (lo <= v_max)
+                hipLaunchKernelGGL(lf_vote_hash_kernel<false>, dim3((unsigned)n_reads), dim3(256), (size_t)caps[k] * 8 + LF_VOTE_FILTER_WORDS * 4, s, n_reads, d_off, d_read_off, d_tpos, d_qpl, d_strand,
+                                   (uint32_t)p->min_anchor_len, (uint32_t)ix->l_pac, (uint32_t)p->min_read_len, lo, hi, caps[k],
+                                   (const uint64_t *)nullptr, (uint32_t *)nullptr, d_mode, d_nreq, d_seg0, d_stage, d_tmp_list, d_vscore);
+            lo = hi + 1;
+        }
+        if (gtab_words) {
+            uint64_t *d_gtab_off = (uint64_t *)VSLOT(3, (size_t)n_reads * 8);
+            uint32_t *d_gtab = (uint32_t *)VSLOT(4, gtab_words * 4 + 16);
+            if (!d_gtab_off || !d_gtab) return LF_ERR_NOMEM;
+            HIPCHK(hipMemcpyAsync(d_gtab_off, gtab_off.data(), (size_t)n_reads * 8, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(lf_vote_hash_kernel<true>, dim3((unsigned)n_reads), dim3(256), 0, s, n_reads, d_off, d_read_off, d_tpos, d_qpl, d_strand,
+                               (uint32_t)p->min_anchor_len, (uint32_t)ix->l_pac, (uint32_t)p->min_read_len, lo, ~0ull, 0u,
+                               (const uint64_t *)d_gtab_off, d_gtab, d_mode, d_nreq, d_seg0, d_stage, d_tmp_list, d_vscore);
+            HIPCHK(hipStreamSynchronize(s));                    /* gtab_off (host vector) is read by the copy above */
+        }
         /* request ids: exclusive scan over n_reads + 1 counts (the last one is a zero pad) */
         { size_t tb = tb3; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, nreq64, d_req0, n_reads, s)); }
         HIPCHK(hipMemcpyAsync(h_small, d_req0 + (R - 1), 8, hipMemcpyDeviceToHost, s));

@@ -158,3 +158,83 @@ def gather_sam_p2p(dist, torch, my_buf, my_len: int, device, dst: int = 0):
     if device.type != "cpu":
         torch.cuda.synchronize()
     return off
+
+
+# ---- packed batches: what travels is two contiguous byte ranges + two offset arrays per shard; no per-read Python object
+# ---- is created on either side (a 100 k-read batch is 1.5 GB: joining / slicing `bytes` costs more than the transfer)
+
+class PackedReads:
+    """A read batch as ONE byte blob: the sequences, each followed by NUL, then the names, each followed by NUL -- the
+    library takes arrays of C strings, so pointers into the blob are all it needs (the reference keeps a chunk the same
+    way: one block per read, `[len][seq\0][qual\0][name\0]`, src/Reads.cpp:84-90)."""
+
+    def __init__(self, blob, seq_off, name_off):
+        self.blob = blob                      # uint8 numpy array (any memory: pinned, shared, ...)
+        self.seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)       # n + 1: start of sequence i (NUL before the next)
+        self.name_off = np.ascontiguousarray(name_off, dtype=np.int64)     # n + 1, absolute offsets into blob
+
+    def __len__(self):
+        return len(self.seq_off) - 1
+
+    @property
+    def seq_lens(self):
+        return (self.seq_off[1:] - self.seq_off[:-1] - 1).astype(np.uint32)
+
+    def arrays(self):
+        """-> (names char**, seqs char**, uint32 lengths) for lf_map_batch_into_lens; valid while self.blob lives"""
+        import ctypes as C
+        base = self.blob.ctypes.data
+        self._np = (self.name_off[:-1] + base).astype(np.uint64)
+        self._sp = (self.seq_off[:-1] + base).astype(np.uint64)
+        return (C.cast(self._np.ctypes.data, C.POINTER(C.c_char_p)), C.cast(self._sp.ctypes.data, C.POINTER(C.c_char_p)), self.seq_lens)
+
+    def tolists(self):
+        b = self.blob.tobytes()
+        n = len(self)
+        return ([b[int(self.name_off[i]):int(self.name_off[i + 1]) - 1] for i in range(n)],
+                [b[int(self.seq_off[i]):int(self.seq_off[i + 1]) - 1] for i in range(n)])
+
+
+def pack_reads(names, seqs) -> PackedReads:
+    n = len(seqs)
+    sl = np.array([len(x) + 1 for x in seqs], dtype=np.int64)
+    nl = np.array([len(x) + 1 for x in names], dtype=np.int64)
+    seq_off = np.concatenate([[0], np.cumsum(sl)]).astype(np.int64)
+    name_off = (np.concatenate([[0], np.cumsum(nl)]) + int(seq_off[-1])).astype(np.int64)
+    blob = np.frombuffer(b"\0".join(seqs) + b"\0" + b"\0".join(names) + b"\0", dtype=np.uint8) if n else np.zeros(0, np.uint8)
+    return PackedReads(blob, seq_off, name_off)
+
+
+def scatter_packed_p2p(dist, torch, packed, device, src: int = 0):
+    """rank `src` holds the packed batch; every rank gets ITS shard (balanced by bases) as a PackedReads.
+    -> (PackedReads, bounds).  Per peer: one small meta message + the two byte ranges of its shard."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if rank == src:
+        lens = packed.seq_lens.astype(np.int64)
+        bounds = shard_bounds(lens, world)
+        blob_t = torch.from_numpy(packed.blob)
+        mine = None
+        for r in range(world):
+            lo, hi = bounds[r]
+            s0, s1 = int(packed.seq_off[lo]), int(packed.seq_off[hi])
+            n0, n1 = int(packed.name_off[lo]), int(packed.name_off[hi])
+            if r == src:
+                mine = PackedReads(packed.blob, packed.seq_off[lo:hi + 1], packed.name_off[lo:hi + 1])
+                continue
+            meta = np.concatenate([[hi - lo], [b for ab in bounds for b in ab], packed.seq_off[lo:hi + 1] - s0,
+                                   packed.name_off[lo:hi + 1] - n0 + (s1 - s0)]).astype(np.int64)
+            _send_bytes(dist, torch, torch.from_numpy(meta.view(np.uint8)), device, r)
+            _send_bytes(dist, torch, blob_t[s0:s1], device, r)
+            _send_bytes(dist, torch, blob_t[n0:n1], device, r)
+        return mine, bounds
+    meta = _recv_tensor(dist, torch, device, src).cpu().numpy().view(np.int64)
+    n = int(meta[0])
+    bounds = [(int(meta[1 + 2 * r]), int(meta[2 + 2 * r])) for r in range(world)]
+    seq_off = meta[1 + 2 * world:2 + 2 * world + n]
+    name_off = meta[2 + 2 * world + n:3 + 2 * world + 2 * n]
+    a = _recv_tensor(dist, torch, device, src)
+    b = _recv_tensor(dist, torch, device, src)
+    blob = torch.empty(a.numel() + b.numel(), dtype=torch.uint8)
+    blob[:a.numel()].copy_(a)
+    blob[a.numel():].copy_(b)
+    return PackedReads(blob.numpy(), seq_off, name_off), bounds

@@ -20,10 +20,15 @@ def revcomp(seq: np.ndarray) -> np.ndarray:
 
 
 def make_genome(total_bp: int, n_contigs: int = 3, seed: int = 11, repeat_frac: float = 0.10,
-                n_families: int = 0) -> list[tuple[str, np.ndarray]]:
+                n_families: int = 0, profile: str = "default") -> list[tuple[str, np.ndarray]]:
     """Uniform ACGT contigs; optionally `repeat_frac` of the sequence is overwritten with copies of
-    `n_families` repeat families (300 bp - 6 kbp, 5-20 % divergence) to emulate repeat content."""
+    `n_families` repeat families (300 bp - 6 kbp, 5-20 % divergence) to emulate repeat content.
+    profile "grch38like": about half of the sequence is repeats with the copy-number structure of a human genome --
+    one 300 bp family with ~10^6 copies per 3 Gbp (Alu-like, 10 % of the sequence, 5-15 % divergence), twenty 1-6 kbp
+    families (LINE-like, 17 %, truncated copies), and `n_families` low-copy families for the rest."""
     rng = np.random.default_rng(seed)
+    if profile == "grch38like":
+        return _make_genome_grch38like(total_bp, n_contigs, rng, max(n_families, 100))
     # contig lengths: geometric-ish split so contigs differ in size
     w = rng.uniform(0.5, 1.5, size=n_contigs)
     lens = np.maximum((w / w.sum() * total_bp).astype(np.int64), 2000)
@@ -52,6 +57,40 @@ def make_genome(total_bp: int, n_contigs: int = 3, seed: int = 11, repeat_frac: 
             p = int(rng.integers(0, len(s) - len(copy)))
             s[p:p + len(copy)] = copy
             used += len(copy)
+    return contigs
+
+
+def _make_genome_grch38like(total_bp, n_contigs, rng, n_families):
+    w = rng.uniform(0.5, 1.5, size=n_contigs)
+    lens = np.maximum((w / w.sum() * total_bp).astype(np.int64), 2000)
+    contigs = [(f"chr{i + 1}", _ACGT[rng.integers(0, 4, size=int(ln), dtype=np.uint8)]) for i, ln in enumerate(lens)]
+    starts = np.concatenate([[0], np.cumsum(lens)])
+
+    def paste(fams, budget, lo_div, hi_div, truncate):
+        used = 0
+        while used < budget:
+            f = fams[int(rng.integers(0, len(fams)))]
+            if truncate and len(f) > 600:                      # 5'-truncated copies, like LINE insertions
+                f = f[int(rng.integers(0, len(f) - 300)):]
+            g = int(rng.integers(0, total_bp))
+            ci = int(np.searchsorted(starts, g, side="right") - 1)
+            ci = min(ci, n_contigs - 1)
+            s = contigs[ci][1]
+            if len(s) <= len(f) + 1:
+                continue
+            copy = f.copy()
+            mut = rng.random(len(copy)) < rng.uniform(lo_div, hi_div)
+            copy[mut] = _ACGT[rng.integers(0, 4, size=int(mut.sum()), dtype=np.uint8)]
+            if rng.random() < 0.5:
+                copy = revcomp(copy)
+            p = int(rng.integers(0, len(s) - len(copy)))
+            s[p:p + len(copy)] = copy
+            used += len(copy)
+
+    rnd = lambda n: _ACGT[rng.integers(0, 4, size=n, dtype=np.uint8)]                 # noqa: E731
+    paste([rnd(int(rng.integers(300, 6001))) for _ in range(n_families)], int(total_bp * 0.23), 0.05, 0.20, False)
+    paste([rnd(int(rng.integers(1000, 6001))) for _ in range(20)], int(total_bp * 0.17), 0.03, 0.15, True)
+    paste([rnd(300)], int(total_bp * 0.10), 0.05, 0.15, False)                       # pasted last: the youngest family
     return contigs
 
 

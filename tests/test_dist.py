@@ -30,6 +30,15 @@ assert b2 == bounds and n2 == my_names and s2 == my_seqs
 buf = torch.zeros(1 << 16, dtype=torch.uint8)
 buf[:len(fake_sam)] = torch.frombuffer(bytearray(fake_sam), dtype=torch.uint8)
 tot = lfd.gather_sam_p2p(dist, torch, buf, len(fake_sam), dev)
+# packed variant: byte ranges + offsets only, pointer arrays straight into the received blob
+pk = lfd.pack_reads(names, seqs) if rank == 0 else None
+shard, b3 = lfd.scatter_packed_p2p(dist, torch, pk, dev)
+assert b3 == bounds and len(shard) == hi - lo
+assert shard.tolists() == (my_names, my_seqs)
+import ctypes as C
+na, sa, sl = shard.arrays()
+assert [na[i] for i in range(len(shard))] == my_names and [sa[i] for i in range(len(shard))] == my_seqs
+assert list(sl) == [len(x) for x in my_seqs]
 if rank == 0:
     exp = b"".join(n + b"\t" + hashlib.md5(s).hexdigest().encode() + b"\n" for n, s in zip(names, seqs))
     assert out == exp

@@ -290,3 +290,15 @@ def test_map_batch_multi_replicas_same_output(golden_dir, golden_reads, monkeypa
     exp = golden_sam(cfg)
     assert sam == exp, first_diff(sam, exp)
     assert st["n_reads"] == len(seqs)
+
+
+@pytest.mark.parametrize("cfg,lds_max", [("default", 0), ("n30", 600), ("clasp", 3000)])
+def test_vote_tables_in_global_memory(lf, golden_reads, monkeypatch, cfg, lds_max):
+    """reads with more votes than the largest LDS hash table keep their vote table in a global scratch area
+    (lf_vote_hash_kernel<true>); LF_VOTE_LDS_MAX_VOTES lowers the threshold so that the golden reads take that path"""
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    monkeypatch.setenv("LF_VOTE_LDS_MAX_VOTES", str(lds_max))
+    sam, st = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
+    exp = golden_sam(cfg)
+    assert sam == exp, first_diff(sam, exp)
