@@ -53,15 +53,16 @@ __device__ __forceinline__ uint32_t vk_hash(uint32_t key, uint32_t mask) { retur
 #define LF_VOTE_FILTER_WORDS 1024u
 __device__ __forceinline__ uint32_t vk_hash2(uint32_t key) { return ((key ^ (key >> 15)) * 0x9E3779B1u) >> 17; }      /* 15 bits */
 
+#define LF_VOTE_THREADS 1024
 template <bool GTAB>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(LF_VOTE_THREADS)
 lf_vote_hash_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_t *__restrict__ read_off,
                     const uint32_t *__restrict__ tpos, const uint32_t *__restrict__ qpl, const uint8_t *__restrict__ strand,
                     uint32_t min_anchor_len, uint32_t l_pac, uint32_t min_read_len,
                     uint64_t votes_lo, uint64_t votes_hi, uint32_t lds_cap,
                     const uint64_t *__restrict__ gtab_off, uint32_t *__restrict__ gtab,
                     uint8_t *__restrict__ mode, uint32_t *__restrict__ nreq, int64_t *__restrict__ seg0,
-                    uint32_t *__restrict__ stage, uint32_t *__restrict__ tmp_list, float *__restrict__ vscore)
+                    uint32_t *__restrict__ stage, uint32_t *__restrict__ tmp_list, float *__restrict__ vscore, unsigned long long *__restrict__ dbg)
 {
     extern __shared__ uint32_t s_tab[];
     __shared__ unsigned long long s_best;
@@ -70,27 +71,30 @@ lf_vote_hash_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_
     if (r >= n_reads) return;
     const uint64_t a = read_off[r], b = read_off[r + 1], votes = 2 * (b - a);
     if (votes < votes_lo || votes > votes_hi) return;                       /* another launch's size class */
+    unsigned long long t_prev = dbg ? __builtin_readcyclecounter() : 0;
+#define VDBG(k) do { if (dbg && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&dbg[k], t_ - t_prev); t_prev = t_; } } while (0)
     uint32_t cap = lds_cap;
     if (GTAB) { cap = 4096; while ((uint64_t)cap < 2 * votes) cap <<= 1; }
-    uint32_t *keys = GTAB ? gtab + gtab_off[r] : s_tab, *cnts = keys + cap, *bits = cnts + cap;
+    uint32_t *tab = GTAB ? gtab + gtab_off[r] : s_tab, *bits = tab + 2 * cap;       /* slot h: key + 1 at tab[2h], count at tab[2h + 1] (one 8-byte read) */
     const uint32_t mask = cap - 1;
     /* bits: a 32 Kbit presence filter over a second hash of the key.  Most windows are isolated, so most neighbour lookups
      * ask for a window that was never touched; the filter answers those with one LDS read instead of a probe sequence whose
      * length -- the longest among the 64 lanes -- the whole wavefront would walk */
-    for (uint32_t i = tid; i < 2 * cap + LF_VOTE_FILTER_WORDS; i += 256) keys[i] = 0;
+    for (uint32_t i = tid; i < 2 * cap + LF_VOTE_FILTER_WORDS; i += LF_VOTE_THREADS) tab[i] = 0;
     if (tid == 0) { s_best = 0; s_second = 0; s_ncand = 0; s_nlist = 0; seg0[r] = (int64_t)(2 * a); }
     __syncthreads();
+    VDBG(0);
     const uint32_t L = (uint32_t)(off[r + 1] - off[r]);
     auto insert = [&](uint32_t key, uint32_t w) {
         uint32_t h = vk_hash(key, mask);
         for (;;) {
-            const uint32_t old = atomicCAS(&keys[h], 0u, key + 1u);
+            const uint32_t old = atomicCAS(&tab[2 * h], 0u, key + 1u);
             if (old == 0u) { const uint32_t fb = vk_hash2(key); atomicOr(&bits[fb >> 5], 1u << (fb & 31)); }
-            if (old == 0u || old == key + 1u) { atomicAdd(&cnts[h], w); return; }
+            if (old == 0u || old == key + 1u) { atomicAdd(&tab[2 * h + 1], w); return; }
             h = (h + 1) & mask;
         }
     };
-    for (uint64_t j = a + tid; j < b; j += 256) {
+    for (uint64_t j = a + tid; j < b; j += LF_VOTE_THREADS) {
         const uint32_t id = tpos[j] / L;
         const uint32_t w = (uint32_t)(1 + ((int32_t)(qpl[j] >> 20) - (int32_t)min_anchor_len));
         const uint32_t sk = (uint32_t)strand[j] << VK_WIN_BITS;
@@ -98,14 +102,15 @@ lf_vote_hash_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_
         if (id >= 1) insert(sk | (id - 1), w);                              /* windows are 2L wide, stride L (:612-619) */
     }
     __syncthreads();
+    VDBG(1);
     auto lookup = [&](uint32_t key) -> int64_t {                           /* count of a window, -1 if it was never touched */
         const uint32_t fb = vk_hash2(key);
         if (!((bits[fb >> 5] >> (fb & 31)) & 1u)) return -1;
         uint32_t h = vk_hash(key, mask);
         for (;;) {
-            const uint32_t k = keys[h];
-            if (k == 0u) return -1;
-            if (k == key + 1u) return (int64_t)(cnts[h] & 0x7fffffffu);
+            const uint2 kc = *reinterpret_cast<const uint2 *>(&tab[2 * h]);
+            if (kc.x == 0u) return -1;
+            if (kc.x == key + 1u) return (int64_t)(kc.y & 0x7fffffffu);
             h = (h + 1) & mask;
         }
     };
@@ -114,16 +119,17 @@ lf_vote_hash_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_
     /* pass A: local maxima below the window limit (:630-632); flagged in the top bit of their count.  Per-thread best /
      * count first, one atomic per wavefront (thousands of same-address LDS atomics serialise) */
     unsigned long long lbest = 0; uint32_t lcnt = 0;
-    for (uint32_t i = tid; i < cap; i += 256) {
-        const uint32_t k = keys[i];
+    for (uint32_t i = tid; i < cap; i += LF_VOTE_THREADS) {
+        const uint2 kc = *reinterpret_cast<const uint2 *>(&tab[2 * i]);
+        const uint32_t k = kc.x;
         if (k == 0u) continue;
-        const uint32_t key = k - 1u, id = key & VK_WMASK, c = cnts[i] & 0x7fffffffu;
+        const uint32_t key = k - 1u, id = key & VK_WMASK, c = kc.y & 0x7fffffffu;
         if (id >= lim) continue;
         bool ok = true;
         if (id != 0) { const int64_t cl = lookup(key - 1u); ok = cl < 0 || (int64_t)c >= cl; }
         if (ok && id != refWinNum - 1) { const int64_t cr = lookup(key + 1u); ok = cr < 0 || (int64_t)c > cr; }
         if (ok) {
-            atomicOr(&cnts[i], 0x80000000u);
+            atomicOr(&tab[2 * i + 1], 0x80000000u);
             const unsigned long long v = ((unsigned long long)c << 32) | key;
             lbest = v > lbest ? v : lbest; lcnt++;
         }
@@ -135,14 +141,15 @@ lf_vote_hash_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_
     }
     if ((tid & 63) == 0 && lcnt) { atomicMax(&s_best, lbest); atomicAdd(&s_ncand, lcnt); }
     __syncthreads();
+    VDBG(2);
     const uint32_t n_cand = s_ncand;
     if (n_cand == 0) { if (tid == 0) { mode[r] = 1; nreq[r] = 0; vscore[r] = 0; } return; }
     const uint32_t best_c = (uint32_t)(s_best >> 32), best_key = (uint32_t)s_best;
     /* pass B: the second-largest score among the local maxima (the largest one itself excluded once) */
     if (n_cand > 1) {
         uint32_t lsec = 0;
-        for (uint32_t i = tid; i < cap; i += 256) {
-            const uint32_t k = keys[i], cc = cnts[i];
+        for (uint32_t i = tid; i < cap; i += LF_VOTE_THREADS) {
+            const uint2 kc = *reinterpret_cast<const uint2 *>(&tab[2 * i]); const uint32_t k = kc.x, cc = kc.y;
             if (k != 0u && (cc & 0x80000000u) && k - 1u != best_key) { const uint32_t v = cc & 0x7fffffffu; lsec = v > lsec ? v : lsec; }
         }
 #pragma unroll
@@ -150,6 +157,7 @@ lf_vote_hash_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_
         if ((tid & 63) == 0 && lsec) atomicMax(&s_second, lsec);
         __syncthreads();
     }
+    VDBG(3);
     const float top = (float)best_c, second = (float)s_second, scoreRatio = 4;
     const uint64_t sg = 2 * a;
     if (n_cand == 1 || top >= scoreRatio * second) {                         /* coarse (:531): one request, the best window */
@@ -158,14 +166,14 @@ lf_vote_hash_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_
     }
     /* fine: every local maximum above best / 4 (:553, :875-877), in scan order = ascending (strand, window) */
     const float minScore = top / scoreRatio;
-    for (uint32_t i = tid; i < cap; i += 256) {
-        const uint32_t k = keys[i], cc = cnts[i];
+    for (uint32_t i = tid; i < cap; i += LF_VOTE_THREADS) {
+        const uint2 kc = *reinterpret_cast<const uint2 *>(&tab[2 * i]); const uint32_t k = kc.x, cc = kc.y;
         if (k != 0u && (cc & 0x80000000u) && (float)(cc & 0x7fffffffu) > minScore) tmp_list[sg + atomicAdd(&s_nlist, 1u)] = k - 1u;
     }
     __syncthreads();
     const uint32_t nl = s_nlist;
     if (nl <= 64) {                                                          /* the usual handful: rank by counting */
-        for (uint32_t e = tid; e < nl; e += 256) {
+        for (uint32_t e = tid; e < nl; e += LF_VOTE_THREADS) {
             const uint32_t key = tmp_list[sg + e];
             uint32_t rank = 0;
             for (uint32_t f = 0; f < nl; f++) rank += tmp_list[sg + f] < key;
@@ -176,21 +184,23 @@ lf_vote_hash_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_
          * The table is not needed any more: its memory holds the list for a bitonic sort (nl <= 2/3 cap, so the next
          * power of two fits into the 2 cap words) */
         uint32_t P = 128; while (P < nl) P <<= 1;
-        for (uint32_t i = tid; i < P; i += 256) keys[i] = i < nl ? tmp_list[sg + i] : 0xffffffffu;
+        for (uint32_t i = tid; i < P; i += LF_VOTE_THREADS) tab[i] = i < nl ? tmp_list[sg + i] : 0xffffffffu;
         __syncthreads();
         for (uint32_t k = 2; k <= P; k <<= 1)
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t i = tid; i < P; i += 256) {
+                for (uint32_t i = tid; i < P; i += LF_VOTE_THREADS) {
                     const uint32_t x = i ^ j;
                     if (x > i) {
-                        const uint32_t va = keys[i], vb = keys[x];
-                        if ((va > vb) == ((i & k) == 0)) { keys[i] = vb; keys[x] = va; }
+                        const uint32_t va = tab[i], vb = tab[x];
+                        if ((va > vb) == ((i & k) == 0)) { tab[i] = vb; tab[x] = va; }
                     }
                 }
                 __syncthreads();
             }
-        for (uint32_t e = tid; e < nl; e += 256) { const uint32_t key = keys[e]; stage[sg + e] = (key & VK_WMASK) | ((key >> VK_WIN_BITS) << 31); }
+        for (uint32_t e = tid; e < nl; e += LF_VOTE_THREADS) { const uint32_t key = tab[e]; stage[sg + e] = (key & VK_WMASK) | ((key >> VK_WIN_BITS) << 31); }
     }
+    VDBG(4);
+    if (dbg && tid == 0) { atomicAdd(&dbg[5], 1ull); atomicAdd(&dbg[6], (unsigned long long)nl); if (nl > 64) atomicAdd(&dbg[7], 1ull); }
     if (tid == 0) { mode[r] = 3; nreq[r] = nl; vscore[r] = top; }
 }
 
@@ -388,13 +398,15 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
         } else { lf_set_error("lfg_vote_chain: no resident seed batch (host offsets)"); return LF_ERR_ARG; }
         static bool attr_set[16] = { false };
         if (!attr_set[dv]) { HIPCHK(hipFuncSetAttribute((const void *)lf_vote_hash_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8 + LF_VOTE_FILTER_WORDS * 4)); attr_set[dv] = true; }
+        unsigned long long *d_dbg = nullptr;
+        if (getenv("LF_VOTE_DEBUG")) { d_dbg = (unsigned long long *)VSLOT(8, 256); if (d_dbg) HIPCHK(hipMemsetAsync(d_dbg, 0, 128, s)); }
         uint64_t lo = 0;
         for (int k = 0; k < 3 && lo <= v_max_lds; k++) {
             uint64_t hi = (uint64_t)caps[k] * 2 / 3; if (hi > v_max_lds) hi = v_max_lds;
             if (lo <= v_max)
-                hipLaunchKernelGGL(lf_vote_hash_kernel<false>, dim3((unsigned)n_reads), dim3(256), (size_t)caps[k] * 8 + LF_VOTE_FILTER_WORDS * 4, s, n_reads, d_off, d_read_off, d_tpos, d_qpl, d_strand,
+                hipLaunchKernelGGL(lf_vote_hash_kernel<false>, dim3((unsigned)n_reads), dim3(LF_VOTE_THREADS), (size_t)caps[k] * 8 + LF_VOTE_FILTER_WORDS * 4, s, n_reads, d_off, d_read_off, d_tpos, d_qpl, d_strand,
                                    (uint32_t)p->min_anchor_len, (uint32_t)ix->l_pac, (uint32_t)p->min_read_len, lo, hi, caps[k],
-                                   (const uint64_t *)nullptr, (uint32_t *)nullptr, d_mode, d_nreq, d_seg0, d_stage, d_tmp_list, d_vscore);
+                                   (const uint64_t *)nullptr, (uint32_t *)nullptr, d_mode, d_nreq, d_seg0, d_stage, d_tmp_list, d_vscore, d_dbg);
             lo = hi + 1;
         }
         if (gtab_words) {
@@ -402,11 +414,13 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
             uint32_t *d_gtab = (uint32_t *)VSLOT(4, gtab_words * 4 + 16);
             if (!d_gtab_off || !d_gtab) return LF_ERR_NOMEM;
             HIPCHK(hipMemcpyAsync(d_gtab_off, gtab_off.data(), (size_t)n_reads * 8, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(lf_vote_hash_kernel<true>, dim3((unsigned)n_reads), dim3(256), 0, s, n_reads, d_off, d_read_off, d_tpos, d_qpl, d_strand,
+            hipLaunchKernelGGL(lf_vote_hash_kernel<true>, dim3((unsigned)n_reads), dim3(LF_VOTE_THREADS), 0, s, n_reads, d_off, d_read_off, d_tpos, d_qpl, d_strand,
                                (uint32_t)p->min_anchor_len, (uint32_t)ix->l_pac, (uint32_t)p->min_read_len, lo, ~0ull, 0u,
-                               (const uint64_t *)d_gtab_off, d_gtab, d_mode, d_nreq, d_seg0, d_stage, d_tmp_list, d_vscore);
+                               (const uint64_t *)d_gtab_off, d_gtab, d_mode, d_nreq, d_seg0, d_stage, d_tmp_list, d_vscore, d_dbg);
             HIPCHK(hipStreamSynchronize(s));                    /* gtab_off (host vector) is read by the copy above */
         }
+        if (d_dbg) { unsigned long long h[8]; HIPCHK(hipMemcpyAsync(h, d_dbg, 64, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+            fprintf(stderr, "[lf] vote kernel cycles (sum over blocks, thread 0): zero %llu insert %llu passA %llu passB %llu fine %llu | fine reads %llu, candidates %llu, lists > 64: %llu (of %d reads)\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], n_reads); }
         /* request ids: exclusive scan over n_reads + 1 counts (the last one is a zero pad) */
         { size_t tb = tb3; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, nreq64, d_req0, n_reads, s)); }
         HIPCHK(hipMemcpyAsync(h_small, d_req0 + (R - 1), 8, hipMemcpyDeviceToHost, s));
