@@ -53,3 +53,66 @@ def test_c5_shape(ecoli_like, oracle_lib):
     fa, g = ecoli_like
     reads = synth.make_reads(g, 40, 50000, 0.10, seed=5, mix=(0.40, 0.25, 0.35))
     _run(fa, reads, oracle_lib, min_anchor_len=17, sampling_count=2000)
+
+
+# ---- the same shapes on a HUMAN-LIKE genome: 120 Mbp, about half of it repeats, incl. a 300 bp family with > 10^4 copies
+# ---- (Alu-like) and truncated 1-6 kbp families: seeds with hundreds of hits, fine mode, big chain windows.  ALL records
+# ---- (primary, secondary, supplementary) are compared, with the oracle and -- where it was built -- the compiled reference.
+
+@pytest.fixture(scope="module")
+def human_like(tmp_path_factory):
+    import lordfast_amd as la
+    d = tmp_path_factory.mktemp("humanlike")
+    g = synth.make_genome(120_000_000, 5, seed=11, n_families=200, profile="grch38like")
+    places = synth.add_duplications(g, seg_len=40000, copies=4, div=0.02)          # segmental duplications: fine mode
+    fa = la.index_build(g, os.path.join(str(d), "human_like.fa"))
+    return fa, g, places
+
+
+def _run_big(fa, reads, oracle_lib, **kw):
+    import lordfast_amd as la
+    from conftest import have_ref
+    names = [r[0].encode() for r in reads]
+    seqs = [r[1] for r in reads]
+    h = la.LordFast(fa, device=0)
+    sam, st = h.map_batch(names, seqs, params=la.default_params(**kw))
+    h.close()
+    orc = oracle_lib.Oracle(fa)
+    exp = orc.map_batch(names, seqs, params=oracle_lib.default_params(threads=16, **kw))
+    orc.close()
+    assert sam == exp, first_diff(sam, exp)
+    if have_ref() and os.path.exists(fa + ".cache"):
+        ref = oracle_lib.Ref()
+        ref.load(fa)
+        ref.set_params(oracle_lib.default_params(threads=1, **kw), "test")
+        rsam, _ = ref.map_mem(names, seqs)
+        assert sam == rsam, first_diff(sam, rsam)
+    return st, sam
+
+
+def test_c2_shape_on_a_repeat_rich_genome(human_like, oracle_lib):
+    import numpy as np
+    fa, g, places = human_like
+    reads = synth.make_reads(g, 300, 15000, 0.15, seed=2024)
+    rng = np.random.default_rng(3)
+    for k, (ci, p) in enumerate(places * 4):                                       # reads out of the duplicated segment
+        frag = g[ci][1][p + 2000 * (k % 5):p + 2000 * (k % 5) + 14000]
+        if k % 2:
+            frag = synth.revcomp(frag)
+        reads.append((f"dup{k}", synth.mutate(frag, 0.15, rng).tobytes()))
+    st, sam = _run_big(fa, reads, oracle_lib)
+    flags = [int(l.split(b"\t")[1]) for l in sam.split(b"\n") if l]
+    assert st["n_seeds"] / len(reads) > 600
+    assert sum(1 for f in flags if f & 256) > 0, "fine mode with secondaries must occur"
+
+
+def test_c4_shape_on_a_repeat_rich_genome(human_like, oracle_lib):
+    fa, g, _ = human_like
+    reads = synth.make_reads(g, 120, 15000, 0.15, seed=9)
+    _run_big(fa, reads, oracle_lib, max_map=30, chain_alg=1)
+
+
+def test_c5_shape_on_a_repeat_rich_genome(human_like, oracle_lib):
+    fa, g, _ = human_like
+    reads = synth.make_reads(g, 30, 50000, 0.10, seed=5, mix=(0.40, 0.25, 0.35))
+    _run_big(fa, reads, oracle_lib, min_anchor_len=17, sampling_count=2000)
