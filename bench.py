@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--err", type=float, default=0.15)
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exclusive", action="store_true", help="skip the exclusive pass (profiler counter runs: exactly the timed steps' launches)")
     ap.add_argument("--workdir", default=os.environ.get("LF_BENCH_DIR", "/tmp/lf_bench"))
     ap.add_argument("--chain-alg", choices=["dp-n2", "clasp"], default="dp-n2",
                     help="BASELINE config C2 (the headline) is dp-n2; clasp + --max-map 30 is config C4's option set")
@@ -341,7 +342,9 @@ def main():
     # on one stream, so that every HIP-event bracket is the kernel (group) ALONE on the GPU.  The timed steps above keep
     # eight chunks in flight: their brackets overlap and are only reported as `overlapped_bracket_ms`.
     excl = None
-    if rank == 0:
+    if rank == 0 and args.no_exclusive:
+        excl = {k: (v / args.steps if isinstance(v, (int, float)) else v) for k, v in agg.items()}      # overlapped brackets instead
+    elif rank == 0:
         saved = {k: os.environ.get(k) for k in ("LF_LANES", "LF_SERIAL_CLASSES")}
         os.environ["LF_LANES"] = "1"; os.environ["LF_SERIAL_CLASSES"] = "1"
         try:
@@ -401,7 +404,8 @@ def main():
         if pmc:
             prefix = dom.split(" ")[0].rstrip("*")
             fam = [v for k, v in pmc.items() if k.startswith(prefix)]
-            if fam:    # bytes per launch; FETCH_SIZE x2 for the wide coalesced reads is NOT applied (profiles/r02_c2/README.md)
+            if fam:    # the counter passes profile exactly ONE step (--no-exclusive --steps 1 --warmup 0): bytes per step / launches per
+                # step; FETCH_SIZE x2 for wide coalesced reads is NOT applied (profiles/r02_c2/README.md)
                 traffic = sum(v.get("fetch_kb", 0.0) + v.get("write_kb", 0.0) for v in fam) * 1024.0 / max(1.0, dl)
         roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=traffic,
                         launches_per_step=int(dl), avg_launch_ms=dms / max(1, dl), algorithmic_bytes_per_launch=dbytes / max(1, dl),

@@ -965,8 +965,11 @@ __global__ void lf_desc_build_kernel(const uint64_t *__restrict__ keys, const ui
     probs[j] = p;
 }
 
+/* dev_desc / dev_opsoff != nullptr: the descriptors are already on the device (lfg_walk_plan) and the results stay there
+ * (res_dev[0..2] = ed, end column, path length arrays) */
 static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len,
-                              int ops_slot, void **ops_dev, void **desc_dev, float *ms)
+                              int ops_slot, void **ops_dev, void **desc_dev, float *ms,
+                              const lf_aln_desc_t *dev_desc = nullptr, const uint64_t *dev_opsoff = nullptr, void **res_dev = nullptr)
 {
     if (ms) *ms = 0;
     if (n == 0) return LF_OK;
@@ -981,17 +984,22 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     if (!e0 || !e1 || !eb) return LF_ERR_HIP;
 #define DSLOT(T, k, bytes) (T *)lfg_dev_slot(device, LF_DS_ALN0 + (k), (bytes))
     /* the descriptors stay with the round's paths when those stay in HBM (lazy paths are resolved against them later) */
-    lf_aln_desc_t *d_desc = ops ? DSLOT(lf_aln_desc_t, 0, (size_t)n * sizeof(lf_aln_desc_t))
+    lf_aln_desc_t *d_desc = dev_desc ? const_cast<lf_aln_desc_t *>(dev_desc)
+                          : ops ? DSLOT(lf_aln_desc_t, 0, (size_t)n * sizeof(lf_aln_desc_t))
                                 : (lf_aln_desc_t *)lfg_dev_slot(device, ops_slot + 1, (size_t)n * sizeof(lf_aln_desc_t));
     if (desc_dev) *desc_dev = d_desc;
-    uint64_t *d_opsoff = DSLOT(uint64_t, 1, (size_t)n * 8);
+    uint64_t *d_opsoff = dev_opsoff ? const_cast<uint64_t *>(dev_opsoff) : DSLOT(uint64_t, 1, (size_t)n * 8);
     uint64_t *d_keys = DSLOT(uint64_t, 3, (size_t)n * 8), *d_keys2 = DSLOT(uint64_t, 8, (size_t)n * 8);
     uint32_t *d_vals = DSLOT(uint32_t, 9, (size_t)n * 4), *d_vals2 = DSLOT(uint32_t, 10, (size_t)n * 4);
     uint64_t *d_ent = DSLOT(uint64_t, 11, (size_t)n * 8), *d_base = DSLOT(uint64_t, 12, (size_t)n * 8 + 8);
     lf_aln_prob *d_probs = DSLOT(lf_aln_prob, 13, (size_t)n * sizeof(lf_aln_prob));
-    int32_t *d_ed = DSLOT(int32_t, 4, (size_t)n * 4), *d_end = DSLOT(int32_t, 5, (size_t)n * 4);
-    uint32_t *d_len = DSLOT(uint32_t, 6, (size_t)n * 4);
+    /* device-planned rounds keep their results in slots of their own: the host-planned rounds that follow (rare chains)
+     * must not overwrite what lf_walk_emit_kernel still reads */
+    const int rs = dev_desc ? 18 : 4;
+    int32_t *d_ed = DSLOT(int32_t, rs, (size_t)n * 4), *d_end = DSLOT(int32_t, rs + 1, (size_t)n * 4);
+    uint32_t *d_len = DSLOT(uint32_t, rs + 2, (size_t)n * 4);
     uint8_t *d_ops = ops ? DSLOT(uint8_t, 7, D->ops_total + 64) : (uint8_t *)lfg_dev_slot(device, ops_slot, D->ops_total + 64);
+    if (res_dev) { res_dev[0] = d_ed; res_dev[1] = d_end; res_dev[2] = d_len; }
     if (ops_dev) *ops_dev = d_ops;
     int *d_cstart = DSLOT(int, 14, 64);
     uint64_t *d_misc = DSLOT(uint64_t, 15, 64);
@@ -1002,8 +1010,10 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     void *d_tmp = lfg_dev_slot(device, LF_DS_ALN0 + 16, std::max(tb1, tb2) + 256);
     if (!d_tmp) return LF_ERR_NOMEM;
 
-    HIPCHK(hipMemcpyAsync(d_desc, D->d, (size_t)n * sizeof(lf_aln_desc_t), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_opsoff, D->ops_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    if (!dev_desc) {
+        HIPCHK(hipMemcpyAsync(d_desc, D->d, (size_t)n * sizeof(lf_aln_desc_t), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_opsoff, D->ops_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    }
     HIPCHK(hipMemsetAsync(d_misc, 0, 64, s));
     HIPCHK(hipEventRecord(e0, s));
     const unsigned gb = (unsigned)((n + 255) / 256);
@@ -1032,14 +1042,17 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     launch_classes<true>(L);         /* targets of descriptors are the 2-bit reference */
     for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && L.cs[k] != s) { HIPCHK(hipEventRecord(cdone[k], L.cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
     HIPCHK(hipEventRecord(e1, s));
-    HIPCHK(hipMemcpyAsync(ed, d_ed, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(endloc, d_end, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(ops_len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (ed) {
+        HIPCHK(hipMemcpyAsync(ed, d_ed, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(endloc, d_end, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(ops_len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    }
     if (ops) HIPCHK(hipMemcpyAsync(ops, d_ops, D->ops_total, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
-    if (cnt(9) + cnt(10) + cnt(11) > 0) for (int i = 0; i < n; i++) if (ed[i] == -2) { lf_set_error("edlib kernel: no Hirschberg split row for descriptor %d (n %u, m %u)", i, D->d[i].n, D->d[i].m); return LF_ERR_HIP; }
+    /* (a device-planned round reports a missing Hirschberg split through lf_walk_emit_kernel: ed == -2 makes the job rare) */
+    if (ed && cnt(9) + cnt(10) + cnt(11) > 0) for (int i = 0; i < n; i++) if (ed[i] == -2) { lf_set_error("edlib kernel: no Hirschberg split row for descriptor %d (n %u, m %u)", i, D->d[i].n, D->d[i].m); return LF_ERR_HIP; }
     return LF_OK;
 }
 
@@ -1064,6 +1077,25 @@ extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_des
         for (int c = 0; c < 12; c++) if (cnt[c]) fprintf(stderr, "[lf] dp nb<=%u: %llu problems, %.1f Mcells, %.2f M block steps\n", edge[c], (unsigned long long)cnt[c], cells[c] / 1e6, hist[c] / 1e6);
     }
     return run_edlib_desc_gpu(ix->device, n, &D, ed, endloc, ops, ops_len, ops_slot, ops_dev, desc_dev, ms);
+}
+
+extern "C" int lfg_edlib_desc_dev(const struct lf_index *ix, int n, const void *d_desc, const void *d_opsoff, uint64_t ops_total, int ops_slot,
+                                  void **ops_dev, void **ed_dev, void **end_dev, void **len_dev, float *ms)
+{
+    lf_dev_state *st = (lf_dev_state *)ix->dev;
+    if (!st) { lf_set_error("index is not on a device"); return LF_ERR_NO_DEVICE; }
+    lf_desc_src D;
+    D.d = nullptr; D.ops_off = nullptr; D.ops_total = ops_total;
+    D.d_reads = (const unsigned char *)lfg_dev_slot(ix->device, LF_DS_SEED0 + 0, 0);
+    D.d_pac = st->view.pac;
+    if (!D.d_reads) { lf_set_error("lfg_edlib_desc_dev: no resident read batch"); return LF_ERR_ARG; }
+    void *res[3] = { nullptr, nullptr, nullptr };
+    const int rc = run_edlib_desc_gpu(ix->device, n, &D, nullptr, nullptr, nullptr, nullptr, ops_slot, ops_dev, nullptr, ms,
+                                      (const lf_aln_desc_t *)d_desc, (const uint64_t *)d_opsoff, res);
+    if (ed_dev) *ed_dev = res[0];
+    if (end_dev) *end_dev = res[1];
+    if (len_dev) *len_dev = res[2];
+    return rc;
 }
 
 extern "C" int lfg_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,

@@ -57,6 +57,8 @@ typedef struct {
     uint32_t *chain_len; float *chain_score; uint64_t *chain_off; Seed_t *chain_seeds;
     uint64_t n_req_seeds, n_chain_seeds, n_tie_req;
     float ms_vote, ms_chain;
+    /* the same chains in HBM (valid until this lane's next lfg_vote_chain): what lf_walk.hip works on */
+    const void *d_chain_seeds, *d_chain_off, *d_chain_len, *d_ctg;
 } lfg_vc_t;
 int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, int n_reads, uint64_t n_hits, uint32_t max_read_len, lfg_vc_t *out);
 void lfg_hits_free(lfg_hits_t *h);
@@ -87,11 +89,13 @@ void *lfg_lane_stream(int device, int which);   /* persistent hipStream_t of the
 void *lfg_lane_event(int device, int which);    /* persistent hipEvent_t (timing enabled) of the calling thread's lane; which < 48 */
 /* slot ids */
 enum { LF_DS_SEED0 = 0 /* ..15 */, LF_DS_CHAIN0 = 16 /* ..23 */, LF_DS_ALN0 = 24 /* ..47 */, LF_DS_KSW0 = 48 /* ..55 */,
-       LF_DS_RND0 = 56 /* ..87: 2 per extension round (ops, spare) */, LF_DS_RENDER0 = 88 /* ..95 */, LF_DS_VOTE0 = 96 /* ..127 */ };
+       LF_DS_RND0 = 56 /* ..87: 2 per extension round (ops, spare) */, LF_DS_RENDER0 = 88 /* ..95 */, LF_DS_VOTE0 = 96 /* ..127 */,
+       LF_DS_WALK0 = 128 /* ..147 */ };
 #define LF_MAX_ED_ROUNDS 16
 enum { LF_PS_READS = 0, LF_PS_READOFF = 1, LF_PS_HITS_T = 2, LF_PS_HITS_Q = 3, LF_PS_HITS_S = 4, LF_PS_HITS_OFF = 5,
        LF_PS_CHAIN_SEEDS = 6, LF_PS_CHAIN_IDX = 7, LF_PS_ALN_Q = 8, LF_PS_ALN_T = 9, LF_PS_ALN_PROB = 10 /* ..16 */,
-       LF_PS_ROUND0 = 20 /* 4 per round: ed, end, len, ops ; up to 16 rounds */, LF_PS_RENDER0 = 84 /* ..91 */, LF_PS_VOTE0 = 92 /* ..107 */ };
+       LF_PS_ROUND0 = 20 /* 4 per round: ed, end, len, ops ; up to 16 rounds */, LF_PS_RENDER0 = 84 /* ..91 */, LF_PS_VOTE0 = 92 /* ..107 */,
+       LF_PS_WALK0 = 108 /* ..111 */, LF_PS_RENDER1 = 112 /* ..115: text of the host-planned records */ };
 
 /* alignment request as a DESCRIPTOR into HBM-resident data: query = the read batch uploaded by the seed stage,
  * target = the 2-bit reference.  Element i = base[start +/- i], optionally complemented (flags LF_F_*). */
@@ -111,8 +115,22 @@ typedef struct {            /* one piece of a record, in output order (32 bytes)
     uint8_t kind, round, lazy, pad;
 } lf_ritem_t;
 typedef struct { uint32_t item0, nitems; } lf_rrecord_t;
-int lfg_render(const struct lf_index *ix, int n_recs, const lf_rrecord_t *recs, uint64_t n_items, const lf_ritem_t *items,
+/* records 0 .. n_dev_recs-1 and their items are already on the device (lfg_walk_emit: d_recs / d_items), the host's follow */
+int lfg_render(const struct lf_index *ix, int n_dev_recs, const void *d_recs_dev, uint64_t n_dev_items, const void *d_items_dev,
+               int n_recs, const lf_rrecord_t *recs, uint64_t n_items, const lf_ritem_t *items,
                const void *const *round_ops, const void *const *round_desc, char **text_out, uint64_t **offs_out, uint64_t *text_bytes, float *ms);
+/* ---- lf_walk.hip: the common path of alignChain_edlib on the device ---- */
+typedef struct { uint32_t req, read, chain_len; uint8_t is_rev, pad[3]; } lf_wjob_t;      /* one kept candidate window: chain request, read (index in the seed batch) */
+typedef struct { uint32_t pos, posEnd, qStart, qEnd; int32_t nm; uint32_t rare, pad[2]; } lf_wrec_t;   /* SAM record fields of a job; rare: replay it on the host */
+typedef struct {
+    int n_jobs; uint64_t n_desc, ops_total, n_items, ext_bytes, block_steps;
+    void *d_jobs, *d_rare, *d_sbase, *d_ibase, *d_desc, *d_opsoff, *d_slot_desc, *d_recs, *d_items;
+} lfg_walk_t;
+int lfg_walk_plan(const struct lf_index *ix, int n_jobs, const lf_wjob_t *jobs, const lfg_vc_t *vc, int lazy, lfg_walk_t *W);
+int lfg_walk_emit(const struct lf_index *ix, const lfg_vc_t *vc, int lazy, lfg_walk_t *W, const void *d_ed, const void *d_end, const void *d_len, lf_wrec_t **wrec_out);
+/* alignments of device-resident descriptors (lfg_walk_plan); results stay on the device */
+int lfg_edlib_desc_dev(const struct lf_index *ix, int n, const void *d_desc, const void *d_opsoff, uint64_t ops_total, int ops_slot,
+                       void **ops_dev, void **ed_dev, void **end_dev, void **len_dev, float *ms);
 int lfg_fetch(int device, void *dst, const void *src_dev, size_t bytes);
 int lfg_upload(int device, void *dst_dev, const void *src, size_t bytes);
 #define LF_F_QREV  1u

@@ -249,6 +249,7 @@ typedef struct ctx {
     uint64_t max_chunk_hits;        /* more seed hits than this in one chunk: map_chunk asks for a split (LF_RC_SPLIT) */
     int host_cigar;                 /* LF_HOST_CIGAR=1: build CIGAR / MD on the host from copied-back paths (cross-check) */
     char *rtext; uint64_t *roffs; int *rrbase;      /* rendered text, per-record offsets, first record of each worker */
+    int n_dev_recs; uint64_t n_dev_items; void *d_dev_recs, *d_dev_items;       /* the device-planned recipe (lf_walk.hip): records 0 .. n_dev_recs-1 */
     /* output assembly */
     char *out_base; uint64_t *out_off;
     const char *const *len_seqs; uint32_t *len_out;
@@ -1435,7 +1436,7 @@ static void phase_bind_text(ctx_t *cx, int tid, int ri)
         for (int j = 0; j < r->maps[w].n; j++) {
             sam_t *s = &r->maps[w].v[j];
             if (s->rec < 0) continue;
-            const size_t g = (size_t)cx->rrbase[s->rtid] + (size_t)s->rec;
+            const size_t g = s->rtid == -2 ? (size_t)s->rec : (size_t)cx->rrbase[s->rtid] + (size_t)s->rec;
             s->cigar = cx->rtext + cx->roffs[2 * g]; s->md = cx->rtext + cx->roffs[2 * g + 1];
         }
 }
@@ -1649,6 +1650,67 @@ extend:
     cx->ed_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
     cx->ksw_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
     cx->edd_jobs = (jobvec_t *)calloc((size_t)nt, sizeof(jobvec_t));
+    /* ---- D0: the common path of alignChain_edlib on the device (lf_walk.hip): pieces -> descriptors -> alignments ->
+     * clip / split triggers -> record fields + CIGAR recipe, all in HBM.  Chains that leave the common path (and everything
+     * when a host cross-check mode is on) are replayed by the host walk below, which then finds them incomplete. ---- */
+    cx->n_dev_recs = 0; cx->n_dev_items = 0; cx->d_dev_recs = NULL; cx->d_dev_items = NULL;
+    if (!host_vote && !cx->host_cigar && !getenv("LF_HOST_WALK")) {
+        int nj = 0;
+        for (int i = 0; i < n; i++) { const rd_t *r = &cx->reads[i]; if (r->mode >= 2) for (int w = 0; w < r->nWins; w++) nj += r->jobs[w].chainLen > 1; }
+        if (nj > 0) {
+            lf_wjob_t *wj = (lf_wjob_t *)lfg_pin_slot(LF_PS_WALK0 + 2, (size_t)nj * sizeof(lf_wjob_t));
+            job_t **owner = (job_t **)malloc((size_t)nj * sizeof(job_t *));
+            if (!wj || !owner) { free(owner); return LF_ERR_NOMEM; }
+            int k = 0;
+            for (int i = 0; i < n; i++) {
+                rd_t *r = &cx->reads[i];
+                if (r->mode < 2) continue;
+                for (int w = 0; w < r->nWins; w++) {
+                    job_t *j = &r->jobs[w];
+                    if (j->chainLen <= 1) continue;
+                    wj[k].req = (uint32_t)r->wins[w].req; wj[k].read = (uint32_t)r->seed_idx; wj[k].chain_len = j->chainLen; wj[k].is_rev = (uint8_t)j->isRev;
+                    wj[k].pad[0] = wj[k].pad[1] = wj[k].pad[2] = 0;
+                    owner[k++] = j;
+                }
+            }
+            lfg_walk_t W;
+            rc = lfg_walk_plan(cx->ix, nj, wj, &cx->vc, cx->lazy, &W);
+            tmark(cx, "WALKPLAN");
+            if (rc != LF_OK) { free(owner); return rc; }
+            void *dops = NULL, *d_ed = NULL, *d_end = NULL, *d_len = NULL; float ms = 0;
+            if (W.n_desc) rc = lfg_edlib_desc_dev(cx->ix, (int)W.n_desc, W.d_desc, W.d_opsoff, W.ops_total, LF_DS_RND0 + 0, &dops, &d_ed, &d_end, &d_len, &ms);
+            tmark(cx, "EDLIB0");
+            if (rc != LF_OK) { free(owner); return rc; }
+            lf_wrec_t *wrec = NULL;
+            rc = lfg_walk_emit(cx->ix, &cx->vc, cx->lazy, &W, d_ed, d_end, d_len, &wrec);
+            tmark(cx, "WALKEMIT");
+            if (rc != LF_OK) { free(owner); return rc; }
+            {   /* extension round 0 lives on the device only */
+                ed_round_t R; memset(&R, 0, sizeof R);
+                R.n = (int)W.n_desc; R.pinned = 1; R.ops_bytes = W.ops_total; R.d_ops = (uint8_t *)dops; R.d_desc = W.d_desc; R.lazy = cx->lazy;
+                cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
+                cx->ed_rounds[cx->n_ed_rounds++] = R;
+            }
+            st->ms_k_edlib += ms; st->n_edlib_problems += W.n_desc; st->edlib_launches += 1; st->ops_bytes += W.ops_total;
+            st->ext_bytes += W.ext_bytes; st->dp_block_steps += W.block_steps;
+            int n_rare = 0;
+            for (k = 0; k < nj; k++) {
+                job_t *j = owner[k];
+                if (wrec[k].rare) { n_rare++; continue; }
+                rd_t *r = &cx->reads[j->read];
+                samlist_t *map = &r->maps[j->widx];
+                sam_t tmp; memset(&tmp, 0, sizeof tmp);
+                tmp.flag = j->isRev ? 16 : 0; tmp.pos = wrec[k].pos; tmp.posEnd = wrec[k].posEnd; tmp.qStart = wrec[k].qStart; tmp.qEnd = wrec[k].qEnd; tmp.nmCount = wrec[k].nm;
+                samlist_clear(map);
+                samlist_push(map, &tmp, NULL, NULL, &cx->arena[0]);
+                map->v[0].rec = k; map->v[0].rtid = -2;                 /* record k of the device-planned recipe */
+                j->complete = 1;
+            }
+            if (timing) fprintf(stderr, "[lf] device walk: %d jobs, %llu pieces aligned, %d jobs (%.1f %%) left to the host replay\n", nj, (unsigned long long)W.n_desc, n_rare, 100.0 * n_rare / nj);
+            cx->n_dev_recs = nj; cx->n_dev_items = W.n_items; cx->d_dev_recs = W.d_recs; cx->d_dev_items = W.d_items;
+            free(owner);
+        }
+    }
     for (int round = 0; round < 64; round++) {
         double tw0 = now_ms();
         parallel_for(cx, n, phase_walk);
@@ -1787,16 +1849,16 @@ extend:
         uint64_t n_items = 0; int n_recs = 0;
         cx->rrbase = (int *)malloc((size_t)nt * sizeof(int));
         uint64_t *ibase = (uint64_t *)malloc((size_t)nt * 8);
-        for (int t = 0; t < nt; t++) { cx->rrbase[t] = n_recs; ibase[t] = n_items; n_recs += cx->stages[t].rrn; n_items += cx->stages[t].rin; }
-        if (n_recs) {
-            if (n_items >= 0xffffffffull) { lf_set_error("lf_map_batch: too many CIGAR pieces in one chunk"); free(ibase); return LF_ERR_ARG; }
+        for (int t = 0; t < nt; t++) { cx->rrbase[t] = cx->n_dev_recs + n_recs; ibase[t] = cx->n_dev_items + n_items; n_recs += cx->stages[t].rrn; n_items += cx->stages[t].rin; }
+        if (n_recs + cx->n_dev_recs) {
+            if (n_items + cx->n_dev_items >= 0xffffffffull) { lf_set_error("lf_map_batch: too many CIGAR pieces in one chunk"); free(ibase); return LF_ERR_ARG; }
             lf_ritem_t *items = (lf_ritem_t *)lfg_pin_slot(LF_PS_RENDER0 + 3, (n_items + 1) * sizeof(lf_ritem_t));
             lf_rrecord_t *recs = (lf_rrecord_t *)lfg_pin_slot(LF_PS_RENDER0 + 4, ((size_t)n_recs + 1) * sizeof(lf_rrecord_t));
             if (!items || !recs) { free(ibase); return LF_ERR_NOMEM; }
             for (int t = 0; t < nt; t++) {
                 const stage_t *s = &cx->stages[t];
-                if (s->rin) memcpy(items + ibase[t], s->ri, s->rin * sizeof(lf_ritem_t));
-                for (int k = 0; k < s->rrn; k++) { lf_rrecord_t q = s->rr[k]; q.item0 += (uint32_t)ibase[t]; recs[cx->rrbase[t] + k] = q; }
+                if (s->rin) memcpy(items + (ibase[t] - cx->n_dev_items), s->ri, s->rin * sizeof(lf_ritem_t));
+                for (int k = 0; k < s->rrn; k++) { lf_rrecord_t q = s->rr[k]; q.item0 += (uint32_t)ibase[t]; recs[cx->rrbase[t] - cx->n_dev_recs + k] = q; }
             }
             /* rounds whose paths were computed through the host (Hirschberg-size problems): put them into HBM too */
             const void *round_ops[LF_MAX_ED_ROUNDS], *round_desc[LF_MAX_ED_ROUNDS]; memset(round_ops, 0, sizeof round_ops); memset(round_desc, 0, sizeof round_desc);
@@ -1813,7 +1875,7 @@ extend:
             }
             float ms = 0; uint64_t tbytes = 0;
             tmark(cx, "recipe");
-            rc = lfg_render(cx->ix, n_recs, recs, n_items, items, round_ops, round_desc, &cx->rtext, &cx->roffs, &tbytes, &ms);
+            rc = lfg_render(cx->ix, cx->n_dev_recs, cx->d_dev_recs, cx->n_dev_items, cx->d_dev_items, n_recs, recs, n_items, items, round_ops, round_desc, &cx->rtext, &cx->roffs, &tbytes, &ms);
             tmark(cx, "RENDER");
             if (timing) fprintf(stderr, "[lf] render: %d records, %llu pieces, %.1f MB text, kernels %.1f ms, total %.1f ms\n", n_recs, (unsigned long long)n_items, tbytes / 1e6, ms, now_ms() - t0);
             if (rc != LF_OK) { free(ibase); return rc; }

@@ -200,11 +200,14 @@ struct lf_widen32 { __host__ __device__ uint64_t operator()(uint32_t v) const { 
 
 /* host entry: items / records in (pinned) host memory; rounds[r] = device address of round r's ops (or NULL);
  * text comes back in a pinned slot, offs[2*rec], offs[2*rec+1] = start of the record's CIGAR / MD (NUL-terminated). */
-extern "C" int lfg_render(const struct lf_index *ix, int n_recs, const lf_rrecord_t *recs, uint64_t n_items, const lf_ritem_t *items,
+extern "C" int lfg_render(const struct lf_index *ix, int n_dev_recs, const void *d_recs_dev, uint64_t n_dev_items, const void *d_items_dev,
+                          int n_host_recs, const lf_rrecord_t *recs, uint64_t n_host_items, const lf_ritem_t *items,
                           const void *const *round_ops, const void *const *round_desc, char **text_out, uint64_t **offs_out, uint64_t *text_bytes, float *ms)
 {
     if (ms) *ms = 0;
     *text_out = nullptr; *offs_out = nullptr; *text_bytes = 0;
+    const int n_recs = n_dev_recs + n_host_recs;
+    const uint64_t n_items = n_dev_items + n_host_items;
     if (n_recs == 0) return LF_OK;
     lf_dev_state *st = (lf_dev_state *)ix->dev;
     if (!st) { lf_set_error("index is not on a device"); return LF_ERR_NO_DEVICE; }
@@ -212,8 +215,19 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_recs, const lf_rrecor
     HIPCHK(hipSetDevice(device));
     hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
     if (!s) return LF_ERR_HIP;
-    lf_rrecord_t *d_recs = (lf_rrecord_t *)lfg_dev_slot(device, LF_DS_RENDER0 + 0, (size_t)n_recs * sizeof(lf_rrecord_t));
-    lf_ritem_t *d_items = (lf_ritem_t *)lfg_dev_slot(device, LF_DS_RENDER0 + 1, (size_t)n_items * sizeof(lf_ritem_t) + 64);
+    /* the device-planned recipe (lf_walk_emit_kernel) is used in place; host-planned records (the rare chains) are appended
+     * behind a copy of it */
+    lf_rrecord_t *d_recs = (lf_rrecord_t *)d_recs_dev;
+    lf_ritem_t *d_items = (lf_ritem_t *)d_items_dev;
+    if (n_host_recs > 0 || !d_recs) {
+        d_recs = (lf_rrecord_t *)lfg_dev_slot(device, LF_DS_RENDER0 + 0, (size_t)n_recs * sizeof(lf_rrecord_t));
+        d_items = (lf_ritem_t *)lfg_dev_slot(device, LF_DS_RENDER0 + 1, (size_t)n_items * sizeof(lf_ritem_t) + 64);
+        if (!d_recs || !d_items) return LF_ERR_NOMEM;
+        if (n_dev_recs) {
+            HIPCHK(hipMemcpyAsync(d_recs, d_recs_dev, (size_t)n_dev_recs * sizeof(lf_rrecord_t), hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(d_items, d_items_dev, (size_t)n_dev_items * sizeof(lf_ritem_t), hipMemcpyDeviceToDevice, s));
+        }
+    }
     uint32_t *d_lens = (uint32_t *)lfg_dev_slot(device, LF_DS_RENDER0 + 2, (size_t)n_recs * 8);
     uint64_t *d_offs = (uint64_t *)lfg_dev_slot(device, LF_DS_RENDER0 + 3, (size_t)n_recs * 16 + 16);
     uint64_t *h_offs = (uint64_t *)lfg_pin_slot(LF_PS_RENDER0 + 0, (size_t)n_recs * 16 + 16);
@@ -229,8 +243,10 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_recs, const lf_rrecor
     const unsigned char *d_reads = (const unsigned char *)lfg_dev_slot(device, LF_DS_SEED0 + 0, 0);      /* read batch left in HBM by lfg_seed */
     hipEvent_t e0 = (hipEvent_t)lfg_lane_event(device, 32), e1 = (hipEvent_t)lfg_lane_event(device, 33);
     if (!e0 || !e1) return LF_ERR_HIP;
-    HIPCHK(hipMemcpyAsync(d_recs, recs, (size_t)n_recs * sizeof(lf_rrecord_t), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_items, items, (size_t)n_items * sizeof(lf_ritem_t), hipMemcpyHostToDevice, s));
+    if (n_host_recs) {       /* the caller has rebased the host records' item0 by n_dev_items */
+        HIPCHK(hipMemcpyAsync(d_recs + n_dev_recs, recs, (size_t)n_host_recs * sizeof(lf_rrecord_t), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_items + n_dev_items, items, (size_t)n_host_items * sizeof(lf_ritem_t), hipMemcpyHostToDevice, s));
+    }
     HIPCHK(hipEventRecord(e0, s));
     hipLaunchKernelGGL(lf_render_kernel<false>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac, d_reads,
                        d_lens, (const uint64_t *)nullptr, (char *)nullptr);

@@ -399,7 +399,7 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
         static bool attr_set[16] = { false };
         if (!attr_set[dv]) { HIPCHK(hipFuncSetAttribute((const void *)lf_vote_hash_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8 + LF_VOTE_FILTER_WORDS * 4)); attr_set[dv] = true; }
         unsigned long long *d_dbg = nullptr;
-        if (getenv("LF_VOTE_DEBUG")) { d_dbg = (unsigned long long *)VSLOT(8, 256); if (d_dbg) HIPCHK(hipMemsetAsync(d_dbg, 0, 128, s)); }
+        if (getenv("LF_VOTE_DEBUG")) { d_dbg = (unsigned long long *)VSLOT(20, 256); if (d_dbg) HIPCHK(hipMemsetAsync(d_dbg, 0, 128, s)); }
         uint64_t lo = 0;
         for (int k = 0; k < 3 && lo <= v_max_lds; k++) {
             uint64_t hi = (uint64_t)caps[k] * 2 / 3; if (hi > v_max_lds) hi = v_max_lds;
@@ -605,6 +605,7 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     out->chain_off[Q] = C; out->req0[R] = n_req;
     out->n_tie_req = have_ties ? h_small[8] : 0;
     out->n_chain_seeds = C;
+    out->d_chain_seeds = d_cseeds; out->d_chain_off = d_coff; out->d_chain_len = d_clen; out->d_ctg = d_ctg;
     HIPCHK(hipEventElapsedTime(&out->ms_vote, e0, e1));
     HIPCHK(hipEventElapsedTime(&out->ms_chain, e1, e2));
 #undef VSLOT

@@ -2,7 +2,7 @@
 # collect.sh <tag> -- run on the GPU box from the repo root: bench + rocprofv3 passes for config C2, summaries into
 # gpurun_out/<tag>/ (copy what you want judged into profiles/<tag>/).  rocprofv3 gets the program itself after `--`.
 set -u
-TAG=${1:-r01_c2}
+TAG=${1:-r02_c2}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
@@ -14,8 +14,8 @@ python3 profiles/tools/trim_stats.py $(ls /tmp/lfp_kt/*/*kernel_stats.csv | head
 python3 profiles/tools/busy.py $(ls /tmp/lfp_kt/*/*kernel_trace.csv | head -1) --last-step 8 > $OUT/gpu_busy_last_step.txt
 cp $(ls /tmp/lfp_kt/*/*agent_info.csv | head -1) $OUT/agent_info.csv 2>/dev/null
 LF_SERIAL_CLASSES=1 LF_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lfp_ser -- $B --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_serialized.json 2> /tmp/lfp_ser.err
-python3 profiles/tools/trim_stats.py $(ls /tmp/lfp_ser/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_one_chunk_at_a_time_classes_serialized.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/lfp_f -- $B --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_under_pmc_fetch.json 2> /tmp/lfp_f.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/lfp_w -- $B --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_under_pmc_write.json 2> /tmp/lfp_w.err
+python3 profiles/tools/trim_stats.py $(ls /tmp/lfp_ser/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_serialized.csv
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/lfp_f -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-exclusive > $OUT/bench_under_pmc_fetch.json 2> /tmp/lfp_f.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/lfp_w -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-exclusive > $OUT/bench_under_pmc_write.json 2> /tmp/lfp_w.err
 python3 profiles/tools/summarize_pmc.py $OUT/pmc_fetch_write_summary.json $(ls /tmp/lfp_f/*/*counter_collection.csv | head -1) $(ls /tmp/lfp_w/*/*counter_collection.csv | head -1)
 ls -la $OUT
