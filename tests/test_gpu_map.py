@@ -302,3 +302,20 @@ def test_vote_tables_in_global_memory(lf, golden_reads, monkeypatch, cfg, lds_ma
     sam, st = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
     exp = golden_sam(cfg)
     assert sam == exp, first_diff(sam, exp)
+
+
+@pytest.mark.parametrize("cfg", ["default", "clasp_n30", "k12c300m20"])
+def test_sam_host_walk_crosscheck(lf, golden_reads, monkeypatch, cfg):
+    """LF_HOST_WALK=1 replays every chain with the host walk of lf_pipeline.c instead of lf_walk.hip (which keeps the
+    common path of alignChain_edlib on the device): both must print the reference's records, and the device path must
+    really have planned the alignments (no descriptors uploaded: n_edlib_problems is the same, counted on the device)"""
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    exp = golden_sam(cfg)
+    sam_d, st_d = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
+    assert sam_d == exp, first_diff(sam_d, exp)
+    monkeypatch.setenv("LF_HOST_WALK", "1")
+    sam_h, st_h = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
+    assert sam_h == exp, first_diff(sam_h, exp)
+    # the device plans every chain's common path; chains with a clip / split trigger are planned again by the host replay
+    assert st_d["n_edlib_problems"] >= st_h["n_edlib_problems"] > 0
