@@ -348,6 +348,7 @@ def main():
         saved = {k: os.environ.get(k) for k in ("LF_LANES", "LF_SERIAL_CLASSES")}
         os.environ["LF_LANES"] = "1"; os.environ["LF_SERIAL_CLASSES"] = "1"
         try:
+            step(False)                      # the one-chunk-at-a-time mode uses larger chunks: let the grow-only buffers settle
             _, excl = step(False)
         finally:
             for k, v in saved.items():

@@ -400,13 +400,49 @@ static void rc_tab_init(void)
     g_rc_tab['a'] = 't'; g_rc_tab['c'] = 'g'; g_rc_tab['g'] = 'c'; g_rc_tab['t'] = 'a';
 }
 static inline char rc_char(char c) { return g_rc_tab[(unsigned char)c]; }
-static void revcomp_into(const char *s, char *out, uint32_t len) { for (uint32_t i = 0; i < len; i++) out[i] = rc_char(s[len - 1 - i]); out[len] = 0; }
+static void rc_copy(char *d, const char *s, size_t l);
+static void revcomp_into(const char *s, char *out, uint32_t len) { rc_copy(out, s, len); out[len] = 0; }
 /* reverse complement / reversed copy written straight into the SAM text (src/LordFAST.cpp:501-502 build both strings
  * for every read; only records on the reverse strand ever print them) */
+/* reverse complement of l bytes: 16 at a time with two nibble-indexed byte shuffles where the CPU has SSSE3 (every x86-64
+ * server of the last 15 years).  A, C, G, T and their lower-case forms differ from every other letter in (low nibble, bit 6,
+ * bit 5): the complement comes out of one table indexed by the low nibble, 'N' everywhere else. */
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("ssse3"))) static void rc_copy_ssse3(char *d, const char *s, size_t l)
+{
+    /* low nibble -> complement (upper case) for A=0x41 C=0x43 G=0x47 T=0x54: nibbles 1, 3, 7, 4 */
+    const __m128i tab = _mm_setr_epi8('N', 'T', 'N', 'G', 'A', 'N', 'N', 'C', 'N', 'N', 'N', 'N', 'N', 'N', 'N', 'N');
+    /* the byte a nibble must come from to be a base: 1 -> 'A', 3 -> 'C', 7 -> 'G', 4 -> 'T' (upper case) */
+    const __m128i src = _mm_setr_epi8(0x20, 'A', 0x20, 'C', 'T', 0x20, 0x20, 'G', 0x20, 0x20, 0x20, 0x20, 0x20, 0x20, 0x20, 0x20);   /* 0x20: no upper-cased byte equals it */
+    const __m128i rev = _mm_setr_epi8(15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0);
+    const __m128i lo4 = _mm_set1_epi8(0x0f), caseb = _mm_set1_epi8(0x20), up = _mm_set1_epi8((char)0xDF), enn = _mm_set1_epi8('N');
+    size_t i = 0;
+    for (; i + 16 <= l; i += 16) {
+        __m128i x = _mm_loadu_si128((const __m128i *)(s + l - 16 - i));
+        x = _mm_shuffle_epi8(x, rev);
+        const __m128i cs = _mm_and_si128(x, caseb), xu = _mm_and_si128(x, up), nib = _mm_and_si128(x, lo4);
+        const __m128i ok = _mm_cmpeq_epi8(_mm_shuffle_epi8(src, nib), xu);           /* really one of ACGT / acgt */
+        __m128i c = _mm_or_si128(_mm_shuffle_epi8(tab, nib), cs);                       /* complement, case kept */
+        c = _mm_or_si128(_mm_and_si128(ok, c), _mm_andnot_si128(ok, enn));
+        _mm_storeu_si128((__m128i *)(d + i), c);
+    }
+    for (; i < l; i++) d[i] = rc_char(s[l - 1 - i]);
+}
+#endif
+static void rc_copy(char *d, const char *s, size_t l)
+{
+#if defined(__x86_64__)
+    static int have = -1;
+    if (have < 0) have = __builtin_cpu_supports("ssse3") ? 1 : 0;
+    if (have) { rc_copy_ssse3(d, s, l); return; }
+#endif
+    for (size_t i = 0; i < l; i++) d[i] = rc_char(s[l - 1 - i]);
+}
 static void str_put_rc(str_t *b, const char *s, size_t l)
 {
     str_room(b, l);
-    if (b->mode != 1) { char *d = b->s + b->n; for (size_t i = 0; i < l; i++) d[i] = rc_char(s[l - 1 - i]); }
+    if (b->mode != 1) rc_copy(b->s + b->n, s, l);
     b->n += l;
     if (b->mode == 0 || b->mode == 3) b->s[b->n] = 0;
 }
@@ -2106,17 +2142,19 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     pthread_once(&g_rc_once, rc_tab_init);
     /* chunks in flight: the host phases of one overlap the GPU phases of the others */
     /* drivers sleep while they wait for the GPU (blocking waits), so small thread budgets still get several chunks in flight */
-    int n_lanes = nt >= 12 ? 8 : (nt >= 4 ? 4 : nt);
-    if (getenv("LF_LANES")) { n_lanes = atoi(getenv("LF_LANES")); if (n_lanes < 1) n_lanes = 1; if (n_lanes > LF_MAX_LANES) n_lanes = LF_MAX_LANES; if (n_lanes > nt) n_lanes = nt; }
+    /* a lane driver spends most of a chunk blocked on the GPU (the chain walk runs on the device now), so the number of
+     * chunks in flight is not tied to the thread budget any more: eight from four threads up */
+    int n_lanes = nt >= 4 ? 8 : nt;
+    if (getenv("LF_LANES")) { n_lanes = atoi(getenv("LF_LANES")); if (n_lanes < 1) n_lanes = 1; if (n_lanes > LF_MAX_LANES) n_lanes = LF_MAX_LANES; }
     if (getenv("LF_ONE_LANE")) n_lanes = 1;
     if (n_ix > 1) {
         /* several devices: LF_LANES / the default is per device (capped by LF_MAX_LANES and the thread budget); every
          * device gets at least one lane.  Lanes pull chunks from one shared counter, so the devices balance themselves. */
-        int per = n_lanes; if (per * n_ix > LF_MAX_LANES) per = LF_MAX_LANES / n_ix; if (per * n_ix > nt && nt >= n_ix) per = nt / n_ix; if (per < 1) per = 1;
+        int per = n_lanes; if (per * n_ix > LF_MAX_LANES) per = LF_MAX_LANES / n_ix; if (per < 1) per = 1;
         n_lanes = per * n_ix;
-        if (nt < n_lanes) nt = n_lanes;
     }
-    const int nw = nt - n_lanes;                       /* pool workers; the lane drivers work too */
+    int nw = nt - n_lanes;                             /* pool workers; the lane drivers work too */
+    if (nw < nt / 2) nw = nt / 2;                      /* few threads, many (mostly sleeping) drivers: keep half the budget as workers */
     pool_ensure(nw);
 
     batch_t B; memset(&B, 0, sizeof B);
