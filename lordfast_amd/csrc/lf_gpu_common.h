@@ -26,6 +26,7 @@ struct lf_dev_index {
 struct lf_dev_state {           /* host-side owner of the device allocations */
     lf_dev_index view;
     void *bwt, *sa_sampled, *sa_full, *cache, *cache14, *pac;
+    void *ctg_names = nullptr, *ctg_name_off = nullptr;      /* contig names for lf_sam.hip (uploaded on first use) */
     hipStream_t stream;
 };
 

@@ -90,12 +90,12 @@ void *lfg_lane_event(int device, int which);    /* persistent hipEvent_t (timing
 /* slot ids */
 enum { LF_DS_SEED0 = 0 /* ..15 */, LF_DS_CHAIN0 = 16 /* ..23 */, LF_DS_ALN0 = 24 /* ..47 */, LF_DS_KSW0 = 48 /* ..55 */,
        LF_DS_RND0 = 56 /* ..87: 2 per extension round (ops, spare) */, LF_DS_RENDER0 = 88 /* ..95 */, LF_DS_VOTE0 = 96 /* ..127 */,
-       LF_DS_WALK0 = 128 /* ..147 */ };
+       LF_DS_WALK0 = 128 /* ..147 */, LF_DS_SAM0 = 148 /* ..157 */ };
 #define LF_MAX_ED_ROUNDS 16
 enum { LF_PS_READS = 0, LF_PS_READOFF = 1, LF_PS_HITS_T = 2, LF_PS_HITS_Q = 3, LF_PS_HITS_S = 4, LF_PS_HITS_OFF = 5,
        LF_PS_CHAIN_SEEDS = 6, LF_PS_CHAIN_IDX = 7, LF_PS_ALN_Q = 8, LF_PS_ALN_T = 9, LF_PS_ALN_PROB = 10 /* ..16 */,
        LF_PS_ROUND0 = 20 /* 4 per round: ed, end, len, ops ; up to 16 rounds */, LF_PS_RENDER0 = 84 /* ..91 */, LF_PS_VOTE0 = 92 /* ..107 */,
-       LF_PS_WALK0 = 108 /* ..111 */, LF_PS_RENDER1 = 112 /* ..115: text of the host-planned records */ };
+       LF_PS_WALK0 = 108 /* ..111 */, LF_PS_RENDER1 = 112 /* ..115 */, LF_PS_SAM0 = 116 /* ..123 */ };
 
 /* alignment request as a DESCRIPTOR into HBM-resident data: query = the read batch uploaded by the seed stage,
  * target = the 2-bit reference.  Element i = base[start +/- i], optionally complemented (flags LF_F_*). */
@@ -104,6 +104,7 @@ typedef struct { int64_t qstart, tstart; uint32_t n, m; uint8_t flags, mode, pad
 int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_desc_t *d, const uint64_t *ops_off, uint64_t ops_total,
                    int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, int ops_slot, void **ops_dev, void **desc_dev, float *ms);
 
+typedef struct { const void *d_text, *d_offs, *d_lens; } lfg_rtext_t;       /* rendered text on the device: offsets / lengths (incl. NUL) 2 per record */
 /* ---- lf_render.hip: CIGAR / MD text from the paths in HBM ---- */
 enum { LF_RI_RUN_M = 0, LF_RI_RUN_I = 1, LF_RI_OPS_FWD = 2, LF_RI_OPS_FWD_TRC = 3, LF_RI_OPS_REV = 4, LF_RI_DEL = 5 };
 typedef struct {            /* one piece of a record, in output order (32 bytes) */
@@ -118,7 +119,8 @@ typedef struct { uint32_t item0, nitems; } lf_rrecord_t;
 /* records 0 .. n_dev_recs-1 and their items are already on the device (lfg_walk_emit: d_recs / d_items), the host's follow */
 int lfg_render(const struct lf_index *ix, int n_dev_recs, const void *d_recs_dev, uint64_t n_dev_items, const void *d_items_dev,
                int n_recs, const lf_rrecord_t *recs, uint64_t n_items, const lf_ritem_t *items,
-               const void *const *round_ops, const void *const *round_desc, char **text_out, uint64_t **offs_out, uint64_t *text_bytes, float *ms);
+               const void *const *round_ops, const void *const *round_desc, char **text_out, uint64_t **offs_out, uint64_t *text_bytes, float *ms,
+               lfg_rtext_t *dev_text /* != NULL: the text stays on the device (only offsets / lengths come back in *offs_out / *lens_out) */, uint32_t **lens_out);
 /* ---- lf_walk.hip: the common path of alignChain_edlib on the device ---- */
 typedef struct { uint32_t req, read, chain_len; uint8_t is_rev, pad[3]; } lf_wjob_t;      /* one kept candidate window: chain request, read (index in the seed batch) */
 typedef struct { uint32_t pos, posEnd, qStart, qEnd; int32_t nm; uint32_t rare, pad[2]; } lf_wrec_t;   /* SAM record fields of a job; rare: replay it on the host */
@@ -131,6 +133,22 @@ int lfg_walk_emit(const struct lf_index *ix, const lfg_vc_t *vc, int lazy, lfg_w
 /* alignments of device-resident descriptors (lfg_walk_plan); results stay on the device */
 int lfg_edlib_desc_dev(const struct lf_index *ix, int n, const void *d_desc, const void *d_opsoff, uint64_t ops_total, int ops_slot,
                        void **ops_dev, void **ed_dev, void **end_dev, void **len_dev, float *ms);
+/* ---- lf_sam.hip: SAM lines assembled on the device ---- */
+enum { LF_SL_MAPPED = 0, LF_SL_UNMAPPED = 1, LF_SL_LITERAL = 2 };
+typedef struct {
+    uint32_t name_off; uint16_t name_len, flag;     /* name in the chunk's name blob; SAM flag as printed */
+    uint32_t read;                                  /* index in the resident read batch (SEQ / QUAL source) */
+    int32_t  rname;                                 /* contig id */
+    uint32_t pos1;                                  /* 1-based position */
+    int32_t  mapq, as; uint32_t nm;                 /* as printed (MAPQ clamped at 0, NM absolute) */
+    uint32_t rec;                                   /* record of the rendered CIGAR / MD text */
+    uint32_t sa_off, sa_len;                        /* SA:Z value in the side blob (0: none); LITERAL: the whole line */
+    uint8_t  kind, is_fq, pad[2];
+} lf_samline_t;                                     /* 48 bytes */
+int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, int n_lines, const lf_samline_t *lines,
+                  const char *names, uint64_t names_bytes, const char *blob, uint64_t blob_bytes,
+                  const char *quals, uint64_t quals_bytes, const lfg_rtext_t *rt, uint64_t *total_out);
+int lfg_sam_fetch(const struct lf_index *ix, char *dst, uint64_t total);
 int lfg_fetch(int device, void *dst, const void *src_dev, size_t bytes);
 int lfg_upload(int device, void *dst_dev, const void *src, size_t bytes);
 #define LF_F_QREV  1u

@@ -250,6 +250,7 @@ typedef struct ctx {
     int host_cigar;                 /* LF_HOST_CIGAR=1: build CIGAR / MD on the host from copied-back paths (cross-check) */
     char *rtext; uint64_t *roffs; int *rrbase;      /* rendered text, per-record offsets, first record of each worker */
     int n_dev_recs; uint64_t n_dev_items; void *d_dev_recs, *d_dev_items;       /* the device-planned recipe (lf_walk.hip): records 0 .. n_dev_recs-1 */
+    int dev_sam; lfg_rtext_t rtext_dev; uint32_t *rlens; uint64_t sam_total;       /* SAM lines assembled on the device (lf_sam.hip): text size of the chunk */
     /* output assembly */
     char *out_base; uint64_t *out_off;
     const char *const *len_seqs; uint32_t *len_out;
@@ -1412,6 +1413,106 @@ static void print_sam_entry(ctx_t *cx, rd_t *r, int num)
     }
 }
 
+/* ---- the same decisions as print_sam_entry, as 48-byte line descriptors for lf_sam.hip (which writes the text) ---- */
+typedef struct {
+    lf_samline_t *ln; int n, cap;
+    char *blob; uint64_t nb, capb;          /* SA:Z values and literal lines */
+    char *names; uint64_t nn, capn;
+} linevec_t;
+static lf_samline_t *lv_line(linevec_t *v)
+{
+    if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 8192; v->ln = (lf_samline_t *)realloc(v->ln, (size_t)v->cap * sizeof(lf_samline_t)); }
+    lf_samline_t *l = &v->ln[v->n++]; memset(l, 0, sizeof *l);
+    return l;
+}
+static uint64_t lv_blob(linevec_t *v, const char *s, size_t n)
+{
+    if (v->nb + n + 1 > v->capb) { v->capb = (v->nb + n + 1) * 2 + 4096; v->blob = (char *)realloc(v->blob, v->capb); }
+    memcpy(v->blob + v->nb, s, n); v->nb += n;
+    return v->nb - n;
+}
+static size_t rec_index(const ctx_t *cx, const sam_t *s) { return s->rtid == -2 ? (size_t)s->rec : (size_t)cx->rrbase[s->rtid] + (size_t)s->rec; }
+/* CIGAR of a record as a C string (SA:Z values of split alignments need a few of them on the host) */
+static char *rec_cigar_host(ctx_t *cx, const sam_t *s, arena_t *ar)
+{
+    if (s->cigar) return s->cigar;
+    const size_t g = rec_index(cx, s);
+    const uint32_t len = cx->rlens[2 * g];                                  /* incl. NUL */
+    char *buf = (char *)ar_alloc(ar, (size_t)len + 1);
+    if (lfg_fetch(cx->ix->device, buf, (const char *)cx->rtext_dev.d_text + cx->roffs[2 * g], len) != LF_OK) buf[0] = 0;
+    buf[len ? len - 1 : 0] = 0;
+    return buf;
+}
+static int rid_of_record(const struct lf_index *ix, const sam_t *s, uint32_t *cbeg)
+{
+    const int rid = pos2rid(ix, (int64_t)(((uint64_t)s->pos + (uint64_t)s->posEnd) >> 1));     /* bwt_get_intv_info: contig of the midpoint */
+    *cbeg = (uint32_t)((uint64_t)s->pos - (uint64_t)ix->contigs[rid].offset);
+    return rid;
+}
+static void line_mapped(ctx_t *cx, linevec_t *v, const rd_t *r, uint32_t name_off, const sam_t *s, int flag, int rid, uint32_t rstart, int mapq, uint32_t sa_off, uint32_t sa_len)
+{
+    lf_samline_t *l = lv_line(v);
+    l->kind = LF_SL_MAPPED; l->name_off = name_off; l->name_len = (uint16_t)strlen(r->name); l->flag = (uint16_t)flag;
+    l->read = (uint32_t)r->seed_idx; l->rname = rid; l->pos1 = rstart + 1; l->mapq = mapq >= 0 ? mapq : 0;
+    l->as = s->alnScore; l->nm = (uint32_t)abs(s->nmCount); l->rec = (uint32_t)rec_index(cx, s);
+    l->sa_off = sa_off; l->sa_len = sa_len; l->is_fq = (uint8_t)r->isFq;
+}
+static void lines_sam_entry(ctx_t *cx, linevec_t *v, rd_t *r, uint32_t name_off, int num, arena_t *ar)
+{   /* src/LordFAST.cpp:318-459; the arithmetic is print_sam_entry's, expression by expression */
+    const samlist_t *mp = r->maps;
+    const int readLen = (int)r->len, maxWin = cx->p->max_map;
+    const double bestEdit = (num > 0 ? (double)(-1 * mp[0].totalScore) / readLen : 1);
+    const double mapqPortion = 50.0 / (maxWin - 1);
+    int x1 = 0, x2 = 0;
+    for (int i = 0; i < num; i++) if (mp[i].n > 0) { x1++; if ((double)(-1 * mp[i].totalScore) / readLen * 0.95 < bestEdit) x2++; }
+    const double mapq = (x2 > 1 ? 2.1 : (maxWin - x1) * mapqPortion);
+    int32_t mapq_int;
+    for (int i = 0; i < num; i++) {
+        if (i == 0) {
+            if (mp[0].n > 0) {
+                const double e0 = (double)(-1 * mp[0].totalScore) / readLen;
+                if (num == 1 || (num > 1 && e0 < 0.15 && e0 < 0.95 * (double)(-1 * mp[1].totalScore) / readLen)) mapq_int = 60;
+                else mapq_int = (int32_t)(mapq + 5 * (0.2 - e0) / 0.2);
+                const int ns = mp[0].n;
+                if (ns == 1) {
+                    uint32_t rs; const int rid = rid_of_record(cx->ix, &mp[0].v[0], &rs);
+                    line_mapped(cx, v, r, name_off, &mp[0].v[0], mp[0].v[0].flag, rid, rs, mapq_int, 0, 0);
+                } else {
+                    /* split alignment: every record carries the others in SA:Z (rname,pos,strand,CIGAR,mapQ,NM;) (:358-373) */
+                    str_t *sa = (str_t *)calloc((size_t)ns, sizeof(str_t));
+                    int *rid = (int *)calloc((size_t)ns, sizeof(int)); uint32_t *rs = (uint32_t *)calloc((size_t)ns, sizeof(uint32_t));
+                    for (int j = 0; j < ns; j++) {
+                        const sam_t *s = &mp[0].v[j];
+                        rid[j] = rid_of_record(cx->ix, s, &rs[j]);
+                        str_init(&sa[j]);
+                        str_puts(&sa[j], cx->ix->contigs[rid[j]].name); str_putc(&sa[j], ','); str_putu(&sa[j], rs[j] + 1); str_putc(&sa[j], ',');
+                        str_puts(&sa[j], (s->flag & 16) ? "-," : "+,"); str_puts(&sa[j], rec_cigar_host(cx, s, ar)); str_putc(&sa[j], ',');
+                        str_puti(&sa[j], mapq_int); str_putc(&sa[j], ','); str_puti(&sa[j], abs(s->nmCount)); str_putc(&sa[j], ';');
+                    }
+                    for (int j = 0; j < ns; j++) {
+                        const sam_t *s = &mp[0].v[j];
+                        uint64_t o0 = v->nb; uint32_t ln = 0;
+                        for (int z = 0; z < ns; z++) if (z != j) { const uint64_t o = lv_blob(v, sa[z].s, sa[z].n); if (!ln) o0 = o; ln += (uint32_t)sa[z].n; }
+                        line_mapped(cx, v, r, name_off, s, j > 0 ? (s->flag | 2048) : s->flag, rid[j], rs[j], mapq_int, (uint32_t)o0, ln);
+                    }
+                    for (int j = 0; j < ns; j++) free(sa[j].s);
+                    free(sa); free(rid); free(rs);
+                }
+            } else {
+                lf_samline_t *l = lv_line(v);
+                l->kind = LF_SL_UNMAPPED; l->name_off = name_off; l->name_len = (uint16_t)strlen(r->name); l->read = (uint32_t)r->seed_idx; l->is_fq = (uint8_t)r->isFq;
+            }
+        } else if (mp[i].n > 0) {
+            mapq_int = (int32_t)(mapq + 5 * (0.2 - (double)(-1 * mp[i].totalScore) / readLen) / 0.2);
+            for (int j = 0; j < mp[i].n; j++) {
+                const sam_t *s = &mp[i].v[j];
+                uint32_t rs; const int rid = rid_of_record(cx->ix, s, &rs);
+                line_mapped(cx, v, r, name_off, s, s->flag | 256, rid, rs, mapq_int, 0, 0);
+            }
+        }
+    }
+}
+
 /* ================================================================ phases driven by lf_map_batch */
 static void phase_prepare(ctx_t *cx, int tid, int ri)
 {
@@ -1911,12 +2012,13 @@ extend:
             }
             float ms = 0; uint64_t tbytes = 0;
             tmark(cx, "recipe");
-            rc = lfg_render(cx->ix, cx->n_dev_recs, cx->d_dev_recs, cx->n_dev_items, cx->d_dev_items, n_recs, recs, n_items, items, round_ops, round_desc, &cx->rtext, &cx->roffs, &tbytes, &ms);
+            rc = lfg_render(cx->ix, cx->n_dev_recs, cx->d_dev_recs, cx->n_dev_items, cx->d_dev_items, n_recs, recs, n_items, items, round_ops, round_desc, &cx->rtext, &cx->roffs, &tbytes, &ms,
+                            cx->dev_sam ? &cx->rtext_dev : NULL, &cx->rlens);
             tmark(cx, "RENDER");
             if (timing) fprintf(stderr, "[lf] render: %d records, %llu pieces, %.1f MB text, kernels %.1f ms, total %.1f ms\n", n_recs, (unsigned long long)n_items, tbytes / 1e6, ms, now_ms() - t0);
             if (rc != LF_OK) { free(ibase); return rc; }
             st->ms_k_render += ms; st->render_bytes += tbytes; st->render_launches += 1;
-            parallel_for(cx, n, phase_bind_text);
+            if (!cx->dev_sam) parallel_for(cx, n, phase_bind_text);
         }
         free(ibase);
     }
@@ -1925,7 +2027,58 @@ extend:
     /* ---- E: SAM (score + count here; the text is written by lf_map_batch straight into the output buffer) ---- */
     parallel_for(cx, n, phase_sam_score);
     cx->out_base = NULL;
-    parallel_for(cx, n, phase_sam_print);
+    if (cx->dev_sam) {
+        /* SAM lines on the device: the host only says what is printed (48 bytes per line) */
+        linevec_t V; memset(&V, 0, sizeof V);
+        arena_t *ar = &cx->arena[0];
+        int any_fq = 0;
+        for (int i = 0; i < n; i++) {
+            rd_t *r = &cx->reads[i];
+            const size_t nl = strlen(r->name);
+            if (V.nn + nl + 1 > V.capn) { V.capn = (V.nn + nl + 1) * 2 + 65536; V.names = (char *)realloc(V.names, V.capn); }
+            memcpy(V.names + V.nn, r->name, nl);
+            const uint32_t name_off = (uint32_t)V.nn; V.nn += nl;
+            if (r->mode == 0) {                 /* shorter than -l: not in the resident batch; the whole line is literal text */
+                str_init(&r->out); print_sam_entry(cx, r, 1);
+                lf_samline_t *l = lv_line(&V); l->kind = LF_SL_LITERAL; l->sa_off = (uint32_t)lv_blob(&V, r->out.s, r->out.n); l->sa_len = (uint32_t)r->out.n;
+                free(r->out.s); memset(&r->out, 0, sizeof r->out);
+                continue;
+            }
+            any_fq |= r->isFq;
+            const int num = r->mode == 3 ? r->nWins : 1;
+            int host_strings = 0;                /* a record whose CIGAR / MD were built per base on the host (the reference's misaligned-MD branch) */
+            if (r->mode >= 2) for (int w = 0; w < num; w++) for (int j = 0; j < r->maps[w].n; j++) host_strings |= r->maps[w].v[j].rec < 0;
+            if (host_strings) {
+                /* rare: print the whole entry on the host (its other records' text is fetched from the device) */
+                for (int w = 0; w < num; w++) for (int j = 0; j < r->maps[w].n; j++) {
+                    sam_t *sr = &r->maps[w].v[j];
+                    if (sr->rec < 0) continue;
+                    const size_t g = rec_index(cx, sr);
+                    sr->cigar = rec_cigar_host(cx, sr, ar);
+                    const uint32_t ml = cx->rlens[2 * g + 1];
+                    sr->md = (char *)ar_alloc(ar, (size_t)ml + 1);
+                    if (lfg_fetch(cx->ix->device, sr->md, (const char *)cx->rtext_dev.d_text + cx->roffs[2 * g + 1], ml) != LF_OK) sr->md[0] = 0;
+                    sr->md[ml ? ml - 1 : 0] = 0;
+                }
+                str_init(&r->out); print_sam_entry(cx, r, num);
+                lf_samline_t *l = lv_line(&V); l->kind = LF_SL_LITERAL; l->sa_off = (uint32_t)lv_blob(&V, r->out.s, r->out.n); l->sa_len = (uint32_t)r->out.n;
+                free(r->out.s); memset(&r->out, 0, sizeof r->out);
+                continue;
+            }
+            lines_sam_entry(cx, &V, r, name_off, num, ar);
+        }
+        if (V.nb >= 0xffffffffull || V.nn >= 0xffffffffull) { free(V.ln); free(V.blob); free(V.names); lf_set_error("lf_map_batch: chunk too large for the SAM writer"); return LF_ERR_ARG; }
+        char *qcat = NULL; uint64_t qbytes = 0;
+        if (any_fq) {                            /* FASTQ: the qualities in the layout of the resident read batch */
+            for (int i = 0; i < n; i++) if ((int)cx->reads[i].len >= cx->p->min_read_len) qbytes += cx->reads[i].len;
+            qcat = (char *)malloc(qbytes + 1);
+            uint64_t o = 0;
+            for (int i = 0; i < n; i++) { const rd_t *r = &cx->reads[i]; if ((int)r->len < cx->p->min_read_len) continue; if (r->isFq) memcpy(qcat + o, r->qual, r->len); else memset(qcat + o, '*', r->len); o += r->len; }
+        }
+        rc = lfg_sam_build(cx->ix, cx->p, V.n, V.ln, V.names, V.nn, V.blob, V.nb, qcat, qbytes, &cx->rtext_dev, &cx->sam_total);
+        free(V.ln); free(V.blob); free(V.names); free(qcat);
+        if (rc != LF_OK) return rc;
+    } else parallel_for(cx, n, phase_sam_print);
     t1 = now_ms(); st->ms_sam += t1 - t0; tstage[5] = t1 - t0;
     tmark(cx, "samcount");
     tmark_dump(cx, t_begin);
@@ -2018,6 +2171,7 @@ static void *lane_main(void *arg_)
         ctx_t cx; memset(&cx, 0, sizeof cx);
         cx.ix = B->ixs[lane % B->n_ix]; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane]; cx.host_cigar = B->host_cigar; cx.host_vote = B->host_vote; cx.lazy = !B->host_cigar && !getenv("LF_NO_LAZY");
         cx.max_chunk_hits = max_hits;
+        cx.dev_sam = !B->host_cigar && !B->host_vote && !getenv("LF_HOST_SAM");
         cx.n_reads = C->i1 - C->i0;
         cx.reads = (rd_t *)calloc((size_t)cx.n_reads, sizeof(rd_t));
         uint64_t chunk_bases = 0;
@@ -2051,7 +2205,8 @@ static void *lane_main(void *arg_)
         uint64_t tot = 0, *ooff = NULL;
         if (rc == LF_OK) {
             ooff = (uint64_t *)malloc(((size_t)cx.n_reads + 1) * 8);
-            for (int i = 0; i < cx.n_reads; i++) { ooff[i] = tot; tot += cx.reads[i].out.n; }
+            if (cx.dev_sam) tot = cx.sam_total;
+            else for (int i = 0; i < cx.n_reads; i++) { ooff[i] = tot; tot += cx.reads[i].out.n; }
         } else { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = rc; }
         /* publish this chunk's size, then wait for the sizes of all chunks of earlier reads: base offset of our text.
          * (entries can be added while we wait: rescan after every wake-up) */
@@ -2084,8 +2239,13 @@ static void *lane_main(void *arg_)
                 pthread_rwlock_rdlock(&B->grow);
             }
             if (B->rc == LF_OK) {
-                cx.out_base = B->all.s + base; cx.out_off = ooff;
-                parallel_for(&cx, cx.n_reads, phase_sam_print);
+                if (cx.dev_sam) {               /* one D2H copy of the chunk's text straight into its place */
+                    const int frc = lfg_sam_fetch(cx.ix, B->all.s + base, tot);
+                    if (frc != LF_OK) { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = frc; }
+                } else {
+                    cx.out_base = B->all.s + base; cx.out_off = ooff;
+                    parallel_for(&cx, cx.n_reads, phase_sam_print);
+                }
             }
             pthread_rwlock_unlock(&B->grow);
             st->ms_sam += now_ms() - tch;

@@ -94,8 +94,28 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
         c_ch = ch; c_run = n;
     };
 
+    /* The items of a record form a chain of dependent loads (item -> its ops -> its descriptor -> bases): the next item, the
+     * first tile of its ops and its descriptor are fetched while the current item is processed, so that a record costs one
+     * round trip per item instead of three or four (a record has ~240 items of ~100 ops). */
+    auto ops_ptr = [&](const lf_ritem_t &X) -> const uint8_t * { return R.ops[X.round] + X.ops_begin; };
+    auto first_tile = [&](const lf_ritem_t &X) -> uint8_t {
+        if (X.n == 0 || X.kind < LF_RI_OPS_FWD || X.kind > LF_RI_OPS_REV || (uint32_t)lane >= X.n) return 0;
+        return ops_ptr(X)[X.kind == LF_RI_OPS_REV ? X.n - 1 - (uint32_t)lane : (uint32_t)lane];
+    };
+    auto desc_of = [&](const lf_ritem_t &X) -> lf_aln_desc_t {
+        lf_aln_desc_t d; d.qstart = 0; d.tstart = 0; d.flags = 0; d.n = d.m = 0; d.mode = 0;
+        if (!WRITE && X.n != 0 && X.kind >= LF_RI_OPS_FWD && X.kind <= LF_RI_OPS_REV && X.lazy) d = R.desc[X.round][X.slot];
+        return d;
+    };
+    lf_ritem_t Inext; memset(&Inext, 0, sizeof Inext);
+    if (rr.nitems) Inext = items[rr.item0];
+    uint8_t op_next = first_tile(Inext);
+    lf_aln_desc_t dsc_next = desc_of(Inext);
     for (uint32_t it = 0; it < rr.nitems; it++) {
-        const lf_ritem_t I = items[rr.item0 + it];
+        const lf_ritem_t I = Inext;
+        const uint8_t op_first = op_next;
+        const lf_aln_desc_t dsc_pref = dsc_next;
+        if (it + 1 < rr.nitems) { Inext = items[rr.item0 + it + 1]; op_next = first_tile(Inext); dsc_next = desc_of(Inext); }
         if (I.n == 0) continue;
         if (I.kind == LF_RI_RUN_M) { cigar_run('M', I.n); m_num += I.n; m_last = T_EQ; continue; }
         if (I.kind == LF_RI_RUN_I) { cigar_run('I', I.n); m_last = T_I; continue; }
@@ -116,15 +136,14 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
         uint32_t tcarry = 0, qcarry = 0;
         /* a lazy path has op 0 for EVERY diagonal move: match / mismatch is decided here, by the comparison the edlib
          * kernels would have made (same accessors, same indices in the problem's own orientation) -- but coalesced */
-        lf_aln_desc_t dsc; dsc.qstart = 0; dsc.tstart = 0; dsc.flags = 0;
-        if (I.lazy && !WRITE) dsc = R.desc[I.round][I.slot];
+        const lf_aln_desc_t dsc = dsc_pref;
         const lf_qacc QA(reads, dsc.qstart, dsc.flags); const lf_tacc TA(nullptr, pac, dsc.tstart, dsc.flags | LF_F_TPAC);
         for (uint32_t base = 0; base < I.n; base += 64) {
             const uint32_t k = base + lane;
             const bool act = k < I.n;
             const uint32_t cnt = (I.n - base < 64u) ? I.n - base : 64u;
             int ty = T_EQ;
-            if (act) { const uint8_t op = ops[rev ? I.n - 1 - k : k]; ty = op == 0 ? T_EQ : op == 1 ? T_I : op == 2 ? T_D : T_X; }
+            if (act) { const uint8_t op = base == 0 ? op_first : ops[rev ? I.n - 1 - k : k]; ty = op == 0 ? T_EQ : op == 1 ? T_I : op == 2 ? T_D : T_X; }
             if (I.lazy && !WRITE) {          /* the counting pass resolves and writes the mismatches back: the writing pass reads final ops */
                 const uint64_t nd_mask = __ballot(act && ty != T_D), ni_mask = __ballot(act && ty != T_I);
                 if (act && ty == T_EQ) {
@@ -202,7 +221,8 @@ struct lf_widen32 { __host__ __device__ uint64_t operator()(uint32_t v) const { 
  * text comes back in a pinned slot, offs[2*rec], offs[2*rec+1] = start of the record's CIGAR / MD (NUL-terminated). */
 extern "C" int lfg_render(const struct lf_index *ix, int n_dev_recs, const void *d_recs_dev, uint64_t n_dev_items, const void *d_items_dev,
                           int n_host_recs, const lf_rrecord_t *recs, uint64_t n_host_items, const lf_ritem_t *items,
-                          const void *const *round_ops, const void *const *round_desc, char **text_out, uint64_t **offs_out, uint64_t *text_bytes, float *ms)
+                          const void *const *round_ops, const void *const *round_desc, char **text_out, uint64_t **offs_out, uint64_t *text_bytes, float *ms,
+                          lfg_rtext_t *dev_text, uint32_t **lens_out)
 {
     if (ms) *ms = 0;
     *text_out = nullptr; *offs_out = nullptr; *text_bytes = 0;
@@ -256,16 +276,20 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_dev_recs, const void 
     HIPCHK(hipStreamSynchronize(s));
     const uint64_t total = h_offs[2 * (size_t)n_recs - 1] + h_tail[0];
     char *d_text = (char *)lfg_dev_slot(device, LF_DS_RENDER0 + 5, total + 64);
-    char *h_text = (char *)lfg_pin_slot(LF_PS_RENDER0 + 2, total + 64);
-    if (!d_text || !h_text) return LF_ERR_NOMEM;
+    char *h_text = dev_text ? nullptr : (char *)lfg_pin_slot(LF_PS_RENDER0 + 2, total + 64);
+    uint32_t *h_lens = dev_text ? (uint32_t *)lfg_pin_slot(LF_PS_RENDER0 + 3, (size_t)n_recs * 8 + 16) : nullptr;
+    if (!d_text || (!dev_text && !h_text) || (dev_text && !h_lens)) return LF_ERR_NOMEM;
     hipLaunchKernelGGL(lf_render_kernel<true>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac, d_reads,
                        d_lens, (const uint64_t *)d_offs, d_text);
     HIPCHK(hipEventRecord(e1, s));
-    HIPCHK(hipMemcpyAsync(h_text, d_text, total, hipMemcpyDeviceToHost, s));
+    if (dev_text) HIPCHK(hipMemcpyAsync(h_lens, d_lens, (size_t)n_recs * 8, hipMemcpyDeviceToHost, s));      /* SA:Z strings need a few CIGARs (lfg_fetch) */
+    else HIPCHK(hipMemcpyAsync(h_text, d_text, total, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
     *text_out = h_text; *offs_out = h_offs; *text_bytes = total;
+    if (dev_text) { dev_text->d_text = d_text; dev_text->d_offs = d_offs; dev_text->d_lens = d_lens; }
+    if (lens_out) *lens_out = h_lens;
     return LF_OK;
 }
 

@@ -1,0 +1,208 @@
+/*
+ * lf_sam.hip -- SAM lines assembled on the device (printSamEntry, src/LordFAST.cpp:377-442).
+ *
+ * Everything a record line is made of is already in HBM when a chunk reaches its last stage: the read batch (SEQ), the
+ * rendered CIGAR / MD text (lf_render.hip), the contig table.  The host decides WHAT is printed -- flags, MAPQ (the
+ * reference's double arithmetic, :325-356), AS / NM, record order, SA:Z strings of split alignments -- as one 48-byte
+ * line descriptor per record; this file turns descriptors into text:
+ *
+ *   lf_sam_len_kernel    one thread per line: its exact length (arithmetic only)          -> exclusive scan -> offsets
+ *   lf_sam_write_kernel  one wavefront per line: coalesced copies of name / CIGAR / SEQ (reverse-complemented for
+ *                        flag 16) / QUAL / MD, decimal fields by lane 0
+ *
+ * and one D2H copy of the chunk's text straight into the caller's output buffer replaces round 1's D2H of the CIGAR / MD
+ * text plus two host passes (count, then memcpy into place) over ~25 kB per read.  Lines the device has no data for (reads
+ * shorter than -l are not in the resident batch) arrive as literal text in a side blob.
+ */
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include <string.h>
+#include <mutex>
+#include "lf_internal.h"
+#include "lf_gpu_common.h"
+
+struct lf_sam_dev {
+    const lf_samline_t *lines; int n_lines;
+    const unsigned char *reads; const uint64_t *read_off;      /* resident read batch */
+    const unsigned char *quals;                                /* same layout as reads, or NULL (FASTA: "*") */
+    const char *names, *blob;                                  /* read names; side blob: SA:Z strings and literal lines */
+    const char *text; const uint64_t *toffs; const uint32_t *tlens;     /* rendered CIGAR / MD: 2 per record (lengths incl. NUL) */
+    const char *ctg_names; const uint32_t *ctg_name_off;       /* contig names, offsets (n_ctg + 1) */
+    const char *rg; uint32_t rg_len;                           /* "\tRG:Z:<id>" or empty */
+};
+
+__device__ __forceinline__ uint32_t lf_ndig(uint32_t v)
+{
+    return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u
+         : v < 10000000u ? 7u : v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
+}
+__device__ __forceinline__ uint32_t lf_ndig_i(int32_t v) { return v < 0 ? 1u + lf_ndig((uint32_t)(-(int64_t)v)) : lf_ndig((uint32_t)v); }
+
+__device__ __forceinline__ uint64_t lf_sam_line_len(const lf_sam_dev &D, const lf_samline_t &Ln)
+{
+    if (Ln.kind == LF_SL_LITERAL) return Ln.sa_len;
+    const uint32_t L = (uint32_t)(D.read_off[Ln.read + 1] - D.read_off[Ln.read]);
+    const uint32_t ql = D.quals && Ln.is_fq ? L : 1u;
+    uint64_t n = Ln.name_len + 1;
+    if (Ln.kind == LF_SL_UNMAPPED) return n + 16 /* "4\t*\t0\t0\t*\t*\t0\t0\t" */ + L + 1 + ql + D.rg_len + 1;
+    n += lf_ndig(Ln.flag) + 1;
+    n += (D.ctg_name_off[Ln.rname + 1] - D.ctg_name_off[Ln.rname]) + 1;
+    n += lf_ndig(Ln.pos1) + 1 + lf_ndig((uint32_t)Ln.mapq) + 1;
+    n += (D.tlens[2 * (size_t)Ln.rec] - 1);                        /* CIGAR */
+    n += 7;                                                        /* "\t*\t0\t0\t" */
+    n += (uint64_t)L + 1 + ql;
+    n += 6 + lf_ndig_i(Ln.as) + 13 + lf_ndig((uint32_t)Ln.nm) + 6 + (D.tlens[2 * (size_t)Ln.rec + 1] - 1);   /* \tAS:i: | \tXS:i:0\tNM:i: | \tMD:Z: */
+    n += D.rg_len;
+    if (Ln.sa_len) n += 6 + Ln.sa_len;                             /* \tSA:Z: */
+    return n + 1;
+}
+
+__global__ void lf_sam_len_kernel(lf_sam_dev D, uint64_t *__restrict__ lens)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.n_lines) return;
+    lens[i] = lf_sam_line_len(D, D.lines[i]);
+}
+
+__global__ void __launch_bounds__(64)
+lf_sam_write_kernel(lf_sam_dev D, const uint64_t *__restrict__ offs, char *__restrict__ out)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= D.n_lines) return;
+    const lf_samline_t Ln = D.lines[i];
+    char *o = out + offs[i];
+    uint64_t w = 0;                                                /* wave-uniform cursor */
+    auto copy = [&](const char *src, uint64_t n) { for (uint64_t k = lane; k < n; k += 64) o[w + k] = src[k]; w += n; };
+    auto lit = [&](const char *s2, uint32_t n) { if ((uint32_t)lane < n) o[w + lane] = s2[lane]; w += n; };      /* n <= 64 */
+    auto put_u = [&](uint32_t v) { const uint32_t nd = lf_ndig(v); if (lane == 0) { uint32_t x = v; for (int k = (int)nd - 1; k >= 0; k--) { o[w + k] = (char)('0' + x % 10u); x /= 10u; } } w += nd; };
+    auto put_i = [&](int32_t v) { if (v < 0) { if (lane == 0) o[w] = '-'; w += 1; put_u((uint32_t)(-(int64_t)v)); } else put_u((uint32_t)v); };
+    auto put_c = [&](char c) { if (lane == 0) o[w] = c; w += 1; };
+    if (Ln.kind == LF_SL_LITERAL) { copy(D.blob + Ln.sa_off, Ln.sa_len); return; }
+    const uint64_t ro = D.read_off[Ln.read];
+    const uint32_t L = (uint32_t)(D.read_off[Ln.read + 1] - ro);
+    const bool rev = Ln.kind == LF_SL_MAPPED && (Ln.flag & 16);
+    auto put_seq_qual = [&]() {
+        const unsigned char *s = D.reads + ro;
+        if (!rev) for (uint32_t k = lane; k < L; k += 64) o[w + k] = (char)s[k];
+        else for (uint32_t k = lane; k < L; k += 64) o[w + k] = (char)lf_rc_char(s[L - 1 - k]);     /* reverseComplement, :501 */
+        w += L; put_c('\t');
+        if (D.quals && Ln.is_fq) {
+            const unsigned char *q = D.quals + ro;
+            if (!rev) for (uint32_t k = lane; k < L; k += 64) o[w + k] = (char)q[k];
+            else for (uint32_t k = lane; k < L; k += 64) o[w + k] = (char)q[L - 1 - k];               /* reverse, :502 */
+            w += L;
+        } else put_c('*');
+    };
+    copy(D.names + Ln.name_off, Ln.name_len); put_c('\t');
+    if (Ln.kind == LF_SL_UNMAPPED) {
+        lit("4\t*\t0\t0\t*\t*\t0\t0\t", 16);
+        put_seq_qual();
+        copy(D.rg, D.rg_len); put_c('\n');
+        return;
+    }
+    put_u(Ln.flag); put_c('\t');
+    copy(D.ctg_names + D.ctg_name_off[Ln.rname], D.ctg_name_off[Ln.rname + 1] - D.ctg_name_off[Ln.rname]); put_c('\t');
+    put_u(Ln.pos1); put_c('\t'); put_u((uint32_t)Ln.mapq); put_c('\t');
+    copy(D.text + D.toffs[2 * (size_t)Ln.rec], D.tlens[2 * (size_t)Ln.rec] - 1);
+    lit("\t*\t0\t0\t", 7);
+    put_seq_qual();
+    lit("\tAS:i:", 6); put_i(Ln.as);
+    lit("\tXS:i:0\tNM:i:", 13); put_u((uint32_t)Ln.nm);
+    lit("\tMD:Z:", 6);
+    copy(D.text + D.toffs[2 * (size_t)Ln.rec + 1], D.tlens[2 * (size_t)Ln.rec + 1] - 1);
+    copy(D.rg, D.rg_len);
+    if (Ln.sa_len) { lit("\tSA:Z:", 6); copy(D.blob + Ln.sa_off, Ln.sa_len); }
+    put_c('\n');
+}
+
+#define SSLOT(T, k, bytes) (T *)lfg_dev_slot(dv, LF_DS_SAM0 + (k), (bytes))
+
+/* lines / names / blob: host memory (pinned slots of the caller).  Returns the chunk's text size; the text itself is written
+ * on the lane's stream and fetched with lfg_sam_fetch once the caller knows where it goes. */
+extern "C" int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, int n_lines, const lf_samline_t *lines,
+                             const char *names, uint64_t names_bytes, const char *blob, uint64_t blob_bytes,
+                             const char *quals, uint64_t quals_bytes, const lfg_rtext_t *rt, uint64_t *total_out)
+{
+    *total_out = 0;
+    if (n_lines == 0) return LF_OK;
+    const int dv = ix->device;
+    HIPCHK(hipSetDevice(dv));
+    hipStream_t s = (hipStream_t)lfg_lane_stream(dv, 1);
+    if (!s) return LF_ERR_HIP;
+    lf_dev_state *st = (lf_dev_state *)ix->dev;
+    if (!st) { lf_set_error("index is not on a device"); return LF_ERR_NO_DEVICE; }
+    const size_t N = (size_t)n_lines;
+    lf_samline_t *d_lines = SSLOT(lf_samline_t, 0, N * sizeof(lf_samline_t));
+    char *d_names = SSLOT(char, 1, names_bytes + 64), *d_blob = SSLOT(char, 2, blob_bytes + 64);
+    uint64_t *d_lens = SSLOT(uint64_t, 3, (N + 1) * 8), *d_offs = SSLOT(uint64_t, 4, (N + 1) * 8);
+    unsigned char *d_quals = quals ? SSLOT(unsigned char, 5, quals_bytes + 64) : nullptr;
+    uint64_t *h = (uint64_t *)lfg_pin_slot(LF_PS_SAM0 + 0, 64);
+    if (!d_lines || !d_names || !d_blob || !d_lens || !d_offs || (quals && !d_quals) || !h) return LF_ERR_NOMEM;
+    /* contig names: a few kB, once per index and device (kept with the device state) */
+    static std::mutex ctg_mu;
+    std::unique_lock<std::mutex> ctg_lock(ctg_mu);
+    if (!st->ctg_names) {
+        size_t nb = 0;
+        for (int c = 0; c < ix->n_seqs; c++) nb += strlen(ix->contigs[c].name);
+        char *hn = (char *)malloc(nb + 16); uint32_t *ho = (uint32_t *)malloc(((size_t)ix->n_seqs + 1) * 4);
+        size_t o = 0;
+        for (int c = 0; c < ix->n_seqs; c++) { ho[c] = (uint32_t)o; const size_t l = strlen(ix->contigs[c].name); memcpy(hn + o, ix->contigs[c].name, l); o += l; }
+        ho[ix->n_seqs] = (uint32_t)o;
+        char *dn = nullptr; uint32_t *dof = nullptr;
+        hipError_t e1 = hipMalloc((void **)&dn, nb + 16), e2 = hipMalloc((void **)&dof, ((size_t)ix->n_seqs + 1) * 4);
+        if (e1 == hipSuccess && e2 == hipSuccess) { e1 = hipMemcpy(dn, hn, nb, hipMemcpyHostToDevice); e2 = hipMemcpy(dof, ho, ((size_t)ix->n_seqs + 1) * 4, hipMemcpyHostToDevice); }
+        free(hn); free(ho);
+        if (e1 != hipSuccess || e2 != hipSuccess) { lf_set_error("lfg_sam_build: contig table upload failed"); return LF_ERR_HIP; }
+        st->ctg_names = dn; st->ctg_name_off = dof;
+    }
+    ctg_lock.unlock();
+    char rg[300]; uint32_t rg_len = 0;
+    if (p->read_group_id[0]) rg_len = (uint32_t)snprintf(rg, sizeof rg, "\tRG:Z:%s", p->read_group_id);
+    char *d_rg = SSLOT(char, 6, 512);
+    if (!d_rg) return LF_ERR_NOMEM;
+    HIPCHK(hipMemcpyAsync(d_lines, lines, N * sizeof(lf_samline_t), hipMemcpyHostToDevice, s));
+    if (names_bytes) HIPCHK(hipMemcpyAsync(d_names, names, names_bytes, hipMemcpyHostToDevice, s));
+    if (blob_bytes) HIPCHK(hipMemcpyAsync(d_blob, blob, blob_bytes, hipMemcpyHostToDevice, s));
+    if (quals) HIPCHK(hipMemcpyAsync(d_quals, quals, quals_bytes, hipMemcpyHostToDevice, s));
+    if (rg_len) HIPCHK(hipMemcpyAsync(d_rg, rg, rg_len, hipMemcpyHostToDevice, s));      /* pageable source: copied before the call returns */
+    lf_sam_dev D;
+    D.lines = d_lines; D.n_lines = n_lines;
+    D.reads = (const unsigned char *)lfg_dev_slot(dv, LF_DS_SEED0 + 0, 0); D.read_off = (const uint64_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 1, 0);
+    D.quals = d_quals; D.names = d_names; D.blob = d_blob;
+    D.text = (const char *)rt->d_text; D.toffs = (const uint64_t *)rt->d_offs; D.tlens = (const uint32_t *)rt->d_lens;
+    D.ctg_names = (const char *)st->ctg_names; D.ctg_name_off = (const uint32_t *)st->ctg_name_off;
+    D.rg = d_rg; D.rg_len = rg_len;
+    hipLaunchKernelGGL(lf_sam_len_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, s, D, d_lens);
+    size_t tb = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_lens, d_offs, n_lines, s);
+    void *d_tmp = SSLOT(void, 7, tb + 256);
+    if (!d_tmp) return LF_ERR_NOMEM;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_lens, d_offs, n_lines, s));
+    HIPCHK(hipMemcpyAsync(h, d_offs + (N - 1), 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h + 1, d_lens + (N - 1), 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const uint64_t total = h[0] + h[1];
+    char *d_out = SSLOT(char, 8, total + 64);
+    if (!d_out) return LF_ERR_NOMEM;
+    hipLaunchKernelGGL(lf_sam_write_kernel, dim3((unsigned)n_lines), dim3(64), 0, s, D, (const uint64_t *)d_offs, d_out);
+    HIPCHK(hipGetLastError());
+    *total_out = total;
+    return LF_OK;
+}
+
+/* the text of the last lfg_sam_build of this lane -> dst (host; pinned memory copies at link speed) */
+extern "C" int lfg_sam_fetch(const struct lf_index *ix, char *dst, uint64_t total)
+{
+    if (!total) return LF_OK;
+    const int dv = ix->device;
+    HIPCHK(hipSetDevice(dv));
+    hipStream_t s = (hipStream_t)lfg_lane_stream(dv, 1);
+    if (!s) return LF_ERR_HIP;
+    const char *d_out = (const char *)lfg_dev_slot(dv, LF_DS_SAM0 + 8, 0);
+    if (!d_out) { lf_set_error("lfg_sam_fetch: nothing was built"); return LF_ERR_ARG; }
+    HIPCHK(hipMemcpyAsync(dst, d_out, total, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return LF_OK;
+}

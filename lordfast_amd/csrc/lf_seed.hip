@@ -152,6 +152,8 @@ extern "C" void lfg_index_free(struct lf_index *ix)
     if (st->cache) (void)hipFree(st->cache);
     if (st->cache14) (void)hipFree(st->cache14);
     if (st->pac) (void)hipFree(st->pac);
+    if (st->ctg_names) (void)hipFree(st->ctg_names);
+    if (st->ctg_name_off) (void)hipFree(st->ctg_name_off);
     if (st->stream) (void)hipStreamDestroy(st->stream);
     delete st;
     ix->dev = NULL;

@@ -319,3 +319,23 @@ def test_sam_host_walk_crosscheck(lf, golden_reads, monkeypatch, cfg):
     assert sam_h == exp, first_diff(sam_h, exp)
     # the device plans every chain's common path; chains with a clip / split trigger are planned again by the host replay
     assert st_d["n_edlib_problems"] >= st_h["n_edlib_problems"] > 0
+
+
+@pytest.mark.parametrize("cfg", ["default", "n30", "clasp"])
+def test_sam_host_assembly_crosscheck(lf, golden_reads, monkeypatch, cfg):
+    """LF_HOST_SAM=1 formats the SAM lines on the host (two passes over the records) instead of lf_sam.hip (line descriptors
+    -> text on the device, one D2H copy into the output buffer): same bytes.  With qualities (FASTQ) and a read group too."""
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    exp = golden_sam(cfg)
+    monkeypatch.setenv("LF_HOST_SAM", "1")
+    sam_h, _ = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
+    assert sam_h == exp, first_diff(sam_h, exp)
+    if cfg == "default":
+        quals = [bytes(33 + (i * 7 + k) % 40 for k in range(len(s))) if i % 3 else b"" for i, s in enumerate(seqs)]
+        p = la.default_params(read_group_id=b"grpX", read_group=b"@RG\tID:grpX")
+        h, _ = lf.map_batch(names, seqs, quals=quals, params=p)
+        monkeypatch.delenv("LF_HOST_SAM")
+        d, _ = lf.map_batch(names, seqs, quals=quals, params=p)
+        assert d == h, first_diff(d, h)
+        assert b"\tRG:Z:grpX" in d
