@@ -178,7 +178,7 @@ struct lf_emitter {
  * longest problem (problems are sorted by target length).
  * ---------------------------------------------------------------------------------------------- */
 template <int NB, bool PAC>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (NB <= 4 ? 4 : NB <= 6 ? 3 : 2))
 lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ ckpt, uint8_t *__restrict__ ops,
                 int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
 {
