@@ -125,6 +125,9 @@ __host__ __device__ __forceinline__ bool lf_leaf(int64_t n, int64_t m) { return 
  * ================================================================================================ */
 
 #define LF_LANE_K   8        /* lane classes: columns per tile (tile in LDS: K x W blocks x 64 lanes x 16 B) */
+#ifndef LF_LANE_W
+#define LF_LANE_W   1        /* 8 KiB of LDS per wave: LDS, not registers, bounds the waves per SIMD of these kernels */
+#endif
 
 __device__ __forceinline__ uint32_t lf_wave_max_u32(uint32_t v)
 {
@@ -162,8 +165,23 @@ struct lf_emitter {
     __device__ __forceinline__ void flush() { if (cnt) spill(); }
 };
 
+/* layout of a wave's checkpoint area (16-byte entries from the hist_base of the wave's first problem):
+ *   lane classes   [0, 96 NB)  bit planes lo / hi / valid of every block: u64 [(b * 3 + x) * 64 + lane]
+ *                  then        carries: the two-bit horizontal deltas ENTERING block b >= 1, 16 columns per u32,
+ *                              u32 [((q * NB + b) * 64 + lane) * 4 + sub], column c in word (c - 1) / 16 = 4 q + sub
+ *                  then        checkpoints (Pv, Mv) after every K-th column: [((j - 1) * NB + b) * 64 + lane]
+ *   sweep classes  [0, 96)     bit planes of the lanes' blocks: u64 [x * 64 + lane]          (KB = 1 only)
+ *                  then        rows of 64 KB + 16 entries (KB = 1; + 4 otherwise), one per K steps: (Pv, Mv) of every lane,
+ *                              tail bytes [0, 64) pending carry of every lane, u16 [32 + lane] the carries the lane
+ *                              RECEIVED during the row's K steps (KB = 1)
+ * With the carries a block can be replayed on its own: lf_edlib_tb_kernel walks one path per lane and recomputes only
+ * the block the path is in. */
+#define LF_PLANE_ENTRIES 96
+__host__ __device__ __forceinline__ int lf_sweep_row(int kb) { return 64 * kb + (kb == 1 ? 16 : 4); }
+__host__ __device__ __forceinline__ uint64_t lf_lane_ck_off(int nb, uint32_t m_max) { return (uint64_t)nb * LF_PLANE_ENTRIES + (uint64_t)((m_max + 63) >> 6) * nb * 64; }
+
 /* ------------------------------------------------------------------------------------------------
- * register-resident classes: ONE LANE PER PROBLEM, NB blocks per column (n <= 64 NB)
+ * register-resident classes: ONE LANE PER PROBLEM, NB blocks per column (n <= 64 NB) -- forward pass
  *
  * The blocks of one column depend on each other through the horizontal carry, and a block depends on itself one
  * column earlier: one lane alone is a single dependent chain.  Walking the lane's OWN blocks as an anti-diagonal
@@ -173,25 +191,22 @@ struct lf_emitter {
  * The time loop carries NO per-lane control flow.  t and b are wave-uniform, so "block b has not started yet"
  * (t - b < 1) is a scalar branch; everything that differs between lanes -- the number of blocks a problem really has,
  * its target length -- is handled by letting a lane compute on: steps beyond its last block or its last column only
- * write its own dead registers and feed other dead steps, and the three places where validity matters (distance
- * bookkeeping, checkpoint stores, LDS tile stores) are selects / predicated stores.  The loop runs to the wavefront's
- * longest problem (problems are sorted by target length).
+ * write its own dead registers and feed other dead steps, and the places where validity matters (distance
+ * bookkeeping, checkpoint / carry stores) are selects / predicated stores.  The loop runs to the wavefront's
+ * longest problem (problems are sorted by target length).  The path itself is walked by lf_edlib_tb_kernel.
  * ---------------------------------------------------------------------------------------------- */
 template <int NB, bool PAC>
-__global__ void __launch_bounds__(64, (NB <= 4 ? 4 : NB <= 6 ? 3 : 2))
-lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ ckpt, uint8_t *__restrict__ ops,
-                int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
+__global__ void __launch_bounds__(64)
+lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ ckpt,
+                int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end)
 {
     constexpr int K = LF_LANE_K;
-    constexpr int W = NB < 2 ? 1 : 2;               /* blocks of a tile kept in LDS: the path's block and the one above */
-    __shared__ lf_hist_t s_tile[K * W * 64];
     const int gid = blockIdx.x * 64 + threadIdx.x;
     const int lane = threadIdx.x;
     const bool live = gid < n_probs;
     const lf_aln_prob pr = probs[live ? gid : n_probs - 1];      /* a dead lane shadows the last problem and stores nothing */
     const lf_qacc Q(S.q, pr.qstart, pr.flags); const lf_tacc T(S.t, S.pac, pr.tstart, pr.flags);
     auto qget = [&](uint32_t r) -> unsigned char { return Q.get(r); };
-    const bool lazy = (pr.flags & LF_F_LAZYX) != 0;      /* diagonal moves are not classified here (lf_render_kernel does it) */
     const uint32_t n = pr.n, m = pr.m;
 
     uint64_t lo[NB], hi[NB], valid[NB], Pv[NB], Mv[NB];
@@ -210,13 +225,23 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
     /* SHW (lib/edlib/edlib.cpp:583-618): min over prefixes, smallest on ties; the empty prefix only exists
      * through the wildcard padding of the last block, i.e. when n % 64 != 0 */
     int best = (n & 63) ? (int)n : 0x7fffffff, best_c = 0;
-    lf_hist_t *ck = ckpt + pr.hist_base + lane;     /* wave-transposed: checkpoint (j, block b) of lane l at ((j * NB + b) * 64 + l) */
-    const bool want_path = pr.task == LF_TASK_PATH;
-    const bool ck_on = want_path && live;
-
-    uint32_t hout[NB], win[NB];
+    const uint32_t m_max = lf_wave_max_u32(m);
+    lf_hist_t *wbase = ckpt + pr.hist_base;          /* the same for every lane: hist_base of the wave's first problem */
+    uint64_t *planes = reinterpret_cast<uint64_t *>(wbase);
+    uint32_t *carr = reinterpret_cast<uint32_t *>(wbase + NB * LF_PLANE_ENTRIES);
+    lf_hist_t *ck = wbase + lf_lane_ck_off(NB, m_max) + lane;     /* checkpoint (j, block b) of lane l at ((j - 1) * NB + b) * 64 + l */
+    const bool ck_on = pr.task == LF_TASK_PATH && live;
+    if (ck_on) {
 #pragma unroll
-    for (int b = 0; b < NB; b++) { hout[b] = 0; win[b] = 0; }
+        for (int b = 0; b < NB; b++) if (b <= lastb) { planes[(b * 3 + 0) * 64 + lane] = lo[b]; planes[(b * 3 + 1) * 64 + lane] = hi[b]; planes[(b * 3 + 2) * 64 + lane] = valid[b]; }
+    }
+
+    uint32_t hout[NB], win[NB], cw[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) { hout[b] = 0; win[b] = 0; cw[b] = 0; }
+    auto carry_store = [&](int b, uint32_t gi) {      /* gi: 16-column group */
+        if (ck_on && b <= lastb && gi * 16 < m) carr[(((size_t)(gi >> 2) * NB + b) * 64 + lane) * 4 + (gi & 3)] = cw[b];
+    };
     const uint32_t steps_w = lf_wave_max_u32(m + (uint32_t)lastb);
     for (uint32_t t0 = 1; t0 <= steps_w; t0 += 8) {
         /* the 8 target bases of this trip are fetched together: their latency is paid once, not per column */
@@ -231,7 +256,7 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
             win[0] = tcs[k];
 #pragma unroll
             for (int b = NB - 1; b >= 0; b--) {
-                if (t > (uint32_t)b) {                                      /* wave-uniform: block b has reached column 1 */
+                if (t > (uint32_t)b && t <= steps_w) {                      /* wave-uniform: block b has reached column 1 */
                     const uint32_t c = t - (uint32_t)b;
                     const uint32_t hin = b == 0 ? LF_HIN_PLUS1 : hout[b > 0 ? b - 1 : 0];
                     const uint64_t Eq = lf_eq_tok<PAC>(win[b], lo[b], hi[b], valid[b], qget, n, b);
@@ -239,97 +264,121 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
                     hout[b] = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
                     const bool inr = c <= m;
                     score += (b == lastb && inr) ? lf_delta_at(ph, mh, lastbit) : 0;
+                    if (b >= 1) cw[b] |= hin << (((c - 1) & 15u) * 2);      /* scalar shift amount */
                     /* checkpoint: the state after every K-th column (one 1 KiB line per wave, block and checkpoint) */
                     if ((c & (K - 1)) == 0) {                               /* wave-uniform */
                         if (ck_on && inr && b <= lastb) { lf_hist_t e; e.pv = Pv[b]; e.ph = Mv[b]; ck[((size_t)(c / K - 1) * NB + b) * 64] = e; }
+                        if (b >= 1 && (c & 15u) == 0) { carry_store(b, c / 16 - 1); cw[b] = 0; }
                     }
                 }
             }
-            {   /* the last block has just finished column t - lastb */
+            if (t <= steps_w) {   /* the last block has just finished column t - lastb */
                 const int cl = (int)t - lastb;
                 const bool upd = cl >= 1 && cl <= (int)m && score < best;
                 best = upd ? score : best; best_c = upd ? cl : best_c;
             }
         }
     }
+    /* the carries of the last, partial group of every block (block b stopped at column steps_w - b) */
+#pragma unroll
+    for (int b = 1; b < NB; b++) if (steps_w > (uint32_t)b) { const uint32_t cl = steps_w - (uint32_t)b; if (cl & 15u) carry_store(b, (cl - 1) >> 4); }
     int ed, tl;
     if (pr.mode == 0) { ed = score; tl = (int)m; } else { ed = best; tl = best_c; }
     if (live) { out_ed[pr.id] = ed; out_end[pr.id] = tl - 1; }
-    if (!__any(want_path)) { if (live) out_len[pr.id] = 0; return; }
+}
 
-    /* traceback from (n, tl); ops written backwards from the end of the region (they stay end-aligned).
-     * Tiles of K columns, last tile first.  A lane whose path is inside the tile restores the checkpoint in front of it,
-     * recomputes the tile's columns for blocks 0 .. (block of its row) -- the same anti-diagonal order as above --
-     * keeps (Pv, Ph) of the W = 2 lowest of those blocks in LDS and follows its path until it leaves the tile on
-     * the left.  A path that climbs out of the LDS window inside one tile (> 64 insertions within K columns)
-     * re-enters the same tile with the window moved up. */
-    lf_emitter em; em.init(ops + pr.ops_off, n + m, live && want_path);
-    uint32_t r = want_path ? n : 0, c = want_path ? (uint32_t)tl : 0;
-    const uint32_t cmax = lf_wave_max_u32(c);
-    for (int ti = cmax ? (int)((cmax - 1) / K) : -1; ti >= 0; ti--) {
-        const uint32_t c0 = (uint32_t)ti * K;
-        for (;;) {
-            const bool act = r > 0 && c > c0;
-            if (!__any(act)) break;
-            /* per lane: the block of the path's row, the LDS window, the columns of this tile left of the path */
-            const int br = act ? (int)((r - 1) >> 6) : -1;
-            const int bw = (W == 2 && br > 0) ? br - 1 : br;
-            const uint32_t ncol = act ? c - c0 : 0;                /* 1 .. K */
-#pragma unroll
-            for (int b = 0; b < NB; b++) {
-                Pv[b] = ~0ull; Mv[b] = 0;
-                if (ti > 0 && b <= br) { const lf_hist_t e = ck[((size_t)(ti - 1) * NB + b) * 64]; Pv[b] = e.pv; Mv[b] = e.ph; }
+/* ------------------------------------------------------------------------------------------------
+ * traceback: ONE LANE PER PATH, for every class whose blocks can be replayed on their own (lane classes; sweep classes
+ * with one block per lane, problems below edlib's Hirschberg switch).
+ *
+ * From (n, tl) the path is followed tile by tile: the tile = the K columns (lane classes) or K sweep steps (sweep classes)
+ * around the current cell, of the ONE block the cell is in.  The lane restores that block's checkpoint in front of the
+ * tile, replays the K block steps with the stored carries as horizontal input, keeps (Pv, Ph) of the K columns in LDS
+ * and walks until the path leaves the tile or the block.  Work per path: ~(m / K + n / 64) tiles of K block steps --
+ * instead of replaying all the blocks above the path (lane classes) or the whole group of lanes (sweep classes, where
+ * the walk itself also kept only one lane of G busy).  Same cells, same Up -> Left -> Diagonal priority
+ * (lib/edlib/edlib.cpp:950,984,1015), same ops.
+ * ---------------------------------------------------------------------------------------------- */
+template <bool LANECLASS, bool PAC>
+__global__ void __launch_bounds__(64)
+lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, const lf_hist_t *__restrict__ ckpt, uint8_t *__restrict__ ops,
+                   const int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len, int W /* NB of the lane class | G of the sweep class */)
+{
+    constexpr int K = LF_LANE_K;
+    __shared__ lf_hist_t s_tile[K * 64];
+    const int lane = threadIdx.x, idx = blockIdx.x * 64 + lane;
+    const bool live = idx < n_probs;
+    const lf_aln_prob pr = probs[live ? idx : n_probs - 1];
+    const lf_qacc Q(S.q, pr.qstart, pr.flags); const lf_tacc T(S.t, S.pac, pr.tstart, pr.flags);
+    auto qget = [&](uint32_t r) -> unsigned char { return Q.get(r); };
+    const bool lazy = (pr.flags & LF_F_LAZYX) != 0;      /* diagonal moves are not classified here (lf_render_kernel does it) */
+    const uint32_t n = pr.n, m = pr.m;
+    const bool mine = live && (LANECLASS || lf_leaf(n, m));      /* above the switch: the sweep kernel's own Hirschberg walk */
+    const bool want = mine && pr.task == LF_TASK_PATH;
+    const uint32_t tl = pr.mode == 0 ? m : (uint32_t)(out_end[pr.id] + 1);
+    /* where the forward kernel left this problem's data */
+    const lf_hist_t *wbase = ckpt + pr.hist_base;
+    const uint64_t *planes = reinterpret_cast<const uint64_t *>(wbase);
+    const int slot = LANECLASS ? lane : idx % (64 / W);
+    const uint32_t m_max = LANECLASS ? lf_wave_max_u32(m) : 0;
+    const lf_hist_t *ck = LANECLASS ? wbase + lf_lane_ck_off(W, m_max) : wbase + LF_PLANE_ENTRIES;
+    const uint32_t *carr = reinterpret_cast<const uint32_t *>(wbase + (size_t)W * LF_PLANE_ENTRIES);      /* lane classes */
+    constexpr int ROW = 64 + 16;                                                                            /* sweep classes, KB = 1 */
+
+    lf_emitter em; em.init(ops + pr.ops_off, n + m, want);
+    uint32_t r = want ? n : 0, c = want ? tl : 0;
+    int cur_b = -1; uint64_t lo = 0, hi = 0, valid = 0;
+    while (__any(r > 0 && c > 0)) {
+        const bool act = r > 0 && c > 0;
+        const uint32_t b = act ? (r - 1) >> 6 : 0;
+        /* the tile: K block steps of block b; step k works on column cbase + k */
+        const uint32_t j = LANECLASS ? (c - 1) / K : (c - 1 + b) / K;
+        const int cbase = LANECLASS ? (int)(j * K) + 1 : (int)(j * K) - (int)b + 1;
+        uint64_t Pv = ~0ull, Mv = 0; uint32_t cw = 0x5555u;      /* block 0: +1 enters every column */
+        if (act) {
+            if (LANECLASS) {
+                if (j > 0) { const lf_hist_t e = ck[((size_t)(j - 1) * W + b) * 64 + slot]; Pv = e.pv; Mv = e.ph; }
+                if (b > 0) { const uint32_t gi = (c - 1) >> 4; cw = carr[(((size_t)(gi >> 2) * W + b) * 64 + slot) * 4 + (gi & 3)] >> ((j & 1u) * 16); }
+                if ((int)b != cur_b) { lo = planes[(b * 3 + 0) * 64 + slot]; hi = planes[(b * 3 + 1) * 64 + slot]; valid = planes[(b * 3 + 2) * 64 + slot]; cur_b = (int)b; }
+            } else {
+                const int ln = slot * W + (int)b;
+                if (j > 0) { const lf_hist_t e = ck[(size_t)(j - 1) * ROW + ln]; Pv = e.pv; Mv = e.ph; }
+                if (b > 0) cw = reinterpret_cast<const uint16_t *>(ck + (size_t)j * ROW + 64)[32 + ln];
+                if ((int)b != cur_b) { lo = planes[ln]; hi = planes[64 + ln]; valid = planes[128 + ln]; cur_b = (int)b; }
             }
-            uint32_t tcs[K];
+        }
+        uint32_t tok[K];
 #pragma unroll
-            for (int k = 0; k < K; k++) tcs[k] = ((uint32_t)k < ncol) ? lf_tok<PAC>(T, c0 + k) : 0u;
+        for (int k = 0; k < K; k++) { const int col = cbase + k; tok[k] = (act && col >= 1 && col <= (int)c) ? lf_tok<PAC>(T, (uint32_t)col - 1) : 0u; }
 #pragma unroll
-            for (int b = 0; b < NB; b++) { hout[b] = 0; win[b] = 0; }
-            const int br_w = lf_wave_max_i32(br);
-            const uint32_t tsteps = (uint32_t)K + (uint32_t)(br_w < 0 ? 0 : br_w);      /* wave-uniform */
-#pragma unroll 1
-            for (uint32_t t = 1; t <= tsteps; t++) {
-#pragma unroll
-                for (int b = NB - 1; b >= 1; b--) win[b] = win[b - 1];
-                uint32_t w0 = 0;
-#pragma unroll
-                for (int k = 0; k < K; k++) w0 = (t == (uint32_t)(k + 1)) ? tcs[k] : w0;       /* t is uniform: scalar selects */
-                win[0] = w0;
-#pragma unroll
-                for (int b = NB - 1; b >= 0; b--) {
-                    if (t > (uint32_t)b && t <= (uint32_t)(K + b)) {       /* wave-uniform: column t - b of the tile, 1 .. K */
-                        const uint32_t cc = t - (uint32_t)b;
-                        const uint32_t hin = b == 0 ? LF_HIN_PLUS1 : hout[b > 0 ? b - 1 : 0];
-                        const uint64_t Eq = lf_eq_tok<PAC>(win[b], lo[b], hi[b], valid[b], qget, n, b);
-                        uint64_t ph, mh;
-                        hout[b] = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
-                        if (b >= bw && b <= br && cc <= ncol) { lf_hist_t e; e.pv = Pv[b]; e.ph = ph; s_tile[((cc - 1) * W + (b - bw)) * 64 + lane] = e; }
-                    }
-                }
-            }
-            /* follow the path through the tile: one (Pv, Ph) word pair per (column, block), re-read only when either changes */
-            {
-                uint32_t ec = 0xffffffffu; int eb = -1; lf_hist_t e; e.pv = e.ph = 0;
-                while (r > 0 && c > c0) {
-                    const int b = (int)((r - 1) >> 6);
-                    if (b < bw) break;                          /* above the window: recompute with the window moved up */
-                    if (c != ec || b != eb) { e = s_tile[((c - c0 - 1) * W + (b - bw)) * 64 + lane]; ec = c; eb = b; }
-                    const int bit = (int)((r - 1) & 63);
-                    const uint32_t up = (uint32_t)(e.pv >> bit) & 1u, lf = ((uint32_t)(e.ph >> bit) & 1u) & ~up, dg = (up | lf) ^ 1u;
-                    uint32_t op = up ? 1u : (lf ? 2u : 0u);      /* Up -> Left -> Diagonal (lib/edlib/edlib.cpp:950,984,1015) */
-                    if (!lazy) { if (dg && Q.get(r - 1) != T.get(c - 1)) op = 3u; }
-                    em.put(op);
-                    r -= up | dg; c -= lf | dg;
-                }
+        for (int k = 0; k < K; k++) {
+            const uint64_t Eq = lf_eq_tok<PAC>(tok[k], lo, hi, valid, qget, n, b);
+            uint64_t nPv = Pv, nMv = Mv, ph, mh;
+            (void)lf_myers_step(nPv, nMv, Eq, (cw >> (2 * k)) & 3u, ph, mh);
+            if (LANECLASS) { Pv = nPv; Mv = nMv; }
+            else { const bool v = cbase + k >= 1; Pv = v ? nPv : Pv; Mv = v ? nMv : Mv; }       /* the block starts at column 1 */
+            lf_hist_t e; e.pv = Pv; e.ph = ph; s_tile[k * 64 + lane] = e;
+        }
+        if (act) {
+            const int cmin = cbase < 1 ? 1 : cbase;
+            uint32_t ec = 0xffffffffu; lf_hist_t e; e.pv = e.ph = 0;
+            while (r > 0 && (int)c >= cmin && ((r - 1) >> 6) == b) {
+                if (c != ec) { e = s_tile[((int)c - cbase) * 64 + lane]; ec = c; }
+                const int bit = (int)((r - 1) & 63);
+                const uint32_t up = (uint32_t)(e.pv >> bit) & 1u, lf = ((uint32_t)(e.ph >> bit) & 1u) & ~up, dg = (up | lf) ^ 1u;
+                uint32_t op = up ? 1u : (lf ? 2u : 0u);      /* Up -> Left -> Diagonal (lib/edlib/edlib.cpp:950,984,1015) */
+                if (!lazy) { if (dg && Q.get(r - 1) != T.get(c - 1)) op = 3u; }
+                em.put(op);
+                r -= up | dg; c -= lf | dg;
             }
         }
     }
-    if (want_path) {
+    if (want) {
         while (c > 0) { em.put(2); c--; }
         while (r > 0) { em.put(1); r--; }
         em.flush();
-        if (live) out_len[pr.id] = n + m - em.w;            /* ops are END-aligned: o[cap - len .. cap) */
-    } else if (live) out_len[pr.id] = 0;
+    }
+    if (mine) out_len[pr.id] = want ? n + m - em.w : 0;            /* ops are END-aligned: o[cap - len .. cap) */
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -438,7 +487,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
                       uint8_t *__restrict__ ops, int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
 {
     constexpr int P = 64 / G;                      /* problems per wave */
-    constexpr int TC = G * 64;                     /* LDS ring of target bytes per group (power of two) */
+    constexpr int TC = G == 64 ? 256 : 128;        /* LDS ring of target bytes per group (power of two; H = TC / 2 >= G + K - 1) */
     constexpr int H = TC / 2;
     __shared__ lf_hist_t s_tile[K * KB * 64];
     __shared__ unsigned char s_t[P * TC];
@@ -452,7 +501,8 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     const bool want_path = pr.task == LF_TASK_PATH;
     unsigned char *my_t = s_t + g * TC;
     /* all groups of a wave share one checkpoint area (base of the wave's first problem) */
-    lf_hist_t *ck = ckpt + probs[(int)blockIdx.x * P].hist_base;
+    lf_hist_t *ck = ckpt + probs[(int)blockIdx.x * P].hist_base + (KB == 1 ? LF_PLANE_ENTRIES : 0);
+    constexpr int ROW = 64 * KB + (KB == 1 ? 16 : 4);      /* lf_sweep_row(KB) */
     const uint64_t gmask = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1);
 
     /* geometry of the (sub)problem being swept: query rows [qlo, qlo + n), target columns [tlo, tlo + m), both walked
@@ -464,6 +514,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     uint64_t lo[KB], hi[KB], valid[KB], Pv[KB], Mv[KB];
     uint32_t nbk = 0, lastb = 0; int lastbit = 0, nl = 0, lane_last = 0;
     uint32_t hout_prev = LF_HIN_PLUS1;               /* carry bits (lf_myers_step) this lane hands to its right neighbour */
+    uint32_t cw = 0;                                 /* KB = 1: the carries this lane received during the current K steps, two bits per step */
     int ring_lo = 0;                                 /* the LDS ring holds target columns [ring_lo, ring_lo + TC) (wave-uniform) */
 
     /* bit planes by ballot: for block b the lanes fetch its 64 query bytes (G at a time per group) and three wave
@@ -500,6 +551,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     auto sweep_step = [&](int s, auto track_c, auto tile_c, int s0) {
         constexpr bool track = decltype(track_c)::value, tile = decltype(tile_c)::value;
         const uint32_t from_left = lf_wave_shr1(hout_prev);
+        if (track && KB == 1) cw |= from_left << ((s & (K - 1)) * 2);      /* scalar shift amount */
         const int c = s - gl + 1;
         if (gl < nl && c >= 1 && c <= (int)m) {
             const uint32_t byte = my_t[(c - 1) & (TC - 1)];
@@ -525,7 +577,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     auto forward = [&](bool want_ck) -> int {
 #pragma unroll
         for (int k = 0; k < KB; k++) { Pv[k] = ~0ull; Mv[k] = 0; }
-        hout_prev = LF_HIN_PLUS1;
+        hout_prev = LF_HIN_PLUS1; cw = 0;
         score = (int)n; best = (n & 63) ? (int)n : 0x7fffffff; best_c = 0;
         const int steps = (int)m + nl - 1;
         const int steps_max = G == 64 ? steps : lf_wave_max_i32(steps);
@@ -534,12 +586,16 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
             sweep_step(s, std::true_type(), std::false_type(), 0);
             if (want_ck && ((s + 1) & (K - 1)) == 0) {
                 const size_t j = (size_t)((s + 1) / K - 1);
-                lf_hist_t *row = ck + j * (64 * KB + 4);
+                lf_hist_t *row = ck + j * ROW;
 #pragma unroll
                 for (int k = 0; k < KB; k++) { lf_hist_t e; e.pv = Pv[k]; e.ph = Mv[k]; row[k * 64 + lane] = e; }
                 reinterpret_cast<unsigned char *>(row + 64 * KB)[lane] = (unsigned char)hout_prev;
+                if (KB == 1) reinterpret_cast<uint16_t *>(row + 64)[32 + lane] = (uint16_t)cw;
             }
+            if (((s + 1) & (K - 1)) == 0) cw = 0;
         }
+        /* the carries of the last, partial row (lf_edlib_tb_kernel replays single blocks from them) */
+        if (KB == 1 && want_ck && (steps_max & (K - 1)) != 0) reinterpret_cast<uint16_t *>(ck + (size_t)(steps_max / K) * ROW + 64)[32 + lane] = (uint16_t)cw;
         return steps_max;
     };
     /* traceback of the current geometry from (r = n, c = tl) through checkpointed tiles; ops go to `em` backwards */
@@ -557,7 +613,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
                 for (int k = 0; k < KB; k++) { nPv[k] = ~0ull; nMv[k] = 0; }
                 nh = LF_HIN_PLUS1;
             } else {
-                const lf_hist_t *row = ck + (size_t)(j - 1) * (64 * KB + 4);
+                const lf_hist_t *row = ck + (size_t)(j - 1) * ROW;
 #pragma unroll
                 for (int k = 0; k < KB; k++) { const lf_hist_t e = row[k * 64 + lane]; nPv[k] = e.pv; nMv[k] = e.ph; }
                 nh = (uint32_t)reinterpret_cast<const unsigned char *>(row + 64 * KB)[lane];
@@ -601,12 +657,17 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     /* ---- the root problem ---- */
     const bool root_leaf = G < 64 || lf_leaf(pr.n, pr.m);      /* G < 64: the binning sends only leaf-size problems */
     build_planes();
+    if (KB == 1 && want_path && root_leaf) {      /* for lf_edlib_tb_kernel */
+        uint64_t *pl = reinterpret_cast<uint64_t *>(ck - LF_PLANE_ENTRIES);
+        pl[lane] = lo[0]; pl[64 + lane] = hi[0]; pl[128 + lane] = valid[0];
+    }
     int steps_max = forward(want_path && root_leaf);
     const int src_last = g * G + lane_last;
     const int ed_nw = __shfl(score, src_last), ed_shw = __shfl(best, src_last), c_shw = __shfl(best_c, src_last);
     int ed, tl;
     if (pr.mode == 0) { ed = ed_nw; tl = (int)m; } else { ed = ed_shw; tl = c_shw; }
     if (live && gl == 0) { out_ed[pr.id] = ed; out_end[pr.id] = tl - 1; }
+    if (KB == 1 && root_leaf) return;             /* wave-uniform (G < 64: always): path and out_len come from lf_edlib_tb_kernel */
     if (!__any(want_path)) { if (live && gl == 0) out_len[pr.id] = 0; return; }
     if (root_leaf) {
         traceback((uint32_t)tl, steps_max, want_path);
@@ -725,10 +786,10 @@ __host__ __device__ __forceinline__ int lf_class_k(int c) { return c == 10 ? 4 :
 /* checkpoint entries of one wave whose longest target is m_max (the wave's last problem: problems are sorted by m) */
 __host__ __device__ __forceinline__ uint64_t lf_class_wave_entries(int c, uint32_t m_max)
 {
-    if (c >= 1 && c <= 6) return 64ull * (m_max / LF_LANE_K) * (uint32_t)lf_class_nb(c);
+    if (c >= 1 && c <= 6) return lf_lane_ck_off(lf_class_nb(c), m_max) + 64ull * (m_max / LF_LANE_K) * (uint32_t)lf_class_nb(c);
     if (c == 0) return 0;
     const uint64_t rows = ((uint64_t)m_max + 64) / (uint32_t)lf_class_k(c) + 1;
-    return rows * (64ull * (uint32_t)lf_class_kb(c) + 4);
+    return (lf_class_kb(c) == 1 ? LF_PLANE_ENTRIES : 0) + rows * (uint64_t)lf_sweep_row(lf_class_kb(c));
 }
 /* Hirschberg scratch of a sweep-class problem above edlib's traceback switch: two columns of n + 1 scores (in u64 words) */
 __host__ __device__ __forceinline__ uint64_t lf_class_aux_words(int c, uint32_t n, uint32_t m)
@@ -775,16 +836,19 @@ static void launch_classes(const lf_launch_ctx &L)
     /* largest problems first: their few long-running waves start while the small classes fill the rest of the chip */
 #define DS(C, GV, KBV, KV) if (cnt(C) > 0) hipLaunchKernelGGL((lf_edlib_sweep_kernel<GV, KBV, KV, PAC>), dim3((unsigned)((cnt(C) + (64 / GV) - 1) / (64 / GV))), dim3(64), 0, L.cs[C], \
         L.d_probs + L.cstart[C], cnt(C), L.S, L.d_hist, L.d_aux, L.d_ops, L.d_ed, L.d_end, L.d_len)
-    DS(11, 64, 8, 2); DS(10, 64, 4, 4); DS(9, 64, 1, 8);
+#define TB(C, LANEC, WV) if (cnt(C) > 0) hipLaunchKernelGGL((lf_edlib_tb_kernel<LANEC, PAC>), dim3((unsigned)((cnt(C) + 63) / 64)), dim3(64), 0, L.cs[C], \
+        L.d_probs + L.cstart[C], cnt(C), L.S, L.d_hist, L.d_ops, L.d_end, L.d_len, WV)
+    DS(11, 64, 8, 2); DS(10, 64, 4, 4); DS(9, 64, 1, 8); TB(9, false, 64);
     if (cnt(0) > 0)
         hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((cnt(0) + 63) / 64)), dim3(64), 0, L.cs[0],
                            L.d_probs + L.cstart[0], cnt(0), L.S, L.d_hist, L.d_aux, L.d_ops, L.d_ed, L.d_end, L.d_len, L.d_cols, L.d_cols_off);
-    DS(8, 32, 1, 8); DS(7, 16, 1, 8);
+    DS(8, 32, 1, 8); TB(8, false, 32); DS(7, 16, 1, 8); TB(7, false, 16);
 #undef DS
 #define DL(C, NBV) if (cnt(C) > 0) hipLaunchKernelGGL((lf_edlib_kernel<NBV, PAC>), dim3((unsigned)((cnt(C) + 63) / 64)), dim3(64), 0, L.cs[C], \
-        L.d_probs + L.cstart[C], cnt(C), L.S, L.d_hist, L.d_ops, L.d_ed, L.d_end, L.d_len)
+        L.d_probs + L.cstart[C], cnt(C), L.S, L.d_hist, L.d_ed, L.d_end); TB(C, true, NBV)
     DL(6, 8); DL(5, 6); DL(4, 4); DL(3, 3); DL(2, 2); DL(1, 1);
 #undef DL
+#undef TB
 }
 
 /* runs DIST/PATH problems (cols == nullptr) or COLS problems (cols != nullptr; generic kernel only) given as byte strings */

@@ -7,7 +7,11 @@
 #include <stdio.h>
 #include "lf_internal.h"
 
-#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+/* every checked HIP call leaves its source position in a per-lane slot: LF_WATCHDOG=<seconds> prints them when a batch
+ * does not finish (lf_pipeline.c) */
+extern "C" void lfg_phase(const char *file, int line);
+extern "C" void lfg_phase_dump(void);
+#define HIPCHK(expr) do { lfg_phase(__FILE__, __LINE__); hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     lf_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); return LF_ERR_HIP; } } while (0)
 
 /* device view of the FM-index (all pointers in HBM) */

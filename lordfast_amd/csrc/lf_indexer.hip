@@ -268,6 +268,7 @@ extern "C" int lf_index_build(const char *fasta_path, int device)
     }
 
     HIPCHK(hipSetDevice(device));
+    lfg_quiesce(device);                     /* hipMalloc / hipFree below synchronise the device: see lf_mem.hip */
     hipStream_t s; HIPCHK(hipStreamCreate(&s));
     /* ---- text in HBM ---- */
     uint8_t *d_fwd; uint64_t *d_w;

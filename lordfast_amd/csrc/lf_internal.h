@@ -85,6 +85,10 @@ void *lfg_pin_slot(int slot, size_t bytes);
 void  lfg_slots_release(void);
 void  lfg_set_lane(int lane);          /* calling thread drives lane 0 or 1 (own slots + streams) */
 int   lfg_get_lane(void);
+void  lfg_phase(const char *file, int line);      /* LF_WATCHDOG: where a lane is */
+void  lfg_phase_dump(void);
+void  lfg_quiesce(int device);                     /* per-stream waits before the runtime's own device-wide ones */
+void  lfg_drain_check(int device);                 /* LF_WATCHDOG: name the stream that never drains */
 void *lfg_lane_stream(int device, int which);   /* persistent hipStream_t of the calling thread's lane */
 void *lfg_lane_event(int device, int which);    /* persistent hipEvent_t (timing enabled) of the calling thread's lane; which < 48 */
 /* slot ids */

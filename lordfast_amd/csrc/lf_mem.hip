@@ -4,6 +4,9 @@
  * (a multi-GB hipMalloc costs 10^2 ms; pageable PCIe copies run at a fraction of the pinned rate).
  */
 #include <mutex>
+#include <time.h>
+#include <stdlib.h>
+#include <stdio.h>
 #include "lf_gpu_common.h"
 
 namespace {
@@ -21,6 +24,49 @@ std::mutex g_mu;
  * set of slots and streams, so nothing is shared between them but the index */
 extern "C" void lfg_set_lane(int lane) { t_lane = (lane >= 0 && lane < MAX_LANE) ? lane : 0; }
 extern "C" int lfg_get_lane(void) { return t_lane; }
+static const char *volatile g_ph_file[MAX_LANE]; static volatile int g_ph_line[MAX_LANE];
+extern "C" void lfg_phase(const char *file, int line) { g_ph_file[t_lane] = file; g_ph_line[t_lane] = line; }
+extern "C" void lfg_phase_dump(void)
+{
+    for (int l = 0; l < MAX_LANE; l++) if (g_ph_file[l]) fprintf(stderr, "[lf watchdog] lane %d: last HIP call at %s:%d\n", l, g_ph_file[l], g_ph_line[l]);
+}
+/* Waits for every lane stream of `device`, one hipStreamSynchronize each.  Called before anything that makes the runtime
+ * synchronise the whole device by itself (hipFree, hipMalloc of a regrown slot, index load / release): with the ~10^2
+ * streams of eight lanes in use, ROCm 7.2's device-wide wait can fail to arm its signal handlers
+ * ("hsa_amd_signal_async_handler() failed to set the handler") and then never returns; after explicit per-stream waits it
+ * finds nothing pending.  g_mu must be held by the caller (or no lane may be running). */
+static void quiesce_locked(int device)
+{
+    if (device < 0 || device >= MAX_DEV) return;
+    for (int l = 0; l < MAX_LANE; l++) for (int k = 0; k < 16; k++) if (g_streams[device][l][k]) (void)hipStreamSynchronize(g_streams[device][l][k]);
+}
+extern "C" void lfg_quiesce(int device)
+{
+    std::lock_guard<std::mutex> g(g_mu);
+    if (hipSetDevice(device) != hipSuccess) return;
+    quiesce_locked(device);
+}
+/* LF_WATCHDOG: before device memory is released every lane stream must drain; one that does not within the limit is
+ * named (lane, stream index) and the process aborts instead of hanging inside hipFree */
+extern "C" void lfg_drain_check(int device)
+{
+    const char *w = getenv("LF_WATCHDOG");
+    if (!w || atoi(w) <= 0 || device < 0 || device >= MAX_DEV) return;
+    const int limit_ms = atoi(w) * 1000;
+    for (int waited = 0;; waited += 20) {
+        int busy = 0;
+        { std::lock_guard<std::mutex> g(g_mu);
+          for (int l = 0; l < MAX_LANE; l++) for (int k = 0; k < 16; k++) if (g_streams[device][l][k] && hipStreamQuery(g_streams[device][l][k]) == hipErrorNotReady) busy++; }
+        if (!busy) return;
+        if (waited >= limit_ms) {
+            std::lock_guard<std::mutex> g(g_mu);
+            for (int l = 0; l < MAX_LANE; l++) for (int k = 0; k < 16; k++) if (g_streams[device][l][k] && hipStreamQuery(g_streams[device][l][k]) == hipErrorNotReady)
+                fprintf(stderr, "[lf watchdog] device %d lane %d stream %d still busy after %d s\n", device, l, k, limit_ms / 1000);
+            lfg_phase_dump(); fflush(stderr); abort();
+        }
+        struct timespec ts = { 0, 20 * 1000000 }; nanosleep(&ts, nullptr);
+    }
+}
 extern "C" void *lfg_lane_stream(int device, int which)
 {
     if (device < 0 || device >= MAX_DEV || which < 0 || which >= 16) return nullptr;
@@ -48,7 +94,7 @@ extern "C" void *lfg_dev_slot(int device, int slot, size_t bytes)
     std::lock_guard<std::mutex> g(g_mu);
     slot_t &s = g_dev[device][slot];
     if (bytes + 256 <= s.cap) return s.p;
-    if (s.p) { (void)hipDeviceSynchronize(); (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }
+    if (s.p) { quiesce_locked(device); (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }
     size_t want = bytes + bytes / 4 + 4096;                       /* head-room so that similar batches do not regrow */
     if (hipMalloc(&s.p, want) != hipSuccess) {
         want = bytes + 256;
@@ -65,7 +111,7 @@ extern "C" void *lfg_pin_slot(int slot, size_t bytes)
     std::lock_guard<std::mutex> g(g_mu);
     slot_t &s = g_pin[slot];
     if (bytes + 64 <= s.cap) return s.p;
-    if (s.p) { (void)hipDeviceSynchronize(); (void)hipHostFree(s.p); s.p = nullptr; s.cap = 0; }
+    if (s.p) { for (int d = 0; d < MAX_DEV; d++) quiesce_locked(d); (void)hipHostFree(s.p); s.p = nullptr; s.cap = 0; }
     size_t want = bytes + bytes / 4 + 4096;
     if (hipHostMalloc(&s.p, want, hipHostMallocDefault) != hipSuccess) { lf_set_error("hipHostMalloc of %zu bytes failed (slot %d)", want, slot); s.p = nullptr; return nullptr; }
     s.cap = want;
@@ -75,7 +121,7 @@ extern "C" void *lfg_pin_slot(int slot, size_t bytes)
 extern "C" void lfg_slots_release(void)
 {
     std::lock_guard<std::mutex> g(g_mu);
-    (void)hipDeviceSynchronize();
+    for (int d = 0; d < MAX_DEV; d++) quiesce_locked(d);
     for (int d = 0; d < MAX_DEV; d++) for (int k = 0; k < MAX_SLOT; k++) if (g_dev[d][k].p) { (void)hipSetDevice(d); (void)hipFree(g_dev[d][k].p); g_dev[d][k] = slot_t(); }
     for (int k = 0; k < MAX_SLOT; k++) if (g_pin[k].p) { (void)hipHostFree(g_pin[k].p); g_pin[k] = slot_t(); }
 }

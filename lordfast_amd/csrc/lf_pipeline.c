@@ -1651,8 +1651,10 @@ static void *hsolve_main(void *arg)
     return NULL;
 }
 
+static const char *volatile g_lane_mark[LF_MAX_LANES];        /* LF_WATCHDOG: the last stage mark of every lane */
 static inline void tmark(ctx_t *cx, const char *label)
 {
+    if (cx->lane >= 0 && cx->lane < LF_MAX_LANES) g_lane_mark[cx->lane] = label;
     if (cx->timing && cx->n_marks < 96) { cx->marks[cx->n_marks].label = label; cx->marks[cx->n_marks].t = now_ms(); cx->n_marks++; }
 }
 static void tmark_dump(ctx_t *cx, double t_begin)
@@ -2260,6 +2262,23 @@ static void *lane_main(void *arg_)
     return NULL;
 }
 
+typedef struct { volatile int stop; int limit_s; } wdog_t;
+static void *wdog_main(void *arg)
+{
+    wdog_t *w = (wdog_t *)arg;
+    for (int ms = 0; !w->stop; ms += 50) {
+        struct timespec ts = { 0, 50 * 1000000 }; nanosleep(&ts, NULL);
+        if (ms >= w->limit_s * 1000) {
+            fprintf(stderr, "[lf watchdog] batch still running after %d s\n", w->limit_s);
+            for (int l = 0; l < LF_MAX_LANES; l++) if (g_lane_mark[l]) fprintf(stderr, "[lf watchdog] lane %d: last stage mark %s\n", l, g_lane_mark[l]);
+            lfg_phase_dump();
+            fflush(stderr);
+            abort();
+        }
+    }
+    return NULL;
+}
+
 static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_params_t *p, int n, const char *const *names,
                           const char *const *seqs, const char *const *quals, const uint32_t *seq_lens, char *ext_buf, size_t ext_cap,
                           char **sam, size_t *sam_len, lf_stats_t *stats)
@@ -2368,11 +2387,16 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
         i0 = i1;
     }
     B.n_chunks0 = B.n_chunks;
+    /* LF_WATCHDOG=<seconds>: a batch that takes longer reports where every lane is and aborts (tests set it: a hang
+     * becomes a failure with a location) */
+    wdog_t wd; memset(&wd, 0, sizeof wd); pthread_t wdt; int have_wd = 0;
+    if (getenv("LF_WATCHDOG") && atoi(getenv("LF_WATCHDOG")) > 0) { wd.limit_s = atoi(getenv("LF_WATCHDOG")); have_wd = pthread_create(&wdt, NULL, wdog_main, &wd) == 0; }
     void *la[LF_MAX_LANES][2]; pthread_t lt[LF_MAX_LANES]; int have[LF_MAX_LANES] = { 0 };
     for (int l = 0; l < LF_MAX_LANES; l++) { la[l][0] = &B; la[l][1] = (void *)(intptr_t)l; }
     for (int l = 1; l < n_lanes && l < B.n_chunks; l++) have[l] = pthread_create(&lt[l], NULL, lane_main, la[l]) == 0;
     lane_main(la[0]);
     for (int l = 1; l < n_lanes; l++) if (have[l]) pthread_join(lt[l], NULL);
+    if (have_wd) { wd.stop = 1; pthread_join(wdt, NULL); }
     lfg_set_lane(0);
     if (g_phase_on) { fprintf(stderr, "[lf] batch of %d reads: %.1f ms wall, %d threads\n", n, now_ms() - T0, nt); phase_report(); }
     pthread_mutex_unlock(&g_map_lock);

@@ -96,6 +96,7 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
     if (!getenv("LF_SPIN_WAIT")) { (void)hipSetDevice(ix->device); (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
 
     HIPCHK(hipSetDevice(ix->device));
+    lfg_quiesce(ix->device);                 /* the hipMallocs below synchronise the device: see lf_mem.hip */
     lf_dev_state *st = new lf_dev_state();
     memset(st, 0, sizeof(*st));
     ix->dev = st;
@@ -146,6 +147,9 @@ extern "C" void lfg_index_free(struct lf_index *ix)
     lf_dev_state *st = (lf_dev_state *)ix->dev;
     if (!st) return;
     (void)hipSetDevice(ix->device);
+    lfg_drain_check(ix->device);
+    lfg_quiesce(ix->device);
+    if (st->stream) (void)hipStreamSynchronize(st->stream);
     if (st->bwt) (void)hipFree(st->bwt);
     if (st->sa_sampled) (void)hipFree(st->sa_sampled);
     if (st->sa_full) (void)hipFree(st->sa_full);

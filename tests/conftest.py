@@ -5,6 +5,9 @@
 """
 import gzip
 import os
+
+# a batch that hangs becomes an abort with the position of every lane (lf_pipeline.c), not a stuck test run
+os.environ.setdefault("LF_WATCHDOG", "150")
 import shutil
 import sys
 
@@ -114,3 +117,13 @@ def ref(oracle_lib):
     if not have_ref():
         pytest.skip("oracle/_ref/liblfref.so not built (needs /root/reference)")
     return oracle_lib.Ref()
+
+
+@pytest.fixture(autouse=True)
+def _gpu_streams_drain(request):
+    """After every GPU test all lane streams of device 0 must be idle: a kernel left running would only show up later, as a
+    hang inside some hipMalloc / hipFree (lfg_drain_check names the stream and aborts after LF_WATCHDOG seconds)."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import lordfast_amd.api as api
+        api.lib().lfg_drain_check(0)
