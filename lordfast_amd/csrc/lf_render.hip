@@ -67,12 +67,20 @@ __device__ __forceinline__ char lf_pac_char(const uint8_t *pac, uint32_t pos, in
 #define T_I  2
 #define T_D  3
 
-template <bool WRITE>
+/* MODE 0: counting pass (exact sizes, resolves lazy mismatches in place)   1: writing pass behind it
+ *      2: SINGLE pass -- writes into per-record regions sized by an upper bound (lf_render_caps_kernel), resolves lazy
+ *         mismatches on the fly and reports the exact lengths; the SAM writer copies the text out of the regions anyway,
+ *         so nothing is gained by packing it first. */
+#define LF_RM_COUNT  0
+#define LF_RM_WRITE  1
+#define LF_RM_SINGLE 2
+template <int MODE>
 __global__ void __launch_bounds__(64)
 lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_ritem_t *__restrict__ items, lf_rrounds R,
                  const uint8_t *__restrict__ pac, const unsigned char *__restrict__ reads, uint32_t *__restrict__ lens /* 2 per record */,
                  const uint64_t *__restrict__ offs /* 2 per record (WRITE) */, char *__restrict__ text)
 {
+    constexpr bool WRITE = MODE != LF_RM_COUNT, RESOLVE = MODE != LF_RM_WRITE;
     const int rec = blockIdx.x;
     if (rec >= n_recs) return;
     const int lane = threadIdx.x;
@@ -104,7 +112,7 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
     };
     auto desc_of = [&](const lf_ritem_t &X) -> lf_aln_desc_t {
         lf_aln_desc_t d; d.qstart = 0; d.tstart = 0; d.flags = 0; d.n = d.m = 0; d.mode = 0;
-        if (!WRITE && X.n != 0 && X.kind >= LF_RI_OPS_FWD && X.kind <= LF_RI_OPS_REV && X.lazy) d = R.desc[X.round][X.slot];
+        if (RESOLVE && X.n != 0 && X.kind >= LF_RI_OPS_FWD && X.kind <= LF_RI_OPS_REV && X.lazy) d = R.desc[X.round][X.slot];
         return d;
     };
     lf_ritem_t Inext; memset(&Inext, 0, sizeof Inext);
@@ -144,12 +152,12 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
             const uint32_t cnt = (I.n - base < 64u) ? I.n - base : 64u;
             int ty = T_EQ;
             if (act) { const uint8_t op = base == 0 ? op_first : ops[rev ? I.n - 1 - k : k]; ty = op == 0 ? T_EQ : op == 1 ? T_I : op == 2 ? T_D : T_X; }
-            if (I.lazy && !WRITE) {          /* the counting pass resolves and writes the mismatches back: the writing pass reads final ops */
+            if (I.lazy && RESOLVE) {         /* the counting pass resolves and writes the mismatches back: the writing pass reads final ops */
                 const uint64_t nd_mask = __ballot(act && ty != T_D), ni_mask = __ballot(act && ty != T_I);
                 if (act && ty == T_EQ) {
                     const uint32_t qe = qcarry + (uint32_t)__popcll(nd_mask & below), te = tcarry + (uint32_t)__popcll(ni_mask & below);
                     const uint32_t qi = rev ? I.qn - 1 - qe : qe, ti2 = rev ? I.tcons - 1 - te : te;
-                    if (QA.get(qi) != TA.get(ti2)) { ty = T_X; const_cast<uint8_t *>(ops)[rev ? I.n - 1 - k : k] = 3; }
+                    if (QA.get(qi) != TA.get(ti2)) { ty = T_X; if (MODE == LF_RM_COUNT) const_cast<uint8_t *>(ops)[rev ? I.n - 1 - k : k] = 3; }
                 }
                 qcarry += (uint32_t)__popcll(nd_mask);
             }
@@ -212,7 +220,26 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
         if (WRITE && lane == 0) { lf_put_token(md + m_out, m_num, nd, 0, 0); cg[c_out] = 0; }
         m_out += nd;
     }
-    if (!WRITE && lane == 0) { lens[2 * rec] = c_out + 1; lens[2 * rec + 1] = m_out + 1; }      /* + NUL */
+    if (MODE != LF_RM_WRITE && lane == 0) { lens[2 * rec] = c_out + 1; lens[2 * rec + 1] = m_out + 1; }      /* + NUL */
+}
+
+/* upper bounds of a record's CIGAR and MD text (single-pass mode).  A run of L ops prints digits(L) + 1 <= 2 L characters;
+ * an MD token is digits(matches before it) + 2 characters at most and every match is counted by one token only:
+ * CIGAR <= 2 ops + 11 per item, MD <= 3 ops + 11 per item + the deleted bases of the pure-deletion items. */
+__global__ void lf_render_caps_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_ritem_t *__restrict__ items, uint32_t *__restrict__ caps /* 2 per record */)
+{
+    const int rec = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
+    if (rec >= n_recs) return;
+    const lf_rrecord_t rr = recs[rec];
+    uint32_t cg = 0, md = 0;
+    for (uint32_t it = lane; it < rr.nitems; it += 64) {
+        const lf_ritem_t I = items[rr.item0 + it];
+        cg += 11; md += 11;
+        if (I.kind >= LF_RI_OPS_FWD && I.kind <= LF_RI_OPS_REV) { cg += 2 * I.n; md += 3 * I.n; }
+        else if (I.kind == LF_RI_DEL) md += I.n;
+    }
+    for (int o = 32; o > 0; o >>= 1) { cg += __shfl_xor(cg, o); md += __shfl_xor(md, o); }
+    if (lane == 0) { caps[2 * rec] = (cg + 16 + 7) & ~7u; caps[2 * rec + 1] = (md + 16 + 7) & ~7u; }
 }
 
 struct lf_widen32 { __host__ __device__ uint64_t operator()(uint32_t v) const { return v; } };
@@ -268,19 +295,26 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_dev_recs, const void 
         HIPCHK(hipMemcpyAsync(d_items + n_dev_items, items, (size_t)n_host_items * sizeof(lf_ritem_t), hipMemcpyHostToDevice, s));
     }
     HIPCHK(hipEventRecord(e0, s));
-    hipLaunchKernelGGL(lf_render_kernel<false>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac, d_reads,
-                       d_lens, (const uint64_t *)nullptr, (char *)nullptr);
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, in, d_offs, 2 * n_recs, s));
+    const bool single = dev_text != nullptr && !getenv("LF_RENDER_TWO_PASS");      /* the two-pass form stays for the host-side consumers (packed text) */
+    uint32_t *d_caps = single ? (uint32_t *)lfg_dev_slot(device, LF_DS_RENDER0 + 6, (size_t)n_recs * 8) : d_lens;
+    if (!d_caps) return LF_ERR_NOMEM;
+    hipcub::TransformInputIterator<uint64_t, lf_widen32, uint32_t *> in_caps(d_caps, lf_widen32());
+    if (single) hipLaunchKernelGGL(lf_render_caps_kernel, dim3((unsigned)((n_recs + 3) / 4)), dim3(256), 0, s, d_recs, n_recs, d_items, d_caps);
+    else hipLaunchKernelGGL(lf_render_kernel<LF_RM_COUNT>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac, d_reads,
+                            d_lens, (const uint64_t *)nullptr, (char *)nullptr);
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, in_caps, d_offs, 2 * n_recs, s));
     HIPCHK(hipMemcpyAsync(h_offs, d_offs, (size_t)n_recs * 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h_tail, d_lens + 2 * (size_t)n_recs - 1, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_tail, d_caps + 2 * (size_t)n_recs - 1, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const uint64_t total = h_offs[2 * (size_t)n_recs - 1] + h_tail[0];
     char *d_text = (char *)lfg_dev_slot(device, LF_DS_RENDER0 + 5, total + 64);
     char *h_text = dev_text ? nullptr : (char *)lfg_pin_slot(LF_PS_RENDER0 + 2, total + 64);
     uint32_t *h_lens = dev_text ? (uint32_t *)lfg_pin_slot(LF_PS_RENDER0 + 3, (size_t)n_recs * 8 + 16) : nullptr;
     if (!d_text || (!dev_text && !h_text) || (dev_text && !h_lens)) return LF_ERR_NOMEM;
-    hipLaunchKernelGGL(lf_render_kernel<true>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac, d_reads,
-                       d_lens, (const uint64_t *)d_offs, d_text);
+    if (single) hipLaunchKernelGGL(lf_render_kernel<LF_RM_SINGLE>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac, d_reads,
+                                   d_lens, (const uint64_t *)d_offs, d_text);
+    else hipLaunchKernelGGL(lf_render_kernel<LF_RM_WRITE>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac, d_reads,
+                            d_lens, (const uint64_t *)d_offs, d_text);
     HIPCHK(hipEventRecord(e1, s));
     if (dev_text) HIPCHK(hipMemcpyAsync(h_lens, d_lens, (size_t)n_recs * 8, hipMemcpyDeviceToHost, s));      /* SA:Z strings need a few CIGARs (lfg_fetch) */
     else HIPCHK(hipMemcpyAsync(h_text, d_text, total, hipMemcpyDeviceToHost, s));
