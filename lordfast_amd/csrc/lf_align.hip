@@ -263,7 +263,7 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
                     uint64_t ph, mh;
                     hout[b] = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
                     const bool inr = c <= m;
-                    score += (b == lastb && inr) ? lf_delta_at(ph, mh, lastbit) : 0;
+                    if (b >= (NB <= 4 ? NB - 1 : NB - 2)) score += (b == lastb && inr) ? lf_delta_at(ph, mh, lastbit) : 0;      /* lf_class_of: the last block of a class-NB problem */
                     if (b >= 1) cw[b] |= hin << (((c - 1) & 15u) * 2);      /* scalar shift amount */
                     /* checkpoint: the state after every K-th column (one 1 KiB line per wave, block and checkpoint) */
                     if ((c & (K - 1)) == 0) {                               /* wave-uniform */
@@ -548,13 +548,15 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     };
     /* one sweep step s (TILE: (Pv, Ph) of the step go to LDS row s - s0) */
     int score = 0, best = 0, best_c = 0;
-    auto sweep_step = [&](int s, auto track_c, auto tile_c, int s0) {
+    /* the bottom-row score is followed column by column only when a problem of the wavefront asks for the best prefix (SHW);
+     * the NW distance is read off the last column afterwards, and the Hirschberg passes use neither */
+    bool track_shw = __any(live && pr.mode != 0);
+    auto sweep_step = [&](int s, auto track_c, auto tile_c, int s0, uint32_t byte) {
         constexpr bool track = decltype(track_c)::value, tile = decltype(tile_c)::value;
         const uint32_t from_left = lf_wave_shr1(hout_prev);
-        if (track && KB == 1) cw |= from_left << ((s & (K - 1)) * 2);      /* scalar shift amount */
+        if (!tile && KB == 1) cw |= from_left << ((s & (K - 1)) * 2);      /* forward passes; scalar shift amount */
         const int c = s - gl + 1;
         if (gl < nl && c >= 1 && c <= (int)m) {
-            const uint32_t byte = my_t[(c - 1) & (TC - 1)];
             const uint32_t tok = PAC ? byte : lf_tok_of_byte((unsigned char)byte);
             uint32_t hin = gl == 0 ? LF_HIN_PLUS1 : from_left;
 #pragma unroll
@@ -581,9 +583,14 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
         score = (int)n; best = (n & 63) ? (int)n : 0x7fffffff; best_c = 0;
         const int steps = (int)m + nl - 1;
         const int steps_max = G == 64 ? steps : lf_wave_max_i32(steps);
+        /* the lane's target symbol is read from the LDS ring ONE STEP AHEAD: the ds_read latency hides behind the step's ALU chain */
+        __syncthreads(); stage_window(0, H); __syncthreads(); ring_lo = 0;
+        uint32_t sym = my_t[(0 - gl) & (TC - 1)];
         for (int s = 0; s < steps_max; s++) {
-            if ((s & (H - 1)) == 0) { __syncthreads(); stage_window(s, H); __syncthreads(); ring_lo = s >= H ? s - H : 0; }
-            sweep_step(s, std::true_type(), std::false_type(), 0);
+            if (((s + 1) & (H - 1)) == 0) { __syncthreads(); stage_window(s + 1, H); __syncthreads(); ring_lo = s + 1 >= H ? s + 1 - H : 0; }
+            const uint32_t sym_next = my_t[(s + 1 - gl) & (TC - 1)];
+            if (track_shw) sweep_step(s, std::true_type(), std::false_type(), 0, sym); else sweep_step(s, std::false_type(), std::false_type(), 0, sym);
+            sym = sym_next;
             if (want_ck && ((s + 1) & (K - 1)) == 0) {
                 const size_t j = (size_t)((s + 1) / K - 1);
                 lf_hist_t *row = ck + j * ROW;
@@ -630,7 +637,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
             /* target columns of this tile: the ring still holds them unless the walk has moved left of it */
             if (s0 - G + 1 < ring_lo) { ring_lo = s0 + K > H ? s0 + K - H : 0; stage_window(ring_lo, H); __syncthreads(); }      /* H >= G + K - 1 columns: the tile's and the next ones' */
             const int s1 = s0 + K < steps_max ? s0 + K : steps_max;
-            for (int s = s0; s < s1; s++) sweep_step(s, std::false_type(), std::true_type(), s0);
+            for (int s = s0; s < s1; s++) sweep_step(s, std::false_type(), std::true_type(), s0, (uint32_t)my_t[(s - gl) & (TC - 1)]);
             __syncthreads();
             for (;;) {
                 const bool act = scur >= s0;
@@ -663,7 +670,24 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     }
     int steps_max = forward(want_path && root_leaf);
     const int src_last = g * G + lane_last;
-    const int ed_nw = __shfl(score, src_last), ed_shw = __shfl(best, src_last), c_shw = __shfl(best_c, src_last);
+    int ed_nw = __shfl(score, src_last);
+    const int ed_shw = __shfl(best, src_last), c_shw = __shfl(best_c, src_last);
+    if (!track_shw) {       /* D[n][m] = m + the vertical deltas of the last column (every lane stopped at column m) */
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+            const uint32_t b = (uint32_t)gl * KB + k;
+            if (b < nbk) {
+                const uint32_t rows = (b == lastb) ? (uint32_t)lastbit + 1 : 64;
+                const uint64_t msk = rows >= 64 ? ~0ull : ((1ull << rows) - 1);
+                mine += __popcll(Pv[k] & msk) - __popcll(Mv[k] & msk);
+            }
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+        ed_nw = (int)m + mine;
+    }
+    track_shw = false;
     int ed, tl;
     if (pr.mode == 0) { ed = ed_nw; tl = (int)m; } else { ed = ed_shw; tl = c_shw; }
     if (live && gl == 0) { out_ed[pr.id] = ed; out_end[pr.id] = tl - 1; }

@@ -250,7 +250,7 @@ typedef struct ctx {
     int host_cigar;                 /* LF_HOST_CIGAR=1: build CIGAR / MD on the host from copied-back paths (cross-check) */
     char *rtext; uint64_t *roffs; int *rrbase;      /* rendered text, per-record offsets, first record of each worker */
     int n_dev_recs; uint64_t n_dev_items; void *d_dev_recs, *d_dev_items;       /* the device-planned recipe (lf_walk.hip): records 0 .. n_dev_recs-1 */
-    int dev_sam; lfg_rtext_t rtext_dev; uint32_t *rlens; uint64_t sam_total;       /* SAM lines assembled on the device (lf_sam.hip): text size of the chunk */
+    int dev_sam; lfg_rtext_t rtext_dev; uint32_t *rlens; uint64_t sam_total; int sam_parity;       /* SAM lines assembled on the device (lf_sam.hip): text size of the chunk */
     /* output assembly */
     char *out_base; uint64_t *out_off;
     const char *const *len_seqs; uint32_t *len_out;
@@ -2077,7 +2077,7 @@ extend:
             uint64_t o = 0;
             for (int i = 0; i < n; i++) { const rd_t *r = &cx->reads[i]; if ((int)r->len < cx->p->min_read_len) continue; if (r->isFq) memcpy(qcat + o, r->qual, r->len); else memset(qcat + o, '*', r->len); o += r->len; }
         }
-        rc = lfg_sam_build(cx->ix, cx->p, V.n, V.ln, V.names, V.nn, V.blob, V.nb, qcat, qbytes, &cx->rtext_dev, &cx->sam_total);
+        rc = lfg_sam_build(cx->ix, cx->p, V.n, V.ln, V.names, V.nn, V.blob, V.nb, qcat, qbytes, &cx->rtext_dev, cx->sam_parity, &cx->sam_total);
         free(V.ln); free(V.blob); free(V.names); free(qcat);
         if (rc != LF_OK) return rc;
     } else parallel_for(cx, n, phase_sam_print);
@@ -2142,6 +2142,58 @@ static void merge_stats(lf_stats_t *d, const lf_stats_t *a)
     d->dp_block_steps += a->dp_block_steps; d->ms_render += a->ms_render; d->ms_k_render += a->ms_k_render; d->ms_k_vote += a->ms_k_vote; d->ops_bytes += a->ops_bytes; d->n_req_seeds += a->n_req_seeds; d->n_tie_requests += a->n_tie_requests; d->render_bytes += a->render_bytes; d->render_launches += a->render_launches;
 }
 
+/* base offset of a chunk's text = the sizes of all chunks of earlier reads.  block == 0: returns 0 when one of them has not
+ * published its size yet (entries can be added while we wait: rescan after every wake-up) */
+static int chunk_base(batch_t *B, const chunk_t *C, int block, uint64_t *base_out)
+{
+    pthread_mutex_lock(&B->mu);
+    uint64_t base;
+    for (;;) {
+        int waiting = 0; base = 0;
+        for (int j = 0; j < B->n_chunks; j++) {
+            if (B->chunks[j].i1 > C->i0) continue;
+            if (!B->chunks[j].sized) { waiting = 1; break; }
+            base += B->chunks[j].size;
+        }
+        if (!waiting) break;
+        if (!block) { pthread_mutex_unlock(&B->mu); return 0; }
+        pthread_cond_wait(&B->cv, &B->mu);
+    }
+    pthread_mutex_unlock(&B->mu);
+    *base_out = base;
+    return 1;
+}
+/* makes room for [base, base + tot] in the batch's output and holds the read lock on return (rc: B->rc) */
+static void out_reserve(batch_t *B, uint64_t base, uint64_t tot)
+{
+    pthread_rwlock_rdlock(&B->grow);
+    if (base + tot + 1 > B->all.cap) {          /* rare: the up-front estimate was too small */
+        pthread_rwlock_unlock(&B->grow);
+        pthread_rwlock_wrlock(&B->grow);
+        if (base + tot + 1 > B->all.cap) {
+            if (B->fixed_out) { snprintf(B->err, sizeof B->err, "lf_map_batch_into: output buffer too small (need more than %llu bytes)", (unsigned long long)(base + tot + 1)); B->rc = LF_ERR_NOMEM; }
+            else { size_t nc = (size_t)((base + tot + 1) * 1.25) + 4096; B->all.s = (char *)realloc(B->all.s, nc); B->all.cap = nc; }
+        }
+        pthread_rwlock_unlock(&B->grow);
+        pthread_rwlock_rdlock(&B->grow);
+    }
+}
+/* a chunk whose SAM text is complete in one of the lane's two device buffers but whose place in the output is not known
+ * yet (an earlier chunk is still being mapped by another lane): the lane maps its next chunk first */
+typedef struct { const chunk_t *C; const lf_index_t *ix; uint64_t tot; int parity, active; } pending_t;
+static void fetch_dev_sam(batch_t *B, const lf_index_t *ix, uint64_t base, uint64_t tot, int parity, lf_stats_t *st)
+{
+    if (B->rc != LF_OK) return;
+    const double t0 = now_ms();
+    out_reserve(B, base, tot);
+    if (B->rc == LF_OK) {               /* one D2H copy of the chunk's text straight into its place */
+        const int frc = lfg_sam_fetch(ix, B->all.s + base, tot, parity);
+        if (frc != LF_OK) { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = frc; }
+    }
+    pthread_rwlock_unlock(&B->grow);
+    st->ms_sam += now_ms() - t0;
+}
+
 static void *lane_main(void *arg_)
 {
     batch_t *B = (batch_t *)((void **)arg_)[0];
@@ -2153,6 +2205,8 @@ static void *lane_main(void *arg_)
     uint64_t max_hits = 1ull << 30;
     if (getenv("LF_MAX_CHUNK_HITS")) { max_hits = strtoull(getenv("LF_MAX_CHUNK_HITS"), NULL, 10); if (max_hits < 1) max_hits = 1; }   /* test hook */
     int todo[64], n_todo = 0;                       /* second halves of chunks this lane had to cut */
+    pending_t pend; memset(&pend, 0, sizeof pend);
+    int parity = 0;
     for (;;) {
         int k;
         if (n_todo > 0) k = todo[--n_todo];
@@ -2174,6 +2228,7 @@ static void *lane_main(void *arg_)
         cx.ix = B->ixs[lane % B->n_ix]; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane]; cx.host_cigar = B->host_cigar; cx.host_vote = B->host_vote; cx.lazy = !B->host_cigar && !getenv("LF_NO_LAZY");
         cx.max_chunk_hits = max_hits;
         cx.dev_sam = !B->host_cigar && !B->host_vote && !getenv("LF_HOST_SAM");
+        cx.sam_parity = parity;
         cx.n_reads = C->i1 - C->i0;
         cx.reads = (rd_t *)calloc((size_t)cx.n_reads, sizeof(rd_t));
         uint64_t chunk_bases = 0;
@@ -2210,47 +2265,39 @@ static void *lane_main(void *arg_)
             if (cx.dev_sam) tot = cx.sam_total;
             else for (int i = 0; i < cx.n_reads; i++) { ooff[i] = tot; tot += cx.reads[i].out.n; }
         } else { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = rc; }
-        /* publish this chunk's size, then wait for the sizes of all chunks of earlier reads: base offset of our text.
-         * (entries can be added while we wait: rescan after every wake-up) */
+        /* publish this chunk's size */
         pthread_mutex_lock(&B->mu);
         C->size = tot; C->sized = 1;
         pthread_cond_broadcast(&B->cv);
-        uint64_t base;
-        for (;;) {
-            int waiting = 0; base = 0;
-            for (int j = 0; j < B->n_chunks; j++) {
-                if (B->chunks[j].i1 > C->i0) continue;
-                if (!B->chunks[j].sized) { waiting = 1; break; }
-                base += B->chunks[j].size;
-            }
-            if (!waiting) break;
-            pthread_cond_wait(&B->cv, &B->mu);
-        }
         pthread_mutex_unlock(&B->mu);
-        if (rc == LF_OK && B->rc == LF_OK) {
-            tch = now_ms();
-            pthread_rwlock_rdlock(&B->grow);
-            if (base + tot + 1 > B->all.cap) {          /* rare: the up-front estimate was too small */
-                pthread_rwlock_unlock(&B->grow);
-                pthread_rwlock_wrlock(&B->grow);
-                if (base + tot + 1 > B->all.cap) {
-                    if (B->fixed_out) { snprintf(B->err, sizeof B->err, "lf_map_batch_into: output buffer too small (need more than %llu bytes)", (unsigned long long)(base + tot + 1)); B->rc = LF_ERR_NOMEM; }
-                    else { size_t nc = (size_t)((base + tot + 1) * 1.25) + 4096; B->all.s = (char *)realloc(B->all.s, nc); B->all.cap = nc; }
+        if (cx.dev_sam) {
+            /* The text sits in device buffer `parity`.  Its place in the output is known once every chunk of earlier reads has
+             * published its size; lanes finish out of order, so instead of waiting here the lane keeps ONE chunk pending and
+             * maps the next one (into the other buffer).  The older pending chunk must leave its buffer first. */
+            uint64_t base;
+            if (pend.active) { (void)chunk_base(B, pend.C, 1, &base); fetch_dev_sam(B, pend.ix, base, pend.tot, pend.parity, st); pend.active = 0; }
+            if (rc == LF_OK) {
+                if (chunk_base(B, C, 0, &base)) fetch_dev_sam(B, cx.ix, base, tot, parity, st);
+                else {
+                    pend.C = C; pend.ix = cx.ix; pend.tot = tot; pend.parity = parity; pend.active = 1;
+                    const int wrc = lfg_sam_wait(cx.ix);       /* the writer kernel still reads this chunk's buffers */
+                    if (wrc != LF_OK) { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = wrc; }
                 }
-                pthread_rwlock_unlock(&B->grow);
-                pthread_rwlock_rdlock(&B->grow);
+                parity ^= 1;
             }
-            if (B->rc == LF_OK) {
-                if (cx.dev_sam) {               /* one D2H copy of the chunk's text straight into its place */
-                    const int frc = lfg_sam_fetch(cx.ix, B->all.s + base, tot);
-                    if (frc != LF_OK) { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = frc; }
-                } else {
+        } else {
+            uint64_t base;
+            (void)chunk_base(B, C, 1, &base);
+            if (rc == LF_OK && B->rc == LF_OK) {
+                tch = now_ms();
+                out_reserve(B, base, tot);
+                if (B->rc == LF_OK) {
                     cx.out_base = B->all.s + base; cx.out_off = ooff;
                     parallel_for(&cx, cx.n_reads, phase_sam_print);
                 }
+                pthread_rwlock_unlock(&B->grow);
+                st->ms_sam += now_ms() - tch;
             }
-            pthread_rwlock_unlock(&B->grow);
-            st->ms_sam += now_ms() - tch;
         }
         free(ooff);
         tch = now_ms();
@@ -2258,6 +2305,7 @@ static void *lane_main(void *arg_)
         free(cx.reads);
         if (timing) fprintf(stderr, "[lf] lane %d chunk %d: chunk_free %.1f ms\n", lane, k, now_ms() - tch);
     }
+    if (pend.active) { uint64_t base; (void)chunk_base(B, pend.C, 1, &base); fetch_dev_sam(B, pend.ix, base, pend.tot, pend.parity, st); }
     if (g_phase_on) phase_account("(lane driver threads, incl. their share of the phases)", (thread_cpu_ns() - lane_c0) / 1e6, 0);
     return NULL;
 }

@@ -122,7 +122,7 @@ lf_sam_write_kernel(lf_sam_dev D, const uint64_t *__restrict__ offs, char *__res
  * on the lane's stream and fetched with lfg_sam_fetch once the caller knows where it goes. */
 extern "C" int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, int n_lines, const lf_samline_t *lines,
                              const char *names, uint64_t names_bytes, const char *blob, uint64_t blob_bytes,
-                             const char *quals, uint64_t quals_bytes, const lfg_rtext_t *rt, uint64_t *total_out)
+                             const char *quals, uint64_t quals_bytes, const lfg_rtext_t *rt, int parity, uint64_t *total_out)
 {
     *total_out = 0;
     if (n_lines == 0) return LF_OK;
@@ -183,7 +183,7 @@ extern "C" int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, in
     HIPCHK(hipMemcpyAsync(h + 1, d_lens + (N - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const uint64_t total = h[0] + h[1];
-    char *d_out = SSLOT(char, 8, total + 64);
+    char *d_out = SSLOT(char, 8 + (parity & 1), total + 64);      /* two text buffers: the previous chunk's may still wait for its place in the output */
     if (!d_out) return LF_ERR_NOMEM;
     hipLaunchKernelGGL(lf_sam_write_kernel, dim3((unsigned)n_lines), dim3(64), 0, s, D, (const uint64_t *)d_offs, d_out);
     HIPCHK(hipGetLastError());
@@ -191,15 +191,28 @@ extern "C" int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, in
     return LF_OK;
 }
 
-/* the text of the last lfg_sam_build of this lane -> dst (host; pinned memory copies at link speed) */
-extern "C" int lfg_sam_fetch(const struct lf_index *ix, char *dst, uint64_t total)
+/* waits until the text of the lane's last lfg_sam_build is complete in its buffer (the kernels read the chunk's reads,
+ * names and CIGAR / MD text: the next chunk may only overwrite those afterwards) */
+extern "C" int lfg_sam_wait(const struct lf_index *ix)
+{
+    const int dv = ix->device;
+    HIPCHK(hipSetDevice(dv));
+    hipStream_t s = (hipStream_t)lfg_lane_stream(dv, 1);
+    if (!s) return LF_ERR_HIP;
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return LF_OK;
+}
+
+/* the text of this lane's last lfg_sam_build with the same parity -> dst (host; pinned memory copies at link speed) */
+extern "C" int lfg_sam_fetch(const struct lf_index *ix, char *dst, uint64_t total, int parity)
 {
     if (!total) return LF_OK;
     const int dv = ix->device;
     HIPCHK(hipSetDevice(dv));
     hipStream_t s = (hipStream_t)lfg_lane_stream(dv, 1);
     if (!s) return LF_ERR_HIP;
-    const char *d_out = (const char *)lfg_dev_slot(dv, LF_DS_SAM0 + 8, 0);
+    const char *d_out = (const char *)lfg_dev_slot(dv, LF_DS_SAM0 + 8 + (parity & 1), 0);
     if (!d_out) { lf_set_error("lfg_sam_fetch: nothing was built"); return LF_ERR_ARG; }
     HIPCHK(hipMemcpyAsync(dst, d_out, total, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
