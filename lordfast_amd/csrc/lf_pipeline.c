@@ -2418,11 +2418,11 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     int CHUNK_READS = 32768;
     if (getenv("LF_CHUNK_READS")) { CHUNK_READS = atoi(getenv("LF_CHUNK_READS")); if (CHUNK_READS < 1) CHUNK_READS = 1; }   /* test hook */
     else if (n_lanes >= 2 && n > 2048) {
-        /* three chunks per lane: the lanes start in lockstep (all seeding, then all extending) and only drift apart from
-         * their second chunk on, and the last generation drains unevenly -- measured at 100 k reads / 8 lanes: 2 per lane
-         * 357-369 ms, 3 per lane 333-342 ms, 4 per lane 352 ms, 6 per lane 414 ms (per-chunk round trips take over).
-         * Unequal first chunks (to break the lockstep at once) were tried and lost: the grow-only slots keep growing. */
-        int want = (n + 3 * n_lanes - 1) / (3 * n_lanes); if (want < 1024) want = 1024;
+        /* two chunks per lane.  Round 1 measured 3 per lane as the optimum (2: 357-369 ms, 3: 333-342 ms, 4: 352 ms, 6: 414 ms per
+         * 100 k reads on 8 lanes) when every lane waited for the chunks of earlier reads before it took its next one; now
+         * that a finished chunk may stay pending (lane_main) larger chunks win: 100 k reads / 8 lanes, same box, chunks of
+         * 3125 / 4167 / 5000 / 6250 reads: 586 / 609 / 642 / 670 k reads/s; 6250 ... 12500 within the noise of each other. */
+        int want = (n + 2 * n_lanes - 1) / (2 * n_lanes); if (want < 1024) want = 1024;
         if (want < CHUNK_READS) CHUNK_READS = want;
     }
     /* reads x sampling positions is a 31-bit index in the seed stage */
