@@ -154,6 +154,8 @@ int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, int n_lines, 
                   const char *quals, uint64_t quals_bytes, const lfg_rtext_t *rt, int parity, uint64_t *total_out);
 int lfg_sam_fetch(const struct lf_index *ix, char *dst, uint64_t total, int parity);
 int lfg_sam_wait(const struct lf_index *ix);
+int lfg_sam_fetch_async(const struct lf_index *ix, char *dst, uint64_t total, int parity);
+int lfg_sam_fetch_wait(const struct lf_index *ix);
 int lfg_fetch(int device, void *dst, const void *src_dev, size_t bytes);
 int lfg_upload(int device, void *dst_dev, const void *src, size_t bytes);
 #define LF_F_QREV  1u

@@ -2187,7 +2187,9 @@ static void fetch_dev_sam(batch_t *B, const lf_index_t *ix, uint64_t base, uint6
     const double t0 = now_ms();
     out_reserve(B, base, tot);
     if (B->rc == LF_OK) {               /* one D2H copy of the chunk's text straight into its place */
-        const int frc = lfg_sam_fetch(ix, B->all.s + base, tot, parity);
+        /* a caller-provided buffer never moves: the copy runs behind the lane's back (lfg_sam_fetch_wait at the lane's end);
+         * a growable one may be reallocated by another lane, so the copy completes under the read lock */
+        const int frc = B->fixed_out ? lfg_sam_fetch_async(ix, B->all.s + base, tot, parity) : lfg_sam_fetch(ix, B->all.s + base, tot, parity);
         if (frc != LF_OK) { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = frc; }
     }
     pthread_rwlock_unlock(&B->grow);
@@ -2280,8 +2282,7 @@ static void *lane_main(void *arg_)
                 if (chunk_base(B, C, 0, &base)) fetch_dev_sam(B, cx.ix, base, tot, parity, st);
                 else {
                     pend.C = C; pend.ix = cx.ix; pend.tot = tot; pend.parity = parity; pend.active = 1;
-                    const int wrc = lfg_sam_wait(cx.ix);       /* the writer kernel still reads this chunk's buffers */
-                    if (wrc != LF_OK) { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = wrc; }
+                    /* the writer kernel still reads this chunk's buffers: the next chunk's first stream waits for it (lfg_sam_build) */
                 }
                 parity ^= 1;
             }
@@ -2306,6 +2307,12 @@ static void *lane_main(void *arg_)
         if (timing) fprintf(stderr, "[lf] lane %d chunk %d: chunk_free %.1f ms\n", lane, k, now_ms() - tch);
     }
     if (pend.active) { uint64_t base; (void)chunk_base(B, pend.C, 1, &base); fetch_dev_sam(B, pend.ix, base, pend.tot, pend.parity, st); }
+    if (B->fixed_out && !B->host_cigar && !B->host_vote) {      /* the asynchronous copies of this lane */
+        const double t0 = now_ms();
+        const int wrc = lfg_sam_fetch_wait(B->ixs[lane % B->n_ix]);
+        if (wrc != LF_OK && B->rc == LF_OK) { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = wrc; }
+        st->ms_sam += now_ms() - t0;
+    }
     if (g_phase_on) phase_account("(lane driver threads, incl. their share of the phases)", (thread_cpu_ns() - lane_c0) / 1e6, 0);
     return NULL;
 }

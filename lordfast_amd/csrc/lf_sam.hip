@@ -185,8 +185,17 @@ extern "C" int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, in
     const uint64_t total = h[0] + h[1];
     char *d_out = SSLOT(char, 8 + (parity & 1), total + 64);      /* two text buffers: the previous chunk's may still wait for its place in the output */
     if (!d_out) return LF_ERR_NOMEM;
+    /* events of this buffer: E = text written, F = text copied out (lfg_sam_fetch_async).  The writer waits for the copy of the
+     * buffer's previous text; the seed stream -- the first one the NEXT chunk touches, with the upload of its reads -- waits
+     * for the writer, which still reads this chunk's batch.  No host wait anywhere. */
+    hipEvent_t E = (hipEvent_t)lfg_lane_event(dv, 42 + (parity & 1)), F = (hipEvent_t)lfg_lane_event(dv, 44 + (parity & 1));
+    hipStream_t s0 = (hipStream_t)lfg_lane_stream(dv, 0);
+    if (!E || !F || !s0) return LF_ERR_HIP;
+    HIPCHK(hipStreamWaitEvent(s, F, 0));
     hipLaunchKernelGGL(lf_sam_write_kernel, dim3((unsigned)n_lines), dim3(64), 0, s, D, (const uint64_t *)d_offs, d_out);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(E, s));
+    HIPCHK(hipStreamWaitEvent(s0, E, 0));
     *total_out = total;
     return LF_OK;
 }
@@ -200,6 +209,34 @@ extern "C" int lfg_sam_wait(const struct lf_index *ix)
     hipStream_t s = (hipStream_t)lfg_lane_stream(dv, 1);
     if (!s) return LF_ERR_HIP;
     HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    return LF_OK;
+}
+
+/* asynchronous form of lfg_sam_fetch: the copy runs on the lane's copy stream behind the writer kernel; the lane maps its
+ * next chunk meanwhile.  dst must stay valid (and should be pinned) until lfg_sam_fetch_wait. */
+extern "C" int lfg_sam_fetch_async(const struct lf_index *ix, char *dst, uint64_t total, int parity)
+{
+    if (!total) return LF_OK;
+    const int dv = ix->device;
+    HIPCHK(hipSetDevice(dv));
+    hipStream_t cs = (hipStream_t)lfg_lane_stream(dv, 14);
+    hipEvent_t E = (hipEvent_t)lfg_lane_event(dv, 42 + (parity & 1)), F = (hipEvent_t)lfg_lane_event(dv, 44 + (parity & 1));
+    if (!cs || !E || !F) return LF_ERR_HIP;
+    const char *d_out = (const char *)lfg_dev_slot(dv, LF_DS_SAM0 + 8 + (parity & 1), 0);
+    if (!d_out) { lf_set_error("lfg_sam_fetch_async: nothing was built"); return LF_ERR_ARG; }
+    HIPCHK(hipStreamWaitEvent(cs, E, 0));
+    HIPCHK(hipMemcpyAsync(dst, d_out, total, hipMemcpyDeviceToHost, cs));
+    HIPCHK(hipEventRecord(F, cs));
+    return LF_OK;
+}
+extern "C" int lfg_sam_fetch_wait(const struct lf_index *ix)
+{
+    const int dv = ix->device;
+    HIPCHK(hipSetDevice(dv));
+    hipStream_t cs = (hipStream_t)lfg_lane_stream(dv, 14);
+    if (!cs) return LF_ERR_HIP;
+    HIPCHK(hipStreamSynchronize(cs));
     HIPCHK(hipGetLastError());
     return LF_OK;
 }
