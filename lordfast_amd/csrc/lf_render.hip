@@ -321,7 +321,9 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_dev_recs, const void 
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
-    *text_out = h_text; *offs_out = h_offs; *text_bytes = total;
+    uint64_t used = total;
+    if (single) { used = 0; for (size_t i = 0; i < 2 * (size_t)n_recs; i++) used += h_lens[i]; }      /* the regions are upper bounds: report the text itself */
+    *text_out = h_text; *offs_out = h_offs; *text_bytes = used;
     if (dev_text) { dev_text->d_text = d_text; dev_text->d_offs = d_offs; dev_text->d_lens = d_lens; }
     if (lens_out) *lens_out = h_lens;
     return LF_OK;

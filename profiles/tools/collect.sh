@@ -18,4 +18,13 @@ python3 profiles/tools/trim_stats.py $(ls /tmp/lfp_ser/*/*kernel_stats.csv | hea
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/lfp_f -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-exclusive > $OUT/bench_under_pmc_fetch.json 2> /tmp/lfp_f.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/lfp_w -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-exclusive > $OUT/bench_under_pmc_write.json 2> /tmp/lfp_w.err
 python3 profiles/tools/summarize_pmc.py $OUT/pmc_fetch_write_summary.json $(ls /tmp/lfp_f/*/*counter_collection.csv | head -1) $(ls /tmp/lfp_w/*/*counter_collection.csv | head -1)
+# SQ instruction / stall counters, one chunk at a time, 50 k reads (three 8-slot passes)
+export LF_LANES=1 LF_SERIAL_CLASSES=1
+BS="python3 bench.py --reads 50000 --steps 1 --warmup 0 --no-cpu-baseline --no-exclusive"
+rm -rf /tmp/lfp_s1 /tmp/lfp_s2 /tmp/lfp_s3
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d /tmp/lfp_s1 -- $BS > /dev/null 2> /tmp/lfp_s1.err
+rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d /tmp/lfp_s2 -- $BS > /dev/null 2> /tmp/lfp_s2.err
+rocprofv3 --pmc SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d /tmp/lfp_s3 -- $BS > /dev/null 2> /tmp/lfp_s3.err
+python3 profiles/tools/summarize_pmc.py $OUT/sq_counters_50k_reads.json $(ls /tmp/lfp_s1/*/*counter_collection.csv /tmp/lfp_s2/*/*counter_collection.csv /tmp/lfp_s3/*/*counter_collection.csv 2>/dev/null)
+unset LF_LANES LF_SERIAL_CLASSES
 ls -la $OUT
