@@ -305,7 +305,6 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
                    const int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len, int W /* NB of the lane class | G of the sweep class */)
 {
     constexpr int K = LF_LANE_K;
-    __shared__ lf_hist_t s_tile[K * 64];
     const int lane = threadIdx.x, idx = blockIdx.x * 64 + lane;
     const bool live = idx < n_probs;
     const lf_aln_prob pr = probs[live ? idx : n_probs - 1];
@@ -327,50 +326,72 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
 
     lf_emitter em; em.init(ops + pr.ops_off, n + m, want);
     uint32_t r = want ? n : 0, c = want ? tl : 0;
-    int cur_b = -1; uint64_t lo = 0, hi = 0, valid = 0;
+    uint64_t lo = 0, hi = 0, valid = 0;
+    auto load_planes = [&](uint32_t b) {
+        if (LANECLASS) { lo = planes[(b * 3 + 0) * 64 + slot]; hi = planes[(b * 3 + 1) * 64 + slot]; valid = planes[(b * 3 + 2) * 64 + slot]; }
+        else { const int ln = slot * W + (int)b; lo = planes[ln]; hi = planes[64 + ln]; valid = planes[128 + ln]; }
+    };
+    uint32_t cur_b = r > 0 ? (r - 1) >> 6 : 0;
+    load_planes(cur_b);
     while (__any(r > 0 && c > 0)) {
         const bool act = r > 0 && c > 0;
         const uint32_t b = act ? (r - 1) >> 6 : 0;
         /* the tile: K block steps of block b; step k works on column cbase + k */
-        const uint32_t j = LANECLASS ? (c - 1) / K : (c - 1 + b) / K;
+        const uint32_t j = !act ? 0 : LANECLASS ? (c - 1) / K : (c - 1 + b) / K;
         const int cbase = LANECLASS ? (int)(j * K) + 1 : (int)(j * K) - (int)b + 1;
-        uint64_t Pv = ~0ull, Mv = 0; uint32_t cw = 0x5555u;      /* block 0: +1 enters every column */
-        if (act) {
-            if (LANECLASS) {
-                if (j > 0) { const lf_hist_t e = ck[((size_t)(j - 1) * W + b) * 64 + slot]; Pv = e.pv; Mv = e.ph; }
-                if (b > 0) { const uint32_t gi = (c - 1) >> 4; cw = carr[(((size_t)(gi >> 2) * W + b) * 64 + slot) * 4 + (gi & 3)] >> ((j & 1u) * 16); }
-                if ((int)b != cur_b) { lo = planes[(b * 3 + 0) * 64 + slot]; hi = planes[(b * 3 + 1) * 64 + slot]; valid = planes[(b * 3 + 2) * 64 + slot]; cur_b = (int)b; }
-            } else {
-                const int ln = slot * W + (int)b;
-                if (j > 0) { const lf_hist_t e = ck[(size_t)(j - 1) * ROW + ln]; Pv = e.pv; Mv = e.ph; }
-                if (b > 0) cw = reinterpret_cast<const uint16_t *>(ck + (size_t)j * ROW + 64)[32 + ln];
-                if ((int)b != cur_b) { lo = planes[ln]; hi = planes[64 + ln]; valid = planes[128 + ln]; cur_b = (int)b; }
-            }
+        /* what the tile needs from HBM -- the block's state in front of it, the carries entering it, its target symbols, the
+         * block's bit planes when the block changed -- is requested with UNCONDITIONAL loads from clamped addresses, so that
+         * all of them are in flight together (one round trip per tile; per-lane branches around the loads made every one of
+         * them wait for the previous: nine dependent round trips) */
+        const uint32_t jm = j > 0 ? j - 1 : 0;
+        lf_hist_t est; uint32_t craw; uint32_t tokp = 0;
+        if (LANECLASS) {
+            est = *(j > 0 ? ck + ((size_t)jm * W + b) * 64 + slot : wbase + slot);      /* j == 0: any address inside the wave's area (a wave of targets < K columns has no checkpoints) */
+            const uint32_t gi = j >> 1;
+            craw = carr[(((size_t)(gi >> 2) * W + b) * 64 + slot) * 4 + (gi & 3)] >> ((j & 1u) * 16);
+        } else {
+            const int ln = slot * W + (int)b;
+            est = ck[(size_t)jm * ROW + ln];
+            craw = reinterpret_cast<const uint16_t *>(ck + (size_t)j * ROW + 64)[32 + ln];
         }
-        uint32_t tok[K];
-#pragma unroll
-        for (int k = 0; k < K; k++) { const int col = cbase + k; tok[k] = (act && col >= 1 && col <= (int)c) ? lf_tok<PAC>(T, (uint32_t)col - 1) : 0u; }
+        if (PAC) tokp = T.pac_codes8((int64_t)cbase - 1);
+        /* lo / hi / valid are the planes of block b: loaded behind the walk that entered the block (below) */
+        uint64_t Pv = j > 0 ? est.pv : ~0ull, Mv = j > 0 ? est.ph : 0ull;      /* column 0 */
+        const uint32_t cw = b > 0 ? craw : 0x5555u;                            /* block 0: +1 enters every column */
+        /* replay: (Pv, Ph) of the tile's K columns stay in REGISTERS (statically indexed: the walk below is unrolled over the
+         * columns), no LDS round trip per move */
+        uint64_t tPv[K], tPh[K];
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const uint64_t Eq = lf_eq_tok<PAC>(tok[k], lo, hi, valid, qget, n, b);
+            const int col = cbase + k;
+            const uint32_t tk = PAC ? (tokp >> (2 * k)) & 3u : ((act && col >= 1 && col <= (int)c) ? lf_tok<PAC>(T, (uint32_t)col - 1) : 0u);
+            const uint64_t Eq = lf_eq_tok<PAC>(tk, lo, hi, valid, qget, n, b);
             uint64_t nPv = Pv, nMv = Mv, ph, mh;
             (void)lf_myers_step(nPv, nMv, Eq, (cw >> (2 * k)) & 3u, ph, mh);
             if (LANECLASS) { Pv = nPv; Mv = nMv; }
-            else { const bool v = cbase + k >= 1; Pv = v ? nPv : Pv; Mv = v ? nMv : Mv; }       /* the block starts at column 1 */
-            lf_hist_t e; e.pv = Pv; e.ph = ph; s_tile[k * 64 + lane] = e;
+            else { const bool v = col >= 1; Pv = v ? nPv : Pv; Mv = v ? nMv : Mv; }       /* the block starts at column 1 */
+            tPv[k] = Pv; tPh[k] = ph;
         }
+        /* walk: column by column from the right; inside a column only Up moves repeat */
         if (act) {
             const int cmin = cbase < 1 ? 1 : cbase;
-            uint32_t ec = 0xffffffffu; lf_hist_t e; e.pv = e.ph = 0;
-            while (r > 0 && (int)c >= cmin && ((r - 1) >> 6) == b) {
-                if (c != ec) { e = s_tile[((int)c - cbase) * 64 + lane]; ec = c; }
-                const int bit = (int)((r - 1) & 63);
-                const uint32_t up = (uint32_t)(e.pv >> bit) & 1u, lf = ((uint32_t)(e.ph >> bit) & 1u) & ~up, dg = (up | lf) ^ 1u;
-                uint32_t op = up ? 1u : (lf ? 2u : 0u);      /* Up -> Left -> Diagonal (lib/edlib/edlib.cpp:950,984,1015) */
-                if (!lazy) { if (dg && Q.get(r - 1) != T.get(c - 1)) op = 3u; }
-                em.put(op);
-                r -= up | dg; c -= lf | dg;
+#pragma unroll
+            for (int k = K - 1; k >= 0; k--) {
+                bool here = r > 0 && (int)c == cbase + k && (int)c >= cmin && ((r - 1) >> 6) == b;
+                while (here) {
+                    const int bit = (int)((r - 1) & 63);
+                    const uint32_t up = (uint32_t)(tPv[k] >> bit) & 1u, lf = ((uint32_t)(tPh[k] >> bit) & 1u) & ~up, dg = (up | lf) ^ 1u;
+                    uint32_t op = up ? 1u : (lf ? 2u : 0u);      /* Up -> Left -> Diagonal (lib/edlib/edlib.cpp:950,984,1015) */
+                    if (!lazy) { if (dg && Q.get(r - 1) != T.get(c - 1)) op = 3u; }
+                    em.put(op);
+                    r -= up | dg; c -= lf | dg;
+                    here = up != 0 && r > 0 && ((r - 1) >> 6) == b;      /* an Up move stays in the column (and maybe in the block) */
+                }
             }
+        }
+        {   /* the path climbed into the block above: its planes are requested now, used by the next tile */
+            const uint32_t nb = r > 0 ? (r - 1) >> 6 : 0;
+            if (nb != cur_b) { load_planes(nb); cur_b = nb; }
         }
     }
     if (want) {

@@ -79,6 +79,22 @@ struct lf_tacc {
         const uint32_t c = ((uint32_t)pac[x >> 2] >> ((~(uint32_t)x & 3u) << 1)) & 3u;
         return comp ? 3u - c : c;
     }
+    /* the 2-bit codes of elements i0 .. i0 + 7, two bits each (element i0 + k at bits 2k): ONE unaligned 4-byte load instead of
+     * eight dependent byte loads.  Elements in front of the array's first symbol come out as garbage (callers do not use them). */
+    __device__ __forceinline__ uint32_t pac_codes8(int64_t i0) const {
+        const int64_t xa = start + (int64_t)dir * i0, xb = xa + 7 * (int64_t)dir;
+        int64_t xlo = xa < xb ? xa : xb; if (xlo < 0) xlo = 0;
+        uint32_t w; __builtin_memcpy(&w, pac + (xlo >> 2), 4);
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int64_t x = xa + (int64_t)dir * k;
+            const uint32_t sh = (uint32_t)(((x >> 2) - (xlo >> 2)) * 8) + ((~(uint32_t)x & 3u) << 1);
+            const uint32_t c = (w >> (sh & 31u)) & 3u;
+            out |= (comp ? 3u - c : c) << (2 * k);
+        }
+        return out;
+    }
     __device__ __forceinline__ unsigned char get(uint32_t i) const {
         if (is_pac) return (unsigned char)(0x54474341u >> (pac_code(i) << 3));   /* "ACGT"[c] without a table load */
         const unsigned char c = b[start + (int64_t)dir * (int64_t)i];
