@@ -4,15 +4,19 @@
  * Reference replaced: edlibAlign (lib/edlib/edlib.cpp:101-221) with config {k=-1, NW|SHW, PATH}, and
  * ksw_extend2 (lib/bwa/ksw.c:380-478).  Integer only; results bit-identical.
  *
- * edlib kernels: Myers/Hyyro bit-vector DP, 64 query rows per 64-bit word.  Problems are binned by ceil(n/64):
- * ONE LANE PER PROBLEM with NB = 1,2,3,4,6,8 register-resident blocks for n <= 512 (the ~10^2 gap problems per read
- * are what fills the lanes), G = 16 / 32 / 64 lanes per problem sweeping the matrix as an anti-diagonal above that,
- * with edlib's Hirschberg recursion on the device for problems over its 1 MiB traceback switch.  Traceback needs two
- * bits per cell -- Pv (vertical +1 => Up) and Ph (horizontal +1 => Left), else Diagonal (match iff bytes equal), which
- * is edlib's move priority (lib/edlib/edlib.cpp:950,984,1015) -- and gets them by RECOMPUTING tiles from checkpoints
- * into LDS instead of streaming them through HBM (see "TRACEBACK WITHOUT A HISTORY STREAM" below).  No banding: the
- * Ukkonen band of the reference only removes cells that cannot be on an optimal path, and a lane (or a group of
- * lanes) that skips out-of-band blocks saves no time, because its neighbours in the wavefront do not.
+ * edlib kernels: Myers/Hyyro bit-vector DP, 64 query rows per 64-bit word.  Problems are binned by ceil(n/64).
+ *   forward pass   ONE LANE PER PROBLEM with NB = 1,2,3,4,6,8 register-resident blocks for n <= 512 (the ~10^2 gap problems
+ *                  per read are what fills the lanes); G = 16 / 32 / 64 lanes per problem sweeping the matrix as an
+ *                  anti-diagonal above that.  Leaves the distance / end column, checkpoints of the bit-vector state every
+ *                  8 columns (steps), the two-bit carries entering every block and the blocks' bit planes in HBM.
+ *   traceback      needs two bits per cell -- Pv (vertical +1 => Up) and Ph (horizontal +1 => Left), else Diagonal (match
+ *                  iff bytes equal), which is edlib's move priority (lib/edlib/edlib.cpp:950,984,1015) -- and gets them by
+ *                  RECOMPUTING 8-column tiles of the ONE block the path is in from a checkpoint and the stored carries:
+ *                  lf_edlib_tb_kernel, one lane per path, the tile in registers.  No history stream through HBM.
+ *   Hirschberg     edlib's recursion for problems over its 1 MiB traceback switch runs inside the 64-lane sweep kernel
+ *                  (one wavefront per problem, LDS stack), including the leaves' tracebacks.
+ * No banding: the Ukkonen band of the reference only removes cells that cannot be on an optimal path, and a lane (or a
+ * group of lanes) that skips out-of-band blocks saves no time, because its neighbours in the wavefront do not.
  */
 #include <hipcub/hipcub.hpp>
 #include "lf_gpu_common.h"
@@ -216,7 +220,10 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
     for (int b = 0; b < NB; b++) {
         if ((uint32_t)b * 64 < n) {
 #pragma unroll 8
-            for (int i = 0; i < 64; i++) { const uint32_t r = b * 64 + i; const unsigned char ch = r < n ? Q.get(r) : (unsigned char)0; lf_plane_add(ch, i, lo[b], hi[b], valid[b]); }
+            for (int i = 0; i < 64; i++) {      /* unconditional loads from a clamped index: a branch per byte makes every load wait for the one before */
+                const uint32_t r = b * 64 + i; const unsigned char qc = Q.get(r < n ? r : n - 1);
+                lf_plane_add(r < n ? qc : (unsigned char)0, i, lo[b], hi[b], valid[b]);
+            }
         }
     }
 
@@ -246,8 +253,13 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
     for (uint32_t t0 = 1; t0 <= steps_w; t0 += 8) {
         /* the 8 target bases of this trip are fetched together: their latency is paid once, not per column */
         uint32_t tcs[8];
+        if (PAC) { const uint32_t p8 = T.pac_codes8((int64_t)t0 - 1, m);      /* one 4-byte load; columns past m are dead anyway */
 #pragma unroll
-        for (int k = 0; k < 8; k++) tcs[k] = (t0 + k <= m) ? lf_tok<PAC>(T, t0 + k - 1) : 0u;
+            for (int k = 0; k < 8; k++) tcs[k] = (p8 >> (2 * k)) & 3u; }
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const uint32_t ti = t0 + k - 1; tcs[k] = lf_tok_of_byte(T.get(ti < m ? ti : m - 1)); }
+        }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t t = t0 + k;
@@ -293,8 +305,8 @@ lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, l
  *
  * From (n, tl) the path is followed tile by tile: the tile = the K columns (lane classes) or K sweep steps (sweep classes)
  * around the current cell, of the ONE block the cell is in.  The lane restores that block's checkpoint in front of the
- * tile, replays the K block steps with the stored carries as horizontal input, keeps (Pv, Ph) of the K columns in LDS
- * and walks until the path leaves the tile or the block.  Work per path: ~(m / K + n / 64) tiles of K block steps --
+ * tile, replays the K block steps with the stored carries as horizontal input, keeps (Pv, Ph) of the K columns in
+ * registers (the walk is unrolled over the columns) and walks until the path leaves the tile or the block.  Work per path: ~(m / K + n / 64) tiles of K block steps --
  * instead of replaying all the blocks above the path (lane classes) or the whole group of lanes (sweep classes, where
  * the walk itself also kept only one lane of G busy).  Same cells, same Up -> Left -> Diagonal priority
  * (lib/edlib/edlib.cpp:950,984,1015), same ops.
@@ -354,7 +366,7 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
             est = ck[(size_t)jm * ROW + ln];
             craw = reinterpret_cast<const uint16_t *>(ck + (size_t)j * ROW + 64)[32 + ln];
         }
-        if (PAC) tokp = T.pac_codes8((int64_t)cbase - 1);
+        if (PAC) tokp = T.pac_codes8((int64_t)cbase - 1, m);
         /* lo / hi / valid are the planes of block b: loaded behind the walk that entered the block (below) */
         uint64_t Pv = j > 0 ? est.pv : ~0ull, Mv = j > 0 ? est.ph : 0ull;      /* column 0 */
         const uint32_t cw = b > 0 ? craw : 0x5555u;                            /* block 0: +1 enters every column */
@@ -551,7 +563,9 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
             for (int sub = 0; sub < P; sub++) {
                 const uint32_t r = b * 64 + (uint32_t)(sub * G + gl);
                 int code = -1;
-                if (b < nbk && r < n) { bool ok; const uint32_t cd = lf_code_upper(qget(r), ok); code = ok ? (int)cd : -1; }
+                {   /* unconditional load from a clamped row (see lf_edlib_kernel) */
+                    const bool in = b < nbk && r < n; bool ok; const uint32_t cd = lf_code_upper(qget(in ? r : n - 1), ok); code = (in && ok) ? (int)cd : -1;
+                }
                 const uint64_t bl = __ballot(code >= 0 && (code & 1)), bh = __ballot(code >= 0 && (code & 2)), bv = __ballot(code >= 0);
                 if ((uint32_t)gl == b / KB) {
                     const int slot = (int)(b % KB);

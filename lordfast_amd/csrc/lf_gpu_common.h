@@ -80,10 +80,15 @@ struct lf_tacc {
         return comp ? 3u - c : c;
     }
     /* the 2-bit codes of elements i0 .. i0 + 7, two bits each (element i0 + k at bits 2k): ONE unaligned 4-byte load instead of
-     * eight dependent byte loads.  Elements in front of the array's first symbol come out as garbage (callers do not use them). */
-    __device__ __forceinline__ uint32_t pac_codes8(int64_t i0) const {
+     * eight dependent byte loads.  Only elements in [0, count) are meaningful; the load address is clamped to the bytes that
+     * hold those (the array has 16 bytes of padding behind its last symbol), the others come out as garbage. */
+    __device__ __forceinline__ uint32_t pac_codes8(int64_t i0, uint32_t count) const {
         const int64_t xa = start + (int64_t)dir * i0, xb = xa + 7 * (int64_t)dir;
-        int64_t xlo = xa < xb ? xa : xb; if (xlo < 0) xlo = 0;
+        const int64_t vlo = dir > 0 ? start : start - ((int64_t)count - 1), vhi = dir > 0 ? start + ((int64_t)count - 1) : start;
+        int64_t xlo = xa < xb ? xa : xb;
+        if (xlo > vhi) xlo = vhi;
+        if (xlo < vlo - 7) xlo = vlo - 7;
+        if (xlo < 0) xlo = 0;
         uint32_t w; __builtin_memcpy(&w, pac + (xlo >> 2), 4);
         uint32_t out = 0;
 #pragma unroll
