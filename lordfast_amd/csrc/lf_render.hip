@@ -31,6 +31,7 @@ struct lf_rrounds { const uint8_t *ops[LF_MAX_ED_ROUNDS]; const lf_aln_desc_t *d
 
 __device__ __forceinline__ int lf_ndigits(uint32_t v)
 {
+    if (!__any(v >= 10000u)) return 1 + (int)(v >= 10u) + (int)(v >= 100u) + (int)(v >= 1000u);      /* run lengths and match counts are small */
     return v < 10u ? 1 : v < 100u ? 2 : v < 1000u ? 3 : v < 10000u ? 4 : v < 100000u ? 5 : v < 1000000u ? 6
          : v < 10000000u ? 7 : v < 100000000u ? 8 : v < 1000000000u ? 9 : 10;
 }
@@ -174,10 +175,7 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
                 rl = sb ? (uint32_t)(lane - (63 - __clzll((long long)sb))) : c_run + (uint32_t)lane;
                 nd = lf_ndigits(rl); tlen = (uint32_t)nd + 1;
             }
-            uint32_t tot; const uint32_t pos = lf_wave_excl_sum(tlen, &tot);
-            if (WRITE && emits) lf_put_token(cg + c_out + pos, rl, nd, (c_first && !(emask & below) && pch == 'I') ? 'S' : (char)pch, 0);
-            c_out += tot;
-            if (emask) c_first = 0;
+            /* (the CIGAR token is placed below: ONE wave scan serves both strings, token lengths packed 16 + 16 bits) */
             const int lastch = __builtin_amdgcn_readlane(ch, __builtin_amdgcn_readfirstlane((int)cnt - 1));
             if (smask) c_run = cnt - (uint32_t)(63 - __clzll((long long)smask)); else c_run += cnt;
             c_ch = lastch;
@@ -197,7 +195,11 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
                     mnd = lf_ndigits(num); mlen = (uint32_t)mnd + (isd ? 2u : 1u);
                 } else mlen = 1;
             }
-            uint32_t mtot; const uint32_t mpos = lf_wave_excl_sum(mlen, &mtot);
+            uint32_t both; const uint32_t excl = lf_wave_excl_sum(tlen | (mlen << 16), &both);      /* <= 64 x 12 per half: no carry */
+            const uint32_t pos = excl & 0xffffu, mpos = excl >> 16, tot = both & 0xffffu, mtot = both >> 16;
+            if (WRITE && emits) lf_put_token(cg + c_out + pos, rl, nd, (c_first && !(emask & below) && pch == 'I') ? 'S' : (char)pch, 0);
+            c_out += tot;
+            if (emask) c_first = 0;
             if (WRITE && (isx || isd)) {
                 if (flush) lf_put_token(md + m_out + mpos, num, mnd, isd ? '^' : bch, isd ? bch : 0);
                 else md[m_out + mpos] = bch;
