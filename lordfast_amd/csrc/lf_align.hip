@@ -525,6 +525,10 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     __shared__ lf_hist_t s_tile[K * KB * 64];
     __shared__ unsigned char s_t[P * TC];
     __shared__ uint32_t s_stack[G == 64 ? LF_HSTACK * 5 : 1];
+    /* match masks of the lane's block against the four target codes (KB = 1, targets from the 2-bit reference): one
+     * ds_read_b64 per step, issued a step ahead, instead of ten ALU ops on the bit planes; every lane touches its own column only */
+    constexpr bool PEQ = PAC && KB == 1;
+    __shared__ uint64_t s_peq[PEQ ? 4 * 64 : 1];
     const int lane = threadIdx.x, g = lane / G, gl = lane % G;
     const int pi = (int)blockIdx.x * P + g;
     const bool live = pi < n_probs;
@@ -575,6 +579,10 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
                 }
             }
         }
+        if (PEQ) {
+#pragma unroll
+            for (uint32_t cde = 0; cde < 4; cde++) s_peq[cde * 64 + lane] = lf_eq_tok<true>(cde, lo[0], hi[0], valid[0], qget, n, (uint32_t)gl);
+        }
     };
     /* target columns [first, first + count) into the group's LDS ring */
     auto stage_window = [&](int first, int count) {
@@ -586,7 +594,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     /* the bottom-row score is followed column by column only when a problem of the wavefront asks for the best prefix (SHW);
      * the NW distance is read off the last column afterwards, and the Hirschberg passes use neither */
     bool track_shw = __any(live && pr.mode != 0);
-    auto sweep_step = [&](int s, auto track_c, auto tile_c, int s0, uint32_t byte) {
+    auto sweep_step = [&](int s, auto track_c, auto tile_c, int s0, uint32_t byte, uint64_t eq_ahead) {
         constexpr bool track = decltype(track_c)::value, tile = decltype(tile_c)::value;
         const uint32_t from_left = lf_wave_shr1(hout_prev);
         if (!tile && KB == 1) cw |= from_left << ((s & (K - 1)) * 2);      /* forward passes; scalar shift amount */
@@ -598,7 +606,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
             for (int k = 0; k < KB; k++) {
                 const uint32_t b = (uint32_t)gl * KB + k;
                 /* blocks past the problem's last one (padding of the lane's KB) compute on dead registers: no branch */
-                const uint64_t Eq = lf_eq_tok<PAC>(tok, lo[k], hi[k], valid[k], qget, n, b);
+                const uint64_t Eq = (PEQ && !tile) ? eq_ahead : lf_eq_tok<PAC>(tok, lo[k], hi[k], valid[k], qget, n, b);
                 uint64_t ph, mh;
                 const uint32_t ho = lf_myers_step(Pv[k], Mv[k], Eq, hin, ph, mh);
                 hin = (KB == 1 || b < nbk) ? ho : hin;
@@ -621,11 +629,13 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
         /* the lane's target symbol is read from the LDS ring ONE STEP AHEAD: the ds_read latency hides behind the step's ALU chain */
         __syncthreads(); stage_window(0, H); __syncthreads(); ring_lo = 0;
         uint32_t sym = my_t[(0 - gl) & (TC - 1)];
+        uint64_t eq = PEQ ? s_peq[(sym & 3u) * 64 + lane] : 0ull;
         for (int s = 0; s < steps_max; s++) {
             if (((s + 1) & (H - 1)) == 0) { __syncthreads(); stage_window(s + 1, H); __syncthreads(); ring_lo = s + 1 >= H ? s + 1 - H : 0; }
             const uint32_t sym_next = my_t[(s + 1 - gl) & (TC - 1)];
-            if (track_shw) sweep_step(s, std::true_type(), std::false_type(), 0, sym); else sweep_step(s, std::false_type(), std::false_type(), 0, sym);
+            if (track_shw) sweep_step(s, std::true_type(), std::false_type(), 0, sym, eq); else sweep_step(s, std::false_type(), std::false_type(), 0, sym, eq);
             sym = sym_next;
+            if (PEQ) eq = s_peq[(sym & 3u) * 64 + lane];
             if (want_ck && ((s + 1) & (K - 1)) == 0) {
                 const size_t j = (size_t)((s + 1) / K - 1);
                 lf_hist_t *row = ck + j * ROW;
@@ -672,7 +682,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
             /* target columns of this tile: the ring still holds them unless the walk has moved left of it */
             if (s0 - G + 1 < ring_lo) { ring_lo = s0 + K > H ? s0 + K - H : 0; stage_window(ring_lo, H); __syncthreads(); }      /* H >= G + K - 1 columns: the tile's and the next ones' */
             const int s1 = s0 + K < steps_max ? s0 + K : steps_max;
-            for (int s = s0; s < s1; s++) sweep_step(s, std::false_type(), std::true_type(), s0, (uint32_t)my_t[(s - gl) & (TC - 1)]);
+            for (int s = s0; s < s1; s++) sweep_step(s, std::false_type(), std::true_type(), s0, (uint32_t)my_t[(s - gl) & (TC - 1)], 0ull);
             __syncthreads();
             for (;;) {
                 const bool act = scur >= s0;
