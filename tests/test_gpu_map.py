@@ -108,6 +108,21 @@ def test_sam_many_chunks(lf, golden_reads, monkeypatch):
     assert sam == golden_sam("default")
 
 
+@pytest.mark.parametrize("lanes,chunk", [(12, 3), (5, 11), (2, 1)])
+def test_sam_many_chunks_into_caller_buffer(lf, golden_reads, monkeypatch, lanes, chunk):
+    """A caller-owned output buffer: the chunks' SAM texts are copied out asynchronously, out of order, from two device
+    buffers per lane; a chunk may stay pending until the chunks of earlier reads have published their sizes.  Many tiny
+    chunks on many lanes must still give the one text."""
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    monkeypatch.setenv("LF_CHUNK_READS", str(chunk))
+    monkeypatch.setenv("LF_LANES", str(lanes))
+    buf = np.full(64 << 20, 0x7f, dtype=np.uint8)
+    for rep in range(2):
+        ln, st = lf.map_batch_into(names, seqs, buf.ctypes.data, buf.size, params=la.default_params(threads=16, **GOLDEN_CONFIGS["default"]))
+        assert bytes(buf[:ln]) == golden_sam("default")
+
+
 def test_sam_fastq_and_readgroup(lf, oracle, oracle_lib, golden_reads):
     import lordfast_amd as la
     names, seqs = golden_reads
