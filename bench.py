@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- aligned reads/s of the GPU seed->chain->extend path on synthetic PacBio-error reads.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1 from a bare shell: this process starts the N ranks itself (python -m torch.distributed.run ... bench.py) and relays
+        rank 0's line; already under torchrun (RANK / WORLD_SIZE set, the driver's form) it is one of the ranks.
 
-A "step" maps one batch of synthetic reads (inputs in host memory -> SAM records in host memory, index
-resident in HBM, index load excluded -- the reference's own timer, src/baseFAST.cpp:69-75).  Weak scaling:
-reads are independent, so every GPU maps its own shard (--reads per GPU) against its own replica of the index
-and keeps its SAM records in its own host buffer: no data-path collective (--single-output adds the gather).  Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the dominant
-kernel and `cpu_baseline` (the real reference, compiled into oracle/_ref, on all host cores, bounded sample).
+A "step" maps one batch of synthetic reads with the index resident in HBM (index load excluded -- the reference's own timer,
+src/baseFAST.cpp:69-75).  `value`: read bases resident in HBM when the timed region starts, SAM records left in HBM
+(lf_map_batch_dev).  `value_pcie_inclusive`: the same steps through the host-buffer boundary the reference has (reads in host
+memory -> SAM text in host memory, lf_map_batch_into_lens).
+N > 1: one process per GPU, index replicated, reads are independent.  --scaling weak (default): --reads per GPU; strong: the
+SAME --reads set cut by bases over the ranks (BASELINE config C3).  --exchange on (default for N > 1): rank 0 owns every step's
+reads and ends with its SAM records; both move over RCCL point-to-point (xGMI), pipelined one step ahead / behind the mapping
+(lordfast_amd/dist.py: PipelinedExchange), inside the timed region.  The rate without any exchange is reported next to it.
+Prints ONE JSON line on rank 0 carrying `roofline` for the dominant kernel group and `cpu_baseline` (the real reference,
+compiled into oracle/_ref, on the host cores, bounded sample).
 """
 from __future__ import annotations
 
@@ -43,8 +50,16 @@ def parse():
     ap.add_argument("--max-map", type=int, default=10, help="-n (config C4: 30)")
     ap.add_argument("--single-output", action="store_true", help="(kept for round-1 command lines) same as --exchange on")
     ap.add_argument("--exchange", choices=["auto", "on", "off"], default="auto",
-                    help="N>1: rank 0 owns the whole read batch; scatter it to the ranks and gather their SAM records back inside "
-                         "the timed region (RCCL point-to-point).  auto = on for N>1.  The rate without the exchange is reported too")
+                    help="N>1: rank 0 owns every step's read batch (in HBM); its shards go to the ranks and their SAM records come back "
+                         "over RCCL point-to-point, pipelined with the mapping, inside the timed region.  auto = on for N>1.  The rate "
+                         "without the exchange is reported too")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --reads per GPU (work grows with N); strong: the same --reads set cut by bases over the N ranks (config C3)")
+    ap.add_argument("--mode", choices=["ranks", "inproc"], default="ranks",
+                    help="ranks: one process per GPU (torch.distributed); inproc: ONE process drives N devices through lf_map_batch_multi "
+                         "(chunks pulled from one counter; every device copies through its own PCIe link)")
+    ap.add_argument("--exchange-timeout", type=float, default=float(os.environ.get("LF_BENCH_EXCHANGE_TIMEOUT", "240")),
+                    help="seconds after which a stuck exchange phase is abandoned: the line is printed with the no-exchange rate as value")
     ap.add_argument("--repeat-profile", choices=["default", "grch38like"], default="default",
                     help="default: 10 %% of the genome from 1000 low-copy families (SURVEY 8d); grch38like: ~50 %% repeats incl. a "
                          "300 bp family with ~10^6 copies per 3 Gbp and truncated 1-6 kbp families")
@@ -185,64 +200,8 @@ def cpu_baseline(args, fa, names, seqs):
                        f"--threads {cores} on {granted} granted CPUs", bp_per_s=bases / secs), sam, n
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # LF_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 code path run on a box with fewer GPUs than ranks
-        # (ranks then share devices); the driver's runs use RCCL ("nccl"), one rank per GPU
-        backend = os.environ.get("LF_BENCH_BACKEND", "nccl")
-        if backend != "nccl":
-            local = local % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend)
-    dev = torch.device("cuda", local)
-    rdev = dev if (not dist or dist.get_backend() == "nccl") else torch.device("cpu")     # where the reduced scalars live
-
-    import lordfast_amd as la
-    from lordfast_amd import dist as lfd
-    if la.device_count() < 1:
-        sys.exit("bench.py: no gfx950 device visible; the HIP path has no CPU fallback")
-
-    fa, contigs = ensure_index(args, rank)
-    if dist:
-        dist.barrier()
-    t0 = time.time()
-    lf = la.LordFast(fa, device=local, full_sa=True)
-    log(f"rank {rank}: index resident in HBM after {time.time() - t0:.1f}s")
-    kk, cc = (17, 2000) if args.config == "c5" else (14, 1000)             # -k 14 -c 1000 --chainAlg dp-n2 (C2); -k 17 -c 2000 (C5)
-    params = la.default_params(min_anchor_len=kk, sampling_count=cc,
-                               chain_alg=1 if args.chain_alg == "clasp" else 0, max_map=args.max_map)
-
-    n_total = args.reads * world
-    exchange = world > 1 and args.exchange in ("auto", "on")
-    names, seqs = make_reads(args, contigs, fa, rank)        # this rank's shard (seed 2024 + rank)
-    packed_all = None
-    if exchange and rank == 0:
-        # rank 0 OWNS the whole job's read batch (shard r = the reads rank r would generate itself), packed once, outside
-        # the timed region, the way a reader thread leaves a chunk in host memory (one blob + offsets)
-        all_names, all_seqs = list(names), list(seqs)
-        for r in range(1, world):
-            nr, sr = make_reads(args, contigs, fa, r)
-            all_names += nr; all_seqs += sr
-        packed_all = lfd.pack_reads(all_names, all_seqs)
-        del all_names, all_seqs
-        log(f"rank 0 owns the batch: {len(packed_all)} reads, {packed_all.blob.nbytes / 1e9:.2f} GB packed")
-    contigs = None
-    bases_local = sum(len(s) for s in seqs)
-
-    # host thread budget: the cgroup quota (or the online CPUs) split between the ranks of this node
+def host_budget():
+    """CPUs this container may use (cgroup quota or online CPUs)"""
     budget = os.cpu_count() or 1
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -250,55 +209,179 @@ def main():
             budget = min(budget, max(1, -(-int(q) // int(per))))
     except Exception:                                                    # noqa: BLE001
         pass
+    return budget
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as FRESH child processes (this process has touched
+    neither HIP nor torch) and exit with their status; rank 0's JSON line goes to our stdout unchanged."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("starting", args.gpus, "ranks:", " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    args = parse()
+    under_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and args.mode == "ranks" and not under_torchrun:
+        sys.exit(spawn_ranks(args))
+    rank = int(os.environ.get("RANK", "0")) if args.mode == "ranks" else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if args.mode == "ranks" else 1
+    local = int(os.environ.get("LOCAL_RANK", "0")) if args.mode == "ranks" else 0
+    if args.mode == "ranks" and world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    import threading
+
+    import torch
+    dist, ctl, backend = None, None, None
+    if world > 1:
+        import datetime
+
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # LF_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 code path run on a box with fewer GPUs than ranks
+        # (ranks then share devices, bulk data goes through host memory); the driver's runs use RCCL ("nccl"), one rank per GPU
+        backend = os.environ.get("LF_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local = local % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=max(600, int(args.exchange_timeout) * 2)))
+        ctl = dist.new_group(backend="gloo") if backend == "nccl" else dist.group.WORLD      # metadata: host tensors
+    dev = torch.device("cuda", local)
+    bulk = dev if (not dist or backend == "nccl") else torch.device("cpu")      # where scattered reads / gathered SAM live
+    rdev = bulk                                                                 # where the reduced scalars live
+
+    import lordfast_amd as la
+    from lordfast_amd import dist as lfd
+    if la.device_count() < 1:
+        sys.exit("bench.py: no gfx950 device visible; the HIP path has no CPU fallback")
+    n_dev = args.gpus if args.mode == "inproc" else 1
+    if args.mode == "inproc" and la.device_count() < n_dev and not os.environ.get("LF_BENCH_SHARE_DEVICES"):
+        sys.exit(f"bench.py --mode inproc --gpus {n_dev}: only {la.device_count()} devices visible")
+
+    fa, contigs = ensure_index(args, rank)
+    if dist:
+        dist.barrier()
+    t0 = time.time()
+    lf = la.LordFast(fa, device=local, full_sa=True)
+    replicas = [lf] + [la.LordFast(fa, device=d % la.device_count(), full_sa=True) for d in range(1, n_dev)]
+    log(f"rank {rank}: index resident in HBM after {time.time() - t0:.1f}s")
+    kk, cc = (17, 2000) if args.config == "c5" else (14, 1000)             # -k 14 -c 1000 --chainAlg dp-n2 (C2); -k 17 -c 2000 (C5)
+    params = la.default_params(min_anchor_len=kk, sampling_count=cc,
+                               chain_alg=1 if args.chain_alg == "clasp" else 0, max_map=args.max_map)
+
+    # ---- the job's reads.  weak: every rank has its own --reads (seed 2024 + rank); strong: ONE --reads set, cut by bases
+    strong = args.scaling == "strong" and world * n_dev > 1
+    exchange = world > 1 and args.exchange in ("auto", "on")
+    if strong:
+        all_names, all_seqs = make_reads(args, contigs, fa, 0)
+        bounds = lfd.shard_bounds([len(x) for x in all_seqs], world)
+        lo, hi = bounds[rank]
+        names, seqs = all_names[lo:hi], all_seqs[lo:hi]
+        n_total = len(all_seqs)
+    else:
+        names, seqs = make_reads(args, contigs, fa, rank)
+        for r in range(1, n_dev):                                         # inproc: the one process holds every device's share
+            nr, sr = make_reads(args, contigs, fa, r)
+            names, seqs = names + nr, seqs + sr
+        n_total = args.reads * world * n_dev
+    own = lfd.make_shards(torch, names, seqs, 1, bulk)[0][0]                  # this rank's shard, resident on the bulk device
+    job_shards = None
+    if exchange and rank == 0:
+        # rank 0 OWNS the whole job's read batch, resident in its HBM, packed once outside the timed region (the way a reader
+        # leaves a chunk in memory): shard r = what rank r would map by itself
+        if strong:
+            job_shards = [lfd.make_shards(torch, all_names[a:b], all_seqs[a:b], 1, bulk)[0][0] for a, b in bounds]
+        else:
+            job_shards = [own]
+            for r in range(1, world):
+                nr, sr = make_reads(args, contigs, fa, r)
+                job_shards.append(lfd.make_shards(torch, nr, sr, 1, bulk)[0][0])
+        log(f"rank 0 owns the job: {sum(len(s) for s in job_shards)} reads, {sum(s.nbytes for s in job_shards) / 1e9:.2f} GB in HBM")
+    if strong:
+        del all_names, all_seqs
+    contigs = None
+    bases_local = sum(len(s) for s in seqs)
+
+    # host thread budget: the cgroup quota (or the online CPUs) split between the ranks of this node
+    budget = host_budget()
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     params.threads = max(2, min(255, budget // max(1, local_world)))
     if os.environ.get("LF_BENCH_THREADS"):
         params.threads = int(os.environ["LF_BENCH_THREADS"])
     log(f"rank {rank}: {params.threads} host threads (budget {budget}, {local_world} ranks on this node)")
 
-    # caller-owned SAM buffer, pinned and reused by every step (rank 0's holds the whole job's SAM: the other ranks'
-    # records are gathered behind its own, so the output order is the input order)
-    est_bases = args.reads * args.read_len * 1.15
-    cap_one = int(2.6 * est_bases) + args.reads * 2048 + (1 << 20)
-    cap = cap_one * (world if (rank == 0 and exchange) else 1)
+    # SAM buffers, reused by every step.  dev_out: HBM (value); host_out: pinned host memory (PCIe-inclusive rate)
+    per_rank_reads = max(len(seqs), -(-n_total // world))
+    cap_one = int(3.0 * max(bases_local, per_rank_reads * args.read_len) * 1.1) + per_rank_reads * 2048 + (1 << 20)
+    read_cap = int(1.25 * max(bases_local, per_rank_reads * args.read_len) * 1.1) + per_rank_reads * 64 + (1 << 20)
+    dev_out = torch.empty(cap_one, dtype=torch.uint8, device=dev)
     try:
-        out_buf = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+        host_out = torch.empty(cap_one * n_dev, dtype=torch.uint8, pin_memory=True)
     except RuntimeError:
-        out_buf = torch.empty(cap, dtype=torch.uint8)
-    out_ptr = out_buf.data_ptr()
+        host_out = torch.empty(cap_one * n_dev, dtype=torch.uint8)
     fixed_arrays = (la.api._cstr_array(names), la.api._cstr_array(seqs))
     seq_lens = np.array([len(x) for x in seqs], dtype=np.uint32)          # Read.length of the reference's records
+    stage_in = torch.empty(read_cap, dtype=torch.uint8, device=dev) if bulk.type == "cpu" and dist else None
 
     class _Sam:                                                          # head()/len() like api.SamBuffer
-        def __init__(self, n):
-            self.n = n
+        def __init__(self, t, n):
+            self.t, self.n = t, n
 
         def __len__(self):
             return self.n
 
         def head(self, k):
-            return bytes(out_buf[:min(k, self.n)].numpy().tobytes())
+            return bytes(self.t[:min(k, self.n)].cpu().numpy().tobytes())
 
-    def step(with_exchange=False):
-        t_x0 = time.perf_counter()
-        if with_exchange:
-            # scatter: every rank receives its shard (two byte ranges + offsets) and maps it straight out of the receive buffer
-            shard, _ = lfd.scatter_packed_p2p(dist, torch, packed_all, rdev)
-            na, sa, sl = shard.arrays()
-            nn = shard
-        else:
-            (na, sa), sl, nn = fixed_arrays, seq_lens, names
+    def map_shard(shard, out):
+        """one step of the product path on a device-resident shard -> SAM text in `out` (HBM, or -- gloo hook -- host)"""
+        na = shard.name_array(torch)
+        blob = shard.blob
+        if blob.device.type == "cpu":                                   # gloo hook: what arrived in host memory is staged into HBM
+            stage_in[:shard.nbytes].copy_(blob[:shard.nbytes]); torch.cuda.current_stream().synchronize()
+            blob = stage_in
+        target = out if out.device.type == "cuda" else dev_out
         t_call = time.perf_counter()
-        ln, st = lf.map_batch_into(nn, None, out_ptr, cap_one, params=params, name_arr=na, seq_arr=sa, seq_lens=sl)
+        ln, st = lf.map_batch_dev(na, blob.data_ptr(), shard.seq_off[:-1], shard.seq_lens, target.data_ptr(), target.numel(), True, params=params)
         st["ms_python_call"] = (time.perf_counter() - t_call) * 1e3
-        t_g0 = time.perf_counter()
-        if with_exchange:                                    # gather: one SAM stream on rank 0, input order
-            ln = lfd.gather_sam_p2p(dist, torch, out_buf, ln, rdev)
-        st["ms_scatter"] = (t_call - t_x0) * 1e3
-        st["ms_gather"] = (time.perf_counter() - t_g0) * 1e3
-        return _Sam(ln or 0), st
+        if target is not out:
+            out[:ln].copy_(dev_out[:ln])
+        return ln, st
 
-    def timed(n_steps, with_exchange):
+    def step_hbm():
+        ln, st = map_shard(own, dev_out)
+        return _Sam(dev_out, ln), st
+
+    def step_host():
+        t_call = time.perf_counter()
+        if n_dev > 1:
+            ln, st = la.api.map_batch_multi_into(replicas, names, host_out.data_ptr(), host_out.numel(), params=params,
+                                                 name_arr=fixed_arrays[0], seq_arr=fixed_arrays[1], seq_lens=seq_lens)
+        else:
+            ln, st = lf.map_batch_into(names, None, host_out.data_ptr(), host_out.numel(), params=params, name_arr=fixed_arrays[0],
+                                       seq_arr=fixed_arrays[1], seq_lens=seq_lens)
+        st["ms_python_call"] = (time.perf_counter() - t_call) * 1e3
+        return _Sam(host_out, ln), st
+
+    def add(agg, st):
+        if agg is None:
+            return dict(st)
+        for k, v in st.items():
+            agg[k] += v
+        return agg
+
+    def timed(fn, n_steps):
+        """EXACTLY n_steps steps between barrier + synchronize on both sides; elapsed = max over ranks"""
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -306,12 +389,8 @@ def main():
         cpu0 = sum(os.times()[:4])
         agg, sam = None, None
         for _ in range(n_steps):
-            sam, st = step(with_exchange)
-            if agg is None:
-                agg = dict(st)
-            else:
-                for k, v in st.items():
-                    agg[k] += v
+            sam, st = fn()
+            agg = add(agg, st)
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -323,15 +402,18 @@ def main():
             el = float(tmax.item())
         return el, cpu_s, agg, sam
 
+    # ---- 1. no exchange: every rank maps the shard resident in its own HBM (N = 1: this is `value`) ----
+    primary = step_host if args.mode == "inproc" else step_hbm
     for _ in range(args.warmup):
-        step(exchange)
-    # the timed region: EXACTLY --steps steps between barrier + synchronize, max over ranks.  With N > 1 the exchange
-    # (scatter of the read batch from rank 0, gather of the SAM records) is INSIDE it; the same number of steps is then
-    # timed again without it (every rank maps the shard it already holds) and reported as value_without_exchange.
-    elapsed, cpu_s, agg, sam = timed(args.steps, exchange)
-    elapsed_nx = None
-    if exchange:
-        elapsed_nx, _, _, _ = timed(args.steps, False)
+        primary()
+    elapsed_nx, cpu_s, agg, sam = timed(primary, args.steps)
+    # ---- 2. the same steps through the host-buffer boundary (PCIe inside the step) ----
+    elapsed_host = None
+    if args.mode != "inproc":
+        step_host()
+        elapsed_host, _, _, _ = timed(step_host, args.steps)
+
+    elapsed, xinfo = elapsed_nx, None
     bases_total = bases_local
     if dist:
         bsum = torch.tensor([bases_local], dtype=torch.int64, device=rdev)
@@ -348,8 +430,8 @@ def main():
         saved = {k: os.environ.get(k) for k in ("LF_LANES", "LF_SERIAL_CLASSES")}
         os.environ["LF_LANES"] = "1"; os.environ["LF_SERIAL_CLASSES"] = "1"
         try:
-            step(False)                      # the one-chunk-at-a-time mode uses larger chunks: let the grow-only buffers settle
-            _, excl = step(False)
+            primary()                      # the one-chunk-at-a-time mode uses larger chunks: let the grow-only buffers settle
+            _, excl = primary()
         finally:
             for k, v in saved.items():
                 if v is None:
@@ -364,13 +446,15 @@ def main():
         hbm_used_gb = (total_b - free_b) / 1e9
     except Exception:                                                    # noqa: BLE001
         hbm_used_gb = None
-    if rank == 0:
+
+    def report(elapsed, sam, xinfo):
         K = args.steps
         bases = bases_total
         value = n_total * K / elapsed
+        per_rank = n_total * K / world
         # ---- roofline: algorithmic bytes (SURVEY 8d counters emitted by the kernels) / EXCLUSIVE kernel time ----
         # Durations come from the exclusive pass (one step = one launch sequence per chunk; HIP events on the launch
-        # streams; nothing else on the GPU).  Their sum is below ms_per_step; profiles/r02_c2 holds the rocprofv3
+        # streams; nothing else on the GPU).  Their sum is below ms_per_step; profiles/ holds the rocprofv3
         # --kernel-trace --stats summary of the same serialized command.
         def kernel_table(a):
             n_hits = a["n_seeds"]
@@ -383,9 +467,9 @@ def main():
                 "lf_chain_* (gather, sort, dp-n2 | clasp)": (a["ms_k_chain"], 16 * a["n_req_seeds"], a["search_launches"]),
                 # the alignment size classes lf_edlib_kernel<1,2,3,4,6,8>, lf_edlib_sweep_kernel<16|32|64, ...>: one launch group per round
                 "lf_edlib_* (size-class launch group)": (a["ms_k_edlib"], a["ext_bytes"], max(1, a["edlib_launches"])),
-                # CIGAR / MD: every op byte read twice (count pass, write pass), text written once
                 "lf_render_kernel": (a["ms_k_render"], a["ops_bytes"] + a["render_bytes"], max(1, a["render_launches"])),      # single pass: ops read once, text written once
-                "lf_ksw_kernel": (a["ms_k_ksw"], 0, max(1, a["n_ksw_problems"] and 1)),
+                # ksw_extend2: the two sequences once + one H / E row pair (8 B per query column) per target row inside the band
+                "lf_ksw_kernel": (a["ms_k_ksw"], a.get("ksw_bytes", 0), max(1, a["n_ksw_problems"] and 1)),
             }
         kx = kernel_table(excl)
         by_kernel = {}
@@ -395,24 +479,15 @@ def main():
                                     achieved_GBps=gbs, frac_of_8TBps=gbs / 8000.0)
         excl_sum = sum(v[0] for v in kx.values())
         dom = max(kx, key=lambda k: kx[k][0])                 # the dominant kernel (group) by exclusive time
-        pmc = None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_c2", "pmc_fetch_write_summary.json")
-        if os.path.exists(pmc_path) and args.genome_mbp == 3100 and args.reads == 100000 and world == 1 and args.config == "c2" and args.repeat_profile == "default":
-            pmc = json.load(open(pmc_path))           # one profiled step of the same command (FETCH_SIZE / WRITE_SIZE passes)
         dms, dbytes, dl = kx[dom]
         achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
-        traffic = None
-        if pmc:
-            prefix = dom.split(" ")[0].rstrip("*")
-            fam = [v for k, v in pmc.items() if k.startswith(prefix)]
-            if fam:    # the counter passes profile exactly ONE step (--no-exclusive --steps 1 --warmup 0): bytes per step / launches per
-                # step; FETCH_SIZE x2 for wide coalesced reads is NOT applied (profiles/r02_c2/README.md)
-                traffic = sum(v.get("fetch_kb", 0.0) + v.get("write_kb", 0.0) for v in fam) * 1024.0 / max(1.0, dl)
+        traffic, traffic_src = load_traffic(args, world, dom, dl)
         roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=traffic,
+                        traffic_source=traffic_src,
                         launches_per_step=int(dl), avg_launch_ms=dms / max(1, dl), algorithmic_bytes_per_launch=dbytes / max(1, dl),
                         exclusive_ms_per_step=dms, exclusive_ms_sum_all_kernels=excl_sum, by_kernel=by_kernel,
                         measured="exclusive pass inside bench.py: LF_LANES=1 LF_SERIAL_CLASSES=1, HIP events on the launch streams, one step "
-                                 "after the timed region; the rocprofv3 summary of the same mode is profiles/r02_c2/kernel_stats_serialized.csv",
+                                 "after the timed region; the rocprofv3 summary of the same mode is under profiles/",
                         overlapped_bracket_ms_per_step={k: round(v[0] / K, 2) for k, v in kernel_table(agg).items()},
                         chunks_in_flight_timed_region=8)
         if dom.startswith("lf_edlib"):
@@ -421,32 +496,40 @@ def main():
             lane_ops = excl["dp_block_steps"] * 55.0
             roofline["alu"] = dict(bound="int32 VALU", achieved=lane_ops / (dms * 1e-3) / 1e12, peak=78.6, unit="T lane-ops/s",
                                    frac=lane_ops / (dms * 1e-3) / 1e12 / 78.6, dp_block_steps_per_step=excl["dp_block_steps"],
-                                   note="forward pass only (algorithmic work); the one-lane-per-path traceback kernel replays ~ (m / 8 + n / 64) single-block tiles per problem on top of it")
+                                   note="forward pass only (algorithmic work); the traceback replays ~ (m / 8 + n / 64) single-block tiles per problem on top of it")
+        shard_desc = (f"the SAME {n_total}-read set cut by bases over {world} ranks" if strong else f"{args.reads} reads per GPU")
         out = {
-            "metric": "aligned reads/s", "value": value, "unit": "reads/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "aligned reads/s", "value": value, "unit": "reads/s", "n_gpus": world * n_dev, "steps": K, "warmup": args.warmup,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {args.reads} synthetic {'ONT' if args.config == 'c5' else 'PacBio'} reads per GPU (~{args.read_len} bp, {args.err:.0%} err) vs "
+            "config": {"workload": f"{args.config}: {shard_desc}, synthetic {'ONT' if args.config == 'c5' else 'PacBio'} reads (~{args.read_len} bp, {args.err:.0%} err) vs "
                                    f"{args.genome_mbp:g} Mbp synthetic genome ({args.repeat_profile} repeats), -k {kk} -c {cc} --chainAlg {args.chain_alg}" + (f" -n {args.max_map}" if args.max_map != 10 else ""),
-                       "reads_per_gpu": args.reads, "mean_read_len": bases / max(1, n_total), "genome_mbp": args.genome_mbp,
-                       "parallelism": (f"rank 0 owns the {n_total}-read batch: RCCL point-to-point scatter of the packed reads + gather of the SAM "
-                                       f"records inside the timed region; {world} GPUs, index replicated" if exchange else
+                       "reads_total": n_total, "mean_read_len": bases / max(1, n_total), "genome_mbp": args.genome_mbp,
+                       "io": ("host buffers (lf_map_batch_multi): one process, every device copies through its own PCIe link" if args.mode == "inproc" else
+                              "read bases resident in HBM when the timed region starts, SAM records left in HBM (lf_map_batch_dev)"),
+                       "parallelism": (f"one process drives {n_dev} devices (lf_map_batch_multi), index replicated" if args.mode == "inproc" else
+                                       f"rank 0 owns the {n_total}-read job in HBM: RCCL point-to-point scatter of the packed reads + gather of the SAM "
+                                       f"records, pipelined with the mapping, inside the timed region; {world} GPUs, index replicated" if (exchange and xinfo and xinfo.get("status") == "ok") else
                                        f"reads sharded over {world} GPU(s), index replicated, no data-path collective"),
                        "index": "FM-index + full SA resident in HBM"},
             "gbp_per_s": bases * K / elapsed / 1e9, "host_cpu_seconds_per_step": cpu_s / K, "hbm_used_gb": hbm_used_gb,
-            "host_ms_per_step": {k: agg[k] / K for k in ("ms_total", "ms_python_call", "ms_seed", "ms_vote", "ms_chain", "ms_extend", "ms_render", "ms_sam", "ms_scatter", "ms_gather")},
-            "per_read": {"seeds": agg["n_seeds"] / (n_total * K / world), "edlib_problems": agg["n_edlib_problems"] / (n_total * K / world),
-                         "seed_bytes": (16 * agg["n_cache"] + 64 * agg["n_occblk"] + 8 * agg["n_sa"] + agg["n_readbytes"]) / (n_total * K / world),
-                         "ext_bytes": agg["ext_bytes"] / (n_total * K / world), "cigar_md_text_bytes": agg["render_bytes"] / (n_total * K / world),
-                         "dp_block_steps": agg["dp_block_steps"] / (n_total * K / world),
-                         "chain_requests": agg["n_chain_problems"] / (n_total * K / world), "tie_requests": agg["n_tie_requests"] / (n_total * K / world),
-                         "ksw_problems": agg["n_ksw_problems"] / (n_total * K / world)},
+            "host_ms_per_step": {k: agg[k] / K for k in ("ms_total", "ms_python_call", "ms_seed", "ms_vote", "ms_chain", "ms_extend", "ms_render", "ms_sam")},
+            "per_read": {"seeds": agg["n_seeds"] / per_rank, "edlib_problems": agg["n_edlib_problems"] / per_rank,
+                         "seed_bytes": (16 * agg["n_cache"] + 64 * agg["n_occblk"] + 8 * agg["n_sa"] + agg["n_readbytes"]) / per_rank,
+                         "ext_bytes": agg["ext_bytes"] / per_rank, "cigar_md_text_bytes": agg["render_bytes"] / per_rank,
+                         "dp_block_steps": agg["dp_block_steps"] / per_rank,
+                         "chain_requests": agg["n_chain_problems"] / per_rank, "tie_requests": agg["n_tie_requests"] / per_rank,
+                         "ksw_problems": agg["n_ksw_problems"] / per_rank},
             "roofline": roofline,
         }
-        if elapsed_nx is not None:
-            out["value_without_exchange"] = n_total * K / elapsed_nx
-            out["ms_per_step_without_exchange"] = elapsed_nx / K * 1e3
-        if not args.no_cpu_baseline and world == 1:
+        out["value_without_exchange"] = n_total * K / elapsed_nx
+        out["ms_per_step_without_exchange"] = elapsed_nx / K * 1e3
+        if elapsed_host is not None:
+            out["value_pcie_inclusive"] = n_total * K / elapsed_host      # reads in host memory -> SAM text in host memory, no exchange
+            out["ms_per_step_pcie_inclusive"] = elapsed_host / K * 1e3
+        if xinfo:
+            out["exchange"] = xinfo
+        if not args.no_cpu_baseline and world == 1 and sam is not None:
             try:
                 cb = cpu_baseline(args, fa, names, seqs)
             except Exception as e:                                          # noqa: BLE001
@@ -459,7 +542,7 @@ def main():
                 # bit-match against the reference on the sampled reads: the sample is a prefix of the batch and records are in
                 # read order, so the head of our SAM holds the same reads.  Primary records (the BASELINE metric) and ALL
                 # records of a read (secondaries, supplementaries: same lines, same order) are compared.
-                head = sam.head(6 * len(ref_sam) + (1 << 20)) if hasattr(sam, "head") else sam[:6 * len(ref_sam) + (1 << 20)]
+                head = sam.head(6 * len(ref_sam) + (1 << 20))
                 def by_read(txt):
                     d = {}
                     for l in txt.split(b"\n"):
@@ -481,11 +564,116 @@ def main():
                 out["all_records_match_rate"] = hit_all / max(1, tot)
                 out["reads_compared"] = tot
                 out["records_compared"] = sum(len(v) for k, v in want.items() if k in mine)
+        if sam is not None and os.environ.get("LF_BENCH_SAM_DIGEST"):
+            # test hook: a digest of the job's gathered records (compared with the 1-rank run of the same read set)
+            out["sam_md5"] = hashlib.md5(sam.head(len(sam))).hexdigest()
+            out["sam_bytes"] = len(sam)
         print(json.dumps(out), flush=True)
-    lf.close()
+
+    # ---- 3. N > 1: the pipelined exchange, inside the timed region ----
+    if exchange:
+        px = lfd.PipelinedExchange(dist, torch, bulk, ctl, read_cap, cap_one)
+        state = {"done": False}
+
+        def run_exchange(n_steps):
+            """step k: post (reads k + 1 out, SAM k - 1 back) -> map k -> complete.  -> length of the last step's gathered text"""
+            cur = job_shards[0] if rank == 0 else None
+            if rank == 0:                                                # scatter of step 0: exposed
+                px.post(-1, next_shards=job_shards)
+            else:
+                px.post(-1, next_shards=True)
+            px.complete()
+            prev_len, st_agg = None, None
+            for k in range(n_steps):
+                more = k + 1 < n_steps
+                px.post(k, next_shards=(job_shards if rank == 0 else True) if more else None, prev_own_len=prev_len)
+                shard = cur if rank == 0 else px.rx_shard[k & 1]
+                prev_len, st = map_shard(shard, px.sam[k & 1])
+                st_agg = add(st_agg, st)
+                px.complete()
+            px.post(n_steps, next_shards=None, prev_own_len=prev_len)   # gather of the last step: exposed
+            px.complete()
+            return st_agg
+
+        def watchdog():
+            if not state["done"]:
+                if rank == 0:
+                    log(f"exchange phase still running after {args.exchange_timeout:.0f}s: reporting the no-exchange rate")
+                    state["timeout"] = True
+                    report(elapsed_nx, None, dict(status="timeout"))
+                os._exit(3 if rank else 0)
+        timer = threading.Timer(args.exchange_timeout, watchdog)
+        timer.daemon = True
+        timer.start()
+        run_exchange(1)                                                   # warm-up: buffers grow, RCCL connects its peers
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_exchange(args.steps)
+        dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        tmax = torch.tensor([el], dtype=torch.float64, device=rdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        state["done"] = True
+        timer.cancel()
+        if rank == 0:
+            gt, glen = px.gathered(args.steps - 1)
+            sam = _Sam(gt, glen)                                          # the whole job's records, input order
+            xinfo = dict(status="ok", transport=backend, bulk_memory=str(bulk), GB_out_per_step=px.bytes_out / (args.steps + 1) / 1e9,
+                         GB_in_per_step=px.bytes_in / (args.steps + 1) / 1e9, gathered_bytes_last_step=glen,
+                         pipeline="reads of step k+1 and SAM of step k-1 in flight while step k maps; first scatter and last gather exposed")
+
+    if rank == 0:
+        report(elapsed, sam, xinfo)
+    for h in replicas:
+        h.close()
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 
+def load_traffic(args, world, dom, launches):
+    """HBM bytes per launch of the dominant kernel group from the committed counter passes -- only if they were taken on THIS
+    source tree (profiles/<dir>/pmc_fetch_write_summary.json carries the git commit of the tree it profiled; collect.sh
+    writes it) and on this configuration; otherwise null: a stale file says nothing about the kernels that just ran."""
+    import subprocess
+    if not (args.genome_mbp == 3100 and args.reads == 100000 and world == 1 and args.config == "c2" and args.repeat_profile == "default"):
+        return None, "not the profiled configuration"
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+    except Exception:                                                    # noqa: BLE001
+        head = ""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c2", "pmc_fetch_write_summary.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+        except Exception:                                                # noqa: BLE001
+            continue
+        commit = pmc.get("_meta", {}).get("source_tree") or pmc.get("_meta", {}).get("git_commit")
+        src_hash = tree_hash()
+        if not commit or commit not in (head, src_hash):
+            continue
+        prefix = dom.split(" ")[0].rstrip("*")
+        fam = [v for k, v in pmc.items() if k.startswith(prefix) and isinstance(v, dict)]
+        if fam:      # the counter passes profile exactly ONE step (--no-exclusive --steps 1 --warmup 0): bytes per step / launches per step
+            return sum(v.get("fetch_kb", 0.0) + v.get("write_kb", 0.0) for v in fam) * 1024.0 / max(1.0, launches), os.path.relpath(path, ROOT)
+    return None, "no counter pass of this source tree under profiles/ (profiles/tools/collect.sh writes one)"
+
+
+def tree_hash():
+    """digest of the kernel sources: what a profile must have been taken on to describe the kernels that ran"""
+    import glob
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "lordfast_amd", "csrc", "*"))):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--tree-hash":
+        print(tree_hash())
+        sys.exit(0)
     main()

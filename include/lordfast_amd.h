@@ -168,6 +168,7 @@ typedef struct {
     uint64_t ops_bytes;                                 /* edit-path bytes left in HBM for the renderer */
     uint64_t n_req_seeds, n_tie_requests;              /* seeds gathered into chain requests; requests whose equal qPos needed the std::sort replay */
     uint64_t dp_block_steps;                            /* sum over alignment problems of ceil(q / 64) * t: Myers block steps of one forward pass */
+    uint64_t ksw_bytes;                                 /* sum over ksw problems of qlen + tlen + 12: the two sequences read once, three results written */
 } lf_stats_t;
 
 int  lf_map_batch(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,
@@ -201,6 +202,16 @@ int  lf_map_batch_into(const lf_index_t *idx, const lf_params_t *p, int n, const
 int  lf_map_batch_into_lens(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,
                             const char *const *seqs, const char *const *quals, const uint32_t *seq_lens,
                             char *out, size_t out_cap, size_t *sam_len, lf_stats_t *stats);
+/* Device-resident form of lf_map_batch_into_lens: the bases (and qualities) are already in HBM of idx's device and the
+ * SAM text is left there (out_is_device) -- the bulk data never crosses PCIe.  This is what one rank of the N-GPU
+ * deployment calls on the shard it received over xGMI (lordfast_amd/dist.py); the reference's equivalent is the chunk
+ * hand-over initFASTChunk(Read *seqList, int n) + mapSeqMT() (src/LordFAST.h:124-125), whose buffers live in host memory.
+ *   read i = d_seqs[seq_off[i] .. seq_off[i] + seq_lens[i])   (anything may sit between two reads);
+ *   d_quals: NULL (FASTA, QUAL printed as "*") or a device blob in the same layout; names / seq_off / seq_lens: host arrays.
+ *   out: out_cap bytes of device memory (out_is_device != 0) or host memory; a device buffer gets no terminating NUL. */
+int  lf_map_batch_dev(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names, const void *d_seqs,
+                      const uint64_t *seq_off, const uint32_t *seq_lens, const void *d_quals, void *out, size_t out_cap,
+                      int out_is_device, size_t *sam_len, lf_stats_t *stats);
 /* ------------------------------------------------------------------------------------------------
  * Several GPUs in one process: idx[d] = the same index loaded on device d (lf_index_load(prefix, d, ...)).
  * Reads are independent, so the batch is cut into chunks that the devices pull from one counter -- the reference's

@@ -53,7 +53,8 @@ class Stats(C.Structure):
                                           "edlib_launches", "search_launches", "locate_launches")] + \
                [("ms_render", C.c_double), ("ms_k_render", C.c_float), ("ms_k_vote", C.c_float),
                 ("render_bytes", C.c_uint64), ("render_launches", C.c_uint64),
-                ("ops_bytes", C.c_uint64), ("n_req_seeds", C.c_uint64), ("n_tie_requests", C.c_uint64), ("dp_block_steps", C.c_uint64)]
+                ("ops_bytes", C.c_uint64), ("n_req_seeds", C.c_uint64), ("n_tie_requests", C.c_uint64), ("dp_block_steps", C.c_uint64),
+                ("ksw_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -294,6 +295,25 @@ class LordFast:
                                         C.byref(ln), C.byref(st)), "lf_map_batch_into")
         return ln.value, st.as_dict()
 
+    def map_batch_dev(self, name_arr, d_seqs: int, seq_off, seq_lens, out_ptr: int, out_cap: int, out_is_device: bool = True,
+                      d_quals: int = 0, params: Params | None = None):
+        """lf_map_batch_dev: the bases are already in HBM (address d_seqs, read i at seq_off[i], seq_lens[i] long) and the SAM
+        text is written to `out_ptr` (device memory unless out_is_device is False).  name_arr: ctypes array of C strings
+        (host).  -> (length, stats)"""
+        p = params or default_params()
+        so = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        sl = np.ascontiguousarray(seq_lens, dtype=np.uint32)
+        n = len(sl)
+        if so.shape != (n,):
+            raise LfError(f"seq_off has shape {so.shape}, expected ({n},)")
+        ln, st = C.c_size_t(), Stats()
+        self.L.lf_map_batch_dev.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t), C.POINTER(Stats)]
+        _check(self.L.lf_map_batch_dev(self.h, C.byref(p), n, name_arr, C.c_void_p(d_seqs), so.ctypes.data, sl.ctypes.data,
+                                       C.c_void_p(d_quals) if d_quals else None, C.c_void_p(out_ptr), out_cap, 1 if out_is_device else 0,
+                                       C.byref(ln), C.byref(st)), "lf_map_batch_dev")
+        return ln.value, st.as_dict()
+
     def map_file(self, reads_path: str, out_path: str, params: Params | None = None, header: bool = True, cmdline: str = "",
                  batch_reads: int = 0):
         """reads file -> SAM file (lf_map_file): the reader runs ahead of the GPU.  -> stats dict"""
@@ -406,3 +426,21 @@ def map_batch_multi(handles, names, seqs, quals=None, params: Params | None = No
     sam = C.string_at(out, ln.value) if ln.value else b""
     L.lf_free(out)
     return sam, st.as_dict()
+
+
+def map_batch_multi_into(handles, names, out_ptr: int, out_cap: int, params: Params | None = None, name_arr=None, seq_arr=None,
+                         seq_lens=None, seqs=None):
+    """lf_map_batch_multi into a caller-owned (pinned) buffer. -> (length, stats dict)"""
+    L = lib()
+    L.lf_map_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Params), C.c_int, C.POINTER(C.c_char_p),
+                                     C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(Stats)]
+    p = params or default_params()
+    hs = (C.c_void_p * len(handles))(*[h.h for h in handles])
+    na = name_arr if name_arr is not None else _cstr_array(names)
+    sa = seq_arr if seq_arr is not None else _cstr_array(seqs)
+    sl = np.ascontiguousarray(seq_lens, dtype=np.uint32) if seq_lens is not None else None
+    ln, st = C.c_size_t(), Stats()
+    _check(L.lf_map_batch_multi(hs, len(handles), C.byref(p), len(names), na, sa, None, sl.ctypes.data if sl is not None else None,
+                                C.c_void_p(out_ptr), out_cap, None, C.byref(ln), C.byref(st)), "lf_map_batch_multi")
+    return ln.value, st.as_dict()

@@ -47,6 +47,10 @@ typedef struct {        /* raw device results of the seed stage, copied to host 
 int  lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads,
               const uint64_t *off, int want_hits, lfg_hits_t *out);
 
+int  lfg_seed_src(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads, const void *d_src, const uint64_t *src_off,
+                  const uint64_t *off, int want_hits, lfg_hits_t *out);
+int  lfg_gather_reads(int device, void *stream, const void *d_src, const uint64_t *d_src_off, const uint64_t *d_off, int n_reads, void *d_dst);
+
 /* ---- lf_vote.hip: votes -> candidate windows -> chains, on the hits that lfg_seed left in HBM ---- */
 typedef struct {
     int n_reads, n_req;
@@ -151,7 +155,8 @@ typedef struct {
 } lf_samline_t;                                     /* 48 bytes */
 int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, int n_lines, const lf_samline_t *lines,
                   const char *names, uint64_t names_bytes, const char *blob, uint64_t blob_bytes,
-                  const char *quals, uint64_t quals_bytes, const lfg_rtext_t *rt, int parity, uint64_t *total_out);
+                  const char *quals, uint64_t quals_bytes, const void *d_quals_src, int n_batch_reads,
+                  const lfg_rtext_t *rt, int parity, uint64_t *total_out);
 int lfg_sam_fetch(const struct lf_index *ix, char *dst, uint64_t total, int parity);
 int lfg_sam_wait(const struct lf_index *ix);
 int lfg_sam_fetch_async(const struct lf_index *ix, char *dst, uint64_t total, int parity);

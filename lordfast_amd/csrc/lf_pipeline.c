@@ -204,6 +204,7 @@ typedef struct job {
 typedef struct {
     const char *name, *seq, *qual;
     uint32_t len; int isFq;
+    uint64_t src_off;      /* lf_map_batch_dev: where the read's bases (and qualities) are in the caller's device blobs; seq / qual == NULL until rd_host_bases */
     char *seq_rev, *qual_rev;
     Seed_t *F, *R; uint32_t nF, nR;
     int mode;              /* 0 short, 1 no window, 2 coarse, 3 fine */
@@ -253,8 +254,9 @@ typedef struct ctx {
     int dev_sam; lfg_rtext_t rtext_dev; uint32_t *rlens; uint64_t sam_total; int sam_parity;       /* SAM lines assembled on the device (lf_sam.hip): text size of the chunk */
     /* output assembly */
     char *out_base; uint64_t *out_off;
-    const char *const *len_seqs; uint32_t *len_out;
+    const char *const *len_seqs; uint32_t *len_out; volatile int len_bad;
     int *seed_map; char *cat; uint64_t *cat_off;
+    const unsigned char *d_seqs, *d_quals;      /* lf_map_batch_dev: the caller's device blobs (NULL: host strings) */
 } ctx_t;
 
 /* ---------------------------------------------------------------- parallel for on a persistent thread pool
@@ -680,11 +682,28 @@ static memo_t *memo_add(job_t *j, const rkey_t *k, arena_t *ar)
     return m;
 }
 
+/* lf_map_batch_dev: the host sees a read's bases only where it has to (reads shorter than -l, the replay of the rare
+ * chains, entries printed on the host): one small D2H copy on demand.  A read is touched by one worker at a time. */
+static void rd_host_bases(ctx_t *cx, rd_t *rd, arena_t *ar)
+{
+    if (rd->seq || !cx->d_seqs) return;
+    char *b = (char *)ar_alloc(ar, ((size_t)rd->len + 1) * (rd->isFq ? 2 : 1));
+    if (rd->len && lfg_fetch(cx->ix->device, b, cx->d_seqs + rd->src_off, rd->len) != LF_OK) memset(b, 'N', rd->len);
+    b[rd->len] = 0;
+    if (rd->isFq) {
+        char *q = b + rd->len + 1;
+        if (rd->len && lfg_fetch(cx->ix->device, q, cx->d_quals + rd->src_off, rd->len) != LF_OK) memset(q, '!', rd->len);
+        q[rd->len] = 0; rd->qual = q;
+    }
+    rd->seq = b;
+}
+
 /* the walk's query string; the reverse complement of a read is only materialised if a byte-string request needs it */
 static const char *walk_query(walk_t *w)
 {
     if (!w->query) {
         rd_t *rd = &w->cx->reads[w->job->read];
+        rd_host_bases(w->cx, rd, &w->cx->arena[w->tid]);
         if (!rd->seq_rev) { rd->seq_rev = (char *)ar_alloc(&w->cx->arena[w->tid], (size_t)rd->len + 1); revcomp_into(rd->seq, rd->seq_rev, rd->len); }
         w->query = rd->seq_rev;
     }
@@ -1120,6 +1139,7 @@ static int walk_chain_mode(ctx_t *cx, int tid, job_t *job, samlist_t *map, int t
     const Seed_t *s = job->chain;
     const uint32_t chainLen = job->chainLen;
     walk_t W; memset(&W, 0, sizeof W);
+    rd_host_bases(cx, rd, &cx->arena[tid]);
     W.cx = cx; W.tid = tid; W.job = job; W.query = isRev ? rd->seq_rev : rd->seq; W.readLen = rd->len; W.build = 1;
     job->hint = 0;
     const int32_t readLen = (int32_t)rd->len;
@@ -1277,6 +1297,7 @@ static void resolve_lazy_ops(ctx_t *cx, int tid, job_t *job, memo_t *m, uint32_t
     const rkey_t *k = &m->key;
     rd_t *rd = &cx->reads[job->read];
     walk_t W; memset(&W, 0, sizeof W);
+    rd_host_bases(cx, rd, &cx->arena[tid]);
     W.cx = cx; W.tid = tid; W.job = job; W.query = job->isRev ? rd->seq_rev : rd->seq; W.readLen = rd->len;
     char *q = (char *)ar_alloc(&cx->arena[tid], (size_t)k->qn + k->tn + 2), *t = q + k->qn + 1;
     put_query(&W, k, q); put_target(&W, k, t);
@@ -1359,6 +1380,7 @@ static void sam_line(str_t *o, const ctx_t *cx, const rd_t *r, const sam_t *s, i
 static void print_sam_entry(ctx_t *cx, rd_t *r, int num)
 {
     str_t *o = &r->out;
+    rd_host_bases(cx, r, &cx->arena[0]);      /* called from the lane driver's serial loop (or, host SAM path, never in device-input mode) */
     const samlist_t *mp = r->maps;
     const int readLen = (int)r->len, maxWin = cx->p->max_map;
     const double bestEdit = (num > 0 ? (double)(-1 * mp[0].totalScore) / readLen : 1);
@@ -1596,6 +1618,12 @@ static void phase_merge_edlib(ctx_t *cx, int tid, int t)
 }
 
 static void phase_strlen(ctx_t *cx, int tid, int i) { (void)tid; cx->len_out[i] = (uint32_t)strlen(cx->len_seqs[i]); }
+static void phase_checklen(ctx_t *cx, int tid, int i)
+{
+    (void)tid;
+    const char *s = cx->len_seqs[i]; const uint32_t l = cx->len_out[i];
+    if (s[l] != 0 || (l > 0 && s[l - 1] == 0)) __sync_lock_test_and_set(&cx->len_bad, i);
+}
 
 static void phase_merge_desc(ctx_t *cx, int tid, int t)
 {
@@ -1687,19 +1715,25 @@ static int map_chunk(ctx_t *cx)
         uint64_t bases = 0;
         for (int i = 0; i < n; i++) if ((int)cx->reads[i].len >= cx->p->min_read_len) { cx->reads[i].seed_idx = m; map[m++] = i; bases += cx->reads[i].len; }
         if (m) {
-            char *cat = (char *)lfg_pin_slot(LF_PS_READS, bases + 64);
-            uint64_t *off = (uint64_t *)lfg_pin_slot(LF_PS_READOFF, ((size_t)m + 1) * 8);
-            if (!cat || !off) { free(map); return LF_ERR_NOMEM; }
+            char *cat = cx->d_seqs ? NULL : (char *)lfg_pin_slot(LF_PS_READS, bases + 64);
+            uint64_t *off = (uint64_t *)lfg_pin_slot(LF_PS_READOFF, ((size_t)m + 1) * 8 * (cx->d_seqs ? 2 : 1));
+            if ((!cat && !cx->d_seqs) || !off) { free(map); return LF_ERR_NOMEM; }
             uint64_t o = 0;
             for (int k = 0; k < m; k++) { off[k] = o; o += cx->reads[map[k]].len; }
             off[m] = o;
             cx->seed_map = map; cx->cat = cat; cx->cat_off = off;
             double tc0 = now_ms();
+            if (cx->d_seqs) {      /* bases already in HBM: a device gather replaces the host concatenation + H2D copy */
+                uint64_t *so = off + m + 1;
+                for (int k = 0; k < m; k++) so[k] = cx->reads[map[k]].src_off;
+                rc = lfg_seed_src(cx->ix, cx->p, m, NULL, cx->d_seqs, so, off, cx->host_vote, &hits);
+            } else {
             parallel_for(cx, m, phase_concat);
             tmark(cx, "concat");
             if (getenv("LF_TIMING")) fprintf(stderr, "[lf] concat %.1f ms\n", now_ms() - tc0);
             tc0 = now_ms();
             rc = lfg_seed(cx->ix, cx->p, m, cat, off, cx->host_vote, &hits);
+            }
             tmark(cx, "SEED");
             if (getenv("LF_TIMING")) fprintf(stderr, "[lf] lfg_seed %.1f ms (search %.1f locate %.1f), %llu hits\n", now_ms() - tc0, hits.ms_search, hits.ms_locate, (unsigned long long)hits.n_hits);
             if (rc != LF_OK) { free(map); return rc; }
@@ -1978,7 +2012,7 @@ extend:
             cx->ksw_rounds = (ksw_round_t *)realloc(cx->ksw_rounds, ((size_t)cx->n_ksw_rounds + 1) * sizeof(ksw_round_t));
             cx->ksw_rounds[cx->n_ksw_rounds++] = R;
             if (rc != LF_OK) return rc;
-            st->ms_k_ksw += ms; st->n_ksw_problems += (uint64_t)nk;
+            st->ms_k_ksw += ms; st->n_ksw_problems += (uint64_t)nk; st->ksw_bytes += qn + tn + 12ull * (uint64_t)nk;
         }
     }
     t1 = now_ms(); st->ms_extend += t1 - t0; tstage[3] = t1 - t0; t0 = t1;
@@ -2048,7 +2082,7 @@ extend:
             }
             any_fq |= r->isFq;
             const int num = r->mode == 3 ? r->nWins : 1;
-            int host_strings = 0;                /* a record whose CIGAR / MD were built per base on the host (the reference's misaligned-MD branch) */
+            int host_strings = nl > 65535;       /* a name longer than the line descriptor's 16-bit length, or a record whose CIGAR / MD were built per base on the host (the reference's misaligned-MD branch) */
             if (r->mode >= 2) for (int w = 0; w < num; w++) for (int j = 0; j < r->maps[w].n; j++) host_strings |= r->maps[w].v[j].rec < 0;
             if (host_strings) {
                 /* rare: print the whole entry on the host (its other records' text is fetched from the device) */
@@ -2070,14 +2104,17 @@ extend:
             lines_sam_entry(cx, &V, r, name_off, num, ar);
         }
         if (V.nb >= 0xffffffffull || V.nn >= 0xffffffffull) { free(V.ln); free(V.blob); free(V.names); lf_set_error("lf_map_batch: chunk too large for the SAM writer"); return LF_ERR_ARG; }
-        char *qcat = NULL; uint64_t qbytes = 0;
-        if (any_fq) {                            /* FASTQ: the qualities in the layout of the resident read batch */
+        char *qcat = NULL; uint64_t qbytes = 0; int n_batch = 0;
+        for (int i = 0; i < n; i++) if ((int)cx->reads[i].len >= cx->p->min_read_len) n_batch++;
+        if (any_fq && cx->d_quals) { for (int i = 0; i < n; i++) if ((int)cx->reads[i].len >= cx->p->min_read_len) qbytes += cx->reads[i].len; }
+        else if (any_fq) {                            /* FASTQ: the qualities in the layout of the resident read batch */
             for (int i = 0; i < n; i++) if ((int)cx->reads[i].len >= cx->p->min_read_len) qbytes += cx->reads[i].len;
             qcat = (char *)malloc(qbytes + 1);
             uint64_t o = 0;
             for (int i = 0; i < n; i++) { const rd_t *r = &cx->reads[i]; if ((int)r->len < cx->p->min_read_len) continue; if (r->isFq) memcpy(qcat + o, r->qual, r->len); else memset(qcat + o, '*', r->len); o += r->len; }
         }
-        rc = lfg_sam_build(cx->ix, cx->p, V.n, V.ln, V.names, V.nn, V.blob, V.nb, qcat, qbytes, &cx->rtext_dev, cx->sam_parity, &cx->sam_total);
+        rc = lfg_sam_build(cx->ix, cx->p, V.n, V.ln, V.names, V.nn, V.blob, V.nb, qcat, qbytes, (any_fq && cx->d_quals) ? cx->d_quals : NULL, n_batch,
+                           &cx->rtext_dev, cx->sam_parity, &cx->sam_total);
         free(V.ln); free(V.blob); free(V.names); free(qcat);
         if (rc != LF_OK) return rc;
     } else parallel_for(cx, n, phase_sam_print);
@@ -2121,6 +2158,7 @@ typedef struct {
     const lf_index_t *const *ixs; int n_ix;       /* one replica of the index per device; lane l works on device l % n_ix */
     const lf_params_t *p;
     const char *const *names, *const *seqs, *const *quals; const uint32_t *lens;
+    const unsigned char *d_seqs, *d_quals; const uint64_t *src_off; int dev_out;     /* lf_map_batch_dev: bases / qualities / SAM text in HBM */
     int slots;                                  /* per-worker scratch slots = pool workers + 2 drivers */
     chunk_t *chunks; int n_chunks, n_chunks0; volatile int next_chunk;   /* n_chunks0: entries cut up front; n_chunks grows when a lane cuts a chunk */
     pthread_mutex_t mu; pthread_cond_t cv;      /* chunk sizes become known in any order */
@@ -2140,6 +2178,7 @@ static void merge_stats(lf_stats_t *d, const lf_stats_t *a)
     d->n_sa += a->n_sa; d->n_readbytes += a->n_readbytes; d->ext_bytes += a->ext_bytes; d->edlib_launches += a->edlib_launches;
     d->search_launches += a->search_launches; d->locate_launches += a->locate_launches;
     d->dp_block_steps += a->dp_block_steps; d->ms_render += a->ms_render; d->ms_k_render += a->ms_k_render; d->ms_k_vote += a->ms_k_vote; d->ops_bytes += a->ops_bytes; d->n_req_seeds += a->n_req_seeds; d->n_tie_requests += a->n_tie_requests; d->render_bytes += a->render_bytes; d->render_launches += a->render_launches;
+    d->ksw_bytes += a->ksw_bytes;
 }
 
 /* base offset of a chunk's text = the sizes of all chunks of earlier reads.  block == 0: returns 0 when one of them has not
@@ -2206,7 +2245,7 @@ static void *lane_main(void *arg_)
     lf_stats_t *st = &B->st[lane];
     uint64_t max_hits = 1ull << 30;
     if (getenv("LF_MAX_CHUNK_HITS")) { max_hits = strtoull(getenv("LF_MAX_CHUNK_HITS"), NULL, 10); if (max_hits < 1) max_hits = 1; }   /* test hook */
-    int todo[64], n_todo = 0;                       /* second halves of chunks this lane had to cut */
+    int todo[66], n_todo = 0;                       /* second halves of chunks this lane had to cut */
     pending_t pend; memset(&pend, 0, sizeof pend);
     int parity = 0;
     for (;;) {
@@ -2231,14 +2270,19 @@ static void *lane_main(void *arg_)
         cx.max_chunk_hits = max_hits;
         cx.dev_sam = !B->host_cigar && !B->host_vote && !getenv("LF_HOST_SAM");
         cx.sam_parity = parity;
+        cx.d_seqs = B->d_seqs; cx.d_quals = B->d_quals;
         cx.n_reads = C->i1 - C->i0;
         cx.reads = (rd_t *)calloc((size_t)cx.n_reads, sizeof(rd_t));
         uint64_t chunk_bases = 0;
         for (int i = C->i0; i < C->i1; i++) {
             rd_t *r = &cx.reads[i - C->i0];
-            r->name = B->names[i]; r->seq = B->seqs[i]; r->len = B->lens[i];
-            r->isFq = (B->quals && B->quals[i] && B->quals[i][0]);
-            r->qual = r->isFq ? B->quals[i] : "*";
+            r->name = B->names[i]; r->len = B->lens[i];
+            if (B->d_seqs) { r->seq = NULL; r->src_off = B->src_off[i]; r->isFq = B->d_quals != NULL; r->qual = r->isFq ? NULL : "*"; }
+            else {
+                r->seq = B->seqs[i];
+                r->isFq = (B->quals && B->quals[i] && B->quals[i][0]);
+                r->qual = r->isFq ? B->quals[i] : "*";
+            }
             chunk_bases += r->len;
         }
         double tch = now_ms();
@@ -2248,7 +2292,9 @@ static void *lane_main(void *arg_)
              * next.  The new entry is registered before the first half publishes its size, so every chunk behind it
              * sees it when it adds up its base offset. */
             chunk_free(&cx); free(cx.reads);
-            if (n_todo >= 63) { snprintf(B->err, sizeof B->err, "lf_map_batch: a chunk could not be cut below the seed-hit limit"); B->rc = LF_ERR_ARG; n_todo = 0; todo[n_todo++] = k; continue; }
+            if (n_todo >= 63) {     /* every entry still in todo[] (registered second halves) and k itself are then published as empty by the branch above */
+                snprintf(B->err, sizeof B->err, "lf_map_batch: a chunk could not be cut below the seed-hit limit"); B->rc = LF_ERR_ARG; todo[n_todo++] = k; continue;
+            }
             pthread_mutex_lock(&B->mu);
             const int mid = C->i0 + (C->i1 - C->i0) / 2, nk = B->n_chunks++;
             B->chunks[nk].i0 = mid; B->chunks[nk].i1 = C->i1; B->chunks[nk].size = 0; B->chunks[nk].sized = 0;
@@ -2334,11 +2380,15 @@ static void *wdog_main(void *arg)
     return NULL;
 }
 
+typedef struct { const void *d_seqs, *d_quals; const uint64_t *seq_off; int dev_out; } devio_t;
 static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_params_t *p, int n, const char *const *names,
                           const char *const *seqs, const char *const *quals, const uint32_t *seq_lens, char *ext_buf, size_t ext_cap,
-                          char **sam, size_t *sam_len, lf_stats_t *stats)
+                          char **sam, size_t *sam_len, lf_stats_t *stats, const devio_t *dio)
 {
     if (!ixs || n_ix < 1 || n_ix > 16 || !p || n < 0 || (!sam && !ext_buf)) { lf_set_error("lf_map_batch: bad argument"); return LF_ERR_ARG; }
+    if (dio && (n_ix != 1 || !dio->d_seqs || !dio->seq_off || !seq_lens || !ext_buf || getenv("LF_HOST_VOTE") || getenv("LF_HOST_CIGAR") || getenv("LF_HOST_SAM") || getenv("LF_HOST_WALK"))) {
+        lf_set_error("lf_map_batch_dev: needs one index, device bases with offsets and lengths, an output buffer, and none of the LF_HOST_* cross-check modes"); return LF_ERR_ARG;
+    }
     for (int d = 0; d < n_ix; d++) {
         if (!ixs[d]) { lf_set_error("lf_map_batch: bad argument"); return LF_ERR_ARG; }
         if (ixs[d]->l_pac != ixs[0]->l_pac || ixs[d]->seq_len != ixs[0]->seq_len || ixs[d]->n_seqs != ixs[0]->n_seqs) { lf_set_error("lf_map_batch_multi: the index replicas differ"); return LF_ERR_ARG; }
@@ -2395,6 +2445,7 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     B.host_cigar = getenv("LF_HOST_CIGAR") != NULL;
     B.host_vote = getenv("LF_HOST_VOTE") != NULL;          /* diagnostic cross-check only; the device stage is the product path */
     B.ixs = ixs; B.n_ix = n_ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + n_lanes; B.rc = LF_OK;
+    if (dio) { B.d_seqs = (const unsigned char *)dio->d_seqs; B.d_quals = (const unsigned char *)dio->d_quals; B.src_off = dio->seq_off; B.dev_out = dio->dev_out; }
     pthread_mutex_init(&B.mu, NULL); pthread_cond_init(&B.cv, NULL); pthread_rwlock_init(&B.grow, NULL);
     if (ext_buf) { B.all.s = ext_buf; B.all.cap = ext_cap; B.all.n = 0; B.all.mode = 2; B.fixed_out = 1; }
     else str_init(&B.all);
@@ -2405,8 +2456,11 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
         c0.n_threads = nw + n_lanes; c0.lane = 0; c0.len_seqs = seqs; c0.len_out = lens;
         if (seq_lens) {                                               /* the caller knows them (Read.length, src/Reads.h): no pass over the bases */
             memcpy(lens, seq_lens, (size_t)n * 4);
-            /* a wrong length would make the device read past a string: one byte per read is checked */
-            for (int i = 0; i < n; i++) if (seqs[i][lens[i]] != 0 || (lens[i] > 0 && seqs[i][lens[i] - 1] == 0)) {
+            /* a wrong length would make the device read past a string: the terminator of every read is checked (best effort: the
+             * check itself trusts lens[i] to stay inside the caller's allocation) */
+            int bad = -1;
+            if (!dio) { c0.len_bad = -1; parallel_for(&c0, n, phase_checklen); bad = c0.len_bad; }      /* one cold cache line per read: all workers */
+            if (bad >= 0) { const int i = bad;
                 lf_set_error("lf_map_batch_into_lens: seq_lens[%d] = %u is not the length of seqs[%d]", i, lens[i], i);
                 free(lens); pthread_rwlock_destroy(&B.grow); pthread_mutex_destroy(&B.mu); pthread_cond_destroy(&B.cv);
                 if (!ext_buf) free(B.all.s);
@@ -2464,7 +2518,7 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     st->ms_total = now_ms() - T0;
     if (getenv("LF_TIMING")) fprintf(stderr, "[lf] lf_map_batch total %.1f ms\n", st->ms_total);
     if (B.rc != LF_OK) { lf_set_error("%s", B.err); if (!ext_buf) free(B.all.s); return B.rc; }
-    B.all.s[total] = 0;
+    if (!B.dev_out) B.all.s[total] = 0;
     if (sam) *sam = B.all.s;
     if (sam_len) *sam_len = total;
     return LF_OK;
@@ -2473,7 +2527,7 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
 int lf_map_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *const *names,
                  const char *const *seqs, const char *const *quals, char **sam, size_t *sam_len, lf_stats_t *stats)
 {
-    return map_batch_core(&ix, 1, p, n, names, seqs, quals, NULL, NULL, 0, sam, sam_len, stats);
+    return map_batch_core(&ix, 1, p, n, names, seqs, quals, NULL, NULL, 0, sam, sam_len, stats, NULL);
 }
 
 /* same, into a caller-owned buffer (e.g. pinned and reused across batches: a fresh multi-GB malloc per batch costs
@@ -2483,7 +2537,7 @@ int lf_map_batch_into(const lf_index_t *ix, const lf_params_t *p, int n, const c
                       const char *const *seqs, const char *const *quals, char *out, size_t out_cap, size_t *sam_len, lf_stats_t *stats)
 {
     if (!out || out_cap < 2) { lf_set_error("lf_map_batch_into: no output buffer"); return LF_ERR_ARG; }
-    return map_batch_core(&ix, 1, p, n, names, seqs, quals, NULL, out, out_cap, NULL, sam_len, stats);
+    return map_batch_core(&ix, 1, p, n, names, seqs, quals, NULL, out, out_cap, NULL, sam_len, stats, NULL);
 }
 
 /* same with the read lengths supplied (seq_lens[i] == strlen(seqs[i]); the strings stay NUL-terminated): the reference's
@@ -2494,7 +2548,23 @@ int lf_map_batch_into_lens(const lf_index_t *ix, const lf_params_t *p, int n, co
 {
     if (!out || out_cap < 2) { lf_set_error("lf_map_batch_into_lens: no output buffer"); return LF_ERR_ARG; }
     if (!seq_lens && n > 0) { lf_set_error("lf_map_batch_into_lens: no lengths"); return LF_ERR_ARG; }
-    return map_batch_core(&ix, 1, p, n, names, seqs, quals, seq_lens, out, out_cap, NULL, sam_len, stats);
+    return map_batch_core(&ix, 1, p, n, names, seqs, quals, seq_lens, out, out_cap, NULL, sam_len, stats, NULL);
+}
+
+/* Device-resident form: the bases (and qualities) of the batch are already in HBM of idx's device and the SAM text is left
+ * there -- nothing of the bulk data crosses PCIe.  What a rank of the N-GPU deployment receives over xGMI is mapped where it
+ * landed, and its records leave over xGMI again (lordfast_amd/dist.py).
+ *   d_seqs / d_quals: device pointers; read i = d_seqs[seq_off[i] .. seq_off[i] + seq_lens[i]) (anything may sit between two
+ *   reads: NULs, names); d_quals NULL = FASTA ("*"), else same layout.  names, seq_off, seq_lens: host arrays.
+ *   out: device buffer when out_is_device (else host memory, e.g. pinned), out_cap bytes; no terminating NUL is written to a
+ *   device buffer.  A chunk's reads are gathered inside HBM (lf_reads_gather_kernel) instead of concatenated and uploaded. */
+int lf_map_batch_dev(const lf_index_t *ix, const lf_params_t *p, int n, const char *const *names, const void *d_seqs,
+                     const uint64_t *seq_off, const uint32_t *seq_lens, const void *d_quals, void *out, size_t out_cap,
+                     int out_is_device, size_t *sam_len, lf_stats_t *stats)
+{
+    if (!out || out_cap < 2) { lf_set_error("lf_map_batch_dev: no output buffer"); return LF_ERR_ARG; }
+    devio_t dio; dio.d_seqs = d_seqs; dio.d_quals = d_quals; dio.seq_off = seq_off; dio.dev_out = out_is_device != 0;
+    return map_batch_core(&ix, 1, p, n, names, NULL, NULL, seq_lens, (char *)out, out_cap, NULL, sam_len, stats, &dio);
 }
 
 /* one batch over SEVERAL devices of this process: idx[d] is a replica of the same index on its own device
@@ -2508,7 +2578,7 @@ int lf_map_batch_multi(const lf_index_t *const *idx, int n_idx, const lf_params_
                        char *out, size_t out_cap, char **sam, size_t *sam_len, lf_stats_t *stats)
 {
     if (out && out_cap < 2) { lf_set_error("lf_map_batch_multi: output buffer too small"); return LF_ERR_ARG; }
-    return map_batch_core(idx, n_idx, p, n, names, seqs, quals, seq_lens, out, out ? out_cap : 0, out ? NULL : sam, sam_len, stats);
+    return map_batch_core(idx, n_idx, p, n, names, seqs, quals, seq_lens, out, out ? out_cap : 0, out ? NULL : sam, sam_len, stats, NULL);
 }
 
 /* printSamHeader (src/BWT.cpp:668-681) */

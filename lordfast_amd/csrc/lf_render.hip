@@ -311,7 +311,7 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_dev_recs, const void 
     const uint64_t total = h_offs[2 * (size_t)n_recs - 1] + h_tail[0];
     char *d_text = (char *)lfg_dev_slot(device, LF_DS_RENDER0 + 5, total + 64);
     char *h_text = dev_text ? nullptr : (char *)lfg_pin_slot(LF_PS_RENDER0 + 2, total + 64);
-    uint32_t *h_lens = dev_text ? (uint32_t *)lfg_pin_slot(LF_PS_RENDER0 + 3, (size_t)n_recs * 8 + 16) : nullptr;
+    uint32_t *h_lens = dev_text ? (uint32_t *)lfg_pin_slot(LF_PS_RENDER1 + 0, (size_t)n_recs * 8 + 16) : nullptr;      /* never the slot of an input (the caller's items live in LF_PS_RENDER0 + 3) */
     if (!d_text || (!dev_text && !h_text) || (dev_text && !h_lens)) return LF_ERR_NOMEM;
     if (single) hipLaunchKernelGGL(lf_render_kernel<LF_RM_SINGLE>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac, d_reads,
                                    d_lens, (const uint64_t *)d_offs, d_text);

@@ -122,7 +122,8 @@ lf_sam_write_kernel(lf_sam_dev D, const uint64_t *__restrict__ offs, char *__res
  * on the lane's stream and fetched with lfg_sam_fetch once the caller knows where it goes. */
 extern "C" int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, int n_lines, const lf_samline_t *lines,
                              const char *names, uint64_t names_bytes, const char *blob, uint64_t blob_bytes,
-                             const char *quals, uint64_t quals_bytes, const lfg_rtext_t *rt, int parity, uint64_t *total_out)
+                             const char *quals, uint64_t quals_bytes, const void *d_quals_src, int n_batch_reads,
+                             const lfg_rtext_t *rt, int parity, uint64_t *total_out)
 {
     *total_out = 0;
     if (n_lines == 0) return LF_OK;
@@ -136,9 +137,10 @@ extern "C" int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, in
     lf_samline_t *d_lines = SSLOT(lf_samline_t, 0, N * sizeof(lf_samline_t));
     char *d_names = SSLOT(char, 1, names_bytes + 64), *d_blob = SSLOT(char, 2, blob_bytes + 64);
     uint64_t *d_lens = SSLOT(uint64_t, 3, (N + 1) * 8), *d_offs = SSLOT(uint64_t, 4, (N + 1) * 8);
-    unsigned char *d_quals = quals ? SSLOT(unsigned char, 5, quals_bytes + 64) : nullptr;
+    /* qualities: host bytes in the resident batch's layout, or (lf_map_batch_dev) a device blob in the caller's layout */
+    unsigned char *d_quals = (quals || d_quals_src) ? SSLOT(unsigned char, 5, quals_bytes + 64) : nullptr;
     uint64_t *h = (uint64_t *)lfg_pin_slot(LF_PS_SAM0 + 0, 64);
-    if (!d_lines || !d_names || !d_blob || !d_lens || !d_offs || (quals && !d_quals) || !h) return LF_ERR_NOMEM;
+    if (!d_lines || !d_names || !d_blob || !d_lens || !d_offs || ((quals || d_quals_src) && !d_quals) || !h) return LF_ERR_NOMEM;
     /* contig names: a few kB, once per index and device (kept with the device state) */
     static std::mutex ctg_mu;
     std::unique_lock<std::mutex> ctg_lock(ctg_mu);
@@ -165,6 +167,12 @@ extern "C" int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, in
     if (names_bytes) HIPCHK(hipMemcpyAsync(d_names, names, names_bytes, hipMemcpyHostToDevice, s));
     if (blob_bytes) HIPCHK(hipMemcpyAsync(d_blob, blob, blob_bytes, hipMemcpyHostToDevice, s));
     if (quals) HIPCHK(hipMemcpyAsync(d_quals, quals, quals_bytes, hipMemcpyHostToDevice, s));
+    else if (d_quals_src) {
+        const uint64_t *d_src_off = (const uint64_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 13, 0), *d_off = (const uint64_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 1, 0);
+        if (!d_src_off || !d_off) { lf_set_error("lfg_sam_build: no resident read batch"); return LF_ERR_ARG; }
+        const int grc = lfg_gather_reads(dv, (void *)s, d_quals_src, d_src_off, d_off, n_batch_reads, d_quals);
+        if (grc != LF_OK) return grc;
+    }
     if (rg_len) HIPCHK(hipMemcpyAsync(d_rg, rg, rg_len, hipMemcpyHostToDevice, s));      /* pageable source: copied before the call returns */
     lf_sam_dev D;
     D.lines = d_lines; D.n_lines = n_lines;
@@ -226,7 +234,7 @@ extern "C" int lfg_sam_fetch_async(const struct lf_index *ix, char *dst, uint64_
     const char *d_out = (const char *)lfg_dev_slot(dv, LF_DS_SAM0 + 8 + (parity & 1), 0);
     if (!d_out) { lf_set_error("lfg_sam_fetch_async: nothing was built"); return LF_ERR_ARG; }
     HIPCHK(hipStreamWaitEvent(cs, E, 0));
-    HIPCHK(hipMemcpyAsync(dst, d_out, total, hipMemcpyDeviceToHost, cs));
+    HIPCHK(hipMemcpyAsync(dst, d_out, total, hipMemcpyDefault, cs));      /* dst: host memory, or HBM (lf_map_batch_dev) */
     HIPCHK(hipEventRecord(F, cs));
     return LF_OK;
 }
@@ -251,7 +259,7 @@ extern "C" int lfg_sam_fetch(const struct lf_index *ix, char *dst, uint64_t tota
     if (!s) return LF_ERR_HIP;
     const char *d_out = (const char *)lfg_dev_slot(dv, LF_DS_SAM0 + 8 + (parity & 1), 0);
     if (!d_out) { lf_set_error("lfg_sam_fetch: nothing was built"); return LF_ERR_ARG; }
-    HIPCHK(hipMemcpyAsync(dst, d_out, total, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(dst, d_out, total, hipMemcpyDefault, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     return LF_OK;

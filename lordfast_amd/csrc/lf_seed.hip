@@ -368,8 +368,36 @@ __global__ void lf_read_first_hit_kernel(int n_reads, uint32_t hash_count, const
     read_off[r] = (r == n_reads) ? total_hits : hit_off[(size_t)r * hash_count];
 }
 
+/* device-resident input (lf_map_batch_dev): read k = src[src_off[k] .. + off[k + 1] - off[k]) -> the lane's resident batch at off[k].
+ * One workgroup per 4 KiB piece of a read; byte granular (neither side is aligned), the L2 merges the lanes' bytes. */
+__global__ void __launch_bounds__(256)
+lf_reads_gather_kernel(const unsigned char *__restrict__ src, const uint64_t *__restrict__ src_off, const uint64_t *__restrict__ off,
+                       int n_reads, unsigned char *__restrict__ dst)
+{
+    const int k = blockIdx.x;
+    if (k >= n_reads) return;
+    const uint64_t o = off[k], len = off[k + 1] - o;
+    const unsigned char *s = src + src_off[k];
+    for (uint64_t i = (uint64_t)blockIdx.y * 256 + threadIdx.x; i < len; i += (uint64_t)gridDim.y * 256) dst[o + i] = s[i];
+}
+extern "C" int lfg_gather_reads(int device, void *stream, const void *d_src, const uint64_t *d_src_off, const uint64_t *d_off, int n_reads, void *d_dst)
+{
+    if (n_reads <= 0) return LF_OK;
+    HIPCHK(hipSetDevice(device));
+    hipLaunchKernelGGL(lf_reads_gather_kernel, dim3((unsigned)n_reads, 8), dim3(256), 0, (hipStream_t)stream, (const unsigned char *)d_src, d_src_off, d_off, n_reads, (unsigned char *)d_dst);
+    HIPCHK(hipGetLastError());
+    return LF_OK;
+}
+
 extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads,
                         const uint64_t *off, int want_hits, lfg_hits_t *out)
+{
+    return lfg_seed_src(ix, p, n_reads, reads, nullptr, nullptr, off, want_hits, out);
+}
+
+/* reads == NULL: the bases are already in HBM of this device (d_src + src_off[k], host array of n_reads offsets) */
+extern "C" int lfg_seed_src(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads, const void *d_src, const uint64_t *src_off,
+                            const uint64_t *off, int want_hits, lfg_hits_t *out)
 {
     memset(out, 0, sizeof(*out));
     lf_dev_state *st = (lf_dev_state *)ix->dev;
@@ -398,8 +426,16 @@ extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_r
     for (int i = 0; i < 6; i++) { ev[i] = (hipEvent_t)lfg_lane_event(dv, 34 + i); if (!ev[i]) return LF_ERR_HIP; }
 
     HIPCHK(hipMemsetAsync(d_counters, 0, 32, s));
-    HIPCHK(hipMemcpyAsync(d_reads, reads, n_bases, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+    if (reads) HIPCHK(hipMemcpyAsync(d_reads, reads, n_bases, hipMemcpyHostToDevice, s));
+    else {
+        if (!d_src || !src_off) { lf_set_error("lfg_seed: no read bases"); return LF_ERR_ARG; }
+        uint64_t *d_src_off = DSLOT(uint64_t, 13, (size_t)(n_reads + 1) * 8);       /* kept for the SAM writer's qualities (same layout) */
+        if (!d_src_off) return LF_ERR_NOMEM;
+        HIPCHK(hipMemcpyAsync(d_src_off, src_off, (size_t)n_reads * 8, hipMemcpyHostToDevice, s));
+        const int grc = lfg_gather_reads(dv, (void *)s, d_src, d_src_off, d_off, n_reads, d_reads);
+        if (grc != LF_OK) return grc;
+    }
 
     hipLaunchKernelGGL(lf_seed_pos_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, d_off, hc, d_pos, d_pos2);
     HIPCHK(hipEventRecord(ev[0], s));

@@ -238,3 +238,133 @@ def scatter_packed_p2p(dist, torch, packed, device, src: int = 0):
     blob[:a.numel()].copy_(a)
     blob[a.numel():].copy_(b)
     return PackedReads(blob.numpy(), seq_off, name_off), bounds
+
+
+# ---- device-resident, pipelined exchange (what bench.py --gpus N uses) ---------------------------------------------------
+# Rank 0 owns the read batch of every step and ends up owning its SAM records; both live in HBM.  A step's bulk data moves
+# with ONE grouped point-to-point call per rank (every peer's link carries its own shard at the same time, both directions)
+# that is posted BEFORE the step is mapped:  reads of step k + 1 travel out and SAM text of step k - 1 travels back while
+# step k is on the GPUs.  Only the first scatter and the last gather are exposed.  Metadata (offsets, lengths: a few hundred
+# kB) goes over a host-side control group (gloo), so no device synchronisation sits between the steps.
+
+class Shard:
+    """one rank's share of a step: ONE byte blob `[seq\\0]* [name\\0]*` on the bulk device + host offset arrays (n + 1 each,
+    absolute in the blob; sequence i is seq_off[i+1] - seq_off[i] - 1 long)."""
+
+    def __init__(self, blob, seq_off, name_off, nbytes=None):
+        self.blob = blob                                   # uint8 tensor (cuda under nccl; cpu under gloo)
+        self.seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+        self.name_off = np.ascontiguousarray(name_off, dtype=np.int64)
+        self.nbytes = int(nbytes if nbytes is not None else (self.name_off[-1] if len(self.name_off) else 0))
+
+    def __len__(self):
+        return len(self.seq_off) - 1
+
+    @property
+    def seq_lens(self):
+        return (self.seq_off[1:] - self.seq_off[:-1] - 1).astype(np.uint32)
+
+    def bases(self):
+        return int(self.seq_lens.astype(np.int64).sum())
+
+    def name_array(self, torch):
+        """ctypes char*[n] into a HOST copy of the names part of the blob (kept alive by self)"""
+        import ctypes as C
+        n0, n1 = int(self.name_off[0]), int(self.name_off[-1])
+        self._names_host = self.blob[n0:n1].cpu().numpy() if n1 > n0 else np.zeros(1, np.uint8)
+        self._np = (self.name_off[:-1] - n0 + self._names_host.ctypes.data).astype(np.uint64)
+        return C.cast(self._np.ctypes.data, C.POINTER(C.c_char_p))
+
+
+def make_shards(torch, names, seqs, world, device, by_bases=True):
+    """cut one read set into `world` contiguous shards (balanced by bases) and pack each as a Shard resident on `device`.
+    -> (shards, bounds)"""
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    bounds = shard_bounds(lens, world)
+    out = []
+    for lo, hi in bounds:
+        pk = pack_reads(names[lo:hi], seqs[lo:hi])
+        t = torch.from_numpy(pk.blob.copy()) if len(pk.blob) else torch.zeros(0, dtype=torch.uint8)
+        out.append(Shard(t.to(device), pk.seq_off, pk.name_off))
+    return out, bounds
+
+
+class PipelinedExchange:
+    def __init__(self, dist, torch, bulk_device, ctl_group, read_cap: int, sam_cap: int, pin=True):
+        self.dist, self.torch, self.dev, self.ctl = dist, torch, bulk_device, ctl_group
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        kw = dict(dtype=torch.uint8, device=bulk_device)
+        if bulk_device.type == "cpu" and pin and torch.cuda.is_available():
+            kw["pin_memory"] = True
+        # rank 0: sam[b] holds the whole step's records (own first, then the peers' in rank order); peers: their own text
+        self.sam = [torch.empty(sam_cap * (self.world if self.rank == 0 else 1), **kw) for _ in range(2)]
+        self.rx = [torch.empty(read_cap, **kw) if self.rank else None for _ in range(2)]
+        self.rx_shard = [None, None]
+        self.works = []
+        self.gather_lens = [None, None]          # rank 0: per step parity, [own, peer1, ...] lengths
+        self.bytes_out = self.bytes_in = 0
+
+    # -- control plane (host tensors over gloo)
+    def _ctl_send(self, arr, dst):
+        self.dist.send(self.torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64)), dst, group=self.ctl)
+
+    def _ctl_recv(self, n, src):
+        t = self.torch.empty(n, dtype=self.torch.int64)
+        self.dist.recv(t, src, group=self.ctl)
+        return t.numpy()
+
+    def post(self, k: int, next_shards=None, prev_own_len=None):
+        """Call before mapping step k.  rank 0: next_shards = the N shards of step k + 1 (or None after the last step),
+        prev_own_len = length of its own SAM text of step k - 1 (None for k == 0).  Peers: next_shards is ignored (pass True
+        when a step k + 1 exists), prev_own_len = length of their SAM text of step k - 1 (None for k == 0).
+        Everything posted here completes in complete()."""
+        dist, torch = self.dist, self.torch
+        ops = []
+        have_next = next_shards is not None and next_shards is not False
+        nb, pb = (k + 1) & 1, (k - 1) & 1
+        if self.rank == 0:
+            if have_next:
+                for r in range(1, self.world):
+                    sh = next_shards[r]
+                    self._ctl_send([len(sh), sh.nbytes], r)
+                    self._ctl_send(np.concatenate([sh.seq_off, sh.name_off]), r)
+                    if sh.nbytes:
+                        ops.append(dist.P2POp(dist.isend, sh.blob[:sh.nbytes], r))
+                        self.bytes_out += sh.nbytes
+            if prev_own_len is not None:
+                lens = [int(prev_own_len)] + [int(self._ctl_recv(1, r)[0]) for r in range(1, self.world)]
+                self.gather_lens[pb] = lens
+                off = lens[0]
+                for r in range(1, self.world):
+                    if off + lens[r] > self.sam[pb].numel():
+                        raise RuntimeError("PipelinedExchange: gather buffer too small")
+                    if lens[r]:
+                        ops.append(dist.P2POp(dist.irecv, self.sam[pb][off:off + lens[r]], r))
+                        self.bytes_in += lens[r]
+                    off += lens[r]
+        else:
+            if have_next:
+                n, nbytes = (int(x) for x in self._ctl_recv(2, 0))
+                meta = self._ctl_recv(2 * (n + 1), 0)
+                if nbytes > self.rx[nb].numel():
+                    raise RuntimeError("PipelinedExchange: receive buffer too small")
+                self.rx_shard[nb] = Shard(self.rx[nb], meta[:n + 1], meta[n + 1:], nbytes)
+                if nbytes:
+                    ops.append(dist.P2POp(dist.irecv, self.rx[nb][:nbytes], 0))
+            if prev_own_len is not None:
+                self._ctl_send([int(prev_own_len)], 0)
+                if prev_own_len:
+                    ops.append(dist.P2POp(dist.isend, self.sam[pb][:int(prev_own_len)], 0))
+        self.works = dist.batch_isend_irecv(ops) if ops else []
+
+    def complete(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.dev.type == "cuda":
+            self.torch.cuda.current_stream().synchronize()      # the waits above only order the current stream behind RCCL's
+
+    def gathered(self, k: int):
+        """rank 0, after the post()/complete() that followed step k: (tensor, total length) of step k's records, input order"""
+        lens = self.gather_lens[k & 1]
+        return self.sam[k & 1], sum(lens)

@@ -70,3 +70,91 @@ def test_scatter_gather_gloo_world2(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "DIST_OK" in r.stdout
+
+
+PIPE_WORKER = r'''
+import os, sys, hashlib
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from lordfast_amd import dist as lfd
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cpu")
+STEPS = 4
+def job(step):
+    rng = np.random.default_rng(100 + step)
+    n = 23 + 5 * step
+    names = [f"s{step}_r{i}".encode() for i in range(n)]
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(rng.integers(1, 3000)))) for _ in range(n)]
+    return names, seqs
+def fake_map(shard, out):
+    """stands in for lf_map_batch_dev: one line per read, from the packed blob only"""
+    b = shard.blob[:shard.nbytes].numpy().tobytes()
+    lines = []
+    for i in range(len(shard)):
+        nm = b[int(shard.name_off[i]):int(shard.name_off[i + 1]) - 1]
+        sq = b[int(shard.seq_off[i]):int(shard.seq_off[i + 1]) - 1]
+        assert len(sq) == int(shard.seq_lens[i])
+        lines.append(nm + b"\t" + hashlib.md5(sq).hexdigest().encode() + b"\n")
+    txt = b"".join(lines)
+    out[:len(txt)] = torch.frombuffer(bytearray(txt), dtype=torch.uint8) if txt else out[:0]
+    return len(txt)
+px = lfd.PipelinedExchange(dist, torch, dev, dist.group.WORLD, read_cap=1 << 20, sam_cap=1 << 20, pin=False)
+shards = {}
+if rank == 0:
+    for k in range(STEPS):
+        nm, sq = job(k)
+        shards[k] = lfd.make_shards(torch, nm, sq, world, dev)[0]
+# step -1: scatter of step 0 (exposed); then: post(k) -> map(k) -> complete()
+px.post(-1, next_shards=shards[0] if rank == 0 else True); px.complete()
+prev = None
+got = {}
+for k in range(STEPS):
+    more = k + 1 < STEPS
+    px.post(k, next_shards=(shards[k + 1] if rank == 0 else True) if more else None, prev_own_len=prev)
+    sh = shards[k][0] if rank == 0 else px.rx_shard[k & 1]
+    prev = fake_map(sh, px.sam[k & 1])
+    px.complete()
+    if rank == 0 and k >= 1:
+        t, ln = px.gathered(k - 1)
+        got[k - 1] = bytes(t[:ln].numpy().tobytes())
+px.post(STEPS, next_shards=None, prev_own_len=prev); px.complete()
+if rank == 0:
+    t, ln = px.gathered(STEPS - 1)
+    got[STEPS - 1] = bytes(t[:ln].numpy().tobytes())
+    for k in range(STEPS):
+        nm, sq = job(k)
+        exp = b"".join(a + b"\t" + hashlib.md5(b).hexdigest().encode() + b"\n" for a, b in zip(nm, sq))
+        assert got[k] == exp, ("step", k)
+    assert px.bytes_out > 0 and px.bytes_in > 0
+    print("PIPE_OK", STEPS, px.bytes_out, px.bytes_in)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_pipelined_exchange_gloo(tmp_path):
+    """rank 0 owns every step's reads and ends with every step's records, in input order, while the transfers of step
+    k + 1 / k - 1 are in flight around the mapping of step k (world sizes 2 and 3)"""
+    script = tmp_path / "p.py"
+    script.write_text(PIPE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for world, port in ((2, 29613), (3, 29614)):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT],
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        assert "PIPE_OK" in r.stdout
+
+
+def test_bench_spawns_its_own_ranks_without_touching_the_gpu(tmp_path):
+    """`python bench.py --gpus 2` from a bare shell must start torch.distributed.run children itself (here: checked up to the
+    point where a rank finds no GPU and says so -- the parent must not have imported torch or initialised HIP)"""
+    env = dict(os.environ, LF_BENCH_BACKEND="gloo", LF_BENCH_DIR=str(tmp_path))
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--genome-mbp", "1",
+                        "--reads", "10", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=300)
+    assert "starting 2 ranks" in r.stderr, r.stderr[-2000:]
+    assert "must be launched with torch.distributed.run" not in (r.stdout + r.stderr)
+    # on this CPU box the ranks stop at the device check; on a GPU box test_gpu_dist.py runs the same command to the end
+    assert r.returncode != 0 or '"metric"' in r.stdout

@@ -50,3 +50,77 @@ def test_sharded_read_set_gives_the_one_rank_sam(golden_dir, tmp_path, world, cf
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "SHARDED_OK" in r.stdout
+
+
+# ---- bench.py's own N > 1 path: started from a bare shell (it spawns its ranks), pipelined device-resident exchange ----
+import json
+
+
+def _bench(workdir, *args, backend=None, timeout=1500):
+    env = dict(os.environ, LF_BENCH_DIR=str(workdir), LF_BENCH_SAM_DIGEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if backend:
+        env["LF_BENCH_BACKEND"] = backend
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--genome-mbp", "5", "--reads", "600", "--read-len", "6000", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"] + list(args)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.fixture(scope="module")
+def bench_dir(tmp_path_factory):
+    return tmp_path_factory.mktemp("bench")
+
+
+@pytest.fixture(scope="module")
+def one_rank_line(bench_dir):
+    return _bench(bench_dir, "--gpus", "1")
+
+
+def test_bench_one_rank_reports_both_boundaries(one_rank_line):
+    j = one_rank_line
+    assert j["n_gpus"] == 1 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["value_pcie_inclusive"] > 0 and "HBM" in j["config"]["io"]
+    assert j["roofline"]["frac"] > 0 and j["roofline"]["by_kernel"]["lf_ksw_kernel"]["algorithmic_GB_per_step"] >= 0
+
+
+def test_bench_strong_scaling_two_ranks_same_records(bench_dir, one_rank_line):
+    """BASELINE config C3 in miniature: the SAME read set cut by bases over 2 ranks, scattered from and gathered to rank 0
+    through PipelinedExchange (gloo hook: both ranks on GPU 0), must leave rank 0 with the 1-rank records, byte for byte"""
+    j = _bench(bench_dir, "--gpus", "2", "--scaling", "strong", backend="gloo")
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong"
+    assert j["exchange"]["status"] == "ok" and j["exchange"]["GB_in_per_step"] > 0
+    assert j["sam_md5"] == one_rank_line["sam_md5"] and j["sam_bytes"] == one_rank_line["sam_bytes"]
+    assert j["value"] > 0 and j["value_without_exchange"] > 0
+
+
+def test_bench_weak_scaling_three_ranks(bench_dir, one_rank_line):
+    j = _bench(bench_dir, "--gpus", "3", backend="gloo")
+    assert j["n_gpus"] == 3 and j["scaling"] == "weak" and j["config"]["reads_total"] == 1800
+    assert j["exchange"]["status"] == "ok"
+    assert j["sam_bytes"] > 2.5 * one_rank_line["sam_bytes"]          # three different shards, rank 0's first
+
+
+def test_bench_rccl_when_two_gpus(bench_dir, one_rank_line):
+    """the real transport: backend nccl (RCCL), one rank per GPU, device tensors end to end.  Needs two visible GPUs."""
+    import lordfast_amd as la
+    if la.device_count() < 2:
+        pytest.skip("one GPU on this box: the RCCL path needs two (the gloo tests above cover the same code with host staging)")
+    j = _bench(bench_dir, "--gpus", "2", "--scaling", "strong")
+    assert j["exchange"]["status"] == "ok" and j["exchange"]["transport"] == "nccl" and "cuda" in j["exchange"]["bulk_memory"]
+    assert j["sam_md5"] == one_rank_line["sam_md5"]
+
+
+def test_bench_inproc_two_replicas(bench_dir, one_rank_line):
+    """--mode inproc: one process, lf_map_batch_multi over N index replicas (two replicas on GPU 0 here)"""
+    env_key = "LF_BENCH_SHARE_DEVICES"
+    os.environ[env_key] = "1"
+    try:
+        j = _bench(bench_dir, "--gpus", "2", "--mode", "inproc", "--scaling", "strong")
+    finally:
+        os.environ.pop(env_key, None)
+    assert j["n_gpus"] == 2 and j["sam_md5"] == one_rank_line["sam_md5"]

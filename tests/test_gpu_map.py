@@ -354,3 +354,62 @@ def test_sam_host_assembly_crosscheck(lf, golden_reads, monkeypatch, cfg):
         d, _ = lf.map_batch(names, seqs, quals=quals, params=p)
         assert d == h, first_diff(d, h)
         assert b"\tRG:Z:grpX" in d
+
+
+def _pack_to_device(torch, names, seqs, quals=None):
+    """the caller's side of lf_map_batch_dev: bases (and qualities) as ONE blob in HBM + host offsets / lengths"""
+    import lordfast_amd as la
+    blob = b"\0".join(seqs) + b"\0"
+    off = np.concatenate([[0], np.cumsum([len(s) + 1 for s in seqs])])[:-1].astype(np.uint64)
+    lens = np.array([len(s) for s in seqs], dtype=np.uint32)
+    d_seqs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+    d_quals = torch.frombuffer(bytearray(b"\0".join(quals) + b"\0"), dtype=torch.uint8).cuda() if quals is not None else None
+    return la.api._cstr_array(names), d_seqs, off, lens, d_quals
+
+
+@pytest.mark.parametrize("cfg", ["default", "clasp_n30", "k12c300m20"])
+def test_map_batch_dev_resident_io(lf, golden_reads, cfg, monkeypatch):
+    """lf_map_batch_dev: bases already in HBM, SAM text left in HBM -- the records the reference prints, also when the batch is
+    cut into many chunks on several lanes (asynchronous device-to-device copies into the caller's buffer)"""
+    import torch
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    exp = golden_sam(cfg)
+    na, d_seqs, off, lens, _ = _pack_to_device(torch, names, seqs)
+    out = torch.zeros(len(exp) + 4096, dtype=torch.uint8, device="cuda")
+    p = la.default_params(**GOLDEN_CONFIGS[cfg])
+    ln, st = lf.map_batch_dev(na, d_seqs.data_ptr(), off, lens, out.data_ptr(), out.numel(), True, params=p)
+    got = bytes(out[:ln].cpu().numpy().tobytes())
+    assert got == exp, first_diff(got, exp)
+    assert st["n_reads"] == len(seqs)
+    # host destination (pinned or not) from device-resident bases
+    hbuf = np.zeros(len(exp) + 4096, dtype=np.uint8)
+    ln, _ = lf.map_batch_dev(na, d_seqs.data_ptr(), off, lens, hbuf.ctypes.data, hbuf.size, False, params=p)
+    assert hbuf[:ln].tobytes() == exp
+    monkeypatch.setenv("LF_CHUNK_READS", "7"); monkeypatch.setenv("LF_LANES", "3")
+    out.zero_()
+    ln, _ = lf.map_batch_dev(na, d_seqs.data_ptr(), off, lens, out.data_ptr(), out.numel(), True, params=p)
+    got = bytes(out[:ln].cpu().numpy().tobytes())
+    assert got == exp, first_diff(got, exp)
+    # a buffer that is too small is an error, not a truncation
+    with pytest.raises(la.api.LfError):
+        lf.map_batch_dev(na, d_seqs.data_ptr(), off, lens, out.data_ptr(), 1000, True, params=p)
+
+
+def test_map_batch_dev_fastq_short_reads_and_readgroup(lf, oracle, oracle_lib, golden_reads):
+    """device-resident qualities (reversed for reverse-strand records), reads shorter than -l (printed from bases fetched on
+    demand) and a read group: the oracle's records"""
+    import torch
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    names, seqs = list(names[:24]), list(seqs[:24])
+    seqs[3] = seqs[3][:400]; seqs[10] = seqs[10][:99]; seqs[17] = b"ACGT"          # below -l 1000
+    rng = np.random.default_rng(5)
+    quals = [bytes(rng.integers(35, 74, size=len(s)).astype(np.uint8)) for s in seqs]
+    exp = oracle.map_batch(names, seqs, quals, params=oracle_lib.default_params(read_group_id=b"grp1"))
+    na, d_seqs, off, lens, d_quals = _pack_to_device(torch, names, seqs, quals)
+    out = torch.zeros(len(exp) + 4096, dtype=torch.uint8, device="cuda")
+    ln, _ = lf.map_batch_dev(na, d_seqs.data_ptr(), off, lens, out.data_ptr(), out.numel(), True, d_quals=d_quals.data_ptr(),
+                             params=la.default_params(read_group_id=b"grp1"))
+    got = bytes(out[:ln].cpu().numpy().tobytes())
+    assert got == exp, first_diff(got, exp)
