@@ -212,6 +212,11 @@ int  lf_map_batch_into_lens(const lf_index_t *idx, const lf_params_t *p, int n, 
 int  lf_map_batch_dev(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names, const void *d_seqs,
                       const uint64_t *seq_off, const uint32_t *seq_lens, const void *d_quals, void *out, size_t out_cap,
                       int out_is_device, size_t *sam_len, lf_stats_t *stats);
+/* device memory for callers that do not link HIP themselves (a caller that does may pass any pointer hipMalloc gave it):
+ * lf_device_copy takes host or device pointers on either side and is synchronous */
+void *lf_device_alloc(int device, size_t bytes);
+void  lf_device_free(int device, void *ptr);
+int   lf_device_copy(int device, void *dst, const void *src, size_t bytes);
 /* ------------------------------------------------------------------------------------------------
  * Several GPUs in one process: idx[d] = the same index loaded on device d (lf_index_load(prefix, d, ...)).
  * Reads are independent, so the batch is cut into chunks that the devices pull from one counter -- the reference's

@@ -135,6 +135,45 @@ def read_file(path: str, batch_reads: int = 0, batch_bases: int = 0):
     return out
 
 
+class DeviceBuffer:
+    """bytes in HBM of one device (lf_device_alloc): what lf_map_batch_dev reads from / writes to when the caller has no
+    HIP-aware framework of its own"""
+
+    def __init__(self, nbytes: int, device: int = 0, data: bytes | None = None):
+        L = lib()
+        L.lf_device_alloc.restype = C.c_void_p
+        L.lf_device_alloc.argtypes = [C.c_int, C.c_size_t]
+        L.lf_device_free.argtypes = [C.c_int, C.c_void_p]
+        L.lf_device_copy.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        self.L, self.device, self.nbytes = L, device, nbytes
+        self.ptr = L.lf_device_alloc(device, nbytes)
+        if not self.ptr:
+            raise LfError(f"lf_device_alloc failed: {L.lf_last_error().decode(errors='replace')}")
+        if data is not None:
+            self.upload(data)
+
+    def upload(self, data: bytes, offset: int = 0):
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        _check(self.L.lf_device_copy(self.device, C.c_void_p(self.ptr + offset), buf, len(data)), "lf_device_copy")
+
+    def download(self, nbytes: int | None = None, offset: int = 0) -> bytes:
+        n = self.nbytes - offset if nbytes is None else nbytes
+        buf = (C.c_char * max(1, n))()
+        _check(self.L.lf_device_copy(self.device, buf, C.c_void_p(self.ptr + offset), n), "lf_device_copy")
+        return bytes(buf[:n])
+
+    def free(self):
+        if self.ptr:
+            self.L.lf_device_free(self.device, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:                                                # noqa: BLE001
+            pass
+
+
 def device_count() -> int:
     return lib().lf_device_count()
 

@@ -20,154 +20,15 @@
  */
 #include <hipcub/hipcub.hpp>
 #include "lf_gpu_common.h"
+#include "lf_edlib_common.h"
+#include "lf_hirsch.h"
+#include <stddef.h>
 #include <algorithm>
 #include <type_traits>
 #include <string.h>
 #include <vector>
 #include <numeric>
 #include <limits.h>
-
-struct lf_aln_prob {
-    int64_t  qstart, tstart; /* element 0 of query / target: byte index (ASCII buffers) or pac coordinate */
-    uint64_t ops_off;        /* output ops region (capacity n + m) */
-    uint64_t hist_base;      /* 16-byte entries; wave-transposed (template classes) or private (generic) */
-    uint64_t aux_off;        /* generic kernel: private state words */
-    uint32_t n, m;
-    uint32_t id;             /* original problem index */
-    uint8_t  mode, task, flags, pad;
-};
-/* flags: how element i of a sequence is fetched -- index start +/- i, optionally complemented.  Requests of the
- * mapping pipeline are DESCRIPTORS into the read batch and the 2-bit reference already resident in HBM
- * (no byte staging, no H2D of sequences); the stage API uploads byte strings and uses the same accessors. */
-
-struct lf_hist_t { uint64_t pv, ph; };
-
-/* one Myers block step. Pv/Mv in-out.  The horizontal delta entering / leaving the block travels as two bits:
- * bit 0 = +1, bit 1 = -1 (no compares, no sign handling on the per-step dependency chain).  ph_out / mh_out =
- * horizontal +1 / -1 bits of the block's rows (unshifted). */
-__device__ __forceinline__ uint32_t lf_myers_step(uint64_t &Pv, uint64_t &Mv, uint64_t Eq, uint32_t hin, uint64_t &ph_out, uint64_t &mh_out)
-{
-    const uint64_t hpos = hin & 1u, hneg = hin >> 1;
-    const uint64_t Xv = Eq | Mv;
-    Eq |= hneg;
-    const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-    uint64_t Ph = Mv | ~(Xh | Pv);
-    uint64_t Mh = Pv & Xh;
-    ph_out = Ph; mh_out = Mh;
-    const uint32_t hout = (uint32_t)(Ph >> 63) | ((uint32_t)(Mh >> 63) << 1);
-    Ph = (Ph << 1) | hpos;
-    Mh = (Mh << 1) | hneg;
-    Pv = Mh | ~(Xv | Ph);
-    Mv = Ph & Xv;
-    return hout;
-}
-#define LF_HIN_PLUS1 1u          /* first block of a column: the row above the matrix grows by one per column */
-/* +1 / 0 / -1 of a two-bit delta at bit `bit` of (ph, mh) */
-__device__ __forceinline__ int lf_delta_at(uint64_t ph, uint64_t mh, int bit) { return (int)((ph >> bit) & 1) - (int)((mh >> bit) & 1); }
-
-/* bit planes of 64 query bytes: uppercase A,C,G,T -> (lo,hi) code + valid; anything else never equals a
- * target base (edlib compares raw bytes, lib/edlib/edlib.cpp:1367-1384; the target comes from the 2-bit
- * reference and is upper case).  Branch-free (lf_code_upper). */
-__device__ __forceinline__ void lf_plane_add(unsigned char ch, int bit, uint64_t &lo, uint64_t &hi, uint64_t &valid)
-{
-    bool ok;
-    const uint32_t c = lf_code_upper(ch, ok);
-    const uint64_t v = ok ? 1ull : 0ull;
-    lo |= (v & (c & 1u)) << bit; hi |= (v & (c >> 1)) << bit; valid |= v << bit;
-}
-
-/* A target symbol inside the DP loops is a 32-bit token: bits 1:0 = code, bit 8 = "not one of ACGT", bits 23:16 = the raw
- * byte.  Targets of the mapping pipeline come from the 2-bit reference: always a bare code (template PAC). */
-__device__ __forceinline__ uint32_t lf_tok_of_byte(unsigned char ch)
-{
-    bool ok;
-    const uint32_t c = lf_code_upper(ch, ok);
-    return c | (ok ? 0u : 0x100u) | ((uint32_t)ch << 16);
-}
-template <bool PAC>
-__device__ __forceinline__ uint32_t lf_tok(const lf_tacc &T, uint32_t i) { return PAC ? T.pac_code(i) : lf_tok_of_byte(T.get(i)); }
-/* Eq mask of a token against a block: three ops per word from the bit planes; a byte outside ACGT takes the exact
- * compare (general alphabets of the stage API; never on the pipeline path) */
-template <bool PAC, class QG>
-__device__ __forceinline__ uint64_t lf_eq_tok(uint32_t tok, uint64_t lo, uint64_t hi, uint64_t valid, const QG &qget, uint32_t n, uint32_t blk)
-{
-    const uint64_t slo = 0ull - (uint64_t)(tok & 1u), shi = 0ull - (uint64_t)((tok >> 1) & 1u);
-    uint64_t e = ~((lo ^ slo) | (hi ^ shi)) & valid;
-    if (!PAC) {
-        if (tok & 0x100u) {
-            const unsigned char tc = (unsigned char)(tok >> 16);
-            e = 0;
-            for (uint32_t i = 0; i < 64; i++) {
-                const uint32_t r = blk * 64 + i;
-                if (r < n && qget(r) == tc) e |= 1ull << i;
-            }
-        }
-    }
-    return e;
-}
-/* the generic kernel's form: raw byte */
-__device__ __forceinline__ uint64_t lf_eq_mask(unsigned char tc, uint64_t lo, uint64_t hi, uint64_t valid,
-                                               const lf_qacc &Q, uint32_t n, uint32_t blk)
-{
-    auto qg = [&](uint32_t r) -> unsigned char { return Q.get(r); };
-    return lf_eq_tok<false>(lf_tok_of_byte(tc), lo, hi, valid, qg, n, blk);
-}
-
-/* edlib's own leaf / Hirschberg switch (lib/edlib/edlib.cpp:1117-1119), callable on the device */
-__host__ __device__ __forceinline__ bool lf_leaf(int64_t n, int64_t m) { return 20LL * ((n + 63) / 64) * m + 8LL * m < 1024 * 1024; }
-/* ================================================================================================
- * TRACEBACK WITHOUT A HISTORY STREAM
- *
- * Round 1 wrote two bits per DP cell (Pv, Ph: 16 B per column and 64-row block) to HBM and read them back:
- * 140 GB per 100 k reads for 4.4 GB of algorithmic bytes.  Now the forward pass keeps only CHECKPOINTS -- the
- * bit-vector state (Pv, Mv) of every block every K columns (lane classes) or every K sweep steps (group / wave
- * classes) -- and the traceback walks the matrix tile by tile from the end: the tile's K columns (steps) are
- * recomputed from the checkpoint in front of it, their (Pv, Ph) words go to LDS, the path is followed through
- * the tile, then the next tile to the left.  HBM sees 1/K of the old stream, the DP work doubles (integer ALU,
- * of which the old kernels used ~5 %), results are identical: the same cells are visited with the same
- * Up -> Left -> Diagonal priority (lib/edlib/edlib.cpp:950,984,1015).
- * ================================================================================================ */
-
-#define LF_LANE_K   8        /* lane classes: columns per tile (tile in LDS: K x W blocks x 64 lanes x 16 B) */
-#ifndef LF_LANE_W
-#define LF_LANE_W   1        /* 8 KiB of LDS per wave: LDS, not registers, bounds the waves per SIMD of these kernels */
-#endif
-
-__device__ __forceinline__ uint32_t lf_wave_max_u32(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(v, o); v = x > v ? x : v; }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);        /* the same in every lane: let loop bounds live in SGPRs */
-}
-__device__ __forceinline__ int lf_wave_max_i32(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(v, o); v = x > v ? x : v; }
-    return __builtin_amdgcn_readfirstlane(v);
-}
-
-/* ops are produced back to front and leave in 8-byte words: bytes are shifted into `acc` and stored when the (descending)
- * address reaches an 8-byte boundary; only the bytes above the first boundary and below the last one are single-byte
- * stores (the neighbouring problems' regions start right there).  `store` = this lane owns the output. */
-struct lf_emitter {
-    uint8_t *o; uint32_t w, mis, cnt; uint64_t acc; bool store;
-    __device__ __forceinline__ void init(uint8_t *base, uint32_t cap, bool st) { o = base; w = cap; mis = (uint32_t)((uintptr_t)base & 7); cnt = 0; acc = 0; store = st; }
-    __device__ __forceinline__ void spill()
-    {   /* the collected bytes start at o + w, lowest address in the lowest byte */
-        if (store) {
-            if (cnt == 8) *reinterpret_cast<uint64_t *>(o + w) = acc;
-            else for (uint32_t i = 0; i < cnt; i++) o[w + i] = (uint8_t)(acc >> (8 * i));
-        }
-        cnt = 0;
-    }
-    __device__ __forceinline__ void put(uint32_t op)
-    {
-        --w;
-        acc = (acc << 8) | op; cnt++;
-        if (((mis + w) & 7) == 0) spill();
-    }
-    __device__ __forceinline__ void flush() { if (cnt) spill(); }
-};
 
 /* layout of a wave's checkpoint area (16-byte entries from the hist_base of the wave's first problem):
  *   lane classes   [0, 96 NB)  bit planes lo / hi / valid of every block: u64 [(b * 3 + x) * 64 + lane]
@@ -415,16 +276,14 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
 }
 
 /* ------------------------------------------------------------------------------------------------
- * generic kernel: any n; per-lane state in HBM (aux words), private FULL history in HBM.  Only for queries longer
- * than the sweep classes take (n > 32768) and for the column-score requests of their host-driven Hirschberg splits.
+ * generic kernel: any n; per-lane state in HBM (aux words), private FULL history in HBM.  Only for leaf-size problems whose
+ * query is longer than the sweep classes take (n > 32768, hence m <= 101 below edlib's traceback switch).
  *   aux layout per problem: nbk x {lo,hi,valid,Pv,Mv}
- *   task LF_TASK_COLS: out_cols[aux2 + r] = D[r][m], r = 0..n, strings walked backwards when rev
  * ---------------------------------------------------------------------------------------------- */
-#define LF_TASK_COLS 2
 __global__ void __launch_bounds__(64)
 lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ hist, uint64_t *__restrict__ aux,
                         uint8_t *__restrict__ ops, int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end,
-                        uint32_t *__restrict__ out_len, int32_t *__restrict__ out_cols, const uint64_t *__restrict__ cols_off)
+                        uint32_t *__restrict__ out_len)
 {
     const int gid = blockIdx.x * 64 + threadIdx.x;
     if (gid >= n_probs) return;
@@ -457,17 +316,6 @@ lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_s
             if (want_path) { lf_hist_t e; e.pv = Pv; e.ph = ph; h[(size_t)(c - 1) * nbk + b] = e; }
         }
         if (score < best) { best = score; best_c = (int)c; }
-    }
-    if (pr.task == LF_TASK_COLS) {
-        int32_t *oc = out_cols + cols_off[pr.id];
-        int v = (int)m;
-        oc[0] = v;
-        for (uint32_t r = 1; r <= n; r++) {
-            const uint32_t b = (r - 1) >> 6; const int bit = (int)((r - 1) & 63);
-            v += (int)((st[b * 5 + 3] >> bit) & 1) - (int)((st[b * 5 + 4] >> bit) & 1);
-            oc[r] = v;
-        }
-        return;
     }
     int ed, tl;
     if (pr.mode == 0) { ed = score; tl = (int)m; } else { ed = best; tl = best_c; }
@@ -509,11 +357,7 @@ lf_edlib_generic_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_s
  *              then n-1 (:1263-1289) found with one ballot per 64 rows.  No host round trip, no byte staging.
  * The target is staged through an LDS ring (refilled every TC/2 steps), so any target length runs out of LDS.
  * ---------------------------------------------------------------------------------------------- */
-/* lane l receives lane l-1's value (lane 0: 0): the horizontal carry of the anti-diagonal sweeps.  DPP wave_shr:1 is a
- * VALU move; __shfl_up goes through the LDS crossbar (ds_bpermute) and sits on the per-step dependency chain. */
-__device__ __forceinline__ uint32_t lf_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
 
-#define LF_HSTACK 48
 template <int G, int KB, int K, bool PAC>
 __global__ void __launch_bounds__(64)
 lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ ckpt, uint64_t *__restrict__ aux,
@@ -524,7 +368,6 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     constexpr int H = TC / 2;
     __shared__ lf_hist_t s_tile[K * KB * 64];
     __shared__ unsigned char s_t[P * TC];
-    __shared__ uint32_t s_stack[G == 64 ? LF_HSTACK * 5 : 1];
     /* match masks of the lane's block against the four target codes (KB = 1, targets from the 2-bit reference): one
      * ds_read_b64 per step, issued a step ahead, instead of ten ALU ops on the bit planes; every lane touches its own column only */
     constexpr bool PEQ = PAC && KB == 1;
@@ -706,8 +549,8 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
         }
     };
 
-    /* ---- the root problem ---- */
-    const bool root_leaf = G < 64 || lf_leaf(pr.n, pr.m);      /* G < 64: the binning sends only leaf-size problems */
+    /* ---- the problem (always below edlib's traceback switch: larger ones were cut into leaves by lf_hirsch.hip) ---- */
+    const bool root_leaf = true;
     build_planes();
     if (KB == 1 && want_path && root_leaf) {      /* for lf_edlib_tb_kernel */
         uint64_t *pl = reinterpret_cast<uint64_t *>(ck - LF_PLANE_ENTRIES);
@@ -740,109 +583,30 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     if (!__any(want_path)) { if (live && gl == 0) out_len[pr.id] = 0; return; }
     if (root_leaf) {
         traceback((uint32_t)tl, steps_max, want_path);
-    } else if (G == 64) {
-        /* obtainAlignment (lib/edlib/edlib.cpp:1090-1143) on (q, t[0 .. tl)) with the known distance: depth-first, right
-         * child first.  Everything below is wave-uniform (one problem per wavefront). */
-        const uint32_t n_root = pr.n;
-        int32_t *Fb = reinterpret_cast<int32_t *>(aux + pr.aux_off), *Rb = Fb + (n_root + 1);
-        int sp = 0;
-        auto push = [&](uint32_t a, uint32_t b, uint32_t c2, uint32_t d, uint32_t e) {
-            if (lane == 0) { s_stack[sp * 5 + 0] = a; s_stack[sp * 5 + 1] = b; s_stack[sp * 5 + 2] = c2; s_stack[sp * 5 + 3] = d; s_stack[sp * 5 + 4] = e; }
-            sp++;
-        };
-        /* D[r][m] for r = 0..n of the sweep that just ended: lane-local sums + exclusive scan over lanes */
-        auto colscores = [&](int32_t *oc) {
-            int mine = 0;
-#pragma unroll
-            for (int k = 0; k < KB; k++) {
-                const uint32_t b = (uint32_t)lane * KB + k;
-                if (b < nbk) {
-                    const uint32_t rows = (b == lastb) ? (uint32_t)lastbit + 1 : 64;
-                    const uint64_t msk = rows >= 64 ? ~0ull : ((1ull << rows) - 1);
-                    mine += __popcll(Pv[k] & msk) - __popcll(Mv[k] & msk);
-                }
-            }
-            int incl = mine;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-            int v = (int)m + incl - mine;
-            if (lane == 0) oc[0] = (int)m;
-#pragma unroll
-            for (int k = 0; k < KB; k++) {
-                const uint32_t b = (uint32_t)lane * KB + k;
-                if (b < nbk) for (int i = 0; i < 64; i++) {
-                    const uint32_t r = b * 64 + i + 1;
-                    if (r <= n) { v += (int)((Pv[k] >> i) & 1) - (int)((Mv[k] >> i) & 1); oc[r] = v; }
-                }
-            }
-        };
-        if (tl == 0) { for (uint32_t i = 0; i < n_root; i++) em.put(1); }
-        else push(0, n_root, 0, (uint32_t)tl, (uint32_t)ed);
-        bool failed = false;
-        while (sp > 0 && !failed) {
-            sp--;
-            __syncthreads();
-            const uint32_t a_q = s_stack[sp * 5 + 0], a_n = s_stack[sp * 5 + 1], a_t = s_stack[sp * 5 + 2], a_m = s_stack[sp * 5 + 3];
-            const int a_best = (int)s_stack[sp * 5 + 4];
-            __syncthreads();
-            if (a_n == 0) { for (uint32_t i = 0; i < a_m; i++) em.put(2); continue; }          /* :1096-1104 */
-            if (a_m == 0) { for (uint32_t i = 0; i < a_n; i++) em.put(1); continue; }
-            if (lf_leaf(a_n, a_m)) {
-                qlo = a_q; n = a_n; tlo = a_t; m = a_m; rev = false;
-                build_planes();
-                steps_max = forward(true);
-                traceback(a_m, steps_max, true);
-                continue;
-            }
-            const uint32_t lw = a_m / 2, rw = a_m - lw;
-            /* F[x] = dist(q[0..x), t[0..lw)) */
-            qlo = a_q; n = a_n; tlo = a_t; m = lw; rev = false;
-            build_planes(); (void)forward(false); colscores(Fb);
-            /* R[x] = dist(last x of q, t[lw..m)): both strings walked backwards */
-            qlo = a_q; n = a_n; tlo = a_t + lw; m = rw; rev = true;
-            build_planes(); (void)forward(false); colscores(Rb);
-            __syncthreads();
-            /* split row (:1263-1289): first qi in 0..n-2 with F[qi+1] + R[n-qi-1] == best, else -1, else n-1 */
-            int split = -2, ls = 0, rs = 0;
-            for (uint32_t base = 0; base + 2 <= a_n && split == -2; base += 64) {
-                const uint32_t qi = base + (uint32_t)lane;
-                const bool hit = qi + 2 <= a_n && Fb[qi + 1] + Rb[a_n - qi - 1] == a_best;
-                const uint64_t bm = __ballot(hit);
-                if (bm) split = (int)(base + (uint32_t)(__ffsll((long long)bm) - 1));
-            }
-            if (split >= 0) { ls = Fb[split + 1]; rs = Rb[a_n - (uint32_t)split - 1]; }
-            else if ((int)lw + Rb[a_n] == a_best) { split = -1; ls = (int)lw; rs = Rb[a_n]; }
-            else if (Fb[a_n] + (int)rw == a_best) { split = (int)a_n - 1; ls = Fb[a_n]; rs = (int)rw; }
-            else { failed = true; break; }
-            __syncthreads();                                   /* Fb / Rb are overwritten by the children */
-            const uint32_t ul = (uint32_t)(split + 1);
-            if (sp + 2 > LF_HSTACK) { failed = true; break; }
-            push(a_q, ul, a_t, lw, (uint32_t)ls);                             /* left child: popped second */
-            push(a_q + ul, a_n - ul, a_t + lw, rw, (uint32_t)rs);             /* right child: popped first */
-        }
-        if (failed && live && lane == 0) out_ed[pr.id] = -2;      /* cannot happen for a consistent distance; the host reports it */
     }
     em.flush();
     if (live && gl == 0) out_len[pr.id] = want_path ? pr.n + pr.m - em.w : 0;            /* ops are END-aligned: o[cap - len .. cap) */
 }
 
 /* ------------------------------------------------------------------------------------------------
- * size classes and checkpoint layout (shared by the host binning of the byte-string API and the device binning of
- * the descriptor batches)
+ * size classes and checkpoint layout
  *   1..6   lane kernels NB 1,2,3,4,6,8 (n <= 512): 64 problems per wave, checkpoint every LF_LANE_K columns
  *   7,8    sweep kernels G 16 / 32, one block per lane (n <= 1024 / 2048): 4 / 2 problems per wave
- *   9..11  sweep kernels G 64, KB 1 / 4 / 8 blocks per lane (n <= 4096 / 16384 / 32768), with device Hirschberg
- *   0      generic lane kernel (n > 32768; full history in HBM; Hirschberg driven by the host)
+ *   9..11  sweep kernels G 64, KB 1 / 4 / 8 blocks per lane (n <= 4096 / 16384 / 32768)
+ *   0      generic lane kernel (n > 32768; full history in HBM) -- below edlib's traceback switch such a problem has m <= 101
+ *   12     not a problem of these kernels: an empty side (a pure run, written at once) or a problem above edlib's traceback
+ *          switch (:1117-1119) -- a ROOT of the breadth-first Hirschberg levels (lf_hirsch.hip), whose leaves come back as
+ *          extra problems of classes 0..11
  * A wave's checkpoints start at the hist_base of its first problem (16-byte entries).
  * ---------------------------------------------------------------------------------------------- */
 #define LF_NCLASS 12
+#define LF_CLASS_SKIP 12
 /* LF_SWEEP_MAX_N: lf_internal.h */
 __host__ __device__ __forceinline__ int lf_class_nb(int c) { return c == 1 ? 1 : c == 2 ? 2 : c == 3 ? 3 : c == 4 ? 4 : c == 5 ? 6 : 8; }
 __host__ __device__ __forceinline__ int lf_class_of(uint32_t n, uint32_t m)
 {
+    if (n == 0 || m == 0 || !lf_leaf(n, m)) return LF_CLASS_SKIP;
     const uint32_t nb = (n + 63) >> 6;
-    /* above edlib's traceback switch the path is Hirschberg's, whatever the query length: the classes that recurse */
-    if (!lf_leaf(n, m)) return n <= 4096 ? 9 : n <= 16384 ? 10 : n <= LF_SWEEP_MAX_N ? 11 : 0;
     if (nb <= 1) return 1; if (nb <= 2) return 2; if (nb <= 3) return 3; if (nb <= 4) return 4; if (nb <= 6) return 5; if (nb <= 8) return 6;
     if (nb <= 16) return 7; if (nb <= 32) return 8;
     if (n <= 4096) return 9; if (n <= 16384) return 10; if (n <= LF_SWEEP_MAX_N) return 11;
@@ -856,47 +620,17 @@ __host__ __device__ __forceinline__ int lf_class_k(int c) { return c == 10 ? 4 :
 __host__ __device__ __forceinline__ uint64_t lf_class_wave_entries(int c, uint32_t m_max)
 {
     if (c >= 1 && c <= 6) return lf_lane_ck_off(lf_class_nb(c), m_max) + 64ull * (m_max / LF_LANE_K) * (uint32_t)lf_class_nb(c);
-    if (c == 0) return 0;
+    if (c == 0 || c == LF_CLASS_SKIP) return 0;
     const uint64_t rows = ((uint64_t)m_max + 64) / (uint32_t)lf_class_k(c) + 1;
     return (lf_class_kb(c) == 1 ? LF_PLANE_ENTRIES : 0) + rows * (uint64_t)lf_sweep_row(lf_class_kb(c));
 }
-/* Hirschberg scratch of a sweep-class problem above edlib's traceback switch: two columns of n + 1 scores (in u64 words) */
-__host__ __device__ __forceinline__ uint64_t lf_class_aux_words(int c, uint32_t n, uint32_t m)
-{
-    if (c == 0) return (uint64_t)((n + 63) >> 6) * 5;
-    if (c >= 9 && !lf_leaf(n, m)) return (uint64_t)n + 2;
-    return 0;
-}
-
-struct lf_dev_buf {
-    void *p = nullptr;
-    ~lf_dev_buf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-    template <class T> T *as() { return (T *)p; }
-};
-
-/* stable counting sort of problems by target length (ascending): O(n), replaces std::sort */
-static void sort_by_m(std::vector<lf_aln_prob> &v)
-{
-    if (v.size() < 2) return;
-    uint32_t mx = 0;
-    for (auto &p : v) mx = std::max(mx, p.m);
-    if ((size_t)mx > 8 * v.size() + 65536) {        /* sparse lengths: comparison sort */
-        std::stable_sort(v.begin(), v.end(), [](const lf_aln_prob &a, const lf_aln_prob &b) { return a.m < b.m; });
-        return;
-    }
-    std::vector<uint32_t> cnt((size_t)mx + 2, 0);
-    for (auto &p : v) cnt[p.m + 1]++;
-    for (size_t i = 1; i < cnt.size(); i++) cnt[i] += cnt[i - 1];
-    std::vector<lf_aln_prob> o(v.size());
-    for (auto &p : v) o[cnt[p.m]++] = p;
-    v.swap(o);
-}
+/* private state words of a generic-kernel problem */
+__host__ __device__ __forceinline__ uint64_t lf_class_aux_words(int c, uint32_t n, uint32_t m) { (void)m; return c == 0 ? (uint64_t)((n + 63) >> 6) * 5 : 0; }
 
 /* the launches of one binned batch: class k = probs[cstart[k] .. cstart[k + 1]) */
 struct lf_launch_ctx {
     hipStream_t cs[LF_NCLASS]; const lf_aln_prob *d_probs; const int *cstart; lf_seqs S; lf_hist_t *d_hist; uint64_t *d_aux;
-    uint8_t *d_ops; int32_t *d_ed, *d_end; uint32_t *d_len; int32_t *d_cols; const uint64_t *d_cols_off;
+    uint8_t *d_ops; int32_t *d_ed, *d_end; uint32_t *d_len;
 };
 template <bool PAC>
 static void launch_classes(const lf_launch_ctx &L)
@@ -910,7 +644,7 @@ static void launch_classes(const lf_launch_ctx &L)
     DS(11, 64, 8, 2); DS(10, 64, 4, 4); DS(9, 64, 1, 8); TB(9, false, 64);
     if (cnt(0) > 0)
         hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((cnt(0) + 63) / 64)), dim3(64), 0, L.cs[0],
-                           L.d_probs + L.cstart[0], cnt(0), L.S, L.d_hist, L.d_aux, L.d_ops, L.d_ed, L.d_end, L.d_len, L.d_cols, L.d_cols_off);
+                           L.d_probs + L.cstart[0], cnt(0), L.S, L.d_hist, L.d_aux, L.d_ops, L.d_ed, L.d_end, L.d_len);
     DS(8, 32, 1, 8); TB(8, false, 32); DS(7, 16, 1, 8); TB(7, false, 16);
 #undef DS
 #define DL(C, NBV) if (cnt(C) > 0) hipLaunchKernelGGL((lf_edlib_kernel<NBV, PAC>), dim3((unsigned)((cnt(C) + 63) / 64)), dim3(64), 0, L.cs[C], \
@@ -920,155 +654,57 @@ static void launch_classes(const lf_launch_ctx &L)
 #undef TB
 }
 
-/* runs DIST/PATH problems (cols == nullptr) or COLS problems (cols != nullptr; generic kernel only) given as byte strings */
-static int run_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
-                     const uint8_t *mode, const uint8_t *task, const uint8_t *rev, int32_t *ed, int32_t *endloc,
-                     uint8_t *ops, uint32_t *ops_len, int32_t *cols, const uint64_t *cols_off, float *ms)
-{
-    if (ms) *ms = 0;
-    if (n == 0) return LF_OK;
-    if (lfg_device_count() <= device) { lf_set_error("no gfx950 device %d visible (no CPU path)", device); return LF_ERR_NO_DEVICE; }
-    HIPCHK(hipSetDevice(device));
-    const uint64_t qbytes = qoff[n], tbytes = toff[n];
-    const uint64_t ops_bytes = qbytes + tbytes;
-#define PN(i) ((uint32_t)(qoff[(i) + 1] - qoff[i]))
-#define PM(i) ((uint32_t)(toff[(i) + 1] - toff[i]))
-
-    /* bin + order (the descriptor path does the same on the device) */
-    std::vector<lf_aln_prob> P[LF_NCLASS];
-    std::vector<int> trivial;          /* n == 0 or m == 0: no DP (lib/edlib/edlib.cpp:1096-1104) */
-    for (int i = 0; i < n; i++) {
-        lf_aln_prob pr; memset(&pr, 0, sizeof pr);
-        pr.n = PN(i); pr.m = PM(i); pr.ops_off = qoff[i] + toff[i]; pr.id = (uint32_t)i;
-        const bool rv = rev && rev[i];                    /* Hirschberg right half: both strings walked backwards */
-        pr.qstart = (int64_t)qoff[i] + (rv ? (int64_t)pr.n - 1 : 0); pr.tstart = (int64_t)toff[i] + (rv ? (int64_t)pr.m - 1 : 0);
-        pr.flags = rv ? (LF_F_QREV | LF_F_TREV) : 0;
-        pr.mode = mode ? mode[i] : 0; pr.task = cols ? LF_TASK_COLS : (task ? task[i] : LF_TASK_PATH);
-        if (pr.n == 0 || (pr.m == 0 && !cols)) { trivial.push_back(i); continue; }
-        P[cols ? 0 : lf_class_of(pr.n, pr.m)].push_back(pr);
-    }
-    int cstart[LF_NCLASS + 1]; cstart[0] = 0;
-    size_t hist_entries = 0, aux_words = 0;
-    for (int k = 0; k < LF_NCLASS; k++) {
-        auto &v = P[k];
-        sort_by_m(v);
-        cstart[k + 1] = cstart[k] + (int)v.size();
-        const size_t ppw = (size_t)lf_class_ppw(k);
-        for (size_t w = 0; w < v.size(); w += ppw) {
-            const size_t e = std::min(v.size(), w + ppw);
-            for (size_t j = w; j < e; j++) {
-                v[j].hist_base = hist_entries;
-                const uint64_t aw = lf_class_aux_words(k, v[j].n, v[j].m);
-                if (aw) { v[j].aux_off = aux_words; aux_words += aw; }
-            }
-            if (k == 0) { if (v[w].task == LF_TASK_PATH) hist_entries += (size_t)v[w].m * ((v[w].n + 63) / 64); }      /* one problem per "wave": full history */
-            else hist_entries += lf_class_wave_entries(k, v[e - 1].m);
-        }
-    }
-    std::vector<lf_aln_prob> all; all.reserve((size_t)cstart[LF_NCLASS]);
-    for (int k = 0; k < LF_NCLASS; k++) all.insert(all.end(), P[k].begin(), P[k].end());
-
-    size_t cols_total = 0;
-    if (cols) for (int i = 0; i < n; i++) cols_total = std::max<size_t>(cols_total, cols_off[i] + PN(i) + 1);
-#define DSLOT(T, k, bytes) (T *)lfg_dev_slot(device, LF_DS_ALN0 + (k), (bytes))
-    unsigned char *d_q = DSLOT(unsigned char, 0, qbytes + 64);
-    unsigned char *d_t = DSLOT(unsigned char, 1, tbytes + 64);
-    lf_hist_t *d_hist = DSLOT(lf_hist_t, 2, hist_entries * sizeof(lf_hist_t) + 64);
-    uint64_t *d_aux = DSLOT(uint64_t, 3, aux_words * 8 + 64);
-    int32_t *d_ed = DSLOT(int32_t, 4, (size_t)n * 4), *d_end = DSLOT(int32_t, 5, (size_t)n * 4);
-    uint32_t *d_len = DSLOT(uint32_t, 6, (size_t)n * 4);
-    uint8_t *d_ops = cols ? nullptr : DSLOT(uint8_t, 7, ops_bytes + 64);
-    int32_t *d_cols = cols ? DSLOT(int32_t, 8, cols_total * 4 + 16) : nullptr;
-    uint64_t *d_cols_off = cols ? DSLOT(uint64_t, 9, (size_t)n * 8) : nullptr;
-    lf_aln_prob *d_probs = DSLOT(lf_aln_prob, 13, (all.size() + 1) * sizeof(lf_aln_prob));
-    if (!d_q || !d_t || !d_hist || !d_aux || !d_ed || !d_end || !d_len || !d_probs || (!cols && !d_ops) || (cols && (!d_cols || !d_cols_off))) return LF_ERR_NOMEM;
-#undef DSLOT
-    /* the size classes run CONCURRENTLY on their own streams: the long-query classes have few, long waves and
-     * would leave most CUs idle if the kernels ran back to back */
-    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
-    if (!s) return LF_ERR_HIP;
-    lf_launch_ctx L;
-    for (int k = 0; k < LF_NCLASS; k++) { L.cs[k] = (hipStream_t)lfg_lane_stream(device, 2 + k); if (!L.cs[k]) return LF_ERR_HIP; }
-    hipEvent_t cdone[LF_NCLASS], e0 = (hipEvent_t)lfg_lane_event(device, 12), e1 = (hipEvent_t)lfg_lane_event(device, 13);
-    for (int k = 0; k < LF_NCLASS; k++) { cdone[k] = (hipEvent_t)lfg_lane_event(device, k); if (!cdone[k]) return LF_ERR_HIP; }
-    if (!e0 || !e1) return LF_ERR_HIP;
-    HIPCHK(hipMemcpyAsync(d_q, q, qbytes, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_t, t, tbytes, hipMemcpyHostToDevice, s));
-    if (cols) HIPCHK(hipMemcpyAsync(d_cols_off, cols_off, (size_t)n * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(d_len, 0, (size_t)n * 4, s));
-    if (!all.empty()) HIPCHK(hipMemcpyAsync(d_probs, all.data(), all.size() * sizeof(lf_aln_prob), hipMemcpyHostToDevice, s));
-    HIPCHK(hipEventRecord(e0, s));
-    for (int k = 0; k < LF_NCLASS; k++) if (!P[k].empty()) HIPCHK(hipStreamWaitEvent(L.cs[k], e0, 0));
-    L.d_probs = d_probs; L.cstart = cstart; L.S.q = d_q; L.S.t = d_t; L.S.pac = nullptr; L.d_hist = d_hist; L.d_aux = d_aux;
-    L.d_ops = d_ops; L.d_ed = d_ed; L.d_end = d_end; L.d_len = d_len; L.d_cols = d_cols; L.d_cols_off = d_cols_off;
-    launch_classes<false>(L);
-    for (int k = 0; k < LF_NCLASS; k++) if (!P[k].empty()) { HIPCHK(hipEventRecord(cdone[k], L.cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
-    HIPCHK(hipEventRecord(e1, s));
-    if (cols) HIPCHK(hipMemcpyAsync(cols, d_cols, cols_total * 4, hipMemcpyDeviceToHost, s));
-    else {
-        HIPCHK(hipMemcpyAsync(ed, d_ed, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(endloc, d_end, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(ops_len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(ops, d_ops, ops_bytes, hipMemcpyDeviceToHost, s));
-    }
-    HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipGetLastError());
-    if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
-
-    /* degenerate problems: one side empty -> pure insertion / deletion run (lib/edlib/edlib.cpp:1096-1104) */
-    for (int i : trivial) {
-        const uint32_t nn = PN(i), mm = PM(i);
-        if (cols) { int32_t *oc = cols + cols_off[i]; oc[0] = (int32_t)mm; continue; }   /* n == 0 */
-        const int md = mode ? mode[i] : 0;
-        uint8_t *o = ops + qoff[i] + toff[i];
-        const uint32_t cap = nn + mm;
-        if (nn == 0) {
-            /* NW: delete the whole target; SHW: the empty prefix is optimal */
-            const uint32_t tl = md == 0 ? mm : 0;
-            ed[i] = (int32_t)tl; endloc[i] = (int32_t)tl - 1; ops_len[i] = tl;
-            for (uint32_t j = 0; j < tl; j++) o[cap - tl + j] = 2;
-        } else { ed[i] = (int32_t)nn; endloc[i] = -1; ops_len[i] = nn; for (uint32_t j = 0; j < nn; j++) o[cap - nn + j] = 1; }
-        if (task && task[i] == LF_TASK_DIST) ops_len[i] = 0;
-    }
-    if (!cols) for (int i = 0; i < n; i++) if (ed[i] == -2) { lf_set_error("edlib kernel: no Hirschberg split row for problem %d (n %u, m %u)", i, PN(i), PM(i)); return LF_ERR_HIP; }
-#undef PN
-#undef PM
-    return LF_OK;
-}
-
 /* ------------------------------------------------------------------------------------------------
- * descriptor batches are binned, ordered and laid out ON THE GPU: key = (size class, target length), one radix
- * sort, one scan for the checkpoint bases, one kernel that writes the per-class problem arrays.  The host uploads
- * 32-byte descriptors and launches; it does no per-problem work.
+ * Batches are binned, ordered and laid out ON THE GPU: key = (size class, target length), one radix sort, one scan for the
+ * checkpoint bases, one kernel that writes the per-class problem arrays.  The host uploads 32-byte descriptors (or finds
+ * them in HBM: lf_walk.hip) and launches; it does no per-problem work.  Items n .. n + n_h - 1 are the leaves the
+ * Hirschberg levels made out of the batch's large problems.
  * ---------------------------------------------------------------------------------------------- */
-struct lf_desc_src { const lf_aln_desc_t *d; const uint64_t *ops_off; uint64_t ops_total; const unsigned char *d_reads; const uint8_t *d_pac; };
+struct lf_desc_src {
+    const lf_aln_desc_t *d; const uint64_t *ops_off; uint64_t ops_total;       /* host arrays (or null: dev_desc / dev_opsoff) */
+    const unsigned char *d_q, *d_t; const uint8_t *d_pac; bool pac;           /* sequences in HBM: read batch + 2-bit reference, or uploaded byte strings */
+    lf_hcount_t hc;                                                           /* the problems above edlib's traceback switch (known to whoever made the descriptors) */
+};
 
-__global__ void lf_desc_keys_kernel(const lf_aln_desc_t *__restrict__ d, int n, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+__global__ void lf_desc_keys_kernel(const lf_aln_desc_t *__restrict__ d, const uint64_t *__restrict__ ops_off, int n, const lf_aln_desc_t *__restrict__ hd, int n_h,
+                                    uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint8_t *__restrict__ ops,
+                                    int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    keys[i] = ((uint64_t)lf_class_of(d[i].n, d[i].m) << 32) | d[i].m;
+    if (i >= n + n_h) return;
+    const lf_aln_desc_t x = i < n ? d[i] : hd[i - n];
+    const int c = (i >= n) ? lf_class_of(x.n, x.m) : lf_class_of(x.n, x.m);
+    keys[i] = ((uint64_t)c << 32) | x.m;
     vals[i] = (uint32_t)i;
+    if (i < n && (x.n == 0 || x.m == 0)) {
+        /* one side empty: no DP (lib/edlib/edlib.cpp:1096-1104).  n == 0: NW deletes the whole target, SHW takes the empty
+         * prefix; m == 0: the query is inserted.  The run is end-aligned in the region like every other path. */
+        const uint32_t len = x.n == 0 ? (x.mode == 0 ? x.m : 0u) : x.n;
+        const uint8_t op = x.n == 0 ? 2 : 1;
+        uint8_t *o = ops + ops_off[i] + (x.n + x.m - len);
+        for (uint32_t k = 0; k < len; k++) o[k] = op;
+        out_ed[i] = (int32_t)len; out_end[i] = x.n == 0 ? (int32_t)len - 1 : -1; out_len[i] = len;
+    }
 }
-__global__ void lf_desc_bounds_kernel(const uint64_t *__restrict__ keys, int n, int *__restrict__ cstart /* LF_NCLASS + 1 */)
+__global__ void lf_desc_bounds_kernel(const uint64_t *__restrict__ keys, int n, int *__restrict__ cstart /* LF_NCLASS + 2 */)
 {
     const int c = threadIdx.x;
-    if (c > LF_NCLASS) return;
+    if (c > LF_NCLASS + 1) return;
     const uint64_t want = (uint64_t)c << 32;
     int lo = 0, hi = n;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
     cstart[c] = lo;
 }
 /* checkpoint entries are charged to the first problem of every wave */
-__global__ void lf_desc_entries_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const lf_aln_desc_t *__restrict__ d,
-                                       const int *__restrict__ cstart, int n, uint64_t *__restrict__ ent)
+__global__ void lf_desc_entries_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const lf_aln_desc_t *__restrict__ d, int n0,
+                                       const lf_aln_desc_t *__restrict__ hd, const int *__restrict__ cstart, int n, uint64_t *__restrict__ ent)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int c = (int)(keys[j] >> 32);
     uint64_t e = 0;
-    if (c == 0) { const uint32_t nb = (d[vals[j]].n + 63) >> 6; e = (uint64_t)(uint32_t)keys[j] * nb; }      /* full history: m rows of nb entries */
-    else {
+    if (c == 0) { const uint32_t i = vals[j]; const uint32_t nb = ((i < (uint32_t)n0 ? d[i].n : hd[i - n0].n) + 63) >> 6; e = (uint64_t)(uint32_t)keys[j] * nb; }      /* full history: m rows of nb entries */
+    else if (c != LF_CLASS_SKIP) {
         const int ppw = lf_class_ppw(c), rel = j - cstart[c];
         if (rel % ppw == 0) {
             int last = j + ppw - 1; if (last > cstart[c + 1] - 1) last = cstart[c + 1] - 1;
@@ -1077,24 +713,26 @@ __global__ void lf_desc_entries_kernel(const uint64_t *__restrict__ keys, const 
     }
     ent[j] = e;
 }
-__global__ void lf_desc_build_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const lf_aln_desc_t *__restrict__ d,
-                                     const uint64_t *__restrict__ ops_off, const int *__restrict__ cstart, const uint64_t *__restrict__ base,
-                                     int n, lf_aln_prob *__restrict__ probs, uint64_t *__restrict__ aux_words_total)
+__global__ void lf_desc_build_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const lf_aln_desc_t *__restrict__ d, int n0,
+                                     const lf_aln_desc_t *__restrict__ hd, const uint64_t *__restrict__ ops_off, const uint64_t *__restrict__ hops_off,
+                                     const int *__restrict__ cstart, const uint64_t *__restrict__ base, int n, int pac,
+                                     lf_aln_prob *__restrict__ probs, uint64_t *__restrict__ aux_words_total)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int c = (int)(keys[j] >> 32);
+    if (c == LF_CLASS_SKIP) return;
     const uint32_t i = vals[j];
-    const lf_aln_desc_t x = d[i];
+    const lf_aln_desc_t x = i < (uint32_t)n0 ? d[i] : hd[i - n0];
     lf_aln_prob p;
-    p.qstart = x.qstart; p.tstart = x.tstart; p.ops_off = ops_off[i];
+    p.qstart = x.qstart; p.tstart = x.tstart; p.ops_off = i < (uint32_t)n0 ? ops_off[i] : hops_off[i - n0];
     int jb = j;
     if (c != 0) { const int ppw = lf_class_ppw(c); jb = cstart[c] + ((j - cstart[c]) / ppw) * ppw; }
     p.hist_base = base[jb];
     p.aux_off = 0;
     const uint64_t aw = lf_class_aux_words(c, x.n, x.m);
     if (aw) p.aux_off = atomicAdd((unsigned long long *)aux_words_total, (unsigned long long)aw);
-    p.n = x.n; p.m = x.m; p.id = i; p.mode = x.mode; p.task = LF_TASK_PATH; p.flags = (uint8_t)(x.flags | LF_F_TPAC); p.pad = 0;
+    p.n = x.n; p.m = x.m; p.id = i; p.mode = x.mode; p.task = LF_TASK_PATH; p.flags = (uint8_t)((x.flags & ~LF_F_TPAC) | (pac ? LF_F_TPAC : 0u)); p.pad = 0;
     probs[j] = p;
 }
 
@@ -1115,6 +753,9 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     hipEvent_t cdone[LF_NCLASS], e0 = (hipEvent_t)lfg_lane_event(device, 12), e1 = (hipEvent_t)lfg_lane_event(device, 13), eb = (hipEvent_t)lfg_lane_event(device, 14);
     for (int k = 0; k < LF_NCLASS; k++) { cdone[k] = (hipEvent_t)lfg_lane_event(device, k); if (!cdone[k]) return LF_ERR_HIP; }
     if (!e0 || !e1 || !eb) return LF_ERR_HIP;
+    const lf_hcount_t HC = D->hc;
+    const size_t hcap = HC.roots ? (size_t)HC.cap : 0, NN = (size_t)n + hcap;      /* upper bound of the items to bin */
+    if (NN >= (1ull << 31)) { lf_set_error("edlib batch too large (%zu problems)", NN); return LF_ERR_ARG; }
 #define DSLOT(T, k, bytes) (T *)lfg_dev_slot(device, LF_DS_ALN0 + (k), (bytes))
     /* the descriptors stay with the round's paths when those stay in HBM (lazy paths are resolved against them later) */
     lf_aln_desc_t *d_desc = dev_desc ? const_cast<lf_aln_desc_t *>(dev_desc)
@@ -1122,15 +763,15 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
                                 : (lf_aln_desc_t *)lfg_dev_slot(device, ops_slot + 1, (size_t)n * sizeof(lf_aln_desc_t));
     if (desc_dev) *desc_dev = d_desc;
     uint64_t *d_opsoff = dev_opsoff ? const_cast<uint64_t *>(dev_opsoff) : DSLOT(uint64_t, 1, (size_t)n * 8);
-    uint64_t *d_keys = DSLOT(uint64_t, 3, (size_t)n * 8), *d_keys2 = DSLOT(uint64_t, 8, (size_t)n * 8);
-    uint32_t *d_vals = DSLOT(uint32_t, 9, (size_t)n * 4), *d_vals2 = DSLOT(uint32_t, 10, (size_t)n * 4);
-    uint64_t *d_ent = DSLOT(uint64_t, 11, (size_t)n * 8), *d_base = DSLOT(uint64_t, 12, (size_t)n * 8 + 8);
-    lf_aln_prob *d_probs = DSLOT(lf_aln_prob, 13, (size_t)n * sizeof(lf_aln_prob));
+    uint64_t *d_keys = DSLOT(uint64_t, 3, NN * 8), *d_keys2 = DSLOT(uint64_t, 8, NN * 8);
+    uint32_t *d_vals = DSLOT(uint32_t, 9, NN * 4), *d_vals2 = DSLOT(uint32_t, 10, NN * 4);
+    uint64_t *d_ent = DSLOT(uint64_t, 11, NN * 8), *d_base = DSLOT(uint64_t, 12, NN * 8 + 8);
+    lf_aln_prob *d_probs = DSLOT(lf_aln_prob, 13, NN * sizeof(lf_aln_prob));
     /* device-planned rounds keep their results in slots of their own: the host-planned rounds that follow (rare chains)
      * must not overwrite what lf_walk_emit_kernel still reads */
     const int rs = dev_desc ? 18 : 4;
-    int32_t *d_ed = DSLOT(int32_t, rs, (size_t)n * 4), *d_end = DSLOT(int32_t, rs + 1, (size_t)n * 4);
-    uint32_t *d_len = DSLOT(uint32_t, rs + 2, (size_t)n * 4);
+    int32_t *d_ed = DSLOT(int32_t, rs, NN * 4), *d_end = DSLOT(int32_t, rs + 1, NN * 4);
+    uint32_t *d_len = DSLOT(uint32_t, rs + 2, NN * 4);
     uint8_t *d_ops = ops ? DSLOT(uint8_t, 7, D->ops_total + 64) : (uint8_t *)lfg_dev_slot(device, ops_slot, D->ops_total + 64);
     if (res_dev) { res_dev[0] = d_ed; res_dev[1] = d_end; res_dev[2] = d_len; }
     if (ops_dev) *ops_dev = d_ops;
@@ -1138,8 +779,8 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     uint64_t *d_misc = DSLOT(uint64_t, 15, 64);
     if (!d_desc || !d_opsoff || !d_keys || !d_keys2 || !d_vals || !d_vals2 || !d_ent || !d_base || !d_probs || !d_ed || !d_end || !d_len || !d_ops || !d_cstart || !d_misc) return LF_ERR_NOMEM;
     size_t tb1 = 0, tb2 = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, d_keys, d_keys2, d_vals, d_vals2, n, 0, 36, s);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, d_ent, d_base, n, s);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, d_keys, d_keys2, d_vals, d_vals2, (int)NN, 0, 36, s);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, d_ent, d_base, (int)NN, s);
     void *d_tmp = lfg_dev_slot(device, LF_DS_ALN0 + 16, std::max(tb1, tb2) + 256);
     if (!d_tmp) return LF_ERR_NOMEM;
 
@@ -1149,17 +790,66 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     }
     HIPCHK(hipMemsetAsync(d_misc, 0, 64, s));
     HIPCHK(hipEventRecord(e0, s));
-    const unsigned gb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(lf_desc_keys_kernel, dim3(gb), dim3(256), 0, s, d_desc, n, d_keys, d_vals);
-    { size_t tb = tb1; HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 36, s)); }
-    hipLaunchKernelGGL(lf_desc_bounds_kernel, dim3(1), dim3(64), 0, s, d_keys2, n, d_cstart);
-    hipLaunchKernelGGL(lf_desc_entries_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, d_cstart, n, d_ent);
-    { size_t tb = tb2; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_ent, d_base, n, s)); }
-    hipLaunchKernelGGL(lf_desc_build_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, d_opsoff, d_cstart, d_base, n, d_probs, d_misc);
-    int cstart[LF_NCLASS + 1]; uint64_t tail[2], aux_total = 0;
+
+    /* ---- the problems above edlib's traceback switch: breadth-first Hirschberg levels (lf_hirsch.hip) ---- */
+    lf_hargs HA; memset(&HA, 0, sizeof HA);
+    uint32_t n_h = 0, n_roots = 0;
+    lf_aln_desc_t *d_hdesc = nullptr; uint64_t *d_hopsoff = nullptr;
+    if (HC.roots) {
+        const size_t q_cap = hcap;
+        lf_hctl *d_ctl = DSLOT(lf_hctl, 21, sizeof(lf_hctl));
+        lf_hroot *d_roots = DSLOT(lf_hroot, 22, (size_t)HC.roots * sizeof(lf_hroot));
+        lf_hseg *d_segs = (lf_hseg *)lfg_dev_slot(device, LF_DS_ALN0 + 23, hcap * sizeof(lf_hseg));
+        lf_hnode *d_q = (lf_hnode *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 0, 6 * q_cap * sizeof(lf_hnode));
+        d_hdesc = (lf_aln_desc_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 1, hcap * sizeof(lf_aln_desc_t));
+        d_hopsoff = (uint64_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 2, hcap * 8);
+        const uint64_t aux_cap = 6 * (HC.sum_n / 64 + HC.roots + hcap) + 64, hcar_cap = 2 * HC.sum_m + 64 * hcap + 4096;
+        uint64_t *d_haux = (uint64_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 3, aux_cap * 8);
+        uint8_t *d_hcar = (uint8_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 4, hcar_cap);
+        lf_hctl *h_ctl = (lf_hctl *)lfg_pin_slot(LF_PS_ALN_PROB + 1, sizeof(lf_hctl));
+        if (!d_ctl || !d_roots || !d_segs || !d_q || !d_hdesc || !d_hopsoff || !d_haux || !d_hcar || !h_ctl) return LF_ERR_NOMEM;
+        HIPCHK(hipMemsetAsync(d_ctl, 0, sizeof(lf_hctl), s));
+        HA.S.q = D->d_q; HA.S.t = D->d_t; HA.S.pac = D->d_pac;
+        HA.q_cap = (uint32_t)q_cap; HA.ctl = d_ctl; HA.roots = d_roots; HA.segs = d_segs; HA.hdesc = d_hdesc; HA.hopsoff = d_hopsoff; HA.hleaf_cap = (uint32_t)hcap;
+        HA.aux = d_haux; HA.aux_cap = aux_cap; HA.hcar = d_hcar; HA.hcar_cap = hcar_cap;
+        HA.ops = d_ops; HA.out_ed = d_ed; HA.out_end = d_end; HA.out_len = d_len; HA.n_desc = (uint32_t)n;
+        auto queue = [&](int par, int kbc) { return d_q + ((size_t)par * 3 + kbc) * q_cap; };
+        int par = 0;
+        for (int k = 0; k < 3; k++) HA.q_out[k] = queue(0, k);
+        HA.out_par = 0;
+        lf_hirsch_launch_roots(s, D->pac, d_desc, d_opsoff, n, HA);
+        for (int level = 0; level < 64; level++) {
+            HIPCHK(hipMemcpyAsync(h_ctl, d_ctl, sizeof(lf_hctl), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (h_ctl->fail > 1) { lf_set_error("edlib Hirschberg levels: scratch bound exceeded (code %u)", h_ctl->fail); return LF_ERR_HIP; }
+            n_roots = h_ctl->n_roots; n_h = h_ctl->n_hleaf;
+            const uint32_t c0 = h_ctl->q_n[par][0], c1 = h_ctl->q_n[par][1], c2 = h_ctl->q_n[par][2];
+            if (c0 + c1 + c2 == 0) break;
+            /* next level's counters and this level's scratch cursors */
+            HIPCHK(hipMemsetAsync((char *)d_ctl + offsetof(lf_hctl, q_n) + (size_t)(par ^ 1) * sizeof(h_ctl->q_n[0]), 0, sizeof(h_ctl->q_n[0]), s));
+            HIPCHK(hipMemsetAsync((char *)d_ctl + offsetof(lf_hctl, aux_used), 0, 16, s));
+            for (int k = 0; k < 3; k++) HA.q_out[k] = queue(par ^ 1, k);
+            HA.out_par = (uint32_t)(par ^ 1);
+            const uint32_t cnt3[3] = { c0, c1, c2 };
+            for (int k = 2; k >= 0; k--) { HA.q_in = queue(par, k); HA.n_in = cnt3[k]; lf_hirsch_launch_level(s, D->pac, k, HA); }
+            par ^= 1;
+        }
+        HIPCHK(hipGetLastError());
+        if (n_roots != HC.roots) { lf_set_error("edlib Hirschberg levels: %u roots found, %llu announced", n_roots, (unsigned long long)HC.roots); return LF_ERR_ARG; }
+    }
+    const int N = n + (int)n_h;
+
+    const unsigned gb = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(lf_desc_keys_kernel, dim3(gb), dim3(256), 0, s, d_desc, d_opsoff, n, d_hdesc, (int)n_h, d_keys, d_vals, d_ops, d_ed, d_end, d_len);
+    { size_t tb = tb1; HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, N, 0, 36, s)); }
+    hipLaunchKernelGGL(lf_desc_bounds_kernel, dim3(1), dim3(64), 0, s, d_keys2, N, d_cstart);
+    hipLaunchKernelGGL(lf_desc_entries_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, n, d_hdesc, d_cstart, N, d_ent);
+    { size_t tb = tb2; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_ent, d_base, N, s)); }
+    hipLaunchKernelGGL(lf_desc_build_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, n, d_hdesc, d_opsoff, d_hopsoff, d_cstart, d_base, N, D->pac ? 1 : 0, d_probs, d_misc);
+    int cstart[LF_NCLASS + 2]; uint64_t tail[2], aux_total = 0;
     HIPCHK(hipMemcpyAsync(cstart, d_cstart, sizeof cstart, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&tail[0], d_base + (n - 1), 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&tail[1], d_ent + (n - 1), 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&tail[0], d_base + (N - 1), 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&tail[1], d_ent + (N - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&aux_total, d_misc, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const uint64_t hist_entries = tail[0] + tail[1];
@@ -1170,10 +860,11 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     HIPCHK(hipEventRecord(eb, s));
     auto cnt = [&](int c) { return cstart[c + 1] - cstart[c]; };
     for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && L.cs[k] != s) HIPCHK(hipStreamWaitEvent(L.cs[k], eb, 0));
-    L.d_probs = d_probs; L.cstart = cstart; L.S.q = D->d_reads; L.S.t = nullptr; L.S.pac = D->d_pac; L.d_hist = d_hist; L.d_aux = d_aux;
-    L.d_ops = d_ops; L.d_ed = d_ed; L.d_end = d_end; L.d_len = d_len; L.d_cols = nullptr; L.d_cols_off = nullptr;
-    launch_classes<true>(L);         /* targets of descriptors are the 2-bit reference */
+    L.d_probs = d_probs; L.cstart = cstart; L.S.q = D->d_q; L.S.t = D->d_t; L.S.pac = D->d_pac; L.d_hist = d_hist; L.d_aux = d_aux;
+    L.d_ops = d_ops; L.d_ed = d_ed; L.d_end = d_end; L.d_len = d_len;
+    if (D->pac) launch_classes<true>(L); else launch_classes<false>(L);
     for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && L.cs[k] != s) { HIPCHK(hipEventRecord(cdone[k], L.cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
+    if (n_roots) lf_hirsch_launch_stitch(s, HA, n_roots);      /* the roots' pieces move together once their leaves have paths */
     HIPCHK(hipEventRecord(e1, s));
     if (ed) {
         HIPCHK(hipMemcpyAsync(ed, d_ed, (size_t)n * 4, hipMemcpyDeviceToHost, s));
@@ -1185,8 +876,16 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
     /* (a device-planned round reports a missing Hirschberg split through lf_walk_emit_kernel: ed == -2 makes the job rare) */
-    if (ed && cnt(9) + cnt(10) + cnt(11) > 0) for (int i = 0; i < n; i++) if (ed[i] == -2) { lf_set_error("edlib kernel: no Hirschberg split row for descriptor %d (n %u, m %u)", i, D->d[i].n, D->d[i].m); return LF_ERR_HIP; }
+    if (ed && n_roots) for (int i = 0; i < n; i++) if (ed[i] == -2) { lf_set_error("edlib kernel: no Hirschberg split row for descriptor %d (n %u, m %u)", i, D->d ? D->d[i].n : 0, D->d ? D->d[i].m : 0); return LF_ERR_HIP; }
     return LF_OK;
+}
+
+/* what the Hirschberg levels need to know about a batch before anything runs (buffer bounds): counted where the descriptors are made */
+static lf_hcount_t count_hroots(int n, const lf_aln_desc_t *d)
+{
+    lf_hcount_t c; memset(&c, 0, sizeof c);
+    for (int i = 0; i < n; i++) if (d[i].n && d[i].m && !lf_leaf(d[i].n, d[i].m)) { c.roots++; c.cap += lf_hroot_cap(d[i].n, d[i].m); c.sum_n += d[i].n; c.sum_m += d[i].m; }
+    return c;
 }
 
 extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_desc_t *d, const uint64_t *ops_off, uint64_t ops_total,
@@ -1196,10 +895,10 @@ extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_des
     if (!st) { lf_set_error("index is not on a device"); return LF_ERR_NO_DEVICE; }
     lf_desc_src D;
     D.d = d; D.ops_off = ops_off; D.ops_total = ops_total;
-    D.d_reads = (const unsigned char *)lfg_dev_slot(ix->device, LF_DS_SEED0 + 0, 0);      /* read batch left in HBM by lfg_seed */
-    D.d_pac = st->view.pac;
-    if (!D.d_reads) { lf_set_error("lfg_edlib_desc: no resident read batch"); return LF_ERR_ARG; }
-    for (int i = 0; i < n; i += 4096) if (d[i].n == 0 || d[i].m == 0) { lf_set_error("lfg_edlib_desc: empty sequence in a descriptor"); return LF_ERR_ARG; }
+    D.d_q = (const unsigned char *)lfg_dev_slot(ix->device, LF_DS_SEED0 + 0, 0);      /* read batch left in HBM by lfg_seed */
+    D.d_t = nullptr; D.d_pac = st->view.pac; D.pac = true;
+    D.hc = count_hroots(n, d);
+    if (!D.d_q) { lf_set_error("lfg_edlib_desc: no resident read batch"); return LF_ERR_ARG; }
     if (getenv("LF_HIST_STATS")) {       /* debug: where the DP cells are (by ceil(n/64)) */
         uint64_t cnt[12] = { 0 }, cells[12] = { 0 }, hist[12] = { 0 };
         static const uint32_t edge[12] = { 1, 2, 3, 4, 5, 6, 8, 12, 16, 32, 64, 256 };
@@ -1212,16 +911,17 @@ extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_des
     return run_edlib_desc_gpu(ix->device, n, &D, ed, endloc, ops, ops_len, ops_slot, ops_dev, desc_dev, ms);
 }
 
-extern "C" int lfg_edlib_desc_dev(const struct lf_index *ix, int n, const void *d_desc, const void *d_opsoff, uint64_t ops_total, int ops_slot,
+extern "C" int lfg_edlib_desc_dev(const struct lf_index *ix, int n, const void *d_desc, const void *d_opsoff, uint64_t ops_total, const lf_hcount_t *hc, int ops_slot,
                                   void **ops_dev, void **ed_dev, void **end_dev, void **len_dev, float *ms)
 {
     lf_dev_state *st = (lf_dev_state *)ix->dev;
     if (!st) { lf_set_error("index is not on a device"); return LF_ERR_NO_DEVICE; }
     lf_desc_src D;
     D.d = nullptr; D.ops_off = nullptr; D.ops_total = ops_total;
-    D.d_reads = (const unsigned char *)lfg_dev_slot(ix->device, LF_DS_SEED0 + 0, 0);
-    D.d_pac = st->view.pac;
-    if (!D.d_reads) { lf_set_error("lfg_edlib_desc_dev: no resident read batch"); return LF_ERR_ARG; }
+    D.d_q = (const unsigned char *)lfg_dev_slot(ix->device, LF_DS_SEED0 + 0, 0);
+    D.d_t = nullptr; D.d_pac = st->view.pac; D.pac = true;
+    D.hc = *hc;
+    if (!D.d_q) { lf_set_error("lfg_edlib_desc_dev: no resident read batch"); return LF_ERR_ARG; }
     void *res[3] = { nullptr, nullptr, nullptr };
     const int rc = run_edlib_desc_gpu(ix->device, n, &D, nullptr, nullptr, nullptr, nullptr, ops_slot, ops_dev, nullptr, ms,
                                       (const lf_aln_desc_t *)d_desc, (const uint64_t *)d_opsoff, res);
@@ -1231,17 +931,35 @@ extern "C" int lfg_edlib_desc_dev(const struct lf_index *ix, int n, const void *
     return rc;
 }
 
+/* problems given as byte strings in host memory (the stage API lf_edlib_batch and the edlibAlign drop-in): the strings are
+ * uploaded once and described exactly like the pipeline's requests -- the same binning, kernels and Hirschberg levels, with the
+ * target read as bytes instead of 2-bit codes */
 extern "C" int lfg_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
-                         const uint8_t *mode, const uint8_t *task, int32_t *ed, int32_t *endloc, uint8_t *ops,
-                         uint32_t *ops_len, float *ms)
+                         const uint8_t *mode, int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, float *ms)
 {
-    return run_edlib(device, n, q, qoff, t, toff, mode, task, nullptr, ed, endloc, ops, ops_len, nullptr, nullptr, ms);
-}
-
-extern "C" int lfg_colscores(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
-                             const uint8_t *rev, int32_t *out, const uint64_t *cs_off, float *ms)
-{
-    return run_edlib(device, n, q, qoff, t, toff, nullptr, nullptr, rev, nullptr, nullptr, nullptr, nullptr, out, cs_off, ms);
+    if (ms) *ms = 0;
+    if (n == 0) return LF_OK;
+    if (lfg_device_count() <= device) { lf_set_error("no gfx950 device %d visible (no CPU path)", device); return LF_ERR_NO_DEVICE; }
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
+    if (!s) return LF_ERR_HIP;
+    const uint64_t qbytes = qoff[n], tbytes = toff[n];
+    unsigned char *d_q = (unsigned char *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 5, qbytes + 64), *d_t = (unsigned char *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 6, tbytes + 64);
+    if (!d_q || !d_t) return LF_ERR_NOMEM;
+    std::vector<lf_aln_desc_t> dd((size_t)n); std::vector<uint64_t> oo((size_t)n);
+    for (int i = 0; i < n; i++) {
+        lf_aln_desc_t &x = dd[(size_t)i]; memset(&x, 0, sizeof x);
+        x.qstart = (int64_t)qoff[i]; x.tstart = (int64_t)toff[i]; x.n = (uint32_t)(qoff[i + 1] - qoff[i]); x.m = (uint32_t)(toff[i + 1] - toff[i]);
+        x.mode = mode ? mode[i] : 0;
+        oo[(size_t)i] = qoff[i] + toff[i];
+    }
+    HIPCHK(hipMemcpyAsync(d_q, q, qbytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_t, t, tbytes, hipMemcpyHostToDevice, s));
+    lf_desc_src D;
+    D.d = dd.data(); D.ops_off = oo.data(); D.ops_total = qbytes + tbytes;
+    D.d_q = d_q; D.d_t = d_t; D.d_pac = nullptr; D.pac = false;
+    D.hc = count_hroots(n, dd.data());
+    return run_edlib_desc_gpu(device, n, &D, ed, endloc, ops, ops_len, 0, nullptr, nullptr, ms);
 }
 
 /* ------------------------------------------------------------------------------------------------

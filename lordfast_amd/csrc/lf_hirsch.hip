@@ -1,0 +1,358 @@
+/*
+ * lf_hirsch.hip -- edlib's Hirschberg recursion (obtainAlignmentHirschberg, lib/edlib/edlib.cpp:1161-1330), BREADTH-FIRST
+ * over all problems of a batch (gfx950).
+ *
+ * edlib switches from the plain traceback to Hirschberg's divide and conquer when the traceback data of a problem would
+ * exceed 1 MiB (:1117-1119).  The recursion picks a different optimal path than the plain traceback on ties, so it has to be
+ * followed node for node.  Round 2 did that depth-first inside ONE wavefront per problem (LDS stack): a few hundred
+ * wavefronts per launch on a 1024-SIMD chip, each running ~2 m dependent sweep steps.  Here the recursion is turned inside
+ * out: level l of ALL problems is one launch,
+ *
+ *   - a node is one 128-thread workgroup: wavefront 0 sweeps the left half of the target forwards, wavefront 1 the right
+ *     half backwards (both strings reversed) -- at the same time; each leaves the last DP column as per-block (Pv, Mv, base)
+ *     triples (24 B per 64 rows instead of 256 B of scores);
+ *   - wavefront 0 then finds the split row in the reference's order -- rows 0 .. n-2 ascending, then -1, then n-1
+ *     (:1263-1289), one ballot per 64 rows -- and emits the two children: a child that is small enough for the plain
+ *     traceback (:1117-1119) becomes an ordinary leaf problem of the size-class kernels (lf_align.hip), a child with an empty
+ *     side is a pure run, anything else is queued for the next level;
+ *   - an NW root needs no distance pass of its own: D[n][m] = min over rows r of F[r] + R[n - r], which the first split
+ *     computes anyway; an SHW root runs one distance sweep first (end column, :141-168) as a node of kind 1.
+ *
+ * Every piece (leaf path, run) lands end-aligned in its own part of the root's ops region; lf_hirsch_stitch_kernel closes
+ * the gaps once the leaves' tracebacks are done, so that the root looks like any other problem (ops end-aligned, out_len).
+ * Queries of any length: a wavefront sweeps 64 x KB blocks (KB = 1 / 4 / 8 registers-resident blocks per lane) and walks
+ * longer queries band by band (32 768 rows), the two-bit carries that cross a band boundary going through HBM.
+ */
+#include "lf_hirsch.h"
+
+#define LF_H_TC 256          /* LDS ring of target symbols per wavefront (power of two) */
+#define LF_H_H  128
+
+/* wavefront-local LDS ordering: DS operations of one wavefront execute in order; this only stops the compiler from moving
+ * them across (two wavefronts of a node run different numbers of ring refills: no workgroup barrier may sit in the sweep) */
+__device__ __forceinline__ void lf_wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+/* One sweep of q[0..n) x t[0..m) by ONE wavefront (anti-diagonal: lane l is l columns behind lane l - 1; carry by DPP).
+ * blk_out != null: the last DP column as 3 u64 per 64-row block: Pv, Mv, D[64 b][m].
+ * Returns D[n][m]; track: also the SHW result (smallest prefix distance, smallest column on ties; the empty prefix only
+ * competes when n % 64 != 0, lib/edlib/edlib.cpp:595,615). */
+template <int KB, bool PAC>
+__device__ __forceinline__ int lf_hsweep(const lf_qacc &Q, const lf_tacc &T, const uint32_t n, const uint32_t m, const bool track,
+                                         unsigned char *ring, unsigned char *cring, uint64_t *peq, uint8_t *hc_a, uint8_t *hc_b,
+                                         uint64_t *blk_out, int &shw_best, int &shw_c)
+{
+    constexpr bool PEQ = PAC && KB == 1;
+    constexpr int TC = LF_H_TC, H = LF_H_H;
+    const int lane = threadIdx.x & 63;
+    auto qget = [&](uint32_t r) -> unsigned char { return Q.get(r); };
+    const uint32_t nbk = (n + 63) >> 6, lastb = (n - 1) >> 6;
+    const int lastbit = (int)((n - 1) & 63);
+    int col_base = (int)m;                       /* D[first row of the band][m] */
+    int score = (int)n, best = (n & 63) ? (int)n : 0x7fffffff, best_c = 0;
+    uint8_t *hc_in = hc_a, *hc_out = hc_b;
+    for (uint32_t b0 = 0; b0 < nbk; b0 += 64 * KB) {
+        const uint32_t band_blocks = nbk - b0 < 64u * KB ? nbk - b0 : 64u * KB;
+        const int nl = (int)((band_blocks + KB - 1) / KB);
+        const bool first_band = b0 == 0, last_band = b0 + 64 * KB >= nbk;
+        const int lane_last = (int)((lastb - b0) / KB);          /* meaningful in the last band */
+        /* bit planes of the band's blocks by ballot: 64 query bytes per block, three ballots, the owning lane keeps them */
+        uint64_t lo[KB], hi[KB], valid[KB], Pv[KB], Mv[KB];
+#pragma unroll
+        for (int k = 0; k < KB; k++) { lo[k] = hi[k] = valid[k] = 0; Pv[k] = ~0ull; Mv[k] = 0; }
+        for (uint32_t b = 0; b < band_blocks; b++) {
+            const uint32_t r = (b0 + b) * 64 + (uint32_t)lane;
+            bool ok; const uint32_t cd = lf_code_upper(qget(r < n ? r : n - 1), ok);
+            const int code = (r < n && ok) ? (int)cd : -1;
+            const uint64_t bl = __ballot(code >= 0 && (code & 1)), bh = __ballot(code >= 0 && (code & 2)), bv = __ballot(code >= 0);
+            if ((uint32_t)lane == b / KB) {
+                const int slot = (int)(b % KB);
+#pragma unroll
+                for (int k = 0; k < KB; k++) if (k == slot) { lo[k] = bl; hi[k] = bh; valid[k] = bv; }
+            }
+        }
+        if (PEQ) {
+#pragma unroll
+            for (uint32_t cde = 0; cde < 4; cde++) peq[cde * 64 + lane] = lf_eq_tok<true>(cde, lo[0], hi[0], valid[0], qget, n, b0 + (uint32_t)lane);
+        }
+        auto stage = [&](int first, int count) {
+            for (int j = first + lane; j < first + count; j += 64) if (j >= 0 && (uint32_t)j < m) {
+                ring[j & (TC - 1)] = PAC ? (unsigned char)T.pac_code((uint32_t)j) : T.get((uint32_t)j);
+                if (!first_band) cring[j & (TC - 1)] = hc_in[j];
+            }
+        };
+        const int steps = (int)m + nl - 1;
+        uint32_t hout_prev = LF_HIN_PLUS1;
+        lf_wave_lds_sync(); stage(0, H); lf_wave_lds_sync();
+        uint32_t sym = ring[(0 - lane) & (TC - 1)];
+        uint64_t eq = PEQ ? peq[(sym & 3u) * 64 + lane] : 0ull;
+        uint32_t cin = first_band ? LF_HIN_PLUS1 : (uint32_t)cring[0];
+        for (int s = 0; s < steps; s++) {
+            if (((s + 1) & (H - 1)) == 0) { lf_wave_lds_sync(); stage(s + 1, H); lf_wave_lds_sync(); }
+            const uint32_t sym_next = ring[(s + 1 - lane) & (TC - 1)];
+            const uint32_t cin_next = first_band ? LF_HIN_PLUS1 : (uint32_t)cring[(s + 1) & (TC - 1)];
+            const uint32_t from_left = lf_wave_shr1(hout_prev);
+            const int c = s - lane + 1;
+            if (lane < nl && c >= 1 && c <= (int)m) {
+                const uint32_t tok = PAC ? sym : lf_tok_of_byte((unsigned char)sym);
+                uint32_t hin = lane == 0 ? cin : from_left;
+#pragma unroll
+                for (int k = 0; k < KB; k++) {
+                    const uint32_t b = b0 + (uint32_t)lane * KB + k;
+                    const uint64_t Eq = PEQ ? eq : lf_eq_tok<PAC>(tok, lo[k], hi[k], valid[k], qget, n, b);
+                    uint64_t ph, mh;
+                    const uint32_t ho = lf_myers_step(Pv[k], Mv[k], Eq, hin, ph, mh);
+                    hin = (KB == 1 || b < nbk) ? ho : hin;      /* blocks past the last one compute on dead registers */
+                    if (track) score += (b == lastb) ? lf_delta_at(ph, mh, lastbit) : 0;
+                }
+                hout_prev = hin;
+                if (track && last_band) { const bool upd = lane == lane_last && score < best; best = upd ? score : best; best_c = upd ? c : best_c; }
+                if (!last_band && lane == 63) hc_out[c - 1] = (uint8_t)hin;      /* the carry leaving the band's last block */
+            }
+            sym = sym_next; cin = cin_next;
+            if (PEQ) eq = peq[(sym & 3u) * 64 + lane];
+        }
+        /* last column of the band: D[r][m] = D[first row][m] + vertical deltas */
+        int mine = 0, part[KB];
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+            const uint32_t b = b0 + (uint32_t)lane * KB + k;
+            part[k] = 0;
+            if (lane < nl && b < nbk) {
+                const uint32_t rows = (b == lastb) ? (uint32_t)lastbit + 1 : 64;
+                const uint64_t msk = rows >= 64 ? ~0ull : ((1ull << rows) - 1);
+                part[k] = __popcll(Pv[k] & msk) - __popcll(Mv[k] & msk);
+            }
+            mine += part[k];
+        }
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        int base = col_base + incl - mine;
+        if (blk_out) {
+#pragma unroll
+            for (int k = 0; k < KB; k++) {
+                const uint32_t b = b0 + (uint32_t)lane * KB + k;
+                if (lane < nl && b < nbk) { blk_out[3 * (size_t)b] = Pv[k]; blk_out[3 * (size_t)b + 1] = Mv[k]; blk_out[3 * (size_t)b + 2] = (uint64_t)(int64_t)base; }
+                base += part[k];
+            }
+        }
+        col_base += __shfl(incl, 63);
+        if (!last_band) { __threadfence(); uint8_t *t = hc_in; hc_in = hc_out; hc_out = t; }
+    }
+    if (track) {
+        const int src = (int)((lastb % (64u * KB)) / KB);
+        shw_best = __shfl(best, src); shw_c = __shfl(best_c, src);
+    }
+    return col_base;
+}
+
+/* D[x][last column] from the per-block triples; x = 0: the first row (`zero`) */
+__device__ __forceinline__ int lf_hcol(const uint64_t *__restrict__ B, uint32_t x, int zero)
+{
+    if (x == 0) return zero;
+    const uint32_t b = (x - 1) >> 6, bit = (x - 1) & 63;
+    const uint64_t pv = B[3 * (size_t)b], mv = B[3 * (size_t)b + 1];
+    const uint64_t msk = bit == 63 ? ~0ull : ((2ull << bit) - 1);
+    return (int)(int64_t)B[3 * (size_t)b + 2] + __popcll(pv & msk) - __popcll(mv & msk);
+}
+
+/* registers a finished piece of a root's path (wave-uniform arguments; lane 0 writes) */
+__device__ __forceinline__ void lf_hpiece(const lf_hargs &A, uint32_t root, uint64_t off, uint32_t cap, uint32_t len)
+{
+    if ((threadIdx.x & 63) == 0) {
+        lf_hroot *R = &A.roots[root];
+        const uint32_t slot = atomicAdd(&R->count, 1u);
+        if (slot < R->seg_cap) { lf_hseg e; e.off = off; e.cap = cap; e.len = len; A.segs[R->seg_off + slot] = e; }
+        else atomicExch(&A.ctl->fail, 2u);
+    }
+}
+
+/* a child (or the truncated SHW root): run, leaf problem of the size classes, or a node of the next level */
+__device__ __forceinline__ void lf_hfinalize(const lf_hargs &A, const lf_hnode &P, uint32_t qo, uint32_t cn, uint32_t to, uint32_t cm, int best, uint64_t off)
+{
+    const int lane = threadIdx.x & 63;
+    if (cn == 0 && cm == 0) return;
+    if (cn == 0 || cm == 0) {            /* lib/edlib/edlib.cpp:1096-1104: all deletions / all insertions */
+        const uint32_t len = cn + cm; const uint8_t op = cn == 0 ? 2 : 1;
+        for (uint32_t i = (uint32_t)lane; i < len; i += 64) A.ops[off + i] = op;
+        lf_hpiece(A, P.root, off, len, len);
+        return;
+    }
+    const int64_t dq = (P.flags & LF_F_QREV) ? -1 : 1, dt = (P.flags & LF_F_TREV) ? -1 : 1;
+    if (lf_leaf(cn, cm)) {
+        uint32_t j = 0;
+        if (lane == 0) j = atomicAdd(&A.ctl->n_hleaf, 1u);
+        j = (uint32_t)__shfl((int)j, 0);
+        if (j >= A.hleaf_cap) { if (lane == 0) atomicExch(&A.ctl->fail, 3u); return; }
+        if (lane == 0) {
+            lf_aln_desc_t d;
+            d.qstart = P.qstart + dq * (int64_t)qo; d.tstart = P.tstart + dt * (int64_t)to; d.n = cn; d.m = cm;
+            d.flags = (uint8_t)(P.flags & ~LF_F_TPAC); d.mode = 0;
+            for (int z = 0; z < 6; z++) d.pad[z] = 0;
+            A.hdesc[j] = d; A.hopsoff[j] = off;
+        }
+        lf_hpiece(A, P.root, off, cn + cm, 0x80000000u | j);
+        return;
+    }
+    if (lane == 0) {
+        const int kbc = lf_hkb_class(cn);
+        const uint32_t idx = atomicAdd(&A.ctl->q_n[A.out_par][kbc], 1u);
+        if (idx >= A.q_cap) { atomicExch(&A.ctl->fail, 4u); return; }
+        lf_hnode c;
+        c.qstart = P.qstart + dq * (int64_t)qo; c.tstart = P.tstart + dt * (int64_t)to; c.ops_off = off; c.n = cn; c.m = cm;
+        c.best = best; c.root = P.root; c.flags = P.flags; c.kind = 0; c.is_root = 0; c.pad = 0; c.pad2 = 0;
+        A.q_out[kbc][idx] = c;
+    }
+}
+
+template <int KB, bool PAC>
+__global__ void __launch_bounds__(128)
+lf_hirsch_level_kernel(lf_hargs A)
+{
+    __shared__ unsigned char s_ring[2][LF_H_TC], s_cring[2][LF_H_TC];
+    __shared__ uint64_t s_peq[2][(PAC && KB == 1) ? 256 : 1];
+    __shared__ unsigned long long s_base[2];
+    const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    if (blockIdx.x >= A.n_in) return;
+    const lf_hnode P = A.q_in[blockIdx.x];
+    const uint32_t n = P.n, m = P.m, nbk = (n + 63) >> 6;
+    const bool banded = nbk > 64u * KB;
+    const uint32_t lw = m / 2, rw = m - lw;
+    if (threadIdx.x == 0) {
+        s_base[0] = P.kind == 0 ? atomicAdd(&A.ctl->aux_used, 6ull * nbk) : 0ull;
+        s_base[1] = banded ? atomicAdd(&A.ctl->hcar_used, 2ull * m + 64) : 0ull;
+    }
+    __syncthreads();
+    const bool aux_ok = P.kind != 0 || s_base[0] + 6ull * nbk <= A.aux_cap, hc_ok = !banded || s_base[1] + 2ull * m + 64 <= A.hcar_cap;
+    if (!aux_ok || !hc_ok) { if (threadIdx.x == 0) { atomicExch(&A.ctl->fail, 5u); A.out_ed[A.roots[P.root].desc] = -2; } return; }
+    uint64_t *Fb = A.aux + s_base[0], *Rb = Fb + 3 * (size_t)nbk;
+    uint8_t *hc = A.hcar + s_base[1];
+    const int64_t dq = (P.flags & LF_F_QREV) ? -1 : 1, dt = (P.flags & LF_F_TREV) ? -1 : 1;
+    const uint32_t desc = A.roots[P.root].desc;
+
+    if (P.kind == 1) {
+        /* SHW root: distance and end column first (lib/edlib/edlib.cpp:141-168), then the path of q vs t[0 .. end] */
+        if (w != 0) return;
+        const lf_qacc Q(A.S.q, P.qstart, P.flags); const lf_tacc T(A.S.t, A.S.pac, P.tstart, P.flags | (PAC ? LF_F_TPAC : 0u));
+        int ed = 0, tl = 0;
+        (void)lf_hsweep<KB, PAC>(Q, T, n, m, true, s_ring[0], s_cring[0], s_peq[0], hc, hc + m + 32, nullptr, ed, tl);
+        if (lane == 0) { A.out_ed[desc] = ed; A.out_end[desc] = tl - 1; }
+        lf_hfinalize(A, P, 0, n, 0, (uint32_t)tl, ed, P.ops_off);
+        return;
+    }
+    {   /* the two half sweeps, one wavefront each */
+        int d0, d1;
+        if (w == 0) {
+            const lf_qacc Q(A.S.q, P.qstart, P.flags); const lf_tacc T(A.S.t, A.S.pac, P.tstart, P.flags | (PAC ? LF_F_TPAC : 0u));
+            if (lw) (void)lf_hsweep<KB, PAC>(Q, T, n, lw, false, s_ring[0], s_cring[0], s_peq[0], hc, hc + (lw + 16), Fb, d0, d1);
+        } else {
+            /* both strings backwards: element i = original element (len - 1 - i) */
+            const unsigned fl = P.flags ^ (LF_F_QREV | LF_F_TREV);
+            const lf_qacc Q(A.S.q, P.qstart + dq * (int64_t)(n - 1), fl); const lf_tacc T(A.S.t, A.S.pac, P.tstart + dt * (int64_t)(m - 1), fl | (PAC ? LF_F_TPAC : 0u));
+            (void)lf_hsweep<KB, PAC>(Q, T, n, rw, false, s_ring[1], s_cring[1], s_peq[1], hc + 2 * (lw + 16), hc + 2 * (lw + 16) + (rw + 16), Rb, d0, d1);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (w != 0) return;
+    /* F[x] = dist(q[0..x), t[0..lw)), R[x] = dist(last x of q, t[lw..m)) */
+    auto F = [&](uint32_t x) -> int { return lw ? lf_hcol(Fb, x, (int)lw) : (int)x; };
+    auto R = [&](uint32_t x) -> int { return lf_hcol(Rb, x, (int)rw); };
+    int best = P.best;
+    if (best < 0) {                          /* NW root: D[n][m] = min over rows r of F[r] + R[n - r] */
+        int mn = 0x7fffffff;
+        for (uint32_t base = 0; base <= n; base += 64) { const uint32_t r = base + (uint32_t)lane; if (r <= n) { const int v = F(r) + R(n - r); mn = v < mn ? v : mn; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(mn, o); mn = v < mn ? v : mn; }
+        best = mn;
+        if (lane == 0 && P.is_root) { A.out_ed[desc] = best; A.out_end[desc] = (int)m - 1; }
+    }
+    /* split row (lib/edlib/edlib.cpp:1263-1289): first qi in 0 .. n-2 with F[qi+1] + R[n-qi-1] == best, else -1, else n-1 */
+    int split = -2, ls = 0, rs = 0;
+    for (uint32_t base = 0; base + 2 <= n && split == -2; base += 64) {
+        const uint32_t qi = base + (uint32_t)lane;
+        const bool hit = qi + 2 <= n && F(qi + 1) + R(n - qi - 1) == best;
+        const uint64_t bm = __ballot(hit);
+        if (bm) split = (int)(base + (uint32_t)(__ffsll((long long)bm) - 1));
+    }
+    if (split >= 0) { ls = F((uint32_t)split + 1); rs = R(n - (uint32_t)split - 1); }
+    else if ((int)lw + R(n) == best) { split = -1; ls = (int)lw; rs = R(n); }
+    else if (F(n) + (int)rw == best) { split = (int)n - 1; ls = F(n); rs = (int)rw; }
+    else { if (lane == 0) { atomicExch(&A.ctl->fail, 1u); A.out_ed[desc] = -2; } return; }      /* cannot happen for a consistent distance */
+    const uint32_t ul = (uint32_t)(split + 1);
+    lf_hfinalize(A, P, 0, ul, 0, lw, ls, P.ops_off);
+    lf_hfinalize(A, P, ul, n - ul, lw, rw, rs, P.ops_off + ul + lw);
+}
+
+/* the problems above edlib's traceback switch become roots: a table entry + a node of level 0 */
+__global__ void lf_hirsch_roots_kernel(const lf_aln_desc_t *__restrict__ d, const uint64_t *__restrict__ ops_off, int n, lf_hargs A)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const lf_aln_desc_t x = d[i];
+    if (x.n == 0 || x.m == 0 || lf_leaf(x.n, x.m)) return;
+    const uint32_t r = atomicAdd(&A.ctl->n_roots, 1u), cap = lf_hroot_cap(x.n, x.m), so = atomicAdd(&A.ctl->seg_used, cap);
+    const int kbc = lf_hkb_class(x.n);
+    const uint32_t idx = atomicAdd(&A.ctl->q_n[A.out_par][kbc], 1u);
+    if (idx >= A.q_cap) { atomicExch(&A.ctl->fail, 4u); return; }
+    lf_hroot R; R.ops_off = ops_off[i]; R.desc = (uint32_t)i; R.n = x.n; R.m = x.m; R.seg_off = so; R.seg_cap = cap; R.count = 0;
+    A.roots[r] = R;
+    lf_hnode c;
+    c.qstart = x.qstart; c.tstart = x.tstart; c.ops_off = ops_off[i]; c.n = x.n; c.m = x.m; c.best = -1; c.root = r;
+    c.flags = x.flags; c.kind = x.mode ? 1 : 0; c.is_root = 1; c.pad = 0; c.pad2 = 0;
+    A.q_out[kbc][idx] = c;
+}
+
+/* after the leaves' tracebacks: a root's pieces, each end-aligned in its own part of the root's region, are moved together
+ * (last piece first, towards higher addresses) so that the root's path is end-aligned in one piece like any other problem's */
+__global__ void __launch_bounds__(64)
+lf_hirsch_stitch_kernel(lf_hargs A, uint32_t n_roots)
+{
+    const uint32_t r = blockIdx.x; const int lane = threadIdx.x;
+    if (r >= n_roots) return;
+    const lf_hroot R = A.roots[r];
+    const uint32_t c = R.count < R.seg_cap ? R.count : R.seg_cap;
+    const lf_hseg *seg = A.segs + R.seg_off;
+    const uint64_t end = R.ops_off + R.n + R.m;
+    uint64_t w = end, cur = ~0ull;
+    for (uint32_t it = 0; it < c; it++) {
+        /* the piece with the largest offset below `cur` (offsets are distinct: empty pieces are never registered) */
+        unsigned long long key = 0;
+        for (uint32_t k = (uint32_t)lane; k < c; k += 64) { const uint64_t o = seg[k].off; if (o < cur) { const unsigned long long kk = ((unsigned long long)(o - R.ops_off + 1) << 24) | k; key = kk > key ? kk : key; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(key, o); key = v > key ? v : key; }
+        if (key == 0) break;
+        const lf_hseg e = seg[key & 0xffffffu];
+        const uint32_t len = (e.len & 0x80000000u) ? A.out_len[A.n_desc + (e.len & 0x7fffffffu)] : e.len;
+        const uint64_t src = e.off + e.cap - len, dst = w - len;
+        if (src != dst) {
+            for (int64_t hi = (int64_t)len; hi > 0; hi -= 256) {
+                uint8_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int64_t i = hi - 1 - (u * 64 + lane); v[u] = i >= 0 ? A.ops[src + (uint64_t)i] : (uint8_t)0; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int64_t i = hi - 1 - (u * 64 + lane); if (i >= 0) A.ops[dst + (uint64_t)i] = v[u]; }
+            }
+        }
+        w -= len; cur = e.off;
+    }
+    if (lane == 0) A.out_len[R.desc] = (uint32_t)(end - w);
+}
+
+void lf_hirsch_launch_roots(hipStream_t s, bool pac_targets, const lf_aln_desc_t *d_desc, const uint64_t *d_opsoff, int n, lf_hargs A)
+{
+    (void)pac_targets;
+    hipLaunchKernelGGL(lf_hirsch_roots_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_desc, d_opsoff, n, A);
+}
+void lf_hirsch_launch_level(hipStream_t s, bool pac, int kbc, lf_hargs A)
+{
+    if (A.n_in == 0) return;
+    const dim3 g(A.n_in), b(128);
+#define LV(KBV) do { if (pac) hipLaunchKernelGGL((lf_hirsch_level_kernel<KBV, true>), g, b, 0, s, A); else hipLaunchKernelGGL((lf_hirsch_level_kernel<KBV, false>), g, b, 0, s, A); } while (0)
+    if (kbc == 0) LV(1); else if (kbc == 1) LV(4); else LV(8);
+#undef LV
+}
+void lf_hirsch_launch_stitch(hipStream_t s, lf_hargs A, uint32_t n_roots)
+{
+    if (n_roots) hipLaunchKernelGGL(lf_hirsch_stitch_kernel, dim3(n_roots), dim3(64), 0, s, A, n_roots);
+}

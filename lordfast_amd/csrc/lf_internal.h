@@ -73,13 +73,9 @@ int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, const Seed_t *
 int lfg_chain_clasp(int device, int n_windows, const Seed_t *seeds, const uint64_t *off,
                     Seed_t *chain_out, uint32_t *chain_len, float *score, float *ms);
 
-/* edlib problems: sequences given as byte strings (host memory) */
+/* edlib problems: sequences given as byte strings (host memory); ops end-aligned in [qoff[i] + toff[i], + n_i + m_i) */
 int lfg_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
-              const uint8_t *mode, const uint8_t *task, int32_t *ed, int32_t *endloc,
-              uint8_t *ops, uint32_t *ops_len, float *ms);
-/* last DP column: out[cs_off[i] + r] = dist(q[0..r), t) for r = 0..n_i ; rev[i] walks both strings backwards */
-int lfg_colscores(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
-                  const uint8_t *rev, int32_t *out, const uint64_t *cs_off, float *ms);
+              const uint8_t *mode, int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, float *ms);
 int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff, const uint8_t *t, const uint64_t *toff,
             const int32_t *prm, int32_t *score, int32_t *qle, int32_t *tle, float *ms);
 
@@ -98,7 +94,7 @@ void *lfg_lane_event(int device, int which);    /* persistent hipEvent_t (timing
 /* slot ids */
 enum { LF_DS_SEED0 = 0 /* ..15 */, LF_DS_CHAIN0 = 16 /* ..23 */, LF_DS_ALN0 = 24 /* ..47 */, LF_DS_KSW0 = 48 /* ..55 */,
        LF_DS_RND0 = 56 /* ..87: 2 per extension round (ops, spare) */, LF_DS_RENDER0 = 88 /* ..95 */, LF_DS_VOTE0 = 96 /* ..127 */,
-       LF_DS_WALK0 = 128 /* ..147 */, LF_DS_SAM0 = 148 /* ..157 */ };
+       LF_DS_WALK0 = 128 /* ..147 */, LF_DS_SAM0 = 148 /* ..157 */, LF_DS_HIRSCH0 = 158 /* ..167 */ };
 #define LF_MAX_ED_ROUNDS 16
 enum { LF_PS_READS = 0, LF_PS_READOFF = 1, LF_PS_HITS_T = 2, LF_PS_HITS_Q = 3, LF_PS_HITS_S = 4, LF_PS_HITS_OFF = 5,
        LF_PS_CHAIN_SEEDS = 6, LF_PS_CHAIN_IDX = 7, LF_PS_ALN_Q = 8, LF_PS_ALN_T = 9, LF_PS_ALN_PROB = 10 /* ..16 */,
@@ -112,6 +108,10 @@ typedef struct { int64_t qstart, tstart; uint32_t n, m; uint8_t flags, mode, pad
 int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_desc_t *d, const uint64_t *ops_off, uint64_t ops_total,
                    int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, int ops_slot, void **ops_dev, void **desc_dev, float *ms);
 
+/* the problems of a descriptor batch that lie above edlib's traceback switch (roots of the Hirschberg levels, lf_hirsch.hip):
+ * their number, the sum of their piece bounds (lf_hroot_cap) and of their query / target lengths -- counted by whoever makes
+ * the descriptors, so that the scratch of the levels can be sized without a round trip */
+typedef struct { uint64_t roots, cap, sum_n, sum_m; } lf_hcount_t;
 typedef struct { const void *d_text, *d_offs, *d_lens; } lfg_rtext_t;       /* rendered text on the device: offsets / lengths (incl. NUL) 2 per record */
 /* ---- lf_render.hip: CIGAR / MD text from the paths in HBM ---- */
 enum { LF_RI_RUN_M = 0, LF_RI_RUN_I = 1, LF_RI_OPS_FWD = 2, LF_RI_OPS_FWD_TRC = 3, LF_RI_OPS_REV = 4, LF_RI_DEL = 5 };
@@ -133,13 +133,13 @@ int lfg_render(const struct lf_index *ix, int n_dev_recs, const void *d_recs_dev
 typedef struct { uint32_t req, read, chain_len; uint8_t is_rev, pad[3]; } lf_wjob_t;      /* one kept candidate window: chain request, read (index in the seed batch) */
 typedef struct { uint32_t pos, posEnd, qStart, qEnd; int32_t nm; uint32_t rare, pad[2]; } lf_wrec_t;   /* SAM record fields of a job; rare: replay it on the host */
 typedef struct {
-    int n_jobs; uint64_t n_desc, ops_total, n_items, ext_bytes, block_steps;
+    int n_jobs; uint64_t n_desc, ops_total, n_items, ext_bytes, block_steps; lf_hcount_t hc;
     void *d_jobs, *d_rare, *d_sbase, *d_ibase, *d_desc, *d_opsoff, *d_slot_desc, *d_recs, *d_items;
 } lfg_walk_t;
 int lfg_walk_plan(const struct lf_index *ix, int n_jobs, const lf_wjob_t *jobs, const lfg_vc_t *vc, int lazy, lfg_walk_t *W);
 int lfg_walk_emit(const struct lf_index *ix, const lfg_vc_t *vc, int lazy, lfg_walk_t *W, const void *d_ed, const void *d_end, const void *d_len, lf_wrec_t **wrec_out);
 /* alignments of device-resident descriptors (lfg_walk_plan); results stay on the device */
-int lfg_edlib_desc_dev(const struct lf_index *ix, int n, const void *d_desc, const void *d_opsoff, uint64_t ops_total, int ops_slot,
+int lfg_edlib_desc_dev(const struct lf_index *ix, int n, const void *d_desc, const void *d_opsoff, uint64_t ops_total, const lf_hcount_t *hc, int ops_slot,
                        void **ops_dev, void **ed_dev, void **end_dev, void **len_dev, float *ms);
 /* ---- lf_sam.hip: SAM lines assembled on the device ---- */
 enum { LF_SL_MAPPED = 0, LF_SL_UNMAPPED = 1, LF_SL_LITERAL = 2 };
@@ -173,11 +173,23 @@ int lfg_upload(int device, void *dst_dev, const void *src, size_t bytes);
 #define LF_TASK_PATH 0
 #define LF_TASK_DIST 1
 
-/* longest query the sweep kernels of lf_align.hip take (64 lanes x 8 blocks x 64 rows); they run edlib's Hirschberg
- * recursion on the device.  Longer queries use the generic kernel and the host-driven splits of lf_stages.c. */
+/* longest query the sweep kernels of lf_align.hip take (64 lanes x 8 blocks x 64 rows).  Problems above edlib's traceback
+ * switch never reach them whole: the Hirschberg levels (lf_hirsch.hip, any query length) cut them into leaves first. */
 #define LF_SWEEP_MAX_N 32768
 /* edlib's own leaf/Hirschberg switch (lib/edlib/edlib.cpp:1117-1119) */
-static inline int lf_is_leaf(int64_t n, int64_t m) { return 20LL * ((n + 63) / 64) * m + 8LL * m < 1024 * 1024; }
+#ifdef __HIPCC__
+#define LF_HD __host__ __device__
+#else
+#define LF_HD
+#endif
+static inline LF_HD int lf_is_leaf(int64_t n, int64_t m) { return 20LL * ((n + 63) / 64) * m + 8LL * m < 1024 * 1024; }
+/* upper bound of the pieces (leaves of edlib's recursion tree) of a problem above the switch: internal nodes only exist while
+ * 20 ceil(n / 64) m + 8 m >= 2^20, and m halves per level */
+static inline LF_HD uint32_t lf_hroot_cap(uint32_t n, uint32_t m)
+{
+    const uint64_t x = ((uint64_t)m * (20ull * ((n + 63) >> 6) + 8) + (1u << 20) - 1) >> 20;
+    return (uint32_t)(2 * x + 4);
+}
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@
 
 namespace {
 struct slot_t { void *p = nullptr; size_t cap = 0; };
-constexpr int MAX_DEV = 16, LANE_STRIDE = 160, MAX_LANE = 64, MAX_SLOT = MAX_LANE * LANE_STRIDE;
+constexpr int MAX_DEV = 16, LANE_STRIDE = 176, MAX_LANE = 64, MAX_SLOT = MAX_LANE * LANE_STRIDE;
 thread_local int t_lane = 0;
 hipStream_t g_streams[MAX_DEV][MAX_LANE][16];
 hipEvent_t g_events[MAX_DEV][MAX_LANE][48];
@@ -67,10 +67,31 @@ extern "C" void lfg_drain_check(int device)
         struct timespec ts = { 0, 20 * 1000000 }; nanosleep(&ts, nullptr);
     }
 }
+/* At process exit the HIP runtime tears its streams down by itself; with the ~10^2 streams of the lanes still alive that
+ * teardown has been seen to stall for tens of seconds or for good (ROCm 7.2).  Registered once, when the first lane stream
+ * is created -- i.e. after the runtime's own handlers, so it runs BEFORE them: every lane stream is drained and destroyed,
+ * events are destroyed, slots released, while the runtime is still whole. */
+static void lf_exit_cleanup(void)
+{
+    std::lock_guard<std::mutex> g(g_mu);
+    for (int d = 0; d < MAX_DEV; d++) {
+        bool any = false;
+        for (int l = 0; l < MAX_LANE && !any; l++) for (int k = 0; k < 16; k++) if (g_streams[d][l][k]) { any = true; break; }
+        if (!any) continue;
+        if (hipSetDevice(d) != hipSuccess) continue;
+        quiesce_locked(d);
+        for (int l = 0; l < MAX_LANE; l++) {
+            for (int k = 0; k < 48; k++) if (g_events[d][l][k]) { (void)hipEventDestroy(g_events[d][l][k]); g_events[d][l][k] = nullptr; }
+            for (int k = 0; k < 16; k++) if (g_streams[d][l][k]) { (void)hipStreamDestroy(g_streams[d][l][k]); g_streams[d][l][k] = nullptr; }
+        }
+    }
+}
 extern "C" void *lfg_lane_stream(int device, int which)
 {
     if (device < 0 || device >= MAX_DEV || which < 0 || which >= 16) return nullptr;
     std::lock_guard<std::mutex> g(g_mu);
+    static bool registered = false;
+    if (!registered) { registered = true; atexit(lf_exit_cleanup); }
     hipStream_t &st = g_streams[device][t_lane][which];
     if (!st) { if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&st) != hipSuccess) { lf_set_error("hipStreamCreate failed"); return nullptr; } }
     return (void *)st;
@@ -124,4 +145,26 @@ extern "C" void lfg_slots_release(void)
     for (int d = 0; d < MAX_DEV; d++) quiesce_locked(d);
     for (int d = 0; d < MAX_DEV; d++) for (int k = 0; k < MAX_SLOT; k++) if (g_dev[d][k].p) { (void)hipSetDevice(d); (void)hipFree(g_dev[d][k].p); g_dev[d][k] = slot_t(); }
     for (int k = 0; k < MAX_SLOT; k++) if (g_pin[k].p) { (void)hipHostFree(g_pin[k].p); g_pin[k] = slot_t(); }
+}
+
+/* ---- device memory for callers of the device-resident entry points (lf_map_batch_dev) that do not link HIP themselves.
+ * Plain allocations outside the slot system: the caller owns them. ---- */
+extern "C" void *lf_device_alloc(int device, size_t bytes)
+{
+    void *p = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { lf_set_error("lf_device_alloc: hipMalloc of %zu bytes on device %d failed", bytes, device); return nullptr; }
+    return p;
+}
+extern "C" void lf_device_free(int device, void *p)
+{
+    if (!p || hipSetDevice(device) != hipSuccess) return;
+    lfg_quiesce(device);              /* hipFree synchronises the device by itself: per-stream waits first (see lfg_quiesce) */
+    (void)hipFree(p);
+}
+/* dst / src: host or device memory of `device` (the runtime tells them apart); synchronous */
+extern "C" int lf_device_copy(int device, void *dst, const void *src, size_t bytes)
+{
+    HIPCHK(hipSetDevice(device));
+    if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
+    return LF_OK;
 }

@@ -32,9 +32,6 @@
 #include "lf_internal.h"
 #include "lf_stdsort.h"
 
-int lf_edlib_solve(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
-                   const uint8_t *mode, int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len,
-                   float *kernel_ms, uint64_t *n_launch_rounds);
 void lf_sort_seeds_by_qpos(Seed_t *s, long n);
 
 /* src/LordFAST.cpp:88-92 */
@@ -727,28 +724,6 @@ static uint8_t code_of(char c)
     switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
 }
 
-static void stage_edlib(walk_t *w, memo_t *m)
-{
-    stage_t *s = &w->cx->stages[w->tid];
-    const rkey_t *k = &m->key;
-    if (s->n == s->cap) {
-        s->cap = s->cap ? s->cap * 2 : 1024;
-        s->qoff = (uint64_t *)realloc(s->qoff, ((size_t)s->cap + 1) * 8); s->toff = (uint64_t *)realloc(s->toff, ((size_t)s->cap + 1) * 8);
-        s->mode = (uint8_t *)realloc(s->mode, (size_t)s->cap); s->owner = (memo_t **)realloc(s->owner, (size_t)s->cap * sizeof(memo_t *));
-        if (s->n == 0) { s->qoff[0] = 0; s->toff[0] = 0; }
-    }
-    if (s->qn + k->qn + 1 > s->qcap) { s->qcap = (s->qn + k->qn + 1) * 2; s->qb = (char *)realloc(s->qb, s->qcap); }
-    if (s->tn + k->tn + 1 > s->tcap) { s->tcap = (s->tn + k->tn + 1) * 2; s->tb = (char *)realloc(s->tb, s->tcap); }
-    put_query(w, k, s->qb + s->qn); put_target(w, k, s->tb + s->tn);
-    s->qn += k->qn; s->tn += k->tn;
-    s->qoff[s->n + 1] = s->qn; s->toff[s->n + 1] = s->tn; s->mode[s->n] = k->mode;
-    /* the memo array may be reallocated later: remember (job, index) through a stable pointer instead */
-    s->owner[s->n] = (memo_t *)(uintptr_t)(((uint64_t)(uintptr_t)(m - w->job->memo)));
-    s->n++;
-    s->ext_bytes += (uint64_t)k->qn + (k->tn + 3) / 4 + k->qn + k->tn;      /* SURVEY 8(d) B_ext */
-    s->blk_steps += (uint64_t)((k->qn + 63) / 64) * k->tn;
-}
-
 /* job owner bookkeeping: parallel arrays */
 typedef struct jobvec { job_t **job; int n, cap; } jobvec_t;
 static void jv_push(jobvec_t *v, job_t *j) { if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 1024; v->job = (job_t **)realloc(v->job, (size_t)v->cap * sizeof(job_t *)); } v->job[v->n++] = j; }
@@ -785,7 +760,7 @@ static void stage_ksw(walk_t *w, memo_t *m)
     s->kn++;
 }
 
-/* leaf-size request -> descriptor (no bytes are copied: the GPU reads the resident read batch and the 2-bit reference) */
+/* request -> descriptor (no bytes are copied: the GPU reads the resident read batch and the 2-bit reference) */
 static void stage_edlib_desc(walk_t *w, memo_t *m)
 {
     stage_t *s = &w->cx->stages[w->tid];
@@ -828,10 +803,9 @@ static edres_t need_edlib(walk_t *w, int qrc, uint32_t qs, uint32_t qseg, uint32
     memo_t *m = memo_find(w->job, &k);
     if (!m) {
         m = memo_add(w->job, &k, &w->cx->arena[w->tid]);
-        /* every request is a descriptor (Hirschberg-size ones included: the sweep kernels recurse on the device);
-         * only queries beyond LF_SWEEP_MAX_N fall back to byte strings and the host-driven splits */
-        if (qn > 0 && tn > 0 && qn <= LF_SWEEP_MAX_N) { stage_edlib_desc(w, m); jv_push(&w->cx->edd_jobs[w->tid], w->job); }
-        else { stage_edlib(w, m); jv_push(&w->cx->ed_jobs[w->tid], w->job); }
+        /* every request is a descriptor: problems above edlib's traceback switch are cut into leaves by the Hirschberg levels
+         * on the device (lf_hirsch.hip, any query length), an empty side is a pure run written by the binning kernel */
+        stage_edlib_desc(w, m); jv_push(&w->cx->edd_jobs[w->tid], w->job);
     }
     if (m->round < 0) { w->missing++; w->build = 0; r.ed = 0; r.end = (mode == 0) ? (int)tn - 1 : (int)tn - 1; return r; }
     const ed_round_t *R = &w->cx->ed_rounds[m->round];
@@ -1600,23 +1574,6 @@ static void phase_bind_text(ctx_t *cx, int tid, int ri)
         }
 }
 
-static void phase_merge_edlib(ctx_t *cx, int tid, int t)
-{
-    (void)tid;
-    stage_t *s = &cx->stages[t];
-    const uint64_t qo = cx->mg_qbase[t], to = cx->mg_tbase[t];
-    if (s->qn) memcpy(cx->mg_qb + qo, s->qb, s->qn);
-    if (s->tn) memcpy(cx->mg_tb + to, s->tb, s->tn);
-    int g = cx->mg_gbase[t];
-    for (int k = 0; k < s->n; k++, g++) {
-        cx->mg_qoff[g] = qo + s->qoff[k]; cx->mg_toff[g] = to + s->toff[k]; cx->mg_mode[g] = s->mode[k];
-        cx->mg_R->ops_off[g] = cx->mg_qoff[g] + cx->mg_toff[g];
-        memo_t *m = &cx->ed_jobs[t].job[k]->memo[(uintptr_t)s->owner[k]];
-        m->round = cx->mg_round; m->slot = g;
-    }
-    s->n = 0; s->qn = 0; s->tn = 0; s->ext_bytes = 0; cx->ed_jobs[t].n = 0;
-}
-
 static void phase_strlen(ctx_t *cx, int tid, int i) { (void)tid; cx->len_out[i] = (uint32_t)strlen(cx->len_seqs[i]); }
 static void phase_checklen(ctx_t *cx, int tid, int i)
 {
@@ -1658,25 +1615,6 @@ static void phase_sam_print(ctx_t *cx, int tid, int ri)
     if (cx->out_base) { r->out.s = cx->out_base + cx->out_off[ri]; r->out.cap = r->out.n; r->out.n = 0; r->out.mode = 2; }
     else { r->out.s = NULL; r->out.cap = 0; r->out.n = 0; r->out.mode = 1; }
     print_sam_entry(cx, r, r->mode < 2 ? 1 : (r->mode == 2 ? 1 : r->nWins));
-}
-
-/* Hirschberg-size problems of one round, solved by lf_edlib_solve on the calling thread or on a helper thread */
-typedef struct {
-    int device, lane, n; const char *q, *t; const uint64_t *qoff, *toff; const uint8_t *mode;
-    int32_t *ed, *end; uint8_t *ops; uint32_t *ops_len;
-    int rc; float ms; uint64_t launches; char err[512];
-} hsolve_t;
-static void *hsolve_main(void *arg)
-{
-    hsolve_t *H = (hsolve_t *)arg;
-    const int prev = lfg_get_lane();
-    lfg_set_lane(H->lane);
-    const long long c0 = g_phase_on ? thread_cpu_ns() : 0;
-    H->rc = lf_edlib_solve(H->device, H->n, H->q, H->qoff, H->t, H->toff, H->mode, H->ed, H->end, H->ops, H->ops_len, &H->ms, &H->launches);
-    if (g_phase_on) phase_account("(hirschberg solve thread)", (thread_cpu_ns() - c0) / 1e6, 0);
-    if (H->rc != LF_OK) snprintf(H->err, sizeof H->err, "%s", lf_last_error());
-    lfg_set_lane(prev);
-    return NULL;
 }
 
 static const char *volatile g_lane_mark[LF_MAX_LANES];        /* LF_WATCHDOG: the last stage mark of every lane */
@@ -1851,7 +1789,7 @@ extend:
             tmark(cx, "WALKPLAN");
             if (rc != LF_OK) { free(owner); return rc; }
             void *dops = NULL, *d_ed = NULL, *d_end = NULL, *d_len = NULL; float ms = 0;
-            if (W.n_desc) rc = lfg_edlib_desc_dev(cx->ix, (int)W.n_desc, W.d_desc, W.d_opsoff, W.ops_total, LF_DS_RND0 + 0, &dops, &d_ed, &d_end, &d_len, &ms);
+            if (W.n_desc) rc = lfg_edlib_desc_dev(cx->ix, (int)W.n_desc, W.d_desc, W.d_opsoff, W.ops_total, &W.hc, LF_DS_RND0 + 0, &dops, &d_ed, &d_end, &d_len, &ms);
             tmark(cx, "EDLIB0");
             if (rc != LF_OK) { free(owner); return rc; }
             lf_wrec_t *wrec = NULL;
@@ -1889,52 +1827,9 @@ extend:
         parallel_for(cx, n, phase_walk);
         tmark(cx, "walk");
         if (timing) fprintf(stderr, "[lf] round %d walk %.1f ms\n", round, now_ms() - tw0);
-        int ne = 0, nk = 0, nd = 0;
-        for (int t = 0; t < nt; t++) { ne += cx->stages[t].n; nk += cx->stages[t].kn; nd += cx->stages[t].dn; }
-        if (ne == 0 && nk == 0 && nd == 0) break;
-        /* the few problems above edlib's leaf size go through the host-orchestrated Hirschberg splits; they are
-         * independent of this round's descriptor problems, so a helper thread (own slots and streams: lane + 4)
-         * drives them while this thread runs the descriptor round */
-        hsolve_t HS; memset(&HS, 0, sizeof HS);
-        pthread_t hs_thread; int hs_spawned = 0;
-        uint64_t *hs_qoff = NULL, *hs_toff = NULL; uint8_t *hs_mode = NULL;
-        double ts0 = 0;
-        if (ne) {
-            uint64_t qn = 0, tn = 0;
-            uint64_t *qbase = (uint64_t *)malloc((size_t)nt * 8), *tbase = (uint64_t *)malloc((size_t)nt * 8); int *gbase = (int *)malloc((size_t)nt * sizeof(int));
-            { int g0 = 0; for (int t = 0; t < nt; t++) { qbase[t] = qn; tbase[t] = tn; gbase[t] = g0; qn += cx->stages[t].qn; tn += cx->stages[t].tn; g0 += cx->stages[t].n; st->ext_bytes += cx->stages[t].ext_bytes; cx->stages[t].ext_bytes = 0; st->dp_block_steps += cx->stages[t].blk_steps; cx->stages[t].blk_steps = 0; } }
-            const int ridx = cx->n_ed_rounds;
-            const int pin = ridx < 16;                       /* persistent pinned slots for the first rounds */
-            char *qb = (char *)lfg_pin_slot(LF_PS_ALN_Q, qn + 1), *tb = (char *)lfg_pin_slot(LF_PS_ALN_T, tn + 1);
-            uint64_t *qoff = (uint64_t *)malloc(((size_t)ne + 1) * 8), *toff = (uint64_t *)malloc(((size_t)ne + 1) * 8);
-            uint8_t *mode = (uint8_t *)malloc((size_t)ne);
-            ed_round_t R; memset(&R, 0, sizeof R);
-            R.n = ne; R.pinned = pin; R.ops_bytes = qn + tn;
-            if (pin) {
-                R.ed = (int32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx, (size_t)ne * 4); R.end = (int32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 1, (size_t)ne * 4);
-                R.ops_len = (uint32_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 2, (size_t)ne * 4); R.ops = (uint8_t *)lfg_pin_slot(LF_PS_ROUND0 + 4 * ridx + 3, qn + tn + 1);
-            } else {
-                R.ed = (int32_t *)malloc((size_t)ne * 4); R.end = (int32_t *)malloc((size_t)ne * 4);
-                R.ops_len = (uint32_t *)malloc((size_t)ne * 4); R.ops = (uint8_t *)malloc(qn + tn + 1);
-            }
-            R.ops_off = (uint64_t *)malloc((size_t)ne * 8);
-            if (!qb || !tb || !R.ed || !R.end || !R.ops_len || !R.ops) return LF_ERR_NOMEM;
-            cx->mg_qb = qb; cx->mg_tb = tb; cx->mg_qoff = qoff; cx->mg_toff = toff; cx->mg_mode = mode; cx->mg_R = &R;
-            cx->mg_qbase = qbase; cx->mg_tbase = tbase; cx->mg_gbase = gbase; cx->mg_round = ridx;
-            double tm0 = now_ms();
-            parallel_for(cx, nt, phase_merge_edlib);         /* every worker copies its own staged requests */
-            if (timing) fprintf(stderr, "[lf] round %d merge %.1f ms (%d problems, %.1f MB)\n", round, now_ms() - tm0, ne, (qn + tn) / 1e6);
-            qoff[ne] = qn; toff[ne] = tn;
-            free(qbase); free(tbase); free(gbase);
-            cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
-            cx->ed_rounds[cx->n_ed_rounds++] = R;            /* the result arrays are filled by the solver below */
-            HS.device = cx->ix->device; HS.lane = cx->lane + LF_MAX_LANES; HS.n = ne; HS.q = qb; HS.qoff = qoff; HS.t = tb; HS.toff = toff; HS.mode = mode;
-            HS.ed = R.ed; HS.end = R.end; HS.ops = R.ops; HS.ops_len = R.ops_len;
-            hs_qoff = qoff; hs_toff = toff; hs_mode = mode;
-            ts0 = now_ms();
-            if (nd && !getenv("LF_NO_HELPER")) hs_spawned = pthread_create(&hs_thread, NULL, hsolve_main, &HS) == 0;
-            if (!hs_spawned) { HS.lane = cx->lane; hsolve_main(&HS); tmark(cx, "HIRSCH"); }
-        }
+        int nk = 0, nd = 0;
+        for (int t = 0; t < nt; t++) { nk += cx->stages[t].kn; nd += cx->stages[t].dn; }
+        if (nk == 0 && nd == 0) break;
         if (nd) {
             /* descriptor requests: nothing but 32-byte descriptors goes to the GPU */
             uint64_t *obase = (uint64_t *)malloc((size_t)nt * 8); int *gbase = (int *)malloc((size_t)nt * sizeof(int));
@@ -1956,7 +1851,7 @@ extend:
             }
             R.ops_off = (uint64_t *)malloc((size_t)nd * 8);
             lf_aln_desc_t *desc = (lf_aln_desc_t *)lfg_pin_slot(LF_PS_ALN_PROB, (size_t)nd * sizeof(lf_aln_desc_t));
-            if (!desc || !R.ed || !R.end || !R.ops_len || (host_ops && !R.ops)) { if (hs_spawned) pthread_join(hs_thread, NULL); return LF_ERR_NOMEM; }
+            if (!desc || !R.ed || !R.end || !R.ops_len || (host_ops && !R.ops)) return LF_ERR_NOMEM;
             cx->mg_desc = desc; cx->mg_R = &R; cx->mg_qbase = obase; cx->mg_gbase = gbase; cx->mg_round = ridx;
             double tm0 = now_ms();
             parallel_for(cx, nt, phase_merge_desc);
@@ -1972,15 +1867,8 @@ extend:
             if (timing) fprintf(stderr, "[lf] round %d: %d descriptor problems, merge+solve %.1f ms (kernels %.1f ms), ops %.1f MB\n", round, nd, now_ms() - tm0, ms, ops_total / 1e6);
             cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
             cx->ed_rounds[cx->n_ed_rounds++] = R;
-            if (rc != LF_OK) { if (hs_spawned) pthread_join(hs_thread, NULL); return rc; }
+            if (rc != LF_OK) return rc;
             st->ms_k_edlib += ms; st->n_edlib_problems += (uint64_t)nd; st->edlib_launches += 1; st->ops_bytes += ops_total;
-        }
-        if (ne) {
-            if (hs_spawned) { pthread_join(hs_thread, NULL); tmark(cx, "hirsch-join"); }
-            if (timing) fprintf(stderr, "[lf] round %d edlib solve %.1f ms (kernels %.1f ms)%s\n", round, now_ms() - ts0, HS.ms, hs_spawned ? " [helper thread]" : "");
-            free(hs_qoff); free(hs_toff); free(hs_mode);
-            if (HS.rc != LF_OK) { lf_set_error("%s", HS.err); return HS.rc; }
-            st->ms_k_edlib += HS.ms; st->n_edlib_problems += (uint64_t)ne; st->edlib_launches += HS.launches;
         }
         if (nk) {
             uint64_t qn = 0, tn = 0;

@@ -100,7 +100,7 @@ lf_walk_plan_kernel(int n_jobs, const lf_wjob_t *__restrict__ jobs, lf_walk_dev 
                     uint32_t *__restrict__ job_ndesc, uint64_t *__restrict__ job_opsbytes, uint8_t *__restrict__ job_rare,
                     const uint64_t *__restrict__ desc_base, const uint64_t *__restrict__ ops_base, const uint64_t *__restrict__ slot_base,
                     lf_aln_desc_t *__restrict__ desc, uint64_t *__restrict__ ops_off, int32_t *__restrict__ slot_desc,
-                    unsigned long long *__restrict__ totals /* ext_bytes, block_steps */)
+                    unsigned long long *__restrict__ totals /* ext_bytes, block_steps, then lf_hcount_t: roots, cap, sum_n, sum_m */)
 {
     const int j = blockIdx.x, lane = threadIdx.x;
     if (j >= n_jobs) return;
@@ -114,13 +114,12 @@ lf_walk_plan_kernel(int n_jobs, const lf_wjob_t *__restrict__ jobs, lf_walk_dev 
     lf_chr_bounds(D, s[0].x, s[chainLen - 1].x, &chrBeg, &chrEnd);           /* :1799 */
     const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     uint32_t nd = 0; uint64_t ob = 0; bool rare = false;
-    unsigned long long ext = 0, blk = 0;
+    unsigned long long ext = 0, blk = 0, hr = 0, hcap = 0, hn = 0, hm = 0;      /* h*: pieces above edlib's traceback switch (roots of the Hirschberg levels) */
     const uint64_t dbase = WRITE ? desc_base[j] : 0, obase = WRITE ? ops_base[j] : 0, sbase = WRITE ? slot_base[j] : 0;
     for (uint32_t base = 0; base <= chainLen; base += 64) {
         const uint32_t k = base + lane;
         lf_piece P; P.kind = 0; P.qn = P.tn = 0;
         if (k <= chainLen) P = lf_piece_of(s, chainLen, k, L, chrBeg, chrEnd);
-        if (P.kind == 1 && P.qn > LF_SWEEP_MAX_N) P.kind = -1;               /* longer than the sweep kernels take */
         const bool aln = P.kind == 1;
         const uint64_t am = __ballot(aln);
         rare |= __any(P.kind < 0) != 0;
@@ -149,15 +148,18 @@ lf_walk_plan_kernel(int n_jobs, const lf_wjob_t *__restrict__ jobs, lf_walk_dev 
                 ops_off[di] = obase + ob + (incl - bytes);
             }
         }
-        if (aln) { ext += (uint64_t)P.qn + (P.tn + 3) / 4 + P.qn + P.tn; blk += (uint64_t)((P.qn + 63) / 64) * P.tn; }
+        if (aln) {
+            ext += (uint64_t)P.qn + (P.tn + 3) / 4 + P.qn + P.tn; blk += (uint64_t)((P.qn + 63) / 64) * P.tn;
+            if (P.qn && P.tn && !lf_is_leaf(P.qn, P.tn)) { hr++; hcap += lf_hroot_cap(P.qn, P.tn); hn += P.qn; hm += P.tn; }
+        }
         nd += (uint32_t)__popcll(am); ob += tile_bytes;
     }
     if (!WRITE) {
         if (lane == 0) { job_ndesc[j] = rare ? 0 : nd; job_opsbytes[j] = rare ? 0 : ob; job_rare[j] = rare ? 1 : 0; }
     } else {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { ext += __shfl_xor(ext, o); blk += __shfl_xor(blk, o); }
-        if (lane == 0) { atomicAdd(&totals[0], ext); atomicAdd(&totals[1], blk); }
+        for (int o = 32; o > 0; o >>= 1) { ext += __shfl_xor(ext, o); blk += __shfl_xor(blk, o); hr += __shfl_xor(hr, o); hcap += __shfl_xor(hcap, o); hn += __shfl_xor(hn, o); hm += __shfl_xor(hm, o); }
+        if (lane == 0) { atomicAdd(&totals[0], ext); atomicAdd(&totals[1], blk); if (hr) { atomicAdd(&totals[2], hr); atomicAdd(&totals[3], hcap); atomicAdd(&totals[4], hn); atomicAdd(&totals[5], hm); } }
     }
 }
 
@@ -293,10 +295,11 @@ extern "C" int lfg_walk_plan(const struct lf_index *ix, int n_jobs, const lf_wjo
     if (!d_desc || !d_opsoff || !d_slot_desc) return LF_ERR_NOMEM;
     hipLaunchKernelGGL(lf_walk_plan_kernel<true>, dim3((unsigned)n_jobs), dim3(64), 0, s, n_jobs, (const lf_wjob_t *)d_jobs, D, lazy, d_nd, d_ob, d_rare,
                        (const uint64_t *)d_dbase, (const uint64_t *)d_obase, (const uint64_t *)d_sbase, d_desc, d_opsoff, d_slot_desc, d_tot);
-    HIPCHK(hipMemcpyAsync(h + 4, d_tot, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h + 4, d_tot, 48, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     W->n_jobs = n_jobs; W->n_desc = n_desc; W->ops_total = ops_total; W->n_items = n_items; W->ext_bytes = h[4]; W->block_steps = h[5];
+    W->hc.roots = h[6]; W->hc.cap = h[7]; W->hc.sum_n = h[8]; W->hc.sum_m = h[9];
     W->d_jobs = d_jobs; W->d_rare = d_rare; W->d_sbase = d_sbase; W->d_ibase = d_ibase; W->d_desc = d_desc; W->d_opsoff = d_opsoff; W->d_slot_desc = d_slot_desc;
     return LF_OK;
 }

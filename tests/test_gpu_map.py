@@ -356,14 +356,16 @@ def test_sam_host_assembly_crosscheck(lf, golden_reads, monkeypatch, cfg):
         assert b"\tRG:Z:grpX" in d
 
 
-def _pack_to_device(torch, names, seqs, quals=None):
-    """the caller's side of lf_map_batch_dev: bases (and qualities) as ONE blob in HBM + host offsets / lengths"""
+def _pack_to_device(names, seqs, quals=None):
+    """the caller's side of lf_map_batch_dev: bases (and qualities) as ONE blob in HBM + host offsets / lengths.  (No torch in
+    this process: torch ships its own HIP runtime, and a process that initialises it before liblfgpu.so runs the library on
+    THAT runtime -- bench.py does so on purpose, the parity tests stay on the system one.)"""
     import lordfast_amd as la
     blob = b"\0".join(seqs) + b"\0"
     off = np.concatenate([[0], np.cumsum([len(s) + 1 for s in seqs])])[:-1].astype(np.uint64)
     lens = np.array([len(s) for s in seqs], dtype=np.uint32)
-    d_seqs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
-    d_quals = torch.frombuffer(bytearray(b"\0".join(quals) + b"\0"), dtype=torch.uint8).cuda() if quals is not None else None
+    d_seqs = la.api.DeviceBuffer(len(blob), data=blob)
+    d_quals = la.api.DeviceBuffer(len(blob), data=b"\0".join(quals) + b"\0") if quals is not None else None
     return la.api._cstr_array(names), d_seqs, off, lens, d_quals
 
 
@@ -371,35 +373,33 @@ def _pack_to_device(torch, names, seqs, quals=None):
 def test_map_batch_dev_resident_io(lf, golden_reads, cfg, monkeypatch):
     """lf_map_batch_dev: bases already in HBM, SAM text left in HBM -- the records the reference prints, also when the batch is
     cut into many chunks on several lanes (asynchronous device-to-device copies into the caller's buffer)"""
-    import torch
     import lordfast_amd as la
     names, seqs = golden_reads
     exp = golden_sam(cfg)
-    na, d_seqs, off, lens, _ = _pack_to_device(torch, names, seqs)
-    out = torch.zeros(len(exp) + 4096, dtype=torch.uint8, device="cuda")
+    na, d_seqs, off, lens, _ = _pack_to_device(names, seqs)
+    out = la.api.DeviceBuffer(len(exp) + 4096)
     p = la.default_params(**GOLDEN_CONFIGS[cfg])
-    ln, st = lf.map_batch_dev(na, d_seqs.data_ptr(), off, lens, out.data_ptr(), out.numel(), True, params=p)
-    got = bytes(out[:ln].cpu().numpy().tobytes())
+    ln, st = lf.map_batch_dev(na, d_seqs.ptr, off, lens, out.ptr, out.nbytes, True, params=p)
+    got = out.download(ln)
     assert got == exp, first_diff(got, exp)
     assert st["n_reads"] == len(seqs)
-    # host destination (pinned or not) from device-resident bases
+    # host destination from device-resident bases
     hbuf = np.zeros(len(exp) + 4096, dtype=np.uint8)
-    ln, _ = lf.map_batch_dev(na, d_seqs.data_ptr(), off, lens, hbuf.ctypes.data, hbuf.size, False, params=p)
+    ln, _ = lf.map_batch_dev(na, d_seqs.ptr, off, lens, hbuf.ctypes.data, hbuf.size, False, params=p)
     assert hbuf[:ln].tobytes() == exp
     monkeypatch.setenv("LF_CHUNK_READS", "7"); monkeypatch.setenv("LF_LANES", "3")
-    out.zero_()
-    ln, _ = lf.map_batch_dev(na, d_seqs.data_ptr(), off, lens, out.data_ptr(), out.numel(), True, params=p)
-    got = bytes(out[:ln].cpu().numpy().tobytes())
+    ln, _ = lf.map_batch_dev(na, d_seqs.ptr, off, lens, out.ptr, out.nbytes, True, params=p)
+    got = out.download(ln)
     assert got == exp, first_diff(got, exp)
     # a buffer that is too small is an error, not a truncation
     with pytest.raises(la.api.LfError):
-        lf.map_batch_dev(na, d_seqs.data_ptr(), off, lens, out.data_ptr(), 1000, True, params=p)
+        lf.map_batch_dev(na, d_seqs.ptr, off, lens, out.ptr, 1000, True, params=p)
+    d_seqs.free(); out.free()
 
 
 def test_map_batch_dev_fastq_short_reads_and_readgroup(lf, oracle, oracle_lib, golden_reads):
     """device-resident qualities (reversed for reverse-strand records), reads shorter than -l (printed from bases fetched on
     demand) and a read group: the oracle's records"""
-    import torch
     import lordfast_amd as la
     names, seqs = golden_reads
     names, seqs = list(names[:24]), list(seqs[:24])
@@ -407,9 +407,10 @@ def test_map_batch_dev_fastq_short_reads_and_readgroup(lf, oracle, oracle_lib, g
     rng = np.random.default_rng(5)
     quals = [bytes(rng.integers(35, 74, size=len(s)).astype(np.uint8)) for s in seqs]
     exp = oracle.map_batch(names, seqs, quals, params=oracle_lib.default_params(read_group_id=b"grp1"))
-    na, d_seqs, off, lens, d_quals = _pack_to_device(torch, names, seqs, quals)
-    out = torch.zeros(len(exp) + 4096, dtype=torch.uint8, device="cuda")
-    ln, _ = lf.map_batch_dev(na, d_seqs.data_ptr(), off, lens, out.data_ptr(), out.numel(), True, d_quals=d_quals.data_ptr(),
+    na, d_seqs, off, lens, d_quals = _pack_to_device(names, seqs, quals)
+    out = la.api.DeviceBuffer(len(exp) + 4096)
+    ln, _ = lf.map_batch_dev(na, d_seqs.ptr, off, lens, out.ptr, out.nbytes, True, d_quals=d_quals.ptr,
                              params=la.default_params(read_group_id=b"grp1"))
-    got = bytes(out[:ln].cpu().numpy().tobytes())
+    got = out.download(ln)
     assert got == exp, first_diff(got, exp)
+    d_seqs.free(); d_quals.free(); out.free()
