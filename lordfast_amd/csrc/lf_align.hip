@@ -22,6 +22,7 @@
 #include "lf_gpu_common.h"
 #include "lf_edlib_common.h"
 #include "lf_hirsch.h"
+#include "lf_rsweep.h"
 #include <stddef.h>
 #include <algorithm>
 #include <type_traits>
@@ -30,154 +31,22 @@
 #include <numeric>
 #include <limits.h>
 
-/* layout of a wave's checkpoint area (16-byte entries from the hist_base of the wave's first problem):
- *   lane classes   [0, 96 NB)  bit planes lo / hi / valid of every block: u64 [(b * 3 + x) * 64 + lane]
- *                  then        carries: the two-bit horizontal deltas ENTERING block b >= 1, 16 columns per u32,
- *                              u32 [((q * NB + b) * 64 + lane) * 4 + sub], column c in word (c - 1) / 16 = 4 q + sub
- *                  then        checkpoints (Pv, Mv) after every K-th column: [((j - 1) * NB + b) * 64 + lane]
- *   sweep classes  [0, 96)     bit planes of the lanes' blocks: u64 [x * 64 + lane]          (KB = 1 only)
- *                  then        rows of 64 KB + 16 entries (KB = 1; + 4 otherwise), one per K steps: (Pv, Mv) of every lane,
- *                              tail bytes [0, 64) pending carry of every lane, u16 [32 + lane] the carries the lane
- *                              RECEIVED during the row's K steps (KB = 1)
- * With the carries a block can be replayed on its own: lf_edlib_tb_kernel walks one path per lane and recomputes only
- * the block the path is in. */
-#define LF_PLANE_ENTRIES 96
-__host__ __device__ __forceinline__ int lf_sweep_row(int kb) { return 64 * kb + (kb == 1 ? 16 : 4); }
-__host__ __device__ __forceinline__ uint64_t lf_lane_ck_off(int nb, uint32_t m_max) { return (uint64_t)nb * LF_PLANE_ENTRIES + (uint64_t)((m_max + 63) >> 6) * nb * 64; }
-
 /* ------------------------------------------------------------------------------------------------
- * register-resident classes: ONE LANE PER PROBLEM, NB blocks per column (n <= 64 NB) -- forward pass
+ * traceback: ONE LANE PER PATH, for every problem of the one-block-per-lane forward kernel (lf_rsweep.hip: n <= 4096, below
+ * edlib's Hirschberg switch -- which includes the leaves lf_hirsch.hip cuts the larger problems into).
  *
- * The blocks of one column depend on each other through the horizontal carry, and a block depends on itself one
- * column earlier: one lane alone is a single dependent chain.  Walking the lane's OWN blocks as an anti-diagonal
- * (time step t: block b works on column t - b, taking the carry block b-1 produced one time step earlier) makes the
- * NB block steps of a time step independent: NB-way ILP per lane.
- *
- * The time loop carries NO per-lane control flow.  t and b are wave-uniform, so "block b has not started yet"
- * (t - b < 1) is a scalar branch; everything that differs between lanes -- the number of blocks a problem really has,
- * its target length -- is handled by letting a lane compute on: steps beyond its last block or its last column only
- * write its own dead registers and feed other dead steps, and the places where validity matters (distance
- * bookkeeping, checkpoint / carry stores) are selects / predicated stores.  The loop runs to the wavefront's
- * longest problem (problems are sorted by target length).  The path itself is walked by lf_edlib_tb_kernel.
+ * From (n, tl) the path is followed tile by tile: the tile = the K sweep steps around the current cell, of the ONE block the
+ * cell is in.  The lane restores that block's checkpoint in front of the tile, replays the K block steps with the stored
+ * carries as horizontal input, keeps (Pv, Ph) of the K columns in registers (the walk is unrolled over the columns) and walks
+ * until the path leaves the tile or the block.  Work per path: ~(m / K + n / 64) tiles of K block steps.  Same cells, same
+ * Up -> Left -> Diagonal priority (lib/edlib/edlib.cpp:950,984,1015), same ops.
  * ---------------------------------------------------------------------------------------------- */
-template <int NB, bool PAC>
-__global__ void __launch_bounds__(64)
-lf_edlib_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, lf_hist_t *__restrict__ ckpt,
-                int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end)
-{
-    constexpr int K = LF_LANE_K;
-    const int gid = blockIdx.x * 64 + threadIdx.x;
-    const int lane = threadIdx.x;
-    const bool live = gid < n_probs;
-    const lf_aln_prob pr = probs[live ? gid : n_probs - 1];      /* a dead lane shadows the last problem and stores nothing */
-    const lf_qacc Q(S.q, pr.qstart, pr.flags); const lf_tacc T(S.t, S.pac, pr.tstart, pr.flags);
-    auto qget = [&](uint32_t r) -> unsigned char { return Q.get(r); };
-    const uint32_t n = pr.n, m = pr.m;
-
-    uint64_t lo[NB], hi[NB], valid[NB], Pv[NB], Mv[NB];
-#pragma unroll
-    for (int b = 0; b < NB; b++) { lo[b] = hi[b] = valid[b] = 0; Pv[b] = ~0ull; Mv[b] = 0; }
-#pragma unroll
-    for (int b = 0; b < NB; b++) {
-        if ((uint32_t)b * 64 < n) {
-#pragma unroll 8
-            for (int i = 0; i < 64; i++) {      /* unconditional loads from a clamped index: a branch per byte makes every load wait for the one before */
-                const uint32_t r = b * 64 + i; const unsigned char qc = Q.get(r < n ? r : n - 1);
-                lf_plane_add(r < n ? qc : (unsigned char)0, i, lo[b], hi[b], valid[b]);
-            }
-        }
-    }
-
-    const int lastb = (int)((n - 1) >> 6), lastbit = (int)((n - 1) & 63);
-    int score = (int)n;                     /* D[n][0] */
-    /* SHW (lib/edlib/edlib.cpp:583-618): min over prefixes, smallest on ties; the empty prefix only exists
-     * through the wildcard padding of the last block, i.e. when n % 64 != 0 */
-    int best = (n & 63) ? (int)n : 0x7fffffff, best_c = 0;
-    const uint32_t m_max = lf_wave_max_u32(m);
-    lf_hist_t *wbase = ckpt + pr.hist_base;          /* the same for every lane: hist_base of the wave's first problem */
-    uint64_t *planes = reinterpret_cast<uint64_t *>(wbase);
-    uint32_t *carr = reinterpret_cast<uint32_t *>(wbase + NB * LF_PLANE_ENTRIES);
-    lf_hist_t *ck = wbase + lf_lane_ck_off(NB, m_max) + lane;     /* checkpoint (j, block b) of lane l at ((j - 1) * NB + b) * 64 + l */
-    const bool ck_on = pr.task == LF_TASK_PATH && live;
-    if (ck_on) {
-#pragma unroll
-        for (int b = 0; b < NB; b++) if (b <= lastb) { planes[(b * 3 + 0) * 64 + lane] = lo[b]; planes[(b * 3 + 1) * 64 + lane] = hi[b]; planes[(b * 3 + 2) * 64 + lane] = valid[b]; }
-    }
-
-    uint32_t hout[NB], win[NB], cw[NB];
-#pragma unroll
-    for (int b = 0; b < NB; b++) { hout[b] = 0; win[b] = 0; cw[b] = 0; }
-    auto carry_store = [&](int b, uint32_t gi) {      /* gi: 16-column group */
-        if (ck_on && b <= lastb && gi * 16 < m) carr[(((size_t)(gi >> 2) * NB + b) * 64 + lane) * 4 + (gi & 3)] = cw[b];
-    };
-    const uint32_t steps_w = lf_wave_max_u32(m + (uint32_t)lastb);
-    for (uint32_t t0 = 1; t0 <= steps_w; t0 += 8) {
-        /* the 8 target bases of this trip are fetched together: their latency is paid once, not per column */
-        uint32_t tcs[8];
-        if (PAC) { const uint32_t p8 = T.pac_codes8((int64_t)t0 - 1, m);      /* one 4-byte load; columns past m are dead anyway */
-#pragma unroll
-            for (int k = 0; k < 8; k++) tcs[k] = (p8 >> (2 * k)) & 3u; }
-        else {
-#pragma unroll
-            for (int k = 0; k < 8; k++) { const uint32_t ti = t0 + k - 1; tcs[k] = lf_tok_of_byte(T.get(ti < m ? ti : m - 1)); }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t t = t0 + k;
-#pragma unroll
-            for (int b = NB - 1; b >= 1; b--) win[b] = win[b - 1];
-            win[0] = tcs[k];
-#pragma unroll
-            for (int b = NB - 1; b >= 0; b--) {
-                if (t > (uint32_t)b && t <= steps_w) {                      /* wave-uniform: block b has reached column 1 */
-                    const uint32_t c = t - (uint32_t)b;
-                    const uint32_t hin = b == 0 ? LF_HIN_PLUS1 : hout[b > 0 ? b - 1 : 0];
-                    const uint64_t Eq = lf_eq_tok<PAC>(win[b], lo[b], hi[b], valid[b], qget, n, b);
-                    uint64_t ph, mh;
-                    hout[b] = lf_myers_step(Pv[b], Mv[b], Eq, hin, ph, mh);
-                    const bool inr = c <= m;
-                    if (b >= (NB <= 4 ? NB - 1 : NB - 2)) score += (b == lastb && inr) ? lf_delta_at(ph, mh, lastbit) : 0;      /* lf_class_of: the last block of a class-NB problem */
-                    if (b >= 1) cw[b] |= hin << (((c - 1) & 15u) * 2);      /* scalar shift amount */
-                    /* checkpoint: the state after every K-th column (one 1 KiB line per wave, block and checkpoint) */
-                    if ((c & (K - 1)) == 0) {                               /* wave-uniform */
-                        if (ck_on && inr && b <= lastb) { lf_hist_t e; e.pv = Pv[b]; e.ph = Mv[b]; ck[((size_t)(c / K - 1) * NB + b) * 64] = e; }
-                        if (b >= 1 && (c & 15u) == 0) { carry_store(b, c / 16 - 1); cw[b] = 0; }
-                    }
-                }
-            }
-            if (t <= steps_w) {   /* the last block has just finished column t - lastb */
-                const int cl = (int)t - lastb;
-                const bool upd = cl >= 1 && cl <= (int)m && score < best;
-                best = upd ? score : best; best_c = upd ? cl : best_c;
-            }
-        }
-    }
-    /* the carries of the last, partial group of every block (block b stopped at column steps_w - b) */
-#pragma unroll
-    for (int b = 1; b < NB; b++) if (steps_w > (uint32_t)b) { const uint32_t cl = steps_w - (uint32_t)b; if (cl & 15u) carry_store(b, (cl - 1) >> 4); }
-    int ed, tl;
-    if (pr.mode == 0) { ed = score; tl = (int)m; } else { ed = best; tl = best_c; }
-    if (live) { out_ed[pr.id] = ed; out_end[pr.id] = tl - 1; }
-}
-
-/* ------------------------------------------------------------------------------------------------
- * traceback: ONE LANE PER PATH, for every class whose blocks can be replayed on their own (lane classes; sweep classes
- * with one block per lane, problems below edlib's Hirschberg switch).
- *
- * From (n, tl) the path is followed tile by tile: the tile = the K columns (lane classes) or K sweep steps (sweep classes)
- * around the current cell, of the ONE block the cell is in.  The lane restores that block's checkpoint in front of the
- * tile, replays the K block steps with the stored carries as horizontal input, keeps (Pv, Ph) of the K columns in
- * registers (the walk is unrolled over the columns) and walks until the path leaves the tile or the block.  Work per path: ~(m / K + n / 64) tiles of K block steps --
- * instead of replaying all the blocks above the path (lane classes) or the whole group of lanes (sweep classes, where
- * the walk itself also kept only one lane of G busy).  Same cells, same Up -> Left -> Diagonal priority
- * (lib/edlib/edlib.cpp:950,984,1015), same ops.
- * ---------------------------------------------------------------------------------------------- */
-template <bool LANECLASS, bool PAC>
 __global__ void __launch_bounds__(64)
 lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, const lf_hist_t *__restrict__ ckpt, uint8_t *__restrict__ ops,
-                   const int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len, int W /* NB of the lane class | G of the sweep class */)
+                   const int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
 {
     constexpr int K = LF_LANE_K;
+    constexpr bool PAC = true;                           /* targets are always 2-bit codes here (byte strings of the stage API are packed first) */
     const int lane = threadIdx.x, idx = blockIdx.x * 64 + lane;
     const bool live = idx < n_probs;
     const lf_aln_prob pr = probs[live ? idx : n_probs - 1];
@@ -185,49 +54,35 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
     auto qget = [&](uint32_t r) -> unsigned char { return Q.get(r); };
     const bool lazy = (pr.flags & LF_F_LAZYX) != 0;      /* diagonal moves are not classified here (lf_render_kernel does it) */
     const uint32_t n = pr.n, m = pr.m;
-    const bool mine = live && (LANECLASS || lf_leaf(n, m));      /* above the switch: the sweep kernel's own Hirschberg walk */
-    const bool want = mine && pr.task == LF_TASK_PATH;
+    const bool want = live && pr.task == LF_TASK_PATH;
     const uint32_t tl = pr.mode == 0 ? m : (uint32_t)(out_end[pr.id] + 1);
-    /* where the forward kernel left this problem's data */
+    /* where the forward kernel left this problem's data: the wave's planes, then its checkpoint rows; block b was lane lane0 + b */
     const lf_hist_t *wbase = ckpt + pr.hist_base;
     const uint64_t *planes = reinterpret_cast<const uint64_t *>(wbase);
-    const int slot = LANECLASS ? lane : idx % (64 / W);
-    const uint32_t m_max = LANECLASS ? lf_wave_max_u32(m) : 0;
-    const lf_hist_t *ck = LANECLASS ? wbase + lf_lane_ck_off(W, m_max) : wbase + LF_PLANE_ENTRIES;
-    const uint32_t *carr = reinterpret_cast<const uint32_t *>(wbase + (size_t)W * LF_PLANE_ENTRIES);      /* lane classes */
-    constexpr int ROW = 64 + 16;                                                                            /* sweep classes, KB = 1 */
+    const int lane0 = (int)pr.pad;
+    const lf_hist_t *ck = wbase + LF_PLANE_ENTRIES;
+    constexpr int ROW = 64 + 16;
 
     lf_emitter em; em.init(ops + pr.ops_off, n + m, want);
     uint32_t r = want ? n : 0, c = want ? tl : 0;
     uint64_t lo = 0, hi = 0, valid = 0;
-    auto load_planes = [&](uint32_t b) {
-        if (LANECLASS) { lo = planes[(b * 3 + 0) * 64 + slot]; hi = planes[(b * 3 + 1) * 64 + slot]; valid = planes[(b * 3 + 2) * 64 + slot]; }
-        else { const int ln = slot * W + (int)b; lo = planes[ln]; hi = planes[64 + ln]; valid = planes[128 + ln]; }
-    };
+    auto load_planes = [&](uint32_t b) { const int ln = lane0 + (int)b; lo = planes[ln]; hi = planes[64 + ln]; valid = planes[128 + ln]; };
     uint32_t cur_b = r > 0 ? (r - 1) >> 6 : 0;
     load_planes(cur_b);
     while (__any(r > 0 && c > 0)) {
         const bool act = r > 0 && c > 0;
         const uint32_t b = act ? (r - 1) >> 6 : 0;
         /* the tile: K block steps of block b; step k works on column cbase + k */
-        const uint32_t j = !act ? 0 : LANECLASS ? (c - 1) / K : (c - 1 + b) / K;
-        const int cbase = LANECLASS ? (int)(j * K) + 1 : (int)(j * K) - (int)b + 1;
+        const uint32_t j = !act ? 0 : (c - 1 + b) / K;
+        const int cbase = (int)(j * K) - (int)b + 1;
         /* what the tile needs from HBM -- the block's state in front of it, the carries entering it, its target symbols, the
          * block's bit planes when the block changed -- is requested with UNCONDITIONAL loads from clamped addresses, so that
-         * all of them are in flight together (one round trip per tile; per-lane branches around the loads made every one of
-         * them wait for the previous: nine dependent round trips) */
+         * all of them are in flight together (one round trip per tile) */
         const uint32_t jm = j > 0 ? j - 1 : 0;
-        lf_hist_t est; uint32_t craw; uint32_t tokp = 0;
-        if (LANECLASS) {
-            est = *(j > 0 ? ck + ((size_t)jm * W + b) * 64 + slot : wbase + slot);      /* j == 0: any address inside the wave's area (a wave of targets < K columns has no checkpoints) */
-            const uint32_t gi = j >> 1;
-            craw = carr[(((size_t)(gi >> 2) * W + b) * 64 + slot) * 4 + (gi & 3)] >> ((j & 1u) * 16);
-        } else {
-            const int ln = slot * W + (int)b;
-            est = ck[(size_t)jm * ROW + ln];
-            craw = reinterpret_cast<const uint16_t *>(ck + (size_t)j * ROW + 64)[32 + ln];
-        }
-        if (PAC) tokp = T.pac_codes8((int64_t)cbase - 1, m);
+        const int ln = lane0 + (int)b;
+        const lf_hist_t est = ck[(size_t)jm * ROW + ln];
+        const uint32_t craw = reinterpret_cast<const uint16_t *>(ck + (size_t)j * ROW + 64)[32 + ln];
+        const uint32_t tokp = T.pac_codes8((int64_t)cbase - 1, m);
         /* lo / hi / valid are the planes of block b: loaded behind the walk that entered the block (below) */
         uint64_t Pv = j > 0 ? est.pv : ~0ull, Mv = j > 0 ? est.ph : 0ull;      /* column 0 */
         const uint32_t cw = b > 0 ? craw : 0x5555u;                            /* block 0: +1 enters every column */
@@ -237,12 +92,11 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const int col = cbase + k;
-            const uint32_t tk = PAC ? (tokp >> (2 * k)) & 3u : ((act && col >= 1 && col <= (int)c) ? lf_tok<PAC>(T, (uint32_t)col - 1) : 0u);
+            const uint32_t tk = (tokp >> (2 * k)) & 3u;
             const uint64_t Eq = lf_eq_tok<PAC>(tk, lo, hi, valid, qget, n, b);
             uint64_t nPv = Pv, nMv = Mv, ph, mh;
             (void)lf_myers_step(nPv, nMv, Eq, (cw >> (2 * k)) & 3u, ph, mh);
-            if (LANECLASS) { Pv = nPv; Mv = nMv; }
-            else { const bool v = col >= 1; Pv = v ? nPv : Pv; Mv = v ? nMv : Mv; }       /* the block starts at column 1 */
+            const bool v = col >= 1; Pv = v ? nPv : Pv; Mv = v ? nMv : Mv;       /* the block starts at column 1 */
             tPv[k] = Pv; tPh[k] = ph;
         }
         /* walk: column by column from the right; inside a column only Up moves repeat */
@@ -272,7 +126,7 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
         while (r > 0) { em.put(1); r--; }
         em.flush();
     }
-    if (mine) out_len[pr.id] = want ? n + m - em.w : 0;            /* ops are END-aligned: o[cap - len .. cap) */
+    if (live) out_len[pr.id] = want ? n + m - em.w : 0;            /* ops are END-aligned: o[cap - len .. cap) */
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -588,93 +442,65 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     if (live && gl == 0) out_len[pr.id] = want_path ? pr.n + pr.m - em.w : 0;            /* ops are END-aligned: o[cap - len .. cap) */
 }
 
+
 /* ------------------------------------------------------------------------------------------------
- * size classes and checkpoint layout
- *   1..6   lane kernels NB 1,2,3,4,6,8 (n <= 512): 64 problems per wave, checkpoint every LF_LANE_K columns
- *   7,8    sweep kernels G 16 / 32, one block per lane (n <= 1024 / 2048): 4 / 2 problems per wave
- *   9..11  sweep kernels G 64, KB 1 / 4 / 8 blocks per lane (n <= 4096 / 16384 / 32768)
- *   0      generic lane kernel (n > 32768; full history in HBM) -- below edlib's traceback switch such a problem has m <= 101
- *   12     not a problem of these kernels: an empty side (a pure run, written at once) or a problem above edlib's traceback
- *          switch (:1117-1119) -- a ROOT of the breadth-first Hirschberg levels (lf_hirsch.hip), whose leaves come back as
- *          extra problems of classes 0..11
+ * classes and checkpoint layout
+ *   1   lf_edlib_rsweep_kernel (lf_rsweep.hip): every problem with <= 64 query blocks (n <= 4096) below edlib's traceback
+ *       switch -- one block per lane, floor(64 / nb) problems of the same nb per wavefront; path by lf_edlib_tb_kernel
+ *   2,3 sweep kernel G 64 with KB 4 / 8 blocks per lane (n <= 16384 / 32768; below the switch such a problem has m < 800),
+ *       forward + its own tile traceback
+ *   0   generic lane kernel: n > 32768 (m <= 101 below the switch), and problems of the stage API whose target holds bytes
+ *       other than upper-case ACGT (exact byte compare)
+ *   4   not a problem of these kernels: an empty side (a pure run, written at once) or a problem above edlib's traceback
+ *       switch (:1117-1119) -- a ROOT of the breadth-first Hirschberg levels (lf_hirsch.hip), whose leaves come back as
+ *       extra problems of classes 0..3
+ * Sort key (32 bits): class << 28 | mode << 23 | nb << 16 | m   (mode, nb: class 1 only; m < 37 450 below the switch).
  * A wave's checkpoints start at the hist_base of its first problem (16-byte entries).
  * ---------------------------------------------------------------------------------------------- */
-#define LF_NCLASS 12
-#define LF_CLASS_SKIP 12
-/* LF_SWEEP_MAX_N: lf_internal.h */
-__host__ __device__ __forceinline__ int lf_class_nb(int c) { return c == 1 ? 1 : c == 2 ? 2 : c == 3 ? 3 : c == 4 ? 4 : c == 5 ? 6 : 8; }
-__host__ __device__ __forceinline__ int lf_class_of(uint32_t n, uint32_t m)
+#define LF_NCLASS 4
+#define LF_CLASS_SKIP 4
+__host__ __device__ __forceinline__ int lf_class_of(uint32_t n, uint32_t m, bool exotic)
 {
     if (n == 0 || m == 0 || !lf_leaf(n, m)) return LF_CLASS_SKIP;
-    const uint32_t nb = (n + 63) >> 6;
-    if (nb <= 1) return 1; if (nb <= 2) return 2; if (nb <= 3) return 3; if (nb <= 4) return 4; if (nb <= 6) return 5; if (nb <= 8) return 6;
-    if (nb <= 16) return 7; if (nb <= 32) return 8;
-    if (n <= 4096) return 9; if (n <= 16384) return 10; if (n <= LF_SWEEP_MAX_N) return 11;
+    if (exotic) return 0;
+    if (n <= 4096) return 1; if (n <= 16384) return 2; if (n <= LF_SWEEP_MAX_N) return 3;
     return 0;
 }
-/* problems per wave, blocks per lane, steps per tile of the sweep classes */
-__host__ __device__ __forceinline__ int lf_class_ppw(int c) { return c >= 1 && c <= 6 ? 64 : c == 7 ? 4 : c == 8 ? 2 : 1; }      /* class 0: 1 (own history) */
-__host__ __device__ __forceinline__ int lf_class_kb(int c) { return c == 10 ? 4 : c == 11 ? 8 : 1; }
-__host__ __device__ __forceinline__ int lf_class_k(int c) { return c == 10 ? 4 : c == 11 ? 2 : 8; }
-/* checkpoint entries of one wave whose longest target is m_max (the wave's last problem: problems are sorted by m) */
-__host__ __device__ __forceinline__ uint64_t lf_class_wave_entries(int c, uint32_t m_max)
+__host__ __device__ __forceinline__ uint32_t lf_class_key(const lf_aln_desc_t &x)
 {
-    if (c >= 1 && c <= 6) return lf_lane_ck_off(lf_class_nb(c), m_max) + 64ull * (m_max / LF_LANE_K) * (uint32_t)lf_class_nb(c);
-    if (c == 0 || c == LF_CLASS_SKIP) return 0;
-    const uint64_t rows = ((uint64_t)m_max + 64) / (uint32_t)lf_class_k(c) + 1;
-    return (lf_class_kb(c) == 1 ? LF_PLANE_ENTRIES : 0) + rows * (uint64_t)lf_sweep_row(lf_class_kb(c));
+    const int c = lf_class_of(x.n, x.m, x.pad[0] != 0);
+    const uint32_t m16 = x.m < 0xffffu ? x.m : 0xffffu;
+    return ((uint32_t)c << 28) | (c == 1 ? ((uint32_t)(x.mode ? 1u : 0u) << 23) | (((x.n + 63) >> 6) << 16) : 0u) | m16;
 }
-/* private state words of a generic-kernel problem */
-__host__ __device__ __forceinline__ uint64_t lf_class_aux_words(int c, uint32_t n, uint32_t m) { (void)m; return c == 0 ? (uint64_t)((n + 63) >> 6) * 5 : 0; }
+/* checkpoint entries of one rsweep wave: the planes, then one row per 8 steps (+ the partial last one) */
+__host__ __device__ __forceinline__ uint64_t lf_rwave_entries(uint32_t nb, uint32_t m_max) { return LF_PLANE_ENTRIES + (uint64_t)((m_max + nb - 1 + 7) / 8 + 1) * (uint32_t)lf_sweep_row(1); }
+/* ... of a G 64 / KB wave (one problem) */
+__host__ __device__ __forceinline__ uint64_t lf_kbwave_entries(int kb, int k, uint32_t m) { return (((uint64_t)m + 64) / (uint32_t)k + 1) * (uint64_t)lf_sweep_row(kb); }
 
-/* the launches of one binned batch: class k = probs[cstart[k] .. cstart[k + 1]) */
-struct lf_launch_ctx {
-    hipStream_t cs[LF_NCLASS]; const lf_aln_prob *d_probs; const int *cstart; lf_seqs S; lf_hist_t *d_hist; uint64_t *d_aux;
-    uint8_t *d_ops; int32_t *d_ed, *d_end; uint32_t *d_len;
-};
-template <bool PAC>
-static void launch_classes(const lf_launch_ctx &L)
-{
-    auto cnt = [&](int c) { return L.cstart[c + 1] - L.cstart[c]; };
-    /* largest problems first: their few long-running waves start while the small classes fill the rest of the chip */
-#define DS(C, GV, KBV, KV) if (cnt(C) > 0) hipLaunchKernelGGL((lf_edlib_sweep_kernel<GV, KBV, KV, PAC>), dim3((unsigned)((cnt(C) + (64 / GV) - 1) / (64 / GV))), dim3(64), 0, L.cs[C], \
-        L.d_probs + L.cstart[C], cnt(C), L.S, L.d_hist, L.d_aux, L.d_ops, L.d_ed, L.d_end, L.d_len)
-#define TB(C, LANEC, WV) if (cnt(C) > 0) hipLaunchKernelGGL((lf_edlib_tb_kernel<LANEC, PAC>), dim3((unsigned)((cnt(C) + 63) / 64)), dim3(64), 0, L.cs[C], \
-        L.d_probs + L.cstart[C], cnt(C), L.S, L.d_hist, L.d_ops, L.d_end, L.d_len, WV)
-    DS(11, 64, 8, 2); DS(10, 64, 4, 4); DS(9, 64, 1, 8); TB(9, false, 64);
-    if (cnt(0) > 0)
-        hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((cnt(0) + 63) / 64)), dim3(64), 0, L.cs[0],
-                           L.d_probs + L.cstart[0], cnt(0), L.S, L.d_hist, L.d_aux, L.d_ops, L.d_ed, L.d_end, L.d_len);
-    DS(8, 32, 1, 8); TB(8, false, 32); DS(7, 16, 1, 8); TB(7, false, 16);
-#undef DS
-#define DL(C, NBV) if (cnt(C) > 0) hipLaunchKernelGGL((lf_edlib_kernel<NBV, PAC>), dim3((unsigned)((cnt(C) + 63) / 64)), dim3(64), 0, L.cs[C], \
-        L.d_probs + L.cstart[C], cnt(C), L.S, L.d_hist, L.d_ed, L.d_end); TB(C, true, NBV)
-    DL(6, 8); DL(5, 6); DL(4, 4); DL(3, 3); DL(2, 2); DL(1, 1);
-#undef DL
-#undef TB
-}
+struct lf_rseg_tab { int lo[257]; int w0[257]; int cstart[8]; int n_waves[2]; };
 
 /* ------------------------------------------------------------------------------------------------
- * Batches are binned, ordered and laid out ON THE GPU: key = (size class, target length), one radix sort, one scan for the
- * checkpoint bases, one kernel that writes the per-class problem arrays.  The host uploads 32-byte descriptors (or finds
- * them in HBM: lf_walk.hip) and launches; it does no per-problem work.  Items n .. n + n_h - 1 are the leaves the
- * Hirschberg levels made out of the batch's large problems.
+ * Batches are binned, ordered and laid out ON THE GPU: one radix sort of 32-bit keys, a 256-thread kernel that finds the
+ * (mode, nb) segments of class 1 and numbers their wavefronts, one scan for the checkpoint bases, one kernel that writes the
+ * problem array and the wave table.  The host uploads 32-byte descriptors (or finds them in HBM: lf_walk.hip) and launches;
+ * it does no per-problem work.  Items n .. n + n_h - 1 are the leaves the Hirschberg levels made out of the large problems.
  * ---------------------------------------------------------------------------------------------- */
 struct lf_desc_src {
     const lf_aln_desc_t *d; const uint64_t *ops_off; uint64_t ops_total;       /* host arrays (or null: dev_desc / dev_opsoff) */
-    const unsigned char *d_q, *d_t; const uint8_t *d_pac; bool pac;           /* sequences in HBM: read batch + 2-bit reference, or uploaded byte strings */
+    const unsigned char *d_q, *d_t; const uint8_t *d_pac; int64_t pac_syms;   /* sequences in HBM: read batch + 2-bit reference; stage API: uploaded bytes + their 2-bit form */
+    const uint64_t *d_planes; int64_t q_words;                                /* bit planes of d_q (lf_pack_planes_kernel) */
+    bool pac;                                                                 /* descriptors address the reference itself (pipeline) */
     lf_hcount_t hc;                                                           /* the problems above edlib's traceback switch (known to whoever made the descriptors) */
 };
 
 __global__ void lf_desc_keys_kernel(const lf_aln_desc_t *__restrict__ d, const uint64_t *__restrict__ ops_off, int n, const lf_aln_desc_t *__restrict__ hd, int n_h,
-                                    uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint8_t *__restrict__ ops,
+                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint8_t *__restrict__ ops,
                                     int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n + n_h) return;
     const lf_aln_desc_t x = i < n ? d[i] : hd[i - n];
-    const int c = (i >= n) ? lf_class_of(x.n, x.m) : lf_class_of(x.n, x.m);
-    keys[i] = ((uint64_t)c << 32) | x.m;
+    keys[i] = lf_class_key(x);
     vals[i] = (uint32_t)i;
     if (i < n && (x.n == 0 || x.m == 0)) {
         /* one side empty: no DP (lib/edlib/edlib.cpp:1096-1104).  n == 0: NW deletes the whole target, SHW takes the empty
@@ -686,53 +512,78 @@ __global__ void lf_desc_keys_kernel(const lf_aln_desc_t *__restrict__ d, const u
         out_ed[i] = (int32_t)len; out_end[i] = x.n == 0 ? (int32_t)len - 1 : -1; out_len[i] = len;
     }
 }
-__global__ void lf_desc_bounds_kernel(const uint64_t *__restrict__ keys, int n, int *__restrict__ cstart /* LF_NCLASS + 2 */)
+__device__ __forceinline__ int lf_lower_bound_u32(const uint32_t *__restrict__ keys, int n, uint32_t want)
 {
-    const int c = threadIdx.x;
-    if (c > LF_NCLASS + 1) return;
-    const uint64_t want = (uint64_t)c << 32;
     int lo = 0, hi = n;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
-    cstart[c] = lo;
+    return lo;
+}
+/* class starts; for class 1 the start of every (mode, nb) segment and the number of its first wavefront */
+__global__ void __launch_bounds__(256)
+lf_desc_segments_kernel(const uint32_t *__restrict__ keys, int n, lf_rseg_tab *__restrict__ tab)
+{
+    __shared__ int s_lo[257], s_w[256];
+    const int t = threadIdx.x;
+    s_lo[t] = lf_lower_bound_u32(keys, n, (1u << 28) | ((uint32_t)t << 16));
+    if (t == 255) s_lo[256] = lf_lower_bound_u32(keys, n, 2u << 28);
+    if (t < 6) tab->cstart[t] = lf_lower_bound_u32(keys, n, (uint32_t)t << 28);
+    __syncthreads();
+    const int nb = t & 127, cnt = s_lo[t + 1] - s_lo[t];
+    s_w[t] = (nb >= 1 && nb <= 64) ? (cnt + (64 / nb) - 1) / (64 / nb) : 0;
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int k = 0; k < 256; k++) { tab->lo[k] = s_lo[k]; tab->w0[k] = acc; acc += s_w[k]; if (k == 127) tab->n_waves[0] = acc; }
+        tab->lo[256] = s_lo[256]; tab->w0[256] = acc; tab->n_waves[1] = acc - tab->n_waves[0];
+    }
 }
 /* checkpoint entries are charged to the first problem of every wave */
-__global__ void lf_desc_entries_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const lf_aln_desc_t *__restrict__ d, int n0,
-                                       const lf_aln_desc_t *__restrict__ hd, const int *__restrict__ cstart, int n, uint64_t *__restrict__ ent)
+__global__ void lf_desc_entries_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, const lf_aln_desc_t *__restrict__ d, int n0,
+                                       const lf_aln_desc_t *__restrict__ hd, const lf_rseg_tab *__restrict__ tab, int n, uint64_t *__restrict__ ent)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const int c = (int)(keys[j] >> 32);
+    const uint32_t key = keys[j];
+    const int c = (int)(key >> 28);
     uint64_t e = 0;
-    if (c == 0) { const uint32_t i = vals[j]; const uint32_t nb = ((i < (uint32_t)n0 ? d[i].n : hd[i - n0].n) + 63) >> 6; e = (uint64_t)(uint32_t)keys[j] * nb; }      /* full history: m rows of nb entries */
-    else if (c != LF_CLASS_SKIP) {
-        const int ppw = lf_class_ppw(c), rel = j - cstart[c];
-        if (rel % ppw == 0) {
-            int last = j + ppw - 1; if (last > cstart[c + 1] - 1) last = cstart[c + 1] - 1;
-            e = lf_class_wave_entries(c, (uint32_t)keys[last]);
-        }
+    if (c == 1) {
+        const int t = (int)((key >> 16) & 0xffu), nb = t & 127, P = 64 / nb, rel = j - tab->lo[t];
+        if (rel % P == 0) { int last = j + P - 1; if (last > tab->lo[t + 1] - 1) last = tab->lo[t + 1] - 1; e = lf_rwave_entries((uint32_t)nb, keys[last] & 0xffffu); }
+    } else if (c != LF_CLASS_SKIP) {
+        const uint32_t i = vals[j];
+        const lf_aln_desc_t x = i < (uint32_t)n0 ? d[i] : hd[i - n0];
+        e = c == 0 ? (uint64_t)x.m * ((x.n + 63) >> 6) : c == 2 ? lf_kbwave_entries(4, 4, x.m) : lf_kbwave_entries(8, 2, x.m);      /* class 0: full history, m rows of nb entries */
     }
     ent[j] = e;
 }
-__global__ void lf_desc_build_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const lf_aln_desc_t *__restrict__ d, int n0,
+__global__ void lf_desc_build_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, const lf_aln_desc_t *__restrict__ d, int n0,
                                      const lf_aln_desc_t *__restrict__ hd, const uint64_t *__restrict__ ops_off, const uint64_t *__restrict__ hops_off,
-                                     const int *__restrict__ cstart, const uint64_t *__restrict__ base, int n, int pac,
-                                     lf_aln_prob *__restrict__ probs, uint64_t *__restrict__ aux_words_total)
+                                     const lf_rseg_tab *__restrict__ tab, const uint64_t *__restrict__ base, int n, int pac,
+                                     lf_aln_prob *__restrict__ probs, lf_rwave *__restrict__ waves, uint64_t *__restrict__ aux_words_total)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const int c = (int)(keys[j] >> 32);
+    const uint32_t key = keys[j];
+    const int c = (int)(key >> 28);
     if (c == LF_CLASS_SKIP) return;
     const uint32_t i = vals[j];
     const lf_aln_desc_t x = i < (uint32_t)n0 ? d[i] : hd[i - n0];
     lf_aln_prob p;
     p.qstart = x.qstart; p.tstart = x.tstart; p.ops_off = i < (uint32_t)n0 ? ops_off[i] : hops_off[i - n0];
-    int jb = j;
-    if (c != 0) { const int ppw = lf_class_ppw(c); jb = cstart[c] + ((j - cstart[c]) / ppw) * ppw; }
-    p.hist_base = base[jb];
-    p.aux_off = 0;
-    const uint64_t aw = lf_class_aux_words(c, x.n, x.m);
-    if (aw) p.aux_off = atomicAdd((unsigned long long *)aux_words_total, (unsigned long long)aw);
-    p.n = x.n; p.m = x.m; p.id = i; p.mode = x.mode; p.task = LF_TASK_PATH; p.flags = (uint8_t)((x.flags & ~LF_F_TPAC) | (pac ? LF_F_TPAC : 0u)); p.pad = 0;
+    p.hist_base = base[j]; p.aux_off = 0; p.pad = 0;
+    if (c == 1) {
+        const int t = (int)((key >> 16) & 0xffu), nb = t & 127, P = 64 / nb, rel = j - tab->lo[t], slot = rel % P;
+        p.hist_base = base[j - slot];
+        p.pad = (uint8_t)(slot * nb);                       /* the problem's first lane in its wavefront */
+        if (slot == 0) {
+            lf_rwave w; w.first = (uint32_t)j; const int left = tab->lo[t + 1] - j; w.count = (uint16_t)(left < P ? left : P); w.G = (uint16_t)nb; w.hist_base = p.hist_base;
+            waves[tab->w0[t] + rel / P] = w;
+        }
+    } else if (c == 0) {
+        p.aux_off = atomicAdd((unsigned long long *)aux_words_total, (unsigned long long)((x.n + 63) >> 6) * 5);      /* private state words of the generic kernel */
+    }
+    p.n = x.n; p.m = x.m; p.id = i; p.mode = x.mode; p.task = LF_TASK_PATH;
+    p.flags = (uint8_t)((x.flags & ~LF_F_TPAC) | ((pac || !x.pad[0]) ? LF_F_TPAC : 0u));
     probs[j] = p;
 }
 
@@ -748,8 +599,8 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
     if (!s) return LF_ERR_HIP;
     const bool serial_classes = getenv("LF_SERIAL_CLASSES") != nullptr;     /* profiling aid: one class at a time (read per call: bench.py switches it) */
-    lf_launch_ctx L;
-    for (int k = 0; k < LF_NCLASS; k++) { L.cs[k] = serial_classes ? s : (hipStream_t)lfg_lane_stream(device, 2 + k); if (!L.cs[k]) return LF_ERR_HIP; }
+    hipStream_t cs[LF_NCLASS];
+    for (int k = 0; k < LF_NCLASS; k++) { cs[k] = serial_classes ? s : (hipStream_t)lfg_lane_stream(device, 2 + k); if (!cs[k]) return LF_ERR_HIP; }
     hipEvent_t cdone[LF_NCLASS], e0 = (hipEvent_t)lfg_lane_event(device, 12), e1 = (hipEvent_t)lfg_lane_event(device, 13), eb = (hipEvent_t)lfg_lane_event(device, 14);
     for (int k = 0; k < LF_NCLASS; k++) { cdone[k] = (hipEvent_t)lfg_lane_event(device, k); if (!cdone[k]) return LF_ERR_HIP; }
     if (!e0 || !e1 || !eb) return LF_ERR_HIP;
@@ -763,10 +614,11 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
                                 : (lf_aln_desc_t *)lfg_dev_slot(device, ops_slot + 1, (size_t)n * sizeof(lf_aln_desc_t));
     if (desc_dev) *desc_dev = d_desc;
     uint64_t *d_opsoff = dev_opsoff ? const_cast<uint64_t *>(dev_opsoff) : DSLOT(uint64_t, 1, (size_t)n * 8);
-    uint64_t *d_keys = DSLOT(uint64_t, 3, NN * 8), *d_keys2 = DSLOT(uint64_t, 8, NN * 8);
+    uint32_t *d_keys = DSLOT(uint32_t, 3, NN * 4), *d_keys2 = DSLOT(uint32_t, 8, NN * 4);
     uint32_t *d_vals = DSLOT(uint32_t, 9, NN * 4), *d_vals2 = DSLOT(uint32_t, 10, NN * 4);
     uint64_t *d_ent = DSLOT(uint64_t, 11, NN * 8), *d_base = DSLOT(uint64_t, 12, NN * 8 + 8);
     lf_aln_prob *d_probs = DSLOT(lf_aln_prob, 13, NN * sizeof(lf_aln_prob));
+    lf_rwave *d_waves = DSLOT(lf_rwave, 0 + 17, (NN + 256) * sizeof(lf_rwave));
     /* device-planned rounds keep their results in slots of their own: the host-planned rounds that follow (rare chains)
      * must not overwrite what lf_walk_emit_kernel still reads */
     const int rs = dev_desc ? 18 : 4;
@@ -775,11 +627,12 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     uint8_t *d_ops = ops ? DSLOT(uint8_t, 7, D->ops_total + 64) : (uint8_t *)lfg_dev_slot(device, ops_slot, D->ops_total + 64);
     if (res_dev) { res_dev[0] = d_ed; res_dev[1] = d_end; res_dev[2] = d_len; }
     if (ops_dev) *ops_dev = d_ops;
-    int *d_cstart = DSLOT(int, 14, 64);
+    lf_rseg_tab *d_tab = DSLOT(lf_rseg_tab, 14, sizeof(lf_rseg_tab));
     uint64_t *d_misc = DSLOT(uint64_t, 15, 64);
-    if (!d_desc || !d_opsoff || !d_keys || !d_keys2 || !d_vals || !d_vals2 || !d_ent || !d_base || !d_probs || !d_ed || !d_end || !d_len || !d_ops || !d_cstart || !d_misc) return LF_ERR_NOMEM;
+    lf_rseg_tab *h_tab = (lf_rseg_tab *)lfg_pin_slot(LF_PS_ALN_PROB + 2, sizeof(lf_rseg_tab) + 64);
+    if (!d_desc || !d_opsoff || !d_keys || !d_keys2 || !d_vals || !d_vals2 || !d_ent || !d_base || !d_probs || !d_waves || !d_ed || !d_end || !d_len || !d_ops || !d_tab || !d_misc || !h_tab) return LF_ERR_NOMEM;
     size_t tb1 = 0, tb2 = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, d_keys, d_keys2, d_vals, d_vals2, (int)NN, 0, 36, s);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, d_keys, d_keys2, d_vals, d_vals2, (int)NN, 0, 31, s);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, d_ent, d_base, (int)NN, s);
     void *d_tmp = lfg_dev_slot(device, LF_DS_ALN0 + 16, std::max(tb1, tb2) + 256);
     if (!d_tmp) return LF_ERR_NOMEM;
@@ -841,29 +694,41 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
 
     const unsigned gb = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(lf_desc_keys_kernel, dim3(gb), dim3(256), 0, s, d_desc, d_opsoff, n, d_hdesc, (int)n_h, d_keys, d_vals, d_ops, d_ed, d_end, d_len);
-    { size_t tb = tb1; HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, N, 0, 36, s)); }
-    hipLaunchKernelGGL(lf_desc_bounds_kernel, dim3(1), dim3(64), 0, s, d_keys2, N, d_cstart);
-    hipLaunchKernelGGL(lf_desc_entries_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, n, d_hdesc, d_cstart, N, d_ent);
+    { size_t tb = tb1; HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, N, 0, 31, s)); }
+    hipLaunchKernelGGL(lf_desc_segments_kernel, dim3(1), dim3(256), 0, s, d_keys2, N, d_tab);
+    hipLaunchKernelGGL(lf_desc_entries_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, n, d_hdesc, d_tab, N, d_ent);
     { size_t tb = tb2; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_ent, d_base, N, s)); }
-    hipLaunchKernelGGL(lf_desc_build_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, n, d_hdesc, d_opsoff, d_hopsoff, d_cstart, d_base, N, D->pac ? 1 : 0, d_probs, d_misc);
-    int cstart[LF_NCLASS + 2]; uint64_t tail[2], aux_total = 0;
-    HIPCHK(hipMemcpyAsync(cstart, d_cstart, sizeof cstart, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(lf_desc_build_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, n, d_hdesc, d_opsoff, d_hopsoff, d_tab, d_base, N, D->pac ? 1 : 0, d_probs, d_waves, d_misc);
+    uint64_t tail[2], aux_total = 0;
+    HIPCHK(hipMemcpyAsync(h_tab, d_tab, sizeof(lf_rseg_tab), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&tail[0], d_base + (N - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&tail[1], d_ent + (N - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&aux_total, d_misc, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const uint64_t hist_entries = tail[0] + tail[1];
     lf_hist_t *d_hist = DSLOT(lf_hist_t, 2, hist_entries * sizeof(lf_hist_t) + 64);
-    uint64_t *d_aux = DSLOT(uint64_t, 17, aux_total * 8 + 64);
+    uint64_t *d_aux = (uint64_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 9, aux_total * 8 + 64);
     if (!d_hist || !d_aux) return LF_ERR_NOMEM;
 #undef DSLOT
+    int cstart[LF_NCLASS + 2]; for (int k = 0; k < LF_NCLASS + 2; k++) cstart[k] = h_tab->cstart[k];
+    const int nw_nw = h_tab->n_waves[0], nw_shw = h_tab->n_waves[1];
     HIPCHK(hipEventRecord(eb, s));
     auto cnt = [&](int c) { return cstart[c + 1] - cstart[c]; };
-    for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && L.cs[k] != s) HIPCHK(hipStreamWaitEvent(L.cs[k], eb, 0));
-    L.d_probs = d_probs; L.cstart = cstart; L.S.q = D->d_q; L.S.t = D->d_t; L.S.pac = D->d_pac; L.d_hist = d_hist; L.d_aux = d_aux;
-    L.d_ops = d_ops; L.d_ed = d_ed; L.d_end = d_end; L.d_len = d_len;
-    if (D->pac) launch_classes<true>(L); else launch_classes<false>(L);
-    for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && L.cs[k] != s) { HIPCHK(hipEventRecord(cdone[k], L.cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
+    for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && cs[k] != s) HIPCHK(hipStreamWaitEvent(cs[k], eb, 0));
+    lf_seqs S; S.q = D->d_q; S.t = D->d_t; S.pac = D->d_pac;
+    /* largest problems first: their few long-running waves start while the rest fills the chip */
+    if (cnt(3) > 0) hipLaunchKernelGGL((lf_edlib_sweep_kernel<64, 8, 2, true>), dim3((unsigned)cnt(3)), dim3(64), 0, cs[3], d_probs + cstart[3], cnt(3), S, d_hist, d_aux, d_ops, d_ed, d_end, d_len);
+    if (cnt(2) > 0) hipLaunchKernelGGL((lf_edlib_sweep_kernel<64, 4, 4, true>), dim3((unsigned)cnt(2)), dim3(64), 0, cs[2], d_probs + cstart[2], cnt(2), S, d_hist, d_aux, d_ops, d_ed, d_end, d_len);
+    if (cnt(0) > 0) hipLaunchKernelGGL(lf_edlib_generic_kernel, dim3((unsigned)((cnt(0) + 63) / 64)), dim3(64), 0, cs[0], d_probs + cstart[0], cnt(0), S, d_hist, d_aux, d_ops, d_ed, d_end, d_len);
+    if (cnt(1) > 0) {
+        lf_rsw_args RA;
+        RA.probs = d_probs; RA.waves = d_waves; RA.qlo = D->d_planes; RA.qhi = D->d_planes + D->q_words; RA.qvalid = D->d_planes + 2 * D->q_words; RA.q_words = D->q_words;
+        RA.pac = D->d_pac; RA.pac_syms = D->pac_syms; RA.ckpt = d_hist; RA.out_ed = d_ed; RA.out_end = d_end;
+        RA.wave0 = 0; RA.n_waves = nw_nw; lf_rsweep_launch(cs[1], false, RA);
+        RA.wave0 = nw_nw; RA.n_waves = nw_shw; lf_rsweep_launch(cs[1], true, RA);
+        hipLaunchKernelGGL(lf_edlib_tb_kernel, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, d_hist, d_ops, d_end, d_len);
+    }
+    for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && cs[k] != s) { HIPCHK(hipEventRecord(cdone[k], cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
     if (n_roots) lf_hirsch_launch_stitch(s, HA, n_roots);      /* the roots' pieces move together once their leaves have paths */
     HIPCHK(hipEventRecord(e1, s));
     if (ed) {
@@ -888,17 +753,27 @@ static lf_hcount_t count_hroots(int n, const lf_aln_desc_t *d)
     return c;
 }
 
-extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_desc_t *d, const uint64_t *ops_off, uint64_t ops_total,
-                              int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, int ops_slot, void **ops_dev, void **desc_dev, float *ms)
+/* the pipeline's sequences: the read batch lfg_seed left in HBM (bytes + bit planes) and the 2-bit reference */
+static int pipeline_src(const struct lf_index *ix, lf_desc_src *D)
 {
     lf_dev_state *st = (lf_dev_state *)ix->dev;
     if (!st) { lf_set_error("index is not on a device"); return LF_ERR_NO_DEVICE; }
+    D->d_q = (const unsigned char *)lfg_dev_slot(ix->device, LF_DS_SEED0 + 0, 0);
+    D->d_planes = (const uint64_t *)lfg_dev_slot(ix->device, LF_DS_SEED0 + 14, 0);
+    D->q_words = (int64_t)lfg_lane_value(ix->device, 0);
+    D->d_t = nullptr; D->d_pac = st->view.pac; D->pac_syms = ix->l_pac; D->pac = true;
+    if (!D->d_q || !D->d_planes || D->q_words < 2) { lf_set_error("no resident read batch"); return LF_ERR_ARG; }
+    return LF_OK;
+}
+
+extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_desc_t *d, const uint64_t *ops_off, uint64_t ops_total,
+                              int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, int ops_slot, void **ops_dev, void **desc_dev, float *ms)
+{
     lf_desc_src D;
+    const int rc = pipeline_src(ix, &D);
+    if (rc != LF_OK) return rc;
     D.d = d; D.ops_off = ops_off; D.ops_total = ops_total;
-    D.d_q = (const unsigned char *)lfg_dev_slot(ix->device, LF_DS_SEED0 + 0, 0);      /* read batch left in HBM by lfg_seed */
-    D.d_t = nullptr; D.d_pac = st->view.pac; D.pac = true;
     D.hc = count_hroots(n, d);
-    if (!D.d_q) { lf_set_error("lfg_edlib_desc: no resident read batch"); return LF_ERR_ARG; }
     if (getenv("LF_HIST_STATS")) {       /* debug: where the DP cells are (by ceil(n/64)) */
         uint64_t cnt[12] = { 0 }, cells[12] = { 0 }, hist[12] = { 0 };
         static const uint32_t edge[12] = { 1, 2, 3, 4, 5, 6, 8, 12, 16, 32, 64, 256 };
@@ -914,14 +789,11 @@ extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_des
 extern "C" int lfg_edlib_desc_dev(const struct lf_index *ix, int n, const void *d_desc, const void *d_opsoff, uint64_t ops_total, const lf_hcount_t *hc, int ops_slot,
                                   void **ops_dev, void **ed_dev, void **end_dev, void **len_dev, float *ms)
 {
-    lf_dev_state *st = (lf_dev_state *)ix->dev;
-    if (!st) { lf_set_error("index is not on a device"); return LF_ERR_NO_DEVICE; }
     lf_desc_src D;
+    const int rc0 = pipeline_src(ix, &D);
+    if (rc0 != LF_OK) return rc0;
     D.d = nullptr; D.ops_off = nullptr; D.ops_total = ops_total;
-    D.d_q = (const unsigned char *)lfg_dev_slot(ix->device, LF_DS_SEED0 + 0, 0);
-    D.d_t = nullptr; D.d_pac = st->view.pac; D.pac = true;
     D.hc = *hc;
-    if (!D.d_q) { lf_set_error("lfg_edlib_desc_dev: no resident read batch"); return LF_ERR_ARG; }
     void *res[3] = { nullptr, nullptr, nullptr };
     const int rc = run_edlib_desc_gpu(ix->device, n, &D, nullptr, nullptr, nullptr, nullptr, ops_slot, ops_dev, nullptr, ms,
                                       (const lf_aln_desc_t *)d_desc, (const uint64_t *)d_opsoff, res);
@@ -932,8 +804,9 @@ extern "C" int lfg_edlib_desc_dev(const struct lf_index *ix, int n, const void *
 }
 
 /* problems given as byte strings in host memory (the stage API lf_edlib_batch and the edlibAlign drop-in): the strings are
- * uploaded once and described exactly like the pipeline's requests -- the same binning, kernels and Hirschberg levels, with the
- * target read as bytes instead of 2-bit codes */
+ * uploaded once, the queries become bit planes and the targets 2-bit codes like the pipeline's, and the problems are
+ * described exactly like the pipeline's requests -- the same binning, kernels and Hirschberg levels.  A target that holds
+ * anything but upper-case ACGT keeps its bytes and goes through the generic kernel (exact byte compare, any alphabet). */
 extern "C" int lfg_edlib(int device, int n, const char *q, const uint64_t *qoff, const char *t, const uint64_t *toff,
                          const uint8_t *mode, int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len, float *ms)
 {
@@ -943,21 +816,26 @@ extern "C" int lfg_edlib(int device, int n, const char *q, const uint64_t *qoff,
     HIPCHK(hipSetDevice(device));
     hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
     if (!s) return LF_ERR_HIP;
-    const uint64_t qbytes = qoff[n], tbytes = toff[n];
+    const uint64_t qbytes = qoff[n], tbytes = toff[n], qw = lf_plane_words(qbytes);
     unsigned char *d_q = (unsigned char *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 5, qbytes + 64), *d_t = (unsigned char *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 6, tbytes + 64);
-    if (!d_q || !d_t) return LF_ERR_NOMEM;
+    uint64_t *d_planes = (uint64_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 7, 3 * qw * 8);
+    uint8_t *d_tpac = (uint8_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 8, tbytes / 4 + 128);
+    if (!d_q || !d_t || !d_planes || !d_tpac) return LF_ERR_NOMEM;
     std::vector<lf_aln_desc_t> dd((size_t)n); std::vector<uint64_t> oo((size_t)n);
     for (int i = 0; i < n; i++) {
         lf_aln_desc_t &x = dd[(size_t)i]; memset(&x, 0, sizeof x);
         x.qstart = (int64_t)qoff[i]; x.tstart = (int64_t)toff[i]; x.n = (uint32_t)(qoff[i + 1] - qoff[i]); x.m = (uint32_t)(toff[i + 1] - toff[i]);
         x.mode = mode ? mode[i] : 0;
+        for (uint64_t k = toff[i]; k < toff[i + 1]; k++) { const char c = t[k]; if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { x.pad[0] = 1; break; } }
         oo[(size_t)i] = qoff[i] + toff[i];
     }
     HIPCHK(hipMemcpyAsync(d_q, q, qbytes, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_t, t, tbytes, hipMemcpyHostToDevice, s));
+    lf_rsweep_pack_planes(s, d_q, qbytes, d_planes, qw);
+    lf_rsweep_pack_pac(s, d_t, tbytes, d_tpac);
     lf_desc_src D;
     D.d = dd.data(); D.ops_off = oo.data(); D.ops_total = qbytes + tbytes;
-    D.d_q = d_q; D.d_t = d_t; D.d_pac = nullptr; D.pac = false;
+    D.d_q = d_q; D.d_t = d_t; D.d_pac = d_tpac; D.pac_syms = (int64_t)tbytes > 0 ? (int64_t)tbytes : 1; D.d_planes = d_planes; D.q_words = (int64_t)qw; D.pac = false;
     D.hc = count_hroots(n, dd.data());
     return run_edlib_desc_gpu(device, n, &D, ed, endloc, ops, ops_len, 0, nullptr, nullptr, ms);
 }

@@ -147,6 +147,22 @@ struct lf_emitter {
 };
 
 
+/* layout of a wave's checkpoint area (16-byte entries from the hist_base of the wave's first problem):
+ *   lane classes   [0, 96 NB)  bit planes lo / hi / valid of every block: u64 [(b * 3 + x) * 64 + lane]
+ *                  then        carries: the two-bit horizontal deltas ENTERING block b >= 1, 16 columns per u32,
+ *                              u32 [((q * NB + b) * 64 + lane) * 4 + sub], column c in word (c - 1) / 16 = 4 q + sub
+ *                  then        checkpoints (Pv, Mv) after every K-th column: [((j - 1) * NB + b) * 64 + lane]
+ *   sweep classes  [0, 96)     bit planes of the lanes' blocks: u64 [x * 64 + lane]          (KB = 1 only)
+ *                  then        rows of 64 KB + 16 entries (KB = 1; + 4 otherwise), one per K steps: (Pv, Mv) of every lane,
+ *                              tail bytes [0, 64) pending carry of every lane, u16 [32 + lane] the carries the lane
+ *                              RECEIVED during the row's K steps (KB = 1)
+ * With the carries a block can be replayed on its own: lf_edlib_tb_kernel walks one path per lane and recomputes only
+ * the block the path is in. */
+#define LF_PLANE_ENTRIES 96
+__host__ __device__ __forceinline__ int lf_sweep_row(int kb) { return 64 * kb + (kb == 1 ? 16 : 4); }
+__host__ __device__ __forceinline__ uint64_t lf_lane_ck_off(int nb, uint32_t m_max) { return (uint64_t)nb * LF_PLANE_ENTRIES + (uint64_t)((m_max + 63) >> 6) * nb * 64; }
+
+
 /* lane l receives lane l-1's value (lane 0: 0): the horizontal carry of the anti-diagonal sweeps.  DPP wave_shr:1 is a
  * VALU move; __shfl_up goes through the LDS crossbar (ds_bpermute) and sits on the per-step dependency chain. */
 __device__ __forceinline__ uint32_t lf_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }

@@ -189,6 +189,7 @@ __device__ __forceinline__ void lf_hfinalize(const lf_hargs &A, const lf_hnode &
             d.qstart = P.qstart + dq * (int64_t)qo; d.tstart = P.tstart + dt * (int64_t)to; d.n = cn; d.m = cm;
             d.flags = (uint8_t)(P.flags & ~LF_F_TPAC); d.mode = 0;
             for (int z = 0; z < 6; z++) d.pad[z] = 0;
+            d.pad[0] = P.pad;                                   /* stage API: the root's target holds bytes other than ACGT */
             A.hdesc[j] = d; A.hopsoff[j] = off;
         }
         lf_hpiece(A, P.root, off, cn + cm, 0x80000000u | j);
@@ -200,7 +201,7 @@ __device__ __forceinline__ void lf_hfinalize(const lf_hargs &A, const lf_hnode &
         if (idx >= A.q_cap) { atomicExch(&A.ctl->fail, 4u); return; }
         lf_hnode c;
         c.qstart = P.qstart + dq * (int64_t)qo; c.tstart = P.tstart + dt * (int64_t)to; c.ops_off = off; c.n = cn; c.m = cm;
-        c.best = best; c.root = P.root; c.flags = P.flags; c.kind = 0; c.is_root = 0; c.pad = 0; c.pad2 = 0;
+        c.best = best; c.root = P.root; c.flags = P.flags; c.kind = 0; c.is_root = 0; c.pad = P.pad; c.pad2 = 0;
         A.q_out[kbc][idx] = c;
     }
 }
@@ -299,7 +300,7 @@ __global__ void lf_hirsch_roots_kernel(const lf_aln_desc_t *__restrict__ d, cons
     A.roots[r] = R;
     lf_hnode c;
     c.qstart = x.qstart; c.tstart = x.tstart; c.ops_off = ops_off[i]; c.n = x.n; c.m = x.m; c.best = -1; c.root = r;
-    c.flags = x.flags; c.kind = x.mode ? 1 : 0; c.is_root = 1; c.pad = 0; c.pad2 = 0;
+    c.flags = x.flags; c.kind = x.mode ? 1 : 0; c.is_root = 1; c.pad = x.pad[0]; c.pad2 = 0;
     A.q_out[kbc][idx] = c;
 }
 

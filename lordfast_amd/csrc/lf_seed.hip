@@ -15,6 +15,7 @@
  */
 #include <hipcub/hipcub.hpp>
 #include "lf_gpu_common.h"
+#include "lf_rsweep.h"
 
 /* ---------------------------------------------------------------- index residency */
 
@@ -437,6 +438,13 @@ extern "C" int lfg_seed_src(const struct lf_index *ix, const lf_params_t *p, int
         if (grc != LF_OK) return grc;
     }
 
+    {   /* the batch as three bit planes (code low / high bit, "is ACGT"): what the alignment kernels build their blocks from */
+        const uint64_t qw = lf_plane_words(n_bases);
+        uint64_t *d_planes = DSLOT(uint64_t, 14, 3 * qw * 8);
+        if (!d_planes) return LF_ERR_NOMEM;
+        lf_rsweep_pack_planes(s, (const unsigned char *)d_reads, n_bases, d_planes, qw);
+        lfg_lane_set_value(dv, 0, qw);
+    }
     hipLaunchKernelGGL(lf_seed_pos_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, d_off, hc, d_pos, d_pos2);
     HIPCHK(hipEventRecord(ev[0], s));
     hipLaunchKernelGGL(lf_seed_search_kernel, dim3((unsigned)((total + 4 * LF_SEARCH_SPAN - 1) / (4 * LF_SEARCH_SPAN))), dim3(256), 0, s, st->view, n_reads, d_reads,
