@@ -212,6 +212,16 @@ int  lf_map_batch_into_lens(const lf_index_t *idx, const lf_params_t *p, int n, 
 int  lf_map_batch_dev(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names, const void *d_seqs,
                       const uint64_t *seq_off, const uint32_t *seq_lens, const void *d_quals, void *out, size_t out_cap,
                       int out_is_device, size_t *sam_len, lf_stats_t *stats);
+/* Stage view of mapSeq (src/LordFAST.cpp:507-561) for a batch of reads: the coarse / fine decision of
+ * findTopWins_coarse / _fine (:582-657, :819-904), the windows alignWin (:995-1189) is called with and its result per window
+ * -- totalScore and the records' positions / alnScore / nmCount -- before the sort and printSamEntry.
+ *   mode[i]: 0 shorter than -l, 1 no window, 2 coarse (one window: the best), 3 fine (the top-N heap array, in array order)
+ *   windows of read i: wins[win0[i] .. win0[i + 1]); records of a window: recs[rec0 .. rec0 + n_records) */
+typedef struct { uint32_t tStart, tEnd, isReverse; float score; int32_t totalScore; uint32_t n_records, rec0; } lf_stage_win_t;
+typedef struct { uint32_t pos, posEnd, qStart, qEnd; int32_t flag, alnScore, nmCount; } lf_stage_rec_t;
+typedef struct { int n_reads; uint8_t *mode; uint32_t *win0; uint32_t n_wins; lf_stage_win_t *wins; uint32_t n_recs; lf_stage_rec_t *recs; } lf_stages_t;
+int  lf_map_stages_batch(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *seqs, lf_stages_t **out);
+void lf_stages_free(lf_stages_t *s);
 /* device memory for callers that do not link HIP themselves (a caller that does may pass any pointer hipMalloc gave it):
  * lf_device_copy takes host or device pointers on either side and is synchronous */
 void *lf_device_alloc(int device, size_t bytes);

@@ -353,6 +353,41 @@ class LordFast:
                                        C.byref(ln), C.byref(st)), "lf_map_batch_dev")
         return ln.value, st.as_dict()
 
+    def map_stages(self, seqs, params: Params | None = None):
+        """lf_map_stages_batch: per read {mode, wins (k,4) u32 [tStart,tEnd,isRev,score bits], maps int32 words
+        ({totalScore, n_records, 7 ints per record} per window)} -- the layout of tests/golden/stages_windows.npz"""
+        class Win(C.Structure):
+            _fields_ = [("tStart", C.c_uint32), ("tEnd", C.c_uint32), ("isReverse", C.c_uint32), ("score", C.c_float),
+                        ("totalScore", C.c_int32), ("n_records", C.c_uint32), ("rec0", C.c_uint32)]
+
+        class Rec(C.Structure):
+            _fields_ = [("pos", C.c_uint32), ("posEnd", C.c_uint32), ("qStart", C.c_uint32), ("qEnd", C.c_uint32),
+                        ("flag", C.c_int32), ("alnScore", C.c_int32), ("nmCount", C.c_int32)]
+
+        class Stages(C.Structure):
+            _fields_ = [("n_reads", C.c_int), ("mode", C.POINTER(C.c_uint8)), ("win0", C.POINTER(C.c_uint32)), ("n_wins", C.c_uint32),
+                        ("wins", C.POINTER(Win)), ("n_recs", C.c_uint32), ("recs", C.POINTER(Rec))]
+        p = params or default_params()
+        out = C.POINTER(Stages)()
+        self.L.lf_map_stages_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(Stages))]
+        self.L.lf_stages_free.argtypes = [C.POINTER(Stages)]
+        _check(self.L.lf_map_stages_batch(self.h, C.byref(p), len(seqs), _cstr_array(seqs), C.byref(out)), "lf_map_stages_batch")
+        S = out.contents
+        res = []
+        for i in range(S.n_reads):
+            wins, maps = [], []
+            for w in range(S.win0[i], S.win0[i + 1]):
+                W = S.wins[w]
+                wins.append([W.tStart, W.tEnd, W.isReverse, int(np.float32(W.score).view(np.uint32))])
+                maps += [W.totalScore, W.n_records]
+                for j in range(W.rec0, W.rec0 + W.n_records):
+                    R = S.recs[j]
+                    maps += [R.pos, R.posEnd, R.qStart, R.qEnd, R.flag, R.alnScore, R.nmCount]
+            res.append(dict(mode=int(S.mode[i]), wins=np.array(wins, dtype=np.uint32).reshape(-1, 4),
+                            maps=np.array(maps, dtype=np.int64).astype(np.int32)))
+        self.L.lf_stages_free(out)
+        return res
+
     def map_file(self, reads_path: str, out_path: str, params: Params | None = None, header: bool = True, cmdline: str = "",
                  batch_reads: int = 0):
         """reads file -> SAM file (lf_map_file): the reader runs ahead of the GPU.  -> stats dict"""

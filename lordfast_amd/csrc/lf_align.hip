@@ -35,18 +35,20 @@
  * traceback: ONE LANE PER PATH, for every problem of the one-block-per-lane forward kernel (lf_rsweep.hip: n <= 4096, below
  * edlib's Hirschberg switch -- which includes the leaves lf_hirsch.hip cuts the larger problems into).
  *
- * From (n, tl) the path is followed tile by tile: the tile = the K sweep steps around the current cell, of the ONE block the
- * cell is in.  The lane restores that block's checkpoint in front of the tile, replays the K block steps with the stored
- * carries as horizontal input, keeps (Pv, Ph) of the K columns in registers (the walk is unrolled over the columns) and walks
- * until the path leaves the tile or the block.  Work per path: ~(m / K + n / 64) tiles of K block steps.  Same cells, same
+ * From (n, tl) the path is followed tile by tile: a tile = the 16 sweep steps of one checkpoint row, of the ONE block the
+ * cell is in.  The lane restores that block's state in front of the tile (one 16-byte load), takes the 16 carries the block
+ * received (one 4-byte load) and the tile's 16 target symbols (one 8-byte load) -- all three in flight together, one round
+ * trip per tile -- and replays the tile in two halves of 8 columns, right half first: (Pv, Ph) of a half stay in registers
+ * (the walk is unrolled over its columns), the path is walked through it, then the left half is replayed from the same
+ * checkpoint.  The kernel waits for memory most of its time, so a checkpoint row per 16 steps (half the round trips, half the
+ * checkpoint traffic of the forward pass) is worth the 8 block steps that are replayed twice.  Same cells, same
  * Up -> Left -> Diagonal priority (lib/edlib/edlib.cpp:950,984,1015), same ops.
  * ---------------------------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(64)
-lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, const lf_hist_t *__restrict__ ckpt, uint8_t *__restrict__ ops,
+lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, int64_t pac_syms, const lf_hist_t *__restrict__ ckpt, uint8_t *__restrict__ ops,
                    const int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
 {
-    constexpr int K = LF_LANE_K;
-    constexpr bool PAC = true;                           /* targets are always 2-bit codes here (byte strings of the stage API are packed first) */
+    constexpr int K = LF_RSTEPS, HK = 8, ROW = LF_RROW;
     const int lane = threadIdx.x, idx = blockIdx.x * 64 + lane;
     const bool live = idx < n_probs;
     const lf_aln_prob pr = probs[live ? idx : n_probs - 1];
@@ -56,12 +58,12 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
     const uint32_t n = pr.n, m = pr.m;
     const bool want = live && pr.task == LF_TASK_PATH;
     const uint32_t tl = pr.mode == 0 ? m : (uint32_t)(out_end[pr.id] + 1);
+    const int dt = (pr.flags & LF_F_TREV) ? -1 : 1; const bool ct = (pr.flags & LF_F_TCOMP) != 0;
     /* where the forward kernel left this problem's data: the wave's planes, then its checkpoint rows; block b was lane lane0 + b */
     const lf_hist_t *wbase = ckpt + pr.hist_base;
     const uint64_t *planes = reinterpret_cast<const uint64_t *>(wbase);
     const int lane0 = (int)pr.pad;
     const lf_hist_t *ck = wbase + LF_PLANE_ENTRIES;
-    constexpr int ROW = 64 + 16;
 
     lf_emitter em; em.init(ops + pr.ops_off, n + m, want);
     uint32_t r = want ? n : 0, c = want ? tl : 0;
@@ -72,47 +74,50 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
     while (__any(r > 0 && c > 0)) {
         const bool act = r > 0 && c > 0;
         const uint32_t b = act ? (r - 1) >> 6 : 0;
-        /* the tile: K block steps of block b; step k works on column cbase + k */
+        /* the tile: the K steps of row j for block b; step k works on column cbase + k */
         const uint32_t j = !act ? 0 : (c - 1 + b) / K;
         const int cbase = (int)(j * K) - (int)b + 1;
-        /* what the tile needs from HBM -- the block's state in front of it, the carries entering it, its target symbols, the
-         * block's bit planes when the block changed -- is requested with UNCONDITIONAL loads from clamped addresses, so that
-         * all of them are in flight together (one round trip per tile) */
+        /* unconditional loads from clamped addresses: all in flight together */
         const uint32_t jm = j > 0 ? j - 1 : 0;
         const int ln = lane0 + (int)b;
         const lf_hist_t est = ck[(size_t)jm * ROW + ln];
-        const uint32_t craw = reinterpret_cast<const uint16_t *>(ck + (size_t)j * ROW + 64)[32 + ln];
-        const uint32_t tokp = T.pac_codes8((int64_t)cbase - 1, m);
-        /* lo / hi / valid are the planes of block b: loaded behind the walk that entered the block (below) */
-        uint64_t Pv = j > 0 ? est.pv : ~0ull, Mv = j > 0 ? est.ph : 0ull;      /* column 0 */
-        const uint32_t cw = b > 0 ? craw : 0x5555u;                            /* block 0: +1 enters every column */
-        /* replay: (Pv, Ph) of the tile's K columns stay in REGISTERS (statically indexed: the walk below is unrolled over the
-         * columns), no LDS round trip per move */
-        uint64_t tPv[K], tPh[K];
+        const uint32_t craw = reinterpret_cast<const uint32_t *>(ck + (size_t)j * ROW + 64)[16 + ln];
+        const uint32_t tok16 = lf_pac16(S.pac, pr.tstart + (int64_t)dt * ((int64_t)cbase - 1), dt, ct, pac_syms);
+        const uint64_t Pv0 = j > 0 ? est.pv : ~0ull, Mv0 = j > 0 ? est.ph : 0ull;      /* column 0 */
+        const uint32_t cw = b > 0 ? craw : 0x55555555u;                            /* block 0: +1 enters every column */
+        /* the two halves, right one first.  A half is replayed only when some path of the wavefront is in it. */
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            const int col = cbase + k;
-            const uint32_t tk = (tokp >> (2 * k)) & 3u;
-            const uint64_t Eq = lf_eq_tok<PAC>(tk, lo, hi, valid, qget, n, b);
-            uint64_t nPv = Pv, nMv = Mv, ph, mh;
-            (void)lf_myers_step(nPv, nMv, Eq, (cw >> (2 * k)) & 3u, ph, mh);
-            const bool v = col >= 1; Pv = v ? nPv : Pv; Mv = v ? nMv : Mv;       /* the block starts at column 1 */
-            tPv[k] = Pv; tPh[k] = ph;
-        }
-        /* walk: column by column from the right; inside a column only Up moves repeat */
-        if (act) {
-            const int cmin = cbase < 1 ? 1 : cbase;
+        for (int half = 1; half >= 0; half--) {
+            const int h0 = cbase + half * HK;                                   /* first column of the half */
+            const bool in_half = r > 0 && c > 0 && ((r - 1) >> 6) == b && (int)c >= h0 && (int)c < h0 + HK && (act);
+            if (!__any(in_half)) continue;
+            uint64_t Pv = Pv0, Mv = Mv0;
+            uint64_t tPv[HK], tPh[HK];
 #pragma unroll
-            for (int k = K - 1; k >= 0; k--) {
-                bool here = r > 0 && (int)c == cbase + k && (int)c >= cmin && ((r - 1) >> 6) == b;
-                while (here) {
-                    const int bit = (int)((r - 1) & 63);
-                    const uint32_t up = (uint32_t)(tPv[k] >> bit) & 1u, lf = ((uint32_t)(tPh[k] >> bit) & 1u) & ~up, dg = (up | lf) ^ 1u;
-                    uint32_t op = up ? 1u : (lf ? 2u : 0u);      /* Up -> Left -> Diagonal (lib/edlib/edlib.cpp:950,984,1015) */
-                    if (!lazy) { if (dg && Q.get(r - 1) != T.get(c - 1)) op = 3u; }
-                    em.put(op);
-                    r -= up | dg; c -= lf | dg;
-                    here = up != 0 && r > 0 && ((r - 1) >> 6) == b;      /* an Up move stays in the column (and maybe in the block) */
+            for (int k = 0; k < HK + half * HK; k++) {
+                const int col = cbase + k;
+                const uint32_t tk = (tok16 >> (2 * k)) & 3u;
+                const uint64_t Eq = lf_eq_tok<true>(tk, lo, hi, valid, qget, n, b);
+                uint64_t nPv = Pv, nMv = Mv, ph, mh;
+                (void)lf_myers_step(nPv, nMv, Eq, (cw >> (2 * k)) & 3u, ph, mh);
+                const bool v = col >= 1; Pv = v ? nPv : Pv; Mv = v ? nMv : Mv;       /* the block starts at column 1 */
+                if (k >= half * HK) { tPv[k - half * HK] = Pv; tPh[k - half * HK] = ph; }
+            }
+            /* walk: column by column from the right; inside a column only Up moves repeat */
+            if (in_half) {
+                const int cmin = h0 < 1 ? 1 : h0;
+#pragma unroll
+                for (int k = HK - 1; k >= 0; k--) {
+                    bool here = r > 0 && (int)c == h0 + k && (int)c >= cmin && ((r - 1) >> 6) == b;
+                    while (here) {
+                        const int bit = (int)((r - 1) & 63);
+                        const uint32_t up = (uint32_t)(tPv[k] >> bit) & 1u, lf = ((uint32_t)(tPh[k] >> bit) & 1u) & ~up, dg = (up | lf) ^ 1u;
+                        uint32_t op = up ? 1u : (lf ? 2u : 0u);      /* Up -> Left -> Diagonal (lib/edlib/edlib.cpp:950,984,1015) */
+                        if (!lazy) { if (dg && Q.get(r - 1) != T.get(c - 1)) op = 3u; }
+                        em.put(op);
+                        r -= up | dg; c -= lf | dg;
+                        here = up != 0 && r > 0 && ((r - 1) >> 6) == b;      /* an Up move stays in the column (and maybe in the block) */
+                    }
                 }
             }
         }
@@ -472,8 +477,8 @@ __host__ __device__ __forceinline__ uint32_t lf_class_key(const lf_aln_desc_t &x
     const uint32_t m16 = x.m < 0xffffu ? x.m : 0xffffu;
     return ((uint32_t)c << 28) | (c == 1 ? ((uint32_t)(x.mode ? 1u : 0u) << 23) | (((x.n + 63) >> 6) << 16) : 0u) | m16;
 }
-/* checkpoint entries of one rsweep wave: the planes, then one row per 8 steps (+ the partial last one) */
-__host__ __device__ __forceinline__ uint64_t lf_rwave_entries(uint32_t nb, uint32_t m_max) { return LF_PLANE_ENTRIES + (uint64_t)((m_max + nb - 1 + 7) / 8 + 1) * (uint32_t)lf_sweep_row(1); }
+/* checkpoint entries of one rsweep wave: the planes, then one row per 16 steps (+ the partial last one) */
+__host__ __device__ __forceinline__ uint64_t lf_rwave_entries(uint32_t nb, uint32_t m_max) { return LF_PLANE_ENTRIES + (uint64_t)((m_max + nb - 1 + LF_RSTEPS - 1) / LF_RSTEPS + 1) * (uint32_t)LF_RROW; }
 /* ... of a G 64 / KB wave (one problem) */
 __host__ __device__ __forceinline__ uint64_t lf_kbwave_entries(int kb, int k, uint32_t m) { return (((uint64_t)m + 64) / (uint32_t)k + 1) * (uint64_t)lf_sweep_row(kb); }
 
@@ -726,7 +731,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         RA.pac = D->d_pac; RA.pac_syms = D->pac_syms; RA.ckpt = d_hist; RA.out_ed = d_ed; RA.out_end = d_end;
         RA.wave0 = 0; RA.n_waves = nw_nw; lf_rsweep_launch(cs[1], false, RA);
         RA.wave0 = nw_nw; RA.n_waves = nw_shw; lf_rsweep_launch(cs[1], true, RA);
-        hipLaunchKernelGGL(lf_edlib_tb_kernel, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, d_hist, d_ops, d_end, d_len);
+        hipLaunchKernelGGL(lf_edlib_tb_kernel, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, D->pac_syms, d_hist, d_ops, d_end, d_len);
     }
     for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && cs[k] != s) { HIPCHK(hipEventRecord(cdone[k], cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
     if (n_roots) lf_hirsch_launch_stitch(s, HA, n_roots);      /* the roots' pieces move together once their leaves have paths */

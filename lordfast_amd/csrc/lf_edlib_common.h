@@ -163,6 +163,40 @@ __host__ __device__ __forceinline__ int lf_sweep_row(int kb) { return 64 * kb + 
 __host__ __device__ __forceinline__ uint64_t lf_lane_ck_off(int nb, uint32_t m_max) { return (uint64_t)nb * LF_PLANE_ENTRIES + (uint64_t)((m_max + 63) >> 6) * nb * 64; }
 
 
+/* sixteen target symbols x0, x0 + dir, ... as one word, symbol k at bits [2k + 1 : 2k].  A lane that has not reached column 1
+ * yet asks for positions in front of its target; where those lie outside the array (the first / last symbols of the
+ * reference, the first problem of an uploaded buffer) the window is taken at the array's edge and shifted, so that the
+ * symbols that do exist keep their places. */
+__device__ __forceinline__ uint32_t lf_pac16(const uint8_t *__restrict__ pac, int64_t x0, int dir, bool comp, int64_t n_syms)
+{
+    int64_t xs = x0; uint32_t pre = 0;
+    uint32_t v;
+    if (dir > 0) {
+        if (xs < 0) { pre = (uint32_t)(-xs); xs = 0; }
+        if (xs > n_syms - 1) xs = n_syms - 1;                 /* past the end: every column of the window is past the target's end too */
+        uint64_t raw; __builtin_memcpy(&raw, pac + (xs >> 2), 8);
+        uint64_t B = __builtin_bswap64(raw);                  /* symbol order = bit order, first symbol on top */
+        B <<= 2 * (uint32_t)(xs & 3);
+        uint32_t r = __brev((uint32_t)(B >> 32));              /* first symbol at the bottom, the two bits of each symbol swapped */
+        v = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+    } else {
+        if (xs > n_syms - 1) { pre = (uint32_t)(xs - (n_syms - 1)); xs = n_syms - 1; }
+        if (xs < 0) xs = 0;
+        int64_t xl = xs - 15; if (xl < 0) xl = 0;
+        const int64_t byteL = xl >> 2;
+        uint64_t raw; __builtin_memcpy(&raw, pac + byteL, 8);
+        const uint64_t B = __builtin_bswap64(raw);
+        v = (uint32_t)(B >> (62 - 2 * (uint32_t)(xs - 4 * byteL)));      /* symbol xs at the bottom, xs - 1 above it, ... */
+    }
+    v = pre >= 16 ? 0u : v << (2 * pre);
+    return comp ? ~v : v;
+}
+
+/* checkpoint row of the one-block-per-lane forward kernel (lf_rsweep.hip), in 16-byte entries: 64 x (Pv, Mv), 64 carry bytes,
+ * 64 x u32 received carries.  One row per 16 sweep steps. */
+#define LF_RROW 84
+#define LF_RSTEPS 16
+
 /* lane l receives lane l-1's value (lane 0: 0): the horizontal carry of the anti-diagonal sweeps.  DPP wave_shr:1 is a
  * VALU move; __shfl_up goes through the LDS crossbar (ds_bpermute) and sits on the per-step dependency chain. */
 __device__ __forceinline__ uint32_t lf_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }

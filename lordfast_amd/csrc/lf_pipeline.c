@@ -254,6 +254,7 @@ typedef struct ctx {
     const char *const *len_seqs; uint32_t *len_out; volatile int len_bad;
     int *seed_map; char *cat; uint64_t *cat_off;
     const unsigned char *d_seqs, *d_quals;      /* lf_map_batch_dev: the caller's device blobs (NULL: host strings) */
+    int32_t **stage_sink; int stage_i0;          /* lf_map_stages_batch: per read (batch index stage_i0 + ri) its decision, windows and alignWin results */
 } ctx_t;
 
 /* ---------------------------------------------------------------- parallel for on a persistent thread pool
@@ -1604,8 +1605,26 @@ static void phase_sam_score(ctx_t *cx, int tid, int ri)
 {
     (void)tid;
     rd_t *r = &cx->reads[ri];
-    if (r->mode < 2) { r->maps = (samlist_t *)ar_zalloc(&cx->arena[tid], 2 * sizeof(samlist_t)); return; }
+    if (r->mode < 2) {
+        r->maps = (samlist_t *)ar_zalloc(&cx->arena[tid], 2 * sizeof(samlist_t));
+        if (cx->stage_sink) { int32_t *o = (int32_t *)malloc(8); o[0] = r->mode; o[1] = 0; cx->stage_sink[cx->stage_i0 + ri] = o; }
+        return;
+    }
     for (int w = 0; w < r->nWins; w++) score_mapping(cx->p, &r->maps[w], r->wins[w].isReverse, r->len, r->jobs[w].chainLen);
+    if (cx->stage_sink) {
+        /* the stage view (lf_map_stages_batch): what mapSeq holds between alignWin and the sort / print (src/LordFAST.cpp:547, :561):
+         * { mode, n_wins, then per window tStart, tEnd, isReverse, score bits, totalScore, n_records, 7 ints per record } */
+        size_t words = 2;
+        for (int w = 0; w < r->nWins; w++) words += 6 + 7 * (size_t)r->maps[w].n;
+        int32_t *o = (int32_t *)malloc(words * 4); size_t k = 0;
+        o[k++] = r->mode; o[k++] = r->nWins;
+        for (int w = 0; w < r->nWins; w++) {
+            const win_t *wn = &r->wins[w]; const samlist_t *m = &r->maps[w];
+            o[k++] = (int32_t)wn->tStart; o[k++] = (int32_t)wn->tEnd; o[k++] = wn->isReverse; memcpy(&o[k++], &wn->score, 4); o[k++] = m->totalScore; o[k++] = m->n;
+            for (int j = 0; j < m->n; j++) { const sam_t *x = &m->v[j]; o[k++] = (int32_t)x->pos; o[k++] = (int32_t)x->posEnd; o[k++] = (int32_t)x->qStart; o[k++] = (int32_t)x->qEnd; o[k++] = x->flag; o[k++] = x->alnScore; o[k++] = x->nmCount; }
+        }
+        cx->stage_sink[cx->stage_i0 + ri] = o;
+    }
     if (r->mode == 3) samsort_sort(r->maps, r->nWins);                     /* std::sort(compareSam) :565 */
 }
 static void phase_sam_print(ctx_t *cx, int tid, int ri)
@@ -2047,6 +2066,7 @@ typedef struct {
     const lf_params_t *p;
     const char *const *names, *const *seqs, *const *quals; const uint32_t *lens;
     const unsigned char *d_seqs, *d_quals; const uint64_t *src_off; int dev_out;     /* lf_map_batch_dev: bases / qualities / SAM text in HBM */
+    int32_t **stage_sink;                       /* lf_map_stages_batch */
     int slots;                                  /* per-worker scratch slots = pool workers + 2 drivers */
     chunk_t *chunks; int n_chunks, n_chunks0; volatile int next_chunk;   /* n_chunks0: entries cut up front; n_chunks grows when a lane cuts a chunk */
     pthread_mutex_t mu; pthread_cond_t cv;      /* chunk sizes become known in any order */
@@ -2158,7 +2178,7 @@ static void *lane_main(void *arg_)
         cx.max_chunk_hits = max_hits;
         cx.dev_sam = !B->host_cigar && !B->host_vote && !getenv("LF_HOST_SAM");
         cx.sam_parity = parity;
-        cx.d_seqs = B->d_seqs; cx.d_quals = B->d_quals;
+        cx.d_seqs = B->d_seqs; cx.d_quals = B->d_quals; cx.stage_sink = B->stage_sink; cx.stage_i0 = C->i0;
         cx.n_reads = C->i1 - C->i0;
         cx.reads = (rd_t *)calloc((size_t)cx.n_reads, sizeof(rd_t));
         uint64_t chunk_bases = 0;
@@ -2268,13 +2288,13 @@ static void *wdog_main(void *arg)
     return NULL;
 }
 
-typedef struct { const void *d_seqs, *d_quals; const uint64_t *seq_off; int dev_out; } devio_t;
+typedef struct { const void *d_seqs, *d_quals; const uint64_t *seq_off; int dev_out; int32_t **stage_sink; } devio_t;
 static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_params_t *p, int n, const char *const *names,
                           const char *const *seqs, const char *const *quals, const uint32_t *seq_lens, char *ext_buf, size_t ext_cap,
                           char **sam, size_t *sam_len, lf_stats_t *stats, const devio_t *dio)
 {
     if (!ixs || n_ix < 1 || n_ix > 16 || !p || n < 0 || (!sam && !ext_buf)) { lf_set_error("lf_map_batch: bad argument"); return LF_ERR_ARG; }
-    if (dio && (n_ix != 1 || !dio->d_seqs || !dio->seq_off || !seq_lens || !ext_buf || getenv("LF_HOST_VOTE") || getenv("LF_HOST_CIGAR") || getenv("LF_HOST_SAM") || getenv("LF_HOST_WALK"))) {
+    if (dio && !dio->stage_sink && (n_ix != 1 || !dio->d_seqs || !dio->seq_off || !seq_lens || !ext_buf || getenv("LF_HOST_VOTE") || getenv("LF_HOST_CIGAR") || getenv("LF_HOST_SAM") || getenv("LF_HOST_WALK"))) {
         lf_set_error("lf_map_batch_dev: needs one index, device bases with offsets and lengths, an output buffer, and none of the LF_HOST_* cross-check modes"); return LF_ERR_ARG;
     }
     for (int d = 0; d < n_ix; d++) {
@@ -2333,7 +2353,8 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     B.host_cigar = getenv("LF_HOST_CIGAR") != NULL;
     B.host_vote = getenv("LF_HOST_VOTE") != NULL;          /* diagnostic cross-check only; the device stage is the product path */
     B.ixs = ixs; B.n_ix = n_ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + n_lanes; B.rc = LF_OK;
-    if (dio) { B.d_seqs = (const unsigned char *)dio->d_seqs; B.d_quals = (const unsigned char *)dio->d_quals; B.src_off = dio->seq_off; B.dev_out = dio->dev_out; }
+    if (dio && dio->stage_sink) B.stage_sink = dio->stage_sink;
+    else if (dio) { B.d_seqs = (const unsigned char *)dio->d_seqs; B.d_quals = (const unsigned char *)dio->d_quals; B.src_off = dio->seq_off; B.dev_out = dio->dev_out; }
     pthread_mutex_init(&B.mu, NULL); pthread_cond_init(&B.cv, NULL); pthread_rwlock_init(&B.grow, NULL);
     if (ext_buf) { B.all.s = ext_buf; B.all.cap = ext_cap; B.all.n = 0; B.all.mode = 2; B.fixed_out = 1; }
     else str_init(&B.all);
@@ -2347,7 +2368,7 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
             /* a wrong length would make the device read past a string: the terminator of every read is checked (best effort: the
              * check itself trusts lens[i] to stay inside the caller's allocation) */
             int bad = -1;
-            if (!dio) { c0.len_bad = -1; parallel_for(&c0, n, phase_checklen); bad = c0.len_bad; }      /* one cold cache line per read: all workers */
+            if (!dio || dio->stage_sink) { c0.len_bad = -1; parallel_for(&c0, n, phase_checklen); bad = c0.len_bad; }      /* one cold cache line per read: all workers */
             if (bad >= 0) { const int i = bad;
                 lf_set_error("lf_map_batch_into_lens: seq_lens[%d] = %u is not the length of seqs[%d]", i, lens[i], i);
                 free(lens); pthread_rwlock_destroy(&B.grow); pthread_mutex_destroy(&B.mu); pthread_cond_destroy(&B.cv);
@@ -2451,9 +2472,51 @@ int lf_map_batch_dev(const lf_index_t *ix, const lf_params_t *p, int n, const ch
                      int out_is_device, size_t *sam_len, lf_stats_t *stats)
 {
     if (!out || out_cap < 2) { lf_set_error("lf_map_batch_dev: no output buffer"); return LF_ERR_ARG; }
-    devio_t dio; dio.d_seqs = d_seqs; dio.d_quals = d_quals; dio.seq_off = seq_off; dio.dev_out = out_is_device != 0;
+    devio_t dio; dio.d_seqs = d_seqs; dio.d_quals = d_quals; dio.seq_off = seq_off; dio.dev_out = out_is_device != 0; dio.stage_sink = NULL;
     return map_batch_core(&ix, 1, p, n, names, NULL, NULL, seq_lens, (char *)out, out_cap, NULL, sam_len, stats, &dio);
 }
+
+/* Stage view of mapSeq for a batch (the reference's findTopWins_coarse / _fine and alignWin are only visible through the SAM
+ * records; this entry point shows what lies between them): per read the decision, the windows alignWin is called with --
+ * coarse: the best window; fine: the heap array of src/LordFAST.cpp:553-562 in array order -- and per window alignWin's
+ * totalScore and records (before the sort and MAPQ of printSamEntry).  Same kernels, same host glue as lf_map_batch. */
+int lf_map_stages_batch(const lf_index_t *ix, const lf_params_t *p, int n, const char *const *seqs, lf_stages_t **out)
+{
+    if (!out || n < 0) { lf_set_error("lf_map_stages_batch: bad argument"); return LF_ERR_ARG; }
+    *out = NULL;
+    int32_t **sink = (int32_t **)calloc((size_t)n + 1, sizeof(int32_t *));
+    const char **names = (const char **)malloc(((size_t)n + 1) * sizeof(char *));
+    for (int i = 0; i < n; i++) names[i] = "r";
+    devio_t dio; memset(&dio, 0, sizeof dio); dio.stage_sink = sink;
+    char *sam = NULL; size_t sl = 0;
+    const int rc = map_batch_core(&ix, 1, p, n, names, seqs, NULL, NULL, NULL, 0, &sam, &sl, NULL, &dio);
+    free(sam); free(names);
+    if (rc != LF_OK) { for (int i = 0; i < n; i++) free(sink[i]); free(sink); return rc; }
+    lf_stages_t *S = (lf_stages_t *)calloc(1, sizeof *S);
+    S->n_reads = n; S->mode = (uint8_t *)calloc((size_t)n + 1, 1); S->win0 = (uint32_t *)calloc((size_t)n + 2, 4);
+    size_t nw = 0, nr = 0;
+    for (int i = 0; i < n; i++) if (sink[i]) { const int32_t *o = sink[i]; size_t k = 2; for (int w = 0; w < o[1]; w++) { nr += (size_t)o[k + 5]; k += 6 + 7 * (size_t)o[k + 5]; } nw += (size_t)o[1]; }
+    S->wins = (lf_stage_win_t *)calloc(nw + 1, sizeof(lf_stage_win_t)); S->recs = (lf_stage_rec_t *)calloc(nr + 1, sizeof(lf_stage_rec_t));
+    nw = 0; nr = 0;
+    for (int i = 0; i < n; i++) {
+        S->win0[i] = (uint32_t)nw;
+        if (!sink[i]) continue;
+        const int32_t *o = sink[i]; size_t k = 2;
+        S->mode[i] = (uint8_t)o[0];
+        for (int w = 0; w < o[1]; w++) {
+            lf_stage_win_t *W = &S->wins[nw++];
+            W->tStart = (uint32_t)o[k]; W->tEnd = (uint32_t)o[k + 1]; W->isReverse = (uint32_t)o[k + 2]; memcpy(&W->score, &o[k + 3], 4); W->totalScore = o[k + 4]; W->n_records = (uint32_t)o[k + 5]; W->rec0 = (uint32_t)nr;
+            k += 6;
+            for (uint32_t j = 0; j < W->n_records; j++, k += 7) { lf_stage_rec_t *R = &S->recs[nr++]; R->pos = (uint32_t)o[k]; R->posEnd = (uint32_t)o[k + 1]; R->qStart = (uint32_t)o[k + 2]; R->qEnd = (uint32_t)o[k + 3]; R->flag = o[k + 4]; R->alnScore = o[k + 5]; R->nmCount = o[k + 6]; }
+        }
+        free(sink[i]);
+    }
+    S->win0[n] = (uint32_t)nw; S->n_wins = (uint32_t)nw; S->n_recs = (uint32_t)nr;
+    free(sink);
+    *out = S;
+    return LF_OK;
+}
+void lf_stages_free(lf_stages_t *S) { if (!S) return; free(S->mode); free(S->win0); free(S->wins); free(S->recs); free(S); }
 
 /* one batch over SEVERAL devices of this process: idx[d] is a replica of the same index on its own device
  * (lf_index_load(prefix, device d, ...)).  The batch is cut into chunks that the devices' lanes pull from one counter

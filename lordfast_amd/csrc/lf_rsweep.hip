@@ -21,25 +21,30 @@
  *   - the step loop is unrolled over 16 steps (two checkpoint rows): symbol extraction, shifts and checkpoint addresses are
  *     immediates; ~45 instructions per block step (sweep kernels of round 2: ~80), ~50 registers: 8 wavefronts per SIMD.
  *
- * Output: distance / end column, and -- for lf_edlib_tb_kernel, one lane per path -- the same checkpoint rows the KB = 1
- * sweep classes wrote: (Pv, Mv) of every lane every 8 steps, the pending carry, the two-bit carries received during the row.
+ * Output: distance / end column, and -- for lf_edlib_tb_kernel, one lane per path -- the wave's planes and one checkpoint row
+ * per 16 steps: (Pv, Mv) of every lane, the pending carry, the 16 two-bit carries the lane received during the row.
  */
 #include "lf_edlib_common.h"
 #include "lf_rsweep.h"
 
 /* ---- read batch -> bit planes: bit i of word (i >> 6) describes base i.  A wavefront transposes 64 x 64 bases through ballots. ---- */
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 lf_pack_planes_kernel(const unsigned char *__restrict__ src, uint64_t n, uint64_t *__restrict__ lo, uint64_t *__restrict__ hi, uint64_t *__restrict__ valid, uint64_t n_words)
 {
-    const int lane = threadIdx.x;
-    const uint64_t w0 = (uint64_t)blockIdx.x * 64;                 /* first of this wavefront's 64 words */
+    const int lane = threadIdx.x & 63;
+    const uint64_t w0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;                 /* first of this wavefront's 64 words */
     uint64_t mlo = 0, mhi = 0, mv = 0;
-    for (int i = 0; i < 64; i++) {
-        const uint64_t p = (w0 + (uint64_t)i) * 64 + (uint64_t)lane;
-        bool ok = false; uint32_t cd = 0;
-        if (p < n) cd = lf_code_upper(src[p], ok);
-        const uint64_t bl = __ballot(ok && (cd & 1u)), bh = __ballot(ok && (cd & 2u)), bv = __ballot(ok);
-        if (lane == i) { mlo = bl; mhi = bh; mv = bv; }
+    /* eight rows of 64 bases are requested together (their latency is paid once per eight), then balloted */
+    for (int i0 = 0; i0 < 64; i0 += 8) {
+        unsigned char ch[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint64_t p = (w0 + (uint64_t)(i0 + u)) * 64 + (uint64_t)lane; ch[u] = p < n ? src[p] : (unsigned char)0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            bool ok; const uint32_t cd = lf_code_upper(ch[u], ok);
+            const uint64_t bl = __ballot(ok && (cd & 1u)), bh = __ballot(ok && (cd & 2u)), bv = __ballot(ok);
+            if (lane == i0 + u) { mlo = bl; mhi = bh; mv = bv; }
+        }
     }
     const uint64_t w = w0 + (uint64_t)lane;
     if (w < n_words) { lo[w] = mlo; hi[w] = mhi; valid[w] = mv; }
@@ -75,40 +80,10 @@ __device__ __forceinline__ uint64_t lf_bits64(const uint64_t *__restrict__ a, in
 }
 __device__ __forceinline__ uint64_t lf_brev64(uint64_t x) { return ((uint64_t)__brev((uint32_t)x) << 32) | (uint64_t)__brev((uint32_t)(x >> 32)); }
 
-/* sixteen target symbols x0, x0 + dir, ... as one word, symbol k at bits [2k + 1 : 2k].  A lane that has not reached column 1
- * yet asks for positions in front of its target; where those lie outside the array (the first / last symbols of the
- * reference, the first problem of an uploaded buffer) the window is taken at the array's edge and shifted, so that the
- * symbols that do exist keep their places. */
-__device__ __forceinline__ uint32_t lf_pac16(const uint8_t *__restrict__ pac, int64_t x0, int dir, bool comp, int64_t n_syms)
-{
-    int64_t xs = x0; uint32_t pre = 0;
-    uint32_t v;
-    if (dir > 0) {
-        if (xs < 0) { pre = (uint32_t)(-xs); xs = 0; }
-        if (xs > n_syms - 1) xs = n_syms - 1;                 /* past the end: every column of the window is past the target's end too */
-        uint64_t raw; __builtin_memcpy(&raw, pac + (xs >> 2), 8);
-        uint64_t B = __builtin_bswap64(raw);                  /* symbol order = bit order, first symbol on top */
-        B <<= 2 * (uint32_t)(xs & 3);
-        uint32_t r = __brev((uint32_t)(B >> 32));              /* first symbol at the bottom, the two bits of each symbol swapped */
-        v = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
-    } else {
-        if (xs > n_syms - 1) { pre = (uint32_t)(xs - (n_syms - 1)); xs = n_syms - 1; }
-        if (xs < 0) xs = 0;
-        int64_t xl = xs - 15; if (xl < 0) xl = 0;
-        const int64_t byteL = xl >> 2;
-        uint64_t raw; __builtin_memcpy(&raw, pac + byteL, 8);
-        const uint64_t B = __builtin_bswap64(raw);
-        v = (uint32_t)(B >> (62 - 2 * (uint32_t)(xs - 4 * byteL)));      /* symbol xs at the bottom, xs - 1 above it, ... */
-    }
-    v = pre >= 16 ? 0u : v << (2 * pre);
-    return comp ? ~v : v;
-}
-
 template <bool TRACK>
 __global__ void __launch_bounds__(64)
 lf_edlib_rsweep_kernel(lf_rsw_args A)
 {
-    constexpr int ROW = 64 + 16;                       /* lf_sweep_row(1): 64 x (Pv, Mv), 64 carry bytes, 64 x u16 received carries */
     __shared__ uint64_t s_peq[4 * 64];
     __shared__ int s_part[64];
     const int lane = threadIdx.x;
@@ -163,7 +138,7 @@ lf_edlib_rsweep_kernel(lf_rsw_args A)
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const uint32_t from_left = lf_wave_shr1(hout);
-            cw |= from_left << (2 * (k & 7));
+            cw |= from_left << (2 * k);
             const uint32_t col0 = (uint32_t)((int)p + k);            /* column - 1; wraps for lanes that have not started */
             if (mine && col0 < m) {
                 const uint32_t sym = (V >> (2 * k)) & 3u;
@@ -176,12 +151,13 @@ lf_edlib_rsweep_kernel(lf_rsw_args A)
                     const bool upd = is_last && score < best; best = upd ? score : best; best_c = upd ? (int)col0 + 1 : best_c;
                 }
             }
-            if ((k & 7) == 7) {
-                const int s = s0 + k;
-                if (any_ck && s < ((steps_max + 7) & ~7)) {
-                    lf_hist_t *row = ck + (size_t)(s >> 3) * ROW;
+            if (k == 15) {
+                /* one checkpoint row per 16 steps: (Pv, Mv) of every lane, the pending carry, the 16 two-bit carries the lane received */
+                const int s = s0 + 15;
+                if (any_ck && s < ((steps_max + 15) & ~15)) {
+                    lf_hist_t *row = ck + (size_t)(s >> 4) * LF_RROW;
                     if (s < steps_max) { lf_hist_t e; e.pv = Pv; e.ph = Mv; row[lane] = e; reinterpret_cast<unsigned char *>(row + 64)[lane] = (unsigned char)hout; }
-                    reinterpret_cast<uint16_t *>(row + 64)[32 + lane] = (uint16_t)cw;
+                    reinterpret_cast<uint32_t *>(row + 64)[16 + lane] = cw;
                 }
                 cw = 0;
             }
@@ -210,7 +186,7 @@ lf_edlib_rsweep_kernel(lf_rsw_args A)
 void lf_rsweep_pack_planes(hipStream_t s, const unsigned char *d_src, uint64_t n_bytes, uint64_t *d_planes, uint64_t n_words)
 {
     if (!n_words) return;
-    hipLaunchKernelGGL(lf_pack_planes_kernel, dim3((unsigned)((n_words + 63) / 64)), dim3(64), 0, s, d_src, n_bytes, d_planes, d_planes + n_words, d_planes + 2 * n_words, n_words);
+    hipLaunchKernelGGL(lf_pack_planes_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, d_src, n_bytes, d_planes, d_planes + n_words, d_planes + 2 * n_words, n_words);
 }
 void lf_rsweep_pack_pac(hipStream_t s, const unsigned char *d_src, uint64_t n_bytes, uint8_t *d_pac)
 {

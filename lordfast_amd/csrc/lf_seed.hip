@@ -370,7 +370,8 @@ __global__ void lf_read_first_hit_kernel(int n_reads, uint32_t hash_count, const
 }
 
 /* device-resident input (lf_map_batch_dev): read k = src[src_off[k] .. + off[k + 1] - off[k]) -> the lane's resident batch at off[k].
- * One workgroup per 4 KiB piece of a read; byte granular (neither side is aligned), the L2 merges the lanes' bytes. */
+ * A workgroup copies 8 bytes per lane and trip (neither side is aligned: unaligned 8-byte accesses are legal on global
+ * memory), the last bytes of a read one by one. */
 __global__ void __launch_bounds__(256)
 lf_reads_gather_kernel(const unsigned char *__restrict__ src, const uint64_t *__restrict__ src_off, const uint64_t *__restrict__ off,
                        int n_reads, unsigned char *__restrict__ dst)
@@ -379,7 +380,12 @@ lf_reads_gather_kernel(const unsigned char *__restrict__ src, const uint64_t *__
     if (k >= n_reads) return;
     const uint64_t o = off[k], len = off[k + 1] - o;
     const unsigned char *s = src + src_off[k];
-    for (uint64_t i = (uint64_t)blockIdx.y * 256 + threadIdx.x; i < len; i += (uint64_t)gridDim.y * 256) dst[o + i] = s[i];
+    unsigned char *d = dst + o;
+    const uint64_t words = len >> 3;
+    for (uint64_t i = (uint64_t)blockIdx.y * 256 + threadIdx.x; i < words; i += (uint64_t)gridDim.y * 256) {
+        uint64_t w; __builtin_memcpy(&w, s + 8 * i, 8); __builtin_memcpy(d + 8 * i, &w, 8);
+    }
+    if (blockIdx.y == 0 && threadIdx.x < (len & 7)) d[8 * words + threadIdx.x] = s[8 * words + threadIdx.x];
 }
 extern "C" int lfg_gather_reads(int device, void *stream, const void *d_src, const uint64_t *d_src_off, const uint64_t *d_off, int n_reads, void *d_dst)
 {

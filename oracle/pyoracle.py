@@ -232,6 +232,29 @@ class Ref:
         self.L.ref_seed(buf, len(seq), p.sampling_count, F.ctypes.data, C.byref(nF), R.ctypes.data, C.byref(nR))
         return F[:nF.value].copy(), R[:nR.value].copy()
 
+    def stage_windows(self, seqs):
+        """the reference's own findTopWins_coarse / _fine + alignWin per read (ref_harness.cpp: ref_stage_windows).
+        -> list of dicts: mode, coarse (k,4) u32 [tStart,tEnd,isRev,score bits], wins (k,4) u32, maps int32 words
+        ({totalScore, n_records, 7 ints per record} per window)"""
+        p = self.params
+        L = self.L
+        L.ref_stage_windows.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int), C.c_void_p,
+                                        C.POINTER(C.c_int), C.c_void_p, C.c_int]
+        out = []
+        L.ref_stage_begin()
+        try:
+            for sq in seqs:
+                coarse = np.zeros((p.max_map + 1, 4), dtype=np.uint32); wins = np.zeros((p.max_map + 1, 4), dtype=np.uint32)
+                maps = np.zeros(1 << 16, dtype=np.int32)
+                mode, nc, nw = C.c_int(), C.c_int(), C.c_int()
+                buf = C.create_string_buffer(sq + b"\0" * 64)
+                words = L.ref_stage_windows(buf, len(sq), C.byref(mode), coarse.ctypes.data, C.byref(nc), wins.ctypes.data, C.byref(nw),
+                                            maps.ctypes.data, maps.size)
+                out.append(dict(mode=mode.value, coarse=coarse[:nc.value].copy(), wins=wins[:nw.value].copy(), maps=maps[:words].copy()))
+        finally:
+            L.ref_stage_end()
+        return out
+
     def chain_n2(self, seeds: np.ndarray):
         s = np.ascontiguousarray(seeds, dtype=np.uint32).copy()
         n = len(s)

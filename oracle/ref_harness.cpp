@@ -202,6 +202,88 @@ int ref_ksw_extend2(int qlen, const uint8_t *q, int tlen, const uint8_t *t, int 
     return ksw_extend2(qlen, q, tlen, t, 5, mat, o_del, e_del, o_ins, e_ins, w, 0, zdrop, h0, qle, tle, 0, 0, 0);
 }
 
+/* ---- the window stage and alignWin as mapSeq drives them (src/LordFAST.cpp:507-561): the reference's own non-static
+ * functions on its own per-thread globals (thread 0).  ref_stage_begin / _end bracket a session (initializeFAST allocates
+ * the per-thread arrays; its output goes to /dev/null). ---- */
+} /* extern "C" */
+extern SeedList *_pf_seedsForward, *_pf_seedsReverse;
+extern WinList *_pf_topWins;
+extern MapInfo *_pf_topMappings;
+extern int _pf_seqListSize;
+void findTopWins_coarse(uint32_t read_len, SeedList *seeds, int isRev, int readIdx, int id);
+void findTopWins_fine(uint32_t read_len, SeedList *seeds, int isRev, int readIdx, float minScore, int id);
+void alignWin(Win_t &win, char *query, char *query_rev, uint32_t rLen, char *qual, char *qual_rev, SamList_t &map, int id);
+bool compareWin(const Win_t &w1, const Win_t &w2);
+#include <algorithm>
+extern "C" {
+
+static int g_stage_t = 0;
+void ref_stage_begin(void)
+{
+    noSamHeader = 1; strcpy(outputMap, "/dev/null");
+    THREAD_COUNT = 1;
+    initializeFAST();
+    _pf_seqListSize = 1 << 20;            /* the tag of fine-mode votes is t + _pf_seqListSize + 1 (src/LordFAST.cpp:554) */
+    /* g_stage_t keeps counting across sessions: the vote array is tagged with the read number (:596-610) and a later
+     * initializeFAST may get the previous session's memory back un-zeroed -- a repeated tag would add to stale counts */
+}
+void ref_stage_end(void) { finalizeFAST(); }
+
+static void put_win(uint32_t *o, const Win_t &w) { o[0] = w.tStart; o[1] = w.tEnd; o[2] = w.isReverse; memcpy(&o[3], &w.score, 4); }
+
+/* one read.  mode: 1 no window, 2 coarse, 3 fine.  coarse[4 * k]: the windows after std::sort_heap (:528); wins[4 * k]: the
+ * windows alignWin is called with (coarse: the first one; fine: the heap array of :553-562, in array order); maps: per such
+ * window { totalScore, n_records, then per record pos, posEnd, qStart, qEnd, flag, alnScore, nmCount }.  Returns words in maps. */
+int ref_stage_windows(const char *seq, uint32_t len, int *mode, uint32_t *coarse, int *n_coarse, uint32_t *wins, int *n_wins, int32_t *maps, int maps_cap)
+{
+    const int id = 0, t = g_stage_t++;
+    *mode = 0; *n_coarse = 0; *n_wins = 0;
+    if ((int)len < MIN_READ_LEN) return 0;
+    std::vector<char> fwd(seq, seq + len + 1), rev(len + 1), qrev(2);
+    fwd[len] = 0;
+    reverseComplement(fwd.data(), rev.data(), len);
+    char qual[2] = "*"; qrev[0] = '*'; qrev[1] = 0;
+    getLocs_extend_whole_step(fwd.data(), len, SAMPLING_COUNT, _pf_seedsForward + id, _pf_seedsReverse + id);
+    _pf_topWins[id].num = 0;
+    findTopWins_coarse(len, _pf_seedsForward + id, 0, t + 1, id);
+    findTopWins_coarse(len, _pf_seedsReverse + id, 1, -(t + 1), id);
+    if (_pf_topWins[id].num == 0) { *mode = 1; return 0; }
+    std::sort_heap(_pf_topWins[id].list, _pf_topWins[id].list + _pf_topWins[id].num, compareWin);
+    *n_coarse = (int)_pf_topWins[id].num;
+    for (uint32_t k = 0; k < _pf_topWins[id].num; k++) put_win(coarse + 4 * k, _pf_topWins[id].list[k]);
+    const float scoreRatio = 4;
+    int nw = 0, words = 0;
+    auto dump = [&](SamList_t &m) {
+        if (words + 2 + 7 * (int)m.samList.size() > maps_cap) return;
+        maps[words++] = m.totalScore; maps[words++] = (int)m.samList.size();
+        for (const Sam_t &r : m.samList) { maps[words++] = (int32_t)r.pos; maps[words++] = (int32_t)r.posEnd; maps[words++] = (int32_t)r.qStart; maps[words++] = (int32_t)r.qEnd; maps[words++] = r.flag; maps[words++] = r.alnScore; maps[words++] = r.nmCount; }
+    };
+    /* a single candidate is compared with a stale slot in the reference (list[1] of an earlier read); both branches align the
+     * same window then, so the harness reports the coarse branch for num == 1 */
+    if (_pf_topWins[id].num == 1 || _pf_topWins[id].list[0].score >= scoreRatio * _pf_topWins[id].list[1].score) {
+        *mode = 2;
+        _pf_topMappings[id].mappings[0].samList.clear();
+        alignWin(_pf_topWins[id].list[0], fwd.data(), rev.data(), len, qual, qrev.data(), _pf_topMappings[id].mappings[0], id);
+        put_win(wins, _pf_topWins[id].list[0]); nw = 1;
+        dump(_pf_topMappings[id].mappings[0]);
+    } else {
+        *mode = 3;
+        _pf_topWins[id].num = 0;
+        const float tmp_minScore = (float)_pf_topWins[id].list[0].score / scoreRatio;
+        findTopWins_fine(len, _pf_seedsForward + id, 0, t + _pf_seqListSize + 1, tmp_minScore, id);
+        findTopWins_fine(len, _pf_seedsReverse + id, 1, -(t + _pf_seqListSize + 1), tmp_minScore, id);
+        for (uint32_t i = 0; i < _pf_topWins[id].num; i++) {
+            _pf_topMappings[id].mappings[i].samList.clear();
+            alignWin(_pf_topWins[id].list[i], fwd.data(), rev.data(), len, qual, qrev.data(), _pf_topMappings[id].mappings[i], id);
+            put_win(wins + 4 * i, _pf_topWins[id].list[i]);
+            dump(_pf_topMappings[id].mappings[i]);
+        }
+        nw = (int)_pf_topWins[id].num;
+    }
+    *n_wins = nw;
+    return words;
+}
+
 void ref_pac2char(uint32_t beg, uint32_t len, char *out) { bwt_str_pac2char(beg, len, out); }
 
 void ref_chr_boundaries(uint64_t beg, uint64_t end, uint32_t *cb, uint32_t *ce) { bwt_get_chr_boundaries(beg, end, cb, ce); }

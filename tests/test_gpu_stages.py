@@ -1,5 +1,7 @@
 """GPU parity, stage level: lf_edlib_batch / lf_chain_n2_batch / lf_ksw_extend2_batch (HIP, through the
 C ABI) vs the golden vectors produced by the real reference, and vs the oracle on seeded random inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -228,3 +230,36 @@ def test_ksw_golden_and_fuzz(stages, oracle_lib):
     res = la.ksw_extend2_batch(qs, ts, prms)
     for i, r in enumerate(res):
         assert tuple(r) == tuple(orc.ksw_extend2(qs[i], ts[i], *prms[i])), (i, len(qs[i]), len(ts[i]), prms[i])
+
+
+WINDOW_CONFIGS = {"default": dict(), "n30": dict(max_map=30), "k12c300m20": dict(min_anchor_len=12, sampling_count=300, max_ref_hits=20),
+                  "clasp": dict(chain_alg=1), "clasp_n30": dict(chain_alg=1, max_map=30)}
+
+
+@pytest.mark.parametrize("cfg", list(WINDOW_CONFIGS))
+def test_windows_and_alignwin_golden(golden_dir, golden_reads, cfg):
+    """Stage vectors of the window vote and alignWin, dumped from the reference's own
+    findTopWins_coarse / _fine / alignWin (src/LordFAST.cpp:582-657, 819-904, 995-1189; oracle/ref_harness.cpp:
+    ref_stage_windows): the coarse / fine decision, the windows alignWin is called with (float score bits; fine mode: the
+    top-N heap array in array order, i.e. with libstdc++'s push_heap / pop_heap moves) and alignWin's totalScore + record
+    fields per window -- for dp-n2 and clasp."""
+    import lordfast_amd as la
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "stages_windows.npz"))
+    names, seqs = golden_reads
+    lf = la.LordFast(os.path.join(golden_dir, "genome.fa"), device=0)
+    try:
+        got = lf.map_stages(seqs, params=la.default_params(**WINDOW_CONFIGS[cfg]))
+    finally:
+        lf.close()
+    mode = z[f"{cfg}_mode"]; wn = z[f"{cfg}_wins_n"]; wins = z[f"{cfg}_wins"]; mn = z[f"{cfg}_maps_n"]; maps = z[f"{cfg}_maps"]
+    assert len(got) == len(mode)
+    wo = np.concatenate([[0], np.cumsum(wn)]); mo = np.concatenate([[0], np.cumsum(mn)])
+    n_fine = 0
+    for i, g in enumerate(got):
+        assert g["mode"] == mode[i], (i, g["mode"], mode[i])
+        ew = wins[wo[i]:wo[i + 1]]
+        assert g["wins"].shape == ew.shape and np.array_equal(g["wins"], ew), (i, names[i], g["wins"], ew)
+        em = maps[mo[i]:mo[i + 1]]
+        assert np.array_equal(g["maps"], em), (i, names[i], g["maps"][:12], em[:12])
+        n_fine += mode[i] == 3
+    assert n_fine >= 5 and (mode == 2).sum() >= 20, "fixture must exercise both branches"

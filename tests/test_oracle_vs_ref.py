@@ -237,3 +237,29 @@ def test_special_inputs_vs_reference(golden_dir, golden_reads, ref, oracle_lib, 
     orc = oracle_lib.Oracle(fa2)
     assert ref.map_mem(ln, ls)[0] == orc.map_batch(ln, ls, params=oracle_lib.default_params(threads=1))
     orc.close()
+
+
+def test_window_stage_goldens_are_the_reference_output(ref, golden_dir, golden_reads):
+    """tests/golden/stages_windows.npz (what the GPU test checks the vote / selection stage and alignWin against) is exactly
+    what the compiled reference's findTopWins_coarse / _fine / alignWin produce today (oracle/ref_harness.cpp:
+    ref_stage_windows) -- also when sessions follow each other in one process (the vote array is tagged by read number)."""
+    import shutil
+    import tempfile
+    from oracle import pyoracle as po
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "stages_windows.npz"))
+    names, seqs = golden_reads
+    tmp = tempfile.mkdtemp()
+    try:
+        fa = os.path.join(tmp, "genome.fa")
+        shutil.copy(os.path.join(golden_dir, "genome.fa"), fa)
+        ref.index_build(fa)                              # the reference needs its 256 MiB .cache file to load
+        ref.load(fa)
+        for cfg, kw in (("n30", dict(max_map=30)), ("default", dict()), ("clasp", dict(chain_alg=1))):
+            ref.set_params(po.default_params(threads=1, **kw), "golden")
+            res = ref.stage_windows(seqs)
+            assert [r["mode"] for r in res] == list(z[f"{cfg}_mode"])
+            assert np.array_equal(np.concatenate([r["wins"].reshape(-1, 4) for r in res]), z[f"{cfg}_wins"])
+            assert np.array_equal(np.concatenate([r["maps"] for r in res]), z[f"{cfg}_maps"])
+            assert np.array_equal(np.concatenate([r["coarse"].reshape(-1, 4) for r in res]), z[f"{cfg}_coarse"])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
