@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <time.h>
 #include "lordfast_amd.h"
 
 #define PROG_VERSION "0.0.10"
@@ -141,9 +142,15 @@ int main(int argc, char *argv[])
     for (int d = 0; d < n_devs; d++)
         if (lf_index_load(ref_file, devs[d], flags, &ixs[d]) != LF_OK) { fprintf(stderr, "[ERROR] (bwt_load) %s\n", lf_last_error()); return EXIT_FAILURE; }
     lf_stats_t st;
+    struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
     const int rc = lf_map_file_multi((const lf_index_t *const *)ixs, n_devs, &P, seq_file, out_file, no_header, cmdline, 0, &st);
     if (rc != LF_OK) fprintf(stderr, "[ERROR] %s\n", lf_last_error());
-    else fprintf(stderr, "[NOTE] processed %llu reads in %.2f seconds\n", (unsigned long long)st.n_reads, st.ms_total / 1000.0);
+    else {
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        const double wall = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        fprintf(stderr, "[NOTE] processed %llu reads in %.2f seconds\n", (unsigned long long)st.n_reads, st.ms_total / 1000.0);
+        fprintf(stderr, "[NOTE] search wall time %.2f seconds (reading + mapping + writing, index resident): %.0f reads/s\n", wall, wall > 0 ? (double)st.n_reads / wall : 0.0);
+    }
     for (int d = 0; d < n_devs; d++) lf_index_free(ixs[d]);
     return rc == LF_OK ? EXIT_SUCCESS : EXIT_FAILURE;
 }

@@ -83,6 +83,8 @@ int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff, const uin
 void *lfg_dev_slot(int device, int slot, size_t bytes);
 void *lfg_pin_slot(int slot, size_t bytes);
 void  lfg_slots_release(void);
+void *lfg_host_alloc(size_t bytes);    /* pinned host memory outside the slot system */
+void  lfg_host_free(void *p);
 void  lfg_lane_set_value(int device, int key, uint64_t v);   /* per-lane scratch numbers; key 0: words of one bit plane of the resident read batch */
 uint64_t lfg_lane_value(int device, int key);
 void  lfg_set_lane(int lane);          /* calling thread drives lane 0 or 1 (own slots + streams) */

@@ -173,3 +173,12 @@ extern "C" int lf_device_copy(int device, void *dst, const void *src, size_t byt
     if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
     return LF_OK;
 }
+
+/* pinned host memory outside the slot system (the SAM buffers of lf_map_file): D2H copies run at link speed into it */
+extern "C" void *lfg_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void lfg_host_free(void *p) { if (p) (void)hipHostFree(p); }

@@ -85,6 +85,10 @@ CASES = {
     "mixed": b"junk before\n>r1\nACGT\n@q1\nAC\n+\nII\n>r2\nGG",
     "no_trailing_newline": b">r1\nACGT",
     "truncated_quality": b"@q1\nACGT\n+\nIIII\n@q2\nACGT\n+\nII\n",
+    # starts like a FASTA (the mapped, multi-threaded parser takes it) but holds a FASTQ record: handed to the sequential parser
+    "fasta_then_fastq": b">r1\nACGT\n@q1\nAC\n+\nII\n>r2\nGG",
+    "fasta_plus_line": b">r1\nACGT\n+\nIIII\n>r2\nGG\n",
+    "fasta_gt_inside_header": b">r1 a>b c\nAC>GT\nAA\n>r2\n\n\nTT\n",
 }
 
 
@@ -134,3 +138,33 @@ def test_reader_vs_reference_reader(tmp_path, golden_dir, golden_reads):
     sam_file, _ = ref.map_file(path, header=False)
     sam_mem, _ = ref.map_mem(pn, ps, [q if q != b"*" else b"" for q in pq])
     assert sam_file == sam_mem
+
+
+def test_mapped_fasta_reader_many_threads_equals_sequential(tmp_path, monkeypatch):
+    """a plain FASTA larger than the multi-thread threshold (pieces cut at record boundaries, wrapped lines, comments, CRLF,
+    empty records): the mapped parser, the sequential parser and the kseq grammar agree, also under read / base limits"""
+    import lordfast_amd as la
+    rng = np.random.default_rng(11)
+    parts = []
+    total = 0
+    i = 0
+    while total < 9_000_000:
+        n = int(rng.integers(0, 60000))
+        s = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=n))
+        w = int(rng.choice([60, 70, 80, 10**9]))
+        eol = b"\r\n" if i % 7 == 3 else b"\n"
+        hdr = b">read%d" % i + (b" comment with > and @ signs" if i % 3 == 0 else b"") + eol
+        body = eol.join(s[k:k + w] for k in range(0, max(1, n), w)) + eol if n else b""
+        parts.append(hdr + body + (b"\n" if i % 11 == 0 else b""))
+        total += len(parts[-1]); i += 1
+    data = b"".join(parts)
+    path = str(tmp_path / "big.fa")
+    with open(path, "wb") as fh:
+        fh.write(data)
+    exp = kseq_python(data)
+    for kw in (dict(), dict(batch_reads=37), dict(batch_bases=1_500_000)):
+        got = [(n, s, q) for names, seqs, quals in la.read_file(path, **kw) for n, s, q in zip(names, seqs, quals)]
+        assert got == exp, kw
+    monkeypatch.setenv("LF_READER_SEQUENTIAL", "1")
+    got = [(n, s, q) for names, seqs, quals in la.read_file(path) for n, s, q in zip(names, seqs, quals)]
+    assert got == exp
