@@ -222,6 +222,10 @@ typedef struct { uint32_t pos, posEnd, qStart, qEnd; int32_t flag, alnScore, nmC
 typedef struct { int n_reads; uint8_t *mode; uint32_t *win0; uint32_t n_wins; lf_stage_win_t *wins; uint32_t n_recs; lf_stage_rec_t *recs; } lf_stages_t;
 int  lf_map_stages_batch(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *seqs, lf_stages_t **out);
 void lf_stages_free(lf_stages_t *s);
+/* Test hook, not a production switch: the host-side cross-check implementations of four device stages (bit 0 vote / selection /
+ * sort, bit 1 CIGAR / MD strings, bit 2 chain walk, bit 3 SAM line assembly) can only be selected through this call; no
+ * environment variable reaches them.  Process-wide; returns the previous mask.  0 = the product path. */
+unsigned lf_debug_crosscheck(unsigned mask);
 /* device memory for callers that do not link HIP themselves (a caller that does may pass any pointer hipMalloc gave it):
  * lf_device_copy takes host or device pointers on either side and is synchronous */
 void *lf_device_alloc(int device, size_t bytes);

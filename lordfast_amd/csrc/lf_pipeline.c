@@ -18,8 +18,8 @@
  *   E  host  MAPQ, SAM line assembly (src/LordFAST.cpp:318-459)
  *
  * The host never computes a DP cell: no CPU alignment, chaining or FM-index code exists in this library.
- * LF_HOST_VOTE=1 / LF_HOST_CIGAR=1 switch stage B resp. D' to host implementations that work on data copied back
- * from the device: diagnostic cross-checks for the tests, never selected automatically.
+ * lf_debug_crosscheck() can switch stages B, D (walk), D' and E to host implementations that work on data copied back
+ * from the device: diagnostic cross-checks for the tests, never selected automatically and not selectable by environment.
  */
 #include <math.h>
 #include <pthread.h>
@@ -40,6 +40,16 @@ void lf_sort_seeds_by_qpos(Seed_t *s, long n);
 #define SPLIT_LEN   80
 #define SPLIT_SIM   0.40
 #define REVERSE_SIM 0.60
+
+/* The host-side re-implementations of four device stages (vote / selection, chain walk, CIGAR / MD strings, SAM line
+ * assembly) are kept as CROSS-CHECKS for the tests.  They are selected through lf_debug_crosscheck() only -- never by an
+ * environment variable: nothing in a production environment can send a batch down a path that is ten times slower. */
+#define LF_XC_HOST_VOTE  1u
+#define LF_XC_HOST_CIGAR 2u
+#define LF_XC_HOST_WALK  4u
+#define LF_XC_HOST_SAM   8u
+static volatile unsigned g_crosscheck = 0;
+unsigned lf_debug_crosscheck(unsigned mask) { const unsigned old = g_crosscheck; g_crosscheck = mask & 15u; return old; }
 
 #define LF_RC_SPLIT 100        /* internal: map_chunk wants its chunk cut in two (too many seed hits for one vote sort) */
 static double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
@@ -242,10 +252,10 @@ typedef struct ctx {
     lf_aln_desc_t *mg_desc; char *mg_qb, *mg_tb; uint64_t *mg_qoff, *mg_toff, *mg_qbase, *mg_tbase; uint8_t *mg_mode; int *mg_gbase; ed_round_t *mg_R; int mg_round;
     struct { const char *label; double t; } marks[96]; int n_marks; int timing;     /* LF_TIMING=1: per-chunk timeline */
     int lazy;                       /* paths leave the edlib kernels with unclassified diagonal moves (resolved by the renderer) */
-    int host_vote;                  /* LF_HOST_VOTE=1: vote / select / sort on the host from copied-back hits (cross-check) */
+    int host_vote;                  /* cross-check: vote / select / sort on the host from copied-back hits (cross-check) */
     lfg_vc_t vc;                    /* device path: modes, requests and chains of this chunk */
     uint64_t max_chunk_hits;        /* more seed hits than this in one chunk: map_chunk asks for a split (LF_RC_SPLIT) */
-    int host_cigar;                 /* LF_HOST_CIGAR=1: build CIGAR / MD on the host from copied-back paths (cross-check) */
+    int host_cigar;                 /* cross-check: build CIGAR / MD on the host from copied-back paths (cross-check) */
     char *rtext; uint64_t *roffs; int *rrbase;      /* rendered text, per-record offsets, first record of each worker */
     int n_dev_recs; uint64_t n_dev_items; void *d_dev_recs, *d_dev_items;       /* the device-planned recipe (lf_walk.hip): records 0 .. n_dev_recs-1 */
     int dev_sam; lfg_rtext_t rtext_dev; uint32_t *rlens; uint64_t sam_total; int sam_parity;       /* SAM lines assembled on the device (lf_sam.hip): text size of the chunk */
@@ -1784,7 +1794,7 @@ extend:
      * clip / split triggers -> record fields + CIGAR recipe, all in HBM.  Chains that leave the common path (and everything
      * when a host cross-check mode is on) are replayed by the host walk below, which then finds them incomplete. ---- */
     cx->n_dev_recs = 0; cx->n_dev_items = 0; cx->d_dev_recs = NULL; cx->d_dev_items = NULL;
-    if (!host_vote && !cx->host_cigar && !getenv("LF_HOST_WALK")) {
+    if (!host_vote && !cx->host_cigar && !(g_crosscheck & LF_XC_HOST_WALK)) {
         int nj = 0;
         for (int i = 0; i < n; i++) { const rd_t *r = &cx->reads[i]; if (r->mode >= 2) for (int w = 0; w < r->nWins; w++) nj += r->jobs[w].chainLen > 1; }
         if (nj > 0) {
@@ -2176,7 +2186,7 @@ static void *lane_main(void *arg_)
         ctx_t cx; memset(&cx, 0, sizeof cx);
         cx.ix = B->ixs[lane % B->n_ix]; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane]; cx.host_cigar = B->host_cigar; cx.host_vote = B->host_vote; cx.lazy = !B->host_cigar && !getenv("LF_NO_LAZY");
         cx.max_chunk_hits = max_hits;
-        cx.dev_sam = !B->host_cigar && !B->host_vote && !getenv("LF_HOST_SAM");
+        cx.dev_sam = !B->host_cigar && !B->host_vote && !(g_crosscheck & LF_XC_HOST_SAM);
         cx.sam_parity = parity;
         cx.d_seqs = B->d_seqs; cx.d_quals = B->d_quals; cx.stage_sink = B->stage_sink; cx.stage_i0 = C->i0;
         cx.n_reads = C->i1 - C->i0;
@@ -2294,15 +2304,15 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
                           char **sam, size_t *sam_len, lf_stats_t *stats, const devio_t *dio)
 {
     if (!ixs || n_ix < 1 || n_ix > 16 || !p || n < 0 || (!sam && !ext_buf)) { lf_set_error("lf_map_batch: bad argument"); return LF_ERR_ARG; }
-    if (dio && !dio->stage_sink && (n_ix != 1 || !dio->d_seqs || !dio->seq_off || !seq_lens || !ext_buf || getenv("LF_HOST_VOTE") || getenv("LF_HOST_CIGAR") || getenv("LF_HOST_SAM") || getenv("LF_HOST_WALK"))) {
-        lf_set_error("lf_map_batch_dev: needs one index, device bases with offsets and lengths, an output buffer, and none of the LF_HOST_* cross-check modes"); return LF_ERR_ARG;
+    if (dio && !dio->stage_sink && (n_ix != 1 || !dio->d_seqs || !dio->seq_off || !seq_lens || !ext_buf || g_crosscheck)) {
+        lf_set_error("lf_map_batch_dev: needs one index, device bases with offsets and lengths, an output buffer, and no cross-check mode (lf_debug_crosscheck)"); return LF_ERR_ARG;
     }
     for (int d = 0; d < n_ix; d++) {
         if (!ixs[d]) { lf_set_error("lf_map_batch: bad argument"); return LF_ERR_ARG; }
         if (ixs[d]->l_pac != ixs[0]->l_pac || ixs[d]->seq_len != ixs[0]->seq_len || ixs[d]->n_seqs != ixs[0]->n_seqs) { lf_set_error("lf_map_batch_multi: the index replicas differ"); return LF_ERR_ARG; }
     }
     if (p->chain_alg != 0 && p->chain_alg != 1) { lf_set_error("lf_map_batch: chain_alg must be 0 (dp-n2) or 1 (clasp)"); return LF_ERR_ARG; }
-    if (p->chain_alg == 1 && getenv("LF_HOST_VOTE") && atoi(getenv("LF_HOST_VOTE"))) { lf_set_error("lf_map_batch: the LF_HOST_VOTE diagnostic path only knows dp-n2; clasp runs on the device vote path"); return LF_ERR_ARG; }
+    if (p->chain_alg == 1 && (g_crosscheck & LF_XC_HOST_VOTE)) { lf_set_error("lf_map_batch: the host-vote cross-check only knows dp-n2; clasp runs on the device vote path"); return LF_ERR_ARG; }
     if (p->min_anchor_len < 12 || p->min_anchor_len > 20 || p->sampling_count <= 0 || p->max_map < 2 || p->max_ref_hits <= 0 || p->min_read_len < 100) {
         lf_set_error("lf_map_batch: option out of range (k in [12,20], c > 0, n >= 2, m > 0, l >= 100)"); return LF_ERR_ARG;
     }
@@ -2350,8 +2360,8 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     pool_ensure(nw);
 
     batch_t B; memset(&B, 0, sizeof B);
-    B.host_cigar = getenv("LF_HOST_CIGAR") != NULL;
-    B.host_vote = getenv("LF_HOST_VOTE") != NULL;          /* diagnostic cross-check only; the device stage is the product path */
+    B.host_cigar = (g_crosscheck & LF_XC_HOST_CIGAR) != 0;
+    B.host_vote = (g_crosscheck & LF_XC_HOST_VOTE) != 0;          /* diagnostic cross-check only; the device stage is the product path */
     B.ixs = ixs; B.n_ix = n_ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + n_lanes; B.rc = LF_OK;
     if (dio && dio->stage_sink) B.stage_sink = dio->stage_sink;
     else if (dio) { B.d_seqs = (const unsigned char *)dio->d_seqs; B.d_quals = (const unsigned char *)dio->d_quals; B.src_off = dio->seq_off; B.dev_out = dio->dev_out; }

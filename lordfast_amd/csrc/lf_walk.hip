@@ -18,7 +18,7 @@
  *                         position, clip lengths and NM, and the ORDER of its pieces as recipe items for lf_render_kernel
  *
  * A job with a trigger (a few per cent), a query longer than the sweep kernels take, or anything else off the common
- * path is flagged and replayed by the host walk of lf_pipeline.c exactly as before.  LF_HOST_WALK=1 sends every job there
+ * path is flagged and replayed by the host walk of lf_pipeline.c exactly as before.  lf_debug_crosscheck(4) sends every job there
  * (cross-check in the tests).
  */
 #include <hip/hip_runtime.h>

@@ -57,6 +57,17 @@ int         MAX_REF_HITS = 1000;
 /* internal (non-static) reference symbols used for stage-level checks */
 extern int8_t _pf_kswMatrix_clip[25];
 
+extern WinCount_t **_pf_refWin_cnt;
+extern uint32_t _pf_refWin_num;
+/* initializeFAST takes the vote array from malloc (getMem, src/Common.cpp:68-75) and never clears it: votes are told apart by
+ * a read-number tag (src/LordFAST.cpp:596-610).  A fresh process gets zeroed pages; a process that runs several sessions
+ * (this harness, the tests) can get a previous session's array back, tags and counts included.  Every session of the
+ * harness therefore starts from what a fresh process sees. */
+static void fresh_vote_array(void)
+{
+    for (int i = 0; i < THREAD_COUNT; i++) memset(_pf_refWin_cnt[i], 0, (size_t)_pf_refWin_num * sizeof(WinCount_t));
+}
+
 static double now_s() { return getRealTime(); }
 
 extern "C" {
@@ -91,6 +102,7 @@ double ref_map_file(const char *reads_path, const char *out_path, int no_header)
     strncpy(outputMap, out_path, sizeof(outputMap) - 1);
     if (!initRead((char *)reads_path, 100000000)) return -1;
     initializeFAST();
+    fresh_vote_array();
     while (readChunk(&seqList, &seqListSize) > 0) {
         initFASTChunk(seqList, seqListSize);
         double t0 = now_s();
@@ -131,6 +143,7 @@ double ref_map_mem(int n, const char **names, const char **seqs, const char **qu
     noSamHeader = no_header;
     strncpy(outputMap, out_path, sizeof(outputMap) - 1);
     initializeFAST();
+    fresh_vote_array();
     initFASTChunk(reads.data(), n);
     double t0 = now_s();
     mapSeqMT();
@@ -223,6 +236,7 @@ void ref_stage_begin(void)
     noSamHeader = 1; strcpy(outputMap, "/dev/null");
     THREAD_COUNT = 1;
     initializeFAST();
+    fresh_vote_array();
     _pf_seqListSize = 1 << 20;            /* the tag of fine-mode votes is t + _pf_seqListSize + 1 (src/LordFAST.cpp:554) */
     /* g_stage_t keeps counting across sessions: the vote array is tagged with the read number (:596-610) and a later
      * initializeFAST may get the previous session's memory back un-zeroed -- a repeated tag would add to stale counts */

@@ -2,7 +2,7 @@
 # collect.sh <tag> -- run on the GPU box from the repo root: bench + rocprofv3 passes for config C2, summaries into
 # gpurun_out/<tag>/ (copy what you want judged into profiles/<tag>/).  rocprofv3 gets the program itself after `--`.
 set -u
-TAG=${1:-r02_c2}
+TAG=${1:-r03_c2}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
@@ -27,4 +27,5 @@ rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACT
 rocprofv3 --pmc SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d /tmp/lfp_s3 -- $BS > /dev/null 2> /tmp/lfp_s3.err
 python3 profiles/tools/summarize_pmc.py $OUT/sq_counters_50k_reads.json $(ls /tmp/lfp_s1/*/*counter_collection.csv /tmp/lfp_s2/*/*counter_collection.csv /tmp/lfp_s3/*/*counter_collection.csv 2>/dev/null)
 unset LF_LANES LF_SERIAL_CLASSES
+python3 bench.py --tree-hash > $OUT/SOURCE_TREE.txt; (git rev-parse HEAD 2>/dev/null || echo "no git on this box") >> $OUT/SOURCE_TREE.txt
 ls -la $OUT

@@ -22,5 +22,21 @@ for path in sys.argv[2:]:
         seen[name].add(r["Dispatch_Id"])
     for name, ids in seen.items():
         out[name]["launches"] = max(out[name]["launches"], len(ids))
-json.dump(dict(sorted(out.items(), key=lambda kv: -(kv[1].get("fetch_kb", 0) + kv[1].get("write_kb", 0)))), open(sys.argv[1], "w"), indent=1)
+res = dict(sorted(out.items(), key=lambda kv: -(kv[1].get("fetch_kb", 0) + kv[1].get("write_kb", 0))))
+# which kernels these counters describe: digest of lordfast_amd/csrc (bench.py --tree-hash) + the git commit if there is one.
+# bench.py only quotes `roofline.traffic` from a summary whose source_tree is the tree it runs on.
+import os
+import subprocess
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+meta = {}
+try:
+    meta["source_tree"] = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--tree-hash"], capture_output=True, text=True, timeout=60).stdout.strip()
+except Exception:                                                        # noqa: BLE001
+    pass
+try:
+    meta["git_commit"] = subprocess.run(["git", "-C", root, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+except Exception:                                                        # noqa: BLE001
+    pass
+res = {"_meta": meta, **res}
+json.dump(res, open(sys.argv[1], "w"), indent=1)
 print("wrote", sys.argv[1], len(out), "kernels")

@@ -6,8 +6,6 @@
 import gzip
 import os
 
-# a batch that hangs becomes an abort with the position of every lane (lf_pipeline.c), not a stuck test run
-os.environ.setdefault("LF_WATCHDOG", "150")
 import shutil
 import sys
 
@@ -117,6 +115,16 @@ def ref(oracle_lib):
     if not have_ref():
         pytest.skip("oracle/_ref/liblfref.so not built (needs /root/reference)")
     return oracle_lib.Ref()
+
+
+@pytest.fixture(autouse=True)
+def _gpu_watchdog(request, monkeypatch):
+    """GPU tests only: a batch that hangs becomes an abort that names where every lane is (lf_pipeline.c) instead of a stuck
+    run.  Scoped to the test (monkeypatch), generous (a slow box must not trip it), and not inherited by the subprocesses of
+    the CPU tests."""
+    if request.node.get_closest_marker("gpu") is not None and "LF_WATCHDOG" not in os.environ:
+        monkeypatch.setenv("LF_WATCHDOG", "600")
+    yield
 
 
 @pytest.fixture(autouse=True)

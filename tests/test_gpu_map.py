@@ -11,6 +11,14 @@ from lordfast_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _product_path_after_each_test():
+    """the cross-check selections (lf_debug_crosscheck) never leak into the next test"""
+    yield
+    import lordfast_amd as la
+    la.lib().lf_debug_crosscheck(0)
+
+
 @pytest.fixture(scope="module")
 def lf(golden_dir):
     import lordfast_amd as la
@@ -44,16 +52,16 @@ def test_sam_golden(lf, golden_reads, cfg):
 
 
 def test_sam_host_cigar_crosscheck(lf, golden_reads, monkeypatch):
-    """LF_HOST_CIGAR=1 builds CIGAR / MD on the host from copied-back edit paths instead of lf_render_kernel: both
+    """lf_debug_crosscheck(2) builds CIGAR / MD on the host from copied-back edit paths instead of lf_render_kernel: both
     must print the reference's records"""
     import lordfast_amd as la
     names, seqs = golden_reads
-    monkeypatch.setenv("LF_HOST_CIGAR", "1")
+    la.lib().lf_debug_crosscheck(2)
     sam, st = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS["default"]))
     assert st["render_launches"] == 0
     exp = golden_sam("default")
     assert sam == exp, first_diff(sam, exp)
-    monkeypatch.delenv("LF_HOST_CIGAR")
+    la.lib().lf_debug_crosscheck(0)
     sam, st = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS["default"]))
     assert st["render_launches"] >= 1 and st["render_bytes"] > 0
     assert sam == exp, first_diff(sam, exp)
@@ -61,10 +69,10 @@ def test_sam_host_cigar_crosscheck(lf, golden_reads, monkeypatch):
 
 @pytest.mark.parametrize("cfg", ["default", "n30"])
 def test_sam_host_vote_crosscheck(lf, golden_reads, monkeypatch, cfg):
-    """LF_HOST_VOTE=1 votes / selects / sorts on the host from copied-back hits instead of lf_vote.hip: same records"""
+    """lf_debug_crosscheck(1) votes / selects / sorts on the host from copied-back hits instead of lf_vote.hip: same records"""
     import lordfast_amd as la
     names, seqs = golden_reads
-    monkeypatch.setenv("LF_HOST_VOTE", "1")
+    la.lib().lf_debug_crosscheck(1)
     sam, st = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
     exp = golden_sam(cfg)
     assert sam == exp, first_diff(sam, exp)
@@ -321,7 +329,7 @@ def test_vote_tables_in_global_memory(lf, golden_reads, monkeypatch, cfg, lds_ma
 
 @pytest.mark.parametrize("cfg", ["default", "clasp_n30", "k12c300m20"])
 def test_sam_host_walk_crosscheck(lf, golden_reads, monkeypatch, cfg):
-    """LF_HOST_WALK=1 replays every chain with the host walk of lf_pipeline.c instead of lf_walk.hip (which keeps the
+    """lf_debug_crosscheck(4) replays every chain with the host walk of lf_pipeline.c instead of lf_walk.hip (which keeps the
     common path of alignChain_edlib on the device): both must print the reference's records, and the device path must
     really have planned the alignments (no descriptors uploaded: n_edlib_problems is the same, counted on the device)"""
     import lordfast_amd as la
@@ -329,7 +337,7 @@ def test_sam_host_walk_crosscheck(lf, golden_reads, monkeypatch, cfg):
     exp = golden_sam(cfg)
     sam_d, st_d = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
     assert sam_d == exp, first_diff(sam_d, exp)
-    monkeypatch.setenv("LF_HOST_WALK", "1")
+    la.lib().lf_debug_crosscheck(4)
     sam_h, st_h = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
     assert sam_h == exp, first_diff(sam_h, exp)
     # the device plans every chain's common path; chains with a clip / split trigger are planned again by the host replay
@@ -338,19 +346,19 @@ def test_sam_host_walk_crosscheck(lf, golden_reads, monkeypatch, cfg):
 
 @pytest.mark.parametrize("cfg", ["default", "n30", "clasp"])
 def test_sam_host_assembly_crosscheck(lf, golden_reads, monkeypatch, cfg):
-    """LF_HOST_SAM=1 formats the SAM lines on the host (two passes over the records) instead of lf_sam.hip (line descriptors
+    """lf_debug_crosscheck(8) formats the SAM lines on the host (two passes over the records) instead of lf_sam.hip (line descriptors
     -> text on the device, one D2H copy into the output buffer): same bytes.  With qualities (FASTQ) and a read group too."""
     import lordfast_amd as la
     names, seqs = golden_reads
     exp = golden_sam(cfg)
-    monkeypatch.setenv("LF_HOST_SAM", "1")
+    la.lib().lf_debug_crosscheck(8)
     sam_h, _ = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
     assert sam_h == exp, first_diff(sam_h, exp)
     if cfg == "default":
         quals = [bytes(33 + (i * 7 + k) % 40 for k in range(len(s))) if i % 3 else b"" for i, s in enumerate(seqs)]
         p = la.default_params(read_group_id=b"grpX", read_group=b"@RG\tID:grpX")
         h, _ = lf.map_batch(names, seqs, quals=quals, params=p)
-        monkeypatch.delenv("LF_HOST_SAM")
+        la.lib().lf_debug_crosscheck(0)
         d, _ = lf.map_batch(names, seqs, quals=quals, params=p)
         assert d == h, first_diff(d, h)
         assert b"\tRG:Z:grpX" in d
