@@ -24,12 +24,14 @@ struct lf_dev_index {
     const uint64_t *sa_full;    /* seq_len + 1 rows, or NULL */
     const uint64_t *cache;      /* 4^12 x (beg,end): SA interval of every 12-mer (src/BWT.cpp:60-115) */
     const uint64_t *cache14;    /* 4^14 x (beg,end), or NULL: two search steps saved per sample when -k >= 14 (4.3 GB; large genomes) */
+    const uint64_t *cache16;    /* 4^16 x (beg,end), or NULL (68.7 GB; genomes >= 2^30 symbols when HBM allows): a sample whose 16-mer occurs starts
+                                 * there -- four search steps saved; one whose 16-mer does not occur falls back to the narrower table */
     const uint8_t  *pac;
 };
 
 struct lf_dev_state {           /* host-side owner of the device allocations */
     lf_dev_index view;
-    void *bwt, *sa_sampled, *sa_full, *cache, *cache14, *pac;
+    void *bwt, *sa_sampled, *sa_full, *cache, *cache14, *cache16, *pac;
     void *ctg_names = nullptr, *ctg_name_off = nullptr;      /* contig names for lf_sam.hip (uploaded on first use) */
     hipStream_t stream;
 };

@@ -65,14 +65,14 @@ __global__ void lf_full_sa_kernel(lf_dev_index ix, uint64_t *__restrict__ sa_ful
 int lfg_build_cache_table(const lf_dev_index *v, hipStream_t stream, int K, uint64_t **table)
 {
     uint64_t *bufA, *bufB;
-    HIPCHK(hipMalloc(&bufA, ((size_t)1 << (2 * K)) * 16));
-    HIPCHK(hipMalloc(&bufB, ((size_t)1 << (2 * (K - 1))) * 16));
+    if (hipMalloc(&bufA, ((size_t)1 << (2 * K)) * 16) != hipSuccess) { (void)hipGetLastError(); lf_set_error("no memory for the %d-mer table", K); return LF_ERR_NOMEM; }
+    if (hipMalloc(&bufB, ((size_t)1 << (2 * (K - 1))) * 16) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(bufA); lf_set_error("no memory for the %d-mer table", K); return LF_ERR_NOMEM; }
     uint64_t *cur = (K % 2 == 0) ? bufA : bufB, *nxt = (K % 2 == 0) ? bufB : bufA;   /* level K lands in bufA */
     const uint64_t root[2] = { 0, v->seq_len };
     HIPCHK(hipMemcpy(cur, root, 16, hipMemcpyHostToDevice));
     for (int k = 0; k < K; k++) {
         const uint32_t np = 1u << (2 * k);
-        hipLaunchKernelGGL(lf_cache_level_kernel, dim3((np + 255) / 256), dim3(256), 0, stream, *v, cur, nxt, np);
+        hipLaunchKernelGGL(lf_cache_level_kernel, dim3((unsigned)(((size_t)np + 255) / 256)), dim3(256), 0, stream, *v, cur, nxt, np);
         uint64_t *t = cur; cur = nxt; nxt = t;
     }
     HIPCHK(hipStreamSynchronize(stream));
@@ -130,6 +130,18 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
             if (rc != LF_OK) return rc;
             st->cache14 = tab; v.cache14 = tab;
         }
+        /* the 16-mer table (68.7 GB + 17 GB while it is built): only where it leaves the batch buffers plenty of room.  On a
+         * human-size text three 16-mers in four occur somewhere, so most samples start their search four steps later.
+         * LF_TABLE16=0/1 overrides. */
+        const char *t16 = getenv("LF_TABLE16");
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const size_t need16 = (((size_t)1 << 32) + ((size_t)1 << 30)) * 16 + ((size_t)8 << 30);
+        if (t16 ? atoi(t16) != 0 : (ix->seq_len >= (1ull << 30) && free_b > need16 + ((size_t)100 << 30) + ((ix->flags & LF_IDX_FULL_SA) ? (ix->seq_len + 1) * 8 : 0))) {
+            rc = lfg_build_cache_table(&v, st->stream, 16, &tab);
+            if (rc == LF_OK) { st->cache16 = tab; v.cache16 = tab; }
+            else if (t16) return rc;                    /* asked for explicitly */
+        }
     }
 
     if (ix->flags & LF_IDX_FULL_SA) {
@@ -156,6 +168,7 @@ extern "C" void lfg_index_free(struct lf_index *ix)
     if (st->sa_full) (void)hipFree(st->sa_full);
     if (st->cache) (void)hipFree(st->cache);
     if (st->cache14) (void)hipFree(st->cache14);
+    if (st->cache16) (void)hipFree(st->cache16);
     if (st->pac) (void)hipFree(st->pac);
     if (st->ctg_names) (void)hipFree(st->ctg_names);
     if (st->ctg_name_off) (void)hipFree(st->ctg_name_off);
@@ -234,22 +247,33 @@ lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ rea
                 lf_sample_t res; res.sp = 0; res.occ = 0; res.m = 0;
                 bool started = false;
                 if ((uint64_t)p + (uint64_t)kmin <= qLen) {
-                    /* the first W <= 14 bases in two (unaligned) 8-byte loads; the batch buffer has 64 bytes of slack */
+                    /* the first 16 bases in two (unaligned) 8-byte loads; the batch buffer has 64 bytes of slack */
                     uint64_t w0, w1;
                     __builtin_memcpy(&w0, q + p, 8); __builtin_memcpy(&w1, q + p + 8, 8);
-                    uint32_t idc = 0, idf = 0; bool ok = true;
+                    int cd[16]; uint32_t bad = 0;
 #pragma unroll
-                    for (int t = 0; t < 14; t++) {
-                        if ((uint32_t)t < W) {
-                            const int c = lf_nt4((unsigned char)((t < 8 ? w0 >> (8 * t) : w1 >> (8 * (t - 8))) & 0xff));
-                            ok &= (c < 4); idc = idc * 4 + (uint32_t)(3 - c);
-                        }
-                    }
+                    for (int t = 0; t < 16; t++) { cd[t] = lf_nt4((unsigned char)((t < 8 ? w0 >> (8 * t) : w1 >> (8 * (t - 8))) & 0xff)); bad |= (cd[t] > 3 ? 1u : 0u) << t; }
+                    /* table index of a pattern: base-4 number with its LAST character most significant; for revcomp(P) the
+                     * characters are the complements of P's, read backwards */
+                    auto idx_of = [&](int Wd, uint32_t &idc_o, uint32_t &idf_o) {
+                        uint32_t idc = 0, idf = 0;
 #pragma unroll
-                    for (int t = 13; t >= 0; t--) {
-                        if ((uint32_t)t < W) idf = idf * 4 + (uint32_t)lf_nt4((unsigned char)((t < 8 ? w0 >> (8 * t) : w1 >> (8 * (t - 8))) & 0xff));
+                        for (int t = 0; t < 16; t++) if (t < Wd) idc = idc * 4 + (uint32_t)(3 - cd[t]);
+#pragma unroll
+                        for (int t = 15; t >= 0; t--) if (t < Wd) idf = idf * 4 + (uint32_t)cd[t];
+                        idc_o = idc; idf_o = idf;
+                    };
+                    /* widest table first: a 16-mer that occurs starts the search at m = 16 (nothing shorter than kmin is wanted,
+                     * and a sample that reaches 16 would have passed through every shorter length with a non-empty interval) */
+                    if (ix.cache16 != nullptr && (uint64_t)p + 16 <= qLen && (bad & 0xffffu) == 0) {
+                        uint32_t idc, idf; idx_of(16, idc, idf);
+                        n_cache += 2;
+                        x1 = ix.cache16[2 * (size_t)idc];
+                        const uint64_t l1 = ix.cache16[2 * (size_t)idc + 1];
+                        if (x1 <= l1) { x0 = ix.cache16[2 * (size_t)idf]; sz = l1 - x1 + 1; m = 16; started = true; }
                     }
-                    if (ok) {
+                    if (!started && (bad & ((1u << W) - 1)) == 0) {
+                        uint32_t idc, idf; idx_of((int)W, idc, idf);
                         n_cache += 2;
                         x1 = tab[2 * (size_t)idc];
                         const uint64_t l1 = tab[2 * (size_t)idc + 1];

@@ -90,3 +90,33 @@ def test_seeds_with_wide_table(golden_dir, golden_reads, stages, monkeypatch):
                 assert np.array_equal(x, y)
     finally:
         h.close(); base.close()
+
+
+def test_seeds_with_16mer_table(golden_dir, golden_reads, stages, monkeypatch):
+    """LF_TABLE16=1 adds the 4^16-entry table (default only for genomes >= 2^30 symbols with HBM to spare: 68.7 GB): a sample
+    whose 16-mer occurs starts there, any other falls back to the 14- / 12-mer table.  Same seeds for -k 14, 12 and 17."""
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    monkeypatch.setenv("LF_WIDE_TABLE", "1"); monkeypatch.setenv("LF_TABLE16", "1")
+    h = la.LordFast(os.path.join(golden_dir, "genome.fa"), device=0, full_sa=True)
+    monkeypatch.delenv("LF_WIDE_TABLE"); monkeypatch.setenv("LF_TABLE16", "0")
+    base = la.LordFast(os.path.join(golden_dir, "genome.fa"), device=0, full_sa=True)
+    try:
+        F = split_ragged(stages["seed_F"], stages["seed_F_n"])
+        R = split_ragged(stages["seed_R"], stages["seed_R_n"])
+        gF, gR, info = h.seed_batch(seqs)
+        _, _, info0 = base.seed_batch(seqs)
+        for i in range(len(seqs)):
+            assert np.array_equal(gF[i], F[i]) and np.array_equal(gR[i], R[i]), names[i]
+        assert info["n_occblk"] < info0["n_occblk"]
+        for kw in (dict(min_anchor_len=12, sampling_count=300, max_ref_hits=20), dict(min_anchor_len=17, sampling_count=2000), dict(min_anchor_len=16)):
+            a = h.seed_batch(seqs[:30], params=la.default_params(**kw))
+            b = base.seed_batch(seqs[:30], params=la.default_params(**kw))
+            for x, y in zip(a[0] + a[1], b[0] + b[1]):
+                assert np.array_equal(x, y)
+        # and through the whole path
+        from conftest import golden_sam
+        sam, _ = h.map_batch(names, seqs)
+        assert sam == golden_sam("default")
+    finally:
+        h.close(); base.close()
