@@ -23,6 +23,7 @@
 #include "lf_edlib_common.h"
 #include "lf_hirsch.h"
 #include "lf_rsweep.h"
+#include "lf_scan.h"
 #include <stddef.h>
 #include <algorithm>
 #include <type_traits>
@@ -636,10 +637,9 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     uint64_t *d_misc = DSLOT(uint64_t, 15, 64);
     lf_rseg_tab *h_tab = (lf_rseg_tab *)lfg_pin_slot(LF_PS_ALN_PROB + 2, sizeof(lf_rseg_tab) + 64);
     if (!d_desc || !d_opsoff || !d_keys || !d_keys2 || !d_vals || !d_vals2 || !d_ent || !d_base || !d_probs || !d_waves || !d_ed || !d_end || !d_len || !d_ops || !d_tab || !d_misc || !h_tab) return LF_ERR_NOMEM;
-    size_t tb1 = 0, tb2 = 0;
+    size_t tb1 = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, d_keys, d_keys2, d_vals, d_vals2, (int)NN, 0, 31, s);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, d_ent, d_base, (int)NN, s);
-    void *d_tmp = lfg_dev_slot(device, LF_DS_ALN0 + 16, std::max(tb1, tb2) + 256);
+    void *d_tmp = lfg_dev_slot(device, LF_DS_ALN0 + 16, tb1 + 256);
     if (!d_tmp) return LF_ERR_NOMEM;
 
     if (!dev_desc) {
@@ -702,7 +702,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     { size_t tb = tb1; HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, N, 0, 31, s)); }
     hipLaunchKernelGGL(lf_desc_segments_kernel, dim3(1), dim3(256), 0, s, d_keys2, N, d_tab);
     hipLaunchKernelGGL(lf_desc_entries_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, n, d_hdesc, d_tab, N, d_ent);
-    { size_t tb = tb2; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_ent, d_base, N, s)); }
+    { lf_scan_u64 f; f.p = d_ent; const int src = lf_scan_excl(device, 4, s, f, d_base, (size_t)N); if (src != LF_OK) return src; }
     hipLaunchKernelGGL(lf_desc_build_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, n, d_hdesc, d_opsoff, d_hopsoff, d_tab, d_base, N, D->pac ? 1 : 0, d_probs, d_waves, d_misc);
     uint64_t tail[2], aux_total = 0;
     HIPCHK(hipMemcpyAsync(h_tab, d_tab, sizeof(lf_rseg_tab), hipMemcpyDeviceToHost, s));

@@ -98,7 +98,7 @@ void *lfg_lane_event(int device, int which);    /* persistent hipEvent_t (timing
 /* slot ids */
 enum { LF_DS_SEED0 = 0 /* ..15 */, LF_DS_CHAIN0 = 16 /* ..23 */, LF_DS_ALN0 = 24 /* ..47 */, LF_DS_KSW0 = 48 /* ..55 */,
        LF_DS_RND0 = 56 /* ..87: 2 per extension round (ops, spare) */, LF_DS_RENDER0 = 88 /* ..95 */, LF_DS_VOTE0 = 96 /* ..127 */,
-       LF_DS_WALK0 = 128 /* ..147 */, LF_DS_SAM0 = 148 /* ..157 */, LF_DS_HIRSCH0 = 158 /* ..167 */ };
+       LF_DS_WALK0 = 128 /* ..147 */, LF_DS_SAM0 = 148 /* ..157 */, LF_DS_HIRSCH0 = 158 /* ..167 */, LF_DS_SCAN0 = 168 /* ..175: lf_scan.h workspaces */ };
 #define LF_MAX_ED_ROUNDS 16
 enum { LF_PS_READS = 0, LF_PS_READOFF = 1, LF_PS_HITS_T = 2, LF_PS_HITS_Q = 3, LF_PS_HITS_S = 4, LF_PS_HITS_OFF = 5,
        LF_PS_CHAIN_SEEDS = 6, LF_PS_CHAIN_IDX = 7, LF_PS_ALN_Q = 8, LF_PS_ALN_T = 9, LF_PS_ALN_PROB = 10 /* ..16 */,

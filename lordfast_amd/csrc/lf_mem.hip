@@ -182,3 +182,27 @@ extern "C" void *lfg_host_alloc(size_t bytes)
     return p;
 }
 extern "C" void lfg_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+/* ---- workspaces of the single-launch scans (lf_scan.h): status words + tile counter, per (device, lane, module) ---- */
+#include "lf_scan.h"
+namespace { struct scan_state_t { void *p = nullptr; size_t cap = 0; unsigned epoch = 0; }; scan_state_t g_scan[MAX_DEV][MAX_LANE][8]; }
+extern "C" int lfg_scan_ws(int device, int which, size_t n, void *stream, lf_scan_ws_t *ws)
+{
+    if (device < 0 || device >= MAX_DEV || which < 0 || which >= 8) { lf_set_error("lfg_scan_ws: bad workspace %d/%d", device, which); return LF_ERR_ARG; }
+    const size_t tiles = (n + LF_SCAN_TILE - 1) / LF_SCAN_TILE + 1;
+    void *p = lfg_dev_slot(device, LF_DS_SCAN0 + which, tiles * 8 + 64);
+    if (!p) return LF_ERR_NOMEM;
+    scan_state_t &S = g_scan[device][t_lane][which];
+    S.epoch = (S.epoch + 1) & 0x3fffu;
+    size_t cap = 0;
+    { std::lock_guard<std::mutex> g(g_mu); cap = g_dev[device][LF_DS_SCAN0 + which + t_lane * LANE_STRIDE].cap; }
+    if (p != S.p || cap != S.cap || S.epoch == 0) {
+        /* a new (regrown) array, or the epoch wrapped: stale words could carry a live epoch */
+        if (hipMemsetAsync(p, 0, cap, (hipStream_t)stream) != hipSuccess) { lf_set_error("lfg_scan_ws: memset failed"); return LF_ERR_HIP; }
+        S.p = p; S.cap = cap; S.epoch = 1;
+    }
+    ws->counter = (unsigned int *)p;                         /* word 0: the tile counter (left at 0 by every launch) */
+    ws->status = (unsigned long long *)p + 1;
+    ws->epoch = S.epoch;
+    return LF_OK;
+}

@@ -26,6 +26,7 @@
 #include <mutex>
 #include "lf_internal.h"
 #include "lf_gpu_common.h"
+#include "lf_scan.h"
 
 struct lf_rrounds { const uint8_t *ops[LF_MAX_ED_ROUNDS]; const lf_aln_desc_t *desc[LF_MAX_ED_ROUNDS]; };
 
@@ -282,11 +283,6 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_dev_recs, const void 
     uint64_t *h_offs = (uint64_t *)lfg_pin_slot(LF_PS_RENDER0 + 0, (size_t)n_recs * 16 + 16);
     uint32_t *h_tail = (uint32_t *)lfg_pin_slot(LF_PS_RENDER0 + 1, 64);
     if (!d_recs || !d_items || !d_lens || !d_offs || !h_offs || !h_tail) return LF_ERR_NOMEM;
-    size_t tb = 0;
-    hipcub::TransformInputIterator<uint64_t, lf_widen32, uint32_t *> in(d_lens, lf_widen32());
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, d_offs, 2 * n_recs, s);
-    void *d_tmp = lfg_dev_slot(device, LF_DS_RENDER0 + 4, tb + 256);
-    if (!d_tmp) return LF_ERR_NOMEM;
     lf_rrounds R;
     for (int r = 0; r < LF_MAX_ED_ROUNDS; r++) { R.ops[r] = (const uint8_t *)round_ops[r]; R.desc[r] = (const lf_aln_desc_t *)round_desc[r]; }
     const unsigned char *d_reads = (const unsigned char *)lfg_dev_slot(device, LF_DS_SEED0 + 0, 0);      /* read batch left in HBM by lfg_seed */
@@ -300,11 +296,10 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_dev_recs, const void 
     const bool single = dev_text != nullptr && !getenv("LF_RENDER_TWO_PASS");      /* the two-pass form stays for the host-side consumers (packed text) */
     uint32_t *d_caps = single ? (uint32_t *)lfg_dev_slot(device, LF_DS_RENDER0 + 6, (size_t)n_recs * 8) : d_lens;
     if (!d_caps) return LF_ERR_NOMEM;
-    hipcub::TransformInputIterator<uint64_t, lf_widen32, uint32_t *> in_caps(d_caps, lf_widen32());
     if (single) hipLaunchKernelGGL(lf_render_caps_kernel, dim3((unsigned)((n_recs + 3) / 4)), dim3(256), 0, s, d_recs, n_recs, d_items, d_caps);
     else hipLaunchKernelGGL(lf_render_kernel<LF_RM_COUNT>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac, d_reads,
                             d_lens, (const uint64_t *)nullptr, (char *)nullptr);
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, in_caps, d_offs, 2 * n_recs, s));
+    { lf_scan_u32 f; f.p = d_caps; const int src = lf_scan_excl(device, 5, s, f, d_offs, 2 * (size_t)n_recs); if (src != LF_OK) return src; }
     HIPCHK(hipMemcpyAsync(h_offs, d_offs, (size_t)n_recs * 16, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_tail, d_caps + 2 * (size_t)n_recs - 1, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -15,12 +15,12 @@
  * shorter than -l are not in the resident batch) arrive as literal text in a side blob.
  */
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <string.h>
 #include <mutex>
 #include "lf_internal.h"
 #include "lf_gpu_common.h"
+#include "lf_scan.h"
 
 struct lf_sam_dev {
     const lf_samline_t *lines; int n_lines;
@@ -182,11 +182,7 @@ extern "C" int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, in
     D.ctg_names = (const char *)st->ctg_names; D.ctg_name_off = (const uint32_t *)st->ctg_name_off;
     D.rg = d_rg; D.rg_len = rg_len;
     hipLaunchKernelGGL(lf_sam_len_kernel, dim3((unsigned)((n_lines + 255) / 256)), dim3(256), 0, s, D, d_lens);
-    size_t tb = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_lens, d_offs, n_lines, s);
-    void *d_tmp = SSLOT(void, 7, tb + 256);
-    if (!d_tmp) return LF_ERR_NOMEM;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_lens, d_offs, n_lines, s));
+    { lf_scan_u64 f; f.p = d_lens; const int src = lf_scan_excl(dv, 6, s, f, d_offs, (size_t)n_lines); if (src != LF_OK) return src; }
     HIPCHK(hipMemcpyAsync(h, d_offs + (N - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h + 1, d_lens + (N - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

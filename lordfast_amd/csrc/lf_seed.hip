@@ -16,6 +16,7 @@
 #include <hipcub/hipcub.hpp>
 #include "lf_gpu_common.h"
 #include "lf_rsweep.h"
+#include "lf_scan.h"
 
 /* ---------------------------------------------------------------- index residency */
 
@@ -482,13 +483,8 @@ extern "C" int lfg_seed_src(const struct lf_index *ix, const lf_params_t *p, int
     HIPCHK(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lf_seed_accept_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, hc, (uint32_t)p->max_ref_hits, d_pos, d_smp, d_cnt);
     HIPCHK(hipMemsetAsync(d_cnt + total, 0, 4, s));
-    size_t tmp_bytes = 0;
-    /* u32 counts summed into u64 offsets */
-    hipcub::TransformInputIterator<uint64_t, lf_widen_op, uint32_t *> cnt64(d_cnt, lf_widen_op());
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt64, d_hit_off, (int)(total + 1), s));
-    void *d_tmp = lfg_dev_slot(dv, LF_DS_SEED0 + 8, tmp_bytes + 16);
-    if (!d_tmp) return LF_ERR_NOMEM;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, cnt64, d_hit_off, (int)(total + 1), s));
+    /* u32 counts summed into u64 offsets: one launch (lf_scan.h) */
+    { lf_scan_u32 f; f.p = d_cnt; const int src = lf_scan_excl(dv, 0, s, f, d_hit_off, total + 1); if (src != LF_OK) return src; }
     HIPCHK(hipEventRecord(ev[2], s));
     uint64_t *h_nhits = (uint64_t *)lfg_pin_slot(LF_PS_HITS_OFF, (size_t)(n_reads + 2) * 8);
     if (!h_nhits) return LF_ERR_NOMEM;

@@ -26,6 +26,7 @@
 #include <mutex>
 #include "lf_internal.h"
 #include "lf_gpu_common.h"
+#include "lf_scan.h"
 #include "lf_chain_kernel.h"
 #include "lf_clasp_kernel.h"
 
@@ -300,14 +301,13 @@ __global__ void lf_chain_gather_kernel(int n_req, const uint64_t *__restrict__ r
     const uint64_t o = req_off[q], co = chain_off[q];
     for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) chain_seeds[co + k] = sorted[o + chain_idx[o + k]];
 }
-struct lf_big_op { uint32_t lim; __host__ __device__ uint64_t operator()(uint32_t n) const { return n > lim ? (uint64_t)n : 0ull; } };
+struct lf_scan_big { const uint32_t *p; uint32_t lim; __device__ __forceinline__ uint64_t operator()(uint32_t i) const { const uint32_t n = p[i]; return n > lim ? (uint64_t)n : 0ull; } };   /* requests above the LDS classes: workspace in HBM */
 /* clasp keeps positions in `int`: windows above 2e9 are shifted down (src/LordFAST.cpp:684-692, 1030-1046) */
 __global__ void lf_req_shift_kernel(int n_req, const int64_t *__restrict__ req_lo, uint32_t *__restrict__ shift)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < n_req) shift[q] = req_lo[q] > 2000000000ll ? 2000000000u : 0u;
 }
-struct lf_w32 { __host__ __device__ uint64_t operator()(uint32_t v) const { return v; } };
 struct lf_twice { __host__ __device__ int operator()(uint64_t v) const { return (int)(2 * v); } };
 struct lf_w8 { __host__ __device__ uint64_t operator()(uint8_t v) const { return v; } };
 
@@ -373,11 +373,6 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
         d_stage = (uint32_t *)VSLOT(1, E * 4 + 16);
         uint32_t *d_tmp_list = (uint32_t *)VSLOT(2, E * 4 + 16);
         if (!d_stage || !d_tmp_list) return LF_ERR_NOMEM;
-        size_t tb3 = 0;
-        hipcub::TransformInputIterator<uint64_t, lf_w32, uint32_t *> nreq64(d_nreq, lf_w32());
-        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb3, nreq64, d_req0, n_reads + 1, s);
-        void *d_tmp = VSLOT(5, tb3 + 256);
-        if (!d_tmp) return LF_ERR_NOMEM;
         /* LDS table classes (load factor <= 2/3); reads above the largest keep their table in a global scratch area */
         static const uint32_t caps[3] = { 4096, 8192, 16384 };
         uint64_t v_max_lds = (uint64_t)caps[2] * 2 / 3;
@@ -422,7 +417,7 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
         if (d_dbg) { unsigned long long h[8]; HIPCHK(hipMemcpyAsync(h, d_dbg, 64, hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
             fprintf(stderr, "[lf] vote kernel cycles (sum over blocks, thread 0): zero %llu insert %llu passA %llu passB %llu fine %llu | fine reads %llu, candidates %llu, lists > 64: %llu (of %d reads)\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], n_reads); }
         /* request ids: exclusive scan over n_reads + 1 counts (the last one is a zero pad) */
-        { size_t tb = tb3; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, nreq64, d_req0, n_reads, s)); }
+        { lf_scan_u32 f; f.p = d_nreq; const int src = lf_scan_excl(dv, 1, s, f, d_req0, (size_t)n_reads); if (src != LF_OK) return src; }
         HIPCHK(hipMemcpyAsync(h_small, d_req0 + (R - 1), 8, hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(h_small + 1, d_nreq + (R - 1), 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -482,17 +477,10 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
                        d_ctg, d_ctg + ix->n_seqs, ix->n_seqs, (int64_t)ix->l_pac, d_req_read, d_req_win, d_req_lo, d_req_hi);
     hipLaunchKernelGGL(lf_req_gather_kernel<false>, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_req_read, d_req_win, d_req_lo, d_req_hi, d_read_off,
                        d_tpos, d_qpl, d_strand, d_req_n, (const uint64_t *)nullptr, (uint2 *)nullptr, (uint64_t *)nullptr, 0);
-    size_t tbs = 0, tbs2 = 0;
-    hipcub::TransformInputIterator<uint64_t, lf_w32, uint32_t *> n64(d_req_n, lf_w32());
     const bool clasp = p->chain_alg == 1;
     const uint32_t big_lim = clasp ? LF_CLASP_LDS_MAX : LF_CHAIN_LDS_MAX;
-    hipcub::TransformInputIterator<uint64_t, lf_big_op, uint32_t *> big64(d_req_n, lf_big_op{big_lim});
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tbs, n64, d_req_off, (int)n_req, s);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tbs2, big64, d_ws_off, (int)n_req, s);
-    void *d_tmp2 = VSLOT(9, std::max(tbs, tbs2) + 256);
-    if (!d_tmp2) return LF_ERR_NOMEM;
-    { size_t tb = tbs; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp2, tb, n64, d_req_off, (int)n_req, s)); }
-    { size_t tb = tbs2; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp2, tb, big64, d_ws_off, (int)n_req, s)); }
+    { lf_scan_u32 f; f.p = d_req_n; const int src = lf_scan_excl(dv, 1, s, f, d_req_off, (size_t)n_req); if (src != LF_OK) return src; }
+    { lf_scan_big f; f.p = d_req_n; f.lim = big_lim; const int src = lf_scan_excl(dv, 1, s, f, d_ws_off, (size_t)n_req); if (src != LF_OK) return src; }
     HIPCHK(hipMemcpyAsync(h_small + 2, d_req_off + (Q - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_small + 3, d_ws_off + (Q - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_small + 4, d_req_n + (Q - 1), 4, hipMemcpyDeviceToHost, s));
@@ -575,12 +563,7 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
             lo = hi + 1;
         }
     }
-    size_t tb5 = 0;
-    hipcub::TransformInputIterator<uint64_t, lf_w32, uint32_t *> cl64(d_clen, lf_w32());
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb5, cl64, d_coff, (int)n_req, s);
-    void *d_tmp4 = VSLOT(18, tb5 + 256);
-    if (!d_tmp4) return LF_ERR_NOMEM;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp4, tb5, cl64, d_coff, (int)n_req, s));
+    { lf_scan_u32 f; f.p = d_clen; const int src = lf_scan_excl(dv, 1, s, f, d_coff, (size_t)n_req); if (src != LF_OK) return src; }
     HIPCHK(hipMemcpyAsync(h_small + 5, d_coff + (Q - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_small + 6, d_clen + (Q - 1), 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

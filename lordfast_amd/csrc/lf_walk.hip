@@ -22,11 +22,12 @@
  * (cross-check in the tests).
  */
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <string.h>
 #include "lf_internal.h"
 #include "lf_gpu_common.h"
+#include "lf_scan.h"
+#include <algorithm>
 
 /* src/LordFAST.cpp:88-92 */
 #define W_CLIP_LEN  500
@@ -231,9 +232,8 @@ lf_walk_emit_kernel(int n_jobs, const lf_wjob_t *__restrict__ jobs, lf_walk_dev 
     }
 }
 
-struct lf_w32_op { __host__ __device__ uint64_t operator()(uint32_t v) const { return v; } };
-struct lf_slots_op { const lf_wjob_t *j; __host__ __device__ uint64_t operator()(int i) const { return (uint64_t)j[i].chain_len + 1; } };
-struct lf_items_op { const lf_wjob_t *j; __host__ __device__ uint64_t operator()(int i) const { return 2ull * j[i].chain_len + 1; } };
+struct lf_slots_op { const lf_wjob_t *j; __device__ uint64_t operator()(uint32_t i) const { return (uint64_t)j[i].chain_len + 1; } };
+struct lf_items_op { const lf_wjob_t *j; __device__ uint64_t operator()(uint32_t i) const { return 2ull * j[i].chain_len + 1; } };
 
 #define WSLOT(T, k, bytes) (T *)lfg_dev_slot(dv, LF_DS_WALK0 + (k), (bytes))
 
@@ -264,22 +264,13 @@ extern "C" int lfg_walk_plan(const struct lf_index *ix, int n_jobs, const lf_wjo
     HIPCHK(hipMemsetAsync(d_tot, 0, 64, s));
     hipLaunchKernelGGL(lf_walk_plan_kernel<false>, dim3((unsigned)n_jobs), dim3(64), 0, s, n_jobs, (const lf_wjob_t *)d_jobs, D, lazy, d_nd, d_ob, d_rare,
                        (const uint64_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr, (lf_aln_desc_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr, d_tot);
-    size_t tb = 0, tb2 = 0;
-    hipcub::TransformInputIterator<uint64_t, lf_w32_op, uint32_t *> nd64(d_nd, lf_w32_op());
-    hipcub::CountingInputIterator<int> cnt(0);
     lf_slots_op so; so.j = d_jobs; lf_items_op io; io.j = d_jobs;
-    hipcub::TransformInputIterator<uint64_t, lf_slots_op, hipcub::CountingInputIterator<int>> slots(cnt, so);
-    hipcub::TransformInputIterator<uint64_t, lf_items_op, hipcub::CountingInputIterator<int>> nitems(cnt, io);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, nd64, d_dbase, n_jobs + 1, s);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb2, d_ob, d_obase, n_jobs + 1, s);
-    void *d_tmp = WSLOT(void, 9, std::max(tb, tb2) + 256);
-    if (!d_tmp) return LF_ERR_NOMEM;
     /* scans over n_jobs + 1 inputs (the extra one is padding past the arrays' used part: zeroed) so that base[n_jobs] = total */
     HIPCHK(hipMemsetAsync(d_nd + J, 0, 4, s)); HIPCHK(hipMemsetAsync(d_ob + J, 0, 8, s));
-    { size_t t = tb; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, t, nd64, d_dbase, n_jobs + 1, s)); }
-    { size_t t = tb2; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, t, d_ob, d_obase, n_jobs + 1, s)); }
-    { size_t t = tb; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, t, slots, d_sbase, n_jobs, s)); }
-    { size_t t = tb; HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, t, nitems, d_ibase, n_jobs, s)); }
+    { lf_scan_u32 f; f.p = d_nd; const int src = lf_scan_excl(dv, 3, s, f, d_dbase, (size_t)n_jobs + 1); if (src != LF_OK) return src; }
+    { lf_scan_u64 f; f.p = d_ob; const int src = lf_scan_excl(dv, 3, s, f, d_obase, (size_t)n_jobs + 1); if (src != LF_OK) return src; }
+    { const int src = lf_scan_excl(dv, 3, s, so, d_sbase, (size_t)n_jobs); if (src != LF_OK) return src; }
+    { const int src = lf_scan_excl(dv, 3, s, io, d_ibase, (size_t)n_jobs); if (src != LF_OK) return src; }
     HIPCHK(hipMemcpyAsync(h, d_dbase + J, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h + 1, d_obase + J, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h + 2, d_sbase + (J - 1), 8, hipMemcpyDeviceToHost, s));
