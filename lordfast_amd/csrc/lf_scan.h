@@ -7,7 +7,10 @@
  * counter (so a tile only ever waits for tiles that are already running), publish (flag, epoch, value) in one 64-bit word --
  * flag 1 = the tile's own sum, 2 = the inclusive prefix up to and including the tile -- and look back over their
  * predecessors' words.  The status words need no clearing between launches: a word is valid only if it carries the
- * launch's epoch (14 bits; lfg_scan_ws clears the array when the epoch wraps or the array is new).
+ * launch's epoch (14 bits; lfg_scan_ws clears the array when the epoch wraps or the array is new).  Flag, epoch and value
+ * travel in ONE word, so the words are read and written with RELAXED agent-scope atomics (they bypass the non-coherent cache
+ * levels by themselves): an acquire / release pair per poll would invalidate / write back the L1 and L2 of a CU that other
+ * chunks' kernels are running on -- measured: 8 ms per step with sixteen chunks in flight.
  * Values are sums below 2^48.  Input is a functor of the element index (counts of another type, lengths derived from
  * records, ...), output u64. */
 #ifndef LF_SCAN_H
@@ -42,22 +45,37 @@ lf_scan_excl_kernel(F f, uint64_t *__restrict__ out, uint32_t n, unsigned long l
     uint64_t wbase = 0;
     for (int j = 0; j < w; j++) wbase += s_wsum[j];
     const uint64_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    if (tid == 0) {
+    if (w == 0) {
+        /* wavefront 0 publishes the tile's own sum at once, then looks back over 64 predecessors per trip: the nearest one that
+         * already knows its inclusive prefix ends the walk, the tiles between it and us contribute their own sums; a word
+         * that is not valid yet (wrong epoch / flag 0) is simply read again */
         const unsigned long long tag = ((unsigned long long)(epoch & 0x3fffu)) << 48, vmask = (1ull << 48) - 1;
         uint64_t prefix = 0;
-        if (tile == 0) __hip_atomic_store(&status[0], (2ull << 62) | tag | (total & vmask), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tile == 0) { if (lane == 0) __hip_atomic_store(&status[0], (2ull << 62) | tag | (total & vmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         else {
-            __hip_atomic_store(&status[tile], (1ull << 62) | tag | (total & vmask), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            for (int64_t j = (int64_t)tile - 1; j >= 0;) {
-                const unsigned long long x = __hip_atomic_load(&status[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                if (((x >> 48) & 0x3fffu) != (epoch & 0x3fffu) || (x >> 62) == 0) { __builtin_amdgcn_s_sleep(1); continue; }
-                prefix += x & vmask;
-                if ((x >> 62) == 2) break;
-                j--;
+            if (lane == 0) __hip_atomic_store(&status[tile], (1ull << 62) | tag | (total & vmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t hi = (int64_t)tile - 1;                       /* nearest predecessor of the current window */
+            for (;;) {
+                const int64_t j = hi - lane;
+                unsigned long long x = 0;
+                if (j >= 0) x = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool valid = j < 0 || (((x >> 48) & 0x3fffu) == (epoch & 0x3fffu) && (x >> 62) != 0);
+                const bool incl = j >= 0 && valid && (x >> 62) == 2;
+                const uint64_t im = __ballot(incl), vm = __ballot(valid);
+                /* lanes 0 .. first are usable when all of them are valid (first = nearest inclusive one, or 63 if none) */
+                const int first = im ? __ffsll((long long)im) - 1 : 63;
+                const uint64_t need = first == 63 ? ~0ull : ((2ull << first) - 1);
+                if ((vm & need) != need) { __builtin_amdgcn_s_sleep(2); continue; }
+                uint64_t part = (j >= 0 && lane <= first) ? (x & vmask) : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+                prefix += part;
+                if (im || hi - 63 <= 0) break;                     /* reached an inclusive prefix, or tile 0's side of the array */
+                hi -= 64;
             }
-            __hip_atomic_store(&status[tile], (2ull << 62) | tag | ((prefix + total) & vmask), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&status[tile], (2ull << 62) | tag | ((prefix + total) & vmask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        s_prefix = prefix;
+        if (lane == 0) s_prefix = prefix;
     }
     __syncthreads();
     uint64_t run = s_prefix + wbase + inc - sum;
