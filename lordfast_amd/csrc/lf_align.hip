@@ -53,9 +53,7 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
     const int lane = threadIdx.x, idx = blockIdx.x * 64 + lane;
     const bool live = idx < n_probs;
     const lf_aln_prob pr = probs[live ? idx : n_probs - 1];
-    const lf_qacc Q(S.q, pr.qstart, pr.flags); const lf_tacc T(S.t, S.pac, pr.tstart, pr.flags);
-    auto qget = [&](uint32_t r) -> unsigned char { return Q.get(r); };
-    const bool lazy = (pr.flags & LF_F_LAZYX) != 0;      /* diagonal moves are not classified here (lf_render_kernel does it) */
+    auto qget = [&](uint32_t) -> unsigned char { return 0; };          /* (lf_eq_tok's byte path is never taken with 2-bit targets) */
     const uint32_t n = pr.n, m = pr.m;
     const bool want = live && pr.task == LF_TASK_PATH;
     const uint32_t tl = pr.mode == 0 ? m : (uint32_t)(out_end[pr.id] + 1);
@@ -114,7 +112,12 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
                         const int bit = (int)((r - 1) & 63);
                         const uint32_t up = (uint32_t)(tPv[k] >> bit) & 1u, lf = ((uint32_t)(tPh[k] >> bit) & 1u) & ~up, dg = (up | lf) ^ 1u;
                         uint32_t op = up ? 1u : (lf ? 2u : 0u);      /* Up -> Left -> Diagonal (lib/edlib/edlib.cpp:950,984,1015) */
-                        if (!lazy) { if (dg && Q.get(r - 1) != T.get(c - 1)) op = 3u; }
+                        /* match or mismatch of a diagonal move: both bases are in registers -- the query's row in the block's bit
+                         * planes, the target's column in the tile's symbol word.  (Round 2 left every diagonal move as 0 and made
+                         * the renderer fetch and compare the bases: two dependent loads per 64-op tile there.) */
+                        const uint32_t tcode = (tok16 >> (2 * (half * HK + k))) & 3u;
+                        const uint32_t same = (uint32_t)(valid >> bit) & ~((uint32_t)(lo >> bit) ^ tcode) & ~((uint32_t)(hi >> bit) ^ (tcode >> 1)) & 1u;
+                        op = (dg & (same ^ 1u)) ? 3u : op;
                         em.put(op);
                         r -= up | dg; c -= lf | dg;
                         here = up != 0 && r > 0 && ((r - 1) >> 6) == b;      /* an Up move stays in the column (and maybe in the block) */

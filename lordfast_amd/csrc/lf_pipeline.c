@@ -2184,7 +2184,7 @@ static void *lane_main(void *arg_)
             continue;                               /* drain the remaining chunk ids the same way */
         }
         ctx_t cx; memset(&cx, 0, sizeof cx);
-        cx.ix = B->ixs[lane % B->n_ix]; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane]; cx.host_cigar = B->host_cigar; cx.host_vote = B->host_vote; cx.lazy = !B->host_cigar && !getenv("LF_NO_LAZY");
+        cx.ix = B->ixs[lane % B->n_ix]; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane]; cx.host_cigar = B->host_cigar; cx.host_vote = B->host_vote; cx.lazy = 0;      /* the traceback kernel classifies diagonal moves itself (from registers); LF_F_LAZYX stays for the kernels' stage users */
         cx.max_chunk_hits = max_hits;
         cx.dev_sam = !B->host_cigar && !B->host_vote && !(g_crosscheck & LF_XC_HOST_SAM);
         cx.sam_parity = parity;
