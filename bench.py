@@ -427,8 +427,12 @@ def main():
     if rank == 0 and args.no_exclusive:
         excl = {k: (v / args.steps if isinstance(v, (int, float)) else v) for k, v in agg.items()}      # overlapped brackets instead
     elif rank == 0:
-        saved = {k: os.environ.get(k) for k in ("LF_LANES", "LF_SERIAL_CLASSES")}
+        saved = {k: os.environ.get(k) for k in ("LF_LANES", "LF_SERIAL_CLASSES", "LF_CHUNK_READS", "LF_CHUNK_BASES")}
         os.environ["LF_LANES"] = "1"; os.environ["LF_SERIAL_CLASSES"] = "1"
+        if not os.environ.get("LF_BENCH_EXCL_CHUNKED"):
+            # the whole batch as ONE chunk: every kernel is launched once per step over all of the step's work, so "alone on the
+            # GPU" also means "with enough wavefronts to fill it" (a 25 k-read chunk left the small size classes with < 2 waves per SIMD)
+            os.environ["LF_CHUNK_READS"] = str(1 << 30); os.environ["LF_CHUNK_BASES"] = str(1 << 40)
         try:
             primary()                      # the one-chunk-at-a-time mode uses larger chunks: let the grow-only buffers settle
             _, excl = primary()
@@ -486,8 +490,9 @@ def main():
                         traffic_source=traffic_src,
                         launches_per_step=int(dl), avg_launch_ms=dms / max(1, dl), algorithmic_bytes_per_launch=dbytes / max(1, dl),
                         exclusive_ms_per_step=dms, exclusive_ms_sum_all_kernels=excl_sum, by_kernel=by_kernel,
-                        measured="exclusive pass inside bench.py: LF_LANES=1 LF_SERIAL_CLASSES=1, HIP events on the launch streams, one step "
-                                 "after the timed region; the rocprofv3 summary of the same mode is under profiles/",
+                        measured="exclusive pass inside bench.py: the whole batch as ONE chunk on one lane (LF_LANES=1, LF_CHUNK_READS / _BASES unlimited), the "
+                                 "alignment classes on one stream (LF_SERIAL_CLASSES=1), HIP events on the launch streams, one step after the timed region; "
+                                 "the rocprofv3 summary of the same mode is under profiles/",
                         overlapped_bracket_ms_per_step={k: round(v[0] / K, 2) for k, v in kernel_table(agg).items()},
                         chunks_in_flight_timed_region=8)
         if dom.startswith("lf_edlib"):

@@ -2394,7 +2394,8 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     }
     if (getenv("LF_TIMING")) fprintf(stderr, "[lf] setup (strlen + SAM buffer) %.1f ms, %d lanes, %d pool workers\n", now_ms() - T0, n_lanes, nw);
     /* chunks bound the device + host working set; reads stay in input order */
-    const uint64_t CHUNK_BASES = 400ull << 20;
+    uint64_t CHUNK_BASES = 400ull << 20;
+    if (getenv("LF_CHUNK_BASES")) { CHUNK_BASES = strtoull(getenv("LF_CHUNK_BASES"), NULL, 10); if (CHUNK_BASES < 1) CHUNK_BASES = 1; }      /* measurement hook: bench.py's exclusive pass maps the whole batch as ONE chunk */
     int CHUNK_READS = 32768;
     if (getenv("LF_CHUNK_READS")) { CHUNK_READS = atoi(getenv("LF_CHUNK_READS")); if (CHUNK_READS < 1) CHUNK_READS = 1; }   /* test hook */
     else if (n_lanes >= 2 && n > 2048) {

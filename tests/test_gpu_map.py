@@ -422,3 +422,29 @@ def test_map_batch_dev_fastq_short_reads_and_readgroup(lf, oracle, oracle_lib, g
     got = out.download(ln)
     assert got == exp, first_diff(got, exp)
     d_seqs.free(); d_quals.free(); out.free()
+
+
+def test_reads_at_the_edges_of_the_reference(lf, oracle, golden_dir):
+    """reads that start at the very first base / end at the very last base of a contig (and of the whole reference), on both
+    strands: the alignment kernels read their target windows 16 symbols at a time and a lane that has not started yet asks
+    for symbols in front of its target -- outside the 2-bit array at the edges of the reference.  Same records as the oracle."""
+    import gzip
+    import lordfast_amd as la
+    from conftest import read_fasta, GOLDEN
+    cn, cs = read_fasta(os.path.join(GOLDEN, "genome.fa.gz"))
+    rng = np.random.default_rng(41)
+    names, seqs = [], []
+    for ci, c in enumerate(cs):
+        a = np.frombuffer(c, dtype=np.uint8)
+        for tag, piece in (("head", a[:2600]), ("tail", a[-2600:]), ("head_short", a[:1100]), ("tail_short", a[-1100:])):
+            for strand in ("f", "r"):
+                x = synth.mutate(piece, 0.12, rng)
+                if strand == "r":
+                    x = synth.revcomp(x)
+                names.append(f"c{ci}_{tag}_{strand}".encode()); seqs.append(x.tobytes())
+    sam, st = lf.map_batch(names, seqs)
+    exp = oracle.map_batch(names, seqs)
+    assert sam == exp, first_diff(sam, exp)
+    mapped = [l for l in sam.split(b"\n") if l and not (int(l.split(b"\t")[1]) & 4)]
+    assert len(mapped) >= len(names) - 2 and st["n_edlib_problems"] > 0
+    assert any(l.split(b"\t")[3] == b"1" for l in mapped), "a record must start at position 1 of a contig"
