@@ -13,19 +13,19 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lfp_kt -- $B --step
 python3 profiles/tools/trim_stats.py $(ls /tmp/lfp_kt/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 python3 profiles/tools/busy.py $(ls /tmp/lfp_kt/*/*kernel_trace.csv | head -1) --last-step 8 > $OUT/gpu_busy_last_step.txt
 cp $(ls /tmp/lfp_kt/*/*agent_info.csv | head -1) $OUT/agent_info.csv 2>/dev/null
-LF_SERIAL_CLASSES=1 LF_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lfp_ser -- $B --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_serialized.json 2> /tmp/lfp_ser.err
+LF_CHUNK_READS=1073741824 LF_CHUNK_BASES=1099511627776 LF_SERIAL_CLASSES=1 LF_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lfp_ser -- $B --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_serialized.json 2> /tmp/lfp_ser.err
 python3 profiles/tools/trim_stats.py $(ls /tmp/lfp_ser/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_serialized.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/lfp_f -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-exclusive > $OUT/bench_under_pmc_fetch.json 2> /tmp/lfp_f.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/lfp_w -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-exclusive > $OUT/bench_under_pmc_write.json 2> /tmp/lfp_w.err
 python3 profiles/tools/summarize_pmc.py $OUT/pmc_fetch_write_summary.json $(ls /tmp/lfp_f/*/*counter_collection.csv | head -1) $(ls /tmp/lfp_w/*/*counter_collection.csv | head -1)
 # SQ instruction / stall counters, one chunk at a time, 50 k reads (three 8-slot passes)
-export LF_LANES=1 LF_SERIAL_CLASSES=1
+export LF_LANES=1 LF_SERIAL_CLASSES=1 LF_CHUNK_READS=1073741824 LF_CHUNK_BASES=1099511627776
 BS="python3 bench.py --reads 50000 --steps 1 --warmup 0 --no-cpu-baseline --no-exclusive"
 rm -rf /tmp/lfp_s1 /tmp/lfp_s2 /tmp/lfp_s3
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d /tmp/lfp_s1 -- $BS > /dev/null 2> /tmp/lfp_s1.err
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d /tmp/lfp_s2 -- $BS > /dev/null 2> /tmp/lfp_s2.err
 rocprofv3 --pmc SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d /tmp/lfp_s3 -- $BS > /dev/null 2> /tmp/lfp_s3.err
 python3 profiles/tools/summarize_pmc.py $OUT/sq_counters_50k_reads.json $(ls /tmp/lfp_s1/*/*counter_collection.csv /tmp/lfp_s2/*/*counter_collection.csv /tmp/lfp_s3/*/*counter_collection.csv 2>/dev/null)
-unset LF_LANES LF_SERIAL_CLASSES
+unset LF_LANES LF_SERIAL_CLASSES LF_CHUNK_READS LF_CHUNK_BASES
 python3 bench.py --tree-hash > $OUT/SOURCE_TREE.txt; (git rev-parse HEAD 2>/dev/null || echo "no git on this box") >> $OUT/SOURCE_TREE.txt
 ls -la $OUT
