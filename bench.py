@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exclusive", action="store_true", help="skip the exclusive pass (profiler counter runs: exactly the timed steps' launches)")
+    ap.add_argument("--no-host-region", action="store_true", help="skip the host-buffer region (kernel-trace runs that measure the GPU-busy fraction of the HBM-resident steps)")
     ap.add_argument("--workdir", default=os.environ.get("LF_BENCH_DIR", "/tmp/lf_bench"))
     ap.add_argument("--chain-alg", choices=["dp-n2", "clasp"], default="dp-n2",
                     help="BASELINE config C2 (the headline) is dp-n2; clasp + --max-map 30 is config C4's option set")
@@ -409,7 +410,7 @@ def main():
     elapsed_nx, cpu_s, agg, sam = timed(primary, args.steps)
     # ---- 2. the same steps through the host-buffer boundary (PCIe inside the step) ----
     elapsed_host = None
-    if args.mode != "inproc":
+    if args.mode != "inproc" and not args.no_host_region:
         step_host()
         elapsed_host, _, _, _ = timed(step_host, args.steps)
 

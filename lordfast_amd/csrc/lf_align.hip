@@ -70,7 +70,7 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
     auto load_planes = [&](uint32_t b) { const int ln = lane0 + (int)b; lo = planes[ln]; hi = planes[64 + ln]; valid = planes[128 + ln]; };
     uint32_t cur_b = r > 0 ? (r - 1) >> 6 : 0;
     load_planes(cur_b);
-    while (__any(r > 0 && c > 0)) {
+    while (lf_any(r > 0 && c > 0)) {
         const bool act = r > 0 && c > 0;
         const uint32_t b = act ? (r - 1) >> 6 : 0;
         /* the tile: the K steps of row j for block b; step k works on column cbase + k */
@@ -89,7 +89,7 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
         for (int half = 1; half >= 0; half--) {
             const int h0 = cbase + half * HK;                                   /* first column of the half */
             const bool in_half = r > 0 && c > 0 && ((r - 1) >> 6) == b && (int)c >= h0 && (int)c < h0 + HK && (act);
-            if (!__any(in_half)) continue;
+            if (!lf_any(in_half)) continue;
             uint64_t Pv = Pv0, Mv = Mv0;
             uint64_t tPv[HK], tPh[HK];
 #pragma unroll
@@ -276,7 +276,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
                 {   /* unconditional load from a clamped row (see lf_edlib_kernel) */
                     const bool in = b < nbk && r < n; bool ok; const uint32_t cd = lf_code_upper(qget(in ? r : n - 1), ok); code = (in && ok) ? (int)cd : -1;
                 }
-                const uint64_t bl = __ballot(code >= 0 && (code & 1)), bh = __ballot(code >= 0 && (code & 2)), bv = __ballot(code >= 0);
+                const uint64_t bl = lf_ballot(code >= 0 && (code & 1)), bh = lf_ballot(code >= 0 && (code & 2)), bv = lf_ballot(code >= 0);
                 if ((uint32_t)gl == b / KB) {
                     const int slot = (int)(b % KB);
                     const uint64_t xl = ((bl >> (g * G)) & gmask) << (sub * G), xh = ((bh >> (g * G)) & gmask) << (sub * G), xv = ((bv >> (g * G)) & gmask) << (sub * G);
@@ -299,7 +299,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     int score = 0, best = 0, best_c = 0;
     /* the bottom-row score is followed column by column only when a problem of the wavefront asks for the best prefix (SHW);
      * the NW distance is read off the last column afterwards, and the Hirschberg passes use neither */
-    bool track_shw = __any(live && pr.mode != 0);
+    bool track_shw = lf_any(live && pr.mode != 0);
     auto sweep_step = [&](int s, auto track_c, auto tile_c, int s0, uint32_t byte, uint64_t eq_ahead) {
         constexpr bool track = decltype(track_c)::value, tile = decltype(tile_c)::value;
         const uint32_t from_left = lf_wave_shr1(hout_prev);
@@ -392,7 +392,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
             __syncthreads();
             for (;;) {
                 const bool act = scur >= s0;
-                if (!__any(act)) break;
+                if (!lf_any(act)) break;
                 if (act) {
                     const uint32_t blk = (r - 1) >> 6;
                     const lf_hist_t e = s_tile[((scur - s0) * KB + (int)(blk % KB)) * 64 + g * G + (int)(blk / KB)];
@@ -443,7 +443,7 @@ lf_edlib_sweep_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seq
     if (pr.mode == 0) { ed = ed_nw; tl = (int)m; } else { ed = ed_shw; tl = c_shw; }
     if (live && gl == 0) { out_ed[pr.id] = ed; out_end[pr.id] = tl - 1; }
     if (KB == 1 && root_leaf) return;             /* wave-uniform (G < 64: always): path and out_len come from lf_edlib_tb_kernel */
-    if (!__any(want_path)) { if (live && gl == 0) out_len[pr.id] = 0; return; }
+    if (!lf_any(want_path)) { if (live && gl == 0) out_len[pr.id] = 0; return; }
     if (root_leaf) {
         traceback((uint32_t)tl, steps_max, want_path);
     }
@@ -959,13 +959,13 @@ lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t 
         int nb = end;
         for (int base = beg; base < end; base += 64) {
             const int j = base + lane;
-            const unsigned long long nz = __ballot(j < end && (H[j] != 0 || E[j] != 0));
+            const unsigned long long nz = lf_ballot(j < end && (H[j] != 0 || E[j] != 0));
             if (nz) { nb = base + (__ffsll((long long)nz) - 1); break; }
         }
         int ne = nb - 1;
         for (int top = end; top >= nb; top -= 64) {
             const int j = top - lane;
-            const unsigned long long nz = __ballot(j >= nb && (H[j] != 0 || E[j] != 0));
+            const unsigned long long nz = lf_ballot(j >= nb && (H[j] != 0 || E[j] != 0));
             if (nz) { ne = top - (__ffsll((long long)nz) - 1); break; }
         }
         beg = nb;

@@ -165,7 +165,7 @@ __device__ __forceinline__ int lf_clasp_rmq(const lf_clasp_mem<R> &m, const R *e
                 if (ey == LF_CLASP_NONE || p2 > pr || (p2 == pr && e > ey)) { pr = p2; ey = e; ix = (uint32_t)k; }
             }
         }
-        if (__ballot(ey != LF_CLASP_NONE) == 0) continue;
+        if (lf_ballot(ey != LF_CLASP_NONE) == 0) continue;
         lf_clasp_cand cd; cd.pr = pr; cd.ey = ey; cd.ix = ix;
         cd = lf_clasp_wreduce(nd->wr).Reduce(cd, lf_clasp_better());
         if (lane == 0) { nd->pr[K] = cd.pr; nd->ix[K] = (int)cd.ix; }

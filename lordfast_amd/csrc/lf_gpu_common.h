@@ -7,6 +7,11 @@
 #include <stdio.h>
 #include "lf_internal.h"
 
+/* wave64 vote: the comparison's own lane mask.  (HIP's __ballot / __any materialise the predicate as 0 / 1 in a VGPR and
+ * compare it with 0 again: two 4-cycle VOP3 instructions per vote in loops that are bound by VALU issue.) */
+#define lf_ballot(pred) ((uint64_t)__builtin_amdgcn_ballot_w64((bool)(pred)))
+#define lf_any(pred) (__builtin_amdgcn_ballot_w64((bool)(pred)) != 0ull)
+
 /* every checked HIP call leaves its source position in a per-lane slot: LF_WATCHDOG=<seconds> prints them when a batch
  * does not finish (lf_pipeline.c) */
 extern "C" void lfg_phase(const char *file, int line);

@@ -63,7 +63,7 @@ __device__ __forceinline__ int lf_hsweep(const lf_qacc &Q, const lf_tacc &T, con
             const uint32_t r = (b0 + b) * 64 + (uint32_t)lane;
             bool ok; const uint32_t cd = lf_code_upper(qget(r < n ? r : n - 1), ok);
             const int code = (r < n && ok) ? (int)cd : -1;
-            const uint64_t bl = __ballot(code >= 0 && (code & 1)), bh = __ballot(code >= 0 && (code & 2)), bv = __ballot(code >= 0);
+            const uint64_t bl = lf_ballot(code >= 0 && (code & 1)), bh = lf_ballot(code >= 0 && (code & 2)), bv = lf_ballot(code >= 0);
             if ((uint32_t)lane == b / KB) {
                 const int slot = (int)(b % KB);
 #pragma unroll
@@ -273,7 +273,7 @@ lf_hirsch_level_kernel(lf_hargs A)
     for (uint32_t base = 0; base + 2 <= n && split == -2; base += 64) {
         const uint32_t qi = base + (uint32_t)lane;
         const bool hit = qi + 2 <= n && F(qi + 1) + R(n - qi - 1) == best;
-        const uint64_t bm = __ballot(hit);
+        const uint64_t bm = lf_ballot(hit);
         if (bm) split = (int)(base + (uint32_t)(__ffsll((long long)bm) - 1));
     }
     if (split >= 0) { ls = F((uint32_t)split + 1); rs = R(n - (uint32_t)split - 1); }

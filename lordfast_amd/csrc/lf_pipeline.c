@@ -2399,11 +2399,13 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     int CHUNK_READS = 32768;
     if (getenv("LF_CHUNK_READS")) { CHUNK_READS = atoi(getenv("LF_CHUNK_READS")); if (CHUNK_READS < 1) CHUNK_READS = 1; }   /* test hook */
     else if (n_lanes >= 2 && n > 2048) {
-        /* two chunks per lane.  Round 1 measured 3 per lane as the optimum (2: 357-369 ms, 3: 333-342 ms, 4: 352 ms, 6: 414 ms per
-         * 100 k reads on 8 lanes) when every lane waited for the chunks of earlier reads before it took its next one; now
-         * that a finished chunk may stay pending (lane_main) larger chunks win: 100 k reads / 8 lanes, same box, chunks of
-         * 3125 / 4167 / 5000 / 6250 reads: 586 / 609 / 642 / 670 k reads/s; 6250 ... 12500 within the noise of each other. */
-        int want = (n + 2 * n_lanes - 1) / (2 * n_lanes); if (want < 1024) want = 1024;
+        /* Chunks per lane.  Reads already in HBM (lf_map_batch_dev): ONE -- nothing of a chunk waits for a bus, the lanes only
+         * overlap each other's host phases, and larger chunks fill the GPU better with fewer launches (100 k reads, 8 lanes, chunks
+         * of 3125 / 6250 / 12500 / 16667 / 25000 / 100000 reads: 0.92 / 1.06 / 1.15-1.22 / 1.19 / 1.19 / 1.13 M reads/s).  Host
+         * buffers: THREE -- the 1.5 GB of bases going up and the 4 GB of SAM text coming down per 100 k reads overlap the other
+         * chunks' kernels better in smaller pieces (same sweep: 768 / 727 / 673-704 / 733 / 705 / 675 k reads/s). */
+        const int per_lane = (dio && !dio->stage_sink) ? 1 : 3;
+        int want = (n + per_lane * n_lanes - 1) / (per_lane * n_lanes); if (want < 1024) want = 1024;
         if (want < CHUNK_READS) CHUNK_READS = want;
     }
     /* reads x sampling positions is a 31-bit index in the seed stage */

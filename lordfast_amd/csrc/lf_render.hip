@@ -28,34 +28,53 @@
 #include "lf_gpu_common.h"
 #include "lf_scan.h"
 
-struct lf_rrounds { const uint8_t *ops[LF_MAX_ED_ROUNDS]; const lf_aln_desc_t *desc[LF_MAX_ED_ROUNDS]; };
+struct lf_rrounds { const uint8_t *ops[LF_MAX_ED_ROUNDS]; };
 
+/* decimal digits of v followed by up to two characters (any v: the scalar path and the rare long runs) */
 __device__ __forceinline__ int lf_ndigits(uint32_t v)
 {
-    if (!__any(v >= 10000u)) return 1 + (int)(v >= 10u) + (int)(v >= 100u) + (int)(v >= 1000u);      /* run lengths and match counts are small */
     return v < 10u ? 1 : v < 100u ? 2 : v < 1000u ? 3 : v < 10000u ? 4 : v < 100000u ? 5 : v < 1000000u ? 6
          : v < 10000000u ? 7 : v < 100000000u ? 8 : v < 1000000000u ? 9 : 10;
 }
-/* decimal digits of v followed by up to two characters */
 __device__ __forceinline__ void lf_put_token(char *dst, uint32_t v, int nd, char c1, char c2)
 {
     for (int k = nd - 1; k >= 0; k--) { dst[k] = (char)('0' + v % 10u); v /= 10u; }
     dst[nd] = c1;
     if (c2) dst[nd + 1] = c2;
 }
-/* exclusive prefix sum over the wavefront + total: rocPRIM's DPP scan (row shifts / broadcasts on the VALU) -- the
- * shuffle version was six dependent LDS-crossbar permutes per call, two calls per 64-op tile */
-__device__ __forceinline__ uint32_t lf_wave_excl_sum(uint32_t v, uint32_t *total)
+/* the tile path: run lengths and match counts below 10 000 (a wave-uniform test sends anything longer to the functions above).
+ * nd = 1 .. 4 without a branch; the token is built in a register -- v / 10 as a 24-bit multiply and a shift (exact below
+ * 81 920) -- and leaves as byte stores under one comparison each. */
+__device__ __forceinline__ int lf_ndigits4(uint32_t v) { return 1 + (int)(v >= 10u) + (int)(v >= 100u) + (int)(v >= 1000u); }
+__device__ __forceinline__ void lf_put_token4(char *dst, uint32_t v, int nd /* 0 .. 4 */, uint32_t c1, uint32_t c2 /* 0: none */)
 {
-    typedef hipcub::WarpScan<uint32_t, 64> scan_t;
-    __shared__ typename scan_t::TempStorage tmp;
-    uint32_t excl, tot;
-    scan_t(tmp).ExclusiveSum(v, excl, tot);
-    *total = tot;
-    return excl;
+    const uint32_t q1 = __umul24(v, 52429u) >> 19, q2 = __umul24(q1, 52429u) >> 19, q3 = __umul24(q2, 52429u) >> 19;
+    const uint32_t d3 = v - 10u * q1, d2 = q1 - 10u * q2, d1 = q2 - 10u * q3;      /* q3 = thousands */
+    const uint64_t dig = (uint64_t)(0x30303030u + (q3 | (d1 << 8) | (d2 << 16) | (d3 << 24))) >> ((4 - nd) << 3);      /* first digit in byte 0; nd 0: none */
+    const uint64_t tok = dig | ((uint64_t)(c1 | (c2 << 8)) << (nd << 3));
+    const int len = nd + 1 + (c2 ? 1 : 0);
+    const uint32_t lo = (uint32_t)tok, hi = (uint32_t)(tok >> 32);
+    dst[0] = (char)lo;
+    if (len > 1) dst[1] = (char)(lo >> 8);
+    if (len > 2) dst[2] = (char)(lo >> 16);
+    if (len > 3) dst[3] = (char)(lo >> 24);
+    if (len > 4) dst[4] = (char)hi;
+    if (len > 5) dst[5] = (char)(hi >> 8);
 }
-/* lane l receives lane l-1's value (lane 0: 0): DPP wave_shr:1 */
-__device__ __forceinline__ int lf_wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+/* DPP form (VALU, no LDS crossbar) of the inclusive prefix sum over the wavefront */
+__device__ __forceinline__ uint32_t lf_wave_incl_sum(uint32_t v)
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      /* row_shr:1 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);      /* row_shr:2 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);      /* row_shr:4 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);      /* row_shr:8 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);     /* row_bcast:15 -> rows 1, 3 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);     /* row_bcast:31 -> rows 2, 3 */
+    return (uint32_t)x;
+}
+/* set bits of m below this lane */
+__device__ __forceinline__ uint32_t lf_mbcnt(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 __device__ __forceinline__ char lf_pac_char(const uint8_t *pac, uint32_t pos, int comp)
 {
     int b = (pac[pos >> 2] >> ((~pos & 3u) << 1)) & 3;
@@ -69,20 +88,20 @@ __device__ __forceinline__ char lf_pac_char(const uint8_t *pac, uint32_t pos, in
 #define T_I  2
 #define T_D  3
 
-/* MODE 0: counting pass (exact sizes, resolves lazy mismatches in place)   1: writing pass behind it
- *      2: SINGLE pass -- writes into per-record regions sized by an upper bound (lf_render_caps_kernel), resolves lazy
- *         mismatches on the fly and reports the exact lengths; the SAM writer copies the text out of the regions anyway,
- *         so nothing is gained by packing it first. */
+/* MODE 0: counting pass (exact sizes)   1: writing pass behind it (packed text: the host-side consumers)
+ *      2: SINGLE pass -- writes into per-record regions sized by an upper bound (lf_render_caps_kernel) and reports the exact
+ *         lengths; the SAM writer copies the text out of the regions anyway, so nothing is gained by packing it first.
+ * Every path arrives with its mismatches marked (op 3): the edlib traceback kernels classify the diagonal moves themselves. */
 #define LF_RM_COUNT  0
 #define LF_RM_WRITE  1
 #define LF_RM_SINGLE 2
 template <int MODE>
 __global__ void __launch_bounds__(64)
 lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_ritem_t *__restrict__ items, lf_rrounds R,
-                 const uint8_t *__restrict__ pac, const unsigned char *__restrict__ reads, uint32_t *__restrict__ lens /* 2 per record */,
+                 const uint8_t *__restrict__ pac, uint32_t *__restrict__ lens /* 2 per record */,
                  const uint64_t *__restrict__ offs /* 2 per record (WRITE) */, char *__restrict__ text)
 {
-    constexpr bool WRITE = MODE != LF_RM_COUNT, RESOLVE = MODE != LF_RM_WRITE;
+    constexpr bool WRITE = MODE != LF_RM_COUNT;
     const int rec = blockIdx.x;
     if (rec >= n_recs) return;
     const int lane = threadIdx.x;
@@ -104,28 +123,22 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
         c_ch = ch; c_run = n;
     };
 
-    /* The items of a record form a chain of dependent loads (item -> its ops -> its descriptor -> bases): the next item, the
-     * first tile of its ops and its descriptor are fetched while the current item is processed, so that a record costs one
-     * round trip per item instead of three or four (a record has ~240 items of ~100 ops). */
-    auto ops_ptr = [&](const lf_ritem_t &X) -> const uint8_t * { return R.ops[X.round] + X.ops_begin; };
-    auto first_tile = [&](const lf_ritem_t &X) -> uint8_t {
-        if (X.n == 0 || X.kind < LF_RI_OPS_FWD || X.kind > LF_RI_OPS_REV || (uint32_t)lane >= X.n) return 0;
-        return ops_ptr(X)[X.kind == LF_RI_OPS_REV ? X.n - 1 - (uint32_t)lane : (uint32_t)lane];
-    };
-    auto desc_of = [&](const lf_ritem_t &X) -> lf_aln_desc_t {
-        lf_aln_desc_t d; d.qstart = 0; d.tstart = 0; d.flags = 0; d.n = d.m = 0; d.mode = 0;
-        if (RESOLVE && X.n != 0 && X.kind >= LF_RI_OPS_FWD && X.kind <= LF_RI_OPS_REV && X.lazy) d = R.desc[X.round][X.slot];
-        return d;
+    /* The items of a record form a chain of dependent loads (item -> its ops): the next item and the first tile of its ops are
+     * fetched while the current item is processed, and inside a path the next tile's ops while the current tile is encoded
+     * (a record has ~240 items of ~100 ops). */
+    auto is_path = [&](const lf_ritem_t &X) -> bool { return X.n != 0 && X.kind >= LF_RI_OPS_FWD && X.kind <= LF_RI_OPS_REV; };
+    auto tile_op = [&](const lf_ritem_t &X, uint32_t base) -> uint32_t {
+        const uint32_t k = base + (uint32_t)lane;
+        if (k >= X.n) return 0;
+        return (R.ops[X.round] + X.ops_begin)[X.kind == LF_RI_OPS_REV ? X.n - 1 - k : k];
     };
     lf_ritem_t Inext; memset(&Inext, 0, sizeof Inext);
     if (rr.nitems) Inext = items[rr.item0];
-    uint8_t op_next = first_tile(Inext);
-    lf_aln_desc_t dsc_next = desc_of(Inext);
+    uint32_t op_next = is_path(Inext) ? tile_op(Inext, 0) : 0;
     for (uint32_t it = 0; it < rr.nitems; it++) {
         const lf_ritem_t I = Inext;
-        const uint8_t op_first = op_next;
-        const lf_aln_desc_t dsc_pref = dsc_next;
-        if (it + 1 < rr.nitems) { Inext = items[rr.item0 + it + 1]; op_next = first_tile(Inext); dsc_next = desc_of(Inext); }
+        uint32_t op_cur = op_next;
+        if (it + 1 < rr.nitems) { Inext = items[rr.item0 + it + 1]; op_next = is_path(Inext) ? tile_op(Inext, 0) : 0; }
         if (I.n == 0) continue;
         if (I.kind == LF_RI_RUN_M) { cigar_run('M', I.n); m_num += I.n; m_last = T_EQ; continue; }
         if (I.kind == LF_RI_RUN_I) { cigar_run('I', I.n); m_last = T_I; continue; }
@@ -136,79 +149,79 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
                 if (WRITE && lane == 0) lf_put_token(md + m_out, m_num, nd, '^', 0);
                 m_out += nd + 1; m_num = 0;
             }
-            if (WRITE) for (uint32_t j = lane; j < I.n; j += 64) md[m_out + j] = lf_pac_char(pac, I.tpos + j, 0);
+            if (WRITE) {
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+                for (uint32_t j = lane; j < I.n; j += 64) md[m_out + j] = lf_pac_char(pac, I.tpos + j, 0);
+            }
             m_out += I.n; m_last = T_D;
             continue;
         }
-        /* an edit path: I.n ops at R.ops[round] + ops_begin, forward or reversed */
-        const uint8_t *ops = R.ops[I.round] + I.ops_begin;
-        const int rev = (I.kind == LF_RI_OPS_REV), trc = (I.kind == LF_RI_OPS_FWD_TRC);
-        uint32_t tcarry = 0, qcarry = 0;
-        /* a lazy path has op 0 for EVERY diagonal move: match / mismatch is decided here, by the comparison the edlib
-         * kernels would have made (same accessors, same indices in the problem's own orientation) -- but coalesced */
-        const lf_aln_desc_t dsc = dsc_pref;
-        const lf_qacc QA(reads, dsc.qstart, dsc.flags); const lf_tacc TA(nullptr, pac, dsc.tstart, dsc.flags | LF_F_TPAC);
+        /* an edit path: I.n ops, forward or reversed */
+        const int trc = (I.kind == LF_RI_OPS_FWD_TRC);
+        uint32_t tcarry = 0;
         for (uint32_t base = 0; base < I.n; base += 64) {
-            const uint32_t k = base + lane;
-            const bool act = k < I.n;
+            const uint32_t op = op_cur;
+            if (base + 64 < I.n) op_cur = tile_op(I, base + 64);
             const uint32_t cnt = (I.n - base < 64u) ? I.n - base : 64u;
-            int ty = T_EQ;
-            if (act) { const uint8_t op = base == 0 ? op_first : ops[rev ? I.n - 1 - k : k]; ty = op == 0 ? T_EQ : op == 1 ? T_I : op == 2 ? T_D : T_X; }
-            if (I.lazy && RESOLVE) {         /* the counting pass resolves and writes the mismatches back: the writing pass reads final ops */
-                const uint64_t nd_mask = __ballot(act && ty != T_D), ni_mask = __ballot(act && ty != T_I);
-                if (act && ty == T_EQ) {
-                    const uint32_t qe = qcarry + (uint32_t)__popcll(nd_mask & below), te = tcarry + (uint32_t)__popcll(ni_mask & below);
-                    const uint32_t qi = rev ? I.qn - 1 - qe : qe, ti2 = rev ? I.tcons - 1 - te : te;
-                    if (QA.get(qi) != TA.get(ti2)) { ty = T_X; if (MODE == LF_RM_COUNT) const_cast<uint8_t *>(ops)[rev ? I.n - 1 - k : k] = 3; }
-                }
-                qcarry += (uint32_t)__popcll(nd_mask);
-            }
-            const int ch = !act ? 0 : (ty == T_I ? 'I' : ty == T_D ? 'D' : 'M');
-            /* ---- CIGAR ---- */
-            int pch = lf_wave_shr1(ch); if (lane == 0) pch = c_ch;
+            const bool act = (uint32_t)lane < cnt;
+            /* op 0 = 1 I 2 D 3 X  ->  type (inactive lanes: T_EQ) and CIGAR letter (inactive: 0) from two register tables */
+            const int ty = (int)((0x78u >> (op << 1)) & 3u);
+            const int ch = act ? (int)((0x4d44494du >> (op << 3)) & 0xffu) : 0;
+            const bool isx = act && ty == T_X, isd = act && ty == T_D, isxd = isx || isd;
+            const uint64_t eqmask = lf_ballot(act && ty == T_EQ), nimask = lf_ballot(act && ty != T_I);
+            /* the reference base of a mismatch / deletion: asked for first, used last */
+            uint32_t bch = 0;
+            if (isxd) { const uint32_t ti = tcarry + lf_mbcnt(nimask); bch = (uint32_t)(uint8_t)lf_pac_char(pac, trc ? I.tpos - ti : I.tpos + ti, trc); }
+            /* ---- CIGAR: a lane whose letter differs from its left neighbour's closes the neighbour's run ---- */
+            const int pch = __builtin_amdgcn_update_dpp(c_ch, ch, 0x138, 0xf, 0xf, false);      /* wave_shr:1; lane 0 keeps the carried letter */
             const bool start = act && ch != pch;
-            const uint64_t smask = __ballot(start);
+            const uint64_t smask = lf_ballot(start);
             const bool emits = start && pch != 0;
-            const uint64_t emask = __ballot(emits);
-            uint32_t tlen = 0, rl = 0; int nd = 0;
-            if (emits) {
-                const uint64_t sb = smask & below;
-                rl = sb ? (uint32_t)(lane - (63 - __clzll((long long)sb))) : c_run + (uint32_t)lane;
-                nd = lf_ndigits(rl); tlen = (uint32_t)nd + 1;
-            }
-            /* (the CIGAR token is placed below: ONE wave scan serves both strings, token lengths packed 16 + 16 bits) */
-            const int lastch = __builtin_amdgcn_readlane(ch, __builtin_amdgcn_readfirstlane((int)cnt - 1));
-            if (smask) c_run = cnt - (uint32_t)(63 - __clzll((long long)smask)); else c_run += cnt;
-            c_ch = lastch;
-            /* ---- MD ---- */
-            int pty = lf_wave_shr1(ty); if (lane == 0) pty = m_last;
-            const bool isx = act && ty == T_X, isd = act && ty == T_D;
+            const uint64_t emask = lf_ballot(emits);
+            /* (straight-line from here to the stores: almost every tile has a lane of every kind, so a branch around a few
+             * operations only adds its exec-mask bookkeeping to a loop that is bound by instruction issue) */
+            const uint64_t sb = smask & below;
+            const uint32_t rl = sb ? (uint32_t)(lane - (63 - __clzll((long long)sb))) : c_run + (uint32_t)lane;
+            /* ---- MD: a mismatch, or the first base of a deletion, flushes the match counter ---- */
+            const int pty = __builtin_amdgcn_update_dpp(m_last, ty, 0x138, 0xf, 0xf, false);
             const bool flush = isx || (isd && pty != T_D);
-            const uint64_t eqmask = __ballot(act && ty == T_EQ), fmask = __ballot(flush), nimask = __ballot(act && ty != T_I);
-            uint32_t mlen = 0, num = 0; int mnd = 0; char bch = 0;
-            if (isx || isd) {
-                const uint32_t ti = tcarry + (uint32_t)__popcll(nimask & below);
-                bch = lf_pac_char(pac, trc ? I.tpos - ti : I.tpos + ti, trc);
-                if (flush) {
-                    const uint64_t fb = fmask & below;
-                    if (fb) { const int p = 63 - __clzll((long long)fb); num = (uint32_t)__popcll(eqmask & below & ~(~0ull >> (63 - p))); }
-                    else num = m_num + (uint32_t)__popcll(eqmask & below);
-                    mnd = lf_ndigits(num); mlen = (uint32_t)mnd + (isd ? 2u : 1u);
-                } else mlen = 1;
-            }
-            uint32_t both; const uint32_t excl = lf_wave_excl_sum(tlen | (mlen << 16), &both);      /* <= 64 x 12 per half: no carry */
+            const uint64_t fmask = lf_ballot(flush);
+            const uint32_t eqb = lf_mbcnt(eqmask);                         /* matches below this lane */
+            const uint64_t fb = fmask & below;
+            const int p = fb ? 63 - __clzll((long long)fb) : 0;            /* the previous flushing lane (not a match itself) */
+            const uint32_t eqp = (uint32_t)__shfl((int)eqb, p);
+            const uint32_t num = fb ? eqb - eqp : m_num + eqb;
+            /* run lengths / match counts of five digits and more: the general functions (wave-uniform, rare) */
+            const bool big = lf_any((emits && rl >= 10000u) || (flush && num >= 10000u));
+            int nd = lf_ndigits4(rl), mnd = flush ? lf_ndigits4(num) : 0;
+            if (big) { nd = lf_ndigits(rl); mnd = flush ? lf_ndigits(num) : 0; }
+            const uint32_t tlen = emits ? (uint32_t)nd + 1u : 0u;
+            const uint32_t mlen = isxd ? (uint32_t)mnd + (flush && isd ? 2u : 1u) : 0u;      /* [count] [^] base */
+            /* ONE wave scan places both strings' tokens: lengths packed 16 + 16 bits (<= 64 x 12 per half: no carry) */
+            const uint32_t packed = tlen | (mlen << 16), incl = lf_wave_incl_sum(packed), excl = incl - packed;
+            const uint32_t both = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             const uint32_t pos = excl & 0xffffu, mpos = excl >> 16, tot = both & 0xffffu, mtot = both >> 16;
-            if (WRITE && emits) lf_put_token(cg + c_out + pos, rl, nd, (c_first && !(emask & below) && pch == 'I') ? 'S' : (char)pch, 0);
+            if (WRITE) {
+                const uint32_t letter = (c_first && !(emask & below) && pch == 'I') ? (uint32_t)'S' : (uint32_t)pch;
+                const uint32_t c1 = (flush && isd) ? (uint32_t)'^' : bch, c2 = (flush && isd) ? bch : 0u;
+                if (!big) {
+                    if (emits) lf_put_token4(cg + c_out + pos, rl, nd, letter, 0);
+                    if (isxd) lf_put_token4(md + m_out + mpos, num, mnd, c1, c2);
+                } else {
+                    if (emits) lf_put_token(cg + c_out + pos, rl, nd, (char)letter, 0);
+                    if (isxd) lf_put_token(md + m_out + mpos, num, mnd, (char)c1, (char)c2);
+                }
+            }
+            /* carried state */
+            const int last = __builtin_amdgcn_readfirstlane((int)cnt - 1);
+            if (smask) c_run = cnt - (uint32_t)(63 - __clzll((long long)smask)); else c_run += cnt;
+            c_ch = __builtin_amdgcn_readlane(ch, last);
             c_out += tot;
             if (emask) c_first = 0;
-            if (WRITE && (isx || isd)) {
-                if (flush) lf_put_token(md + m_out + mpos, num, mnd, isd ? '^' : bch, isd ? bch : 0);
-                else md[m_out + mpos] = bch;
-            }
             m_out += mtot;
             if (fmask) { const int p = 63 - __clzll((long long)fmask); m_num = (uint32_t)__popcll(eqmask & ~(~0ull >> (63 - p))); }
             else m_num += (uint32_t)__popcll(eqmask);
-            m_last = __builtin_amdgcn_readlane(ty, __builtin_amdgcn_readfirstlane((int)cnt - 1));
+            m_last = __builtin_amdgcn_readlane(ty, last);
             tcarry += (uint32_t)__popcll(nimask);
         }
     }
@@ -284,8 +297,8 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_dev_recs, const void 
     uint32_t *h_tail = (uint32_t *)lfg_pin_slot(LF_PS_RENDER0 + 1, 64);
     if (!d_recs || !d_items || !d_lens || !d_offs || !h_offs || !h_tail) return LF_ERR_NOMEM;
     lf_rrounds R;
-    for (int r = 0; r < LF_MAX_ED_ROUNDS; r++) { R.ops[r] = (const uint8_t *)round_ops[r]; R.desc[r] = (const lf_aln_desc_t *)round_desc[r]; }
-    const unsigned char *d_reads = (const unsigned char *)lfg_dev_slot(device, LF_DS_SEED0 + 0, 0);      /* read batch left in HBM by lfg_seed */
+    for (int r = 0; r < LF_MAX_ED_ROUNDS; r++) { R.ops[r] = (const uint8_t *)round_ops[r]; }
+    (void)round_desc;
     hipEvent_t e0 = (hipEvent_t)lfg_lane_event(device, 32), e1 = (hipEvent_t)lfg_lane_event(device, 33);
     if (!e0 || !e1) return LF_ERR_HIP;
     if (n_host_recs) {       /* the caller has rebased the host records' item0 by n_dev_items */
@@ -297,7 +310,7 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_dev_recs, const void 
     uint32_t *d_caps = single ? (uint32_t *)lfg_dev_slot(device, LF_DS_RENDER0 + 6, (size_t)n_recs * 8) : d_lens;
     if (!d_caps) return LF_ERR_NOMEM;
     if (single) hipLaunchKernelGGL(lf_render_caps_kernel, dim3((unsigned)((n_recs + 3) / 4)), dim3(256), 0, s, d_recs, n_recs, d_items, d_caps);
-    else hipLaunchKernelGGL(lf_render_kernel<LF_RM_COUNT>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac, d_reads,
+    else hipLaunchKernelGGL(lf_render_kernel<LF_RM_COUNT>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac,
                             d_lens, (const uint64_t *)nullptr, (char *)nullptr);
     { lf_scan_u32 f; f.p = d_caps; const int src = lf_scan_excl(device, 5, s, f, d_offs, 2 * (size_t)n_recs); if (src != LF_OK) return src; }
     HIPCHK(hipMemcpyAsync(h_offs, d_offs, (size_t)n_recs * 16, hipMemcpyDeviceToHost, s));
@@ -308,9 +321,9 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_dev_recs, const void 
     char *h_text = dev_text ? nullptr : (char *)lfg_pin_slot(LF_PS_RENDER0 + 2, total + 64);
     uint32_t *h_lens = dev_text ? (uint32_t *)lfg_pin_slot(LF_PS_RENDER1 + 0, (size_t)n_recs * 8 + 16) : nullptr;      /* never the slot of an input (the caller's items live in LF_PS_RENDER0 + 3) */
     if (!d_text || (!dev_text && !h_text) || (dev_text && !h_lens)) return LF_ERR_NOMEM;
-    if (single) hipLaunchKernelGGL(lf_render_kernel<LF_RM_SINGLE>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac, d_reads,
+    if (single) hipLaunchKernelGGL(lf_render_kernel<LF_RM_SINGLE>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac,
                                    d_lens, (const uint64_t *)d_offs, d_text);
-    else hipLaunchKernelGGL(lf_render_kernel<LF_RM_WRITE>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac, d_reads,
+    else hipLaunchKernelGGL(lf_render_kernel<LF_RM_WRITE>, dim3((unsigned)n_recs), dim3(64), 0, s, d_recs, n_recs, d_items, R, st->view.pac,
                             d_lens, (const uint64_t *)d_offs, d_text);
     HIPCHK(hipEventRecord(e1, s));
     if (dev_text) HIPCHK(hipMemcpyAsync(h_lens, d_lens, (size_t)n_recs * 8, hipMemcpyDeviceToHost, s));      /* SA:Z strings need a few CIGARs (lfg_fetch) */

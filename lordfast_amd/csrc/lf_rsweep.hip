@@ -42,7 +42,7 @@ lf_pack_planes_kernel(const unsigned char *__restrict__ src, uint64_t n, uint64_
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             bool ok; const uint32_t cd = lf_code_upper(ch[u], ok);
-            const uint64_t bl = __ballot(ok && (cd & 1u)), bh = __ballot(ok && (cd & 2u)), bv = __ballot(ok);
+            const uint64_t bl = lf_ballot(ok && (cd & 1u)), bh = lf_ballot(ok && (cd & 2u)), bv = lf_ballot(ok);
             if (lane == i0 + u) { mlo = bl; mhi = bh; mv = bv; }
         }
     }
@@ -118,7 +118,7 @@ lf_edlib_rsweep_kernel(lf_rsw_args A)
     }
     lf_hist_t *wbase = A.ckpt + W.hist_base;
     const bool ck_on = live && pr.task == LF_TASK_PATH;
-    const bool any_ck = __any(ck_on);
+    const bool any_ck = lf_any(ck_on);
     if (any_ck) { uint64_t *pl = reinterpret_cast<uint64_t *>(wbase); pl[lane] = lo; pl[64 + lane] = hi; pl[128 + lane] = valid; }
     lf_hist_t *ck = wbase + LF_PLANE_ENTRIES;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();

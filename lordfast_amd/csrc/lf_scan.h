@@ -61,7 +61,7 @@ lf_scan_excl_kernel(F f, uint64_t *__restrict__ out, uint32_t n, unsigned long l
                 if (j >= 0) x = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool valid = j < 0 || (((x >> 48) & 0x3fffu) == (epoch & 0x3fffu) && (x >> 62) != 0);
                 const bool incl = j >= 0 && valid && (x >> 62) == 2;
-                const uint64_t im = __ballot(incl), vm = __ballot(valid);
+                const uint64_t im = lf_ballot(incl), vm = lf_ballot(valid);
                 /* lanes 0 .. first are usable when all of them are valid (first = nearest inclusive one, or 63 if none) */
                 const int first = im ? __ffsll((long long)im) - 1 : 63;
                 const uint64_t need = first == 63 ? ~0ull : ((2ull << first) - 1);

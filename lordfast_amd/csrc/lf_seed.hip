@@ -182,7 +182,7 @@ extern "C" void lfg_index_free(struct lf_index *ix)
 
 /* sample positions: seed_pos accumulates `step` in FP64 exactly like src/BWT.cpp:320-321,388-389
  * (sequential adds, truncation), one lane per read. Layout pos[i * n_reads + r] (coalesced). */
-__global__ void lf_seed_pos_kernel(int n_reads, const uint64_t *__restrict__ off, uint32_t hash_count, uint32_t *__restrict__ pos,
+__global__ void lf_seed_pos_kernel(int n_reads, const uint64_t *__restrict__ off, uint32_t hash_count,
                                    uint32_t *__restrict__ pos_by_sample /* [r * hash_count + i]: coalesced for the per-sample kernels */)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,7 +192,6 @@ __global__ void lf_seed_pos_kernel(int n_reads, const uint64_t *__restrict__ off
     double sp = 0;
     uint32_t p = 0;
     for (uint32_t i = 0; i < hash_count; i++) {
-        pos[(size_t)i * n_reads + r] = p;
         pos_by_sample[(size_t)r * hash_count + i] = p;
         sp += step;
         p = (uint32_t)sp;
@@ -229,7 +228,7 @@ lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ rea
     size_t gid = 0; const unsigned char *q = nullptr; uint32_t p = 0, qLen = 0, m = 0;
     uint64_t x0 = 0, x1 = 0, sz = 0;
     for (;;) {
-        const uint64_t idle = __ballot(!active);
+        const uint64_t idle = lf_ballot(!active);
         if (idle && nxt < end) {
             const size_t cand = nxt + (size_t)__popcll(idle & below);
             if (!active && cand < end) {
@@ -286,7 +285,7 @@ lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ rea
             nxt += (size_t)__popcll(idle);
             if (nxt > end) nxt = end;
         }
-        if (!__ballot(active)) { if (nxt >= end) break; continue; }
+        if (!lf_ballot(active)) { if (nxt >= end) break; continue; }
         if (active) {
             bool more = false;
             if (p + m < qLen) {
@@ -311,20 +310,42 @@ lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ rea
     if (threadIdx.x == 0 && (s_cnt[0] | s_cnt[1])) { atomicAdd(&counters[0], s_cnt[0]); atomicAdd(&counters[1], s_cnt[1]); }
 }
 
-/* acceptance is sequential per read: 0 < occ < MAX_REF_HITS and not contained in the previous accepted
- * seed (src/BWT.cpp:345,386).  One lane per read; writes the number of hits to locate per sample. */
-__global__ void lf_seed_accept_kernel(int n_reads, uint32_t hash_count, uint32_t max_ref_hits, const uint32_t *__restrict__ pos,
-                                      const lf_sample_t *__restrict__ smp, uint32_t *__restrict__ cnt)
+/* acceptance is sequential per read: 0 < occ < MAX_REF_HITS and not contained in the previous accepted seed
+ * (src/BWT.cpp:345,386: pos + len > lastPos, lastPos = end of the last ACCEPTED seed).  A usable seed that is rejected ends
+ * at or before lastPos, so lastPos is also the maximum end over ALL usable seeds before it: acceptance is an exclusive prefix
+ * maximum.  One wavefront per read, 64 samples per trip (coalesced 16-byte records), the maximum carried from trip to trip;
+ * writes the number of hits to locate per sample. */
+__device__ __forceinline__ uint32_t lf_wave_incl_max(uint32_t v)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x = v;
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));      /* row_shr:1 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));      /* row_shr:2 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));      /* row_shr:4 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));      /* row_shr:8 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));     /* row_bcast:15 -> rows 1, 3 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));     /* row_bcast:31 -> rows 2, 3 */
+    return x;
+}
+__global__ void __launch_bounds__(256)
+lf_seed_accept_kernel(int n_reads, uint32_t hash_count, uint32_t max_ref_hits, const uint32_t *__restrict__ pos /* [r * hash_count + i] */,
+                      const lf_sample_t *__restrict__ smp, uint32_t *__restrict__ cnt)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= n_reads) return;
-    uint32_t last_pos = 0;
-    for (uint32_t i = 0; i < hash_count; i++) {
-        const lf_sample_t s = smp[(size_t)r * hash_count + i];
-        const uint32_t p = pos[(size_t)i * n_reads + r];
-        uint32_t c = 0;
-        if (s.m && s.occ > 0 && s.occ < max_ref_hits && (p + s.m) > last_pos) { c = s.occ; last_pos = p + s.m; }
-        cnt[(size_t)r * hash_count + i] = c;
+    const size_t row = (size_t)r * hash_count;
+    uint32_t last_pos = 0;                                   /* wave-uniform */
+    for (uint32_t i0 = 0; i0 < hash_count; i0 += 64) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        uint32_t end = 0, occ = 0;                           /* end 0: not usable (a usable seed ends at >= 1) */
+        if (i < hash_count) {
+            const lf_sample_t s = smp[row + i];
+            if (s.m && s.occ > 0 && s.occ < max_ref_hits) { end = pos[row + i] + s.m; occ = s.occ; }
+        }
+        const uint32_t inc = lf_wave_incl_max(end);
+        uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x138, 0xf, 0xf, false);      /* wave_shr:1, lane 0: 0 */
+        before = max(before, last_pos);
+        if (i < hash_count) cnt[row + i] = end > before ? occ : 0u;
+        last_pos = max(last_pos, (uint32_t)__builtin_amdgcn_readlane((int)inc, 63));
     }
 }
 
@@ -447,13 +468,13 @@ extern "C" int lfg_seed_src(const struct lf_index *ix, const lf_params_t *p, int
 #define DSLOT(T, k, bytes) (T *)lfg_dev_slot(dv, LF_DS_SEED0 + (k), (bytes))
     char *d_reads = DSLOT(char, 0, n_bases + 64);
     uint64_t *d_off = DSLOT(uint64_t, 1, (size_t)(n_reads + 1) * 8);
-    uint32_t *d_pos = DSLOT(uint32_t, 2, total * 4 + 4), *d_pos2 = DSLOT(uint32_t, 12, total * 4 + 4);
+    uint32_t *d_pos2 = DSLOT(uint32_t, 12, total * 4 + 4);
     lf_sample_t *d_smp = DSLOT(lf_sample_t, 3, total * sizeof(lf_sample_t) + 16);
     uint32_t *d_cnt = DSLOT(uint32_t, 4, (total + 1) * 4);
     uint64_t *d_hit_off = DSLOT(uint64_t, 5, (total + 1) * 8);
     uint64_t *d_read_off = DSLOT(uint64_t, 6, (size_t)(n_reads + 1) * 8);
     unsigned long long *d_counters = DSLOT(unsigned long long, 7, 64);
-    if (!d_reads || !d_off || !d_pos || !d_pos2 || !d_smp || !d_cnt || !d_hit_off || !d_read_off || !d_counters) return LF_ERR_NOMEM;
+    if (!d_reads || !d_off || !d_pos2 || !d_smp || !d_cnt || !d_hit_off || !d_read_off || !d_counters) return LF_ERR_NOMEM;
     hipEvent_t ev[6];
     for (int i = 0; i < 6; i++) { ev[i] = (hipEvent_t)lfg_lane_event(dv, 34 + i); if (!ev[i]) return LF_ERR_HIP; }
 
@@ -476,12 +497,12 @@ extern "C" int lfg_seed_src(const struct lf_index *ix, const lf_params_t *p, int
         lf_rsweep_pack_planes(s, (const unsigned char *)d_reads, n_bases, d_planes, qw);
         lfg_lane_set_value(dv, 0, qw);
     }
-    hipLaunchKernelGGL(lf_seed_pos_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, d_off, hc, d_pos, d_pos2);
+    hipLaunchKernelGGL(lf_seed_pos_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, d_off, hc, d_pos2);
     HIPCHK(hipEventRecord(ev[0], s));
     hipLaunchKernelGGL(lf_seed_search_kernel, dim3((unsigned)((total + 4 * LF_SEARCH_SPAN - 1) / (4 * LF_SEARCH_SPAN))), dim3(256), 0, s, st->view, n_reads, d_reads,
                        d_off, hc, p->min_anchor_len, d_pos2, d_smp, d_counters);
     HIPCHK(hipEventRecord(ev[1], s));
-    hipLaunchKernelGGL(lf_seed_accept_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, hc, (uint32_t)p->max_ref_hits, d_pos, d_smp, d_cnt);
+    hipLaunchKernelGGL(lf_seed_accept_kernel, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, s, n_reads, hc, (uint32_t)p->max_ref_hits, d_pos2, d_smp, d_cnt);
     HIPCHK(hipMemsetAsync(d_cnt + total, 0, 4, s));
     /* u32 counts summed into u64 offsets: one launch (lf_scan.h) */
     { lf_scan_u32 f; f.p = d_cnt; const int src = lf_scan_excl(dv, 0, s, f, d_hit_off, total + 1); if (src != LF_OK) return src; }

@@ -249,7 +249,7 @@ lf_req_gather_kernel(int n_req, const uint32_t *__restrict__ req_read, const uin
         const uint64_t j = base + lane;
         bool in = false; uint32_t t = 0, ql = 0;
         if (j < b && strand[j] == s) { t = tpos[j]; in = (int64_t)t >= lo && (int64_t)t <= hi; if (WRITE && in) ql = qpl[j]; }
-        const uint64_t m = __ballot(in);
+        const uint64_t m = lf_ballot(in);
         if (WRITE && in) {
             const uint64_t p = out + cnt + (uint32_t)__popcll(m & below);
             gathered[p] = make_uint2(t, ql);

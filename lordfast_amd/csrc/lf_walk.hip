@@ -122,8 +122,8 @@ lf_walk_plan_kernel(int n_jobs, const lf_wjob_t *__restrict__ jobs, lf_walk_dev 
         lf_piece P; P.kind = 0; P.qn = P.tn = 0;
         if (k <= chainLen) P = lf_piece_of(s, chainLen, k, L, chrBeg, chrEnd);
         const bool aln = P.kind == 1;
-        const uint64_t am = __ballot(aln);
-        rare |= __any(P.kind < 0) != 0;
+        const uint64_t am = lf_ballot(aln);
+        rare |= lf_any(P.kind < 0) != 0;
         /* inclusive-exclusive prefix of the ops bytes of this tile's alignments (wave scan by shuffles: once per 64 pieces) */
         uint32_t bytes = aln ? P.qn + P.tn : 0, incl = bytes;
 #pragma unroll
@@ -216,7 +216,7 @@ lf_walk_emit_kernel(int n_jobs, const lf_wjob_t *__restrict__ jobs, lf_walk_dev 
             if (k >= 1) { lf_ritem_t m; memset(&m, 0, sizeof m); m.kind = LF_RI_RUN_M; m.n = s[k - 1].y >> 20; items[ib + 2 * (uint64_t)k - 1] = m; }
         }
     }
-    rare = __any(rare) != 0;
+    rare = lf_any(rare) != 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nm += __shfl_xor(nm, o);
     /* head values live in lane 0 of the first tile, tail values in the lane of slot chainLen of the last tile */

@@ -96,10 +96,11 @@ def test_edlib_fuzz_vs_oracle(oracle_lib):
 
 
 def test_edlib_checkpoint_tiles_and_device_hirschberg(oracle_lib):
-    """shapes aimed at the recompute-from-checkpoint traceback and the on-device Hirschberg recursion of lf_align.hip:
-    tile boundaries (m around multiples of 8 / 16), paths that climb > 64 rows inside one 8-column tile (the LDS window of
-    the lane classes moves), every size class (lane NB 1..8, groups of 16 / 32 lanes, wave KB 1 / 4 / 8), targets longer
-    than the LDS ring, tall-and-thin / short-and-wide leaves, several recursion levels, SHW roots whose prefix is a leaf"""
+    """shapes aimed at the recompute-from-checkpoint traceback and the breadth-first Hirschberg levels (lf_rsweep.hip,
+    lf_align.hip, lf_hirsch.hip): tile boundaries (m around multiples of 8 / 16), paths that climb > 64 rows inside one
+    16-column tile, every block count per problem (1 .. 64 lanes) and the 4 / 8 blocks-per-lane classes, targets longer
+    than the LDS ring of the level kernels, tall-and-thin / short-and-wide leaves, several recursion levels, SHW roots
+    whose prefix is a leaf"""
     import lordfast_amd as la
     orc = oracle_lib.Oracle()
     rng = np.random.default_rng(77)
@@ -138,6 +139,27 @@ def test_edlib_checkpoint_tiles_and_device_hirschberg(oracle_lib):
         add(q.tobytes(), t.tobytes())
     q = rseq(rng, 2100); t = b"AC" * 1200 + q[1000:] + b"GT" * 900                                  # low complexity: many co-optimal paths, tie rules decide
     add(q, t)
+    res, ms = la.edlib_batch(qs, ts, modes)
+    for i, r in enumerate(res):
+        o = orc.edlib(qs[i], ts[i], modes[i])
+        assert (r[0], r[1]) == (o[0], o[1]), (i, len(qs[i]), len(ts[i]), modes[i])
+        assert np.array_equal(r[2], o[2]), (i, len(qs[i]), len(ts[i]), modes[i])
+
+
+def test_edlib_queries_above_32768_rows(oracle_lib):
+    """queries longer than one wavefront holds as register-resident blocks (64 lanes x 8 blocks x 64 rows = 32 768): the
+    Hirschberg levels sweep them in row bands whose boundary carries go through HBM (lf_hirsch.hip); NW and SHW roots,
+    a band boundary one row before the end of the query, a tall-and-thin problem above the traceback switch"""
+    import lordfast_amd as la
+    orc = oracle_lib.Oracle()
+    rng = np.random.default_rng(3276833)
+    qs, ts, modes = [], [], []
+    for n, e, mode, tail in ((32769, 0.12, 0, 0), (33000, 0.1, 1, 900), (41000, 0.2, 0, 0)):
+        q = np.frombuffer(rseq(rng, n), dtype=np.uint8)
+        t = synth.mutate(q, e, rng).tobytes() + (rseq(rng, tail) if tail else b"")
+        qs.append(q.tobytes()); ts.append(t); modes.append(mode)
+    q = rseq(rng, 36000)
+    qs.append(q); ts.append(q[17000:17300]); modes.append(0)
     res, ms = la.edlib_batch(qs, ts, modes)
     for i, r in enumerate(res):
         o = orc.edlib(qs[i], ts[i], modes[i])
