@@ -1,7 +1,7 @@
 #!/bin/bash
 # configs.sh -- bench lines of the other BASELINE configs' option sets and of the repeat-rich genome profile (builder-run
 # evidence; the driver's headline stays config C2 on the default genome)
-OUT=$PWD/gpurun_out/r02_configs
+OUT=$PWD/gpurun_out/${1:-r03_configs}
 mkdir -p $OUT
 python3 bench.py --config c4 --steps 2 --warmup 1 > $OUT/bench_c4_clasp_n30.json 2> $OUT/bench_c4.err
 python3 bench.py --config c5 --steps 2 --warmup 1 > $OUT/bench_c5_ont50k_k17c2000.json 2> $OUT/bench_c5.err
