@@ -527,6 +527,7 @@ def main():
                          "chain_requests": agg["n_chain_problems"] / per_rank, "tie_requests": agg["n_tie_requests"] / per_rank,
                          "ksw_problems": agg["n_ksw_problems"] / per_rank},
             "roofline": roofline,
+            "source_tree": tree_hash(),      # digest of lordfast_amd/csrc: which kernels produced this line
         }
         out["value_without_exchange"] = n_total * K / elapsed_nx
         out["ms_per_step_without_exchange"] = elapsed_nx / K * 1e3
