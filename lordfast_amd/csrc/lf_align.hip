@@ -50,6 +50,7 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
                    const int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
 {
     constexpr int K = LF_RSTEPS, HK = 8, ROW = LF_RROW;
+    __shared__ ulonglong2 s_tile[HK * 64];               /* (Pv, Ph) of a half's eight columns, [column][lane] */
     const int lane = threadIdx.x, idx = blockIdx.x * 64 + lane;
     const bool live = idx < n_probs;
     const lf_aln_prob pr = probs[live ? idx : n_probs - 1];
@@ -91,7 +92,6 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
             const bool in_half = r > 0 && c > 0 && ((r - 1) >> 6) == b && (int)c >= h0 && (int)c < h0 + HK && (act);
             if (!lf_any(in_half)) continue;
             uint64_t Pv = Pv0, Mv = Mv0;
-            uint64_t tPv[HK], tPh[HK];
 #pragma unroll
             for (int k = 0; k < HK + half * HK; k++) {
                 const int col = cbase + k;
@@ -100,28 +100,29 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
                 uint64_t nPv = Pv, nMv = Mv, ph, mh;
                 (void)lf_myers_step(nPv, nMv, Eq, (cw >> (2 * k)) & 3u, ph, mh);
                 const bool v = col >= 1; Pv = v ? nPv : Pv; Mv = v ? nMv : Mv;       /* the block starts at column 1 */
-                if (k >= half * HK) { tPv[k - half * HK] = Pv; tPh[k - half * HK] = ph; }
+                if (k >= half * HK) s_tile[(k - half * HK) * 64 + lane] = make_ulonglong2(Pv, ph);      /* the lane's own slots: no barrier */
             }
-            /* walk: column by column from the right; inside a column only Up moves repeat */
-            if (in_half) {
-                const int cmin = h0 < 1 ? 1 : h0;
-#pragma unroll
-                for (int k = HK - 1; k >= 0; k--) {
-                    bool here = r > 0 && (int)c == h0 + k && (int)c >= cmin && ((r - 1) >> 6) == b;
-                    while (here) {
-                        const int bit = (int)((r - 1) & 63);
-                        const uint32_t up = (uint32_t)(tPv[k] >> bit) & 1u, lf = ((uint32_t)(tPh[k] >> bit) & 1u) & ~up, dg = (up | lf) ^ 1u;
-                        uint32_t op = up ? 1u : (lf ? 2u : 0u);      /* Up -> Left -> Diagonal (lib/edlib/edlib.cpp:950,984,1015) */
-                        /* match or mismatch of a diagonal move: both bases are in registers -- the query's row in the block's bit
-                         * planes, the target's column in the tile's symbol word.  (Round 2 left every diagonal move as 0 and made
-                         * the renderer fetch and compare the bases: two dependent loads per 64-op tile there.) */
-                        const uint32_t tcode = (tok16 >> (2 * (half * HK + k))) & 3u;
-                        const uint32_t same = (uint32_t)(valid >> bit) & ~((uint32_t)(lo >> bit) ^ tcode) & ~((uint32_t)(hi >> bit) ^ (tcode >> 1)) & 1u;
-                        op = (dg & (same ^ 1u)) ? 3u : op;
-                        em.put(op);
-                        r -= up | dg; c -= lf | dg;
-                        here = up != 0 && r > 0 && ((r - 1) >> 6) == b;      /* an Up move stays in the column (and maybe in the block) */
-                    }
+            /* walk: ONE MOVE per trip for every lane that is still inside the half (its column's (Pv, Ph) comes out of the
+             * lane's LDS slots).  Unrolled over the columns, with the Up moves of a column in an inner loop, the wavefront paid
+             * every column's longest Up run among its 64 paths: ~2.2 trips per column for ~1.05 moves per path. */
+            const int cmin = h0 < 1 ? 1 : h0;
+            bool inh = in_half;
+            while (lf_any(inh)) {
+                if (inh) {
+                    const int k = (int)c - h0;
+                    const ulonglong2 pp = s_tile[k * 64 + lane];
+                    const int bit = (int)((r - 1) & 63);
+                    const uint32_t up = (uint32_t)(pp.x >> bit) & 1u, lf = ((uint32_t)(pp.y >> bit) & 1u) & ~up, dg = (up | lf) ^ 1u;
+                    uint32_t op = up ? 1u : (lf ? 2u : 0u);      /* Up -> Left -> Diagonal (lib/edlib/edlib.cpp:950,984,1015) */
+                    /* match or mismatch of a diagonal move: both bases are in registers -- the query's row in the block's bit
+                     * planes, the target's column in the tile's symbol word.  (Round 2 left every diagonal move as 0 and made
+                     * the renderer fetch and compare the bases: two dependent loads per 64-op tile there.) */
+                    const uint32_t tcode = (tok16 >> (2 * (half * HK + k))) & 3u;
+                    const uint32_t same = (uint32_t)(valid >> bit) & ~((uint32_t)(lo >> bit) ^ tcode) & ~((uint32_t)(hi >> bit) ^ (tcode >> 1)) & 1u;
+                    op = (dg & (same ^ 1u)) ? 3u : op;
+                    em.put(op);
+                    r -= up | dg; c -= lf | dg;
+                    inh = r > 0 && (int)c >= cmin && ((r - 1) >> 6) == b;      /* still in this block and this half */
                 }
             }
         }

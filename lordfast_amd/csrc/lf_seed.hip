@@ -198,7 +198,52 @@ __global__ void lf_seed_pos_kernel(int n_reads, const uint64_t *__restrict__ off
     }
 }
 
-struct lf_sample_t { uint64_t sp; uint32_t occ; uint32_t m; };   /* occ saturates at 2^32-1; m = 0: no seed */
+struct lf_sample_t { uint64_t sp; uint32_t occ; uint32_t m; };
+
+/* One Occ block for the bidirectional step: Occ(k, a) and the sum of Occ(k, j) over j > a, branch-free.  The block is loaded
+ * whole (4 x 16 B, all in flight together with the other row's block); rows -1 and seq_len are special (bwt_occ4,
+ * lib/bwa/bwt.c:169-186) and read block 0 for nothing.  Per 16-symbol word: the low / high bit planes on the even bits, one
+ * mask for "== a", one for "> a", one keep mask for the symbols in front of the row. */
+struct lf_occ_blk { ulonglong2 h01, h23; uint4 s0, s1; };
+__device__ __forceinline__ const uint32_t *lf_occ_addr(const lf_dev_index &ix, uint64_t k, bool &none, bool &all, int &rem)
+{
+    none = k == ~0ull; all = k == ix.seq_len;
+    const uint64_t kk = (none || all) ? 0ull : k - (k >= ix.primary ? 1ull : 0ull);
+    rem = (int)(kk & 127) + 1;
+    return ix.bwt + ((kk >> 7) << 4);
+}
+__device__ __forceinline__ lf_occ_blk lf_occ_load(const uint32_t *blk)
+{
+    lf_occ_blk B;
+    B.h01 = *reinterpret_cast<const ulonglong2 *>(blk); B.h23 = *reinterpret_cast<const ulonglong2 *>(blk + 4);
+    B.s0 = *reinterpret_cast<const uint4 *>(blk + 8); B.s1 = *reinterpret_cast<const uint4 *>(blk + 12);
+    return B;
+}
+__device__ __forceinline__ void lf_occ_eq_gt(const lf_dev_index &ix, const lf_occ_blk &B, int a, bool none, bool all, int rem, uint64_t &eq, uint64_t &gt)
+{
+    const uint32_t M5 = 0x55555555u;
+    const uint32_t a0n = (a & 1) ? 0u : M5, a1n = (a & 2) ? 0u : M5;        /* flip masks: bit set where the plane equals a's bit */
+    const uint32_t na0 = (a & 1) ? 0u : ~0u, na1 = (a & 2) ? 0u : ~0u;      /* a's bit is 0: the plane may be greater */
+    uint32_t ce = 0, cg = 0;
+    const uint32_t w[8] = { B.s0.x, B.s0.y, B.s0.z, B.s0.w, B.s1.x, B.s1.y, B.s1.z, B.s1.w };
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int r = rem - 16 * i;                                         /* symbols of this word in front of (and at) the row */
+        const uint32_t keep = r >= 16 ? ~0u : (r <= 0 ? 0u : (~0u << (32 - 2 * r)));      /* symbols are MSB first */
+        const uint32_t lp = w[i] & M5, hp = (w[i] >> 1) & M5;
+        const uint32_t t1 = hp ^ a1n;                                       /* high bit equal */
+        const uint32_t e = (lp ^ a0n) & t1;
+        const uint32_t g = (hp & na1) | (t1 & lp & na0);
+        ce += (uint32_t)__popc(e & keep); cg += (uint32_t)__popc(g & keep);
+    }
+    const uint64_t c0 = B.h01.x, c1 = B.h01.y, c2 = B.h23.x, c3 = B.h23.y;
+    uint64_t he = a == 0 ? c0 : a == 1 ? c1 : a == 2 ? c2 : c3;
+    uint64_t hg = (a < 3 ? c3 : 0ull) + (a < 2 ? c2 : 0ull) + (a < 1 ? c1 : 0ull);
+    eq = he + ce; gt = hg + cg;
+    if (all) { eq = ix.L2[a + 1] - ix.L2[a]; gt = ix.L2[4] - ix.L2[a + 1]; }
+    if (none) { eq = 0; gt = 0; }
+}
+   /* occ saturates at 2^32-1; m = 0: no seed */
 
 /* Maximal exact match of every (read, sample) starting at its sample position, >= k long.
  * Match lengths are very uneven (a sample inside an error-free stretch extends for dozens of steps, most stop after a
@@ -227,6 +272,7 @@ lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ rea
     bool active = false;                      /* this lane is in the middle of a sample */
     size_t gid = 0; const unsigned char *q = nullptr; uint32_t p = 0, qLen = 0, m = 0;
     uint64_t x0 = 0, x1 = 0, sz = 0;
+    uint32_t ahead = 0;                       /* codes of the bases at offsets 12 .. 23 (2 bits each), bits 24 .. 27: how many are usable */
     for (;;) {
         const uint64_t idle = lf_ballot(!active);
         if (idle && nxt < end) {
@@ -248,11 +294,24 @@ lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ rea
                 bool started = false;
                 if ((uint64_t)p + (uint64_t)kmin <= qLen) {
                     /* the first 16 bases in two (unaligned) 8-byte loads; the batch buffer has 64 bytes of slack */
-                    uint64_t w0, w1;
-                    __builtin_memcpy(&w0, q + p, 8); __builtin_memcpy(&w1, q + p + 8, 8);
-                    int cd[16]; uint32_t bad = 0;
+                    /* ... and the next eight in a third: the bases at offsets 12 .. 23 stay in ONE register as 2-bit codes + the
+                     * number of usable ones in front of the first base outside ACGT / the end of the read, so that the first
+                     * extension steps do not start with a dependent byte load */
+                    uint64_t w0, w1, w2;
+                    __builtin_memcpy(&w0, q + p, 8); __builtin_memcpy(&w1, q + p + 8, 8); __builtin_memcpy(&w2, q + p + 16, 8);
+                    int cd[24]; uint32_t bad = 0;
 #pragma unroll
-                    for (int t = 0; t < 16; t++) { cd[t] = lf_nt4((unsigned char)((t < 8 ? w0 >> (8 * t) : w1 >> (8 * (t - 8))) & 0xff)); bad |= (cd[t] > 3 ? 1u : 0u) << t; }
+                    for (int t = 0; t < 24; t++) { cd[t] = lf_nt4((unsigned char)((t < 8 ? w0 >> (8 * t) : t < 16 ? w1 >> (8 * (t - 8)) : w2 >> (8 * (t - 16))) & 0xff)); bad |= (cd[t] > 3 ? 1u : 0u) << t; }
+                    {
+                        uint32_t codes = 0;
+#pragma unroll
+                        for (int t = 12; t < 24; t++) codes |= (uint32_t)(cd[t] & 3) << (2 * (t - 12));
+                        const uint32_t inread = qLen - p > 12u ? (qLen - p - 12u < 12u ? qLen - p - 12u : 12u) : 0u;      /* bases of the read at offsets >= 12 (of 12) */
+                        const uint32_t badhi = (bad >> 12) | (1u << 12);
+                        uint32_t lead = (uint32_t)__ffs((int)badhi) - 1u;                      /* usable bases in front of the first bad one */
+                        if (lead > inread) lead = inread;
+                        ahead = codes | (lead << 24);
+                    }
                     /* table index of a pattern: base-4 number with its LAST character most significant; for revcomp(P) the
                      * characters are the complements of P's, read backwards */
                     auto idx_of = [&](int Wd, uint32_t &idc_o, uint32_t &idf_o) {
@@ -268,16 +327,16 @@ lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ rea
                     if (ix.cache16 != nullptr && (uint64_t)p + 16 <= qLen && (bad & 0xffffu) == 0) {
                         uint32_t idc, idf; idx_of(16, idc, idf);
                         n_cache += 2;
-                        x1 = ix.cache16[2 * (size_t)idc];
-                        const uint64_t l1 = ix.cache16[2 * (size_t)idc + 1];
-                        if (x1 <= l1) { x0 = ix.cache16[2 * (size_t)idf]; sz = l1 - x1 + 1; m = 16; started = true; }
+                        const ulonglong2 e1 = *reinterpret_cast<const ulonglong2 *>(ix.cache16 + 2 * (size_t)idc);      /* both entries in flight together */
+                        const uint64_t f0 = ix.cache16[2 * (size_t)idf];
+                        if (e1.x <= e1.y) { x1 = e1.x; x0 = f0; sz = e1.y - e1.x + 1; m = 16; started = true; }
                     }
                     if (!started && (bad & ((1u << W) - 1)) == 0) {
                         uint32_t idc, idf; idx_of((int)W, idc, idf);
                         n_cache += 2;
-                        x1 = tab[2 * (size_t)idc];
-                        const uint64_t l1 = tab[2 * (size_t)idc + 1];
-                        if (x1 <= l1) { x0 = tab[2 * (size_t)idf]; sz = l1 - x1 + 1; m = W; started = true; }
+                        const ulonglong2 e1 = *reinterpret_cast<const ulonglong2 *>(tab + 2 * (size_t)idc);
+                        const uint64_t f0 = tab[2 * (size_t)idf];
+                        if (e1.x <= e1.y) { x1 = e1.x; x0 = f0; sz = e1.y - e1.x + 1; m = W; started = true; }
                     }
                 }
                 if (started) active = true; else out[gid] = res;
@@ -288,9 +347,32 @@ lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ rea
         if (!lf_ballot(active)) { if (nxt >= end) break; continue; }
         if (active) {
             bool more = false;
-            if (p + m < qLen) {
-                const int c = lf_nt4(q[p + m]);
-                if (c <= 3 && lf_extend_right(ix, x0, x1, sz, c, n_blk)) { m++; more = true; }
+            /* the next base: from the register while m < 24, else one byte of the read */
+            int c = 4;
+            if (m < 24u) { if (m - 12u < (ahead >> 24)) c = (int)((ahead >> (2 * (m - 12u))) & 3u); }
+            else if (p + m < qLen) c = lf_nt4(q[p + m]);
+            if (c <= 3) {
+                /* bwt_extend, is_back = 0 (lib/bwa/bwt.c:262-275; lf_extend_right): one backward step on x1 with the counts of
+                 * rows x1 - 1 and x1 - 1 + s.  Both blocks are asked for before either is used. */
+                const uint64_t km = x1 - 1, l = x1 - 1 + sz;
+                bool kn, ka, ln, la; int kr, lr;
+                const uint32_t *bk = lf_occ_addr(ix, km, kn, ka, kr), *bl = lf_occ_addr(ix, l, ln, la, lr);
+                const lf_occ_blk BK = lf_occ_load(bk), BL = lf_occ_load(bl);
+                {   /* touches counted like bwt_2occ (lib/bwa/bwt.c:132-139): 1 block if the two rows share one, else 2 */
+                    const uint64_t _k = (km >= ix.primary) ? km - 1 : km, _l = (l >= ix.primary) ? l - 1 : l;
+                    n_blk += (km == ~0ull || l == ~0ull || (_k >> 7) != (_l >> 7)) ? 2u : 1u;
+                }
+                const int a = 3 - c;                                   /* symbol prepended on the complement strand */
+                uint64_t ek, gk, el, gl;
+                lf_occ_eq_gt(ix, BK, a, kn, ka, kr, ek, gk); lf_occ_eq_gt(ix, BL, a, ln, la, lr, el, gl);
+                const uint64_t ns = el - ek;
+                if (ns != 0) {
+                    /* rows of P.d for d = 0..3 follow each other inside P's interval in the order of d; on the complement strand d
+                     * appears as 3 - d, so P.c starts after the sentinel row (if P's complement interval spans it) and all a' > a */
+                    x0 = x0 + ((x1 <= ix.primary && x1 + sz - 1 >= ix.primary) ? 1u : 0u) + (gl - gk);
+                    x1 = ix.L2[a] + 1 + ek; sz = ns;
+                    m++; more = true;
+                }
             }
             if (!more) {
                 lf_sample_t res; res.sp = 0; res.occ = 0; res.m = 0;

@@ -527,12 +527,12 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     if (clasp) {
         uint32_t *d_shift = (uint32_t *)d_prev;
         hipLaunchKernelGGL(lf_req_shift_kernel, dim3((unsigned)((n_req + 255) / 256)), dim3(256), 0, s, (int)n_req, d_req_lo, d_shift);
-        /* LDS size classes (136 B per fragment: 18 / 9 / 6 / 4 / 3 / 2 / 1 / 1 windows per CU), the HBM-workspace class last.
+        /* LDS size classes (136 B per fragment: 18 / 12 / 9 / 7 / 6 / 4 / 3 / 2 / 1 / 1 windows per CU), the HBM-workspace class last.
          * A window is one wavefront with a long dependent chain, so the classes run CONCURRENTLY on their own streams
          * (the ones the alignment stage of this lane uses later), largest first: back to back on one stream the 512 class
          * -- one window per CU -- would hold the whole stage up. */
-        enum { NCC = 9 };
-        static const uint32_t CCAPS[NCC] = { 64, 128, 192, 256, 384, 512, 768, LF_CLASP_LDS_MAX, 0 };
+        enum { NCC = 11 };
+        static const uint32_t CCAPS[NCC] = { 64, 96, 128, 160, 192, 256, 384, 512, 768, LF_CLASP_LDS_MAX, 0 };
         hipEvent_t ev[NCC + 1];
         for (int k = 0; k <= NCC; k++) { ev[k] = (hipEvent_t)lfg_lane_event(dv, 20 + k); if (!ev[k]) return LF_ERR_HIP; }
         HIPCHK(hipEventRecord(ev[NCC], s));
