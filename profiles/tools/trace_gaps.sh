@@ -10,4 +10,5 @@ T=$(find /tmp/tg -name '*kernel_trace.csv' | head -1)
 python3 $R/profiles/tools/busy.py $T --last-step $K > $R/gpurun_out/tg/busy.txt
 python3 $R/profiles/tools/gaps.py $T --last-step $K 10 > $R/gpurun_out/tg/gaps.txt
 cp $(find /tmp/tg -name '*kernel_stats.csv' | head -1) $R/gpurun_out/tg/kernel_stats.csv
-cat $R/gpurun_out/tg/busy.txt $R/gpurun_out/tg/gaps.txt
+python3 $R/profiles/tools/timeline.py $T --last-step $K > $R/gpurun_out/tg/timeline.txt
+cat $R/gpurun_out/tg/busy.txt $R/gpurun_out/tg/gaps.txt; head -150 $R/gpurun_out/tg/timeline.txt
