@@ -4,19 +4,21 @@
  * Reference replaced: edlibAlign (lib/edlib/edlib.cpp:101-221) with config {k=-1, NW|SHW, PATH}, and
  * ksw_extend2 (lib/bwa/ksw.c:380-478).  Integer only; results bit-identical.
  *
- * edlib kernels: Myers/Hyyro bit-vector DP, 64 query rows per 64-bit word.  Problems are binned by ceil(n/64).
- *   forward pass   ONE LANE PER PROBLEM with NB = 1,2,3,4,6,8 register-resident blocks for n <= 512 (the ~10^2 gap problems
- *                  per read are what fills the lanes); G = 16 / 32 / 64 lanes per problem sweeping the matrix as an
- *                  anti-diagonal above that.  Leaves the distance / end column, checkpoints of the bit-vector state every
- *                  8 columns (steps), the two-bit carries entering every block and the blocks' bit planes in HBM.
+ * edlib kernels: Myers/Hyyro bit-vector DP, 64 query rows per 64-bit word.
+ *   batching       descriptors -> 32-bit class keys -> one radix sort -> (mode, nb) segments -> checkpoint bases (one scan) ->
+ *                  problem array + wave table, all on the device (lf_desc_*_kernel below).
+ *   forward pass   lf_rsweep.hip: nb CONSECUTIVE LANES per problem (nb = ceil(n / 64) = 1 .. 64, a run-time value), query bit
+ *                  planes precomputed once per chunk, one checkpoint row per 16 sweep steps.  Leaves the distance / end
+ *                  column, the rows and the planes in HBM.  (Leaves with 4096 < n <= 32768: lf_edlib_sweep_kernel<64, 4 / 8>
+ *                  below, one wavefront per problem; targets with bytes outside ACGT: lf_edlib_generic_kernel.)
  *   traceback      needs two bits per cell -- Pv (vertical +1 => Up) and Ph (horizontal +1 => Left), else Diagonal (match
  *                  iff bytes equal), which is edlib's move priority (lib/edlib/edlib.cpp:950,984,1015) -- and gets them by
- *                  RECOMPUTING 8-column tiles of the ONE block the path is in from a checkpoint and the stored carries:
- *                  lf_edlib_tb_kernel, one lane per path, the tile in registers.  No history stream through HBM.
- *   Hirschberg     edlib's recursion for problems over its 1 MiB traceback switch runs inside the 64-lane sweep kernel
- *                  (one wavefront per problem, LDS stack), including the leaves' tracebacks.
- * No banding: the Ukkonen band of the reference only removes cells that cannot be on an optimal path, and a lane (or a
- * group of lanes) that skips out-of-band blocks saves no time, because its neighbours in the wavefront do not.
+ *                  RECOMPUTING 16-column tiles of the ONE block the path is in from a checkpoint row and the stored carries:
+ *                  lf_edlib_tb_kernel, one lane per path.  No history stream through HBM.
+ *   Hirschberg     edlib's recursion for problems over its 1 MiB traceback switch: lf_hirsch.hip, breadth-first (level l of
+ *                  all problems is one launch); its leaves are ordinary problems of the kernels above.
+ * No banding: the Ukkonen band of the reference only removes cells that cannot be on an optimal path, and lanes that skip
+ * out-of-band blocks save no time, because their neighbours in the wavefront's lock-step sweep do not.
  */
 #include <hipcub/hipcub.hpp>
 #include "lf_gpu_common.h"
@@ -39,8 +41,8 @@
  * From (n, tl) the path is followed tile by tile: a tile = the 16 sweep steps of one checkpoint row, of the ONE block the
  * cell is in.  The lane restores that block's state in front of the tile (one 16-byte load), takes the 16 carries the block
  * received (one 4-byte load) and the tile's 16 target symbols (one 8-byte load) -- all three in flight together, one round
- * trip per tile -- and replays the tile in two halves of 8 columns, right half first: (Pv, Ph) of a half stay in registers
- * (the walk is unrolled over its columns), the path is walked through it, then the left half is replayed from the same
+ * trip per tile -- and replays the tile in two halves of 8 columns, right half first: (Pv, Ph) of a half's columns go to the
+ * lane's own LDS slots, the path is walked through the half one move per trip, then the left half is replayed from the same
  * checkpoint.  The kernel waits for memory most of its time, so a checkpoint row per 16 steps (half the round trips, half the
  * checkpoint traffic of the forward pass) is worth the 8 block steps that are replayed twice.  Same cells, same
  * Up -> Left -> Diagonal priority (lib/edlib/edlib.cpp:950,984,1015), same ops.

@@ -12,12 +12,14 @@
  *   MD     <matches><mismatched reference base> ... ^<deleted reference bases> ...; an insertion breaks a deletion run
  *          (src/LordFAST.cpp:1717-1760)
  *
- * Per 64-element tile the lanes classify their element, find run starts with one ballot, get the run lengths from
- * the position of the previous set bit, and place their tokens with a wave prefix sum; only the open run, the match
- * counter and the output cursors are carried from tile to tile.  The kernel runs twice: a counting pass (exact
- * sizes -> one exclusive scan -> offsets), then the writing pass.  The edit paths never leave the device.
+ * Per 64-element tile the lanes classify their element (register tables), find run starts and match-counter flushes as
+ * comparison masks, get the run lengths from the position of the previous set bit and the match counts from a difference of
+ * prefix counts (v_mbcnt), and place the tokens of BOTH strings with one DPP prefix sum; only the open run, the match counter
+ * and the output cursors are carried from tile to tile.  On the product path the kernel runs ONCE, into per-record regions
+ * sized by an upper bound (lf_render_caps_kernel -> one scan); the count + write form remains for packed text.  The edit
+ * paths never leave the device, and they arrive with their mismatches marked (the traceback kernels classify diagonal moves).
  *
- * Traffic per record: ops bytes read twice, text written once, a few 2-bit reference bases.
+ * Traffic per record: ops bytes read once, text written once, a few 2-bit reference bases.
  */
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
