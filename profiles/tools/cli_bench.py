@@ -12,6 +12,7 @@ ap.add_argument("--reads", type=int, default=100000)
 ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--gz", action="store_true")
 ap.add_argument("--fastq", action="store_true")
+ap.add_argument("--devnull-only", action="store_true", help="no SAM file on disk (large read sets)")
 a = ap.parse_args()
 sys.argv = [sys.argv[0], "--genome-mbp", str(a.genome_mbp), "--reads", str(a.reads)]
 args = bench.parse()
@@ -32,7 +33,7 @@ if not os.path.exists(rp):
     print(f"[cli_bench] wrote {rp} in {time.time() - t0:.1f}s", file=sys.stderr)
 bases = sum(len(s) for s in seqs)
 exe = os.path.join(ROOT, "lordfast_amd", "lordfast")
-for out in ("/dev/null", os.path.join(d, "cli_out.sam")):
+for out in (("/dev/null",) if a.devnull_only else ("/dev/null", os.path.join(d, "cli_out.sam"))):
     for rep in range(2):
         t0 = time.time()
         r = subprocess.run([exe, "--search", fa, "--seq", rp, "-o", out, "-t", str(a.threads)], capture_output=True, text=True)
