@@ -101,9 +101,11 @@ int lf_reads_open(const char *path, lf_reads_t **out)
     *out = r;
     return LF_OK;
 }
+static void blob_pool_trim(void);
 void lf_reads_close(lf_reads_t *r)
 {
     if (!r) return;
+    blob_pool_trim();                           /* the blobs cached for this file's batches (batches freed later are cached again) */
     if (r->map) munmap((void *)r->map, r->map_size);
     gzclose(r->fp); free(r->buf); free(r);
 }
@@ -161,6 +163,12 @@ static char *blob_get(size_t need, size_t *cap_out)
     if (!p) { cap = need + need / 8 + 4096; p = (char *)malloc(cap); }      /* the pieces of later batches differ by a few per cent */
     *cap_out = cap;
     return p;
+}
+static void blob_pool_trim(void)
+{
+    pthread_mutex_lock(&g_blob_mu);
+    for (int i = 0; i < LF_BLOB_POOL; i++) { free(g_blob_pool[i].p); g_blob_pool[i].p = NULL; g_blob_pool[i].cap = 0; }
+    pthread_mutex_unlock(&g_blob_mu);
 }
 static void blob_put(char *p, size_t cap)
 {
