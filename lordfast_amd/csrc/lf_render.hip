@@ -84,19 +84,35 @@ __device__ __forceinline__ char lf_pac_char(const uint8_t *pac, uint32_t pos, in
     return (char)(0x54474341u >> (b << 3));          /* "ACGT"[b] without a table load */
 }
 
-/* element types */
-#define T_EQ 0
-#define T_X  1
-#define T_I  2
-#define T_D  3
-
 /* MODE 0: counting pass (exact sizes)   1: writing pass behind it (packed text: the host-side consumers)
  *      2: SINGLE pass -- writes into per-record regions sized by an upper bound (lf_render_caps_kernel) and reports the exact
  *         lengths; the SAM writer copies the text out of the regions anyway, so nothing is gained by packing it first.
- * Every path arrives with its mismatches marked (op 3): the edlib traceback kernels classify the diagonal moves themselves. */
+ * Every path arrives with its mismatches marked (op 3): the edlib traceback kernels classify the diagonal moves themselves.
+ *
+ * Two levels.  85 % of a record's elements are matches, which print nothing by themselves: a 64-op tile of a path is only
+ * CLASSIFIED -- its mismatches, insertions and deletions become EVENTS (type, the number of matches in front of it, the
+ * reference base of a mismatch / deletion) in an LDS queue, anchor runs just add to the count of pending matches -- and the
+ * expensive part (run lengths, match counts, digits, token placement, stores) runs once per 64 EVENTS, i.e. once per ~430
+ * elements.  An event stands for two segments of the CIGAR's letter stream: 'M' x eq (if eq > 0), then its own letter x len
+ * (mismatch: 'M' x 1).  Run lengths follow R_i = carry_i * R_(i-1) + add_i -- an affine recurrence, composed over the
+ * wavefront by one DPP scan of (carry, add) pairs; match counts are differences of a prefix sum of eq. */
 #define LF_RM_COUNT  0
 #define LF_RM_WRITE  1
 #define LF_RM_SINGLE 2
+#define EV_X 0
+#define EV_I 1
+#define EV_D 2
+/* inclusive scan of affine maps x -> c x + a (c in {0, 1}) over the wavefront: lane i ends with the composition of lanes 0 .. i */
+__device__ __forceinline__ void lf_wave_affine_scan(uint32_t &c, uint32_t &a)
+{
+#define LF_AFF_STEP(CTRL, RM) { \
+        const uint32_t tc = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)c, CTRL, RM, 0xf, false); \
+        const uint32_t ta = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, CTRL, RM, 0xf, false); \
+        a += c ? ta : 0u; c &= tc; }
+    LF_AFF_STEP(0x111, 0xf) LF_AFF_STEP(0x112, 0xf) LF_AFF_STEP(0x114, 0xf) LF_AFF_STEP(0x118, 0xf)
+    LF_AFF_STEP(0x142, 0xa) LF_AFF_STEP(0x143, 0xc)
+#undef LF_AFF_STEP
+}
 template <int MODE>
 __global__ void __launch_bounds__(64)
 lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_ritem_t *__restrict__ items, lf_rrounds R,
@@ -104,6 +120,7 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
                  const uint64_t *__restrict__ offs /* 2 per record (WRITE) */, char *__restrict__ text)
 {
     constexpr bool WRITE = MODE != LF_RM_COUNT;
+    __shared__ uint2 s_ev[128];                      /* the event queue: x = matches in front, y = len << 10 | base << 2 | type */
     const int rec = blockIdx.x;
     if (rec >= n_recs) return;
     const int lane = threadIdx.x;
@@ -112,7 +129,9 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
     char *cg = WRITE ? text + offs[2 * rec] : nullptr, *md = WRITE ? text + offs[2 * rec + 1] : nullptr;
     /* carried state (wave-uniform) */
     int c_ch = 0; uint32_t c_run = 0; int c_first = 1; uint32_t c_out = 0;
-    uint32_t m_num = 0; int m_last = T_EQ; uint32_t m_out = 0;
+    uint32_t m_num = 0; int m_last = -1 /* type of the last event, -1: matches (or nothing) */; uint32_t m_out = 0;
+    uint32_t pending = 0;                            /* matches seen since the last event */
+    int n_ev = 0;                                    /* events waiting in s_ev */
 
     /* close the open CIGAR run and open a new one (wave-uniform path, lane 0 writes) */
     auto cigar_run = [&](int ch, uint32_t n) {
@@ -125,8 +144,88 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
         c_ch = ch; c_run = n;
     };
 
+    /* ---- the first `cnt` events of the queue -> text ---- */
+    auto flush_events = [&](int cnt) {
+        const bool act = lane < cnt;
+        const uint2 ev = s_ev[lane];
+        const uint32_t eq = act ? ev.x : 0u, ty = ev.y & 3u, len = act ? ev.y >> 10 : 0u, bch = (ev.y >> 2) & 0xffu;
+        const bool hasA = eq > 0;
+        const int L = !act ? 0 : ty == EV_I ? 'I' : ty == EV_D ? 'D' : 'M';
+        /* ---- CIGAR ---- */
+        const int pL0 = __builtin_amdgcn_update_dpp(c_ch, L, 0x138, 0xf, 0xf, false);        /* letter of the previous event (lane 0: the open run's) */
+        const int pL = pL0;
+        const int lbB = hasA ? 'M' : pL;                                                       /* letter in front of the event's own segment */
+        const bool tokA = hasA && pL != 'M' && pL != 0;                                        /* the matches close the previous run */
+        const bool tokB = act && L != lbB && lbB != 0;                                         /* the event closes the run in front of it */
+        /* length of the run that is open after the event: R_i = carry_i R_(i-1) + add_i; lanes past the last event pass R on */
+        uint32_t cr = !act ? 1u : hasA ? (uint32_t)(pL == 'M' && L == 'M') : (uint32_t)(L == pL);
+        uint32_t ad = hasA && L == 'M' ? eq + len : len;
+        lf_wave_affine_scan(cr, ad);
+        const uint32_t Rn = (cr ? c_run : 0u) + ad;
+        const uint32_t Rp = (uint32_t)__builtin_amdgcn_update_dpp((int)c_run, (int)Rn, 0x138, 0xf, 0xf, false);      /* R_(i-1) */
+        const uint32_t valA = Rp;
+        const uint32_t valB = hasA ? (pL == 'M' ? Rp : 0u) + eq : Rp;
+        /* ---- MD ---- */
+        const int pty0 = __builtin_amdgcn_update_dpp(m_last, act ? (int)ty : -1, 0x138, 0xf, 0xf, false);      /* (every lane executes the move: a lane that sat out would not be a source) */
+        const int pty = hasA ? -1 : pty0;
+        const bool isx = act && ty == EV_X, isd = act && ty == EV_D, isxd = isx || isd;
+        const bool flush = isx || (isd && pty != EV_D);
+        const uint64_t fmask = lf_ballot(flush);
+        const uint32_t E = lf_wave_incl_sum(eq);                                               /* matches up to and including the event's own */
+        const uint64_t fb = fmask & below;
+        const int p = fb ? 63 - __clzll((long long)fb) : 0;
+        const uint32_t Ep = (uint32_t)__shfl((int)E, p);
+        const uint32_t num = fb ? E - Ep : m_num + E;
+        /* ---- digits, placement ---- */
+        const bool big = lf_any((tokA && valA >= 10000u) || (tokB && valB >= 10000u) || (flush && num >= 10000u));
+        int ndA = lf_ndigits4(valA), ndB = lf_ndigits4(valB), mnd = flush ? lf_ndigits4(num) : 0;
+        if (big) { ndA = lf_ndigits(valA); ndB = lf_ndigits(valB); mnd = flush ? lf_ndigits(num) : 0; }
+        const uint32_t lenA = tokA ? (uint32_t)ndA + 1u : 0u, lenB = tokB ? (uint32_t)ndB + 1u : 0u;
+        const uint32_t mlen = isxd ? (uint32_t)mnd + (flush && isd ? 2u : 1u) : 0u;
+        const uint32_t packed = (lenA + lenB) | (mlen << 16), incl = lf_wave_incl_sum(packed), excl = incl - packed;
+        const uint32_t both = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t pos = excl & 0xffffu, mpos = excl >> 16, tot = both & 0xffffu, mtot = both >> 16;
+        const uint64_t tmask = lf_ballot(tokA || tokB);
+        if (WRITE) {
+            uint32_t letA = (uint32_t)pL, letB = (uint32_t)lbB;
+            if (c_first && tmask && !(tmask & below) && (tokA || tokB)) {                      /* the record's first token: I prints as S */
+                if (tokA) { if (letA == 'I') letA = 'S'; } else if (letB == 'I') letB = 'S';
+            }
+            const uint32_t c1 = (flush && isd) ? (uint32_t)'^' : bch, c2 = (flush && isd) ? bch : 0u;
+            if (!big) {
+                if (tokA) lf_put_token4(cg + c_out + pos, valA, ndA, letA, 0);
+                if (tokB) lf_put_token4(cg + c_out + pos + lenA, valB, ndB, letB, 0);
+                if (isxd) lf_put_token4(md + m_out + mpos, num, mnd, c1, c2);
+            } else {
+                if (tokA) lf_put_token(cg + c_out + pos, valA, ndA, (char)letA, 0);
+                if (tokB) lf_put_token(cg + c_out + pos + lenA, valB, ndB, (char)letB, 0);
+                if (isxd) lf_put_token(md + m_out + mpos, num, mnd, (char)c1, (char)c2);
+            }
+        }
+        /* carried state: the run open after the last event, the matches since the last flush, the last event's type */
+        const int last = cnt - 1;
+        c_run = (uint32_t)__builtin_amdgcn_readlane((int)Rn, last);
+        c_ch = __builtin_amdgcn_readlane(L, last);
+        c_out += tot;
+        if (tmask) c_first = 0;
+        m_out += mtot;
+        const uint32_t Etot = (uint32_t)__builtin_amdgcn_readlane((int)E, 63);
+        if (fmask) { const int pf = 63 - __clzll((long long)fmask); m_num = Etot - (uint32_t)__builtin_amdgcn_readlane((int)E, pf); }
+        else m_num += Etot;
+        m_last = (int)(__builtin_amdgcn_readlane((int)ev.y, last) & 3);
+    };
+    /* keep at most 63 events waiting */
+    auto drain = [&]() {
+        while (n_ev >= 64) {
+            flush_events(64);
+            const uint2 t = s_ev[64 + lane];                           /* (one wavefront: DS operations execute in order) */
+            s_ev[lane] = t;
+            n_ev -= 64;
+        }
+    };
+
     /* The items of a record form a chain of dependent loads (item -> its ops): the next item and the first tile of its ops are
-     * fetched while the current item is processed, and inside a path the next tile's ops while the current tile is encoded
+     * fetched while the current item is processed, and inside a path the next tile's ops while the current tile is classified
      * (a record has ~240 items of ~100 ops). */
     auto is_path = [&](const lf_ritem_t &X) -> bool { return X.n != 0 && X.kind >= LF_RI_OPS_FWD && X.kind <= LF_RI_OPS_REV; };
     auto tile_op = [&](const lf_ritem_t &X, uint32_t base) -> uint32_t {
@@ -142,20 +241,20 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
         uint32_t op_cur = op_next;
         if (it + 1 < rr.nitems) { Inext = items[rr.item0 + it + 1]; op_next = is_path(Inext) ? tile_op(Inext, 0) : 0; }
         if (I.n == 0) continue;
-        if (I.kind == LF_RI_RUN_M) { cigar_run('M', I.n); m_num += I.n; m_last = T_EQ; continue; }
-        if (I.kind == LF_RI_RUN_I) { cigar_run('I', I.n); m_last = T_I; continue; }
+        if (I.kind == LF_RI_RUN_M) { pending += I.n; continue; }
+        if (I.kind == LF_RI_RUN_I) {
+            if (lane == 0) s_ev[n_ev] = make_uint2(pending, (I.n << 10) | EV_I);
+            n_ev++; pending = 0;
+            drain();
+            continue;
+        }
         if (I.kind == LF_RI_DEL) {
-            cigar_run('D', I.n);
-            if (m_last != T_D) {
-                const int nd = lf_ndigits(m_num);
-                if (WRITE && lane == 0) lf_put_token(md + m_out, m_num, nd, '^', 0);
-                m_out += nd + 1; m_num = 0;
+            for (uint32_t j0 = 0; j0 < I.n; j0 += 64) {
+                const uint32_t j = j0 + (uint32_t)lane, c = I.n - j0 < 64u ? I.n - j0 : 64u;
+                if (j < I.n) s_ev[n_ev + lane] = make_uint2(j == 0 ? pending : 0u, (1u << 10) | ((uint32_t)(uint8_t)lf_pac_char(pac, I.tpos + j, 0) << 2) | EV_D);
+                n_ev += (int)c; pending = 0;
+                drain();
             }
-            if (WRITE) {
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-                for (uint32_t j = lane; j < I.n; j += 64) md[m_out + j] = lf_pac_char(pac, I.tpos + j, 0);
-            }
-            m_out += I.n; m_last = T_D;
             continue;
         }
         /* an edit path: I.n ops, forward or reversed */
@@ -166,68 +265,26 @@ lf_render_kernel(const lf_rrecord_t *__restrict__ recs, int n_recs, const lf_rit
             if (base + 64 < I.n) op_cur = tile_op(I, base + 64);
             const uint32_t cnt = (I.n - base < 64u) ? I.n - base : 64u;
             const bool act = (uint32_t)lane < cnt;
-            /* op 0 = 1 I 2 D 3 X  ->  type (inactive lanes: T_EQ) and CIGAR letter (inactive: 0) from two register tables */
-            const int ty = (int)((0x78u >> (op << 1)) & 3u);
-            const int ch = act ? (int)((0x4d44494du >> (op << 3)) & 0xffu) : 0;
-            const bool isx = act && ty == T_X, isd = act && ty == T_D, isxd = isx || isd;
-            const uint64_t eqmask = lf_ballot(act && ty == T_EQ), nimask = lf_ballot(act && ty != T_I);
-            /* the reference base of a mismatch / deletion: asked for first, used last */
-            uint32_t bch = 0;
-            if (isxd) { const uint32_t ti = tcarry + lf_mbcnt(nimask); bch = (uint32_t)(uint8_t)lf_pac_char(pac, trc ? I.tpos - ti : I.tpos + ti, trc); }
-            /* ---- CIGAR: a lane whose letter differs from its left neighbour's closes the neighbour's run ---- */
-            const int pch = __builtin_amdgcn_update_dpp(c_ch, ch, 0x138, 0xf, 0xf, false);      /* wave_shr:1; lane 0 keeps the carried letter */
-            const bool start = act && ch != pch;
-            const uint64_t smask = lf_ballot(start);
-            const bool emits = start && pch != 0;
-            const uint64_t emask = lf_ballot(emits);
-            /* (straight-line from here to the stores: almost every tile has a lane of every kind, so a branch around a few
-             * operations only adds its exec-mask bookkeeping to a loop that is bound by instruction issue) */
-            const uint64_t sb = smask & below;
-            const uint32_t rl = sb ? (uint32_t)(lane - (63 - __clzll((long long)sb))) : c_run + (uint32_t)lane;
-            /* ---- MD: a mismatch, or the first base of a deletion, flushes the match counter ---- */
-            const int pty = __builtin_amdgcn_update_dpp(m_last, ty, 0x138, 0xf, 0xf, false);
-            const bool flush = isx || (isd && pty != T_D);
-            const uint64_t fmask = lf_ballot(flush);
-            const uint32_t eqb = lf_mbcnt(eqmask);                         /* matches below this lane */
-            const uint64_t fb = fmask & below;
-            const int p = fb ? 63 - __clzll((long long)fb) : 0;            /* the previous flushing lane (not a match itself) */
-            const uint32_t eqp = (uint32_t)__shfl((int)eqb, p);
-            const uint32_t num = fb ? eqb - eqp : m_num + eqb;
-            /* run lengths / match counts of five digits and more: the general functions (wave-uniform, rare) */
-            const bool big = lf_any((emits && rl >= 10000u) || (flush && num >= 10000u));
-            int nd = lf_ndigits4(rl), mnd = flush ? lf_ndigits4(num) : 0;
-            if (big) { nd = lf_ndigits(rl); mnd = flush ? lf_ndigits(num) : 0; }
-            const uint32_t tlen = emits ? (uint32_t)nd + 1u : 0u;
-            const uint32_t mlen = isxd ? (uint32_t)mnd + (flush && isd ? 2u : 1u) : 0u;      /* [count] [^] base */
-            /* ONE wave scan places both strings' tokens: lengths packed 16 + 16 bits (<= 64 x 12 per half: no carry) */
-            const uint32_t packed = tlen | (mlen << 16), incl = lf_wave_incl_sum(packed), excl = incl - packed;
-            const uint32_t both = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            const uint32_t pos = excl & 0xffffu, mpos = excl >> 16, tot = both & 0xffffu, mtot = both >> 16;
-            if (WRITE) {
-                const uint32_t letter = (c_first && !(emask & below) && pch == 'I') ? (uint32_t)'S' : (uint32_t)pch;
-                const uint32_t c1 = (flush && isd) ? (uint32_t)'^' : bch, c2 = (flush && isd) ? bch : 0u;
-                if (!big) {
-                    if (emits) lf_put_token4(cg + c_out + pos, rl, nd, letter, 0);
-                    if (isxd) lf_put_token4(md + m_out + mpos, num, mnd, c1, c2);
-                } else {
-                    if (emits) lf_put_token(cg + c_out + pos, rl, nd, (char)letter, 0);
-                    if (isxd) lf_put_token(md + m_out + mpos, num, mnd, (char)c1, (char)c2);
-                }
+            /* op 0 = 1 I 2 D 3 X  ->  event type (X 0, I 1, D 2); op 0 is no event */
+            const bool isev = act && op != 0u;
+            const uint64_t nz = lf_ballot(isev), nimask = lf_ballot(act && op != 1u);
+            if (isev) {
+                const uint32_t ety = op == 3u ? EV_X : op == 1u ? EV_I : EV_D;
+                uint32_t bch = 0;
+                if (op != 1u) { const uint32_t ti = tcarry + lf_mbcnt(nimask); bch = (uint32_t)(uint8_t)lf_pac_char(pac, trc ? I.tpos - ti : I.tpos + ti, trc); }
+                const uint64_t nb = nz & below;
+                const uint32_t eq = nb ? (uint32_t)(lane - 1 - (63 - __clzll((long long)nb))) : pending + (uint32_t)lane;      /* everything between two events is a match */
+                s_ev[n_ev + (int)lf_mbcnt(nz)] = make_uint2(eq, (1u << 10) | (bch << 2) | ety);
             }
-            /* carried state */
-            const int last = __builtin_amdgcn_readfirstlane((int)cnt - 1);
-            if (smask) c_run = cnt - (uint32_t)(63 - __clzll((long long)smask)); else c_run += cnt;
-            c_ch = __builtin_amdgcn_readlane(ch, last);
-            c_out += tot;
-            if (emask) c_first = 0;
-            m_out += mtot;
-            if (fmask) { const int p = 63 - __clzll((long long)fmask); m_num = (uint32_t)__popcll(eqmask & ~(~0ull >> (63 - p))); }
-            else m_num += (uint32_t)__popcll(eqmask);
-            m_last = __builtin_amdgcn_readlane(ty, last);
+            if (nz) { pending = cnt - 1u - (uint32_t)(63 - __clzll((long long)nz)); n_ev += __popcll(nz); } else pending += cnt;
             tcarry += (uint32_t)__popcll(nimask);
+            drain();
         }
     }
-    /* close the record (src/LordFAST.cpp:1704-1708, :1756-1760): the last CIGAR run (I -> S), the match counter */
+    if (n_ev) { flush_events(n_ev); n_ev = 0; }
+    /* the matches behind the last event, then close the record (src/LordFAST.cpp:1704-1708, :1756-1760): the last CIGAR run
+     * (I -> S), the match counter */
+    if (pending) { cigar_run('M', pending); m_num += pending; }
     if (c_ch) {
         const int nd = lf_ndigits(c_run);
         if (WRITE && lane == 0) lf_put_token(cg + c_out, c_run, nd, c_ch == 'I' ? 'S' : (char)c_ch, 0);
