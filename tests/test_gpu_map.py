@@ -448,3 +448,46 @@ def test_reads_at_the_edges_of_the_reference(lf, oracle, golden_dir):
     mapped = [l for l in sam.split(b"\n") if l and not (int(l.split(b"\t")[1]) & 4)]
     assert len(mapped) >= len(names) - 2 and st["n_edlib_problems"] > 0
     assert any(l.split(b"\t")[3] == b"1" for l in mapped), "a record must start at position 1 of a contig"
+
+
+def test_long_runs_of_matches_and_sparse_edits(lf, golden_dir, oracle_lib):
+    """records whose CIGAR carries numbers of five digits and runs that span hundreds of recipe items and many event tiles of the
+    renderer: 38 kbp reads with ONE mismatch every 1 500 bases (CIGAR `38000M`, MD `700C1499G...`), the same with a 3-base
+    deletion / a 5-base insertion in the middle (an M run of 20 000 is closed inside an event tile: the general digit path),
+    both strands.  Expected records: the compiled reference's (error-free stretches are quadratic in the reference's seed
+    search and in the oracle's; 1 500 bases keep it at seconds)."""
+    from conftest import read_fasta, GOLDEN, have_ref
+    if not have_ref():
+        pytest.skip("needs oracle/_ref/liblfref.so")
+    import shutil
+    cn, cs = read_fasta(os.path.join(GOLDEN, "genome.fa.gz"))
+    a = np.frombuffer(max(cs, key=len), dtype=np.uint8)
+    assert len(a) > 42000
+    base = a[2000:40000].copy()
+    for p in range(700, len(base), 1500):
+        base[p] = ord("A") if base[p] != ord("A") else ord("G")
+    names, seqs = [], []
+
+    def add(tag, x):
+        names.append((tag + "_f").encode()); seqs.append(bytes(x.tobytes()))
+        names.append((tag + "_r").encode()); seqs.append(bytes(synth.revcomp(x).tobytes()))
+
+    add("sparse", base)
+    add("sparse_del3", np.concatenate([base[:20000], base[20003:]]))
+    add("sparse_ins5", np.concatenate([base[:15000], np.frombuffer(b"ACGTA", dtype=np.uint8), base[15000:]]))
+    sam, st = lf.map_batch(names, seqs)
+    fa = os.path.join(golden_dir, "genome.fa")
+    ref = oracle_lib.Ref()
+    made_cache = not os.path.exists(fa + ".cache")
+    if made_cache:                                     # the reference reads its k-mer table from a file; the GPU side never does
+        d2 = os.path.join(golden_dir, "refidx"); os.makedirs(d2, exist_ok=True)
+        shutil.copy(fa, os.path.join(d2, "genome.fa")); fa = os.path.join(d2, "genome.fa")
+        ref.index_build(fa)
+    ref.load(fa)
+    ref.set_params(oracle_lib.default_params(threads=1), "t")            # one thread: records in input order
+    exp, _ = ref.map_mem(names, seqs)
+    assert sam == exp, first_diff(sam, exp)
+    import re
+    recs = [l.split(b"\t") for l in sam.split(b"\n") if l]
+    assert sum(f[5] == b"38000M" for f in recs) == 2, "mismatches only: one M run"
+    assert sum(bool(re.search(rb"\d{5}M\d[ID]", f[5])) for f in recs) == 4, "five-digit runs closed by an indel"
