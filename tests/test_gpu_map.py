@@ -475,6 +475,8 @@ def test_long_runs_of_matches_and_sparse_edits(lf, golden_dir, oracle_lib):
     add("sparse", base)
     add("sparse_del3", np.concatenate([base[:20000], base[20003:]]))
     add("sparse_ins5", np.concatenate([base[:15000], np.frombuffer(b"ACGTA", dtype=np.uint8), base[15000:]]))
+    add("exact1500", a[1000:2500].copy())              # an error-free read: every sample's match runs to the end of the read, all but
+                                                       # the first are "contained" (src/BWT.cpp:345): the reference leaves it unmapped
     sam, st = lf.map_batch(names, seqs)
     fa = os.path.join(golden_dir, "genome.fa")
     ref = oracle_lib.Ref()
