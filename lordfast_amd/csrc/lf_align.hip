@@ -864,6 +864,19 @@ extern "C" int lfg_edlib(int device, int n, const char *q, const uint64_t *qoff,
  *   - H(i,j) is stored one column to the right (the reference's eh[j].h = h1 trick): a wave_shr:1 move.
  * The band trimming, z-drop and maximum bookkeeping are the reference's scalar code on wave-uniform values.
  * ---------------------------------------------------------------------------------------------- */
+/* signed inclusive max-scan / 64-bit max-reduction over the wavefront by DPP row shifts and broadcasts (no LDS) */
+__device__ __forceinline__ int lf_wave_incl_max_i32(int v)
+{
+    int x = v;
+    const int lo = INT_MIN;
+    x = max(x, __builtin_amdgcn_update_dpp(lo, x, 0x111, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(lo, x, 0x112, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(lo, x, 0x114, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(lo, x, 0x118, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(lo, x, 0x142, 0xa, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(lo, x, 0x143, 0xc, 0xf, false));
+    return x;
+}
 struct lf_ksw_prob { uint64_t qoff, toff, ws_off; int32_t qlen, tlen, o_del, e_del, o_ins, e_ins, w, zdrop, h0, id; };
 
 template <bool LDS>
@@ -872,9 +885,7 @@ lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t 
               int32_t *__restrict__ ws, int32_t *__restrict__ out_score, int32_t *__restrict__ out_qle, int32_t *__restrict__ out_tle, int lds_q)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t s_he[];
-    typedef hipcub::WarpScan<int, 64> scan_t;
     typedef hipcub::WarpReduce<unsigned long long, 64> red_t;
-    __shared__ typename scan_t::TempStorage scan_tmp;
     __shared__ typename red_t::TempStorage red_tmp;
     const int gid = blockIdx.x, lane = threadIdx.x;
     if (gid >= n_probs) return;
@@ -911,6 +922,7 @@ lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t 
         if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
         else h1 = 0;
         int f = 0, m = 0, mj = -1;
+        unsigned long long best = 0;                     /* this lane's (h << 32 | j) maximum over the row's tiles */
         for (int base = beg; base < end; base += 64) {
             const int j = base + lane;
             const bool act = j < end;
@@ -925,8 +937,9 @@ lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t 
             }
             /* f entering column base + k: max(carry, max_{l<k} B(l)) - k e_ins */
             const int Bv = act ? tins + (lane + 1) * e_ins : INT_MIN / 2;
-            int G;
-            scan_t(scan_tmp).ExclusiveScan(Bv, G, f, hipcub::Max());
+            const int incl = lf_wave_incl_max_i32(Bv);
+            int G = __builtin_amdgcn_update_dpp(INT_MIN, incl, 0x138, 0xf, 0xf, false);      /* exclusive: lane l takes lanes < l */
+            G = G > f ? G : f;
             const int fin = G - lane * e_ins;
             int h = M > e ? M : e;
             h = h > fin ? h : fin;
@@ -939,16 +952,17 @@ lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t 
                 int e2 = e - e_del; if (e2 < tt) e2 = tt;
                 E[j] = e2;
             }
-            /* row maximum, last column on ties */
-            unsigned long long key = act ? (((unsigned long long)(unsigned)h << 32) | (unsigned)j) : 0ull;
-            key = red_t(red_tmp).Reduce(key, hipcub::Max());
-            const int tm = __builtin_amdgcn_readfirstlane((int)(key >> 32)), tj = __builtin_amdgcn_readfirstlane((int)(key & 0xFFFFFFFFu));
-            if (tm >= m) { m = tm; mj = tj; }
+            /* row maximum, last column on ties: kept per lane over the tiles (a lane's columns ascend), reduced ONCE per row */
+            { const unsigned long long key = act ? (((unsigned long long)(unsigned)h << 32) | (unsigned)j) : 0ull; best = key > best ? key : best; }
             /* carries into the next tile */
             const int last = __builtin_amdgcn_readfirstlane(cnt - 1);
             h1 = __builtin_amdgcn_readlane(h, last);
             int fout = fin - e_ins; if (fout < tins) fout = tins;
             f = __builtin_amdgcn_readlane(fout, last);
+        }
+        if (beg < end) {
+            const unsigned long long key = red_t(red_tmp).Reduce(best, hipcub::Max());
+            m = __builtin_amdgcn_readfirstlane((int)(key >> 32)); mj = __builtin_amdgcn_readfirstlane((int)(key & 0xFFFFFFFFu));
         }
         if (lane == 0) { H[end] = h1; E[end] = 0; }
         __syncthreads();
