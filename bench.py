@@ -6,19 +6,24 @@
         rank 0's line; already under torchrun (RANK / WORLD_SIZE set, the driver's form) it is one of the ranks.
 
 A "step" maps one batch of synthetic reads with the index resident in HBM (index load excluded -- the reference's own timer,
-src/baseFAST.cpp:69-75).  `value`: read bases resident in HBM when the timed region starts, SAM records left in HBM
-(lf_map_batch_dev).  `value_pcie_inclusive`: the same steps through the host-buffer boundary the reference has (reads in host
-memory -> SAM text in host memory, lf_map_batch_into_lens).
-N > 1: one process per GPU, index replicated, reads are independent.  --scaling weak (default): --reads per GPU; strong: the
-SAME --reads set cut by bases over the ranks (BASELINE config C3).  --exchange on (default for N > 1): rank 0 owns every step's
-reads and ends with its SAM records; both move over RCCL point-to-point (xGMI), pipelined one step ahead / behind the mapping
-(lordfast_amd/dist.py: PipelinedExchange), inside the timed region.  The rate without any exchange is reported next to it.
-Prints ONE JSON line on rank 0 carrying `roofline` for the dominant kernel group and `cpu_baseline` (the real reference,
-compiled into oracle/_ref, on the host cores, bounded sample).
+src/baseFAST.cpp:69-75).
+N = 1: `value` / `ms_per_step` = the boundary SURVEY 8(d) defines and the reference has: reads in host memory -> SAM records in
+host memory (lf_map_batch_into_lens; H2D and D2H are inside the step).  `value_hbm_resident`: the same steps with the read bases
+already in HBM and the SAM text left there (lf_map_batch_dev) -- what one rank of the N-GPU deployment does.
+N > 1: one process per GPU, index replicated, reads are independent.  --scaling strong (default for N > 1): the SAME --reads set
+cut by bases over the ranks (BASELINE config C3); weak: --reads per GPU.  `value` = the rate with the exchange (--exchange on,
+default): rank 0 owns every step's reads and ends with its SAM records; both move over RCCL point-to-point (xGMI), pipelined one
+step ahead / behind the mapping (lordfast_amd/dist.py: PipelinedExchange), inside the timed region.  The rates without any
+exchange (HBM-resident shards; every rank's own host buffers) and the weak-scaling rate are reported next to it.
+The records the TIMED steps wrote are snapshotted (digest + head) before anything else runs; that snapshot is what is compared
+with the reference, and it must equal the output of the exclusive (one lane, one chunk) pass.
+Prints ONE JSON line on rank 0 carrying `roofline` for the single kernel with the largest exclusive time (all kernels in
+`by_kernel`) and `cpu_baseline` (the real reference, compiled into oracle/_ref, on the host cores, bounded sample).
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import hashlib
 import json
 import os
@@ -35,7 +40,7 @@ import numpy as np  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=None, help="default 4 (c4: 10 -- 10 x 100 k = the 1 M reads of BASELINE config C4)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-mbp", type=float, default=float(os.environ.get("LF_BENCH_GENOME_MBP", "3100")))
     ap.add_argument("--reads", type=int, default=int(os.environ.get("LF_BENCH_READS", "100000")), help="reads per GPU per step")
@@ -54,8 +59,14 @@ def parse():
                     help="N>1: rank 0 owns every step's read batch (in HBM); its shards go to the ranks and their SAM records come back "
                          "over RCCL point-to-point, pipelined with the mapping, inside the timed region.  auto = on for N>1.  The rate "
                          "without the exchange is reported too")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: --reads per GPU (work grows with N); strong: the same --reads set cut by bases over the N ranks (config C3)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="strong (default for N > 1): the same --reads set cut by bases over the N ranks (config C3); weak: --reads per GPU "
+                         "(work grows with N; reported as value_weak_* next to the strong line)")
+    ap.add_argument("--dup-frac", type=float, default=None,
+                    help="fraction of the reads drawn from segmental duplications (2-4 copies of 40-80 kbp segments at 1-3 %% divergence, "
+                         "--segdups of them pasted into the genome): those reads have several near-equal candidate windows, so mapSeq "
+                         "takes its fine branch (src/LordFAST.cpp:542-562) and -n windows are chained and extended.  c4 default 0.3, else 0")
+    ap.add_argument("--segdups", type=int, default=2000, help="duplicated segments in the genome when --dup-frac > 0")
     ap.add_argument("--mode", choices=["ranks", "inproc"], default="ranks",
                     help="ranks: one process per GPU (torch.distributed); inproc: ONE process drives N devices through lf_map_batch_multi "
                          "(chunks pulled from one counter; every device copies through its own PCIe link)")
@@ -72,6 +83,14 @@ def parse():
         a.exchange = "on"
     if a.config == "c4":
         a.chain_alg, a.max_map = "clasp", 30
+        if a.dup_frac is None:
+            a.dup_frac = 0.3
+    if a.dup_frac is None:
+        a.dup_frac = 0.0
+    if a.steps is None:
+        a.steps = 10 if a.config == "c4" else 4
+    if a.scaling is None:
+        a.scaling = "strong" if a.gpus > 1 else "weak"
     if a.config == "c5":
         if a.read_len == 15000:
             a.read_len = 50000
@@ -92,16 +111,23 @@ def genome_recipe(args):
 
 
 def make_contigs(args):
-    """the synthetic genome is a pure function of its recipe: any rank can regenerate it instead of parsing the FASTA"""
+    """the synthetic genome is a pure function of its recipe: any rank can regenerate it instead of parsing the FASTA.
+    -> (contigs, segdup families or None)"""
     from lordfast_amd import synth
     total, n_contigs, fams = genome_recipe(args)
-    return synth.make_genome(total, n_contigs, seed=11, repeat_frac=0.10, n_families=fams, profile=args.repeat_profile)
+    contigs = synth.make_genome(total, n_contigs, seed=11, repeat_frac=0.10, n_families=fams, profile=args.repeat_profile)
+    segd = None
+    if args.dup_frac > 0:
+        nseg = max(1, min(args.segdups, total // 400_000))
+        seg_len = (40000, 80000) if total >= 50_000_000 else (12000, 20000)
+        segd = synth.add_segdups(contigs, nseg, seg_len=seg_len, seed=7)
+    return contigs, segd
 
 
 def ensure_index(args, rank):
     """synthetic genome + index files under workdir (rank 0 builds, others wait on the done marker)"""
     from lordfast_amd import synth
-    tag = f"g{args.genome_mbp:g}" + ("" if args.repeat_profile == "default" else "_" + args.repeat_profile)
+    tag = f"g{args.genome_mbp:g}" + ("" if args.repeat_profile == "default" else "_" + args.repeat_profile) + (f"_sd{args.segdups}" if args.dup_frac > 0 else "")
     d = os.path.join(args.workdir, tag)
     fa = os.path.join(d, "genome.fa")
     done = os.path.join(d, "DONE")
@@ -110,10 +136,10 @@ def ensure_index(args, rank):
         t0 = time.time()
         total, n_contigs, fams = genome_recipe(args)
         contigs = make_contigs(args)
-        log(f"genome {total} bp, {n_contigs} contigs, {fams} repeat families: {time.time() - t0:.1f}s")
+        log(f"genome {total} bp, {n_contigs} contigs, {fams} repeat families" + (f", {len(contigs[1])} segmental duplications" if contigs[1] else "") + f": {time.time() - t0:.1f}s")
         t0 = time.time()
         import lordfast_amd as la
-        la.index_build(contigs, fa)                           # GPU indexer (writes the reference's file formats)
+        la.index_build(contigs[0], fa)                        # GPU indexer (writes the reference's file formats)
         log(f"index built in {time.time() - t0:.1f}s")
         open(done, "w").write("ok")
         return fa, contigs
@@ -126,7 +152,7 @@ def make_reads(args, contigs, fa, rank):
     """this rank's seeded reads (seed 2024 + rank: every GPU maps DIFFERENT reads); cached on disk so that repeated
     bench runs on one box skip generation"""
     from lordfast_amd import synth
-    key = hashlib.md5(f"{fa}|{args.reads}|{args.read_len}|{args.err}|{rank}|{args.config == 'c5'}".encode()).hexdigest()[:12]
+    key = hashlib.md5((f"{fa}|{args.reads}|{args.read_len}|{args.err}|{rank}|{args.config == 'c5'}" + (f"|dup{args.dup_frac:g}" if args.dup_frac > 0 else "")).encode()).hexdigest()[:12]
     path = os.path.join(os.path.dirname(fa), f"reads_{key}.npz")
     if os.path.exists(path):
         z = np.load(path)
@@ -138,7 +164,7 @@ def make_reads(args, contigs, fa, rank):
         contigs = make_contigs(args)
     t0 = time.time()
     mix = (0.40, 0.25, 0.35) if args.config == "c5" else (0.15, 0.50, 0.35)          # ONT / PacBio CLR profile
-    reads = synth.make_reads(contigs, args.reads, args.read_len, args.err, seed=2024 + rank, mix=mix)
+    reads = synth.make_reads(contigs[0], args.reads, args.read_len, args.err, seed=2024 + rank, mix=mix, segdups=contigs[1], dup_frac=args.dup_frac)
     names = [(r[0] if rank == 0 else f"g{rank}_{r[0]}").encode() for r in reads]
     seqs = [r[1] for r in reads]
     log(f"rank {rank}: {args.reads} reads generated in {time.time() - t0:.1f}s")
@@ -230,6 +256,9 @@ def spawn_ranks(args):
 
 def main():
     args = parse()
+    if os.environ.get("LF_BENCH_STACKS"):      # debugging aid: the Python stacks of all threads every N seconds (where a hung run is)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["LF_BENCH_STACKS"]), repeat=True, file=sys.stderr)
     under_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and args.mode == "ranks" and not under_torchrun:
         sys.exit(spawn_ranks(args))
@@ -274,6 +303,7 @@ def main():
         dist.barrier()
     t0 = time.time()
     lf = la.LordFast(fa, device=local, full_sa=True)
+    lf.L.lf_device_copy.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
     replicas = [lf] + [la.LordFast(fa, device=d % la.device_count(), full_sa=True) for d in range(1, n_dev)]
     log(f"rank {rank}: index resident in HBM after {time.time() - t0:.1f}s")
     kk, cc = (17, 2000) if args.config == "c5" else (14, 1000)             # -k 14 -c 1000 --chainAlg dp-n2 (C2); -k 17 -c 2000 (C5)
@@ -342,7 +372,12 @@ def main():
             return self.n
 
         def head(self, k):
-            return bytes(self.t[:min(k, self.n)].cpu().numpy().tobytes())
+            k = min(k, self.n)
+            if self.t.device.type == "cpu":
+                return bytes(self.t[:k].numpy().tobytes())
+            buf = (C.c_char * k)()                           # through the library's own copy, not torch's (see digest)
+            la.api._check(lf.L.lf_device_copy(local, buf, C.c_void_p(self.t.data_ptr()), C.c_size_t(k)), "lf_device_copy")
+            return bytes(buf)
 
     def map_shard(shard, out):
         """one step of the product path on a device-resident shard -> SAM text in `out` (HBM, or -- gloo hook -- host)"""
@@ -403,30 +438,79 @@ def main():
             el = float(tmax.item())
         return el, cpu_s, agg, sam
 
-    # ---- 1. no exchange: every rank maps the shard resident in its own HBM (N = 1: this is `value`) ----
-    primary = step_host if args.mode == "inproc" else step_hbm
-    for _ in range(args.warmup):
-        primary()
-    elapsed_nx, cpu_s, agg, sam = timed(primary, args.steps)
-    # ---- 2. the same steps through the host-buffer boundary (PCIe inside the step) ----
-    elapsed_host = None
-    if args.mode != "inproc" and not args.no_host_region:
-        step_host()
-        elapsed_host, _, _, _ = timed(step_host, args.steps)
+    def digest(sam):
+        """(xxh3-128 of the whole text, its length).  Device text is brought over by the LIBRARY's copy (lf_device_copy, one
+        D2H into the pinned buffer) -- not by torch: a torch-side `.cpu()` of a few GB between two regions left the next
+        library call waiting for the GPU forever (two runs of two; the runtime's device-wide wait with the lanes' ~10^2
+        streams alive, see DESIGN.md 'runtime trap')."""
+        import xxhash
+        n = len(sam)
+        if sam.t.device.type != "cpu":
+            if n > host_out.numel():
+                return None
+            la.api._check(lf.L.lf_device_copy(local, C.c_void_p(host_out.data_ptr()), C.c_void_p(sam.t.data_ptr()), C.c_size_t(n)), "lf_device_copy")
+            view = host_out.numpy()
+        else:
+            view = sam.t.numpy()
+        h = xxhash.xxh3_128()
+        for a in range(0, n, 1 << 28):
+            h.update(memoryview(view[a:min(n, a + (1 << 28))]))
+        return h.hexdigest(), n
 
-    elapsed, xinfo = elapsed_nx, None
+    # ---- 1. the shard resident in this rank's HBM, SAM text left in HBM, no exchange (`value_hbm_resident`) ----
+    hbm_step = step_host if args.mode == "inproc" else step_hbm
+    for _ in range(args.warmup):
+        hbm_step()
+    elapsed_nx, cpu_s_hbm, agg_hbm, sam_hbm = timed(hbm_step, args.steps)
+    snap_hbm = digest(sam_hbm) if (rank == 0 and world == 1 and not args.no_exclusive) else None
+    # ---- 2. the same steps through the host-buffer boundary the reference has: reads in host memory -> SAM records in host memory
+    #         (H2D and D2H inside the step).  N = 1: this is `value` (SURVEY 8d) ----
+    elapsed_host = cpu_s_host = agg_host = sam_host = None
+    snap_host = head_host = None
+    if args.mode != "inproc" and not args.no_host_region:
+        for _ in range(max(1, args.warmup)):
+            step_host()
+        elapsed_host, cpu_s_host, agg_host, sam_host = timed(step_host, args.steps)
+        if rank == 0 and world == 1:
+            # the records the TIMED steps wrote, before anything else runs: a digest of all of them and the head that is compared with the reference
+            snap_host = digest(sam_host)
+            head_host = sam_host.head(int(6.5 * args.cpu_seconds * 1100 * args.read_len) + (8 << 20)) if not args.no_cpu_baseline else None
+    elif args.mode == "inproc":
+        elapsed_host, cpu_s_host, agg_host, sam_host = elapsed_nx, cpu_s_hbm, agg_hbm, sam_hbm
+    primary_is_host = world * n_dev == 1 and elapsed_host is not None or args.mode == "inproc"
+    agg, cpu_s, sam = (agg_host, cpu_s_host, sam_host) if primary_is_host else (agg_hbm, cpu_s_hbm, sam_hbm)
+
+    elapsed, xinfo = (elapsed_host if primary_is_host else elapsed_nx), None
     bases_total = bases_local
     if dist:
         bsum = torch.tensor([bases_local], dtype=torch.int64, device=rdev)
         dist.all_reduce(bsum, op=dist.ReduceOp.SUM)
         bases_total = int(bsum.item())
 
+    # ---- weak-scaling rate next to a strong-scaling line: every rank maps --reads reads of its own (seed 2024 + rank), HBM-resident
+    elapsed_weak = None
+    if strong and dist and not os.environ.get("LF_BENCH_NO_WEAK"):
+        wn, ws = make_reads(args, None, fa, rank)
+        wshard = lfd.make_shards(torch, wn, ws, 1, bulk)[0][0]
+        wcap = int(3.0 * sum(len(x) for x in ws) * 1.1) + len(ws) * 2048 + (1 << 20)
+        wout = dev_out if wcap <= dev_out.numel() else torch.empty(wcap, dtype=torch.uint8, device=dev)
+        if stage_in is not None and stage_in.numel() < wshard.nbytes:
+            stage_in = torch.empty(wshard.nbytes + (1 << 20), dtype=torch.uint8, device=dev)
+        del wn, ws
+        def step_weak():
+            ln, st = map_shard(wshard, wout)
+            return _Sam(wout, ln), st
+        step_weak()
+        elapsed_weak, _, _, _ = timed(step_weak, args.steps)
+        del wshard, wout
+
     # ---- exclusive pass (rank 0, outside the timed region): ONE step with one chunk at a time and the alignment size classes
     # on one stream, so that every HIP-event bracket is the kernel (group) ALONE on the GPU.  The timed steps above keep
     # eight chunks in flight: their brackets overlap and are only reported as `overlapped_bracket_ms`.
     excl = None
+    snap_excl = None
     if rank == 0 and args.no_exclusive:
-        excl = {k: (v / args.steps if isinstance(v, (int, float)) else v) for k, v in agg.items()}      # overlapped brackets instead
+        excl = {k: (v / args.steps if isinstance(v, (int, float)) else v) for k, v in agg_hbm.items()}      # overlapped brackets instead
     elif rank == 0:
         saved = {k: os.environ.get(k) for k in ("LF_LANES", "LF_SERIAL_CLASSES", "LF_CHUNK_READS", "LF_CHUNK_BASES")}
         os.environ["LF_LANES"] = "1"; os.environ["LF_SERIAL_CLASSES"] = "1"
@@ -435,8 +519,10 @@ def main():
             # GPU" also means "with enough wavefronts to fill it" (a 25 k-read chunk left the small size classes with < 2 waves per SIMD)
             os.environ["LF_CHUNK_READS"] = str(1 << 30); os.environ["LF_CHUNK_BASES"] = str(1 << 40)
         try:
-            primary()                      # the one-chunk-at-a-time mode uses larger chunks: let the grow-only buffers settle
-            _, excl = primary()
+            hbm_step()                      # the one-chunk-at-a-time mode uses larger chunks: let the grow-only buffers settle
+            sam_x, excl = hbm_step()
+            if world == 1 and args.mode != "inproc":
+                snap_excl = digest(sam_x)
         finally:
             for k, v in saved.items():
                 if v is None:
@@ -452,6 +538,8 @@ def main():
     except Exception:                                                    # noqa: BLE001
         hbm_used_gb = None
 
+    index_desc = lf.describe()
+
     def report(elapsed, sam, xinfo):
         K = args.steps
         bases = bases_total
@@ -460,64 +548,81 @@ def main():
         # ---- roofline: algorithmic bytes (SURVEY 8d counters emitted by the kernels) / EXCLUSIVE kernel time ----
         # Durations come from the exclusive pass (one step = one launch sequence per chunk; HIP events on the launch
         # streams; nothing else on the GPU).  Their sum is below ms_per_step; profiles/ holds the rocprofv3
-        # --kernel-trace --stats summary of the same serialized command.
+        # --kernel-trace --stats summary of the same serialized command.  The first block are single kernels (the event bracket
+        # holds that kernel alone); the second block are small groups (a stage's helper kernels around its main kernel).
         def kernel_table(a):
             n_hits = a["n_seeds"]
             return {
-                "lf_seed_search_kernel": (a["ms_k_search"], 16 * a["n_cache"] + 64 * a["n_occblk"] + a["n_readbytes"], a["search_launches"]),
-                "lf_seed_locate_kernel": (a["ms_k_locate"], 8 * a["n_sa"] + 9 * a["n_sa"], a["locate_launches"]),
+                "lf_seed_search_kernel": (a["ms_k_search"], 16 * a["n_cache"] + 64 * a["n_occblk"] + a["n_readbytes"], a["search_launches"], True),
+                "lf_edlib_rsweep_kernel": (a["ms_k_rsweep"], a["ext_bytes"] - a["ops_bytes"], max(1, 2 * a["edlib_launches"]), True),      # NW + SHW instantiation per round: q + t/4 read
+                "lf_edlib_tb_kernel": (a["ms_k_tb"], a["ops_bytes"], max(1, a["edlib_launches"]), True),                               # the paths written (q + t region per problem)
+                "lf_seed_locate_kernel": (a["ms_k_locate"], 8 * a["n_sa"] + 9 * a["n_sa"], a["locate_launches"], True),
+                "lf_ksw_kernel": (a["ms_k_ksw"], a.get("ksw_bytes", 0), max(1, a["n_ksw_problems"] and 1), True),
+                # ---- groups ----
                 # lf_vote_hash_kernel (+ request-count scan): 9 B per hit read; votes live in LDS
-                "lf_vote_hash_kernel (+ scan)": (a["ms_k_vote"], 9 * n_hits, a["search_launches"]),
+                "lf_vote_hash_kernel (+ scan)": (a["ms_k_vote"], 9 * n_hits, a["search_launches"], False),
                 # request gather + sort by qPos + lf_chain_n2_kernel + chain gather: 16 B per request seed, 8 B per chain seed
-                "lf_chain_* (gather, sort, dp-n2 | clasp)": (a["ms_k_chain"], 16 * a["n_req_seeds"], a["search_launches"]),
-                # the alignment size classes lf_edlib_kernel<1,2,3,4,6,8>, lf_edlib_sweep_kernel<16|32|64, ...>: one launch group per round
-                "lf_edlib_* (size-class launch group)": (a["ms_k_edlib"], a["ext_bytes"], max(1, a["edlib_launches"])),
-                "lf_render_kernel": (a["ms_k_render"], a["ops_bytes"] + a["render_bytes"], max(1, a["render_launches"])),      # single pass: ops read once, text written once
-                # ksw_extend2: the two sequences once + one H / E row pair (8 B per query column) per target row inside the band
-                "lf_ksw_kernel": (a["ms_k_ksw"], a.get("ksw_bytes", 0), max(1, a["n_ksw_problems"] and 1)),
+                "lf_chain_* (gather, sort, dp-n2 | clasp)": (a["ms_k_chain"], 16 * a["n_req_seeds"], a["search_launches"], False),
+                "lf_hirsch_* (levels incl. per-level readbacks)": (a["ms_k_hirsch"], 0, max(1, a["edlib_launches"]), False),
+                "lf_desc_* (alignment binning: keys, sort, segments, scan, build)": (a["ms_k_bin"], 100 * a["n_edlib_problems"], max(1, a["edlib_launches"]), False),
+                "lf_render_kernel (+ caps, scan)": (a["ms_k_render"], a["ops_bytes"] + a["render_bytes"], max(1, a["render_launches"]), False),      # single pass: ops read once, text written once
             }
         kx = kernel_table(excl)
+        pmc, pmc_src = load_pmc(args, world)
         by_kernel = {}
-        for kname, (kms, kbytes, kl) in kx.items():
+        for kname, (kms, kbytes, kl, single) in kx.items():
             gbs = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+            traffic = None
+            if pmc is not None:
+                prefix = kname.split(" ")[0].rstrip("*")
+                fam = [v for k, v in pmc.items() if k.startswith(prefix) and isinstance(v, dict)]
+                if fam:      # the counter passes profile exactly ONE step (--no-exclusive --steps 1 --warmup 0): bytes per step
+                    traffic = sum(v.get("fetch_kb", 0.0) + v.get("write_kb", 0.0) for v in fam) * 1024.0
             by_kernel[kname] = dict(ms_per_step=kms, launches_per_step=kl, avg_launch_ms=kms / max(1, kl), algorithmic_GB_per_step=kbytes / 1e9,
-                                    achieved_GBps=gbs, frac_of_8TBps=gbs / 8000.0)
-        excl_sum = sum(v[0] for v in kx.values())
-        dom = max(kx, key=lambda k: kx[k][0])                 # the dominant kernel (group) by exclusive time
-        dms, dbytes, dl = kx[dom]
+                                    achieved_GBps=gbs, frac_of_8TBps=gbs / 8000.0, single_kernel=single,
+                                    hbm_traffic_GB_per_step=(traffic / 1e9 if traffic is not None else None))
+        other = max(0.0, excl["ms_k_edlib"] - excl["ms_k_rsweep"] - excl["ms_k_tb"] - excl["ms_k_hirsch"] - excl["ms_k_bin"])      # large-leaf sweeps, stitch
+        excl_sum = sum(v[0] for v in kx.values()) + other
+        dom = max((k for k in kx if kx[k][3]), key=lambda k: kx[k][0])      # the single kernel with the largest exclusive time
+        dms, dbytes, dl, _ = kx[dom]
         achieved = dbytes / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
-        traffic, traffic_src = load_traffic(args, world, dom, dl)
-        roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0, traffic=traffic,
-                        traffic_source=traffic_src,
+        traffic = by_kernel[dom]["hbm_traffic_GB_per_step"]
+        roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=8000.0, unit="GB/s", frac=achieved / 8000.0,
+                        traffic=(traffic * 1e9 / max(1, dl) if traffic is not None else None), traffic_source=pmc_src,
                         launches_per_step=int(dl), avg_launch_ms=dms / max(1, dl), algorithmic_bytes_per_launch=dbytes / max(1, dl),
-                        exclusive_ms_per_step=dms, exclusive_ms_sum_all_kernels=excl_sum, by_kernel=by_kernel,
+                        exclusive_ms_per_step=dms, exclusive_ms_sum_all_kernels=excl_sum,
+                        alignment_group_exclusive_ms=excl["ms_k_edlib"], by_kernel=by_kernel,
                         measured="exclusive pass inside bench.py: the whole batch as ONE chunk on one lane (LF_LANES=1, LF_CHUNK_READS / _BASES unlimited), the "
                                  "alignment classes on one stream (LF_SERIAL_CLASSES=1), HIP events on the launch streams, one step after the timed region; "
                                  "the rocprofv3 summary of the same mode is under profiles/",
-                        overlapped_bracket_ms_per_step={k: round(v[0] / K, 2) for k, v in kernel_table(agg).items()},
-                        chunks_in_flight_timed_region=8)
-        if dom.startswith("lf_edlib"):
-            # the alignment kernels are integer-ALU work, not HBM work: one Myers block step (64 DP cells) is ~55 32-bit lane
+                        overlapped_bracket_ms_per_step={k: round(v[0] / K, 2) for k, v in kernel_table(agg_hbm).items()},
+                        lanes_in_flight_timed_region=int(os.environ.get("LF_LANES", "8")) if params.threads >= 4 else params.threads)
+        if dom.startswith("lf_edlib_rsweep"):
+            # the forward kernel is integer-ALU work, not HBM work: one Myers block step (64 DP cells) is ~55 32-bit lane
             # operations; the chip issues 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s
             lane_ops = excl["dp_block_steps"] * 55.0
             roofline["alu"] = dict(bound="int32 VALU", achieved=lane_ops / (dms * 1e-3) / 1e12, peak=78.6, unit="T lane-ops/s",
-                                   frac=lane_ops / (dms * 1e-3) / 1e12 / 78.6, dp_block_steps_per_step=excl["dp_block_steps"],
-                                   note="forward pass only (algorithmic work); the traceback replays ~ (m / 8 + n / 64) single-block tiles per problem on top of it")
+                                   frac=lane_ops / (dms * 1e-3) / 1e12 / 78.6, dp_block_steps_per_step=excl["dp_block_steps"])
         shard_desc = (f"the SAME {n_total}-read set cut by bases over {world} ranks" if strong else f"{args.reads} reads per GPU")
+        io_host = "reads in host memory -> SAM records in host memory (lf_map_batch_into_lens): H2D and D2H inside the step"
+        io_hbm = "read bases resident in HBM when the timed region starts, SAM records left in HBM (lf_map_batch_dev)"
+        with_x = bool(exchange and xinfo and xinfo.get("status") == "ok")
         out = {
             "metric": "aligned reads/s", "value": value, "unit": "reads/s", "n_gpus": world * n_dev, "steps": K, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {shard_desc}, synthetic {'ONT' if args.config == 'c5' else 'PacBio'} reads (~{args.read_len} bp, {args.err:.0%} err) vs "
+            "config": {"workload": f"{args.config}: {shard_desc}, synthetic {'ONT' if args.config == 'c5' else 'PacBio'} reads (~{args.read_len} bp, {args.err:.0%} err"
+                                   + (f", {args.dup_frac:.0%} of them from 2-4-copy segmental duplications at 1-3 % divergence" if args.dup_frac > 0 else "") + f") vs "
                                    f"{args.genome_mbp:g} Mbp synthetic genome ({args.repeat_profile} repeats), -k {kk} -c {cc} --chainAlg {args.chain_alg}" + (f" -n {args.max_map}" if args.max_map != 10 else ""),
-                       "reads_total": n_total, "mean_read_len": bases / max(1, n_total), "genome_mbp": args.genome_mbp,
+                       "reads_total": n_total, "reads_mapped_in_timed_region": n_total * K, "mean_read_len": bases / max(1, n_total), "genome_mbp": args.genome_mbp,
                        "io": ("host buffers (lf_map_batch_multi): one process, every device copies through its own PCIe link" if args.mode == "inproc" else
-                              "read bases resident in HBM when the timed region starts, SAM records left in HBM (lf_map_batch_dev)"),
+                              "rank 0 owns the job's reads in its HBM and ends with the job's SAM records there; scatter / gather over RCCL inside the step" if with_x else
+                              io_host if primary_is_host else io_hbm),
                        "parallelism": (f"one process drives {n_dev} devices (lf_map_batch_multi), index replicated" if args.mode == "inproc" else
                                        f"rank 0 owns the {n_total}-read job in HBM: RCCL point-to-point scatter of the packed reads + gather of the SAM "
-                                       f"records, pipelined with the mapping, inside the timed region; {world} GPUs, index replicated" if (exchange and xinfo and xinfo.get("status") == "ok") else
+                                       f"records, pipelined with the mapping, inside the timed region; {world} GPUs, index replicated" if with_x else
                                        f"reads sharded over {world} GPU(s), index replicated, no data-path collective"),
-                       "index": "FM-index + full SA resident in HBM"},
+                       "index": index_desc},
             "gbp_per_s": bases * K / elapsed / 1e9, "host_cpu_seconds_per_step": cpu_s / K, "hbm_used_gb": hbm_used_gb,
             "host_ms_per_step": {k: agg[k] / K for k in ("ms_total", "ms_python_call", "ms_seed", "ms_vote", "ms_chain", "ms_extend", "ms_render", "ms_sam")},
             "per_read": {"seeds": agg["n_seeds"] / per_rank, "edlib_problems": agg["n_edlib_problems"] / per_rank,
@@ -529,14 +634,32 @@ def main():
             "roofline": roofline,
             "source_tree": tree_hash(),      # digest of lordfast_amd/csrc: which kernels produced this line
         }
-        out["value_without_exchange"] = n_total * K / elapsed_nx
-        out["ms_per_step_without_exchange"] = elapsed_nx / K * 1e3
+        # every region that was timed, under its own name
+        out["value_hbm_resident"] = n_total * K / elapsed_nx               # no exchange, shards resident in HBM, SAM left in HBM
+        out["ms_per_step_hbm_resident"] = elapsed_nx / K * 1e3
+        out["host_cpu_seconds_per_step_hbm_resident"] = cpu_s_hbm / K
         if elapsed_host is not None:
-            out["value_pcie_inclusive"] = n_total * K / elapsed_host      # reads in host memory -> SAM text in host memory, no exchange
-            out["ms_per_step_pcie_inclusive"] = elapsed_host / K * 1e3
+            out["value_host_boundary"] = n_total * K / elapsed_host       # every rank: its reads in host memory -> its SAM records in host memory
+            out["ms_per_step_host_boundary"] = elapsed_host / K * 1e3
+            out["host_cpu_seconds_per_step_host_boundary"] = cpu_s_host / K
+            out["host_boundary_bytes_per_step"] = {"h2d_bases": bases, "d2h_sam_text": int(len(sam_host)) if sam_host is not None else None,
+                                                   "sam_egress": "SEQ / QUAL columns filled on the host (lf_sam.hip HOLES mode)" if not os.environ.get("LF_SAM_FULL") else "whole lines from the device"}
+        if elapsed_weak is not None:
+            out["value_weak_hbm_resident"] = args.reads * world * K / elapsed_weak
+            out["ms_per_step_weak_hbm_resident"] = elapsed_weak / K * 1e3
         if xinfo:
             out["exchange"] = xinfo
-        if not args.no_cpu_baseline and world == 1 and sam is not None:
+        if args.dup_frac > 0:
+            ndup = sum(1 for nm in names if nm.endswith(b"_dup"))
+            out["per_read"]["dup_reads_fraction"] = ndup / max(1, len(names))
+            if dup_probe is not None:
+                out["per_read"]["chain_requests_on_dup_reads"] = dup_probe
+        # ---- parity: the records of the TIMED steps ----
+        if snap_host is not None or snap_hbm is not None or snap_excl is not None:
+            snaps = {k: v for k, v in (("host_boundary_timed_steps", snap_host), ("hbm_resident_timed_steps", snap_hbm), ("exclusive_pass", snap_excl)) if v is not None}
+            out["sam_digests"] = {k: {"xxh3_128": v[0], "bytes": v[1]} for k, v in snaps.items()}
+            out["timed_output_equals_exclusive_pass_output"] = len({v for v in snaps.values()}) == 1 if len(snaps) > 1 else None
+        if not args.no_cpu_baseline and world == 1 and (head_host is not None or sam is not None):
             try:
                 cb = cpu_baseline(args, fa, names, seqs)
             except Exception as e:                                          # noqa: BLE001
@@ -545,11 +668,15 @@ def main():
             if cb:
                 base, ref_sam, n = cb
                 out["cpu_baseline"] = base
+                # same boundary on both sides: host memory -> host memory
                 out["speedup_vs_cpu_baseline"] = value / base["value"]          # vs `cpus_granted` host CPUs (not an optimisation target)
+                out["speedup_vs_cpu_baseline_hbm_resident"] = out["value_hbm_resident"] / base["value"]
                 # bit-match against the reference on the sampled reads: the sample is a prefix of the batch and records are in
-                # read order, so the head of our SAM holds the same reads.  Primary records (the BASELINE metric) and ALL
-                # records of a read (secondaries, supplementaries: same lines, same order) are compared.
-                head = sam.head(6 * len(ref_sam) + (1 << 20))
+                # read order, so the head of our SAM holds the same reads.  `head_host` was copied out of the timed steps' output
+                # before any other pass ran.  Primary records (the BASELINE metric) and ALL records of a read (secondaries,
+                # supplementaries: same lines, same order) are compared.
+                head = head_host if head_host is not None else sam.head(6 * len(ref_sam) + (1 << 20))
+                out["records_compared_come_from"] = "the timed host-boundary steps (snapshot taken before the exclusive pass)" if head_host is not None else "the last pass"
                 def by_read(txt):
                     d = {}
                     for l in txt.split(b"\n"):
@@ -570,12 +697,21 @@ def main():
                 out["primary_record_match_rate"] = hit / max(1, tot)
                 out["all_records_match_rate"] = hit_all / max(1, tot)
                 out["reads_compared"] = tot
+                out["reads_in_reference_sample"] = len(want)
                 out["records_compared"] = sum(len(v) for k, v in want.items() if k in mine)
         if sam is not None and os.environ.get("LF_BENCH_SAM_DIGEST"):
             # test hook: a digest of the job's gathered records (compared with the 1-rank run of the same read set)
             out["sam_md5"] = hashlib.md5(sam.head(len(sam))).hexdigest()
             out["sam_bytes"] = len(sam)
         print(json.dumps(out), flush=True)
+
+    # chain requests per read on the duplicated fraction alone (one untimed call on a sample of them): fine mode must really happen
+    dup_probe = None
+    if args.dup_frac > 0 and rank == 0:
+        di = [i for i, nm in enumerate(names) if nm.endswith(b"_dup")][:2000]
+        if di:
+            _, dst = lf.map_batch([names[i] for i in di], [seqs[i] for i in di], params=params, copy=False)
+            dup_probe = dst["n_chain_problems"] / len(di)
 
     # ---- 3. N > 1: the pipelined exchange, inside the timed region ----
     if exchange:
@@ -607,8 +743,8 @@ def main():
                 if rank == 0:
                     log(f"exchange phase still running after {args.exchange_timeout:.0f}s: reporting the no-exchange rate")
                     state["timeout"] = True
-                    report(elapsed_nx, None, dict(status="timeout"))
-                os._exit(3 if rank else 0)
+                    report(elapsed_nx, None, dict(status="timeout"))       # the line says status "timeout" and carries the no-exchange rate ...
+                os._exit(3)                                                   # ... and the process fails: a hung exchange is not a successful N-GPU run
         timer = threading.Timer(args.exchange_timeout, watchdog)
         timer.daemon = True
         timer.start()
@@ -641,31 +777,27 @@ def main():
         dist.destroy_process_group()
 
 
-def load_traffic(args, world, dom, launches):
-    """HBM bytes per launch of the dominant kernel group from the committed counter passes -- only if they were taken on THIS
-    source tree (profiles/<dir>/pmc_fetch_write_summary.json carries the git commit of the tree it profiled; collect.sh
-    writes it) and on this configuration; otherwise null: a stale file says nothing about the kernels that just ran."""
+def load_pmc(args, world):
+    """the committed FETCH_SIZE / WRITE_SIZE counter passes (per kernel, one step) -- only if they were taken on THIS source tree
+    (profiles/<dir>/pmc_fetch_write_summary.json carries the digest of the tree it profiled; collect.sh writes it) and on this
+    configuration; otherwise None: a stale file says nothing about the kernels that just ran."""
     import subprocess
-    if not (args.genome_mbp == 3100 and args.reads == 100000 and world == 1 and args.config == "c2" and args.repeat_profile == "default"):
+    if not (args.genome_mbp == 3100 and args.reads == 100000 and world == 1 and args.config == "c2" and args.repeat_profile == "default" and args.dup_frac == 0):
         return None, "not the profiled configuration"
     try:
         head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
     except Exception:                                                    # noqa: BLE001
         head = ""
     import glob
+    src_hash = tree_hash()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c2", "pmc_fetch_write_summary.json")), reverse=True):
         try:
             pmc = json.load(open(path))
         except Exception:                                                # noqa: BLE001
             continue
         commit = pmc.get("_meta", {}).get("source_tree") or pmc.get("_meta", {}).get("git_commit")
-        src_hash = tree_hash()
-        if not commit or commit not in (head, src_hash):
-            continue
-        prefix = dom.split(" ")[0].rstrip("*")
-        fam = [v for k, v in pmc.items() if k.startswith(prefix) and isinstance(v, dict)]
-        if fam:      # the counter passes profile exactly ONE step (--no-exclusive --steps 1 --warmup 0): bytes per step / launches per step
-            return sum(v.get("fetch_kb", 0.0) + v.get("write_kb", 0.0) for v in fam) * 1024.0 / max(1.0, launches), os.path.relpath(path, ROOT)
+        if commit and commit in (head, src_hash):
+            return pmc, os.path.relpath(path, ROOT)
     return None, "no counter pass of this source tree under profiles/ (profiles/tools/collect.sh writes one)"
 
 

@@ -90,6 +90,9 @@ int  lf_index_build(const char *fasta_path, int device);
 uint32_t lf_index_genome_len(const lf_index_t *idx);          /* bwt_get_refGenLen, src/BWT.cpp:305 */
 int  lf_index_n_contigs(const lf_index_t *idx);
 const char *lf_index_contig(const lf_index_t *idx, int i, int64_t *offset, int32_t *len);
+/* one line naming the index structures that are resident in HBM and their sizes (full SA; which of the 12- / 14- / 16-mer
+ * tables were built -- the wide ones are dropped when HBM is short, which changes speed, never results) */
+int  lf_index_describe(const lf_index_t *idx, char *buf, size_t cap);
 
 /* ------------------------------------------------------------------------------------------------
  * Stage 1: seeding -- getLocs_extend_whole_step for a batch of reads (src/BWT.cpp:312-394)
@@ -169,6 +172,9 @@ typedef struct {
     uint64_t n_req_seeds, n_tie_requests;              /* seeds gathered into chain requests; requests whose equal qPos needed the std::sort replay */
     uint64_t dp_block_steps;                            /* sum over alignment problems of ceil(q / 64) * t: Myers block steps of one forward pass */
     uint64_t ksw_bytes;                                 /* sum over ksw problems of qlen + tlen + 12: the two sequences read once, three results written */
+    /* the alignment group's kernels one by one (HIP events): lf_edlib_rsweep_kernel (both modes), lf_edlib_tb_kernel, the
+     * Hirschberg levels (incl. their readbacks), request binning */
+    float ms_k_rsweep, ms_k_tb, ms_k_hirsch, ms_k_bin;
 } lf_stats_t;
 
 int  lf_map_batch(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,

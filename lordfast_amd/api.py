@@ -54,7 +54,8 @@ class Stats(C.Structure):
                [("ms_render", C.c_double), ("ms_k_render", C.c_float), ("ms_k_vote", C.c_float),
                 ("render_bytes", C.c_uint64), ("render_launches", C.c_uint64),
                 ("ops_bytes", C.c_uint64), ("n_req_seeds", C.c_uint64), ("n_tie_requests", C.c_uint64), ("dp_block_steps", C.c_uint64),
-                ("ksw_bytes", C.c_uint64)]
+                ("ksw_bytes", C.c_uint64)] + \
+               [(n, C.c_float) for n in ("ms_k_rsweep", "ms_k_tb", "ms_k_hirsch", "ms_k_bin")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -268,6 +269,12 @@ class LordFast:
         if self.h:
             self.L.lf_index_free(self.h)
             self.h = None
+
+    def describe(self) -> str:
+        buf = C.create_string_buffer(1024)
+        self.L.lf_index_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        _check(self.L.lf_index_describe(self.h, buf, 1024), "lf_index_describe")
+        return buf.value.decode()
 
     def genome_len(self) -> int:
         return self.L.lf_index_genome_len(self.h)

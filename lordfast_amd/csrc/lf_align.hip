@@ -599,6 +599,12 @@ __global__ void lf_desc_build_kernel(const uint32_t *__restrict__ keys, const ui
     probs[j] = p;
 }
 
+/* HIP-event brackets of the last alignment batch of the calling thread: forward sweeps (lf_edlib_rsweep_kernel, both modes),
+ * traceback (lf_edlib_tb_kernel), Hirschberg levels (incl. their per-level readbacks), binning (keys, sort, segments, scan, build).
+ * Alone on the GPU only when the classes run on one stream (LF_SERIAL_CLASSES: bench.py's exclusive pass). */
+static thread_local float t_breakdown[4];
+extern "C" void lfg_edlib_breakdown(float *out4) { for (int k = 0; k < 4; k++) out4[k] = t_breakdown[k]; }
+
 /* dev_desc / dev_opsoff != nullptr: the descriptors are already on the device (lfg_walk_plan) and the results stay there
  * (res_dev[0..2] = ed, end column, path length arrays) */
 static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *ed, int32_t *endloc, uint8_t *ops, uint32_t *ops_len,
@@ -606,11 +612,13 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
                               const lf_aln_desc_t *dev_desc = nullptr, const uint64_t *dev_opsoff = nullptr, void **res_dev = nullptr)
 {
     if (ms) *ms = 0;
+    for (int k = 0; k < 4; k++) t_breakdown[k] = 0;
     if (n == 0) return LF_OK;
     HIPCHK(hipSetDevice(device));
     hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
     if (!s) return LF_ERR_HIP;
     const bool serial_classes = getenv("LF_SERIAL_CLASSES") != nullptr;     /* profiling aid: one class at a time (read per call: bench.py switches it) */
+    hipEvent_t bd[5]; for (int k = 0; k < 5; k++) { bd[k] = (hipEvent_t)lfg_lane_event(device, 4 + k); if (!bd[k]) return LF_ERR_HIP; }
     hipStream_t cs[LF_NCLASS];
     for (int k = 0; k < LF_NCLASS; k++) { cs[k] = serial_classes ? s : (hipStream_t)lfg_lane_stream(device, 2 + k); if (!cs[k]) return LF_ERR_HIP; }
     hipEvent_t cdone[LF_NCLASS], e0 = (hipEvent_t)lfg_lane_event(device, 12), e1 = (hipEvent_t)lfg_lane_event(device, 13), eb = (hipEvent_t)lfg_lane_event(device, 14);
@@ -702,6 +710,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         if (n_roots != HC.roots) { lf_set_error("edlib Hirschberg levels: %u roots found, %llu announced", n_roots, (unsigned long long)HC.roots); return LF_ERR_ARG; }
     }
     const int N = n + (int)n_h;
+    HIPCHK(hipEventRecord(bd[0], s));                      /* Hirschberg levels: e0 .. bd[0]; binning: bd[0] .. eb */
 
     const unsigned gb = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(lf_desc_keys_kernel, dim3(gb), dim3(256), 0, s, d_desc, d_opsoff, n, d_hdesc, (int)n_h, d_keys, d_vals, d_ops, d_ed, d_end, d_len);
@@ -735,9 +744,12 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         lf_rsw_args RA;
         RA.probs = d_probs; RA.waves = d_waves; RA.qlo = D->d_planes; RA.qhi = D->d_planes + D->q_words; RA.qvalid = D->d_planes + 2 * D->q_words; RA.q_words = D->q_words;
         RA.pac = D->d_pac; RA.pac_syms = D->pac_syms; RA.ckpt = d_hist; RA.out_ed = d_ed; RA.out_end = d_end;
+        HIPCHK(hipEventRecord(bd[1], cs[1]));
         RA.wave0 = 0; RA.n_waves = nw_nw; lf_rsweep_launch(cs[1], false, RA);
         RA.wave0 = nw_nw; RA.n_waves = nw_shw; lf_rsweep_launch(cs[1], true, RA);
+        HIPCHK(hipEventRecord(bd[2], cs[1]));
         hipLaunchKernelGGL(lf_edlib_tb_kernel, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, D->pac_syms, d_hist, d_ops, d_end, d_len);
+        HIPCHK(hipEventRecord(bd[3], cs[1]));
     }
     for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && cs[k] != s) { HIPCHK(hipEventRecord(cdone[k], cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
     if (n_roots) lf_hirsch_launch_stitch(s, HA, n_roots);      /* the roots' pieces move together once their leaves have paths */
@@ -751,6 +763,8 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));
+    if (cnt(1) > 0) { HIPCHK(hipEventElapsedTime(&t_breakdown[0], bd[1], bd[2])); HIPCHK(hipEventElapsedTime(&t_breakdown[1], bd[2], bd[3])); }
+    HIPCHK(hipEventElapsedTime(&t_breakdown[2], e0, bd[0])); HIPCHK(hipEventElapsedTime(&t_breakdown[3], bd[0], eb));
     /* (a device-planned round reports a missing Hirschberg split through lf_walk_emit_kernel: ed == -2 makes the job rare) */
     if (ed && n_roots) for (int i = 0; i < n; i++) if (ed[i] == -2) { lf_set_error("edlib kernel: no Hirschberg split row for descriptor %d (n %u, m %u)", i, D->d ? D->d[i].n : 0, D->d ? D->d[i].m : 0); return LF_ERR_HIP; }
     return LF_OK;

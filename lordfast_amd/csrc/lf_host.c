@@ -172,6 +172,11 @@ void lf_index_free(lf_index_t *ix)
 
 uint32_t lf_index_genome_len(const lf_index_t *ix) { return (uint32_t)ix->l_pac; }
 int lf_index_n_contigs(const lf_index_t *ix) { return ix->n_seqs; }
+int lf_index_describe(const lf_index_t *ix, char *buf, size_t cap)
+{
+    if (!ix || !buf || cap < 2) { lf_set_error("lf_index_describe: bad argument"); return LF_ERR_ARG; }
+    return lfg_index_describe(ix, buf, cap);
+}
 const char *lf_index_contig(const lf_index_t *ix, int i, int64_t *offset, int32_t *len)
 {
     if (i < 0 || i >= ix->n_seqs) return NULL;

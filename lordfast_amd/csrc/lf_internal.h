@@ -32,6 +32,7 @@ void lf_set_error(const char *fmt, ...);
 int  lfg_device_count(void);
 int  lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const uint64_t *sa_sampled);
 void lfg_index_free(struct lf_index *ix);
+int  lfg_index_describe(const struct lf_index *ix, char *buf, size_t cap);
 
 typedef struct {        /* raw device results of the seed stage, copied to host */
     uint64_t n_hits;
@@ -142,6 +143,7 @@ typedef struct {
 } lfg_walk_t;
 int lfg_walk_plan(const struct lf_index *ix, int n_jobs, const lf_wjob_t *jobs, const lfg_vc_t *vc, int lazy, lfg_walk_t *W);
 int lfg_walk_emit(const struct lf_index *ix, const lfg_vc_t *vc, int lazy, lfg_walk_t *W, const void *d_ed, const void *d_end, const void *d_len, lf_wrec_t **wrec_out);
+void lfg_edlib_breakdown(float *out4);      /* event brackets of the calling thread's last alignment batch: forward, traceback, Hirschberg levels, binning */
 /* alignments of device-resident descriptors (lfg_walk_plan); results stay on the device */
 int lfg_edlib_desc_dev(const struct lf_index *ix, int n, const void *d_desc, const void *d_opsoff, uint64_t ops_total, const lf_hcount_t *hc, int ops_slot,
                        void **ops_dev, void **ed_dev, void **end_dev, void **len_dev, float *ms);
@@ -160,7 +162,8 @@ typedef struct {
 int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, int n_lines, const lf_samline_t *lines,
                   const char *names, uint64_t names_bytes, const char *blob, uint64_t blob_bytes,
                   const char *quals, uint64_t quals_bytes, const void *d_quals_src, int n_batch_reads,
-                  const lfg_rtext_t *rt, int parity, uint64_t *total_out);
+                  const lfg_rtext_t *rt, int parity, int holes, uint64_t *total_out, const uint64_t **h_offs_out, const uint32_t **h_hole_out);
+int lfg_host_mapped(int device, const void *p, size_t bytes);      /* kernels of `device` can store into [p, p + bytes) (pinned host memory) */
 int lfg_sam_fetch(const struct lf_index *ix, char *dst, uint64_t total, int parity);
 int lfg_sam_wait(const struct lf_index *ix);
 int lfg_sam_fetch_async(const struct lf_index *ix, char *dst, uint64_t total, int parity);

@@ -170,6 +170,7 @@ extern "C" void lf_device_free(int device, void *p)
 extern "C" int lf_device_copy(int device, void *dst, const void *src, size_t bytes)
 {
     HIPCHK(hipSetDevice(device));
+    lfg_quiesce(device);              /* a synchronous copy waits for the device by itself: per-stream waits first (see lfg_quiesce) */
     if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
     return LF_OK;
 }

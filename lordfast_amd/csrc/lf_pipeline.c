@@ -265,7 +265,10 @@ typedef struct ctx {
     int *seed_map; char *cat; uint64_t *cat_off;
     const unsigned char *d_seqs, *d_quals;      /* lf_map_batch_dev: the caller's device blobs (NULL: host strings) */
     int32_t **stage_sink; int stage_i0;          /* lf_map_stages_batch: per read (batch index stage_i0 + ri) its decision, windows and alignWin results */
+    /* HOLES mode (lf_sam.hip): the SEQ / QUAL column of every line is filled on the host from the caller's strings */
+    int holes; struct fill *fill; int n_fill;
 } ctx_t;
+typedef struct fill { uint64_t pos; const char *seq, *qual; uint32_t len; uint8_t rev, fq; } fill_t;
 
 /* ---------------------------------------------------------------- parallel for on a persistent thread pool
  * Up to eight chunks ("lanes") are in flight at once so that the host phases of one overlap the GPU phases of the others.
@@ -1422,13 +1425,15 @@ static void print_sam_entry(ctx_t *cx, rd_t *r, int num)
 
 /* ---- the same decisions as print_sam_entry, as 48-byte line descriptors for lf_sam.hip (which writes the text) ---- */
 typedef struct {
-    lf_samline_t *ln; int n, cap;
+    lf_samline_t *ln; int *rd; int n, cap;  /* rd: the read (index in the chunk) a line belongs to */
     char *blob; uint64_t nb, capb;          /* SA:Z values and literal lines */
     char *names; uint64_t nn, capn;
+    int cur_rd;
 } linevec_t;
 static lf_samline_t *lv_line(linevec_t *v)
 {
-    if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 8192; v->ln = (lf_samline_t *)realloc(v->ln, (size_t)v->cap * sizeof(lf_samline_t)); }
+    if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 8192; v->ln = (lf_samline_t *)realloc(v->ln, (size_t)v->cap * sizeof(lf_samline_t)); v->rd = (int *)realloc(v->rd, (size_t)v->cap * sizeof(int)); }
+    v->rd[v->n] = v->cur_rd;
     lf_samline_t *l = &v->ln[v->n++]; memset(l, 0, sizeof *l);
     return l;
 }
@@ -1832,6 +1837,7 @@ extend:
                 cx->ed_rounds[cx->n_ed_rounds++] = R;
             }
             st->ms_k_edlib += ms; st->n_edlib_problems += W.n_desc; st->edlib_launches += 1; st->ops_bytes += W.ops_total;
+            if (W.n_desc) { float bd[4]; lfg_edlib_breakdown(bd); st->ms_k_rsweep += bd[0]; st->ms_k_tb += bd[1]; st->ms_k_hirsch += bd[2]; st->ms_k_bin += bd[3]; }
             st->ext_bytes += W.ext_bytes; st->dp_block_steps += W.block_steps;
             int n_rare = 0;
             for (k = 0; k < nj; k++) {
@@ -1898,6 +1904,7 @@ extend:
             cx->ed_rounds[cx->n_ed_rounds++] = R;
             if (rc != LF_OK) return rc;
             st->ms_k_edlib += ms; st->n_edlib_problems += (uint64_t)nd; st->edlib_launches += 1; st->ops_bytes += ops_total;
+            { float bd[4]; lfg_edlib_breakdown(bd); st->ms_k_rsweep += bd[0]; st->ms_k_tb += bd[1]; st->ms_k_hirsch += bd[2]; st->ms_k_bin += bd[3]; }
         }
         if (nk) {
             uint64_t qn = 0, tn = 0;
@@ -1987,6 +1994,7 @@ extend:
         int any_fq = 0;
         for (int i = 0; i < n; i++) {
             rd_t *r = &cx->reads[i];
+            V.cur_rd = i;
             const size_t nl = strlen(r->name);
             if (V.nn + nl + 1 > V.capn) { V.capn = (V.nn + nl + 1) * 2 + 65536; V.names = (char *)realloc(V.names, V.capn); }
             memcpy(V.names + V.nn, r->name, nl);
@@ -2020,19 +2028,33 @@ extend:
             }
             lines_sam_entry(cx, &V, r, name_off, num, ar);
         }
-        if (V.nb >= 0xffffffffull || V.nn >= 0xffffffffull) { free(V.ln); free(V.blob); free(V.names); lf_set_error("lf_map_batch: chunk too large for the SAM writer"); return LF_ERR_ARG; }
+        if (V.nb >= 0xffffffffull || V.nn >= 0xffffffffull) { free(V.ln); free(V.rd); free(V.blob); free(V.names); lf_set_error("lf_map_batch: chunk too large for the SAM writer"); return LF_ERR_ARG; }
         char *qcat = NULL; uint64_t qbytes = 0; int n_batch = 0;
         for (int i = 0; i < n; i++) if ((int)cx->reads[i].len >= cx->p->min_read_len) n_batch++;
         if (any_fq && cx->d_quals) { for (int i = 0; i < n; i++) if ((int)cx->reads[i].len >= cx->p->min_read_len) qbytes += cx->reads[i].len; }
+        else if (any_fq && cx->holes) qcat = (char *)"";      /* the host prints the qualities itself: the device only has to know that there are some */
         else if (any_fq) {                            /* FASTQ: the qualities in the layout of the resident read batch */
             for (int i = 0; i < n; i++) if ((int)cx->reads[i].len >= cx->p->min_read_len) qbytes += cx->reads[i].len;
             qcat = (char *)malloc(qbytes + 1);
             uint64_t o = 0;
             for (int i = 0; i < n; i++) { const rd_t *r = &cx->reads[i]; if ((int)r->len < cx->p->min_read_len) continue; if (r->isFq) memcpy(qcat + o, r->qual, r->len); else memset(qcat + o, '*', r->len); o += r->len; }
         }
+        const uint64_t *h_offs = NULL; const uint32_t *h_hole = NULL;
         rc = lfg_sam_build(cx->ix, cx->p, V.n, V.ln, V.names, V.nn, V.blob, V.nb, qcat, qbytes, (any_fq && cx->d_quals) ? cx->d_quals : NULL, n_batch,
-                           &cx->rtext_dev, cx->sam_parity, &cx->sam_total);
-        free(V.ln); free(V.blob); free(V.names); free(qcat);
+                           &cx->rtext_dev, cx->sam_parity, cx->holes, &cx->sam_total, &h_offs, &h_hole);
+        cx->fill = NULL; cx->n_fill = 0;
+        if (rc == LF_OK && cx->holes && V.n > 0) {
+            /* where the host puts SEQ (/ QUAL): one entry per line that has a hole */
+            cx->fill = (fill_t *)malloc(((size_t)V.n + 1) * sizeof(fill_t));
+            for (int k = 0; k < V.n; k++) {
+                if (!h_hole[2 * (size_t)k + 1]) continue;
+                const rd_t *r = &cx->reads[V.rd[k]];
+                fill_t *f = &cx->fill[cx->n_fill++];
+                f->pos = h_offs[k] + h_hole[2 * (size_t)k]; f->seq = r->seq; f->qual = r->qual; f->len = r->len;
+                f->rev = (uint8_t)(V.ln[k].kind == LF_SL_MAPPED && (V.ln[k].flag & 16)); f->fq = (uint8_t)(h_hole[2 * (size_t)k + 1] > r->len);
+            }
+        }
+        free(V.ln); free(V.rd); free(V.blob); free(V.names); if (!(any_fq && cx->holes)) free(qcat);
         if (rc != LF_OK) return rc;
     } else parallel_for(cx, n, phase_sam_print);
     t1 = now_ms(); st->ms_sam += t1 - t0; tstage[5] = t1 - t0;
@@ -2082,6 +2104,7 @@ typedef struct {
     pthread_mutex_t mu; pthread_cond_t cv;      /* chunk sizes become known in any order */
     pthread_rwlock_t grow;                      /* writers of SAM text hold it shared; growing the buffer exclusive */
     int host_cigar, host_vote; str_t all; int fixed_out;                   /* fixed_out: caller-provided buffer, never reallocated */
+    int holes;                                  /* the output buffer is pinned host memory and the reads are host strings: SEQ-less egress (lf_sam.hip) */
     volatile int rc; char err[1024];
     lf_stats_t st[LF_MAX_LANES];
 } batch_t;
@@ -2097,6 +2120,7 @@ static void merge_stats(lf_stats_t *d, const lf_stats_t *a)
     d->search_launches += a->search_launches; d->locate_launches += a->locate_launches;
     d->dp_block_steps += a->dp_block_steps; d->ms_render += a->ms_render; d->ms_k_render += a->ms_k_render; d->ms_k_vote += a->ms_k_vote; d->ops_bytes += a->ops_bytes; d->n_req_seeds += a->n_req_seeds; d->n_tie_requests += a->n_tie_requests; d->render_bytes += a->render_bytes; d->render_launches += a->render_launches;
     d->ksw_bytes += a->ksw_bytes;
+    d->ms_k_rsweep += a->ms_k_rsweep; d->ms_k_tb += a->ms_k_tb; d->ms_k_hirsch += a->ms_k_hirsch; d->ms_k_bin += a->ms_k_bin;
 }
 
 /* base offset of a chunk's text = the sizes of all chunks of earlier reads.  block == 0: returns 0 when one of them has not
@@ -2137,10 +2161,24 @@ static void out_reserve(batch_t *B, uint64_t base, uint64_t tot)
 }
 /* a chunk whose SAM text is complete in one of the lane's two device buffers but whose place in the output is not known
  * yet (an earlier chunk is still being mapped by another lane): the lane maps its next chunk first */
-typedef struct { const chunk_t *C; const lf_index_t *ix; uint64_t tot; int parity, active; } pending_t;
-static void fetch_dev_sam(batch_t *B, const lf_index_t *ix, uint64_t base, uint64_t tot, int parity, lf_stats_t *st)
+typedef struct { const chunk_t *C; const lf_index_t *ix; uint64_t tot; int parity, active; fill_t *fill; int n_fill; } pending_t;
+/* HOLES mode: SEQ (/ QUAL) of line k goes to out_base + fill[k].pos -- the strings printSamEntry prints (src/LordFAST.cpp:377-402):
+ * the read as given, or its reverse complement / reversed qualities for a record on the reverse strand (:501-502) */
+static void phase_fill(ctx_t *cx, int tid, int k)
 {
-    if (B->rc != LF_OK) return;
+    (void)tid;
+    const fill_t *f = &cx->fill[k];
+    char *d = cx->out_base + f->pos;
+    if (!f->rev) memcpy(d, f->seq, f->len); else rc_copy(d, f->seq, f->len);
+    if (f->fq) {
+        d[f->len] = '\t';
+        char *q = d + f->len + 1;
+        if (!f->rev) memcpy(q, f->qual, f->len); else for (uint32_t i = 0; i < f->len; i++) q[i] = f->qual[f->len - 1 - i];
+    }
+}
+static void fetch_dev_sam(batch_t *B, const lf_index_t *ix, uint64_t base, uint64_t tot, int parity, lf_stats_t *st, fill_t *fill, int n_fill, int lane)
+{
+    if (B->rc != LF_OK) { free(fill); return; }
     const double t0 = now_ms();
     out_reserve(B, base, tot);
     if (B->rc == LF_OK) {               /* one D2H copy of the chunk's text straight into its place */
@@ -2148,8 +2186,14 @@ static void fetch_dev_sam(batch_t *B, const lf_index_t *ix, uint64_t base, uint6
          * a growable one may be reallocated by another lane, so the copy completes under the read lock */
         const int frc = B->fixed_out ? lfg_sam_fetch_async(ix, B->all.s + base, tot, parity) : lfg_sam_fetch(ix, B->all.s + base, tot, parity);
         if (frc != LF_OK) { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = frc; }
+        else if (n_fill > 0) {          /* the holes, while the scatter kernel moves the rest over the link */
+            ctx_t fx; memset(&fx, 0, sizeof fx);
+            fx.lane = lane; fx.n_threads = B->slots; fx.fill = fill; fx.n_fill = n_fill; fx.out_base = B->all.s + base;
+            parallel_for(&fx, n_fill, phase_fill);
+        }
     }
     pthread_rwlock_unlock(&B->grow);
+    free(fill);
     st->ms_sam += now_ms() - t0;
 }
 
@@ -2187,6 +2231,7 @@ static void *lane_main(void *arg_)
         cx.ix = B->ixs[lane % B->n_ix]; cx.p = B->p; cx.n_threads = B->slots; cx.st = st; cx.lane = lane; cx.arena = g_arena[lane]; cx.host_cigar = B->host_cigar; cx.host_vote = B->host_vote; cx.lazy = 0;      /* the traceback kernel classifies diagonal moves itself (from registers); LF_F_LAZYX stays for the kernels' stage users */
         cx.max_chunk_hits = max_hits;
         cx.dev_sam = !B->host_cigar && !B->host_vote && !(g_crosscheck & LF_XC_HOST_SAM);
+        cx.holes = B->holes && cx.dev_sam;
         cx.sam_parity = parity;
         cx.d_seqs = B->d_seqs; cx.d_quals = B->d_quals; cx.stage_sink = B->stage_sink; cx.stage_i0 = C->i0;
         cx.n_reads = C->i1 - C->i0;
@@ -2241,15 +2286,16 @@ static void *lane_main(void *arg_)
              * published its size; lanes finish out of order, so instead of waiting here the lane keeps ONE chunk pending and
              * maps the next one (into the other buffer).  The older pending chunk must leave its buffer first. */
             uint64_t base;
-            if (pend.active) { (void)chunk_base(B, pend.C, 1, &base); fetch_dev_sam(B, pend.ix, base, pend.tot, pend.parity, st); pend.active = 0; }
+            if (pend.active) { (void)chunk_base(B, pend.C, 1, &base); fetch_dev_sam(B, pend.ix, base, pend.tot, pend.parity, st, pend.fill, pend.n_fill, lane); pend.active = 0; }
             if (rc == LF_OK) {
-                if (chunk_base(B, C, 0, &base)) fetch_dev_sam(B, cx.ix, base, tot, parity, st);
+                if (chunk_base(B, C, 0, &base)) fetch_dev_sam(B, cx.ix, base, tot, parity, st, cx.fill, cx.n_fill, lane);
                 else {
-                    pend.C = C; pend.ix = cx.ix; pend.tot = tot; pend.parity = parity; pend.active = 1;
+                    pend.C = C; pend.ix = cx.ix; pend.tot = tot; pend.parity = parity; pend.active = 1; pend.fill = cx.fill; pend.n_fill = cx.n_fill;
                     /* the writer kernel still reads this chunk's buffers: the next chunk's first stream waits for it (lfg_sam_build) */
                 }
+                cx.fill = NULL; cx.n_fill = 0;
                 parity ^= 1;
-            }
+            } else { free(cx.fill); cx.fill = NULL; }
         } else {
             uint64_t base;
             (void)chunk_base(B, C, 1, &base);
@@ -2270,7 +2316,7 @@ static void *lane_main(void *arg_)
         free(cx.reads);
         if (timing) fprintf(stderr, "[lf] lane %d chunk %d: chunk_free %.1f ms\n", lane, k, now_ms() - tch);
     }
-    if (pend.active) { uint64_t base; (void)chunk_base(B, pend.C, 1, &base); fetch_dev_sam(B, pend.ix, base, pend.tot, pend.parity, st); }
+    if (pend.active) { uint64_t base; (void)chunk_base(B, pend.C, 1, &base); fetch_dev_sam(B, pend.ix, base, pend.tot, pend.parity, st, pend.fill, pend.n_fill, lane); }
     if (B->fixed_out && !B->host_cigar && !B->host_vote) {      /* the asynchronous copies of this lane */
         const double t0 = now_ms();
         const int wrc = lfg_sam_fetch_wait(B->ixs[lane % B->n_ix]);
@@ -2368,6 +2414,12 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     pthread_mutex_init(&B.mu, NULL); pthread_cond_init(&B.cv, NULL); pthread_rwlock_init(&B.grow, NULL);
     if (ext_buf) { B.all.s = ext_buf; B.all.cap = ext_cap; B.all.n = 0; B.all.mode = 2; B.fixed_out = 1; }
     else str_init(&B.all);
+    /* SEQ-less egress: the caller's reads are host strings (we can print SEQ / QUAL ourselves) and its output buffer is pinned host
+     * memory that kernels of every device can store into.  LF_SAM_FULL=1 keeps the whole line on the device (A / B measurements). */
+    if (ext_buf && !dio && seqs && !getenv("LF_SAM_FULL")) {
+        B.holes = 1;
+        for (int d = 0; d < n_ix; d++) if (!lfg_host_mapped(ixs[d]->device, ext_buf, ext_cap)) B.holes = 0;
+    }
     uint32_t *lens = (uint32_t *)malloc(((size_t)n + 1) * 4);
     B.lens = lens;
     {   /* read lengths once, in parallel; one allocation for the SAM text (~2 x bases + per-record overhead) */

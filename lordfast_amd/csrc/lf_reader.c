@@ -22,16 +22,35 @@
 #include <time.h>
 #include "lf_internal.h"
 
+/* How a file is read:
+ *   window parser   plain FASTA / FASTQ, BGZF and gzip files whose text starts with '>' or '@': a WINDOW of text (a slice of the
+ *                   mapped file, or freshly inflated bytes) is cut into pieces at record starts and parsed by several threads;
+ *                   BGZF blocks (gzip members with a 'BC' size field, what bgzip writes) are inflated by several threads too.
+ *                   FASTQ records must be the usual four lines; anything the fast grammar does not cover (wrapped FASTQ, '@' /
+ *                   '+' / '>' line starts inside a FASTA record, junk between records) hands the rest of the file to the
+ *   sequential parser, which states kseq's grammar byte by byte over gzread (any input, pipes included). */
 struct lf_reads {
+    char path[1024];
+    /* sequential parser */
     gzFile fp;
     unsigned char *buf; int beg, end, eof;
     int last_char;                     /* header character already consumed ('>' / '@'), 0 if none */
-    char path[1024];
-    /* plain (uncompressed) FASTA in a regular file: the file is mapped and a batch is parsed by several threads at once
-     * (lf_reads_next_mapped).  Anything else -- gzip, FASTQ, pipes -- goes through the sequential parser below. */
-    const unsigned char *map; size_t map_size, map_pos; int mapped;
+    /* window parser */
+    int win;                           /* 1: active */
+    int src;                           /* 0 plain text (mapped), 1 BGZF, 2 gzip stream (one or several members, inflated by one thread) */
+    int fmt;                           /* '>' or '@' */
+    const unsigned char *map; size_t map_size;      /* the file as it is on disk */
+    size_t cpos;                       /* compressed sources: first byte of the file not yet inflated */
+    unsigned char *tbuf; size_t tcap, tbeg, tend;   /* compressed sources: inflated text not yet consumed = tbuf[tbeg .. tend) */
+    int src_eof;
+    uint64_t text_pos;                 /* offset (in the uncompressed text) of the first unconsumed byte */
+    z_stream zs; int zs_live;
+    double avg_rec;                    /* bytes of text per record, from the batches so far (window sizing) */
+    double inflate_cpu_s;              /* CPU seconds spent in inflate (all threads): LF_TIMING prints it at close */
 };
 #define LF_RBUF (4 << 20)
+#define LF_PARSE_THREADS 8
+#define LF_INFLATE_THREADS 16
 
 static inline int rd_getc(struct lf_reads *r)
 {
@@ -76,6 +95,38 @@ static int gs_getline(struct lf_reads *r, gstr_t *g, int stop_at_space)
     }
 }
 
+static int cpu_budget(int cap)
+{
+    int nt = (int)sysconf(_SC_NPROCESSORS_ONLN);
+    FILE *fq = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (fq) {
+        long long period = 0; char qs[64];
+        if (fscanf(fq, "%63s %lld", qs, &period) == 2 && strcmp(qs, "max") != 0 && period > 0) { const int lim = (int)((atoll(qs) + period - 1) / period); if (lim >= 1 && lim < nt) nt = lim; }
+        fclose(fq);
+    }
+    if (nt > cap) nt = cap;
+    return nt < 1 ? 1 : nt;
+}
+static double thread_cpu_s(void) { struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+
+/* BGZF block header at p (RFC 1952 member with an extra subfield 'B' 'C' holding the block size - 1): returns the block's size
+ * and where its deflate data starts, 0 if p is not such a header */
+static size_t bgzf_block(const unsigned char *p, size_t avail, size_t *data_off)
+{
+    if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+    const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8);
+    if (avail < 12 + xlen) return 0;
+    size_t bsize = 0;
+    for (size_t o = 12; o + 4 <= 12 + xlen; ) {
+        const size_t slen = (size_t)p[o + 2] | ((size_t)p[o + 3] << 8);
+        if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) bsize = ((size_t)p[o + 4] | ((size_t)p[o + 5] << 8)) + 1;
+        o += 4 + slen;
+    }
+    if (!bsize || bsize > avail || bsize < 12 + xlen + 8 || (p[3] & ~4)) return 0;      /* other header fields (name, comment, crc): not what bgzip writes */
+    *data_off = 12 + xlen;
+    return bsize;
+}
+
 int lf_reads_open(const char *path, lf_reads_t **out)
 {
     if (!path || !out) { lf_set_error("lf_reads_open: bad argument"); return LF_ERR_ARG; }
@@ -86,14 +137,29 @@ int lf_reads_open(const char *path, lf_reads_t **out)
     r->fp = fp; r->buf = (unsigned char *)malloc(LF_RBUF);
     snprintf(r->path, sizeof r->path, "%s", path);
     if (!getenv("LF_READER_SEQUENTIAL")) {
-        /* a regular file whose first byte is '>' (not gzip's 0x1f, not FASTQ's '@'): map it */
+        /* a regular file: map it and look at the first bytes (of the text, for gzip) */
         const int fd = open(path, O_RDONLY);
         struct stat sb;
         if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
             void *m = mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m != MAP_FAILED) {
-                if (((const unsigned char *)m)[0] == '>') { r->map = (const unsigned char *)m; r->map_size = (size_t)sb.st_size; r->map_pos = 0; r->mapped = 1; (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL); }
-                else munmap(m, (size_t)sb.st_size);
+                const unsigned char *mp = (const unsigned char *)m; const size_t ms = (size_t)sb.st_size;
+                int first = -1, src = 0;
+                if (ms >= 2 && mp[0] == 0x1f && mp[1] == 0x8b) {
+                    size_t doff; src = bgzf_block(mp, ms, &doff) ? 1 : 2;
+                    unsigned char c1; z_stream z; memset(&z, 0, sizeof z);
+                    if (inflateInit2(&z, 15 + 32) == Z_OK) {
+                        z.next_in = (Bytef *)mp; z.avail_in = (uInt)(ms > (1u << 20) ? (1u << 20) : ms); z.next_out = &c1; z.avail_out = 1;
+                        /* an empty first member (bgzip's end marker, or an empty file) yields nothing: leave it to the sequential parser */
+                        const int zr = inflate(&z, Z_NO_FLUSH);
+                        if ((zr == Z_OK || zr == Z_STREAM_END) && z.avail_out == 0) first = c1;
+                        inflateEnd(&z);
+                    }
+                } else first = mp[0];
+                if (first == '>' || first == '@') {
+                    r->map = mp; r->map_size = ms; r->win = 1; r->src = src; r->fmt = first;
+                    (void)madvise(m, ms, MADV_SEQUENTIAL);
+                } else munmap(m, ms);
             }
         }
         if (fd >= 0) close(fd);
@@ -105,8 +171,11 @@ static void blob_pool_trim(void);
 void lf_reads_close(lf_reads_t *r)
 {
     if (!r) return;
+    if (getenv("LF_TIMING") && r->inflate_cpu_s > 0) fprintf(stderr, "[lf] reader %s: %.2f CPU-s in inflate (%s)\n", r->path, r->inflate_cpu_s, r->src == 1 ? "BGZF blocks, several threads" : "one gzip stream, one thread");
     blob_pool_trim();                           /* the blobs cached for this file's batches (batches freed later are cached again) */
+    if (r->zs_live) inflateEnd(&r->zs);
     if (r->map) munmap((void *)r->map, r->map_size);
+    free(r->tbuf);
     gzclose(r->fp); free(r->buf); free(r);
 }
 
@@ -146,7 +215,7 @@ static int read_record(struct lf_reads *r, gstr_t *name, gstr_t *seq, gstr_t *qu
     return 1;
 }
 
-/* Blobs of the mapped-FASTA batches are recycled: a batch is ~0.75 GB in eight blobs, and memory fresh from malloc (= mmap
+/* Blobs of the window parser's batches are recycled: a batch is ~0.75 GB in eight blobs, and memory fresh from malloc (= mmap
  * at that size) costs a page fault and a zeroed page per 4 KiB on first touch and an munmap on free -- more than the parse
  * itself (1 M reads: the reader took 3.0 s, the mapper 2.6 s).  Up to 32 freed blobs wait here for the next batch. */
 #define LF_BLOB_POOL 32
@@ -188,8 +257,8 @@ static void blob_put(char *p, size_t cap)
 
 struct lf_read_batch {
     int n; uint64_t bases;
-    const char **names, **seqs, **quals; uint32_t *lens;
-    char *blobs[8]; size_t blob_caps[8]; int nblobs;                    /* mapped FASTA: one blob per parser thread */
+    const char **names, **seqs, **quals; uint32_t *lens; int rcap;
+    char **blobs; size_t *blob_caps; int nblobs, capblobs;              /* window parser: one blob per piece */
     char *blob; size_t blob_n, blob_cap;
     size_t *off; int cap;                          /* 3 offsets per record into blob */
 };
@@ -197,6 +266,7 @@ void lf_read_batch_free(lf_read_batch_t *b)
 {
     if (!b) return;
     for (int t = 0; t < b->nblobs; t++) blob_put(b->blobs[t], b->blob_caps[t]);
+    free(b->blobs); free(b->blob_caps);
     free(b->names); free(b->seqs); free(b->quals); free(b->lens); free(b->blob); free(b->off); free(b);
 }
 int lf_read_batch_size(const lf_read_batch_t *b) { return b ? b->n : 0; }
@@ -211,111 +281,303 @@ static void batch_put(lf_read_batch_t *b, const char *s, size_t n, size_t *off)
     *off = b->blob_n; b->blob_n += n + 1;
 }
 
-/* ---- mapped plain FASTA: a batch = a byte range of the file that ends at a record boundary, cut into one piece per thread
- * (again at record boundaries: a '>' at the start of a line); every thread copies its records' names and sequence lines
- * into a blob of its own.  Same grammar as read_record: the name ends at the first white space, sequence lines are
- * concatenated, "\r\n" line ends and empty lines are dropped.  A line that starts with '@' or '+' inside a record would
- * start a new record / a quality string in the reference's reader (kseq): such a file is handed to the sequential parser. ---- */
+/* ================================================================ the window parser
+ * A window = [a, e) of text that starts at a record.  It is cut into one piece per thread at record starts; every thread
+ * copies its records' names, sequences (lines concatenated) and qualities into a blob of its own.  Same grammar as read_record
+ * for what it accepts: the name ends at the first white space, "\r\n" line ends and empty lines are dropped.
+ *   FASTA   a record runs to the next line that starts with '>'; a line that starts with '@' or '+' inside a record would start
+ *           a new record / a quality string in kseq: not ours (weird)
+ *   FASTQ   '@' header line, ONE sequence line, '+' line, ONE quality line of the same length, then '@' again (or blank lines,
+ *           or the end); anything else -- wrapped records, '>' records in between, junk -- is weird
+ * weird = the sequential parser takes over at the start of the batch.  The last piece of a window that is not the end of the
+ * text stops in front of the first record it cannot see the end of. */
 typedef struct {
-    const unsigned char *p, *end; size_t file_off0;
+    const unsigned char *p, *end; const unsigned char *win0; int fmt, open_end;
     char *blob; size_t n, cap;
-    size_t *off; size_t *rec_file_off; int nrec, caprec; uint64_t bases; int weird;
-} mpiece_t;
-static const unsigned char *next_record_start(const unsigned char *p, const unsigned char *end)
-{   /* first '>' at the start of a line at or after p (p itself counts only if it is the start of the mapping or follows '\n') */
+    size_t *off /* 3 per record: name, seq, qual (== seq's NUL for FASTA) */, *rec_off /* offset of the record in the window */; int nrec, caprec;
+    uint64_t bases; int weird; size_t consumed;      /* offset in the window behind the last complete record (+ blank lines) */
+} piece_t;
+static inline const unsigned char *line_end(const unsigned char *p, const unsigned char *end) { const unsigned char *nl = (const unsigned char *)memchr(p, '\n', (size_t)(end - p)); return nl ? nl : end; }
+static const unsigned char *next_record_start(int fmt, const unsigned char *p, const unsigned char *end)
+{   /* first record start at a line start behind p; `end` if none can be confirmed inside the window */
     while (p < end) {
         const unsigned char *nl = (const unsigned char *)memchr(p, '\n', (size_t)(end - p));
         if (!nl || nl + 1 >= end) return end;
-        if (nl[1] == '>') return nl + 1;
-        p = nl + 1;
+        const unsigned char *l0 = nl + 1;
+        if (fmt == '>') { if (*l0 == '>') return l0; }
+        else if (*l0 == '@') {
+            /* a header, not a quality line that happens to start with '@': the line after next starts with '+' (after a quality
+             * line come a header and a sequence line), and the lines around it have one length */
+            const unsigned char *e0 = line_end(l0, end); if (e0 >= end) return end;
+            const unsigned char *l1 = e0 + 1, *e1 = line_end(l1, end); if (e1 >= end) return end;
+            const unsigned char *l2 = e1 + 1; if (l2 >= end) return end;
+            if (*l2 == '+') {
+                const unsigned char *e2 = line_end(l2, end); if (e2 >= end) return end;
+                const unsigned char *l3 = e2 + 1, *e3 = line_end(l3, end);
+                if (e3 >= end) return end;
+                if (e3 - l3 == e1 - l1) return l0;
+            }
+        }
+        p = l0;
     }
     return end;
 }
-static void *mpiece_main(void *arg)
+static inline int is_space_c(unsigned char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+static void *piece_main(void *arg)
 {
-    mpiece_t *M = (mpiece_t *)arg;
+    piece_t *M = (piece_t *)arg;
     const unsigned char *p = M->p, *end = M->end;
     M->blob = blob_get((size_t)(end - p) + 64, &M->cap); M->n = 0;
+    M->consumed = (size_t)(p - M->win0);
     while (p < end) {
-        if (*p != '>') { M->weird = 1; return NULL; }
-        if (M->nrec == M->caprec) { M->caprec = M->caprec ? M->caprec * 2 : 4096; M->off = (size_t *)realloc(M->off, (size_t)M->caprec * 2 * sizeof(size_t)); M->rec_file_off = (size_t *)realloc(M->rec_file_off, (size_t)M->caprec * sizeof(size_t)); }
-        M->rec_file_off[M->nrec] = (size_t)(p - M->p) + M->file_off0;
-        const unsigned char *q = p + 1;
-        const unsigned char *nl = (const unsigned char *)memchr(q, '\n', (size_t)(end - q));
-        const unsigned char *le = nl ? nl : end;
+        if (*p == '\n' || (*p == '\r' && p + 1 < end && p[1] == '\n')) { p += (*p == '\r') ? 2 : 1; if (M->nrec || M->fmt == '@') { M->consumed = (size_t)(p - M->win0); continue; } M->weird = 1; return NULL; }   /* blank line between records */
+        if (*p != (unsigned char)M->fmt) { M->weird = 1; return NULL; }
+        if (M->nrec == M->caprec) { M->caprec = M->caprec ? M->caprec * 2 : 4096; M->off = (size_t *)realloc(M->off, (size_t)M->caprec * 3 * sizeof(size_t)); M->rec_off = (size_t *)realloc(M->rec_off, (size_t)M->caprec * sizeof(size_t)); }
+        const size_t n0 = M->n;
+        const unsigned char *rec = p;
+        const unsigned char *q = p + 1, *le = line_end(q, end);
+        if (le >= end && M->open_end) break;                          /* header line not complete */
         const unsigned char *ne = q;
-        while (ne < le && !(*ne == ' ' || *ne == '\t' || *ne == '\r' || *ne == '\v' || *ne == '\f')) ne++;
-        M->off[2 * M->nrec] = M->n;
-        memcpy(M->blob + M->n, q, (size_t)(ne - q)); M->n += (size_t)(ne - q); M->blob[M->n++] = 0;
-        M->off[2 * M->nrec + 1] = M->n;
-        p = nl ? nl + 1 : end;
-        while (p < end && *p != '>') {
-            if (*p == '@' || *p == '+') { M->weird = 1; return NULL; }
-            nl = (const unsigned char *)memchr(p, '\n', (size_t)(end - p));
-            le = nl ? nl : end;
-            size_t len = (size_t)(le - p);
-            if (len > 0) {                                    /* (an empty line adds nothing) */
-                memcpy(M->blob + M->n, p, len); M->n += len;
-                if (M->n - M->off[2 * M->nrec + 1] > 1 && M->blob[M->n - 1] == '\r') M->n--;      /* kseq.h:140 */
+        while (ne < le && !is_space_c(*ne)) ne++;
+        size_t *o = &M->off[3 * M->nrec];
+        o[0] = M->n; memcpy(M->blob + M->n, q, (size_t)(ne - q)); M->n += (size_t)(ne - q); M->blob[M->n++] = 0;
+        o[1] = M->n;
+        p = le < end ? le + 1 : end;
+        if (M->fmt == '>') {
+            int complete = 0;
+            while (p < end) {
+                if (*p == '>') { complete = 1; break; }
+                if (*p == '@' || *p == '+') { M->weird = 1; return NULL; }
+                le = line_end(p, end);
+                if (le >= end && M->open_end) break;                  /* the line may go on behind the window */
+                const size_t len = (size_t)(le - p);
+                if (len > 0) {
+                    memcpy(M->blob + M->n, p, len); M->n += len;
+                    if (M->n - o[1] > 1 && M->blob[M->n - 1] == '\r') M->n--;      /* kseq.h:140 */
+                }
+                p = le < end ? le + 1 : end;
             }
-            p = nl ? nl + 1 : end;
+            if (!complete && M->open_end) { M->n = n0; break; }      /* its end is not in sight */
+            M->bases += M->n - o[1];
+            M->blob[M->n] = 0; o[2] = M->n; M->n++;                  /* QUAL "" = the sequence's terminator */
+        } else {
+            /* sequence line */
+            if (p >= end) { if (M->open_end) { M->n = n0; break; } M->weird = 1; return NULL; }
+            if (*p == '>' || *p == '@' || *p == '+' || *p == '\n') { M->weird = 1; return NULL; }
+            le = line_end(p, end);
+            if (le >= end) { if (M->open_end) { M->n = n0; break; } M->weird = 1; return NULL; }      /* a FASTQ record that ends with its sequence line: kseq's business */
+            size_t len = (size_t)(le - p);
+            memcpy(M->blob + M->n, p, len); M->n += len;
+            if (len > 1 && M->blob[M->n - 1] == '\r') { M->n--; len--; }
+            M->blob[M->n++] = 0;
+            p = le + 1;
+            /* '+' line */
+            if (p >= end) { if (M->open_end) { M->n = n0; break; } M->weird = 1; return NULL; }
+            if (*p != '+') { M->weird = 1; return NULL; }
+            le = line_end(p, end);
+            if (le >= end) { if (M->open_end) { M->n = n0; break; } M->weird = 1; return NULL; }
+            p = le + 1;
+            /* quality line: complete when its newline is in sight, or at the end of the text */
+            le = line_end(p, end);
+            if (le >= end && M->open_end) { M->n = n0; break; }
+            size_t ql = (size_t)(le - p);
+            if (ql > 1 && p[ql - 1] == '\r') ql--;
+            if (ql != len) { M->weird = 1; return NULL; }             /* wrapped or truncated: kseq's business */
+            o[2] = M->n; memcpy(M->blob + M->n, p, ql); M->n += ql; M->blob[M->n++] = 0;
+            M->bases += len;
+            p = le < end ? le + 1 : end;
         }
-        M->bases += M->n - M->off[2 * M->nrec + 1];
-        M->blob[M->n++] = 0;
+        M->rec_off[M->nrec] = (size_t)(rec - M->win0);
         M->nrec++;
+        M->consumed = (size_t)(p - M->win0);
     }
     return NULL;
 }
-static int lf_reads_next_mapped(lf_reads_t *r, int max_reads, uint64_t max_bases, lf_read_batch_t **out)
+
+/* ---- text for the window parser ---- */
+typedef struct { const unsigned char *src; size_t n_in; unsigned char *dst; size_t n_out; } zblock_t;
+typedef struct { zblock_t *blk; int n; int rc; double cpu_s; } zjob_t;
+static void *zjob_main(void *arg)
+{
+    zjob_t *J = (zjob_t *)arg;
+    const double c0 = thread_cpu_s();
+    z_stream z; memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, -15) != Z_OK) { J->rc = 1; return NULL; }
+    for (int k = 0; k < J->n; k++) {
+        if (k && inflateReset(&z) != Z_OK) { J->rc = 1; break; }
+        z.next_in = (Bytef *)J->blk[k].src; z.avail_in = (uInt)J->blk[k].n_in; z.next_out = J->blk[k].dst; z.avail_out = (uInt)J->blk[k].n_out;
+        const int zr = inflate(&z, Z_FINISH);
+        if (zr != Z_STREAM_END || z.avail_out != 0) { J->rc = 1; break; }
+    }
+    inflateEnd(&z);
+    J->cpu_s = thread_cpu_s() - c0;
+    return NULL;
+}
+static int tbuf_room(struct lf_reads *r, size_t extra)
+{
+    if (r->tbeg > 0) { memmove(r->tbuf, r->tbuf + r->tbeg, r->tend - r->tbeg); r->tend -= r->tbeg; r->tbeg = 0; }
+    if (r->tend + extra + 64 > r->tcap) {
+        const size_t nc = (r->tend + extra) + (r->tend + extra) / 4 + (1 << 20);
+        unsigned char *nb = (unsigned char *)realloc(r->tbuf, nc);
+        if (!nb) { lf_set_error("lf_reads_next: out of memory"); return LF_ERR_NOMEM; }
+        r->tbuf = nb; r->tcap = nc;
+    }
+    return LF_OK;
+}
+/* compressed sources: make tbuf[tbeg .. tend) at least `want` bytes long (or reach the end of the file) */
+static int inflate_more(struct lf_reads *r, size_t want)
+{
+    while (!r->src_eof && r->tend - r->tbeg < want) {
+        const size_t need = want - (r->tend - r->tbeg);
+        if (r->src == 1) {
+            /* the BGZF blocks that hold the next `need` bytes: sizes from the headers (one pass over 18 bytes per 64 KiB), then
+             * every thread inflates a run of blocks straight into its place */
+            size_t cp = r->cpos, out = 0; int nb = 0, capb = 0; zblock_t *blk = NULL;
+            while (cp < r->map_size && out < need) {
+                size_t doff; const size_t bs = bgzf_block(r->map + cp, r->map_size - cp, &doff);
+                if (!bs) break;
+                const unsigned char *tl = r->map + cp + bs - 4;
+                const size_t isize = (size_t)tl[0] | ((size_t)tl[1] << 8) | ((size_t)tl[2] << 16) | ((size_t)tl[3] << 24);
+                if (nb == capb) { capb = capb ? capb * 2 : 4096; blk = (zblock_t *)realloc(blk, (size_t)capb * sizeof(zblock_t)); }
+                blk[nb].src = r->map + cp + doff; blk[nb].n_in = bs - doff - 8; blk[nb].dst = (unsigned char *)(uintptr_t)out; blk[nb].n_out = isize; nb++;
+                out += isize; cp += bs;
+            }
+            if (nb == 0) {
+                if (cp >= r->map_size) { r->src_eof = 1; free(blk); break; }
+                free(blk); lf_set_error("lf_reads_next: %s: not a BGZF block at offset %zu", r->path, cp); return LF_ERR_IO;      /* (a plain gzip member in the middle of a BGZF file) */
+            }
+            const int rc0 = tbuf_room(r, out); if (rc0 != LF_OK) { free(blk); return rc0; }
+            for (int k = 0; k < nb; k++) blk[k].dst = r->tbuf + r->tend + (size_t)(uintptr_t)blk[k].dst;
+            int nt = cpu_budget(LF_INFLATE_THREADS); if (nt > nb) nt = nb;
+            zjob_t J[LF_INFLATE_THREADS]; pthread_t th[LF_INFLATE_THREADS]; int started[LF_INFLATE_THREADS];
+            for (int t = 0; t < nt; t++) { const int b0 = (int)((long long)nb * t / nt), b1 = (int)((long long)nb * (t + 1) / nt); J[t].blk = blk + b0; J[t].n = b1 - b0; J[t].rc = 0; J[t].cpu_s = 0; }
+            for (int t = 1; t < nt; t++) started[t] = pthread_create(&th[t], NULL, zjob_main, &J[t]) == 0;
+            zjob_main(&J[0]);
+            int bad = J[0].rc;
+            for (int t = 1; t < nt; t++) { if (started[t]) pthread_join(th[t], NULL); else zjob_main(&J[t]); bad |= J[t].rc; }
+            for (int t = 0; t < nt; t++) r->inflate_cpu_s += J[t].cpu_s;
+            free(blk);
+            if (bad) { lf_set_error("lf_reads_next: %s: corrupt BGZF block", r->path); return LF_ERR_IO; }
+            r->tend += out; r->cpos = cp;
+            if (r->cpos >= r->map_size) r->src_eof = 1;
+        } else {
+            /* one gzip stream (possibly several members back to back): one thread, zlib's speed */
+            const double c0 = thread_cpu_s();
+            if (!r->zs_live) { memset(&r->zs, 0, sizeof r->zs); if (inflateInit2(&r->zs, 15 + 32) != Z_OK) { lf_set_error("lf_reads_next: inflateInit failed"); return LF_ERR_IO; } r->zs_live = 1; }
+            size_t chunk = need < ((size_t)8 << 20) ? ((size_t)8 << 20) : need;
+            const int rc0 = tbuf_room(r, chunk); if (rc0 != LF_OK) return rc0;
+            while (chunk > 0 && !r->src_eof) {
+                const size_t in_left = r->map_size - r->cpos;
+                if (in_left == 0) { r->src_eof = 1; break; }
+                r->zs.next_in = (Bytef *)(r->map + r->cpos); r->zs.avail_in = (uInt)(in_left > (1u << 30) ? (1u << 30) : in_left);
+                r->zs.next_out = r->tbuf + r->tend; r->zs.avail_out = (uInt)(chunk > (1u << 30) ? (1u << 30) : chunk);
+                const uInt in0 = r->zs.avail_in, out0 = r->zs.avail_out;
+                const int zr = inflate(&r->zs, Z_NO_FLUSH);
+                r->cpos += in0 - r->zs.avail_in; r->tend += out0 - r->zs.avail_out; chunk -= out0 - r->zs.avail_out;
+                if (zr == Z_STREAM_END) {                               /* next member, if any (gzread does the same) */
+                    if (r->cpos >= r->map_size) { r->src_eof = 1; break; }
+                    if (r->map[r->cpos] != 0x1f) { r->src_eof = 1; break; }      /* trailing garbage: ignored like gzread does */
+                    if (inflateReset(&r->zs) != Z_OK) { lf_set_error("lf_reads_next: inflateReset failed"); return LF_ERR_IO; }
+                } else if (zr != Z_OK && zr != Z_BUF_ERROR) { lf_set_error("lf_reads_next: %s: corrupt gzip data", r->path); return LF_ERR_IO; }
+                else if (zr == Z_BUF_ERROR && in0 == r->zs.avail_in && out0 == r->zs.avail_out) { r->src_eof = 1; break; }      /* truncated file */
+            }
+            r->inflate_cpu_s += thread_cpu_s() - c0;
+        }
+    }
+    return LF_OK;
+}
+
+static void batch_room(lf_read_batch_t *b, int more)
+{
+    if (b->n + more + 1 <= b->rcap) return;
+    b->rcap = (b->n + more + 1) + (b->n + more + 1) / 2;
+    b->names = (const char **)realloc(b->names, (size_t)b->rcap * sizeof(char *)); b->seqs = (const char **)realloc(b->seqs, (size_t)b->rcap * sizeof(char *));
+    b->quals = (const char **)realloc(b->quals, (size_t)b->rcap * sizeof(char *)); b->lens = (uint32_t *)realloc(b->lens, (size_t)b->rcap * sizeof(uint32_t));
+}
+static int lf_reads_next_window(lf_reads_t *r, int max_reads, uint64_t max_bases, lf_read_batch_t **out)
 {
     *out = NULL;
-    if (r->map_pos >= r->map_size) return LF_OK;
-    const unsigned char *base = r->map, *fend = r->map + r->map_size;
-    const unsigned char *a = base + r->map_pos;
-    uint64_t want = max_bases + (max_bases >> 6) + 4096;                 /* bytes: bases + headers + newlines */
-    if (want > (uint64_t)(fend - a)) want = (uint64_t)(fend - a);
-    const unsigned char *e = (a + want >= fend) ? fend : next_record_start(a + want - 1, fend);
-    int nt = (int)sysconf(_SC_NPROCESSORS_ONLN); if (nt > 8) nt = 8; if (nt < 1) nt = 1;
-    if ((size_t)(e - a) < ((size_t)4 << 20)) nt = 1;
-    mpiece_t M[8]; pthread_t th[8]; int started[8];
-    memset(M, 0, sizeof M);
-    const unsigned char *cut = a;
-    for (int t = 0; t < nt; t++) {
-        const unsigned char *nx = (t == nt - 1) ? e : next_record_start(a + (size_t)(e - a) / (size_t)nt * (size_t)(t + 1), e);
-        M[t].p = cut; M[t].end = nx; M[t].file_off0 = (size_t)(cut - base);
-        cut = nx;
-    }
-    for (int t = 0; t < nt; t++) { started[t] = (t > 0 && M[t].p < M[t].end) ? pthread_create(&th[t], NULL, mpiece_main, &M[t]) == 0 : 0; }
-    mpiece_main(&M[0]);
-    for (int t = 1; t < nt; t++) { if (started[t]) pthread_join(th[t], NULL); else if (M[t].p < M[t].end) mpiece_main(&M[t]); }
-    int weird = 0, total = 0;
-    for (int t = 0; t < nt; t++) { weird |= M[t].weird; total += M[t].nrec; }
-    if (weird) {
-        /* not a plain FASTA after all: the sequential parser takes over from the start of this batch */
-        for (int t = 0; t < nt; t++) { blob_put(M[t].blob, M[t].cap); free(M[t].off); free(M[t].rec_file_off); }
-        r->mapped = 0;
-        if (gzseek(r->fp, (z_off_t)r->map_pos, SEEK_SET) < 0) { lf_set_error("lf_reads_next: cannot reposition %s", r->path); return LF_ERR_IO; }
-        r->beg = r->end = 0; r->eof = 0; r->last_char = 0;
-        return lf_reads_next(r, max_reads, max_bases, out);
-    }
-    /* max_reads / max_bases: keep the leading records that fit (at least one), continue at the first one that does not */
     lf_read_batch_t *b = (lf_read_batch_t *)calloc(1, sizeof *b);
-    int keep = 0; uint64_t bases = 0; size_t next_pos = (size_t)(e - base);
-    if (max_reads <= 0) max_reads = 1 << 30;
-    b->names = (const char **)malloc(((size_t)total + 1) * sizeof(char *)); b->seqs = (const char **)malloc(((size_t)total + 1) * sizeof(char *)); b->quals = (const char **)malloc(((size_t)total + 1) * sizeof(char *));
-    b->lens = (uint32_t *)malloc(((size_t)total + 1) * sizeof(uint32_t));
-    int stop = 0;
-    for (int t = 0; t < nt && !stop; t++) for (int k = 0; k < M[t].nrec; k++) {
-        const size_t so = M[t].off[2 * k + 1], eo = (k + 1 < M[t].nrec) ? M[t].off[2 * k + 2] : M[t].n;
-        const uint32_t len = (uint32_t)(eo - so - 1);
-        if (keep > 0 && (keep >= max_reads || bases >= max_bases)) { next_pos = M[t].rec_file_off[k]; stop = 1; break; }
-        b->names[keep] = M[t].blob + M[t].off[2 * k]; b->seqs[keep] = M[t].blob + so; b->quals[keep] = "";
-        b->lens[keep] = len; bases += len; keep++;
+    const uint64_t batch_text0 = r->text_pos;
+    const double per_base = r->fmt == '@' ? 2.04 : 1.02;          /* bytes of text per base: sequence (+ quality) + newlines */
+    size_t grow = 0;                                                /* a window that holds no complete record is doubled */
+    for (;;) {
+        /* how much text the rest of the batch is likely to be: bounded by BOTH limits (a batch limited by reads only must not
+         * parse the rest of the file), from the record size seen so far; the first window of a file is a small probe */
+        const double rec = r->avg_rec > 0 ? r->avg_rec : 0;
+        uint64_t want = (uint64_t)1 << 40;
+        if (max_bases - b->bases < ((uint64_t)1 << 38)) want = (uint64_t)((double)(max_bases - b->bases) * per_base) + 4096;
+        const uint64_t by_reads = rec > 0 ? (uint64_t)((double)(max_reads - b->n) * rec * 1.05) + 65536 : ((uint64_t)4 << 20);
+        if (by_reads < want) want = by_reads;
+        if (rec <= 0 && want > ((uint64_t)64 << 20)) want = (uint64_t)64 << 20;
+        if (r->src != 0 && want > ((uint64_t)256 << 20)) want = (uint64_t)256 << 20;      /* inflated text is buffered: a window at a time */
+        if (want < grow) want = grow;
+        const unsigned char *a, *e; int at_eof;
+        if (r->src == 0) {
+            a = r->map + r->text_pos; const size_t left = r->map_size - (size_t)r->text_pos;
+            e = a + (want < left ? (size_t)want : left); at_eof = e == r->map + r->map_size;
+        } else {
+            const int irc = inflate_more(r, (size_t)want);
+            if (irc != LF_OK) { lf_read_batch_free(b); return irc; }
+            a = r->tbuf + r->tbeg; e = r->tbuf + r->tend; at_eof = r->src_eof;
+            if ((size_t)(e - a) > want && !at_eof) e = a + want;
+            if (e < r->tbuf + r->tend) at_eof = 0;
+        }
+        if (a >= e) break;                                          /* end of the text */
+        int nt = cpu_budget(LF_PARSE_THREADS);
+        if ((size_t)(e - a) < ((size_t)4 << 20)) nt = 1;
+        piece_t M[LF_PARSE_THREADS]; pthread_t th[LF_PARSE_THREADS]; int started[LF_PARSE_THREADS];
+        memset(M, 0, sizeof M);
+        const unsigned char *cut = a;
+        for (int t = 0; t < nt; t++) {
+            const unsigned char *nx = (t == nt - 1) ? e : next_record_start(r->fmt, a + (size_t)(e - a) / (size_t)nt * (size_t)(t + 1), e);
+            if (nx < cut) nx = cut;
+            M[t].p = cut; M[t].end = nx; M[t].win0 = a; M[t].fmt = r->fmt; M[t].open_end = (nx == e) && !at_eof;
+            cut = nx;
+        }
+        for (int t = 0; t < nt; t++) started[t] = (t > 0 && M[t].p < M[t].end) ? pthread_create(&th[t], NULL, piece_main, &M[t]) == 0 : 0;
+        piece_main(&M[0]);
+        for (int t = 1; t < nt; t++) { if (started[t]) pthread_join(th[t], NULL); else if (M[t].p < M[t].end) piece_main(&M[t]); }
+        int weird = 0, total = 0;
+        for (int t = 0; t < nt; t++) { weird |= M[t].weird; total += M[t].nrec; }
+        if (getenv("LF_READER_DEBUG")) { fprintf(stderr, "[lf reader] window %zu bytes, %d pieces, %d records, weird %d, at_eof %d:", (size_t)(e - a), nt, total, weird, at_eof); for (int t = 0; t < nt; t++) fprintf(stderr, " %zu/%d", (size_t)(M[t].end - M[t].p), M[t].nrec); fprintf(stderr, "\n"); }
+        /* a piece that stopped early (open end) must be the last one with any text */
+        for (int t = 0; t + 1 < nt; t++) if (M[t].p < M[t].end && M[t].consumed != (size_t)(M[t].end - a)) { int later = 0; for (int u = t + 1; u < nt; u++) later |= M[u].p < M[u].end; if (later) weird = 1; }
+        if (weird) {
+            /* not what the window grammar covers: the sequential parser takes over from the start of this BATCH */
+            for (int t = 0; t < nt; t++) { blob_put(M[t].blob, M[t].cap); free(M[t].off); free(M[t].rec_off); }
+            lf_read_batch_free(b);
+            r->win = 0;
+            if (gzseek(r->fp, (z_off_t)batch_text0, SEEK_SET) < 0) { lf_set_error("lf_reads_next: cannot reposition %s", r->path); return LF_ERR_IO; }
+            r->beg = r->end = 0; r->eof = 0; r->last_char = 0;
+            return lf_reads_next(r, max_reads, max_bases, out);
+        }
+        /* keep the leading records that fit (at least one per batch); the text continues at the first one that does not */
+        size_t consumed = 0; int stop = 0, kept = 0; uint64_t kept_bytes = 0;
+        batch_room(b, total);
+        for (int t = 0; t < nt; t++) { if (M[t].p < M[t].end) consumed = M[t].consumed; }
+        for (int t = 0; t < nt && !stop; t++) for (int k = 0; k < M[t].nrec; k++) {
+            const size_t *o = &M[t].off[3 * k];
+            const uint32_t len = (uint32_t)(o[2] - o[1] - (r->fmt == '@' ? 1 : 0));
+            if (b->n > 0 && (b->n >= max_reads || b->bases >= max_bases)) { consumed = M[t].rec_off[k]; stop = 1; break; }
+            b->names[b->n] = M[t].blob + o[0]; b->seqs[b->n] = M[t].blob + o[1]; b->quals[b->n] = M[t].blob + o[2];
+            b->lens[b->n] = len; b->bases += len; b->n++; kept++;
+        }
+        kept_bytes = consumed;
+        if (b->nblobs + nt > b->capblobs) { b->capblobs = (b->nblobs + nt) * 2; b->blobs = (char **)realloc(b->blobs, (size_t)b->capblobs * sizeof(char *)); b->blob_caps = (size_t *)realloc(b->blob_caps, (size_t)b->capblobs * sizeof(size_t)); }
+        for (int t = 0; t < nt; t++) { if (M[t].blob) { b->blobs[b->nblobs] = M[t].blob; b->blob_caps[b->nblobs] = M[t].cap; b->nblobs++; } free(M[t].off); free(M[t].rec_off); }
+        if (kept > 0) r->avg_rec = r->avg_rec > 0 ? 0.5 * r->avg_rec + 0.5 * ((double)kept_bytes / kept) : (double)kept_bytes / kept;
+        r->text_pos += consumed;
+        if (r->src != 0) r->tbeg += consumed;
+        if (stop || b->n >= max_reads || b->bases >= max_bases) break;
+        if (at_eof) {
+            if (consumed < (size_t)(e - a) && total == 0) { r->text_pos += (size_t)(e - a) - consumed; if (r->src != 0) r->tbeg = r->tend; }
+            break;
+        }
+        if (total == 0) grow = (size_t)(e - a) * 2 + ((size_t)1 << 20);      /* a record longer than the window */
+        else grow = 0;
     }
-    b->n = keep; b->bases = bases;
-    b->nblobs = nt; for (int t = 0; t < nt; t++) { b->blobs[t] = M[t].blob; b->blob_caps[t] = M[t].cap; free(M[t].off); free(M[t].rec_file_off); }
-    r->map_pos = next_pos;
-    if (keep == 0) { lf_read_batch_free(b); return LF_OK; }
+    if (b->n == 0) { lf_read_batch_free(b); return LF_OK; }
     *out = b;
     return LF_OK;
 }
@@ -326,7 +588,7 @@ int lf_reads_next(lf_reads_t *r, int max_reads, uint64_t max_bases, lf_read_batc
     *out = NULL;
     if (max_reads <= 0) max_reads = 1 << 30;
     if (max_bases == 0) max_bases = ~0ull;
-    if (r->mapped) return lf_reads_next_mapped(r, max_reads, max_bases == ~0ull ? ((uint64_t)1 << 40) : max_bases, out);
+    if (r->win) return lf_reads_next_window(r, max_reads, max_bases, out);
     lf_read_batch_t *b = (lf_read_batch_t *)calloc(1, sizeof *b);
     gstr_t name = { 0, 0, 0 }, seq = { 0, 0, 0 }, qual = { 0, 0, 0 };
     int rc = LF_OK;
@@ -471,7 +733,12 @@ int lf_map_file_multi(const lf_index_t *const *idx, int n_idx, const lf_params_t
     pthread_mutex_init(&A.mu, NULL); pthread_cond_init(&A.cv, NULL);
     writer_t W; memset(&W, 0, sizeof W);
     W.fo = fo;
-    { struct stat sb; W.regular = fstat(fileno(fo), &sb) == 0 && S_ISREG(sb.st_mode); W.at = W.regular ? lseek(fileno(fo), 0, SEEK_CUR) : 0; if (W.at < 0) W.regular = 0; }
+    {   /* pwrite at explicit offsets needs a descriptor whose position is ours alone: on an O_APPEND descriptor (`-o - >> out.sam`)
+         * Linux ignores the offset and appends, so the four pieces of a batch would land in completion order */
+        struct stat sb; const int fl = fcntl(fileno(fo), F_GETFL);
+        W.regular = fstat(fileno(fo), &sb) == 0 && S_ISREG(sb.st_mode) && fl != -1 && !(fl & O_APPEND);
+        W.at = W.regular ? lseek(fileno(fo), 0, SEEK_CUR) : 0; if (W.at < 0) W.regular = 0;
+    }
     pthread_mutex_init(&W.mu, NULL); pthread_cond_init(&W.cv, NULL);
     char *obuf[2] = { NULL, NULL }; size_t ocap[2] = { 0, 0 };
     pthread_t th, wth, ath; int have_w = 0, have_a = 0;

@@ -62,6 +62,38 @@ __global__ void lf_full_sa_kernel(lf_dev_index ix, uint64_t *__restrict__ sa_ful
     }
 }
 
+/* A search starts from TWO table entries: the interval of revcomp(P_W) (rows x1, size) and the first row of P_W itself (x0).
+ * The two indices are digit-reversed complements of each other, i.e. two random lines of a table of up to 68.7 GB per sample.
+ * Packed form, same 16 bytes per k-mer: entry i = (first row of k-mer i : 33 bits, interval size : 33 bits, first row of the
+ * reverse-complement k-mer : 33 bits) -- ONE line per start.  In place: a thread owns the pair (i, rc(i)). */
+#define LF_M33 ((1ull << 33) - 1)
+__device__ __forceinline__ uint32_t lf_kmer_rc_index(uint32_t i, int K)
+{
+    uint32_t x = __brev(i);
+    x = ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);        /* 2-bit digits reversed, bits of a digit in place */
+    x >>= (32 - 2 * K);
+    return x ^ (K == 16 ? 0xffffffffu : ((1u << (2 * K)) - 1u));
+}
+__global__ void lf_cache_pack_kernel(uint64_t *__restrict__ tab, int K, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = lf_kmer_rc_index((uint32_t)i, K);
+    if ((uint64_t)j < i) return;
+    const uint64_t ab = tab[2 * i], ae = tab[2 * i + 1], bb = tab[2 * (size_t)j], be = tab[2 * (size_t)j + 1];
+    const uint64_t as = ab <= ae ? ae - ab + 1 : 0, bs = bb <= be ? be - bb + 1 : 0;
+    tab[2 * i] = (ab & LF_M33) | ((as & 0x7fffffffull) << 33); tab[2 * i + 1] = (bb & LF_M33) | ((as >> 31) << 33);
+    if ((uint64_t)j != i) { tab[2 * (size_t)j] = (bb & LF_M33) | ((bs & 0x7fffffffull) << 33); tab[2 * (size_t)j + 1] = (ab & LF_M33) | ((bs >> 31) << 33); }
+}
+static int lfg_pack_cache_table(hipStream_t stream, int K, uint64_t *tab)
+{
+    const uint64_t n = 1ull << (2 * K);
+    hipLaunchKernelGGL(lf_cache_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tab, K, n);
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipGetLastError());
+    return LF_OK;
+}
+
 /* 12-mer table (src/BWT.cpp:60-115), level by level, ping-pong between two buffers; *table = 4^12 pairs */
 int lfg_build_cache_table(const lf_dev_index *v, hipStream_t stream, int K, uint64_t **table)
 {
@@ -121,6 +153,7 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
     {
         uint64_t *tab = nullptr;
         int rc = lfg_build_cache_table(&v, st->stream, 12, &tab);
+        if (rc == LF_OK) rc = lfg_pack_cache_table(st->stream, 12, tab);
         if (rc != LF_OK) return rc;
         st->cache = tab;
         v.cache = tab;
@@ -128,6 +161,7 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
         const char *wt = getenv("LF_WIDE_TABLE");
         if (wt ? atoi(wt) != 0 : ix->seq_len >= (1ull << 28)) {
             rc = lfg_build_cache_table(&v, st->stream, 14, &tab);
+            if (rc == LF_OK) rc = lfg_pack_cache_table(st->stream, 14, tab);
             if (rc != LF_OK) return rc;
             st->cache14 = tab; v.cache14 = tab;
         }
@@ -140,6 +174,7 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
         const size_t need16 = (((size_t)1 << 32) + ((size_t)1 << 30)) * 16 + ((size_t)8 << 30);
         if (t16 ? atoi(t16) != 0 : (ix->seq_len >= (1ull << 30) && free_b > need16 + ((size_t)100 << 30) + ((ix->flags & LF_IDX_FULL_SA) ? (ix->seq_len + 1) * 8 : 0))) {
             rc = lfg_build_cache_table(&v, st->stream, 16, &tab);
+            if (rc == LF_OK) rc = lfg_pack_cache_table(st->stream, 16, tab);
             if (rc == LF_OK) { st->cache16 = tab; v.cache16 = tab; }
             else if (t16) return rc;                    /* asked for explicitly */
         }
@@ -176,6 +211,21 @@ extern "C" void lfg_index_free(struct lf_index *ix)
     if (st->stream) (void)hipStreamDestroy(st->stream);
     delete st;
     ix->dev = NULL;
+}
+
+/* which index structures are resident (bench.py's config.index; a table that did not fit changes speed, never results) */
+extern "C" int lfg_index_describe(const struct lf_index *ix, char *buf, size_t cap)
+{
+    const lf_dev_state *st = (const lf_dev_state *)ix->dev;
+    if (!st || !buf || cap < 2) return LF_ERR_ARG;
+    const double GB = 1e9;
+    int o = snprintf(buf, cap, "BWT + Occ %.2f GB; ", ix->bwt_size * 4 / GB);
+    if (st->sa_full) o += snprintf(buf + o, o < (int)cap ? cap - o : 0, "full suffix array (u64 per row) %.1f GB; ", (ix->seq_len + 1) * 8 / GB);
+    o += snprintf(buf + o, o < (int)cap ? cap - o : 0, "sampled suffix array (every 32nd row) %.2f GB; k-mer tables: 12 (%.2f GB)", ix->n_sa * 8 / GB, (double)(1ull << 24) * 16 / GB);
+    if (st->cache14) o += snprintf(buf + o, o < (int)cap ? cap - o : 0, ", 14 (%.1f GB)", (double)(1ull << 28) * 16 / GB);
+    if (st->cache16) o += snprintf(buf + o, o < (int)cap ? cap - o : 0, ", 16 (%.1f GB)", (double)(1ull << 32) * 16 / GB);
+    o += snprintf(buf + o, o < (int)cap ? cap - o : 0, "; 2-bit reference %.2f GB", (double)(ix->l_pac / 4 + 1) / GB);
+    return LF_OK;
 }
 
 /* ---------------------------------------------------------------- seeding kernels */
@@ -312,32 +362,25 @@ lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ rea
                         if (lead > inread) lead = inread;
                         ahead = codes | (lead << 24);
                     }
-                    /* table index of a pattern: base-4 number with its LAST character most significant; for revcomp(P) the
-                     * characters are the complements of P's, read backwards */
-                    auto idx_of = [&](int Wd, uint32_t &idc_o, uint32_t &idf_o) {
-                        uint32_t idc = 0, idf = 0;
+                    /* table index of revcomp(P_W): base-4 number whose digit W - 1 - t is the complement of P's character t (the LAST
+                     * character of a pattern is the most significant digit, src/BWT.cpp:270-277).  Its packed entry holds the
+                     * rows of revcomp(P_W), their number and the first row of P_W itself: one 16-byte load per start */
+                    auto idx_of = [&](int Wd) {
+                        uint32_t idc = 0;
 #pragma unroll
                         for (int t = 0; t < 16; t++) if (t < Wd) idc = idc * 4 + (uint32_t)(3 - cd[t]);
-#pragma unroll
-                        for (int t = 15; t >= 0; t--) if (t < Wd) idf = idf * 4 + (uint32_t)cd[t];
-                        idc_o = idc; idf_o = idf;
+                        return idc;
+                    };
+                    auto take = [&](const uint64_t *__restrict__ T, uint32_t idc, uint32_t Wd) {
+                        n_cache += 1;
+                        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T + 2 * (size_t)idc);
+                        const uint64_t size = (e.x >> 33) | ((e.y >> 33) << 31);
+                        if (size != 0) { x1 = e.x & LF_M33; x0 = e.y & LF_M33; sz = size; m = Wd; started = true; }
                     };
                     /* widest table first: a 16-mer that occurs starts the search at m = 16 (nothing shorter than kmin is wanted,
                      * and a sample that reaches 16 would have passed through every shorter length with a non-empty interval) */
-                    if (ix.cache16 != nullptr && (uint64_t)p + 16 <= qLen && (bad & 0xffffu) == 0) {
-                        uint32_t idc, idf; idx_of(16, idc, idf);
-                        n_cache += 2;
-                        const ulonglong2 e1 = *reinterpret_cast<const ulonglong2 *>(ix.cache16 + 2 * (size_t)idc);      /* both entries in flight together */
-                        const uint64_t f0 = ix.cache16[2 * (size_t)idf];
-                        if (e1.x <= e1.y) { x1 = e1.x; x0 = f0; sz = e1.y - e1.x + 1; m = 16; started = true; }
-                    }
-                    if (!started && (bad & ((1u << W) - 1)) == 0) {
-                        uint32_t idc, idf; idx_of((int)W, idc, idf);
-                        n_cache += 2;
-                        const ulonglong2 e1 = *reinterpret_cast<const ulonglong2 *>(tab + 2 * (size_t)idc);
-                        const uint64_t f0 = tab[2 * (size_t)idf];
-                        if (e1.x <= e1.y) { x1 = e1.x; x0 = f0; sz = e1.y - e1.x + 1; m = W; started = true; }
-                    }
+                    if (ix.cache16 != nullptr && (uint64_t)p + 16 <= qLen && (bad & 0xffffu) == 0) take(ix.cache16, idx_of(16), 16u);
+                    if (!started && (bad & ((1u << W) - 1)) == 0) take(tab, idx_of((int)W), W);
                 }
                 if (started) active = true; else out[gid] = res;
             }

@@ -115,6 +115,55 @@ def add_duplications(contigs, seg_len: int = 12000, copies: int = 3, div: float 
     return places
 
 
+def add_segdups(contigs, n_segments: int, seg_len=(40000, 80000), copies=(2, 4), div=(0.01, 0.03), seed: int = 7):
+    """Segmental duplications: `n_segments` source segments of seg_len[0] .. seg_len[1] bp, each present in 2 .. 4 copies
+    (the source + pasted copies on random contigs, either strand) at 1 - 3 % divergence (substitutions).  Reads drawn from
+    them have several near-equal candidate windows: lordFAST's fine mode (src/LordFAST.cpp:542-562) with -n > 1 aligns every
+    one of them.  Copies do not overlap each other (10 kbp occupancy grid).  Returns one list of (contig, pos, len) per
+    family; contigs are modified in place."""
+    rng = np.random.default_rng(seed)
+    G = 10000
+    occ = [np.zeros(len(s) // G + 2, dtype=bool) for _, s in contigs]
+    clens = np.array([len(s) for _, s in contigs], dtype=np.float64)
+    pc = clens / clens.sum()
+
+    def place(ln):
+        for _ in range(200):
+            ci = int(rng.choice(len(contigs), p=pc))
+            s = contigs[ci][1]
+            if len(s) <= ln + 2 * G:
+                continue
+            p = int(rng.integers(0, len(s) - ln))
+            a, b = p // G, (p + ln) // G + 1
+            if not occ[ci][a:b].any():
+                occ[ci][a:b] = True
+                return ci, p
+        return None
+
+    fams = []
+    for _ in range(n_segments):
+        ln = int(rng.integers(seg_len[0], seg_len[1] + 1))
+        src = place(ln)
+        if src is None:
+            continue
+        seg = contigs[src[0]][1][src[1]:src[1] + ln].copy()
+        fam = [(src[0], src[1], ln)]
+        for _k in range(int(rng.integers(copies[0], copies[1] + 1)) - 1):
+            dst = place(ln)
+            if dst is None:
+                break
+            c = seg.copy()
+            mut = rng.random(ln) < rng.uniform(div[0], div[1])
+            cur = np.searchsorted(_ACGT, c[mut])
+            c[mut] = _ACGT[(cur + rng.integers(1, 4, size=int(mut.sum()))) % 4]
+            if rng.random() < 0.5:
+                c = revcomp(c)
+            contigs[dst[0]][1][dst[1]:dst[1] + ln] = c
+            fam.append((dst[0], dst[1], ln))
+        fams.append(fam)
+    return fams
+
+
 def special_reads(contigs, dup_places=None, seed: int = 77, err: float = 0.10):
     """Reads engineered to reach the rare branches of the extension code:
     big deletion / insertion (split + supplementary), inversion with indel (inverted middle segment),
@@ -213,9 +262,12 @@ def mutate(seq: np.ndarray, err: float, rng, mix=(0.15, 0.50, 0.35)) -> np.ndarr
 
 
 def make_reads(contigs, n_reads: int, mean_len: int, err: float, seed: int = 2024,
-               mix=(0.15, 0.50, 0.35), min_len: int = 1000, sigma: float = 0.35):
-    """Returns list of (name, seq_bytes). Name carries the true origin: r<i>_<contig>_<pos>_<strand>."""
+               mix=(0.15, 0.50, 0.35), min_len: int = 1000, sigma: float = 0.35, segdups=None, dup_frac: float = 0.0):
+    """Returns list of (name, seq_bytes). Name carries the true origin: r<i>_<contig>_<pos>_<strand>.
+    segdups (add_segdups) + dup_frac: that fraction of the reads lies inside a copy of a duplicated segment (name ends in
+    `_dup`); with dup_frac == 0 the random stream, hence the read set, is what it always was."""
     rng = np.random.default_rng(seed)
+    rng_dup = np.random.default_rng(seed + 100003) if (segdups and dup_frac > 0) else None
     clens = np.array([len(s) for _, s in contigs], dtype=np.float64)
     pc = clens / clens.sum()
     mu = np.log(mean_len) - 0.5 * sigma * sigma
@@ -228,13 +280,21 @@ def make_reads(contigs, n_reads: int, mean_len: int, err: float, seed: int = 202
             if ln < len(s):
                 break
         p = int(rng.integers(0, len(s) - ln))
+        tag = ""
+        if rng_dup is not None and rng_dup.random() < dup_frac:
+            fam = segdups[int(rng_dup.integers(0, len(segdups)))]
+            ci, p0, sl = fam[int(rng_dup.integers(0, len(fam)))]
+            name, s = contigs[ci]
+            ln = min(ln, sl)
+            p = p0 + int(rng_dup.integers(0, sl - ln + 1))
+            tag = "_dup"
         frag = s[p:p + ln]
         strand = "+"
         if rng.random() < 0.5:
             frag = revcomp(frag)
             strand = "-"
         r = mutate(frag, err, rng, mix)
-        reads.append((f"r{i}_{name}_{p}_{strand}", r.tobytes()))
+        reads.append((f"r{i}_{name}_{p}_{strand}{tag}", r.tobytes()))
     return reads
 
 

@@ -101,3 +101,33 @@ def test_index_mode_builds_reference_files(cli, tmp_path):
     assert r.returncode == 0, r.stderr.decode()
     for ext in ("bwt", "sa", "pac", "ann", "amb"):
         assert open(f"{fa}.{ext}", "rb").read() == open(os.path.join(GOLDEN, f"genome.fa.{ext}"), "rb").read(), ext
+
+
+@pytest.mark.gpu
+def test_output_appended_to_a_file_stays_in_order(cli, golden_dir, tmp_path):
+    """`lordfast ... >> out.sam`: on an O_APPEND descriptor pwrite ignores its offset, so the writer must not cut a batch's text
+    into concurrently written pieces there (the SAM would come out in completion order).  > 8 MB of records, the size from which
+    a regular file is written in four pieces."""
+    from conftest import read_fasta
+    src = str(tmp_path / "src.fa")
+    with gzip.open(os.path.join(GOLDEN, "reads.fa.gz"), "rb") as fi, open(src, "wb") as fo:
+        fo.write(fi.read())
+    names, seqs = read_fasta(src)
+    reads = str(tmp_path / "many.fa")
+    with open(reads, "wb") as fo:
+        for k in range(24):
+            for n, s in zip(names, seqs):
+                fo.write(b">" + n + b"_c%d\n" % k + s + b"\n")
+    fa = os.path.join(golden_dir, "genome.fa")
+    plain = str(tmp_path / "plain.sam")
+    r = run(cli, "--search", fa, "--seq", reads, "--noSamHeader", "-o", plain, "-t", "4")
+    assert r.returncode == 0, r.stderr.decode()
+    want = open(plain, "rb").read()
+    assert len(want) > (8 << 20) and want.count(b"\n") >= 24 * len(names)
+    appended = str(tmp_path / "appended.sam")
+    with open(appended, "wb") as fo:
+        fo.write(b"@CO\tsomething that was there before\n")
+    with open(appended, "ab") as fo:
+        r = subprocess.run([cli, "--search", fa, "--seq", reads, "--noSamHeader", "-t", "4"], stdout=fo, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()
+    assert open(appended, "rb").read() == b"@CO\tsomething that was there before\n" + want

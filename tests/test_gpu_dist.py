@@ -84,22 +84,24 @@ def one_rank_line(bench_dir):
 def test_bench_one_rank_reports_both_boundaries(one_rank_line):
     j = one_rank_line
     assert j["n_gpus"] == 1 and j["scaling"] == "weak" and j["value"] > 0
-    assert j["value_pcie_inclusive"] > 0 and "HBM" in j["config"]["io"]
+    # N = 1: `value` is the host boundary; the HBM-resident rate is reported next to it
+    assert j["value_host_boundary"] == j["value"] and j["value_hbm_resident"] > 0 and "host memory" in j["config"]["io"]
+    assert j["roofline"]["kernel"] in j["roofline"]["by_kernel"] and j["roofline"]["by_kernel"][j["roofline"]["kernel"]]["single_kernel"]
     assert j["roofline"]["frac"] > 0 and j["roofline"]["by_kernel"]["lf_ksw_kernel"]["algorithmic_GB_per_step"] >= 0
 
 
 def test_bench_strong_scaling_two_ranks_same_records(bench_dir, one_rank_line):
     """BASELINE config C3 in miniature: the SAME read set cut by bases over 2 ranks, scattered from and gathered to rank 0
     through PipelinedExchange (gloo hook: both ranks on GPU 0), must leave rank 0 with the 1-rank records, byte for byte"""
-    j = _bench(bench_dir, "--gpus", "2", "--scaling", "strong", backend="gloo")
-    assert j["n_gpus"] == 2 and j["scaling"] == "strong"
+    j = _bench(bench_dir, "--gpus", "2", backend="gloo")                 # N > 1 defaults to strong scaling (config C3)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value_weak_hbm_resident"] > 0
     assert j["exchange"]["status"] == "ok" and j["exchange"]["GB_in_per_step"] > 0
     assert j["sam_md5"] == one_rank_line["sam_md5"] and j["sam_bytes"] == one_rank_line["sam_bytes"]
-    assert j["value"] > 0 and j["value_without_exchange"] > 0
+    assert j["value"] > 0 and j["value_hbm_resident"] > 0
 
 
 def test_bench_weak_scaling_three_ranks(bench_dir, one_rank_line):
-    j = _bench(bench_dir, "--gpus", "3", backend="gloo")
+    j = _bench(bench_dir, "--gpus", "3", "--scaling", "weak", backend="gloo")
     assert j["n_gpus"] == 3 and j["scaling"] == "weak" and j["config"]["reads_total"] == 1800
     assert j["exchange"]["status"] == "ok"
     assert j["sam_bytes"] > 2.5 * one_rank_line["sam_bytes"]          # three different shards, rank 0's first

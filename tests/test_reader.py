@@ -168,3 +168,113 @@ def test_mapped_fasta_reader_many_threads_equals_sequential(tmp_path, monkeypatc
     monkeypatch.setenv("LF_READER_SEQUENTIAL", "1")
     got = [(n, s, q) for names, seqs, quals in la.read_file(path) for n, s, q in zip(names, seqs, quals)]
     assert got == exp
+
+
+def _bgzf(data: bytes, block: int = 0xff00) -> bytes:
+    """what bgzip writes: gzip members with a 'BC' extra subfield holding the member's size - 1, then the 28-byte end marker"""
+    import struct
+    import zlib
+    out = []
+    for a in list(range(0, len(data), block)) + [None]:
+        chunk = data[a:a + block] if a is not None else b""
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        bsize = 12 + 6 + len(body) + 8
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+                   + body + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+    return b"".join(out)
+
+
+def _big_fastq(total_bytes: int, seed: int, crlf_every: int = 0):
+    rng = np.random.default_rng(seed)
+    parts, recs, total, i = [], [], 0, 0
+    qa = np.frombuffer(bytes(range(33, 74)), dtype=np.uint8)
+    while total < total_bytes:
+        n = int(rng.integers(1, 40000))
+        s = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=n))
+        q = bytearray(rng.choice(qa, size=n).tobytes())
+        if i % 5 == 0:
+            q[0] = ord("@")                              # a quality line that starts like a header
+        if i % 7 == 0:
+            q[0] = ord("+")
+        q = bytes(q)
+        eol = b"\r\n" if (crlf_every and i % crlf_every == 0) else b"\n"
+        name = b"q%d" % i
+        parts.append(b"@" + name + (b" a comment @ with signs" if i % 3 == 0 else b"") + eol + s + eol + b"+" + (name if i % 4 == 0 else b"") + eol + q + eol
+                     + (b"\n" if i % 13 == 0 else b""))
+        recs.append((name, s, q))
+        total += len(parts[-1]); i += 1
+    return b"".join(parts), recs
+
+
+@pytest.mark.parametrize("container", ["plain", "bgzf", "gz", "gz_multi_member"])
+def test_window_parser_fastq_all_containers(tmp_path, container):
+    """four-line FASTQ larger than the multi-thread threshold: the window parser (pieces cut at record starts -- a quality line
+    may begin with '@' or '+'), the BGZF block inflater and the one-stream gzip path all give kseq's records, also under
+    read-only / base-only batch limits"""
+    import lordfast_amd as la
+    data, recs = _big_fastq(12_000_000, 5, crlf_every=9)
+    assert kseq_python(data[:400_000])[:5] == recs[:5]            # the generator and the grammar statement agree
+    path = str(tmp_path / ("reads.fq" + ("" if container == "plain" else ".gz")))
+    with open(path, "wb") as fh:
+        if container == "plain":
+            fh.write(data)
+        elif container == "bgzf":
+            fh.write(_bgzf(data))
+        elif container == "gz":
+            fh.write(gzip.compress(data, 1))
+        else:
+            cut = [0, 1_000_003, 5_000_001, len(data)]
+            fh.write(b"".join(gzip.compress(data[a:b], 1) for a, b in zip(cut, cut[1:])))
+    for kw in (dict(), dict(batch_reads=41), dict(batch_bases=2_000_000)):
+        batches = la.read_file(path, **kw)
+        got = [(n, s, q) for names, seqs, quals in batches for n, s, q in zip(names, seqs, quals)]
+        assert got == recs, (container, kw)
+        if "batch_reads" in kw:
+            assert all(len(b[0]) == 41 for b in batches[:-1])
+        if "batch_bases" in kw:
+            assert all(sum(len(x) for x in b[1]) >= 2_000_000 for b in batches[:-1])
+
+
+def test_window_parser_hands_wrapped_fastq_to_the_sequential_parser(tmp_path):
+    """a big FASTQ whose later records are wrapped over several lines: the batches before them come from the window parser,
+    the rest from the sequential one -- one record stream, kseq's"""
+    import lordfast_amd as la
+    data, recs = _big_fastq(6_000_000, 8)
+    rng = np.random.default_rng(1)
+    extra = []
+    for i in range(40):
+        n = int(rng.integers(100, 3000))
+        s = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n))
+        q = bytes(rng.integers(35, 60, size=n).astype(np.uint8))                 # no '@' / '+' / '>' in these qualities
+        w = 70
+        extra.append(b"@w%d\n" % i + b"\n".join(s[k:k + w] for k in range(0, n, w)) + b"\n+\n" + b"\n".join(q[k:k + w] for k in range(0, n, w)) + b"\n")
+        recs.append((b"w%d" % i, s, q))
+    data += b"".join(extra)
+    assert kseq_python(data) == recs
+    for gz in (False, True):
+        path = str(tmp_path / ("mixed.fq" + (".gz" if gz else "")))
+        with open(path, "wb") as fh:
+            fh.write(_bgzf(data) if gz else data)
+        got = [(n, s, q) for names, seqs, quals in la.read_file(path, batch_reads=100) for n, s, q in zip(names, seqs, quals)]
+        assert got == recs, gz
+
+
+def test_window_parser_reads_only_limit_parses_a_batch_not_the_file(tmp_path):
+    """a batch limited by reads only (lf_reads_next(max_reads = N, max_bases = 0)) must cost O(batch), not O(rest of the file):
+    300 batches of a 60 MB FASTA in well under the time one pass per batch would take"""
+    import time
+    import lordfast_amd as la
+    rng = np.random.default_rng(2)
+    body = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=200))
+    n = 300_000
+    data = b"".join(b">s%d\n" % i + body + b"\n" for i in range(n))
+    path = str(tmp_path / "short.fa")
+    with open(path, "wb") as fh:
+        fh.write(data)
+    t0 = time.time()
+    batches = la.read_file(path, batch_reads=1000)
+    dt = time.time() - t0
+    assert len(batches) == 300 and all(len(b[0]) == 1000 for b in batches)
+    assert batches[-1][0][-1] == b"s%d" % (n - 1) and batches[17][1][5] == body
+    assert dt < 20, dt           # quadratic behaviour (every batch parses the rest of the file) takes minutes here
