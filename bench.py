@@ -67,6 +67,10 @@ def parse():
                          "--segdups of them pasted into the genome): those reads have several near-equal candidate windows, so mapSeq "
                          "takes its fine branch (src/LordFAST.cpp:542-562) and -n windows are chained and extended.  c4 default 0.3, else 0")
     ap.add_argument("--segdups", type=int, default=2000, help="duplicated segments in the genome when --dup-frac > 0")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="steps in flight at once (threads calling the library concurrently; its lane allocator shares the device's 8 lanes "
+                         "between them).  1 = one step after the other.  Small shards (a rank's share under strong scaling) are bound by the "
+                         "latency of a chunk's launch chain, which the next steps' kernels hide; every step is still a complete call")
     ap.add_argument("--mode", choices=["ranks", "inproc"], default="ranks",
                     help="ranks: one process per GPU (torch.distributed); inproc: ONE process drives N devices through lf_map_batch_multi "
                          "(chunks pulled from one counter; every device copies through its own PCIe link)")
@@ -353,7 +357,8 @@ def main():
 
     # SAM buffers, reused by every step.  dev_out: HBM (value); host_out: pinned host memory (PCIe-inclusive rate)
     per_rank_reads = max(len(seqs), -(-n_total // world))
-    cap_one = int(3.0 * max(bases_local, per_rank_reads * args.read_len) * 1.1) + per_rank_reads * 2048 + (1 << 20)
+    # a record is ~1.7 x its read (SEQ + CIGAR + MD); -n > 1 on duplicated reads prints every candidate's record with the full SEQ
+    cap_one = int(3.0 * (1.0 + 4.0 * args.dup_frac) * max(bases_local, per_rank_reads * args.read_len) * 1.1) + per_rank_reads * 2048 + (1 << 20)
     read_cap = int(1.25 * max(bases_local, per_rank_reads * args.read_len) * 1.1) + per_rank_reads * 64 + (1 << 20)
     dev_out = torch.empty(cap_one, dtype=torch.uint8, device=dev)
     try:
@@ -394,20 +399,29 @@ def main():
             out[:ln].copy_(dev_out[:ln])
         return ln, st
 
-    def step_hbm():
-        ln, st = map_shard(own, dev_out)
-        return _Sam(dev_out, ln), st
+    # --inflight D: slot j > 0 has output buffers of its own (slot 0: dev_out / host_out)
+    D = max(1, args.inflight)
+    dev_outs = [dev_out] + [torch.empty(cap_one, dtype=torch.uint8, device=dev) for _ in range(D - 1)]
+    host_outs = [host_out] + [torch.empty(cap_one * n_dev, dtype=torch.uint8, pin_memory=True) for _ in range(D - 1)]
 
-    def step_host():
+    def step_hbm(j=0):
         t_call = time.perf_counter()
+        ln, st = lf.map_batch_dev(own.name_array(torch), own.blob.data_ptr(), own.seq_off[:-1], own.seq_lens, dev_outs[j].data_ptr(), dev_outs[j].numel(), True, params=params) \
+            if (j > 0 and own.blob.device.type == "cuda") else map_shard(own, dev_outs[j])
+        st.setdefault("ms_python_call", (time.perf_counter() - t_call) * 1e3)
+        return _Sam(dev_outs[j], ln), st
+
+    def step_host(j=0):
+        t_call = time.perf_counter()
+        ho = host_outs[j]
         if n_dev > 1:
-            ln, st = la.api.map_batch_multi_into(replicas, names, host_out.data_ptr(), host_out.numel(), params=params,
+            ln, st = la.api.map_batch_multi_into(replicas, names, ho.data_ptr(), ho.numel(), params=params,
                                                  name_arr=fixed_arrays[0], seq_arr=fixed_arrays[1], seq_lens=seq_lens)
         else:
-            ln, st = lf.map_batch_into(names, None, host_out.data_ptr(), host_out.numel(), params=params, name_arr=fixed_arrays[0],
+            ln, st = lf.map_batch_into(names, None, ho.data_ptr(), ho.numel(), params=params, name_arr=fixed_arrays[0],
                                        seq_arr=fixed_arrays[1], seq_lens=seq_lens)
         st["ms_python_call"] = (time.perf_counter() - t_call) * 1e3
-        return _Sam(host_out, ln), st
+        return _Sam(ho, ln), st
 
     def add(agg, st):
         if agg is None:
@@ -416,6 +430,32 @@ def main():
             agg[k] += v
         return agg
 
+    def run_steps(fn, n_steps):
+        """n_steps complete calls, D of them in flight; -> (summed stats, last SAM)"""
+        agg, sam = None, None
+        if D == 1:
+            for _ in range(n_steps):
+                sam, st = fn()
+                agg = add(agg, st)
+        else:
+            # D steps in flight: thread j runs steps j, j + D, ... (the calls release the GIL); EXACTLY n_steps complete calls
+            from concurrent.futures import ThreadPoolExecutor
+
+            def worker(j):
+                a, last = None, None
+                for _k in range(j, n_steps, D):
+                    last, st = fn(j)
+                    a = add(a, st)
+                return a, last
+            with ThreadPoolExecutor(D) as ex:
+                for a, last in ex.map(worker, range(D)):
+                    if a is not None:
+                        for k in ("ms_python_call",):
+                            a.setdefault(k, 0.0)
+                        agg = dict(a) if agg is None else {k: agg.get(k, 0) + v for k, v in a.items()}
+                    sam = sam if sam is not None else last
+        return agg, sam
+
     def timed(fn, n_steps):
         """EXACTLY n_steps steps between barrier + synchronize on both sides; elapsed = max over ranks"""
         if dist:
@@ -423,10 +463,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         cpu0 = sum(os.times()[:4])
-        agg, sam = None, None
-        for _ in range(n_steps):
-            sam, st = fn()
-            agg = add(agg, st)
+        agg, sam = run_steps(fn, n_steps)
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -459,8 +496,8 @@ def main():
 
     # ---- 1. the shard resident in this rank's HBM, SAM text left in HBM, no exchange (`value_hbm_resident`) ----
     hbm_step = step_host if args.mode == "inproc" else step_hbm
-    for _ in range(args.warmup):
-        hbm_step()
+    if args.warmup:
+        run_steps(hbm_step, args.warmup * D)            # every slot in flight warms its lanes' buffers
     elapsed_nx, cpu_s_hbm, agg_hbm, sam_hbm = timed(hbm_step, args.steps)
     snap_hbm = digest(sam_hbm) if (rank == 0 and world == 1 and not args.no_exclusive) else None
     # ---- 2. the same steps through the host-buffer boundary the reference has: reads in host memory -> SAM records in host memory
@@ -468,8 +505,7 @@ def main():
     elapsed_host = cpu_s_host = agg_host = sam_host = None
     snap_host = head_host = None
     if args.mode != "inproc" and not args.no_host_region:
-        for _ in range(max(1, args.warmup)):
-            step_host()
+        run_steps(step_host, max(1, args.warmup) * D)
         elapsed_host, cpu_s_host, agg_host, sam_host = timed(step_host, args.steps)
         if rank == 0 and world == 1:
             # the records the TIMED steps wrote, before anything else runs: a digest of all of them and the head that is compared with the reference
@@ -497,7 +533,7 @@ def main():
         if stage_in is not None and stage_in.numel() < wshard.nbytes:
             stage_in = torch.empty(wshard.nbytes + (1 << 20), dtype=torch.uint8, device=dev)
         del wn, ws
-        def step_weak():
+        def step_weak(j=0):
             ln, st = map_shard(wshard, wout)
             return _Sam(wout, ln), st
         step_weak()
@@ -632,6 +668,7 @@ def main():
                          "chain_requests": agg["n_chain_problems"] / per_rank, "tie_requests": agg["n_tie_requests"] / per_rank,
                          "ksw_problems": agg["n_ksw_problems"] / per_rank},
             "roofline": roofline,
+            "steps_in_flight": D,
             "source_tree": tree_hash(),      # digest of lordfast_amd/csrc: which kernels produced this line
         }
         # every region that was timed, under its own name

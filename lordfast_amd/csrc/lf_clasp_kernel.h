@@ -34,9 +34,11 @@
 #include "lf_gpu_common.h"
 #include "lf_chain_kernel.h"
 #include <float.h>
-#include <hipcub/hipcub.hpp>
 #include <type_traits>
 
+/* one wavefront per workgroup: a hand-over between its lanes needs the outstanding LDS / memory operations to be complete (the
+ * fence's wait counters) and no motion of accesses across it -- not an s_barrier */
+#define LF_CLASP_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 #define LF_CLASP_BYTES_PER_FRAG 200u       /* HBM working set per fragment (32-bit ranks), see lf_clasp_carve */
 #define LF_CLASP_LDS_BYTES_PER_FRAG 136u   /* LDS working set per fragment (16-bit ranks, keys aliased) */
 #define LF_CLASP_LDS_MAX 1024u             /* windows up to this many fragments work in LDS (136 KiB) */
@@ -53,6 +55,7 @@ struct lf_clasp_mem {
     R *entyA, *entfA, *entyB, *entfB;
     int *keys;                    /* keys[k * N + point]; 16-bit ranks: aliases tr + ent* (dead once the ranks exist) */
     R *sorted;                    /* sorted[k * N + rank] = point; aliases prioA/prioB (dead before the sweep) */
+    uint32_t *ring; int ring_cap; /* pending ranges of the breadth-first sort; aliases chain_scr / best_scr (dead while a cluster is sorted) */
 };
 
 template <class R>
@@ -77,6 +80,7 @@ __device__ __forceinline__ void lf_clasp_carve(lf_clasp_mem<R> &m, unsigned char
     }
     m.entfA = m.entyA + N; m.entyB = m.entfA + N; m.entfB = m.entyB + N;
     m.sorted = reinterpret_cast<R *>(m.prioA);
+    m.ring = reinterpret_cast<uint32_t *>(m.chain_scr); m.ring_cap = (int)(4 * cap);      /* 2 * cap doubles = 4 * cap entries >= 4 arrays x N / 2 ranges */
 }
 
 /* D(a,b) of lib/clasp/slchain.h:40 */
@@ -115,6 +119,51 @@ __device__ __forceinline__ void lf_clasp_qsort(R *sorted, const int *keys, int s
     }
 }
 
+/* The same sort, replayed BREADTH-FIRST by the whole wavefront (16-bit instantiation: at most 2^15 elements per array).
+ * quickSort's result does not depend on the order in which its pending sub-ranges are processed -- they are disjoint, and a
+ * partition step only looks at its own range -- so instead of one lane walking the recursion (N log N dependent LDS round
+ * trips) every pending range gets a lane of its own: a FIFO ring of (array, left, right) entries, 64 ranges partitioned per
+ * round with the reference's own Hoare loop, children appended behind.  The longest range of a round bounds its time:
+ * ~2 N steps for the whole sort.  `n_arr` arrays of `size` elements, array a at sorted + a * stride / keys + a * stride, are
+ * sorted together.  ring: 2 * n_arr * size / 2 entries at most are ever pending (ranges of >= 2 elements are disjoint). */
+template <class R>
+__device__ __forceinline__ void lf_clasp_qsort_bf(R *sorted, const int *keys, int size, int n_arr, int stride, uint32_t *ring, int ring_cap, int lane)
+{
+    if (size < 2) return;
+    if (lane < n_arr) ring[lane] = ((uint32_t)lane << 30) | (uint32_t)(size - 1);       /* (array, left = 0, right = size - 1) */
+    int head = 0, cnt = n_arr;                                     /* wave-uniform */
+    const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    while (cnt > 0) {
+        LF_CLASP_SYNC();
+        const int take = cnt < 64 ? cnt : 64;
+        int c0 = 0, c1 = 0; uint32_t e0 = 0, e1 = 0;
+        if (lane < take) {
+            int idx = head + lane; if (idx >= ring_cap) idx -= ring_cap;
+            const uint32_t e = ring[idx];
+            const int a = (int)(e >> 30), left = (int)((e >> 15) & 0x7fffu), right = (int)(e & 0x7fffu);
+            R *sd = sorted + a * stride; const int *ky = keys + a * stride;
+            const int xk = ky[sd[(left + right) >> 1]];
+            int l2 = left, r2 = right;
+            do {
+                while (ky[sd[l2]] < xk) l2++;
+                while (ky[sd[r2]] > xk) r2--;
+                if (l2 <= r2) { const R t = sd[r2]; sd[r2] = sd[l2]; sd[l2] = t; l2++; r2--; }
+            } while (r2 >= l2);
+            if (left < r2) { c0 = 1; e0 = ((uint32_t)a << 30) | ((uint32_t)left << 15) | (uint32_t)r2; }
+            if (l2 < right) { c1 = 1; e1 = ((uint32_t)a << 30) | ((uint32_t)l2 << 15) | (uint32_t)right; }
+        }
+        const uint64_t b0 = lf_ballot(c0 != 0), b1 = lf_ballot(c1 != 0);
+        const int n0 = __popcll(b0), n1 = __popcll(b1);
+        head += take; if (head >= ring_cap) head -= ring_cap;
+        cnt -= take;
+        int tail = head + cnt; if (tail >= ring_cap) tail -= ring_cap;
+        if (c0) { int w = tail + __popcll(b0 & below); if (w >= ring_cap) w -= ring_cap; ring[w] = e0; }
+        if (c1) { int w = tail + n0 + __popcll(b1 & below); if (w >= ring_cap) w -= ring_cap; if (w >= ring_cap) w -= ring_cap; ring[w] = e1; }
+        cnt += n0 + n1;
+    }
+    LF_CLASP_SYNC();
+}
+
 /* one candidate of a range-tree node: the entry with the greatest (prio, y-rank) below the query's y-rank */
 struct lf_clasp_cand { double pr; uint32_t ey, ix; };
 struct lf_clasp_better {
@@ -124,22 +173,58 @@ struct lf_clasp_better {
         return take_b ? b : a;
     }
 };
-/* wavefront arg-max, result valid in lane 0 (rocPRIM moves the four dwords with DPP row shifts / broadcasts instead of
- * LDS-crossbar permutes) */
-typedef hipcub::WarpReduce<lf_clasp_cand, 64> lf_clasp_wreduce;
+/* wavefront maximum of an unsigned, in every lane: DPP row shifts + row broadcasts (no LDS), then one readlane */
+__device__ __forceinline__ uint32_t lf_clasp_wave_max_u32(uint32_t v)
+{
+    uint32_t x = v;
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));      /* row_shr:1 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));      /* row_shr:2 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));      /* row_shr:4 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));      /* row_shr:8 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));      /* row_bcast:15 -> rows 1, 3 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));      /* row_bcast:31 -> rows 2, 3 */
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+/* wavefront arg-max of (prio, y-rank), lexicographic, over the lanes that hold a candidate; the winner's prio and entry index
+ * come back in every lane.  Three 32-bit maxima (high word of the order-preserving image of the double, low word among the
+ * lanes that tie on it, y-rank among those) instead of a generic reduction of a 16-byte struct: y-ranks are distinct, so one
+ * lane is left. */
+__device__ __forceinline__ bool lf_clasp_wave_best(bool cand, double pr, uint32_t ey, uint32_t ix, double &wpr, uint32_t &wix)
+{
+    if (lf_ballot(cand) == 0) return false;
+    uint64_t k = (uint64_t)__double_as_longlong(pr + 0.0);
+    k = (k >> 63) ? ~k : (k | 0x8000000000000000ull);               /* a < b  <=>  image(a) < image(b) */
+    /* (every maximum is taken by ALL lanes, outside the && : a DPP move that only some lanes execute reads stale registers of the others) */
+    const uint32_t hi = cand ? (uint32_t)(k >> 32) : 0u;
+    const uint32_t hmax = lf_clasp_wave_max_u32(hi);
+    const bool c2 = cand && hi == hmax;
+    const uint32_t lo = c2 ? (uint32_t)k : 0u;
+    const uint32_t lmax = lf_clasp_wave_max_u32(lo);
+    const bool c3 = c2 && lo == lmax;
+    const uint32_t e = c3 ? ey + 1u : 0u;
+    const uint32_t emax = lf_clasp_wave_max_u32(e);
+    const bool c4 = c3 && e == emax;
+    const int src = __ffsll((long long)lf_ballot(c4)) - 1;
+    const uint64_t pb = (uint64_t)__double_as_longlong(pr);
+    const uint32_t ph = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pb >> 32), src), pl = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pb, src);
+    wpr = __longlong_as_double((long long)(((uint64_t)ph << 32) | pl));
+    wix = (uint32_t)__builtin_amdgcn_readlane((int)ix, src);
+    return true;
+}
 
-/* per-query scratch of one tree walk: the winners of the canonical nodes, root to leaf (at most ~log2 N + 1) */
+/* per-query scratch of one tree walk: what lane 0 needs of the canonical nodes' winners, root to leaf (at most ~log2 N + 1) */
 #define LF_CLASP_MAX_NODES 40
 struct lf_clasp_nodes {
     double pr[LF_CLASP_MAX_NODES], cmp[LF_CLASP_MAX_NODES], nw[LF_CLASP_MAX_NODES];
-    int ix[LF_CLASP_MAX_NODES], tf[LF_CLASP_MAX_NODES], first[LF_CLASP_MAX_NODES];
-    lf_clasp_wreduce::TempStorage wr;
+    int tf[LF_CLASP_MAX_NODES], first[LF_CLASP_MAX_NODES];
 };
 
 /* bl_slChainSopRMQ (slchain.c:841-912) for the start point of fragment `cur`; returns the chosen chain or -1 (lane 0).
- * Three phases: (A) every canonical node, root to leaf: strided scan + wavefront arg-max, winner parked in LDS;
- * (B) lane k evaluates node k's winner -- gap cost, the test of :877 and both score expressions -- all nodes at once;
- * (C) lane 0 applies the side effects and picks the result in node order, which is all that has to be sequential. */
+ * Three phases: (A) every canonical node, root to leaf: strided scan + wavefront arg-max, node K's winner parked in lane K's
+ * registers; (B) lane k evaluates node k's winner -- gap cost, the test of :877 and both score expressions -- all nodes at
+ * once; (C) lane 0 applies the side effects and picks the result in node order, which is all that has to be sequential.
+ * One wavefront works on a window and LDS operations of a wavefront complete in order: a wave-level fence orders the
+ * hand-over (B) -> (C), no workgroup barrier. */
 template <class R>
 __device__ __forceinline__ int lf_clasp_rmq(const lf_clasp_mem<R> &m, const R *enty, const R *entf, const double *prio,
                                    int N, uint32_t x, uint32_t y, int cur, int lane, lf_clasp_nodes *nd)
@@ -147,6 +232,7 @@ __device__ __forceinline__ int lf_clasp_rmq(const lf_clasp_mem<R> &m, const R *e
     const int cs = m.fp[cur], cq = m.fq[cur]; const double cscr = (double)m.fl[cur];
     int K = 0;
     int s = 0, cnt = N;
+    double my_pr = 0; uint32_t my_ix = 0;
     while (cnt > 0) {
         int lo, len;
         if (cnt == 1) {                         /* leaf: its own map, then right == NULL / left == NULL */
@@ -160,29 +246,26 @@ __device__ __forceinline__ int lf_clasp_rmq(const lf_clasp_mem<R> &m, const R *e
         double pr = 0; uint32_t ey = LF_CLASP_NONE, ix = 0;
         for (int k = lo + lane; k < lo + len; k += 64) {
             const uint32_t e = enty[k];            /* an unset entry is (R)~0: never below a rank */
-            if (e < y) {
-                const double p2 = prio[k];
-                if (ey == LF_CLASP_NONE || p2 > pr || (p2 == pr && e > ey)) { pr = p2; ey = e; ix = (uint32_t)k; }
-            }
+            const double p2 = prio[k];             /* (both loads are issued together) */
+            if (e < y && (ey == LF_CLASP_NONE || p2 > pr || (p2 == pr && e > ey))) { pr = p2; ey = e; ix = (uint32_t)k; }
         }
-        if (lf_ballot(ey != LF_CLASP_NONE) == 0) continue;
-        lf_clasp_cand cd; cd.pr = pr; cd.ey = ey; cd.ix = ix;
-        cd = lf_clasp_wreduce(nd->wr).Reduce(cd, lf_clasp_better());
-        if (lane == 0) { nd->pr[K] = cd.pr; nd->ix[K] = (int)cd.ix; }
+        double wpr; uint32_t wix;
+        if (!lf_clasp_wave_best(ey != LF_CLASP_NONE, pr, ey, ix, wpr, wix)) continue;
+        if (lane == K) { my_pr = wpr; my_ix = wix; }
         K++;
     }
     if (K == 0) return -1;
-    __syncthreads();
     if (lane < K) {
-        const int tf = (int)entf[nd->ix[lane]];
+        const int tf = (int)entf[my_ix];
         const double g = lf_clasp_gsop(cs, cq, m.fp[tf] + m.fl[tf] - 1, m.fq[tf] + m.fl[tf] - 1);
         const double cscr_tf = m.chain_scr[tf];
+        nd->pr[lane] = my_pr;
         nd->tf[lane] = tf;
         nd->first[lane] = (cscr >= g) ? m.chain_first[tf] : -1;                        /* :877 */
         nd->cmp[lane] = cscr + cscr_tf - g;                                            /* :884 */
         nd->nw[lane] = cscr_tf + (cscr - g);                                           /* :890 */
     }
-    __syncthreads();
+    LF_CLASP_SYNC();
     int res = -1;
     if (lane == 0) {
         double resprio = -DBL_MAX;
@@ -192,6 +275,7 @@ __device__ __forceinline__ int lf_clasp_rmq(const lf_clasp_mem<R> &m, const R *e
             if (nd->pr[k] > resprio) { res = tf; resprio = nd->pr[k]; }                /* :898 */
         }
     }
+    LF_CLASP_SYNC();
     return res;
 }
 
@@ -203,8 +287,25 @@ __device__ __forceinline__ void lf_clasp_chain_sop(const lf_clasp_mem<R> &m, int
     const int xmin = m.fp[cb];
     /* ---- bl_slExtractPoints: fragment ends sorted with clasp's quickSort, merged with the starts ---- */
     for (int i = lane; i < cm; i += 64) { m.sorted[i] = (R)i; m.keys[i] = m.fp[cb + i] + m.fl[cb + i] - 1 - xmin; m.best_base[cb + i] = -1; m.prev[cb + i] = -1; }
-    __syncthreads();
-    if (lane == 0) {
+    LF_CLASP_SYNC();
+    if (sizeof(R) == 2) {
+        lf_clasp_qsort_bf(m.sorted, m.keys, cm, 1, 0, m.ring, m.ring_cap, lane);
+        /* the merge of slchain.c:49-90 emits, in front of start a, every end (in sorted order) that lies before it: the place of
+         * a point is its rank in its own list + the number of points of the other list in front of it -- two binary searches
+         * per fragment instead of one lane walking both lists (starts are in target order: the fragments arrive sorted) */
+        for (int i = lane; i < cm; i += 64) {
+            const int a = cb + i, sa = m.fp[a] - xmin;
+            int lo = 0, hi = cm;                                   /* ends with end < start_a */
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (m.keys[m.sorted[mid]] < sa) lo = mid + 1; else hi = mid; }
+            const int np = i + lo;
+            m.px[np] = m.fp[a]; m.py[np] = m.fq[a]; m.pidx[np] = (a << 1) | 1;
+            const int b = cb + (int)m.sorted[i], eb = m.keys[m.sorted[i]] + xmin;
+            lo = 0; hi = cm;                                       /* starts with start <= end_b */
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (m.fp[cb + mid] <= eb) lo = mid + 1; else hi = mid; }
+            const int nq = i + lo;
+            m.px[nq] = eb; m.py[nq] = m.fq[b] + m.fl[b] - 1; m.pidx[nq] = b << 1;
+        }
+    } else if (lane == 0) {
         lf_clasp_qsort(m.sorted, m.keys, cm);
         int np = 0, j = 0;
         for (int i = 0; i < cm; i++) {
@@ -220,7 +321,7 @@ __device__ __forceinline__ void lf_clasp_chain_sop(const lf_clasp_mem<R> &m, int
             m.px[np] = m.fp[b] + m.fl[b] - 1; m.py[np] = m.fq[b] + m.fl[b] - 1; m.pidx[np] = b << 1; np++; j++;
         }
     }
-    __syncthreads();
+    LF_CLASP_SYNC();
     /* ---- bl_slGetTrans: four orders of the points (comparators slchain.c:452-559 folded into int keys) ---- */
     for (int i = lane; i < N; i += 64) {
         const int x = m.px[i] - xmin, y = m.py[i], st = m.pidx[i] & 1;
@@ -230,9 +331,10 @@ __device__ __forceinline__ void lf_clasp_chain_sop(const lf_clasp_mem<R> &m, int
         m.keys[3 * N + i] = (y - x) * 2 + st;       /* T2.y = y - x, end points first */
         m.sorted[i] = m.sorted[N + i] = m.sorted[2 * N + i] = m.sorted[3 * N + i] = (R)i;
     }
-    __syncthreads();
-    if (lane < 4) lf_clasp_qsort(m.sorted + lane * N, m.keys + lane * N, N);
-    __syncthreads();
+    LF_CLASP_SYNC();
+    if (sizeof(R) == 2) lf_clasp_qsort_bf(m.sorted, m.keys, N, 4, N, m.ring, m.ring_cap, lane);
+    else if (lane < 4) lf_clasp_qsort(m.sorted + lane * N, m.keys + lane * N, N);
+    LF_CLASP_SYNC();
     for (int r = lane; r < N; r += 64) {
         uint32_t rk[4];
 #pragma unroll
@@ -241,9 +343,9 @@ __device__ __forceinline__ void lf_clasp_chain_sop(const lf_clasp_mem<R> &m, int
         for (int k = 0; k < 4; k++) m.tr[k * N + rk[k]] = (R)r;
     }
     const int ta = m.px[m.sorted[2 * N + N - 1]], tb = m.py[m.sorted[N + N - 1]];     /* t.a, t.b :703-706 */
-    __syncthreads();
+    LF_CLASP_SYNC();
     for (int i = lane; i < N; i += 64) { m.entyA[i] = (R)~(R)0; m.entyB[i] = (R)~(R)0; }
-    __syncthreads();
+    LF_CLASP_SYNC();
     /* ---- the sweep over the points ---- */
     for (int t = 0; t < N; t++) {
         const int pi = m.pidx[t], cur = pi >> 1;
@@ -285,7 +387,7 @@ __device__ __forceinline__ void lf_clasp_chain_sop(const lf_clasp_mem<R> &m, int
             m.prioA[t0] = scr - g1; m.entfA[t0] = (R)cur; m.entyA[t0] = (R)t1;
             m.prioB[t2] = scr - g2; m.entfB[t2] = (R)cur; m.entyB[t2] = (R)t3;
         }
-        __syncthreads();
+        LF_CLASP_SYNC();
     }
 }
 
@@ -315,7 +417,7 @@ lf_clasp_kernel(const lf_chain_win *__restrict__ wins, int n_wins, const uint32_
     const uint32_t sh = shift ? shift[w.id] : 0u;
     const uint32_t *sd = seeds + 2 * w.off;
     for (int i = lane; i < n; i += 64) { const uint32_t qpl = sd[2 * i + 1]; m.fp[i] = (int)(sd[2 * i] - sh); m.fq[i] = (int)(qpl & 0xFFFFF); m.fl[i] = (int)(qpl >> 20); }
-    __syncthreads();
+    LF_CLASP_SYNC();
 
     /* bl_slClusterSop (slchain.c:568-655): lane 0 scans, every cluster is chained as soon as it closes.  The scan
      * state is NOT reset at a cluster boundary (neither does the reference). */
@@ -354,7 +456,7 @@ lf_clasp_kernel(const lf_chain_win *__restrict__ wins, int n_wins, const uint32_
             for (int j = begin; j <= end; j++)
                 if (m.best_base[j] >= 0 && m.best_scr[j] > (double)bestScore) { bestScore = (float)m.best_scr[j]; bestFrag = j; }
         }
-        __syncthreads();
+        LF_CLASP_SYNC();
         begin = end + 1;
     }
     if (lane == 0) {

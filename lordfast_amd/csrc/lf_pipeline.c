@@ -202,6 +202,7 @@ typedef struct {
 
 typedef struct job {
     int read, widx;        /* owning read, slot in that read's mapping list */
+    int req;               /* chain request whose chain this window is aligned with (its own, or -- clasp, window without seeds -- a stale one) */
     int isRev;
     Seed_t *chain; uint32_t chainLen;
     memo_t *memo; int nmemo, capmemo;
@@ -1549,9 +1550,20 @@ static void phase_make_jobs(ctx_t *cx, int tid, int ri)
     if (r->mode < 2) return;
     r->jobs = (job_t *)ar_zalloc(&cx->arena[tid], ((size_t)r->nWins + 1) * sizeof(job_t));
     r->maps = (samlist_t *)ar_zalloc(&cx->arena[tid], ((size_t)cx->p->max_map + 1) * sizeof(samlist_t));
+    /* clasp, fine mode: chain_seeds_clasp called for a window WITHOUT seeds (all of them in the neighbouring contig) sets the
+     * score to -1 and leaves the previous call's chain in place (src/Chain.cpp:68,92); alignWin (src/LordFAST.cpp:1028-1046)
+     * then extends that stale chain -- the read's previous window, or the last candidate calcChainScore looked at -- on the
+     * window's own strand, and its record is printed once more as a secondary.  Restated: such a window takes the request of
+     * the most recent chain call of this read that had seeds (none before it in the read: thread history in the reference,
+     * empty here; positions above 2 * 10^9, where the reference also adds its shift to the stale chain once more: not restated). */
+    int last_req = -1;
+    if (cx->p->chain_alg == 1 && r->mode == 3 && !cx->host_vote)
+        for (int c = 0; c < r->ncand; c++) if (cx->chain_len[r->cands[c].req] > 0) last_req = r->cands[c].req;
     for (int w = 0; w < r->nWins; w++) {
         job_t *j = &r->jobs[w];
-        const int rq = r->wins[w].req;
+        int rq = r->wins[w].req;
+        if (cx->p->chain_alg == 1 && r->mode == 3 && !cx->host_vote) { if (cx->chain_len[rq] == 0 && last_req >= 0) rq = last_req; else if (cx->chain_len[rq] > 0) last_req = rq; }
+        j->req = rq;
         j->read = ri; j->widx = w; j->isRev = r->wins[w].isReverse;
         j->chainLen = cx->chain_len[rq];
         j->chain = (Seed_t *)ar_alloc(&cx->arena[tid], ((size_t)j->chainLen + 1) * sizeof(Seed_t));
@@ -1813,7 +1825,7 @@ extend:
                 for (int w = 0; w < r->nWins; w++) {
                     job_t *j = &r->jobs[w];
                     if (j->chainLen <= 1) continue;
-                    wj[k].req = (uint32_t)r->wins[w].req; wj[k].read = (uint32_t)r->seed_idx; wj[k].chain_len = j->chainLen; wj[k].is_rev = (uint8_t)j->isRev;
+                    wj[k].req = (uint32_t)j->req; wj[k].read = (uint32_t)r->seed_idx; wj[k].chain_len = j->chainLen; wj[k].is_rev = (uint8_t)j->isRev;
                     wj[k].pad[0] = wj[k].pad[1] = wj[k].pad[2] = 0;
                     owner[k++] = j;
                 }
@@ -2088,7 +2100,34 @@ static void chunk_free(ctx_t *cx)
     free(cx->rrbase); cx->rrbase = NULL; cx->rtext = NULL; cx->roffs = NULL;
 }
 
-static pthread_mutex_t g_map_lock = PTHREAD_MUTEX_INITIALIZER;     /* the worker pool and the lanes serve one batch at a time */
+/* Several batches may be mapped at once (calls from different threads): a call's lane drivers take LANE IDS -- the key of
+ * the per-lane device slots, streams, arenas and pool job slot -- from one process-wide allocator, lowest free id first, and
+ * give them back when they run out of chunks.  `cap` bounds the ids in use at a time (8 per device: every id owns a few GB of
+ * grow-only working memory in HBM), so a second large batch waits for lanes of the first instead of doubling the working
+ * set, while small batches (a rank's 12 k-read shards under strong scaling) overlap: the launch / sync chain of one hides
+ * behind the kernels of the others. */
+static pthread_mutex_t g_lanes_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_lanes_cv = PTHREAD_COND_INITIALIZER;
+static unsigned g_lanes_used;                    /* bit l: lane id l is taken */
+static int g_active_calls;                       /* batches inside map_batch_core (the pool is only resized when there is none) */
+/* next / n0: the batch's chunk cursor -- a driver that would only find its batch's chunks all taken gives up (-1) instead of
+ * waiting for a lane another batch holds */
+static int lane_acquire(int cap, volatile int *next, int n0)
+{
+    pthread_mutex_lock(&g_lanes_mu);
+    for (;;) {
+        if (next && *next >= n0) { pthread_mutex_unlock(&g_lanes_mu); return -1; }
+        if (__builtin_popcount(g_lanes_used) < cap) for (int l = 0; l < LF_MAX_LANES; l++) if (!(g_lanes_used & (1u << l))) { g_lanes_used |= 1u << l; pthread_mutex_unlock(&g_lanes_mu); return l; }
+        pthread_cond_wait(&g_lanes_cv, &g_lanes_mu);
+    }
+}
+static void lane_release(int lane)
+{
+    pthread_mutex_lock(&g_lanes_mu);
+    g_lanes_used &= ~(1u << lane);
+    pthread_cond_broadcast(&g_lanes_cv);
+    pthread_mutex_unlock(&g_lanes_mu);
+}
 
 /* ---- a batch is cut into chunks; two lane threads pull chunks and run them through map_chunk.  While one lane waits
  * for the GPU the other lane's host phases keep the cores busy.  SAM text is written in chunk order. ---- */
@@ -2099,7 +2138,8 @@ typedef struct {
     const char *const *names, *const *seqs, *const *quals; const uint32_t *lens;
     const unsigned char *d_seqs, *d_quals; const uint64_t *src_off; int dev_out;     /* lf_map_batch_dev: bases / qualities / SAM text in HBM */
     int32_t **stage_sink;                       /* lf_map_stages_batch */
-    int slots;                                  /* per-worker scratch slots = pool workers + 2 drivers */
+    int slots;                                  /* per-worker scratch slots = pool workers + lane ids */
+    int lane_cap;                               /* lane ids this process may have in use while this batch takes one (lane_acquire) */
     chunk_t *chunks; int n_chunks, n_chunks0; volatile int next_chunk;   /* n_chunks0: entries cut up front; n_chunks grows when a lane cuts a chunk */
     pthread_mutex_t mu; pthread_cond_t cv;      /* chunk sizes become known in any order */
     pthread_rwlock_t grow;                      /* writers of SAM text hold it shared; growing the buffer exclusive */
@@ -2200,7 +2240,9 @@ static void fetch_dev_sam(batch_t *B, const lf_index_t *ix, uint64_t base, uint6
 static void *lane_main(void *arg_)
 {
     batch_t *B = (batch_t *)((void **)arg_)[0];
-    const int lane = (int)(intptr_t)((void **)arg_)[1];
+    const int held = (int)(intptr_t)((void **)arg_)[1];
+    const int lane = held ? held - 1 : lane_acquire(B->lane_cap, &B->next_chunk, B->n_chunks0);
+    if (lane < 0) return NULL;
     const int timing = getenv("LF_TIMING") != NULL;
     lfg_set_lane(lane);
     const long long lane_c0 = g_phase_on ? thread_cpu_ns() : 0;
@@ -2324,6 +2366,7 @@ static void *lane_main(void *arg_)
         st->ms_sam += now_ms() - t0;
     }
     if (g_phase_on) phase_account("(lane driver threads, incl. their share of the phases)", (thread_cpu_ns() - lane_c0) / 1e6, 0);
+    lane_release(lane);
     return NULL;
 }
 
@@ -2385,8 +2428,6 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     if (nt > 255) nt = 255;
     if (nt < 1) nt = 1;
     const double T0 = now_ms();
-    pthread_mutex_lock(&g_map_lock);
-    g_phase_on = getenv("LF_PHASES") != NULL;
     pthread_once(&g_rc_once, rc_tab_init);
     /* chunks in flight: the host phases of one overlap the GPU phases of the others */
     /* drivers sleep while they wait for the GPU (blocking waits), so small thread budgets still get several chunks in flight */
@@ -2403,12 +2444,19 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     }
     int nw = nt - n_lanes;                             /* pool workers; the lane drivers work too */
     if (nw < nt / 2) nw = nt / 2;                      /* few threads, many (mostly sleeping) drivers: keep half the budget as workers */
-    pool_ensure(nw);
+    if (nw > 220) nw = 220;                            /* worker ids: pool threads, then one per lane id (< 260 in all) */
+    pthread_mutex_lock(&g_lanes_mu);
+    if (g_active_calls == 0 || !g_pool.started) { g_phase_on = getenv("LF_PHASES") != NULL; pool_ensure(nw); }
+    else nw = g_pool.nw;                               /* another batch is being mapped: the pool keeps its size */
+    g_active_calls++;
+    pthread_mutex_unlock(&g_lanes_mu);
+    const int lane_cap = n_lanes > 8 ? n_lanes : 8;
+    const int lane0 = lane_acquire(lane_cap, NULL, 0); /* this thread's lane id: the set-up passes below, then its chunks */
 
     batch_t B; memset(&B, 0, sizeof B);
     B.host_cigar = (g_crosscheck & LF_XC_HOST_CIGAR) != 0;
     B.host_vote = (g_crosscheck & LF_XC_HOST_VOTE) != 0;          /* diagnostic cross-check only; the device stage is the product path */
-    B.ixs = ixs; B.n_ix = n_ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + n_lanes; B.rc = LF_OK;
+    B.ixs = ixs; B.n_ix = n_ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + LF_MAX_LANES; B.rc = LF_OK; B.lane_cap = lane_cap;
     if (dio && dio->stage_sink) B.stage_sink = dio->stage_sink;
     else if (dio) { B.d_seqs = (const unsigned char *)dio->d_seqs; B.d_quals = (const unsigned char *)dio->d_quals; B.src_off = dio->seq_off; B.dev_out = dio->dev_out; }
     pthread_mutex_init(&B.mu, NULL); pthread_cond_init(&B.cv, NULL); pthread_rwlock_init(&B.grow, NULL);
@@ -2424,7 +2472,7 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     B.lens = lens;
     {   /* read lengths once, in parallel; one allocation for the SAM text (~2 x bases + per-record overhead) */
         ctx_t c0; memset(&c0, 0, sizeof c0);
-        c0.n_threads = nw + n_lanes; c0.lane = 0; c0.len_seqs = seqs; c0.len_out = lens;
+        c0.n_threads = nw + LF_MAX_LANES; c0.lane = lane0; c0.len_seqs = seqs; c0.len_out = lens;
         if (seq_lens) {                                               /* the caller knows them (Read.length, src/Reads.h): no pass over the bases */
             memcpy(lens, seq_lens, (size_t)n * 4);
             /* a wrong length would make the device read past a string: the terminator of every read is checked (best effort: the
@@ -2435,7 +2483,8 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
                 lf_set_error("lf_map_batch_into_lens: seq_lens[%d] = %u is not the length of seqs[%d]", i, lens[i], i);
                 free(lens); pthread_rwlock_destroy(&B.grow); pthread_mutex_destroy(&B.mu); pthread_cond_destroy(&B.cv);
                 if (!ext_buf) free(B.all.s);
-                pthread_mutex_unlock(&g_map_lock);
+                lane_release(lane0);
+                pthread_mutex_lock(&g_lanes_mu); g_active_calls--; pthread_mutex_unlock(&g_lanes_mu);
                 return LF_ERR_ARG;
             }
         }
@@ -2456,8 +2505,15 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
          * of 3125 / 6250 / 12500 / 16667 / 25000 / 100000 reads: 0.92 / 1.06 / 1.15-1.22 / 1.19 / 1.19 / 1.13 M reads/s).  Host
          * buffers: THREE -- the 1.5 GB of bases going up and the 4 GB of SAM text coming down per 100 k reads overlap the other
          * chunks' kernels better in smaller pieces (same sweep: 768 / 727 / 673-704 / 733 / 705 / 675 k reads/s). */
-        const int per_lane = (dio && !dio->stage_sink) ? 1 : 3;
-        int want = (n + per_lane * n_lanes - 1) / (per_lane * n_lanes); if (want < 1024) want = 1024;
+        /* round 4 (packed k-mer tables, SEQ-less egress: 1.0 GB instead of 2.6 GB of text comes down per 100 k reads): two per lane
+         * for host batches whose output buffer is pinned (chunks of 4167 / 6250 / 8334 / 12500 / 25000 reads: 123 / 110 / 113 /
+         * 113 / 117 ms per 100 k reads; whole lines: 122 ms at 4167, 136 at 12500).  A chunk's launch / sync chain does not
+         * shrink with the chunk, so small batches get FEWER chunks, not smaller ones: at least 6250 reads each (HBM-resident
+         * 12.5 k reads as 8 / 4 / 2 / 1 chunks: 17.1 / 17.5 / 15.2 / 15.6 ms; 25 k: 27.5 (8) / 26.5 (4) / 27.6 (2); 50 k: 42.0 (8) / 43.9 (4)). */
+        const int dev_in = dio && !dio->stage_sink;
+        const int per_lane = dev_in ? 1 : (B.holes ? 2 : 3);
+        const int min_chunk = (dev_in || B.holes) ? 6250 : 1024;
+        int want = (n + per_lane * n_lanes - 1) / (per_lane * n_lanes); if (want < min_chunk) want = min_chunk;
         if (want < CHUNK_READS) CHUNK_READS = want;
     }
     /* reads x sampling positions is a 31-bit index in the seed stage */
@@ -2475,14 +2531,14 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     wdog_t wd; memset(&wd, 0, sizeof wd); pthread_t wdt; int have_wd = 0;
     if (getenv("LF_WATCHDOG") && atoi(getenv("LF_WATCHDOG")) > 0) { wd.limit_s = atoi(getenv("LF_WATCHDOG")); have_wd = pthread_create(&wdt, NULL, wdog_main, &wd) == 0; }
     void *la[LF_MAX_LANES][2]; pthread_t lt[LF_MAX_LANES]; int have[LF_MAX_LANES] = { 0 };
-    for (int l = 0; l < LF_MAX_LANES; l++) { la[l][0] = &B; la[l][1] = (void *)(intptr_t)l; }
+    for (int l = 0; l < LF_MAX_LANES; l++) { la[l][0] = &B; la[l][1] = (void *)(intptr_t)(l == 0 ? lane0 + 1 : 0); }      /* [1]: lane id + 1 already held, 0: take one */
     for (int l = 1; l < n_lanes && l < B.n_chunks; l++) have[l] = pthread_create(&lt[l], NULL, lane_main, la[l]) == 0;
     lane_main(la[0]);
     for (int l = 1; l < n_lanes; l++) if (have[l]) pthread_join(lt[l], NULL);
     if (have_wd) { wd.stop = 1; pthread_join(wdt, NULL); }
     lfg_set_lane(0);
     if (g_phase_on) { fprintf(stderr, "[lf] batch of %d reads: %.1f ms wall, %d threads\n", n, now_ms() - T0, nt); phase_report(); }
-    pthread_mutex_unlock(&g_map_lock);
+    pthread_mutex_lock(&g_lanes_mu); g_active_calls--; pthread_mutex_unlock(&g_lanes_mu);
 
     uint64_t total = 0;
     for (int k = 0; k < B.n_chunks; k++) total += B.chunks[k].size;

@@ -76,19 +76,21 @@ __device__ __forceinline__ uint32_t lf_kmer_rc_index(uint32_t i, int K)
 }
 __global__ void lf_cache_pack_kernel(uint64_t *__restrict__ tab, int K, uint64_t n)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t j = lf_kmer_rc_index((uint32_t)i, K);
-    if ((uint64_t)j < i) return;
-    const uint64_t ab = tab[2 * i], ae = tab[2 * i + 1], bb = tab[2 * (size_t)j], be = tab[2 * (size_t)j + 1];
-    const uint64_t as = ab <= ae ? ae - ab + 1 : 0, bs = bb <= be ? be - bb + 1 : 0;
-    tab[2 * i] = (ab & LF_M33) | ((as & 0x7fffffffull) << 33); tab[2 * i + 1] = (bb & LF_M33) | ((as >> 31) << 33);
-    if ((uint64_t)j != i) { tab[2 * (size_t)j] = (bb & LF_M33) | ((bs & 0x7fffffffull) << 33); tab[2 * (size_t)j + 1] = (ab & LF_M33) | ((bs >> 31) << 33); }
+    /* grid-stride: 4^16 entries are more work-items than one dispatch can have (2^32 - 1) */
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t j = lf_kmer_rc_index((uint32_t)i, K);
+        if ((uint64_t)j < i) continue;
+        const uint64_t ab = tab[2 * i], ae = tab[2 * i + 1], bb = tab[2 * (size_t)j], be = tab[2 * (size_t)j + 1];
+        const uint64_t as = ab <= ae ? ae - ab + 1 : 0, bs = bb <= be ? be - bb + 1 : 0;
+        tab[2 * i] = (ab & LF_M33) | ((as & 0x7fffffffull) << 33); tab[2 * i + 1] = (bb & LF_M33) | ((as >> 31) << 33);
+        if ((uint64_t)j != i) { tab[2 * (size_t)j] = (bb & LF_M33) | ((bs & 0x7fffffffull) << 33); tab[2 * (size_t)j + 1] = (ab & LF_M33) | ((bs >> 31) << 33); }
+    }
 }
 static int lfg_pack_cache_table(hipStream_t stream, int K, uint64_t *tab)
 {
     const uint64_t n = 1ull << (2 * K);
-    hipLaunchKernelGGL(lf_cache_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tab, K, n);
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(lf_cache_pack_kernel, dim3((unsigned)(blocks < (1u << 20) ? blocks : (1u << 20))), dim3(256), 0, stream, tab, K, n);
     HIPCHK(hipStreamSynchronize(stream));
     HIPCHK(hipGetLastError());
     return LF_OK;
@@ -174,7 +176,7 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
         const size_t need16 = (((size_t)1 << 32) + ((size_t)1 << 30)) * 16 + ((size_t)8 << 30);
         if (t16 ? atoi(t16) != 0 : (ix->seq_len >= (1ull << 30) && free_b > need16 + ((size_t)100 << 30) + ((ix->flags & LF_IDX_FULL_SA) ? (ix->seq_len + 1) * 8 : 0))) {
             rc = lfg_build_cache_table(&v, st->stream, 16, &tab);
-            if (rc == LF_OK) rc = lfg_pack_cache_table(st->stream, 16, tab);
+            if (rc == LF_OK) { rc = lfg_pack_cache_table(st->stream, 16, tab); if (rc != LF_OK) (void)hipFree(tab); }
             if (rc == LF_OK) { st->cache16 = tab; v.cache16 = tab; }
             else if (t16) return rc;                    /* asked for explicitly */
         }

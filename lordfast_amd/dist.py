@@ -270,9 +270,11 @@ class Shard:
     def name_array(self, torch):
         """ctypes char*[n] into a HOST copy of the names part of the blob (kept alive by self)"""
         import ctypes as C
-        n0, n1 = int(self.name_off[0]), int(self.name_off[-1])
-        self._names_host = self.blob[n0:n1].cpu().numpy() if n1 > n0 else np.zeros(1, np.uint8)
-        self._np = (self.name_off[:-1] - n0 + self._names_host.ctypes.data).astype(np.uint64)
+        if getattr(self, "_na_for", None) is not self.blob:      # built once per shard content: callers may be concurrent threads
+            n0, n1 = int(self.name_off[0]), int(self.name_off[-1])
+            names_host = self.blob[n0:n1].cpu().numpy() if n1 > n0 else np.zeros(1, np.uint8)
+            ptrs = (self.name_off[:-1] - n0 + names_host.ctypes.data).astype(np.uint64)
+            self._names_host, self._np, self._na_for = names_host, ptrs, self.blob
         return C.cast(self._np.ctypes.data, C.POINTER(C.c_char_p))
 
 

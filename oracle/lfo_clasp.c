@@ -310,12 +310,14 @@ static void chain_sop(const cfrag_t *frag, uint32_t size, cchain_t *chain, cbest
     free(prev); free(pt); tree_free(&A); tree_free(&B);
 }
 
-/* chain_seeds_clasp (src/Chain.cpp:39-209).  `seeds` is not modified.  For n == 0 the reference leaves
- * chainLen untouched and sets score = -1; we report chainLen = 0. */
+/* chain_seeds_clasp (src/Chain.cpp:39-209).  `seeds` is not modified.  For n == 0 the reference sets score = -1 and leaves
+ * chainLen AND the chain's seeds as its previous call left them (:68, :92): the caller then works with a STALE chain
+ * (lfo_map.c keeps one chain buffer per mapping context like the reference's _pf_topChains, and clears it per read). */
 void lfo_chain_clasp(const lfo_seed_t *seeds, uint32_t n, lfo_seed_t *out, uint32_t *chainLen, float *score)
 {
-    *score = -1; *chainLen = 0;
+    *score = -1;
     if (n == 0) return;
+    *chainLen = 0;
     cfrag_t *f = (cfrag_t *)malloc(sizeof(cfrag_t) * n), *tmpf = (cfrag_t *)malloc(sizeof(cfrag_t) * n);
     for (uint32_t k = 0; k < n; k++) {
         f[k].p = seeds[k].tPos; f[k].i = (int)seeds[k].qPos; f[k].q = f[k].j = (int)seeds[k].len;

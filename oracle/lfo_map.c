@@ -687,6 +687,11 @@ static void map_one(ctx_t *cx, int t, const char *name, const char *seq, const c
 
     lfo_seed(cx->ix, cx->p, seq, readLen, cx->F, &cx->nF, cx->R, &cx->nR, NULL);
     cx->nWins = 0;
+    /* chain_seeds_clasp on a window without seeds leaves the PREVIOUS call's chain in place (src/Chain.cpp:68,92) and alignWin
+     * then extends that stale chain.  Inside a read the previous call is this read's previous window: deterministic, restated
+     * here by keeping cx->chain between calls.  Across reads it is whatever the reference's thread mapped before -- scheduling
+     * dependent under --threads > 1 -- so every read starts without a chain (the first window of a read comes out empty). */
+    cx->chainLen = 0;
     top_wins_coarse(cx, readLen, cx->F, cx->nF, 0, t + 1);
     top_wins_coarse(cx, readLen, cx->R, cx->nR, 1, -(t + 1));
 

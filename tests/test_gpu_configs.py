@@ -116,3 +116,27 @@ def test_c5_shape_on_a_repeat_rich_genome(human_like, oracle_lib):
     fa, g, _ = human_like
     reads = synth.make_reads(g, 30, 50000, 0.10, seed=5, mix=(0.40, 0.25, 0.35))
     _run_big(fa, reads, oracle_lib, min_anchor_len=17, sampling_count=2000)
+
+
+# ---- BASELINE config C4 as it is benchmarked (bench.py --config c4): reads out of 2-4-copy segmental duplications, --chainAlg
+# ---- clasp, -n 30: the fine branch of mapSeq aligns every near-equal candidate window.  Many small contigs, so that candidate
+# ---- windows at contig borders occur whose seeds all lie in the neighbouring contig: chain_seeds_clasp then leaves its previous
+# ---- chain in place and the reference extends that stale chain (src/Chain.cpp:68,92) -- restated, not avoided.
+@pytest.fixture(scope="module")
+def segdup_genome(tmp_path_factory):
+    import lordfast_amd as la
+    d = tmp_path_factory.mktemp("segdup")
+    g = synth.make_genome(24_000_000, 24, seed=11, repeat_frac=0.10, n_families=100)
+    fams = synth.add_segdups(g, 120, seg_len=(12000, 20000), seed=7)
+    fa = la.index_build(g, os.path.join(str(d), "segdup.fa"))
+    return fa, g, fams
+
+
+def test_c4_segdup_workload_clasp_n30(segdup_genome, oracle_lib):
+    fa, g, fams = segdup_genome
+    reads = synth.make_reads(g, 700, 15000, 0.15, seed=2024, segdups=fams, dup_frac=0.5)
+    st, sam = _run_big(fa, reads, oracle_lib, max_map=30, chain_alg=1)
+    assert st["n_chain_problems"] / len(reads) > 1.5, "the duplicated reads must reach the fine branch"
+    flags = [int(l.split(b"\t")[1]) for l in sam.split(b"\n") if l]
+    assert sum(1 for f in flags if f & 256) > 100
+    st, _ = _run_big(fa, reads[:300], oracle_lib, max_map=30)                        # the same reads through dp-n2

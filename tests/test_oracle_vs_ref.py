@@ -263,3 +263,40 @@ def test_window_stage_goldens_are_the_reference_output(ref, golden_dir, golden_r
             assert np.array_equal(np.concatenate([r["coarse"].reshape(-1, 4) for r in res]), z[f"{cfg}_coarse"])
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_segdup_workload_clasp_n30_restatement_equals_reference(tmp_path):
+    """the C4 workload (reads out of segmental duplications, -a clasp -n 30, many contigs): the restatement prints the
+    reference's records, secondaries included -- also where the reference extends a STALE chain for a candidate window
+    without seeds (src/Chain.cpp:68,92)"""
+    from conftest import have_ref
+    if not have_ref():
+        pytest.skip("needs oracle/_ref/liblfref.so")
+    from oracle import pyoracle as po
+    g = synth.make_genome(12_000_000, 24, seed=11, repeat_frac=0.10, n_families=60)
+    fams = synth.add_segdups(g, 60, seg_len=(12000, 20000), seed=7)
+    fa = str(tmp_path / "segdup.fa")
+    synth.write_fasta(fa, g)
+    ref = po.Ref()
+    ref.index_build(fa)
+    reads = synth.make_reads(g, 260, 15000, 0.15, seed=2024, segdups=fams, dup_frac=0.6)
+    names = [r[0].encode() for r in reads]
+    seqs = [r[1] for r in reads]
+    ref.load(fa)
+    for th in (1, 4):
+        ref.set_params(po.default_params(threads=th, chain_alg=1, max_map=30), "t")
+        want, _ = ref.map_mem(names, seqs)
+        orc = po.Oracle(fa)
+        got = orc.map_batch(names, seqs, params=po.default_params(chain_alg=1, max_map=30, threads=8))
+        orc.close()
+        if th == 1:
+            assert got == want                                   # --threads 1 prints in input order
+        else:                                                    # more threads: the same records per read, in completion order
+            def by_read(txt):
+                d = {}
+                for l in txt.split(b"\n"):
+                    if l:
+                        d.setdefault(l.split(b"\t", 1)[0], []).append(l)
+                return d
+            assert by_read(got) == by_read(want), th
+    assert sum(1 for l in want.split(b"\n") if l and int(l.split(b"\t")[1]) & 256) > 50
