@@ -199,7 +199,10 @@ void lf_read_batch_free(lf_read_batch_t *b);
 int  lf_map_file(const lf_index_t *idx, const lf_params_t *p, const char *reads_path, const char *out_path, int no_header,
                  const char *cmdline, int batch_reads, lf_stats_t *total);
 
-/* same, SAM text written into a caller-owned buffer (reusable / pinned); LF_ERR_NOMEM when out_cap is too small */
+/* same, SAM text written into a caller-owned buffer (reusable); LF_ERR_NOMEM when out_cap is too small.
+ * If the buffer is PINNED host memory of the HIP runtime (hipHostMalloc / hipHostRegister; lf_map_file allocates its own that
+ * way), the SEQ / QUAL columns -- 60 % of the text, bytes the caller handed in -- never cross the link: a kernel stores the
+ * rest of every line straight into the buffer and host threads copy SEQ / QUAL in from `seqs` / `quals` (byte-identical output). */
 int  lf_map_batch_into(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,
                        const char *const *seqs, const char *const *quals, char *out, size_t out_cap, size_t *sam_len,
                        lf_stats_t *stats);
@@ -214,7 +217,12 @@ int  lf_map_batch_into_lens(const lf_index_t *idx, const lf_params_t *p, int n, 
  * hand-over initFASTChunk(Read *seqList, int n) + mapSeqMT() (src/LordFAST.h:124-125), whose buffers live in host memory.
  *   read i = d_seqs[seq_off[i] .. seq_off[i] + seq_lens[i])   (anything may sit between two reads);
  *   d_quals: NULL (FASTA, QUAL printed as "*") or a device blob in the same layout; names / seq_off / seq_lens: host arrays.
- *   out: out_cap bytes of device memory (out_is_device != 0) or host memory; a device buffer gets no terminating NUL. */
+ *   out: out_cap bytes of device memory (out_is_device != 0) or host memory; a device buffer gets no terminating NUL.
+ *   Stream ordering: the library reads d_seqs / d_quals and writes `out` on streams of its own -- whatever produced the blobs
+ *   (a copy, a collective, a kernel of the caller) must be COMPLETE before the call, and the text in `out` is complete when the
+ *   call returns.
+ * All lf_map_batch* calls are re-entrant: threads may map several batches at once; they share the device's eight lanes (the
+ * per-lane working memory in HBM) through one allocator, so small batches overlap and large ones queue for lanes. */
 int  lf_map_batch_dev(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names, const void *d_seqs,
                       const uint64_t *seq_off, const uint32_t *seq_lens, const void *d_quals, void *out, size_t out_cap,
                       int out_is_device, size_t *sam_len, lf_stats_t *stats);

@@ -899,8 +899,6 @@ lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t 
               int32_t *__restrict__ ws, int32_t *__restrict__ out_score, int32_t *__restrict__ out_qle, int32_t *__restrict__ out_tle, int lds_q)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t s_he[];
-    typedef hipcub::WarpReduce<unsigned long long, 64> red_t;
-    __shared__ typename red_t::TempStorage red_tmp;
     const int gid = blockIdx.x, lane = threadIdx.x;
     if (gid >= n_probs) return;
     const lf_ksw_prob pr = probs[gid];
@@ -975,8 +973,10 @@ lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t 
             f = __builtin_amdgcn_readlane(fout, last);
         }
         if (beg < end) {
-            const unsigned long long key = red_t(red_tmp).Reduce(best, hipcub::Max());
-            m = __builtin_amdgcn_readfirstlane((int)(key >> 32)); mj = __builtin_amdgcn_readfirstlane((int)(key & 0xFFFFFFFFu));
+            /* wave maximum of (h << 32 | j): the high words first, then the low words of the lanes that tie on them (DPP, no LDS) */
+            const uint32_t bh = (uint32_t)(best >> 32), hmax = lf_wave_max_u32(bh);
+            const uint32_t bl = bh == hmax ? (uint32_t)best : 0u, lmax = lf_wave_max_u32(bl);
+            m = (int)hmax; mj = (int)lmax;
         }
         if (lane == 0) { H[end] = h1; E[end] = 0; }
         __syncthreads();

@@ -173,18 +173,6 @@ struct lf_clasp_better {
         return take_b ? b : a;
     }
 };
-/* wavefront maximum of an unsigned, in every lane: DPP row shifts + row broadcasts (no LDS), then one readlane */
-__device__ __forceinline__ uint32_t lf_clasp_wave_max_u32(uint32_t v)
-{
-    uint32_t x = v;
-    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));      /* row_shr:1 */
-    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));      /* row_shr:2 */
-    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));      /* row_shr:4 */
-    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));      /* row_shr:8 */
-    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));      /* row_bcast:15 -> rows 1, 3 */
-    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));      /* row_bcast:31 -> rows 2, 3 */
-    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
-}
 /* wavefront arg-max of (prio, y-rank), lexicographic, over the lanes that hold a candidate; the winner's prio and entry index
  * come back in every lane.  Three 32-bit maxima (high word of the order-preserving image of the double, low word among the
  * lanes that tie on it, y-rank among those) instead of a generic reduction of a 16-byte struct: y-ranks are distinct, so one
@@ -196,13 +184,13 @@ __device__ __forceinline__ bool lf_clasp_wave_best(bool cand, double pr, uint32_
     k = (k >> 63) ? ~k : (k | 0x8000000000000000ull);               /* a < b  <=>  image(a) < image(b) */
     /* (every maximum is taken by ALL lanes, outside the && : a DPP move that only some lanes execute reads stale registers of the others) */
     const uint32_t hi = cand ? (uint32_t)(k >> 32) : 0u;
-    const uint32_t hmax = lf_clasp_wave_max_u32(hi);
+    const uint32_t hmax = lf_wave_max_u32(hi);
     const bool c2 = cand && hi == hmax;
     const uint32_t lo = c2 ? (uint32_t)k : 0u;
-    const uint32_t lmax = lf_clasp_wave_max_u32(lo);
+    const uint32_t lmax = lf_wave_max_u32(lo);
     const bool c3 = c2 && lo == lmax;
     const uint32_t e = c3 ? ey + 1u : 0u;
-    const uint32_t emax = lf_clasp_wave_max_u32(e);
+    const uint32_t emax = lf_wave_max_u32(e);
     const bool c4 = c3 && e == emax;
     const int src = __ffsll((long long)lf_ballot(c4)) - 1;
     const uint64_t pb = (uint64_t)__double_as_longlong(pr);

@@ -110,12 +110,7 @@ __host__ __device__ __forceinline__ bool lf_leaf(int64_t n, int64_t m) { return 
 #define LF_LANE_W   1        /* 8 KiB of LDS per wave: LDS, not registers, bounds the waves per SIMD of these kernels */
 #endif
 
-__device__ __forceinline__ uint32_t lf_wave_max_u32(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(v, o); v = x > v ? x : v; }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);        /* the same in every lane: let loop bounds live in SGPRs */
-}
+/* lf_wave_max_u32: lf_gpu_common.h (DPP row shifts + broadcasts; the same value in every lane, so loop bounds live in SGPRs) */
 __device__ __forceinline__ int lf_wave_max_i32(int v)
 {
 #pragma unroll

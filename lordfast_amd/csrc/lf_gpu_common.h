@@ -213,4 +213,17 @@ __device__ __forceinline__ uint64_t lf_sa_walk(const lf_dev_index &ix, uint64_t 
     return off + ix.sa_sampled[k >> 5];
 }
 
+/* wavefront maximum of an unsigned, in every lane: DPP row shifts + row broadcasts (no LDS), then one readlane */
+__device__ __forceinline__ uint32_t lf_wave_max_u32(uint32_t v)
+{
+    uint32_t x = v;
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));      /* row_shr:1 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));      /* row_shr:2 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));      /* row_shr:4 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));      /* row_shr:8 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));      /* row_bcast:15 -> rows 1, 3 */
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));      /* row_bcast:31 -> rows 2, 3 */
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 #endif

@@ -14,6 +14,7 @@
  *   dependent-load chains per CU in flight.
  */
 #include <hipcub/hipcub.hpp>
+#include <mutex>
 #include "lf_gpu_common.h"
 #include "lf_rsweep.h"
 #include "lf_scan.h"
@@ -607,8 +608,18 @@ extern "C" int lfg_seed_src(const struct lf_index *ix, const lf_params_t *p, int
 
     HIPCHK(hipMemsetAsync(d_counters, 0, 32, s));
     HIPCHK(hipMemcpyAsync(d_off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
-    if (reads) HIPCHK(hipMemcpyAsync(d_reads, reads, n_bases, hipMemcpyHostToDevice, s));
-    else {
+    if (reads) {
+        /* Uploads take turns: eight lanes start a step together, and eight concurrent copies share the link -- every lane would
+         * get its bases after ~8 x the time of one copy.  In turn, the first lane's kernels start after one copy and the other
+         * lanes' copies run under them.  (One stream wait per chunk; LF_UPLOAD_TURNS=0 switches it off for A / B runs.) */
+        static std::mutex upload_turn;
+        static const bool turns = !(getenv("LF_UPLOAD_TURNS") && atoi(getenv("LF_UPLOAD_TURNS")) == 0);
+        if (turns) {
+            std::lock_guard<std::mutex> g(upload_turn);
+            HIPCHK(hipMemcpyAsync(d_reads, reads, n_bases, hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+        } else HIPCHK(hipMemcpyAsync(d_reads, reads, n_bases, hipMemcpyHostToDevice, s));
+    } else {
         if (!d_src || !src_off) { lf_set_error("lfg_seed: no read bases"); return LF_ERR_ARG; }
         uint64_t *d_src_off = DSLOT(uint64_t, 13, (size_t)(n_reads + 1) * 8);       /* kept for the SAM writer's qualities (same layout) */
         if (!d_src_off) return LF_ERR_NOMEM;

@@ -270,7 +270,7 @@ class Shard:
     def name_array(self, torch):
         """ctypes char*[n] into a HOST copy of the names part of the blob (kept alive by self)"""
         import ctypes as C
-        if getattr(self, "_na_for", None) is not self.blob:      # built once per shard content: callers may be concurrent threads
+        if getattr(self, "_na_for", None) is not self.blob:      # built once per shard content (call it once before sharing a shard between threads)
             n0, n1 = int(self.name_off[0]), int(self.name_off[-1])
             names_host = self.blob[n0:n1].cpu().numpy() if n1 > n0 else np.zeros(1, np.uint8)
             ptrs = (self.name_off[:-1] - n0 + names_host.ctypes.data).astype(np.uint64)
