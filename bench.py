@@ -511,7 +511,8 @@ def main():
         if rank == 0 and world == 1:
             # the records the TIMED steps wrote, before anything else runs: a digest of all of them and the head that is compared with the reference
             snap_host = digest(sam_host)
-            head_host = sam_host.head(int(6.5 * args.cpu_seconds * 1100 * args.read_len) + (8 << 20)) if not args.no_cpu_baseline else None
+            # (the reference maps ~ 1 k reads/s on the box's cores: room for 1.5 x 1.2 k reads/s x the sample time, ~1.75 x read_len + header per record, x candidates)
+            head_host = sam_host.head(int(1.5 * args.cpu_seconds * 1200 * (1.75 * args.read_len + 600) * (1.0 + 4.0 * args.dup_frac)) + (8 << 20)) if not args.no_cpu_baseline else None
     elif args.mode == "inproc":
         elapsed_host, cpu_s_host, agg_host, sam_host = elapsed_nx, cpu_s_hbm, agg_hbm, sam_hbm
     primary_is_host = world * n_dev == 1 and elapsed_host is not None or args.mode == "inproc"

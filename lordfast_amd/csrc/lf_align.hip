@@ -20,7 +20,6 @@
  * No banding: the Ukkonen band of the reference only removes cells that cannot be on an optimal path, and lanes that skip
  * out-of-band blocks save no time, because their neighbours in the wavefront's lock-step sweep do not.
  */
-#include <hipcub/hipcub.hpp>
 #include "lf_gpu_common.h"
 #include "lf_edlib_common.h"
 #include "lf_hirsch.h"
@@ -505,15 +504,34 @@ struct lf_desc_src {
     lf_hcount_t hc;                                                           /* the problems above edlib's traceback switch (known to whoever made the descriptors) */
 };
 
+/* Binning is a COUNTING sort, not a comparison / radix sort: what the launch layout needs is the problems grouped by class and,
+ * inside class 1, by (mode, nb) with similar target lengths next to each other (a wavefront's sweep lasts as long as its longest
+ * target) -- not a total order.  A bin = (class, mode, nb, bucket of the target length: 32 columns wide below 512, 256 above);
+ * 4 100 bins.  Most problems of a chunk fall into a handful of bins (one or two blocks, short targets), so neither pass sends
+ * its atomics to HBM one by one (a first version did: 28 ms per 100 k reads on a few hot counters): a workgroup counts its
+ * 4 096 problems in an LDS histogram, adds the non-zero counters to the global ones (pass 1), and after a single-workgroup scan
+ * reserves ONE range per non-zero bin and hands its places out through LDS (pass 2).  The order inside a bin is whatever the
+ * atomics give -- problems are independent, results do not depend on it. */
+#define LF_BIN_MB 32
+#define LF_NBINS (1 + 2 * 64 * LF_BIN_MB + 3)
+#define LF_BIN_ITEMS 4                       /* problems per thread of the two counting passes (1024 threads) */
+__host__ __device__ __forceinline__ uint32_t lf_bin_of_key(uint32_t key)
+{
+    const uint32_t c = key >> 28;
+    if (c == 0) return 0u;
+    if (c != 1) return 1u + 2u * 64u * LF_BIN_MB + (c - 2u);
+    const uint32_t mode = (key >> 23) & 1u, nb = (key >> 16) & 127u, m = key & 0xffffu;
+    const uint32_t mb = m < 512u ? (m >> 5) : 16u + (((m - 512u) >> 8) < 15u ? ((m - 512u) >> 8) : 15u);
+    return 1u + (mode * 64u + (nb - 1u)) * LF_BIN_MB + mb;
+}
 __global__ void lf_desc_keys_kernel(const lf_aln_desc_t *__restrict__ d, const uint64_t *__restrict__ ops_off, int n, const lf_aln_desc_t *__restrict__ hd, int n_h,
-                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ vals, uint8_t *__restrict__ ops,
+                                    uint32_t *__restrict__ keys, uint8_t *__restrict__ ops,
                                     int32_t *__restrict__ out_ed, int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n + n_h) return;
     const lf_aln_desc_t x = i < n ? d[i] : hd[i - n];
     keys[i] = lf_class_key(x);
-    vals[i] = (uint32_t)i;
     if (i < n && (x.n == 0 || x.m == 0)) {
         /* one side empty: no DP (lib/edlib/edlib.cpp:1096-1104).  n == 0: NW deletes the whole target, SHW takes the empty
          * prefix; m == 0: the query is inserted.  The run is end-aligned in the region like every other path. */
@@ -522,6 +540,54 @@ __global__ void lf_desc_keys_kernel(const lf_aln_desc_t *__restrict__ d, const u
         uint8_t *o = ops + ops_off[i] + (x.n + x.m - len);
         for (uint32_t k = 0; k < len; k++) o[k] = op;
         out_ed[i] = (int32_t)len; out_end[i] = x.n == 0 ? (int32_t)len - 1 : -1; out_len[i] = len;
+    }
+}
+/* exclusive scan of the bin counters, in place (one workgroup; 24 580 counters): hist[b] becomes the first place of bin b */
+__global__ void __launch_bounds__(1024)
+lf_desc_binscan_kernel(uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t s_sum[1024];
+    const int t = threadIdx.x;
+    constexpr int PER = (LF_NBINS + 1023) / 1024;
+    uint32_t loc[PER]; uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { const int b = t * PER + k; loc[k] = b < LF_NBINS ? hist[b] : 0u; acc += loc[k]; }
+    s_sum[t] = acc;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { const uint32_t v = t >= o ? s_sum[t - o] : 0u; __syncthreads(); s_sum[t] += v; __syncthreads(); }
+    uint32_t base = t ? s_sum[t - 1] : 0u;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { const int b = t * PER + k; if (b < LF_NBINS) hist[b] = base; base += loc[k]; }
+}
+/* pass 1 (SCATTER = false): per-workgroup LDS histogram -> global counters; pass 2 (SCATTER = true): the same histogram, one
+ * range of the (scanned) global cursor per non-zero bin, places inside the range through a second LDS counter */
+template <bool SCATTER>
+__global__ void __launch_bounds__(1024)
+lf_desc_count_kernel(const uint32_t *__restrict__ keys, int n, uint32_t *__restrict__ bins, uint32_t *__restrict__ keys2, uint32_t *__restrict__ vals2)
+{
+    __shared__ uint32_t s_cnt[LF_NBINS], s_base[SCATTER ? LF_NBINS : 1];
+    const int t = threadIdx.x;
+    for (int b = t; b < LF_NBINS; b += 1024) s_cnt[b] = 0;
+    __syncthreads();
+    const int i0 = (int)blockIdx.x * 1024 * LF_BIN_ITEMS;
+    uint32_t key[LF_BIN_ITEMS], bin[LF_BIN_ITEMS], rank[LF_BIN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < LF_BIN_ITEMS; k++) {
+        const int i = i0 + k * 1024 + t;
+        bin[k] = 0xffffffffu; key[k] = 0; rank[k] = 0;
+        if (i < n) { key[k] = keys[i]; bin[k] = lf_bin_of_key(key[k]); rank[k] = atomicAdd(&s_cnt[bin[k]], 1u); }
+    }
+    __syncthreads();
+    for (int b = t; b < LF_NBINS; b += 1024) {
+        const uint32_t c = s_cnt[b];
+        if (c) { const uint32_t g = atomicAdd(&bins[b], c); if (SCATTER) s_base[b] = g; }
+    }
+    if (!SCATTER) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < LF_BIN_ITEMS; k++) {
+        const int i = i0 + k * 1024 + t;
+        if (i < n) { const uint32_t at = s_base[bin[k]] + rank[k]; keys2[at] = key[k]; vals2[at] = (uint32_t)i; }
     }
 }
 __device__ __forceinline__ int lf_lower_bound_u32(const uint32_t *__restrict__ keys, int n, uint32_t want)
@@ -560,7 +626,12 @@ __global__ void lf_desc_entries_kernel(const uint32_t *__restrict__ keys, const 
     uint64_t e = 0;
     if (c == 1) {
         const int t = (int)((key >> 16) & 0xffu), nb = t & 127, P = 64 / nb, rel = j - tab->lo[t];
-        if (rel % P == 0) { int last = j + P - 1; if (last > tab->lo[t + 1] - 1) last = tab->lo[t + 1] - 1; e = lf_rwave_entries((uint32_t)nb, keys[last] & 0xffffu); }
+        if (rel % P == 0) {      /* the wave's checkpoint rows: as many as its LONGEST target needs (a bin holds a range of lengths, in no particular order) */
+            int last = j + P - 1; if (last > tab->lo[t + 1] - 1) last = tab->lo[t + 1] - 1;
+            uint32_t mmax = 0;
+            for (int k = j; k <= last; k++) { const uint32_t mk = keys[k] & 0xffffu; mmax = mk > mmax ? mk : mmax; }
+            e = lf_rwave_entries((uint32_t)nb, mmax);
+        }
     } else if (c != LF_CLASS_SKIP) {
         const uint32_t i = vals[j];
         const lf_aln_desc_t x = i < (uint32_t)n0 ? d[i] : hd[i - n0];
@@ -651,10 +722,8 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     uint64_t *d_misc = DSLOT(uint64_t, 15, 64);
     lf_rseg_tab *h_tab = (lf_rseg_tab *)lfg_pin_slot(LF_PS_ALN_PROB + 2, sizeof(lf_rseg_tab) + 64);
     if (!d_desc || !d_opsoff || !d_keys || !d_keys2 || !d_vals || !d_vals2 || !d_ent || !d_base || !d_probs || !d_waves || !d_ed || !d_end || !d_len || !d_ops || !d_tab || !d_misc || !h_tab) return LF_ERR_NOMEM;
-    size_t tb1 = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, d_keys, d_keys2, d_vals, d_vals2, (int)NN, 0, 31, s);
-    void *d_tmp = lfg_dev_slot(device, LF_DS_ALN0 + 16, tb1 + 256);
-    if (!d_tmp) return LF_ERR_NOMEM;
+    uint32_t *d_bins = (uint32_t *)lfg_dev_slot(device, LF_DS_ALN0 + 16, (size_t)LF_NBINS * 4 + 256);
+    if (!d_bins) return LF_ERR_NOMEM;
 
     if (!dev_desc) {
         HIPCHK(hipMemcpyAsync(d_desc, D->d, (size_t)n * sizeof(lf_aln_desc_t), hipMemcpyHostToDevice, s));
@@ -713,8 +782,12 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     HIPCHK(hipEventRecord(bd[0], s));                      /* Hirschberg levels: e0 .. bd[0]; binning: bd[0] .. eb */
 
     const unsigned gb = (unsigned)((N + 255) / 256);
-    hipLaunchKernelGGL(lf_desc_keys_kernel, dim3(gb), dim3(256), 0, s, d_desc, d_opsoff, n, d_hdesc, (int)n_h, d_keys, d_vals, d_ops, d_ed, d_end, d_len);
-    { size_t tb = tb1; HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys, d_keys2, d_vals, d_vals2, N, 0, 31, s)); }
+    HIPCHK(hipMemsetAsync(d_bins, 0, (size_t)LF_NBINS * 4, s));
+    hipLaunchKernelGGL(lf_desc_keys_kernel, dim3(gb), dim3(256), 0, s, d_desc, d_opsoff, n, d_hdesc, (int)n_h, d_keys, d_ops, d_ed, d_end, d_len);
+    const unsigned gc = (unsigned)((N + 1024 * LF_BIN_ITEMS - 1) / (1024 * LF_BIN_ITEMS));
+    hipLaunchKernelGGL(lf_desc_count_kernel<false>, dim3(gc), dim3(1024), 0, s, (const uint32_t *)d_keys, N, d_bins, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(lf_desc_binscan_kernel, dim3(1), dim3(1024), 0, s, d_bins);
+    hipLaunchKernelGGL(lf_desc_count_kernel<true>, dim3(gc), dim3(1024), 0, s, (const uint32_t *)d_keys, N, d_bins, d_keys2, d_vals2);
     hipLaunchKernelGGL(lf_desc_segments_kernel, dim3(1), dim3(256), 0, s, d_keys2, N, d_tab);
     hipLaunchKernelGGL(lf_desc_entries_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, n, d_hdesc, d_tab, N, d_ent);
     { lf_scan_u64 f; f.p = d_ent; const int src = lf_scan_excl(device, 4, s, f, d_base, (size_t)N); if (src != LF_OK) return src; }

@@ -22,7 +22,6 @@
  * Traffic per record: ops bytes read once, text written once, a few 2-bit reference bases.
  */
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <string.h>
 #include <mutex>

@@ -531,7 +531,9 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
          * shrink with the chunk, so small batches get FEWER chunks, not smaller ones: at least 6250 reads each (HBM-resident
          * 12.5 k reads as 8 / 4 / 2 / 1 chunks: 17.1 / 17.5 / 15.2 / 15.6 ms; 25 k: 27.5 (8) / 26.5 (4) / 27.6 (2); 50 k: 42.0 (8) / 43.9 (4)). */
         const int dev_in = dio && !dio->stage_sink;
-        const int per_lane = dev_in ? 1 : (B.holes ? 2 : 3);
+        /* (with the lanes' uploads taking turns, lf_seed.hip: ONE chunk per lane for pinned host batches too -- 6250 / 8334 / 12500
+         * reads per chunk: 99.4 / 97.5 / 96.0 ms per 100 k reads) */
+        const int per_lane = (dev_in || B.holes) ? 1 : 3;
         const int min_chunk = (dev_in || B.holes) ? 6250 : 1024;
         int want = (n + per_lane * n_lanes - 1) / (per_lane * n_lanes); if (want < min_chunk) want = min_chunk;
         if (want < CHUNK_READS) CHUNK_READS = want;

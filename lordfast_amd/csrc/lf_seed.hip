@@ -13,8 +13,10 @@
  *   HBM-bound on random 64-byte Occ blocks: one lane per sample position, thousands of independent
  *   dependent-load chains per CU in flight.
  */
-#include <hipcub/hipcub.hpp>
 #include <mutex>
+#include <string.h>
+#include <stdlib.h>
+#include <stdio.h>
 #include "lf_gpu_common.h"
 #include "lf_rsweep.h"
 #include "lf_scan.h"

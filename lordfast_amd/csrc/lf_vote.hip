@@ -258,7 +258,51 @@ lf_req_gather_kernel(int n_req, const uint32_t *__restrict__ req_read, const uin
         }
         cnt += (uint32_t)__popcll(m);
     }
-    if (!WRITE && lane == 0) req_n[q] = cnt;
+    if (!WRITE && lane == 0) { req_n[q] = cnt; if (skeys) atomicMax(reinterpret_cast<unsigned int *>(skeys), cnt); }      /* (count pass: skeys = one word for the largest request) */
+}
+
+/* ---- 5b: a request's seeds in key order -- qPos for dp-n2 (what std::sort(compare_seed) orders by, src/Chain.cpp:244), target
+ * start for clasp (qsort(cmp_slmatch_qsort), src/Chain.cpp:94) -- STABLE, i.e. equal keys keep the gathered order (clasp's
+ * qsort is glibc's stable merge sort; for dp-n2 the unstable std::sort is replayed afterwards on the requests that have ties).
+ * A SEGMENTED sort: requests are independent and a few hundred seeds long, so every request is sorted by its own workgroup in
+ * LDS -- a bitonic network over 64-bit words (key << 32 | place in the gathered order): the words are distinct, so the network's
+ * result is THE stable order -- instead of one radix sort over (request, key) pairs of the whole chunk through HBM (round 3:
+ * hipCUB, 14 launches and four passes over 1.3 M pairs per chunk). ---- */
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS)
+lf_req_sort_kernel(int n_req, const uint64_t *__restrict__ req_off, const uint32_t *__restrict__ req_n, const uint2 *__restrict__ gathered,
+                   uint2 *__restrict__ sorted, uint64_t *__restrict__ skeys_sorted, int key_by_tpos, uint32_t n_lo, uint32_t n_hi)
+{
+    extern __shared__ uint64_t s_w[];
+    const int q = blockIdx.x, t = threadIdx.x;
+    if (q >= n_req) return;
+    const uint32_t n = req_n[q];
+    if (n < n_lo || n > n_hi) return;                       /* another launch's size class */
+    const uint64_t off = req_off[q];
+    uint32_t N = 1; while (N < n) N <<= 1;
+    for (uint32_t i = t; i < N; i += THREADS) {
+        uint64_t w = ~0ull;
+        if (i < n) { const uint2 sd = gathered[off + i]; w = ((uint64_t)(key_by_tpos ? sd.x : (sd.y & 0xFFFFFu)) << 32) | i; }
+        s_w[i] = w;
+    }
+    auto sync = [&]() { if (THREADS > 64) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } };
+    sync();
+    for (uint32_t k = 2; k <= N; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = t; i < N; i += THREADS) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint64_t a = s_w[i], b = s_w[l];
+                    if ((a > b) == ((i & k) == 0)) { s_w[i] = b; s_w[l] = a; }
+                }
+            }
+            sync();
+        }
+    for (uint32_t i = t; i < n; i += THREADS) {
+        const uint2 sd = gathered[off + (uint32_t)s_w[i]];
+        sorted[off + i] = sd;
+        skeys_sorted[off + i] = key_by_tpos ? (((uint64_t)(uint32_t)q << 32) | sd.x) : (((uint64_t)(uint32_t)q << 20) | (sd.y & 0xFFFFFu));
+    }
 }
 
 /* ---- 6: equal qPos inside a request -> replay std::sort on the original order ---- */
@@ -267,6 +311,12 @@ __global__ void lf_tie_flag_kernel(uint64_t n, const uint64_t *__restrict__ skey
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 || i >= n) return;
     if (skeys_sorted[i] == skeys_sorted[i - 1]) flag[skeys_sorted[i] >> 20] = 1;
+}
+__global__ void lf_count_flags_kernel(const uint8_t *__restrict__ flag, int n, unsigned long long *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t b = lf_ballot(i < n && flag[i] != 0);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (unsigned long long)__popcll(b));
 }
 struct lf_dseed { uint32_t tPos, qpl; };
 #define DSEED_QLESS(a, b) (((a)->qpl & 0xFFFFFu) < ((b)->qpl & 0xFFFFFu))     /* compare_seed (src/Chain.cpp:227-230) */
@@ -451,7 +501,7 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
 
     /* ---- requests ---- */
     const size_t Q = (size_t)n_req;
-    char *pq = (char *)VSLOT(6, al256(Q * 4) * 4 + al256(Q * 8) * 2 + al256((Q + 1) * 8) * 3 + al256(Q) + al256(Q * sizeof(lf_chain_win)) + 1024);
+    char *pq = (char *)VSLOT(6, al256(Q * 4) * 4 + al256(Q * 8) * 2 + al256((Q + 1) * 8) * 3 + al256(Q) + al256(Q * sizeof(lf_chain_win)) + 256 + 1024);
     int64_t *d_ctg = (int64_t *)VSLOT(7, (size_t)ix->n_seqs * 16 + 64);
     if (!pq || !d_ctg) return LF_ERR_NOMEM;
     uint32_t *d_req_read = (uint32_t *)pq; pq += al256(Q * 4);
@@ -464,7 +514,8 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     uint64_t *d_ws_off = (uint64_t *)pq; pq += al256((Q + 1) * 8);
     uint64_t *d_coff = (uint64_t *)pq; pq += al256((Q + 1) * 8);
     uint8_t *d_flag = (uint8_t *)pq; pq += al256(Q);
-    lf_chain_win *d_wins = (lf_chain_win *)pq;
+    lf_chain_win *d_wins = (lf_chain_win *)pq; pq += al256(Q * sizeof(lf_chain_win));
+    uint64_t *d_maxn = (uint64_t *)pq;                      /* the largest request (sizes the segmented sort's LDS) */
     float *d_cscore = (float *)VSLOT(8, Q * 4 + 64);
     if (!d_cscore) return LF_ERR_NOMEM;
     {
@@ -475,8 +526,9 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     }
     hipLaunchKernelGGL(lf_req_build_kernel, dim3((unsigned)((n_reads + 127) / 128)), dim3(128), 0, s, n_reads, d_off, d_nreq, d_req0, d_seg0, d_stage,
                        d_ctg, d_ctg + ix->n_seqs, ix->n_seqs, (int64_t)ix->l_pac, d_req_read, d_req_win, d_req_lo, d_req_hi);
+    HIPCHK(hipMemsetAsync(d_maxn, 0, 8, s));
     hipLaunchKernelGGL(lf_req_gather_kernel<false>, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_req_read, d_req_win, d_req_lo, d_req_hi, d_read_off,
-                       d_tpos, d_qpl, d_strand, d_req_n, (const uint64_t *)nullptr, (uint2 *)nullptr, (uint64_t *)nullptr, 0);
+                       d_tpos, d_qpl, d_strand, d_req_n, (const uint64_t *)nullptr, (uint2 *)nullptr, d_maxn, 0);
     const bool clasp = p->chain_alg == 1;
     const uint32_t big_lim = clasp ? LF_CLASP_LDS_MAX : LF_CHAIN_LDS_MAX;
     { lf_scan_u32 f; f.p = d_req_n; const int src = lf_scan_excl(dv, 1, s, f, d_req_off, (size_t)n_req); if (src != LF_OK) return src; }
@@ -484,8 +536,9 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     HIPCHK(hipMemcpyAsync(h_small + 2, d_req_off + (Q - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_small + 3, d_ws_off + (Q - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_small + 4, d_req_n + (Q - 1), 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_small + 9, d_maxn, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    const uint32_t last_n = (uint32_t)h_small[4];
+    const uint32_t last_n = (uint32_t)h_small[4], max_n = (uint32_t)h_small[9];
     const uint64_t S = h_small[2] + last_n, WS = h_small[3] + (last_n > big_lim ? last_n : 0);
     if (S >= (1ull << 31)) { lf_set_error("lfg_vote_chain: too many seeds in candidate windows (%llu)", (unsigned long long)S); return LF_ERR_ARG; }
     out->n_req_seeds = S;
@@ -499,22 +552,36 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     if (S) {
         hipLaunchKernelGGL(lf_req_gather_kernel<true>, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_req_read, d_req_win, d_req_lo, d_req_hi, d_read_off,
                            d_tpos, d_qpl, d_strand, d_req_n, (const uint64_t *)d_req_off, d_gath, d_sk, clasp ? 1 : 0);
-        int qbits = 1; while ((1ull << qbits) < (uint64_t)n_req + 1) qbits++;
-        size_t tb4 = 0;
-        const int kbits = (clasp ? 32 : 20) + qbits;        /* the radix sort is stable: equal keys keep the gathered order */
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb4, d_sk, d_sk2, (uint64_t *)d_gath, (uint64_t *)d_sorted, (int)S, 0, kbits, s);
-        void *d_tmp3 = VSLOT(17, tb4 + 256);
-        if (!d_tmp3) return LF_ERR_NOMEM;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp3, tb4, d_sk, d_sk2, (uint64_t *)d_gath, (uint64_t *)d_sorted, (int)S, 0, kbits, s));
+        void *d_tmp3 = nullptr; size_t tb4 = 0;
+        if (max_n <= 8192u) {
+            /* segmented sort in LDS: one wavefront per request up to 512 seeds (4 KiB), a 256-thread workgroup up to 8192 (64 KiB) */
+            const uint32_t small_hi = max_n < 512u ? max_n : 512u;
+            uint32_t cap1 = 64; while (cap1 < small_hi) cap1 <<= 1;
+            hipLaunchKernelGGL(lf_req_sort_kernel<64>, dim3((unsigned)n_req), dim3(64), (size_t)cap1 * 8, s, (int)n_req, (const uint64_t *)d_req_off, (const uint32_t *)d_req_n,
+                               (const uint2 *)d_gath, d_sorted, d_sk2, clasp ? 1 : 0, 0u, 512u);
+            if (max_n > 512u) {
+                uint32_t cap2 = 1024; while (cap2 < max_n) cap2 <<= 1;
+                hipLaunchKernelGGL(lf_req_sort_kernel<256>, dim3((unsigned)n_req), dim3(256), (size_t)cap2 * 8, s, (int)n_req, (const uint64_t *)d_req_off, (const uint32_t *)d_req_n,
+                                   (const uint2 *)d_gath, d_sorted, d_sk2, clasp ? 1 : 0, 513u, 8192u);
+            }
+        } else {
+            /* a request above 8192 seeds (a window over a satellite-like repeat): the chunk-wide radix sort on (request, key) */
+            int qbits = 1; while ((1ull << qbits) < (uint64_t)n_req + 1) qbits++;
+            const int kbits = (clasp ? 32 : 20) + qbits;        /* the radix sort is stable: equal keys keep the gathered order */
+            (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb4, d_sk, d_sk2, (uint64_t *)d_gath, (uint64_t *)d_sorted, (int)S, 0, kbits, s);
+            d_tmp3 = VSLOT(17, tb4 + 256);
+            if (!d_tmp3) return LF_ERR_NOMEM;
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp3, tb4, d_sk, d_sk2, (uint64_t *)d_gath, (uint64_t *)d_sorted, (int)S, 0, kbits, s));
+        }
         HIPCHK(hipMemsetAsync(d_flag, 0, Q, s));
         if (!clasp) {
         hipLaunchKernelGGL(lf_tie_flag_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, S, d_sk2, d_flag);
         hipLaunchKernelGGL(lf_tie_sort_kernel, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_flag, d_req_off, d_req_n, d_gath, d_sorted);
         {   /* how many requests needed the introsort replay (statistics) */
-            size_t tbf = 0; uint64_t *d_nt = (uint64_t *)d_nruns + 1;
-            hipcub::TransformInputIterator<uint64_t, lf_w8, uint8_t *> f64(d_flag, lf_w8());
-            (void)hipcub::DeviceReduce::Sum(nullptr, tbf, f64, d_nt, (int)n_req, s);
-            if (tbf <= tb4) { HIPCHK(hipcub::DeviceReduce::Sum(d_tmp3, tbf, f64, d_nt, (int)n_req, s)); HIPCHK(hipMemcpyAsync(h_small + 8, d_nt, 8, hipMemcpyDeviceToHost, s)); have_ties = true; }
+            uint64_t *d_nt = (uint64_t *)d_nruns + 1;
+            HIPCHK(hipMemsetAsync(d_nt, 0, 8, s));
+            hipLaunchKernelGGL(lf_count_flags_kernel, dim3((unsigned)((n_req + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_flag, (int)n_req, (unsigned long long *)d_nt);
+            HIPCHK(hipMemcpyAsync(h_small + 8, d_nt, 8, hipMemcpyDeviceToHost, s)); have_ties = true;
         }
         }
     }

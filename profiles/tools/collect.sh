@@ -2,7 +2,7 @@
 # collect.sh <tag> -- run on the GPU box from the repo root: bench + rocprofv3 passes for config C2, summaries into
 # gpurun_out/<tag>/ (copy what you want judged into profiles/<tag>/).  rocprofv3 gets the program itself after `--`.
 set -u
-TAG=${1:-r03_c2}
+TAG=${1:-r04_c2}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null

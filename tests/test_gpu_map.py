@@ -493,3 +493,45 @@ def test_long_runs_of_matches_and_sparse_edits(lf, golden_dir, oracle_lib):
     recs = [l.split(b"\t") for l in sam.split(b"\n") if l]
     assert sum(f[5] == b"38000M" for f in recs) == 2, "mismatches only: one M run"
     assert sum(bool(re.search(rb"\d{5}M\d[ID]", f[5])) for f in recs) == 4, "five-digit runs closed by an indel"
+
+
+@pytest.mark.parametrize("chunk,lanes", [(0, 8), (5, 8), (9, 2)])
+def test_seq_less_egress_into_a_pinned_buffer(lf, oracle, oracle_lib, golden_reads, monkeypatch, chunk, lanes):
+    """lf_map_batch_into with PINNED host memory: the SEQ / QUAL columns are left out of the device text, a kernel stores the rest
+    of every line straight into the buffer, host threads fill SEQ (reverse-complemented for flag 16) / QUAL from the caller's
+    strings (lf_sam.hip HOLES mode) -- same bytes as the whole-line path (LF_SAM_FULL=1) and the oracle: FASTA and FASTQ, a read
+    group, records on both strands, secondaries, unmapped and too-short reads, chunks waiting for their place in the output"""
+    import ctypes as C
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    L = lf.L
+    L.lfg_host_alloc.restype = C.c_void_p
+    L.lfg_host_alloc.argtypes = [C.c_size_t]
+    L.lfg_host_free.argtypes = [C.c_void_p]
+    L.lfg_host_mapped.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+    cap = 8 << 20
+    buf = L.lfg_host_alloc(cap)
+    assert buf and L.lfg_host_mapped(0, buf, cap) == 1
+    plain = np.zeros(16, dtype=np.uint8)
+    assert L.lfg_host_mapped(0, plain.ctypes.data, plain.size) == 0          # ordinary memory: the whole-line path
+    if chunk:
+        monkeypatch.setenv("LF_CHUNK_READS", str(chunk))
+    monkeypatch.setenv("LF_LANES", str(lanes))
+    rng = np.random.default_rng(9)
+    quals = [bytes(rng.integers(35, 74, size=len(s)).astype(np.uint8)) for s in seqs]
+    try:
+        for q, kw in ((None, dict(GOLDEN_CONFIGS["n30"])), (quals, dict(read_group_id=b"grp1"))):
+            p = la.default_params(**kw)
+            exp = oracle.map_batch(names, seqs, q, params=oracle_lib.default_params(**kw))
+            C.memset(buf, 0x23, cap)
+            ln, _ = lf.map_batch_into(names, seqs, buf, cap, quals=q, params=p)
+            got = C.string_at(buf, ln)
+            assert got == exp, first_diff(got, exp)
+            assert C.string_at(buf + ln, 1) == b"\0"
+            monkeypatch.setenv("LF_SAM_FULL", "1")
+            C.memset(buf, 0x23, cap)
+            ln2, _ = lf.map_batch_into(names, seqs, buf, cap, quals=q, params=p)
+            assert C.string_at(buf, ln2) == exp
+            monkeypatch.delenv("LF_SAM_FULL")
+    finally:
+        L.lfg_host_free(buf)
