@@ -46,12 +46,13 @@
  * checkpoint traffic of the forward pass) is worth the 8 block steps that are replayed twice.  Same cells, same
  * Up -> Left -> Diagonal priority (lib/edlib/edlib.cpp:950,984,1015), same ops.
  * ---------------------------------------------------------------------------------------------- */
+template <int HK>
 __global__ void __launch_bounds__(64)
 lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, int64_t pac_syms, const lf_hist_t *__restrict__ ckpt, uint8_t *__restrict__ ops,
                    const int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
 {
-    constexpr int K = LF_RSTEPS, HK = 8, ROW = LF_RROW;
-    __shared__ ulonglong2 s_tile[HK * 64];               /* (Pv, Ph) of a half's eight columns, [column][lane] */
+    constexpr int K = LF_RSTEPS, ROW = LF_RROW, NPART = K / HK;
+    __shared__ ulonglong2 s_tile[HK * 64];               /* (Pv, Ph) of a part's HK columns, [column][lane] */
     const int lane = threadIdx.x, idx = blockIdx.x * 64 + lane;
     const bool live = idx < n_probs;
     const lf_aln_prob pr = probs[live ? idx : n_probs - 1];
@@ -88,8 +89,8 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
         const uint32_t cw = b > 0 ? craw : 0x55555555u;                            /* block 0: +1 enters every column */
         /* the two halves, right one first.  A half is replayed only when some path of the wavefront is in it. */
 #pragma unroll
-        for (int half = 1; half >= 0; half--) {
-            const int h0 = cbase + half * HK;                                   /* first column of the half */
+        for (int half = NPART - 1; half >= 0; half--) {
+            const int h0 = cbase + half * HK;                                   /* first column of the part */
             const bool in_half = r > 0 && c > 0 && ((r - 1) >> 6) == b && (int)c >= h0 && (int)c < h0 + HK && (act);
             if (!lf_any(in_half)) continue;
             uint64_t Pv = Pv0, Mv = Mv0;
@@ -821,7 +822,12 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         RA.wave0 = 0; RA.n_waves = nw_nw; lf_rsweep_launch(cs[1], false, RA);
         RA.wave0 = nw_nw; RA.n_waves = nw_shw; lf_rsweep_launch(cs[1], true, RA);
         HIPCHK(hipEventRecord(bd[2], cs[1]));
-        hipLaunchKernelGGL(lf_edlib_tb_kernel, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, D->pac_syms, d_hist, d_ops, d_end, d_len);
+        {
+            /* columns per replayed part of a 16-step tile: 8 (two parts, 8 KiB of LDS per wavefront) or 4 (four parts, 4 KiB: twice the wavefronts per CU, 5 / 3 of the replayed steps) */
+            const int tb_hk = getenv("LF_TB_HK") ? atoi(getenv("LF_TB_HK")) : 8;
+            if (tb_hk == 4) hipLaunchKernelGGL(lf_edlib_tb_kernel<4>, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, D->pac_syms, d_hist, d_ops, d_end, d_len);
+            else hipLaunchKernelGGL(lf_edlib_tb_kernel<8>, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, D->pac_syms, d_hist, d_ops, d_end, d_len);
+        }
         HIPCHK(hipEventRecord(bd[3], cs[1]));
     }
     for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && cs[k] != s) { HIPCHK(hipEventRecord(cdone[k], cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }
@@ -966,16 +972,30 @@ __device__ __forceinline__ int lf_wave_incl_max_i32(int v)
 }
 struct lf_ksw_prob { uint64_t qoff, toff, ws_off; int32_t qlen, tlen, o_del, e_del, o_ins, e_ins, w, zdrop, h0, id; };
 
+/* the band width ksw_extend2 really uses (lib/bwa/ksw.c:409-416) */
+__host__ __device__ __forceinline__ int lf_ksw_band(int qlen, int o_del, int e_del, int o_ins, int e_ins, int w)
+{
+    int max_ins = (int)((double)(qlen * 2 - o_ins) / e_ins + 1.);
+    if (max_ins < 1) max_ins = 1;
+    if (w > max_ins) w = max_ins;
+    int max_del = (int)((double)(qlen * 2 - o_del) / e_del + 1.);
+    if (max_del < 1) max_del = 1;
+    if (w > max_del) w = max_del;
+    return w;
+}
+#define LF_KSW_MW_MAXW 127       /* lf_ksw_mw_kernel: a row's band (<= 2 w + 1 columns) fits the 256 threads of its workgroup */
+
 template <bool LDS>
 __global__ void __launch_bounds__(64)
 lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t *__restrict__ qs, const uint8_t *__restrict__ ts,
-              int32_t *__restrict__ ws, int32_t *__restrict__ out_score, int32_t *__restrict__ out_qle, int32_t *__restrict__ out_tle, int lds_q)
+              int32_t *__restrict__ ws, int32_t *__restrict__ out_score, int32_t *__restrict__ out_qle, int32_t *__restrict__ out_tle, int lds_q, int wide_only)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t s_he[];
     const int gid = blockIdx.x, lane = threadIdx.x;
     if (gid >= n_probs) return;
     const lf_ksw_prob pr = probs[gid];
     if (LDS != (pr.qlen <= lds_q)) return;            /* the other instantiation serves this problem */
+    if (wide_only && lf_ksw_band(pr.qlen, pr.o_del, pr.e_del, pr.o_ins, pr.e_ins, pr.w) <= LF_KSW_MW_MAXW) return;      /* lf_ksw_mw_kernel does */
     const uint8_t *q = qs + pr.qoff, *t = ts + pr.toff;
     const int qlen = pr.qlen, tlen = pr.tlen, o_del = pr.o_del, e_del = pr.e_del, o_ins = pr.o_ins, e_ins = pr.e_ins;
     const int zdrop = pr.zdrop, h0 = pr.h0;
@@ -991,12 +1011,7 @@ lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t 
         H[j] = v; E[j] = 0;
     }
     __syncthreads();
-    int max_ins = (int)((double)(qlen * 2 - o_ins) / e_ins + 1.);
-    if (max_ins < 1) max_ins = 1;
-    if (w > max_ins) w = max_ins;
-    int max_del = (int)((double)(qlen * 2 - o_del) / e_del + 1.);
-    if (max_del < 1) max_del = 1;
-    if (w > max_del) w = max_del;
+    w = lf_ksw_band(qlen, o_del, e_del, o_ins, e_ins, w);
     int mx = h0, max_i = -1, max_j = -1, beg = 0, end = qlen;
     for (int i = 0; i < tlen; ++i) {
         const int tc = t[i];
@@ -1079,6 +1094,137 @@ lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t 
     if (lane == 0) { out_score[pr.id] = mx; out_qle[pr.id] = max_j + 1; out_tle[pr.id] = max_i + 1; }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * ksw_extend2 with the row spread over the FOUR wavefronts of a workgroup: the problems of the clip tests are few and long
+ * (thousands of dependent rows), so what counts is the time of one row.  lf_ksw_kernel walks a row's band tile by tile (up
+ * to four 64-column tiles, each a round trip to LDS, a DPP scan, a carry to the next tile) and spends ~1.3 us per row; here
+ * thread k owns column beg + k of the row (band <= 2 w + 1 <= 255 columns: w <= LF_KSW_MW_MAXW, all of lordFAST's calls):
+ *   phase 1   M, E, the insertion candidates; max-scan inside the wavefront; the tile's aggregate to LDS        | barrier
+ *   phase 2   f entering the tile from the aggregates of the tiles to its left (carry(t + 1) = max(carry(t), A(t)) - 64 e_ins),
+ *             h, the new E; H(i, j) is stored one slot to the right by its own thread; per wavefront: the row maximum with the
+ *             reference's tie rule, and the first / last slot of the NEXT row's band that is not all zero (from h and e in
+ *             registers: slot p holds h(p - 1) and e(p)), to LDS                                              | barrier
+ *   phase 3   every thread combines the four wavefronts' results: z-drop, maximum bookkeeping and band trimming are the
+ *             reference's scalar code on workgroup-uniform values
+ * Two barriers per row, no second pass over the row for the trimming, the read's bases in LDS.  Same arithmetic, same results.
+ * ---------------------------------------------------------------------------------------------- */
+template <bool LDS>
+__global__ void __launch_bounds__(256)
+lf_ksw_mw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t *__restrict__ qs, const uint8_t *__restrict__ ts,
+                 int32_t *__restrict__ ws, int32_t *__restrict__ out_score, int32_t *__restrict__ out_qle, int32_t *__restrict__ out_tle, int lds_q)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t s_he[];
+    __shared__ int s_A[4], s_mn[4], s_mxp[4];
+    __shared__ uint32_t s_bh[4], s_bl[4];
+    const int gid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (gid >= n_probs) return;
+    const lf_ksw_prob pr = probs[gid];
+    if (LDS != (pr.qlen <= lds_q)) return;            /* the other instantiation serves this problem */
+    const int qlen = pr.qlen, tlen = pr.tlen, o_del = pr.o_del, e_del = pr.e_del, o_ins = pr.o_ins, e_ins = pr.e_ins;
+    const int zdrop = pr.zdrop, h0 = pr.h0;
+    const int w = lf_ksw_band(qlen, o_del, e_del, o_ins, e_ins, pr.w);
+    if (w > LF_KSW_MW_MAXW) return;                   /* lf_ksw_kernel does */
+    const uint8_t *q = qs + pr.qoff, *t = ts + pr.toff;
+    int32_t *H, *E; const uint8_t *Q = q;
+    if (LDS) {
+        H = s_he; E = s_he + qlen + 2;
+        uint8_t *sq = reinterpret_cast<uint8_t *>(s_he + 2 * (lds_q + 2));
+        for (int j = tid; j < qlen; j += 256) sq[j] = q[j];
+        Q = sq;
+    } else { H = ws + pr.ws_off; E = H + qlen + 2; }
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    /* first row (lib/bwa/ksw.c:404-407): h0, h0 - oe_ins, then -e_ins per column while positive */
+    for (int j = tid; j <= qlen + 1; j += 256) {
+        int v = 0;
+        if (j == 0) v = h0;
+        else if (j <= qlen && h0 > oe_ins) { const long long x = (long long)h0 - oe_ins - (long long)(j - 1) * e_ins; v = (j == 1 || x + e_ins > e_ins) ? (int)(x > 0 ? x : 0) : 0; }
+        H[j] = v; E[j] = 0;
+    }
+    __syncthreads();
+    int mx = h0, max_i = -1, max_j = -1, beg = 0, end = qlen;
+    int tc = tlen > 0 ? (int)t[0] : 0;
+    for (int i = 0; i < tlen; ++i) {
+        const int tc_next = i + 1 < tlen ? (int)t[i + 1] : 0;      /* requested a row ahead */
+        if (beg < i - w) beg = i - w;
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        int h1;
+        if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
+        else h1 = 0;
+        const int j = beg + tid;
+        const bool act = j < end;
+        /* ---- phase 1 ---- */
+        int M = 0, e = 0, tins = 0;
+        if (act) {
+            M = H[j]; e = E[j];
+            const int qc = Q[j];
+            const int sc = (tc > 3 || qc > 3) ? 0 : (tc == qc ? 2 : -16);
+            M = M ? M + sc : 0;
+            tins = M - oe_ins; if (tins < 0) tins = 0;
+        }
+        const int Bv = act ? tins + (lane + 1) * e_ins : INT_MIN / 2;
+        const int incl = lf_wave_incl_max_i32(Bv);
+        const int excl = __builtin_amdgcn_update_dpp(INT_MIN, incl, 0x138, 0xf, 0xf, false);      /* lane l takes lanes < l */
+        if (lane == 63) s_A[wv] = incl;
+        __syncthreads();
+        /* ---- phase 2 ---- */
+        int carry = 0;                                   /* f entering the row's first column */
+#pragma unroll
+        for (int u = 0; u < 3; u++) if (u < wv) { const int a = s_A[u]; carry = (a > carry ? a : carry) - 64 * e_ins; }
+        const int G = excl > carry ? excl : carry;
+        const int fin = G - lane * e_ins;
+        int h = M > e ? M : e;
+        h = h > fin ? h : fin;
+        if (!act) h = 0;
+        int e2 = 0;
+        if (act) {
+            H[j + 1] = h;                                /* H(i, j) goes to slot j + 1 of the next row (the reference's eh[j].h = h1 trick) */
+            int tt = M - oe_del; if (tt < 0) tt = 0;
+            e2 = e - e_del; if (e2 < tt) e2 = tt;
+            E[j] = e2;
+            if (j + 1 == end) E[end] = 0;
+        }
+        if (tid == 0) { H[beg] = h1; if (beg >= end) E[end] = 0; }
+        {
+            /* row maximum, the LAST column on ties (`mj = m > h ? mj : j`): the high words first, then the columns of the lanes that tie */
+            const uint32_t bh = act ? (uint32_t)h : 0u, hmax = lf_wave_max_u32(bh);
+            const uint32_t bl = (act && bh == hmax) ? (uint32_t)j : 0u, lmax = lf_wave_max_u32(bl);
+            /* slots of the next row that are not all zero: slot j + 1 through h, slot j through e2 */
+            const unsigned long long ba = lf_ballot(act && h != 0), bb = lf_ballot(act && e2 != 0);
+            if (lane == 0) {
+                const int base = beg + 64 * wv;
+                int mn = INT_MAX, mxp = INT_MIN;
+                if (ba) { mn = base + (__ffsll((long long)ba) - 1) + 1; mxp = base + (63 - __clzll((long long)ba)) + 1; }
+                if (bb) { const int a0 = base + (__ffsll((long long)bb) - 1), a1 = base + (63 - __clzll((long long)bb)); mn = a0 < mn ? a0 : mn; mxp = a1 > mxp ? a1 : mxp; }
+                s_bh[wv] = hmax; s_bl[wv] = lmax; s_mn[wv] = mn; s_mxp[wv] = mxp;
+            }
+        }
+        __syncthreads();
+        /* ---- phase 3: workgroup-uniform ---- */
+        uint32_t hm = 0, lm = 0; int mn = h1 != 0 ? beg : INT_MAX, mxp = h1 != 0 ? beg : INT_MIN;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t a = s_bh[u], b = s_bl[u];
+            if (a > hm) { hm = a; lm = b; } else if (a == hm && b > lm) lm = b;
+            const int x = s_mn[u], y = s_mxp[u];
+            mn = x < mn ? x : mn; mxp = y > mxp ? y : mxp;
+        }
+        const int m = beg < end ? (int)hm : 0, mj = beg < end ? (int)lm : -1;
+        tc = tc_next;
+        if (m == 0) break;
+        if (m > mx) { mx = m; max_i = i; max_j = mj; }
+        else if (zdrop > 0) {
+            if (i - max_i > mj - max_j) { if (mx - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
+            else { if (mx - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
+        }
+        /* trim the band: first / last slot of [beg, end] that is not all zero (lib/bwa/ksw.c:462-465) */
+        const int nb = mn == INT_MAX ? end : mn, ne = mxp == INT_MIN ? end - 1 : mxp;
+        beg = nb;
+        end = ne + 2 < qlen ? ne + 2 : qlen;
+    }
+    if (tid == 0) { out_score[pr.id] = mx; out_qle[pr.id] = max_j + 1; out_tle[pr.id] = max_i + 1; }
+}
+
 extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff, const uint8_t *t, const uint64_t *toff,
                        const int32_t *prm, int32_t *score, int32_t *qle, int32_t *tle, float *ms)
 {
@@ -1111,13 +1257,28 @@ extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff
     HIPCHK(hipMemcpyAsync(d_t, t, toff[n], hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_p, P.data(), P.size() * sizeof(lf_ksw_prob), hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(e0, s));
-    int qmax = 0;
-    for (int i = 0; i < n; i++) qmax = std::max(qmax, P[i].qlen);
+    int qmax = 0, n_wide = 0, n_narrow = 0, qmax_wide = 0, qmax_narrow = 0;
+    const bool one_wave = getenv("LF_KSW_1WAVE") && atoi(getenv("LF_KSW_1WAVE")) != 0;      /* A / B: every problem on lf_ksw_kernel */
+    for (int i = 0; i < n; i++) {
+        qmax = std::max(qmax, P[i].qlen);
+        const bool wide = one_wave || lf_ksw_band(P[i].qlen, P[i].o_del, P[i].e_del, P[i].o_ins, P[i].e_ins, P[i].w) > LF_KSW_MW_MAXW;
+        if (wide) { n_wide++; qmax_wide = std::max(qmax_wide, P[i].qlen); } else { n_narrow++; qmax_narrow = std::max(qmax_narrow, P[i].qlen); }
+    }
     const int lds_q = std::min(qmax, 6000);
-    hipLaunchKernelGGL(lf_ksw_kernel<true>, dim3((unsigned)n), dim3(64), (size_t)(2 * (lds_q + 2)) * 4, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
-                       (const uint8_t *)d_t, d_ws, d_s, d_ql, d_tl, lds_q);
-    if (qmax > lds_q) hipLaunchKernelGGL(lf_ksw_kernel<false>, dim3((unsigned)n), dim3(64), 0, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
-                       (const uint8_t *)d_t, d_ws, d_s, d_ql, d_tl, lds_q);
+    if (n_narrow) {
+        /* H, E and the read's bases in LDS */
+        hipLaunchKernelGGL(lf_ksw_mw_kernel<true>, dim3((unsigned)n), dim3(256), (size_t)(2 * (lds_q + 2)) * 4 + (size_t)lds_q + 16, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
+                           (const uint8_t *)d_t, d_ws, d_s, d_ql, d_tl, lds_q);
+        if (qmax_narrow > lds_q) hipLaunchKernelGGL(lf_ksw_mw_kernel<false>, dim3((unsigned)n), dim3(256), 0, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
+                           (const uint8_t *)d_t, d_ws, d_s, d_ql, d_tl, lds_q);
+    }
+    if (n_wide) {
+        const int wide_only = one_wave ? 0 : 1;
+        hipLaunchKernelGGL(lf_ksw_kernel<true>, dim3((unsigned)n), dim3(64), (size_t)(2 * (lds_q + 2)) * 4, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
+                           (const uint8_t *)d_t, d_ws, d_s, d_ql, d_tl, lds_q, wide_only);
+        if (qmax_wide > lds_q) hipLaunchKernelGGL(lf_ksw_kernel<false>, dim3((unsigned)n), dim3(64), 0, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
+                           (const uint8_t *)d_t, d_ws, d_s, d_ql, d_tl, lds_q, wide_only);
+    }
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipMemcpyAsync(score, d_s, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(qle, d_ql, (size_t)n * 4, hipMemcpyDeviceToHost, s));

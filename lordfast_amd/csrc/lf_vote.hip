@@ -205,6 +205,197 @@ lf_vote_hash_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_
     if (tid == 0) { mode[r] = 3; nreq[r] = nl; vscore[r] = top; }
 }
 
+/* ---- 1-3 again, for the reads whose table fits into LDS: CELLS instead of windows, every cell looked at by its creator ----
+ * lf_vote_hash_kernel inserts two votes per hit and finds the local maxima by scanning the whole table three times; it issued
+ * more scalar than vector instructions (3.3 G against 2.6 G per 100 k reads: divergent probe loops and `continue`s) and ran at
+ * the CU's scalar issue rate.  Two observations remove half of the work:
+ *   - a hit in cell i = floor(tPos / L) votes for the windows i and i - 1 (src/LordFAST.cpp:612-619), so
+ *     score(w) = cell(w) + cell(w + 1): ONE insert per hit into a table of cells (half the atomics, half the table -- twice
+ *     the reads per CU), and the local-maximum test of window w (:630-632), score(w) >= score(w - 1) && score(w) > score(w + 1),
+ *     is   cell(w + 1) >= cell(w - 1)  &&  cell(w) > cell(w + 2);
+ *   - a distinct cell has exactly one creator, the thread whose compare-and-swap found the slot empty.  It keeps the slot in
+ *     a register (H hits per thread, H a template parameter: all loops unrolled) and tests the cell's windows after the
+ *     barrier: window c always; window c - 1 only when cell c - 1 does not exist (otherwise that cell's creator does it) --
+ *     and that window can only be a maximum when it is the last one of the reference.  The table is never scanned.
+ * Same candidate set, same scores, same outputs as the scan (which the reads above the LDS classes still take, GTAB). */
+template <int H>
+__global__ void __launch_bounds__(LF_VOTE_THREADS)
+lf_vote_cell_kernel(int n_reads, const uint64_t *__restrict__ off, const uint64_t *__restrict__ read_off,
+                    const uint32_t *__restrict__ tpos, const uint32_t *__restrict__ qpl, const uint8_t *__restrict__ strand,
+                    uint32_t min_anchor_len, uint32_t l_pac, uint32_t min_read_len,
+                    uint64_t hits_lo, uint64_t hits_hi, uint32_t cap,
+                    uint8_t *__restrict__ mode, uint32_t *__restrict__ nreq, int64_t *__restrict__ seg0,
+                    uint32_t *__restrict__ stage, uint32_t *__restrict__ tmp_list, float *__restrict__ vscore)
+{
+    extern __shared__ uint32_t s_tab[];
+    __shared__ unsigned long long s_best;
+    __shared__ uint32_t s_second, s_ncand, s_nlist;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t a = read_off[r], b = read_off[r + 1], hits = b - a;
+    if (hits < hits_lo || hits > hits_hi) return;                           /* another launch's size class */
+    uint32_t *tab = s_tab, *bits = tab + 2 * cap;                            /* slot h: cell key + 1 at tab[2h], weight sum at tab[2h + 1] */
+    const uint32_t mask = cap - 1;
+    {   /* 2 cap + LF_VOTE_FILTER_WORDS words, 16 bytes per store */
+        uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+        for (uint32_t i = tid; i < (2 * cap + LF_VOTE_FILTER_WORDS) / 4; i += LF_VOTE_THREADS) t4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (tid == 0) { s_best = 0; s_second = 0; s_ncand = 0; s_nlist = 0; seg0[r] = (int64_t)(2 * a); }
+    /* the thread's hits: all loads in flight together */
+    const uint32_t L = (uint32_t)(off[r + 1] - off[r]);
+    uint32_t h_t[H], h_q[H], h_s[H];
+#pragma unroll
+    for (int u = 0; u < H; u++) {
+        const uint64_t j = a + (uint64_t)tid + (uint64_t)u * LF_VOTE_THREADS;
+        const bool in = j < b;
+        h_t[u] = in ? tpos[j] : 0u; h_q[u] = in ? qpl[j] : 0u; h_s[u] = in ? (uint32_t)strand[j] : 0xffu;      /* 0xff: no hit */
+    }
+    __syncthreads();
+    /* Probe loops are WAVE-SYNCHRONOUS: the loop condition is a ballot (one scalar branch per trip), everything inside is
+     * predicated -- a lane that is done keeps walking without effect.  The compiler's own structurisation of per-lane `for (;;)`
+     * probe loops with early exits cost ~25 scalar instructions per trip and lookup. */
+    uint32_t own[H];                                                         /* slot of a cell this thread created, ~0 otherwise */
+    {
+        uint32_t key[H], wgt[H], hh[H], pend = 0;
+#pragma unroll
+        for (int u = 0; u < H; u++) {
+            own[u] = ~0u;
+            key[u] = (h_s[u] << VK_WIN_BITS) | (h_t[u] / L);
+            wgt[u] = (uint32_t)(1 + ((int32_t)(h_q[u] >> 20) - (int32_t)min_anchor_len));
+            hh[u] = vk_hash(key[u], mask);
+            pend |= (h_s[u] != 0xffu ? 1u : 0u) << u;
+        }
+        while (lf_any(pend != 0u)) {
+#pragma unroll
+            for (int u = 0; u < H; u++) {
+                if ((pend >> u) & 1u) {
+                    const uint32_t old = atomicCAS(&tab[2 * hh[u]], 0u, key[u] + 1u);
+                    if (old == 0u) { const uint32_t fb = vk_hash2(key[u]); atomicOr(&bits[fb >> 5], 1u << (fb & 31)); own[u] = hh[u]; }
+                    if (old == 0u || old == key[u] + 1u) { atomicAdd(&tab[2 * hh[u] + 1], wgt[u]); pend &= ~(1u << u); }
+                    hh[u] = (hh[u] + 1) & mask;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    /* weight sums of three cells at once, 0 for a cell that does not exist (existing cells have >= 1); go = look at all */
+    auto cells3 = [&](bool go, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t &c0, uint32_t &c1, uint32_t &c2) {
+        const uint32_t f0 = vk_hash2(k0), f1 = vk_hash2(k1), f2 = vk_hash2(k2);
+        bool p0 = go && ((bits[f0 >> 5] >> (f0 & 31)) & 1u), p1 = go && ((bits[f1 >> 5] >> (f1 & 31)) & 1u), p2 = go && ((bits[f2 >> 5] >> (f2 & 31)) & 1u);
+        uint32_t h0 = vk_hash(k0, mask), h1 = vk_hash(k1, mask), h2 = vk_hash(k2, mask);
+        c0 = 0; c1 = 0; c2 = 0;
+        while (lf_any(p0 || p1 || p2)) {
+            const uint2 a0 = *reinterpret_cast<const uint2 *>(&tab[2 * h0]), a1 = *reinterpret_cast<const uint2 *>(&tab[2 * h1]), a2 = *reinterpret_cast<const uint2 *>(&tab[2 * h2]);
+            c0 = p0 && a0.x == k0 + 1u ? a0.y : c0; p0 = p0 && a0.x != 0u && a0.x != k0 + 1u; h0 = (h0 + 1) & mask;
+            c1 = p1 && a1.x == k1 + 1u ? a1.y : c1; p1 = p1 && a1.x != 0u && a1.x != k1 + 1u; h1 = (h1 + 1) & mask;
+            c2 = p2 && a2.x == k2 + 1u ? a2.y : c2; p2 = p2 && a2.x != 0u && a2.x != k2 + 1u; h2 = (h2 + 1) & mask;
+        }
+    };
+    const uint32_t refWinNum = l_pac / min_read_len;                        /* src/LordFAST.cpp:130 */
+    uint32_t lim = l_pac / L + 2; if (lim > refWinNum) lim = refWinNum;     /* :622-624 */
+    /* windows of the thread's cells: local maxima below the window limit (:630-632).  Entry e: window c of cell u = e;
+     * entry H + e: window c - 1 of the same cell (only without a cell c - 1) */
+    uint32_t w_key[H], w_sc[H], w_cc[H];
+    uint32_t is_max = 0;
+    unsigned long long lbest = 0; uint32_t lcnt = 0;
+#pragma unroll
+    for (int e = 0; e < H; e++) {
+        {
+            const bool mine = own[e] != ~0u;
+            const uint2 kc = *reinterpret_cast<const uint2 *>(&tab[2 * (mine ? own[e] : 0u)]);
+            const uint32_t key = kc.x - 1u, c = key & VK_WMASK, cc = kc.y;
+            uint32_t l1, r1, r2;
+            cells3(mine, key - 1u, key + 1u, key + 2u, l1, r1, r2);
+            l1 = c >= 1 ? l1 : 0u;                                         /* (key - 1 of cell 0 is another strand's or no cell at all) */
+            const uint32_t sc = cc + r1;
+            w_key[e] = mine ? key : 0u; w_sc[e] = mine ? sc : 0u; w_cc[e] = mine ? cc : 0u;
+            if (mine && c < lim && (c == 0 || r1 >= l1) && (c == refWinNum - 1 || cc > r2)) {
+                is_max |= 1u << e;
+                const unsigned long long v = ((unsigned long long)sc << 32) | key;
+                lbest = v > lbest ? v : lbest; lcnt++;
+            }
+            /* window c - 1 without a cell c - 1: score cc, never above its right neighbour's cc + r1 -- a maximum only as the
+             * reference's last window, where the right neighbour is not looked at (a hit past the last window: rare) */
+            const bool sec = mine && c >= 1 && l1 == 0u && c - 1 < lim && c - 1 == refWinNum - 1;
+            if (lf_any(sec)) {
+                uint32_t l2, d1, d2;
+                cells3(sec && c >= 2, key - 2u, key - 2u, key - 2u, l2, d1, d2);
+                if (sec && (c - 1 == 0 || cc >= l2)) {
+                    is_max |= 1u << (H + e);
+                    const unsigned long long v = ((unsigned long long)cc << 32) | (key - 1u);
+                    lbest = v > lbest ? v : lbest; lcnt++;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long x = __shfl_xor(lbest, o); lbest = x > lbest ? x : lbest;
+        lcnt += __shfl_xor(lcnt, o);
+    }
+    if ((tid & 63) == 0 && lcnt) { atomicMax(&s_best, lbest); atomicAdd(&s_ncand, lcnt); }
+    __syncthreads();
+    const uint32_t n_cand = s_ncand;
+    if (n_cand == 0) { if (tid == 0) { mode[r] = 1; nreq[r] = 0; vscore[r] = 0; } return; }
+    const uint32_t best_c = (uint32_t)(s_best >> 32), best_key = (uint32_t)s_best;
+    /* the second-largest score among the local maxima (the largest one itself excluded once) */
+    if (n_cand > 1) {
+        uint32_t lsec = 0;
+#pragma unroll
+        for (int e = 0; e < H; e++) {
+            const uint32_t v1 = ((is_max >> e) & 1u) && w_key[e] != best_key ? w_sc[e] : 0u; lsec = v1 > lsec ? v1 : lsec;
+            const uint32_t v2 = ((is_max >> (H + e)) & 1u) && w_key[e] - 1u != best_key ? w_cc[e] : 0u; lsec = v2 > lsec ? v2 : lsec;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t x = __shfl_xor(lsec, o); lsec = x > lsec ? x : lsec; }
+        if ((tid & 63) == 0 && lsec) atomicMax(&s_second, lsec);
+        __syncthreads();
+    }
+    const float top = (float)best_c, second = (float)s_second, scoreRatio = 4;
+    const uint64_t sg = 2 * a;
+    if (n_cand == 1 || top >= scoreRatio * second) {                         /* coarse (:531): one request, the best window */
+        if (tid == 0) { mode[r] = 2; nreq[r] = 1; stage[sg] = (best_key & VK_WMASK) | ((best_key >> VK_WIN_BITS) << 31); vscore[r] = top; }
+        return;
+    }
+    /* fine: every local maximum above best / 4 (:553, :875-877), in scan order = ascending (strand, window) */
+    const float minScore = top / scoreRatio;
+#pragma unroll
+    for (int e = 0; e < H; e++) {
+        if (((is_max >> e) & 1u) && (float)w_sc[e] > minScore) tmp_list[sg + atomicAdd(&s_nlist, 1u)] = w_key[e];
+        if (((is_max >> (H + e)) & 1u) && (float)w_cc[e] > minScore) tmp_list[sg + atomicAdd(&s_nlist, 1u)] = w_key[e] - 1u;
+    }
+    __syncthreads();
+    const uint32_t nl = s_nlist;
+    if (nl <= 64) {                                                          /* the usual handful: rank by counting */
+        for (uint32_t e = tid; e < nl; e += LF_VOTE_THREADS) {
+            const uint32_t key = tmp_list[sg + e];
+            uint32_t rank = 0;
+            for (uint32_t f = 0; f < nl; f++) rank += tmp_list[sg + f] < key;
+            stage[sg + rank] = (key & VK_WMASK) | ((key >> VK_WIN_BITS) << 31);
+        }
+    } else {
+        /* a read without a dominant window makes every local maximum a candidate: thousands.  The table is not needed any
+         * more: its memory holds the list for a bitonic sort (at most one window per cell and cells <= 2/3 cap, so the next
+         * power of two fits into the 2 cap words) */
+        uint32_t P = 128; while (P < nl) P <<= 1;
+        for (uint32_t i = tid; i < P; i += LF_VOTE_THREADS) tab[i] = i < nl ? tmp_list[sg + i] : 0xffffffffu;
+        __syncthreads();
+        for (uint32_t k = 2; k <= P; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = tid; i < P; i += LF_VOTE_THREADS) {
+                    const uint32_t x = i ^ j;
+                    if (x > i) {
+                        const uint32_t va = tab[i], vb = tab[x];
+                        if ((va > vb) == ((i & k) == 0)) { tab[i] = vb; tab[x] = va; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t e = tid; e < nl; e += LF_VOTE_THREADS) { const uint32_t key = tab[e]; stage[sg + e] = (key & VK_WMASK) | ((key >> VK_WIN_BITS) << 31); }
+    }
+    if (tid == 0) { mode[r] = 3; nreq[r] = nl; vscore[r] = top; }
+}
+
 /* ---- 4: requests ---- */
 __global__ void lf_req_build_kernel(int n_reads, const uint64_t *__restrict__ off, const uint32_t *__restrict__ nreq, const uint64_t *__restrict__ req0,
                                     const int64_t *__restrict__ seg0, const uint32_t *__restrict__ stage,
@@ -423,9 +614,14 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
         d_stage = (uint32_t *)VSLOT(1, E * 4 + 16);
         uint32_t *d_tmp_list = (uint32_t *)VSLOT(2, E * 4 + 16);
         if (!d_stage || !d_tmp_list) return LF_ERR_NOMEM;
-        /* LDS table classes (load factor <= 2/3); reads above the largest keep their table in a global scratch area */
+        /* LDS table classes (load factor <= 2/3): tables of cells (lf_vote_cell_kernel: hits <= 2/3 cap) or, with LF_VOTE_SCAN=1 /
+         * LF_VOTE_DEBUG (A / B runs; the scan kernel's per-phase cycle counters), of windows (lf_vote_hash_kernel: votes <= 2/3
+         * cap).  Reads above the largest class keep a table of windows in a global scratch area. */
+        const bool vote_scan_env = getenv("LF_VOTE_SCAN") && atoi(getenv("LF_VOTE_SCAN")) != 0;
+        const bool vote_scan = vote_scan_env || getenv("LF_VOTE_DEBUG") != nullptr;
         static const uint32_t caps[3] = { 4096, 8192, 16384 };
-        uint64_t v_max_lds = (uint64_t)caps[2] * 2 / 3;
+        static const uint32_t cell_caps[4] = { 2048, 4096, 8192, 16384 };
+        uint64_t v_max_lds = vote_scan ? (uint64_t)caps[2] * 2 / 3 : 2 * ((uint64_t)cell_caps[3] * 2 / 3);      /* in votes = 2 x hits */
         if (getenv("LF_VOTE_LDS_MAX_VOTES")) { const uint64_t x = strtoull(getenv("LF_VOTE_LDS_MAX_VOTES"), nullptr, 10); if (x < v_max_lds) v_max_lds = x; }   /* test hook: push reads to the global-table path */
         const uint64_t *h_read_off = (const uint64_t *)lfg_pin_slot(LF_PS_HITS_OFF, 0);      /* lfg_seed left it there */
         uint64_t gtab_words = 0; std::vector<uint64_t> gtab_off;
@@ -442,10 +638,32 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
             }
         } else { lf_set_error("lfg_vote_chain: no resident seed batch (host offsets)"); return LF_ERR_ARG; }
         static bool attr_set[16] = { false };
-        if (!attr_set[dv]) { HIPCHK(hipFuncSetAttribute((const void *)lf_vote_hash_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8 + LF_VOTE_FILTER_WORDS * 4)); attr_set[dv] = true; }
+        if (!attr_set[dv]) {
+            const int big = 16384 * 8 + LF_VOTE_FILTER_WORDS * 4;
+            HIPCHK(hipFuncSetAttribute((const void *)lf_vote_hash_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIPCHK(hipFuncSetAttribute((const void *)lf_vote_cell_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIPCHK(hipFuncSetAttribute((const void *)lf_vote_cell_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIPCHK(hipFuncSetAttribute((const void *)lf_vote_cell_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            HIPCHK(hipFuncSetAttribute((const void *)lf_vote_cell_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+            attr_set[dv] = true;
+        }
         unsigned long long *d_dbg = nullptr;
         if (getenv("LF_VOTE_DEBUG")) { d_dbg = (unsigned long long *)VSLOT(20, 256); if (d_dbg) HIPCHK(hipMemsetAsync(d_dbg, 0, 128, s)); }
-        uint64_t lo = 0;
+        uint64_t lo = 0;                                         /* in votes */
+        if (!vote_scan) {
+            /* hits per thread of a class: hits <= 2/3 cap <= H x LF_VOTE_THREADS */
+            uint64_t hlo = 0; const uint64_t h_max_lds = v_max_lds / 2;
+            for (int k = 0; k < 4 && hlo <= h_max_lds; k++) {
+                uint64_t hhi = (uint64_t)cell_caps[k] * 2 / 3; if (hhi > h_max_lds) hhi = h_max_lds;
+                const size_t lds = (size_t)cell_caps[k] * 8 + LF_VOTE_FILTER_WORDS * 4;
+#define LF_VOTE_CELL(HH) hipLaunchKernelGGL(lf_vote_cell_kernel<HH>, dim3((unsigned)n_reads), dim3(LF_VOTE_THREADS), lds, s, n_reads, d_off, d_read_off, d_tpos, d_qpl, d_strand, \
+                                   (uint32_t)p->min_anchor_len, (uint32_t)ix->l_pac, (uint32_t)p->min_read_len, hlo, hhi, cell_caps[k], d_mode, d_nreq, d_seg0, d_stage, d_tmp_list, d_vscore)
+                if (2 * hlo <= v_max) { if (k == 0) LF_VOTE_CELL(2); else if (k == 1) LF_VOTE_CELL(3); else if (k == 2) LF_VOTE_CELL(6); else LF_VOTE_CELL(11); }
+#undef LF_VOTE_CELL
+                hlo = hhi + 1;
+            }
+            lo = 2 * h_max_lds + 2;
+        } else
         for (int k = 0; k < 3 && lo <= v_max_lds; k++) {
             uint64_t hi = (uint64_t)caps[k] * 2 / 3; if (hi > v_max_lds) hi = v_max_lds;
             if (lo <= v_max)

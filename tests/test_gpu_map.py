@@ -327,6 +327,22 @@ def test_vote_tables_in_global_memory(lf, golden_reads, monkeypatch, cfg, lds_ma
     assert sam == exp, first_diff(sam, exp)
 
 
+@pytest.mark.parametrize("cfg", ["default", "n30", "clasp_n30", "k12c300m20"])
+def test_vote_by_cells_equals_vote_by_window_scan(lf, golden_reads, monkeypatch, cfg):
+    """lf_vote_cell_kernel (one insert per hit into a table of cells, score(w) = cell(w) + cell(w + 1), every cell's windows
+    tested by the thread that created the cell) and lf_vote_hash_kernel (two votes per hit, table scans; LF_VOTE_SCAN=1) must
+    select the same candidate windows: same SAM, same request counts"""
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    exp = golden_sam(cfg)
+    sam_c, st_c = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
+    monkeypatch.setenv("LF_VOTE_SCAN", "1")
+    sam_s, st_s = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
+    assert sam_c == exp, first_diff(sam_c, exp)
+    assert sam_s == exp, first_diff(sam_s, exp)
+    assert st_c["n_req_seeds"] == st_s["n_req_seeds"] > 0
+
+
 @pytest.mark.parametrize("cfg", ["default", "clasp_n30", "k12c300m20"])
 def test_sam_host_walk_crosscheck(lf, golden_reads, monkeypatch, cfg):
     """lf_debug_crosscheck(4) replays every chain with the host walk of lf_pipeline.c instead of lf_walk.hip (which keeps the
