@@ -53,6 +53,7 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
 {
     constexpr int K = LF_RSTEPS, ROW = LF_RROW, NPART = K / HK;
     __shared__ ulonglong2 s_tile[HK * 64];               /* (Pv, Ph) of a part's HK columns, [column][lane] */
+    __shared__ uint64_t s_peq[4 * 64];                   /* the four match masks of the block the lane's path is in, [code][lane] */
     const int lane = threadIdx.x, idx = blockIdx.x * 64 + lane;
     const bool live = idx < n_probs;
     const lf_aln_prob pr = probs[live ? idx : n_probs - 1];
@@ -70,7 +71,11 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
     lf_emitter em; em.init(ops + pr.ops_off, n + m, want);
     uint32_t r = want ? n : 0, c = want ? tl : 0;
     uint64_t lo = 0, hi = 0, valid = 0;
-    auto load_planes = [&](uint32_t b) { const int ln = lane0 + (int)b; lo = planes[ln]; hi = planes[64 + ln]; valid = planes[128 + ln]; };
+    auto load_planes = [&](uint32_t b) {
+        const int ln = lane0 + (int)b; lo = planes[ln]; hi = planes[64 + ln]; valid = planes[128 + ln];
+#pragma unroll
+        for (uint32_t cde = 0; cde < 4; cde++) s_peq[cde * 64 + lane] = lf_eq_tok<true>(cde, lo, hi, valid, qget, n, b);      /* the lane's own slots: no barrier */
+    };
     uint32_t cur_b = r > 0 ? (r - 1) >> 6 : 0;
     load_planes(cur_b);
     while (lf_any(r > 0 && c > 0)) {
@@ -87,24 +92,27 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
         const uint32_t tok16 = lf_pac16(S.pac, pr.tstart + (int64_t)dt * ((int64_t)cbase - 1), dt, ct, pac_syms);
         const uint64_t Pv0 = j > 0 ? est.pv : ~0ull, Mv0 = j > 0 ? est.ph : 0ull;      /* column 0 */
         const uint32_t cw = b > 0 ? craw : 0x55555555u;                            /* block 0: +1 enters every column */
-        /* the two halves, right one first.  A half is replayed only when some path of the wavefront is in it. */
-#pragma unroll
-        for (int half = NPART - 1; half >= 0; half--) {
+        /* the parts of the tile, right one first.  A part is replayed only when some path of the wavefront is in it; a replayed
+         * step is one LDS read (match mask), the block step, one LDS write -- the test for columns in front of the block's first
+         * one (col < 1: only in the first tile of a block below the first) is compiled in only when some lane needs it */
+        auto part = [&](auto half_tag, auto guard_tag) {
+            constexpr int half = decltype(half_tag)::value;
+            constexpr bool GUARD = decltype(guard_tag)::value;
             const int h0 = cbase + half * HK;                                   /* first column of the part */
             const bool in_half = r > 0 && c > 0 && ((r - 1) >> 6) == b && (int)c >= h0 && (int)c < h0 + HK && (act);
-            if (!lf_any(in_half)) continue;
+            if (!lf_any(in_half)) return;
             uint64_t Pv = Pv0, Mv = Mv0;
 #pragma unroll
             for (int k = 0; k < HK + half * HK; k++) {
-                const int col = cbase + k;
                 const uint32_t tk = (tok16 >> (2 * k)) & 3u;
-                const uint64_t Eq = lf_eq_tok<true>(tk, lo, hi, valid, qget, n, b);
+                const uint64_t Eq = s_peq[tk * 64 + lane];
                 uint64_t nPv = Pv, nMv = Mv, ph, mh;
                 (void)lf_myers_step(nPv, nMv, Eq, (cw >> (2 * k)) & 3u, ph, mh);
-                const bool v = col >= 1; Pv = v ? nPv : Pv; Mv = v ? nMv : Mv;       /* the block starts at column 1 */
+                if (GUARD) { const bool v = cbase + k >= 1; Pv = v ? nPv : Pv; Mv = v ? nMv : Mv; }       /* the block starts at column 1 */
+                else { Pv = nPv; Mv = nMv; }
                 if (k >= half * HK) s_tile[(k - half * HK) * 64 + lane] = make_ulonglong2(Pv, ph);      /* the lane's own slots: no barrier */
             }
-            /* walk: ONE MOVE per trip for every lane that is still inside the half (its column's (Pv, Ph) comes out of the
+            /* walk: ONE MOVE per trip for every lane that is still inside the part (its column's (Pv, Ph) comes out of the
              * lane's LDS slots).  Unrolled over the columns, with the Up moves of a column in an inner loop, the wavefront paid
              * every column's longest Up run among its 64 paths: ~2.2 trips per column for ~1.05 moves per path. */
             const int cmin = h0 < 1 ? 1 : h0;
@@ -124,10 +132,17 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
                     op = (dg & (same ^ 1u)) ? 3u : op;
                     em.put(op);
                     r -= up | dg; c -= lf | dg;
-                    inh = r > 0 && (int)c >= cmin && ((r - 1) >> 6) == b;      /* still in this block and this half */
+                    inh = r > 0 && (int)c >= cmin && ((r - 1) >> 6) == b;      /* still in this block and this part */
                 }
             }
-        }
+        };
+        auto parts = [&](auto guard_tag) {
+            if constexpr (NPART > 3) part(std::integral_constant<int, 3>{}, guard_tag);
+            if constexpr (NPART > 2) part(std::integral_constant<int, 2>{}, guard_tag);
+            if constexpr (NPART > 1) part(std::integral_constant<int, 1>{}, guard_tag);
+            part(std::integral_constant<int, 0>{}, guard_tag);
+        };
+        if (lf_any(act && cbase < 1)) parts(std::true_type{}); else parts(std::false_type{});
         {   /* the path climbed into the block above: its planes are requested now, used by the next tile */
             const uint32_t nb = r > 0 ? (r - 1) >> 6 : 0;
             if (nb != cur_b) { load_planes(nb); cur_b = nb; }
@@ -825,7 +840,8 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         {
             /* columns per replayed part of a 16-step tile: 8 (two parts, 8 KiB of LDS per wavefront) or 4 (four parts, 4 KiB: twice the wavefronts per CU, 5 / 3 of the replayed steps) */
             const int tb_hk = getenv("LF_TB_HK") ? atoi(getenv("LF_TB_HK")) : 8;
-            if (tb_hk == 4) hipLaunchKernelGGL(lf_edlib_tb_kernel<4>, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, D->pac_syms, d_hist, d_ops, d_end, d_len);
+            if (tb_hk == 16) hipLaunchKernelGGL(lf_edlib_tb_kernel<16>, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, D->pac_syms, d_hist, d_ops, d_end, d_len);
+            else if (tb_hk == 4) hipLaunchKernelGGL(lf_edlib_tb_kernel<4>, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, D->pac_syms, d_hist, d_ops, d_end, d_len);
             else hipLaunchKernelGGL(lf_edlib_tb_kernel<8>, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, D->pac_syms, d_hist, d_ops, d_end, d_len);
         }
         HIPCHK(hipEventRecord(bd[3], cs[1]));
@@ -983,7 +999,7 @@ __host__ __device__ __forceinline__ int lf_ksw_band(int qlen, int o_del, int e_d
     if (w > max_del) w = max_del;
     return w;
 }
-#define LF_KSW_MW_MAXW 127       /* lf_ksw_mw_kernel: a row's band (<= 2 w + 1 columns) fits the 256 threads of its workgroup */
+#define LF_KSW_MW_MAXW 127       /* lf_ksw_mw_kernel: a row's band (<= 2 w + 1 columns) fits the 256 threads of its workgroup and a 256-entry ring */
 
 template <bool LDS>
 __global__ void __launch_bounds__(64)
@@ -1107,13 +1123,17 @@ lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t 
  *   phase 3   every thread combines the four wavefronts' results: z-drop, maximum bookkeeping and band trimming are the
  *             reference's scalar code on workgroup-uniform values
  * Two barriers per row, no second pass over the row for the trimming, the read's bases in LDS.  Same arithmetic, same results.
+ * Measured (profiles/r04_ksw/): 1.0 us per row alone (lf_ksw_kernel: 1.5 - 1.9 with the reference's w = 100), config C4's ksw
+ * 162 -> 98 ms per step.  A one-wavefront version of the same ring design (four tiles in registers, all loads up front, no
+ * barrier) issues 2.8 x fewer instructions per row but takes 1.65 us per row: the row is a chain of dependent steps, not an
+ * instruction count, and C4's launches of a few hundred problems each are bound by that chain too.
  * ---------------------------------------------------------------------------------------------- */
 template <bool LDS>
 __global__ void __launch_bounds__(256)
 lf_ksw_mw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t *__restrict__ qs, const uint8_t *__restrict__ ts,
-                 int32_t *__restrict__ ws, int32_t *__restrict__ out_score, int32_t *__restrict__ out_qle, int32_t *__restrict__ out_tle, int lds_q)
+                 int32_t *__restrict__ out_score, int32_t *__restrict__ out_qle, int32_t *__restrict__ out_tle, int lds_q)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t s_he[];
+    extern __shared__ __attribute__((aligned(16))) int32_t s_he[];      /* H ring, E ring (256 slots each), then the read's bases (LDS instantiation) */
     __shared__ int s_A[4], s_mn[4], s_mxp[4];
     __shared__ uint32_t s_bh[4], s_bl[4];
     const int gid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1125,21 +1145,26 @@ lf_ksw_mw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8
     const int w = lf_ksw_band(qlen, o_del, e_del, o_ins, e_ins, pr.w);
     if (w > LF_KSW_MW_MAXW) return;                   /* lf_ksw_kernel does */
     const uint8_t *q = qs + pr.qoff, *t = ts + pr.toff;
-    int32_t *H, *E; const uint8_t *Q = q;
+    /* The H / E arrays of the reference (qlen + 2 entries) are only ever touched inside the row's band [beg, end], beg never
+     * decreases and end - beg <= 2 w + 1 <= 255: entry j lives in slot j & 255 of a ring, 2 KiB per problem whatever the read's
+     * length (the full arrays took 48 KiB of LDS per workgroup -- two problems per CU -- or went through HBM for reads above
+     * 6 000 bases: a round trip to memory per row).  Rows write [beg, end] without gaps, so the entries above the highest `end`
+     * so far still hold the first row's values (lib/bwa/ksw.c:404-407), which are a closed form: no initialisation pass. */
+    int32_t *H = s_he, *E = s_he + 256;
+    const uint8_t *Q = q;
     if (LDS) {
-        H = s_he; E = s_he + qlen + 2;
-        uint8_t *sq = reinterpret_cast<uint8_t *>(s_he + 2 * (lds_q + 2));
+        uint8_t *sq = reinterpret_cast<uint8_t *>(s_he + 512);
         for (int j = tid; j < qlen; j += 256) sq[j] = q[j];
         Q = sq;
-    } else { H = ws + pr.ws_off; E = H + qlen + 2; }
-    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    /* first row (lib/bwa/ksw.c:404-407): h0, h0 - oe_ins, then -e_ins per column while positive */
-    for (int j = tid; j <= qlen + 1; j += 256) {
-        int v = 0;
-        if (j == 0) v = h0;
-        else if (j <= qlen && h0 > oe_ins) { const long long x = (long long)h0 - oe_ins - (long long)(j - 1) * e_ins; v = (j == 1 || x + e_ins > e_ins) ? (int)(x > 0 ? x : 0) : 0; }
-        H[j] = v; E[j] = 0;
     }
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    auto h_first = [&](int j) -> int {               /* h0, h0 - oe_ins, then -e_ins per column while positive */
+        if (j == 0) return h0;
+        if (j > qlen || h0 <= oe_ins) return 0;
+        const long long x = (long long)h0 - oe_ins - (long long)(j - 1) * e_ins;
+        return (int)(x > 0 ? x : 0);
+    };
+    int hiw = -1;                                     /* entries [0, hiw] have been written */
     __syncthreads();
     int mx = h0, max_i = -1, max_j = -1, beg = 0, end = qlen;
     int tc = tlen > 0 ? (int)t[0] : 0;
@@ -1156,7 +1181,8 @@ lf_ksw_mw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8
         /* ---- phase 1 ---- */
         int M = 0, e = 0, tins = 0;
         if (act) {
-            M = H[j]; e = E[j];
+            M = H[j & 255]; e = E[j & 255];
+            if (j > hiw) { M = h_first(j); e = 0; }   /* (the columns that enter the band: one or two per row) */
             const int qc = Q[j];
             const int sc = (tc > 3 || qc > 3) ? 0 : (tc == qc ? 2 : -16);
             M = M ? M + sc : 0;
@@ -1178,13 +1204,14 @@ lf_ksw_mw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8
         if (!act) h = 0;
         int e2 = 0;
         if (act) {
-            H[j + 1] = h;                                /* H(i, j) goes to slot j + 1 of the next row (the reference's eh[j].h = h1 trick) */
+            H[(j + 1) & 255] = h;                        /* H(i, j) goes to entry j + 1 of the next row (the reference's eh[j].h = h1 trick) */
             int tt = M - oe_del; if (tt < 0) tt = 0;
             e2 = e - e_del; if (e2 < tt) e2 = tt;
-            E[j] = e2;
-            if (j + 1 == end) E[end] = 0;
+            E[j & 255] = e2;
+            if (j + 1 == end) E[end & 255] = 0;
         }
-        if (tid == 0) { H[beg] = h1; if (beg >= end) E[end] = 0; }
+        if (tid == 0) { H[beg & 255] = h1; if (beg >= end) E[end & 255] = 0; }
+        hiw = end > hiw ? end : hiw;
         {
             /* row maximum, the LAST column on ties (`mj = m > h ? mj : j`): the high words first, then the columns of the lanes that tie */
             const uint32_t bh = act ? (uint32_t)h : 0u, hmax = lf_wave_max_u32(bh);
@@ -1266,11 +1293,12 @@ extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff
     }
     const int lds_q = std::min(qmax, 6000);
     if (n_narrow) {
-        /* H, E and the read's bases in LDS */
-        hipLaunchKernelGGL(lf_ksw_mw_kernel<true>, dim3((unsigned)n), dim3(256), (size_t)(2 * (lds_q + 2)) * 4 + (size_t)lds_q + 16, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
-                           (const uint8_t *)d_t, d_ws, d_s, d_ql, d_tl, lds_q);
-        if (qmax_narrow > lds_q) hipLaunchKernelGGL(lf_ksw_mw_kernel<false>, dim3((unsigned)n), dim3(256), 0, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
-                           (const uint8_t *)d_t, d_ws, d_s, d_ql, d_tl, lds_q);
+        /* H / E rings, and the read's bases up to 32 KiB, in LDS */
+        const int mw_q = std::min(qmax_narrow, 32768);
+        hipLaunchKernelGGL(lf_ksw_mw_kernel<true>, dim3((unsigned)n), dim3(256), (size_t)2048 + (size_t)mw_q + 16, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
+                           (const uint8_t *)d_t, d_s, d_ql, d_tl, mw_q);
+        if (qmax_narrow > mw_q) hipLaunchKernelGGL(lf_ksw_mw_kernel<false>, dim3((unsigned)n), dim3(256), (size_t)2048, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
+                           (const uint8_t *)d_t, d_s, d_ql, d_tl, mw_q);
     }
     if (n_wide) {
         const int wide_only = one_wave ? 0 : 1;

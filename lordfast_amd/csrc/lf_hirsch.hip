@@ -24,6 +24,7 @@
  * longer queries band by band (32 768 rows), the two-bit carries that cross a band boundary going through HBM.
  */
 #include "lf_hirsch.h"
+#include <stdlib.h>
 
 #define LF_H_TC 256          /* LDS ring of target symbols per wavefront (power of two) */
 #define LF_H_H  128
@@ -32,35 +33,51 @@
  * them across (two wavefronts of a node run different numbers of ring refills: no workgroup barrier may sit in the sweep) */
 __device__ __forceinline__ void lf_wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-/* One sweep of q[0..n) x t[0..m) by ONE wavefront (anti-diagonal: lane l is l columns behind lane l - 1; carry by DPP).
+#define LF_H_B   16          /* multi-wavefront sweeps: steps between two workgroup barriers */
+#define LF_H_LAG 96          /* ... and the number of steps a sub-band's wavefront runs behind the one above it (64 lanes + 2 B) */
+
+/* One sweep of q[0..n) x t[0..m) by the W wavefronts of a node's half (anti-diagonal: lane l is l columns behind lane l - 1,
+ * carry by DPP; wavefront wsub owns the blocks [wsub, wsub + 1) x 64 KB of every super-band of 64 KB W blocks and runs
+ * LF_H_LAG steps behind wavefront wsub - 1, whose last lane leaves its two-bit carries in an LDS ring (cw_out -> cw_in); a
+ * workgroup barrier every LF_H_B steps makes them visible long before they are read.  Round 3 gave a node's half to ONE
+ * wavefront with KB = 4 / 8 blocks per lane: KB dependent block steps per sweep step -- the latency of every Hirschberg level,
+ * and the levels of the few long problems are what a chunk with a clipped chain waits for).
  * blk_out != null: the last DP column as 3 u64 per 64-row block: Pv, Mv, D[64 b][m].
- * Returns D[n][m]; track: also the SHW result (smallest prefix distance, smallest column on ties; the empty prefix only
- * competes when n % 64 != 0, lib/edlib/edlib.cpp:595,615). */
-template <int KB, bool PAC>
-__device__ __forceinline__ int lf_hsweep(const lf_qacc &Q, const lf_tacc &T, const uint32_t n, const uint32_t m, const bool track,
-                                         unsigned char *ring, unsigned char *cring, uint64_t *peq, uint8_t *hc_a, uint8_t *hc_b,
-                                         uint64_t *blk_out, int &shw_best, int &shw_c)
+ * track: the SHW result (smallest prefix distance, smallest column on ties; the empty prefix only competes when n % 64 != 0,
+ * lib/edlib/edlib.cpp:595,615).  idle: a wavefront group without a sweep of its own walks through the same barriers.
+ * EVERY wavefront of the workgroup has to call this with the same n, m_max, track (barrier counts). */
+template <int KB, int W, bool PAC>
+__device__ __forceinline__ void lf_hsweep(const lf_qacc &Q, const lf_tacc &T, const uint32_t n, const uint32_t m, const uint32_t m_max, const bool track, const bool idle,
+                                          const int wsub, unsigned char *ring, unsigned char *cring, const unsigned char *cw_in, unsigned char *cw_out,
+                                          uint64_t *peq, uint8_t *hc_a, uint8_t *hc_b, uint64_t *blk_out, int *s_tot, int *s_shw, int &shw_best, int &shw_c)
 {
     constexpr bool PEQ = PAC && KB == 1;
     constexpr int TC = LF_H_TC, H = LF_H_H;
+    constexpr uint32_t SB = 64u * KB * W;        /* blocks of a super-band */
     const int lane = threadIdx.x & 63;
     auto qget = [&](uint32_t r) -> unsigned char { return Q.get(r); };
     const uint32_t nbk = (n + 63) >> 6, lastb = (n - 1) >> 6;
     const int lastbit = (int)((n - 1) & 63);
-    int col_base = (int)m;                       /* D[first row of the band][m] */
+    int col_base = (int)m;                       /* D[first row of the super-band][m] */
     int score = (int)n, best = (n & 63) ? (int)n : 0x7fffffff, best_c = 0;
     uint8_t *hc_in = hc_a, *hc_out = hc_b;
-    for (uint32_t b0 = 0; b0 < nbk; b0 += 64 * KB) {
-        const uint32_t band_blocks = nbk - b0 < 64u * KB ? nbk - b0 : 64u * KB;
+    bool had_last = false;
+    for (uint32_t b0 = 0; b0 < nbk; b0 += SB) {
+        const uint32_t sb0 = b0 + (uint32_t)wsub * 64u * KB;          /* this wavefront's sub-band */
+        const uint32_t band_blocks = (idle || sb0 >= nbk) ? 0u : (nbk - sb0 < 64u * KB ? nbk - sb0 : 64u * KB);
         const int nl = (int)((band_blocks + KB - 1) / KB);
-        const bool first_band = b0 == 0, last_band = b0 + 64 * KB >= nbk;
-        const int lane_last = (int)((lastb - b0) / KB);          /* meaningful in the last band */
+        const bool more_sb = b0 + SB < nbk;
+        const bool from_hbm = wsub == 0 && b0 != 0, from_wave = wsub > 0;
+        const bool to_wave = W > 1 && wsub + 1 < W && band_blocks && sb0 + 64u * KB < nbk, to_hbm = wsub == W - 1 && more_sb && band_blocks;
+        const bool last_band = band_blocks && lastb >= sb0 && lastb < sb0 + 64u * KB;
+        const int lane_last = last_band ? (int)((lastb - sb0) / KB) : -1;
+        had_last = had_last || last_band;
         /* bit planes of the band's blocks by ballot: 64 query bytes per block, three ballots, the owning lane keeps them */
         uint64_t lo[KB], hi[KB], valid[KB], Pv[KB], Mv[KB];
 #pragma unroll
         for (int k = 0; k < KB; k++) { lo[k] = hi[k] = valid[k] = 0; Pv[k] = ~0ull; Mv[k] = 0; }
         for (uint32_t b = 0; b < band_blocks; b++) {
-            const uint32_t r = (b0 + b) * 64 + (uint32_t)lane;
+            const uint32_t r = (sb0 + b) * 64 + (uint32_t)lane;
             bool ok; const uint32_t cd = lf_code_upper(qget(r < n ? r : n - 1), ok);
             const int code = (r < n && ok) ? (int)cd : -1;
             const uint64_t bl = lf_ballot(code >= 0 && (code & 1)), bh = lf_ballot(code >= 0 && (code & 2)), bv = lf_ballot(code >= 0);
@@ -70,34 +87,46 @@ __device__ __forceinline__ int lf_hsweep(const lf_qacc &Q, const lf_tacc &T, con
                 for (int k = 0; k < KB; k++) if (k == slot) { lo[k] = bl; hi[k] = bh; valid[k] = bv; }
             }
         }
-        if (PEQ) {
+        if (PEQ && band_blocks) {
 #pragma unroll
-            for (uint32_t cde = 0; cde < 4; cde++) peq[cde * 64 + lane] = lf_eq_tok<true>(cde, lo[0], hi[0], valid[0], qget, n, b0 + (uint32_t)lane);
+            for (uint32_t cde = 0; cde < 4; cde++) peq[cde * 64 + lane] = lf_eq_tok<true>(cde, lo[0], hi[0], valid[0], qget, n, sb0 + (uint32_t)lane);
         }
         auto stage = [&](int first, int count) {
             for (int j = first + lane; j < first + count; j += 64) if (j >= 0 && (uint32_t)j < m) {
                 ring[j & (TC - 1)] = PAC ? (unsigned char)T.pac_code((uint32_t)j) : T.get((uint32_t)j);
-                if (!first_band) cring[j & (TC - 1)] = hc_in[j];
+                if (from_hbm) cring[j & (TC - 1)] = hc_in[j];
             }
         };
-        const int steps = (int)m + nl - 1;
-        uint32_t hout_prev = LF_HIN_PLUS1;
-        lf_wave_lds_sync(); stage(0, H); lf_wave_lds_sync();
-        uint32_t sym = ring[(0 - lane) & (TC - 1)];
-        uint64_t eq = PEQ ? peq[(sym & 3u) * 64 + lane] : 0ull;
-        uint32_t cin = first_band ? LF_HIN_PLUS1 : (uint32_t)cring[0];
-        for (int s = 0; s < steps; s++) {
-            if (((s + 1) & (H - 1)) == 0) { lf_wave_lds_sync(); stage(s + 1, H); lf_wave_lds_sync(); }
-            const uint32_t sym_next = ring[(s + 1 - lane) & (TC - 1)];
-            const uint32_t cin_next = first_band ? LF_HIN_PLUS1 : (uint32_t)cring[(s + 1) & (TC - 1)];
+        /* the carry entering lane 0 at the column with 0-based index x */
+        auto carry_in = [&](int x) -> uint32_t { return from_wave ? (uint32_t)cw_in[x & 63] : from_hbm ? (uint32_t)cring[x & (TC - 1)] : LF_HIN_PLUS1; };
+        const int my_steps = nl > 0 ? (int)m + nl - 1 : 0;
+        const int t0 = wsub * LF_H_LAG;
+        const int steps_total = W > 1 ? (int)m_max + 63 + (W - 1) * LF_H_LAG : my_steps;
+        uint32_t hout_prev = LF_HIN_PLUS1, sym = 0, cin = LF_HIN_PLUS1;
+        uint64_t eq = 0;
+        for (int s = 0; s < steps_total; s++) {
+            if (W > 1 && (s & (LF_H_B - 1)) == 0) __syncthreads();
+            const int sl = s - t0;
+            if (sl < 0 || sl >= my_steps) continue;
+            if (sl == 0) {
+                lf_wave_lds_sync(); stage(0, H); lf_wave_lds_sync();
+                sym = ring[(0 - lane) & (TC - 1)];
+                eq = PEQ ? peq[(sym & 3u) * 64 + lane] : 0ull;
+                cin = carry_in(0);
+            }
+            if (((sl + 1) & (H - 1)) == 0) { lf_wave_lds_sync(); stage(sl + 1, H); lf_wave_lds_sync(); }
+            const uint32_t sym_next = ring[(sl + 1 - lane) & (TC - 1)];
+            const uint32_t cin_next = carry_in(sl + 1);
             const uint32_t from_left = lf_wave_shr1(hout_prev);
-            const int c = s - lane + 1;
-            if (lane < nl && c >= 1 && c <= (int)m) {
+            const int c = sl - lane + 1;
+            /* between the step at which the last lane enters its first column and the one at which lane 0 leaves its last, every
+             * lane with blocks is inside the target: no per-lane range test (lanes without blocks compute on dead registers) */
+            auto body = [&]() {
                 const uint32_t tok = PAC ? sym : lf_tok_of_byte((unsigned char)sym);
                 uint32_t hin = lane == 0 ? cin : from_left;
 #pragma unroll
                 for (int k = 0; k < KB; k++) {
-                    const uint32_t b = b0 + (uint32_t)lane * KB + k;
+                    const uint32_t b = sb0 + (uint32_t)lane * KB + k;
                     const uint64_t Eq = PEQ ? eq : lf_eq_tok<PAC>(tok, lo[k], hi[k], valid[k], qget, n, b);
                     uint64_t ph, mh;
                     const uint32_t ho = lf_myers_step(Pv[k], Mv[k], Eq, hin, ph, mh);
@@ -106,16 +135,21 @@ __device__ __forceinline__ int lf_hsweep(const lf_qacc &Q, const lf_tacc &T, con
                 }
                 hout_prev = hin;
                 if (track && last_band) { const bool upd = lane == lane_last && score < best; best = upd ? score : best; best_c = upd ? c : best_c; }
-                if (!last_band && lane == 63) hc_out[c - 1] = (uint8_t)hin;      /* the carry leaving the band's last block */
-            }
+                if (lane == 63) {                               /* the carry leaving the sub-band's last block (only full sub-bands pass one on) */
+                    if (to_hbm) hc_out[c - 1] = (uint8_t)hin;
+                    if (to_wave) cw_out[(c - 1) & 63] = (unsigned char)hin;
+                }
+            };
+            if (sl >= nl - 1 && sl <= (int)m - 1) body();
+            else if (lane < nl && c >= 1 && c <= (int)m) body();
             sym = sym_next; cin = cin_next;
             if (PEQ) eq = peq[(sym & 3u) * 64 + lane];
         }
-        /* last column of the band: D[r][m] = D[first row][m] + vertical deltas */
+        /* last column of the sub-band: D[r][m] = D[first row][m] + vertical deltas */
         int mine = 0, part[KB];
 #pragma unroll
         for (int k = 0; k < KB; k++) {
-            const uint32_t b = b0 + (uint32_t)lane * KB + k;
+            const uint32_t b = sb0 + (uint32_t)lane * KB + k;
             part[k] = 0;
             if (lane < nl && b < nbk) {
                 const uint32_t rows = (b == lastb) ? (uint32_t)lastbit + 1 : 64;
@@ -127,23 +161,42 @@ __device__ __forceinline__ int lf_hsweep(const lf_qacc &Q, const lf_tacc &T, con
         int incl = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-        int base = col_base + incl - mine;
+        const int wave_tot = __shfl(incl, 63);
+        int pre = 0, all = wave_tot;
+        if (W > 1) {
+            if (lane == 0) s_tot[wsub] = wave_tot;
+            __syncthreads();
+            all = 0;
+#pragma unroll
+            for (int u = 0; u < W; u++) { const int x = s_tot[u]; pre += u < wsub ? x : 0; all += x; }
+        }
+        int base = col_base + pre + incl - mine;
         if (blk_out) {
 #pragma unroll
             for (int k = 0; k < KB; k++) {
-                const uint32_t b = b0 + (uint32_t)lane * KB + k;
+                const uint32_t b = sb0 + (uint32_t)lane * KB + k;
                 if (lane < nl && b < nbk) { blk_out[3 * (size_t)b] = Pv[k]; blk_out[3 * (size_t)b + 1] = Mv[k]; blk_out[3 * (size_t)b + 2] = (uint64_t)(int64_t)base; }
                 base += part[k];
             }
         }
-        col_base += __shfl(incl, 63);
-        if (!last_band) { __threadfence(); uint8_t *t = hc_in; hc_in = hc_out; hc_out = t; }
+        col_base += all;
+        if (more_sb) { __threadfence(); uint8_t *t = hc_in; hc_in = hc_out; hc_out = t; }
+        if (W > 1) __syncthreads();              /* s_tot is reused; the carries that left the super-band are in HBM */
     }
     if (track) {
-        const int src = (int)((lastb % (64u * KB)) / KB);
-        shw_best = __shfl(best, src); shw_c = __shfl(best_c, src);
+        if (W > 1) {
+            if (had_last) {
+                const int src = (int)((lastb % (64u * KB)) / KB);
+                const int b1 = __shfl(best, src), b2 = __shfl(best_c, src);
+                if (lane == 0) { s_shw[0] = b1; s_shw[1] = b2; }
+            }
+            __syncthreads();
+            shw_best = s_shw[0]; shw_c = s_shw[1];
+        } else {
+            const int src = (int)((lastb % (64u * KB)) / KB);
+            shw_best = __shfl(best, src); shw_c = __shfl(best_c, src);
+        }
     }
-    return col_base;
 }
 
 /* D[x][last column] from the per-block triples; x = 0: the first row (`zero`) */
@@ -206,18 +259,20 @@ __device__ __forceinline__ void lf_hfinalize(const lf_hargs &A, const lf_hnode &
     }
 }
 
-template <int KB, bool PAC>
-__global__ void __launch_bounds__(128)
+template <int KB, int W, bool PAC>
+__global__ void __launch_bounds__(128 * W)
 lf_hirsch_level_kernel(lf_hargs A)
 {
-    __shared__ unsigned char s_ring[2][LF_H_TC], s_cring[2][LF_H_TC];
-    __shared__ uint64_t s_peq[2][(PAC && KB == 1) ? 256 : 1];
+    __shared__ unsigned char s_ring[2 * W][LF_H_TC], s_cring[2 * W][LF_H_TC], s_cw[2 * W][64];
+    __shared__ uint64_t s_peq[2 * W][(PAC && KB == 1) ? 256 : 1];
+    __shared__ int s_tot[2][W], s_shw[2][2];
     __shared__ unsigned long long s_base[2];
-    const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int w = wave / W, wsub = wave % W;             /* w: the node's half; wsub: the wavefront's sub-band */
     if (blockIdx.x >= A.n_in) return;
     const lf_hnode P = A.q_in[blockIdx.x];
     const uint32_t n = P.n, m = P.m, nbk = (n + 63) >> 6;
-    const bool banded = nbk > 64u * KB;
+    const bool banded = nbk > 64u * KB * W;
     const uint32_t lw = m / 2, rw = m - lw;
     if (threadIdx.x == 0) {
         s_base[0] = P.kind == 0 ? atomicAdd(&A.ctl->aux_used, 6ull * nbk) : 0ull;
@@ -230,32 +285,35 @@ lf_hirsch_level_kernel(lf_hargs A)
     uint8_t *hc = A.hcar + s_base[1];
     const int64_t dq = (P.flags & LF_F_QREV) ? -1 : 1, dt = (P.flags & LF_F_TREV) ? -1 : 1;
     const uint32_t desc = A.roots[P.root].desc;
+    const unsigned char *cw_in = wsub > 0 ? s_cw[wave - 1] : nullptr;
 
     if (P.kind == 1) {
-        /* SHW root: distance and end column first (lib/edlib/edlib.cpp:141-168), then the path of q vs t[0 .. end] */
-        if (w != 0) return;
+        /* SHW root: distance and end column first (lib/edlib/edlib.cpp:141-168), then the path of q vs t[0 .. end].  The
+         * wavefronts of the first half sweep; the others only keep the barriers company */
+        if (W == 1 && w != 0) return;
         const lf_qacc Q(A.S.q, P.qstart, P.flags); const lf_tacc T(A.S.t, A.S.pac, P.tstart, P.flags | (PAC ? LF_F_TPAC : 0u));
         int ed = 0, tl = 0;
-        (void)lf_hsweep<KB, PAC>(Q, T, n, m, true, s_ring[0], s_cring[0], s_peq[0], hc, hc + m + 32, nullptr, ed, tl);
+        lf_hsweep<KB, W, PAC>(Q, T, n, m, m, true, w != 0, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc, hc + m + 32, nullptr, s_tot[w], s_shw[w], ed, tl);
+        if (wave != 0) return;
         if (lane == 0) { A.out_ed[desc] = ed; A.out_end[desc] = tl - 1; }
         lf_hfinalize(A, P, 0, n, 0, (uint32_t)tl, ed, P.ops_off);
         return;
     }
-    {   /* the two half sweeps, one wavefront each */
+    {   /* the two half sweeps, W wavefronts each */
         int d0, d1;
         if (w == 0) {
             const lf_qacc Q(A.S.q, P.qstart, P.flags); const lf_tacc T(A.S.t, A.S.pac, P.tstart, P.flags | (PAC ? LF_F_TPAC : 0u));
-            if (lw) (void)lf_hsweep<KB, PAC>(Q, T, n, lw, false, s_ring[0], s_cring[0], s_peq[0], hc, hc + (lw + 16), Fb, d0, d1);
+            if (lw || W > 1) lf_hsweep<KB, W, PAC>(Q, T, n, lw, rw, false, lw == 0, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc, hc + (lw + 16), Fb, s_tot[0], s_shw[0], d0, d1);
         } else {
             /* both strings backwards: element i = original element (len - 1 - i) */
             const unsigned fl = P.flags ^ (LF_F_QREV | LF_F_TREV);
             const lf_qacc Q(A.S.q, P.qstart + dq * (int64_t)(n - 1), fl); const lf_tacc T(A.S.t, A.S.pac, P.tstart + dt * (int64_t)(m - 1), fl | (PAC ? LF_F_TPAC : 0u));
-            (void)lf_hsweep<KB, PAC>(Q, T, n, rw, false, s_ring[1], s_cring[1], s_peq[1], hc + 2 * (lw + 16), hc + 2 * (lw + 16) + (rw + 16), Rb, d0, d1);
+            lf_hsweep<KB, W, PAC>(Q, T, n, rw, rw, false, false, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc + 2 * (lw + 16), hc + 2 * (lw + 16) + (rw + 16), Rb, s_tot[1], s_shw[1], d0, d1);
         }
     }
     __threadfence_block();
     __syncthreads();
-    if (w != 0) return;
+    if (wave != 0) return;
     /* F[x] = dist(q[0..x), t[0..lw)), R[x] = dist(last x of q, t[lw..m)) */
     auto F = [&](uint32_t x) -> int { return lw ? lf_hcol(Fb, x, (int)lw) : (int)x; };
     auto R = [&](uint32_t x) -> int { return lf_hcol(Rb, x, (int)rw); };
@@ -348,9 +406,13 @@ void lf_hirsch_launch_roots(hipStream_t s, bool pac_targets, const lf_aln_desc_t
 void lf_hirsch_launch_level(hipStream_t s, bool pac, int kbc, lf_hargs A)
 {
     if (A.n_in == 0) return;
-    const dim3 g(A.n_in), b(128);
-#define LV(KBV) do { if (pac) hipLaunchKernelGGL((lf_hirsch_level_kernel<KBV, true>), g, b, 0, s, A); else hipLaunchKernelGGL((lf_hirsch_level_kernel<KBV, false>), g, b, 0, s, A); } while (0)
-    if (kbc == 0) LV(1); else if (kbc == 1) LV(4); else LV(8);
+    /* blocks per lane x wavefronts per half: queries of <= 4096 / 16384 / 32768 rows in one super-band (more rows: several) */
+    const dim3 g(A.n_in);
+    const bool one_wave = getenv("LF_HIRSCH_1WAVE") && atoi(getenv("LF_HIRSCH_1WAVE")) != 0;      /* A / B: round 3's one wavefront per half, 4 / 8 blocks per lane */
+#define LV(KBV, WV) do { if (pac) hipLaunchKernelGGL((lf_hirsch_level_kernel<KBV, WV, true>), g, dim3(128 * WV), 0, s, A); else hipLaunchKernelGGL((lf_hirsch_level_kernel<KBV, WV, false>), g, dim3(128 * WV), 0, s, A); } while (0)
+    if (kbc == 0) LV(1, 1);
+    else if (one_wave) { if (kbc == 1) LV(4, 1); else LV(8, 1); }
+    else if (kbc == 1) LV(1, 4); else LV(2, 4);
 #undef LV
 }
 void lf_hirsch_launch_stitch(hipStream_t s, lf_hargs A, uint32_t n_roots)

@@ -95,13 +95,16 @@ def test_edlib_fuzz_vs_oracle(oracle_lib):
         assert np.array_equal(r[2], o[2]), (i, len(qs[i]), len(ts[i]), modes[i])
 
 
-def test_edlib_checkpoint_tiles_and_device_hirschberg(oracle_lib):
+@pytest.mark.parametrize("one_wave", [0, 1])
+def test_edlib_checkpoint_tiles_and_device_hirschberg(oracle_lib, monkeypatch, one_wave):
     """shapes aimed at the recompute-from-checkpoint traceback and the breadth-first Hirschberg levels (lf_rsweep.hip,
     lf_align.hip, lf_hirsch.hip): tile boundaries (m around multiples of 8 / 16), paths that climb > 64 rows inside one
     16-column tile, every block count per problem (1 .. 64 lanes) and the 4 / 8 blocks-per-lane classes, targets longer
     than the LDS ring of the level kernels, tall-and-thin / short-and-wide leaves, several recursion levels, SHW roots
     whose prefix is a leaf"""
     import lordfast_amd as la
+    # 1: one wavefront per half of a node with 4 / 8 blocks per lane (round 3); 0: four wavefronts per half, 1 / 2 blocks per lane
+    monkeypatch.setenv("LF_HIRSCH_1WAVE", str(one_wave))
     orc = oracle_lib.Oracle()
     rng = np.random.default_rng(77)
     qs, ts, modes = [], [], []
@@ -146,11 +149,14 @@ def test_edlib_checkpoint_tiles_and_device_hirschberg(oracle_lib):
         assert np.array_equal(r[2], o[2]), (i, len(qs[i]), len(ts[i]), modes[i])
 
 
-def test_edlib_queries_above_32768_rows(oracle_lib):
+@pytest.mark.parametrize("one_wave", [0, 1])
+def test_edlib_queries_above_32768_rows(oracle_lib, monkeypatch, one_wave):
     """queries longer than one wavefront holds as register-resident blocks (64 lanes x 8 blocks x 64 rows = 32 768): the
     Hirschberg levels sweep them in row bands whose boundary carries go through HBM (lf_hirsch.hip); NW and SHW roots,
     a band boundary one row before the end of the query, a tall-and-thin problem above the traceback switch"""
     import lordfast_amd as la
+    # 1: one wavefront per half of a node with 4 / 8 blocks per lane (round 3); 0: four wavefronts per half, 1 / 2 blocks per lane
+    monkeypatch.setenv("LF_HIRSCH_1WAVE", str(one_wave))
     orc = oracle_lib.Oracle()
     rng = np.random.default_rng(3276833)
     qs, ts, modes = [], [], []
