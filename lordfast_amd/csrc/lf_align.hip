@@ -5,8 +5,8 @@
  * ksw_extend2 (lib/bwa/ksw.c:380-478).  Integer only; results bit-identical.
  *
  * edlib kernels: Myers/Hyyro bit-vector DP, 64 query rows per 64-bit word.
- *   batching       descriptors -> 32-bit class keys -> one radix sort -> (mode, nb) segments -> checkpoint bases (one scan) ->
- *                  problem array + wave table, all on the device (lf_desc_*_kernel below).
+ *   batching       descriptors -> 32-bit class keys -> counting sort (LDS histograms) -> (mode, nb) segments -> checkpoint bases
+ *                  (one scan) -> problem array + wave table, all on the device (lf_desc_*_kernel below).
  *   forward pass   lf_rsweep.hip: nb CONSECUTIVE LANES per problem (nb = ceil(n / 64) = 1 .. 64, a run-time value), query bit
  *                  planes precomputed once per chunk, one checkpoint row per 16 sweep steps.  Leaves the distance / end
  *                  column, the rows and the planes in HBM.  (Leaves with 4096 < n <= 32768: lf_edlib_sweep_kernel<64, 4 / 8>
@@ -16,7 +16,10 @@
  *                  RECOMPUTING 16-column tiles of the ONE block the path is in from a checkpoint row and the stored carries:
  *                  lf_edlib_tb_kernel, one lane per path.  No history stream through HBM.
  *   Hirschberg     edlib's recursion for problems over its 1 MiB traceback switch: lf_hirsch.hip, breadth-first (level l of
- *                  all problems is one launch); its leaves are ordinary problems of the kernels above.
+ *                  all problems is one launch, 1 / 4 / 8 wavefronts per half of a node); its leaves are ordinary problems of
+ *                  the kernels above.
+ * ksw_extend2: lf_ksw_mw_kernel (a row's band over the four wavefronts of a workgroup, H / E in LDS rings) for bands of at most 255
+ *                  columns, lf_ksw_kernel (one wavefront, 64 columns at a time) for wider ones.
  * No banding: the Ukkonen band of the reference only removes cells that cannot be on an optimal path, and lanes that skip
  * out-of-band blocks save no time, because their neighbours in the wavefront's lock-step sweep do not.
  */
@@ -30,6 +33,7 @@
 #include <type_traits>
 #include <string.h>
 #include <vector>
+#include <chrono>
 #include <numeric>
 #include <limits.h>
 
@@ -766,7 +770,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         lf_hctl *h_ctl = (lf_hctl *)lfg_pin_slot(LF_PS_ALN_PROB + 1, sizeof(lf_hctl));
         if (!d_ctl || !d_roots || !d_segs || !d_q || !d_hdesc || !d_hopsoff || !d_haux || !d_hcar || !h_ctl) return LF_ERR_NOMEM;
         HIPCHK(hipMemsetAsync(d_ctl, 0, sizeof(lf_hctl), s));
-        HA.S.q = D->d_q; HA.S.t = D->d_t; HA.S.pac = D->d_pac;
+        HA.S.q = D->d_q; HA.S.t = D->d_t; HA.S.pac = D->d_pac; HA.pac_syms = D->pac_syms;
         HA.q_cap = (uint32_t)q_cap; HA.ctl = d_ctl; HA.roots = d_roots; HA.segs = d_segs; HA.hdesc = d_hdesc; HA.hopsoff = d_hopsoff; HA.hleaf_cap = (uint32_t)hcap;
         HA.aux = d_haux; HA.aux_cap = aux_cap; HA.hcar = d_hcar; HA.hcar_cap = hcar_cap;
         HA.ops = d_ops; HA.out_ed = d_ed; HA.out_end = d_end; HA.out_len = d_len; HA.n_desc = (uint32_t)n;
@@ -775,9 +779,18 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         for (int k = 0; k < 3; k++) HA.q_out[k] = queue(0, k);
         HA.out_par = 0;
         lf_hirsch_launch_roots(s, D->pac, d_desc, d_opsoff, n, HA);
+        const bool hdbg = getenv("LF_HIRSCH_DEBUG") != nullptr;      /* per call: roots and their sizes; per level: nodes by class, milliseconds since the previous readback */
+        std::chrono::steady_clock::time_point hd_t0 = std::chrono::steady_clock::now();
+        if (hdbg) fprintf(stderr, "[lf] hirschberg: %llu roots, sum n %llu, sum m %llu (of %d problems)\n", (unsigned long long)HC.roots, (unsigned long long)HC.sum_n, (unsigned long long)HC.sum_m, n);
         for (int level = 0; level < 64; level++) {
             HIPCHK(hipMemcpyAsync(h_ctl, d_ctl, sizeof(lf_hctl), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
+            if (hdbg) {
+                const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
+                fprintf(stderr, "[lf]   level %d: nodes %u / %u / %u (<= 4096 / <= 16384 / more rows), leaves so far %u, %.3f ms\n", level, h_ctl->q_n[par][0], h_ctl->q_n[par][1], h_ctl->q_n[par][2], h_ctl->n_hleaf,
+                        std::chrono::duration<double, std::milli>(t1 - hd_t0).count());
+                hd_t0 = t1;
+            }
             if (h_ctl->fail > 1) { lf_set_error("edlib Hirschberg levels: scratch bound exceeded (code %u)", h_ctl->fail); return LF_ERR_HIP; }
             n_roots = h_ctl->n_roots; n_h = h_ctl->n_hleaf;
             const uint32_t c0 = h_ctl->q_n[par][0], c1 = h_ctl->q_n[par][1], c2 = h_ctl->q_n[par][2];

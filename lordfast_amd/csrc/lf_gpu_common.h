@@ -226,4 +226,20 @@ __device__ __forceinline__ uint32_t lf_wave_max_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 
+/* host side: every wait for a stream outside lf_mem.hip sleeps on the calling thread's blocking event (lf_mem.hip) */
+#ifndef LF_NO_SYNC_WRAP
+#include <stdlib.h>
+extern "C" void *lfg_thread_wait_event(int device);
+static inline hipError_t lf_stream_wait(hipStream_t s)
+{
+    static const bool spin = getenv("LF_SPIN_WAIT") != nullptr;
+    int dev = -1;
+    if (spin || hipGetDevice(&dev) != hipSuccess) return hipStreamSynchronize(s);
+    hipEvent_t e = (hipEvent_t)lfg_thread_wait_event(dev);
+    if (!e || hipEventRecord(e, s) != hipSuccess) { (void)hipGetLastError(); return hipStreamSynchronize(s); }
+    return hipEventSynchronize(e);
+}
+#define hipStreamSynchronize(s) lf_stream_wait(s)
+#endif
+
 #endif

@@ -26,7 +26,7 @@ struct lf_hctl {
     unsigned long long aux_used, hcar_used;
 };
 struct lf_hargs {
-    lf_seqs S;
+    lf_seqs S; int64_t pac_syms;          /* symbols in S.pac (2-bit targets) */
     const lf_hnode *q_in; lf_hnode *q_out[3];
     uint32_t n_in, q_cap, out_par;
     lf_hctl *ctl; lf_hroot *roots; lf_hseg *segs;

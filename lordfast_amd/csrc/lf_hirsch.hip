@@ -25,6 +25,7 @@
  */
 #include "lf_hirsch.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define LF_H_TC 256          /* LDS ring of target symbols per wavefront (power of two) */
 #define LF_H_H  128
@@ -47,7 +48,7 @@ __device__ __forceinline__ void lf_wave_lds_sync() { __builtin_amdgcn_fence(__AT
  * lib/edlib/edlib.cpp:595,615).  idle: a wavefront group without a sweep of its own walks through the same barriers.
  * EVERY wavefront of the workgroup has to call this with the same n, m_max, track (barrier counts). */
 template <int KB, int W, bool PAC>
-__device__ __forceinline__ void lf_hsweep(const lf_qacc &Q, const lf_tacc &T, const uint32_t n, const uint32_t m, const uint32_t m_max, const bool track, const bool idle,
+__device__ __forceinline__ void lf_hsweep(const lf_qacc &Q, const lf_tacc &T, const int64_t pac_syms, const uint32_t n, const uint32_t m, const uint32_t m_max, const bool track, const bool idle,
                                           const int wsub, unsigned char *ring, unsigned char *cring, const unsigned char *cw_in, unsigned char *cw_out,
                                           uint64_t *peq, uint8_t *hc_a, uint8_t *hc_b, uint64_t *blk_out, int *s_tot, int *s_shw, int &shw_best, int &shw_c)
 {
@@ -102,6 +103,58 @@ __device__ __forceinline__ void lf_hsweep(const lf_qacc &Q, const lf_tacc &T, co
         const int my_steps = nl > 0 ? (int)m + nl - 1 : 0;
         const int t0 = wsub * LF_H_LAG;
         const int steps_total = W > 1 ? (int)m_max + 63 + (W - 1) * LF_H_LAG : my_steps;
+        bool swept = false;
+        if constexpr (PEQ) { if (nbk <= SB) {
+            swept = true;
+            /* One block per lane, 2-bit targets, one super-band (every query of the mapping pipeline up to 4096 W rows): the step
+             * loop of the forward kernel (lf_rsweep.hip) -- 16 steps unrolled, the lane's 16 target symbols in one register
+             * straight from the 2-bit reference, match masks from the LDS table, no range test in the groups of 16 steps during
+             * which every lane is inside the target; the carries between the wavefronts of a half travel as ONE 32-bit word per 16
+             * steps.  ~40 instructions per step instead of ~150 in the general loop below: a level lasts as long as the sweep of
+             * its longest node, which is a chain of dependent steps, and the chunks with long clipped tails (config C4) wait for
+             * exactly that. */
+            const uint64_t *peq_l = peq + lane;
+            const uint32_t *cw32_in = reinterpret_cast<const uint32_t *>(cw_in); uint32_t *cw32_out = reinterpret_cast<uint32_t *>(cw_out);
+            const bool is_last = last_band && lane == lane_last;
+            const int n_groups = (steps_total + 15) >> 4;
+            uint32_t hout = LF_HIN_PLUS1, acc = 0;
+            auto steps16 = [&](auto fast_tag, const int sl0, const uint32_t V, const uint32_t cin16) {
+                constexpr bool FAST = decltype(fast_tag)::value;
+                const int p0 = sl0 - lane;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t from_left = lf_wave_shr1(hout);
+                    const uint32_t col0 = (uint32_t)(p0 + k);                /* column - 1; wraps for lanes that have not started */
+                    if (FAST || (lane < nl && col0 < m)) {
+                        const uint32_t sy = (V >> (2 * k)) & 3u;
+                        const uint64_t Eq = peq_l[sy * 64];
+                        const uint32_t hin = lane == 0 ? ((cin16 >> (2 * k)) & 3u) : from_left;
+                        uint64_t ph, mh;
+                        hout = lf_myers_step(Pv[0], Mv[0], Eq, hin, ph, mh);
+                        if (track) {
+                            score += is_last ? lf_delta_at(ph, mh, lastbit) : 0;
+                            const bool upd = is_last && score < best; best = upd ? score : best; best_c = upd ? (int)col0 + 1 : best_c;
+                        }
+                    }
+                    acc |= hout << (2 * k);
+                }
+            };
+            for (int g = 0; g < n_groups; g++) {
+                if (W > 1) __syncthreads();
+                const int sl0 = 16 * g - t0;                                 /* LF_H_LAG is a multiple of 16 */
+                if (sl0 < 0 || sl0 >= my_steps) continue;
+                const uint32_t V = lf_pac16(T.pac, T.start + (int64_t)T.dir * ((int64_t)sl0 - lane), T.dir, T.comp, pac_syms);
+                /* carries entering lane 0: +1 per column above the first block; else what the last lane of the wavefront above left
+                 * for the same columns 63 steps (3 groups and 15 steps) later in ITS numbering */
+                uint32_t cin16 = 0x55555555u;
+                if (from_wave) { const int gl = sl0 >> 4; const uint32_t a = cw32_in[(gl + 3) & 7], b = cw32_in[(gl + 4) & 7]; cin16 = (a >> 30) | (b << 2); }
+                acc = 0;
+                if (sl0 >= nl - 1 && sl0 + 15 <= (int)m - 1) steps16(std::true_type{}, sl0, V, cin16);
+                else steps16(std::false_type{}, sl0, V, cin16);
+                if (to_wave && lane == 63) cw32_out[(sl0 >> 4) & 7] = acc;
+            }
+        } }
+        if (!swept) {
         uint32_t hout_prev = LF_HIN_PLUS1, sym = 0, cin = LF_HIN_PLUS1;
         uint64_t eq = 0;
         for (int s = 0; s < steps_total; s++) {
@@ -144,6 +197,7 @@ __device__ __forceinline__ void lf_hsweep(const lf_qacc &Q, const lf_tacc &T, co
             else if (lane < nl && c >= 1 && c <= (int)m) body();
             sym = sym_next; cin = cin_next;
             if (PEQ) eq = peq[(sym & 3u) * 64 + lane];
+        }
         }
         /* last column of the sub-band: D[r][m] = D[first row][m] + vertical deltas */
         int mine = 0, part[KB];
@@ -293,7 +347,7 @@ lf_hirsch_level_kernel(lf_hargs A)
         if (W == 1 && w != 0) return;
         const lf_qacc Q(A.S.q, P.qstart, P.flags); const lf_tacc T(A.S.t, A.S.pac, P.tstart, P.flags | (PAC ? LF_F_TPAC : 0u));
         int ed = 0, tl = 0;
-        lf_hsweep<KB, W, PAC>(Q, T, n, m, m, true, w != 0, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc, hc + m + 32, nullptr, s_tot[w], s_shw[w], ed, tl);
+        lf_hsweep<KB, W, PAC>(Q, T, A.pac_syms, n, m, m, true, w != 0, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc, hc + m + 32, nullptr, s_tot[w], s_shw[w], ed, tl);
         if (wave != 0) return;
         if (lane == 0) { A.out_ed[desc] = ed; A.out_end[desc] = tl - 1; }
         lf_hfinalize(A, P, 0, n, 0, (uint32_t)tl, ed, P.ops_off);
@@ -303,12 +357,12 @@ lf_hirsch_level_kernel(lf_hargs A)
         int d0, d1;
         if (w == 0) {
             const lf_qacc Q(A.S.q, P.qstart, P.flags); const lf_tacc T(A.S.t, A.S.pac, P.tstart, P.flags | (PAC ? LF_F_TPAC : 0u));
-            if (lw || W > 1) lf_hsweep<KB, W, PAC>(Q, T, n, lw, rw, false, lw == 0, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc, hc + (lw + 16), Fb, s_tot[0], s_shw[0], d0, d1);
+            if (lw || W > 1) lf_hsweep<KB, W, PAC>(Q, T, A.pac_syms, n, lw, rw, false, lw == 0, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc, hc + (lw + 16), Fb, s_tot[0], s_shw[0], d0, d1);
         } else {
             /* both strings backwards: element i = original element (len - 1 - i) */
             const unsigned fl = P.flags ^ (LF_F_QREV | LF_F_TREV);
             const lf_qacc Q(A.S.q, P.qstart + dq * (int64_t)(n - 1), fl); const lf_tacc T(A.S.t, A.S.pac, P.tstart + dt * (int64_t)(m - 1), fl | (PAC ? LF_F_TPAC : 0u));
-            lf_hsweep<KB, W, PAC>(Q, T, n, rw, rw, false, false, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc + 2 * (lw + 16), hc + 2 * (lw + 16) + (rw + 16), Rb, s_tot[1], s_shw[1], d0, d1);
+            lf_hsweep<KB, W, PAC>(Q, T, A.pac_syms, n, rw, rw, false, false, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc + 2 * (lw + 16), hc + 2 * (lw + 16) + (rw + 16), Rb, s_tot[1], s_shw[1], d0, d1);
         }
     }
     __threadfence_block();
@@ -406,13 +460,14 @@ void lf_hirsch_launch_roots(hipStream_t s, bool pac_targets, const lf_aln_desc_t
 void lf_hirsch_launch_level(hipStream_t s, bool pac, int kbc, lf_hargs A)
 {
     if (A.n_in == 0) return;
-    /* blocks per lane x wavefronts per half: queries of <= 4096 / 16384 / 32768 rows in one super-band (more rows: several) */
+    /* blocks per lane x wavefronts per half: one block per lane, 1 / 4 / 8 wavefronts: queries of <= 4096 / 16384 / 32768 rows in one
+     * super-band (more rows: several) */
     const dim3 g(A.n_in);
     const bool one_wave = getenv("LF_HIRSCH_1WAVE") && atoi(getenv("LF_HIRSCH_1WAVE")) != 0;      /* A / B: round 3's one wavefront per half, 4 / 8 blocks per lane */
 #define LV(KBV, WV) do { if (pac) hipLaunchKernelGGL((lf_hirsch_level_kernel<KBV, WV, true>), g, dim3(128 * WV), 0, s, A); else hipLaunchKernelGGL((lf_hirsch_level_kernel<KBV, WV, false>), g, dim3(128 * WV), 0, s, A); } while (0)
     if (kbc == 0) LV(1, 1);
     else if (one_wave) { if (kbc == 1) LV(4, 1); else LV(8, 1); }
-    else if (kbc == 1) LV(1, 4); else LV(2, 4);
+    else if (kbc == 1) LV(1, 4); else LV(1, 8);
 #undef LV
 }
 void lf_hirsch_launch_stitch(hipStream_t s, lf_hargs A, uint32_t n_roots)

@@ -7,7 +7,9 @@
 #include <time.h>
 #include <stdlib.h>
 #include <stdio.h>
+#define LF_NO_SYNC_WRAP 1      /* this file hands the blocking wait events out and drains streams of other devices: plain waits here */
 #include "lf_gpu_common.h"
+#include <vector>
 
 namespace {
 struct slot_t { void *p = nullptr; size_t cap = 0; };
@@ -86,6 +88,30 @@ static void lf_exit_cleanup(void)
         }
     }
 }
+/* ---- blocking waits.  A host thread that waits for a stream SLEEPS on an event created with hipEventBlockingSync, whatever the
+ * device's scheduling flags are: hipSetDeviceFlags(hipDeviceScheduleBlockingSync) (lfg_index_upload) is refused once the process
+ * has an active context -- a host program that initialised the runtime first, like bench.py's torch -- and HIP's default wait
+ * spins: eight lane drivers waiting for their chunks burnt 0.2 - 1.5 core-seconds per step that way.  One event per host thread
+ * and device (two threads on one event would wait for each other's marker); a thread that ends gives its events back. ---- */
+static std::mutex g_wev_mu;
+static std::vector<hipEvent_t> g_wev_pool[MAX_DEV];
+struct lf_wev_holder {
+    hipEvent_t ev[MAX_DEV];
+    lf_wev_holder() { for (int d = 0; d < MAX_DEV; d++) ev[d] = nullptr; }
+    ~lf_wev_holder() { std::lock_guard<std::mutex> g(g_wev_mu); for (int d = 0; d < MAX_DEV; d++) if (ev[d]) g_wev_pool[d].push_back(ev[d]); }
+};
+static thread_local lf_wev_holder t_wev;
+extern "C" void *lfg_thread_wait_event(int device)
+{
+    if (device < 0 || device >= MAX_DEV) return nullptr;
+    hipEvent_t &e = t_wev.ev[device];
+    if (!e) {
+        { std::lock_guard<std::mutex> g(g_wev_mu); if (!g_wev_pool[device].empty()) { e = g_wev_pool[device].back(); g_wev_pool[device].pop_back(); } }
+        if (!e && hipEventCreateWithFlags(&e, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); e = nullptr; }
+    }
+    return (void *)e;
+}
+
 extern "C" void *lfg_lane_stream(int device, int which)
 {
     if (device < 0 || device >= MAX_DEV || which < 0 || which >= 16) return nullptr;

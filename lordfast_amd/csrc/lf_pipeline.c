@@ -355,6 +355,39 @@ extend:
             free(owner);
         }
     }
+    if (cx->d_seqs) {
+        /* lf_map_batch_dev: the reads whose chains the host is about to replay, fetched together (rd_host_bases would get them
+         * one by one, each copy behind a lock and a wait) */
+        int nf = 0; size_t tot = 0;
+        for (int i = 0; i < n; i++) {
+            rd_t *r = &cx->reads[i];
+            if (r->mode < 2 || r->seq) continue;
+            int open = 0;
+            for (int w = 0; w < r->nWins; w++) open |= !r->jobs[w].complete;
+            if (open) { nf++; tot += ((size_t)r->len + 1) * (r->isFq ? 2 : 1); }
+        }
+        if (nf) {
+            char *buf = (char *)lfg_pin_slot(LF_PS_HOSTBASES, tot + 64);
+            void **dst = (void **)malloc((size_t)nf * 2 * sizeof(void *)); const void **src = (const void **)malloc((size_t)nf * 2 * sizeof(void *));
+            size_t *nb = (size_t *)malloc((size_t)nf * 2 * sizeof(size_t));
+            if (!buf || !dst || !src || !nb) { free(dst); free(src); free(nb); return LF_ERR_NOMEM; }
+            int k = 0; size_t o = 0;
+            for (int i = 0; i < n; i++) {
+                rd_t *r = &cx->reads[i];
+                if (r->mode < 2 || r->seq) continue;
+                int open = 0;
+                for (int w = 0; w < r->nWins; w++) open |= !r->jobs[w].complete;
+                if (!open) continue;
+                dst[k] = buf + o; src[k] = cx->d_seqs + r->src_off; nb[k] = r->len; k++;
+                buf[o + r->len] = 0; r->seq = buf + o; o += (size_t)r->len + 1;
+                if (r->isFq) { dst[k] = buf + o; src[k] = cx->d_quals + r->src_off; nb[k] = r->len; k++; buf[o + r->len] = 0; r->qual = buf + o; o += (size_t)r->len + 1; }
+            }
+            rc = lfg_fetch_many(cx->ix->device, k, dst, src, nb);
+            free(dst); free(src); free(nb);
+            if (rc != LF_OK) return rc;
+            tmark(cx, "fetch");
+        }
+    }
     for (int round = 0; round < 64; round++) {
         double tw0 = now_ms();
         parallel_for(cx, n, phase_walk);

@@ -449,7 +449,8 @@ lf_req_gather_kernel(int n_req, const uint32_t *__restrict__ req_read, const uin
         }
         cnt += (uint32_t)__popcll(m);
     }
-    if (!WRITE && lane == 0) { req_n[q] = cnt; if (skeys) atomicMax(reinterpret_cast<unsigned int *>(skeys), cnt); }      /* (count pass: skeys = one word for the largest request) */
+    /* (count pass: skeys = 256 words for the largest request, request q uses word q mod 256 -- 100 k wavefronts on ONE word took longer than the gather itself) */
+    if (!WRITE && lane == 0) { req_n[q] = cnt; if (skeys) atomicMax(reinterpret_cast<unsigned int *>(skeys) + (q & 255), cnt); }
 }
 
 /* ---- 5b: a request's seeds in key order -- qPos for dp-n2 (what std::sort(compare_seed) orders by, src/Chain.cpp:244), target
@@ -603,7 +604,7 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     int64_t *d_seg0 = (int64_t *)pr; pr += al256(R * 8);
     float *d_vscore = (float *)pr; pr += al256(R * 4);
     int *d_nruns = (int *)pr;
-    uint64_t *h_small = (uint64_t *)lfg_pin_slot(LF_PS_VOTE0 + 0, 256);
+    uint64_t *h_small = (uint64_t *)lfg_pin_slot(LF_PS_VOTE0 + 0, 256 + 1024);
     if (!h_small) return LF_ERR_NOMEM;
 
     uint32_t n_req = 0;
@@ -744,7 +745,7 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     }
     hipLaunchKernelGGL(lf_req_build_kernel, dim3((unsigned)((n_reads + 127) / 128)), dim3(128), 0, s, n_reads, d_off, d_nreq, d_req0, d_seg0, d_stage,
                        d_ctg, d_ctg + ix->n_seqs, ix->n_seqs, (int64_t)ix->l_pac, d_req_read, d_req_win, d_req_lo, d_req_hi);
-    HIPCHK(hipMemsetAsync(d_maxn, 0, 8, s));
+    HIPCHK(hipMemsetAsync(d_maxn, 0, 1024, s));
     hipLaunchKernelGGL(lf_req_gather_kernel<false>, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_req_read, d_req_win, d_req_lo, d_req_hi, d_read_off,
                        d_tpos, d_qpl, d_strand, d_req_n, (const uint64_t *)nullptr, (uint2 *)nullptr, d_maxn, 0);
     const bool clasp = p->chain_alg == 1;
@@ -754,9 +755,11 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     HIPCHK(hipMemcpyAsync(h_small + 2, d_req_off + (Q - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_small + 3, d_ws_off + (Q - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_small + 4, d_req_n + (Q - 1), 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h_small + 9, d_maxn, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_small + 32, d_maxn, 1024, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    const uint32_t last_n = (uint32_t)h_small[4], max_n = (uint32_t)h_small[9];
+    uint32_t max_n = 0;
+    for (int u = 0; u < 256; u++) { const uint32_t x = reinterpret_cast<const uint32_t *>(h_small + 32)[u]; if (x > max_n) max_n = x; }
+    const uint32_t last_n = (uint32_t)h_small[4];
     const uint64_t S = h_small[2] + last_n, WS = h_small[3] + (last_n > big_lim ? last_n : 0);
     if (S >= (1ull << 31)) { lf_set_error("lfg_vote_chain: too many seeds in candidate windows (%llu)", (unsigned long long)S); return LF_ERR_ARG; }
     out->n_req_seeds = S;
