@@ -599,10 +599,10 @@ def main():
                 "lf_edlib_rsweep_kernel": (a["ms_k_rsweep"], a["ext_bytes"] - a["ops_bytes"], max(1, 2 * a["edlib_launches"]), True),      # NW + SHW instantiation per round: q + t/4 read
                 "lf_edlib_tb_kernel": (a["ms_k_tb"], a["ops_bytes"], max(1, a["edlib_launches"]), True),                               # the paths written (q + t region per problem)
                 "lf_seed_locate_kernel": (a["ms_k_locate"], 8 * a["n_sa"] + 9 * a["n_sa"], a["locate_launches"], True),
-                "lf_ksw_kernel": (a["ms_k_ksw"], a.get("ksw_bytes", 0), max(1, a["n_ksw_problems"] and 1), True),
+                "lf_ksw_mw_kernel": (a["ms_k_ksw"], a.get("ksw_bytes", 0), max(1, a["n_ksw_problems"] and 1), True),
                 # ---- groups ----
-                # lf_vote_hash_kernel (+ request-count scan): 9 B per hit read; votes live in LDS
-                "lf_vote_hash_kernel (+ scan)": (a["ms_k_vote"], 9 * n_hits, a["search_launches"], False),
+                # lf_vote_cell_kernel (+ request-count scan): 9 B per hit read; votes live in LDS
+                "lf_vote_cell_kernel (+ scan)": (a["ms_k_vote"], 9 * n_hits, a["search_launches"], False),
                 # request gather + sort by qPos + lf_chain_n2_kernel + chain gather: 16 B per request seed, 8 B per chain seed
                 "lf_chain_* (gather, sort, dp-n2 | clasp)": (a["ms_k_chain"], 16 * a["n_req_seeds"], a["search_launches"], False),
                 "lf_hirsch_* (levels incl. per-level readbacks)": (a["ms_k_hirsch"], 0, max(1, a["edlib_launches"]), False),

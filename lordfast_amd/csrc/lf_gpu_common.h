@@ -226,17 +226,35 @@ __device__ __forceinline__ uint32_t lf_wave_max_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 
-/* host side: every wait for a stream outside lf_mem.hip sleeps on the calling thread's blocking event (lf_mem.hip) */
+/* host side: every wait for a stream outside lf_mem.hip polls the calling thread's own event for LF_SPIN_US microseconds
+ * (default 3000) and then SLEEPS on it (the event is created with hipEventBlockingSync, lf_mem.hip).  Measured on config C2,
+ * HBM-resident step / host CPU per step: runtime's own spinning wait 69.2 ms / 0.57 core-s, sleep at once 77.5 ms / 0.18 -- a
+ * sleeping thread is back ~0.2 ms after its stream is done, and a chunk waits ~40 times.  Most of those waits are for a few
+ * microseconds of copy or a small kernel: polling briefly catches them, the long ones sleep (profiles/r04_waits/: 100 us -> 70.5 ms /
+ * 0.20, 3000 us -> 67.7 ms / 0.34).  LF_SPIN_WAIT=1: the runtime's wait. */
 #ifndef LF_NO_SYNC_WRAP
 #include <stdlib.h>
+#include <time.h>
 extern "C" void *lfg_thread_wait_event(int device);
 static inline hipError_t lf_stream_wait(hipStream_t s)
 {
     static const bool spin = getenv("LF_SPIN_WAIT") != nullptr;
+    static const long spin_us = getenv("LF_SPIN_US") ? atol(getenv("LF_SPIN_US")) : 3000;
     int dev = -1;
     if (spin || hipGetDevice(&dev) != hipSuccess) return hipStreamSynchronize(s);
     hipEvent_t e = (hipEvent_t)lfg_thread_wait_event(dev);
     if (!e || hipEventRecord(e, s) != hipSuccess) { (void)hipGetLastError(); return hipStreamSynchronize(s); }
+    if (spin_us > 0) {
+        struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (;;) {
+            const hipError_t q = hipEventQuery(e);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000L >= spin_us) break;
+            __builtin_ia32_pause();
+        }
+    }
     return hipEventSynchronize(e);
 }
 #define hipStreamSynchronize(s) lf_stream_wait(s)

@@ -45,6 +45,10 @@ typedef struct {        /* raw device results of the seed stage, copied to host 
 } lfg_hits_t;
 
 /* want_hits == 0: the hits stay in HBM for lfg_vote_chain (out gets n_hits, read_off and the counters only) */
+/* the read batch as three bit planes made on the host (bit i of word i / 64 of plane x describes base i: code low bit, code high
+ * bit, "is one of ACGT", upper case; planes[x * qw + w]) plus the bytes that are NOT upper-case ACGT: 3 / 8 of the bytes on the link */
+typedef struct { const uint64_t *planes; uint64_t qw; const uint64_t *exc_pos; const uint8_t *exc_byte; uint64_t n_exc; } lf_packed_src_t;
+int  lfg_seed_packed(const struct lf_index *ix, const lf_params_t *p, int n_reads, const lf_packed_src_t *pk, const uint64_t *off, int want_hits, lfg_hits_t *out);
 int  lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads,
               const uint64_t *off, int want_hits, lfg_hits_t *out);
 
@@ -104,7 +108,7 @@ enum { LF_DS_SEED0 = 0 /* ..15 */, LF_DS_CHAIN0 = 16 /* ..23 */, LF_DS_ALN0 = 24
 enum { LF_PS_READS = 0, LF_PS_READOFF = 1, LF_PS_HITS_T = 2, LF_PS_HITS_Q = 3, LF_PS_HITS_S = 4, LF_PS_HITS_OFF = 5,
        LF_PS_CHAIN_SEEDS = 6, LF_PS_CHAIN_IDX = 7, LF_PS_ALN_Q = 8, LF_PS_ALN_T = 9, LF_PS_ALN_PROB = 10 /* ..16 */,
        LF_PS_ROUND0 = 20 /* 4 per round: ed, end, len, ops ; up to 16 rounds */, LF_PS_RENDER0 = 84 /* ..91 */, LF_PS_VOTE0 = 92 /* ..107 */,
-       LF_PS_WALK0 = 108 /* ..111 */, LF_PS_RENDER1 = 112 /* ..115 */, LF_PS_SAM0 = 116 /* ..123 */, LF_PS_HOSTBASES = 124 };
+       LF_PS_WALK0 = 108 /* ..111 */, LF_PS_RENDER1 = 112 /* ..115 */, LF_PS_SAM0 = 116 /* ..123 */, LF_PS_HOSTBASES = 124, LF_PS_EXC_POS = 125, LF_PS_EXC_BYTE = 126 };
 
 /* alignment request as a DESCRIPTOR into HBM-resident data: query = the read batch uploaded by the seed stage,
  * target = the 2-bit reference.  Element i = base[start +/- i], optionally complemented (flags LF_F_*). */

@@ -251,6 +251,7 @@ typedef struct ctx {
     char *out_base; uint64_t *out_off;
     const char *const *len_seqs; uint32_t *len_out; volatile int len_bad;
     int *seed_map; char *cat; uint64_t *cat_off;
+    uint64_t *pk_planes, pk_qw, *pk_xpos, pk_xcap, pk_xn; uint8_t *pk_xbyte; volatile int pk_overflow;      /* packed upload (phase_pack) */
     const unsigned char *d_seqs, *d_quals;      /* lf_map_batch_dev: the caller's device blobs (NULL: host strings) */
     int32_t **stage_sink; int stage_i0;          /* lf_map_stages_batch: per read (batch index stage_i0 + ri) its decision, windows and alignWin results */
     /* HOLES mode (lf_sam.hip): the SEQ / QUAL column of every line is filled on the host from the caller's strings */
@@ -289,6 +290,7 @@ static inline char rc_char(char c) { return g_rc_tab[(unsigned char)c]; }
 void rc_copy(char *d, const char *s, size_t l);
 void rc_copy_stream(char *d, const char *s, size_t l);      /* the same bytes through non-temporal stores */
 void lf_copy_stream(char *d, const char *s, size_t n);      /* memcpy through non-temporal stores */
+int lf_pack_read(uint64_t *planes, uint64_t qw, uint64_t a, const char *seq, uint32_t len, uint64_t *exc_pos, uint8_t *exc_byte, uint64_t exc_cap, uint64_t *exc_n);
 void revcomp_into(const char *s, char *out, uint32_t len);
 void str_put_rc(str_t *b, const char *s, size_t l);
 void str_put_rev(str_t *b, const char *s, size_t l);

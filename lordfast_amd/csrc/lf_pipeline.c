@@ -96,6 +96,13 @@ static void phase_concat(ctx_t *cx, int tid, int k)
     lf_copy_stream(cx->cat + cx->cat_off[k], r->seq, r->len);      /* pinned staging: written once, read by the copy engine only */
 }
 
+static void phase_pack(ctx_t *cx, int tid, int k)
+{
+    (void)tid;
+    const rd_t *r = &cx->reads[cx->seed_map[k]];
+    if (!lf_pack_read(cx->pk_planes, cx->pk_qw, cx->cat_off[k], r->seq, r->len, cx->pk_xpos, cx->pk_xbyte, cx->pk_xcap, &cx->pk_xn)) cx->pk_overflow = 1;
+}
+
 void phase_make_jobs(ctx_t *cx, int tid, int ri)
 {
     (void)tid;
@@ -234,11 +241,48 @@ int map_chunk(ctx_t *cx)
             } else {
             /* the lanes of a step all start with this copy: one at a time, with every pool thread on it, so that the first lane's
              * bases are ready (and on their way, see lfg_seed_src) after 1 / 8 of the time instead of all lanes' after all of it */
-            { static pthread_mutex_t concat_turn = PTHREAD_MUTEX_INITIALIZER; pthread_mutex_lock(&concat_turn); parallel_for(cx, m, phase_concat); pthread_mutex_unlock(&concat_turn); }
+            static pthread_mutex_t concat_turn = PTHREAD_MUTEX_INITIALIZER;
+            /* Packed upload: the pool threads turn the reads into the three bit planes the alignment kernels work on anyway
+             * (lo / hi / valid: 3 / 8 of the bytes; the device rebuilds the bytes for the seed search and the SAM writer) plus a
+             * list of the bytes that are not upper-case ACGT -- the link carries 0.57 instead of 1.53 GB per 100 k reads, and the
+             * lanes of a step start 1.3 instead of 3.4 ms apart.  A chunk with more than one such byte in 64 (lower-case reads)
+             * goes up as bytes.  LF_UPLOAD_PACKED=0: always bytes. */
+            static int packed_on = -1;
+            if (packed_on < 0) packed_on = !(getenv("LF_UPLOAD_PACKED") && atoi(getenv("LF_UPLOAD_PACKED")) == 0);
+            int packed = 0;
+            if (packed_on && !cx->host_vote) {
+                const uint64_t qw = (bases + 63) / 64 + 2;                  /* lf_plane_words (lf_rsweep.h) */
+                const uint64_t xcap = bases / 64 + 1024;
+                uint64_t *xpos = (uint64_t *)lfg_pin_slot(LF_PS_EXC_POS, xcap * 8); uint8_t *xbyte = (uint8_t *)lfg_pin_slot(LF_PS_EXC_BYTE, xcap);
+                if (xpos && xbyte && 3 * qw * 8 <= bases + 64) {            /* the planes take the staging buffer's place */
+                    uint64_t *planes = (uint64_t *)cat;
+                    cx->pk_planes = planes; cx->pk_qw = qw; cx->pk_xpos = xpos; cx->pk_xbyte = xbyte; cx->pk_xcap = xcap; cx->pk_xn = 0; cx->pk_overflow = 0;
+                    pthread_mutex_lock(&concat_turn);
+                    /* the words that hold a read boundary (two reads OR their bits in) and the slack behind the last base */
+                    for (int x = 0; x < 3; x++) {
+                        uint64_t *P = planes + (size_t)x * qw;
+                        for (int k = 0; k <= m; k++) P[off[k] >> 6] = 0;
+                        for (uint64_t w = off[m] >> 6; w < qw; w++) P[w] = 0;
+                    }
+                    parallel_for(cx, m, phase_pack);
+                    pthread_mutex_unlock(&concat_turn);
+                    tmark(cx, "pack");
+                    if (!cx->pk_overflow) {
+                        lf_packed_src_t pk; pk.planes = planes; pk.qw = qw; pk.exc_pos = xpos; pk.exc_byte = xbyte; pk.n_exc = cx->pk_xn;
+                        if (getenv("LF_TIMING")) fprintf(stderr, "[lf] pack %.1f ms, %llu bytes outside ACGT\n", now_ms() - tc0, (unsigned long long)pk.n_exc);
+                        tc0 = now_ms();
+                        rc = lfg_seed_packed(cx->ix, cx->p, m, &pk, off, cx->host_vote, &hits);
+                        packed = 1;
+                    }
+                }
+            }
+            if (!packed) {
+            { pthread_mutex_lock(&concat_turn); parallel_for(cx, m, phase_concat); pthread_mutex_unlock(&concat_turn); }
             tmark(cx, "concat");
             if (getenv("LF_TIMING")) fprintf(stderr, "[lf] concat %.1f ms\n", now_ms() - tc0);
             tc0 = now_ms();
             rc = lfg_seed(cx->ix, cx->p, m, cat, off, cx->host_vote, &hits);
+            }
             }
             tmark(cx, "SEED");
             if (getenv("LF_TIMING")) fprintf(stderr, "[lf] lfg_seed %.1f ms (search %.1f locate %.1f), %llu hits\n", now_ms() - tc0, hits.ms_search, hits.ms_locate, (unsigned long long)hits.n_hits);

@@ -66,6 +66,76 @@ void lf_copy_stream(char *d, const char *s, size_t n)
 #endif
     memcpy(d, s, n);
 }
+/* ---- packed upload: a read's bases as bit planes, written at bit offset `a` of the chunk's planes (lo / hi / valid, `qw` words
+ * each; bit i of word i / 64 describes base i of the concatenated chunk).  valid = the byte is one of "ACGT" (upper case: what
+ * edlib's raw byte compare can match); code = A0 C1 G2 T3, zero where not valid -- exactly what lf_pack_planes_kernel makes of
+ * the bytes on the device.  Whole words are plain stores; the (up to two) words a read shares with its neighbours are OR-ed in
+ * atomically (the caller zeroes every word that holds a read boundary).  Bytes that are not valid go to the exception list
+ * (position in the chunk, byte); returns 0 when the list is full (the caller uploads the bytes instead). ---- */
+static inline void pack_bits_scalar(const unsigned char *s, size_t n, uint64_t *lo, uint64_t *hi, uint64_t *va)
+{
+    uint64_t l = 0, h = 0, v = 0;
+    for (size_t i = 0; i < n; i++) {
+        const unsigned c = s[i];
+        const uint64_t ok = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
+        const unsigned x = (c >> 1) & 3u, code = x ^ (x >> 1);
+        l |= (ok & (code & 1u)) << i; h |= (ok & (code >> 1)) << i; v |= ok << i;
+    }
+    *lo = l; *hi = h; *va = v;
+}
+int lf_pack_read(uint64_t *planes, uint64_t qw, uint64_t a, const char *seq, uint32_t len,
+                 uint64_t *exc_pos, uint8_t *exc_byte, uint64_t exc_cap, uint64_t *exc_n)
+{
+    uint64_t *LO = planes, *HI = planes + qw, *VA = planes + 2 * qw;
+    const unsigned char *s = (const unsigned char *)seq;
+    size_t i = 0; int ok_all = 1;
+    uint64_t pos = a;
+#define LF_PACK_EXC(word_valid, count, base_i) do { \
+        uint64_t bad_ = ~(word_valid) & ((count) >= 64 ? ~0ull : ((1ull << (count)) - 1)); \
+        while (bad_) { const int b_ = __builtin_ctzll(bad_); bad_ &= bad_ - 1; \
+            const uint64_t k_ = __atomic_fetch_add(exc_n, 1, __ATOMIC_RELAXED); \
+            if (k_ < exc_cap) { exc_pos[k_] = a + (base_i) + (uint64_t)b_; exc_byte[k_] = s[(base_i) + (size_t)b_]; } else ok_all = 0; } } while (0)
+    /* head: up to the next word boundary */
+    if (pos & 63) {
+        size_t n = 64 - (size_t)(pos & 63); if (n > len) n = len;
+        uint64_t l, h, v; pack_bits_scalar(s, n, &l, &h, &v);
+        const unsigned sh = (unsigned)(pos & 63);
+        __atomic_fetch_or(&LO[pos >> 6], l << sh, __ATOMIC_RELAXED); __atomic_fetch_or(&HI[pos >> 6], h << sh, __ATOMIC_RELAXED); __atomic_fetch_or(&VA[pos >> 6], v << sh, __ATOMIC_RELAXED);
+        LF_PACK_EXC(v, n, (size_t)0);
+        i = n; pos += n;
+    }
+    /* whole words: 64 bases each */
+    for (; i + 64 <= len; i += 64, pos += 64) {
+        uint64_t l, h, v;
+#if defined(__x86_64__)
+        l = h = v = 0;
+        for (int q = 0; q < 4; q++) {
+            const __m128i x = _mm_loadu_si128((const __m128i *)(s + i + 16 * q));
+            const __m128i b2 = _mm_slli_epi16(x, 5), b1 = _mm_slli_epi16(x, 6);           /* bit 2 / bit 1 of every byte in its top bit */
+            const __m128i okv = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(x, _mm_set1_epi8('A')), _mm_cmpeq_epi8(x, _mm_set1_epi8('C'))),
+                                             _mm_or_si128(_mm_cmpeq_epi8(x, _mm_set1_epi8('G')), _mm_cmpeq_epi8(x, _mm_set1_epi8('T'))));
+            const uint64_t vm = (uint64_t)(uint32_t)_mm_movemask_epi8(okv);
+            const uint64_t hm = (uint64_t)(uint32_t)_mm_movemask_epi8(b2) & vm;            /* code high bit = bit 2 (A C: 0, G T: 1) */
+            const uint64_t lm = (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_xor_si128(b1, b2)) & vm;   /* low bit = bit 1 ^ bit 2 */
+            l |= lm << (16 * q); h |= hm << (16 * q); v |= vm << (16 * q);
+        }
+#else
+        pack_bits_scalar(s + i, 64, &l, &h, &v);
+#endif
+        LO[pos >> 6] = l; HI[pos >> 6] = h; VA[pos >> 6] = v;
+        if (v != ~0ull) LF_PACK_EXC(v, 64, i);
+    }
+    /* tail */
+    if (i < len) {
+        const size_t n = len - i;
+        uint64_t l, h, v; pack_bits_scalar(s + i, n, &l, &h, &v);
+        __atomic_fetch_or(&LO[pos >> 6], l, __ATOMIC_RELAXED); __atomic_fetch_or(&HI[pos >> 6], h, __ATOMIC_RELAXED); __atomic_fetch_or(&VA[pos >> 6], v, __ATOMIC_RELAXED);
+        LF_PACK_EXC(v, n, i);
+    }
+#undef LF_PACK_EXC
+    return ok_all;
+}
+
 #if defined(__x86_64__)
 __attribute__((target("ssse3"))) static void rc_copy_stream_ssse3(char *d, const char *s, size_t l)
 {

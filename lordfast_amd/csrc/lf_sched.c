@@ -244,6 +244,15 @@ static void fetch_dev_sam(batch_t *B, const lf_index_t *ix, uint64_t base, uint6
     if (B->rc == LF_OK) {               /* one D2H copy of the chunk's text straight into its place */
         /* a caller-provided buffer never moves: the copy runs behind the lane's back (lfg_sam_fetch_wait at the lane's end);
          * a growable one may be reallocated by another lane, so the copy completes under the read lock */
+        /* A chunk's place in the output is known when every earlier chunk has its size, so the chunks behind a late one are
+         * released together: the last 17 ms of a 96 ms step (under the profiler) are five scatter kernels sharing the link at
+         * 37 GB/s where one moves 53 (profiles/r04_waits/).  LF_EGRESS_TURNS=1 lets them go one at a time, each with its own host
+         * fill beside it: measured equal (86.8 / 91.4 against 86.8 / 87.4 ms per step), so it is off. */
+        static pthread_mutex_t egress_turn = PTHREAD_MUTEX_INITIALIZER;
+        static int turns = -1;
+        if (turns < 0) turns = getenv("LF_EGRESS_TURNS") && atoi(getenv("LF_EGRESS_TURNS")) != 0;
+        const int my_turn = turns && B->fixed_out && n_fill > 0;
+        if (my_turn) pthread_mutex_lock(&egress_turn);
         const int frc = B->fixed_out ? lfg_sam_fetch_async(ix, B->all.s + base, tot, parity) : lfg_sam_fetch(ix, B->all.s + base, tot, parity);
         if (frc != LF_OK) { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = frc; }
         else if (n_fill > 0) {          /* the holes, while the scatter kernel moves the rest over the link */
@@ -251,6 +260,7 @@ static void fetch_dev_sam(batch_t *B, const lf_index_t *ix, uint64_t base, uint6
             fx.lane = lane; fx.n_threads = B->slots; fx.fill = fill; fx.n_fill = n_fill; fx.out_base = B->all.s + base;
             parallel_for(&fx, n_fill, phase_fill);
         }
+        if (my_turn) { if (frc == LF_OK) (void)lfg_sam_fetch_wait(ix); pthread_mutex_unlock(&egress_turn); }
     }
     pthread_rwlock_unlock(&B->grow);
     free(fill);

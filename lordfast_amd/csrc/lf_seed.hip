@@ -578,9 +578,45 @@ extern "C" int lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_r
     return lfg_seed_src(ix, p, n_reads, reads, nullptr, nullptr, off, want_hits, out);
 }
 
+/* packed upload (lfg_seed_packed): the read bytes back from the bit planes -- 'A' 'C' 'G' 'T' by code where the valid bit is set,
+ * 0 elsewhere (lf_patch_bytes_kernel then stores the few bytes that are not upper-case ACGT) */
+__global__ void __launch_bounds__(256)
+lf_unpack_planes_kernel(const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi, const uint64_t *__restrict__ valid, uint64_t n_bases, char *__restrict__ dst)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      /* four bases per thread */
+    if (4 * t >= n_bases) return;
+    const uint64_t w = t >> 4; const uint32_t sh = (uint32_t)(t & 15) * 4;
+    const uint32_t l = (uint32_t)(lo[w] >> sh) & 15u, h = (uint32_t)(hi[w] >> sh) & 15u, v = (uint32_t)(valid[w] >> sh) & 15u;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t c = ((l >> k) & 1u) | (((h >> k) & 1u) << 1);
+        const uint32_t ch = ((v >> k) & 1u) ? ((0x54474341u >> (c << 3)) & 0xffu) : 0u;
+        out |= ch << (8 * k);
+    }
+    if (4 * t + 4 <= n_bases) *reinterpret_cast<uint32_t *>(dst + 4 * t) = out;      /* the buffer starts 256-byte aligned */
+    else for (uint64_t k = 0; 4 * t + k < n_bases; k++) dst[4 * t + k] = (char)(out >> (8 * k));
+}
+__global__ void lf_patch_bytes_kernel(const uint64_t *__restrict__ pos, const uint8_t *__restrict__ byte, uint64_t n, char *__restrict__ dst)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[pos[i]] = (char)byte[i];
+}
+
+static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads, const void *d_src, const uint64_t *src_off,
+                        const lf_packed_src_t *pk, const uint64_t *off, int want_hits, lfg_hits_t *out);
+extern "C" int lfg_seed_packed(const struct lf_index *ix, const lf_params_t *p, int n_reads, const lf_packed_src_t *pk, const uint64_t *off, int want_hits, lfg_hits_t *out)
+{
+    return lfg_seed_any(ix, p, n_reads, nullptr, nullptr, nullptr, pk, off, want_hits, out);
+}
 /* reads == NULL: the bases are already in HBM of this device (d_src + src_off[k], host array of n_reads offsets) */
 extern "C" int lfg_seed_src(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads, const void *d_src, const uint64_t *src_off,
                             const uint64_t *off, int want_hits, lfg_hits_t *out)
+{
+    return lfg_seed_any(ix, p, n_reads, reads, d_src, src_off, nullptr, off, want_hits, out);
+}
+static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads, const void *d_src, const uint64_t *src_off,
+                        const lf_packed_src_t *pk, const uint64_t *off, int want_hits, lfg_hits_t *out)
 {
     memset(out, 0, sizeof(*out));
     lf_dev_state *st = (lf_dev_state *)ix->dev;
@@ -610,12 +646,33 @@ extern "C" int lfg_seed_src(const struct lf_index *ix, const lf_params_t *p, int
 
     HIPCHK(hipMemsetAsync(d_counters, 0, 32, s));
     HIPCHK(hipMemcpyAsync(d_off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
-    if (reads) {
+    const uint64_t qw = lf_plane_words(n_bases);
+    uint64_t *d_planes = DSLOT(uint64_t, 14, 3 * qw * 8);
+    if (!d_planes) return LF_ERR_NOMEM;
+    static std::mutex upload_turn;
+    static const bool turns = !(getenv("LF_UPLOAD_TURNS") && atoi(getenv("LF_UPLOAD_TURNS")) == 0);
+    if (pk) {
+        /* the batch arrives as bit planes (3 / 8 of the bytes): they are what the alignment kernels want anyway; the seed search
+         * and the SAM writer get the bytes back from them */
+        if (pk->qw != qw) { lf_set_error("lfg_seed_packed: %llu plane words for %llu bases", (unsigned long long)pk->qw, (unsigned long long)n_bases); return LF_ERR_ARG; }
+        uint64_t *d_xpos = DSLOT(uint64_t, 2, pk->n_exc * 8 + 16); uint8_t *d_xbyte = DSLOT(uint8_t, 8, pk->n_exc + 16);
+        if (!d_xpos || !d_xbyte) return LF_ERR_NOMEM;
+        {
+            std::unique_lock<std::mutex> g(upload_turn, std::defer_lock);
+            if (turns) g.lock();
+            HIPCHK(hipMemcpyAsync(d_planes, pk->planes, 3 * qw * 8, hipMemcpyHostToDevice, s));
+            if (pk->n_exc) {
+                HIPCHK(hipMemcpyAsync(d_xpos, pk->exc_pos, pk->n_exc * 8, hipMemcpyHostToDevice, s));
+                HIPCHK(hipMemcpyAsync(d_xbyte, pk->exc_byte, pk->n_exc, hipMemcpyHostToDevice, s));
+            }
+            if (turns) HIPCHK(hipStreamSynchronize(s));
+        }
+        hipLaunchKernelGGL(lf_unpack_planes_kernel, dim3((unsigned)((n_bases / 4 + 256) / 256)), dim3(256), 0, s, d_planes, d_planes + qw, d_planes + 2 * qw, n_bases, d_reads);
+        if (pk->n_exc) hipLaunchKernelGGL(lf_patch_bytes_kernel, dim3((unsigned)((pk->n_exc + 255) / 256)), dim3(256), 0, s, (const uint64_t *)d_xpos, (const uint8_t *)d_xbyte, pk->n_exc, d_reads);
+    } else if (reads) {
         /* Uploads take turns: eight lanes start a step together, and eight concurrent copies share the link -- every lane would
          * get its bases after ~8 x the time of one copy.  In turn, the first lane's kernels start after one copy and the other
          * lanes' copies run under them.  (One stream wait per chunk; LF_UPLOAD_TURNS=0 switches it off for A / B runs.) */
-        static std::mutex upload_turn;
-        static const bool turns = !(getenv("LF_UPLOAD_TURNS") && atoi(getenv("LF_UPLOAD_TURNS")) == 0);
         if (turns) {
             std::lock_guard<std::mutex> g(upload_turn);
             HIPCHK(hipMemcpyAsync(d_reads, reads, n_bases, hipMemcpyHostToDevice, s));
@@ -631,10 +688,7 @@ extern "C" int lfg_seed_src(const struct lf_index *ix, const lf_params_t *p, int
     }
 
     {   /* the batch as three bit planes (code low / high bit, "is ACGT"): what the alignment kernels build their blocks from */
-        const uint64_t qw = lf_plane_words(n_bases);
-        uint64_t *d_planes = DSLOT(uint64_t, 14, 3 * qw * 8);
-        if (!d_planes) return LF_ERR_NOMEM;
-        lf_rsweep_pack_planes(s, (const unsigned char *)d_reads, n_bases, d_planes, qw);
+        if (!pk) lf_rsweep_pack_planes(s, (const unsigned char *)d_reads, n_bases, d_planes, qw);
         lfg_lane_set_value(dv, 0, qw);
     }
     hipLaunchKernelGGL(lf_seed_pos_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, d_off, hc, d_pos2);

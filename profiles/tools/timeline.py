@@ -1,26 +1,18 @@
 #!/usr/bin/env python3
-"""timeline.py <kernel_trace.csv> --last-step <chunks per step> -- per queue (= lane stream) the sequence of kernels of the last
-step with start offsets and durations (ms), to see what a chunk waits for between its stages."""
-import csv
-import sys
+"""timeline.py <kernel_trace.csv> --last-step <chunks per step> [lead_ms] [min_ms] -- the kernels of the last step of a rocprofv3 --kernel-trace CSV in start
+order: start (ms after the window's begin = lead_ms before the step's first seed search), duration, name; kernels shorter than min_ms are summed per 5 ms."""
+import csv, sys
 from collections import defaultdict
-
 rows = list(csv.DictReader(open(sys.argv[1])))
-k = int(sys.argv[3])
-iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:40], r.get("Queue_Id", "?")) for r in rows)
-starts = [s for s, _, n, _ in iv if n.startswith("lf_seed_search_kernel")]
-lo = starts[-k]
-by_q = defaultdict(list)
-for s, e, n, q in iv:
-    if s >= lo:
-        by_q[q].append((s, e, n))
-for q, lst in sorted(by_q.items(), key=lambda kv: kv[1][0][0]):
-    big = [x for x in lst if x[1] - x[0] > 150e3 or x[2].startswith(("lf_ksw", "lf_walk", "lf_render", "lf_sam", "lf_seed_search", "lf_vote_hash"))]
-    if len(big) < 3:
-        continue
-    print(f"queue {q}: {len(lst)} launches")
-    prev_e = None
-    for s, e, n in big:
-        gap = "" if prev_e is None else f"  (+{(s - prev_e) / 1e6:6.2f} after previous listed)"
-        print(f"   {(s - lo) / 1e6:8.2f} ms  {(e - s) / 1e6:7.2f} ms  {n}{gap}")
-        prev_e = e
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
+k = int(sys.argv[3]); lead = float(sys.argv[4]) if len(sys.argv) > 4 else 15.0; min_ms = float(sys.argv[5]) if len(sys.argv) > 5 else 0.5
+starts = [s for s, _, n in iv if n.startswith("lf_seed_search_kernel")]
+lo = starts[-k] - int(lead * 1e6); hi = max(e for _, e, _ in iv)
+small = defaultdict(float)
+for s, e, n in iv:
+    if e <= lo: continue
+    d = (e - s) / 1e6
+    if d >= min_ms: print(f"{(s - lo) / 1e6:8.2f} ms  +{d:7.2f}  {n.split('(')[0][:60]}")
+    else: small[int((s - lo) / 5e6)] += d
+print("kernels below", min_ms, "ms, summed per 5 ms bucket:", {5 * b: round(v, 2) for b, v in sorted(small.items())})
+print("window", round((hi - lo) / 1e6, 1), "ms")
