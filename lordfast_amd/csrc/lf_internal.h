@@ -108,7 +108,7 @@ enum { LF_DS_SEED0 = 0 /* ..15 */, LF_DS_CHAIN0 = 16 /* ..23 */, LF_DS_ALN0 = 24
 enum { LF_PS_READS = 0, LF_PS_READOFF = 1, LF_PS_HITS_T = 2, LF_PS_HITS_Q = 3, LF_PS_HITS_S = 4, LF_PS_HITS_OFF = 5,
        LF_PS_CHAIN_SEEDS = 6, LF_PS_CHAIN_IDX = 7, LF_PS_ALN_Q = 8, LF_PS_ALN_T = 9, LF_PS_ALN_PROB = 10 /* ..16 */,
        LF_PS_ROUND0 = 20 /* 4 per round: ed, end, len, ops ; up to 16 rounds */, LF_PS_RENDER0 = 84 /* ..91 */, LF_PS_VOTE0 = 92 /* ..107 */,
-       LF_PS_WALK0 = 108 /* ..111 */, LF_PS_RENDER1 = 112 /* ..115 */, LF_PS_SAM0 = 116 /* ..123 */, LF_PS_HOSTBASES = 124, LF_PS_EXC_POS = 125, LF_PS_EXC_BYTE = 126 };
+       LF_PS_WALK0 = 108 /* ..111 */, LF_PS_RENDER1 = 112 /* ..115 */, LF_PS_SAM0 = 116 /* ..123 */, LF_PS_HOSTBASES = 124, LF_PS_EXC_POS = 125, LF_PS_EXC_BYTE = 126, LF_PS_FETCH_META = 127 };
 
 /* alignment request as a DESCRIPTOR into HBM-resident data: query = the read batch uploaded by the seed stage,
  * target = the 2-bit reference.  Element i = base[start +/- i], optionally complemented (flags LF_F_*). */
@@ -173,7 +173,7 @@ int lfg_sam_wait(const struct lf_index *ix);
 int lfg_sam_fetch_async(const struct lf_index *ix, char *dst, uint64_t total, int parity);
 int lfg_sam_fetch_wait(const struct lf_index *ix);
 int lfg_fetch(int device, void *dst, const void *src_dev, size_t bytes);
-int lfg_fetch_many(int device, int n, void *const *dst, const void *const *src_dev, const size_t *bytes);
+int lfg_fetch_gather(int device, int n, void *host_base, const uint64_t *host_off, const void *const *src_dev, const size_t *bytes, uint64_t total);
 int lfg_upload(int device, void *dst_dev, const void *src, size_t bytes);
 #define LF_F_QREV  1u
 #define LF_F_QCOMP 2u

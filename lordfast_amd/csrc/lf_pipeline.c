@@ -247,8 +247,7 @@ int map_chunk(ctx_t *cx)
              * list of the bytes that are not upper-case ACGT -- the link carries 0.57 instead of 1.53 GB per 100 k reads, and the
              * lanes of a step start 1.3 instead of 3.4 ms apart.  A chunk with more than one such byte in 64 (lower-case reads)
              * goes up as bytes.  LF_UPLOAD_PACKED=0: always bytes. */
-            static int packed_on = -1;
-            if (packed_on < 0) packed_on = !(getenv("LF_UPLOAD_PACKED") && atoi(getenv("LF_UPLOAD_PACKED")) == 0);
+            const int packed_on = !(getenv("LF_UPLOAD_PACKED") && atoi(getenv("LF_UPLOAD_PACKED")) == 0);
             int packed = 0;
             if (packed_on && !cx->host_vote) {
                 const uint64_t qw = (bases + 63) / 64 + 2;                  /* lf_plane_words (lf_rsweep.h) */
@@ -412,9 +411,9 @@ extend:
         }
         if (nf) {
             char *buf = (char *)lfg_pin_slot(LF_PS_HOSTBASES, tot + 64);
-            void **dst = (void **)malloc((size_t)nf * 2 * sizeof(void *)); const void **src = (const void **)malloc((size_t)nf * 2 * sizeof(void *));
+            uint64_t *hoff = (uint64_t *)malloc((size_t)nf * 2 * sizeof(uint64_t)); const void **src = (const void **)malloc((size_t)nf * 2 * sizeof(void *));
             size_t *nb = (size_t *)malloc((size_t)nf * 2 * sizeof(size_t));
-            if (!buf || !dst || !src || !nb) { free(dst); free(src); free(nb); return LF_ERR_NOMEM; }
+            if (!buf || !hoff || !src || !nb) { free(hoff); free(src); free(nb); return LF_ERR_NOMEM; }
             int k = 0; size_t o = 0;
             for (int i = 0; i < n; i++) {
                 rd_t *r = &cx->reads[i];
@@ -422,12 +421,14 @@ extend:
                 int open = 0;
                 for (int w = 0; w < r->nWins; w++) open |= !r->jobs[w].complete;
                 if (!open) continue;
-                dst[k] = buf + o; src[k] = cx->d_seqs + r->src_off; nb[k] = r->len; k++;
-                buf[o + r->len] = 0; r->seq = buf + o; o += (size_t)r->len + 1;
-                if (r->isFq) { dst[k] = buf + o; src[k] = cx->d_quals + r->src_off; nb[k] = r->len; k++; buf[o + r->len] = 0; r->qual = buf + o; o += (size_t)r->len + 1; }
+                hoff[k] = o; src[k] = cx->d_seqs + r->src_off; nb[k] = r->len; k++;
+                r->seq = buf + o; o += (size_t)r->len + 1;
+                if (r->isFq) { hoff[k] = o; src[k] = cx->d_quals + r->src_off; nb[k] = r->len; k++; r->qual = buf + o; o += (size_t)r->len + 1; }
             }
-            rc = lfg_fetch_many(cx->ix->device, k, dst, src, nb);
-            free(dst); free(src); free(nb);
+            rc = lfg_fetch_gather(cx->ix->device, k, buf, hoff, src, nb, o);
+            /* (the copy brings the staging buffer's gaps along: the terminators are written after it) */
+            for (int i = 0; i < k; i++) buf[hoff[i] + nb[i]] = 0;
+            free(hoff); free(src); free(nb);
             if (rc != LF_OK) return rc;
             tmark(cx, "fetch");
         }

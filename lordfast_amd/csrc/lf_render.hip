@@ -410,17 +410,36 @@ extern "C" int lfg_fetch(int device, void *dst, const void *src_dev, size_t byte
     HIPCHK(hipStreamSynchronize(fs[device]));
     return LF_OK;
 }
-/* many small device -> host copies (dst in pinned memory), one wait: the bases of the reads whose chains the host replays.
- * lfg_fetch per read -- one mutex, one stream, one wait each, into pageable memory -- took 30 ms of a 6 250-read chunk of the C4
- * workload (2 000 fetches per step, served one after the other for all lanes). */
-extern "C" int lfg_fetch_many(int device, int n, void *const *dst, const void *const *src_dev, const size_t *bytes)
+/* many small pieces of device memory -> one pinned host buffer: ONE gather kernel, ONE copy, one wait (the bases of the reads
+ * whose chains the host replays).  lfg_fetch per read -- one lock, one stream, one wait each, into pageable memory -- took 30 ms
+ * of a 6 250-read chunk of the C4 workload; one asynchronous copy per read on the lane's stream still took 8 - 30 ms, each of the
+ * 500 copies a blit kernel queued behind the other lanes' kernels. */
+__global__ void __launch_bounds__(256)
+lf_gather_bytes_kernel(int n, const uint64_t *__restrict__ meta /* n source addresses, n destination offsets, n lengths */, uint8_t *__restrict__ dst)
+{
+    const int j = blockIdx.x;
+    if (j >= n) return;
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(meta[j]);
+    uint8_t *d = dst + meta[n + j];
+    const uint64_t len = meta[2 * (size_t)n + j];
+    for (uint64_t i = threadIdx.x; i < len; i += 256) d[i] = src[i];
+}
+extern "C" int lfg_fetch_gather(int device, int n, void *host_base, const uint64_t *host_off, const void *const *src_dev, const size_t *bytes, uint64_t total)
 {
     if (n <= 0) return LF_OK;
     HIPCHK(hipSetDevice(device));
     hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
     if (!s) return LF_ERR_HIP;
-    for (int i = 0; i < n; i++) if (bytes[i]) HIPCHK(hipMemcpyAsync(dst[i], src_dev[i], bytes[i], hipMemcpyDeviceToHost, s));
+    uint64_t *h_meta = (uint64_t *)lfg_pin_slot(LF_PS_FETCH_META, (size_t)n * 24 + 64);
+    uint64_t *d_meta = (uint64_t *)lfg_dev_slot(device, LF_DS_WALK0 + 15, (size_t)n * 24 + 64);
+    uint8_t *d_stage = (uint8_t *)lfg_dev_slot(device, LF_DS_WALK0 + 16, total + 64);
+    if (!h_meta || !d_meta || !d_stage) return LF_ERR_NOMEM;
+    for (int i = 0; i < n; i++) { h_meta[i] = (uint64_t)(uintptr_t)src_dev[i]; h_meta[n + i] = host_off[i]; h_meta[2 * (size_t)n + i] = bytes[i]; }
+    HIPCHK(hipMemcpyAsync(d_meta, h_meta, (size_t)n * 24, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(lf_gather_bytes_kernel, dim3((unsigned)n), dim3(256), 0, s, n, (const uint64_t *)d_meta, d_stage);
+    HIPCHK(hipMemcpyAsync(host_base, d_stage, total, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
     return LF_OK;
 }
 extern "C" int lfg_upload(int device, void *dst_dev, const void *src, size_t bytes)

@@ -315,6 +315,34 @@ def test_map_batch_multi_replicas_same_output(golden_dir, golden_reads, monkeypa
     assert st["n_reads"] == len(seqs)
 
 
+def test_packed_upload_equals_byte_upload(lf, golden_reads, monkeypatch):
+    """host batches go up as three bit planes made by the host threads + a list of the bytes that are not upper-case ACGT
+    (lf_pack_read, lf_unpack_planes_kernel); LF_UPLOAD_PACKED=0 uploads the bytes.  Same SAM for: the golden reads, reads with
+    N runs / IUPAC codes / lower-case stretches at word boundaries, very short reads (several per 64-bit plane word), and a batch
+    that is lower case throughout (more exceptions than the list takes: the chunk falls back to bytes)"""
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    rng = np.random.default_rng(41)
+    mixed = []
+    for i, s in enumerate(seqs[:40]):
+        b = bytearray(s)
+        for a in (0, 63, 64, 65, 127, 128, len(b) - 70, len(b) - 1):
+            if 0 <= a < len(b): b[a:a + int(rng.integers(1, 9))] = b"N" * len(b[a:a + int(rng.integers(1, 9))])
+        a = int(rng.integers(0, max(1, len(b) - 200))); b[a:a + 130] = bytes(b[a:a + 130]).lower()
+        b[int(rng.integers(0, len(b)))] = ord("R")
+        mixed.append(bytes(b)[: len(b) - (i % 7)])
+    tiny = [bytes(s[: int(rng.integers(1, 40))]) for s in seqs[:64]]
+    lower = [bytes(s).lower() for s in seqs[:30]]
+    for batch in (list(seqs), mixed + tiny, lower):
+        nm = [b"r%d" % i for i in range(len(batch))]
+        monkeypatch.delenv("LF_UPLOAD_PACKED", raising=False)
+        sam_p, st_p = lf.map_batch(nm, batch)
+        monkeypatch.setenv("LF_UPLOAD_PACKED", "0")
+        sam_b, st_b = lf.map_batch(nm, batch)
+        assert sam_p == sam_b, first_diff(sam_p, sam_b)
+        assert st_p["n_seeds"] == st_b["n_seeds"]
+
+
 @pytest.mark.parametrize("cfg,lds_max", [("default", 0), ("n30", 600), ("clasp", 3000)])
 def test_vote_tables_in_global_memory(lf, golden_reads, monkeypatch, cfg, lds_max):
     """reads with more votes than the largest LDS hash table keep their vote table in a global scratch area
