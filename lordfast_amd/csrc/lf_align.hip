@@ -828,6 +828,14 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     HIPCHK(hipMemcpyAsync(&aux_total, d_misc, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const uint64_t hist_entries = tail[0] + tail[1];
+    if (getenv("LF_HIST_STATS")) {       /* debug: the class-1 problems of this round by (mode, blocks, target-length bucket) -- the scanned bin starts */
+        std::vector<uint32_t> hb((size_t)LF_NBINS + 1);
+        HIPCHK(hipMemcpy(hb.data(), d_bins, (size_t)LF_NBINS * 4, hipMemcpyDeviceToHost));
+        for (int b = 1; b < 1 + 2 * 64 * LF_BIN_MB; b++) {      /* (the scatter pass advanced every cursor to its bin's end) */
+            const uint32_t c = hb[(size_t)b] - hb[(size_t)b - 1];
+            if (c) fprintf(stderr, "[lf] bin mode %d nb %d mb %d: %u\n", (b - 1) / (64 * LF_BIN_MB), ((b - 1) / LF_BIN_MB) % 64 + 1, (b - 1) % LF_BIN_MB, c);
+        }
+    }
     lf_hist_t *d_hist = DSLOT(lf_hist_t, 2, hist_entries * sizeof(lf_hist_t) + 64);
     uint64_t *d_aux = (uint64_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 9, aux_total * 8 + 64);
     if (!d_hist || !d_aux) return LF_ERR_NOMEM;
