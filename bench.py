@@ -67,10 +67,12 @@ def parse():
                          "--segdups of them pasted into the genome): those reads have several near-equal candidate windows, so mapSeq "
                          "takes its fine branch (src/LordFAST.cpp:542-562) and -n windows are chained and extended.  c4 default 0.3, else 0")
     ap.add_argument("--segdups", type=int, default=2000, help="duplicated segments in the genome when --dup-frac > 0")
-    ap.add_argument("--inflight", type=int, default=1,
+    ap.add_argument("--inflight", type=int, default=None,
                     help="steps in flight at once (threads calling the library concurrently; its lane allocator shares the device's 8 lanes "
                          "between them).  1 = one step after the other.  Small shards (a rank's share under strong scaling) are bound by the "
-                         "latency of a chunk's launch chain, which the next steps' kernels hide; every step is still a complete call")
+                         "latency of a chunk's launch chain, which the next steps' kernels hide; every step is still a complete call.  "
+                         "Default: 2 for N > 1 under strong scaling (a rank's shard is 1 / N of the batch; the exchange loop keeps that many of a "
+                         "rank's steps in flight too, lordfast_amd/dist.py: run_pipeline), else 1")
     ap.add_argument("--mode", choices=["ranks", "inproc"], default="ranks",
                     help="ranks: one process per GPU (torch.distributed); inproc: ONE process drives N devices through lf_map_batch_multi "
                          "(chunks pulled from one counter; every device copies through its own PCIe link)")
@@ -95,6 +97,8 @@ def parse():
         a.steps = 10 if a.config == "c4" else 4
     if a.scaling is None:
         a.scaling = "strong" if a.gpus > 1 else "weak"
+    if a.inflight is None:
+        a.inflight = 2 if (a.gpus > 1 and a.scaling == "strong" and a.mode == "ranks") else 1
     if a.config == "c5":
         if a.read_len == 15000:
             a.read_len = 50000
@@ -181,8 +185,38 @@ def make_reads(args, contigs, fa, rank):
     return names, seqs
 
 
+def sample_order(n_total, n_want):
+    """read indices for the parity / CPU-baseline sample: a golden-ratio stride over the WHOLE batch, so that any prefix of the
+    list is spread over every chunk and lane of the step (not the first reads only)"""
+    n_want = max(1, min(n_total, n_want))
+    g = max(1, int(n_total * 0.6180339887))
+    while np.gcd(g, n_total) != 1:
+        g += 1
+    return [int((j * g) % n_total) for j in range(n_want)]
+
+
+def records_of(view, n_bytes, wanted):
+    """-> {read name: [its SAM lines]} for the names in `wanted`, out of n_bytes of SAM text (numpy uint8 view); records of a read
+    are consecutive lines that start with its name"""
+    out = {}
+    wanted = set(wanted)
+    CH = 1 << 28
+    carry = b""
+    for a in range(0, n_bytes, CH):
+        blk = carry + bytes(memoryview(view[a:min(n_bytes, a + CH)]))
+        cut = blk.rfind(b"\n") + 1
+        carry = blk[cut:]
+        for l in blk[:cut].split(b"\n"):
+            if l:
+                nm = l.split(b"\t", 1)[0]
+                if nm in wanted:
+                    out.setdefault(nm, []).append(l)
+    return out
+
+
 def cpu_baseline(args, fa, names, seqs):
-    """the REAL reference (oracle/_ref/liblfref.so) on all host cores, on a bounded sample"""
+    """the REAL reference (oracle/_ref/liblfref.so) on all host cores, on a bounded sample (the caller hands over the sample: reads
+    spread over the whole batch)"""
     from oracle import pyoracle as po
     if not os.path.exists(po.REF_SO):
         return None
@@ -227,7 +261,7 @@ def cpu_baseline(args, fa, names, seqs):
     # `cores` = the CPUs this container may use (cgroup quota), `threads` = the reference's --threads value that was fastest
     return dict(value=n / secs, unit="reads/s", cores=granted, cpus_granted=granted, cpus_online=os.cpu_count(), threads=cores,
                 kind="reference",
-                sample=f"first {n} reads of the same batch ({bases / 1e6:.1f} Mbp), mapSeqMT only, {secs:.1f}s, "
+                sample=f"{n} reads of the same batch, taken with a golden-ratio stride across ALL of it ({bases / 1e6:.1f} Mbp), mapSeqMT only, {secs:.1f}s, "
                        f"--threads {cores} on {granted} granted CPUs", bp_per_s=bases / secs), sam, n
 
 
@@ -385,30 +419,34 @@ def main():
             la.api._check(lf.L.lf_device_copy(local, buf, C.c_void_p(self.t.data_ptr()), C.c_size_t(k)), "lf_device_copy")
             return bytes(buf)
 
-    def map_shard(shard, out):
-        """one step of the product path on a device-resident shard -> SAM text in `out` (HBM, or -- gloo hook -- host)"""
+    # --inflight D: slot j > 0 has output (and, gloo hook, staging) buffers of its own (slot 0: dev_out / host_out / stage_in)
+    D = max(1, args.inflight)
+    dev_outs = [dev_out] + [torch.empty(cap_one, dtype=torch.uint8, device=dev) for _ in range(D - 1)]
+    host_outs = [host_out] + [torch.empty(cap_one * n_dev, dtype=torch.uint8, pin_memory=True) for _ in range(D - 1)]
+    stage_ins = [stage_in] + [torch.empty(read_cap, dtype=torch.uint8, device=dev) if stage_in is not None else None for _ in range(D - 1)]
+
+    def map_shard(shard, out, j=0):
+        """one step of the product path on a device-resident shard -> SAM text in `out` (HBM, or -- gloo hook -- host); j: the
+        calling thread's slot when several steps are in flight"""
         na = shard.name_array(torch)
         blob = shard.blob
         if blob.device.type == "cpu":                                   # gloo hook: what arrived in host memory is staged into HBM
-            stage_in[:shard.nbytes].copy_(blob[:shard.nbytes]); torch.cuda.current_stream().synchronize()
-            blob = stage_in
-        target = out if out.device.type == "cuda" else dev_out
+            if stage_ins[j].numel() < shard.nbytes:
+                stage_ins[j] = torch.empty(shard.nbytes + (1 << 20), dtype=torch.uint8, device=dev)
+            stage_ins[j][:shard.nbytes].copy_(blob[:shard.nbytes]); torch.cuda.current_stream().synchronize()
+            blob = stage_ins[j]
+        target = out if out.device.type == "cuda" else dev_outs[j]
         t_call = time.perf_counter()
         ln, st = lf.map_batch_dev(na, blob.data_ptr(), shard.seq_off[:-1], shard.seq_lens, target.data_ptr(), target.numel(), True, params=params)
         st["ms_python_call"] = (time.perf_counter() - t_call) * 1e3
         if target is not out:
-            out[:ln].copy_(dev_out[:ln])
+            out[:ln].copy_(target[:ln])
         return ln, st
-
-    # --inflight D: slot j > 0 has output buffers of its own (slot 0: dev_out / host_out)
-    D = max(1, args.inflight)
-    dev_outs = [dev_out] + [torch.empty(cap_one, dtype=torch.uint8, device=dev) for _ in range(D - 1)]
-    host_outs = [host_out] + [torch.empty(cap_one * n_dev, dtype=torch.uint8, pin_memory=True) for _ in range(D - 1)]
 
     def step_hbm(j=0):
         t_call = time.perf_counter()
         ln, st = lf.map_batch_dev(own_na, own.blob.data_ptr(), own.seq_off[:-1], own.seq_lens, dev_outs[j].data_ptr(), dev_outs[j].numel(), True, params=params) \
-            if (j > 0 and own.blob.device.type == "cuda") else map_shard(own, dev_outs[j])
+            if (j > 0 and own.blob.device.type == "cuda") else map_shard(own, dev_outs[j], j)
         st.setdefault("ms_python_call", (time.perf_counter() - t_call) * 1e3)
         return _Sam(dev_outs[j], ln), st
 
@@ -505,6 +543,7 @@ def main():
     #         (H2D and D2H inside the step).  N = 1: this is `value` ----
     elapsed_host = cpu_s_host = agg_host = sam_host = None
     snap_host = head_host = None
+    order = None
     if args.mode != "inproc" and not args.no_host_region:
         run_steps(step_host, max(1, args.warmup) * D)
         elapsed_host, cpu_s_host, agg_host, sam_host = timed(step_host, args.steps)
@@ -512,7 +551,13 @@ def main():
             # the records the TIMED steps wrote, before anything else runs: a digest of all of them and the head that is compared with the reference
             snap_host = digest(sam_host)
             # (the reference maps ~ 1 k reads/s on the box's cores: room for 1.5 x 1.2 k reads/s x the sample time, ~1.75 x read_len + header per record, x candidates)
-            head_host = sam_host.head(int(1.5 * args.cpu_seconds * 1200 * (1.75 * args.read_len + 600) * (1.0 + 4.0 * args.dup_frac)) + (8 << 20)) if not args.no_cpu_baseline else None
+            # the reads the reference will be timed on: a golden-ratio stride over the WHOLE batch (any prefix of the list covers every
+            # chunk and lane); their records are taken out of the timed output now, before any other pass touches the buffer
+            if not args.no_cpu_baseline:
+                order = sample_order(len(seqs), int(1.5 * args.cpu_seconds * 1200 * 15000 / max(1000, args.read_len)) + 256)
+                t_x = time.time()
+                head_host = records_of(sam_host.t.numpy(), len(sam_host), [names[i] for i in order])
+                log(f"records of {len(head_host)} sampled reads taken out of the timed output in {time.time() - t_x:.1f}s")
     elif args.mode == "inproc":
         elapsed_host, cpu_s_host, agg_host, sam_host = elapsed_nx, cpu_s_hbm, agg_hbm, sam_hbm
     primary_is_host = world * n_dev == 1 and elapsed_host is not None or args.mode == "inproc"
@@ -532,8 +577,6 @@ def main():
         wshard = lfd.make_shards(torch, wn, ws, 1, bulk)[0][0]
         wcap = int(3.0 * sum(len(x) for x in ws) * 1.1) + len(ws) * 2048 + (1 << 20)
         wout = dev_out if wcap <= dev_out.numel() else torch.empty(wcap, dtype=torch.uint8, device=dev)
-        if stage_in is not None and stage_in.numel() < wshard.nbytes:
-            stage_in = torch.empty(wshard.nbytes + (1 << 20), dtype=torch.uint8, device=dev)
         del wn, ws
         def step_weak(j=0):
             ln, st = map_shard(wshard, wout)
@@ -704,7 +747,9 @@ def main():
             out["timed_output_equals_exclusive_pass_output"] = len({v for v in snaps.values()}) == 1 if len(snaps) > 1 else None
         if not args.no_cpu_baseline and world == 1 and (head_host is not None or sam is not None):
             try:
-                cb = cpu_baseline(args, fa, names, seqs)
+                if order is None:
+                    order = sample_order(len(seqs), int(1.5 * args.cpu_seconds * 1200 * 15000 / max(1000, args.read_len)) + 256)
+                cb = cpu_baseline(args, fa, [names[i] for i in order], [seqs[i] for i in order])
             except Exception as e:                                          # noqa: BLE001
                 log("cpu baseline failed:", e)
                 cb = None
@@ -714,19 +759,23 @@ def main():
                 # same boundary on both sides: host memory -> host memory
                 out["speedup_vs_cpu_baseline"] = value / base["value"]          # vs `cpus_granted` host CPUs (not an optimisation target)
                 out["speedup_vs_cpu_baseline_hbm_resident"] = out["value_hbm_resident"] / base["value"]
-                # bit-match against the reference on the sampled reads: the sample is a prefix of the batch and records are in
-                # read order, so the head of our SAM holds the same reads.  `head_host` was copied out of the timed steps' output
-                # before any other pass ran.  Primary records (the BASELINE metric) and ALL records of a read (secondaries,
-                # supplementaries: same lines, same order) are compared.
-                head = head_host if head_host is not None else sam.head(6 * len(ref_sam) + (1 << 20))
-                out["records_compared_come_from"] = "the timed host-boundary steps (snapshot taken before the exclusive pass)" if head_host is not None else "the last pass"
+                # bit-match against the reference on the sampled reads (a stride over the whole batch).  `head_host` holds their records
+                # as the TIMED host-boundary steps wrote them (taken before any other pass ran).  Primary records (the BASELINE metric)
+                # and ALL records of a read (secondaries, supplementaries: same lines, same order) are compared.
                 def by_read(txt):
                     d = {}
                     for l in txt.split(b"\n"):
                         if l:
                             d.setdefault(l.split(b"\t", 1)[0], []).append(l)
                     return d
-                want, mine = by_read(ref_sam), by_read(head[:head.rfind(b"\n") + 1])
+                if head_host is not None:
+                    mine = head_host
+                    out["records_compared_come_from"] = "the timed host-boundary steps (taken out of their output before the exclusive pass)"
+                else:
+                    view = sam.t.numpy() if sam.t.device.type == "cpu" else np.frombuffer(sam.head(len(sam)), dtype=np.uint8)
+                    mine = records_of(view, len(sam), [names[i] for i in order[:n]])
+                    out["records_compared_come_from"] = "the last pass"
+                want = by_read(ref_sam)
                 hit = tot = hit_all = 0
                 for nm, lines in want.items():
                     got = mine.get(nm)
@@ -737,6 +786,7 @@ def main():
                     pw = [l for l in lines if not (int(l.split(b"\t")[1]) & (256 | 2048))]
                     pg = [l for l in got if not (int(l.split(b"\t")[1]) & (256 | 2048))]
                     hit += (pw == pg)
+                out["parity_sample"] = f"golden-ratio stride over all {len(seqs)} reads of the step: read indices {min(order[:n])} .. {max(order[:n])}"
                 out["primary_record_match_rate"] = hit / max(1, tot)
                 out["all_records_match_rate"] = hit_all / max(1, tot)
                 out["reads_compared"] = tot
@@ -758,28 +808,30 @@ def main():
 
     # ---- 3. N > 1: the pipelined exchange, inside the timed region ----
     if exchange:
-        px = lfd.PipelinedExchange(dist, torch, bulk, ctl, read_cap, cap_one)
+        # D steps of every rank in flight (ring of D + 1 buffers): lordfast_amd/dist.py: run_pipeline.  Rank 0's gather buffers hold a
+        # whole step's records: sized from the job's bases (a record is ~1.7 x its read; cap_one's generous per-rank bound x world x
+        # ring would not fit beside the index under weak scaling)
+        job_bases = sum(sh.bases() for sh in job_shards) if rank == 0 else 0
+        gcap = int(2.2 * (1.0 + 4.0 * args.dup_frac) * job_bases) + n_total * 1024 + (64 << 20) if rank == 0 else None
+        px = lfd.PipelinedExchange(dist, torch, bulk, ctl, read_cap, cap_one, ring=D + 1, gather_cap=gcap)
         state = {"done": False}
+        from concurrent.futures import ThreadPoolExecutor
+        xpool = ThreadPoolExecutor(D)
+        xagg = {}
+        xlock = threading.Lock()
+
+        def map_step(k, shard, out, j):
+            ln, st = map_shard(shard, out, j)
+            with xlock:
+                xagg["st"] = add(xagg.get("st"), st)
+            return ln
 
         def run_exchange(n_steps):
-            """step k: post (reads k + 1 out, SAM k - 1 back) -> map k -> complete.  -> length of the last step's gathered text"""
-            cur = job_shards[0] if rank == 0 else None
-            if rank == 0:                                                # scatter of step 0: exposed
-                px.post(-1, next_shards=job_shards)
-            else:
-                px.post(-1, next_shards=True)
-            px.complete()
-            prev_len, st_agg = None, None
-            for k in range(n_steps):
-                more = k + 1 < n_steps
-                px.post(k, next_shards=(job_shards if rank == 0 else True) if more else None, prev_own_len=prev_len)
-                shard = cur if rank == 0 else px.rx_shard[k & 1]
-                prev_len, st = map_shard(shard, px.sam[k & 1])
-                st_agg = add(st_agg, st)
-                px.complete()
-            px.post(n_steps, next_shards=None, prev_own_len=prev_len)   # gather of the last step: exposed
-            px.complete()
-            return st_agg
+            """EXACTLY n_steps steps, D of them in flight on every rank; reads of step t + 1 go out and records of step t - D come back
+            as one grouped RCCL call per tick; the first scatter and the last gather are exposed"""
+            xagg.pop("st", None)
+            lfd.run_pipeline(px, n_steps, D, (lambda k: job_shards), map_step, pool=xpool)
+            return xagg.get("st")
 
         def watchdog():
             if not state["done"]:
@@ -791,7 +843,8 @@ def main():
         timer = threading.Timer(args.exchange_timeout, watchdog)
         timer.daemon = True
         timer.start()
-        run_exchange(1)                                                   # warm-up: buffers grow, RCCL connects its peers
+        x_warm = max(1, args.warmup) * D
+        run_exchange(x_warm)                                              # warm-up: buffers grow (every slot in flight), RCCL connects its peers
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -807,9 +860,10 @@ def main():
         if rank == 0:
             gt, glen = px.gathered(args.steps - 1)
             sam = _Sam(gt, glen)                                          # the whole job's records, input order
-            xinfo = dict(status="ok", transport=backend, bulk_memory=str(bulk), GB_out_per_step=px.bytes_out / (args.steps + 1) / 1e9,
-                         GB_in_per_step=px.bytes_in / (args.steps + 1) / 1e9, gathered_bytes_last_step=glen,
-                         pipeline="reads of step k+1 and SAM of step k-1 in flight while step k maps; first scatter and last gather exposed")
+            xinfo = dict(status="ok", transport=backend, bulk_memory=str(bulk), GB_out_per_step=px.bytes_out / (args.steps + x_warm) / 1e9,
+                         GB_in_per_step=px.bytes_in / (args.steps + x_warm) / 1e9, gathered_bytes_last_step=glen,
+                         steps_in_flight_per_rank=D,
+                         pipeline=f"{D} step(s) of every rank in flight; reads of step t+1 and SAM of step t-{D} travel (one grouped call per tick) while they map; first scatter and last gather exposed")
 
     if rank == 0:
         report(elapsed, sam, xinfo)

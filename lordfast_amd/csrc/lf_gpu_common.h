@@ -32,7 +32,56 @@ struct lf_dev_index {
     const uint64_t *cache16;    /* 4^16 x (beg,end), or NULL (68.7 GB; genomes >= 2^30 symbols when HBM allows): a sample whose 16-mer occurs starts
                                  * there -- four search steps saved; one whose 16-mer does not occur falls back to the narrower table */
     const uint8_t  *pac;
+    const uint8_t  *occ2;       /* the BWT in the HBM layout of the mapping kernels (lf_occ2_* below): made IN PLACE out of `bwt` once the
+                                 * tables and the full SA are built (bwt is NULL from then on); NULL while the index is being built */
 };
+
+/* ---- the occurrence blocks as the mapping kernels read them (not bwa's file layout: nothing requires the resident form to equal
+ * the one on disk).  64 bytes per 128 symbols, one HBM burst:
+ *     u64 C[4]    CUMULATIVE counts in front of the block: C[j] = occurrences of symbols 0 .. j  (count of a = C[a] - C[a-1], of everything
+ *                 above a = C[3] - C[a]: a lane fetches the two words its symbol needs instead of four and selecting)
+ *     u64 lo[2]   bit i & 63 of word i >> 6 = low code bit of symbol i of the block
+ *     u64 hi[2]   ... high code bit
+ * "symbol == a" is (lo ^ ~A0) & (hi ^ ~A1), "symbol > a" is (hi & ~A1) | ((hi ^ ~A1) & lo & ~A0) with A0 / A1 = a's bits spread over a
+ * word: two masks for 128 symbols in 12 word operations, against eight 16-symbol words with interleaved bits before; the symbols
+ * in front of a row are the low bits of a 128-bit mask.  lib/bwa/bwt.h:72-73 (file layout), lib/bwa/bwt.c:98-163 (bwt_occ / bwt_2occ). ---- */
+struct lf_occ2_masks { uint64_t e0, e1, g0, g1; };
+__device__ __forceinline__ lf_occ2_masks lf_occ2_eq_gt(uint64_t lo0, uint64_t lo1, uint64_t hi0, uint64_t hi1, int a)
+{
+    const uint64_t nA0 = (a & 1) ? 0ull : ~0ull, nA1 = (a & 2) ? 0ull : ~0ull;
+    lf_occ2_masks M;
+    const uint64_t t0 = hi0 ^ nA1, t1 = hi1 ^ nA1;                 /* high bit equal */
+    M.e0 = (lo0 ^ nA0) & t0; M.e1 = (lo1 ^ nA0) & t1;
+    M.g0 = (hi0 & nA1) | (t0 & lo0 & nA0); M.g1 = (hi1 & nA1) | (t1 & lo1 & nA0);
+    return M;
+}
+/* the first rem symbols of a block as a 128-bit mask, 1 <= rem <= 128 */
+__device__ __forceinline__ void lf_occ2_first(uint32_t rem, uint64_t &m0, uint64_t &m1)
+{
+    m0 = rem >= 64u ? ~0ull : ((1ull << (rem & 63u)) - 1ull);
+    m1 = rem <= 64u ? 0ull : (rem >= 128u ? ~0ull : ((1ull << ((rem - 64u) & 63u)) - 1ull));
+}
+/* bwt_occ on the resident layout (one symbol; the locate walk of the sampled-SA variant) */
+__device__ __forceinline__ uint64_t lf_occ2(const lf_dev_index &ix, uint64_t k, int c)
+{
+    if (k == ix.seq_len) return ix.L2[c + 1] - ix.L2[c];
+    if (k == ~0ull) return 0;
+    k -= (k >= ix.primary);
+    const uint64_t *blk = reinterpret_cast<const uint64_t *>(ix.occ2 + ((k >> 7) << 6));
+    const uint64_t n = blk[c] - (c ? blk[c - 1] : 0ull);
+    const lf_occ2_masks M = lf_occ2_eq_gt(blk[4], blk[5], blk[6], blk[7], c);
+    uint64_t m0, m1; lf_occ2_first((uint32_t)(k & 127) + 1u, m0, m1);
+    return n + (uint64_t)__popcll(M.e0 & m0) + (uint64_t)__popcll(M.e1 & m1);
+}
+__device__ __forceinline__ uint64_t lf_inv_psi2(const lf_dev_index &ix, uint64_t k)
+{
+    if (k == ix.primary) return 0;
+    const uint64_t x = k - (k > ix.primary);
+    const uint64_t *blk = reinterpret_cast<const uint64_t *>(ix.occ2 + ((x >> 7) << 6));
+    const uint32_t i = (uint32_t)(x & 127);
+    const int c = (int)(((blk[4 + (i >> 6)] >> (i & 63)) & 1ull) | (((blk[6 + (i >> 6)] >> (i & 63)) & 1ull) << 1));
+    return ix.L2[c] + lf_occ2(ix, k, c);
+}
 
 struct lf_dev_state {           /* host-side owner of the device allocations */
     lf_dev_index view;
@@ -208,7 +257,8 @@ __device__ __forceinline__ uint64_t lf_inv_psi(const lf_dev_index &ix, uint64_t 
 __device__ __forceinline__ uint64_t lf_sa_walk(const lf_dev_index &ix, uint64_t k, uint32_t &steps)
 {
     uint64_t off = 0;
-    while (k & 31) { ++off; k = lf_inv_psi(ix, k); }
+    if (ix.occ2) while (k & 31) { ++off; k = lf_inv_psi2(ix, k); }      /* the resident layout (mapping); bwa's file layout while an index is built */
+    else while (k & 31) { ++off; k = lf_inv_psi(ix, k); }
     steps += (uint32_t)off;
     return off + ix.sa_sampled[k >> 5];
 }

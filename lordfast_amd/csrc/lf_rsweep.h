@@ -13,7 +13,8 @@ struct lf_rsw_args {
 };
 /* words of ONE plane for a buffer of n bytes (three planes follow each other) */
 static inline uint64_t lf_plane_words(uint64_t n_bytes) { return (n_bytes + 63) / 64 + 2; }
-void lf_rsweep_pack_planes(hipStream_t s, const unsigned char *d_src, uint64_t n_bytes, uint64_t *d_planes, uint64_t n_words);
+/* lower_flag (optional): set to non-zero when the bytes hold a lower-case a / c / g / t (seeding accepts those, the planes do not) */
+void lf_rsweep_pack_planes(hipStream_t s, const unsigned char *d_src, uint64_t n_bytes, uint64_t *d_planes, uint64_t n_words, unsigned long long *lower_flag = nullptr);
 void lf_rsweep_pack_pac(hipStream_t s, const unsigned char *d_src, uint64_t n_bytes, uint8_t *d_pac);
 void lf_rsweep_launch(hipStream_t s, bool track, lf_rsw_args A);
 #endif

@@ -30,11 +30,13 @@
 
 /* ---- read batch -> bit planes: bit i of word (i >> 6) describes base i.  A wavefront transposes 64 x 64 bases through ballots. ---- */
 __global__ void __launch_bounds__(256)
-lf_pack_planes_kernel(const unsigned char *__restrict__ src, uint64_t n, uint64_t *__restrict__ lo, uint64_t *__restrict__ hi, uint64_t *__restrict__ valid, uint64_t n_words)
+lf_pack_planes_kernel(const unsigned char *__restrict__ src, uint64_t n, uint64_t *__restrict__ lo, uint64_t *__restrict__ hi, uint64_t *__restrict__ valid, uint64_t n_words,
+                      unsigned long long *__restrict__ lower_flag)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t w0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;                 /* first of this wavefront's 64 words */
     uint64_t mlo = 0, mhi = 0, mv = 0;
+    bool lower = false;
     /* eight rows of 64 bases are requested together (their latency is paid once per eight), then balloted */
     for (int i0 = 0; i0 < 64; i0 += 8) {
         unsigned char ch[8];
@@ -43,12 +45,14 @@ lf_pack_planes_kernel(const unsigned char *__restrict__ src, uint64_t n, uint64_
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             bool ok; const uint32_t cd = lf_code_upper(ch[u], ok);
+            { bool okl; (void)lf_code_upper((uint32_t)ch[u] & 0xDFu, okl); lower = lower || (okl && !ok); }
             const uint64_t bl = lf_ballot(ok && (cd & 1u)), bh = lf_ballot(ok && (cd & 2u)), bv = lf_ballot(ok);
             if (lane == i0 + u) { mlo = bl; mhi = bh; mv = bv; }
         }
     }
     const uint64_t w = w0 + (uint64_t)lane;
     if (w < n_words) { lo[w] = mlo; hi[w] = mhi; valid[w] = mv; }
+    if (lower_flag != nullptr && lf_any(lower) && lane == 0) atomicOr(lower_flag, 1ull);
 }
 
 /* byte targets of the stage API -> the reference's 2-bit layout (four symbols per byte, first symbol in the top bits,
@@ -194,10 +198,10 @@ lf_edlib_rsweep_kernel(lf_rsw_args A)
     }
 }
 
-void lf_rsweep_pack_planes(hipStream_t s, const unsigned char *d_src, uint64_t n_bytes, uint64_t *d_planes, uint64_t n_words)
+void lf_rsweep_pack_planes(hipStream_t s, const unsigned char *d_src, uint64_t n_bytes, uint64_t *d_planes, uint64_t n_words, unsigned long long *lower_flag)
 {
     if (!n_words) return;
-    hipLaunchKernelGGL(lf_pack_planes_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, d_src, n_bytes, d_planes, d_planes + n_words, d_planes + 2 * n_words, n_words);
+    hipLaunchKernelGGL(lf_pack_planes_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, d_src, n_bytes, d_planes, d_planes + n_words, d_planes + 2 * n_words, n_words, lower_flag);
 }
 void lf_rsweep_pack_pac(hipStream_t s, const unsigned char *d_src, uint64_t n_bytes, uint8_t *d_pac)
 {

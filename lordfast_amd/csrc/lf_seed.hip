@@ -22,6 +22,7 @@
 #include "lf_scan.h"
 
 /* ---------------------------------------------------------------- index residency */
+__global__ void lf_occ2_convert_kernel(uint32_t *__restrict__ bwt, uint64_t n_blocks);
 
 /* src/BWT.cpp:60-115 -- one level of the 12-mer table: child (4i+j) = j prepended to k-mer i */
 __global__ void lf_cache_level_kernel(lf_dev_index ix, const uint64_t *__restrict__ parent, uint64_t *__restrict__ child, uint32_t n_parent)
@@ -192,6 +193,13 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
         HIPCHK(hipStreamSynchronize(st->stream));
         v.sa_full = (const uint64_t *)st->sa_full;
     }
+    {   /* everything that reads bwa's file layout is built: the blocks take the form the mapping kernels read (in place) */
+        const uint64_t n_blocks = (ix->seq_len + 127) >> 7;
+        if ((n_blocks << 4) * 4 > bwt_bytes + 256) { lf_set_error("BWT array shorter than its %llu occurrence blocks", (unsigned long long)n_blocks); return LF_ERR_ARG; }
+        hipLaunchKernelGGL(lf_occ2_convert_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st->stream, (uint32_t *)st->bwt, n_blocks);
+        HIPCHK(hipStreamSynchronize(st->stream));
+        v.occ2 = (const uint8_t *)st->bwt; v.bwt = nullptr;
+    }
     HIPCHK(hipGetLastError());
     return LF_OK;
 }
@@ -224,7 +232,7 @@ extern "C" int lfg_index_describe(const struct lf_index *ix, char *buf, size_t c
     const lf_dev_state *st = (const lf_dev_state *)ix->dev;
     if (!st || !buf || cap < 2) return LF_ERR_ARG;
     const double GB = 1e9;
-    int o = snprintf(buf, cap, "BWT + Occ %.2f GB; ", ix->bwt_size * 4 / GB);
+    int o = snprintf(buf, cap, "BWT + Occ %.2f GB (64-byte blocks: cumulative counts + two bit planes of 128 symbols); ", ix->bwt_size * 4 / GB);
     if (st->sa_full) o += snprintf(buf + o, o < (int)cap ? cap - o : 0, "full suffix array (u64 per row) %.1f GB; ", (ix->seq_len + 1) * 8 / GB);
     o += snprintf(buf + o, o < (int)cap ? cap - o : 0, "sampled suffix array (every 32nd row) %.2f GB; k-mer tables: 12 (%.2f GB)", ix->n_sa * 8 / GB, (double)(1ull << 24) * 16 / GB);
     if (st->cache14) o += snprintf(buf + o, o < (int)cap ? cap - o : 0, ", 14 (%.1f GB)", (double)(1ull << 28) * 16 / GB);
@@ -253,182 +261,267 @@ __global__ void lf_seed_pos_kernel(int n_reads, const uint64_t *__restrict__ off
     }
 }
 
-struct lf_sample_t { uint64_t sp; uint32_t occ; uint32_t m; };
+struct lf_sample_t { uint64_t sp; uint32_t occ; uint32_t m; };   /* occ saturates at 2^32-1; m = 0: no seed */
 
-/* One Occ block for the bidirectional step: Occ(k, a) and the sum of Occ(k, j) over j > a, branch-free.  The block is loaded
- * whole (4 x 16 B, all in flight together with the other row's block); rows -1 and seq_len are special (bwt_occ4,
- * lib/bwa/bwt.c:169-186) and read block 0 for nothing.  Per 16-symbol word: the low / high bit planes on the even bits, one
- * mask for "== a", one for "> a", one keep mask for the symbols in front of the row. */
-struct lf_occ_blk { ulonglong2 h01, h23; uint4 s0, s1; };
-__device__ __forceinline__ const uint32_t *lf_occ_addr(const lf_dev_index &ix, uint64_t k, bool &none, bool &all, int &rem)
+/* the resident form of the occurrence blocks (lf_gpu_common.h: lf_occ2_*), made in place out of bwa's file layout once the
+ * k-mer tables and the full suffix array are built: a thread owns one 64-byte block */
+__global__ void lf_occ2_convert_kernel(uint32_t *__restrict__ bwt, uint64_t n_blocks)
 {
-    none = k == ~0ull; all = k == ix.seq_len;
-    const uint64_t kk = (none || all) ? 0ull : k - (k >= ix.primary ? 1ull : 0ull);
-    rem = (int)(kk & 127) + 1;
-    return ix.bwt + ((kk >> 7) << 4);
-}
-__device__ __forceinline__ lf_occ_blk lf_occ_load(const uint32_t *blk)
-{
-    lf_occ_blk B;
-    B.h01 = *reinterpret_cast<const ulonglong2 *>(blk); B.h23 = *reinterpret_cast<const ulonglong2 *>(blk + 4);
-    B.s0 = *reinterpret_cast<const uint4 *>(blk + 8); B.s1 = *reinterpret_cast<const uint4 *>(blk + 12);
-    return B;
-}
-__device__ __forceinline__ void lf_occ_eq_gt(const lf_dev_index &ix, const lf_occ_blk &B, int a, bool none, bool all, int rem, uint64_t &eq, uint64_t &gt)
-{
-    const uint32_t M5 = 0x55555555u;
-    const uint32_t a0n = (a & 1) ? 0u : M5, a1n = (a & 2) ? 0u : M5;        /* flip masks: bit set where the plane equals a's bit */
-    const uint32_t na0 = (a & 1) ? 0u : ~0u, na1 = (a & 2) ? 0u : ~0u;      /* a's bit is 0: the plane may be greater */
-    uint32_t ce = 0, cg = 0;
-    const uint32_t w[8] = { B.s0.x, B.s0.y, B.s0.z, B.s0.w, B.s1.x, B.s1.y, B.s1.z, B.s1.w };
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int r = rem - 16 * i;                                         /* symbols of this word in front of (and at) the row */
-        const uint32_t keep = r >= 16 ? ~0u : (r <= 0 ? 0u : (~0u << (32 - 2 * r)));      /* symbols are MSB first */
-        const uint32_t lp = w[i] & M5, hp = (w[i] >> 1) & M5;
-        const uint32_t t1 = hp ^ a1n;                                       /* high bit equal */
-        const uint32_t e = (lp ^ a0n) & t1;
-        const uint32_t g = (hp & na1) | (t1 & lp & na0);
-        ce += (uint32_t)__popc(e & keep); cg += (uint32_t)__popc(g & keep);
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    uint32_t *blk = bwt + (b << 4);
+    uint64_t c[4]; uint32_t w[8];
+    for (int j = 0; j < 4; j++) c[j] = reinterpret_cast<const uint64_t *>(blk)[j];
+    for (int j = 0; j < 8; j++) w[j] = blk[8 + j];
+    uint64_t lo[2] = { 0, 0 }, hi[2] = { 0, 0 };
+    for (int i = 0; i < 128; i++) {
+        const uint32_t sym = (w[i >> 4] >> ((~(uint32_t)i & 15u) << 1)) & 3u;       /* 16 symbols per word, first one in the top bits (lib/bwa/bwt.h:78) */
+        lo[i >> 6] |= (uint64_t)(sym & 1u) << (i & 63); hi[i >> 6] |= (uint64_t)(sym >> 1) << (i & 63);
     }
-    const uint64_t c0 = B.h01.x, c1 = B.h01.y, c2 = B.h23.x, c3 = B.h23.y;
-    uint64_t he = a == 0 ? c0 : a == 1 ? c1 : a == 2 ? c2 : c3;
-    uint64_t hg = (a < 3 ? c3 : 0ull) + (a < 2 ? c2 : 0ull) + (a < 1 ? c1 : 0ull);
-    eq = he + ce; gt = hg + cg;
-    if (all) { eq = ix.L2[a + 1] - ix.L2[a]; gt = ix.L2[4] - ix.L2[a + 1]; }
-    if (none) { eq = 0; gt = 0; }
+    uint64_t *o = reinterpret_cast<uint64_t *>(blk);
+    o[0] = c[0]; o[1] = c[0] + c[1]; o[2] = c[0] + c[1] + c[2]; o[3] = c[0] + c[1] + c[2] + c[3];
+    o[4] = lo[0]; o[5] = lo[1]; o[6] = hi[0]; o[7] = hi[1];
 }
-   /* occ saturates at 2^32-1; m = 0: no seed */
 
-/* Maximal exact match of every (read, sample) starting at its sample position, >= k long.
- * Match lengths are very uneven (a sample inside an error-free stretch extends for dozens of steps, most stop after a
- * few), so a lane is not tied to one sample: a wavefront owns LF_SEARCH_SPAN consecutive samples and every lane that
- * finishes its sample takes the next unassigned one (ballot + prefix count on a wave-uniform cursor).  The wave's trip
- * count is then the SUM of the chain lengths / 64 instead of 64 x the longest chain. */
-#define LF_SEARCH_SPAN 512
-__global__ void __launch_bounds__(256)
-lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ reads, const uint64_t *__restrict__ off,
-                      uint32_t hash_count, int kmin, const uint32_t *__restrict__ pos, lf_sample_t *__restrict__ out,
-                      unsigned long long *__restrict__ counters)
+/* bit j of x -> bit 2 j (16 digits of a table index) */
+__device__ __forceinline__ uint32_t lf_spread16(uint32_t x)
 {
-    const size_t total = (size_t)n_reads * hash_count;
-    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+/* Maximal exact match of every (read, sample) starting at its sample position, >= k long (bwt_count_exact_cached restarted per
+ * length in the reference, src/BWT.cpp:330-342; here ONE bidirectional pass, see DESIGN.md "seed search formulation").
+ *
+ * The kernel is a stream of DEPENDENT random 64-byte reads: table entry -> occurrence block -> occurrence block ..., two to
+ * four per sample, each a row activation somewhere in 70 GB.  What it can reach is set by how many of them are in flight, so
+ *   - a lane runs S searches at once (S slots; their loads are issued together, then awaited together), and a slot whose search
+ *     ends takes the wavefront's next sample (match lengths are very uneven: ballot + prefix count on a wave-uniform cursor);
+ *   - a trip costs every slot exactly ONE block: a step whose two rows (k - 1 and l of lib/bwa/bwt.c:132-139) lie in different
+ *     blocks -- a few per cent of the steps -- is done in two trips (first row's counts parked in the slot), so that no wavefront
+ *     ever executes a second, mostly idle, instruction stream for them;
+ *   - the bases come from the batch's bit planes (three unaligned 8-byte windows = 56 bases: table index by bit tricks, the next
+ *     32 codes in two registers) instead of 24 byte loads and 24 classifications; batches with lower-case bases (which the
+ *     reference's nst_nt4_table accepts and the planes do not) take the byte variant (PLANES = false);
+ *   - a block holds cumulative counts and two bit planes (lf_occ2_*): counts of "== a" and "> a" in front of both rows are three
+ *     masked popcounts of 128-bit masks.
+ * A wavefront owns the samples of `rpw` whole reads (no division per sample when rpw <= 2). */
+#define LF_SEARCH_MIN_SPAN 1024
+template <int S, bool PLANES>
+__global__ void __launch_bounds__(256)
+lf_seed_search_kernel(lf_dev_index ix, int n_reads, const char *__restrict__ reads, const uint64_t *__restrict__ planes, int64_t q_words,
+                      const uint64_t *__restrict__ off, uint32_t hash_count, uint32_t rpw, int kmin, const uint32_t *__restrict__ pos,
+                      lf_sample_t *__restrict__ out, unsigned long long *__restrict__ counters)
+{
+    const uint32_t wave = (uint32_t)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    size_t nxt = wave * LF_SEARCH_SPAN;
-    const size_t end = nxt + LF_SEARCH_SPAN < total ? nxt + LF_SEARCH_SPAN : total;
+    const uint32_t r0 = wave * rpw;
     uint32_t n_cache = 0, n_blk = 0;
-    /* table width W: 14 when the wide table exists and -k >= 14 (a match shorter than k is dropped anyway, so nothing
-     * is lost by starting at 14), else the reference's 12 */
+    const bool lower = counters[4] != 0ull;              /* the batch holds lower-case acgt (lf_pack_planes_kernel / the host's exception list) */
+    if (r0 < (uint32_t)n_reads && lower != PLANES) {
+    const uint32_t r1 = r0 + rpw < (uint32_t)n_reads ? r0 + rpw : (uint32_t)n_reads;
+    uint32_t nxt = r0 * hash_count; const uint32_t first = nxt, end = r1 * hash_count;
+    /* table width W: 14 when the wide table exists and -k >= 14 (a match shorter than k is dropped anyway), else the reference's 12 */
     const bool wide = ix.cache14 != nullptr && kmin >= 14;
     const uint32_t W = wide ? 14u : 12u;
-    const uint64_t *__restrict__ tab = wide ? ix.cache14 : ix.cache;
+    const uint64_t *__restrict__ tabW = wide ? ix.cache14 : ix.cache;
+    const uint64_t *__restrict__ plo = planes, *__restrict__ phi = planes + q_words, *__restrict__ pva = planes + 2 * q_words;
+    /* the first bases of the wavefront's (first three) reads */
+    const uint64_t offa = off[r0], offb = off[r0 + 1 <= (uint32_t)n_reads ? r0 + 1 : (uint32_t)n_reads], offc = off[r0 + 2 <= (uint32_t)n_reads ? r0 + 2 : (uint32_t)n_reads];
+    const float inv_hc = 1.0f / (float)hash_count;
 
-    bool active = false;                      /* this lane is in the middle of a sample */
-    size_t gid = 0; const unsigned char *q = nullptr; uint32_t p = 0, qLen = 0, m = 0;
-    uint64_t x0 = 0, x1 = 0, sz = 0;
-    uint32_t ahead = 0;                       /* codes of the bases at offsets 12 .. 23 (2 bits each), bits 24 .. 27: how many are usable */
+    /* slot state.  ph: 0 idle | 1 table entry of the 16-mer wanted | 3 of the W-mer | 2 stepping | 4 code window used up, next one wanted |
+     * 5 second half of a step across two blocks (bits 8..14 row's place in the block, 16..17 symbol, 18 bit 32 of the parked count,
+     * 19 the step moves x0 past the sentinel row) */
+    uint32_t ph[S], m[S], rlen[S], gidx[S], alo[S], ahi[S], aw[S], tix[S], gks[S];
+    uint64_t P[S], x0[S], x1[S], sz[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) { ph[s] = 0; m[s] = 0; rlen[s] = 0; gidx[s] = 0; alo[s] = 0; ahi[s] = 0; aw[s] = 0; tix[s] = 0; gks[s] = 0; P[s] = 0; x0[s] = 0; x1[s] = 0; sz[s] = 0; }
+
     for (;;) {
-        const uint64_t idle = lf_ballot(!active);
-        if (idle && nxt < end) {
-            const size_t cand = nxt + (size_t)__popcll(idle & below);
-            if (!active && cand < end) {
-                /* Bidirectional search (the index holds forward + reverse-complement text, like bwa mem's SMEM search):
-                 * (x0, x1, s) = first row of P = q[p..p+m), first row of revcomp(P), interval size.  Start from the two
-                 * table entries, then append one base at a time while P still occurs: the maximal m AND the exact rows
-                 * of P come out of the same pass.  Table index: base-4 number with the LAST character of the pattern
-                 * most significant (src/BWT.cpp:270-277); pattern P_W = q[p..p+W), and revcomp(P_W) whose last W
-                 * characters are comp(q[p+W-1..p]) */
-                gid = cand;
-                const int r = (int)(gid / hash_count);
-                const uint32_t i = (uint32_t)(gid % hash_count);
-                qLen = (uint32_t)(off[r + 1] - off[r]);
-                q = reinterpret_cast<const unsigned char *>(reads) + off[r];
-                p = pos[gid];                              /* pos_by_sample layout */
-                lf_sample_t res; res.sp = 0; res.occ = 0; res.m = 0;
-                bool started = false;
-                if ((uint64_t)p + (uint64_t)kmin <= qLen) {
-                    /* the first 16 bases in two (unaligned) 8-byte loads; the batch buffer has 64 bytes of slack */
-                    /* ... and the next eight in a third: the bases at offsets 12 .. 23 stay in ONE register as 2-bit codes + the
-                     * number of usable ones in front of the first base outside ACGT / the end of the read, so that the first
-                     * extension steps do not start with a dependent byte load */
-                    uint64_t w0, w1, w2;
-                    __builtin_memcpy(&w0, q + p, 8); __builtin_memcpy(&w1, q + p + 8, 8); __builtin_memcpy(&w2, q + p + 16, 8);
-                    int cd[24]; uint32_t bad = 0;
+        /* ---- (1) idle slots take the wavefront's next samples; the code windows of new and of exhausted slots are asked for ---- */
+        uint64_t wl[S], wh[S], wv[S]; uint32_t wsh[S]; bool win[S];
 #pragma unroll
-                    for (int t = 0; t < 24; t++) { cd[t] = lf_nt4((unsigned char)((t < 8 ? w0 >> (8 * t) : t < 16 ? w1 >> (8 * (t - 8)) : w2 >> (8 * (t - 16))) & 0xff)); bad |= (cd[t] > 3 ? 1u : 0u) << t; }
-                    {
-                        uint32_t codes = 0;
+        for (int s = 0; s < S; s++) {
+            win[s] = ph[s] == 4u; wl[s] = wh[s] = wv[s] = 0; wsh[s] = 0;
+            const uint64_t idle = lf_ballot(ph[s] == 0u);
+            if (idle && nxt < end) {
+                const uint32_t cand = nxt + (uint32_t)__popcll(idle & below);
+                if (ph[s] == 0u && cand < end) {
+                    const uint32_t local = cand - first;
+                    uint32_t rr;
+                    if (rpw <= 2u) rr = local >= hash_count ? 1u : 0u;
+                    else { rr = (uint32_t)((float)local * inv_hc); const int rem = (int)(local - rr * hash_count); rr = rem < 0 ? rr - 1u : (rem >= (int)hash_count ? rr + 1u : rr); }
+                    uint64_t ob, oe;
+                    if (rpw <= 2u) { ob = rr ? offb : offa; oe = rr ? offc : offb; } else { ob = off[r0 + rr]; oe = off[r0 + rr + 1]; }
+                    const uint32_t p = pos[cand];
+                    gidx[s] = cand; P[s] = ob + p; m[s] = 0;
+                    const uint32_t qLen = (uint32_t)(oe - ob);
+                    rlen[s] = qLen > p ? qLen - p : 0u;
+                    ph[s] = 1u; win[s] = true;
+                }
+                nxt += (uint32_t)__popcll(idle); nxt = nxt > end ? end : nxt;
+            }
+            if (win[s]) {
+                const uint64_t bitpos = P[s] + m[s];
+                if (PLANES) {
+                    const uint64_t by = bitpos >> 3; wsh[s] = (uint32_t)(bitpos & 7);
+                    __builtin_memcpy(&wl[s], reinterpret_cast<const char *>(plo) + by, 8); __builtin_memcpy(&wh[s], reinterpret_cast<const char *>(phi) + by, 8);
+                    __builtin_memcpy(&wv[s], reinterpret_cast<const char *>(pva) + by, 8);
+                } else {      /* bytes: 24 of them (the batch buffer has 64 bytes of slack) */
+                    __builtin_memcpy(&wl[s], reads + bitpos, 8); __builtin_memcpy(&wh[s], reads + bitpos + 8, 8); __builtin_memcpy(&wv[s], reads + bitpos + 16, 8);
+                }
+            }
+        }
+        /* ---- (2) stepping slots: the next base and the block of this trip ---- */
+        uint32_t bidx[S], rA[S], rB[S], sym[S]; bool go[S];
 #pragma unroll
-                        for (int t = 12; t < 24; t++) codes |= (uint32_t)(cd[t] & 3) << (2 * (t - 12));
-                        const uint32_t inread = qLen - p > 12u ? (qLen - p - 12u < 12u ? qLen - p - 12u : 12u) : 0u;      /* bases of the read at offsets >= 12 (of 12) */
-                        const uint32_t badhi = (bad >> 12) | (1u << 12);
-                        uint32_t lead = (uint32_t)__ffs((int)badhi) - 1u;                      /* usable bases in front of the first bad one */
-                        if (lead > inread) lead = inread;
-                        ahead = codes | (lead << 24);
+        for (int s = 0; s < S; s++) {
+            go[s] = false; bidx[s] = 0; rA[s] = 0; rB[s] = 1; sym[s] = 0;
+            if (ph[s] == 2u) {
+                const uint32_t ab = aw[s] & 0xffffffu, an = (aw[s] >> 24) & 63u, i = m[s] - ab;
+                if (i < an) {
+                    const uint32_t c = ((alo[s] >> i) & 1u) | (((ahi[s] >> i) & 1u) << 1);
+                    const uint32_t a = 3u - c;                                   /* symbol prepended on the complement strand */
+                    /* bwt_extend, is_back = 0 (lib/bwa/bwt.c:262-275): one backward step on x1 with the counts of rows x1 - 1 and x1 - 1 + s */
+                    const uint64_t km = x1[s] - 1, l = km + sz[s];
+                    const uint64_t kk = km - (km >= ix.primary ? 1ull : 0ull), ll = l - (l >= ix.primary ? 1ull : 0ull);
+                    const uint32_t bK = (uint32_t)(kk >> 7), bL = (uint32_t)(ll >> 7), remK = (uint32_t)(kk & 127) + 1u, remL = (uint32_t)(ll & 127) + 1u;
+                    sym[s] = a; bidx[s] = bK; go[s] = true;
+                    if (bK == bL) { rA[s] = remK; rB[s] = remL; n_blk += 1u; }
+                    else {
+                        /* two blocks: this trip the first row's counts, the next trip the second row's (touches counted like bwt_2occ) */
+                        rA[s] = 0; rB[s] = remK; n_blk += 2u;
+                        tix[s] = bL;
+                        const uint32_t sent = (x1[s] <= ix.primary && x1[s] + sz[s] - 1 >= ix.primary) ? 1u : 0u;
+                        ph[s] = 6u | ((remL - 1u) << 8) | (a << 16) | (sent << 19);      /* 6: first half (this trip); becomes 5 */
                     }
-                    /* table index of revcomp(P_W): base-4 number whose digit W - 1 - t is the complement of P's character t (the LAST
-                     * character of a pattern is the most significant digit, src/BWT.cpp:270-277).  Its packed entry holds the
-                     * rows of revcomp(P_W), their number and the first row of P_W itself: one 16-byte load per start */
-                    auto idx_of = [&](int Wd) {
-                        uint32_t idc = 0;
+                } else if (aw[s] >> 31) ph[s] = 4u;                              /* window used up, the read goes on: fetch the next 32 codes */
+                else ph[s] = 7u;                                                  /* no further base: the search ends (written in (4)) */
+            } else if ((ph[s] & 255u) == 5u) {
+                go[s] = true; bidx[s] = tix[s]; rA[s] = 0; rB[s] = ((ph[s] >> 8) & 127u) + 1u; sym[s] = (ph[s] >> 16) & 3u;
+            }
+        }
+        ulonglong2 hd[S], blo[S], bhi[S]; uint64_t c3[S];
 #pragma unroll
-                        for (int t = 0; t < 16; t++) if (t < Wd) idc = idc * 4 + (uint32_t)(3 - cd[t]);
-                        return idc;
-                    };
-                    auto take = [&](const uint64_t *__restrict__ T, uint32_t idc, uint32_t Wd) {
-                        n_cache += 1;
-                        const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(T + 2 * (size_t)idc);
-                        const uint64_t size = (e.x >> 33) | ((e.y >> 33) << 31);
-                        if (size != 0) { x1 = e.x & LF_M33; x0 = e.y & LF_M33; sz = size; m = Wd; started = true; }
-                    };
-                    /* widest table first: a 16-mer that occurs starts the search at m = 16 (nothing shorter than kmin is wanted,
-                     * and a sample that reaches 16 would have passed through every shorter length with a non-empty interval) */
-                    if (ix.cache16 != nullptr && (uint64_t)p + 16 <= qLen && (bad & 0xffffu) == 0) take(ix.cache16, idx_of(16), 16u);
-                    if (!started && (bad & ((1u << W) - 1)) == 0) take(tab, idx_of((int)W), W);
-                }
-                if (started) active = true; else out[gid] = res;
+        for (int s = 0; s < S; s++) {
+            hd[s] = make_ulonglong2(0, 0); blo[s] = hd[s]; bhi[s] = hd[s]; c3[s] = 0;
+            if (go[s]) {
+                const uint8_t *blk = ix.occ2 + ((uint64_t)bidx[s] << 6);
+                hd[s] = *reinterpret_cast<const ulonglong2 *>(blk + 8u * (sym[s] ? sym[s] - 1u : 0u));      /* (C[a-1], C[a]); a = 0: (C[0], C[1]) */
+                c3[s] = *reinterpret_cast<const uint64_t *>(blk + 24);
+                blo[s] = *reinterpret_cast<const ulonglong2 *>(blk + 32); bhi[s] = *reinterpret_cast<const ulonglong2 *>(blk + 48);
             }
-            nxt += (size_t)__popcll(idle);
-            if (nxt > end) nxt = end;
         }
-        if (!lf_ballot(active)) { if (nxt >= end) break; continue; }
-        if (active) {
-            bool more = false;
-            /* the next base: from the register while m < 24, else one byte of the read */
-            int c = 4;
-            if (m < 24u) { if (m - 12u < (ahead >> 24)) c = (int)((ahead >> (2 * (m - 12u))) & 3u); }
-            else if (p + m < qLen) c = lf_nt4(q[p + m]);
-            if (c <= 3) {
-                /* bwt_extend, is_back = 0 (lib/bwa/bwt.c:262-275; lf_extend_right): one backward step on x1 with the counts of
-                 * rows x1 - 1 and x1 - 1 + s.  Both blocks are asked for before either is used. */
-                const uint64_t km = x1 - 1, l = x1 - 1 + sz;
-                bool kn, ka, ln, la; int kr, lr;
-                const uint32_t *bk = lf_occ_addr(ix, km, kn, ka, kr), *bl = lf_occ_addr(ix, l, ln, la, lr);
-                const lf_occ_blk BK = lf_occ_load(bk), BL = lf_occ_load(bl);
-                {   /* touches counted like bwt_2occ (lib/bwa/bwt.c:132-139): 1 block if the two rows share one, else 2 */
-                    const uint64_t _k = (km >= ix.primary) ? km - 1 : km, _l = (l >= ix.primary) ? l - 1 : l;
-                    n_blk += (km == ~0ull || l == ~0ull || (_k >> 7) != (_l >> 7)) ? 2u : 1u;
+        /* ---- (3) new code windows: usable bases, table index; the table entries of this trip ---- */
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if (win[s]) {
+                uint64_t lo56, hi56; uint32_t lead;
+                if (PLANES) {
+                    lo56 = wl[s] >> wsh[s]; hi56 = wh[s] >> wsh[s];
+                    const uint64_t bad = ~(wv[s] >> wsh[s]) | (1ull << 56);
+                    lead = (uint32_t)__ffsll((long long)bad) - 1u;               /* usable bases in front of the first one outside ACGT */
+                } else {
+                    lo56 = 0; hi56 = 0; uint32_t bad = 1u << 24;
+#pragma unroll
+                    for (int t = 0; t < 24; t++) {
+                        const int cd = lf_nt4((unsigned char)((t < 8 ? wl[s] >> (8 * t) : t < 16 ? wh[s] >> (8 * (t - 8)) : wv[s] >> (8 * (t - 16))) & 0xff));
+                        bad |= (cd > 3 ? 1u : 0u) << t; lo56 |= (uint64_t)(cd & 1) << t; hi56 |= (uint64_t)((cd >> 1) & 1) << t;
+                    }
+                    lead = (uint32_t)__ffs((int)bad) - 1u;
                 }
-                const int a = 3 - c;                                   /* symbol prepended on the complement strand */
-                uint64_t ek, gk, el, gl;
-                lf_occ_eq_gt(ix, BK, a, kn, ka, kr, ek, gk); lf_occ_eq_gt(ix, BL, a, ln, la, lr, el, gl);
-                const uint64_t ns = el - ek;
-                if (ns != 0) {
-                    /* rows of P.d for d = 0..3 follow each other inside P's interval in the order of d; on the complement strand d
-                     * appears as 3 - d, so P.c starts after the sentinel row (if P's complement interval spans it) and all a' > a */
-                    x0 = x0 + ((x1 <= ix.primary && x1 + sz - 1 >= ix.primary) ? 1u : 0u) + (gl - gk);
-                    x1 = ix.L2[a] + 1 + ek; sz = ns;
-                    m++; more = true;
+                const uint32_t left = rlen[s] > m[s] ? rlen[s] - m[s] : 0u;       /* bases of the read from here on */
+                lead = lead < left ? lead : left;
+                if (ph[s] == 4u) {
+                    /* a search in progress: the codes of offsets m .. m + 31 */
+                    const uint32_t CAP = PLANES ? 32u : 24u, an = lead < CAP ? lead : CAP;
+                    alo[s] = (uint32_t)lo56; ahi[s] = (uint32_t)hi56;
+                    aw[s] = m[s] | (an << 24) | (an == CAP ? 0x80000000u : 0u);
+                    ph[s] = an ? 2u : 7u;
+                } else {
+                    /* a new sample.  Table index of revcomp(P_W): base-4 number whose digit W - 1 - t is the complement of P's character t
+                     * (the LAST character of a pattern is the most significant digit, src/BWT.cpp:270-277): the complemented code bits,
+                     * bit-reversed, interleaved.  idx14 = idx16 >> 4, idx12 = idx16 >> 8. */
+                    const uint32_t L16 = __brev(~(uint32_t)lo56) >> 16, H16 = __brev(~(uint32_t)hi56) >> 16;
+                    const uint32_t idx16 = lf_spread16(L16) | (lf_spread16(H16) << 1);
+                    const uint32_t CAP = PLANES ? 32u : 12u;
+                    const uint32_t an = lead > 12u ? (lead - 12u < CAP ? lead - 12u : CAP) : 0u;
+                    alo[s] = (uint32_t)(lo56 >> 12); ahi[s] = (uint32_t)(hi56 >> 12);
+                    aw[s] = 12u | (an << 24) | (an == CAP ? 0x80000000u : 0u) | (lead >= W ? 0x40000000u : 0u);
+                    /* widest table first: a 16-mer that occurs starts the search at m = 16 (nothing shorter than kmin is wanted, and a sample
+                     * that reaches 16 would have passed through every shorter length with a non-empty interval) */
+                    if (rlen[s] >= (uint32_t)kmin && ix.cache16 != nullptr && lead >= 16u) { ph[s] = 1u; tix[s] = idx16; }
+                    else if (rlen[s] >= (uint32_t)kmin && lead >= W) { ph[s] = 3u; tix[s] = idx16 >> (32u - 2u * W); }
+                    else ph[s] = 7u;
                 }
             }
-            if (!more) {
+        }
+        ulonglong2 te[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            te[s] = make_ulonglong2(0, 0);
+            if (ph[s] == 1u || ph[s] == 3u) {
+                const uint64_t *T = ph[s] == 1u ? ix.cache16 : tabW;
+                te[s] = *reinterpret_cast<const ulonglong2 *>(T + 2 * (size_t)tix[s]);
+                n_cache += 1u;
+            }
+        }
+        /* ---- (4) this trip's blocks and table entries ---- */
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if (go[s]) {
+                const uint32_t a = sym[s];
+                const lf_occ2_masks M = lf_occ2_eq_gt(blo[s].x, blo[s].y, bhi[s].x, bhi[s].y, (int)a);
+                uint64_t a0, a1, b0, b1;
+                lf_occ2_first(rA[s], a0, a1); lf_occ2_first(rB[s], b0, b1);
+                const uint64_t d0 = a0 ^ b0, d1 = a1 ^ b1;                        /* rows rA .. rB - 1 of the block (rA <= rB) */
+                const uint32_t EA = (uint32_t)__popcll(M.e0 & a0) + (uint32_t)__popcll(M.e1 & a1);
+                const uint32_t ED = (uint32_t)__popcll(M.e0 & d0) + (uint32_t)__popcll(M.e1 & d1);
+                const uint32_t GD = (uint32_t)__popcll(M.g0 & d0) + (uint32_t)__popcll(M.g1 & d1);
+                const uint64_t Ca = a ? hd[s].y : hd[s].x, Cm = a ? hd[s].x : 0ull;
+                const uint64_t HE = Ca - Cm, HG = c3[s] - Ca;                     /* occurrences of a / of everything above a in front of the block */
+                const uint64_t L2a = a == 0u ? ix.L2[0] : a == 1u ? ix.L2[1] : a == 2u ? ix.L2[2] : ix.L2[3];
+                const uint32_t mode = ph[s] & 255u;
+                if (mode == 6u) {
+                    /* first half: park ek (as the row it leads to) and gk; x1 is not needed any more */
+                    const uint64_t gk = HG + GD;
+                    x1[s] = L2a + 1 + HE + ED;
+                    gks[s] = (uint32_t)gk;
+                    ph[s] = (ph[s] & ~255u & ~(1u << 18)) | 5u | ((uint32_t)(gk >> 32) & 1u) << 18;
+                } else {
+                    uint64_t ns, gd, nx1; uint32_t sent;
+                    if (mode == 2u) { ns = ED; gd = GD; nx1 = L2a + 1 + HE + EA; sent = (x1[s] <= ix.primary && x1[s] + sz[s] - 1 >= ix.primary) ? 1u : 0u; }
+                    else {
+                        const uint64_t el = HE + ED, gl = HG + GD, ek = x1[s] - L2a - 1, gk = (uint64_t)gks[s] | ((uint64_t)((ph[s] >> 18) & 1u) << 32);
+                        ns = el - ek; gd = gl - gk; nx1 = x1[s]; sent = (ph[s] >> 19) & 1u;
+                    }
+                    if (ns != 0) {
+                        /* rows of P.d for d = 0..3 follow each other inside P's interval in the order of d; on the complement strand d appears
+                         * as 3 - d, so P.c starts after the sentinel row (if P's complement interval spans it) and all a' > a */
+                        x0[s] += sent + gd; x1[s] = nx1; sz[s] = ns; m[s] += 1u; ph[s] = 2u;
+                    } else ph[s] = 7u;
+                }
+            }
+            if (ph[s] == 1u || ph[s] == 3u) {
+                const uint64_t size = (te[s].x >> 33) | ((te[s].y >> 33) << 31);
+                if (size != 0) { x1[s] = te[s].x & LF_M33; x0[s] = te[s].y & LF_M33; sz[s] = size; m[s] = ph[s] == 1u ? 16u : W; ph[s] = 2u; }
+                else if (ph[s] == 1u && (aw[s] & 0x40000000u)) { ph[s] = 3u; tix[s] >>= (32u - 2u * W); }      /* the 16-mer does not occur: the narrower table */
+                else ph[s] = 7u;
+            }
+            if (ph[s] == 7u) {
                 lf_sample_t res; res.sp = 0; res.occ = 0; res.m = 0;
-                if ((int)m >= kmin) { res.sp = x0; res.m = m; res.occ = sz > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sz; }
-                out[gid] = res;
-                active = false;
+                if ((int)m[s] >= kmin) { res.sp = x0[s]; res.m = m[s]; res.occ = sz[s] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sz[s]; }
+                out[gidx[s]] = res;
+                ph[s] = 0u; m[s] = 0;
             }
         }
+        bool busy = false;
+#pragma unroll
+        for (int s = 0; s < S; s++) busy = busy || ph[s] != 0u;
+        if (!lf_any(busy) && nxt >= end) break;
+    }
     }
     /* SURVEY 8(d) counters: one atomic pair per BLOCK (same-address atomics serialise) */
     __shared__ unsigned long long s_cnt[2];
@@ -644,7 +737,7 @@ static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_r
     hipEvent_t ev[6];
     for (int i = 0; i < 6; i++) { ev[i] = (hipEvent_t)lfg_lane_event(dv, 34 + i); if (!ev[i]) return LF_ERR_HIP; }
 
-    HIPCHK(hipMemsetAsync(d_counters, 0, 32, s));
+    HIPCHK(hipMemsetAsync(d_counters, 0, 40, s));          /* [0..3] SURVEY 8(d) counters, [4] "a lower-case base somewhere in the batch" */
     HIPCHK(hipMemcpyAsync(d_off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, s));
     const uint64_t qw = lf_plane_words(n_bases);
     uint64_t *d_planes = DSLOT(uint64_t, 14, 3 * qw * 8);
@@ -667,6 +760,11 @@ static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_r
             }
             if (turns) HIPCHK(hipStreamSynchronize(s));
         }
+        {   /* seeding is case-insensitive (nst_nt4_table), the planes are not: a lower-case base among the exceptions selects the byte variant of the search */
+            bool lower = false;
+            for (uint64_t i = 0; i < pk->n_exc && !lower; i++) { const uint8_t b = pk->exc_byte[i]; lower = b == 'a' || b == 'c' || b == 'g' || b == 't'; }
+            if (lower) HIPCHK(hipMemsetAsync(d_counters + 4, 0xff, 8, s));
+        }
         hipLaunchKernelGGL(lf_unpack_planes_kernel, dim3((unsigned)((n_bases / 4 + 256) / 256)), dim3(256), 0, s, d_planes, d_planes + qw, d_planes + 2 * qw, n_bases, d_reads);
         if (pk->n_exc) hipLaunchKernelGGL(lf_patch_bytes_kernel, dim3((unsigned)((pk->n_exc + 255) / 256)), dim3(256), 0, s, (const uint64_t *)d_xpos, (const uint8_t *)d_xbyte, pk->n_exc, d_reads);
     } else if (reads) {
@@ -688,13 +786,26 @@ static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_r
     }
 
     {   /* the batch as three bit planes (code low / high bit, "is ACGT"): what the alignment kernels build their blocks from */
-        if (!pk) lf_rsweep_pack_planes(s, (const unsigned char *)d_reads, n_bases, d_planes, qw);
+        if (!pk) lf_rsweep_pack_planes(s, (const unsigned char *)d_reads, n_bases, d_planes, qw, d_counters + 4);
         lfg_lane_set_value(dv, 0, qw);
     }
     hipLaunchKernelGGL(lf_seed_pos_kernel, dim3((n_reads + 63) / 64), dim3(64), 0, s, n_reads, d_off, hc, d_pos2);
     HIPCHK(hipEventRecord(ev[0], s));
-    hipLaunchKernelGGL(lf_seed_search_kernel, dim3((unsigned)((total + 4 * LF_SEARCH_SPAN - 1) / (4 * LF_SEARCH_SPAN))), dim3(256), 0, s, st->view, n_reads, d_reads,
-                       d_off, hc, p->min_anchor_len, d_pos2, d_smp, d_counters);
+    {
+        /* a wavefront owns the samples of rpw whole reads; both variants are launched and the batch's flag (a lower-case base somewhere:
+         * seeding is case-insensitive, the bit planes are not) decides which of them works */
+        const uint32_t rpw = hc >= LF_SEARCH_MIN_SPAN ? 1u : (LF_SEARCH_MIN_SPAN + hc - 1) / hc;
+        const unsigned waves = (unsigned)(((uint32_t)n_reads + rpw - 1) / rpw), blocks = (waves + 3) / 4;
+        static const int slots = getenv("LF_SEARCH_SLOTS") ? atoi(getenv("LF_SEARCH_SLOTS")) : 1;
+#define LF_SEARCH_LAUNCH(SS, PL) hipLaunchKernelGGL((lf_seed_search_kernel<SS, PL>), dim3(blocks), dim3(256), 0, s, st->view, n_reads, d_reads, (const uint64_t *)d_planes, (int64_t)qw, \
+                                                     d_off, hc, rpw, p->min_anchor_len, d_pos2, d_smp, d_counters)
+        if (slots == 1) { LF_SEARCH_LAUNCH(1, true); LF_SEARCH_LAUNCH(1, false); }
+        else if (slots == 3) { LF_SEARCH_LAUNCH(3, true); LF_SEARCH_LAUNCH(3, false); }
+        else if (slots == 4) { LF_SEARCH_LAUNCH(4, true); LF_SEARCH_LAUNCH(4, false); }
+        else if (slots == 2) { LF_SEARCH_LAUNCH(2, true); LF_SEARCH_LAUNCH(2, false); }
+        else { LF_SEARCH_LAUNCH(1, true); LF_SEARCH_LAUNCH(1, false); }
+#undef LF_SEARCH_LAUNCH
+    }
     HIPCHK(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(lf_seed_accept_kernel, dim3((unsigned)((n_reads + 3) / 4)), dim3(256), 0, s, n_reads, hc, (uint32_t)p->max_ref_hits, d_pos2, d_smp, d_cnt);
     HIPCHK(hipMemsetAsync(d_cnt + total, 0, 4, s));

@@ -292,18 +292,26 @@ def make_shards(torch, names, seqs, world, device, by_bases=True):
 
 
 class PipelinedExchange:
-    def __init__(self, dist, torch, bulk_device, ctl_group, read_cap: int, sam_cap: int, pin=True):
+    """ring = number of steps whose buffers exist at once.  2: the one-step-ahead / one-step-behind pipeline (post / complete around
+    every mapping).  D + 1: D steps of a rank are mapped concurrently (bench.py --inflight D; a rank's shard under strong scaling
+    is small, and two or three small steps in flight keep the GPU as busy as one large one): tick t waits for the mapping of step
+    t - D, completes tick t - 1's transfers, posts {records of step t - D back, reads of step t + 1 out} as ONE grouped
+    point-to-point call and hands step t to a mapper thread -- every rank issues the same groups in the same order."""
+
+    def __init__(self, dist, torch, bulk_device, ctl_group, read_cap: int, sam_cap: int, pin=True, ring: int = 2, gather_cap: int | None = None):
         self.dist, self.torch, self.dev, self.ctl = dist, torch, bulk_device, ctl_group
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.ring = max(2, int(ring))
         kw = dict(dtype=torch.uint8, device=bulk_device)
         if bulk_device.type == "cpu" and pin and torch.cuda.is_available():
             kw["pin_memory"] = True
         # rank 0: sam[b] holds the whole step's records (own first, then the peers' in rank order); peers: their own text
-        self.sam = [torch.empty(sam_cap * (self.world if self.rank == 0 else 1), **kw) for _ in range(2)]
-        self.rx = [torch.empty(read_cap, **kw) if self.rank else None for _ in range(2)]
-        self.rx_shard = [None, None]
+        cap0 = int(gather_cap) if gather_cap else sam_cap * self.world
+        self.sam = [torch.empty(cap0 if self.rank == 0 else sam_cap, **kw) for _ in range(self.ring)]
+        self.rx = [torch.empty(read_cap, **kw) if self.rank else None for _ in range(self.ring)]
+        self.rx_shard = [None] * self.ring
         self.works = []
-        self.gather_lens = [None, None]          # rank 0: per step parity, [own, peer1, ...] lengths
+        self.gather_lens = [None] * self.ring     # rank 0: per ring slot, [own, peer1, ...] lengths
         self.bytes_out = self.bytes_in = 0
 
     # -- control plane (host tensors over gloo)
@@ -315,26 +323,24 @@ class PipelinedExchange:
         self.dist.recv(t, src, group=self.ctl)
         return t.numpy()
 
-    def post(self, k: int, next_shards=None, prev_own_len=None):
-        """Call before mapping step k.  rank 0: next_shards = the N shards of step k + 1 (or None after the last step),
-        prev_own_len = length of its own SAM text of step k - 1 (None for k == 0).  Peers: next_shards is ignored (pass True
-        when a step k + 1 exists), prev_own_len = length of their SAM text of step k - 1 (None for k == 0).
-        Everything posted here completes in complete()."""
-        dist, torch = self.dist, self.torch
+    def post_steps(self, scatter_step=None, shards=None, gather_step=None, own_len=None):
+        """ONE grouped point-to-point call: the reads of step `scatter_step` travel out (rank 0: `shards` = that step's N shards)
+        and the records of step `gather_step` come back (`own_len` = length of this rank's text of that step, which lies in
+        sam[gather_step % ring]).  Either may be None.  Completes in complete()."""
+        dist = self.dist
         ops = []
-        have_next = next_shards is not None and next_shards is not False
-        nb, pb = (k + 1) & 1, (k - 1) & 1
         if self.rank == 0:
-            if have_next:
+            if scatter_step is not None:
                 for r in range(1, self.world):
-                    sh = next_shards[r]
+                    sh = shards[r]
                     self._ctl_send([len(sh), sh.nbytes], r)
                     self._ctl_send(np.concatenate([sh.seq_off, sh.name_off]), r)
                     if sh.nbytes:
                         ops.append(dist.P2POp(dist.isend, sh.blob[:sh.nbytes], r))
                         self.bytes_out += sh.nbytes
-            if prev_own_len is not None:
-                lens = [int(prev_own_len)] + [int(self._ctl_recv(1, r)[0]) for r in range(1, self.world)]
+            if gather_step is not None:
+                pb = gather_step % self.ring
+                lens = [int(own_len)] + [int(self._ctl_recv(1, r)[0]) for r in range(1, self.world)]
                 self.gather_lens[pb] = lens
                 off = lens[0]
                 for r in range(1, self.world):
@@ -345,7 +351,8 @@ class PipelinedExchange:
                         self.bytes_in += lens[r]
                     off += lens[r]
         else:
-            if have_next:
+            if scatter_step is not None:
+                nb = scatter_step % self.ring
                 n, nbytes = (int(x) for x in self._ctl_recv(2, 0))
                 meta = self._ctl_recv(2 * (n + 1), 0)
                 if nbytes > self.rx[nb].numel():
@@ -353,11 +360,21 @@ class PipelinedExchange:
                 self.rx_shard[nb] = Shard(self.rx[nb], meta[:n + 1], meta[n + 1:], nbytes)
                 if nbytes:
                     ops.append(dist.P2POp(dist.irecv, self.rx[nb][:nbytes], 0))
-            if prev_own_len is not None:
-                self._ctl_send([int(prev_own_len)], 0)
-                if prev_own_len:
-                    ops.append(dist.P2POp(dist.isend, self.sam[pb][:int(prev_own_len)], 0))
+            if gather_step is not None:
+                pb = gather_step % self.ring
+                self._ctl_send([int(own_len)], 0)
+                if own_len:
+                    ops.append(dist.P2POp(dist.isend, self.sam[pb][:int(own_len)], 0))
         self.works = dist.batch_isend_irecv(ops) if ops else []
+
+    def post(self, k: int, next_shards=None, prev_own_len=None):
+        """Call before mapping step k (ring 2).  rank 0: next_shards = the N shards of step k + 1 (or None after the last step),
+        prev_own_len = length of its own SAM text of step k - 1 (None for k == 0).  Peers: next_shards is ignored (pass True
+        when a step k + 1 exists), prev_own_len = length of their SAM text of step k - 1 (None for k == 0).
+        Everything posted here completes in complete()."""
+        have_next = next_shards is not None and next_shards is not False
+        self.post_steps(k + 1 if have_next else None, next_shards if have_next else None,
+                        k - 1 if prev_own_len is not None else None, prev_own_len)
 
     def complete(self):
         for w in self.works:
@@ -367,6 +384,44 @@ class PipelinedExchange:
             self.torch.cuda.current_stream().synchronize()      # the waits above only order the current stream behind RCCL's
 
     def gathered(self, k: int):
-        """rank 0, after the post()/complete() that followed step k: (tensor, total length) of step k's records, input order"""
-        lens = self.gather_lens[k & 1]
-        return self.sam[k & 1], sum(lens)
+        """rank 0, after the transfers of step k's records completed: (tensor, total length) of step k's records, input order"""
+        lens = self.gather_lens[k % self.ring]
+        return self.sam[k % self.ring], sum(lens)
+
+
+def run_pipeline(px, n_steps: int, depth: int, shards_of, map_step, pool=None, on_gathered=None):
+    """The exchange loop with `depth` steps of every rank in flight (ring = depth + 1).  shards_of(k) -> rank 0: the N shards of
+    step k (peers: ignored); map_step(k, shard, out_tensor, slot) -> length of the text written to out_tensor (called on a pool
+    thread; slot = k % depth: per-thread staging buffers).  Returns the lengths (per step) of this rank's own texts.
+    on_gathered(k, tensor, length): rank 0, called once step k's records are complete in input order (the buffer is reused by step
+    k + depth + 1 right afterwards).
+    Order of events per tick t: wait map(t - depth) | complete tick t - 1's transfers (reads of step t have arrived, the buffer
+    of step t - depth - 1's records is free) | post {records of t - depth, reads of t + 1} | start map(t)."""
+    from concurrent.futures import ThreadPoolExecutor
+    D = max(1, int(depth))
+    if px.ring < D + 1:
+        raise ValueError("run_pipeline: ring %d < depth %d + 1" % (px.ring, D))
+    own = {}
+    ex = pool or ThreadPoolExecutor(D)
+    try:
+        px.post_steps(0 if n_steps > 0 else None, shards_of(0) if (px.rank == 0 and n_steps > 0) else None)      # reads of step 0: exposed
+        futs = {}
+        for t in range(n_steps + D):
+            g = t - D
+            if g >= 0:
+                own[g] = futs.pop(g).result()
+            px.complete()
+            if on_gathered is not None and px.rank == 0 and g - 1 >= 0:
+                on_gathered(g - 1, *px.gathered(g - 1))
+            s = t + 1 if t + 1 < n_steps else None
+            px.post_steps(s, shards_of(s) if (s is not None and px.rank == 0) else None, g if g >= 0 else None, own.get(g) if g >= 0 else None)
+            if t < n_steps:
+                shard = shards_of(t)[0] if px.rank == 0 else px.rx_shard[t % px.ring]
+                futs[t] = ex.submit(map_step, t, shard, px.sam[t % px.ring], t % D)
+        px.complete()
+        if on_gathered is not None and px.rank == 0 and n_steps > 0:
+            on_gathered(n_steps - 1, *px.gathered(n_steps - 1))
+    finally:
+        if pool is None:
+            ex.shutdown(wait=True)
+    return own

@@ -147,6 +147,77 @@ def test_pipelined_exchange_gloo(tmp_path):
         assert "PIPE_OK" in r.stdout
 
 
+RING_WORKER = r'''
+import os, sys, hashlib, time, threading
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from lordfast_amd import dist as lfd
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cpu")
+STEPS, DEPTH = int(sys.argv[2]), int(sys.argv[3])
+def job(step):
+    rng = np.random.default_rng(500 + step)
+    n = 19 + 3 * step
+    names = [f"s{step}_r{i}".encode() for i in range(n)]
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(rng.integers(1, 2500)))) for _ in range(n)]
+    return names, seqs
+running, peak, lock = [0], [0], threading.Lock()
+def fake_map(k, shard, out, slot):
+    with lock:
+        running[0] += 1; peak[0] = max(peak[0], running[0])
+    assert slot == k % DEPTH
+    time.sleep(0.02 * (1 + (k + rank) % 3))           # steps finish out of order across ranks
+    b = shard.blob[:shard.nbytes].numpy().tobytes()
+    lines = []
+    for i in range(len(shard)):
+        nm = b[int(shard.name_off[i]):int(shard.name_off[i + 1]) - 1]
+        sq = b[int(shard.seq_off[i]):int(shard.seq_off[i + 1]) - 1]
+        lines.append(nm + b"\t" + hashlib.md5(sq).hexdigest().encode() + b"\n")
+    txt = b"".join(lines)
+    out[:len(txt)] = torch.frombuffer(bytearray(txt), dtype=torch.uint8) if txt else out[:0]
+    with lock:
+        running[0] -= 1
+    return len(txt)
+px = lfd.PipelinedExchange(dist, torch, dev, dist.group.WORLD, read_cap=1 << 20, sam_cap=1 << 20, pin=False, ring=DEPTH + 1)
+cache = {}
+def shards_of(k):
+    if k not in cache:
+        nm, sq = job(k)
+        cache[k] = lfd.make_shards(torch, nm, sq, world, dev)[0]
+    return cache[k]
+got = {}
+def on_gathered(k, t, ln):
+    got[k] = bytes(t[:ln].numpy().tobytes())
+own = lfd.run_pipeline(px, STEPS, DEPTH, shards_of, fake_map, on_gathered=on_gathered)
+assert sorted(own) == list(range(STEPS))
+if rank == 0:
+    for k in range(STEPS):
+        nm, sq = job(k)
+        exp = b"".join(a + b"\t" + hashlib.md5(b).hexdigest().encode() + b"\n" for a, b in zip(nm, sq))
+        assert got[k] == exp, ("step", k)
+    assert STEPS < 2 or DEPTH < 2 or peak[0] >= 2, peak
+    print("RING_OK", STEPS, DEPTH, peak[0], px.bytes_out, px.bytes_in)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_pipelined_exchange_with_several_steps_in_flight_gloo(tmp_path):
+    """lfd.run_pipeline: `depth` steps of every rank are mapped concurrently (ring = depth + 1 buffers) while the reads of the next
+    step and the records of the step that just left the ring travel; rank 0 sees every step's records complete and in input
+    order (world 2 / depth 2, world 3 / depth 3, and more depth than steps)"""
+    script = tmp_path / "r.py"
+    script.write_text(RING_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for world, steps, depth, port in ((2, 7, 2, 29615), (3, 5, 3, 29616), (2, 1, 2, 29617)):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(steps), str(depth)],
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        assert "RING_OK" in r.stdout
+
+
 def test_bench_spawns_its_own_ranks_without_touching_the_gpu(tmp_path):
     """`python bench.py --gpus 2` from a bare shell must start torch.distributed.run children itself (here: checked up to the
     point where a rank finds no GPU and says so -- the parent must not have imported torch or initialised HIP)"""
