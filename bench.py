@@ -78,9 +78,13 @@ def parse():
                          "(chunks pulled from one counter; every device copies through its own PCIe link)")
     ap.add_argument("--exchange-timeout", type=float, default=float(os.environ.get("LF_BENCH_EXCHANGE_TIMEOUT", "240")),
                     help="seconds after which a stuck exchange phase is abandoned: the line is printed with the no-exchange rate as value")
-    ap.add_argument("--repeat-profile", choices=["default", "grch38like"], default="default",
+    ap.add_argument("--ref-fasta", default=os.environ.get("LF_BENCH_REF_FASTA"),
+                    help="a real reference FASTA (plain or .gz) to index and draw the synthetic-error reads from (SURVEY 8d: 'real FASTA if present on the "
+                         "box, else synthetic').  Default: $LF_BENCH_REF_FASTA, else the first existing one of a few conventional paths, else the synthetic genome")
+    ap.add_argument("--repeat-profile", choices=["default", "grch38like", "t2tlike"], default=None,
                     help="default: 10 %% of the genome from 1000 low-copy families (SURVEY 8d); grch38like: ~50 %% repeats incl. a "
-                         "300 bp family with ~10^6 copies per 3 Gbp and truncated 1-6 kbp families")
+                         "300 bp family with ~10^6 copies per 3 Gbp and truncated 1-6 kbp families; t2tlike (default of --config c5, 'vs CHM13 T2T'): "
+                         "grch38like + a centromeric satellite array (171 bp monomers in higher-order repeats) per contig and simple-sequence arrays")
     ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2",
                     help="BASELINE.json config: c2 = 15 kbp / 15 %% PacBio, -k 14 -c 1000 dp-n2 (headline); c4 = clasp -n 30; "
                          "c5 = 50 kbp / 10 %% ONT error mix, -k 17 -c 2000")
@@ -99,6 +103,15 @@ def parse():
         a.scaling = "strong" if a.gpus > 1 else "weak"
     if a.inflight is None:
         a.inflight = 2 if (a.gpus > 1 and a.scaling == "strong" and a.mode == "ranks") else 1
+    if a.repeat_profile is None:
+        a.repeat_profile = "t2tlike" if a.config == "c5" else "default"
+    if not a.ref_fasta:
+        for cand in ("/data/reference/GRCh38.fa", "/data/GRCh38.fa", "/data/chm13v2.0.fa", "/opt/data/GRCh38.fa", os.path.expanduser("~/GRCh38.fa")):
+            if os.path.exists(cand) or os.path.exists(cand + ".gz"):
+                a.ref_fasta = cand if os.path.exists(cand) else cand + ".gz"
+                break
+    if a.ref_fasta and not os.path.exists(a.ref_fasta):
+        sys.exit(f"bench.py: --ref-fasta {a.ref_fasta}: no such file")
     if a.config == "c5":
         if a.read_len == 15000:
             a.read_len = 50000
@@ -122,8 +135,14 @@ def make_contigs(args):
     """the synthetic genome is a pure function of its recipe: any rank can regenerate it instead of parsing the FASTA.
     -> (contigs, segdup families or None)"""
     from lordfast_amd import synth
-    total, n_contigs, fams = genome_recipe(args)
-    contigs = synth.make_genome(total, n_contigs, seed=11, repeat_frac=0.10, n_families=fams, profile=args.repeat_profile)
+    if args.ref_fasta:
+        contigs = synth.read_fasta(args.ref_fasta)
+        if not contigs:
+            sys.exit(f"bench.py: no contig of >= 2000 bases in {args.ref_fasta}")
+        total = sum(len(c[1]) for c in contigs)
+    else:
+        total, n_contigs, fams = genome_recipe(args)
+        contigs = synth.make_genome(total, n_contigs, seed=11, repeat_frac=0.10, n_families=fams, profile=args.repeat_profile)
     segd = None
     if args.dup_frac > 0:
         nseg = max(1, min(args.segdups, total // 400_000))
@@ -136,15 +155,18 @@ def ensure_index(args, rank):
     """synthetic genome + index files under workdir (rank 0 builds, others wait on the done marker)"""
     from lordfast_amd import synth
     tag = f"g{args.genome_mbp:g}" + ("" if args.repeat_profile == "default" else "_" + args.repeat_profile) + (f"_sd{args.segdups}" if args.dup_frac > 0 else "")
+    if args.ref_fasta:
+        st = os.stat(args.ref_fasta)
+        tag = "ref_" + hashlib.md5(f"{os.path.abspath(args.ref_fasta)}|{st.st_size}".encode()).hexdigest()[:10] + (f"_sd{args.segdups}" if args.dup_frac > 0 else "")
     d = os.path.join(args.workdir, tag)
     fa = os.path.join(d, "genome.fa")
     done = os.path.join(d, "DONE")
     if rank == 0 and not os.path.exists(done):
         os.makedirs(d, exist_ok=True)
         t0 = time.time()
-        total, n_contigs, fams = genome_recipe(args)
         contigs = make_contigs(args)
-        log(f"genome {total} bp, {n_contigs} contigs, {fams} repeat families" + (f", {len(contigs[1])} segmental duplications" if contigs[1] else "") + f": {time.time() - t0:.1f}s")
+        log((f"reference {args.ref_fasta}: " if args.ref_fasta else f"synthetic genome ({args.repeat_profile} repeats): ") + f"{sum(len(c[1]) for c in contigs[0])} bp, {len(contigs[0])} contigs"
+            + (f", {len(contigs[1])} segmental duplications" if contigs[1] else "") + f": {time.time() - t0:.1f}s")
         t0 = time.time()
         import lordfast_amd as la
         la.index_build(contigs[0], fa)                        # GPU indexer (writes the reference's file formats)
@@ -172,7 +194,8 @@ def make_reads(args, contigs, fa, rank):
         contigs = make_contigs(args)
     t0 = time.time()
     mix = (0.40, 0.25, 0.35) if args.config == "c5" else (0.15, 0.50, 0.35)          # ONT / PacBio CLR profile
-    reads = synth.make_reads(contigs[0], args.reads, args.read_len, args.err, seed=2024 + rank, mix=mix, segdups=contigs[1], dup_frac=args.dup_frac)
+    reads = synth.make_reads(contigs[0], args.reads, args.read_len, args.err, seed=2024 + rank, mix=mix, segdups=contigs[1], dup_frac=args.dup_frac,
+                             acgt_only=bool(args.ref_fasta))
     names = [(r[0] if rank == 0 else f"g{rank}_{r[0]}").encode() for r in reads]
     seqs = [r[1] for r in reads]
     log(f"rank {rank}: {args.reads} reads generated in {time.time() - t0:.1f}s")
@@ -624,6 +647,10 @@ def main():
         hbm_used_gb = None
 
     index_desc = lf.describe()
+    try:
+        bases_genome = (os.path.getsize(fa + ".pac") - 1) * 4
+    except OSError:
+        bases_genome = 0
 
     def report(elapsed, sam, xinfo):
         K = args.steps
@@ -648,12 +675,13 @@ def main():
                 "lf_vote_cell_kernel (+ scan)": (a["ms_k_vote"], 9 * n_hits, a["search_launches"], False),
                 # request gather + sort by qPos + lf_chain_n2_kernel + chain gather: 16 B per request seed, 8 B per chain seed
                 "lf_chain_* (gather, sort, dp-n2 | clasp)": (a["ms_k_chain"], 16 * a["n_req_seeds"], a["search_launches"], False),
-                "lf_hirsch_* (levels incl. per-level readbacks)": (a["ms_k_hirsch"], 0, max(1, a["edlib_launches"]), False),
+                "lf_hirsch_* (levels incl. per-level readbacks)": (a["ms_k_hirsch"], a.get("hirsch_bytes", 0), max(1, a["edlib_launches"]), False),
                 "lf_desc_* (alignment binning: keys, sort, segments, scan, build)": (a["ms_k_bin"], 100 * a["n_edlib_problems"], max(1, a["edlib_launches"]), False),
                 "lf_render_kernel (+ caps, scan)": (a["ms_k_render"], a["ops_bytes"] + a["render_bytes"], max(1, a["render_launches"]), False),      # single pass: ops read once, text written once
             }
         kx = kernel_table(excl)
         pmc, pmc_src = load_pmc(args, world)
+        sq, isa, sq_src = load_sq(args, world)
         by_kernel = {}
         for kname, (kms, kbytes, kl, single) in kx.items():
             gbs = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
@@ -665,7 +693,8 @@ def main():
                     traffic = sum(v.get("fetch_kb", 0.0) + v.get("write_kb", 0.0) for v in fam) * 1024.0
             by_kernel[kname] = dict(ms_per_step=kms, launches_per_step=kl, avg_launch_ms=kms / max(1, kl), algorithmic_GB_per_step=kbytes / 1e9,
                                     achieved_GBps=gbs, frac_of_8TBps=gbs / 8000.0, single_kernel=single,
-                                    hbm_traffic_GB_per_step=(traffic / 1e9 if traffic is not None else None))
+                                    hbm_traffic_GB_per_step=(traffic / 1e9 if traffic is not None else None),
+                                    alu=alu_of(kname, kms, sq, isa, sq_src, args.reads))
         other = max(0.0, excl["ms_k_edlib"] - excl["ms_k_rsweep"] - excl["ms_k_tb"] - excl["ms_k_hirsch"] - excl["ms_k_bin"])      # large-leaf sweeps, stitch
         excl_sum = sum(v[0] for v in kx.values()) + other
         dom = max((k for k in kx if kx[k][3]), key=lambda k: kx[k][0])      # the single kernel with the largest exclusive time
@@ -682,12 +711,9 @@ def main():
                                  "the rocprofv3 summary of the same mode is under profiles/",
                         overlapped_bracket_ms_per_step={k: round(v[0] / K, 2) for k, v in kernel_table(agg_hbm).items()},
                         lanes_in_flight_timed_region=int(os.environ.get("LF_LANES", "8")) if params.threads >= 4 else params.threads)
-        if dom.startswith("lf_edlib_rsweep"):
-            # the forward kernel is integer-ALU work, not HBM work: one Myers block step (64 DP cells) is ~55 32-bit lane
-            # operations; the chip issues 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s
-            lane_ops = excl["dp_block_steps"] * 55.0
-            roofline["alu"] = dict(bound="int32 VALU", achieved=lane_ops / (dms * 1e-3) / 1e12, peak=78.6, unit="T lane-ops/s",
-                                   frac=lane_ops / (dms * 1e-3) / 1e12 / 78.6, dp_block_steps_per_step=excl["dp_block_steps"])
+        # the issue-bound kernels' own roofline: VALU wave-instructions (SQ counters of this tree) x issue cycles per form (static mix of the
+        # kernel's loops, profiles/tools/isa_mix.py; rates of profiles/tools/ubench/valu_rate.hip) / 1024 SIMDs / sustained clock vs exclusive time
+        roofline["alu"] = by_kernel[dom]["alu"]
         shard_desc = (f"the SAME {n_total}-read set cut by bases over {world} ranks" if strong else f"{args.reads} reads per GPU")
         io_host = "reads in host memory -> SAM records in host memory (lf_map_batch_into_lens): H2D and D2H inside the step"
         io_hbm = "read bases resident in HBM when the timed region starts, SAM records left in HBM (lf_map_batch_dev)"
@@ -695,11 +721,13 @@ def main():
         out = {
             "metric": "aligned reads/s", "value": value, "unit": "reads/s", "n_gpus": world * n_dev, "steps": K, "warmup": args.warmup,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
+            "dtype": "u64", "data": ("synthetic-error reads drawn from a real reference FASTA" if args.ref_fasta else "synthetic"),
             "config": {"workload": f"{args.config}: {shard_desc}, synthetic {'ONT' if args.config == 'c5' else 'PacBio'} reads (~{args.read_len} bp, {args.err:.0%} err"
                                    + (f", {args.dup_frac:.0%} of them from 2-4-copy segmental duplications at 1-3 % divergence" if args.dup_frac > 0 else "") + f") vs "
-                                   f"{args.genome_mbp:g} Mbp synthetic genome ({args.repeat_profile} repeats), -k {kk} -c {cc} --chainAlg {args.chain_alg}" + (f" -n {args.max_map}" if args.max_map != 10 else ""),
-                       "reads_total": n_total, "reads_mapped_in_timed_region": n_total * K, "mean_read_len": bases / max(1, n_total), "genome_mbp": args.genome_mbp,
+                                   + (f"the reference {os.path.basename(args.ref_fasta)} ({bases_genome / 1e6:.0f} Mbp)" if args.ref_fasta else f"{args.genome_mbp:g} Mbp synthetic genome ({args.repeat_profile} repeats)")
+                                   + f", -k {kk} -c {cc} --chainAlg {args.chain_alg}" + (f" -n {args.max_map}" if args.max_map != 10 else "")
+                                   + (f"; every step maps the SAME {n_total} reads ({K} steps = {n_total * K} mapped reads, not {n_total * K} different ones)" if K > 1 else ""),
+                       "reads_total": n_total, "reads_mapped_in_timed_region": n_total * K, "mean_read_len": bases / max(1, n_total), "genome_mbp": (bases_genome / 1e6 if args.ref_fasta else args.genome_mbp),
                        "io": ("host buffers (lf_map_batch_multi): one process, every device copies through its own PCIe link" if args.mode == "inproc" else
                               "rank 0 owns the job's reads in its HBM and ends with the job's SAM records there; scatter / gather over RCCL inside the step" if with_x else
                               io_host if primary_is_host else io_hbm),
@@ -717,6 +745,7 @@ def main():
                          "chain_requests": agg["n_chain_problems"] / per_rank, "tie_requests": agg["n_tie_requests"] / per_rank,
                          "ksw_problems": agg["n_ksw_problems"] / per_rank},
             "roofline": roofline,
+            "host_waits_per_chunk": agg.get("n_host_waits", 0) / max(1, agg.get("n_chunks", 0)), "chunks_per_step": agg.get("n_chunks", 0) / K,
             "steps_in_flight": D,
             "source_tree": tree_hash(),      # digest of lordfast_amd/csrc: which kernels produced this line
         }
@@ -879,7 +908,7 @@ def load_pmc(args, world):
     (profiles/<dir>/pmc_fetch_write_summary.json carries the digest of the tree it profiled; collect.sh writes it) and on this
     configuration; otherwise None: a stale file says nothing about the kernels that just ran."""
     import subprocess
-    if not (args.genome_mbp == 3100 and args.reads == 100000 and world == 1 and args.config == "c2" and args.repeat_profile == "default" and args.dup_frac == 0):
+    if not (args.genome_mbp == 3100 and args.reads == 100000 and world == 1 and args.config == "c2" and args.repeat_profile == "default" and args.dup_frac == 0 and not args.ref_fasta):
         return None, "not the profiled configuration"
     try:
         head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
@@ -896,6 +925,49 @@ def load_pmc(args, world):
         if commit and commit in (head, src_hash):
             return pmc, os.path.relpath(path, ROOT)
     return None, "no counter pass of this source tree under profiles/ (profiles/tools/collect.sh writes one)"
+
+
+def load_sq(args, world):
+    """the committed SQ counter pass (per kernel: VALU / SALU wave-instructions, GRBM cycles; profiles/tools/collect.sh) and the static
+    instruction mix of the kernels' loops (profiles/tools/isa_mix.py) -- only if both describe THIS source tree"""
+    import glob
+    src_hash = tree_hash()
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c2")), reverse=True):
+        try:
+            sq = json.load(open(os.path.join(d, "sq_counters_50k_reads.json")))
+            isa = json.load(open(os.path.join(d, "isa_mix.json")))
+        except Exception:                                                # noqa: BLE001
+            continue
+        if sq.get("_meta", {}).get("source_tree") == src_hash and isa.get("_meta", {}).get("source_tree") == src_hash:
+            return sq, isa, os.path.relpath(d, ROOT)
+    return None, None, "no SQ counter pass + instruction mix of this source tree under profiles/ (profiles/tools/collect.sh, isa_mix.py)"
+
+
+def alu_of(kname, kms, sq, isa, src, reads_now):
+    """VALU-issue roofline of one kernel (family): sum over its instantiations of wave-level VALU instructions x cycles per instruction
+    of the instantiation's loop mix, over 1024 SIMDs at the clock the counter pass saw"""
+    if sq is None:
+        return dict(frac=None, source=src)
+    prefix = kname.split(" ")[0].rstrip("*")
+    reads_sq = sq.get("_meta", {}).get("reads_per_step", 50000)
+    scale = reads_now / float(reads_sq)
+    n_valu = n_salu = cyc = 0.0
+    clk = []
+    for k, v in sq.items():
+        if not isinstance(v, dict) or not k.startswith(prefix) or "sq_insts_valu" not in v:
+            continue
+        mix = isa.get(k) or next((m for kk, m in isa.items() if kk.startswith(k.split("<")[0]) and isinstance(m, dict) and m.get("cycles_per_valu")), None)
+        cpi = (mix or {}).get("cycles_per_valu") or 2.7
+        n_valu += v["sq_insts_valu"] * scale; n_salu += v.get("sq_insts_salu", 0.0) * scale
+        cyc += v["sq_insts_valu"] * scale * cpi
+        if v.get("clock_ghz"):
+            clk.append(v["clock_ghz"])
+    if n_valu == 0:
+        return dict(frac=None, source=src)
+    ghz = sum(clk) / len(clk) if clk else 2.4
+    alu_ms = cyc / 1024.0 / (ghz * 1e9) * 1e3
+    return dict(bound="VALU issue (integer)", valu_wave_instructions_per_step=n_valu, salu_wave_instructions_per_step=n_salu, cycles_per_valu_instruction=cyc / n_valu,
+                clock_ghz=ghz, simds=1024, alu_ms_per_step=alu_ms, exclusive_ms_per_step=kms, frac=(alu_ms / kms if kms > 0 else None), source=src)
 
 
 def tree_hash():

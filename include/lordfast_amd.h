@@ -175,6 +175,8 @@ typedef struct {
     /* the alignment group's kernels one by one (HIP events): lf_edlib_rsweep_kernel (both modes), lf_edlib_tb_kernel, the
      * Hirschberg levels (incl. their readbacks), request binning */
     float ms_k_rsweep, ms_k_tb, ms_k_hirsch, ms_k_bin;
+    uint64_t hirsch_bytes;                              /* sum over the problems above edlib's traceback switch of (q + ceil(t/4) + q + t): what the Hirschberg levels read and write */
+    uint64_t n_host_waits, n_chunks;                    /* host waits for a stream / event on the chunk drivers' threads, and the chunks they drove */
 } lf_stats_t;
 
 int  lf_map_batch(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,

@@ -88,39 +88,39 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
         /* the tile: the K steps of row j for block b; step k works on column cbase + k */
         const uint32_t j = !act ? 0 : (c - 1 + b) / K;
         const int cbase = (int)(j * K) - (int)b + 1;
-        /* unconditional loads from clamped addresses: all in flight together */
-        const uint32_t jm = j > 0 ? j - 1 : 0;
-        const int ln = lane0 + (int)b;
-        const lf_hist_t est = ck[(size_t)jm * ROW + ln];
-        const uint32_t craw = reinterpret_cast<const uint32_t *>(ck + (size_t)j * ROW + 64)[16 + ln];
-        const uint32_t tok16 = lf_pac16(S.pac, pr.tstart + (int64_t)dt * ((int64_t)cbase - 1), dt, ct, pac_syms);
-        const uint64_t Pv0 = j > 0 ? est.pv : ~0ull, Mv0 = j > 0 ? est.ph : 0ull;      /* column 0 */
-        const uint32_t cw = b > 0 ? craw : 0x55555555u;                            /* block 0: +1 enters every column */
-        /* the parts of the tile, right one first.  A part is replayed only when some path of the wavefront is in it; a replayed
-         * step is one LDS read (match mask), the block step, one LDS write -- the test for columns in front of the block's first
-         * one (col < 1: only in the first tile of a block below the first) is compiled in only when some lane needs it */
-        auto part = [&](auto half_tag, auto guard_tag) {
-            constexpr int half = decltype(half_tag)::value;
-            constexpr bool GUARD = decltype(guard_tag)::value;
-            const int h0 = cbase + half * HK;                                   /* first column of the part */
-            const bool in_half = r > 0 && c > 0 && ((r - 1) >> 6) == b && (int)c >= h0 && (int)c < h0 + HK && (act);
-            if (!lf_any(in_half)) return;
-            uint64_t Pv = Pv0, Mv = Mv0;
+        /* the block's state in front of the row, the carries it received during the row and the row's 32 target symbols: four loads in
+         * flight together, from clamped addresses */
+        const lf_hist_t *row = ck + (size_t)j * ROW;
+        const lf_hist_t est = row[lane0 + (int)b];
+        const uint64_t craw = reinterpret_cast<const uint64_t *>(row + 64)[lane0 + (int)b];
+        const uint32_t tokA = lf_pac16(S.pac, pr.tstart + (int64_t)dt * ((int64_t)cbase - 1), dt, ct, pac_syms);
+        const uint32_t tokB = lf_pac16(S.pac, pr.tstart + (int64_t)dt * ((int64_t)cbase + 15), dt, ct, pac_syms);
+        const uint64_t tok = (uint64_t)tokA | ((uint64_t)tokB << 32);
+        const uint64_t cw = b > 0 ? craw : 0x5555555555555555ull;                /* block 0: +1 enters every column */
+        auto in_part = [&](int p) -> bool { const int h0 = cbase + p * HK; return act && r > 0 && c > 0 && ((r - 1) >> 6) == b && (int)c >= h0 && (int)c < h0 + HK; };
+        /* steps FROM .. TO - 1 of the tile; (Pv, Ph) of the columns from step ST on go to the lane's own LDS slots (no barrier).  The test for
+         * columns in front of the block's first one (col < 1: only in the first tile of a block below the first) is compiled in only when some
+         * lane needs it */
+        auto replay = [&](auto from_c, auto to_c, auto store_c, auto guard_c, uint64_t &Pv, uint64_t &Mv) {
+            constexpr int FROM = decltype(from_c)::value, TO = decltype(to_c)::value; constexpr bool STORE = decltype(store_c)::value, GUARD = decltype(guard_c)::value;
 #pragma unroll
-            for (int k = 0; k < HK + half * HK; k++) {
-                const uint32_t tk = (tok16 >> (2 * k)) & 3u;
+            for (int k = FROM; k < TO; k++) {
+                const uint32_t tk = (uint32_t)(tok >> (2 * k)) & 3u;
                 const uint64_t Eq = s_peq[tk * 64 + lane];
                 uint64_t nPv = Pv, nMv = Mv, ph, mh;
-                (void)lf_myers_step(nPv, nMv, Eq, (cw >> (2 * k)) & 3u, ph, mh);
+                (void)lf_myers_step(nPv, nMv, Eq, (uint32_t)(cw >> (2 * k)) & 3u, ph, mh);
                 if (GUARD) { const bool v = cbase + k >= 1; Pv = v ? nPv : Pv; Mv = v ? nMv : Mv; }       /* the block starts at column 1 */
                 else { Pv = nPv; Mv = nMv; }
-                if (k >= half * HK) s_tile[(k - half * HK) * 64 + lane] = make_ulonglong2(Pv, ph);      /* the lane's own slots: no barrier */
+                if (STORE) s_tile[(k - FROM) * 64 + lane] = make_ulonglong2(Pv, ph);
             }
-            /* walk: ONE MOVE per trip for every lane that is still inside the part (its column's (Pv, Ph) comes out of the
-             * lane's LDS slots).  Unrolled over the columns, with the Up moves of a column in an inner loop, the wavefront paid
-             * every column's longest Up run among its 64 paths: ~2.2 trips per column for ~1.05 moves per path. */
+        };
+        /* walk through part p: ONE MOVE per trip for every lane that is still inside the part (its column's (Pv, Ph) comes out of the
+         * lane's LDS slots).  Unrolled over the columns, with the Up moves of a column in an inner loop, the wavefront paid every column's
+         * longest Up run among its 64 paths: ~2.2 trips per column for ~1.05 moves per path. */
+        auto walk = [&](int p) {
+            const int h0 = cbase + p * HK;
             const int cmin = h0 < 1 ? 1 : h0;
-            bool inh = in_half;
+            bool inh = in_part(p);
             while (lf_any(inh)) {
                 if (inh) {
                     const int k = (int)c - h0;
@@ -128,10 +128,9 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
                     const int bit = (int)((r - 1) & 63);
                     const uint32_t up = (uint32_t)(pp.x >> bit) & 1u, lf = ((uint32_t)(pp.y >> bit) & 1u) & ~up, dg = (up | lf) ^ 1u;
                     uint32_t op = up ? 1u : (lf ? 2u : 0u);      /* Up -> Left -> Diagonal (lib/edlib/edlib.cpp:950,984,1015) */
-                    /* match or mismatch of a diagonal move: both bases are in registers -- the query's row in the block's bit
-                     * planes, the target's column in the tile's symbol word.  (Round 2 left every diagonal move as 0 and made
-                     * the renderer fetch and compare the bases: two dependent loads per 64-op tile there.) */
-                    const uint32_t tcode = (tok16 >> (2 * (half * HK + k))) & 3u;
+                    /* match or mismatch of a diagonal move: both bases are in registers -- the query's row in the block's bit planes, the
+                     * target's column in the tile's symbol word */
+                    const uint32_t tcode = (uint32_t)(tok >> (2 * (p * HK + k))) & 3u;
                     const uint32_t same = (uint32_t)(valid >> bit) & ~((uint32_t)(lo >> bit) ^ tcode) & ~((uint32_t)(hi >> bit) ^ (tcode >> 1)) & 1u;
                     op = (dg & (same ^ 1u)) ? 3u : op;
                     em.put(op);
@@ -140,13 +139,38 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
                 }
             }
         };
-        auto parts = [&](auto guard_tag) {
-            if constexpr (NPART > 3) part(std::integral_constant<int, 3>{}, guard_tag);
-            if constexpr (NPART > 2) part(std::integral_constant<int, 2>{}, guard_tag);
-            if constexpr (NPART > 1) part(std::integral_constant<int, 1>{}, guard_tag);
-            part(std::integral_constant<int, 0>{}, guard_tag);
+        /* The parts are walked right to left.  The state in front of part p is the tile's start state stepped through parts 0 .. p - 1:
+         * those boundary states are made ONCE per tile (up to the rightmost part some path of the wavefront is in) and kept in registers,
+         * then every part that holds a path is replayed from its own boundary -- 24 + 8 x (parts in use) block steps per tile instead of
+         * 8 + 16 + 24 + 32. */
+        auto tile = [&](auto guard_c) {
+            int pmax = -1;
+#pragma unroll
+            for (int p = NPART - 1; p >= 0; p--) if (pmax < 0 && lf_any(in_part(p))) pmax = p;
+            if (pmax < 0) return;
+            uint64_t sPv[NPART], sMv[NPART];
+            sPv[0] = est.pv; sMv[0] = est.ph;
+            uint64_t Pv = est.pv, Mv = est.ph;
+            auto bound = [&](auto p_c) {
+                constexpr int p = decltype(p_c)::value;
+                if constexpr (p + 1 < NPART) {
+                    if (p < pmax) { replay(std::integral_constant<int, p * HK>{}, std::integral_constant<int, (p + 1) * HK>{}, std::false_type{}, guard_c, Pv, Mv); sPv[p + 1] = Pv; sMv[p + 1] = Mv; }
+                }
+            };
+            bound(std::integral_constant<int, 0>{}); bound(std::integral_constant<int, 1>{}); bound(std::integral_constant<int, 2>{});
+            auto part = [&](auto p_c) {
+                constexpr int p = decltype(p_c)::value;
+                if constexpr (p < NPART) {
+                    if (p <= pmax && lf_any(in_part(p))) {
+                        uint64_t qPv = sPv[p], qMv = sMv[p];
+                        replay(std::integral_constant<int, p * HK>{}, std::integral_constant<int, (p + 1) * HK>{}, std::true_type{}, guard_c, qPv, qMv);
+                        walk(p);
+                    }
+                }
+            };
+            part(std::integral_constant<int, 3>{}); part(std::integral_constant<int, 2>{}); part(std::integral_constant<int, 1>{}); part(std::integral_constant<int, 0>{});
         };
-        if (lf_any(act && cbase < 1)) parts(std::true_type{}); else parts(std::false_type{});
+        if (lf_any(act && cbase < 1)) tile(std::true_type{}); else tile(std::false_type{});
         {   /* the path climbed into the block above: its planes are requested now, used by the next tile */
             const uint32_t nb = r > 0 ? (r - 1) >> 6 : 0;
             if (nb != cur_b) { load_planes(nb); cur_b = nb; }
@@ -503,7 +527,7 @@ __host__ __device__ __forceinline__ uint32_t lf_class_key(const lf_aln_desc_t &x
     const uint32_t m16 = x.m < 0xffffu ? x.m : 0xffffu;
     return ((uint32_t)c << 28) | (c == 1 ? ((uint32_t)(x.mode ? 1u : 0u) << 23) | (((x.n + 63) >> 6) << 16) : 0u) | m16;
 }
-/* checkpoint entries of one rsweep wave: the planes, then one row per 16 steps (+ the partial last one) */
+/* checkpoint entries of one rsweep wave: the planes, then one row per 32 steps (+ the partial last one) */
 __host__ __device__ __forceinline__ uint64_t lf_rwave_entries(uint32_t nb, uint32_t m_max) { return LF_PLANE_ENTRIES + (uint64_t)((m_max + nb - 1 + LF_RSTEPS - 1) / LF_RSTEPS + 1) * (uint32_t)LF_RROW; }
 /* ... of a G 64 / KB wave (one problem) */
 __host__ __device__ __forceinline__ uint64_t lf_kbwave_entries(int kb, int k, uint32_t m) { return (((uint64_t)m + 64) / (uint32_t)k + 1) * (uint64_t)lf_sweep_row(kb); }
@@ -859,10 +883,9 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         RA.wave0 = nw_nw; RA.n_waves = nw_shw; lf_rsweep_launch(cs[1], true, RA);
         HIPCHK(hipEventRecord(bd[2], cs[1]));
         {
-            /* columns per replayed part of a 16-step tile: 8 (two parts, 8 KiB of LDS per wavefront) or 4 (four parts, 4 KiB: twice the wavefronts per CU, 5 / 3 of the replayed steps) */
+            /* columns per replayed part of a 32-step tile: 8 (four parts, 8 KiB of LDS per wavefront) or 16 (two parts, 16 KiB) */
             const int tb_hk = getenv("LF_TB_HK") ? atoi(getenv("LF_TB_HK")) : 8;
             if (tb_hk == 16) hipLaunchKernelGGL(lf_edlib_tb_kernel<16>, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, D->pac_syms, d_hist, d_ops, d_end, d_len);
-            else if (tb_hk == 4) hipLaunchKernelGGL(lf_edlib_tb_kernel<4>, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, D->pac_syms, d_hist, d_ops, d_end, d_len);
             else hipLaunchKernelGGL(lf_edlib_tb_kernel<8>, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, D->pac_syms, d_hist, d_ops, d_end, d_len);
         }
         HIPCHK(hipEventRecord(bd[3], cs[1]));

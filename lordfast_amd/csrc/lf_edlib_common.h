@@ -187,10 +187,13 @@ __device__ __forceinline__ uint32_t lf_pac16(const uint8_t *__restrict__ pac, in
     return comp ? ~v : v;
 }
 
-/* checkpoint row of the one-block-per-lane forward kernel (lf_rsweep.hip), in 16-byte entries: 64 x (Pv, Mv), 64 carry bytes,
- * 64 x u32 received carries.  One row per 16 sweep steps. */
-#define LF_RROW 84
-#define LF_RSTEPS 16
+/* checkpoint row of the one-block-per-lane forward kernel (lf_rsweep.hip): ONE ROW PER 32 SWEEP STEPS = 96 16-byte units: 64 x (Pv, Mv)
+ * in FRONT of the row's first step, then 64 x u64 = the 32 two-bit carries every lane received during the row.  Both parts are written
+ * coalesced (a wavefront stores 1 KiB + 2 x 256 B per 32 steps: 48 bytes per step instead of 84), and a path's tile is two 32-byte
+ * sectors of ONE row: state and carries of its block.  (Rounds 2 - 4: a row per 16 steps with the state BEHIND it, so that a tile
+ * needed two rows; a 32-byte entry per lane was tried in round 5 and cost the forward pass its coalesced stores.) */
+#define LF_RROW 96           /* 16-byte units per row */
+#define LF_RSTEPS 32
 
 /* lane l receives lane l-1's value (lane 0: 0): the horizontal carry of the anti-diagonal sweeps.  DPP wave_shr:1 is a
  * VALU move; __shfl_up goes through the LDS crossbar (ds_bpermute) and sits on the per-step dependency chain. */

@@ -286,8 +286,10 @@ __device__ __forceinline__ uint32_t lf_wave_max_u32(uint32_t v)
 #include <stdlib.h>
 #include <time.h>
 extern "C" void *lfg_thread_wait_event(int device);
+extern "C" void lfg_count_wait(void);
 static inline hipError_t lf_stream_wait(hipStream_t s)
 {
+    lfg_count_wait();
     static const bool spin = getenv("LF_SPIN_WAIT") != nullptr;
     static const long spin_us = getenv("LF_SPIN_US") ? atol(getenv("LF_SPIN_US")) : 3000;
     int dev = -1;

@@ -96,6 +96,7 @@ void  lfg_set_lane(int lane);          /* calling thread drives lane 0 or 1 (own
 int   lfg_get_lane(void);
 void  lfg_phase(const char *file, int line);      /* LF_WATCHDOG: where a lane is */
 void  lfg_phase_dump(void);
+uint64_t lfg_take_waits(void);                     /* host waits of the calling thread since the last call */
 void  lfg_quiesce(int device);                     /* per-stream waits before the runtime's own device-wide ones */
 void  lfg_drain_check(int device);                 /* LF_WATCHDOG: name the stream that never drains */
 void *lfg_lane_stream(int device, int which);   /* persistent hipStream_t of the calling thread's lane */

@@ -101,6 +101,10 @@ struct lf_wev_holder {
     ~lf_wev_holder() { std::lock_guard<std::mutex> g(g_wev_mu); for (int d = 0; d < MAX_DEV; d++) if (ev[d]) g_wev_pool[d].push_back(ev[d]); }
 };
 static thread_local lf_wev_holder t_wev;
+/* host waits of the calling thread since it last asked (lf_stats_t.n_host_waits: a chunk's launch chain is judged by them) */
+static thread_local uint64_t t_waits = 0;
+extern "C" void lfg_count_wait(void) { t_waits++; }
+extern "C" uint64_t lfg_take_waits(void) { const uint64_t w = t_waits; t_waits = 0; return w; }
 extern "C" void *lfg_thread_wait_event(int device)
 {
     if (device < 0 || device >= MAX_DEV) return nullptr;

@@ -241,6 +241,8 @@ int map_chunk(ctx_t *cx)
             } else {
             /* the lanes of a step all start with this copy: one at a time, with every pool thread on it, so that the first lane's
              * bases are ready (and on their way, see lfg_seed_src) after 1 / 8 of the time instead of all lanes' after all of it */
+            /* (process-wide on purpose: the turn is for the process-wide worker pool's CPU time, and it is never held across a GPU wait;
+             * the turn for the host LINK is per device, lfg_seed_any) */
             static pthread_mutex_t concat_turn = PTHREAD_MUTEX_INITIALIZER;
             /* Packed upload: the pool threads turn the reads into the three bit planes the alignment kernels work on anyway
              * (lo / hi / valid: 3 / 8 of the bytes; the device rebuilds the bytes for the seed search and the SAM writer) plus a
@@ -380,6 +382,7 @@ extend:
             st->ms_k_edlib += ms; st->n_edlib_problems += W.n_desc; st->edlib_launches += 1; st->ops_bytes += W.ops_total;
             if (W.n_desc) { float bd[4]; lfg_edlib_breakdown(bd); st->ms_k_rsweep += bd[0]; st->ms_k_tb += bd[1]; st->ms_k_hirsch += bd[2]; st->ms_k_bin += bd[3]; }
             st->ext_bytes += W.ext_bytes; st->dp_block_steps += W.block_steps;
+            st->hirsch_bytes += 2 * W.hc.sum_n + W.hc.sum_m + (W.hc.sum_m + 3) / 4;
             int n_rare = 0;
             for (k = 0; k < nj; k++) {
                 job_t *j = owner[k];
@@ -480,6 +483,8 @@ extend:
             cx->ed_rounds[cx->n_ed_rounds++] = R;
             if (rc != LF_OK) return rc;
             st->ms_k_edlib += ms; st->n_edlib_problems += (uint64_t)nd; st->edlib_launches += 1; st->ops_bytes += ops_total;
+            for (int i = 0; i < nd; i++) if (desc[i].n && desc[i].m && 20ull * ((desc[i].n + 63) / 64) * desc[i].m + 8ull * desc[i].m >= 1024 * 1024)      /* edlib's traceback switch (lib/edlib/edlib.cpp:1117-1119) */
+                st->hirsch_bytes += 2ull * desc[i].n + desc[i].m + (desc[i].m + 3) / 4;
             { float bd[4]; lfg_edlib_breakdown(bd); st->ms_k_rsweep += bd[0]; st->ms_k_tb += bd[1]; st->ms_k_hirsch += bd[2]; st->ms_k_bin += bd[3]; }
         }
         if (nk) {

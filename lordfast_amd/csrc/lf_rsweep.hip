@@ -22,7 +22,7 @@
  *     immediates; ~45 instructions per block step (sweep kernels of round 2: ~80), ~50 registers: 8 wavefronts per SIMD.
  *
  * Output: distance / end column, and -- for lf_edlib_tb_kernel, one lane per path -- the wave's planes and one checkpoint row
- * per 16 steps: (Pv, Mv) of every lane, the pending carry, the 16 two-bit carries the lane received during the row.
+ * per 32 steps: (Pv, Mv) of every lane in front of the row, then the 32 two-bit carries every lane received during it.
  */
 #include "lf_edlib_common.h"
 #include "lf_rsweep.h"
@@ -159,13 +159,8 @@ lf_edlib_rsweep_kernel(lf_rsw_args A)
                 }
             }
             if (k == 15) {
-                /* one checkpoint row per 16 steps: (Pv, Mv) of every lane, the pending carry, the 16 two-bit carries the lane received */
-                const int s = s0 + 15;
-                if (any_ck && s < ((steps_max + 15) & ~15)) {
-                    lf_hist_t *row = ck + (size_t)(s >> 4) * LF_RROW;
-                    if (s < steps_max) { lf_hist_t e; e.pv = Pv; e.ph = Mv; row[lane] = e; reinterpret_cast<unsigned char *>(row + 64)[lane] = (unsigned char)hout; }
-                    reinterpret_cast<uint32_t *>(row + 64)[16 + lane] = cw;
-                }
+                /* the 16 two-bit carries the lane received: one half of the row entry's carry word */
+                if (any_ck) reinterpret_cast<uint32_t *>(ck + (size_t)(s0 >> 5) * LF_RROW + 64)[2 * lane + ((s0 >> 4) & 1)] = cw;
                 cw = 0;
             }
         }
@@ -174,6 +169,8 @@ lf_edlib_rsweep_kernel(lf_rsw_args A)
         /* the lane's next 16 target symbols: stream position s - gl */
         const int64_t p = (int64_t)s0 - gl;
         const uint32_t V = lf_pac16(A.pac, pr.tstart + (int64_t)dt * p, dt, ct, A.pac_syms);
+        /* a row starts: the state in front of it */
+        if (any_ck && (s0 & 31) == 0) { lf_hist_t e; e.pv = Pv; e.ph = Mv; ck[(size_t)(s0 >> 5) * LF_RROW + lane] = e; }
         const bool partial = mine && (p < 0 || p + 15 >= (int64_t)m);       /* (lanes without a block compute on dead registers) */
         if (!lf_any(partial)) steps16(std::true_type{}, s0, V);
         else steps16(std::false_type{}, s0, V);

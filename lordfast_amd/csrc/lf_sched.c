@@ -183,6 +183,9 @@ typedef struct {
     lf_stats_t st[LF_MAX_LANES];
 } batch_t;
 
+#ifndef LF_CHUNK_RAMP_DEFAULT
+#define LF_CHUNK_RAMP_DEFAULT 0.25
+#endif
 static void merge_stats(lf_stats_t *d, const lf_stats_t *a)
 {
     d->ms_seed += a->ms_seed; d->ms_vote += a->ms_vote; d->ms_chain += a->ms_chain; d->ms_extend += a->ms_extend; d->ms_sam += a->ms_sam;
@@ -195,6 +198,7 @@ static void merge_stats(lf_stats_t *d, const lf_stats_t *a)
     d->dp_block_steps += a->dp_block_steps; d->ms_render += a->ms_render; d->ms_k_render += a->ms_k_render; d->ms_k_vote += a->ms_k_vote; d->ops_bytes += a->ops_bytes; d->n_req_seeds += a->n_req_seeds; d->n_tie_requests += a->n_tie_requests; d->render_bytes += a->render_bytes; d->render_launches += a->render_launches;
     d->ksw_bytes += a->ksw_bytes;
     d->ms_k_rsweep += a->ms_k_rsweep; d->ms_k_tb += a->ms_k_tb; d->ms_k_hirsch += a->ms_k_hirsch; d->ms_k_bin += a->ms_k_bin;
+    d->hirsch_bytes += a->hirsch_bytes; d->n_host_waits += a->n_host_waits; d->n_chunks += a->n_chunks;
 }
 
 /* base offset of a chunk's text = the sizes of all chunks of earlier reads.  block == 0: returns 0 when one of them has not
@@ -321,7 +325,9 @@ static void *lane_main(void *arg_)
             chunk_bases += r->len;
         }
         double tch = now_ms();
+        (void)lfg_take_waits();
         int rc = map_chunk(&cx);
+        st->n_host_waits += lfg_take_waits(); st->n_chunks += 1;
         if (rc == LF_RC_SPLIT) {
             /* cut the chunk: this entry keeps the first half, the second half becomes a new entry that this lane maps
              * next.  The new entry is registered before the first half publishes its size, so every chunk behind it
@@ -556,9 +562,24 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
      * chunks small so that the kernels start earlier (experiment: the small chunks' fixed costs ate the gain). */
     int first_reads = 0;         /* measured (100 k reads, host boundary): no ramp 109.5 ms, a third of a chunk 115.0, 1 024 reads 111.1 -- off; the uploads take turns instead (lf_seed.hip) */
     if (getenv("LF_FIRST_CHUNK_READS")) first_reads = atoi(getenv("LF_FIRST_CHUNK_READS"));
+    /* Pinned host batches, one chunk per lane: the chunks GROW along the batch.  A chunk's place in the output is the sum of the sizes of
+     * the chunks in front of it; with equal chunks the lanes finish together, in any order, and the SAM text of all of them crosses the
+     * link at the very end (17 ms of an 88 ms step, profiles/r04_waits/).  With chunk k about (1 + ramp (2 k / (L - 1) - 1)) times the mean
+     * the lanes finish in chunk order: every chunk but the last leaves while the larger ones are still being mapped.  LF_CHUNK_RAMP=<percent>. */
+    double ramp = 0.0;
+    if (B.holes && !getenv("LF_CHUNK_READS") && n_lanes >= 2 && n > 2048 && (n + n_lanes - 1) / n_lanes >= 6250) {
+        ramp = getenv("LF_CHUNK_RAMP") ? atof(getenv("LF_CHUNK_RAMP")) / 100.0 : LF_CHUNK_RAMP_DEFAULT;
+        if (ramp < 0) ramp = 0; if (ramp > 0.9) ramp = 0.9;
+    }
     for (int i0 = 0; i0 < n; ) {
         int i1 = i0; uint64_t bases = 0;
-        const int lim = (first_reads > 0 && B.n_chunks < n_lanes) ? first_reads : CHUNK_READS;
+        int lim = (first_reads > 0 && B.n_chunks < n_lanes) ? first_reads : CHUNK_READS;
+        if (ramp > 0) {
+            const int k = B.n_chunks;
+            if (k >= n_lanes - 1) lim = n - i0;                         /* the last lane's chunk takes what is left */
+            else lim = (int)((double)n / n_lanes * (1.0 + ramp * (2.0 * k / (n_lanes - 1) - 1.0)) + 0.5);
+            if (lim < 1) lim = 1;
+        }
         while (i1 < n && i1 - i0 < lim && bases < CHUNK_BASES) { bases += lens[i1]; i1++; }
         B.chunks[B.n_chunks].i0 = i0; B.chunks[B.n_chunks].i1 = i1; B.n_chunks++;
         i0 = i1;

@@ -742,7 +742,11 @@ static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_r
     const uint64_t qw = lf_plane_words(n_bases);
     uint64_t *d_planes = DSLOT(uint64_t, 14, 3 * qw * 8);
     if (!d_planes) return LF_ERR_NOMEM;
-    static std::mutex upload_turn;
+    /* one turn per DEVICE (a host link each): lanes of different devices in one process (lf_map_batch_multi) do not wait for each other.
+     * Before a lane asks for its turn it lets its own stream drain: the stream may still be waiting for the lane's previous chunk's SAM
+     * writer (which reads the buffers the upload overwrites), and that wait must not be spent holding the turn. */
+    static std::mutex upload_turns[64];
+    std::mutex &upload_turn = upload_turns[dv & 63];
     static const bool turns = !(getenv("LF_UPLOAD_TURNS") && atoi(getenv("LF_UPLOAD_TURNS")) == 0);
     if (pk) {
         /* the batch arrives as bit planes (3 / 8 of the bytes): they are what the alignment kernels want anyway; the seed search
@@ -751,6 +755,7 @@ static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_r
         uint64_t *d_xpos = DSLOT(uint64_t, 2, pk->n_exc * 8 + 16); uint8_t *d_xbyte = DSLOT(uint8_t, 8, pk->n_exc + 16);
         if (!d_xpos || !d_xbyte) return LF_ERR_NOMEM;
         {
+            if (turns) HIPCHK(hipStreamSynchronize(s));
             std::unique_lock<std::mutex> g(upload_turn, std::defer_lock);
             if (turns) g.lock();
             HIPCHK(hipMemcpyAsync(d_planes, pk->planes, 3 * qw * 8, hipMemcpyHostToDevice, s));
@@ -772,6 +777,7 @@ static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_r
          * get its bases after ~8 x the time of one copy.  In turn, the first lane's kernels start after one copy and the other
          * lanes' copies run under them.  (One stream wait per chunk; LF_UPLOAD_TURNS=0 switches it off for A / B runs.) */
         if (turns) {
+            HIPCHK(hipStreamSynchronize(s));
             std::lock_guard<std::mutex> g(upload_turn);
             HIPCHK(hipMemcpyAsync(d_reads, reads, n_bases, hipMemcpyHostToDevice, s));
             HIPCHK(hipStreamSynchronize(s));

@@ -25,10 +25,17 @@ def make_genome(total_bp: int, n_contigs: int = 3, seed: int = 11, repeat_frac: 
     `n_families` repeat families (300 bp - 6 kbp, 5-20 % divergence) to emulate repeat content.
     profile "grch38like": about half of the sequence is repeats with the copy-number structure of a human genome --
     one 300 bp family with ~10^6 copies per 3 Gbp (Alu-like, 10 % of the sequence, 5-15 % divergence), twenty 1-6 kbp
-    families (LINE-like, 17 %, truncated copies), and `n_families` low-copy families for the rest."""
+    families (LINE-like, 17 %, truncated copies), and `n_families` low-copy families for the rest.
+    profile "t2tlike": grch38like plus what a telomere-to-telomere assembly adds -- one centromeric satellite array per contig (a
+    171 bp monomer family in higher-order repeats of 4 - 16 monomers, monomers 20 - 30 % apart, HOR copies 0.1 - 2 % apart, arrays
+    summing to ~6 % of the sequence) and simple-sequence arrays (a 5 bp unit at ~5 % divergence, ~1 %)."""
     rng = np.random.default_rng(seed)
     if profile == "grch38like":
         return _make_genome_grch38like(total_bp, n_contigs, rng, max(n_families, 100))
+    if profile == "t2tlike":
+        contigs = _make_genome_grch38like(total_bp, n_contigs, rng, max(n_families, 100))
+        _add_satellites(contigs, total_bp, rng)
+        return contigs
     # contig lengths: geometric-ish split so contigs differ in size
     w = rng.uniform(0.5, 1.5, size=n_contigs)
     lens = np.maximum((w / w.sum() * total_bp).astype(np.int64), 2000)
@@ -91,6 +98,66 @@ def _make_genome_grch38like(total_bp, n_contigs, rng, n_families):
     paste([rnd(int(rng.integers(300, 6001))) for _ in range(n_families)], int(total_bp * 0.23), 0.05, 0.20, False)
     paste([rnd(int(rng.integers(1000, 6001))) for _ in range(20)], int(total_bp * 0.17), 0.03, 0.15, True)
     paste([rnd(300)], int(total_bp * 0.10), 0.05, 0.15, False)                       # pasted last: the youngest family
+    return contigs
+
+
+def _add_satellites(contigs, total_bp, rng):
+    """centromeric alpha-satellite-like arrays and simple-sequence arrays, pasted over the middle of every contig (in place)"""
+    cons = _ACGT[rng.integers(0, 4, size=171, dtype=np.uint8)]
+    n_contigs = len(contigs)
+    for ci, (_, s) in enumerate(contigs):
+        arr_len = int(min(len(s) * 0.5, max(20000, total_bp * 0.06 / n_contigs)))
+        if len(s) < 4 * 171 or arr_len < 4 * 171:
+            continue
+        k = int(rng.integers(4, 17))
+        monos = []
+        for _ in range(k):                                      # the HOR's monomers: 20 - 30 % from the consensus
+            mo = cons.copy()
+            mut = rng.random(171) < rng.uniform(0.20, 0.30)
+            mo[mut] = _ACGT[rng.integers(0, 4, size=int(mut.sum()), dtype=np.uint8)]
+            monos.append(mo)
+        hor = np.concatenate(monos)
+        reps = arr_len // len(hor) + 1
+        arr = np.tile(hor, reps)[:arr_len].copy()
+        # HOR copies 0.1 - 2 % apart: divergence drawn per copy
+        for a in range(0, arr_len, len(hor)):
+            b = min(arr_len, a + len(hor))
+            mut = rng.random(b - a) < rng.uniform(0.001, 0.02)
+            if mut.any():
+                arr[a:b][mut] = _ACGT[rng.integers(0, 4, size=int(mut.sum()), dtype=np.uint8)]
+        p = (len(s) - arr_len) // 2
+        s[p:p + arr_len] = arr
+        # a simple-sequence array next to it
+        ss_len = int(min(len(s) * 0.1, max(2000, total_bp * 0.01 / n_contigs)))
+        unit = _ACGT[rng.integers(0, 4, size=5, dtype=np.uint8)]
+        ss = np.tile(unit, ss_len // 5 + 1)[:ss_len].copy()
+        mut = rng.random(ss_len) < 0.05
+        ss[mut] = _ACGT[rng.integers(0, 4, size=int(mut.sum()), dtype=np.uint8)]
+        q = p + arr_len
+        if q + ss_len < len(s):
+            s[q:q + ss_len] = ss
+
+
+def read_fasta(path: str, min_contig: int = 2000) -> list[tuple[str, np.ndarray]]:
+    """A reference FASTA (plain or gzip) as (name, uint8 array) contigs, upper-cased; contigs shorter than min_contig are dropped."""
+    import gzip
+    op = gzip.open if path.endswith(".gz") else open
+    contigs, name, parts = [], None, []
+
+    def flush():
+        if name is not None and parts:
+            a = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+            a[(a >= 97) & (a <= 122)] -= 32
+            if len(a) >= min_contig:
+                contigs.append((name, a))
+    with op(path, "rb") as fh:
+        for line in fh:
+            if line.startswith(b">"):
+                flush()
+                name, parts = line[1:].split()[0].decode(), []
+            else:
+                parts.append(line.strip())
+    flush()
     return contigs
 
 
@@ -262,10 +329,12 @@ def mutate(seq: np.ndarray, err: float, rng, mix=(0.15, 0.50, 0.35)) -> np.ndarr
 
 
 def make_reads(contigs, n_reads: int, mean_len: int, err: float, seed: int = 2024,
-               mix=(0.15, 0.50, 0.35), min_len: int = 1000, sigma: float = 0.35, segdups=None, dup_frac: float = 0.0):
+               mix=(0.15, 0.50, 0.35), min_len: int = 1000, sigma: float = 0.35, segdups=None, dup_frac: float = 0.0,
+               acgt_only: bool = False):
     """Returns list of (name, seq_bytes). Name carries the true origin: r<i>_<contig>_<pos>_<strand>.
     segdups (add_segdups) + dup_frac: that fraction of the reads lies inside a copy of a duplicated segment (name ends in
-    `_dup`); with dup_frac == 0 the random stream, hence the read set, is what it always was."""
+    `_dup`); with dup_frac == 0 the random stream, hence the read set, is what it always was.  acgt_only: reads off a real reference
+    (bench.py --ref-fasta) avoid its N runs."""
     rng = np.random.default_rng(seed)
     rng_dup = np.random.default_rng(seed + 100003) if (segdups and dup_frac > 0) else None
     clens = np.array([len(s) for _, s in contigs], dtype=np.float64)
@@ -289,6 +358,13 @@ def make_reads(contigs, n_reads: int, mean_len: int, err: float, seed: int = 202
             p = p0 + int(rng_dup.integers(0, sl - ln + 1))
             tag = "_dup"
         frag = s[p:p + ln]
+        if acgt_only:            # a real reference holds N runs: a read is drawn again until its origin is (almost) free of them
+            for _ in range(50):
+                if np.isin(frag, _ACGT).mean() > 0.99:
+                    break
+                p = int(rng.integers(0, len(s) - ln)); frag = s[p:p + ln]
+            frag = frag.copy(); bad = ~np.isin(frag, _ACGT)
+            frag[bad] = _ACGT[rng.integers(0, 4, size=int(bad.sum()), dtype=np.uint8)]
         strand = "+"
         if rng.random() < 0.5:
             frag = revcomp(frag)

@@ -28,7 +28,7 @@ rm -rf /tmp/lfp_s1 /tmp/lfp_s2 /tmp/lfp_s3
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d /tmp/lfp_s1 -- $BS > /dev/null 2> /tmp/lfp_s1.err
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d /tmp/lfp_s2 -- $BS > /dev/null 2> /tmp/lfp_s2.err
 rocprofv3 --pmc SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d /tmp/lfp_s3 -- $BS > /dev/null 2> /tmp/lfp_s3.err
-python3 profiles/tools/summarize_pmc.py $OUT/sq_counters_50k_reads.json $(ls /tmp/lfp_s1/*/*counter_collection.csv /tmp/lfp_s2/*/*counter_collection.csv /tmp/lfp_s3/*/*counter_collection.csv 2>/dev/null)
+LF_PMC_READS=50000 python3 profiles/tools/summarize_pmc.py $OUT/sq_counters_50k_reads.json $(ls /tmp/lfp_s1/*/*counter_collection.csv /tmp/lfp_s2/*/*counter_collection.csv /tmp/lfp_s3/*/*counter_collection.csv 2>/dev/null)
 unset LF_LANES LF_SERIAL_CLASSES LF_CHUNK_READS LF_CHUNK_BASES
 python3 bench.py --tree-hash > $OUT/SOURCE_TREE.txt; (git rev-parse HEAD 2>/dev/null || echo "no git on this box") >> $OUT/SOURCE_TREE.txt
 ls -la $OUT

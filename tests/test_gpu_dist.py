@@ -100,6 +100,16 @@ def test_bench_strong_scaling_two_ranks_same_records(bench_dir, one_rank_line):
     assert j["value"] > 0 and j["value_hbm_resident"] > 0
 
 
+def test_bench_exchange_keeps_two_steps_of_a_rank_in_flight(bench_dir, one_rank_line):
+    """the strong-scaling default: every rank maps two of its steps concurrently inside the exchange loop (lordfast_amd/dist.py:
+    run_pipeline, ring of three buffers); records identical to the 1-rank run; an explicit --inflight 3 too"""
+    j = _bench(bench_dir, "--gpus", "2", "--steps", "4", backend="gloo")
+    assert j["steps_in_flight"] == 2 and j["exchange"]["steps_in_flight_per_rank"] == 2 and j["exchange"]["status"] == "ok"
+    assert j["sam_md5"] == one_rank_line["sam_md5"] and j["sam_bytes"] == one_rank_line["sam_bytes"]
+    j3 = _bench(bench_dir, "--gpus", "2", "--steps", "3", "--inflight", "3", backend="gloo")
+    assert j3["exchange"]["steps_in_flight_per_rank"] == 3 and j3["sam_md5"] == one_rank_line["sam_md5"]
+
+
 def test_bench_weak_scaling_three_ranks(bench_dir, one_rank_line):
     j = _bench(bench_dir, "--gpus", "3", "--scaling", "weak", backend="gloo")
     assert j["n_gpus"] == 3 and j["scaling"] == "weak" and j["config"]["reads_total"] == 1800
@@ -112,9 +122,67 @@ def test_bench_rccl_when_two_gpus(bench_dir, one_rank_line):
     import lordfast_amd as la
     if la.device_count() < 2:
         pytest.skip("one GPU on this box: the RCCL path needs two (the gloo tests above cover the same code with host staging)")
-    j = _bench(bench_dir, "--gpus", "2", "--scaling", "strong")
+    j = _bench(bench_dir, "--gpus", "2", "--scaling", "strong", "--steps", "4")
     assert j["exchange"]["status"] == "ok" and j["exchange"]["transport"] == "nccl" and "cuda" in j["exchange"]["bulk_memory"]
+    assert j["exchange"]["steps_in_flight_per_rank"] == 2          # device tensors through PipelinedExchange / run_pipeline over RCCL
     assert j["sam_md5"] == one_rank_line["sam_md5"]
+
+
+NCCL_RING_WORKER = r'''
+import os, sys, hashlib
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from lordfast_amd import dist as lfd
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl")
+ctl = dist.new_group(backend="gloo")
+dev = torch.device("cuda", rank)
+STEPS, DEPTH = 6, 2
+def job(step):
+    rng = np.random.default_rng(900 + step)
+    n = 40 + 7 * step
+    names = [f"s{step}_r{i}".encode() for i in range(n)]
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(rng.integers(1, 20000)))) for _ in range(n)]
+    return names, seqs
+def fake_map(k, shard, out, slot):
+    b = shard.blob[:shard.nbytes].cpu().numpy().tobytes()
+    txt = b"".join(b[int(shard.name_off[i]):int(shard.name_off[i + 1]) - 1] + b"\t" + hashlib.md5(b[int(shard.seq_off[i]):int(shard.seq_off[i + 1]) - 1]).hexdigest().encode() + b"\n" for i in range(len(shard)))
+    out[:len(txt)].copy_(torch.frombuffer(bytearray(txt), dtype=torch.uint8)) if txt else None
+    torch.cuda.current_stream().synchronize()
+    return len(txt)
+px = lfd.PipelinedExchange(dist, torch, dev, ctl, read_cap=4 << 20, sam_cap=1 << 20, ring=DEPTH + 1)
+cache = {}
+def shards_of(k):
+    if k not in cache:
+        nm, sq = job(k)
+        cache[k] = lfd.make_shards(torch, nm, sq, world, dev)[0]
+    return cache[k]
+got = {}
+lfd.run_pipeline(px, STEPS, DEPTH, shards_of, fake_map, on_gathered=lambda k, t, ln: got.__setitem__(k, bytes(t[:ln].cpu().numpy().tobytes())))
+if rank == 0:
+    for k in range(STEPS):
+        nm, sq = job(k)
+        assert got[k] == b"".join(a + b"\t" + hashlib.md5(b).hexdigest().encode() + b"\n" for a, b in zip(nm, sq)), ("step", k)
+    print("NCCL_RING_OK", px.bytes_out, px.bytes_in)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_pipelined_exchange_device_tensors_over_rccl_when_two_gpus(tmp_path):
+    """PipelinedExchange / run_pipeline with device tensors through a 2-rank nccl (RCCL) group, two steps in flight: the transport the
+    N-GPU bench uses, without the mapper.  Needs two visible GPUs (tests/test_dist.py runs the same loop over gloo on the CPU)."""
+    import lordfast_amd as la
+    if la.device_count() < 2:
+        pytest.skip("one GPU on this box: the RCCL transport needs two")
+    script = tmp_path / "n.py"
+    script.write_text(NCCL_RING_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29671", str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "NCCL_RING_OK" in r.stdout
 
 
 def test_bench_inproc_two_replicas(bench_dir, one_rank_line):
