@@ -26,7 +26,7 @@ struct lf_dev_index {
     uint64_t n_sa;
     const uint32_t *bwt;        /* reference layout: per 128 symbols 4 x u64 Occ + 8 x u32 (lib/bwa/bwt.h:72-73) */
     const uint64_t *sa_sampled; /* every 32nd row (lib/bwa/bwt.c:62-84), sa[0] = -1 */
-    const uint64_t *sa_full;    /* seq_len + 1 rows, or NULL */
+    const uint8_t  *sa_full;    /* seq_len + 1 rows of FIVE bytes (positions are below 2^33: 40 bits hold them; 31 GB instead of 49.6 GB for a 3.1 Gbp genome), or NULL */
     const uint64_t *cache;      /* 4^12 x (beg,end): SA interval of every 12-mer (src/BWT.cpp:60-115) */
     const uint64_t *cache14;    /* 4^14 x (beg,end), or NULL: two search steps saved per sample when -k >= 14 (4.3 GB; large genomes) */
     const uint64_t *cache16;    /* 4^16 x (beg,end), or NULL (68.7 GB; genomes >= 2^30 symbols when HBM allows): a sample whose 16-mer occurs starts
@@ -35,6 +35,19 @@ struct lf_dev_index {
     const uint8_t  *occ2;       /* the BWT in the HBM layout of the mapping kernels (lf_occ2_* below): made IN PLACE out of `bwt` once the
                                  * tables and the full SA are built (bwt is NULL from then on); NULL while the index is being built */
 };
+
+/* full suffix array, five bytes per row (little endian); rows of one interval are contiguous: hits of a sample are 5 n consecutive bytes */
+#define LF_SA_ROW_BYTES 5
+__device__ __forceinline__ uint64_t lf_sa_full_get(const uint8_t *__restrict__ sa, uint64_t row)
+{
+    uint64_t w; __builtin_memcpy(&w, sa + row * LF_SA_ROW_BYTES, 8);      /* (the array has 8 bytes of slack behind its last row) */
+    return w & 0xFFFFFFFFFFull;
+}
+__device__ __forceinline__ void lf_sa_full_put(uint8_t *__restrict__ sa, uint64_t row, uint64_t v)
+{
+    uint8_t *p = sa + row * LF_SA_ROW_BYTES;                               /* exactly five bytes: the neighbouring rows belong to other threads */
+    const uint32_t lo = (uint32_t)v; __builtin_memcpy(p, &lo, 4); p[4] = (uint8_t)(v >> 32);
+}
 
 /* ---- the occurrence blocks as the mapping kernels read them (not bwa's file layout: nothing requires the resident form to equal
  * the one on disk).  64 bytes per 128 symbols, one HBM burst:
@@ -263,7 +276,10 @@ __device__ __forceinline__ uint64_t lf_sa_walk(const lf_dev_index &ix, uint64_t 
     return off + ix.sa_sampled[k >> 5];
 }
 
-/* wavefront maximum of an unsigned, in every lane: DPP row shifts + row broadcasts (no LDS), then one readlane */
+/* wavefront maximum of an unsigned, in every lane: DPP row shifts + row broadcasts (no LDS), then one readlane.
+ * PRECONDITION: all 64 lanes active (EXEC = ~0) -- a DPP move reads the registers of lanes that sit out a branch as they are (stale),
+ * and lane 63 must hold the reduction.  Call it outside divergent control flow (every caller does: loop bounds at the top of a
+ * kernel / of a wave-uniform loop); inside a branch use a ballot-based form instead. */
 __device__ __forceinline__ uint32_t lf_wave_max_u32(uint32_t v)
 {
     uint32_t x = v;

@@ -34,7 +34,8 @@
 struct lf_sam_dev {
     const lf_samline_t *lines; int n_lines;
     const unsigned char *reads; const uint64_t *read_off;      /* resident read batch */
-    const unsigned char *quals;                                /* same layout as reads, or NULL (FASTA: "*") */
+    const unsigned char *quals;                                /* same layout as reads, or NULL (FASTA: "*"; HOLES mode: the host has them) */
+    int has_quals;                                             /* the batch has qualities (FASTQ) -- wherever they are: decides the LAYOUT of a line */
     const char *names, *blob;                                  /* read names; side blob: SA:Z strings and literal lines */
     const char *text; const uint64_t *toffs; const uint32_t *tlens;     /* rendered CIGAR / MD: 2 per record (lengths incl. NUL) */
     const char *ctg_names; const uint32_t *ctg_name_off;       /* contig names, offsets (n_ctg + 1) */
@@ -53,7 +54,7 @@ __device__ __forceinline__ uint64_t lf_sam_line_len(const lf_sam_dev &D, const l
 {
     if (Ln.kind == LF_SL_LITERAL) return Ln.sa_len;
     const uint32_t L = (uint32_t)(D.read_off[Ln.read + 1] - D.read_off[Ln.read]);
-    const uint32_t ql = D.quals && Ln.is_fq ? L : 1u;
+    const uint32_t ql = D.has_quals && Ln.is_fq ? L : 1u;
     uint64_t n = Ln.name_len + 1;
     if (Ln.kind == LF_SL_UNMAPPED) return n + 16 /* "4\t*\t0\t0\t*\t*\t0\t0\t" */ + L + 1 + ql + D.rg_len + 1;
     n += lf_ndig(Ln.flag) + 1;
@@ -74,7 +75,7 @@ __device__ __forceinline__ void lf_sam_hole(const lf_sam_dev &D, const lf_samlin
     hoff = 0; hlen = 0;
     if (!D.holes || Ln.kind == LF_SL_LITERAL) return;
     const uint32_t L = (uint32_t)(D.read_off[Ln.read + 1] - D.read_off[Ln.read]);
-    hlen = (D.quals && Ln.is_fq) ? 2u * L + 1u : L;
+    hlen = (D.has_quals && Ln.is_fq) ? 2u * L + 1u : L;
     uint32_t n = Ln.name_len + 1u;
     if (Ln.kind == LF_SL_UNMAPPED) { hoff = n + 16u; return; }
     n += lf_ndig(Ln.flag) + 1;
@@ -114,7 +115,7 @@ lf_sam_write_kernel(lf_sam_dev D, const uint64_t *__restrict__ offs, char *__res
     auto put_seq_qual = [&]() {
         if (D.holes) {                                   /* the host fills SEQ (and QUAL) from the caller's own strings */
             w += L;
-            if (D.quals && Ln.is_fq) w += 1 + (uint64_t)L; else { put_c('\t'); put_c('*'); }
+            if (D.has_quals && Ln.is_fq) w += 1 + (uint64_t)L; else { put_c('\t'); put_c('*'); }
             return;
         }
         const unsigned char *s = D.reads + ro;
@@ -217,7 +218,7 @@ extern "C" int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, in
     /* qualities: host bytes in the resident batch's layout, or (lf_map_batch_dev) a device blob in the caller's layout.  In HOLES
      * mode the host prints them itself; the device only needs to know that they exist (a non-null pointer). */
     const bool dev_quals = !holes && (quals || d_quals_src);
-    unsigned char *d_quals = dev_quals ? SSLOT(unsigned char, 5, quals_bytes + 64) : (holes && (quals || d_quals_src)) ? reinterpret_cast<unsigned char *>(d_lines) : nullptr;
+    unsigned char *d_quals = dev_quals ? SSLOT(unsigned char, 5, quals_bytes + 64) : nullptr;      /* HOLES mode: no qualities on the device, only the fact that there are some */
     uint64_t *h = (uint64_t *)lfg_pin_slot(LF_PS_SAM0 + 0, 64);
     uint64_t *h_offs = holes ? (uint64_t *)lfg_pin_slot(LF_PS_SAM0 + 1 + (parity & 1), (N + 1) * 8 + 2 * N * 4) : nullptr;
     if (!d_lines || !d_names || !d_blob || !d_lens || !d_offs || (dev_quals && !d_quals) || !h || (holes && !h_offs)) return LF_ERR_NOMEM;
@@ -262,7 +263,7 @@ extern "C" int lfg_sam_build(const struct lf_index *ix, const lf_params_t *p, in
     lf_sam_dev D;
     D.lines = d_lines; D.n_lines = n_lines;
     D.reads = (const unsigned char *)lfg_dev_slot(dv, LF_DS_SEED0 + 0, 0); D.read_off = (const uint64_t *)lfg_dev_slot(dv, LF_DS_SEED0 + 1, 0);
-    D.quals = d_quals; D.names = d_names; D.blob = d_blob;
+    D.quals = d_quals; D.has_quals = (quals || d_quals_src) ? 1 : 0; D.names = d_names; D.blob = d_blob;
     D.text = (const char *)rt->d_text; D.toffs = (const uint64_t *)rt->d_offs; D.tlens = (const uint32_t *)rt->d_lens;
     D.ctg_names = (const char *)st->ctg_names; D.ctg_name_off = (const uint32_t *)st->ctg_name_off;
     D.rg = d_rg; D.rg_len = rg_len; D.holes = holes ? 1 : 0;

@@ -47,13 +47,13 @@ __global__ void lf_cache_level_kernel(lf_dev_index ix, const uint64_t *__restric
  * Chains have geometric lengths (mean 32, max in the hundreds), so a lane is not tied to one chain: each loop iteration
  * is ONE LF step of whatever chain the lane is on, and a lane that reaches a sampled row takes its next chain.
  * Row 0 (the sentinel suffix) is stored as -1 like the reference does (sa[0] = -1) but precedes text position seq_len - 1. */
-__global__ void lf_full_sa_kernel(lf_dev_index ix, uint64_t *__restrict__ sa_full)
+__global__ void lf_full_sa_kernel(lf_dev_index ix, uint8_t *__restrict__ sa_full)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ix.n_sa) return;
     uint64_t k = i << 5, v = ix.sa_sampled[i];
-    sa_full[k] = v;
+    lf_sa_full_put(sa_full, k, v);
     if (i == 0) v = ix.seq_len;
     for (;;) {
         k = lf_inv_psi(ix, k);
@@ -61,8 +61,8 @@ __global__ void lf_full_sa_kernel(lf_dev_index ix, uint64_t *__restrict__ sa_ful
             i += stride;
             if (i >= ix.n_sa) break;
             k = i << 5; v = ix.sa_sampled[i];
-            sa_full[k] = v;
-        } else { --v; sa_full[k] = v; }
+            lf_sa_full_put(sa_full, k, v);
+        } else { --v; lf_sa_full_put(sa_full, k, v); }
     }
 }
 
@@ -178,7 +178,7 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         const size_t need16 = (((size_t)1 << 32) + ((size_t)1 << 30)) * 16 + ((size_t)8 << 30);
-        if (t16 ? atoi(t16) != 0 : (ix->seq_len >= (1ull << 30) && free_b > need16 + ((size_t)100 << 30) + ((ix->flags & LF_IDX_FULL_SA) ? (ix->seq_len + 1) * 8 : 0))) {
+        if (t16 ? atoi(t16) != 0 : (ix->seq_len >= (1ull << 30) && free_b > need16 + ((size_t)100 << 30) + ((ix->flags & LF_IDX_FULL_SA) ? (ix->seq_len + 1) * LF_SA_ROW_BYTES : 0))) {
             rc = lfg_build_cache_table(&v, st->stream, 16, &tab);
             if (rc == LF_OK) { rc = lfg_pack_cache_table(st->stream, 16, tab); if (rc != LF_OK) (void)hipFree(tab); }
             if (rc == LF_OK) { st->cache16 = tab; v.cache16 = tab; }
@@ -188,10 +188,10 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
 
     if (ix->flags & LF_IDX_FULL_SA) {
         const uint64_t rows = ix->seq_len + 1;
-        HIPCHK(hipMalloc(&st->sa_full, rows * 8));
-        hipLaunchKernelGGL(lf_full_sa_kernel, dim3(256 * 16), dim3(256), 0, st->stream, v, (uint64_t *)st->sa_full);
+        HIPCHK(hipMalloc(&st->sa_full, rows * LF_SA_ROW_BYTES + 16));
+        hipLaunchKernelGGL(lf_full_sa_kernel, dim3(256 * 16), dim3(256), 0, st->stream, v, (uint8_t *)st->sa_full);
         HIPCHK(hipStreamSynchronize(st->stream));
-        v.sa_full = (const uint64_t *)st->sa_full;
+        v.sa_full = (const uint8_t *)st->sa_full;
     }
     {   /* everything that reads bwa's file layout is built: the blocks take the form the mapping kernels read (in place) */
         const uint64_t n_blocks = (ix->seq_len + 127) >> 7;
@@ -233,7 +233,7 @@ extern "C" int lfg_index_describe(const struct lf_index *ix, char *buf, size_t c
     if (!st || !buf || cap < 2) return LF_ERR_ARG;
     const double GB = 1e9;
     int o = snprintf(buf, cap, "BWT + Occ %.2f GB (64-byte blocks: cumulative counts + two bit planes of 128 symbols); ", ix->bwt_size * 4 / GB);
-    if (st->sa_full) o += snprintf(buf + o, o < (int)cap ? cap - o : 0, "full suffix array (u64 per row) %.1f GB; ", (ix->seq_len + 1) * 8 / GB);
+    if (st->sa_full) o += snprintf(buf + o, o < (int)cap ? cap - o : 0, "full suffix array (5 bytes per row) %.1f GB; ", (ix->seq_len + 1) * 5 / GB);
     o += snprintf(buf + o, o < (int)cap ? cap - o : 0, "sampled suffix array (every 32nd row) %.2f GB; k-mer tables: 12 (%.2f GB)", ix->n_sa * 8 / GB, (double)(1ull << 24) * 16 / GB);
     if (st->cache14) o += snprintf(buf + o, o < (int)cap ? cap - o : 0, ", 14 (%.1f GB)", (double)(1ull << 28) * 16 / GB);
     if (st->cache16) o += snprintf(buf + o, o < (int)cap ? cap - o : 0, ", 16 (%.1f GB)", (double)(1ull << 32) * 16 / GB);
@@ -611,7 +611,7 @@ lf_seed_locate_kernel(lf_dev_index ix, int n_reads, const uint64_t *__restrict__
         const int k = wbase + lo;
         const uint32_t j = h - s_rel[k], m = s_m[k], p = s_p[k], qLen = s_ql[k];
         const uint64_t row = s_sp[k] + j;
-        const uint64_t sapos = ix.sa_full ? ix.sa_full[row] : lf_sa_walk(ix, row, n_blk);
+        const uint64_t sapos = ix.sa_full ? lf_sa_full_get(ix.sa_full, row) : lf_sa_walk(ix, row, n_blk);
         n_sa++;
         uint32_t t, qp; uint8_t rv;
         if (sapos >= l_pac) { t = (uint32_t)((l_pac << 1) - sapos - m); qp = qLen - p - m; rv = 1; }

@@ -18,7 +18,6 @@
  * Integer work; the hits are read once (9 B per hit) by the vote and once per request by the gather.
  */
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <string.h>
 #include <math.h>
@@ -497,6 +496,44 @@ lf_req_sort_kernel(int n_req, const uint64_t *__restrict__ req_off, const uint32
     }
 }
 
+/* ... and the requests above 8192 seeds (a window over a satellite array: every sample of the read hits it): the same network over a
+ * scratch array in HBM (2 n words at 2 x the request's offset: the next power of two is below 2 n), one 1024-thread workgroup per
+ * request.  Rare and L2-sized; replaces the chunk-wide hipCUB radix sort such a request used to switch the whole chunk to. */
+__global__ void __launch_bounds__(1024)
+lf_req_sort_big_kernel(int n_req, const uint64_t *__restrict__ req_off, const uint32_t *__restrict__ req_n, const uint2 *__restrict__ gathered,
+                       uint2 *__restrict__ sorted, uint64_t *__restrict__ skeys_sorted, uint64_t *__restrict__ scratch, int key_by_tpos, uint32_t n_lo)
+{
+    const int q = blockIdx.x, t = threadIdx.x;
+    if (q >= n_req) return;
+    const uint32_t n = req_n[q];
+    if (n < n_lo) return;
+    const uint64_t off = req_off[q];
+    uint64_t *w = scratch + 2 * off;
+    uint32_t N = 1; while (N < n) N <<= 1;
+    for (uint32_t i = t; i < N; i += 1024) {
+        uint64_t x = ~0ull;
+        if (i < n) { const uint2 sd = gathered[off + i]; x = ((uint64_t)(key_by_tpos ? sd.x : (sd.y & 0xFFFFFu)) << 32) | i; }
+        w[i] = x;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= N; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = t; i < N; i += 1024) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint64_t a = w[i], b = w[l];
+                    if ((a > b) == ((i & k) == 0)) { w[i] = b; w[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = t; i < n; i += 1024) {
+        const uint2 sd = gathered[off + (uint32_t)w[i]];
+        sorted[off + i] = sd;
+        skeys_sorted[off + i] = key_by_tpos ? (((uint64_t)(uint32_t)q << 32) | sd.x) : (((uint64_t)(uint32_t)q << 20) | (sd.y & 0xFFFFFu));
+    }
+}
+
 /* ---- 6: equal qPos inside a request -> replay std::sort on the original order ---- */
 __global__ void lf_tie_flag_kernel(uint64_t n, const uint64_t *__restrict__ skeys_sorted, uint8_t *__restrict__ flag)
 {
@@ -773,26 +810,27 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     if (S) {
         hipLaunchKernelGGL(lf_req_gather_kernel<true>, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_req_read, d_req_win, d_req_lo, d_req_hi, d_read_off,
                            d_tpos, d_qpl, d_strand, d_req_n, (const uint64_t *)d_req_off, d_gath, d_sk, clasp ? 1 : 0);
-        void *d_tmp3 = nullptr; size_t tb4 = 0;
-        if (max_n <= 8192u) {
-            /* segmented sort in LDS: one wavefront per request up to 512 seeds (4 KiB), a 256-thread workgroup up to 8192 (64 KiB) */
-            const uint32_t small_hi = max_n < 512u ? max_n : 512u;
+        {
+            /* segmented sort in LDS: one wavefront per request up to 512 seeds (4 KiB), a 256-thread workgroup up to 8192 (64 KiB); above that
+             * (LF_REQ_SORT_BIG_FROM lowers the bound: test hook) a 1024-thread workgroup over a scratch array in HBM */
+            const uint32_t big_from = getenv("LF_REQ_SORT_BIG_FROM") ? (uint32_t)atoi(getenv("LF_REQ_SORT_BIG_FROM")) : 8193u;
+            const uint32_t lds_hi = big_from - 1u < 8192u ? big_from - 1u : 8192u;
+            const uint32_t small_hi = max_n < 512u ? max_n : 512u, hi1 = lds_hi < 512u ? lds_hi : 512u;
             uint32_t cap1 = 64; while (cap1 < small_hi) cap1 <<= 1;
             hipLaunchKernelGGL(lf_req_sort_kernel<64>, dim3((unsigned)n_req), dim3(64), (size_t)cap1 * 8, s, (int)n_req, (const uint64_t *)d_req_off, (const uint32_t *)d_req_n,
-                               (const uint2 *)d_gath, d_sorted, d_sk2, clasp ? 1 : 0, 0u, 512u);
-            if (max_n > 512u) {
-                uint32_t cap2 = 1024; while (cap2 < max_n) cap2 <<= 1;
+                               (const uint2 *)d_gath, d_sorted, d_sk2, clasp ? 1 : 0, 0u, hi1);
+            if (max_n > 512u && lds_hi > 512u) {
+                const uint32_t top = max_n < lds_hi ? max_n : lds_hi;
+                uint32_t cap2 = 1024; while (cap2 < top) cap2 <<= 1;
                 hipLaunchKernelGGL(lf_req_sort_kernel<256>, dim3((unsigned)n_req), dim3(256), (size_t)cap2 * 8, s, (int)n_req, (const uint64_t *)d_req_off, (const uint32_t *)d_req_n,
-                                   (const uint2 *)d_gath, d_sorted, d_sk2, clasp ? 1 : 0, 513u, 8192u);
+                                   (const uint2 *)d_gath, d_sorted, d_sk2, clasp ? 1 : 0, 513u, lds_hi);
             }
-        } else {
-            /* a request above 8192 seeds (a window over a satellite-like repeat): the chunk-wide radix sort on (request, key) */
-            int qbits = 1; while ((1ull << qbits) < (uint64_t)n_req + 1) qbits++;
-            const int kbits = (clasp ? 32 : 20) + qbits;        /* the radix sort is stable: equal keys keep the gathered order */
-            (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb4, d_sk, d_sk2, (uint64_t *)d_gath, (uint64_t *)d_sorted, (int)S, 0, kbits, s);
-            d_tmp3 = VSLOT(17, tb4 + 256);
-            if (!d_tmp3) return LF_ERR_NOMEM;
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp3, tb4, d_sk, d_sk2, (uint64_t *)d_gath, (uint64_t *)d_sorted, (int)S, 0, kbits, s));
+            if (max_n > lds_hi) {
+                uint64_t *d_big = (uint64_t *)VSLOT(17, 2 * S * 8 + 256);
+                if (!d_big) return LF_ERR_NOMEM;
+                hipLaunchKernelGGL(lf_req_sort_big_kernel, dim3((unsigned)n_req), dim3(1024), 0, s, (int)n_req, (const uint64_t *)d_req_off, (const uint32_t *)d_req_n,
+                                   (const uint2 *)d_gath, d_sorted, d_sk2, d_big, clasp ? 1 : 0, lds_hi + 1u);
+            }
         }
         HIPCHK(hipMemsetAsync(d_flag, 0, Q, s));
         if (!clasp) {

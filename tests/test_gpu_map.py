@@ -51,6 +51,50 @@ def test_sam_golden(lf, golden_reads, cfg):
     print("tie requests:", st["n_tie_requests"], "of", st["n_chain_problems"])
 
 
+@pytest.mark.parametrize("cfg", ["default", "clasp"])
+def test_sam_golden_with_the_large_request_sort(lf, golden_reads, cfg, monkeypatch):
+    """requests above 8192 seeds (a candidate window over a satellite array) are sorted by lf_req_sort_big_kernel (a bitonic network
+    over a scratch array in HBM; no library sort on the mapping path).  LF_REQ_SORT_BIG_FROM lowers the bound so that the golden
+    reads' requests (a few hundred seeds) take that kernel: records must not change, neither by qPos (dp-n2) nor by tPos (clasp)"""
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    monkeypatch.setenv("LF_REQ_SORT_BIG_FROM", "65")
+    sam, st = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
+    exp = golden_sam(cfg)
+    assert sam == exp, first_diff(sam, exp)
+
+
+def test_satellite_array_reads_take_the_large_request_sort(tmp_path, oracle_lib):
+    """a genome with a tandem satellite array (171 bp monomers, 60 kbp): a read out of the array hits it with every sample, so its
+    candidate window's request holds thousands of seeds; records == oracle"""
+    import numpy as np
+    import lordfast_amd as la
+    from lordfast_amd import synth
+    rng = np.random.default_rng(5)
+    contigs = synth.make_genome(1_500_000, 2, seed=3, repeat_frac=0.0, n_families=0)
+    mono = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=171)]
+    arr = np.tile(mono, 120)
+    mut = rng.random(len(arr)) < 0.01
+    arr[mut] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(mut.sum()))]
+    s0 = contigs[0][1]
+    s0[300000:300000 + len(arr)] = arr
+    fa = str(tmp_path / "sat.fa")
+    la.index_build(contigs, fa)
+    reads = [(f"sat{i}", synth.mutate(s0[300000 + 2000 * i + 500:300000 + 2000 * i + 5500].copy(), 0.10, rng).tobytes()) for i in range(6)]
+    reads += synth.make_reads(contigs, 20, 6000, 0.12, seed=9)
+    names, seqs = [r[0].encode() for r in reads], [r[1] for r in reads]
+    prm = dict(sampling_count=300)                       # (a request of n seeds costs the oracle's dp-n2 chainer n^2 / 2 steps)
+    lf = la.LordFast(fa, device=0)
+    try:
+        sam, st = lf.map_batch(names, seqs, params=la.default_params(**prm))
+    finally:
+        lf.close()
+    po = oracle_lib
+    exp = po.Oracle(fa).map_batch(names, seqs, params=po.default_params(**prm))
+    assert sam == exp, first_diff(sam, exp)
+    assert st["n_req_seeds"] > 6 * 8192, "the satellite reads' requests are not above the LDS sort's 8192 seeds"
+
+
 def test_sam_host_cigar_crosscheck(lf, golden_reads, monkeypatch):
     """lf_debug_crosscheck(2) builds CIGAR / MD on the host from copied-back edit paths instead of lf_render_kernel: both
     must print the reference's records"""
