@@ -330,6 +330,14 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     import threading
 
+    # how long a lane driver polls for its stream before it sleeps (lf_gpu_common.h: lf_stream_wait): 3 ms on a box of its own; with several
+    # ranks on one node the polling threads of all of them share the node's CPUs, so the budget is split (profiles/r04_waits/: 300 us costs
+    # a third of the CPU time of 3 000 us for ~2 ms per 100 k-read step)
+    if "LF_SPIN_US" not in os.environ and args.mode == "ranks":
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        if lw > 1:
+            os.environ["LF_SPIN_US"] = str(max(100, 3000 // lw))
+
     import torch
     dist, ctl, backend = None, None, None
     if world > 1:

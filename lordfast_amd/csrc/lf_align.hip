@@ -411,7 +411,8 @@ __host__ __device__ __forceinline__ uint32_t lf_class_key(const lf_aln_desc_t &x
 {
     const int c = lf_class_of(x.n, x.m, x.pad[0] != 0);
     const uint32_t m16 = x.m < 0xffffu ? x.m : 0xffffu;
-    return ((uint32_t)c << 28) | (c == 1 ? ((uint32_t)(x.mode ? 1u : 0u) << 23) | (((x.n + 63) >> 6) << 16) : 0u) | m16;
+    const uint32_t nbf = ((x.n + 63) >> 6) + (lf_small_prob(x.n, x.m) ? 64u : 0u);      /* small problems: segments of their own */
+    return ((uint32_t)c << 28) | (c == 1 ? ((uint32_t)(x.mode ? 1u : 0u) << 23) | (nbf << 16) : 0u) | m16;
 }
 /* checkpoint entries of one rsweep wave: the planes, then one row per 32 steps (+ the partial last one) */
 __host__ __device__ __forceinline__ uint64_t lf_rwave_entries(uint32_t nb, uint32_t m_max) { return LF_PLANE_ENTRIES + (uint64_t)((m_max + nb - 1 + LF_RSTEPS - 1) / LF_RSTEPS + 1) * (uint32_t)LF_RROW; }
@@ -443,16 +444,16 @@ struct lf_desc_src {
  * reserves ONE range per non-zero bin and hands its places out through LDS (pass 2).  The order inside a bin is whatever the
  * atomics give -- problems are independent, results do not depend on it. */
 #define LF_BIN_MB 32
-#define LF_NBINS (1 + 2 * 64 * LF_BIN_MB + 3)
+#define LF_NBINS (1 + 2 * LF_SEG_NB_MAX * LF_BIN_MB + 3)
 #define LF_BIN_ITEMS 4                       /* problems per thread of the two counting passes (1024 threads) */
 __host__ __device__ __forceinline__ uint32_t lf_bin_of_key(uint32_t key)
 {
     const uint32_t c = key >> 28;
     if (c == 0) return 0u;
-    if (c != 1) return 1u + 2u * 64u * LF_BIN_MB + (c - 2u);
+    if (c != 1) return 1u + 2u * LF_SEG_NB_MAX * LF_BIN_MB + (c - 2u);
     const uint32_t mode = (key >> 23) & 1u, nb = (key >> 16) & 127u, m = key & 0xffffu;
     const uint32_t mb = m < 512u ? (m >> 5) : 16u + (((m - 512u) >> 8) < 15u ? ((m - 512u) >> 8) : 15u);
-    return 1u + (mode * 64u + (nb - 1u)) * LF_BIN_MB + mb;
+    return 1u + (mode * LF_SEG_NB_MAX + (nb - 1u)) * LF_BIN_MB + mb;
 }
 __global__ void lf_desc_keys_kernel(const lf_aln_desc_t *__restrict__ d, const uint64_t *__restrict__ ops_off, int n, const lf_aln_desc_t *__restrict__ hd, int n_h,
                                     uint32_t *__restrict__ keys, uint8_t *__restrict__ ops,
@@ -536,8 +537,8 @@ lf_desc_segments_kernel(const uint32_t *__restrict__ keys, int n, lf_rseg_tab *_
     if (t == 255) s_lo[256] = lf_lower_bound_u32(keys, n, 2u << 28);
     if (t < 6) tab->cstart[t] = lf_lower_bound_u32(keys, n, (uint32_t)t << 28);
     __syncthreads();
-    const int nb = t & 127, cnt = s_lo[t + 1] - s_lo[t];
-    s_w[t] = (nb >= 1 && nb <= 64) ? (cnt + (64 / nb) - 1) / (64 / nb) : 0;
+    const int nbf = t & 127, nb = lf_seg_blocks(nbf), cnt = s_lo[t + 1] - s_lo[t];
+    s_w[t] = (nbf >= 1 && nbf <= LF_SEG_NB_MAX) ? (cnt + (64 / nb) - 1) / (64 / nb) : 0;
     __syncthreads();
     if (t == 0) {
         int acc = 0;
@@ -547,7 +548,7 @@ lf_desc_segments_kernel(const uint32_t *__restrict__ keys, int n, lf_rseg_tab *_
 }
 /* checkpoint entries are charged to the first problem of every wave */
 __global__ void lf_desc_entries_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, const lf_aln_desc_t *__restrict__ d, int n0,
-                                       const lf_aln_desc_t *__restrict__ hd, const lf_rseg_tab *__restrict__ tab, int n, uint64_t *__restrict__ ent)
+                                       const lf_aln_desc_t *__restrict__ hd, const lf_rseg_tab *__restrict__ tab, int n, uint64_t *__restrict__ ent, int fused_small)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
@@ -555,8 +556,8 @@ __global__ void lf_desc_entries_kernel(const uint32_t *__restrict__ keys, const 
     const int c = (int)(key >> 28);
     uint64_t e = 0;
     if (c == 1) {
-        const int t = (int)((key >> 16) & 0xffu), nb = t & 127, P = 64 / nb, rel = j - tab->lo[t];
-        if (rel % P == 0) {      /* the wave's checkpoint rows: as many as its LONGEST target needs (a bin holds a range of lengths, in no particular order) */
+        const int t = (int)((key >> 16) & 0xffu), nb = lf_seg_blocks(t & 127), P = 64 / nb, rel = j - tab->lo[t];
+        if (((t & 127) <= 64 || !fused_small) && rel % P == 0) {      /* (the fused kernel keeps the small problems' rows in LDS) the wave's checkpoint rows: as many as its LONGEST target needs (a bin holds a range of lengths, in no particular order) */
             int last = j + P - 1; if (last > tab->lo[t + 1] - 1) last = tab->lo[t + 1] - 1;
             uint32_t mmax = 0;
             for (int k = j; k <= last; k++) { const uint32_t mk = keys[k] & 0xffffu; mmax = mk > mmax ? mk : mmax; }
@@ -585,11 +586,11 @@ __global__ void lf_desc_build_kernel(const uint32_t *__restrict__ keys, const ui
     p.qstart = x.qstart; p.tstart = x.tstart; p.ops_off = i < (uint32_t)n0 ? ops_off[i] : hops_off[i - n0];
     p.hist_base = base[j]; p.aux_off = 0; p.pad = 0;
     if (c == 1) {
-        const int t = (int)((key >> 16) & 0xffu), nb = t & 127, P = 64 / nb, rel = j - tab->lo[t], slot = rel % P;
+        const int t = (int)((key >> 16) & 0xffu), nb = lf_seg_blocks(t & 127), P = 64 / nb, rel = j - tab->lo[t], slot = rel % P;
         p.hist_base = base[j - slot];
         p.pad = (uint8_t)(slot * nb);                       /* the problem's first lane in its wavefront */
         if (slot == 0) {
-            lf_rwave w; w.first = (uint32_t)j; const int left = tab->lo[t + 1] - j; w.count = (uint16_t)(left < P ? left : P); w.G = (uint16_t)nb; w.hist_base = p.hist_base;
+            lf_rwave w; w.first = (uint32_t)j; const int left = tab->lo[t + 1] - j; w.count = (uint16_t)(left < P ? left : P); w.G = (uint16_t)nb; w.hist_base = p.hist_base;      /* (small segments: no rows in HBM, hist_base unused) */
             waves[tab->w0[t] + rel / P] = w;
         }
     } else if (c == 0) {
@@ -728,22 +729,29 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     hipLaunchKernelGGL(lf_desc_binscan_kernel, dim3(1), dim3(1024), 0, s, d_bins);
     hipLaunchKernelGGL(lf_desc_count_kernel<true>, dim3(gc), dim3(1024), 0, s, (const uint32_t *)d_keys, N, d_bins, d_keys2, d_vals2);
     hipLaunchKernelGGL(lf_desc_segments_kernel, dim3(1), dim3(256), 0, s, d_keys2, N, d_tab);
-    hipLaunchKernelGGL(lf_desc_entries_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, n, d_hdesc, d_tab, N, d_ent);
+    /* LF_SMALL_FUSED=1: the small problems' segments go through lf_edlib_small_kernel (forward + traceback in one wavefront, rows in LDS).
+     * Built and measured in round 5 -- 14 KB of LDS and 112 registers per wavefront leave its forward pass three wavefronts per SIMD, and the
+     * step's alignment kernels took 24.3 instead of 21.1 ms (profiles/r05_search/) -- so the default keeps them on the forward / traceback pair. */
+    const int fused_small = getenv("LF_SMALL_FUSED") && atoi(getenv("LF_SMALL_FUSED")) != 0;
+    hipLaunchKernelGGL(lf_desc_entries_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, n, d_hdesc, d_tab, N, d_ent, fused_small);
     { lf_scan_u64 f; f.p = d_ent; const int src = lf_scan_excl(device, 4, s, f, d_base, (size_t)N); if (src != LF_OK) return src; }
     hipLaunchKernelGGL(lf_desc_build_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, n, d_hdesc, d_opsoff, d_hopsoff, d_tab, d_base, N, D->pac ? 1 : 0, d_probs, d_waves, d_misc);
-    uint64_t tail[2], aux_total = 0;
+    /* (into PINNED memory: an asynchronous copy into pageable memory -- a stack variable -- makes the runtime wait for the stream inside the
+     * call, spinning, instead of in lf_stream_wait) */
+    uint64_t *tail = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(h_tab) + ((sizeof(lf_rseg_tab) + 15) & ~(size_t)15));
     HIPCHK(hipMemcpyAsync(h_tab, d_tab, sizeof(lf_rseg_tab), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&tail[0], d_base + (N - 1), 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&tail[1], d_ent + (N - 1), 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&aux_total, d_misc, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&tail[2], d_misc, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    const uint64_t aux_total = tail[2];
     const uint64_t hist_entries = tail[0] + tail[1];
     if (getenv("LF_HIST_STATS")) {       /* debug: the class-1 problems of this round by (mode, blocks, target-length bucket) -- the scanned bin starts */
         std::vector<uint32_t> hb((size_t)LF_NBINS + 1);
         HIPCHK(hipMemcpy(hb.data(), d_bins, (size_t)LF_NBINS * 4, hipMemcpyDeviceToHost));
-        for (int b = 1; b < 1 + 2 * 64 * LF_BIN_MB; b++) {      /* (the scatter pass advanced every cursor to its bin's end) */
+        for (int b = 1; b < 1 + 2 * LF_SEG_NB_MAX * LF_BIN_MB; b++) {      /* (the scatter pass advanced every cursor to its bin's end) */
             const uint32_t c = hb[(size_t)b] - hb[(size_t)b - 1];
-            if (c) fprintf(stderr, "[lf] bin mode %d nb %d mb %d: %u\n", (b - 1) / (64 * LF_BIN_MB), ((b - 1) / LF_BIN_MB) % 64 + 1, (b - 1) % LF_BIN_MB, c);
+            if (c) fprintf(stderr, "[lf] bin mode %d nb %d mb %d: %u\n", (b - 1) / (LF_SEG_NB_MAX * LF_BIN_MB), lf_seg_blocks(((b - 1) / LF_BIN_MB) % LF_SEG_NB_MAX + 1), (b - 1) % LF_BIN_MB, c);
         }
     }
     lf_hist_t *d_hist = DSLOT(lf_hist_t, 2, hist_entries * sizeof(lf_hist_t) + 64);
@@ -764,15 +772,34 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         lf_rsw_args RA;
         RA.probs = d_probs; RA.waves = d_waves; RA.qlo = D->d_planes; RA.qhi = D->d_planes + D->q_words; RA.qvalid = D->d_planes + 2 * D->q_words; RA.q_words = D->q_words;
         RA.pac = D->d_pac; RA.pac_syms = D->pac_syms; RA.ckpt = d_hist; RA.out_ed = d_ed; RA.out_end = d_end;
+        /* segments t = mode * 128 + block field; the small problems' segments (block field 65 .. 64 + LF_SMALL_NB) close each mode's range:
+         * their waves go to the fused kernel (rows in LDS, paths walked by the same wavefront), everything else to forward + traceback */
+        const int w_nw_small = h_tab->w0[65], w_shw0 = h_tab->w0[128], w_shw_small = h_tab->w0[128 + 65], w_end = h_tab->w0[256];
+        const int p_nw_small = h_tab->lo[65], p_shw0 = h_tab->lo[128], p_shw_small = h_tab->lo[128 + 65], p_end = h_tab->lo[256];
+        (void)nw_nw; (void)nw_shw;
+        RA.ops = d_ops; RA.out_len = d_len;
         HIPCHK(hipEventRecord(bd[1], cs[1]));
-        RA.wave0 = 0; RA.n_waves = nw_nw; lf_rsweep_launch(cs[1], false, RA);
-        RA.wave0 = nw_nw; RA.n_waves = nw_shw; lf_rsweep_launch(cs[1], true, RA);
+        if (fused_small) {
+            RA.wave0 = 0; RA.n_waves = w_nw_small; lf_rsweep_launch(cs[1], false, RA);
+            RA.wave0 = w_shw0; RA.n_waves = w_shw_small - w_shw0; lf_rsweep_launch(cs[1], true, RA);
+            RA.wave0 = w_nw_small; RA.n_waves = w_shw0 - w_nw_small; lf_small_launch(cs[1], false, RA);
+            RA.wave0 = w_shw_small; RA.n_waves = w_end - w_shw_small; lf_small_launch(cs[1], true, RA);
+        } else {
+            RA.wave0 = 0; RA.n_waves = w_shw0; lf_rsweep_launch(cs[1], false, RA);
+            RA.wave0 = w_shw0; RA.n_waves = w_end - w_shw0; lf_rsweep_launch(cs[1], true, RA);
+        }
         HIPCHK(hipEventRecord(bd[2], cs[1]));
         {
-            /* columns per replayed part of a 32-step tile: 8 (four parts, 8 KiB of LDS per wavefront) or 16 (two parts, 16 KiB) */
+            /* columns per replayed part of a 32-step tile: 8 (four parts, 8 KiB of LDS per wavefront) or 16 (two parts, 16 KiB); the paths of the
+             * problems the fused kernel did not take: two ranges of the sorted problem array */
             const int tb_hk = getenv("LF_TB_HK") ? atoi(getenv("LF_TB_HK")) : 8;
-            if (tb_hk == 16) hipLaunchKernelGGL(lf_edlib_tb_kernel<16>, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, D->pac_syms, d_hist, d_ops, d_end, d_len);
-            else hipLaunchKernelGGL(lf_edlib_tb_kernel<8>, dim3((unsigned)((cnt(1) + 63) / 64)), dim3(64), 0, cs[1], d_probs + cstart[1], cnt(1), S, D->pac_syms, d_hist, d_ops, d_end, d_len);
+            const int r0[2] = { cstart[1], p_shw0 }, r1[2] = { fused_small ? p_nw_small : p_shw0, fused_small ? p_shw_small : p_end };
+            for (int q = 0; q < 2; q++) {
+                const int np = r1[q] - r0[q];
+                if (np <= 0) continue;
+                if (tb_hk == 16) hipLaunchKernelGGL(lf_edlib_tb_kernel<16>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, cs[1], d_probs + r0[q], np, S, D->pac_syms, d_hist, d_ops, d_end, d_len);
+                else hipLaunchKernelGGL(lf_edlib_tb_kernel<8>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, cs[1], d_probs + r0[q], np, S, D->pac_syms, d_hist, d_ops, d_end, d_len);
+            }
         }
         HIPCHK(hipEventRecord(bd[3], cs[1]));
     }

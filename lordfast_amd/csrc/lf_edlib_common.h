@@ -195,6 +195,17 @@ __device__ __forceinline__ uint32_t lf_pac16(const uint8_t *__restrict__ pac, in
 #define LF_RROW 96           /* 16-byte units per row */
 #define LF_RSTEPS 32
 
+/* SMALL problems: at most LF_SMALL_NB query blocks and LF_SMALL_M target columns, i.e. at most 128 sweep steps = four checkpoint rows.  More
+ * than half of a C2 step's problems (profiles/r05_search/alignment_problem_histogram_20k_reads.txt) -- their rows never leave the
+ * CU: the forward pass keeps them in LDS and the same wavefront walks the paths (lf_edlib_small_kernel, lf_rsweep.hip).  In the
+ * binning they form segments of their own: blocks + 64 in the key's block field. */
+#define LF_SMALL_NB 2
+#define LF_SMALL_M 127
+#define LF_SMALL_ROWS 4
+__host__ __device__ __forceinline__ bool lf_small_prob(uint32_t n, uint32_t m) { return n <= 64u * LF_SMALL_NB && m <= LF_SMALL_M; }
+__host__ __device__ __forceinline__ int lf_seg_blocks(int nbf) { return nbf > 64 ? nbf - 64 : nbf; }      /* key's block field -> lanes per problem */
+#define LF_SEG_NB_MAX (64 + LF_SMALL_NB)
+
 /* lane l receives lane l-1's value (lane 0: 0): the horizontal carry of the anti-diagonal sweeps.  DPP wave_shr:1 is a
  * VALU move; __shfl_up goes through the LDS crossbar (ds_bpermute) and sits on the per-step dependency chain. */
 __device__ __forceinline__ uint32_t lf_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }

@@ -126,9 +126,11 @@ void phase_make_jobs(ctx_t *cx, int tid, int ri)
         j->req = rq;
         j->read = ri; j->widx = w; j->isRev = r->wins[w].isReverse;
         j->chainLen = cx->chain_len[rq];
-        j->chain = (Seed_t *)ar_alloc(&cx->arena[tid], ((size_t)j->chainLen + 1) * sizeof(Seed_t));
-        if (!cx->host_vote) memcpy(j->chain, cx->vc.chain_seeds + cx->vc.chain_off[rq], (size_t)j->chainLen * sizeof(Seed_t));
+        /* the chain is only READ on the host, and only by the replay of the few chains that leave the common path (lf_replay.c): it stays
+         * where the chain stage left it (the lane's pinned slot, valid until this lane's next lfg_vote_chain) -- no copy per job */
+        if (!cx->host_vote) j->chain = cx->vc.chain_seeds + cx->vc.chain_off[rq];
         else {
+            j->chain = (Seed_t *)ar_alloc(&cx->arena[tid], ((size_t)j->chainLen + 1) * sizeof(Seed_t));
             const creq_t *cq = &cx->creq[rq];
             for (uint32_t k = 0; k < j->chainLen; k++) j->chain[k] = cx->cseeds[cq->off + cx->chain_idx[cq->off + k]];
         }

@@ -10,6 +10,7 @@ struct lf_rsw_args {
     const uint64_t *qlo, *qhi, *qvalid; int64_t q_words;      /* bit planes of the query buffer (lf_pack_planes_kernel) */
     const uint8_t *pac; int64_t pac_syms;                      /* 2-bit targets, four per byte, first symbol in the top bits */
     lf_hist_t *ckpt; int32_t *out_ed, *out_end;
+    uint8_t *ops; uint32_t *out_len;                           /* the fused small-problem kernel writes the paths itself */
 };
 /* words of ONE plane for a buffer of n bytes (three planes follow each other) */
 static inline uint64_t lf_plane_words(uint64_t n_bytes) { return (n_bytes + 63) / 64 + 2; }
@@ -17,4 +18,5 @@ static inline uint64_t lf_plane_words(uint64_t n_bytes) { return (n_bytes + 63) 
 void lf_rsweep_pack_planes(hipStream_t s, const unsigned char *d_src, uint64_t n_bytes, uint64_t *d_planes, uint64_t n_words, unsigned long long *lower_flag = nullptr);
 void lf_rsweep_pack_pac(hipStream_t s, const unsigned char *d_src, uint64_t n_bytes, uint8_t *d_pac);
 void lf_rsweep_launch(hipStream_t s, bool track, lf_rsw_args A);
+void lf_small_launch(hipStream_t s, bool track, lf_rsw_args A);      /* waves of small problems (lf_edlib_common.h: LF_SMALL_*): forward + traceback in one wavefront, rows in LDS */
 #endif

@@ -549,7 +549,8 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
         const int dev_in = dio && !dio->stage_sink;
         /* (with the lanes' uploads taking turns, lf_seed.hip: ONE chunk per lane for pinned host batches too -- 6250 / 8334 / 12500
          * reads per chunk: 99.4 / 97.5 / 96.0 ms per 100 k reads) */
-        const int per_lane = (dev_in || B.holes) ? 1 : 3;
+        int per_lane = (dev_in || B.holes) ? 1 : 3;
+        if (B.holes && getenv("LF_CHUNKS_PER_LANE")) { per_lane = atoi(getenv("LF_CHUNKS_PER_LANE")); if (per_lane < 1) per_lane = 1; if (per_lane > 4) per_lane = 4; }      /* experiment hook */
         const int min_chunk = (dev_in || B.holes) ? 6250 : 1024;
         int want = (n + per_lane * n_lanes - 1) / (per_lane * n_lanes); if (want < min_chunk) want = min_chunk;
         if (want < CHUNK_READS) CHUNK_READS = want;
@@ -567,17 +568,19 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
      * link at the very end (17 ms of an 88 ms step, profiles/r04_waits/).  With chunk k about (1 + ramp (2 k / (L - 1) - 1)) times the mean
      * the lanes finish in chunk order: every chunk but the last leaves while the larger ones are still being mapped.  LF_CHUNK_RAMP=<percent>. */
     double ramp = 0.0;
+    int n_ramp = n_lanes;                                /* chunks of the ramp: one per lane (LF_CHUNKS_PER_LANE: more) */
     if (B.holes && !getenv("LF_CHUNK_READS") && n_lanes >= 2 && n > 2048 && (n + n_lanes - 1) / n_lanes >= 6250) {
         ramp = getenv("LF_CHUNK_RAMP") ? atof(getenv("LF_CHUNK_RAMP")) / 100.0 : LF_CHUNK_RAMP_DEFAULT;
         if (ramp < 0) ramp = 0; if (ramp > 0.9) ramp = 0.9;
+        if (getenv("LF_CHUNKS_PER_LANE")) { int pl = atoi(getenv("LF_CHUNKS_PER_LANE")); if (pl < 1) pl = 1; if (pl > 4) pl = 4; n_ramp = n_lanes * pl; }
     }
     for (int i0 = 0; i0 < n; ) {
         int i1 = i0; uint64_t bases = 0;
         int lim = (first_reads > 0 && B.n_chunks < n_lanes) ? first_reads : CHUNK_READS;
         if (ramp > 0) {
             const int k = B.n_chunks;
-            if (k >= n_lanes - 1) lim = n - i0;                         /* the last lane's chunk takes what is left */
-            else lim = (int)((double)n / n_lanes * (1.0 + ramp * (2.0 * k / (n_lanes - 1) - 1.0)) + 0.5);
+            if (k >= n_ramp - 1) lim = n - i0;                          /* the last chunk takes what is left */
+            else lim = (int)((double)n / n_ramp * (1.0 + ramp * (2.0 * k / (n_ramp - 1) - 1.0)) + 0.5);
             if (lim < 1) lim = 1;
         }
         while (i1 < n && i1 - i0 < lim && bases < CHUNK_BASES) { bases += lens[i1]; i1++; }

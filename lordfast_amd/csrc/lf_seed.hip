@@ -818,7 +818,7 @@ static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_r
     /* u32 counts summed into u64 offsets: one launch (lf_scan.h) */
     { lf_scan_u32 f; f.p = d_cnt; const int src = lf_scan_excl(dv, 0, s, f, d_hit_off, total + 1); if (src != LF_OK) return src; }
     HIPCHK(hipEventRecord(ev[2], s));
-    uint64_t *h_nhits = (uint64_t *)lfg_pin_slot(LF_PS_HITS_OFF, (size_t)(n_reads + 2) * 8);
+    uint64_t *h_nhits = (uint64_t *)lfg_pin_slot(LF_PS_HITS_OFF, (size_t)(n_reads + 2 + 8) * 8);
     if (!h_nhits) return LF_ERR_NOMEM;
     HIPCHK(hipMemcpyAsync(h_nhits, d_hit_off + total, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -847,8 +847,10 @@ static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_r
         HIPCHK(hipMemcpyAsync(out->strand, d_strand, n_hits, hipMemcpyDeviceToHost, s));
     }
     HIPCHK(hipMemcpyAsync(out->read_off, d_read_off, (size_t)(n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out->counters, d_counters, 32, hipMemcpyDeviceToHost, s));
+    uint64_t *h_cnt = h_nhits + (n_reads + 2);             /* pinned (a copy into the caller's struct would make the runtime wait for the stream inside the call) */
+    HIPCHK(hipMemcpyAsync(h_cnt, d_counters, 32, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    for (int k = 0; k < 4; k++) out->counters[k] = h_cnt[k];
     HIPCHK(hipGetLastError());
     out->counters[3] = n_bases;
     out->counters[2] = n_hits;                 /* N_sa: one suffix-array read per hit */

@@ -64,8 +64,21 @@ def test_sam_golden_with_the_large_request_sort(lf, golden_reads, cfg, monkeypat
     assert sam == exp, first_diff(sam, exp)
 
 
+def test_sam_golden_with_the_fused_small_problem_kernel(lf, golden_reads, monkeypatch):
+    """LF_SMALL_FUSED=1: problems of at most two query blocks and 127 target columns (more than half of all problems) run forward pass AND
+    traceback in one wavefront with their checkpoint rows in LDS (lf_edlib_small_kernel).  Off by default (measured slower: too few
+    wavefronts per SIMD); the records must be the same either way"""
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    monkeypatch.setenv("LF_SMALL_FUSED", "1")
+    for cfg in ("default", "n30"):
+        sam, st = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
+        exp = golden_sam(cfg)
+        assert sam == exp, first_diff(sam, exp)
+
+
 def test_satellite_array_reads_take_the_large_request_sort(tmp_path, oracle_lib):
-    """a genome with a tandem satellite array (171 bp monomers, 60 kbp): a read out of the array hits it with every sample, so its
+    """a genome with a tandem satellite array (171 bp monomers, 27 kbp): a read out of the array hits it with every sample, so its
     candidate window's request holds thousands of seeds; records == oracle"""
     import numpy as np
     import lordfast_amd as la
@@ -73,17 +86,17 @@ def test_satellite_array_reads_take_the_large_request_sort(tmp_path, oracle_lib)
     rng = np.random.default_rng(5)
     contigs = synth.make_genome(1_500_000, 2, seed=3, repeat_frac=0.0, n_families=0)
     mono = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=171)]
-    arr = np.tile(mono, 120)
+    arr = np.tile(mono, 160)
     mut = rng.random(len(arr)) < 0.01
     arr[mut] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(mut.sum()))]
     s0 = contigs[0][1]
     s0[300000:300000 + len(arr)] = arr
     fa = str(tmp_path / "sat.fa")
     la.index_build(contigs, fa)
-    reads = [(f"sat{i}", synth.mutate(s0[300000 + 2000 * i + 500:300000 + 2000 * i + 5500].copy(), 0.10, rng).tobytes()) for i in range(6)]
+    reads = [(f"sat{i}", synth.mutate(s0[300000 + 2000 * i + 500:300000 + 2000 * i + 7500].copy(), 0.10, rng).tobytes()) for i in range(6)]
     reads += synth.make_reads(contigs, 20, 6000, 0.12, seed=9)
     names, seqs = [r[0].encode() for r in reads], [r[1] for r in reads]
-    prm = dict(sampling_count=300)                       # (a request of n seeds costs the oracle's dp-n2 chainer n^2 / 2 steps)
+    prm = dict()                                         # (a request of n seeds costs the oracle's dp-n2 chainer n^2 / 2 steps: ~10^8 per satellite read)
     lf = la.LordFast(fa, device=0)
     try:
         sam, st = lf.map_batch(names, seqs, params=la.default_params(**prm))
