@@ -438,13 +438,18 @@ static int inflate_more(struct lf_reads *r, size_t want)
                 if (!bs) break;
                 const unsigned char *tl = r->map + cp + bs - 4;
                 const size_t isize = (size_t)tl[0] | ((size_t)tl[1] << 8) | ((size_t)tl[2] << 16) | ((size_t)tl[3] << 24);
+                if (isize > 65536) break;                               /* not a BGZF block (they hold at most 64 KiB): the streaming inflater takes it from here */
                 if (nb == capb) { capb = capb ? capb * 2 : 4096; blk = (zblock_t *)realloc(blk, (size_t)capb * sizeof(zblock_t)); }
                 blk[nb].src = r->map + cp + doff; blk[nb].n_in = bs - doff - 8; blk[nb].dst = (unsigned char *)(uintptr_t)out; blk[nb].n_out = isize; nb++;
                 out += isize; cp += bs;
             }
             if (nb == 0) {
                 if (cp >= r->map_size) { r->src_eof = 1; free(blk); break; }
-                free(blk); lf_set_error("lf_reads_next: %s: not a BGZF block at offset %zu", r->path, cp); return LF_ERR_IO;      /* (a plain gzip member in the middle of a BGZF file) */
+                free(blk);
+                /* a plain gzip member (or a BGZF block with extra flags) in the middle of a BGZF file -- `cat a.bgz b.gz`: gzread-based readers
+                 * (the reference's kseq) read such files, so the rest of the file goes through the one-stream inflater below */
+                if (cp + 2 <= r->map_size && r->map[cp] == 0x1f && r->map[cp + 1] == 0x8b) { r->src = 2; r->cpos = cp; continue; }
+                lf_set_error("lf_reads_next: %s: neither a BGZF block nor a gzip member at offset %zu", r->path, cp); return LF_ERR_IO;
             }
             const int rc0 = tbuf_room(r, out); if (rc0 != LF_OK) { free(blk); return rc0; }
             for (int k = 0; k < nb; k++) blk[k].dst = r->tbuf + r->tend + (size_t)(uintptr_t)blk[k].dst;

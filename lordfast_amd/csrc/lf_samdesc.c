@@ -83,6 +83,27 @@ static inline void pack_bits_scalar(const unsigned char *s, size_t n, uint64_t *
     }
     *lo = l; *hi = h; *va = v;
 }
+#if defined(__x86_64__)
+/* 64 bases -> (low bit, high bit, valid) words, 32 bytes per step where the host has AVX2 (checked once): half the instructions of the
+ * SSE2 form -- the pack is the first thing every lane of a host batch waits for, one lane after the other */
+__attribute__((target("avx2"))) static inline void pack64_avx2(const unsigned char *p, uint64_t *lo, uint64_t *hi, uint64_t *va)
+{
+    uint64_t l = 0, h = 0, v = 0;
+    for (int q = 0; q < 2; q++) {
+        const __m256i x = _mm256_loadu_si256((const __m256i *)(p + 32 * q));
+        const __m256i b2 = _mm256_slli_epi16(x, 5), b1 = _mm256_slli_epi16(x, 6);
+        const __m256i okv = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(x, _mm256_set1_epi8('A')), _mm256_cmpeq_epi8(x, _mm256_set1_epi8('C'))),
+                                            _mm256_or_si256(_mm256_cmpeq_epi8(x, _mm256_set1_epi8('G')), _mm256_cmpeq_epi8(x, _mm256_set1_epi8('T'))));
+        const uint64_t vm = (uint64_t)(uint32_t)_mm256_movemask_epi8(okv);
+        const uint64_t hm = (uint64_t)(uint32_t)_mm256_movemask_epi8(b2) & vm;
+        const uint64_t lm = (uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_xor_si256(b1, b2)) & vm;
+        l |= lm << (32 * q); h |= hm << (32 * q); v |= vm << (32 * q);
+    }
+    *lo = l; *hi = h; *va = v;
+}
+static int have_avx2(void) { static int x = -1; if (x < 0) x = __builtin_cpu_supports("avx2") ? 1 : 0; return x; }
+#endif
+
 int lf_pack_read(uint64_t *planes, uint64_t qw, uint64_t a, const char *seq, uint32_t len,
                  uint64_t *exc_pos, uint8_t *exc_byte, uint64_t exc_cap, uint64_t *exc_n)
 {
@@ -90,6 +111,9 @@ int lf_pack_read(uint64_t *planes, uint64_t qw, uint64_t a, const char *seq, uin
     const unsigned char *s = (const unsigned char *)seq;
     size_t i = 0; int ok_all = 1;
     uint64_t pos = a;
+#if defined(__x86_64__)
+    const int avx2 = have_avx2();
+#endif
 #define LF_PACK_EXC(word_valid, count, base_i) do { \
         uint64_t bad_ = ~(word_valid) & ((count) >= 64 ? ~0ull : ((1ull << (count)) - 1)); \
         while (bad_) { const int b_ = __builtin_ctzll(bad_); bad_ &= bad_ - 1; \
@@ -109,7 +133,8 @@ int lf_pack_read(uint64_t *planes, uint64_t qw, uint64_t a, const char *seq, uin
         uint64_t l, h, v;
 #if defined(__x86_64__)
         l = h = v = 0;
-        for (int q = 0; q < 4; q++) {
+        if (avx2) pack64_avx2(s + i, &l, &h, &v);
+        else for (int q = 0; q < 4; q++) {
             const __m128i x = _mm_loadu_si128((const __m128i *)(s + i + 16 * q));
             const __m128i b2 = _mm_slli_epi16(x, 5), b1 = _mm_slli_epi16(x, 6);           /* bit 2 / bit 1 of every byte in its top bit */
             const __m128i okv = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(x, _mm_set1_epi8('A')), _mm_cmpeq_epi8(x, _mm_set1_epi8('C'))),

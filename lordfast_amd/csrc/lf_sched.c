@@ -181,6 +181,7 @@ typedef struct {
     int holes;                                  /* the output buffer is pinned host memory and the reads are host strings: SEQ-less egress (lf_sam.hip) */
     volatile int rc; char err[1024];
     lf_stats_t st[LF_MAX_LANES];
+    double t0;                                  /* LF_TIMING: the batch's start */
 } batch_t;
 
 #ifndef LF_CHUNK_RAMP_DEFAULT
@@ -244,6 +245,7 @@ static void fetch_dev_sam(batch_t *B, const lf_index_t *ix, uint64_t base, uint6
 {
     if (B->rc != LF_OK) { free(fill); return; }
     const double t0 = now_ms();
+    static int timing = -1; if (timing < 0) timing = getenv("LF_TIMING") != NULL;
     out_reserve(B, base, tot);
     if (B->rc == LF_OK) {               /* one D2H copy of the chunk's text straight into its place */
         /* a caller-provided buffer never moves: the copy runs behind the lane's back (lfg_sam_fetch_wait at the lane's end);
@@ -269,6 +271,7 @@ static void fetch_dev_sam(batch_t *B, const lf_index_t *ix, uint64_t base, uint6
     pthread_rwlock_unlock(&B->grow);
     free(fill);
     st->ms_sam += now_ms() - t0;
+    if (timing) fprintf(stderr, "[lf] lane %d egress: %.1f MB placed at offset %.1f MB; issued at t=%.1f ms of the batch, host fill done at t=%.1f\n", lane, tot / 1e6, base / 1e6, t0 - B->t0, now_ms() - B->t0);
 }
 
 static void *lane_main(void *arg_)
@@ -347,7 +350,7 @@ static void *lane_main(void *arg_)
         }
         st->n_bases += chunk_bases;
         st->n_reads += (uint64_t)cx.n_reads;
-        if (timing) fprintf(stderr, "[lf] lane %d chunk %d (%d reads): map_chunk %.1f ms\n", lane, k, cx.n_reads, now_ms() - tch);
+        if (timing) fprintf(stderr, "[lf] lane %d chunk %d (%d reads): map_chunk %.1f ms, done at t=%.1f ms of the batch\n", lane, k, cx.n_reads, now_ms() - tch, now_ms() - B->t0);
         uint64_t tot = 0, *ooff = NULL;
         if (rc == LF_OK) {
             ooff = (uint64_t *)malloc(((size_t)cx.n_reads + 1) * 8);
@@ -400,6 +403,7 @@ static void *lane_main(void *arg_)
         const int wrc = lfg_sam_fetch_wait(B->ixs[lane % B->n_ix]);
         if (wrc != LF_OK && B->rc == LF_OK) { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = wrc; }
         st->ms_sam += now_ms() - t0;
+        if (timing) fprintf(stderr, "[lf] lane %d: its scatter kernels done at t=%.1f ms of the batch (waited %.1f ms)\n", lane, now_ms() - B->t0, now_ms() - t0);
     }
     if (g_phase_on) phase_account("(lane driver threads, incl. their share of the phases)", (thread_cpu_ns() - lane_c0) / 1e6, 0);
     lane_release(lane);
@@ -490,6 +494,7 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     const int lane0 = lane_acquire(lane_cap, NULL, 0); /* this thread's lane id: the set-up passes below, then its chunks */
 
     batch_t B; memset(&B, 0, sizeof B);
+    B.t0 = T0;
     B.host_cigar = (g_crosscheck & LF_XC_HOST_CIGAR) != 0;
     B.host_vote = (g_crosscheck & LF_XC_HOST_VOTE) != 0;          /* diagnostic cross-check only; the device stage is the product path */
     B.ixs = ixs; B.n_ix = n_ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + LF_MAX_LANES; B.rc = LF_OK; B.lane_cap = lane_cap;

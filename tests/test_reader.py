@@ -236,6 +236,23 @@ def test_window_parser_fastq_all_containers(tmp_path, container):
             assert all(sum(len(x) for x in b[1]) >= 2_000_000 for b in batches[:-1])
 
 
+def test_bgzf_file_with_a_plain_gzip_member_appended(tmp_path):
+    """`cat a.bgz b.gz`: the file is taken for BGZF from its first member; when a member that is not a BGZF block turns up the rest of the
+    file goes through the one-stream inflater (gzread-based readers -- the reference's kseq -- read such files); record boundaries need
+    not coincide with member boundaries"""
+    import lordfast_amd as la
+    data, recs = _big_fastq(5_000_000, 11)
+    cut = 3_000_001
+    bg = _bgzf(data[:cut])
+    bg = bg[:-28]                                        # (without the empty end-of-file block, as `cat` of a truncated stream would leave it)
+    path = str(tmp_path / "cat.fq.gz")
+    with open(path, "wb") as fh:
+        fh.write(bg + gzip.compress(data[cut:], 1))
+    for kw in (dict(), dict(batch_reads=53)):
+        got = [(n, s, q) for names, seqs, quals in la.read_file(path, **kw) for n, s, q in zip(names, seqs, quals)]
+        assert got == recs, kw
+
+
 def test_window_parser_hands_wrapped_fastq_to_the_sequential_parser(tmp_path):
     """a big FASTQ whose later records are wrapped over several lines: the batches before them come from the window parser,
     the rest from the sequential one -- one record stream, kseq's"""
