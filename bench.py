@@ -330,13 +330,12 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     import threading
 
-    # how long a lane driver polls for its stream before it sleeps (lf_gpu_common.h: lf_stream_wait): 3 ms on a box of its own; with several
-    # ranks on one node the polling threads of all of them share the node's CPUs, so the budget is split (profiles/r04_waits/: 300 us costs
-    # a third of the CPU time of 3 000 us for ~2 ms per 100 k-read step)
+    # how long a lane driver polls for its stream before it sleeps (lf_gpu_common.h: lf_stream_wait): 200 us on a box of its own; with several
+    # ranks on one node the polling threads of all of them share the node's CPUs, so the budget is split
     if "LF_SPIN_US" not in os.environ and args.mode == "ranks":
         lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
         if lw > 1:
-            os.environ["LF_SPIN_US"] = str(max(100, 3000 // lw))
+            os.environ["LF_SPIN_US"] = str(max(50, 200 // lw))
 
     import torch
     dist, ctl, backend = None, None, None
@@ -718,7 +717,7 @@ def main():
                                  "alignment classes on one stream (LF_SERIAL_CLASSES=1), HIP events on the launch streams, one step after the timed region; "
                                  "the rocprofv3 summary of the same mode is under profiles/",
                         overlapped_bracket_ms_per_step={k: round(v[0] / K, 2) for k, v in kernel_table(agg_hbm).items()},
-                        lanes_in_flight_timed_region=int(os.environ.get("LF_LANES", "8")) if params.threads >= 4 else params.threads)
+                        lanes_in_flight_timed_region=int(os.environ.get("LF_LANES", "4")) if params.threads >= 4 else params.threads)
         # the issue-bound kernels' own roofline: VALU wave-instructions (SQ counters of this tree) x issue cycles per form (static mix of the
         # kernel's loops, profiles/tools/isa_mix.py; rates of profiles/tools/ubench/valu_rate.hip) / 1024 SIMDs / sustained clock vs exclusive time
         roofline["alu"] = by_kernel[dom]["alu"]

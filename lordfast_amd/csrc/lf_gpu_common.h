@@ -297,7 +297,8 @@ __device__ __forceinline__ uint32_t lf_wave_max_u32(uint32_t v)
  * HBM-resident step / host CPU per step: runtime's own spinning wait 69.2 ms / 0.57 core-s, sleep at once 77.5 ms / 0.18 -- a
  * sleeping thread is back ~0.2 ms after its stream is done, and a chunk waits ~40 times.  Most of those waits are for a few
  * microseconds of copy or a small kernel: polling briefly catches them, the long ones sleep (profiles/r04_waits/: 100 us -> 70.5 ms /
- * 0.20, 3000 us -> 67.7 ms / 0.34).  LF_SPIN_WAIT=1: the runtime's wait. */
+ * 0.20, 3000 us -> 67.7 ms / 0.34 with eight lanes).  Round 5, four lanes: 100 / 300 / 1000 us -> 64.1 / 63.7 - 66.0 / 65.0 ms at 0.145 / 0.15 - 0.165 /
+ * 0.187 core-s (profiles/r05_lanes/): the default is 200 us.  LF_SPIN_WAIT=1: the runtime's wait. */
 #ifndef LF_NO_SYNC_WRAP
 #include <stdlib.h>
 #include <time.h>
@@ -307,7 +308,7 @@ static inline hipError_t lf_stream_wait(hipStream_t s)
 {
     lfg_count_wait();
     static const bool spin = getenv("LF_SPIN_WAIT") != nullptr;
-    static const long spin_us = getenv("LF_SPIN_US") ? atol(getenv("LF_SPIN_US")) : 3000;
+    static const long spin_us = getenv("LF_SPIN_US") ? atol(getenv("LF_SPIN_US")) : 200;
     int dev = -1;
     if (spin || hipGetDevice(&dev) != hipSuccess) return hipStreamSynchronize(s);
     hipEvent_t e = (hipEvent_t)lfg_thread_wait_event(dev);

@@ -473,7 +473,10 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     /* drivers sleep while they wait for the GPU (blocking waits), so small thread budgets still get several chunks in flight */
     /* a lane driver spends most of a chunk blocked on the GPU (the chain walk runs on the device now), so the number of
      * chunks in flight is not tied to the thread budget any more: eight from four threads up */
-    int n_lanes = nt >= 4 ? 8 : nt;
+    /* FOUR chunks in flight (round 5; eight before): with the search kernel 30 % shorter the step is the sum of its kernels sooner, four 25 k-read
+     * chunks run at least as fast as eight 12.5 k ones (63.7 - 66.4 against 67.6 - 70.3 ms per 100 k reads, same box; three: 69.9, two: 74.1)
+     * and cost half the launches, waits and driver threads: 0.15 - 0.17 instead of 0.34 host core-s per step (profiles/r05_lanes/) */
+    int n_lanes = nt >= 4 ? 4 : nt;
     if (getenv("LF_LANES")) { n_lanes = atoi(getenv("LF_LANES")); if (n_lanes < 1) n_lanes = 1; if (n_lanes > LF_MAX_LANES) n_lanes = LF_MAX_LANES; }
     if (getenv("LF_ONE_LANE")) n_lanes = 1;
     if (n_ix > 1) {
@@ -579,7 +582,29 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
         if (ramp < 0) ramp = 0; if (ramp > 0.9) ramp = 0.9;
         if (getenv("LF_CHUNKS_PER_LANE")) { int pl = atoi(getenv("LF_CHUNKS_PER_LANE")); if (pl < 1) pl = 1; if (pl > 4) pl = 4; n_ramp = n_lanes * pl; }
     }
-    for (int i0 = 0; i0 < n; ) {
+    /* One chunk per lane (reads resident in HBM, or a pinned host batch): the chunks are cut by BASES -- equal shares (a lane's time goes with
+     * its bases, not its reads), times the ramp for host batches -- and there are exactly as many as lanes (or as the working-set bound asks
+     * for): with four lanes a cut by read count left a fifth, tiny chunk behind the four large ones. */
+    int by_bases = 0;
+    if (!getenv("LF_CHUNK_READS") && !getenv("LF_CHUNK_BASES") && !getenv("LF_CHUNKS_PER_LANE") && first_reads == 0 && n_lanes >= 2 && n > 2048 && ((dio && !dio->stage_sink) || B.holes)) {
+        uint64_t total_b = 0; for (int i = 0; i < n; i++) total_b += lens[i];
+        int nck = n_lanes; if (nck > n / 6250) nck = n / 6250 > 0 ? n / 6250 : 1;
+        const uint64_t cap_b = 768ull << 20;                                    /* working set of a lane: ~ 13 bytes of HBM per base */
+        if ((uint64_t)nck * cap_b < total_b) nck = (int)((total_b + cap_b - 1) / cap_b);
+        double wsum = 0; for (int k = 0; k < nck; k++) wsum += 1.0 + (nck > 1 ? ramp * (2.0 * k / (nck - 1) - 1.0) : 0.0);
+        int i0 = 0; double acc_w = 0; uint64_t acc_b = 0;
+        for (int k = 0; k < nck && i0 < n; k++) {
+            acc_w += 1.0 + (nck > 1 ? ramp * (2.0 * k / (nck - 1) - 1.0) : 0.0);
+            const uint64_t goal = k == nck - 1 ? total_b : (uint64_t)((double)total_b * acc_w / wsum);
+            int i1 = i0;
+            while (i1 < n && (acc_b < goal || i1 == i0)) { acc_b += lens[i1]; i1++; }
+            if (k == nck - 1) i1 = n;
+            B.chunks[B.n_chunks].i0 = i0; B.chunks[B.n_chunks].i1 = i1; B.n_chunks++;
+            i0 = i1;
+        }
+        by_bases = 1;
+    }
+    for (int i0 = 0; i0 < n && !by_bases; ) {
         int i1 = i0; uint64_t bases = 0;
         int lim = (first_reads > 0 && B.n_chunks < n_lanes) ? first_reads : CHUNK_READS;
         if (ramp > 0) {
