@@ -660,6 +660,7 @@ def main():
         bases_genome = 0
 
     def report(elapsed, sam, xinfo):
+        nonlocal order
         K = args.steps
         bases = bases_total
         value = n_total * K / elapsed

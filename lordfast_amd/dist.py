@@ -247,6 +247,10 @@ def scatter_packed_p2p(dist, torch, packed, device, src: int = 0):
 # step k is on the GPUs.  Only the first scatter and the last gather are exposed.  Metadata (offsets, lengths: a few hundred
 # kB) goes over a host-side control group (gloo), so no device synchronisation sits between the steps.
 
+import threading as _threading
+_NA_LOCK = _threading.Lock()
+
+
 class Shard:
     """one rank's share of a step: ONE byte blob `[seq\\0]* [name\\0]*` on the bulk device + host offset arrays (n + 1 each,
     absolute in the blob; sequence i is seq_off[i+1] - seq_off[i] - 1 long)."""
@@ -270,12 +274,13 @@ class Shard:
     def name_array(self, torch):
         """ctypes char*[n] into a HOST copy of the names part of the blob (kept alive by self)"""
         import ctypes as C
-        if getattr(self, "_na_for", None) is not self.blob:      # built once per shard content (call it once before sharing a shard between threads)
-            n0, n1 = int(self.name_off[0]), int(self.name_off[-1])
-            names_host = self.blob[n0:n1].cpu().numpy() if n1 > n0 else np.zeros(1, np.uint8)
-            ptrs = (self.name_off[:-1] - n0 + names_host.ctypes.data).astype(np.uint64)
-            self._names_host, self._np, self._na_for = names_host, ptrs, self.blob
-        return C.cast(self._np.ctypes.data, C.POINTER(C.c_char_p))
+        with _NA_LOCK:                                           # a shard may be mapped by several threads at once (steps in flight): built once per shard content
+            if getattr(self, "_na_for", None) is not self.blob:
+                n0, n1 = int(self.name_off[0]), int(self.name_off[-1])
+                names_host = self.blob[n0:n1].cpu().numpy() if n1 > n0 else np.zeros(1, np.uint8)
+                ptrs = (self.name_off[:-1] - n0 + names_host.ctypes.data).astype(np.uint64)
+                self._names_host, self._np, self._na_for = names_host, ptrs, self.blob
+            return C.cast(self._np.ctypes.data, C.POINTER(C.c_char_p))
 
 
 def make_shards(torch, names, seqs, world, device, by_bases=True):
