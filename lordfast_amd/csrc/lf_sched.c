@@ -476,7 +476,10 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     /* FOUR chunks in flight (round 5; eight before): with the search kernel 30 % shorter the step is the sum of its kernels sooner, four 25 k-read
      * chunks run at least as fast as eight 12.5 k ones (63.7 - 66.4 against 67.6 - 70.3 ms per 100 k reads, same box; three: 69.9, two: 74.1)
      * and cost half the launches, waits and driver threads: 0.15 - 0.17 instead of 0.34 host core-s per step (profiles/r05_lanes/) */
-    int n_lanes = nt >= 4 ? 4 : nt;
+    /* (host batches keep eight: their step time is set by the chunk that happens to hold a read with a long replay -- every chunk behind it waits
+     * for its size -- and with four 25 k-read chunks that one chunk is a quarter of the batch: 85.6 / 103.0 ms against 84.1 / 88.1 with eight,
+     * same box, at equal host CPU: profiles/r05_lanes/) */
+    int n_lanes = nt >= 4 ? ((dio && !dio->stage_sink) ? 4 : 8) : nt;
     if (getenv("LF_LANES")) { n_lanes = atoi(getenv("LF_LANES")); if (n_lanes < 1) n_lanes = 1; if (n_lanes > LF_MAX_LANES) n_lanes = LF_MAX_LANES; }
     if (getenv("LF_ONE_LANE")) n_lanes = 1;
     if (n_ix > 1) {
