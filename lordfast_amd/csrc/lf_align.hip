@@ -1088,7 +1088,7 @@ lf_ksw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t 
 template <bool LDS>
 __global__ void __launch_bounds__(256)
 lf_ksw_mw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t *__restrict__ qs, const uint8_t *__restrict__ ts,
-                 int32_t *__restrict__ out_score, int32_t *__restrict__ out_qle, int32_t *__restrict__ out_tle, int lds_q)
+                 int32_t *__restrict__ out_score, int32_t *__restrict__ out_qle, int32_t *__restrict__ out_tle, int lds_q, int r4_on)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t s_he[];      /* H ring, E ring (256 slots each), then the read's bases (LDS instantiation) */
     __shared__ int s_A[4], s_mn[4], s_mxp[4];
@@ -1101,6 +1101,7 @@ lf_ksw_mw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8
     const int zdrop = pr.zdrop, h0 = pr.h0;
     const int w = lf_ksw_band(qlen, o_del, e_del, o_ins, e_ins, pr.w);
     if (w > LF_KSW_MW_MAXW) return;                   /* lf_ksw_kernel does */
+    if (r4_on && w <= 120 /* LF_KSW_R4_MAXW */) return;      /* lf_ksw_r4_kernel does */
     const uint8_t *q = qs + pr.qoff, *t = ts + pr.toff;
     /* The H / E arrays of the reference (qlen + 2 entries) are only ever touched inside the row's band [beg, end], beg never
      * decreases and end - beg <= 2 w + 1 <= 255: entry j lives in slot j & 255 of a ring, 2 KiB per problem whatever the read's
@@ -1209,6 +1210,157 @@ lf_ksw_mw_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8
     if (tid == 0) { out_score[pr.id] = mx; out_qle[pr.id] = max_j + 1; out_tle[pr.id] = max_i + 1; }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * ksw_extend2 with the row's band IN REGISTERS: one wavefront per problem, lane l owns the four consecutive columns base + 4 l ... of a
+ * 256-column window that holds the band [beg, end] (w <= LF_KSW_R4_MAXW).  What a clip test costs is the time of ONE row times thousands
+ * of dependent rows, and a row of lf_ksw_mw_kernel is ~300 instructions per wavefront around two workgroup barriers and three LDS round
+ * trips (1.0 us).  Here a row has no LDS access and no barrier at all:
+ *   - H (the reference's eh[j].h: H(i-1, j-1), the diagonal predecessor of column j) and E stay in the registers of the column's owner;
+ *     "eh[j].h = h1" -- every column takes the h of its left neighbour -- is a move inside the lane and ONE DPP wave_shr for the lane's
+ *     first column; columns outside [beg, end] keep their old values exactly like the reference's array does;
+ *   - F: a lane folds its four columns (B(j) = max(M - oe_ins, 0) + (j + 1) e_ins, prefix maxima), ONE exclusive max-scan over the lanes'
+ *     aggregates gives every lane the gap that enters it;
+ *   - row maximum with the reference's tie rule (last column wins) = one wave maximum of (h << 8 | column in the window);
+ *   - band trimming: a lane's first / last slot that is not all zero, one ballot, two readlanes;
+ *   - the window follows the band: when the band's left edge has moved 64 columns (or the right edge nears the window's end) the
+ *     registers move down by whole lanes (ds_bpermute) and the lanes that become free take the closed form of the first row
+ *     (lib/bwa/ksw.c:404-407): columns above the highest `end` so far have never been written.
+ * Same arithmetic, same results (tests/test_gpu_stages.py::test_ksw_golden_and_fuzz).  Wider bands: lf_ksw_mw_kernel / lf_ksw_kernel.
+ * ---------------------------------------------------------------------------------------------- */
+#define LF_KSW_R4_MAXW 120
+__global__ void __launch_bounds__(64)
+lf_ksw_r4_kernel(const lf_ksw_prob *__restrict__ probs, int n_probs, const uint8_t *__restrict__ qs, const uint8_t *__restrict__ ts,
+                 int32_t *__restrict__ out_score, int32_t *__restrict__ out_qle, int32_t *__restrict__ out_tle)
+{
+    const int gid = blockIdx.x, lane = threadIdx.x;
+    if (gid >= n_probs) return;
+    const lf_ksw_prob pr = probs[gid];
+    const int qlen = pr.qlen, tlen = pr.tlen, o_del = pr.o_del, e_del = pr.e_del, o_ins = pr.o_ins, e_ins = pr.e_ins;
+    const int zdrop = pr.zdrop, h0 = pr.h0;
+    const int w = lf_ksw_band(qlen, o_del, e_del, o_ins, e_ins, pr.w);
+    if (w > LF_KSW_R4_MAXW) return;                   /* lf_ksw_mw_kernel / lf_ksw_kernel do */
+    const uint8_t *q = qs + pr.qoff, *t = ts + pr.toff;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    constexpr int NEG = INT_MIN / 2;
+    auto h_first = [&](int j) -> int {               /* h0, h0 - oe_ins, then -e_ins per column while positive */
+        if (j == 0) return h0;
+        if (j > qlen || h0 <= oe_ins) return 0;
+        const long long x = (long long)h0 - oe_ins - (long long)(j - 1) * e_ins;
+        return (int)(x > 0 ? x : 0);
+    };
+    int base = 0;                                     /* first column of the window, a multiple of 4 */
+    int Hd[4], E[4], qc[4];
+    auto fresh = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { Hd[k] = h_first(base + 4 * lane + k); E[k] = 0; }
+    };
+    auto load_q = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int j = base + 4 * lane + k; qc[k] = j < qlen ? (int)q[j] : 4; }
+    };
+    fresh(); load_q();
+    int mx = h0, max_i = -1, max_j = -1, beg = 0, end = qlen;
+    int tc = tlen > 0 ? (int)t[0] : 0;
+    for (int i = 0; i < tlen; ++i) {
+        const int tc_next = i + 1 < tlen ? (int)t[i + 1] : 0;      /* requested a row ahead */
+        if (beg < i - w) beg = i - w;
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        /* the window follows the band (wave-uniform): slots up to end + 1 are written this row, end grows by at most two per row */
+        if (beg - base >= 64 || end + 4 >= base + 256) {
+            const int sl = (beg - base) >> 2;
+            if (sl > 0) {
+                const int src = (lane + sl) & 63;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { Hd[k] = __shfl(Hd[k], src); E[k] = __shfl(E[k], src); }
+                base += 4 * sl;
+                if (lane >= 64 - sl) fresh();
+                load_q();
+            }
+        }
+        int h1;
+        if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
+        else h1 = 0;
+        const int j0 = base + 4 * lane, r0 = 4 * lane;            /* the lane's first column, absolute / inside the window */
+        bool act[4]; int M[4], tin[4], B[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = j0 + k;
+            act[k] = j >= beg && j < end;
+            const int sc = (tc > 3 || qc[k] > 3) ? 0 : (tc == qc[k] ? 2 : -16);
+            int m0 = Hd[k] ? Hd[k] + sc : 0;
+            M[k] = act[k] ? m0 : 0;
+            int ti = M[k] - oe_ins; tin[k] = ti < 0 ? 0 : ti;
+            B[k] = act[k] ? tin[k] + (r0 + k + 1) * e_ins : NEG;
+        }
+        /* f entering column j = max over the columns l < j of B(l), minus (j + 1 - 1) e_ins; at least the row's initial 0 decayed (never above E >= 0) */
+        const int P0 = B[0], P1 = P0 > B[1] ? P0 : B[1], P2 = P1 > B[2] ? P1 : B[2], P3 = P2 > B[3] ? P2 : B[3];
+        const int incl = lf_wave_incl_max_i32(P3);
+        int G = __builtin_amdgcn_update_dpp(NEG, incl, 0x138, 0xf, 0xf, false);      /* exclusive: lane l takes lanes < l */
+        G = G > 0 ? G : 0;
+        int h[4], e2[4];
+        {
+            const int pre[4] = { G, G > P0 ? G : P0, G > P1 ? G : P1, G > P2 ? G : P2 };
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int fin = pre[k] - (r0 + k) * e_ins;
+                int hh = M[k] > E[k] ? M[k] : E[k];
+                hh = hh > fin ? hh : fin;
+                h[k] = act[k] ? hh : 0;
+                int tt = M[k] - oe_del; tt = tt < 0 ? 0 : tt;
+                int ee = E[k] - e_del; ee = ee < tt ? tt : ee;
+                e2[k] = ee;
+            }
+        }
+        /* row maximum, the LAST column on ties (`mj = m > h ? mj : j`): (h << 8 | column in the window); slots of the NEXT row that are not all
+         * zero: slot j + 1 through h(j), slot j through e2(j) -- the lane's first and last */
+        uint32_t key = 0; int lmn = INT_MAX, lmx = INT_MIN;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t kk = act[k] ? (((uint32_t)h[k] << 8) | (uint32_t)(r0 + k)) : 0u;
+            key = kk > key ? kk : key;
+            if (act[k] && e2[k] != 0) lmx = j0 + k;
+            if (act[k] && h[k] != 0) lmx = j0 + k + 1;
+        }
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            if (act[k] && h[k] != 0) lmn = j0 + k + 1;
+            if (act[k] && e2[k] != 0) lmn = j0 + k;
+        }
+        const uint32_t kmax = lf_wave_max_u32(key);
+        const unsigned long long nzb = lf_ballot(lmn != INT_MAX);
+        int mn = h1 != 0 ? beg : INT_MAX, mxp = h1 != 0 ? beg : INT_MIN;
+        if (nzb) {
+            const int a = __builtin_amdgcn_readlane(lmn, __ffsll((long long)nzb) - 1), b = __builtin_amdgcn_readlane(lmx, 63 - __clzll((long long)nzb));
+            mn = a < mn ? a : mn; mxp = b > mxp ? b : mxp;
+        }
+        /* the next row's arrays: column j takes the h of column j - 1 (column beg: h1), E(j) the new e; E(end) = 0; everything else stays */
+        {
+            int hleft0 = lf_wave_shr1((uint32_t)h[3]);                       /* the left neighbour lane's last column */
+            const int hl[4] = { hleft0, h[0], h[1], h[2] };
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = j0 + k;
+                Hd[k] = j == beg ? h1 : ((j > beg && j <= end) ? hl[k] : Hd[k]);
+                E[k] = act[k] ? e2[k] : (j == end ? 0 : E[k]);
+            }
+        }
+        const int m = beg < end ? (int)(kmax >> 8) : 0, mj = beg < end ? base + (int)(kmax & 255u) : -1;
+        tc = tc_next;
+        if (m == 0) break;
+        if (m > mx) { mx = m; max_i = i; max_j = mj; }
+        else if (zdrop > 0) {
+            if (i - max_i > mj - max_j) { if (mx - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break; }
+            else { if (mx - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break; }
+        }
+        /* trim the band: first / last slot of [beg, end] that is not all zero (lib/bwa/ksw.c:462-465) */
+        const int nb = mn == INT_MAX ? end : mn, ne = mxp == INT_MIN ? end - 1 : mxp;
+        beg = nb;
+        end = ne + 2 < qlen ? ne + 2 : qlen;
+    }
+    if (lane == 0) { out_score[pr.id] = mx; out_qle[pr.id] = max_j + 1; out_tle[pr.id] = max_i + 1; }
+}
+
 extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff, const uint8_t *t, const uint64_t *toff,
                        const int32_t *prm, int32_t *score, int32_t *qle, int32_t *tle, float *ms)
 {
@@ -1249,13 +1401,20 @@ extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff
         if (wide) { n_wide++; qmax_wide = std::max(qmax_wide, P[i].qlen); } else { n_narrow++; qmax_narrow = std::max(qmax_narrow, P[i].qlen); }
     }
     const int lds_q = std::min(qmax, 6000);
-    if (n_narrow) {
+    /* bands of at most 2 x 120 + 1 columns (every call of the reference: w = 100): the register kernel; LF_KSW_R4=0: the four-wavefront LDS kernel (A / B) */
+    const bool r4 = !(getenv("LF_KSW_R4") && atoi(getenv("LF_KSW_R4")) == 0) && !one_wave;
+    bool r4_all = r4;
+    if (r4) {
+        for (int i = 0; i < n && r4_all; i++) r4_all = lf_ksw_band(P[i].qlen, P[i].o_del, P[i].e_del, P[i].o_ins, P[i].e_ins, P[i].w) <= LF_KSW_R4_MAXW;
+        hipLaunchKernelGGL(lf_ksw_r4_kernel, dim3((unsigned)n), dim3(64), 0, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q, (const uint8_t *)d_t, d_s, d_ql, d_tl);
+    }
+    if (n_narrow && !(r4 && r4_all)) {
         /* H / E rings, and the read's bases up to 32 KiB, in LDS */
         const int mw_q = std::min(qmax_narrow, 32768);
         hipLaunchKernelGGL(lf_ksw_mw_kernel<true>, dim3((unsigned)n), dim3(256), (size_t)2048 + (size_t)mw_q + 16, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
-                           (const uint8_t *)d_t, d_s, d_ql, d_tl, mw_q);
+                           (const uint8_t *)d_t, d_s, d_ql, d_tl, mw_q, r4 ? 1 : 0);
         if (qmax_narrow > mw_q) hipLaunchKernelGGL(lf_ksw_mw_kernel<false>, dim3((unsigned)n), dim3(256), (size_t)2048, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
-                           (const uint8_t *)d_t, d_s, d_ql, d_tl, mw_q);
+                           (const uint8_t *)d_t, d_s, d_ql, d_tl, mw_q, r4 ? 1 : 0);
     }
     if (n_wide) {
         const int wide_only = one_wave ? 0 : 1;

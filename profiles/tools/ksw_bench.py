@@ -22,14 +22,15 @@ def problems(n, L, seed):
 def main():
     out = []
     for L in (2000, 10000):
-        for n in (1, 64, 512, 2048):
+        for n in (1, 64, 512):
             qs, ts = problems(n, L, 7 + n)
             for name, prm in (("w40", (0, 1, 0, 1, 40, 40, L)), ("w100", (8, 1, 4, 1, 100, 200, L))):
                 prms = [prm] * n
                 row = {"rows": L, "problems": n, "prm": name}
-                for mode in ("default", "onewave"):
+                for mode in ("default", "mw", "onewave"):      # default: lf_ksw_r4_kernel (round 5); mw: LF_KSW_R4=0 (round 4's four-wavefront kernel); onewave: round 3's
+                    os.environ.pop("LF_KSW_1WAVE", None); os.environ.pop("LF_KSW_R4", None)
                     if mode == "onewave": os.environ["LF_KSW_1WAVE"] = "1"
-                    else: os.environ.pop("LF_KSW_1WAVE", None)
+                    if mode == "mw": os.environ["LF_KSW_R4"] = "0"
                     la.ksw_extend2_batch(qs, ts, prms)
                     t0 = time.perf_counter(); res = la.ksw_extend2_batch(qs, ts, prms); dt = time.perf_counter() - t0
                     rows_done = sum(r[2] for r in res)
