@@ -751,7 +751,8 @@ def main():
                          "ext_bytes": agg["ext_bytes"] / per_rank, "cigar_md_text_bytes": agg["render_bytes"] / per_rank,
                          "dp_block_steps": agg["dp_block_steps"] / per_rank,
                          "chain_requests": agg["n_chain_problems"] / per_rank, "tie_requests": agg["n_tie_requests"] / per_rank,
-                         "ksw_problems": agg["n_ksw_problems"] / per_rank},
+                         "ksw_problems": agg["n_ksw_problems"] / per_rank,
+                         "stale_first_windows_per_step": agg.get("n_stale_first_windows", 0) / K},
             "roofline": roofline,
             "host_waits_per_chunk": agg.get("n_host_waits", 0) / max(1, agg.get("n_chunks", 0)), "chunks_per_step": agg.get("n_chunks", 0) / K,
             "steps_in_flight": D,

@@ -122,7 +122,11 @@ void phase_make_jobs(ctx_t *cx, int tid, int ri)
     for (int w = 0; w < r->nWins; w++) {
         job_t *j = &r->jobs[w];
         int rq = r->wins[w].req;
-        if (cx->p->chain_alg == 1 && r->mode == 3 && !cx->host_vote) { if (cx->chain_len[rq] == 0 && last_req >= 0) rq = last_req; else if (cx->chain_len[rq] > 0) last_req = rq; }
+        if (cx->p->chain_alg == 1 && r->mode == 3 && !cx->host_vote) {
+            if (cx->chain_len[rq] == 0 && last_req >= 0) rq = last_req;
+            else if (cx->chain_len[rq] > 0) last_req = rq;
+            else __atomic_fetch_add(&cx->st->n_stale_first_windows, 1, __ATOMIC_RELAXED);      /* no chain of this read to fall back on: the one corner that stays divergent */
+        }
         j->req = rq;
         j->read = ri; j->widx = w; j->isRev = r->wins[w].isReverse;
         j->chainLen = cx->chain_len[rq];

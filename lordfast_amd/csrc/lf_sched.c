@@ -199,7 +199,7 @@ static void merge_stats(lf_stats_t *d, const lf_stats_t *a)
     d->dp_block_steps += a->dp_block_steps; d->ms_render += a->ms_render; d->ms_k_render += a->ms_k_render; d->ms_k_vote += a->ms_k_vote; d->ops_bytes += a->ops_bytes; d->n_req_seeds += a->n_req_seeds; d->n_tie_requests += a->n_tie_requests; d->render_bytes += a->render_bytes; d->render_launches += a->render_launches;
     d->ksw_bytes += a->ksw_bytes;
     d->ms_k_rsweep += a->ms_k_rsweep; d->ms_k_tb += a->ms_k_tb; d->ms_k_hirsch += a->ms_k_hirsch; d->ms_k_bin += a->ms_k_bin;
-    d->hirsch_bytes += a->hirsch_bytes; d->n_host_waits += a->n_host_waits; d->n_chunks += a->n_chunks;
+    d->hirsch_bytes += a->hirsch_bytes; d->n_host_waits += a->n_host_waits; d->n_chunks += a->n_chunks; d->n_stale_first_windows += a->n_stale_first_windows;
 }
 
 /* base offset of a chunk's text = the sizes of all chunks of earlier reads.  block == 0: returns 0 when one of them has not
