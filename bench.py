@@ -677,7 +677,7 @@ def main():
                 "lf_edlib_rsweep_kernel": (a["ms_k_rsweep"], a["ext_bytes"] - a["ops_bytes"], max(1, 2 * a["edlib_launches"]), True),      # NW + SHW instantiation per round: q + t/4 read
                 "lf_edlib_tb_kernel": (a["ms_k_tb"], a["ops_bytes"], max(1, a["edlib_launches"]), True),                               # the paths written (q + t region per problem)
                 "lf_seed_locate_kernel": (a["ms_k_locate"], 8 * a["n_sa"] + 9 * a["n_sa"], a["locate_launches"], True),
-                "lf_ksw_mw_kernel": (a["ms_k_ksw"], a.get("ksw_bytes", 0), max(1, a["n_ksw_problems"] and 1), True),
+                "lf_ksw_r4_kernel": (a["ms_k_ksw"], a.get("ksw_bytes", 0), max(1, a["n_ksw_problems"] and 1), True),      # (bands above 241 columns: lf_ksw_mw_kernel / lf_ksw_kernel)
                 # ---- groups ----
                 # lf_vote_cell_kernel (+ request-count scan): 9 B per hit read; votes live in LDS
                 "lf_vote_cell_kernel (+ scan)": (a["ms_k_vote"], 9 * n_hits, a["search_launches"], False),
@@ -948,6 +948,10 @@ def load_sq(args, world):
         except Exception:                                                # noqa: BLE001
             continue
         if sq.get("_meta", {}).get("source_tree") == src_hash and isa.get("_meta", {}).get("source_tree") == src_hash:
+            # one clock for the device: GRBM_GUI_ACTIVE (summed over the 8 XCDs) over the dispatch durations of the kernels that run for milliseconds
+            # (a short dispatch's counter window is longer than its start .. end), never above the 2.4 GHz the part is specified at
+            g = [(v["grbm_gui_active"], v["dur_ns_in_the_grbm_pass"]) for v in sq.values() if isinstance(v, dict) and v.get("dur_ns_in_the_grbm_pass", 0) >= 2e6 and v.get("launches", 0) <= 64]
+            sq["_meta"]["clock_ghz"] = min(2.4, sum(a for a, _ in g) / 8.0 / sum(b for _, b in g)) if g else 2.4
             return sq, isa, os.path.relpath(d, ROOT)
     return None, None, "no SQ counter pass + instruction mix of this source tree under profiles/ (profiles/tools/collect.sh, isa_mix.py)"
 
@@ -961,7 +965,6 @@ def alu_of(kname, kms, sq, isa, src, reads_now):
     reads_sq = sq.get("_meta", {}).get("reads_per_step", 50000)
     scale = reads_now / float(reads_sq)
     n_valu = n_salu = cyc = 0.0
-    clk = []
     for k, v in sq.items():
         if not isinstance(v, dict) or not k.startswith(prefix) or "sq_insts_valu" not in v:
             continue
@@ -969,11 +972,9 @@ def alu_of(kname, kms, sq, isa, src, reads_now):
         cpi = (mix or {}).get("cycles_per_valu") or 2.7
         n_valu += v["sq_insts_valu"] * scale; n_salu += v.get("sq_insts_salu", 0.0) * scale
         cyc += v["sq_insts_valu"] * scale * cpi
-        if v.get("clock_ghz"):
-            clk.append(v["clock_ghz"])
     if n_valu == 0:
         return dict(frac=None, source=src)
-    ghz = sum(clk) / len(clk) if clk else 2.4
+    ghz = sq.get("_meta", {}).get("clock_ghz", 2.4)
     alu_ms = cyc / 1024.0 / (ghz * 1e9) * 1e3
     return dict(bound="VALU issue (integer)", valu_wave_instructions_per_step=n_valu, salu_wave_instructions_per_step=n_salu, cycles_per_valu_instruction=cyc / n_valu,
                 clock_ghz=ghz, simds=1024, alu_ms_per_step=alu_ms, exclusive_ms_per_step=kms, frac=(alu_ms / kms if kms > 0 else None), source=src)

@@ -11,7 +11,7 @@ lo, hi = iv[0][0], max(e for _, e, _ in iv)
 if len(sys.argv) > 3 and sys.argv[2] == "--last-step":
     # window = the last K launches of the seed search kernel (K = chunks per step) up to the last kernel of the trace
     k = int(sys.argv[3])
-    starts = [s for s, _, n in iv if n.startswith("lf_seed_search_kernel")]
+    starts = [s for s, _, n in iv if "lf_seed_search_kernel" in n.split("(")[0]]
     lo = starts[-k]
 elif len(sys.argv) > 3:
     a, b = float(sys.argv[2]), float(sys.argv[3])

@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:44]) for r in rows)
 k = int(sys.argv[3])
 min_ns = float(sys.argv[4]) * 1e3 if len(sys.argv) > 4 else 20e3
-starts = [s for s, _, n in iv if n.startswith("lf_seed_search_kernel")]
+starts = [s for s, _, n in iv if "lf_seed_search_kernel" in n.split("(")[0]]
 lo = starts[-k]
 hi = max(e for _, e, _ in iv)
 iv = [x for x in iv if x[1] > lo]

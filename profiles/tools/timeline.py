@@ -6,7 +6,7 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 k = int(sys.argv[3]); lead = float(sys.argv[4]) if len(sys.argv) > 4 else 15.0; min_ms = float(sys.argv[5]) if len(sys.argv) > 5 else 0.5
-starts = [s for s, _, n in iv if n.startswith("lf_seed_search_kernel")]
+starts = [s for s, _, n in iv if "lf_seed_search_kernel" in n.split("(")[0]]
 lo = starts[-k] - int(lead * 1e6); hi = max(e for _, e, _ in iv)
 small = defaultdict(float)
 for s, e, n in iv:

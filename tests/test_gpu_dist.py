@@ -87,7 +87,7 @@ def test_bench_one_rank_reports_both_boundaries(one_rank_line):
     # N = 1: `value` is the host boundary; the HBM-resident rate is reported next to it
     assert j["value_host_boundary"] == j["value"] and j["value_hbm_resident"] > 0 and "host memory" in j["config"]["io"]
     assert j["roofline"]["kernel"] in j["roofline"]["by_kernel"] and j["roofline"]["by_kernel"][j["roofline"]["kernel"]]["single_kernel"]
-    assert j["roofline"]["frac"] > 0 and j["roofline"]["by_kernel"]["lf_ksw_mw_kernel"]["algorithmic_GB_per_step"] >= 0
+    assert j["roofline"]["frac"] > 0 and j["roofline"]["by_kernel"]["lf_ksw_r4_kernel"]["algorithmic_GB_per_step"] >= 0
 
 
 def test_bench_strong_scaling_two_ranks_same_records(bench_dir, one_rank_line):
