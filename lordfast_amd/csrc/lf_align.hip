@@ -1388,9 +1388,7 @@ extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff
     int32_t *d_ws = KSLOT(int32_t, 3, ws * 4 + 16), *d_s = KSLOT(int32_t, 4, (size_t)n * 4), *d_ql = KSLOT(int32_t, 5, (size_t)n * 4), *d_tl = KSLOT(int32_t, 6, (size_t)n * 4);
 #undef KSLOT
     if (!d_q || !d_t || !d_p || !d_ws || !d_s || !d_ql || !d_tl) return LF_ERR_NOMEM;
-    /* (LF_KSW_CUS: a round of few problems runs on the stream that owns the reserved CUs, lf_mem.hip) */
-    static const int ksw_cus = getenv("LF_KSW_CUS") ? atoi(getenv("LF_KSW_CUS")) : 0;
-    hipStream_t s = (hipStream_t)lfg_lane_stream(device, (ksw_cus > 0 && n <= 16 * ksw_cus) ? 13 : 15);
+    hipStream_t s = (hipStream_t)lfg_lane_stream(device, 15);
     if (!s) return LF_ERR_HIP;
     hipEvent_t e0 = (hipEvent_t)lfg_lane_event(device, 40), e1 = (hipEvent_t)lfg_lane_event(device, 41);
     if (!e0 || !e1) return LF_ERR_HIP;

@@ -129,19 +129,7 @@ extern "C" void *lfg_lane_stream(int device, int which)
          * memory requests, not by issue slots -- runs on every k-th CU, all other streams on the remaining ones */
         static int split = -1;
         if (split < 0) { const char *e = getenv("LF_CU_SPLIT"); split = e ? atoi(e) : 0; if (split < 2 || split > 16) split = 0; }
-        /* LF_KSW_CUS=n (experiment, round 5): n CUs are kept free of every other stream for stream 13, on which lfg_ksw runs the few long
-         * clip-test problems of a replay round -- a lone wavefront whose row is a chain of dependent instructions gets one issue slot in
-         * nine on a SIMD that also holds eight wavefronts of the forward sweep */
-        static int ksw_cus = -1;
-        if (ksw_cus < 0) { const char *e = getenv("LF_KSW_CUS"); ksw_cus = e ? atoi(e) : 0; if (ksw_cus < 0 || ksw_cus > 64) ksw_cus = 0; }
         hipError_t rc;
-        if (ksw_cus && !split) {
-            hipDeviceProp_t pr; int ncu = 256;
-            if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount;
-            uint32_t mask[16]; for (int k = 0; k < 16; k++) mask[k] = 0;
-            for (int c = 0; c < ncu && c < 512; c++) if ((c < ksw_cus) == (which == 13)) mask[c >> 5] |= 1u << (c & 31);
-            rc = hipExtStreamCreateWithCUMask(&st, (uint32_t)((ncu + 31) / 32), mask);
-        } else
         if (split && which != 14) {
             hipDeviceProp_t pr; int ncu = 256;
             if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount;
