@@ -54,11 +54,12 @@
 template <int HK>
 __global__ void __launch_bounds__(64)
 lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S, int64_t pac_syms, const lf_hist_t *__restrict__ ckpt, uint8_t *__restrict__ ops,
-                   const int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len)
+                   const int32_t *__restrict__ out_end, uint32_t *__restrict__ out_len, int rev)
 {
     __shared__ ulonglong2 s_tile[HK * 64];               /* (Pv, Ph) of a part's HK columns, [column][lane] */
     __shared__ uint64_t s_peq[4 * 64];                   /* the four match masks of the block the lane's path is in, [code][lane] */
-    const int lane = threadIdx.x, idx = blockIdx.x * 64 + lane;
+    /* rev: the problems are sorted by size, ascending -- the long paths start first (see lf_rsweep_body) */
+    const int lane = threadIdx.x, idx = (rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 64 + lane;
     const bool live = idx < n_probs;
     const lf_aln_prob pr = probs[live ? idx : n_probs - 1];
     const bool want = live && pr.task == LF_TASK_PATH;
@@ -778,6 +779,18 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         const int p_nw_small = h_tab->lo[65], p_shw0 = h_tab->lo[128], p_shw_small = h_tab->lo[128 + 65], p_end = h_tab->lo[256];
         (void)nw_nw; (void)nw_shw;
         RA.ops = d_ops; RA.out_len = d_len;
+        RA.rev = !(getenv("LF_ALIGN_LONG_FIRST") && atoi(getenv("LF_ALIGN_LONG_FIRST")) == 0);      /* A / B hook: 0 = ascending order (round 4) */
+        /* The two modes' problems are independent: NW (the pieces between anchors) sweeps and walks its paths on the class stream, SHW (the pieces in front
+         * of the first / behind the last anchor) on a stream of its own.  Each mode's traceback ends with ONE long path (1.3 and 0.9 ms in a chunk of
+         * 1 600 or 6 250 reads alike, profiles/r05_chain/): back to back they were a quarter of a small chunk's launch chain.  (One stream when the
+         * classes are serialized for the exclusive timings, and for the fused small-problem kernel's A / B.) */
+        hipStream_t cb = cs[1];
+        hipEvent_t shw_done = nullptr;
+        if (!serial_classes && !fused_small && !(getenv("LF_ALIGN_MODE_STREAMS") && atoi(getenv("LF_ALIGN_MODE_STREAMS")) == 0)) {
+            cb = (hipStream_t)lfg_lane_stream(device, 6); shw_done = (hipEvent_t)lfg_lane_event(device, 9);
+            if (!cb || !shw_done) return LF_ERR_HIP;
+            HIPCHK(hipStreamWaitEvent(cb, eb, 0));
+        }
         HIPCHK(hipEventRecord(bd[1], cs[1]));
         if (fused_small) {
             RA.wave0 = 0; RA.n_waves = w_nw_small; lf_rsweep_launch(cs[1], false, RA);
@@ -786,7 +799,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
             RA.wave0 = w_shw_small; RA.n_waves = w_end - w_shw_small; lf_small_launch(cs[1], true, RA);
         } else {
             RA.wave0 = 0; RA.n_waves = w_shw0; lf_rsweep_launch(cs[1], false, RA);
-            RA.wave0 = w_shw0; RA.n_waves = w_end - w_shw0; lf_rsweep_launch(cs[1], true, RA);
+            RA.wave0 = w_shw0; RA.n_waves = w_end - w_shw0; lf_rsweep_launch(cb, true, RA);
         }
         HIPCHK(hipEventRecord(bd[2], cs[1]));
         {
@@ -797,10 +810,12 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
             for (int q = 0; q < 2; q++) {
                 const int np = r1[q] - r0[q];
                 if (np <= 0) continue;
-                if (tb_hk == 16) hipLaunchKernelGGL(lf_edlib_tb_kernel<16>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, cs[1], d_probs + r0[q], np, S, D->pac_syms, d_hist, d_ops, d_end, d_len);
-                else hipLaunchKernelGGL(lf_edlib_tb_kernel<8>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, cs[1], d_probs + r0[q], np, S, D->pac_syms, d_hist, d_ops, d_end, d_len);
+                hipStream_t ts = q == 0 ? cs[1] : cb;
+                if (tb_hk == 16) hipLaunchKernelGGL(lf_edlib_tb_kernel<16>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, ts, d_probs + r0[q], np, S, D->pac_syms, d_hist, d_ops, d_end, d_len, RA.rev);
+                else hipLaunchKernelGGL(lf_edlib_tb_kernel<8>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, ts, d_probs + r0[q], np, S, D->pac_syms, d_hist, d_ops, d_end, d_len, RA.rev);
             }
         }
+        if (cb != cs[1]) { HIPCHK(hipEventRecord(shw_done, cb)); HIPCHK(hipStreamWaitEvent(cs[1], shw_done, 0)); }
         HIPCHK(hipEventRecord(bd[3], cs[1]));
     }
     for (int k = 0; k < LF_NCLASS; k++) if (cnt(k) > 0 && cs[k] != s) { HIPCHK(hipEventRecord(cdone[k], cs[k])); HIPCHK(hipStreamWaitEvent(s, cdone[k], 0)); }

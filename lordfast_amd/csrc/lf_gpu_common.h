@@ -304,9 +304,12 @@ __device__ __forceinline__ uint32_t lf_wave_max_u32(uint32_t v)
 #include <time.h>
 extern "C" void *lfg_thread_wait_event(int device);
 extern "C" void lfg_count_wait(void);
-static inline hipError_t lf_stream_wait(hipStream_t s)
+extern "C" void lfg_count_wait_at(const char *file, int line);        /* LF_WAIT_TRACE=1: waits per call site, printed at exit */
+static inline hipError_t lf_stream_wait(hipStream_t s, const char *file, int line)
 {
     lfg_count_wait();
+    static const bool trace = getenv("LF_WAIT_TRACE") != nullptr;
+    if (trace) lfg_count_wait_at(file, line);
     static const bool spin = getenv("LF_SPIN_WAIT") != nullptr;
     static const long spin_us = getenv("LF_SPIN_US") ? atol(getenv("LF_SPIN_US")) : 200;
     int dev = -1;
@@ -326,7 +329,7 @@ static inline hipError_t lf_stream_wait(hipStream_t s)
     }
     return hipEventSynchronize(e);
 }
-#define hipStreamSynchronize(s) lf_stream_wait(s)
+#define hipStreamSynchronize(s) lf_stream_wait(s, __FILE__, __LINE__)
 #endif
 
 #endif

@@ -7,6 +7,7 @@
 #include <time.h>
 #include <stdlib.h>
 #include <stdio.h>
+#include <string.h>
 #define LF_NO_SYNC_WRAP 1      /* this file hands the blocking wait events out and drains streams of other devices: plain waits here */
 #include "lf_gpu_common.h"
 #include <vector>
@@ -105,6 +106,21 @@ static thread_local lf_wev_holder t_wev;
 static thread_local uint64_t t_waits = 0;
 extern "C" void lfg_count_wait(void) { t_waits++; }
 extern "C" uint64_t lfg_take_waits(void) { const uint64_t w = t_waits; t_waits = 0; return w; }
+/* LF_WAIT_TRACE=1: a census of the waits by call site, printed when the process ends (measurement aid, profiles/tools/r05_waits.sh) */
+static std::mutex g_wsite_mu;
+static struct { const char *file; int line; uint64_t n; } g_wsite[128];
+static int g_nwsite = 0;
+static void wsite_dump(void)
+{
+    for (int i = 0; i < g_nwsite; i++) { const char *b = strrchr(g_wsite[i].file, '/'); fprintf(stderr, "[lf] waits %8llu at %s:%d\n", (unsigned long long)g_wsite[i].n, b ? b + 1 : g_wsite[i].file, g_wsite[i].line); }
+}
+extern "C" void lfg_count_wait_at(const char *file, int line)
+{
+    std::lock_guard<std::mutex> g(g_wsite_mu);
+    for (int i = 0; i < g_nwsite; i++) if (g_wsite[i].line == line && g_wsite[i].file == file) { g_wsite[i].n++; return; }
+    if (g_nwsite == 0) atexit(wsite_dump);
+    if (g_nwsite < 128) { g_wsite[g_nwsite].file = file; g_wsite[g_nwsite].line = line; g_wsite[g_nwsite].n = 1; g_nwsite++; }
+}
 extern "C" void *lfg_thread_wait_event(int device)
 {
     if (device < 0 || device >= MAX_DEV) return nullptr;

@@ -18,7 +18,8 @@ typedef struct {
     const char *query;        /* read forward or reverse complement */
     uint32_t readLen;
     int missing;              /* edlib results still to come */
-    int bail;                 /* a ksw result is missing: stop walking */
+    int bail;                 /* a ksw result is missing: the walk goes on as if the test had not fired (nothing it asks for later depends on the result),
+                               * so ALL extension requests of a chain leave in one round instead of one round per test */
     int build;                /* build strings (results complete so far) */
 } walk_t;
 
@@ -179,7 +180,12 @@ static int need_ksw(walk_t *w, int set, int qrc, uint32_t qs, uint32_t qseg, int
     k.type = 1; k.qrc = (uint8_t)qrc; k.trc = (uint8_t)trc; k.mode = (uint8_t)set;
     k.qs = qs; k.qseg = qseg; k.qn = qseg; k.ts = ts; k.tseg = tseg; k.tn = tseg;
     memo_t *m = memo_find(w->job, &k);
-    if (!m) { m = memo_add(w->job, &k, &w->cx->arena[w->tid]); stage_ksw(w, m); jv_push(&w->cx->ksw_jobs[w->tid], w->job); }
+    if (!m) {
+        static int one_per_round = -1;                     /* LF_KSW_ONE_PER_ROUND=1 (A / B): round 4's behaviour, a walk asks for ONE extension and stops asking */
+        if (one_per_round < 0) one_per_round = getenv("LF_KSW_ONE_PER_ROUND") && atoi(getenv("LF_KSW_ONE_PER_ROUND")) != 0;
+        if (one_per_round && w->bail) return 0;
+        m = memo_add(w->job, &k, &w->cx->arena[w->tid]); stage_ksw(w, m); jv_push(&w->cx->ksw_jobs[w->tid], w->job);
+    }
     if (m->round < 0) { w->bail = 1; w->build = 0; return 0; }
     const ksw_round_t *R = &w->cx->ksw_rounds[m->round];
     *qle = R->qle[m->slot]; *tle = R->tle[m->slot];
@@ -493,8 +499,7 @@ static int walk_chain_mode(ctx_t *cx, int tid, job_t *job, samlist_t *map, int t
             edres_t r = need_edlib(&W, 1, 0, (uint32_t)readAlnLen, (uint32_t)readAlnLen, 1, refAlnStart, (uint32_t)refAlnLen, (uint32_t)refAlnLen, 1);
             int realigned = 0;
             if (r.have && readAlnLen > CLIP_LEN && (1 - ((float)r.ed / readAlnLen)) < CLIP_SIM) {
-                if (!need_ksw(&W, 0, 1, 0, (uint32_t)readAlnLen, 1, refAlnStart, (uint32_t)refAlnLen, &qle, &tle)) goto bail;
-                if (qle > 0 && qle < readAlnLen) {
+                if (need_ksw(&W, 0, 1, 0, (uint32_t)readAlnLen, 1, refAlnStart, (uint32_t)refAlnLen, &qle, &tle) && qle > 0 && qle < readAlnLen) {
                     edres_t r2 = need_edlib(&W, 1, 0, (uint32_t)readAlnLen, (uint32_t)qle, 1, refAlnStart, (uint32_t)refAlnLen, (uint32_t)tle, 0);
                     ab_front_ops(&ab, &r2, refAlnStart, (uint32_t)refAlnLen);
                     editScore -= r2.ed;
@@ -525,13 +530,13 @@ static int walk_chain_mode(ctx_t *cx, int tid, job_t *job, samlist_t *map, int t
             int handled = 0;
             if (r.have && abs(readAlnLen - refAlnLen) >= SPLIT_LEN && (1 - ((float)r.ed / readAlnLen)) < SPLIT_SIM) {
                 /* split test: extension from both ends of the gap (:1967-1983) */
-                int q1, t1, q2, t2;
-                if (!need_ksw(&W, 1, 0, readAlnStart, (uint32_t)readAlnLen, 0, refAlnStart, (uint32_t)refAlnLen, &q1, &t1)) goto bail;
-                if (!need_ksw(&W, 1, 1, readAlnStart, (uint32_t)readAlnLen, 1, refAlnStart, (uint32_t)refAlnLen, &q2, &t2)) goto bail;
+                int q1 = 0, t1 = 0, q2 = 0, t2 = 0;
+                const int k1 = need_ksw(&W, 1, 0, readAlnStart, (uint32_t)readAlnLen, 0, refAlnStart, (uint32_t)refAlnLen, &q1, &t1);
+                const int k2 = need_ksw(&W, 1, 1, readAlnStart, (uint32_t)readAlnLen, 1, refAlnStart, (uint32_t)refAlnLen, &q2, &t2);
                 const uint32_t rs_new = readAlnStart + (uint32_t)q1, ts_new = refAlnStart + (uint32_t)t1;
                 const uint32_t re_new = readAlnEnd - (uint32_t)q2, te_new = refAlnEnd - (uint32_t)t2;
                 const int32_t tl_new = (int32_t)(te_new - ts_new), rl_new = (int32_t)(re_new - rs_new);
-                if (rs_new < re_new || ts_new < te_new) {                                    /* :1995 */
+                if (k1 && k2 && (rs_new < re_new || ts_new < te_new)) {                      /* :1995 */
                     handled = 1;
                     if (rs_new > readAlnStart || ts_new > refAlnStart) {                     /* first part :1998-2007 */
                         edres_t a = need_edlib(&W, 0, readAlnStart, (uint32_t)readAlnLen, rs_new - readAlnStart, 0, refAlnStart, (uint32_t)refAlnLen, ts_new - refAlnStart, 0);
@@ -590,8 +595,7 @@ static int walk_chain_mode(ctx_t *cx, int tid, job_t *job, samlist_t *map, int t
             edres_t r = need_edlib(&W, 0, readAlnStart, (uint32_t)readAlnLen, (uint32_t)readAlnLen, 0, refAlnStart, (uint32_t)refAlnLen, (uint32_t)refAlnLen, 1);
             int realigned = 0;
             if (r.have && readAlnLen > CLIP_LEN && (1 - ((float)r.ed / readAlnLen)) < CLIP_SIM) {
-                if (!need_ksw(&W, 0, 0, readAlnStart, (uint32_t)readAlnLen, 0, refAlnStart, (uint32_t)refAlnLen, &qle, &tle)) goto bail;
-                if (qle > 0 && qle < readAlnLen) {
+                if (need_ksw(&W, 0, 0, readAlnStart, (uint32_t)readAlnLen, 0, refAlnStart, (uint32_t)refAlnLen, &qle, &tle) && qle > 0 && qle < readAlnLen) {
                     edres_t r2 = need_edlib(&W, 0, readAlnStart, (uint32_t)readAlnLen, (uint32_t)qle, 0, refAlnStart, (uint32_t)refAlnLen, (uint32_t)tle, 0);
                     ab_back_ops(&ab, &r2, 0, refAlnStart, (uint32_t)refAlnLen);
                     editScore -= r2.ed;
@@ -611,7 +615,6 @@ static int walk_chain_mode(ctx_t *cx, int tid, job_t *job, samlist_t *map, int t
     }
     tmp.nmCount = editScore;
     emit_sam(&W, map, &tmp, &ab);
-bail:
     *need_track = ab.need_track;
     ab_free(&ab);
     job->complete = (W.missing == 0 && !W.bail);

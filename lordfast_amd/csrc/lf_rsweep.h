@@ -6,7 +6,7 @@
 /* one wavefront of the forward kernel: `count` problems of G blocks each, probs[first ..], checkpoints from hist_base */
 struct lf_rwave { uint32_t first; uint16_t count, G; uint64_t hist_base; };
 struct lf_rsw_args {
-    const lf_aln_prob *probs; const lf_rwave *waves; int wave0, n_waves;
+    const lf_aln_prob *probs; const lf_rwave *waves; int wave0, n_waves, rev;      /* rev: workgroup b takes wave n_waves - 1 - b */
     const uint64_t *qlo, *qhi, *qvalid; int64_t q_words;      /* bit planes of the query buffer (lf_pack_planes_kernel) */
     const uint8_t *pac; int64_t pac_syms;                      /* 2-bit targets, four per byte, first symbol in the top bits */
     lf_hist_t *ckpt; int32_t *out_ed, *out_end;

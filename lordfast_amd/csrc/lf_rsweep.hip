@@ -101,7 +101,9 @@ __device__ __forceinline__ void lf_rsweep_body(const lf_rsw_args &A)
     __shared__ ulonglong2 s_tile[SMALL ? LF_SMALL_HK * 64 : 1];
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= A.n_waves) return;
-    const lf_rwave W = A.waves[A.wave0 + blockIdx.x];
+    /* the segments are sorted by blocks per problem and target length, ascending: handed out from the END, the long sweeps start first and the
+     * short ones fill in behind them (the launch ends with the last short wave, not with a long one that started last) */
+    const lf_rwave W = A.waves[A.wave0 + (A.rev ? A.n_waves - 1 - (int)blockIdx.x : (int)blockIdx.x)];
     const int G = (int)W.G;
     const int g = lane / G, gl = lane - g * G;
     const bool live = g < (int)W.count;
