@@ -606,7 +606,20 @@ __global__ void lf_desc_build_kernel(const uint32_t *__restrict__ keys, const ui
  * traceback (lf_edlib_tb_kernel), Hirschberg levels (incl. their per-level readbacks), binning (keys, sort, segments, scan, build).
  * Alone on the GPU only when the classes run on one stream (LF_SERIAL_CLASSES: bench.py's exclusive pass). */
 static thread_local float t_breakdown[4];
-extern "C" void lfg_edlib_breakdown(float *out4) { for (int k = 0; k < 4; k++) out4[k] = t_breakdown[k]; }
+/* A device-planned round (lfg_edlib_desc_dev) hands nothing to the host: its consumer, lf_walk_emit_kernel, is queued behind it on the same stream, and
+ * the call returns without waiting.  Its event brackets are read when somebody asks -- lf_pipeline.c does after lfg_walk_emit's wait. */
+static thread_local struct { bool on, class1; hipEvent_t e0, e1, eb, bd[4]; float ms; } t_pend;
+static void breakdown_resolve(void)
+{
+    if (!t_pend.on) return;
+    t_pend.on = false;
+    if (hipEventElapsedTime(&t_pend.ms, t_pend.e0, t_pend.e1) != hipSuccess) { (void)hipGetLastError(); t_pend.ms = 0; return; }
+    if (t_pend.class1) { (void)hipEventElapsedTime(&t_breakdown[0], t_pend.bd[1], t_pend.bd[2]); (void)hipEventElapsedTime(&t_breakdown[1], t_pend.bd[2], t_pend.bd[3]); }
+    (void)hipEventElapsedTime(&t_breakdown[2], t_pend.e0, t_pend.bd[0]); (void)hipEventElapsedTime(&t_breakdown[3], t_pend.bd[0], t_pend.eb);
+    (void)hipGetLastError();
+}
+extern "C" void lfg_edlib_breakdown(float *out4) { breakdown_resolve(); for (int k = 0; k < 4; k++) out4[k] = t_breakdown[k]; }
+extern "C" float lfg_edlib_round_ms(void) { breakdown_resolve(); return t_pend.ms; }      /* e0 .. e1 of the calling thread's last device-planned round */
 
 /* dev_desc / dev_opsoff != nullptr: the descriptors are already on the device (lfg_walk_plan) and the results stay there
  * (res_dev[0..2] = ed, end column, path length arrays) */
@@ -616,6 +629,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
 {
     if (ms) *ms = 0;
     for (int k = 0; k < 4; k++) t_breakdown[k] = 0;
+    t_pend.on = false; t_pend.ms = 0;
     if (n == 0) return LF_OK;
     HIPCHK(hipSetDevice(device));
     hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
@@ -827,6 +841,11 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         HIPCHK(hipMemcpyAsync(ops_len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     }
     if (ops) HIPCHK(hipMemcpyAsync(ops, d_ops, D->ops_total, hipMemcpyDeviceToHost, s));
+    if (dev_desc && !ed && !ops && !getenv("LF_HIST_STATS")) {
+        HIPCHK(hipGetLastError());
+        t_pend.on = true; t_pend.class1 = cnt(1) > 0; t_pend.e0 = e0; t_pend.e1 = e1; t_pend.eb = eb; for (int k = 0; k < 4; k++) t_pend.bd[k] = bd[k];
+        return LF_OK;
+    }
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
     if (ms) HIPCHK(hipEventElapsedTime(ms, e0, e1));

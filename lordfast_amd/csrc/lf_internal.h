@@ -63,13 +63,14 @@ typedef struct {
     uint64_t *req0;           /* n_reads + 1: first request of each read */
     uint32_t *nreq; float *vscore;
     uint32_t *req_win;        /* per request: window id | isReverse << 31 */
-    uint32_t *chain_len; float *chain_score; uint64_t *chain_off; Seed_t *chain_seeds;
+    uint32_t *chain_len; float *chain_score; uint64_t *chain_off; Seed_t *chain_seeds;      /* chain_seeds: NULL (in HBM only) until lfg_vote_fetch_chains */
     uint64_t n_req_seeds, n_chain_seeds, n_tie_req;
     float ms_vote, ms_chain;
     /* the same chains in HBM (valid until this lane's next lfg_vote_chain): what lf_walk.hip works on */
     const void *d_chain_seeds, *d_chain_off, *d_chain_len, *d_ctg;
 } lfg_vc_t;
 int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, int n_reads, uint64_t n_hits, uint32_t max_read_len, lfg_vc_t *out);
+int lfg_vote_fetch_chains(const struct lf_index *ix, lfg_vc_t *vc);      /* out->chain_seeds is NULL after lfg_vote_chain: the chains stay in HBM unless this is called */
 void lfg_hits_free(lfg_hits_t *h);
 
 int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, const Seed_t *sorted_seeds,
@@ -149,6 +150,7 @@ typedef struct {
 int lfg_walk_plan(const struct lf_index *ix, int n_jobs, const lf_wjob_t *jobs, const lfg_vc_t *vc, int lazy, lfg_walk_t *W);
 int lfg_walk_emit(const struct lf_index *ix, const lfg_vc_t *vc, int lazy, lfg_walk_t *W, const void *d_ed, const void *d_end, const void *d_len, lf_wrec_t **wrec_out);
 void lfg_edlib_breakdown(float *out4);      /* event brackets of the calling thread's last alignment batch: forward, traceback, Hirschberg levels, binning */
+float lfg_edlib_round_ms(void);
 /* alignments of device-resident descriptors (lfg_walk_plan); results stay on the device */
 int lfg_edlib_desc_dev(const struct lf_index *ix, int n, const void *d_desc, const void *d_opsoff, uint64_t ops_total, const lf_hcount_t *hc, int ops_slot,
                        void **ops_dev, void **ed_dev, void **end_dev, void **len_dev, float *ms);

@@ -256,6 +256,8 @@ typedef struct ctx {
     int32_t **stage_sink; int stage_i0;          /* lf_map_stages_batch: per read (batch index stage_i0 + ri) its decision, windows and alignWin results */
     /* HOLES mode (lf_sam.hip): the SEQ / QUAL column of every line is filled on the host from the caller's strings */
     int holes; struct fill *fill; int n_fill;
+    /* the chains the device walk left to the host replay: the reads that still have an open job (NULL: every read is looked at, the cross-check paths) */
+    int *open; int n_open; struct job **wj_owner; const void *wj_rec; volatile int n_rare;
 } ctx_t;
 typedef struct fill { uint64_t pos; const char *seq, *qual; uint32_t len; uint8_t rev, fq; } fill_t;
 

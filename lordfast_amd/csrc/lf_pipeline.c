@@ -132,7 +132,7 @@ void phase_make_jobs(ctx_t *cx, int tid, int ri)
         j->chainLen = cx->chain_len[rq];
         /* the chain is only READ on the host, and only by the replay of the few chains that leave the common path (lf_replay.c): it stays
          * where the chain stage left it (the lane's pinned slot, valid until this lane's next lfg_vote_chain) -- no copy per job */
-        if (!cx->host_vote) j->chain = cx->vc.chain_seeds + cx->vc.chain_off[rq];
+        if (!cx->host_vote) j->chain = cx->vc.chain_seeds ? cx->vc.chain_seeds + cx->vc.chain_off[rq] : NULL;      /* NULL: fetched with the open list, if the job ends up on it */
         else {
             j->chain = (Seed_t *)ar_alloc(&cx->arena[tid], ((size_t)j->chainLen + 1) * sizeof(Seed_t));
             const creq_t *cq = &cx->creq[rq];
@@ -141,6 +141,26 @@ void phase_make_jobs(ctx_t *cx, int tid, int ri)
         j->complete = (j->chainLen <= 1);                   /* nothing to extend: totalScore = -2L (:1089) */
     }
 }
+
+static int cmp_int(const void *a, const void *b) { const int x = *(const int *)a, y = *(const int *)b; return (x > y) - (x < y); }
+static void phase_select_jobs(ctx_t *cx, int tid, int ri) { phase_select(cx, tid, ri); phase_fine_select(cx, tid, ri); phase_make_jobs(cx, tid, ri); }
+
+/* the device walk's records (lfg_walk_emit) become the jobs' mappings; the chains it left to the host are collected */
+static void phase_take_wrec(ctx_t *cx, int tid, int k)
+{
+    job_t *j = cx->wj_owner[k];
+    const lf_wrec_t *wr = (const lf_wrec_t *)cx->wj_rec + k;
+    if (wr->rare) { cx->open[__atomic_fetch_add(&cx->n_rare, 1, __ATOMIC_RELAXED)] = k; return; }
+    rd_t *r = &cx->reads[j->read];
+    samlist_t *map = &r->maps[j->widx];
+    sam_t tmp; memset(&tmp, 0, sizeof tmp);
+    tmp.flag = j->isRev ? 16 : 0; tmp.pos = wr->pos; tmp.posEnd = wr->posEnd; tmp.qStart = wr->qStart; tmp.qEnd = wr->qEnd; tmp.nmCount = wr->nm;
+    samlist_clear(map);
+    samlist_push(map, &tmp, NULL, NULL, &cx->arena[tid]);
+    map->v[0].rec = k; map->v[0].rtid = -2;                 /* record k of the device-planned recipe */
+    j->complete = 1;
+}
+static void phase_walk_open(ctx_t *cx, int tid, int k);
 
 static void phase_walk(ctx_t *cx, int tid, int ri)
 {
@@ -152,6 +172,8 @@ static void phase_walk(ctx_t *cx, int tid, int ri)
         walk_chain(cx, tid, j, &r->maps[w]);
     }
 }
+
+static void phase_walk_open(ctx_t *cx, int tid, int k) { phase_walk(cx, tid, cx->open[k]); }
 
 static void phase_merge_desc(ctx_t *cx, int tid, int t)
 {
@@ -320,12 +342,12 @@ int map_chunk(ctx_t *cx)
         tmark(cx, "VOTECHAIN");
         if (rc != LF_OK) return rc;
         cx->n_creq = cx->vc.n_req; cx->chain_len = cx->vc.chain_len; cx->chain_score = cx->vc.chain_score;
+        /* every chain is walked on the host in the cross-check modes: all of them come back; otherwise only the ones the device walk leaves open (extend) */
+        if (cx->host_cigar || (g_crosscheck & LF_XC_HOST_WALK)) { rc = lfg_vote_fetch_chains(cx->ix, &cx->vc); if (rc != LF_OK) return rc; }
         st->ms_k_vote += cx->vc.ms_vote; st->ms_k_chain += cx->vc.ms_chain; st->n_chain_problems += (uint64_t)cx->vc.n_req;
         st->n_req_seeds += cx->vc.n_req_seeds; st->n_tie_requests += cx->vc.n_tie_req;
-        parallel_for(cx, n, phase_select);
         t1 = now_ms(); st->ms_vote += t1 - t0; tstage[1] = t1 - t0; t0 = t1;
-        parallel_for(cx, n, phase_fine_select);
-        parallel_for(cx, n, phase_make_jobs);
+        parallel_for(cx, n, phase_select_jobs);            /* selection, fine-mode heap and the jobs of a read: one pass over the reads */
         tmark(cx, "select+jobs");
         t1 = now_ms(); st->ms_chain += t1 - t0; tstage[2] = t1 - t0; t0 = t1;
         goto extend;
@@ -348,6 +370,7 @@ extend:
      * clip / split triggers -> record fields + CIGAR recipe, all in HBM.  Chains that leave the common path (and everything
      * when a host cross-check mode is on) are replayed by the host walk below, which then finds them incomplete. ---- */
     cx->n_dev_recs = 0; cx->n_dev_items = 0; cx->d_dev_recs = NULL; cx->d_dev_items = NULL;
+    free(cx->open); cx->open = NULL; cx->n_open = 0;
     if (!host_vote && !cx->host_cigar && !(g_crosscheck & LF_XC_HOST_WALK)) {
         int nj = 0;
         for (int i = 0; i < n; i++) { const rd_t *r = &cx->reads[i]; if (r->mode >= 2) for (int w = 0; w < r->nWins; w++) nj += r->jobs[w].chainLen > 1; }
@@ -385,66 +408,87 @@ extend:
                 cx->ed_rounds = (ed_round_t *)realloc(cx->ed_rounds, ((size_t)cx->n_ed_rounds + 1) * sizeof(ed_round_t));
                 cx->ed_rounds[cx->n_ed_rounds++] = R;
             }
+            if (W.n_desc) ms = lfg_edlib_round_ms();           /* (the round returned without waiting: its events are complete now, behind lfg_walk_emit's wait) */
             st->ms_k_edlib += ms; st->n_edlib_problems += W.n_desc; st->edlib_launches += 1; st->ops_bytes += W.ops_total;
             if (W.n_desc) { float bd[4]; lfg_edlib_breakdown(bd); st->ms_k_rsweep += bd[0]; st->ms_k_tb += bd[1]; st->ms_k_hirsch += bd[2]; st->ms_k_bin += bd[3]; }
             st->ext_bytes += W.ext_bytes; st->dp_block_steps += W.block_steps;
             st->hirsch_bytes += 2 * W.hc.sum_n + W.hc.sum_m + (W.hc.sum_m + 3) / 4;
-            int n_rare = 0;
-            for (k = 0; k < nj; k++) {
-                job_t *j = owner[k];
-                if (wrec[k].rare) { n_rare++; continue; }
-                rd_t *r = &cx->reads[j->read];
-                samlist_t *map = &r->maps[j->widx];
-                sam_t tmp; memset(&tmp, 0, sizeof tmp);
-                tmp.flag = j->isRev ? 16 : 0; tmp.pos = wrec[k].pos; tmp.posEnd = wrec[k].posEnd; tmp.qStart = wrec[k].qStart; tmp.qEnd = wrec[k].qEnd; tmp.nmCount = wrec[k].nm;
-                samlist_clear(map);
-                samlist_push(map, &tmp, NULL, NULL, &cx->arena[0]);
-                map->v[0].rec = k; map->v[0].rtid = -2;                 /* record k of the device-planned recipe */
-                j->complete = 1;
-            }
+            /* (the pool: one sam_t per job, 100 k of them per step) */
+            cx->open = (int *)malloc(((size_t)nj + 1) * sizeof(int));
+            if (!cx->open) { free(owner); return LF_ERR_NOMEM; }
+            cx->wj_owner = owner; cx->wj_rec = wrec; cx->n_rare = 0;
+            parallel_for(cx, nj, phase_take_wrec);
+            const int n_rare = cx->n_rare;
+            /* rare jobs -> the reads that hold them, each once, in read order (the replay's requests are staged in this order) */
+            for (k = 0; k < n_rare; k++) cx->open[k] = owner[cx->open[k]]->read;
+            qsort(cx->open, (size_t)n_rare, sizeof(int), cmp_int);
+            { int u = 0; for (k = 0; k < n_rare; k++) if (u == 0 || cx->open[u - 1] != cx->open[k]) cx->open[u++] = cx->open[k]; cx->n_open = u; }
+            cx->wj_owner = NULL; cx->wj_rec = NULL;
             if (timing) fprintf(stderr, "[lf] device walk: %d jobs, %llu pieces aligned, %d jobs (%.1f %%) left to the host replay\n", nj, (unsigned long long)W.n_desc, n_rare, 100.0 * n_rare / nj);
             cx->n_dev_recs = nj; cx->n_dev_items = W.n_items; cx->d_dev_recs = W.d_recs; cx->d_dev_items = W.d_items;
             free(owner);
         }
     }
-    if (cx->d_seqs) {
-        /* lf_map_batch_dev: the reads whose chains the host is about to replay, fetched together (rd_host_bases would get them
-         * one by one, each copy behind a lock and a wait) */
+    if (cx->open ? cx->n_open > 0 : cx->d_seqs != NULL) {
+        /* What the host replay reads, fetched together with ONE gather kernel, one copy, one wait: the chains of the jobs the device walk left open
+         * (the chain stage keeps all chains in HBM; round 5 still copied every chain of every chunk back -- 64 MB per 100 k reads -- for the one or
+         * two chains per chunk the host ever looks at) and, for lf_map_batch_dev, those reads' bases (rd_host_bases would get them one by one, each
+         * copy behind a lock and a wait).  Without an open list (cross-check paths: every chain is walked on the host, all chains were copied back
+         * after the chain stage) only the bases. */
+        const int nscan = cx->open ? cx->n_open : n;
         int nf = 0; size_t tot = 0;
-        for (int i = 0; i < n; i++) {
-            rd_t *r = &cx->reads[i];
-            if (r->mode < 2 || r->seq) continue;
-            int open = 0;
-            for (int w = 0; w < r->nWins; w++) open |= !r->jobs[w].complete;
-            if (open) { nf++; tot += ((size_t)r->len + 1) * (r->isFq ? 2 : 1); }
-        }
-        if (nf) {
-            char *buf = (char *)lfg_pin_slot(LF_PS_HOSTBASES, tot + 64);
-            uint64_t *hoff = (uint64_t *)malloc((size_t)nf * 2 * sizeof(uint64_t)); const void **src = (const void **)malloc((size_t)nf * 2 * sizeof(void *));
-            size_t *nb = (size_t *)malloc((size_t)nf * 2 * sizeof(size_t));
-            if (!buf || !hoff || !src || !nb) { free(hoff); free(src); free(nb); return LF_ERR_NOMEM; }
+        char *buf = NULL; uint64_t *hoff = NULL; const void **src = NULL; size_t *nb = NULL; uint8_t *term = NULL;
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1) {
+                if (!nf) break;
+                buf = (char *)lfg_pin_slot(LF_PS_HOSTBASES, tot + 64);
+                hoff = (uint64_t *)malloc((size_t)nf * sizeof(uint64_t)); src = (const void **)malloc((size_t)nf * sizeof(void *)); nb = (size_t *)malloc((size_t)nf * sizeof(size_t));
+                term = (uint8_t *)malloc((size_t)nf);
+                if (!buf || !hoff || !src || !nb || !term) { free(hoff); free(src); free(nb); free(term); return LF_ERR_NOMEM; }
+            }
             int k = 0; size_t o = 0;
-            for (int i = 0; i < n; i++) {
-                rd_t *r = &cx->reads[i];
-                if (r->mode < 2 || r->seq) continue;
+            for (int x = 0; x < nscan; x++) {
+                rd_t *r = &cx->reads[cx->open ? cx->open[x] : x];
+                if (r->mode < 2) continue;
                 int open = 0;
                 for (int w = 0; w < r->nWins; w++) open |= !r->jobs[w].complete;
                 if (!open) continue;
-                hoff[k] = o; src[k] = cx->d_seqs + r->src_off; nb[k] = r->len; k++;
-                r->seq = buf + o; o += (size_t)r->len + 1;
-                if (r->isFq) { hoff[k] = o; src[k] = cx->d_quals + r->src_off; nb[k] = r->len; k++; r->qual = buf + o; o += (size_t)r->len + 1; }
+                if (cx->d_seqs && !r->seq) {                /* (a read is visited once per pass: still NULL in the second) */
+                    if (pass == 1) { hoff[k] = o; src[k] = cx->d_seqs + r->src_off; nb[k] = r->len; term[k] = 1; r->seq = buf + o; }
+                    k++; o += (size_t)r->len + 1;
+                    if (r->isFq) { if (pass == 1) { hoff[k] = o; src[k] = cx->d_quals + r->src_off; nb[k] = r->len; term[k] = 1; r->qual = buf + o; } k++; o += (size_t)r->len + 1; }
+                }
+                if (cx->open && !cx->vc.chain_seeds) for (int w = 0; w < r->nWins; w++) {
+                    job_t *j = &r->jobs[w];
+                    if (j->complete || j->chainLen == 0) continue;
+                    o = (o + 7) & ~(size_t)7;
+                    if (pass == 1) { hoff[k] = o; src[k] = (const Seed_t *)cx->vc.d_chain_seeds + cx->vc.chain_off[j->req]; nb[k] = (size_t)j->chainLen * sizeof(Seed_t); term[k] = 0; j->chain = (Seed_t *)(buf + o); }
+                    k++; o += (size_t)j->chainLen * sizeof(Seed_t);
+                }
             }
+            if (pass == 0) { nf = k; tot = o; continue; }
             rc = lfg_fetch_gather(cx->ix->device, k, buf, hoff, src, nb, o);
-            /* (the copy brings the staging buffer's gaps along: the terminators are written after it) */
-            for (int i = 0; i < k; i++) buf[hoff[i] + nb[i]] = 0;
-            free(hoff); free(src); free(nb);
+            /* (the copy brings the staging buffer's gaps along: the strings' terminators are written after it) */
+            for (int i = 0; i < k; i++) if (term[i]) buf[hoff[i] + nb[i]] = 0;
+            free(hoff); free(src); free(nb); free(term);
             if (rc != LF_OK) return rc;
             tmark(cx, "fetch");
         }
     }
     for (int round = 0; round < 64; round++) {
         double tw0 = now_ms();
-        parallel_for(cx, n, phase_walk);
+        if (cx->open) {
+            /* only the reads that still have an open job; the list shrinks as their jobs complete */
+            if (cx->n_open) parallel_for(cx, cx->n_open, phase_walk_open);
+            int u = 0;
+            for (int x = 0; x < cx->n_open; x++) {
+                const rd_t *r = &cx->reads[cx->open[x]];
+                int open = 0;
+                for (int w = 0; w < r->nWins; w++) open |= !r->jobs[w].complete;
+                if (open) cx->open[u++] = cx->open[x];
+            }
+            cx->n_open = u;
+        } else parallel_for(cx, n, phase_walk);
         tmark(cx, "walk");
         if (timing) fprintf(stderr, "[lf] round %d walk %.1f ms\n", round, now_ms() - tw0);
         int nk = 0, nd = 0;
@@ -590,6 +634,7 @@ void chunk_free(ctx_t *cx)
 {
     for (int t = 0; t < cx->n_threads; t++) ar_reset(&cx->arena[t]);      /* every per-read object at once */
     free(cx->creq); free(cx->cseeds); free(cx->chain_idx);
+    free(cx->open); cx->open = NULL; cx->n_open = 0;
     if (cx->host_vote) { free(cx->chain_len); free(cx->chain_score); }          /* device path: pinned slots of lfg_vote_chain */
     for (int k = 0; k < cx->n_ed_rounds; k++) { ed_round_t *R = &cx->ed_rounds[k]; if (!R->pinned) { free(R->ed); free(R->end); free(R->ops_len); free(R->ops); } free(R->ops_off); }
     for (int k = 0; k < cx->n_ksw_rounds; k++) { ksw_round_t *R = &cx->ksw_rounds[k]; free(R->score); free(R->qle); free(R->tle); }

@@ -110,6 +110,12 @@ void parallel_for_named(ctx_t *cx, int n, pf_fn fn, const char *name)
     pjob_t *J = &P->job[cx->lane];
     const int self = P->nw + cx->lane;
     const double w0 = g_phase_on ? now_ms() : 0;
+    if (n <= 4) {                                           /* a handful of items (the replay of a chunk's one or two rare chains): not worth waking the pool */
+        const long long c0 = g_phase_on ? thread_cpu_ns() : 0;
+        for (int i = 0; i < n; i++) fn(cx, self, i);
+        if (g_phase_on) phase_account(name, (thread_cpu_ns() - c0) / 1e6, now_ms() - w0);
+        return;
+    }
     pthread_mutex_lock(&P->mu);
     J->fn = fn; J->cx = cx; J->n = n; J->next = 0; J->timed = g_phase_on; J->cpu_ns = 0;
     J->grain = n / ((P->nw + 1) * 16) + 1; if (J->grain > 64) J->grain = 64;

@@ -890,11 +890,10 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
         }
     }
     { lf_scan_u32 f; f.p = d_clen; const int src = lf_scan_excl(dv, 1, s, f, d_coff, (size_t)n_req); if (src != LF_OK) return src; }
-    HIPCHK(hipMemcpyAsync(h_small + 5, d_coff + (Q - 1), 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h_small + 6, d_clen + (Q - 1), 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    const uint64_t C = h_small[5] + (uint32_t)h_small[6];
-    uint2 *d_cseeds = (uint2 *)VSLOT(19, C * 8 + 64);
+    /* a chain is a subset of its request's seeds: S bounds the chains' total, so the gather needs no readback of it; and the chains stay in HBM --
+     * the device walk (lf_walk.hip) reads them there, the host fetches the few it replays itself (lf_pipeline.c) or all of them on request
+     * (lfg_vote_fetch_chains: the cross-check paths) */
+    uint2 *d_cseeds = (uint2 *)VSLOT(19, S * 8 + 64);
     if (!d_cseeds) return LF_ERR_NOMEM;
     hipLaunchKernelGGL(lf_chain_gather_kernel, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_req_off, d_cidx, d_clen, d_coff, d_sorted, d_cseeds);
     HIPCHK(hipEventRecord(e2, s));
@@ -902,15 +901,16 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     out->chain_len = (uint32_t *)lfg_pin_slot(LF_PS_VOTE0 + 7, Q * 4 + 16);
     out->chain_score = (float *)lfg_pin_slot(LF_PS_VOTE0 + 8, Q * 4 + 16);
     out->chain_off = (uint64_t *)lfg_pin_slot(LF_PS_VOTE0 + 9, (Q + 1) * 8);
-    out->chain_seeds = (Seed_t *)lfg_pin_slot(LF_PS_VOTE0 + 10, C * 8 + 16);
-    if (!out->req_win || !out->chain_len || !out->chain_score || !out->chain_off || !out->chain_seeds) return LF_ERR_NOMEM;
+    if (!out->req_win || !out->chain_len || !out->chain_score || !out->chain_off) return LF_ERR_NOMEM;
     HIPCHK(hipMemcpyAsync(out->req_win, d_req_win, Q * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out->chain_len, d_clen, Q * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out->chain_score, d_cscore, Q * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(out->chain_off, d_coff, Q * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(out->chain_seeds, d_cseeds, C * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
+    const uint64_t C = out->chain_off[Q - 1] + out->chain_len[Q - 1];
+    if (C > S) { lf_set_error("lfg_vote_chain: %llu chain seeds out of %llu request seeds", (unsigned long long)C, (unsigned long long)S); return LF_ERR_HIP; }
+    out->chain_seeds = nullptr;
     out->chain_off[Q] = C; out->req0[R] = n_req;
     out->n_tie_req = have_ties ? h_small[8] : 0;
     out->n_chain_seeds = C;
@@ -918,5 +918,21 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
     HIPCHK(hipEventElapsedTime(&out->ms_vote, e0, e1));
     HIPCHK(hipEventElapsedTime(&out->ms_chain, e1, e2));
 #undef VSLOT
+    return LF_OK;
+}
+
+/* all chains of the lane's last lfg_vote_chain, copied to a pinned host array (valid until the lane's next call): for the callers that walk every
+ * chain on the host (lf_debug_crosscheck's host walk / host CIGAR modes) */
+extern "C" int lfg_vote_fetch_chains(const struct lf_index *ix, lfg_vc_t *vc)
+{
+    if (vc->chain_seeds || !vc->n_chain_seeds || !vc->d_chain_seeds) return LF_OK;
+    HIPCHK(hipSetDevice(ix->device));
+    hipStream_t s = (hipStream_t)lfg_lane_stream(ix->device, 0);
+    if (!s) return LF_ERR_HIP;
+    Seed_t *h = (Seed_t *)lfg_pin_slot(LF_PS_VOTE0 + 10, vc->n_chain_seeds * 8 + 16);
+    if (!h) return LF_ERR_NOMEM;
+    HIPCHK(hipMemcpyAsync(h, vc->d_chain_seeds, vc->n_chain_seeds * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    vc->chain_seeds = h;
     return LF_OK;
 }

@@ -275,24 +275,25 @@ extern "C" int lfg_walk_plan(const struct lf_index *ix, int n_jobs, const lf_wjo
     { lf_scan_u64 f; f.p = d_ob; const int src = lf_scan_excl(dv, 3, s, f, d_obase, (size_t)n_jobs + 1); if (src != LF_OK) return src; }
     { const int src = lf_scan_excl(dv, 3, s, so, d_sbase, (size_t)n_jobs); if (src != LF_OK) return src; }
     { const int src = lf_scan_excl(dv, 3, s, io, d_ibase, (size_t)n_jobs); if (src != LF_OK) return src; }
-    HIPCHK(hipMemcpyAsync(h, d_dbase + J, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h + 1, d_obase + J, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h + 2, d_sbase + (J - 1), 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h + 3, d_ibase + (J - 1), 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    const uint64_t n_desc = h[0], ops_total = h[1];
-    const uint64_t n_slots = h[2] + jobs[J - 1].chain_len + 1, n_items = h[3] + 2ull * jobs[J - 1].chain_len + 1;
-    if (n_desc >= (1ull << 31) || n_items >= 0xffffffffull) { lf_set_error("lfg_walk_plan: too many alignment pieces in one chunk"); return LF_ERR_ARG; }
+    /* slots and items follow from the chain lengths (host); a chain of L anchors has at most L + 1 pieces, so the slots bound the descriptors too:
+     * the second pass is launched without waiting for the first one's totals (they come back with the statistics, one wait for both) */
+    uint64_t n_slots = 0, n_items = 0;
+    for (size_t k = 0; k < J; k++) { n_slots += (uint64_t)jobs[k].chain_len + 1; n_items += 2ull * jobs[k].chain_len + 1; }
+    if (n_slots >= (1ull << 31) || n_items >= 0xffffffffull) { lf_set_error("lfg_walk_plan: too many alignment pieces in one chunk"); return LF_ERR_ARG; }
     /* the round's descriptors live next to its paths (slot of extension round 0), like the host-planned rounds' */
-    lf_aln_desc_t *d_desc = (lf_aln_desc_t *)lfg_dev_slot(dv, LF_DS_RND0 + 1, (n_desc + 1) * sizeof(lf_aln_desc_t));
-    uint64_t *d_opsoff = WSLOT(uint64_t, 10, (n_desc + 1) * 8);
+    lf_aln_desc_t *d_desc = (lf_aln_desc_t *)lfg_dev_slot(dv, LF_DS_RND0 + 1, (n_slots + 1) * sizeof(lf_aln_desc_t));
+    uint64_t *d_opsoff = WSLOT(uint64_t, 10, (n_slots + 1) * 8);
     int32_t *d_slot_desc = WSLOT(int32_t, 11, (n_slots + 1) * 4);
     if (!d_desc || !d_opsoff || !d_slot_desc) return LF_ERR_NOMEM;
     hipLaunchKernelGGL(lf_walk_plan_kernel<true>, dim3((unsigned)n_jobs), dim3(64), 0, s, n_jobs, (const lf_wjob_t *)d_jobs, D, lazy, d_nd, d_ob, d_rare,
                        (const uint64_t *)d_dbase, (const uint64_t *)d_obase, (const uint64_t *)d_sbase, d_desc, d_opsoff, d_slot_desc, d_tot);
+    HIPCHK(hipMemcpyAsync(h, d_dbase + J, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h + 1, d_obase + J, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h + 32, d_tot, LF_WALK_TOT * 64, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
+    const uint64_t n_desc = h[0], ops_total = h[1];
+    if (n_desc > n_slots) { lf_set_error("lfg_walk_plan: %llu pieces for %llu slots", (unsigned long long)n_desc, (unsigned long long)n_slots); return LF_ERR_HIP; }
     for (int k = 0; k < 6; k++) { uint64_t t = 0; for (int u = 0; u < LF_WALK_TOT; u++) t += h[32 + 8 * u + k]; h[4 + k] = t; }
     W->n_jobs = n_jobs; W->n_desc = n_desc; W->ops_total = ops_total; W->n_items = n_items; W->ext_bytes = h[4]; W->block_steps = h[5];
     W->hc.roots = h[6]; W->hc.cap = h[7]; W->hc.sum_n = h[8]; W->hc.sum_m = h[9];
