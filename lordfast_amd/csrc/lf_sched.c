@@ -600,10 +600,14 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
         int nck = n_lanes; if (nck > n / 6250) nck = n / 6250 > 0 ? n / 6250 : 1;
         const uint64_t cap_b = 768ull << 20;                                    /* working set of a lane: ~ 13 bytes of HBM per base */
         if ((uint64_t)nck * cap_b < total_b) nck = (int)((total_b + cap_b - 1) / cap_b);
-        double wsum = 0; for (int k = 0; k < nck; k++) wsum += 1.0 + (nck > 1 ? ramp * (2.0 * k / (nck - 1) - 1.0) : 0.0);
+        /* share of chunk k: the linear ramp, or LF_CHUNK_WEIGHTS=w0,w1,... (experiment hook: any profile; chunks past the list take the last weight) */
+        double cw[LF_MAX_LANES * 4]; int ncw = 0;
+        if (getenv("LF_CHUNK_WEIGHTS")) { const char *q = getenv("LF_CHUNK_WEIGHTS"); while (*q && ncw < LF_MAX_LANES * 4) { char *e; const double v = strtod(q, &e); if (e == q) break; cw[ncw++] = v > 0.01 ? v : 0.01; q = *e == ',' ? e + 1 : e; } }
+#define CHUNK_W(k) (ncw ? cw[(k) < ncw ? (k) : ncw - 1] : 1.0 + (nck > 1 ? ramp * (2.0 * (k) / (nck - 1) - 1.0) : 0.0))
+        double wsum = 0; for (int k = 0; k < nck; k++) wsum += CHUNK_W(k);
         int i0 = 0; double acc_w = 0; uint64_t acc_b = 0;
         for (int k = 0; k < nck && i0 < n; k++) {
-            acc_w += 1.0 + (nck > 1 ? ramp * (2.0 * k / (nck - 1) - 1.0) : 0.0);
+            acc_w += CHUNK_W(k);
             const uint64_t goal = k == nck - 1 ? total_b : (uint64_t)((double)total_b * acc_w / wsum);
             int i1 = i0;
             while (i1 < n && (acc_b < goal || i1 == i0)) { acc_b += lens[i1]; i1++; }
@@ -611,6 +615,7 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
             B.chunks[B.n_chunks].i0 = i0; B.chunks[B.n_chunks].i1 = i1; B.n_chunks++;
             i0 = i1;
         }
+#undef CHUNK_W
         by_bases = 1;
     }
     for (int i0 = 0; i0 < n && !by_bases; ) {
