@@ -71,7 +71,7 @@ def parse():
                     help="steps in flight at once (threads calling the library concurrently; its lane allocator shares the device's 8 lanes "
                          "between them).  1 = one step after the other.  Small shards (a rank's share under strong scaling) are bound by the "
                          "latency of a chunk's launch chain, which the next steps' kernels hide; every step is still a complete call.  "
-                         "Default: 2 for N > 1 under strong scaling, 4 when a rank's shard is at most 16 k reads (a rank's shard is 1 / N of the batch; the "
+                         "Default: 2 for N > 1 under strong scaling, 4 when a rank's shard is at most 32 k reads (a rank's shard is 1 / N of the batch; the "
                          "exchange loop keeps that many of a rank's steps in flight too, lordfast_amd/dist.py: run_pipeline), else 1")
     ap.add_argument("--mode", choices=["ranks", "inproc"], default="ranks",
                     help="ranks: one process per GPU (torch.distributed); inproc: ONE process drives N devices through lf_map_batch_multi "
@@ -102,10 +102,10 @@ def parse():
     if a.scaling is None:
         a.scaling = "strong" if a.gpus > 1 else "weak"
     if a.inflight is None:
-        # a rank's shard under strong scaling: 2 steps in flight, 4 when the shard is small (12.5 k reads at N = 8: 9.2 -> 8.5 ms per step on the
-        # one-GPU proxy, profiles/r05_shard_sweep/); one step after the other everywhere else
+        # a rank's shard under strong scaling: 2 steps in flight, 4 when the shard is small (12.5 k reads at N = 8: 9.2 -> 8.3 ms per step, 25 k at
+        # N = 4: 18.0 -> 17.4 ms on the one-GPU proxy, profiles/r05_shard_sweep/); one step after the other everywhere else
         strong_ranks = a.gpus > 1 and a.scaling == "strong" and a.mode == "ranks"
-        a.inflight = (4 if a.reads // a.gpus <= 16384 else 2) if strong_ranks else 1
+        a.inflight = (4 if a.reads // a.gpus <= 32768 else 2) if strong_ranks else 1
     if a.repeat_profile is None:
         a.repeat_profile = "t2tlike" if a.config == "c5" else "default"
     if not a.ref_fasta:

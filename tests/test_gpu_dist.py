@@ -100,12 +100,15 @@ def test_bench_strong_scaling_two_ranks_same_records(bench_dir, one_rank_line):
     assert j["value"] > 0 and j["value_hbm_resident"] > 0
 
 
-def test_bench_exchange_keeps_two_steps_of_a_rank_in_flight(bench_dir, one_rank_line):
-    """the strong-scaling default: every rank maps two of its steps concurrently inside the exchange loop (lordfast_amd/dist.py:
-    run_pipeline, ring of three buffers); records identical to the 1-rank run; an explicit --inflight 3 too"""
+def test_bench_exchange_keeps_several_steps_of_a_rank_in_flight(bench_dir, one_rank_line):
+    """the strong-scaling default: every rank maps several of its steps concurrently inside the exchange loop (lordfast_amd/dist.py:
+    run_pipeline, a ring of depth + 1 buffers) -- four for shards of at most 32 k reads like this one, two for larger ones; records identical to the
+    1-rank run; explicit --inflight 2 and 3 too"""
     j = _bench(bench_dir, "--gpus", "2", "--steps", "4", backend="gloo")
-    assert j["steps_in_flight"] == 2 and j["exchange"]["steps_in_flight_per_rank"] == 2 and j["exchange"]["status"] == "ok"
+    assert j["steps_in_flight"] == 4 and j["exchange"]["steps_in_flight_per_rank"] == 4 and j["exchange"]["status"] == "ok"
     assert j["sam_md5"] == one_rank_line["sam_md5"] and j["sam_bytes"] == one_rank_line["sam_bytes"]
+    j2 = _bench(bench_dir, "--gpus", "2", "--steps", "4", "--inflight", "2", backend="gloo")
+    assert j2["steps_in_flight"] == 2 and j2["exchange"]["steps_in_flight_per_rank"] == 2 and j2["sam_md5"] == one_rank_line["sam_md5"]
     j3 = _bench(bench_dir, "--gpus", "2", "--steps", "3", "--inflight", "3", backend="gloo")
     assert j3["exchange"]["steps_in_flight_per_rank"] == 3 and j3["sam_md5"] == one_rank_line["sam_md5"]
 
