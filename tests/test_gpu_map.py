@@ -278,6 +278,37 @@ def test_sam_tandem_repeats_tie_order(tmp_path, oracle_lib):
     assert sam == exp, first_diff(sam, exp)
 
 
+def test_reads_with_junk_ends_and_insertions_replay_in_one_round(tmp_path, oracle_lib, monkeypatch):
+    """Reads with random sequence in front, behind and in the middle: alignChain_edlib's clip test fires at both ends and its split test inside
+    (src/LordFAST.cpp:1840-1867, 1952-2107, 2172-2199), so a chain needs several ksw_extend results.  The host replay (lf_replay.c) asks for all of
+    them in ONE round; the records equal the oracle's, and equal what one request per round (round 4's behaviour, LF_KSW_ONE_PER_ROUND=1) gives."""
+    import lordfast_amd as la
+    g = synth.make_genome(900000, 3, seed=41, n_families=40, repeat_frac=0.08)
+    fa = la.index_build(g, str(tmp_path / "g.fa"))
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    junk = lambda n: acgt[rng.integers(0, 4, size=int(n))].tobytes()
+    base = synth.make_reads(g, 48, 7000, 0.10, seed=21, sigma=0.15)
+    names, seqs = [], []
+    for i, (nm, sq) in enumerate(base):
+        kind = i % 4
+        if kind == 0:   sq = junk(rng.integers(700, 2500)) + sq + junk(rng.integers(700, 2500))                    # clip tests at both ends
+        elif kind == 1: h = len(sq) // 2; sq = sq[:h] + junk(rng.integers(300, 1500)) + sq[h:]                       # split test in the middle
+        elif kind == 2: h = len(sq) // 3; sq = junk(900) + sq[:h] + junk(600) + sq[h:2 * h] + junk(400) + sq[2 * h:] + junk(1200)   # all of them
+        names.append(nm.encode()); seqs.append(sq)
+    orc = oracle_lib.Oracle(fa)
+    exp = orc.map_batch(names, seqs, params=oracle_lib.default_params(threads=8))
+    orc.close()
+    h = la.LordFast(fa, device=0)
+    sam, st = h.map_batch(names, seqs)
+    assert st["n_ksw_problems"] >= 40, "the fixture must trigger clip / split tests"
+    assert sam == exp, first_diff(sam, exp)
+    monkeypatch.setenv("LF_KSW_ONE_PER_ROUND", "1")       # (read once per process: only effective if this is the library's first replay; the comparison below holds either way)
+    sam1, st1 = h.map_batch(names, seqs)
+    h.close()
+    assert sam1 == exp and st1["n_ksw_problems"] == st["n_ksw_problems"]
+
+
 def test_map_file_fasta_gz(lf, golden_dir, tmp_path):
     """lf_map_file: gzip FASTA in (the reference's reader grammar), SAM with header out, batches read ahead of the GPU"""
     import lordfast_amd as la
