@@ -127,6 +127,7 @@ static size_t bgzf_block(const unsigned char *p, size_t avail, size_t *data_off)
     return bsize;
 }
 
+static void blob_pool_reader(int delta);
 int lf_reads_open(const char *path, lf_reads_t **out)
 {
     if (!path || !out) { lf_set_error("lf_reads_open: bad argument"); return LF_ERR_ARG; }
@@ -164,6 +165,7 @@ int lf_reads_open(const char *path, lf_reads_t **out)
         }
         if (fd >= 0) close(fd);
     }
+    blob_pool_reader(+1);
     *out = r;
     return LF_OK;
 }
@@ -172,7 +174,7 @@ void lf_reads_close(lf_reads_t *r)
 {
     if (!r) return;
     if (getenv("LF_TIMING") && r->inflate_cpu_s > 0) fprintf(stderr, "[lf] reader %s: %.2f CPU-s in inflate (%s)\n", r->path, r->inflate_cpu_s, r->src == 1 ? "BGZF blocks, several threads" : "one gzip stream, one thread");
-    blob_pool_trim();                           /* the blobs cached for this file's batches (batches freed later are cached again) */
+    blob_pool_reader(-1);                       /* the last open reader takes the cached blobs with it (batches freed after that are freed, not cached) */
     if (r->zs_live) inflateEnd(&r->zs);
     if (r->map) munmap((void *)r->map, r->map_size);
     free(r->tbuf);
@@ -221,6 +223,7 @@ static int read_record(struct lf_reads *r, gstr_t *name, gstr_t *seq, gstr_t *qu
 #define LF_BLOB_POOL 32
 static struct { char *p; size_t cap; } g_blob_pool[LF_BLOB_POOL];
 static pthread_mutex_t g_blob_mu = PTHREAD_MUTEX_INITIALIZER;
+static int g_blob_readers;                       /* open readers: the pool serves all of them and is emptied when the last one closes */
 static char *blob_get(size_t need, size_t *cap_out)
 {
     pthread_mutex_lock(&g_blob_mu);
@@ -239,11 +242,21 @@ static void blob_pool_trim(void)
     for (int i = 0; i < LF_BLOB_POOL; i++) { free(g_blob_pool[i].p); g_blob_pool[i].p = NULL; g_blob_pool[i].cap = 0; }
     pthread_mutex_unlock(&g_blob_mu);
 }
+static void blob_pool_reader(int delta)
+{
+    pthread_mutex_lock(&g_blob_mu);
+    g_blob_readers += delta;
+    const int last = g_blob_readers <= 0;
+    if (last) g_blob_readers = 0;
+    pthread_mutex_unlock(&g_blob_mu);
+    if (last && delta < 0) blob_pool_trim();
+}
 static void blob_put(char *p, size_t cap)
 {
     if (!p) return;
     pthread_mutex_lock(&g_blob_mu);
     int slot = -1, smallest = -1;
+    if (g_blob_readers <= 0) { pthread_mutex_unlock(&g_blob_mu); free(p); return; }      /* nobody left to reuse it (a batch freed after its reader was closed) */
     for (int i = 0; i < LF_BLOB_POOL; i++) {
         if (!g_blob_pool[i].p) { slot = i; break; }
         if (smallest < 0 || g_blob_pool[i].cap < g_blob_pool[smallest].cap) smallest = i;

@@ -181,9 +181,8 @@ static int need_ksw(walk_t *w, int set, int qrc, uint32_t qs, uint32_t qseg, int
     k.qs = qs; k.qseg = qseg; k.qn = qseg; k.ts = ts; k.tseg = tseg; k.tn = tseg;
     memo_t *m = memo_find(w->job, &k);
     if (!m) {
-        static int one_per_round = -1;                     /* LF_KSW_ONE_PER_ROUND=1 (A / B): round 4's behaviour, a walk asks for ONE extension and stops asking */
-        if (one_per_round < 0) one_per_round = getenv("LF_KSW_ONE_PER_ROUND") && atoi(getenv("LF_KSW_ONE_PER_ROUND")) != 0;
-        if (one_per_round && w->bail) return 0;
+        /* LF_KSW_ONE_PER_ROUND=1 (A / B, read per request: a miss is rare): round 4's behaviour, a walk asks for ONE extension and stops asking */
+        if (w->bail && getenv("LF_KSW_ONE_PER_ROUND") && atoi(getenv("LF_KSW_ONE_PER_ROUND")) != 0) return 0;
         m = memo_add(w->job, &k, &w->cx->arena[w->tid]); stage_ksw(w, m); jv_push(&w->cx->ksw_jobs[w->tid], w->job);
     }
     if (m->round < 0) { w->bail = 1; w->build = 0; return 0; }
