@@ -690,7 +690,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         lf_hnode *d_q = (lf_hnode *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 0, 6 * q_cap * sizeof(lf_hnode));
         d_hdesc = (lf_aln_desc_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 1, hcap * sizeof(lf_aln_desc_t));
         d_hopsoff = (uint64_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 2, hcap * 8);
-        const uint64_t aux_cap = 6 * (HC.sum_n / 64 + HC.roots + hcap) + 64, hcar_cap = 2 * HC.sum_m + 64 * hcap + 4096;
+        const uint64_t aux_cap = 6 * (HC.sum_n / 64 + HC.roots + hcap) + 64, hcar_cap = 2 * HC.sum_m + 64 * hcap + 4096 + 1024 * (HC.sum_n / 32768 + 2);      /* (lf_hband_reserve: at most sum_n / 32768 nodes of a level sweep in super-bands) */
         uint64_t *d_haux = (uint64_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 3, aux_cap * 8);
         uint8_t *d_hcar = (uint8_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 4, hcar_cap);
         lf_hctl *h_ctl = (lf_hctl *)lfg_pin_slot(LF_PS_ALN_PROB + 1, sizeof(lf_hctl));

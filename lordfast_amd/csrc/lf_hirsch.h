@@ -34,6 +34,11 @@ struct lf_hargs {
     uint64_t *aux; uint64_t aux_cap; uint8_t *hcar; uint64_t hcar_cap;
     uint8_t *ops; int32_t *out_ed, *out_end; uint32_t *out_len; uint32_t n_desc;
 };
+/* The carries that leave a super-band of a query above 32 768 rows wait in HBM for the super-band below.  2-bit targets, one block per lane: one 32-bit word per 16
+ * steps of the super-band's last lane (the sweep's steps incl. the lag of up to eight wavefronts, read up to four words ahead); other instantiations: one byte
+ * per column.  A node reserves room for four such buffers (two per half) in either form. */
+__host__ __device__ __forceinline__ uint64_t lf_hband_bytes(uint32_t m) { return (((uint64_t)m + 63 + 7 * 96 + 15) / 16 + 8) * 4; }
+__host__ __device__ __forceinline__ uint64_t lf_hband_reserve(uint32_t m) { const uint64_t a = 2ull * m + 64, b = 4 * lf_hband_bytes(m); return ((a > b ? a : b) + 3) & ~3ull; }
 __host__ __device__ __forceinline__ int lf_hkb_class(uint32_t n) { return n <= 4096 ? 0 : n <= 16384 ? 1 : 2; }
 
 void lf_hirsch_launch_roots(hipStream_t s, bool pac_targets, const lf_aln_desc_t *d_desc, const uint64_t *d_opsoff, int n, lf_hargs A);

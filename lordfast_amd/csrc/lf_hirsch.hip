@@ -104,9 +104,10 @@ __device__ __forceinline__ void lf_hsweep(const lf_qacc &Q, const lf_tacc &T, co
         const int t0 = wsub * LF_H_LAG;
         const int steps_total = W > 1 ? (int)m_max + 63 + (W - 1) * LF_H_LAG : my_steps;
         bool swept = false;
-        if constexpr (PEQ) { if (nbk <= SB) {
+        if constexpr (PEQ) { {
             swept = true;
-            /* One block per lane, 2-bit targets, one super-band (every query of the mapping pipeline up to 4096 W rows): the step
+            /* One block per lane, 2-bit targets (every query of the mapping pipeline; round 5: also the queries above 4096 W rows, super-band by
+             * super-band -- the carries that leave a super-band go to HBM in the same packed form, lf_hband_bytes): the step
              * loop of the forward kernel (lf_rsweep.hip) -- 16 steps unrolled, the lane's 16 target symbols in one register
              * straight from the 2-bit reference, match masks from the LDS table, no range test in the groups of 16 steps during
              * which every lane is inside the target; the carries between the wavefronts of a half travel as ONE 32-bit word per 16
@@ -115,6 +116,7 @@ __device__ __forceinline__ void lf_hsweep(const lf_qacc &Q, const lf_tacc &T, co
              * exactly that. */
             const uint64_t *peq_l = peq + lane;
             const uint32_t *cw32_in = reinterpret_cast<const uint32_t *>(cw_in); uint32_t *cw32_out = reinterpret_cast<uint32_t *>(cw_out);
+            const uint32_t *h32_in = reinterpret_cast<const uint32_t *>(hc_in); uint32_t *h32_out = reinterpret_cast<uint32_t *>(hc_out);      /* one word per 16 steps of the super-band's last lane */
             const bool is_last = last_band && lane == lane_last;
             const int n_groups = (steps_total + 15) >> 4;
             uint32_t hout = LF_HIN_PLUS1, acc = 0;
@@ -148,10 +150,12 @@ __device__ __forceinline__ void lf_hsweep(const lf_qacc &Q, const lf_tacc &T, co
                  * for the same columns 63 steps (3 groups and 15 steps) later in ITS numbering */
                 uint32_t cin16 = 0x55555555u;
                 if (from_wave) { const int gl = sl0 >> 4; const uint32_t a = cw32_in[(gl + 3) & 7], b = cw32_in[(gl + 4) & 7]; cin16 = (a >> 30) | (b << 2); }
+                else if (from_hbm) { const int gl = sl0 >> 4; const uint32_t a = h32_in[gl + 3], b = h32_in[gl + 4]; cin16 = (a >> 30) | (b << 2); }      /* the same columns, left by the super-band above */
                 acc = 0;
                 if (sl0 >= nl - 1 && sl0 + 15 <= (int)m - 1) steps16(std::true_type{}, sl0, V, cin16);
                 else steps16(std::false_type{}, sl0, V, cin16);
                 if (to_wave && lane == 63) cw32_out[(sl0 >> 4) & 7] = acc;
+                if (to_hbm && lane == 63) h32_out[sl0 >> 4] = acc;
             }
         } }
         if (!swept) {
@@ -330,13 +334,16 @@ lf_hirsch_level_kernel(lf_hargs A)
     const uint32_t lw = m / 2, rw = m - lw;
     if (threadIdx.x == 0) {
         s_base[0] = P.kind == 0 ? atomicAdd(&A.ctl->aux_used, 6ull * nbk) : 0ull;
-        s_base[1] = banded ? atomicAdd(&A.ctl->hcar_used, 2ull * m + 64) : 0ull;
+        s_base[1] = banded ? atomicAdd(&A.ctl->hcar_used, lf_hband_reserve(m)) : 0ull;
     }
     __syncthreads();
-    const bool aux_ok = P.kind != 0 || s_base[0] + 6ull * nbk <= A.aux_cap, hc_ok = !banded || s_base[1] + 2ull * m + 64 <= A.hcar_cap;
+    const bool aux_ok = P.kind != 0 || s_base[0] + 6ull * nbk <= A.aux_cap, hc_ok = !banded || s_base[1] + lf_hband_reserve(m) <= A.hcar_cap;
     if (!aux_ok || !hc_ok) { if (threadIdx.x == 0) { atomicExch(&A.ctl->fail, 5u); A.out_ed[A.roots[P.root].desc] = -2; } return; }
     uint64_t *Fb = A.aux + s_base[0], *Rb = Fb + 3 * (size_t)nbk;
     uint8_t *hc = A.hcar + s_base[1];
+    static_assert(LF_H_LAG == 96, "lf_hband_bytes (lf_hirsch.h) counts the lag");
+    constexpr bool PK = PAC && KB == 1;                   /* packed carries (lf_hsweep's 16-step loop) */
+    const size_t HB = (size_t)lf_hband_bytes(m);
     const int64_t dq = (P.flags & LF_F_QREV) ? -1 : 1, dt = (P.flags & LF_F_TREV) ? -1 : 1;
     const uint32_t desc = A.roots[P.root].desc;
     const unsigned char *cw_in = wsub > 0 ? s_cw[wave - 1] : nullptr;
@@ -347,7 +354,7 @@ lf_hirsch_level_kernel(lf_hargs A)
         if (W == 1 && w != 0) return;
         const lf_qacc Q(A.S.q, P.qstart, P.flags); const lf_tacc T(A.S.t, A.S.pac, P.tstart, P.flags | (PAC ? LF_F_TPAC : 0u));
         int ed = 0, tl = 0;
-        lf_hsweep<KB, W, PAC>(Q, T, A.pac_syms, n, m, m, true, w != 0, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc, hc + m + 32, nullptr, s_tot[w], s_shw[w], ed, tl);
+        lf_hsweep<KB, W, PAC>(Q, T, A.pac_syms, n, m, m, true, w != 0, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc, PK ? hc + HB : hc + m + 32, nullptr, s_tot[w], s_shw[w], ed, tl);
         if (wave != 0) return;
         if (lane == 0) { A.out_ed[desc] = ed; A.out_end[desc] = tl - 1; }
         lf_hfinalize(A, P, 0, n, 0, (uint32_t)tl, ed, P.ops_off);
@@ -357,12 +364,12 @@ lf_hirsch_level_kernel(lf_hargs A)
         int d0, d1;
         if (w == 0) {
             const lf_qacc Q(A.S.q, P.qstart, P.flags); const lf_tacc T(A.S.t, A.S.pac, P.tstart, P.flags | (PAC ? LF_F_TPAC : 0u));
-            if (lw || W > 1) lf_hsweep<KB, W, PAC>(Q, T, A.pac_syms, n, lw, rw, false, lw == 0, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc, hc + (lw + 16), Fb, s_tot[0], s_shw[0], d0, d1);
+            if (lw || W > 1) lf_hsweep<KB, W, PAC>(Q, T, A.pac_syms, n, lw, rw, false, lw == 0, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc, PK ? hc + HB : hc + (lw + 16), Fb, s_tot[0], s_shw[0], d0, d1);
         } else {
             /* both strings backwards: element i = original element (len - 1 - i) */
             const unsigned fl = P.flags ^ (LF_F_QREV | LF_F_TREV);
             const lf_qacc Q(A.S.q, P.qstart + dq * (int64_t)(n - 1), fl); const lf_tacc T(A.S.t, A.S.pac, P.tstart + dt * (int64_t)(m - 1), fl | (PAC ? LF_F_TPAC : 0u));
-            lf_hsweep<KB, W, PAC>(Q, T, A.pac_syms, n, rw, rw, false, false, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc + 2 * (lw + 16), hc + 2 * (lw + 16) + (rw + 16), Rb, s_tot[1], s_shw[1], d0, d1);
+            lf_hsweep<KB, W, PAC>(Q, T, A.pac_syms, n, rw, rw, false, false, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], PK ? hc + 2 * HB : hc + 2 * (lw + 16), PK ? hc + 3 * HB : hc + 2 * (lw + 16) + (rw + 16), Rb, s_tot[1], s_shw[1], d0, d1);
         }
     }
     __threadfence_block();

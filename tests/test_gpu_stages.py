@@ -160,7 +160,7 @@ def test_edlib_queries_above_32768_rows(oracle_lib, monkeypatch, one_wave):
     orc = oracle_lib.Oracle()
     rng = np.random.default_rng(3276833)
     qs, ts, modes = [], [], []
-    for n, e, mode, tail in ((32769, 0.12, 0, 0), (33000, 0.1, 1, 900), (41000, 0.2, 0, 0)):
+    for n, e, mode, tail in ((32769, 0.12, 0, 0), (33000, 0.1, 1, 900), (41000, 0.2, 0, 0), (70001, 0.08, 0, 0), (66000, 0.1, 1, 300)):      # the last two: three super-bands
         q = np.frombuffer(rseq(rng, n), dtype=np.uint8)
         t = synth.mutate(q, e, rng).tobytes() + (rseq(rng, tail) if tail else b"")
         qs.append(q.tobytes()); ts.append(t); modes.append(mode)
