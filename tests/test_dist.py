@@ -229,3 +229,23 @@ def test_bench_spawns_its_own_ranks_without_touching_the_gpu(tmp_path):
     assert "must be launched with torch.distributed.run" not in (r.stdout + r.stderr)
     # on this CPU box the ranks stop at the device check; on a GPU box test_gpu_dist.py runs the same command to the end
     assert r.returncode != 0 or '"metric"' in r.stdout
+
+
+def test_bench_steps_in_flight_defaults(monkeypatch):
+    """bench.py's --inflight default: one step after the other at one GPU and under weak scaling; under strong scaling two steps of a rank in flight,
+    four when the rank's shard is at most 32 k reads (N = 4 and 8 of the 100 k-read set); an explicit value wins"""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+
+    def inflight(*argv):
+        monkeypatch.setattr(sys, "argv", ["bench.py", *argv])
+        return bench.parse().inflight
+
+    assert inflight() == 1
+    assert inflight("--gpus", "2") == 2            # 50 k reads per rank
+    assert inflight("--gpus", "4") == 4            # 25 k
+    assert inflight("--gpus", "8") == 4            # 12.5 k
+    assert inflight("--gpus", "8", "--reads", "400000") == 2
+    assert inflight("--gpus", "8", "--scaling", "weak") == 1
+    assert inflight("--gpus", "8", "--inflight", "3") == 3
