@@ -137,6 +137,9 @@ def test_c4_segdup_workload_clasp_n30(segdup_genome, oracle_lib):
     reads = synth.make_reads(g, 700, 15000, 0.15, seed=2024, segdups=fams, dup_frac=0.5)
     st, sam = _run_big(fa, reads, oracle_lib, max_map=30, chain_alg=1)
     assert st["n_chain_problems"] / len(reads) > 1.5, "the duplicated reads must reach the fine branch"
+    # the one corner of -a clasp where the reference depends on what its thread mapped before (a read's FIRST window without seeds: it extends the previous
+    # read's chain, src/Chain.cpp:68,92) is counted, not restated: the comparison above is only meaningful while this workload does not hit it
+    assert st["n_stale_first_windows"] == 0, st["n_stale_first_windows"]
     flags = [int(l.split(b"\t")[1]) for l in sam.split(b"\n") if l]
     assert sum(1 for f in flags if f & 256) > 100
     st, _ = _run_big(fa, reads[:300], oracle_lib, max_map=30)                        # the same reads through dp-n2
