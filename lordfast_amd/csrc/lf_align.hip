@@ -687,7 +687,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         lf_hctl *d_ctl = DSLOT(lf_hctl, 21, sizeof(lf_hctl));
         lf_hroot *d_roots = DSLOT(lf_hroot, 22, (size_t)HC.roots * sizeof(lf_hroot));
         lf_hseg *d_segs = (lf_hseg *)lfg_dev_slot(device, LF_DS_ALN0 + 23, hcap * sizeof(lf_hseg));
-        lf_hnode *d_q = (lf_hnode *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 0, 6 * q_cap * sizeof(lf_hnode));
+        lf_hnode *d_q = (lf_hnode *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 0, 2 * LF_HQ * q_cap * sizeof(lf_hnode));
         d_hdesc = (lf_aln_desc_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 1, hcap * sizeof(lf_aln_desc_t));
         d_hopsoff = (uint64_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 2, hcap * 8);
         const uint64_t aux_cap = 6 * (HC.sum_n / 64 + HC.roots + hcap) + 64, hcar_cap = 2 * HC.sum_m + 64 * hcap + 4096 + 1024 * (HC.sum_n / 32768 + 2);      /* (lf_hband_reserve: at most sum_n / 32768 nodes of a level sweep in super-bands) */
@@ -697,12 +697,14 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         if (!d_ctl || !d_roots || !d_segs || !d_q || !d_hdesc || !d_hopsoff || !d_haux || !d_hcar || !h_ctl) return LF_ERR_NOMEM;
         HIPCHK(hipMemsetAsync(d_ctl, 0, sizeof(lf_hctl), s));
         HA.S.q = D->d_q; HA.S.t = D->d_t; HA.S.pac = D->d_pac; HA.pac_syms = D->pac_syms;
+        { const char *e_ = getenv("LF_HIRSCH_BAND"); HA.no_band = (e_ && atoi(e_) == 0) ? 1u : 0u; }      /* (read per call: the tests switch it) */
+        HA.qlo = D->d_planes; HA.qhi = D->d_planes + D->q_words; HA.qvalid = D->d_planes + 2 * D->q_words; HA.q_words = D->q_words;
         HA.q_cap = (uint32_t)q_cap; HA.ctl = d_ctl; HA.roots = d_roots; HA.segs = d_segs; HA.hdesc = d_hdesc; HA.hopsoff = d_hopsoff; HA.hleaf_cap = (uint32_t)hcap;
         HA.aux = d_haux; HA.aux_cap = aux_cap; HA.hcar = d_hcar; HA.hcar_cap = hcar_cap;
         HA.ops = d_ops; HA.out_ed = d_ed; HA.out_end = d_end; HA.out_len = d_len; HA.n_desc = (uint32_t)n;
-        auto queue = [&](int par, int kbc) { return d_q + ((size_t)par * 3 + kbc) * q_cap; };
+        auto queue = [&](int par, int kbc) { return d_q + ((size_t)par * LF_HQ + kbc) * q_cap; };
         int par = 0;
-        for (int k = 0; k < 3; k++) HA.q_out[k] = queue(0, k);
+        for (int k = 0; k < LF_HQ; k++) HA.q_out[k] = queue(0, k);
         HA.out_par = 0;
         lf_hirsch_launch_roots(s, D->pac, d_desc, d_opsoff, n, HA);
         const bool hdbg = getenv("LF_HIRSCH_DEBUG") != nullptr;      /* per call: roots and their sizes; per level: nodes by class, milliseconds since the previous readback */
@@ -713,21 +715,24 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
             HIPCHK(hipStreamSynchronize(s));
             if (hdbg) {
                 const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
-                fprintf(stderr, "[lf]   level %d: nodes %u / %u / %u (<= 4096 / <= 16384 / more rows), leaves so far %u, %.3f ms\n", level, h_ctl->q_n[par][0], h_ctl->q_n[par][1], h_ctl->q_n[par][2], h_ctl->n_hleaf,
+                fprintf(stderr, "[lf]   level %d: nodes %u / %u / %u (<= 4096 / <= 16384 / more rows), banded %u / %u / %u (1 / 2 / 4 wavefronts per half), trials %u failed %u, leaves so far %u, %.3f ms\n", level,
+                        h_ctl->q_n[par][0], h_ctl->q_n[par][1], h_ctl->q_n[par][2], h_ctl->q_n[par][3], h_ctl->q_n[par][4], h_ctl->q_n[par][5], h_ctl->n_trial, h_ctl->n_trial_failed, h_ctl->n_hleaf,
                         std::chrono::duration<double, std::milli>(t1 - hd_t0).count());
                 hd_t0 = t1;
             }
             if (h_ctl->fail > 1) { lf_set_error("edlib Hirschberg levels: scratch bound exceeded (code %u)", h_ctl->fail); return LF_ERR_HIP; }
             n_roots = h_ctl->n_roots; n_h = h_ctl->n_hleaf;
-            const uint32_t c0 = h_ctl->q_n[par][0], c1 = h_ctl->q_n[par][1], c2 = h_ctl->q_n[par][2];
-            if (c0 + c1 + c2 == 0) break;
+            uint32_t cntq[LF_HQ], cnt_all = 0;
+            for (int k = 0; k < LF_HQ; k++) { cntq[k] = h_ctl->q_n[par][k]; cnt_all += cntq[k]; }
+            if (cnt_all == 0) break;
             /* next level's counters and this level's scratch cursors */
             HIPCHK(hipMemsetAsync((char *)d_ctl + offsetof(lf_hctl, q_n) + (size_t)(par ^ 1) * sizeof(h_ctl->q_n[0]), 0, sizeof(h_ctl->q_n[0]), s));
             HIPCHK(hipMemsetAsync((char *)d_ctl + offsetof(lf_hctl, aux_used), 0, 16, s));
-            for (int k = 0; k < 3; k++) HA.q_out[k] = queue(par ^ 1, k);
+            for (int k = 0; k < LF_HQ; k++) HA.q_out[k] = queue(par ^ 1, k);
             HA.out_par = (uint32_t)(par ^ 1);
-            const uint32_t cnt3[3] = { c0, c1, c2 };
-            for (int k = 2; k >= 0; k--) { HA.q_in = queue(par, k); HA.n_in = cnt3[k]; lf_hirsch_launch_level(s, D->pac, k, HA); }
+            /* the classes with the longest sweeps first: wide bands, unbanded large queries, ... */
+            static const int order[LF_HQ] = { 5, 2, 4, 1, 3, 0 };
+            for (int o = 0; o < LF_HQ; o++) { const int k = order[o]; HA.q_in = queue(par, k); HA.n_in = cntq[k]; lf_hirsch_launch_level(s, D->pac, k, HA); }
             par ^= 1;
         }
         HIPCHK(hipGetLastError());

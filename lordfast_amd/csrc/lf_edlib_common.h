@@ -206,6 +206,19 @@ __host__ __device__ __forceinline__ bool lf_small_prob(uint32_t n, uint32_t m) {
 __host__ __device__ __forceinline__ int lf_seg_blocks(int nbf) { return nbf > 64 ? nbf - 64 : nbf; }      /* key's block field -> lanes per problem */
 #define LF_SEG_NB_MAX (64 + LF_SMALL_NB)
 
+/* 64 consecutive bits of a plane starting at (signed) bit position p0; positions outside [0, 64 n_words) read as garbage
+ * inside the array (the caller masks them) */
+__device__ __forceinline__ uint64_t lf_bits64(const uint64_t *__restrict__ a, int64_t p0, int64_t n_words)
+{
+    const int64_t w = p0 >> 6;                                      /* floor: -1 for a window that starts before the buffer */
+    const uint32_t sh = (uint32_t)(p0 & 63);
+    const int64_t i0 = w < 0 ? 0 : (w > n_words - 1 ? n_words - 1 : w), i1 = w + 1 < 0 ? 0 : (w + 1 > n_words - 1 ? n_words - 1 : w + 1);
+    uint64_t a0 = a[i0], a1 = a[i1];                                /* unconditional loads from clamped indices */
+    a0 = (w >= 0 && w <= n_words - 1) ? a0 : 0ull; a1 = (w + 1 >= 0 && w + 1 <= n_words - 1) ? a1 : 0ull;
+    return sh ? (a0 >> sh) | (a1 << (64 - sh)) : a0;
+}
+__device__ __forceinline__ uint64_t lf_brev64(uint64_t x) { return ((uint64_t)__brev((uint32_t)x) << 32) | (uint64_t)__brev((uint32_t)(x >> 32)); }
+
 /* lane l receives lane l-1's value (lane 0: 0): the horizontal carry of the anti-diagonal sweeps.  DPP wave_shr:1 is a
  * VALU move; __shfl_up goes through the LDS crossbar (ds_bpermute) and sits on the per-step dependency chain. */
 __device__ __forceinline__ uint32_t lf_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }

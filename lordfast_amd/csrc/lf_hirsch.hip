@@ -300,19 +300,32 @@ __device__ __forceinline__ void lf_hfinalize(const lf_hargs &A, const lf_hnode &
             d.qstart = P.qstart + dq * (int64_t)qo; d.tstart = P.tstart + dt * (int64_t)to; d.n = cn; d.m = cm;
             d.flags = (uint8_t)(P.flags & ~LF_F_TPAC); d.mode = 0;
             for (int z = 0; z < 6; z++) d.pad[z] = 0;
-            d.pad[0] = P.pad;                                   /* stage API: the root's target holds bytes other than ACGT */
+            d.pad[0] = P.pad & 1u;                              /* stage API: the root's target holds bytes other than ACGT */
             A.hdesc[j] = d; A.hopsoff[j] = off;
         }
         lf_hpiece(A, P.root, off, cn + cm, 0x80000000u | j);
         return;
     }
     if (lane == 0) {
-        const int kbc = lf_hkb_class(cn);
+        uint32_t k0;
+        const int kbc = lf_hqueue_of(cn, cm, best, 0, (P.pad & 1u) | A.no_band, &k0);      /* (its distance is known: a band of exactly that width, no trial) */
         const uint32_t idx = atomicAdd(&A.ctl->q_n[A.out_par][kbc], 1u);
         if (idx >= A.q_cap) { atomicExch(&A.ctl->fail, 4u); return; }
         lf_hnode c;
         c.qstart = P.qstart + dq * (int64_t)qo; c.tstart = P.tstart + dt * (int64_t)to; c.ops_off = off; c.n = cn; c.m = cm;
-        c.best = best; c.root = P.root; c.flags = P.flags; c.kind = 0; c.is_root = 0; c.pad = P.pad; c.pad2 = 0;
+        c.best = best; c.root = P.root; c.flags = P.flags; c.kind = 0; c.is_root = 0; c.pad = P.pad & 1u; c.k0 = k0;
+        A.q_out[kbc][idx] = c;
+    }
+}
+/* a node whose trial bound was too small goes back to the queue as it is, for the unbanded sweep of its size */
+__device__ __forceinline__ void lf_hrequeue_unbanded(const lf_hargs &A, const lf_hnode &P)
+{
+    if ((threadIdx.x & 63) == 0) {
+        const int kbc = lf_hkb_class(P.n);
+        const uint32_t idx = atomicAdd(&A.ctl->q_n[A.out_par][kbc], 1u);
+        atomicAdd(&A.ctl->n_trial_failed, 1u);
+        if (idx >= A.q_cap) { atomicExch(&A.ctl->fail, 4u); return; }
+        lf_hnode c = P; c.pad = (uint8_t)(P.pad | LF_HN_NOBAND); c.k0 = 0;
         A.q_out[kbc][idx] = c;
     }
 }
@@ -404,6 +417,248 @@ lf_hirsch_level_kernel(lf_hargs A)
     lf_hfinalize(A, P, ul, n - ul, lw, rw, rs, P.ops_off + ul + lw);
 }
 
+/* ================================================================================================
+ * BANDED LEVELS (round 6).  What a level costs is the sweep of its LONGEST node -- a chain of m / 2 + blocks dependent steps -- and a node of more than 4096
+ * rows used to be swept by 4 or 8 wavefronts per half, every block of every column, a workgroup barrier per 16 steps (0.27 - 0.5 us per column).  Below the
+ * root a node's distance is known exactly (its side of `left + right == best`), so only the diagonals of lf_hband_nw can hold an optimal path: at 15 % error a
+ * sixth of the matrix, and -- what matters for the chain -- few enough blocks per column for ONE wavefront, without a barrier:
+ *
+ *   - block b lives on lane b mod 64 W of the half's W wavefronts (W = 1 for bands of up to 4066 diagonals, 2 / 4 above) and handles column j at step
+ *     j + skew(b), skew(b) = b for W = 1: the carry into block b + 1 is a DPP move from the lane on the left one step later, wave_ror:1 taking it from lane 63
+ *     round to lane 0; with W > 1 the wavefront below runs 33 steps behind and takes its carries from an LDS ring (one word per 16 steps, as in lf_hsweep);
+ *   - a lane keeps its block while the block is inside the band (columns [64 b + dlo, 64 b + 63 + dhi]), then takes block b + 64 W: blocks change hands at the
+ *     boundaries of 16-step groups only, the new block starts at the group's first column from a column of +1s whose bottom value is the left neighbour's
+ *     bottom value one column earlier + 64 (edlib's new block, lib/edlib/edlib.cpp:527-541);
+ *   - +1 enters a block at the columns at which the block above has left the band (:500: `hout = 1`);
+ *   - every lane follows the value at the bottom of its block (+ / - of its carries out, summed per group from the packed carry word): the last column leaves
+ *     (Pv, Mv, value above the block) triples exactly like the unbanded sweep, for the blocks that are inside the band there -- rows outside read as "far";
+ *   - match masks: four LDS words per lane, rebuilt from the read batch's bit planes when the lane changes blocks (planes of the NEXT block are fetched when a
+ *     block starts, the next group's 16 target symbols while this group is stepped).
+ * Roots do not know their distance: they try the band of lf_htrial_nw / _shw (k0) -- min (F + R) <= k0, resp. the SHW minimum <= k0, proves the result exact --
+ * and go back to the queue for the unbanded sweep otherwise.  tests/models/hband_model.cpp is this schedule lane by lane on the host, checked against the
+ * full matrix (tests/test_hband_model.py).
+ * ================================================================================================ */
+__device__ __forceinline__ uint32_t lf_wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false); }
+#define LF_HB_FAR (1 << 28)
+
+template <int W, bool TRACK>
+__device__ __forceinline__ void lf_hband_sweep(const lf_hargs &A, const int64_t qstart, const int64_t tstart, const unsigned flags, const uint32_t n, const int mm, const lf_hband B,
+                                               const bool idle, const int nG, const int wsub, uint64_t *peq, const uint32_t *cw_in, const int *sc_in, uint32_t *cw_out, int *sc_out,
+                                               uint64_t *blk_out, int *s_shw)
+{
+    constexpr int LAG = LF_HB_LAG(W), NL = 64 * W;
+    const int lane = threadIdx.x & 63;
+    const int dq = (flags & LF_F_QREV) ? -1 : 1, dt = (flags & LF_F_TREV) ? -1 : 1;
+    const bool cq = (flags & LF_F_QCOMP) != 0, ct = (flags & LF_F_TCOMP) != 0;
+    const int nbk = (int)((n + 63) >> 6), lastb = (int)((n - 1) >> 6), lastbit = (int)((n - 1) & 63);
+    int nbA = idle || mm <= 0 ? 0 : (mm - 1 - B.dlo) / 64 + 1; if (nbA > nbk) nbA = nbk;
+    auto skew = [&](int b) { return (b & 63) + LAG * (b >> 6); };
+    auto jlo = [&](int b) { const int x = 64 * b + B.dlo; return x < 0 ? 0 : x; };
+    auto jhi = [&](int b) { const int x = 64 * b + 63 + B.dhi; return x > mm - 1 ? mm - 1 : x; };
+    /* bit planes of block bb out of the packed read batch (lf_rsweep.hip does the same for its one block per lane) */
+    auto planes = [&](int bb, uint64_t &lo, uint64_t &hi, uint64_t &valid) {
+        const int64_t r0 = (int64_t)bb * 64;
+        const int64_t p0 = dq > 0 ? qstart + r0 : qstart - r0 - 63;
+        lo = lf_bits64(A.qlo, p0, A.q_words); hi = lf_bits64(A.qhi, p0, A.q_words); valid = lf_bits64(A.qvalid, p0, A.q_words);
+        if (dq < 0) { lo = lf_brev64(lo); hi = lf_brev64(hi); valid = lf_brev64(valid); }
+        if (cq) { lo = ~lo; hi = ~hi; }
+        const int64_t rows = (int64_t)n - r0;
+        const uint64_t rmask = rows <= 0 ? 0ull : rows >= 64 ? ~0ull : ((1ull << rows) - 1);
+        valid &= rmask; lo &= valid; hi &= valid;
+    };
+    int b = -1, nbnext = wsub * 64 + lane, skw = 0, sc = 0;
+    uint32_t jend = 0, jtop = 0, hout = LF_HIN_PLUS1;
+    uint64_t Pv = ~0ull, Mv = 0, nlo = 0, nhi = 0, nvalid = 0;
+    int score = 0, best = 0x7fffffff, best_c = 0;
+    if (nbnext < nbA) planes(nbnext, nlo, nhi, nvalid);
+    uint64_t *peq_l = peq + lane;
+    auto finish = [&]() {
+        if (blk_out && jend == (uint32_t)mm) {
+            blk_out[3 * (size_t)b] = Pv; blk_out[3 * (size_t)b + 1] = Mv;
+            blk_out[3 * (size_t)b + 2] = (uint64_t)(int64_t)(sc - (__popcll(Pv) - __popcll(Mv)));
+        }
+        if (TRACK && b == lastb) { s_shw[0] = best; s_shw[1] = best_c; }
+        b = -1; jend = 0;
+    };
+    /* the 16 target symbols of the group that starts at step s, for the block the lane will hold then */
+    auto fetch = [&](int s, int sk) -> uint32_t { return lf_pac16(A.S.pac, tstart + (int64_t)dt * ((int64_t)s - sk), dt, ct, A.pac_syms); };
+    uint32_t Vn = 0;
+    {   /* group 0: blocks that start in it */
+        const bool act0 = nbnext < nbA && 16 > jlo(nbnext) + skew(nbnext);
+        Vn = fetch(0, act0 ? skew(nbnext) : 0);
+    }
+    for (int G = 0; G < nG; G++) {
+        if (W > 1) __syncthreads();
+        if (idle) continue;
+        const int s0 = 16 * G;
+        /* the left neighbour as it was at the end of the previous group (all lanes, before anything changes) */
+        int sc_left; uint32_t h_left, cin16 = 0;
+        if (W == 1) { sc_left = (int)lf_wave_ror1((uint32_t)sc); h_left = lf_wave_ror1(hout); }
+        else {
+            sc_left = (int)lf_wave_shr1((uint32_t)sc); h_left = lf_wave_shr1(hout);
+            const uint32_t a = cw_in[(G + 5) & 7], c = cw_in[(G + 6) & 7];      /* groups G - 3 and G - 2 of the wavefront above: the same columns, 33 steps earlier */
+            cin16 = (a >> 30) | (c << 2);
+            if (lane == 0) { sc_left = sc_in[(G + 5) & 7]; h_left = cin16 & 3u; }
+        }
+        if (b >= 0 && s0 > (int)jend - 1 + skw) finish();
+        if (b < 0 && nbnext < nbA && s0 + 16 > jlo(nbnext) + skew(nbnext)) {
+            b = nbnext; nbnext += NL;
+            skw = skew(b); jend = (uint32_t)(jhi(b) + 1);
+            { const int x = 64 * b + B.dhi; jtop = b == 0 ? 0u : (uint32_t)(x > mm ? mm : x); }
+            Pv = ~0ull; Mv = 0;
+            sc = s0 - skw <= 0 ? 64 * (b + 1) : sc_left - ((int)(h_left & 1u) - (int)(h_left >> 1)) + 64;
+            if (TRACK && b == lastb) { score = sc - (63 - lastbit); best = (n & 63) ? (int)n : 0x7fffffff; best_c = 0; }
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                const uint64_t slo = 0ull - (uint64_t)(c & 1u), shi = 0ull - (uint64_t)(c >> 1);
+                peq_l[c * 64] = ~((nlo ^ slo) | (nhi ^ shi)) & nvalid;
+            }
+            if (nbnext < nbA) planes(nbnext, nlo, nhi, nvalid);
+        }
+        const uint32_t V = Vn;
+        {   /* next group's symbols: the block the lane will hold then is a matter of geometry, not of data */
+            const int s1 = s0 + 16;
+            const bool done1 = b >= 0 && s1 > (int)jend - 1 + skw;
+            const bool act1 = (b < 0 || done1) && nbnext < nbA && s1 + 16 > jlo(nbnext) + skew(nbnext);
+            Vn = fetch(s1, act1 ? skew(nbnext) : skw);
+        }
+        uint32_t acc = 0;
+        if (lf_any(jend != 0u)) {
+            const int p0 = s0 - skw;
+            const bool is_last = TRACK && b == lastb;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t from_left = W == 1 ? lf_wave_ror1(hout) : lf_wave_shr1(hout);
+                const uint32_t col0 = (uint32_t)(p0 + k);                    /* wraps for columns in front of the target */
+                if (col0 < jend) {
+                    const uint32_t sy = (V >> (2 * k)) & 3u;
+                    const uint64_t Eq = peq_l[sy * 64];
+                    uint32_t hin = (W > 1 && lane == 0) ? ((cin16 >> (2 * k)) & 3u) : from_left;
+                    hin = col0 < jtop ? hin : LF_HIN_PLUS1;
+                    uint64_t ph, mh;
+                    hout = lf_myers_step(Pv, Mv, Eq, hin, ph, mh);
+                    acc |= hout << (2 * k);
+                    if (TRACK) {
+                        score += is_last ? lf_delta_at(ph, mh, lastbit) : 0;
+                        const bool upd = is_last && score < best; best = upd ? score : best; best_c = upd ? (int)col0 + 1 : best_c;
+                    }
+                }
+            }
+        }
+        sc += __popc(acc & 0x55555555u) - __popc(acc & 0xAAAAAAAAu);
+        if (W > 1 && lane == 63) { cw_out[G & 7] = acc; sc_out[G & 7] = sc; }
+    }
+    if (b >= 0) finish();
+}
+
+/* groups of 16 steps a half needs (the same function of the geometry in every wavefront of the workgroup: barrier counts) */
+template <int W>
+__device__ __forceinline__ int lf_hband_groups(uint32_t n, int mm, lf_hband B)
+{
+    if (mm <= 0) return 0;
+    const int nbk = (int)((n + 63) >> 6);
+    int nbA = (mm - 1 - B.dlo) / 64 + 1; if (nbA > nbk) nbA = nbk;
+    const int bl = nbA - 1;
+    int jh = 64 * bl + 63 + B.dhi; if (jh > mm - 1) jh = mm - 1;
+    return (jh + (bl & 63) + LF_HB_LAG(W) * (bl >> 6)) / 16 + 1;
+}
+
+/* D[x][last column] of a banded half: rows whose block is outside the band at the last column are "far" */
+__device__ __forceinline__ int lf_hcol_band(const uint64_t *__restrict__ Bk, uint32_t x, int zero, int mm, lf_hband B, int nbk)
+{
+    if (x == 0) return zero;
+    const int b = (int)((x - 1) >> 6);
+    int nbA = (mm - 1 - B.dlo) / 64 + 1; if (nbA > nbk) nbA = nbk;
+    if (b >= nbA || 64 * b + 63 + B.dhi < mm - 1) return LF_HB_FAR;
+    return lf_hcol(Bk, x, zero);
+}
+
+template <int W>
+__global__ void __launch_bounds__(128 * W)
+lf_hband_level_kernel(lf_hargs A)
+{
+    __shared__ uint64_t s_peq[2 * W][256];
+    __shared__ uint32_t s_cw[2 * W][8];
+    __shared__ int s_scr[2 * W][8], s_shw[2];
+    __shared__ unsigned long long s_base;
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int w = wave / W, wsub = wave % W;             /* w: the node's half; wsub: the wavefront inside it */
+    if (blockIdx.x >= A.n_in) return;
+    const lf_hnode P = A.q_in[blockIdx.x];
+    const uint32_t n = P.n, m = P.m, nbk = (n + 63) >> 6;
+    const uint32_t lw = m / 2, rw = m - lw;
+    const uint32_t desc = A.roots[P.root].desc;
+    if (threadIdx.x == 0) {
+        s_base = P.kind == 0 ? atomicAdd(&A.ctl->aux_used, 6ull * nbk) : 0ull;
+        s_shw[0] = (n & 63) ? (int)n : 0x7fffffff; s_shw[1] = 0;
+    }
+    __syncthreads();
+    if (P.kind == 0 && s_base + 6ull * nbk > A.aux_cap) { if (threadIdx.x == 0) { atomicExch(&A.ctl->fail, 5u); A.out_ed[desc] = -2; } return; }
+    uint64_t *Fb = A.aux + s_base, *Rb = Fb + 3 * (size_t)nbk;
+    const int64_t dq = (P.flags & LF_F_QREV) ? -1 : 1, dt = (P.flags & LF_F_TREV) ? -1 : 1;
+    const int pw = w * W + (wsub + W - 1) % W;            /* the wavefront whose last lane hands its carries to this one's lane 0 */
+
+    if (P.kind == 1) {
+        /* SHW root inside the band of the trial bound: distance and end column (lib/edlib/edlib.cpp:141-168); the second half's wavefronts keep the barriers company */
+        const int k = (int)P.k0;
+        const lf_hband B = lf_hband_shw(k);
+        const int64_t mme64 = (int64_t)n + k; const int mme = (int)(mme64 < (int64_t)m ? mme64 : (int64_t)m);
+        if (W == 1 && w != 0) return;
+        const int nG = lf_hband_groups<W>(n, mme, B);
+        lf_hband_sweep<W, true>(A, P.qstart, P.tstart, P.flags, n, mme, B, w != 0, nG, wsub, s_peq[wave], s_cw[pw], s_scr[pw], s_cw[wave], s_scr[wave], nullptr, s_shw);
+        __syncthreads();
+        if (wave != 0) return;
+        const int ed = s_shw[0], tl = s_shw[1];
+        if (ed > k) { lf_hrequeue_unbanded(A, P); return; }
+        if (lane == 0) { A.out_ed[desc] = ed; A.out_end[desc] = tl - 1; }
+        lf_hfinalize(A, P, 0, n, 0, (uint32_t)tl, ed, P.ops_off);
+        return;
+    }
+    const int k = P.best >= 0 ? P.best : (int)P.k0;
+    const lf_hband B = lf_hband_nw(n, m, k);
+    {
+        const int gF = lf_hband_groups<W>(n, (int)lw, B), gR = lf_hband_groups<W>(n, (int)rw, B);
+        const int nG = W > 1 ? (gF > gR ? gF : gR) : (w == 0 ? gF : gR);
+        if (w == 0) {
+            lf_hband_sweep<W, false>(A, P.qstart, P.tstart, P.flags, n, (int)lw, B, lw == 0, nG, wsub, s_peq[wave], s_cw[pw], s_scr[pw], s_cw[wave], s_scr[wave], Fb, s_shw);
+        } else {
+            /* both strings backwards: element i = original element (len - 1 - i) */
+            const unsigned fl = P.flags ^ (LF_F_QREV | LF_F_TREV);
+            lf_hband_sweep<W, false>(A, P.qstart + dq * (int64_t)(n - 1), P.tstart + dt * (int64_t)(m - 1), fl, n, (int)rw, B, false, nG, wsub, s_peq[wave], s_cw[pw], s_scr[pw], s_cw[wave], s_scr[wave], Rb, s_shw);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (wave != 0) return;
+    auto F = [&](uint32_t x) -> int { return lw ? lf_hcol_band(Fb, x, (int)lw, (int)lw, B, (int)nbk) : (int)x; };
+    auto R = [&](uint32_t x) -> int { return lf_hcol_band(Rb, x, (int)rw, (int)rw, B, (int)nbk); };
+    int best = P.best;
+    if (best < 0) {                          /* a root inside its trial band: min (F + R) <= k0 is the distance, anything larger proves nothing */
+        int mn = 0x7fffffff;
+        for (uint32_t base = 0; base <= n; base += 64) { const uint32_t r = base + (uint32_t)lane; if (r <= n) { const int v = F(r) + R(n - r); mn = v < mn ? v : mn; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(mn, o); mn = v < mn ? v : mn; }
+        if (mn > k) { lf_hrequeue_unbanded(A, P); return; }
+        best = mn;
+        if (lane == 0 && P.is_root) { A.out_ed[desc] = best; A.out_end[desc] = (int)m - 1; }
+    }
+    /* split row (lib/edlib/edlib.cpp:1263-1289), exactly as in the unbanded kernel: rows outside the band cannot satisfy the equality */
+    int split = -2, ls = 0, rs = 0;
+    for (uint32_t base = 0; base + 2 <= n && split == -2; base += 64) {
+        const uint32_t qi = base + (uint32_t)lane;
+        const bool hit = qi + 2 <= n && F(qi + 1) + R(n - qi - 1) == best;
+        const uint64_t bm = lf_ballot(hit);
+        if (bm) split = (int)(base + (uint32_t)(__ffsll((long long)bm) - 1));
+    }
+    if (split >= 0) { ls = F((uint32_t)split + 1); rs = R(n - (uint32_t)split - 1); }
+    else if ((int)lw + R(n) == best) { split = -1; ls = (int)lw; rs = R(n); }
+    else if (F(n) + (int)rw == best) { split = (int)n - 1; ls = F(n); rs = (int)rw; }
+    else { if (lane == 0) { atomicExch(&A.ctl->fail, 1u); A.out_ed[desc] = -2; } return; }
+    const uint32_t ul = (uint32_t)(split + 1);
+    lf_hfinalize(A, P, 0, ul, 0, lw, ls, P.ops_off);
+    lf_hfinalize(A, P, ul, n - ul, lw, rw, rs, P.ops_off + ul + lw);
+}
+
 /* the problems above edlib's traceback switch become roots: a table entry + a node of level 0 */
 __global__ void lf_hirsch_roots_kernel(const lf_aln_desc_t *__restrict__ d, const uint64_t *__restrict__ ops_off, int n, lf_hargs A)
 {
@@ -412,14 +667,16 @@ __global__ void lf_hirsch_roots_kernel(const lf_aln_desc_t *__restrict__ d, cons
     const lf_aln_desc_t x = d[i];
     if (x.n == 0 || x.m == 0 || lf_leaf(x.n, x.m)) return;
     const uint32_t r = atomicAdd(&A.ctl->n_roots, 1u), cap = lf_hroot_cap(x.n, x.m), so = atomicAdd(&A.ctl->seg_used, cap);
-    const int kbc = lf_hkb_class(x.n);
+    uint32_t k0;
+    const int kbc = lf_hqueue_of(x.n, x.m, -1, x.mode ? 1 : 0, (x.pad[0] != 0 ? 1u : 0u) | A.no_band, &k0);
     const uint32_t idx = atomicAdd(&A.ctl->q_n[A.out_par][kbc], 1u);
     if (idx >= A.q_cap) { atomicExch(&A.ctl->fail, 4u); return; }
+    if (k0) atomicAdd(&A.ctl->n_trial, 1u);
     lf_hroot R; R.ops_off = ops_off[i]; R.desc = (uint32_t)i; R.n = x.n; R.m = x.m; R.seg_off = so; R.seg_cap = cap; R.count = 0;
     A.roots[r] = R;
     lf_hnode c;
     c.qstart = x.qstart; c.tstart = x.tstart; c.ops_off = ops_off[i]; c.n = x.n; c.m = x.m; c.best = -1; c.root = r;
-    c.flags = x.flags; c.kind = x.mode ? 1 : 0; c.is_root = 1; c.pad = x.pad[0]; c.pad2 = 0;
+    c.flags = x.flags; c.kind = x.mode ? 1 : 0; c.is_root = 1; c.pad = x.pad[0] ? 1 : 0; c.k0 = k0;
     A.q_out[kbc][idx] = c;
 }
 
@@ -467,13 +724,18 @@ void lf_hirsch_launch_roots(hipStream_t s, bool pac_targets, const lf_aln_desc_t
 void lf_hirsch_launch_level(hipStream_t s, bool pac, int kbc, lf_hargs A)
 {
     if (A.n_in == 0) return;
+    if (kbc >= 3) {      /* banded sweeps: 1 / 2 / 4 wavefronts per half by band width */
+        const dim3 gb(A.n_in);
+        if (kbc == 3) hipLaunchKernelGGL((lf_hband_level_kernel<1>), gb, dim3(128), 0, s, A);
+        else if (kbc == 4) hipLaunchKernelGGL((lf_hband_level_kernel<2>), gb, dim3(256), 0, s, A);
+        else hipLaunchKernelGGL((lf_hband_level_kernel<4>), gb, dim3(512), 0, s, A);
+        return;
+    }
     /* blocks per lane x wavefronts per half: one block per lane, 1 / 4 / 8 wavefronts: queries of <= 4096 / 16384 / 32768 rows in one
      * super-band (more rows: several) */
     const dim3 g(A.n_in);
-    const bool one_wave = getenv("LF_HIRSCH_1WAVE") && atoi(getenv("LF_HIRSCH_1WAVE")) != 0;      /* A / B: round 3's one wavefront per half, 4 / 8 blocks per lane */
 #define LV(KBV, WV) do { if (pac) hipLaunchKernelGGL((lf_hirsch_level_kernel<KBV, WV, true>), g, dim3(128 * WV), 0, s, A); else hipLaunchKernelGGL((lf_hirsch_level_kernel<KBV, WV, false>), g, dim3(128 * WV), 0, s, A); } while (0)
     if (kbc == 0) LV(1, 1);
-    else if (one_wave) { if (kbc == 1) LV(4, 1); else LV(8, 1); }
     else if (kbc == 1) LV(1, 4); else LV(1, 8);
 #undef LV
 }

@@ -73,19 +73,6 @@ __global__ void lf_pack_pac_kernel(const unsigned char *__restrict__ src, uint64
     pac[b] = (uint8_t)v;
 }
 
-/* 64 consecutive bits of a plane starting at (signed) bit position p0; positions outside [0, 64 n_words) read as garbage
- * inside the array (the caller masks them) */
-__device__ __forceinline__ uint64_t lf_bits64(const uint64_t *__restrict__ a, int64_t p0, int64_t n_words)
-{
-    const int64_t w = p0 >> 6;                                      /* floor: -1 for a window that starts before the buffer */
-    const uint32_t sh = (uint32_t)(p0 & 63);
-    const int64_t i0 = w < 0 ? 0 : (w > n_words - 1 ? n_words - 1 : w), i1 = w + 1 < 0 ? 0 : (w + 1 > n_words - 1 ? n_words - 1 : w + 1);
-    uint64_t a0 = a[i0], a1 = a[i1];                                /* unconditional loads from clamped indices */
-    a0 = (w >= 0 && w <= n_words - 1) ? a0 : 0ull; a1 = (w + 1 >= 0 && w + 1 <= n_words - 1) ? a1 : 0ull;
-    return sh ? (a0 >> sh) | (a1 << (64 - sh)) : a0;
-}
-__device__ __forceinline__ uint64_t lf_brev64(uint64_t x) { return ((uint64_t)__brev((uint32_t)x) << 32) | (uint64_t)__brev((uint32_t)(x >> 32)); }
-
 /* SMALL (lf_edlib_small_kernel): the wavefront's problems have at most LF_SMALL_NB blocks and LF_SMALL_M target columns -- four checkpoint
  * rows, kept in LDS together with the planes; when the sweep is done lane g walks the path of the wavefront's problem g out of them
  * (lf_tb_core.h), with the forward pass's match masks.  Nothing of these problems but their paths touches HBM. */

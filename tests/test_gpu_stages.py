@@ -95,16 +95,16 @@ def test_edlib_fuzz_vs_oracle(oracle_lib):
         assert np.array_equal(r[2], o[2]), (i, len(qs[i]), len(ts[i]), modes[i])
 
 
-@pytest.mark.parametrize("one_wave", [0, 1])
-def test_edlib_checkpoint_tiles_and_device_hirschberg(oracle_lib, monkeypatch, one_wave):
+@pytest.mark.parametrize("band", [1, 0])
+def test_edlib_checkpoint_tiles_and_device_hirschberg(oracle_lib, monkeypatch, band):
     """shapes aimed at the recompute-from-checkpoint traceback and the breadth-first Hirschberg levels (lf_rsweep.hip,
     lf_align.hip, lf_hirsch.hip): tile boundaries (m around multiples of 8 / 16), paths that climb > 64 rows inside one
     16-column tile, every block count per problem (1 .. 64 lanes) and the 4 / 8 blocks-per-lane classes, targets longer
     than the LDS ring of the level kernels, tall-and-thin / short-and-wide leaves, several recursion levels, SHW roots
     whose prefix is a leaf"""
     import lordfast_amd as la
-    # 1: one wavefront per half of a node with 4 / 8 blocks per lane (round 3); 0: four wavefronts per half, 1 / 2 blocks per lane
-    monkeypatch.setenv("LF_HIRSCH_1WAVE", str(one_wave))
+    # 1: nodes above 4096 rows are swept inside the band of their distance (one to four wavefronts per half); 0: every block of every column
+    monkeypatch.setenv("LF_HIRSCH_BAND", str(band))
     orc = oracle_lib.Oracle()
     rng = np.random.default_rng(77)
     qs, ts, modes = [], [], []
@@ -149,14 +149,13 @@ def test_edlib_checkpoint_tiles_and_device_hirschberg(oracle_lib, monkeypatch, o
         assert np.array_equal(r[2], o[2]), (i, len(qs[i]), len(ts[i]), modes[i])
 
 
-@pytest.mark.parametrize("one_wave", [0, 1])
-def test_edlib_queries_above_32768_rows(oracle_lib, monkeypatch, one_wave):
+@pytest.mark.parametrize("band", [1, 0])
+def test_edlib_queries_above_32768_rows(oracle_lib, monkeypatch, band):
     """queries longer than one wavefront holds as register-resident blocks (64 lanes x 8 blocks x 64 rows = 32 768): the
     Hirschberg levels sweep them in row bands whose boundary carries go through HBM (lf_hirsch.hip); NW and SHW roots,
     a band boundary one row before the end of the query, a tall-and-thin problem above the traceback switch"""
     import lordfast_amd as la
-    # 1: one wavefront per half of a node with 4 / 8 blocks per lane (round 3); 0: four wavefronts per half, 1 / 2 blocks per lane
-    monkeypatch.setenv("LF_HIRSCH_1WAVE", str(one_wave))
+    monkeypatch.setenv("LF_HIRSCH_BAND", str(band))      # 1: banded where the band fits four wavefronts (the 41 k-row root, the children of all); 0: super-bands only
     orc = oracle_lib.Oracle()
     rng = np.random.default_rng(3276833)
     qs, ts, modes = [], [], []
@@ -168,6 +167,45 @@ def test_edlib_queries_above_32768_rows(oracle_lib, monkeypatch, one_wave):
     qs.append(q); ts.append(q[17000:17300]); modes.append(0)
     res, ms = la.edlib_batch(qs, ts, modes)
     for i, r in enumerate(res):
+        o = orc.edlib(qs[i], ts[i], modes[i])
+        assert (r[0], r[1]) == (o[0], o[1]), (i, len(qs[i]), len(ts[i]), modes[i])
+        assert np.array_equal(r[2], o[2]), (i, len(qs[i]), len(ts[i]), modes[i])
+
+
+def test_edlib_banded_levels_on_low_complexity_strings(oracle_lib, monkeypatch):
+    """the banded Hirschberg levels (lf_hirsch.hip: lf_hband_level_kernel) where ties decide: two-letter and tandem-repeat strings of 4 500 - 20 000
+    rows, both modes -- the split rule `first row with left + right == best` (lib/edlib/edlib.cpp:1263-1289) must see every candidate row although only
+    the band's diagonals are swept.  Roots whose trial bound holds (15 % error), roots whose bound fails (unrelated strings: back to the unbanded sweep),
+    bands for one / two / four wavefronts, a lane that takes a second and a third block (queries above 4096 + band rows).  Every result against the
+    oracle, and the banded run against the unbanded one."""
+    import lordfast_amd as la
+    orc = oracle_lib.Oracle()
+    rng = np.random.default_rng(60606)
+    qs, ts, modes = [], [], []
+
+    def add(q, t, ms=(0, 1)):
+        for mode in ms:
+            qs.append(bytes(q)); ts.append(bytes(t) + (rseq(rng, 300) if mode else b"")); modes.append(mode)
+
+    for n, e in ((4500, 0.15), (6000, 0.1), (9000, 0.17), (12000, 0.12)):
+        q = np.frombuffer(rseq(rng, n, ACGT[:2], [0.6, 0.4]), dtype=np.uint8)                       # two letters
+        add(q.tobytes(), synth.mutate(q, e, rng).tobytes())
+        unit = rseq(rng, int(rng.integers(2, 9)))
+        q = np.frombuffer((unit * (n // len(unit) + 1))[:n], dtype=np.uint8)                        # a tandem array: every shift of a unit is co-optimal
+        add(q.tobytes(), synth.mutate(q, e, rng).tobytes())
+    q = np.frombuffer(rseq(rng, 20000), dtype=np.uint8)                                              # 15 %: the band of the children needs one, the root's trial two wavefronts
+    add(q.tobytes(), synth.mutate(q, 0.15, rng).tobytes())
+    q = np.frombuffer(rseq(rng, 16000), dtype=np.uint8)                                              # 30 %: the root's trial bound fails, the children's bands are wide
+    add(q.tobytes(), synth.mutate(q, 0.30, rng).tobytes(), ms=(0,))
+    add(rseq(rng, 5200), rseq(rng, 5600))                                                            # unrelated: trial fails, children near the width limit
+    add(rseq(rng, 9000), rseq(rng, 2500), ms=(0,))                                                   # much longer than the target: the band is the length difference
+    q = rseq(rng, 7000); add(q, q[:3000] + q[3400:], ms=(0,))                                        # one long gap, otherwise identical: distance == |m - n|, band of +- 0
+    q = rseq(rng, 4200 + 64 * 3); add(q, q)                                                           # identical strings
+    res, _ = la.edlib_batch(qs, ts, modes)
+    monkeypatch.setenv("LF_HIRSCH_BAND", "0")
+    res0, _ = la.edlib_batch(qs, ts, modes)
+    for i, (r, r0) in enumerate(zip(res, res0)):
+        assert (r[0], r[1]) == (r0[0], r0[1]) and np.array_equal(r[2], r0[2]), ("banded != unbanded", i, len(qs[i]), len(ts[i]), modes[i])
         o = orc.edlib(qs[i], ts[i], modes[i])
         assert (r[0], r[1]) == (o[0], o[1]), (i, len(qs[i]), len(ts[i]), modes[i])
         assert np.array_equal(r[2], o[2]), (i, len(qs[i]), len(ts[i]), modes[i])
