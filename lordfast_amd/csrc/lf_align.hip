@@ -26,6 +26,9 @@
 #include "lf_gpu_common.h"
 #include "lf_edlib_common.h"
 #include "lf_hirsch.h"
+#include <atomic>
+void lf_htrial_learn(const uint32_t hist[2][16]);
+void lf_htrial_pick(uint32_t trial16[2]);
 #include "lf_rsweep.h"
 #include "lf_tb_core.h"
 #include "lf_scan.h"
@@ -697,6 +700,8 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         if (!d_ctl || !d_roots || !d_segs || !d_q || !d_hdesc || !d_hopsoff || !d_haux || !d_hcar || !h_ctl) return LF_ERR_NOMEM;
         HIPCHK(hipMemsetAsync(d_ctl, 0, sizeof(lf_hctl), s));
         HA.S.q = D->d_q; HA.S.t = D->d_t; HA.S.pac = D->d_pac; HA.pac_syms = D->pac_syms;
+        lf_htrial_pick(HA.trial16);
+        if (const char *e_ = getenv("LF_HIRSCH_TRIAL")) { unsigned a_ = 0, b_ = 0; if (sscanf(e_, "%u,%u", &a_, &b_) == 2 && a_ <= 16 && b_ <= 16) { HA.trial16[0] = a_; HA.trial16[1] = b_; } }      /* test hook: fixed bounds "nw,shw" */
         { const char *e_ = getenv("LF_HIRSCH_BAND"); HA.no_band = (e_ && atoi(e_) == 0) ? 1u : 0u; }      /* (read per call: the tests switch it) */
         HA.qlo = D->d_planes; HA.qhi = D->d_planes + D->q_words; HA.qvalid = D->d_planes + 2 * D->q_words; HA.q_words = D->q_words;
         HA.q_cap = (uint32_t)q_cap; HA.ctl = d_ctl; HA.roots = d_roots; HA.segs = d_segs; HA.hdesc = d_hdesc; HA.hopsoff = d_hopsoff; HA.hleaf_cap = (uint32_t)hcap;
@@ -715,8 +720,9 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
             HIPCHK(hipStreamSynchronize(s));
             if (hdbg) {
                 const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
-                fprintf(stderr, "[lf]   level %d: nodes %u / %u / %u (<= 4096 / <= 16384 / more rows), banded %u / %u / %u (1 / 2 / 4 wavefronts per half), trials %u failed %u, leaves so far %u, %.3f ms\n", level,
-                        h_ctl->q_n[par][0], h_ctl->q_n[par][1], h_ctl->q_n[par][2], h_ctl->q_n[par][3], h_ctl->q_n[par][4], h_ctl->q_n[par][5], h_ctl->n_trial, h_ctl->n_trial_failed, h_ctl->n_hleaf,
+                fprintf(stderr, "[lf]   level %d: unbanded %u / %u / %u (<= 4096 / <= 16384 / more rows), banded NW %u / %u / %u / %u (1 / 2 / 4 / 8 wavefronts per half), SHW %u / %u / %u / %u / %u (1 .. 16 wavefronts), trials %u failed %u, leaves so far %u, %.3f ms\n", level,
+                        h_ctl->q_n[par][0], h_ctl->q_n[par][1], h_ctl->q_n[par][2], h_ctl->q_n[par][3], h_ctl->q_n[par][4], h_ctl->q_n[par][5], h_ctl->q_n[par][6],
+                        h_ctl->q_n[par][7], h_ctl->q_n[par][8], h_ctl->q_n[par][9], h_ctl->q_n[par][10], h_ctl->q_n[par][11], h_ctl->n_trial, h_ctl->n_trial_failed, h_ctl->n_hleaf,
                         std::chrono::duration<double, std::milli>(t1 - hd_t0).count());
                 hd_t0 = t1;
             }
@@ -731,9 +737,17 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
             for (int k = 0; k < LF_HQ; k++) HA.q_out[k] = queue(par ^ 1, k);
             HA.out_par = (uint32_t)(par ^ 1);
             /* the classes with the longest sweeps first: wide bands, unbanded large queries, ... */
-            static const int order[LF_HQ] = { 5, 2, 4, 1, 3, 0 };
+            static const int order[LF_HQ] = { 2, 1, 11, 6, 10, 5, 9, 4, 8, 3, 7, 0 };
             for (int o = 0; o < LF_HQ; o++) { const int k = order[o]; HA.q_in = queue(par, k); HA.n_in = cntq[k]; lf_hirsch_launch_level(s, D->pac, k, HA); }
             par ^= 1;
+        }
+        lf_htrial_learn(h_ctl->ratio_hist);
+        if (hdbg) {
+            fprintf(stderr, "[lf]   trial bounds %u / %u sixteenths (NW / SHW); roots above 4096 rows by 16 * distance / rows, NW:", HA.trial16[0], HA.trial16[1]);
+            for (int r = 0; r < 16; r++) fprintf(stderr, " %u", h_ctl->ratio_hist[0][r]);
+            fprintf(stderr, "  SHW:");
+            for (int r = 0; r < 16; r++) fprintf(stderr, " %u", h_ctl->ratio_hist[1][r]);
+            fprintf(stderr, "\n");
         }
         HIPCHK(hipGetLastError());
         if (n_roots != HC.roots) { lf_set_error("edlib Hirschberg levels: %u roots found, %llu announced", n_roots, (unsigned long long)HC.roots); return LF_ERR_ARG; }
@@ -859,6 +873,31 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     /* (a device-planned round reports a missing Hirschberg split through lf_walk_emit_kernel: ed == -2 makes the job rare) */
     if (ed && n_roots) for (int i = 0; i < n; i++) if (ed[i] == -2) { lf_set_error("edlib kernel: no Hirschberg split row for descriptor %d (n %u, m %u)", i, D->d ? D->d[i].n : 0, D->d ? D->d[i].m : 0); return LF_ERR_HIP; }
     return LF_OK;
+}
+
+/* ---- trial bounds of the Hirschberg roots (lf_hirsch.h): chosen from what the process has seen.  g_hratio[mode][r] counts the roots above 4096 rows whose
+ * distance was r / 16 .. (r + 1) / 16 of their rows (halved now and then, so that a new kind of input takes over); a mode's bound is the first sixteenth
+ * below which nine roots in ten ended, no trial at all when that is above 5 / 16 (the band of such a bound covers most of the matrix and the sweep's length --
+ * its latency -- is the same with or without it).  Before anything was seen: NW 4 / 16, SHW none. ---- */
+static std::atomic<uint32_t> g_hratio[2][16];
+void lf_htrial_learn(const uint32_t hist[2][16])
+{
+    for (int k = 0; k < 2; k++) {
+        uint32_t tot = 0;
+        for (int r = 0; r < 16; r++) if (hist[k][r]) tot += g_hratio[k][r].fetch_add(hist[k][r], std::memory_order_relaxed) + hist[k][r];
+        if (tot > (1u << 20)) for (int r = 0; r < 16; r++) g_hratio[k][r].store(g_hratio[k][r].load(std::memory_order_relaxed) / 2, std::memory_order_relaxed);
+    }
+}
+void lf_htrial_pick(uint32_t trial16[2])
+{
+    for (int k = 0; k < 2; k++) {
+        uint32_t c[16], tot = 0;
+        for (int r = 0; r < 16; r++) { c[r] = g_hratio[k][r].load(std::memory_order_relaxed); tot += c[r]; }
+        if (tot < 8) { trial16[k] = k == 0 ? 4u : 0u; continue; }
+        uint32_t cum = 0; int r = 0;
+        for (; r < 16; r++) { cum += c[r]; if ((uint64_t)cum * 10 >= (uint64_t)tot * 9) break; }
+        trial16[k] = r + 1 > 5 ? 0u : (uint32_t)(r + 1);
+    }
 }
 
 /* what the Hirschberg levels need to know about a batch before anything runs (buffer bounds): counted where the descriptors are made */

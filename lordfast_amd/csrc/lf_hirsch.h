@@ -13,20 +13,20 @@ struct lf_hnode {
     uint32_t n, m;
     int32_t  best;             /* edit distance of the node, -1 = not known yet (NW roots: the first split finds it) */
     uint32_t root;             /* index into the root table */
-    uint8_t  flags, kind, is_root, pad;      /* pad: bit 0 = the root's target holds bytes other than ACGT (stage API), bit 1 = LF_HN_NOBAND */
-    uint32_t k0;               /* != 0: a TRIAL bound -- the node is swept inside the band of distance k0 and goes back to the queue unbanded if its distance is larger */
+    uint8_t  flags, kind, is_root, pad;      /* pad: the root's target holds bytes other than ACGT (stage API) */
+    uint32_t k0;               /* banded queues, distance not known: the node is swept inside the band of distance k0 (n + m: the whole matrix) and goes back to the
+                                * queue with the whole matrix if its distance turns out larger */
 };
-#define LF_HN_NOBAND 2u
-#define LF_HQ 6
+#define LF_HQ 12
 struct lf_hroot { uint64_t ops_off; uint32_t desc, n, m, seg_off, seg_cap, count; };      /* count: pieces registered so far (atomic) */
 /* one finished piece of a root's path: its region inside the root's ops region and its length (bit 31 set: H-leaf j, whose
  * length the traceback kernels leave in out_len[n_desc + j]) */
 struct lf_hseg { uint64_t off; uint32_t cap, len; };
 struct lf_hctl {
     uint32_t n_roots, seg_used, n_hleaf, fail;
-    uint32_t q_n[2][LF_HQ];              /* nodes queued for the next / current level: classes 0 .. 2 unbanded sweeps by query rows (1 / 4 / 8 wavefronts per half),
-                                          * 3 .. 5 banded sweeps by band width (1 / 2 / 4 wavefronts per half) */
+    uint32_t q_n[2][LF_HQ];              /* nodes queued for the next / current level, by queue (lf_hqueue_of) */
     uint32_t n_trial, n_trial_failed, pad_[2];
+    uint32_t ratio_hist[2][16];          /* the roots above 4096 rows by 16 distance / rows, NW and SHW: what the next calls' trial bounds are chosen from */
     unsigned long long aux_used, hcar_used;
 };
 struct lf_hargs {
@@ -35,6 +35,7 @@ struct lf_hargs {
     const uint64_t *qlo, *qhi, *qvalid; int64_t q_words;      /* bit planes of S.q (lf_pack_planes_kernel): the banded sweeps take a block's match masks from them */
     uint32_t n_in, q_cap, out_par;
     uint32_t no_band;                     /* A / B and test hook (LF_HIRSCH_BAND=0): every node takes the unbanded sweep of its size */
+    uint32_t trial16[2];                  /* trial bound of the NW / SHW roots in sixteenths of their rows, 0 = none */
     lf_hctl *ctl; lf_hroot *roots; lf_hseg *segs;
     lf_aln_desc_t *hdesc; uint64_t *hopsoff; uint32_t hleaf_cap;
     uint64_t *aux; uint64_t aux_cap; uint8_t *hcar; uint64_t hcar_cap;
@@ -64,28 +65,47 @@ static inline __host__ __device__ lf_hband lf_hband_nw(uint32_t n, uint32_t m, i
 }
 static inline __host__ __device__ lf_hband lf_hband_shw(int k) { lf_hband B; B.dlo = -k; B.dhi = k < 1 ? 1 : k; return B; }
 /* block b of a banded sweep lives on lane b mod 64 W of the half's W wavefronts and runs skew(b) steps behind block 0; a lane must be done with block b before
- * block b + 64 W enters the band (blocks change hands at the boundaries of 16-step groups): the widest band W wavefronts hold */
+ * block b + 64 W enters the band (blocks change hands at the boundaries of 16-step groups): the widest band W wavefronts hold.  What counts is the band INSIDE the
+ * matrix of the half (n rows, mm columns): block b is in it for columns [max(0, 64 b + dlo), min(mm - 1, 64 b + 63 + dhi)]. */
 #define LF_HB_LAG(W) ((W) == 1 ? 64 : 96)
-static inline __host__ __device__ bool lf_hband_fits(lf_hband B, int W) { return B.dhi - B.dlo <= 4096 * W + LF_HB_LAG(W) * W - 94; }
-/* trial bounds of the roots: a quarter of the longer string on top of the length difference (15 % reads end up at 0.16 - 0.2 n) */
-static inline __host__ __device__ uint32_t lf_htrial_nw(uint32_t n, uint32_t m) { const uint32_t d = n > m ? n - m : m - n, x = n > m ? n : m; return d + x / 4 + 1; }
-static inline __host__ __device__ uint32_t lf_htrial_shw(uint32_t n) { return n / 4 + 1; }
-/* the queue of a node: 3 + log2(W) when its band fits W <= 4 wavefronts (only queries above 4096 rows: a smaller one is ONE wavefront per half either way
- * and its sweep lasts m + blocks steps with or without a band), else by rows.  *k0: the trial bound when the distance is not known */
-static inline __host__ __device__ int lf_hqueue_of(uint32_t n, uint32_t m, int best, int kind, unsigned pad, uint32_t *k0)
+static inline __host__ __device__ bool lf_hband_fits(lf_hband B, uint32_t n, int mm, int W)
+{
+    const int nbk = (int)((n + 63) >> 6);
+    const int dhi = B.dhi < mm - 64 ? B.dhi : mm - 64, dlo = B.dlo > -64 * (nbk - 1) ? B.dlo : -64 * (nbk - 1);
+    return dhi - dlo <= 4096 * W + LF_HB_LAG(W) * W - 94;
+}
+/* trial bounds of the roots above 4096 rows, in sixteenths of the rows (trial16; 0 = none).  A root does not know its distance: it is swept inside the band of a
+ * bound k0 -- min (F + R) <= k0, resp. the SHW minimum <= k0, proves the result exact -- and k0 = n + m is the whole matrix.  The levels are a chain of dependent
+ * steps whose number a band does not change, so a trial that fails costs a whole level: lf_align.hip picks trial16 per mode from the distances of the roots the
+ * process has seen so far (a batch is homogeneous: PacBio tails in the right place end at 0.16 - 0.2 of their rows, ONT ones at 0.1, tails in the wrong copy of a
+ * duplication at 0.47).  Results do not depend on it. */
+static inline __host__ __device__ uint32_t lf_htrial_nw(uint32_t n, uint32_t m, uint32_t trial16) { const uint32_t d = n > m ? n - m : m - n, x = n > m ? n : m; return d + (uint32_t)((uint64_t)x * trial16 / 16) + 1; }
+static inline __host__ __device__ uint32_t lf_htrial_shw(uint32_t n, uint32_t trial16) { return (uint32_t)((uint64_t)n * trial16 / 16) + 1; }
+/* the queue of a node.  Queues 3 .. 6: NW nodes on the banded sweep with 1 / 2 / 4 / 8 wavefronts per half; 7 .. 11: SHW roots (one half) on 1 .. 16 wavefronts;
+ * 0 .. 2: what does not fit sixteen wavefronts, and targets with bytes other than ACGT (stage API), on the unbanded sweeps by rows (super-bands through HBM
+ * above 32 768 rows).  *k0: the bound a node of unknown distance is swept with */
+#define LF_HQ_NW0 3
+#define LF_HQ_SHW0 7
+static inline __host__ __device__ int lf_hqueue_of(uint32_t n, uint32_t m, int best, int kind, unsigned pad, uint32_t trial16, uint32_t *k0)
 {
     *k0 = 0;
-    if (n > 4096 && pad == 0) {
-        uint32_t t = 0; lf_hband B;
-        if (kind == 1) { t = lf_htrial_shw(n); B = lf_hband_shw((int)t); }
-        else if (best >= 0) B = lf_hband_nw(n, m, best);
-        else { t = lf_htrial_nw(n, m); B = lf_hband_nw(n, m, (int)t); }
-        for (int c = 0, W = 1; c < 3; c++, W *= 2) if (lf_hband_fits(B, W)) { *k0 = t; return 3 + c; }
+    if (pad == 0 && (uint64_t)n + m < (1u << 30)) {
+        const bool trial = n > 4096 && trial16 != 0;
+        if (kind == 1) {
+            const uint32_t t = trial ? lf_htrial_shw(n, trial16) : n + m;
+            const lf_hband B = lf_hband_shw((int)t);
+            const uint64_t me = (uint64_t)n + t; const int mm = (int)(me < m ? me : m);
+            for (int c = 0, W = 1; c < 5; c++, W *= 2) if (lf_hband_fits(B, n, mm, W)) { *k0 = t; return LF_HQ_SHW0 + c; }
+        } else {
+            const uint32_t t = best >= 0 ? 0u : trial ? lf_htrial_nw(n, m, trial16) : n + m;
+            const lf_hband B = lf_hband_nw(n, m, best >= 0 ? best : (int)t);
+            for (int c = 0, W = 1; c < 4; c++, W *= 2) if (lf_hband_fits(B, n, (int)(m - m / 2), W)) { *k0 = t; return LF_HQ_NW0 + c; }
+        }
     }
     return lf_hkb_class(n);
 }
 
 void lf_hirsch_launch_roots(hipStream_t s, bool pac_targets, const lf_aln_desc_t *d_desc, const uint64_t *d_opsoff, int n, lf_hargs A);
-void lf_hirsch_launch_level(hipStream_t s, bool pac_targets, int kbc, lf_hargs A);      /* kbc 0 .. 2: unbanded, 3 .. 5: banded */
+void lf_hirsch_launch_level(hipStream_t s, bool pac_targets, int kbc, lf_hargs A);      /* kbc: the queue (lf_hqueue_of) */
 void lf_hirsch_launch_stitch(hipStream_t s, lf_hargs A, uint32_t n_roots);
 #endif

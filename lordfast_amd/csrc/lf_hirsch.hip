@@ -123,13 +123,17 @@ __device__ __forceinline__ void lf_hsweep(const lf_qacc &Q, const lf_tacc &T, co
             auto steps16 = [&](auto fast_tag, const int sl0, const uint32_t V, const uint32_t cin16) {
                 constexpr bool FAST = decltype(fast_tag)::value;
                 const int p0 = sl0 - lane;
+                /* the group's sixteen match masks first, all in flight together (round 6): read inside the steps, each LDS access sat on the dependent chain of
+                 * a wavefront that has its SIMD to itself -- 0.25 us per column for one wavefront, 0.45 - 0.55 for four / eight (profiles/r06_hirsch/) */
+                uint64_t EQ[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) EQ[k] = peq_l[((V >> (2 * k)) & 3u) * 64];
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const uint32_t from_left = lf_wave_shr1(hout);
                     const uint32_t col0 = (uint32_t)(p0 + k);                /* column - 1; wraps for lanes that have not started */
                     if (FAST || (lane < nl && col0 < m)) {
-                        const uint32_t sy = (V >> (2 * k)) & 3u;
-                        const uint64_t Eq = peq_l[sy * 64];
+                        const uint64_t Eq = EQ[k];
                         const uint32_t hin = lane == 0 ? ((cin16 >> (2 * k)) & 3u) : from_left;
                         uint64_t ph, mh;
                         hout = lf_myers_step(Pv[0], Mv[0], Eq, hin, ph, mh);
@@ -141,16 +145,25 @@ __device__ __forceinline__ void lf_hsweep(const lf_qacc &Q, const lf_tacc &T, co
                     acc |= hout << (2 * k);
                 }
             };
+            /* the 16 target symbols of the group that starts at local step sl (and, below a super-band boundary, the carry words of its columns) are
+             * requested one group ahead: a global load right in front of its use was the other stall of the chain */
+            auto fetchV = [&](int sl) -> uint32_t { return lf_pac16(T.pac, T.start + (int64_t)T.dir * ((int64_t)sl - lane), T.dir, T.comp, pac_syms); };
+            const int g_first = t0 >> 4;                                      /* the first group with sl0 >= 0 */
+            uint32_t Vn = fetchV(0), ha_n = 0, hb_n = 0;
+            if (from_hbm && my_steps > 0) { ha_n = h32_in[3]; hb_n = h32_in[4]; }
             for (int g = 0; g < n_groups; g++) {
                 if (W > 1) __syncthreads();
                 const int sl0 = 16 * g - t0;                                 /* LF_H_LAG is a multiple of 16 */
                 if (sl0 < 0 || sl0 >= my_steps) continue;
-                const uint32_t V = lf_pac16(T.pac, T.start + (int64_t)T.dir * ((int64_t)sl0 - lane), T.dir, T.comp, pac_syms);
+                (void)g_first;
+                const uint32_t V = Vn, ha = ha_n, hb = hb_n;
+                Vn = fetchV(sl0 + 16);
+                if (from_hbm && sl0 + 16 < my_steps) { const int gl = (sl0 + 16) >> 4; ha_n = h32_in[gl + 3]; hb_n = h32_in[gl + 4]; }
                 /* carries entering lane 0: +1 per column above the first block; else what the last lane of the wavefront above left
                  * for the same columns 63 steps (3 groups and 15 steps) later in ITS numbering */
                 uint32_t cin16 = 0x55555555u;
                 if (from_wave) { const int gl = sl0 >> 4; const uint32_t a = cw32_in[(gl + 3) & 7], b = cw32_in[(gl + 4) & 7]; cin16 = (a >> 30) | (b << 2); }
-                else if (from_hbm) { const int gl = sl0 >> 4; const uint32_t a = h32_in[gl + 3], b = h32_in[gl + 4]; cin16 = (a >> 30) | (b << 2); }      /* the same columns, left by the super-band above */
+                else if (from_hbm) cin16 = (ha >> 30) | (hb << 2);             /* the same columns, left by the super-band above */
                 acc = 0;
                 if (sl0 >= nl - 1 && sl0 + 15 <= (int)m - 1) steps16(std::true_type{}, sl0, V, cin16);
                 else steps16(std::false_type{}, sl0, V, cin16);
@@ -267,6 +280,13 @@ __device__ __forceinline__ int lf_hcol(const uint64_t *__restrict__ B, uint32_t 
     return (int)(int64_t)B[3 * (size_t)b + 2] + __popcll(pv & msk) - __popcll(mv & msk);
 }
 
+/* the roots above 4096 rows by distance / rows: the next calls' trial bounds are chosen from these counts (lf_align.hip) */
+__device__ __forceinline__ void lf_hratio(const lf_hargs &A, int shw, int ed, uint32_t n)
+{
+    if (n <= 4096) return;
+    uint32_t r = (uint32_t)(16ull * (uint32_t)ed / n); if (r > 15) r = 15;
+    atomicAdd(&A.ctl->ratio_hist[shw][r], 1u);
+}
 /* registers a finished piece of a root's path (wave-uniform arguments; lane 0 writes) */
 __device__ __forceinline__ void lf_hpiece(const lf_hargs &A, uint32_t root, uint64_t off, uint32_t cap, uint32_t len)
 {
@@ -308,7 +328,7 @@ __device__ __forceinline__ void lf_hfinalize(const lf_hargs &A, const lf_hnode &
     }
     if (lane == 0) {
         uint32_t k0;
-        const int kbc = lf_hqueue_of(cn, cm, best, 0, (P.pad & 1u) | A.no_band, &k0);      /* (its distance is known: a band of exactly that width, no trial) */
+        const int kbc = lf_hqueue_of(cn, cm, best, 0, (P.pad & 1u) | A.no_band, 0, &k0);      /* (its distance is known: a band of exactly that width, no trial) */
         const uint32_t idx = atomicAdd(&A.ctl->q_n[A.out_par][kbc], 1u);
         if (idx >= A.q_cap) { atomicExch(&A.ctl->fail, 4u); return; }
         lf_hnode c;
@@ -317,15 +337,16 @@ __device__ __forceinline__ void lf_hfinalize(const lf_hargs &A, const lf_hnode &
         A.q_out[kbc][idx] = c;
     }
 }
-/* a node whose trial bound was too small goes back to the queue as it is, for the unbanded sweep of its size */
-__device__ __forceinline__ void lf_hrequeue_unbanded(const lf_hargs &A, const lf_hnode &P)
+/* a root whose trial bound was too small goes back to the queue with the whole matrix as its band */
+__device__ __forceinline__ void lf_hrequeue_full(const lf_hargs &A, const lf_hnode &P)
 {
     if ((threadIdx.x & 63) == 0) {
-        const int kbc = lf_hkb_class(P.n);
+        uint32_t k0;
+        const int kbc = lf_hqueue_of(P.n, P.m, -1, P.kind, P.pad, 0, &k0);
         const uint32_t idx = atomicAdd(&A.ctl->q_n[A.out_par][kbc], 1u);
         atomicAdd(&A.ctl->n_trial_failed, 1u);
         if (idx >= A.q_cap) { atomicExch(&A.ctl->fail, 4u); return; }
-        lf_hnode c = P; c.pad = (uint8_t)(P.pad | LF_HN_NOBAND); c.k0 = 0;
+        lf_hnode c = P; c.k0 = k0;
         A.q_out[kbc][idx] = c;
     }
 }
@@ -369,7 +390,7 @@ lf_hirsch_level_kernel(lf_hargs A)
         int ed = 0, tl = 0;
         lf_hsweep<KB, W, PAC>(Q, T, A.pac_syms, n, m, m, true, w != 0, wsub, s_ring[wave], s_cring[wave], cw_in, s_cw[wave], s_peq[wave], hc, PK ? hc + HB : hc + m + 32, nullptr, s_tot[w], s_shw[w], ed, tl);
         if (wave != 0) return;
-        if (lane == 0) { A.out_ed[desc] = ed; A.out_end[desc] = tl - 1; }
+        if (lane == 0) { A.out_ed[desc] = ed; A.out_end[desc] = tl - 1; lf_hratio(A, 1, ed, n); }
         lf_hfinalize(A, P, 0, n, 0, (uint32_t)tl, ed, P.ops_off);
         return;
     }
@@ -398,7 +419,7 @@ lf_hirsch_level_kernel(lf_hargs A)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(mn, o); mn = v < mn ? v : mn; }
         best = mn;
-        if (lane == 0 && P.is_root) { A.out_ed[desc] = best; A.out_end[desc] = (int)m - 1; }
+        if (lane == 0 && P.is_root) { A.out_ed[desc] = best; A.out_end[desc] = (int)m - 1; lf_hratio(A, 0, best, n); }
     }
     /* split row (lib/edlib/edlib.cpp:1263-1289): first qi in 0 .. n-2 with F[qi+1] + R[n-qi-1] == best, else -1, else n-1 */
     int split = -2, ls = 0, rs = 0;
@@ -526,13 +547,17 @@ __device__ __forceinline__ void lf_hband_sweep(const lf_hargs &A, const int64_t 
         if (lf_any(jend != 0u)) {
             const int p0 = s0 - skw;
             const bool is_last = TRACK && b == lastb;
+            /* the group's sixteen match masks first, all in flight together: inside the steps an LDS read sits on the dependent chain of a wavefront that
+             * has the SIMD to itself (the unbanded one-wavefront sweep takes 0.25 us per column that way) */
+            uint64_t EQ[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) EQ[k] = peq_l[((V >> (2 * k)) & 3u) * 64];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint32_t from_left = W == 1 ? lf_wave_ror1(hout) : lf_wave_shr1(hout);
                 const uint32_t col0 = (uint32_t)(p0 + k);                    /* wraps for columns in front of the target */
                 if (col0 < jend) {
-                    const uint32_t sy = (V >> (2 * k)) & 3u;
-                    const uint64_t Eq = peq_l[sy * 64];
+                    const uint64_t Eq = EQ[k];
                     uint32_t hin = (W > 1 && lane == 0) ? ((cin16 >> (2 * k)) & 3u) : from_left;
                     hin = col0 < jtop ? hin : LF_HIN_PLUS1;
                     uint64_t ph, mh;
@@ -573,13 +598,14 @@ __device__ __forceinline__ int lf_hcol_band(const uint64_t *__restrict__ Bk, uin
     return lf_hcol(Bk, x, zero);
 }
 
-template <int W>
-__global__ void __launch_bounds__(128 * W)
+template <int W, bool SHW>
+__global__ void __launch_bounds__(SHW ? 64 * W : 128 * W)
 lf_hband_level_kernel(lf_hargs A)
 {
-    __shared__ uint64_t s_peq[2 * W][256];
-    __shared__ uint32_t s_cw[2 * W][8];
-    __shared__ int s_scr[2 * W][8], s_shw[2];
+    constexpr int NW_ = SHW ? W : 2 * W;                  /* wavefronts of the workgroup: an SHW root has one half */
+    __shared__ uint64_t s_peq[NW_][256];
+    __shared__ uint32_t s_cw[NW_][8];
+    __shared__ int s_scr[NW_][8], s_shw[2];
     __shared__ unsigned long long s_base;
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     const int w = wave / W, wsub = wave % W;             /* w: the node's half; wsub: the wavefront inside it */
@@ -589,28 +615,27 @@ lf_hband_level_kernel(lf_hargs A)
     const uint32_t lw = m / 2, rw = m - lw;
     const uint32_t desc = A.roots[P.root].desc;
     if (threadIdx.x == 0) {
-        s_base = P.kind == 0 ? atomicAdd(&A.ctl->aux_used, 6ull * nbk) : 0ull;
+        s_base = !SHW ? atomicAdd(&A.ctl->aux_used, 6ull * nbk) : 0ull;
         s_shw[0] = (n & 63) ? (int)n : 0x7fffffff; s_shw[1] = 0;
     }
     __syncthreads();
-    if (P.kind == 0 && s_base + 6ull * nbk > A.aux_cap) { if (threadIdx.x == 0) { atomicExch(&A.ctl->fail, 5u); A.out_ed[desc] = -2; } return; }
+    if (!SHW && s_base + 6ull * nbk > A.aux_cap) { if (threadIdx.x == 0) { atomicExch(&A.ctl->fail, 5u); A.out_ed[desc] = -2; } return; }
     uint64_t *Fb = A.aux + s_base, *Rb = Fb + 3 * (size_t)nbk;
     const int64_t dq = (P.flags & LF_F_QREV) ? -1 : 1, dt = (P.flags & LF_F_TREV) ? -1 : 1;
     const int pw = w * W + (wsub + W - 1) % W;            /* the wavefront whose last lane hands its carries to this one's lane 0 */
 
-    if (P.kind == 1) {
-        /* SHW root inside the band of the trial bound: distance and end column (lib/edlib/edlib.cpp:141-168); the second half's wavefronts keep the barriers company */
-        const int k = (int)P.k0;
+    if constexpr (SHW) {
+        /* SHW root inside the band of its bound: distance and end column (lib/edlib/edlib.cpp:141-168) */
+        const int64_t k64 = (int64_t)P.k0; const int k = (int)k64;
         const lf_hband B = lf_hband_shw(k);
         const int64_t mme64 = (int64_t)n + k; const int mme = (int)(mme64 < (int64_t)m ? mme64 : (int64_t)m);
-        if (W == 1 && w != 0) return;
         const int nG = lf_hband_groups<W>(n, mme, B);
-        lf_hband_sweep<W, true>(A, P.qstart, P.tstart, P.flags, n, mme, B, w != 0, nG, wsub, s_peq[wave], s_cw[pw], s_scr[pw], s_cw[wave], s_scr[wave], nullptr, s_shw);
+        lf_hband_sweep<W, true>(A, P.qstart, P.tstart, P.flags, n, mme, B, false, nG, wsub, s_peq[wave], s_cw[pw], s_scr[pw], s_cw[wave], s_scr[wave], nullptr, s_shw);
         __syncthreads();
         if (wave != 0) return;
         const int ed = s_shw[0], tl = s_shw[1];
-        if (ed > k) { lf_hrequeue_unbanded(A, P); return; }
-        if (lane == 0) { A.out_ed[desc] = ed; A.out_end[desc] = tl - 1; }
+        if (ed > k) { lf_hrequeue_full(A, P); return; }
+        if (lane == 0) { A.out_ed[desc] = ed; A.out_end[desc] = tl - 1; lf_hratio(A, 1, ed, n); }
         lf_hfinalize(A, P, 0, n, 0, (uint32_t)tl, ed, P.ops_off);
         return;
     }
@@ -638,9 +663,9 @@ lf_hband_level_kernel(lf_hargs A)
         for (uint32_t base = 0; base <= n; base += 64) { const uint32_t r = base + (uint32_t)lane; if (r <= n) { const int v = F(r) + R(n - r); mn = v < mn ? v : mn; } }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(mn, o); mn = v < mn ? v : mn; }
-        if (mn > k) { lf_hrequeue_unbanded(A, P); return; }
+        if (mn > k) { lf_hrequeue_full(A, P); return; }
         best = mn;
-        if (lane == 0 && P.is_root) { A.out_ed[desc] = best; A.out_end[desc] = (int)m - 1; }
+        if (lane == 0 && P.is_root) { A.out_ed[desc] = best; A.out_end[desc] = (int)m - 1; lf_hratio(A, 0, best, n); }
     }
     /* split row (lib/edlib/edlib.cpp:1263-1289), exactly as in the unbanded kernel: rows outside the band cannot satisfy the equality */
     int split = -2, ls = 0, rs = 0;
@@ -668,10 +693,10 @@ __global__ void lf_hirsch_roots_kernel(const lf_aln_desc_t *__restrict__ d, cons
     if (x.n == 0 || x.m == 0 || lf_leaf(x.n, x.m)) return;
     const uint32_t r = atomicAdd(&A.ctl->n_roots, 1u), cap = lf_hroot_cap(x.n, x.m), so = atomicAdd(&A.ctl->seg_used, cap);
     uint32_t k0;
-    const int kbc = lf_hqueue_of(x.n, x.m, -1, x.mode ? 1 : 0, (x.pad[0] != 0 ? 1u : 0u) | A.no_band, &k0);
+    const int kbc = lf_hqueue_of(x.n, x.m, -1, x.mode ? 1 : 0, (x.pad[0] != 0 ? 1u : 0u) | A.no_band, A.trial16[x.mode ? 1 : 0], &k0);
     const uint32_t idx = atomicAdd(&A.ctl->q_n[A.out_par][kbc], 1u);
     if (idx >= A.q_cap) { atomicExch(&A.ctl->fail, 4u); return; }
-    if (k0) atomicAdd(&A.ctl->n_trial, 1u);
+    if (k0 && k0 != x.n + x.m) atomicAdd(&A.ctl->n_trial, 1u);
     lf_hroot R; R.ops_off = ops_off[i]; R.desc = (uint32_t)i; R.n = x.n; R.m = x.m; R.seg_off = so; R.seg_cap = cap; R.count = 0;
     A.roots[r] = R;
     lf_hnode c;
@@ -724,11 +749,19 @@ void lf_hirsch_launch_roots(hipStream_t s, bool pac_targets, const lf_aln_desc_t
 void lf_hirsch_launch_level(hipStream_t s, bool pac, int kbc, lf_hargs A)
 {
     if (A.n_in == 0) return;
-    if (kbc >= 3) {      /* banded sweeps: 1 / 2 / 4 wavefronts per half by band width */
+    if (kbc >= LF_HQ_NW0) {      /* banded sweeps, by the wavefronts the band needs */
         const dim3 gb(A.n_in);
-        if (kbc == 3) hipLaunchKernelGGL((lf_hband_level_kernel<1>), gb, dim3(128), 0, s, A);
-        else if (kbc == 4) hipLaunchKernelGGL((lf_hband_level_kernel<2>), gb, dim3(256), 0, s, A);
-        else hipLaunchKernelGGL((lf_hband_level_kernel<4>), gb, dim3(512), 0, s, A);
+        switch (kbc) {
+        case LF_HQ_NW0 + 0: hipLaunchKernelGGL((lf_hband_level_kernel<1, false>), gb, dim3(128), 0, s, A); break;
+        case LF_HQ_NW0 + 1: hipLaunchKernelGGL((lf_hband_level_kernel<2, false>), gb, dim3(256), 0, s, A); break;
+        case LF_HQ_NW0 + 2: hipLaunchKernelGGL((lf_hband_level_kernel<4, false>), gb, dim3(512), 0, s, A); break;
+        case LF_HQ_NW0 + 3: hipLaunchKernelGGL((lf_hband_level_kernel<8, false>), gb, dim3(1024), 0, s, A); break;
+        case LF_HQ_SHW0 + 0: hipLaunchKernelGGL((lf_hband_level_kernel<1, true>), gb, dim3(64), 0, s, A); break;
+        case LF_HQ_SHW0 + 1: hipLaunchKernelGGL((lf_hband_level_kernel<2, true>), gb, dim3(128), 0, s, A); break;
+        case LF_HQ_SHW0 + 2: hipLaunchKernelGGL((lf_hband_level_kernel<4, true>), gb, dim3(256), 0, s, A); break;
+        case LF_HQ_SHW0 + 3: hipLaunchKernelGGL((lf_hband_level_kernel<8, true>), gb, dim3(512), 0, s, A); break;
+        default: hipLaunchKernelGGL((lf_hband_level_kernel<16, true>), gb, dim3(1024), 0, s, A); break;
+        }
         return;
     }
     /* blocks per lane x wavefronts per half: one block per lane, 1 / 4 / 8 wavefronts: queries of <= 4096 / 16384 / 32768 rows in one

@@ -61,7 +61,13 @@ struct HalfOut {
 
 /* width limit of W wavefronts of L lanes (lane reuse: a lane must be done with block b before block b + L W starts) */
 inline int lagw(int L, int W) { return W == 1 ? L : L + 32; }
-inline bool band_fits(Band B, int L, int W) { return B.dhi - B.dlo <= 64 * L * W + lagw(L, W) * W - 94; }
+/* (lf_hband_fits, lf_hirsch.h: the band inside the half's matrix of n rows and mm columns) */
+inline bool band_fits(Band B, int n, int mm, int L, int W)
+{
+    const int nbk = (n + 63) >> 6;
+    const int dhi = std::min(B.dhi, mm - 64), dlo = std::max(B.dlo, -64 * (nbk - 1));
+    return dhi - dlo <= 64 * L * W + lagw(L, W) * W - 94;
+}
 
 /* one half: q codes (0..3, or -1 = never matches) for rows, t codes for columns; mm columns */
 void sweep_half(const int8_t *q, int n, const int8_t *t, int mm, Band B, bool track, int L, int W, HalfOut &O)
@@ -201,10 +207,10 @@ int split_rule(int n, int lw, int rw, int best, FF F, RF R, int &ls, int &rs)
 extern "C" {
 
 /* returns the number of wavefronts per half the device would pick for this band (0: does not fit any class up to Wmax) */
-int hbm_pick_w(int dlo, int dhi, int L, int Wmax)
+int hbm_pick_w(int dlo, int dhi, int n, int mm, int L, int Wmax)
 {
     Band B; B.dlo = dlo; B.dhi = dhi;
-    for (int W = 1; W <= Wmax; W *= 2) if (band_fits(B, L, W)) return W;
+    for (int W = 1; W <= Wmax; W *= 2) if (band_fits(B, n, mm, L, W)) return W;
     return 0;
 }
 
@@ -215,7 +221,7 @@ void hbm_node(const int8_t *q, int n, const int8_t *t, int m, int k, int trial, 
 {
     const int lw = m / 2, rw = m - lw;
     const Band B = nw_band(n, m, k);
-    const int W = hbm_pick_w(B.dlo, B.dhi, L, Wmax);
+    const int W = hbm_pick_w(B.dlo, B.dhi, n, rw, L, Wmax);
     out[5] = W;
     if (!W) { out[0] = -1; return; }
     std::vector<int8_t> qr(q, q + n), tr(t, t + m);
@@ -259,10 +265,10 @@ void hbm_ref_node(const int8_t *q, int n, const int8_t *t, int m, long *out)
 void hbm_shw(const int8_t *q, int n, const int8_t *t, int m, int k, int L, int Wmax, long *out)
 {
     const Band B = shw_band(k);
-    const int W = hbm_pick_w(B.dlo, B.dhi, L, Wmax);
+    const long mme = std::min<long>(m, (long)n + k);
+    const int W = hbm_pick_w(B.dlo, B.dhi, n, (int)mme, L, Wmax);
     out[5] = W;
     if (!W) { out[0] = -1; return; }
-    const long mme = std::min<long>(m, (long)n + k);
     HalfOut O;
     sweep_half(q, n, t, (int)mme, B, true, L, W, O);
     out[6] = O.steps; out[7] = O.active_steps;

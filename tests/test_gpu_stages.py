@@ -201,7 +201,17 @@ def test_edlib_banded_levels_on_low_complexity_strings(oracle_lib, monkeypatch):
     add(rseq(rng, 9000), rseq(rng, 2500), ms=(0,))                                                   # much longer than the target: the band is the length difference
     q = rseq(rng, 7000); add(q, q[:3000] + q[3400:], ms=(0,))                                        # one long gap, otherwise identical: distance == |m - n|, band of +- 0
     q = rseq(rng, 4200 + 64 * 3); add(q, q)                                                           # identical strings
-    res, _ = la.edlib_batch(qs, ts, modes)
+    # the roots' trial bounds follow what the process has seen (lf_align.hip: lf_htrial_pick); fixed here: generous, tight (most trials fail), none
+    runs = []
+    for trial in ("4,4", "2,2", "0,0"):
+        monkeypatch.setenv("LF_HIRSCH_TRIAL", trial)
+        runs.append(la.edlib_batch(qs, ts, modes)[0])
+    monkeypatch.delenv("LF_HIRSCH_TRIAL")
+    runs.append(la.edlib_batch(qs, ts, modes)[0])                                                   # ... and chosen from the three runs above
+    res = runs[0]
+    for other in runs[1:]:
+        for i, (r, r0) in enumerate(zip(res, other)):
+            assert (r[0], r[1]) == (r0[0], r0[1]) and np.array_equal(r[2], r0[2]), ("trial bounds changed a result", i, len(qs[i]), len(ts[i]), modes[i])
     monkeypatch.setenv("LF_HIRSCH_BAND", "0")
     res0, _ = la.edlib_batch(qs, ts, modes)
     for i, (r, r0) in enumerate(zip(res, res0)):

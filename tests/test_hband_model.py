@@ -74,7 +74,7 @@ def ref_node(model, q, t):
     return out
 
 
-@pytest.mark.parametrize("L,Wmax,nmax,ncase", [(64, 1, 6500, 24), (8, 1, 1500, 150), (8, 4, 3000, 150), (4, 2, 900, 150), (64, 2, 9000, 6)])
+@pytest.mark.parametrize("L,Wmax,nmax,ncase", [(64, 1, 6500, 24), (8, 1, 1500, 150), (8, 4, 3000, 150), (4, 2, 900, 150), (4, 16, 3000, 100), (64, 2, 9000, 6)])
 def test_banded_node_equals_full_matrix_node(model, L, Wmax, nmax, ncase):
     rng = np.random.default_rng(1000 * L + Wmax)
     done = fits = 0
@@ -93,7 +93,7 @@ def test_banded_node_equals_full_matrix_node(model, L, Wmax, nmax, ncase):
         ws.add(int(got[5]))
         assert got[0] == 1 and tuple(got[1:5]) == tuple(ref[1:5]), (it, n, len(t), best, got, ref)
         # a trial bound at or above the distance: the distance falls out of the sweep; below it: the sweep says so
-        for k0 in (best, best + int(rng.integers(1, 40))):
+        for k0 in (best, best + int(rng.integers(1, 40)), n + len(t)):           # (n + m: the whole matrix -- what a root without a trial bound is swept with)
             g2 = run_node(model, q, t, k0, 1, L, Wmax)
             if g2[0] != -1:
                 assert g2[0] == 1 and tuple(g2[1:5]) == tuple(ref[1:5]), (it, "trial", k0, g2, ref)
@@ -106,7 +106,7 @@ def test_banded_node_equals_full_matrix_node(model, L, Wmax, nmax, ncase):
         assert len(ws) > 1, ws              # more than one wavefront class was exercised
 
 
-@pytest.mark.parametrize("L,Wmax,nmax,ncase", [(64, 2, 5000, 16), (8, 4, 1200, 150), (4, 4, 600, 150)])
+@pytest.mark.parametrize("L,Wmax,nmax,ncase", [(64, 2, 5000, 16), (8, 4, 1200, 150), (4, 4, 600, 150), (4, 16, 2500, 100)])
 def test_banded_shw_equals_full_matrix_shw(model, L, Wmax, nmax, ncase):
     rng = np.random.default_rng(77 * L + Wmax)
     fits = 0
@@ -119,7 +119,7 @@ def test_banded_shw_equals_full_matrix_shw(model, L, Wmax, nmax, ncase):
         t = np.ascontiguousarray(np.concatenate([t0, rng.integers(0, 4, int(rng.integers(1, n // 2 + 2))).astype(np.int8)]))
         ref = np.zeros(8, dtype=np.int64); model.hbm_ref_shw(q, n, t, len(t), ref)
         ed = int(ref[1])
-        for k0 in (ed, ed + int(rng.integers(1, 50)), max(0, ed - 1 - int(rng.integers(0, 10)))):
+        for k0 in (ed, ed + int(rng.integers(1, 50)), max(0, ed - 1 - int(rng.integers(0, 10))), n + len(t)):
             out = np.zeros(8, dtype=np.int64)
             model.hbm_shw(q, n, t, len(t), k0, L, Wmax, out)
             if out[0] == -1:
