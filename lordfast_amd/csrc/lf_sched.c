@@ -2,6 +2,7 @@
  * and the place of their SAM text in the output, and the lf_map_batch* entry points (the reference's pthread pool takes reads
  * from a shared cursor the same way, src/LordFAST.cpp:295-303).  What a chunk goes through is lf_pipeline.c. */
 #include "lf_pipe.h"
+#include <errno.h>
 
 volatile unsigned g_crosscheck = 0;
 unsigned lf_debug_crosscheck(unsigned mask) { const unsigned old = g_crosscheck; g_crosscheck = mask & 15u; return old; }
@@ -416,13 +417,15 @@ static void *lane_main(void *arg_)
     return NULL;
 }
 
-typedef struct { volatile int stop; int limit_s; } wdog_t;
+/* (sleeps on a condition variable: the batch's end wakes it -- a plain 50 ms sleep made every batch that ran under LF_WATCHDOG last a multiple of 50 ms) */
+typedef struct { int stop; int limit_s; pthread_mutex_t mu; pthread_cond_t cv; } wdog_t;
 static void *wdog_main(void *arg)
 {
     wdog_t *w = (wdog_t *)arg;
-    for (int ms = 0; !w->stop; ms += 50) {
-        struct timespec ts = { 0, 50 * 1000000 }; nanosleep(&ts, NULL);
-        if (ms >= w->limit_s * 1000) {
+    struct timespec dl; clock_gettime(CLOCK_REALTIME, &dl); dl.tv_sec += w->limit_s;
+    pthread_mutex_lock(&w->mu);
+    while (!w->stop) {
+        if (pthread_cond_timedwait(&w->cv, &w->mu, &dl) == ETIMEDOUT && !w->stop) {
             fprintf(stderr, "[lf watchdog] batch still running after %d s\n", w->limit_s);
             for (int l = 0; l < LF_MAX_LANES; l++) if (g_lane_mark[l]) fprintf(stderr, "[lf watchdog] lane %d: last stage mark %s\n", l, g_lane_mark[l]);
             lfg_phase_dump();
@@ -430,6 +433,7 @@ static void *wdog_main(void *arg)
             abort();
         }
     }
+    pthread_mutex_unlock(&w->mu);
     return NULL;
 }
 
@@ -635,13 +639,16 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     /* LF_WATCHDOG=<seconds>: a batch that takes longer reports where every lane is and aborts (tests set it: a hang
      * becomes a failure with a location) */
     wdog_t wd; memset(&wd, 0, sizeof wd); pthread_t wdt; int have_wd = 0;
-    if (getenv("LF_WATCHDOG") && atoi(getenv("LF_WATCHDOG")) > 0) { wd.limit_s = atoi(getenv("LF_WATCHDOG")); have_wd = pthread_create(&wdt, NULL, wdog_main, &wd) == 0; }
+    if (getenv("LF_WATCHDOG") && atoi(getenv("LF_WATCHDOG")) > 0) {
+        wd.limit_s = atoi(getenv("LF_WATCHDOG")); pthread_mutex_init(&wd.mu, NULL); pthread_cond_init(&wd.cv, NULL);
+        have_wd = pthread_create(&wdt, NULL, wdog_main, &wd) == 0;
+    }
     void *la[LF_MAX_LANES][2]; pthread_t lt[LF_MAX_LANES]; int have[LF_MAX_LANES] = { 0 };
     for (int l = 0; l < LF_MAX_LANES; l++) { la[l][0] = &B; la[l][1] = (void *)(intptr_t)(l == 0 ? lane0 + 1 : 0); }      /* [1]: lane id + 1 already held, 0: take one */
     for (int l = 1; l < n_lanes && l < B.n_chunks; l++) have[l] = pthread_create(&lt[l], NULL, lane_main, la[l]) == 0;
     lane_main(la[0]);
     for (int l = 1; l < n_lanes; l++) if (have[l]) pthread_join(lt[l], NULL);
-    if (have_wd) { wd.stop = 1; pthread_join(wdt, NULL); }
+    if (have_wd) { pthread_mutex_lock(&wd.mu); wd.stop = 1; pthread_cond_signal(&wd.cv); pthread_mutex_unlock(&wd.mu); pthread_join(wdt, NULL); }
     lfg_set_lane(0);
     if (g_phase_on) { fprintf(stderr, "[lf] batch of %d reads: %.1f ms wall, %d threads\n", n, now_ms() - T0, nt); phase_report(); }
     pthread_mutex_lock(&g_lanes_mu); g_active_calls--; pthread_mutex_unlock(&g_lanes_mu);

@@ -1,4 +1,4 @@
-export LF_WATCHDOG=600
+# (no LF_WATCHDOG in timing runs)
 mkdir -p gpurun_out/r6_c4
 for band in 1 0; do
   LF_HIRSCH_BAND=$band timeout 900 python3 bench.py --config c4 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r6_c4/bench_band$band.json 2> gpurun_out/r6_c4/bench_band$band.err

@@ -1,4 +1,4 @@
-export LF_WATCHDOG=600
+# (no LF_WATCHDOG in timing runs)
 mkdir -p gpurun_out/r6_s2
 timeout 900 python -m pytest tests/test_gpu_stages.py -x -q -m gpu -k "edlib" 2>&1 | tail -5 > gpurun_out/r6_s2/tests.log; cat gpurun_out/r6_s2/tests.log
 LF_HIRSCH_DEBUG=1 timeout 600 python3 profiles/tools/r06_hlat.py > gpurun_out/r6_s2/lat.txt 2> gpurun_out/r6_s2/levels.txt; cat gpurun_out/r6_s2/lat.txt
