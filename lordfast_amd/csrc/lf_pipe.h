@@ -318,4 +318,7 @@ void phase_bind_text(ctx_t *cx, int tid, int ri);
 void phase_sam_print(ctx_t *cx, int tid, int ri);
 void phase_fine_select(ctx_t *cx, int tid, int ri);                                                        /* lf_pipeline.c */
 void phase_make_jobs(ctx_t *cx, int tid, int ri);
+/* lf_sched.c: the by-bases chunk cutter (exported so that tests/test_sched.py can call it without a device) */
+int lf_cut_chunks_by_bases(const uint32_t *lens, int n, int n_lanes, double ramp, int sampling_count, int *ends, int cap);
+
 #endif

@@ -437,6 +437,50 @@ static void *wdog_main(void *arg)
     return NULL;
 }
 
+/* One chunk per lane (reads resident in HBM, or a pinned host batch): the chunks are cut by BASES -- equal shares (a lane's time goes with its bases, not
+ * its reads), times the linear ramp for host batches (chunk k about 1 + ramp (2 k / (L - 1) - 1) times the mean: the lanes finish in chunk order) -- and
+ * there are as many as lanes, or as the bounds ask for:
+ *   - a lane's working set: 768 MB of bases per chunk (~ 13 bytes of HBM per base);
+ *   - reads per chunk: reads x sampling positions is a 31-bit index in the seed stage and sizes its buffers (lf_seed.hip), so at most
+ *     2^30 / sampling_count reads and never more than LF_CHUNK_READS_MAX -- a batch of millions of short reads is cut into more chunks, not failed
+ *     ("seed batch too large") or given gigabytes of sample buffers per lane;
+ *   - no chunk below 6250 reads when fewer chunks than lanes would do (a chunk's launch / sync chain does not shrink with it).
+ * ends[k] = one past the last read of chunk k; returns the number of chunks (<= cap), 0 if cap is too small. */
+#define LF_CHUNK_READS_MAX 65536
+int lf_cut_chunks_by_bases(const uint32_t *lens, int n, int n_lanes, double ramp, int sampling_count, int *ends, int cap)
+{
+    if (n <= 0 || cap <= 0) return 0;
+    uint64_t total_b = 0; for (int i = 0; i < n; i++) total_b += lens[i];
+    int nck = n_lanes < 1 ? 1 : n_lanes; if (nck > n / 6250) nck = n / 6250 > 0 ? n / 6250 : 1;
+    const uint64_t cap_b = 768ull << 20;
+    if ((uint64_t)nck * cap_b < total_b) nck = (int)((total_b + cap_b - 1) / cap_b);
+    long long cap_r = (1ll << 30) / (sampling_count > 0 ? sampling_count : 1); if (cap_r > LF_CHUNK_READS_MAX) cap_r = LF_CHUNK_READS_MAX; if (cap_r < 1) cap_r = 1;
+    if ((long long)nck * cap_r < n) nck = (int)((n + cap_r - 1) / cap_r);
+    if (nck > 1 && ramp > 0) {          /* the largest chunk of the ramp holds (1 + ramp) times the mean */
+        while ((long long)((double)n / nck * (1.0 + ramp)) + 1 > cap_r && nck < n) nck++;
+    }
+#define CHUNK_W(k) (1.0 + (nck > 1 ? ramp * (2.0 * (k) / (nck - 1) - 1.0) : 0.0))
+    double wsum = 0; for (int k = 0; k < nck; k++) wsum += CHUNK_W(k);
+    int i0 = 0, out = 0; double acc_w = 0; uint64_t acc_b = 0;
+    for (int k = 0; k < nck && i0 < n; k++) {
+        acc_w += CHUNK_W(k);
+        const uint64_t goal = k == nck - 1 ? total_b : (uint64_t)((double)total_b * acc_w / wsum);
+        int i1 = i0;
+        while (i1 < n && (acc_b < goal || i1 == i0) && i1 - i0 < cap_r) { acc_b += lens[i1]; i1++; }
+        if (k == nck - 1 && n - i0 <= cap_r) i1 = n;
+        if (out >= cap) return 0;
+        ends[out++] = i1;
+        i0 = i1;
+    }
+    while (i0 < n) {                     /* (reads the read cap pushed behind the last planned chunk) */
+        int i1 = i0 + (int)cap_r; if (i1 > n) i1 = n;
+        if (out >= cap) return 0;
+        ends[out++] = i1; i0 = i1;
+    }
+#undef CHUNK_W
+    return out;
+}
+
 typedef struct { const void *d_seqs, *d_quals; const uint64_t *seq_off; int dev_out; int32_t **stage_sink; } devio_t;
 static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_params_t *p, int n, const char *const *names,
                           const char *const *seqs, const char *const *quals, const uint32_t *seq_lens, char *ext_buf, size_t ext_cap,
@@ -600,26 +644,11 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
      * for): with four lanes a cut by read count left a fifth, tiny chunk behind the four large ones. */
     int by_bases = 0;
     if (!getenv("LF_CHUNK_READS") && !getenv("LF_CHUNK_BASES") && !getenv("LF_CHUNKS_PER_LANE") && first_reads == 0 && n_lanes >= 2 && n > 2048 && ((dio && !dio->stage_sink) || B.holes)) {
-        uint64_t total_b = 0; for (int i = 0; i < n; i++) total_b += lens[i];
-        int nck = n_lanes; if (nck > n / 6250) nck = n / 6250 > 0 ? n / 6250 : 1;
-        const uint64_t cap_b = 768ull << 20;                                    /* working set of a lane: ~ 13 bytes of HBM per base */
-        if ((uint64_t)nck * cap_b < total_b) nck = (int)((total_b + cap_b - 1) / cap_b);
-        /* share of chunk k: the linear ramp, or LF_CHUNK_WEIGHTS=w0,w1,... (experiment hook: any profile; chunks past the list take the last weight) */
-        double cw[LF_MAX_LANES * 4]; int ncw = 0;
-        if (getenv("LF_CHUNK_WEIGHTS")) { const char *q = getenv("LF_CHUNK_WEIGHTS"); while (*q && ncw < LF_MAX_LANES * 4) { char *e; const double v = strtod(q, &e); if (e == q) break; cw[ncw++] = v > 0.01 ? v : 0.01; q = *e == ',' ? e + 1 : e; } }
-#define CHUNK_W(k) (ncw ? cw[(k) < ncw ? (k) : ncw - 1] : 1.0 + (nck > 1 ? ramp * (2.0 * (k) / (nck - 1) - 1.0) : 0.0))
-        double wsum = 0; for (int k = 0; k < nck; k++) wsum += CHUNK_W(k);
-        int i0 = 0; double acc_w = 0; uint64_t acc_b = 0;
-        for (int k = 0; k < nck && i0 < n; k++) {
-            acc_w += CHUNK_W(k);
-            const uint64_t goal = k == nck - 1 ? total_b : (uint64_t)((double)total_b * acc_w / wsum);
-            int i1 = i0;
-            while (i1 < n && (acc_b < goal || i1 == i0)) { acc_b += lens[i1]; i1++; }
-            if (k == nck - 1) i1 = n;
-            B.chunks[B.n_chunks].i0 = i0; B.chunks[B.n_chunks].i1 = i1; B.n_chunks++;
-            i0 = i1;
-        }
-#undef CHUNK_W
+        int *ends = (int *)malloc(((size_t)n + 1) * sizeof(int));
+        const int nck = ends ? lf_cut_chunks_by_bases(lens, n, n_lanes, ramp, p->sampling_count, ends, n + 1) : 0;
+        for (int k = 0, i0 = 0; k < nck; k++) { B.chunks[B.n_chunks].i0 = i0; B.chunks[B.n_chunks].i1 = ends[k]; B.n_chunks++; i0 = ends[k]; }
+        free(ends);
+        if (nck <= 0) { free(lens); free(B.chunks); lf_set_error("out of memory (chunk table)"); return LF_ERR_NOMEM; }
         by_bases = 1;
     }
     for (int i0 = 0; i0 < n && !by_bases; ) {
