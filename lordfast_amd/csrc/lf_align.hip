@@ -738,7 +738,26 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
             HA.out_par = (uint32_t)(par ^ 1);
             /* the classes with the longest sweeps first: wide bands, unbanded large queries, ... */
             static const int order[LF_HQ] = { 2, 1, 11, 6, 10, 5, 9, 4, 8, 3, 7, 0 };
-            for (int o = 0; o < LF_HQ; o++) { const int k = order[o]; HA.q_in = queue(par, k); HA.n_in = cntq[k]; lf_hirsch_launch_level(s, D->pac, k, HA); }
+            /* A level's queues are independent, and each lasts as long as its longest node: one after the other on one stream a level cost the SUM of its
+             * queues' longest sweeps (round 6 has twelve queues where round 5 had three).  They go out side by side on the lane's class streams -- idle
+             * until the binning below -- and the level's stream waits for all of them. */
+            hipStream_t ls[6]; int n_ls = 1; ls[0] = s;
+            if (!serial_classes) { for (int k = 0; k < LF_NCLASS && n_ls < 6; k++) ls[n_ls++] = cs[k]; hipStream_t x6 = (hipStream_t)lfg_lane_stream(device, 6); if (x6 && n_ls < 6) ls[n_ls++] = x6; }
+            hipEvent_t lfork = (hipEvent_t)lfg_lane_event(device, 28); if (!lfork) return LF_ERR_HIP;
+            bool used_ls[6] = { false, false, false, false, false, false }; int slot = 0;
+            HIPCHK(hipEventRecord(lfork, s));
+            for (int o = 0; o < LF_HQ; o++) {
+                const int k = order[o];
+                if (!cntq[k]) continue;
+                const int u = slot % n_ls; slot++;
+                if (u != 0 && !used_ls[u]) HIPCHK(hipStreamWaitEvent(ls[u], lfork, 0));
+                used_ls[u] = true;
+                HA.q_in = queue(par, k); HA.n_in = cntq[k]; lf_hirsch_launch_level(ls[u], D->pac, k, HA);
+            }
+            for (int u = 1; u < n_ls; u++) if (used_ls[u]) {
+                hipEvent_t ld = (hipEvent_t)lfg_lane_event(device, 20 + u); if (!ld) return LF_ERR_HIP;
+                HIPCHK(hipEventRecord(ld, ls[u])); HIPCHK(hipStreamWaitEvent(s, ld, 0));
+            }
             par ^= 1;
         }
         lf_htrial_learn(h_ctl->ratio_hist);
