@@ -177,6 +177,9 @@ typedef struct {
     float ms_k_rsweep, ms_k_tb, ms_k_hirsch, ms_k_bin;
     uint64_t hirsch_bytes;                              /* sum over the problems above edlib's traceback switch of (q + ceil(t/4) + q + t): what the Hirschberg levels read and write */
     uint64_t n_host_waits, n_chunks;                    /* host waits for a stream / event on the chunk drivers' threads, and the chunks they drove */
+    uint64_t hirsch_max_rows;                           /* the longest query among the problems above edlib's traceback switch */
+    uint64_t hirsch_banded_nodes, hirsch_unbanded_nodes;        /* nodes of edlib's recursion swept inside a band (lf_hband_level_kernel) / by the unbanded sweeps (queries with more
+                                                         * diagonals than sixteen wavefronts hold, targets with bytes other than ACGT) */
     uint64_t n_stale_first_windows;                     /* -a clasp, fine mode: candidate windows without seeds that had NO earlier chain of the same read to fall back on -- where the
                                                          * reference extends whatever chain its thread mapped last (src/Chain.cpp:68,92: scheduling-dependent) and this library none */
 } lf_stats_t;

@@ -56,7 +56,7 @@ class Stats(C.Structure):
                 ("ops_bytes", C.c_uint64), ("n_req_seeds", C.c_uint64), ("n_tie_requests", C.c_uint64), ("dp_block_steps", C.c_uint64),
                 ("ksw_bytes", C.c_uint64)] + \
                [(n, C.c_float) for n in ("ms_k_rsweep", "ms_k_tb", "ms_k_hirsch", "ms_k_bin")] + \
-               [(n, C.c_uint64) for n in ("hirsch_bytes", "n_host_waits", "n_chunks", "n_stale_first_windows")]
+               [(n, C.c_uint64) for n in ("hirsch_bytes", "n_host_waits", "n_chunks", "hirsch_max_rows", "hirsch_banded_nodes", "hirsch_unbanded_nodes", "n_stale_first_windows")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -66,20 +66,13 @@ extern "C" int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, con
     HIPCHK(hipMemcpyAsync(d_seeds, sorted_seeds, total * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_pen, pen.data(), pen.size() * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(e0, s));
-    /* windows are sorted by size; one launch per LDS size class so small windows keep the CU full */
-    static const uint32_t CAPS[5] = { 128, 512, 2048, LF_CHAIN_LDS_MAX, 0 };
-    size_t lo = 0;
-    for (int c = 0; c < 5; c++) {
-        size_t hi = lo;
-        while (hi < W.size() && (CAPS[c] == 0 || W[hi].n <= CAPS[c])) hi++;
-        if (hi > lo) {
-            const uint32_t cap = CAPS[c] ? CAPS[c] : 1;
-            const size_t smem = (size_t)cap * 22 + 16;
-            hipLaunchKernelGGL(lf_chain_n2_kernel, dim3((unsigned)(hi - lo)), dim3(64), smem, s, (const lf_chain_win *)d_w + lo, (int)(hi - lo),
-                               (const uint32_t *)d_seeds, (const double *)d_pen, (uint32_t)pen.size(), reward, p->chain_penalty, CAPS[c],
-                               (double *)d_dp, (int *)d_prev, (uint32_t *)d_idx, (uint32_t *)d_len, (float *)d_sc, 0u, 0xFFFFFFFFu);
-        }
-        lo = hi;
+    /* one launch per size class (lf_chain_kernel.h) */
+    {
+        uint32_t n_largest = 0; bool ws = false;
+        for (const lf_chain_win &x : W) { if (x.n > n_largest) n_largest = x.n; if (x.n > LF_CHAIN_LDS_MAX) ws = true; }
+        const int lrc = lf_chain_n2_launch_classes(s, (const lf_chain_win *)d_w, (int)W.size(), (const uint32_t *)d_seeds, (const double *)d_pen, (uint32_t)pen.size(), reward, p->chain_penalty,
+                                                   (double *)d_dp, (int *)d_prev, ws, (uint32_t *)d_idx, (uint32_t *)d_len, (float *)d_sc, n_largest);
+        if (lrc != LF_OK) return lrc;
     }
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipMemcpyAsync(chain_idx, d_idx, total * 4, hipMemcpyDeviceToHost, s));

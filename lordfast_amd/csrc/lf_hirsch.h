@@ -25,7 +25,7 @@ struct lf_hseg { uint64_t off; uint32_t cap, len; };
 struct lf_hctl {
     uint32_t n_roots, seg_used, n_hleaf, fail;
     uint32_t q_n[2][LF_HQ];              /* nodes queued for the next / current level, by queue (lf_hqueue_of) */
-    uint32_t n_trial, n_trial_failed, pad_[2];
+    uint32_t n_trial, n_trial_failed, max_root_n, pad_;
     uint32_t ratio_hist[2][16];          /* the roots above 4096 rows by 16 distance / rows, NW and SHW: what the next calls' trial bounds are chosen from */
     unsigned long long aux_used, hcar_used;
 };

@@ -697,6 +697,7 @@ __global__ void lf_hirsch_roots_kernel(const lf_aln_desc_t *__restrict__ d, cons
     const uint32_t idx = atomicAdd(&A.ctl->q_n[A.out_par][kbc], 1u);
     if (idx >= A.q_cap) { atomicExch(&A.ctl->fail, 4u); return; }
     if (k0 && k0 != x.n + x.m) atomicAdd(&A.ctl->n_trial, 1u);
+    atomicMax(&A.ctl->max_root_n, x.n);
     lf_hroot R; R.ops_off = ops_off[i]; R.desc = (uint32_t)i; R.n = x.n; R.m = x.m; R.seg_off = so; R.seg_cap = cap; R.count = 0;
     A.roots[r] = R;
     lf_hnode c;

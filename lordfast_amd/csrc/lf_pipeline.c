@@ -126,7 +126,8 @@ void phase_make_jobs(ctx_t *cx, int tid, int ri)
             if (cx->chain_len[rq] == 0 && last_req >= 0) rq = last_req;
             else if (cx->chain_len[rq] > 0) last_req = rq;
             else __atomic_fetch_add(&cx->st->n_stale_first_windows, 1, __ATOMIC_RELAXED);      /* no chain of this read to fall back on: the one corner that stays divergent */
-        }
+        } else if (cx->p->chain_alg == 1 && r->mode == 2 && !cx->host_vote && cx->chain_len[rq] == 0)
+            __atomic_fetch_add(&cx->st->n_stale_first_windows, 1, __ATOMIC_RELAXED);          /* the same corner in coarse mode: the read's ONE window has no seeds of its own contig */
         j->req = rq;
         j->read = ri; j->widx = w; j->isRev = r->wins[w].isReverse;
         j->chainLen = cx->chain_len[rq];
@@ -218,6 +219,14 @@ static void phase_sam_score(ctx_t *cx, int tid, int ri)
         cx->stage_sink[cx->stage_i0 + ri] = o;
     }
     if (r->mode == 3) samsort_sort(r->maps, r->nWins);                     /* std::sort(compareSam) :565 */
+}
+/* what the Hirschberg levels of the lane's alignment calls left in lane values 1 .. 3 (lf_align.hip): longest root, nodes by kind of sweep */
+static void take_hirsch_stats(int device, lf_stats_t *st)
+{
+    const uint64_t mx = lfg_lane_value(device, 1);
+    if (mx > st->hirsch_max_rows) st->hirsch_max_rows = mx;
+    st->hirsch_banded_nodes += lfg_lane_value(device, 2); st->hirsch_unbanded_nodes += lfg_lane_value(device, 3);
+    lfg_lane_set_value(device, 1, 0); lfg_lane_set_value(device, 2, 0); lfg_lane_set_value(device, 3, 0);
 }
 static inline void tmark(ctx_t *cx, const char *label)
 {
@@ -413,6 +422,7 @@ extend:
             if (W.n_desc) { float bd[4]; lfg_edlib_breakdown(bd); st->ms_k_rsweep += bd[0]; st->ms_k_tb += bd[1]; st->ms_k_hirsch += bd[2]; st->ms_k_bin += bd[3]; }
             st->ext_bytes += W.ext_bytes; st->dp_block_steps += W.block_steps;
             st->hirsch_bytes += 2 * W.hc.sum_n + W.hc.sum_m + (W.hc.sum_m + 3) / 4;
+            take_hirsch_stats(cx->ix->device, st);
             /* (the pool: one sam_t per job, 100 k of them per step) */
             cx->open = (int *)malloc(((size_t)nj + 1) * sizeof(int));
             if (!cx->open) { free(owner); return LF_ERR_NOMEM; }
@@ -536,6 +546,7 @@ extend:
             for (int i = 0; i < nd; i++) if (desc[i].n && desc[i].m && 20ull * ((desc[i].n + 63) / 64) * desc[i].m + 8ull * desc[i].m >= 1024 * 1024)      /* edlib's traceback switch (lib/edlib/edlib.cpp:1117-1119) */
                 st->hirsch_bytes += 2ull * desc[i].n + desc[i].m + (desc[i].m + 3) / 4;
             { float bd[4]; lfg_edlib_breakdown(bd); st->ms_k_rsweep += bd[0]; st->ms_k_tb += bd[1]; st->ms_k_hirsch += bd[2]; st->ms_k_bin += bd[3]; }
+            take_hirsch_stats(cx->ix->device, st);
         }
         if (nk) {
             uint64_t qn = 0, tn = 0;

@@ -207,6 +207,8 @@ static void merge_stats(lf_stats_t *d, const lf_stats_t *a)
     d->ksw_bytes += a->ksw_bytes;
     d->ms_k_rsweep += a->ms_k_rsweep; d->ms_k_tb += a->ms_k_tb; d->ms_k_hirsch += a->ms_k_hirsch; d->ms_k_bin += a->ms_k_bin;
     d->hirsch_bytes += a->hirsch_bytes; d->n_host_waits += a->n_host_waits; d->n_chunks += a->n_chunks; d->n_stale_first_windows += a->n_stale_first_windows;
+    if (a->hirsch_max_rows > d->hirsch_max_rows) d->hirsch_max_rows = a->hirsch_max_rows;
+    d->hirsch_banded_nodes += a->hirsch_banded_nodes; d->hirsch_unbanded_nodes += a->hirsch_unbanded_nodes;
 }
 
 /* base offset of a chunk's text = the sizes of all chunks of earlier reads.  block == 0: returns 0 when one of them has not

@@ -877,17 +877,9 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
             HIPCHK(hipStreamWaitEvent(s, ev[c], 0));
         }
     } else {
-        static const uint32_t CAPS[5] = { 128, 512, 2048, LF_CHAIN_LDS_MAX, 0 };
-        uint32_t lo = 0;                                     /* one launch per LDS size class; a block outside its class exits */
-        for (int c = 0; c < 5; c++) {
-            const uint32_t hi = CAPS[c] ? CAPS[c] : 0xFFFFFFFFu;
-            if (c == 4 && WS == 0) break;
-            const uint32_t cap = CAPS[c] ? CAPS[c] : 1;
-            const size_t smem = (size_t)cap * 22 + 16;
-            hipLaunchKernelGGL(lf_chain_n2_kernel, dim3((unsigned)n_req), dim3(64), smem, s, (const lf_chain_win *)d_wins, (int)n_req,
-                               (const uint32_t *)d_sorted, d_pen, pen_n, reward, p->chain_penalty, CAPS[c], d_dp, d_prev, d_cidx, d_clen, d_cscore, lo, hi);
-            lo = hi + 1;
-        }
+        const int lrc = lf_chain_n2_launch_classes(s, (const lf_chain_win *)d_wins, (int)n_req, (const uint32_t *)d_sorted, d_pen, pen_n, reward, p->chain_penalty,
+                                                   d_dp, d_prev, WS != 0, d_cidx, d_clen, d_cscore, max_n);
+        if (lrc != LF_OK) return lrc;
     }
     { lf_scan_u32 f; f.p = d_clen; const int src = lf_scan_excl(dv, 1, s, f, d_coff, (size_t)n_req); if (src != LF_OK) return src; }
     /* a chain is a subset of its request's seeds: S bounds the chains' total, so the gather needs no readback of it; and the chains stay in HBM --

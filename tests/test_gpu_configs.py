@@ -143,3 +143,122 @@ def test_c4_segdup_workload_clasp_n30(segdup_genome, oracle_lib):
     flags = [int(l.split(b"\t")[1]) for l in sam.split(b"\n") if l]
     assert sum(1 for f in flags if f & 256) > 100
     st, _ = _run_big(fa, reads[:300], oracle_lib, max_map=30)                        # the same reads through dp-n2
+
+
+# ---- BASELINE config C5 as it is benchmarked (bench.py --config c5: "vs CHM13 T2T"): a T2T-like genome -- centromeric satellite arrays (171 bp monomers in
+# ---- higher-order repeats, thousands of near-identical copies) and simple-sequence arrays on top of the GRCh38-like repeats.  A read out of an array has more
+# ---- hits per sample than MAX_REF_HITS; the few seeds that survive chain into partial candidates whose 40 - 50 k-row tails edlib aligns as a whole: Hirschberg
+# ---- roots above 32 768 rows, satellite windows with thousands of seeds in the chainer, clip tests (ksw) on the tails.
+@pytest.fixture(scope="module")
+def t2t_like(tmp_path_factory):
+    import lordfast_amd as la
+    d = tmp_path_factory.mktemp("t2tlike")
+    g = synth.make_genome(64_000_000, 4, seed=23, n_families=100, profile="t2tlike")
+    fa = la.index_build(g, os.path.join(str(d), "t2t_like.fa"))
+    return fa, g
+
+
+def test_c5_shape_on_a_t2tlike_genome(t2t_like, oracle_lib):
+    import numpy as np
+    fa, g = t2t_like
+    total = sum(len(s) for _, s in g)
+    reads = synth.make_reads(g, 4, 50000, 0.10, seed=5, mix=(0.40, 0.25, 0.35))
+    rng = np.random.default_rng(17)
+    for k in range(6):                                                              # reads out of (k < 4) and across the edge of (k >= 4) the satellite arrays
+        ci = k % len(g)
+        s = g[ci][1]
+        arr_len = int(min(len(s) * 0.5, max(20000, total * 0.06 / len(g))))       # (synth._add_satellites)
+        p0 = (len(s) - arr_len) // 2
+        start = p0 + arr_len // 5 + 7919 * k if k < 4 else p0 - 22000 - 3000 * k
+        frag = s[start:start + 48000 + 1000 * k]
+        if k % 2:
+            frag = synth.revcomp(frag)
+        reads.append((f"sat{k}", synth.mutate(frag, 0.10, rng).tobytes()))
+    st, sam = _run_big(fa, reads, oracle_lib, min_anchor_len=17, sampling_count=2000)
+    assert st["hirsch_max_rows"] > 32768, st["hirsch_max_rows"]                    # a tail longer than one wavefront's 64 x 8 register-resident blocks
+    assert st["hirsch_banded_nodes"] > 0 and st["n_ksw_problems"] >= 1, (st["hirsch_banded_nodes"], st["hirsch_unbanded_nodes"], st["n_ksw_problems"])
+
+
+# ---- the one corner of the path where the reference's output depends on what its THREAD mapped before: a candidate window whose midpoint lies in the
+# ---- neighbouring contig keeps none of its seeds (alignWin selects inside the contig of the window's midpoint, src/LordFAST.cpp:1000-1003,
+# ---- src/BWT.cpp:653-660), chain_seeds_clasp called with zero fragments sets the score to -1 and leaves the PREVIOUS call's chain in place
+# ---- (src/Chain.cpp:62-92), and alignWin extends it.  Inside a read "the previous call" is the read's previous window: restated (oracle and GPU).  For a
+# ---- read's first such window it is the thread's previous READ -- scheduling under --threads > 1 -- and this library starts every read without a chain:
+# ---- counted (lf_stats_t.n_stale_first_windows), not restated.  The reads below hit exactly that: the last L - r bases of a contig, read
+# ---- length L chosen so that the window [i L, (i + 2) L) that holds all hits has its midpoint (i + 1) L - 1 just behind the contig's end.  dp-n2 has no such
+# ---- state (zero seeds = no chain): there every record must equal the reference's.
+def _border_reads(g, rng):
+    import numpy as np
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads, B = [], 0
+    for ci in range(len(g) - 1):
+        B += len(g[ci][1])                                                          # first coordinate of the next contig
+        pick = None
+        for L in range(9000, 16000):
+            r = (-B) % L                                                            # (i + 1) L = B + r
+            if 1 <= r <= 120:
+                pick = (L, r); break
+        if pick is None:
+            continue
+        L, r = pick
+        span = L - r - 250                                                          # reference bases under the read: all hits fall into cell i = [B + r - L, B + r)
+        frag = g[ci][1][len(g[ci][1]) - span:].copy()
+        sub = rng.random(span) < 0.05
+        frag[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+        ins_at = np.sort(rng.integers(0, span, L - span))                            # insertions only: the read is L long, its footprint shorter
+        read = np.insert(frag, ins_at, acgt[rng.integers(0, 4, L - span)])
+        assert len(read) == L
+        if ci % 2:
+            read = synth.revcomp(read)
+        reads.append((f"border{ci}", read.tobytes()))
+    return reads
+
+
+def test_window_without_seeds_at_a_contig_border(segdup_genome, oracle_lib):
+    import numpy as np
+    import lordfast_amd as la
+    from conftest import have_ref
+    fa, g, _ = segdup_genome
+    rng = np.random.default_rng(99)
+    border = _border_reads(g, rng)
+    assert len(border) >= 8
+    plain = synth.make_reads(g, len(border), 6000, 0.12, seed=77)                    # every border read follows a SHORTER ordinary read
+    reads = [x for pair in zip(plain, border) for x in pair]
+    names = [r[0].encode() for r in reads]
+    seqs = [r[1] for r in reads]
+    is_border = [n.startswith(b"border") for n in names]
+    for alg in (0, 1):
+        kw = dict(chain_alg=alg)
+        h = la.LordFast(fa, device=0)
+        sam, st = h.map_batch(names, seqs, params=la.default_params(**kw))
+        h.close()
+        orc = oracle_lib.Oracle(fa)
+        exp = orc.map_batch(names, seqs, params=oracle_lib.default_params(threads=8, **kw))
+        orc.close()
+        assert sam == exp, first_diff(sam, exp)                                      # GPU == restatement, both algorithms, every read
+        recs = {}
+        for line in sam.split(b"\n"):
+            if line:
+                recs.setdefault(line.split(b"\t")[0], []).append(line)
+        if alg == 1:
+            assert st["n_stale_first_windows"] == len(border), (st["n_stale_first_windows"], len(border))
+        else:
+            assert st["n_stale_first_windows"] == 0
+            for n in names:
+                if n.startswith(b"border"):
+                    assert int(recs[n][0].split(b"\t")[1]) & 4, recs[n][0][:200]      # no seeds in the window's contig: no chain, unmapped -- in the reference too (below)
+        if have_ref() and os.path.exists(fa + ".cache"):
+            ref = oracle_lib.Ref()
+            ref.load(fa)
+            ref.set_params(oracle_lib.default_params(threads=1, **kw), "test")
+            rsam, _ = ref.map_mem(names, seqs)
+            rrecs = {}
+            for line in rsam.split(b"\n"):
+                if line:
+                    rrecs.setdefault(line.split(b"\t")[0], []).append(line)
+            for n, b in zip(names, is_border):
+                if alg == 0 or not b:
+                    assert recs[n] == rrecs[n], (alg, n, recs[n][0][:150], rrecs[n][0][:150])
+                else:
+                    # documented divergence: the reference extends the chain of the read in front (flag / position of THAT read's locus); here: no chain
+                    assert int(recs[n][0].split(b"\t")[1]) & 4

@@ -257,6 +257,19 @@ def test_chain_fuzz_vs_oracle(oracle_lib):
             t = rng.integers(50000, 90000, size=n).astype(np.uint32)
         ln = rng.integers(14, 25, size=n).astype(np.uint32)
         wins.append(np.stack([t, q, ln], axis=1) if n else np.zeros((0, 3), dtype=np.uint32))
+    # large windows (the workgroup kernel, lf_chain_kernel.h: 513 .. 16 384 seeds; above: the one-wavefront kernel on its HBM workspace): satellite-array shapes --
+    # few distinct query positions, a handful of diagonals, equal lengths: ties in dp everywhere, the reference's `first j from the top wins` decides
+    for n, nq, kind in ((600, 40, 0), (2048, 300, 1), (2049, 2049, 2), (4096, 500, 0), (4097, 64, 1), (8000, 900, 0), (8000, 8000, 2), (12000, 200, 1), (16384, 3000, 0), (17000, 1500, 1)):
+        qpool = np.sort(rng.integers(0, 60000, size=nq))
+        q = np.sort(qpool[rng.integers(0, nq, size=n)]).astype(np.uint32)
+        if kind == 0:
+            t = (q.astype(np.int64) + rng.choice([100000, 100171, 100342, 100513], size=n)).astype(np.uint32)       # a few diagonals one monomer apart
+        elif kind == 1:
+            t = (q.astype(np.int64) * 0 + rng.integers(100000, 100000 + 171 * 40, size=n)).astype(np.uint32)       # any query position anywhere in the array
+        else:
+            t = (q.astype(np.int64) + rng.integers(-3, 4, size=n) + 100000).astype(np.uint32)                      # one noisy diagonal
+        ln = np.full(n, 17, dtype=np.uint32) if kind != 2 else rng.integers(14, 25, size=n).astype(np.uint32)
+        wins.append(np.stack([t, q, ln], axis=1))
     for kw in (dict(), dict(chain_reward=5.0, chain_penalty=8.0, min_anchor_len=17)):
         res = la.chain_n2_batch(wins, la.default_params(**kw))
         for i, (w, r) in enumerate(zip(wins, res)):
