@@ -593,6 +593,26 @@ def main():
                 log(f"records of {len(head_host)} sampled reads taken out of the timed output in {time.time() - t_x:.1f}s")
     elif args.mode == "inproc":
         elapsed_host, cpu_s_host, agg_host, sam_host = elapsed_nx, cpu_s_hbm, agg_hbm, sam_hbm
+    # ---- 2b. the same host boundary with a MAPPER-READY batch (lf_batch_create / lf_map_batch_from): lengths and the bit planes the batch crosses the link as
+    #          are made once, when the batch is made -- the analogue of the reference's readChunk output, which its mapping timer excludes
+    #          (src/Reads.cpp:84-104, src/baseFAST.cpp:59-75).  `value` stays the region above (the caller hands over plain strings every step). ----
+    elapsed_pre = cpu_s_pre = snap_pre = t_create = None
+    if args.mode != "inproc" and not args.no_host_region and world == 1 and n_dev == 1 and hasattr(la, "ReadBatch"):
+        t_c = time.perf_counter()
+        pre_batch = la.ReadBatch(names, seqs, None, min_read_len=params.min_read_len, seq_lens=seq_lens)
+        t_create = time.perf_counter() - t_c
+
+        def step_pre(j=0):
+            t_call = time.perf_counter()
+            ho = host_outs[j]
+            ln, st = lf.map_batch_from(pre_batch, ho.data_ptr(), ho.numel(), params=params)
+            st["ms_python_call"] = (time.perf_counter() - t_call) * 1e3
+            return _Sam(ho, ln), st
+        run_steps(step_pre, max(1, args.warmup) * D)
+        elapsed_pre, cpu_s_pre, _agg_pre, sam_pre = timed(step_pre, args.steps)
+        if rank == 0 and not args.no_exclusive:
+            snap_pre = digest(sam_pre)
+        pre_batch.close()
     primary_is_host = world * n_dev == 1 and elapsed_host is not None or args.mode == "inproc"
     agg, cpu_s, sam = (agg_host, cpu_s_host, sam_host) if primary_is_host else (agg_hbm, cpu_s_hbm, sam_hbm)
 
@@ -771,6 +791,14 @@ def main():
             out["host_cpu_seconds_per_step_host_boundary"] = cpu_s_host / K
             out["host_boundary_bytes_per_step"] = {"h2d_bases": bases, "d2h_sam_text": int(len(sam_host)) if sam_host is not None else None,
                                                    "sam_egress": "SEQ / QUAL columns filled on the host (lf_sam.hip HOLES mode)" if not os.environ.get("LF_SAM_FULL") else "whole lines from the device"}
+        if elapsed_pre is not None:
+            out["value_prepacked_batch"] = n_total * K / elapsed_pre       # host boundary with a mapper-ready batch (lf_batch_create once, lf_map_batch_from per step)
+            out["ms_per_step_prepacked_batch"] = elapsed_pre / K * 1e3
+            out["host_cpu_seconds_per_step_prepacked_batch"] = cpu_s_pre / K
+            out["prepacked_batch"] = {"io": "lf_batch_create (lengths + bit planes of the batch in pinned host memory: OUTSIDE the step, made once -- the reference's readChunk is "
+                                            "outside its mapping timer the same way) -> lf_map_batch_from per step: the planes' bit ranges cross the link, SAM records come back "
+                                            "into the caller's pinned buffer, SEQ / QUAL filled from the caller's strings",
+                                      "create_seconds": t_create}
         if elapsed_weak is not None:
             out["value_weak_hbm_resident"] = args.reads * world * K / elapsed_weak
             out["ms_per_step_weak_hbm_resident"] = elapsed_weak / K * 1e3
@@ -783,7 +811,7 @@ def main():
                 out["per_read"]["chain_requests_on_dup_reads"] = dup_probe
         # ---- parity: the records of the TIMED steps ----
         if snap_host is not None or snap_hbm is not None or snap_excl is not None:
-            snaps = {k: v for k, v in (("host_boundary_timed_steps", snap_host), ("hbm_resident_timed_steps", snap_hbm), ("exclusive_pass", snap_excl)) if v is not None}
+            snaps = {k: v for k, v in (("host_boundary_timed_steps", snap_host), ("prepacked_batch_timed_steps", snap_pre), ("hbm_resident_timed_steps", snap_hbm), ("exclusive_pass", snap_excl)) if v is not None}
             out["sam_digests"] = {k: {"xxh3_128": v[0], "bytes": v[1]} for k, v in snaps.items()}
             out["timed_output_equals_exclusive_pass_output"] = len({v for v in snaps.values()}) == 1 if len(snaps) > 1 else None
         if not args.no_cpu_baseline and world == 1 and (head_host is not None or sam is not None):

@@ -4,4 +4,4 @@ The product is lordfast_amd/liblfgpu.so (C ABI in include/lordfast_amd.h, HIP ke
 lordfast_amd/csrc).  This package is only the thin ctypes binding the tests and bench.py use.
 """
 from .api import (LordFast, Params, default_params, lib, lib_path, build_library, device_count,  # noqa: F401
-                  LfError, index_build, edlib_batch, chain_n2_batch, chain_clasp_batch, ksw_extend2_batch, read_file, map_batch_multi)
+                  LfError, index_build, edlib_batch, chain_n2_batch, chain_clasp_batch, ksw_extend2_batch, read_file, map_batch_multi, ReadBatch)

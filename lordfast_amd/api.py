@@ -254,6 +254,40 @@ class SamBuffer:
         self.free()
 
 
+class ReadBatch:
+    """lf_batch_create: the reads as the caller has them (the Python byte strings are kept alive by this object) plus what every mapping call would
+    otherwise make per call -- lengths and, for reads of at least min_read_len bases, the bit planes the batch crosses the host link as."""
+
+    def __init__(self, names, seqs, quals=None, min_read_len: int = 1000, threads: int = 0, seq_lens=None):
+        L = lib()
+        self.names, self.seqs, self.quals = list(names), list(seqs), (list(quals) if quals is not None else None)
+        self._na, self._sa = _cstr_array(self.names), _cstr_array(self.seqs)
+        self._qa = _cstr_array(self.quals) if self.quals is not None else None
+        sl = np.ascontiguousarray(seq_lens, dtype=np.uint32) if seq_lens is not None else None
+        L.lf_batch_create.restype = C.c_void_p
+        L.lf_batch_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        self.h = L.lf_batch_create(len(self.names), self._na, self._sa, self._qa, sl.ctypes.data if sl is not None else None, min_read_len, threads)
+        if not self.h:
+            raise LfError("lf_batch_create: " + L.lf_last_error().decode(errors="replace"))
+        self.L = L
+
+    def __len__(self):
+        self.L.lf_batch_size.argtypes = [C.c_void_p]
+        return int(self.L.lf_batch_size(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lf_batch_free.argtypes = [C.c_void_p]
+            self.L.lf_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class LordFast:
     """An FM-index resident in one GPU's HBM + the batch entry points."""
 
@@ -340,6 +374,16 @@ class LordFast:
             return ln.value, st.as_dict()
         _check(self.L.lf_map_batch_into(self.h, C.byref(p), len(names), na, sa, q, C.c_void_p(out_ptr), out_cap,
                                         C.byref(ln), C.byref(st)), "lf_map_batch_into")
+        return ln.value, st.as_dict()
+
+    def map_batch_from(self, batch: "ReadBatch", out_ptr: int, out_cap: int, params: Params | None = None):
+        """lf_map_batch_from: a mapper-ready batch (ReadBatch: lengths and bit planes made when it was created) -> SAM text in a caller-owned
+        buffer.  -> (length, stats)"""
+        p = params or default_params()
+        ln = C.c_size_t()
+        st = Stats()
+        self.L.lf_map_batch_from.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Stats)]
+        _check(self.L.lf_map_batch_from(self.h, C.byref(p), batch.h, C.c_void_p(out_ptr), out_cap, C.byref(ln), C.byref(st)), "lf_map_batch_from")
         return ln.value, st.as_dict()
 
     def map_batch_dev(self, name_arr, d_seqs: int, seq_off, seq_lens, out_ptr: int, out_cap: int, out_is_device: bool = True,

@@ -47,7 +47,12 @@ typedef struct {        /* raw device results of the seed stage, copied to host 
 /* want_hits == 0: the hits stay in HBM for lfg_vote_chain (out gets n_hits, read_off and the counters only) */
 /* the read batch as three bit planes made on the host (bit i of word i / 64 of plane x describes base i: code low bit, code high
  * bit, "is one of ACGT", upper case; planes[x * qw + w]) plus the bytes that are NOT upper-case ACGT: 3 / 8 of the bytes on the link */
-typedef struct { const uint64_t *planes; uint64_t qw; const uint64_t *exc_pos; const uint8_t *exc_byte; uint64_t n_exc; } lf_packed_src_t;
+typedef struct {
+    const uint64_t *planes; uint64_t qw; const uint64_t *exc_pos; const uint8_t *exc_byte; uint64_t n_exc;
+    /* a chunk of a PREPACKED batch (lf_batch.h): its bases are bits [64 word0 + shift, ... + n_bases) of planes whose stride is src_qw words; the exception
+     * positions count from exc_base.  src_qw == 0: the planes are this chunk's own (stride qw, first base at bit 0). */
+    uint64_t src_qw, word0, exc_base; uint32_t shift;
+} lf_packed_src_t;
 int  lfg_seed_packed(const struct lf_index *ix, const lf_params_t *p, int n_reads, const lf_packed_src_t *pk, const uint64_t *off, int want_hits, lfg_hits_t *out);
 int  lfg_seed(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads,
               const uint64_t *off, int want_hits, lfg_hits_t *out);

@@ -252,6 +252,7 @@ typedef struct ctx {
     const char *const *len_seqs; uint32_t *len_out; volatile int len_bad;
     int *seed_map; char *cat; uint64_t *cat_off;
     uint64_t *pk_planes, pk_qw, *pk_xpos, pk_xcap, pk_xn; uint8_t *pk_xbyte; volatile int pk_overflow;      /* packed upload (phase_pack) */
+    const struct lf_prepack *pre; int pre_i0;        /* the batch is prepacked (lf_batch.h): its planes, and the chunk's first read in the batch */
     const unsigned char *d_seqs, *d_quals;      /* lf_map_batch_dev: the caller's device blobs (NULL: host strings) */
     int32_t **stage_sink; int stage_i0;          /* lf_map_stages_batch: per read (batch index stage_i0 + ri) its decision, windows and alignWin results */
     /* HOLES mode (lf_sam.hip): the SEQ / QUAL column of every line is filled on the host from the caller's strings */

@@ -22,6 +22,7 @@
  * from the device: diagnostic cross-checks for the tests, never selected automatically and not selectable by environment.
  */
 #include "lf_pipe.h"
+#include "lf_batch.h"
 
 void top_push(win_t *l, int *n, int maxWin, uint32_t i, uint32_t L, float score, int isRev, int req)
 {   /* src/LordFAST.cpp:634-654 */
@@ -288,7 +289,24 @@ int map_chunk(ctx_t *cx)
              * goes up as bytes.  LF_UPLOAD_PACKED=0: always bytes. */
             const int packed_on = !(getenv("LF_UPLOAD_PACKED") && atoi(getenv("LF_UPLOAD_PACKED")) == 0);
             int packed = 0;
-            if (packed_on && !cx->host_vote) {
+            if (packed_on && !cx->host_vote && cx->pre && cx->pre->min_read_len == cx->p->min_read_len) {
+                /* the batch was packed when it was made (lf_batch.h): this chunk's planes are a bit range of the batch's -- nothing to do on the host but
+                 * to say where it is; the device shifts it into place (lf_seed.hip) */
+                const lf_prepack_t *P = cx->pre;
+                const uint64_t o0 = P->boff[cx->pre_i0];
+                lf_packed_src_t pk; memset(&pk, 0, sizeof pk);
+                pk.planes = P->planes; pk.qw = (bases + 63) / 64 + 2; pk.src_qw = P->QW; pk.word0 = o0 >> 6; pk.shift = (uint32_t)(o0 & 63); pk.exc_base = o0;
+                uint64_t e0 = 0, e1 = P->n_exc;
+                { uint64_t lo_ = 0, hi_ = P->n_exc; while (lo_ < hi_) { const uint64_t md = (lo_ + hi_) >> 1; if (P->exc_pos[md] < o0) lo_ = md + 1; else hi_ = md; } e0 = lo_; }
+                { uint64_t lo_ = e0, hi_ = P->n_exc; while (lo_ < hi_) { const uint64_t md = (lo_ + hi_) >> 1; if (P->exc_pos[md] < o0 + bases) lo_ = md + 1; else hi_ = md; } e1 = lo_; }
+                pk.exc_pos = P->exc_pos + e0; pk.exc_byte = P->exc_byte + e0; pk.n_exc = e1 - e0;
+                if (P->boff[cx->pre_i0 + n] - o0 == bases) {
+                    tmark(cx, "prepacked");
+                    rc = lfg_seed_packed(cx->ix, cx->p, m, &pk, off, cx->host_vote, &hits);
+                    packed = 1;
+                }
+            }
+            if (!packed && packed_on && !cx->host_vote) {
                 const uint64_t qw = (bases + 63) / 64 + 2;                  /* lf_plane_words (lf_rsweep.h) */
                 const uint64_t xcap = bases / 64 + 1024;
                 uint64_t *xpos = (uint64_t *)lfg_pin_slot(LF_PS_EXC_POS, xcap * 8); uint8_t *xbyte = (uint8_t *)lfg_pin_slot(LF_PS_EXC_BYTE, xcap);

@@ -21,6 +21,7 @@
 #include <fcntl.h>
 #include <time.h>
 #include "lf_internal.h"
+#include "lf_batch.h"
 
 /* How a file is read:
  *   window parser   plain FASTA / FASTQ, BGZF and gzip files whose text starts with '>' or '@': a WINDOW of text (a slice of the
@@ -268,18 +269,12 @@ static void blob_put(char *p, size_t cap)
     free(drop); free(p);
 }
 
-struct lf_read_batch {
-    int n; uint64_t bases;
-    const char **names, **seqs, **quals; uint32_t *lens; int rcap;
-    char **blobs; size_t *blob_caps; int nblobs, capblobs;              /* window parser: one blob per piece */
-    char *blob; size_t blob_n, blob_cap;
-    size_t *off; int cap;                          /* 3 offsets per record into blob */
-};
 void lf_read_batch_free(lf_read_batch_t *b)
 {
     if (!b) return;
     for (int t = 0; t < b->nblobs; t++) blob_put(b->blobs[t], b->blob_caps[t]);
     free(b->blobs); free(b->blob_caps);
+    lf_prepack_free(b->pre);
     free(b->names); free(b->seqs); free(b->quals); free(b->lens); free(b->blob); free(b->off); free(b);
 }
 int lf_read_batch_size(const lf_read_batch_t *b) { return b ? b->n : 0; }

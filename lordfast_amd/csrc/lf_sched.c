@@ -2,6 +2,7 @@
  * and the place of their SAM text in the output, and the lf_map_batch* entry points (the reference's pthread pool takes reads
  * from a shared cursor the same way, src/LordFAST.cpp:295-303).  What a chunk goes through is lf_pipeline.c. */
 #include "lf_pipe.h"
+#include "lf_batch.h"
 #include <errno.h>
 
 volatile unsigned g_crosscheck = 0;
@@ -178,6 +179,7 @@ typedef struct {
     const lf_params_t *p;
     const char *const *names, *const *seqs, *const *quals; const uint32_t *lens;
     const unsigned char *d_seqs, *d_quals; const uint64_t *src_off; int dev_out;     /* lf_map_batch_dev: bases / qualities / SAM text in HBM */
+    const lf_prepack_t *pre;                    /* lf_map_batch_from: the batch's planes were made when it was created (lf_batch.h) */
     int32_t **stage_sink;                       /* lf_map_stages_batch */
     int slots;                                  /* per-worker scratch slots = pool workers + lane ids */
     int lane_cap;                               /* lane ids this process may have in use while this batch takes one (lane_acquire) */
@@ -322,6 +324,7 @@ static void *lane_main(void *arg_)
         cx.holes = B->holes && cx.dev_sam;
         cx.sam_parity = parity;
         cx.d_seqs = B->d_seqs; cx.d_quals = B->d_quals; cx.stage_sink = B->stage_sink; cx.stage_i0 = C->i0;
+        cx.pre = B->pre; cx.pre_i0 = C->i0;
         cx.n_reads = C->i1 - C->i0;
         cx.reads = (rd_t *)calloc((size_t)cx.n_reads, sizeof(rd_t));
         uint64_t chunk_bases = 0;
@@ -484,6 +487,7 @@ int lf_cut_chunks_by_bases(const uint32_t *lens, int n, int n_lanes, double ramp
 }
 
 typedef struct { const void *d_seqs, *d_quals; const uint64_t *seq_off; int dev_out; int32_t **stage_sink; } devio_t;
+static __thread const lf_prepack_t *t_pre;      /* set by lf_map_batch_from around its call of map_batch_core */
 static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_params_t *p, int n, const char *const *names,
                           const char *const *seqs, const char *const *quals, const uint32_t *seq_lens, char *ext_buf, size_t ext_cap,
                           char **sam, size_t *sam_len, lf_stats_t *stats, const devio_t *dio)
@@ -560,6 +564,7 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     B.host_cigar = (g_crosscheck & LF_XC_HOST_CIGAR) != 0;
     B.host_vote = (g_crosscheck & LF_XC_HOST_VOTE) != 0;          /* diagnostic cross-check only; the device stage is the product path */
     B.ixs = ixs; B.n_ix = n_ix; B.p = p; B.names = names; B.seqs = seqs; B.quals = quals; B.slots = nw + LF_MAX_LANES; B.rc = LF_OK; B.lane_cap = lane_cap;
+    B.pre = t_pre; t_pre = NULL;
     if (dio && dio->stage_sink) B.stage_sink = dio->stage_sink;
     else if (dio) { B.d_seqs = (const unsigned char *)dio->d_seqs; B.d_quals = (const unsigned char *)dio->d_quals; B.src_off = dio->seq_off; B.dev_out = dio->dev_out; }
     pthread_mutex_init(&B.mu, NULL); pthread_cond_init(&B.cv, NULL); pthread_rwlock_init(&B.grow, NULL);
@@ -581,7 +586,7 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
             /* a wrong length would make the device read past a string: the terminator of every read is checked (best effort: the
              * check itself trusts lens[i] to stay inside the caller's allocation) */
             int bad = -1;
-            if (!dio || dio->stage_sink) { c0.len_bad = -1; parallel_for(&c0, n, phase_checklen); bad = c0.len_bad; }      /* one cold cache line per read: all workers */
+            if ((!dio || dio->stage_sink) && !B.pre) { c0.len_bad = -1; parallel_for(&c0, n, phase_checklen); bad = c0.len_bad; }      /* one cold cache line per read: all workers (a prepacked batch measured its reads itself) */
             if (bad >= 0) { const int i = bad;
                 lf_set_error("lf_map_batch_into_lens: seq_lens[%d] = %u is not the length of seqs[%d]", i, lens[i], i);
                 free(lens); pthread_rwlock_destroy(&B.grow); pthread_mutex_destroy(&B.mu); pthread_cond_destroy(&B.cv);
@@ -723,6 +728,105 @@ int lf_map_batch_into_lens(const lf_index_t *ix, const lf_params_t *p, int n, co
     if (!out || out_cap < 2) { lf_set_error("lf_map_batch_into_lens: no output buffer"); return LF_ERR_ARG; }
     if (!seq_lens && n > 0) { lf_set_error("lf_map_batch_into_lens: no lengths"); return LF_ERR_ARG; }
     return map_batch_core(&ix, 1, p, n, names, seqs, quals, seq_lens, out, out_cap, NULL, sam_len, stats, NULL);
+}
+
+/* ---- the mapper-ready batch (lf_batch.h, include/lordfast_amd.h) ---- */
+typedef struct { struct lf_read_batch *b; lf_prepack_t *P; int n; int nthr; uint64_t xcap; volatile int overflow; } ppk_t;
+static void *prepack_main(void *arg)
+{
+    void **a = (void **)arg; ppk_t *K = (ppk_t *)a[0]; const int t = (int)(intptr_t)a[1];
+    /* reads in contiguous shares by index: neighbouring threads meet in at most one plane word per share boundary (lf_pack_read ORs its first and last word in atomically) */
+    const int i0 = (int)((int64_t)K->n * t / K->nthr), i1 = (int)((int64_t)K->n * (t + 1) / K->nthr);
+    for (int i = i0; i < i1; i++) {
+        if ((int)K->b->lens[i] < K->P->min_read_len) continue;
+        if (!lf_pack_read(K->P->planes, K->P->QW, K->P->boff[i], K->b->seqs[i], K->b->lens[i], K->P->exc_pos, K->P->exc_byte, K->xcap, &K->P->n_exc)) K->overflow = 1;
+    }
+    return NULL;
+}
+static int exc_cmp(const void *x, const void *y) { const uint64_t a = ((const uint64_t *)x)[0], b = ((const uint64_t *)y)[0]; return a < b ? -1 : a > b; }
+void lf_prepack_free(lf_prepack_t *P)
+{
+    if (!P) return;
+    if (P->pinned) lfg_host_free(P->planes); else free(P->planes);
+    free(P->boff); free(P->exc_pos); free(P->exc_byte); free(P);
+}
+int lf_read_batch_prepack(struct lf_read_batch *b, int min_read_len, int threads)
+{
+    if (!b || min_read_len < 1) { lf_set_error("lf_read_batch_prepack: bad argument"); return LF_ERR_ARG; }
+    if (b->pre && b->pre->min_read_len == min_read_len) return LF_OK;
+    lf_prepack_free(b->pre); b->pre = NULL;
+    lf_prepack_t *P = (lf_prepack_t *)calloc(1, sizeof *P);
+    if (!P) return LF_ERR_NOMEM;
+    P->min_read_len = min_read_len;
+    P->boff = (uint64_t *)malloc(((size_t)b->n + 1) * 8);
+    if (!P->boff) { lf_prepack_free(P); return LF_ERR_NOMEM; }
+    uint64_t o = 0;
+    for (int i = 0; i < b->n; i++) { P->boff[i] = o; if ((int)b->lens[i] >= min_read_len) o += b->lens[i]; }
+    P->boff[b->n] = o; P->bases = o;
+    P->QW = (o + 63) / 64 + 8;
+    const size_t bytes = 3 * P->QW * 8;
+    P->planes = lfg_device_count() > 0 ? (uint64_t *)lfg_host_alloc(bytes) : NULL;
+    P->pinned = P->planes != NULL;
+    if (!P->planes) P->planes = (uint64_t *)malloc(bytes);
+    if (!P->planes) { lf_prepack_free(P); return LF_ERR_NOMEM; }
+    memset(P->planes, 0, bytes);
+    uint64_t xcap = o / 64 + 4096;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        P->exc_pos = (uint64_t *)malloc(xcap * 8); P->exc_byte = (uint8_t *)malloc(xcap); P->n_exc = 0;
+        if (!P->exc_pos || !P->exc_byte) { lf_prepack_free(P); return LF_ERR_NOMEM; }
+        int nthr = threads; long online = sysconf(_SC_NPROCESSORS_ONLN);
+        if (nthr <= 0 || nthr > online) nthr = (int)online;
+        if (nthr > 64) nthr = 64; if (nthr > b->n) nthr = b->n > 0 ? b->n : 1;
+        ppk_t K; K.b = b; K.P = P; K.n = b->n; K.nthr = nthr; K.xcap = xcap; K.overflow = 0;
+        pthread_t th[64]; void *args[64][2]; int started[64];
+        for (int t = 0; t < nthr; t++) { args[t][0] = &K; args[t][1] = (void *)(intptr_t)t; started[t] = t > 0 && pthread_create(&th[t], NULL, prepack_main, args[t]) == 0; }
+        prepack_main(args[0]);
+        for (int t = 1; t < nthr; t++) { if (started[t]) pthread_join(th[t], NULL); else prepack_main(args[t]); }
+        if (!K.overflow) break;
+        /* more bytes outside ACGT than one in 64 (lower-case reads): a list for all of them */
+        free(P->exc_pos); free(P->exc_byte); P->exc_pos = NULL; P->exc_byte = NULL;
+        if (attempt == 1) { lf_prepack_free(P); lf_set_error("lf_read_batch_prepack: exception list overflow"); return LF_ERR_NOMEM; }
+        xcap = o + 64; memset(P->planes, 0, bytes);
+    }
+    if (P->n_exc > 1) {          /* ascending positions: a chunk's exceptions are a contiguous range */
+        uint64_t *pair = (uint64_t *)malloc(P->n_exc * 16);
+        if (!pair) { lf_prepack_free(P); return LF_ERR_NOMEM; }
+        for (uint64_t k = 0; k < P->n_exc; k++) { pair[2 * k] = P->exc_pos[k]; pair[2 * k + 1] = P->exc_byte[k]; }
+        qsort(pair, P->n_exc, 16, exc_cmp);
+        for (uint64_t k = 0; k < P->n_exc; k++) { P->exc_pos[k] = pair[2 * k]; P->exc_byte[k] = (uint8_t)pair[2 * k + 1]; }
+        free(pair);
+    }
+    b->pre = P;
+    return LF_OK;
+}
+lf_read_batch_t *lf_batch_create(int n, const char *const *names, const char *const *seqs, const char *const *quals, const uint32_t *seq_lens, int min_read_len, int threads)
+{
+    if (n < 0 || (n > 0 && (!names || !seqs))) { lf_set_error("lf_batch_create: bad argument"); return NULL; }
+    struct lf_read_batch *b = (struct lf_read_batch *)calloc(1, sizeof *b);
+    if (!b) { lf_set_error("out of memory"); return NULL; }
+    b->n = n; b->rcap = n;
+    b->names = (const char **)malloc(((size_t)n + 1) * sizeof(char *)); b->seqs = (const char **)malloc(((size_t)n + 1) * sizeof(char *));
+    b->quals = (const char **)malloc(((size_t)n + 1) * sizeof(char *)); b->lens = (uint32_t *)malloc(((size_t)n + 1) * 4);
+    if (!b->names || !b->seqs || !b->quals || !b->lens) { lf_read_batch_free(b); lf_set_error("out of memory"); return NULL; }
+    for (int i = 0; i < n; i++) {
+        b->names[i] = names[i]; b->seqs[i] = seqs[i]; b->quals[i] = (quals && quals[i]) ? quals[i] : "";
+        b->lens[i] = seq_lens ? seq_lens[i] : (uint32_t)strlen(seqs[i]);
+        b->bases += b->lens[i];
+    }
+    if (lf_read_batch_prepack(b, min_read_len > 0 ? min_read_len : 1000, threads) != LF_OK) { lf_read_batch_free(b); return NULL; }
+    return b;
+}
+void lf_batch_free(lf_read_batch_t *b) { lf_read_batch_free(b); }
+int lf_batch_size(const lf_read_batch_t *b) { return b ? b->n : 0; }
+int lf_map_batch_from(const lf_index_t *ix, const lf_params_t *p, const lf_read_batch_t *b, char *out, size_t out_cap, size_t *sam_len, lf_stats_t *stats)
+{
+    if (!b || !p) { lf_set_error("lf_map_batch_from: no batch"); return LF_ERR_ARG; }
+    if (!out || out_cap < 2) { lf_set_error("lf_map_batch_from: no output buffer"); return LF_ERR_ARG; }
+    /* the planes serve when they were made for this -l (reads below it are not in them); otherwise the call packs like lf_map_batch_into_lens */
+    t_pre = (b->pre && b->pre->min_read_len == p->min_read_len) ? b->pre : NULL;
+    const int rc = map_batch_core(&ix, 1, p, b->n, b->names, b->seqs, b->quals, b->lens, out, out_cap, NULL, sam_len, stats, NULL);
+    t_pre = NULL;
+    return rc;
 }
 
 /* Device-resident form: the bases (and qualities) of the batch are already in HBM of idx's device and the SAM text is left

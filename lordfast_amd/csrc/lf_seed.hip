@@ -690,10 +690,24 @@ lf_unpack_planes_kernel(const uint64_t *__restrict__ lo, const uint64_t *__restr
     if (4 * t + 4 <= n_bases) *reinterpret_cast<uint32_t *>(dst + 4 * t) = out;      /* the buffer starts 256-byte aligned */
     else for (uint64_t k = 0; 4 * t + k < n_bases; k++) dst[4 * t + k] = (char)(out >> (8 * k));
 }
-__global__ void lf_patch_bytes_kernel(const uint64_t *__restrict__ pos, const uint8_t *__restrict__ byte, uint64_t n, char *__restrict__ dst)
+__global__ void lf_patch_bytes_kernel(const uint64_t *__restrict__ pos, const uint8_t *__restrict__ byte, uint64_t n, uint64_t base, char *__restrict__ dst)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[pos[i]] = (char)byte[i];
+    if (i < n) dst[pos[i] - base] = (char)byte[i];
+}
+/* a chunk of a prepacked batch: its planes are a BIT range of the batch's -- the words that hold it came up as they are (qs words per plane), this kernel
+ * moves them to bit 0 and clears what lies behind the chunk's last base (the next chunk's first bases) */
+__global__ void lf_planes_shift_kernel(const uint64_t *__restrict__ src, uint64_t qs, uint32_t shift, uint64_t n_bases, uint64_t *__restrict__ dst, uint64_t qw)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * qw) return;
+    const uint64_t x = t / qw, w = t - x * qw;
+    const uint64_t *S = src + x * qs;
+    uint64_t v = 0;
+    if (w < qs) { const uint64_t a = S[w], b = w + 1 < qs ? S[w + 1] : 0ull; v = shift ? (a >> shift) | (b << (64 - shift)) : a; }
+    const uint64_t first = w * 64;
+    if (first >= n_bases) v = 0; else if (n_bases - first < 64) v &= (1ull << (n_bases - first)) - 1;
+    dst[t] = v;
 }
 
 static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads, const void *d_src, const uint64_t *src_off,
@@ -758,6 +772,14 @@ static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_r
             if (turns) HIPCHK(hipStreamSynchronize(s));
             std::unique_lock<std::mutex> g(upload_turn, std::defer_lock);
             if (turns) g.lock();
+            if (pk->src_qw) {
+                /* prepacked batch: the three word ranges that hold the chunk's bits, then a shift on the device */
+                const uint64_t qs = (n_bases + pk->shift + 63) / 64 + 1;
+                uint64_t *d_stage = DSLOT(uint64_t, 15, 3 * qs * 8 + 64);
+                if (!d_stage) return LF_ERR_NOMEM;
+                for (int x = 0; x < 3; x++) HIPCHK(hipMemcpyAsync(d_stage + (size_t)x * qs, pk->planes + (size_t)x * pk->src_qw + pk->word0, qs * 8, hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(lf_planes_shift_kernel, dim3((unsigned)((3 * qw + 255) / 256)), dim3(256), 0, s, (const uint64_t *)d_stage, qs, pk->shift, n_bases, d_planes, qw);
+            } else
             HIPCHK(hipMemcpyAsync(d_planes, pk->planes, 3 * qw * 8, hipMemcpyHostToDevice, s));
             if (pk->n_exc) {
                 HIPCHK(hipMemcpyAsync(d_xpos, pk->exc_pos, pk->n_exc * 8, hipMemcpyHostToDevice, s));
@@ -771,7 +793,7 @@ static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_r
             if (lower) HIPCHK(hipMemsetAsync(d_counters + 4, 0xff, 8, s));
         }
         hipLaunchKernelGGL(lf_unpack_planes_kernel, dim3((unsigned)((n_bases / 4 + 256) / 256)), dim3(256), 0, s, d_planes, d_planes + qw, d_planes + 2 * qw, n_bases, d_reads);
-        if (pk->n_exc) hipLaunchKernelGGL(lf_patch_bytes_kernel, dim3((unsigned)((pk->n_exc + 255) / 256)), dim3(256), 0, s, (const uint64_t *)d_xpos, (const uint8_t *)d_xbyte, pk->n_exc, d_reads);
+        if (pk->n_exc) hipLaunchKernelGGL(lf_patch_bytes_kernel, dim3((unsigned)((pk->n_exc + 255) / 256)), dim3(256), 0, s, (const uint64_t *)d_xpos, (const uint8_t *)d_xbyte, pk->n_exc, pk->src_qw ? pk->exc_base : 0ull, d_reads);
     } else if (reads) {
         /* Uploads take turns: eight lanes start a step together, and eight concurrent copies share the link -- every lane would
          * get its bases after ~8 x the time of one copy.  In turn, the first lane's kernels start after one copy and the other

@@ -668,3 +668,50 @@ def test_seq_less_egress_into_a_pinned_buffer(lf, oracle, oracle_lib, golden_rea
             monkeypatch.delenv("LF_SAM_FULL")
     finally:
         L.lfg_host_free(buf)
+
+
+@pytest.mark.parametrize("chunk,lanes", [(0, 8), (7, 3), (1, 2)])
+def test_prepacked_batch_maps_like_the_strings(lf, oracle, oracle_lib, golden_reads, monkeypatch, chunk, lanes):
+    """lf_batch_create + lf_map_batch_from (SURVEY 7 step 3's lf_batch_create; the reference's readChunk leaves a mapper-ready chunk outside its
+    mapping timer, src/Reads.cpp:84-104): the batch's bit planes are made ONCE, a chunk uploads its bit range of them and the device shifts it into
+    place (lf_seed.hip: lf_planes_shift_kernel).  Same bytes as lf_map_batch on the strings: chunks that start at any bit offset (one / seven reads per
+    chunk), reads below -l (not packed), N and lower-case bases (exception list), FASTQ, a pinned and an ordinary output buffer, a -l other than the
+    batch's (falls back to packing per call)."""
+    import ctypes as C
+    import lordfast_amd as la
+    names, seqs = golden_reads
+    names, seqs = list(names), list(seqs)
+    rng = np.random.default_rng(31)
+    seqs[3] = seqs[3][:500] + b"N" * 7 + seqs[3][507:]
+    seqs[5] = seqs[5].lower()
+    seqs.insert(4, seqs[0][:650]); names.insert(4, b"short_one")                       # shorter than -l 1000: unmapped record, not in the planes
+    quals = [bytes(rng.integers(35, 74, size=len(s)).astype(np.uint8)) for s in seqs]
+    L = lf.L
+    L.lfg_host_alloc.restype = C.c_void_p
+    L.lfg_host_alloc.argtypes = [C.c_size_t]
+    L.lfg_host_free.argtypes = [C.c_void_p]
+    cap = 8 << 20
+    buf = L.lfg_host_alloc(cap)
+    plain = np.zeros(cap, dtype=np.uint8)
+    if chunk:
+        monkeypatch.setenv("LF_CHUNK_READS", str(chunk))
+    monkeypatch.setenv("LF_LANES", str(lanes))
+    try:
+        for q in (None, quals):
+            kw = dict(read_group_id=b"grp1") if q is not None else {}
+            exp = oracle.map_batch(names, seqs, q, params=oracle_lib.default_params(**kw))
+            b = la.ReadBatch(names, seqs, q, min_read_len=1000)
+            for ptr in (buf, plain.ctypes.data):
+                C.memset(ptr, 0x23, cap)
+                ln, st = lf.map_batch_from(b, ptr, cap, params=la.default_params(**kw))
+                got = C.string_at(ptr, ln)
+                assert got == exp, first_diff(got, exp)
+                assert st["n_reads"] == len(seqs)
+            # another -l than the one the batch was packed for: same call, per-call packing
+            kw2 = dict(kw, min_read_len=600)
+            exp2 = oracle.map_batch(names, seqs, q, params=oracle_lib.default_params(**kw2))
+            ln, _ = lf.map_batch_from(b, buf, cap, params=la.default_params(**kw2))
+            assert C.string_at(buf, ln) == exp2
+            b.close()
+    finally:
+        L.lfg_host_free(buf)

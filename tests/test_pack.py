@@ -51,3 +51,61 @@ def test_pack_read_equals_device_plane_layout():
     xn2 = C.c_uint64(0); small = np.zeros(4, dtype=np.uint64); smallb = np.full(8, 7, dtype=np.uint8)
     oks = [L.lf_pack_read(planes.ctypes.data, qw, int(off[k]), r, len(r), small.ctypes.data, smallb.ctypes.data, 4, C.byref(xn2)) for k, r in enumerate(reads)]
     assert 0 in oks and xn2.value == len(exc) and np.all(smallb[4:] == 7)
+
+
+def test_prepacked_batch_planes_equal_the_per_call_packing():
+    """lf_batch_create (lf_sched.c: lf_read_batch_prepack) packs a whole batch once; a chunk of it is a bit range of those planes.  Every read's bits
+    must equal what lf_pack_read makes of the read alone, reads below -l must be left out, the exception list must be sorted."""
+    import lordfast_amd as la
+    rng = np.random.default_rng(5)
+    reads = []
+    for i in range(300):
+        n = int(rng.integers(200, 3000))
+        r = bytearray(b"ACGT"[int(x)] for x in rng.integers(0, 4, n))
+        if i % 17 == 0:
+            r[n // 2] = ord("N")
+        if i % 29 == 0:
+            r[3:9] = b"acgtnn"
+        reads.append(bytes(r))
+    names = [b"r%d" % i for i in range(len(reads))]
+    b = la.ReadBatch(names, reads, min_read_len=1000, threads=3)
+    assert len(b) == len(reads)
+    L = la.lib()
+
+    class Pre(C.Structure):
+        _fields_ = [("min_read_len", C.c_int), ("bases", C.c_uint64), ("QW", C.c_uint64), ("planes", C.POINTER(C.c_uint64)), ("pinned", C.c_int),
+                    ("boff", C.POINTER(C.c_uint64)), ("exc_pos", C.POINTER(C.c_uint64)), ("exc_byte", C.POINTER(C.c_uint8)), ("n_exc", C.c_uint64)]
+
+    class Batch(C.Structure):
+        _fields_ = [("n", C.c_int), ("bases", C.c_uint64), ("names", C.c_void_p), ("seqs", C.c_void_p), ("quals", C.c_void_p), ("lens", C.POINTER(C.c_uint32)), ("rcap", C.c_int),
+                    ("blobs", C.c_void_p), ("blob_caps", C.c_void_p), ("nblobs", C.c_int), ("capblobs", C.c_int), ("blob", C.c_void_p), ("blob_n", C.c_size_t), ("blob_cap", C.c_size_t),
+                    ("off", C.c_void_p), ("cap", C.c_int), ("pre", C.POINTER(Pre))]
+
+    B = C.cast(b.h, C.POINTER(Batch)).contents
+    P = B.pre.contents
+    assert P.min_read_len == 1000 and P.pinned == 0                       # (no device here: plain memory)
+    mapped = [r for r in reads if len(r) >= 1000]
+    assert P.bases == sum(len(r) for r in mapped)
+    QW = int(P.QW)
+    planes = np.ctypeslib.as_array(P.planes, shape=(3 * QW,)).reshape(3, QW)
+    bits = np.unpackbits(planes.view(np.uint8), bitorder="little").reshape(3, QW * 64)
+    o = 0
+    for i, r in enumerate(reads):
+        assert P.boff[i] == o
+        if len(r) < 1000:
+            continue
+        a = np.frombuffer(r, dtype=np.uint8)
+        ok = np.isin(a, np.frombuffer(b"ACGT", dtype=np.uint8))
+        code = np.select([a == ord("A"), a == ord("C"), a == ord("G"), a == ord("T")], [0, 1, 2, 3], 0)
+        assert np.array_equal(bits[2, o:o + len(r)], ok.astype(np.uint8)), i
+        assert np.array_equal(bits[0, o:o + len(r)], ((code & 1) * ok).astype(np.uint8)), i
+        assert np.array_equal(bits[1, o:o + len(r)], ((code >> 1) * ok).astype(np.uint8)), i
+        o += len(r)
+    assert P.boff[len(reads)] == o and not bits[:, o:].any()
+    pos = np.ctypeslib.as_array(P.exc_pos, shape=(int(P.n_exc),)) if P.n_exc else np.zeros(0, np.uint64)
+    byt = np.ctypeslib.as_array(P.exc_byte, shape=(int(P.n_exc),)) if P.n_exc else np.zeros(0, np.uint8)
+    assert np.all(np.diff(pos.astype(np.int64)) > 0)
+    cat = np.frombuffer(b"".join(mapped), dtype=np.uint8)
+    bad = np.nonzero(~np.isin(cat, np.frombuffer(b"ACGT", dtype=np.uint8)))[0]
+    assert np.array_equal(pos, bad.astype(np.uint64)) and np.array_equal(byt, cat[bad])
+    b.close()
