@@ -304,6 +304,13 @@ int map_chunk(ctx_t *cx)
                     tmark(cx, "prepacked");
                     rc = lfg_seed_packed(cx->ix, cx->p, m, &pk, off, cx->host_vote, &hits);
                     packed = 1;
+                    if (getenv("LF_PREPACK_VERIFY") && rc == LF_OK) {      /* debug: the bytes the device rebuilt against the caller's strings */
+                        parallel_for(cx, m, phase_concat);
+                        extern int lfg_debug_compare_reads(const struct lf_index *ix, const char *cat, uint64_t n);
+                        const int bad = lfg_debug_compare_reads(cx->ix, cat, bases);
+                        fprintf(stderr, "[lf] prepack verify: chunk i0 %d n %d m %d o0 %llu shift %u word0 %llu bases %llu exc %llu -> %s\n", cx->pre_i0, n, m, (unsigned long long)o0, pk.shift,
+                                (unsigned long long)pk.word0, (unsigned long long)bases, (unsigned long long)pk.n_exc, bad ? "MISMATCH" : "ok");
+                    }
                 }
             }
             if (!packed && packed_on && !cx->host_vote) {
@@ -324,7 +331,7 @@ int map_chunk(ctx_t *cx)
                     pthread_mutex_unlock(&concat_turn);
                     tmark(cx, "pack");
                     if (!cx->pk_overflow) {
-                        lf_packed_src_t pk; pk.planes = planes; pk.qw = qw; pk.exc_pos = xpos; pk.exc_byte = xbyte; pk.n_exc = cx->pk_xn;
+                        lf_packed_src_t pk; memset(&pk, 0, sizeof pk); pk.planes = planes; pk.qw = qw; pk.exc_pos = xpos; pk.exc_byte = xbyte; pk.n_exc = cx->pk_xn;
                         if (getenv("LF_TIMING")) fprintf(stderr, "[lf] pack %.1f ms, %llu bytes outside ACGT\n", now_ms() - tc0, (unsigned long long)pk.n_exc);
                         tc0 = now_ms();
                         rc = lfg_seed_packed(cx->ix, cx->p, m, &pk, off, cx->host_vote, &hits);
