@@ -730,10 +730,10 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
             n_roots = h_ctl->n_roots; n_h = h_ctl->n_hleaf;
             uint32_t cntq[LF_HQ], cnt_all = 0;
             for (int k = 0; k < LF_HQ; k++) { cntq[k] = h_ctl->q_n[par][k]; cnt_all += cntq[k]; }
-            /* statistics of the lane's calls (lf_stats_t.hirsch_*): lane values 1 .. 3 */
+            /* statistics of the lane's calls (lf_stats_t.hirsch_*): lane values 4 .. 6 (0: plane words, lf_seed.hip; 2, 3: lines of the SAM buffers, lf_sam.hip) */
             { uint64_t nb_ = 0, nu_ = 0; for (int k = 0; k < LF_HQ; k++) (k >= LF_HQ_NW0 ? nb_ : nu_) += cntq[k];
-              const uint64_t mx_ = lfg_lane_value(device, 1); if (h_ctl->max_root_n > mx_) lfg_lane_set_value(device, 1, h_ctl->max_root_n);
-              lfg_lane_set_value(device, 2, lfg_lane_value(device, 2) + nb_); lfg_lane_set_value(device, 3, lfg_lane_value(device, 3) + nu_); }
+              const uint64_t mx_ = lfg_lane_value(device, 4); if (h_ctl->max_root_n > mx_) lfg_lane_set_value(device, 4, h_ctl->max_root_n);
+              lfg_lane_set_value(device, 5, lfg_lane_value(device, 5) + nb_); lfg_lane_set_value(device, 6, lfg_lane_value(device, 6) + nu_); }
             if (cnt_all == 0) break;
             /* next level's counters and this level's scratch cursors */
             HIPCHK(hipMemsetAsync((char *)d_ctl + offsetof(lf_hctl, q_n) + (size_t)(par ^ 1) * sizeof(h_ctl->q_n[0]), 0, sizeof(h_ctl->q_n[0]), s));

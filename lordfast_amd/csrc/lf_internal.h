@@ -96,7 +96,7 @@ void *lfg_pin_slot(int slot, size_t bytes);
 void  lfg_slots_release(void);
 void *lfg_host_alloc(size_t bytes);    /* pinned host memory outside the slot system */
 void  lfg_host_free(void *p);
-void  lfg_lane_set_value(int device, int key, uint64_t v);   /* per-lane scratch numbers; key 0: words of one bit plane of the resident read batch */
+void  lfg_lane_set_value(int device, int key, uint64_t v);   /* per-lane scratch numbers, key < 8; 0: words of one bit plane of the resident read batch (lf_seed.hip), 2 / 3: lines of the lane's two SAM buffers (lf_sam.hip), 4 .. 6: Hirschberg statistics (lf_align.hip) */
 uint64_t lfg_lane_value(int device, int key);
 void  lfg_set_lane(int lane);          /* calling thread drives lane 0 or 1 (own slots + streams) */
 int   lfg_get_lane(void);

@@ -170,9 +170,9 @@ extern "C" void *lfg_lane_event(int device, int which)
 }
 
 /* a few numbers a lane leaves for its later stages (e.g. the size of the bit planes lfg_seed made of the resident batch) */
-static uint64_t g_lane_val[MAX_DEV][MAX_LANE][4];
-extern "C" void lfg_lane_set_value(int device, int key, uint64_t v) { if (device >= 0 && device < MAX_DEV && key >= 0 && key < 4) g_lane_val[device][t_lane][key] = v; }
-extern "C" uint64_t lfg_lane_value(int device, int key) { return (device >= 0 && device < MAX_DEV && key >= 0 && key < 4) ? g_lane_val[device][t_lane][key] : 0; }
+static uint64_t g_lane_val[MAX_DEV][MAX_LANE][8];
+extern "C" void lfg_lane_set_value(int device, int key, uint64_t v) { if (device >= 0 && device < MAX_DEV && key >= 0 && key < 8) g_lane_val[device][t_lane][key] = v; }
+extern "C" uint64_t lfg_lane_value(int device, int key) { return (device >= 0 && device < MAX_DEV && key >= 0 && key < 8) ? g_lane_val[device][t_lane][key] : 0; }
 
 extern "C" void *lfg_dev_slot(int device, int slot, size_t bytes)
 {

@@ -221,13 +221,13 @@ static void phase_sam_score(ctx_t *cx, int tid, int ri)
     }
     if (r->mode == 3) samsort_sort(r->maps, r->nWins);                     /* std::sort(compareSam) :565 */
 }
-/* what the Hirschberg levels of the lane's alignment calls left in lane values 1 .. 3 (lf_align.hip): longest root, nodes by kind of sweep */
+/* what the Hirschberg levels of the lane's alignment calls left in lane values 4 .. 6 (lf_align.hip): longest root, nodes by kind of sweep */
 static void take_hirsch_stats(int device, lf_stats_t *st)
 {
-    const uint64_t mx = lfg_lane_value(device, 1);
+    const uint64_t mx = lfg_lane_value(device, 4);
     if (mx > st->hirsch_max_rows) st->hirsch_max_rows = mx;
-    st->hirsch_banded_nodes += lfg_lane_value(device, 2); st->hirsch_unbanded_nodes += lfg_lane_value(device, 3);
-    lfg_lane_set_value(device, 1, 0); lfg_lane_set_value(device, 2, 0); lfg_lane_set_value(device, 3, 0);
+    st->hirsch_banded_nodes += lfg_lane_value(device, 5); st->hirsch_unbanded_nodes += lfg_lane_value(device, 6);
+    lfg_lane_set_value(device, 4, 0); lfg_lane_set_value(device, 5, 0); lfg_lane_set_value(device, 6, 0);
 }
 static inline void tmark(ctx_t *cx, const char *label)
 {
@@ -304,13 +304,6 @@ int map_chunk(ctx_t *cx)
                     tmark(cx, "prepacked");
                     rc = lfg_seed_packed(cx->ix, cx->p, m, &pk, off, cx->host_vote, &hits);
                     packed = 1;
-                    if (getenv("LF_PREPACK_VERIFY") && rc == LF_OK) {      /* debug: the bytes the device rebuilt against the caller's strings */
-                        parallel_for(cx, m, phase_concat);
-                        extern int lfg_debug_compare_reads(const struct lf_index *ix, const char *cat, uint64_t n);
-                        const int bad = lfg_debug_compare_reads(cx->ix, cat, bases);
-                        fprintf(stderr, "[lf] prepack verify: chunk i0 %d n %d m %d o0 %llu shift %u word0 %llu bases %llu exc %llu -> %s\n", cx->pre_i0, n, m, (unsigned long long)o0, pk.shift,
-                                (unsigned long long)pk.word0, (unsigned long long)bases, (unsigned long long)pk.n_exc, bad ? "MISMATCH" : "ok");
-                    }
                 }
             }
             if (!packed && packed_on && !cx->host_vote) {

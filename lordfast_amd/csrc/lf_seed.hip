@@ -712,17 +712,6 @@ __global__ void lf_planes_shift_kernel(const uint64_t *__restrict__ src, uint64_
 
 static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_reads, const char *reads, const void *d_src, const uint64_t *src_off,
                         const lf_packed_src_t *pk, const uint64_t *off, int want_hits, lfg_hits_t *out);
-extern "C" int lfg_debug_compare_reads(const struct lf_index *ix, const char *cat, uint64_t n)
-{
-    const int dv = ix->device;
-    char *d_reads = (char *)lfg_dev_slot(dv, LF_DS_SEED0 + 0, 0);
-    std::vector<char> h(n);
-    hipStream_t s = (hipStream_t)lfg_lane_stream(dv, 0);
-    (void)hipStreamSynchronize(s);
-    if (hipMemcpy(h.data(), d_reads, n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    for (uint64_t i = 0; i < n; i++) if (h[i] != cat[i]) { fprintf(stderr, "[lf] prepack verify: first mismatch at base %llu of %llu: device %d host %d\n", (unsigned long long)i, (unsigned long long)n, (int)(unsigned char)h[i], (int)(unsigned char)cat[i]); return 1; }
-    return 0;
-}
 extern "C" int lfg_seed_packed(const struct lf_index *ix, const lf_params_t *p, int n_reads, const lf_packed_src_t *pk, const uint64_t *off, int want_hits, lfg_hits_t *out)
 {
     return lfg_seed_any(ix, p, n_reads, nullptr, nullptr, nullptr, pk, off, want_hits, out);
