@@ -70,7 +70,7 @@ lf_edlib_tb_kernel(const lf_aln_prob *__restrict__ probs, int n_probs, lf_seqs S
     /* where the forward kernel left this problem's data: the wave's planes, then its checkpoint rows; block b was lane lane0 + b */
     const lf_hist_t *wbase = ckpt + pr.hist_base;
     uint32_t len = 0;
-    lf_tb_core<HK, false>(pr, want, tl, (int)pr.pad, lane, wbase + LF_PLANE_ENTRIES, reinterpret_cast<const uint64_t *>(wbase), s_peq, s_tile, S.pac, pac_syms, ops, len);
+    lf_tb_core<HK>(pr, want, tl, (int)pr.pad, lane, wbase + LF_PLANE_ENTRIES, reinterpret_cast<const uint64_t *>(wbase), s_peq, s_tile, S.pac, pac_syms, ops, len);
     if (live) out_len[pr.id] = len;
 }
 
@@ -637,7 +637,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     HIPCHK(hipSetDevice(device));
     hipStream_t s = (hipStream_t)lfg_lane_stream(device, 1);
     if (!s) return LF_ERR_HIP;
-    const bool serial_classes = getenv("LF_SERIAL_CLASSES") != nullptr;     /* profiling aid: one class at a time (read per call: bench.py switches it) */
+    const bool serial_classes = lf_env_set("LF_SERIAL_CLASSES") != 0;     /* profiling aid: one class at a time (read per call: bench.py switches it) */
     hipEvent_t bd[5]; for (int k = 0; k < 5; k++) { bd[k] = (hipEvent_t)lfg_lane_event(device, 4 + k); if (!bd[k]) return LF_ERR_HIP; }
     hipStream_t cs[LF_NCLASS];
     for (int k = 0; k < LF_NCLASS; k++) { cs[k] = serial_classes ? s : (hipStream_t)lfg_lane_stream(device, 2 + k); if (!cs[k]) return LF_ERR_HIP; }
@@ -701,8 +701,8 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         HIPCHK(hipMemsetAsync(d_ctl, 0, sizeof(lf_hctl), s));
         HA.S.q = D->d_q; HA.S.t = D->d_t; HA.S.pac = D->d_pac; HA.pac_syms = D->pac_syms;
         lf_htrial_pick(HA.trial16);
-        if (const char *e_ = getenv("LF_HIRSCH_TRIAL")) { unsigned a_ = 0, b_ = 0; if (sscanf(e_, "%u,%u", &a_, &b_) == 2 && a_ <= 16 && b_ <= 16) { HA.trial16[0] = a_; HA.trial16[1] = b_; } }      /* test hook: fixed bounds "nw,shw" */
-        { const char *e_ = getenv("LF_HIRSCH_BAND"); HA.no_band = (e_ && atoi(e_) == 0) ? 1u : 0u; }      /* (read per call: the tests switch it) */
+        if (const char *e_ = lf_env("LF_HIRSCH_TRIAL")) { unsigned a_ = 0, b_ = 0; if (sscanf(e_, "%u,%u", &a_, &b_) == 2 && a_ <= 16 && b_ <= 16) { HA.trial16[0] = a_; HA.trial16[1] = b_; } }      /* test hook: fixed bounds "nw,shw" */
+        HA.no_band = lf_env_long("LF_HIRSCH_BAND", 1) == 0 ? 1u : 0u;      /* (read per call: the tests switch it) */
         HA.qlo = D->d_planes; HA.qhi = D->d_planes + D->q_words; HA.qvalid = D->d_planes + 2 * D->q_words; HA.q_words = D->q_words;
         HA.q_cap = (uint32_t)q_cap; HA.ctl = d_ctl; HA.roots = d_roots; HA.segs = d_segs; HA.hdesc = d_hdesc; HA.hopsoff = d_hopsoff; HA.hleaf_cap = (uint32_t)hcap;
         HA.aux = d_haux; HA.aux_cap = aux_cap; HA.hcar = d_hcar; HA.hcar_cap = hcar_cap;
@@ -712,7 +712,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         for (int k = 0; k < LF_HQ; k++) HA.q_out[k] = queue(0, k);
         HA.out_par = 0;
         lf_hirsch_launch_roots(s, D->pac, d_desc, d_opsoff, n, HA);
-        const bool hdbg = getenv("LF_HIRSCH_DEBUG") != nullptr;      /* per call: roots and their sizes; per level: nodes by class, milliseconds since the previous readback */
+        const bool hdbg = lf_env_set("LF_HIRSCH_DEBUG") != 0;      /* per call: roots and their sizes; per level: nodes by class, milliseconds since the previous readback */
         std::chrono::steady_clock::time_point hd_t0 = std::chrono::steady_clock::now();
         if (hdbg) fprintf(stderr, "[lf] hirschberg: %llu roots, sum n %llu, sum m %llu (of %d problems)\n", (unsigned long long)HC.roots, (unsigned long long)HC.sum_n, (unsigned long long)HC.sum_m, n);
         for (int level = 0; level < 64; level++) {
@@ -786,10 +786,10 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     hipLaunchKernelGGL(lf_desc_binscan_kernel, dim3(1), dim3(1024), 0, s, d_bins);
     hipLaunchKernelGGL(lf_desc_count_kernel<true>, dim3(gc), dim3(1024), 0, s, (const uint32_t *)d_keys, N, d_bins, d_keys2, d_vals2);
     hipLaunchKernelGGL(lf_desc_segments_kernel, dim3(1), dim3(256), 0, s, d_keys2, N, d_tab);
-    /* LF_SMALL_FUSED=1: the small problems' segments go through lf_edlib_small_kernel (forward + traceback in one wavefront, rows in LDS).
-     * Built and measured in round 5 -- 14 KB of LDS and 112 registers per wavefront leave its forward pass three wavefronts per SIMD, and the
-     * step's alignment kernels took 24.3 instead of 21.1 ms (profiles/r05_search/) -- so the default keeps them on the forward / traceback pair. */
-    const int fused_small = getenv("LF_SMALL_FUSED") && atoi(getenv("LF_SMALL_FUSED")) != 0;
+    /* (A fused forward + traceback kernel for the problems of at most two query blocks and 127 columns -- rows in LDS, paths walked by the same wavefront --
+     * was built and measured in round 5: 14 KB of LDS and 112 registers left its forward pass three wavefronts per SIMD, the step's alignment kernels took 24.3
+     * instead of 21.1 ms, profiles/r05_search/.  It is not in the tree; the binning still gives such problems segments of their own, block field 65 ..) */
+    const int fused_small = 0;
     hipLaunchKernelGGL(lf_desc_entries_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, n, d_hdesc, d_tab, N, d_ent, fused_small);
     { lf_scan_u64 f; f.p = d_ent; const int src = lf_scan_excl(device, 4, s, f, d_base, (size_t)N); if (src != LF_OK) return src; }
     hipLaunchKernelGGL(lf_desc_build_kernel, dim3(gb), dim3(256), 0, s, d_keys2, d_vals2, d_desc, n, d_hdesc, d_opsoff, d_hopsoff, d_tab, d_base, N, D->pac ? 1 : 0, d_probs, d_waves, d_misc);
@@ -803,14 +803,6 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
     HIPCHK(hipStreamSynchronize(s));
     const uint64_t aux_total = tail[2];
     const uint64_t hist_entries = tail[0] + tail[1];
-    if (getenv("LF_HIST_STATS")) {       /* debug: the class-1 problems of this round by (mode, blocks, target-length bucket) -- the scanned bin starts */
-        std::vector<uint32_t> hb((size_t)LF_NBINS + 1);
-        HIPCHK(hipMemcpy(hb.data(), d_bins, (size_t)LF_NBINS * 4, hipMemcpyDeviceToHost));
-        for (int b = 1; b < 1 + 2 * LF_SEG_NB_MAX * LF_BIN_MB; b++) {      /* (the scatter pass advanced every cursor to its bin's end) */
-            const uint32_t c = hb[(size_t)b] - hb[(size_t)b - 1];
-            if (c) fprintf(stderr, "[lf] bin mode %d nb %d mb %d: %u\n", (b - 1) / (LF_SEG_NB_MAX * LF_BIN_MB), lf_seg_blocks(((b - 1) / LF_BIN_MB) % LF_SEG_NB_MAX + 1), (b - 1) % LF_BIN_MB, c);
-        }
-    }
     lf_hist_t *d_hist = DSLOT(lf_hist_t, 2, hist_entries * sizeof(lf_hist_t) + 64);
     uint64_t *d_aux = (uint64_t *)lfg_dev_slot(device, LF_DS_HIRSCH0 + 9, aux_total * 8 + 64);
     if (!d_hist || !d_aux) return LF_ERR_NOMEM;
@@ -831,44 +823,35 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         RA.pac = D->d_pac; RA.pac_syms = D->pac_syms; RA.ckpt = d_hist; RA.out_ed = d_ed; RA.out_end = d_end;
         /* segments t = mode * 128 + block field; the small problems' segments (block field 65 .. 64 + LF_SMALL_NB) close each mode's range:
          * their waves go to the fused kernel (rows in LDS, paths walked by the same wavefront), everything else to forward + traceback */
-        const int w_nw_small = h_tab->w0[65], w_shw0 = h_tab->w0[128], w_shw_small = h_tab->w0[128 + 65], w_end = h_tab->w0[256];
-        const int p_nw_small = h_tab->lo[65], p_shw0 = h_tab->lo[128], p_shw_small = h_tab->lo[128 + 65], p_end = h_tab->lo[256];
+        const int w_shw0 = h_tab->w0[128], w_end = h_tab->w0[256];
+        const int p_shw0 = h_tab->lo[128], p_end = h_tab->lo[256];
         (void)nw_nw; (void)nw_shw;
         RA.ops = d_ops; RA.out_len = d_len;
-        RA.rev = !(getenv("LF_ALIGN_LONG_FIRST") && atoi(getenv("LF_ALIGN_LONG_FIRST")) == 0);      /* A / B hook: 0 = ascending order (round 4) */
+        RA.rev = true;                                       /* the long problems of a launch first */
         /* The two modes' problems are independent: NW (the pieces between anchors) sweeps and walks its paths on the class stream, SHW (the pieces in front
          * of the first / behind the last anchor) on a stream of its own.  Each mode's traceback ends with ONE long path (1.3 and 0.9 ms in a chunk of
          * 1 600 or 6 250 reads alike, profiles/r05_chain/): back to back they were a quarter of a small chunk's launch chain.  (One stream when the
          * classes are serialized for the exclusive timings, and for the fused small-problem kernel's A / B.) */
         hipStream_t cb = cs[1];
         hipEvent_t shw_done = nullptr;
-        if (!serial_classes && !fused_small && !(getenv("LF_ALIGN_MODE_STREAMS") && atoi(getenv("LF_ALIGN_MODE_STREAMS")) == 0)) {
+        if (!serial_classes) {
             cb = (hipStream_t)lfg_lane_stream(device, 6); shw_done = (hipEvent_t)lfg_lane_event(device, 9);
             if (!cb || !shw_done) return LF_ERR_HIP;
             HIPCHK(hipStreamWaitEvent(cb, eb, 0));
         }
         HIPCHK(hipEventRecord(bd[1], cs[1]));
-        if (fused_small) {
-            RA.wave0 = 0; RA.n_waves = w_nw_small; lf_rsweep_launch(cs[1], false, RA);
-            RA.wave0 = w_shw0; RA.n_waves = w_shw_small - w_shw0; lf_rsweep_launch(cs[1], true, RA);
-            RA.wave0 = w_nw_small; RA.n_waves = w_shw0 - w_nw_small; lf_small_launch(cs[1], false, RA);
-            RA.wave0 = w_shw_small; RA.n_waves = w_end - w_shw_small; lf_small_launch(cs[1], true, RA);
-        } else {
-            RA.wave0 = 0; RA.n_waves = w_shw0; lf_rsweep_launch(cs[1], false, RA);
-            RA.wave0 = w_shw0; RA.n_waves = w_end - w_shw0; lf_rsweep_launch(cb, true, RA);
-        }
+        RA.wave0 = 0; RA.n_waves = w_shw0; lf_rsweep_launch(cs[1], false, RA);
+        RA.wave0 = w_shw0; RA.n_waves = w_end - w_shw0; lf_rsweep_launch(cb, true, RA);
         HIPCHK(hipEventRecord(bd[2], cs[1]));
         {
-            /* columns per replayed part of a 32-step tile: 8 (four parts, 8 KiB of LDS per wavefront) or 16 (two parts, 16 KiB); the paths of the
-             * problems the fused kernel did not take: two ranges of the sorted problem array */
-            const int tb_hk = getenv("LF_TB_HK") ? atoi(getenv("LF_TB_HK")) : 8;
-            const int r0[2] = { cstart[1], p_shw0 }, r1[2] = { fused_small ? p_nw_small : p_shw0, fused_small ? p_shw_small : p_end };
+            /* eight columns per replayed part of a 32-step tile (four parts, 8 KiB of LDS per wavefront; parts of 4 and of 16 columns measured 12.0 and 10.1 ms
+             * against 9.4, round 4); the NW paths on the class stream, the SHW paths on theirs */
+            const int r0[2] = { cstart[1], p_shw0 }, r1[2] = { p_shw0, p_end };
             for (int q = 0; q < 2; q++) {
                 const int np = r1[q] - r0[q];
                 if (np <= 0) continue;
                 hipStream_t ts = q == 0 ? cs[1] : cb;
-                if (tb_hk == 16) hipLaunchKernelGGL(lf_edlib_tb_kernel<16>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, ts, d_probs + r0[q], np, S, D->pac_syms, d_hist, d_ops, d_end, d_len, RA.rev);
-                else hipLaunchKernelGGL(lf_edlib_tb_kernel<8>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, ts, d_probs + r0[q], np, S, D->pac_syms, d_hist, d_ops, d_end, d_len, RA.rev);
+                hipLaunchKernelGGL(lf_edlib_tb_kernel<8>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, ts, d_probs + r0[q], np, S, D->pac_syms, d_hist, d_ops, d_end, d_len, RA.rev);
             }
         }
         if (cb != cs[1]) { HIPCHK(hipEventRecord(shw_done, cb)); HIPCHK(hipStreamWaitEvent(cs[1], shw_done, 0)); }
@@ -883,7 +866,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         HIPCHK(hipMemcpyAsync(ops_len, d_len, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     }
     if (ops) HIPCHK(hipMemcpyAsync(ops, d_ops, D->ops_total, hipMemcpyDeviceToHost, s));
-    if (dev_desc && !ed && !ops && !getenv("LF_HIST_STATS")) {
+    if (dev_desc && !ed && !ops) {
         HIPCHK(hipGetLastError());
         t_pend.on = true; t_pend.class1 = cnt(1) > 0; t_pend.e0 = e0; t_pend.e1 = e1; t_pend.eb = eb; for (int k = 0; k < 4; k++) t_pend.bd[k] = bd[k];
         return LF_OK;
@@ -952,15 +935,6 @@ extern "C" int lfg_edlib_desc(const struct lf_index *ix, int n, const lf_aln_des
     if (rc != LF_OK) return rc;
     D.d = d; D.ops_off = ops_off; D.ops_total = ops_total;
     D.hc = count_hroots(n, d);
-    if (getenv("LF_HIST_STATS")) {       /* debug: where the DP cells are (by ceil(n/64)) */
-        uint64_t cnt[12] = { 0 }, cells[12] = { 0 }, hist[12] = { 0 };
-        static const uint32_t edge[12] = { 1, 2, 3, 4, 5, 6, 8, 12, 16, 32, 64, 256 };
-        for (int i = 0; i < n; i++) {
-            const uint32_t nb = (d[i].n + 63) >> 6; int c = 0; while (c < 11 && nb > edge[c]) c++;
-            cnt[c]++; cells[c] += (uint64_t)d[i].n * d[i].m; hist[c] += (uint64_t)nb * d[i].m;
-        }
-        for (int c = 0; c < 12; c++) if (cnt[c]) fprintf(stderr, "[lf] dp nb<=%u: %llu problems, %.1f Mcells, %.2f M block steps\n", edge[c], (unsigned long long)cnt[c], cells[c] / 1e6, hist[c] / 1e6);
-    }
     return run_edlib_desc_gpu(ix->device, n, &D, ed, endloc, ops, ops_len, ops_slot, ops_dev, desc_dev, ms);
 }
 
@@ -1498,15 +1472,14 @@ extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff
     HIPCHK(hipMemcpyAsync(d_p, P.data(), P.size() * sizeof(lf_ksw_prob), hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(e0, s));
     int qmax = 0, n_wide = 0, n_narrow = 0, qmax_wide = 0, qmax_narrow = 0;
-    const bool one_wave = getenv("LF_KSW_1WAVE") && atoi(getenv("LF_KSW_1WAVE")) != 0;      /* A / B: every problem on lf_ksw_kernel */
     for (int i = 0; i < n; i++) {
         qmax = std::max(qmax, P[i].qlen);
-        const bool wide = one_wave || lf_ksw_band(P[i].qlen, P[i].o_del, P[i].e_del, P[i].o_ins, P[i].e_ins, P[i].w) > LF_KSW_MW_MAXW;
+        const bool wide = lf_ksw_band(P[i].qlen, P[i].o_del, P[i].e_del, P[i].o_ins, P[i].e_ins, P[i].w) > LF_KSW_MW_MAXW;
         if (wide) { n_wide++; qmax_wide = std::max(qmax_wide, P[i].qlen); } else { n_narrow++; qmax_narrow = std::max(qmax_narrow, P[i].qlen); }
     }
     const int lds_q = std::min(qmax, 6000);
-    /* bands of at most 2 x 120 + 1 columns (every call of the reference: w = 100): the register kernel; LF_KSW_R4=0: the four-wavefront LDS kernel (A / B) */
-    const bool r4 = !(getenv("LF_KSW_R4") && atoi(getenv("LF_KSW_R4")) == 0) && !one_wave;
+    /* bands of at most 2 x 120 + 1 columns (every call of the reference: w = 100): the register kernel; wider ones: the four-wavefront LDS kernel, then the general one */
+    const bool r4 = true;
     bool r4_all = r4;
     if (r4) {
         for (int i = 0; i < n && r4_all; i++) r4_all = lf_ksw_band(P[i].qlen, P[i].o_del, P[i].e_del, P[i].o_ins, P[i].e_ins, P[i].w) <= LF_KSW_R4_MAXW;
@@ -1521,7 +1494,7 @@ extern "C" int lfg_ksw(int device, int n, const uint8_t *q, const uint64_t *qoff
                            (const uint8_t *)d_t, d_s, d_ql, d_tl, mw_q, r4 ? 1 : 0);
     }
     if (n_wide) {
-        const int wide_only = one_wave ? 0 : 1;
+        const int wide_only = 1;
         hipLaunchKernelGGL(lf_ksw_kernel<true>, dim3((unsigned)n), dim3(64), (size_t)(2 * (lds_q + 2)) * 4, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,
                            (const uint8_t *)d_t, d_ws, d_s, d_ql, d_tl, lds_q, wide_only);
         if (qmax_wide > lds_q) hipLaunchKernelGGL(lf_ksw_kernel<false>, dim3((unsigned)n), dim3(64), 0, s, (const lf_ksw_prob *)d_p, n, (const uint8_t *)d_q,

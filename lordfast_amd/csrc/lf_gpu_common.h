@@ -308,10 +308,10 @@ extern "C" void lfg_count_wait_at(const char *file, int line);        /* LF_WAIT
 static inline hipError_t lf_stream_wait(hipStream_t s, const char *file, int line)
 {
     lfg_count_wait();
-    static const bool trace = getenv("LF_WAIT_TRACE") != nullptr;
+    static const bool trace = lf_env_set("LF_WAIT_TRACE") != 0;
     if (trace) lfg_count_wait_at(file, line);
-    static const bool spin = getenv("LF_SPIN_WAIT") != nullptr;
-    static const long spin_us = getenv("LF_SPIN_US") ? atol(getenv("LF_SPIN_US")) : 200;
+    const bool spin = false;
+    static const long spin_us = lf_env_long("LF_SPIN_US", 200);
     int dev = -1;
     if (spin || hipGetDevice(&dev) != hipSuccess) return hipStreamSynchronize(s);
     hipEvent_t e = (hipEvent_t)lfg_thread_wait_event(dev);

@@ -232,3 +232,9 @@ void lf_seeds_free(lf_seeds_t *s)
     if (!s) return;
     free(s->offF); free(s->offR); free(s->F); free(s->R); free(s);
 }
+
+/* ---- the ONE place the library reads its environment (INTEGRATION.md lists every name: operational knobs and the hooks the tests use;
+ * none of them selects a different algorithm or a CPU path) ---- */
+const char *lf_env(const char *name) { return getenv(name); }
+long lf_env_long(const char *name, long dflt) { const char *v = getenv(name); return v && *v ? atol(v) : dflt; }
+int lf_env_set(const char *name) { return getenv(name) != NULL; }

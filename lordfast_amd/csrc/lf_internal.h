@@ -107,6 +107,10 @@ void  lfg_quiesce(int device);                     /* per-stream waits before th
 void  lfg_drain_check(int device);                 /* LF_WATCHDOG: name the stream that never drains */
 void *lfg_lane_stream(int device, int which);   /* persistent hipStream_t of the calling thread's lane */
 void *lfg_lane_event(int device, int which);    /* persistent hipEvent_t (timing enabled) of the calling thread's lane; which < 48 */
+/* the environment (lf_host.c): lf_env_set = the variable exists; lf_env_long = its value as a number, or the default */
+const char *lf_env(const char *name);
+long lf_env_long(const char *name, long dflt);
+int  lf_env_set(const char *name);
 /* slot ids */
 enum { LF_DS_SEED0 = 0 /* ..15 */, LF_DS_CHAIN0 = 16 /* ..23 */, LF_DS_ALN0 = 24 /* ..47 */, LF_DS_KSW0 = 48 /* ..55 */,
        LF_DS_RND0 = 56 /* ..87: 2 per extension round (ops, spare) */, LF_DS_RENDER0 = 88 /* ..95 */, LF_DS_VOTE0 = 96 /* ..127 */,

@@ -53,7 +53,7 @@ extern "C" void lfg_quiesce(int device)
  * named (lane, stream index) and the process aborts instead of hanging inside hipFree */
 extern "C" void lfg_drain_check(int device)
 {
-    const char *w = getenv("LF_WATCHDOG");
+    const char *w = lf_env("LF_WATCHDOG");
     if (!w || atoi(w) <= 0 || device < 0 || device >= MAX_DEV) return;
     const int limit_ms = atoi(w) * 1000;
     for (int waited = 0;; waited += 20) {
@@ -141,18 +141,9 @@ extern "C" void *lfg_lane_stream(int device, int which)
     hipStream_t &st = g_streams[device][t_lane][which];
     if (!st) {
         if (hipSetDevice(device) != hipSuccess) { lf_set_error("hipSetDevice failed"); return nullptr; }
-        /* LF_CU_SPLIT=k (experiment, profiles/r04_cu_split): the seed / vote stream of every lane -- kernels bound by outstanding
-         * memory requests, not by issue slots -- runs on every k-th CU, all other streams on the remaining ones */
-        static int split = -1;
-        if (split < 0) { const char *e = getenv("LF_CU_SPLIT"); split = e ? atoi(e) : 0; if (split < 2 || split > 16) split = 0; }
-        hipError_t rc;
-        if (split && which != 14) {
-            hipDeviceProp_t pr; int ncu = 256;
-            if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount;
-            uint32_t mask[16]; for (int k = 0; k < 16; k++) mask[k] = 0;
-            for (int c = 0; c < ncu && c < 512; c++) if (((c % split) == 0) == (which == 0)) mask[c >> 5] |= 1u << (c & 31);
-            rc = hipExtStreamCreateWithCUMask(&st, (uint32_t)((ncu + 31) / 32), mask);
-        } else rc = hipStreamCreate(&st);
+        /* (CU-masked streams -- seed / vote on every k-th CU, everything else on the rest -- were measured in round 4, profiles/r04_cu_split/: 366 ms per step
+         * against 77; not in the tree) */
+        const hipError_t rc = hipStreamCreate(&st);
         if (rc != hipSuccess) { lf_set_error("hipStreamCreate failed"); st = nullptr; return nullptr; }
     }
     return (void *)st;

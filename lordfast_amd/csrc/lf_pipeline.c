@@ -249,13 +249,13 @@ int map_chunk(ctx_t *cx)
     lf_stats_t *st = cx->st;
     int rc = LF_OK;
     double t0 = now_ms(), t1;
-    const int timing = getenv("LF_TIMING") != NULL, timing0 = timing;
+    const int timing = lf_env_set("LF_TIMING"), timing0 = timing;
     cx->timing = timing; cx->n_marks = 0;
     const double t_begin = t0;
 
     parallel_for(cx, n, phase_prepare);
     tmark(cx, "prepare");
-    if (getenv("LF_TIMING")) fprintf(stderr, "[lf] prepare %.1f ms\n", now_ms() - t0);
+    if (lf_env_set("LF_TIMING")) fprintf(stderr, "[lf] prepare %.1f ms\n", now_ms() - t0);
 
     /* ---- A: seeds ---- */
     lfg_hits_t hits; memset(&hits, 0, sizeof hits);
@@ -287,7 +287,7 @@ int map_chunk(ctx_t *cx)
              * list of the bytes that are not upper-case ACGT -- the link carries 0.57 instead of 1.53 GB per 100 k reads, and the
              * lanes of a step start 1.3 instead of 3.4 ms apart.  A chunk with more than one such byte in 64 (lower-case reads)
              * goes up as bytes.  LF_UPLOAD_PACKED=0: always bytes. */
-            const int packed_on = !(getenv("LF_UPLOAD_PACKED") && atoi(getenv("LF_UPLOAD_PACKED")) == 0);
+            const int packed_on = lf_env_long("LF_UPLOAD_PACKED", 1) != 0;
             int packed = 0;
             if (packed_on && !cx->host_vote && cx->pre && cx->pre->min_read_len == cx->p->min_read_len) {
                 /* the batch was packed when it was made (lf_batch.h): this chunk's planes are a bit range of the batch's -- nothing to do on the host but
@@ -325,7 +325,7 @@ int map_chunk(ctx_t *cx)
                     tmark(cx, "pack");
                     if (!cx->pk_overflow) {
                         lf_packed_src_t pk; memset(&pk, 0, sizeof pk); pk.planes = planes; pk.qw = qw; pk.exc_pos = xpos; pk.exc_byte = xbyte; pk.n_exc = cx->pk_xn;
-                        if (getenv("LF_TIMING")) fprintf(stderr, "[lf] pack %.1f ms, %llu bytes outside ACGT\n", now_ms() - tc0, (unsigned long long)pk.n_exc);
+                        if (lf_env_set("LF_TIMING")) fprintf(stderr, "[lf] pack %.1f ms, %llu bytes outside ACGT\n", now_ms() - tc0, (unsigned long long)pk.n_exc);
                         tc0 = now_ms();
                         rc = lfg_seed_packed(cx->ix, cx->p, m, &pk, off, cx->host_vote, &hits);
                         packed = 1;
@@ -335,13 +335,13 @@ int map_chunk(ctx_t *cx)
             if (!packed) {
             { pthread_mutex_lock(&concat_turn); parallel_for(cx, m, phase_concat); pthread_mutex_unlock(&concat_turn); }
             tmark(cx, "concat");
-            if (getenv("LF_TIMING")) fprintf(stderr, "[lf] concat %.1f ms\n", now_ms() - tc0);
+            if (lf_env_set("LF_TIMING")) fprintf(stderr, "[lf] concat %.1f ms\n", now_ms() - tc0);
             tc0 = now_ms();
             rc = lfg_seed(cx->ix, cx->p, m, cat, off, cx->host_vote, &hits);
             }
             }
             tmark(cx, "SEED");
-            if (getenv("LF_TIMING")) fprintf(stderr, "[lf] lfg_seed %.1f ms (search %.1f locate %.1f), %llu hits\n", now_ms() - tc0, hits.ms_search, hits.ms_locate, (unsigned long long)hits.n_hits);
+            if (lf_env_set("LF_TIMING")) fprintf(stderr, "[lf] lfg_seed %.1f ms (search %.1f locate %.1f), %llu hits\n", now_ms() - tc0, hits.ms_search, hits.ms_locate, (unsigned long long)hits.n_hits);
             if (rc != LF_OK) { free(map); return rc; }
             /* the vote stage sorts 2 keys per hit with 31-bit indices: a chunk above the limit is cut in two by the
              * caller and mapped again (the reference has no such limit; it must stay an implementation detail) */

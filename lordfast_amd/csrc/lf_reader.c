@@ -138,7 +138,7 @@ int lf_reads_open(const char *path, lf_reads_t **out)
     struct lf_reads *r = (struct lf_reads *)calloc(1, sizeof *r);
     r->fp = fp; r->buf = (unsigned char *)malloc(LF_RBUF);
     snprintf(r->path, sizeof r->path, "%s", path);
-    if (!getenv("LF_READER_SEQUENTIAL")) {
+    if (!lf_env_set("LF_READER_SEQUENTIAL")) {
         /* a regular file: map it and look at the first bytes (of the text, for gzip) */
         const int fd = open(path, O_RDONLY);
         struct stat sb;
@@ -174,7 +174,7 @@ static void blob_pool_trim(void);
 void lf_reads_close(lf_reads_t *r)
 {
     if (!r) return;
-    if (getenv("LF_TIMING") && r->inflate_cpu_s > 0) fprintf(stderr, "[lf] reader %s: %.2f CPU-s in inflate (%s)\n", r->path, r->inflate_cpu_s, r->src == 1 ? "BGZF blocks, several threads" : "one gzip stream, one thread");
+    if (lf_env_set("LF_TIMING") && r->inflate_cpu_s > 0) fprintf(stderr, "[lf] reader %s: %.2f CPU-s in inflate (%s)\n", r->path, r->inflate_cpu_s, r->src == 1 ? "BGZF blocks, several threads" : "one gzip stream, one thread");
     blob_pool_reader(-1);                       /* the last open reader takes the cached blobs with it (batches freed after that are freed, not cached) */
     if (r->zs_live) inflateEnd(&r->zs);
     if (r->map) munmap((void *)r->map, r->map_size);
@@ -553,7 +553,6 @@ static int lf_reads_next_window(lf_reads_t *r, int max_reads, uint64_t max_bases
         for (int t = 1; t < nt; t++) { if (started[t]) pthread_join(th[t], NULL); else if (M[t].p < M[t].end) piece_main(&M[t]); }
         int weird = 0, total = 0;
         for (int t = 0; t < nt; t++) { weird |= M[t].weird; total += M[t].nrec; }
-        if (getenv("LF_READER_DEBUG")) { fprintf(stderr, "[lf reader] window %zu bytes, %d pieces, %d records, weird %d, at_eof %d:", (size_t)(e - a), nt, total, weird, at_eof); for (int t = 0; t < nt; t++) fprintf(stderr, " %zu/%d", (size_t)(M[t].end - M[t].p), M[t].nrec); fprintf(stderr, "\n"); }
         /* a piece that stopped early (open end) must be the last one with any text */
         for (int t = 0; t + 1 < nt; t++) if (M[t].p < M[t].end && M[t].consumed != (size_t)(M[t].end - a)) { int later = 0; for (int u = t + 1; u < nt; u++) later |= M[u].p < M[u].end; if (later) weird = 1; }
         if (weird) {
@@ -765,7 +764,7 @@ int lf_map_file_multi(const lf_index_t *const *idx, int n_idx, const lf_params_t
         obuf[0] = (char *)lfg_host_alloc(cap_all); ocap[0] = obuf[0] ? cap_all : 0;
         have_a = pthread_create(&ath, NULL, palloc_main, &PA) == 0;
     }
-    const int ftiming = getenv("LF_TIMING") != NULL;
+    const int ftiming = lf_env_set("LF_TIMING");
     for (int k = 0;; k++) {
         const double tq0 = ftiming ? wall_ms() : 0;
         pthread_mutex_lock(&A.mu);

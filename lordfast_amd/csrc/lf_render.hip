@@ -364,7 +364,7 @@ extern "C" int lfg_render(const struct lf_index *ix, int n_dev_recs, const void 
         HIPCHK(hipMemcpyAsync(d_items + n_dev_items, items, (size_t)n_host_items * sizeof(lf_ritem_t), hipMemcpyHostToDevice, s));
     }
     HIPCHK(hipEventRecord(e0, s));
-    const bool single = dev_text != nullptr && !getenv("LF_RENDER_TWO_PASS");      /* the two-pass form stays for the host-side consumers (packed text) */
+    const bool single = dev_text != nullptr;      /* the two-pass form stays for the host-side consumers (packed text) */
     uint32_t *d_caps = single ? (uint32_t *)lfg_dev_slot(device, LF_DS_RENDER0 + 6, (size_t)n_recs * 8) : d_lens;
     if (!d_caps) return LF_ERR_NOMEM;
     if (single) hipLaunchKernelGGL(lf_render_caps_kernel, dim3((unsigned)((n_recs + 3) / 4)), dim3(256), 0, s, d_recs, n_recs, d_items, d_caps);

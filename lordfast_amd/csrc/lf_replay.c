@@ -182,7 +182,7 @@ static int need_ksw(walk_t *w, int set, int qrc, uint32_t qs, uint32_t qseg, int
     memo_t *m = memo_find(w->job, &k);
     if (!m) {
         /* LF_KSW_ONE_PER_ROUND=1 (A / B, read per request: a miss is rare): round 4's behaviour, a walk asks for ONE extension and stops asking */
-        if (w->bail && getenv("LF_KSW_ONE_PER_ROUND") && atoi(getenv("LF_KSW_ONE_PER_ROUND")) != 0) return 0;
+        if (w->bail && lf_env_long("LF_KSW_ONE_PER_ROUND", 0) != 0) return 0;
         m = memo_add(w->job, &k, &w->cx->arena[w->tid]); stage_ksw(w, m); jv_push(&w->cx->ksw_jobs[w->tid], w->job);
     }
     if (m->round < 0) { w->bail = 1; w->build = 0; return 0; }

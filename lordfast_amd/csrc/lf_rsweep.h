@@ -18,5 +18,4 @@ static inline uint64_t lf_plane_words(uint64_t n_bytes) { return (n_bytes + 63) 
 void lf_rsweep_pack_planes(hipStream_t s, const unsigned char *d_src, uint64_t n_bytes, uint64_t *d_planes, uint64_t n_words, unsigned long long *lower_flag = nullptr);
 void lf_rsweep_pack_pac(hipStream_t s, const unsigned char *d_src, uint64_t n_bytes, uint8_t *d_pac);
 void lf_rsweep_launch(hipStream_t s, bool track, lf_rsw_args A);
-void lf_small_launch(hipStream_t s, bool track, lf_rsw_args A);      /* waves of small problems (lf_edlib_common.h: LF_SMALL_*): forward + traceback in one wavefront, rows in LDS */
 #endif

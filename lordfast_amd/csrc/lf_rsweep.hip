@@ -73,19 +73,11 @@ __global__ void lf_pack_pac_kernel(const unsigned char *__restrict__ src, uint64
     pac[b] = (uint8_t)v;
 }
 
-/* SMALL (lf_edlib_small_kernel): the wavefront's problems have at most LF_SMALL_NB blocks and LF_SMALL_M target columns -- four checkpoint
- * rows, kept in LDS together with the planes; when the sweep is done lane g walks the path of the wavefront's problem g out of them
- * (lf_tb_core.h), with the forward pass's match masks.  Nothing of these problems but their paths touches HBM. */
-#define LF_SMALL_HK 4
-template <bool TRACK, bool SMALL>
+template <bool TRACK>
 __device__ __forceinline__ void lf_rsweep_body(const lf_rsw_args &A)
 {
     __shared__ uint64_t s_peq[4 * 64];
     __shared__ int s_part[64];
-    __shared__ lf_hist_t s_rows[SMALL ? LF_SMALL_ROWS * LF_RROW : 1];
-    __shared__ uint64_t s_planes[SMALL ? 3 * 64 : 1];
-    __shared__ int s_tl[SMALL ? 64 : 1];
-    __shared__ ulonglong2 s_tile[SMALL ? LF_SMALL_HK * 64 : 1];
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= A.n_waves) return;
     /* the segments are sorted by blocks per problem and target length, ascending: handed out from the END, the long sweeps start first and the
@@ -120,15 +112,9 @@ __device__ __forceinline__ void lf_rsweep_body(const lf_rsw_args &A)
     }
     const bool ck_on = live && pr.task == LF_TASK_PATH;
     const bool any_ck = lf_any(ck_on);
-    lf_hist_t *ck;
-    if constexpr (SMALL) {
-        if (any_ck) { s_planes[lane] = lo; s_planes[64 + lane] = hi; s_planes[128 + lane] = valid; }
-        ck = s_rows;
-    } else {
-        lf_hist_t *wbase = A.ckpt + W.hist_base;
-        if (any_ck) { uint64_t *pl = reinterpret_cast<uint64_t *>(wbase); pl[lane] = lo; pl[64 + lane] = hi; pl[128 + lane] = valid; }
-        ck = wbase + LF_PLANE_ENTRIES;
-    }
+    lf_hist_t *wbase = A.ckpt + W.hist_base;
+    if (any_ck) { uint64_t *pl = reinterpret_cast<uint64_t *>(wbase); pl[lane] = lo; pl[64 + lane] = hi; pl[128 + lane] = valid; }
+    lf_hist_t *ck = wbase + LF_PLANE_ENTRIES;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 
     const uint32_t lastb = (n - 1) >> 6; const int lastbit = (int)((n - 1) & 63);
@@ -195,26 +181,11 @@ __device__ __forceinline__ void lf_rsweep_body(const lf_rsw_args &A)
         int tl = (int)m;
         if (TRACK && pr.mode != 0) { ed = b_ed; tl = b_c; }
         A.out_ed[pr.id] = ed; A.out_end[pr.id] = tl - 1;
-        if constexpr (SMALL) s_tl[g] = tl;
-    }
-    if constexpr (SMALL) {
-        if (!any_ck) return;                                   /* (wave-uniform) distances only */
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-        /* lane g: the path of the wavefront's problem g (its blocks were lanes g * G ...) */
-        const bool mine2 = lane < (int)W.count;
-        const lf_aln_prob p2 = A.probs[W.first + (mine2 ? (uint32_t)lane : 0u)];
-        uint32_t len = 0;
-        lf_tb_core<LF_SMALL_HK, true>(p2, mine2 && p2.task == LF_TASK_PATH, (uint32_t)s_tl[mine2 ? lane : 0], (mine2 ? lane : 0) * G, lane, s_rows, s_planes, s_peq, s_tile,
-                                      A.pac, A.pac_syms, A.ops, len);
-        if (mine2) A.out_len[p2.id] = len;
     }
 }
 template <bool TRACK>
 __global__ void __launch_bounds__(64)
-lf_edlib_rsweep_kernel(lf_rsw_args A) { lf_rsweep_body<TRACK, false>(A); }
-template <bool TRACK>
-__global__ void __launch_bounds__(64)
-lf_edlib_small_kernel(lf_rsw_args A) { lf_rsweep_body<TRACK, true>(A); }
+lf_edlib_rsweep_kernel(lf_rsw_args A) { lf_rsweep_body<TRACK>(A); }
 
 void lf_rsweep_pack_planes(hipStream_t s, const unsigned char *d_src, uint64_t n_bytes, uint64_t *d_planes, uint64_t n_words, unsigned long long *lower_flag)
 {
@@ -225,12 +196,6 @@ void lf_rsweep_pack_pac(hipStream_t s, const unsigned char *d_src, uint64_t n_by
 {
     const uint64_t nb = (n_bytes + 64 + 3) / 4;
     hipLaunchKernelGGL(lf_pack_pac_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, d_src, n_bytes, d_pac);
-}
-void lf_small_launch(hipStream_t s, bool track, lf_rsw_args A)
-{
-    if (A.n_waves <= 0) return;
-    if (track) hipLaunchKernelGGL((lf_edlib_small_kernel<true>), dim3((unsigned)A.n_waves), dim3(64), 0, s, A);
-    else hipLaunchKernelGGL((lf_edlib_small_kernel<false>), dim3((unsigned)A.n_waves), dim3(64), 0, s, A);
 }
 void lf_rsweep_launch(hipStream_t s, bool track, lf_rsw_args A)
 {

@@ -256,20 +256,14 @@ static void fetch_dev_sam(batch_t *B, const lf_index_t *ix, uint64_t base, uint6
 {
     if (B->rc != LF_OK) { free(fill); return; }
     const double t0 = now_ms();
-    static int timing = -1; if (timing < 0) timing = getenv("LF_TIMING") != NULL;
+    static int timing = -1; if (timing < 0) timing = lf_env_set("LF_TIMING");
     out_reserve(B, base, tot);
     if (B->rc == LF_OK) {               /* one D2H copy of the chunk's text straight into its place */
         /* a caller-provided buffer never moves: the copy runs behind the lane's back (lfg_sam_fetch_wait at the lane's end);
          * a growable one may be reallocated by another lane, so the copy completes under the read lock */
-        /* A chunk's place in the output is known when every earlier chunk has its size, so the chunks behind a late one are
-         * released together: the last 17 ms of a 96 ms step (under the profiler) are five scatter kernels sharing the link at
-         * 37 GB/s where one moves 53 (profiles/r04_waits/).  LF_EGRESS_TURNS=1 lets them go one at a time, each with its own host
-         * fill beside it: measured equal (86.8 / 91.4 against 86.8 / 87.4 ms per step), so it is off. */
-        static pthread_mutex_t egress_turn = PTHREAD_MUTEX_INITIALIZER;
-        static int turns = -1;
-        if (turns < 0) turns = getenv("LF_EGRESS_TURNS") && atoi(getenv("LF_EGRESS_TURNS")) != 0;
-        const int my_turn = turns && B->fixed_out && n_fill > 0;
-        if (my_turn) pthread_mutex_lock(&egress_turn);
+        /* (A chunk's place in the output is known when every earlier chunk has its size, so the chunks behind a late one are released together and their
+         * scatter kernels share the link.  Letting them go one at a time measured equal -- 86.8 / 91.4 against 86.8 / 87.4 ms per step, profiles/r04_waits/ --
+         * and is not in the tree.) */
         const int frc = B->fixed_out ? lfg_sam_fetch_async(ix, B->all.s + base, tot, parity) : lfg_sam_fetch(ix, B->all.s + base, tot, parity);
         if (frc != LF_OK) { snprintf(B->err, sizeof B->err, "%s", lf_last_error()); B->rc = frc; }
         else if (n_fill > 0) {          /* the holes, while the scatter kernel moves the rest over the link */
@@ -277,7 +271,6 @@ static void fetch_dev_sam(batch_t *B, const lf_index_t *ix, uint64_t base, uint6
             fx.lane = lane; fx.n_threads = B->slots; fx.fill = fill; fx.n_fill = n_fill; fx.out_base = B->all.s + base;
             parallel_for(&fx, n_fill, phase_fill);
         }
-        if (my_turn) { if (frc == LF_OK) (void)lfg_sam_fetch_wait(ix); pthread_mutex_unlock(&egress_turn); }
     }
     pthread_rwlock_unlock(&B->grow);
     free(fill);
@@ -291,12 +284,12 @@ static void *lane_main(void *arg_)
     const int held = (int)(intptr_t)((void **)arg_)[1];
     const int lane = held ? held - 1 : lane_acquire(B->lane_cap, &B->next_chunk, B->n_chunks0);
     if (lane < 0) return NULL;
-    const int timing = getenv("LF_TIMING") != NULL;
+    const int timing = lf_env_set("LF_TIMING");
     lfg_set_lane(lane);
     const long long lane_c0 = g_phase_on ? thread_cpu_ns() : 0;
     lf_stats_t *st = &B->st[lane];
     uint64_t max_hits = 1ull << 30;
-    if (getenv("LF_MAX_CHUNK_HITS")) { max_hits = strtoull(getenv("LF_MAX_CHUNK_HITS"), NULL, 10); if (max_hits < 1) max_hits = 1; }   /* test hook */
+    if (lf_env_set("LF_MAX_CHUNK_HITS")) { max_hits = strtoull(lf_env("LF_MAX_CHUNK_HITS"), NULL, 10); if (max_hits < 1) max_hits = 1; }   /* test hook */
     int todo[66], n_todo = 0;                       /* second halves of chunks this lane had to cut */
     pending_t pend; memset(&pend, 0, sizeof pend);
     int parity = 0;
@@ -540,8 +533,7 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
      * for its size -- and with four 25 k-read chunks that one chunk is a quarter of the batch: 85.6 / 103.0 ms against 84.1 / 88.1 with eight,
      * same box, at equal host CPU: profiles/r05_lanes/) */
     int n_lanes = nt >= 4 ? ((dio && !dio->stage_sink) ? 4 : 8) : nt;
-    if (getenv("LF_LANES")) { n_lanes = atoi(getenv("LF_LANES")); if (n_lanes < 1) n_lanes = 1; if (n_lanes > LF_MAX_LANES) n_lanes = LF_MAX_LANES; }
-    if (getenv("LF_ONE_LANE")) n_lanes = 1;
+    if (lf_env_set("LF_LANES")) { n_lanes = (int)lf_env_long("LF_LANES", n_lanes); if (n_lanes < 1) n_lanes = 1; if (n_lanes > LF_MAX_LANES) n_lanes = LF_MAX_LANES; }
     if (n_ix > 1) {
         /* several devices: LF_LANES / the default is per device (capped by LF_MAX_LANES and the thread budget); every
          * device gets at least one lane.  Lanes pull chunks from one shared counter, so the devices balance themselves. */
@@ -552,7 +544,7 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     if (nw < nt / 2) nw = nt / 2;                      /* few threads, many (mostly sleeping) drivers: keep half the budget as workers */
     if (nw > 220) nw = 220;                            /* worker ids: pool threads, then one per lane id (< 260 in all) */
     pthread_mutex_lock(&g_lanes_mu);
-    if (g_active_calls == 0 || !g_pool.started) { g_phase_on = getenv("LF_PHASES") != NULL; pool_ensure(nw); }
+    if (g_active_calls == 0 || !g_pool.started) { g_phase_on = lf_env_set("LF_PHASES"); pool_ensure(nw); }
     else nw = g_pool.nw;                               /* another batch is being mapped: the pool keeps its size */
     g_active_calls++;
     pthread_mutex_unlock(&g_lanes_mu);
@@ -572,7 +564,7 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     else str_init(&B.all);
     /* SEQ-less egress: the caller's reads are host strings (we can print SEQ / QUAL ourselves) and its output buffer is pinned host
      * memory that kernels of every device can store into.  LF_SAM_FULL=1 keeps the whole line on the device (A / B measurements). */
-    if (ext_buf && !dio && seqs && !getenv("LF_SAM_FULL")) {
+    if (ext_buf && !dio && seqs && !lf_env_set("LF_SAM_FULL")) {
         B.holes = 1;
         for (int d = 0; d < n_ix; d++) if (!lfg_host_mapped(ixs[d]->device, ext_buf, ext_cap)) B.holes = 0;
     }
@@ -601,12 +593,12 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
         for (int i = 0; i < n; i++) est += 2 * (uint64_t)lens[i] + 640;
         if (!ext_buf) str_room(&B.all, est + est / 8);
     }
-    if (getenv("LF_TIMING")) fprintf(stderr, "[lf] setup (strlen + SAM buffer) %.1f ms, %d lanes, %d pool workers\n", now_ms() - T0, n_lanes, nw);
+    if (lf_env_set("LF_TIMING")) fprintf(stderr, "[lf] setup (strlen + SAM buffer) %.1f ms, %d lanes, %d pool workers\n", now_ms() - T0, n_lanes, nw);
     /* chunks bound the device + host working set; reads stay in input order */
     uint64_t CHUNK_BASES = 400ull << 20;
-    if (getenv("LF_CHUNK_BASES")) { CHUNK_BASES = strtoull(getenv("LF_CHUNK_BASES"), NULL, 10); if (CHUNK_BASES < 1) CHUNK_BASES = 1; }      /* measurement hook: bench.py's exclusive pass maps the whole batch as ONE chunk */
+    if (lf_env_set("LF_CHUNK_BASES")) { CHUNK_BASES = strtoull(lf_env("LF_CHUNK_BASES"), NULL, 10); if (CHUNK_BASES < 1) CHUNK_BASES = 1; }      /* measurement hook: bench.py's exclusive pass maps the whole batch as ONE chunk */
     int CHUNK_READS = 32768;
-    if (getenv("LF_CHUNK_READS")) { CHUNK_READS = atoi(getenv("LF_CHUNK_READS")); if (CHUNK_READS < 1) CHUNK_READS = 1; }   /* test hook */
+    if (lf_env_set("LF_CHUNK_READS")) { CHUNK_READS = (int)lf_env_long("LF_CHUNK_READS", CHUNK_READS); if (CHUNK_READS < 1) CHUNK_READS = 1; }   /* test hook */
     else if (n_lanes >= 2 && n > 2048) {
         /* Chunks per lane.  Reads already in HBM (lf_map_batch_dev): ONE -- nothing of a chunk waits for a bus, the lanes only
          * overlap each other's host phases, and larger chunks fill the GPU better with fewer launches (100 k reads, 8 lanes, chunks
@@ -622,7 +614,6 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
         /* (with the lanes' uploads taking turns, lf_seed.hip: ONE chunk per lane for pinned host batches too -- 6250 / 8334 / 12500
          * reads per chunk: 99.4 / 97.5 / 96.0 ms per 100 k reads) */
         int per_lane = (dev_in || B.holes) ? 1 : 3;
-        if (B.holes && getenv("LF_CHUNKS_PER_LANE")) { per_lane = atoi(getenv("LF_CHUNKS_PER_LANE")); if (per_lane < 1) per_lane = 1; if (per_lane > 4) per_lane = 4; }      /* experiment hook */
         const int min_chunk = (dev_in || B.holes) ? 6250 : 1024;
         int want = (n + per_lane * n_lanes - 1) / (per_lane * n_lanes); if (want < min_chunk) want = min_chunk;
         if (want < CHUNK_READS) CHUNK_READS = want;
@@ -630,27 +621,20 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     /* reads x sampling positions is a 31-bit index in the seed stage */
     { const long long cap = (1ll << 30) / (p->sampling_count > 0 ? p->sampling_count : 1); if (cap < CHUNK_READS) CHUNK_READS = cap < 1 ? 1 : (int)cap; }
     B.chunks = (chunk_t *)calloc((size_t)n + 1, sizeof(chunk_t));
-    /* Host batches: every lane's first chunk waits for its bases to be concatenated and to cross the link, all lanes at once
-     * (8 x 96 MB at 57 GB/s: the GPU idles for the first ~20 ms of a step).  LF_FIRST_CHUNK_READS makes the first round's
-     * chunks small so that the kernels start earlier (experiment: the small chunks' fixed costs ate the gain). */
-    int first_reads = 0;         /* measured (100 k reads, host boundary): no ramp 109.5 ms, a third of a chunk 115.0, 1 024 reads 111.1 -- off; the uploads take turns instead (lf_seed.hip) */
-    if (getenv("LF_FIRST_CHUNK_READS")) first_reads = atoi(getenv("LF_FIRST_CHUNK_READS"));
+    /* (Small first-round chunks, so that the kernels start while the bulk of the bases still crosses the link, were measured and are not in the tree: no ramp
+     * 109.5 ms, a third of a chunk 115.0, 1 024 reads 111.1 -- the small chunks' fixed costs ate the gain; the lanes' uploads take turns instead, lf_seed.hip.) */
     /* Pinned host batches, one chunk per lane: the chunks GROW along the batch.  A chunk's place in the output is the sum of the sizes of
      * the chunks in front of it; with equal chunks the lanes finish together, in any order, and the SAM text of all of them crosses the
      * link at the very end (17 ms of an 88 ms step, profiles/r04_waits/).  With chunk k about (1 + ramp (2 k / (L - 1) - 1)) times the mean
-     * the lanes finish in chunk order: every chunk but the last leaves while the larger ones are still being mapped.  LF_CHUNK_RAMP=<percent>. */
+     * the lanes finish in chunk order: every chunk but the last leaves while the larger ones are still being mapped. */
     double ramp = 0.0;
-    int n_ramp = n_lanes;                                /* chunks of the ramp: one per lane (LF_CHUNKS_PER_LANE: more) */
-    if (B.holes && !getenv("LF_CHUNK_READS") && n_lanes >= 2 && n > 2048 && (n + n_lanes - 1) / n_lanes >= 6250) {
-        ramp = getenv("LF_CHUNK_RAMP") ? atof(getenv("LF_CHUNK_RAMP")) / 100.0 : LF_CHUNK_RAMP_DEFAULT;
-        if (ramp < 0) ramp = 0; if (ramp > 0.9) ramp = 0.9;
-        if (getenv("LF_CHUNKS_PER_LANE")) { int pl = atoi(getenv("LF_CHUNKS_PER_LANE")); if (pl < 1) pl = 1; if (pl > 4) pl = 4; n_ramp = n_lanes * pl; }
-    }
+    const int n_ramp = n_lanes;                          /* chunks of the ramp: one per lane */
+    if (B.holes && !lf_env_set("LF_CHUNK_READS") && n_lanes >= 2 && n > 2048 && (n + n_lanes - 1) / n_lanes >= 6250) ramp = LF_CHUNK_RAMP_DEFAULT;
     /* One chunk per lane (reads resident in HBM, or a pinned host batch): the chunks are cut by BASES -- equal shares (a lane's time goes with
      * its bases, not its reads), times the ramp for host batches -- and there are exactly as many as lanes (or as the working-set bound asks
      * for): with four lanes a cut by read count left a fifth, tiny chunk behind the four large ones. */
     int by_bases = 0;
-    if (!getenv("LF_CHUNK_READS") && !getenv("LF_CHUNK_BASES") && !getenv("LF_CHUNKS_PER_LANE") && first_reads == 0 && n_lanes >= 2 && n > 2048 && ((dio && !dio->stage_sink) || B.holes)) {
+    if (!lf_env_set("LF_CHUNK_READS") && !lf_env_set("LF_CHUNK_BASES") && n_lanes >= 2 && n > 2048 && ((dio && !dio->stage_sink) || B.holes)) {
         int *ends = (int *)malloc(((size_t)n + 1) * sizeof(int));
         const int nck = ends ? lf_cut_chunks_by_bases(lens, n, n_lanes, ramp, p->sampling_count, ends, n + 1) : 0;
         for (int k = 0, i0 = 0; k < nck; k++) { B.chunks[B.n_chunks].i0 = i0; B.chunks[B.n_chunks].i1 = ends[k]; B.n_chunks++; i0 = ends[k]; }
@@ -660,7 +644,7 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     }
     for (int i0 = 0; i0 < n && !by_bases; ) {
         int i1 = i0; uint64_t bases = 0;
-        int lim = (first_reads > 0 && B.n_chunks < n_lanes) ? first_reads : CHUNK_READS;
+        int lim = CHUNK_READS;
         if (ramp > 0) {
             const int k = B.n_chunks;
             if (k >= n_ramp - 1) lim = n - i0;                          /* the last chunk takes what is left */
@@ -675,8 +659,8 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     /* LF_WATCHDOG=<seconds>: a batch that takes longer reports where every lane is and aborts (tests set it: a hang
      * becomes a failure with a location) */
     wdog_t wd; memset(&wd, 0, sizeof wd); pthread_t wdt; int have_wd = 0;
-    if (getenv("LF_WATCHDOG") && atoi(getenv("LF_WATCHDOG")) > 0) {
-        wd.limit_s = atoi(getenv("LF_WATCHDOG")); pthread_mutex_init(&wd.mu, NULL); pthread_cond_init(&wd.cv, NULL);
+    if (lf_env_long("LF_WATCHDOG", 0) > 0) {
+        wd.limit_s = (int)lf_env_long("LF_WATCHDOG", 0); pthread_mutex_init(&wd.mu, NULL); pthread_cond_init(&wd.cv, NULL);
         have_wd = pthread_create(&wdt, NULL, wdog_main, &wd) == 0;
     }
     void *la[LF_MAX_LANES][2]; pthread_t lt[LF_MAX_LANES]; int have[LF_MAX_LANES] = { 0 };
@@ -695,7 +679,7 @@ static int map_batch_core(const lf_index_t *const *ixs, int n_ix, const lf_param
     free(lens); free(B.chunks);
     pthread_mutex_destroy(&B.mu); pthread_cond_destroy(&B.cv); pthread_rwlock_destroy(&B.grow);
     st->ms_total = now_ms() - T0;
-    if (getenv("LF_TIMING")) fprintf(stderr, "[lf] lf_map_batch total %.1f ms\n", st->ms_total);
+    if (lf_env_set("LF_TIMING")) fprintf(stderr, "[lf] lf_map_batch total %.1f ms\n", st->ms_total);
     if (B.rc != LF_OK) { lf_set_error("%s", B.err); if (!ext_buf) free(B.all.s); return B.rc; }
     if (!B.dev_out) B.all.s[total] = 0;
     if (sam) *sam = B.all.s;

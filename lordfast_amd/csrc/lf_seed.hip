@@ -133,7 +133,7 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
     /* The chunk drivers wait for the GPU many times per chunk.  HIP's default wait spins on the CPU; with eight drivers
      * that burns half of a 16-CPU quota.  Blocking waits give those cores to the worker pool (LF_SPIN_WAIT=1 keeps
      * the default). */
-    if (!getenv("LF_SPIN_WAIT")) { (void)hipSetDevice(ix->device); (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
+    { (void)hipSetDevice(ix->device); (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
 
     HIPCHK(hipSetDevice(ix->device));
     lfg_quiesce(ix->device);                 /* the hipMallocs below synchronise the device: see lf_mem.hip */
@@ -164,7 +164,7 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
         st->cache = tab;
         v.cache = tab;
         /* a 14-mer table pays when it is not larger than the text itself (LF_WIDE_TABLE=0/1 overrides) */
-        const char *wt = getenv("LF_WIDE_TABLE");
+        const char *wt = lf_env("LF_WIDE_TABLE");
         if (wt ? atoi(wt) != 0 : ix->seq_len >= (1ull << 28)) {
             rc = lfg_build_cache_table(&v, st->stream, 14, &tab);
             if (rc == LF_OK) rc = lfg_pack_cache_table(st->stream, 14, tab);
@@ -174,7 +174,7 @@ extern "C" int lfg_index_upload(struct lf_index *ix, const uint32_t *bwt, const 
         /* the 16-mer table (68.7 GB + 17 GB while it is built): only where it leaves the batch buffers plenty of room.  On a
          * human-size text three 16-mers in four occur somewhere, so most samples start their search four steps later.
          * LF_TABLE16=0/1 overrides. */
-        const char *t16 = getenv("LF_TABLE16");
+        const char *t16 = lf_env("LF_TABLE16");
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         const size_t need16 = (((size_t)1 << 32) + ((size_t)1 << 30)) * 16 + ((size_t)8 << 30);
@@ -761,7 +761,7 @@ static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_r
      * writer (which reads the buffers the upload overwrites), and that wait must not be spent holding the turn. */
     static std::mutex upload_turns[64];
     std::mutex &upload_turn = upload_turns[dv & 63];
-    static const bool turns = !(getenv("LF_UPLOAD_TURNS") && atoi(getenv("LF_UPLOAD_TURNS")) == 0);
+    const bool turns = true;       /* (the lanes' uploads take turns: 99.4 against 106.6 ms per step without, profiles/r04_pcie/) */
     if (pk) {
         /* the batch arrives as bit planes (3 / 8 of the bytes): they are what the alignment kernels want anyway; the seed search
          * and the SAM writer get the bytes back from them */
@@ -824,14 +824,10 @@ static int lfg_seed_any(const struct lf_index *ix, const lf_params_t *p, int n_r
          * seeding is case-insensitive, the bit planes are not) decides which of them works */
         const uint32_t rpw = hc >= LF_SEARCH_MIN_SPAN ? 1u : (LF_SEARCH_MIN_SPAN + hc - 1) / hc;
         const unsigned waves = (unsigned)(((uint32_t)n_reads + rpw - 1) / rpw), blocks = (waves + 3) / 4;
-        static const int slots = getenv("LF_SEARCH_SLOTS") ? atoi(getenv("LF_SEARCH_SLOTS")) : 1;
+        /* one search per lane (two / three per lane measured equal, 9.96 / 10.5 against 10.2 ms: a slot costs as many registers as a wavefront does) */
 #define LF_SEARCH_LAUNCH(SS, PL) hipLaunchKernelGGL((lf_seed_search_kernel<SS, PL>), dim3(blocks), dim3(256), 0, s, st->view, n_reads, d_reads, (const uint64_t *)d_planes, (int64_t)qw, \
                                                      d_off, hc, rpw, p->min_anchor_len, d_pos2, d_smp, d_counters)
-        if (slots == 1) { LF_SEARCH_LAUNCH(1, true); LF_SEARCH_LAUNCH(1, false); }
-        else if (slots == 3) { LF_SEARCH_LAUNCH(3, true); LF_SEARCH_LAUNCH(3, false); }
-        else if (slots == 4) { LF_SEARCH_LAUNCH(4, true); LF_SEARCH_LAUNCH(4, false); }
-        else if (slots == 2) { LF_SEARCH_LAUNCH(2, true); LF_SEARCH_LAUNCH(2, false); }
-        else { LF_SEARCH_LAUNCH(1, true); LF_SEARCH_LAUNCH(1, false); }
+        LF_SEARCH_LAUNCH(1, true); LF_SEARCH_LAUNCH(1, false);
 #undef LF_SEARCH_LAUNCH
     }
     HIPCHK(hipEventRecord(ev[1], s));

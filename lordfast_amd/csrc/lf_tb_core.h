@@ -1,7 +1,6 @@
 /* lf_tb_core.h -- one path per lane: the traceback of a problem of the one-block-per-lane forward kernel from its checkpoint rows
  * (lf_edlib_common.h: one row per 32 sweep steps).  Shared by lf_edlib_tb_kernel (lf_align.hip: rows and planes in HBM, 64 paths of 64
- * different problems) and by the fused small-problem kernel (lf_rsweep.hip: rows, planes and match masks still in the forward
- * pass's LDS).  gfx950 only.
+ * different problems).  gfx950 only.
  *
  * From (n, tl) the path is followed tile by tile: a tile = the 32 sweep steps of one checkpoint row, of the ONE block the cell is
  * in.  The lane takes that block's state in front of the row, the 32 carries the block received during it and the row's 32 target
@@ -17,9 +16,8 @@
 template <int I, int N, class F> __device__ __forceinline__ void lf_static_for(F &&f) { if constexpr (I < N) { f(std::integral_constant<int, I>{}); lf_static_for<I + 1, N>(f); } }
 template <int I, class F> __device__ __forceinline__ void lf_static_rfor(F &&f) { if constexpr (I >= 0) { f(std::integral_constant<int, I>{}); lf_static_rfor<I - 1>(f); } }
 
-/* FUSED: `ck`, `planes` and `s_peq` are the forward pass's own LDS arrays (match masks of forward lane l at s_peq[code * 64 + l]);
- * else they are this problem's data in HBM and s_peq is the lane's private table (rebuilt when the path changes block). */
-template <int HK, bool FUSED>
+/* `ck`, `planes`: this problem's checkpoint rows and bit planes in HBM; s_peq: the lane's private table of match masks (rebuilt when the path changes block). */
+template <int HK>
 __device__ __forceinline__ void lf_tb_core(const lf_aln_prob &pr, const bool want, const uint32_t tl, const int lane0, const int lane,
                                            const lf_hist_t *ck, const uint64_t *planes, uint64_t *s_peq, ulonglong2 *s_tile,
                                            const uint8_t *__restrict__ pac, const int64_t pac_syms, uint8_t *__restrict__ ops, uint32_t &path_len)
@@ -31,14 +29,11 @@ __device__ __forceinline__ void lf_tb_core(const lf_aln_prob &pr, const bool wan
     lf_emitter em; em.init(ops + pr.ops_off, n + m, want);
     uint32_t r = want ? n : 0, c = want ? tl : 0;
     uint64_t lo = 0, hi = 0, valid = 0;
-    int pq = lane;                                                      /* where the current block's match masks are: s_peq[code * 64 + pq] */
+    const int pq = lane;                                                /* where the current block's match masks are: s_peq[code * 64 + pq] */
     auto load_planes = [&](uint32_t b) {
         const int ln = lane0 + (int)b; lo = planes[ln]; hi = planes[64 + ln]; valid = planes[128 + ln];
-        if (FUSED) pq = ln;
-        else {
 #pragma unroll
-            for (uint32_t cde = 0; cde < 4; cde++) s_peq[cde * 64 + lane] = lf_eq_tok<true>(cde, lo, hi, valid, qget, n, b);      /* the lane's own slots: no barrier */
-        }
+        for (uint32_t cde = 0; cde < 4; cde++) s_peq[cde * 64 + lane] = lf_eq_tok<true>(cde, lo, hi, valid, qget, n, b);      /* the lane's own slots: no barrier */
     };
     uint32_t cur_b = r > 0 ? (r - 1) >> 6 : 0;
     load_planes(cur_b);

@@ -655,12 +655,11 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
         /* LDS table classes (load factor <= 2/3): tables of cells (lf_vote_cell_kernel: hits <= 2/3 cap) or, with LF_VOTE_SCAN=1 /
          * LF_VOTE_DEBUG (A / B runs; the scan kernel's per-phase cycle counters), of windows (lf_vote_hash_kernel: votes <= 2/3
          * cap).  Reads above the largest class keep a table of windows in a global scratch area. */
-        const bool vote_scan_env = getenv("LF_VOTE_SCAN") && atoi(getenv("LF_VOTE_SCAN")) != 0;
-        const bool vote_scan = vote_scan_env || getenv("LF_VOTE_DEBUG") != nullptr;
+        const bool vote_scan = lf_env_long("LF_VOTE_SCAN", 0) != 0;
         static const uint32_t caps[3] = { 4096, 8192, 16384 };
         static const uint32_t cell_caps[4] = { 2048, 4096, 8192, 16384 };
         uint64_t v_max_lds = vote_scan ? (uint64_t)caps[2] * 2 / 3 : 2 * ((uint64_t)cell_caps[3] * 2 / 3);      /* in votes = 2 x hits */
-        if (getenv("LF_VOTE_LDS_MAX_VOTES")) { const uint64_t x = strtoull(getenv("LF_VOTE_LDS_MAX_VOTES"), nullptr, 10); if (x < v_max_lds) v_max_lds = x; }   /* test hook: push reads to the global-table path */
+        if (lf_env_set("LF_VOTE_LDS_MAX_VOTES")) { const uint64_t x = strtoull(lf_env("LF_VOTE_LDS_MAX_VOTES"), nullptr, 10); if (x < v_max_lds) v_max_lds = x; }   /* test hook: push reads to the global-table path */
         const uint64_t *h_read_off = (const uint64_t *)lfg_pin_slot(LF_PS_HITS_OFF, 0);      /* lfg_seed left it there */
         uint64_t gtab_words = 0; std::vector<uint64_t> gtab_off;
         uint64_t v_max = 0;
@@ -686,7 +685,6 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
             attr_set[dv] = true;
         }
         unsigned long long *d_dbg = nullptr;
-        if (getenv("LF_VOTE_DEBUG")) { d_dbg = (unsigned long long *)VSLOT(20, 256); if (d_dbg) HIPCHK(hipMemsetAsync(d_dbg, 0, 128, s)); }
         uint64_t lo = 0;                                         /* in votes */
         if (!vote_scan) {
             /* hits per thread of a class: hits <= 2/3 cap <= H x LF_VOTE_THREADS */
@@ -813,7 +811,7 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
         {
             /* segmented sort in LDS: one wavefront per request up to 512 seeds (4 KiB), a 256-thread workgroup up to 8192 (64 KiB); above that
              * (LF_REQ_SORT_BIG_FROM lowers the bound: test hook) a 1024-thread workgroup over a scratch array in HBM */
-            const uint32_t big_from = getenv("LF_REQ_SORT_BIG_FROM") ? (uint32_t)atoi(getenv("LF_REQ_SORT_BIG_FROM")) : 8193u;
+            const uint32_t big_from = (uint32_t)lf_env_long("LF_REQ_SORT_BIG_FROM", 8193);
             const uint32_t lds_hi = big_from - 1u < 8192u ? big_from - 1u : 8192u;
             const uint32_t small_hi = max_n < 512u ? max_n : 512u, hi1 = lds_hi < 512u ? lds_hi : 512u;
             uint32_t cap1 = 64; while (cap1 < small_hi) cap1 <<= 1;

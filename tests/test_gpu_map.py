@@ -64,19 +64,6 @@ def test_sam_golden_with_the_large_request_sort(lf, golden_reads, cfg, monkeypat
     assert sam == exp, first_diff(sam, exp)
 
 
-def test_sam_golden_with_the_fused_small_problem_kernel(lf, golden_reads, monkeypatch):
-    """LF_SMALL_FUSED=1: problems of at most two query blocks and 127 target columns (more than half of all problems) run forward pass AND
-    traceback in one wavefront with their checkpoint rows in LDS (lf_edlib_small_kernel).  Off by default (measured slower: too few
-    wavefronts per SIMD); the records must be the same either way"""
-    import lordfast_amd as la
-    names, seqs = golden_reads
-    monkeypatch.setenv("LF_SMALL_FUSED", "1")
-    for cfg in ("default", "n30"):
-        sam, st = lf.map_batch(names, seqs, params=la.default_params(**GOLDEN_CONFIGS[cfg]))
-        exp = golden_sam(cfg)
-        assert sam == exp, first_diff(sam, exp)
-
-
 def test_satellite_array_reads_take_the_large_request_sort(tmp_path, oracle_lib):
     """a genome with a tandem satellite array (171 bp monomers, 27 kbp): a read out of the array hits it with every sample, so its
     candidate window's request holds thousands of seeds; records == oracle"""
