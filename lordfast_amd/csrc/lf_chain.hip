@@ -89,15 +89,9 @@ extern "C" int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, con
  * order; the stable sort by target start that the reference's qsort performs (src/Chain.cpp:94) is one device radix
  * sort on (window, tPos).  Kernel: lf_clasp_kernel.h.  chain_out[off[w] .. off[w] + chain_len[w]) receives the chain.
  * ------------------------------------------------------------------------------------------------------------- */
-#include <hipcub/hipcub.hpp>
+#include "lf_reqsort.h"
 #include "lf_clasp_kernel.h"
 
-static __global__ void lf_clasp_keys_kernel(int n_windows, const uint64_t *__restrict__ off, const uint2 *__restrict__ seeds, uint64_t *__restrict__ keys)
-{
-    const int w = blockIdx.x;
-    if (w >= n_windows) return;
-    for (uint64_t k = off[w] + threadIdx.x; k < off[w + 1]; k += blockDim.x) keys[k] = ((uint64_t)(uint32_t)w << 32) | seeds[k].x;
-}
 static __global__ void lf_clasp_gather_kernel(int n_windows, const uint64_t *__restrict__ off, const uint32_t *__restrict__ chain_idx,
                                               const uint32_t *__restrict__ chain_len, const uint2 *__restrict__ sorted, uint2 *__restrict__ chain_out)
 {
@@ -131,17 +125,19 @@ extern "C" int lfg_chain_clasp(int device, int n_windows, const Seed_t *seeds, c
         }
     }
 #define CSLOT(k, bytes) lfg_dev_slot(device, LF_DS_CHAIN0 + (k), (bytes))
-    int wbits = 1; while ((1ull << wbits) < (uint64_t)n_windows + 1) wbits++;
-    size_t tb = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (int)total, 0, 32 + wbits, (hipStream_t)0);
+    /* the windows' fragments in target order, stable (clasp's qsort is glibc's merge sort): the segmented sort of the pipeline (lf_reqsort.h) */
+    uint32_t max_n = 0;
+    std::vector<uint32_t> wn((size_t)n_windows + 1);
+    for (int i = 0; i < n_windows; i++) { wn[(size_t)i] = W[(size_t)i].n; if (W[(size_t)i].n > max_n) max_n = W[(size_t)i].n; }
+    const size_t tb = max_n > 8192u ? 2 * (size_t)total * 8 + 256 : 0;
     void *d_w = CSLOT(0, W.size() * sizeof(lf_chain_win)), *d_seeds = CSLOT(1, total * 8 + 16), *d_sorted = CSLOT(2, total * 8 + 16);
     void *d_ws = CSLOT(3, ws * LF_CLASP_BYTES_PER_FRAG + 16), *d_keys = CSLOT(4, total * 16 + 16), *d_idx = CSLOT(5, total * 4 + 16);
     /* the chain stage owns 8 slots: the three per-window arrays share one, sort scratch and output another */
     const size_t wpad = (((size_t)n_windows + 1) * 4 + 255) & ~(size_t)255, tpad = (tb + 511) & ~(size_t)255;
-    char *d_small = (char *)CSLOT(6, 2 * wpad + ((size_t)n_windows + 1) * 8), *d_big = (char *)CSLOT(7, tpad + total * 8 + 16);
+    char *d_small = (char *)CSLOT(6, 3 * wpad + ((size_t)n_windows + 1) * 8), *d_big = (char *)CSLOT(7, tpad + total * 8 + 16);
 #undef CSLOT
     if (!d_w || !d_seeds || !d_sorted || !d_ws || !d_keys || !d_idx || !d_small || !d_big) return LF_ERR_NOMEM;
-    void *d_len = d_small, *d_sc = d_small + wpad, *d_off = d_small + 2 * wpad, *d_tmp = d_big, *d_out = d_big + tpad;
+    void *d_len = d_small, *d_sc = d_small + wpad, *d_wn = d_small + 2 * wpad, *d_off = d_small + 3 * wpad, *d_tmp = d_big, *d_out = d_big + tpad;
     hipStream_t s = (hipStream_t)lfg_lane_stream(device, 15);
     if (!s) return LF_ERR_HIP;
     hipEvent_t e0 = (hipEvent_t)lfg_lane_event(device, 30), e1 = (hipEvent_t)lfg_lane_event(device, 31);
@@ -151,9 +147,11 @@ extern "C" int lfg_chain_clasp(int device, int n_windows, const Seed_t *seeds, c
     HIPCHK(hipMemcpyAsync(d_off, off, ((size_t)n_windows + 1) * 8, hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(e0, s));
     if (total) {
-        uint64_t *k1 = (uint64_t *)d_keys, *k2 = k1 + total;
-        hipLaunchKernelGGL(lf_clasp_keys_kernel, dim3((unsigned)n_windows), dim3(64), 0, s, n_windows, (const uint64_t *)d_off, (const uint2 *)d_seeds, k1);
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, k1, k2, (uint64_t *)d_seeds, (uint64_t *)d_sorted, (int)total, 0, 32 + wbits, s));
+        HIPCHK(hipMemcpyAsync(d_wn, wn.data(), (size_t)n_windows * 4, hipMemcpyHostToDevice, s));
+        const int src = lf_req_sort_launch(device, s, n_windows, (const uint64_t *)d_off, (const uint32_t *)d_wn, (const uint2 *)d_seeds, (uint2 *)d_sorted, (uint64_t *)d_keys, 1, max_n, 8193u,
+                                           tb ? (uint64_t *)d_tmp : nullptr);
+        if (src != LF_OK) return src;
+        HIPCHK(hipStreamSynchronize(s));          /* (wn lives on this function's stack frame) */
     }
     static const uint32_t CCAPS[5] = { 128, 256, 512, LF_CLASP_LDS_MAX, 0 };
     uint32_t lo = 0;

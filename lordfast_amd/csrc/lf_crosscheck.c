@@ -1,10 +1,13 @@
-/* lf_crosscheck.c -- host re-implementations of device stages, kept as CROSS-CHECKS for the tests.  They are reached through
+/* lf_crosscheck.c -- TEST LIBRARY (liblfxcheck.so), not part of liblfgpu.so: host re-implementations of device stages, kept as CROSS-CHECKS for the tests.  They are reached through
  * lf_debug_crosscheck() only (bit 0: vote / selection / std::sort, bit 1: CIGAR / MD strings -- the STREAM / TRACK builders live
  * with the replay in lf_replay.c --, bit 3: SAM line assembly) and work on data copied back from the device; nothing in a
  * production environment can select them. */
 #include "lf_pipe.h"
 
 void lf_sort_seeds_by_qpos(Seed_t *s, long n);
+int  crosscheck_vote_chain(ctx_t *cx);
+void phase_bind_text(ctx_t *cx, int tid, int ri);
+void phase_sam_print(ctx_t *cx, int tid, int ri);
 
 /* ================================================================ B: vote, candidates, selection */
 typedef struct { uint32_t win, cnt; } wc_t;
@@ -213,3 +216,10 @@ void phase_sam_print(ctx_t *cx, int tid, int ri)
     print_sam_entry(cx, r, r->mode < 2 ? 1 : (r->mode == 2 ? 1 : r->nWins));
 }
 
+
+/* liblfxcheck.so's entry point: lf_debug_crosscheck() (liblfgpu.so) calls it once */
+void lf_xcheck_install(void)
+{
+    lf_xc_hooks_t h; h.vote_chain = crosscheck_vote_chain; h.bind_text = phase_bind_text; h.sam_print = phase_sam_print;
+    lf_xc_register(&h);
+}

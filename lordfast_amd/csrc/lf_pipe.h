@@ -6,7 +6,7 @@
  *   lf_pipeline.c    one chunk through the stages (map_chunk): which kernel stage runs when, what the host decides in between
  *   lf_replay.c      alignChain_edlib (src/LordFAST.cpp:1765-2258) as a host REPLAY for the few chains that leave the device's common path
  *   lf_samdesc.c     printSamEntry (src/LordFAST.cpp:318-459): MAPQ, flags, SA:Z, one 48-byte descriptor per line; host fill of SEQ / QUAL
- *   lf_crosscheck.c  host re-implementations of device stages, reachable through lf_debug_crosscheck() only (tests)
+ *   lf_crosscheck.c  host re-implementations of device stages: a TEST library (liblfxcheck.so), loaded by lf_debug_crosscheck() only
  */
 #ifndef LF_PIPE_H
 #define LF_PIPE_H
@@ -314,9 +314,11 @@ void score_mapping(const lf_params_t *p, samlist_t *map, int isReverse, uint32_t
 void print_sam_entry(ctx_t *cx, rd_t *r, int num);                                                         /* lf_samdesc.c */
 int  sam_stage_dev(ctx_t *cx);
 void phase_fill(ctx_t *cx, int tid, int k);
-int  crosscheck_vote_chain(ctx_t *cx);                                                                     /* lf_crosscheck.c */
-void phase_bind_text(ctx_t *cx, int tid, int ri);
-void phase_sam_print(ctx_t *cx, int tid, int ri);
+/* lf_crosscheck.c is NOT part of liblfgpu.so: the host re-implementations of four device stages are a test library of their own (liblfxcheck.so, built beside
+ * it) that lf_debug_crosscheck() loads on first use and that registers its entry points here */
+typedef struct { int (*vote_chain)(ctx_t *cx); void (*bind_text)(ctx_t *cx, int tid, int ri); void (*sam_print)(ctx_t *cx, int tid, int ri); } lf_xc_hooks_t;
+extern lf_xc_hooks_t g_xc;
+void lf_xc_register(const lf_xc_hooks_t *h);
 void phase_fine_select(ctx_t *cx, int tid, int ri);                                                        /* lf_pipeline.c */
 void phase_make_jobs(ctx_t *cx, int tid, int ri);
 /* lf_sched.c: the by-bases chunk cutter (exported so that tests/test_sched.py can call it without a device) */

@@ -380,7 +380,7 @@ int map_chunk(ctx_t *cx)
         goto extend;
     }
     /* ---- B + C through the host cross-check (lf_debug_crosscheck bit 0): vote, selection, std::sort on the host, chains on the device ---- */
-    rc = crosscheck_vote_chain(cx);
+    rc = g_xc.vote_chain ? g_xc.vote_chain(cx) : LF_ERR_ARG;
     if (rc != LF_OK) return rc;
     t1 = now_ms(); st->ms_vote += t1 - t0; tstage[1] = t1 - t0; t0 = t1;
     parallel_for(cx, n, phase_fine_select);
@@ -638,7 +638,7 @@ extend:
             if (timing) fprintf(stderr, "[lf] render: %d records, %llu pieces, %.1f MB text, kernels %.1f ms, total %.1f ms\n", n_recs, (unsigned long long)n_items, tbytes / 1e6, ms, now_ms() - t0);
             if (rc != LF_OK) { free(ibase); return rc; }
             st->ms_k_render += ms; st->render_bytes += tbytes; st->render_launches += 1;
-            if (!cx->dev_sam) parallel_for(cx, n, phase_bind_text);
+            if (!cx->dev_sam) parallel_for(cx, n, g_xc.bind_text);
         }
         free(ibase);
     }
@@ -650,7 +650,7 @@ extend:
     if (cx->dev_sam) {
         rc = sam_stage_dev(cx);
         if (rc != LF_OK) return rc;
-    } else parallel_for(cx, n, phase_sam_print);
+    } else parallel_for(cx, n, g_xc.sam_print);
     t1 = now_ms(); st->ms_sam += t1 - t0; tstage[5] = t1 - t0;
     tmark(cx, "samcount");
     tmark_dump(cx, t_begin);

@@ -1,12 +1,34 @@
 /* lf_sched.c -- lanes and batches of lf_map_batch: the persistent worker pool, the lane allocator, the order of a batch's chunks
  * and the place of their SAM text in the output, and the lf_map_batch* entry points (the reference's pthread pool takes reads
  * from a shared cursor the same way, src/LordFAST.cpp:295-303).  What a chunk goes through is lf_pipeline.c. */
+#define _GNU_SOURCE
+#include <dlfcn.h>
 #include "lf_pipe.h"
 #include "lf_batch.h"
 #include <errno.h>
 
 volatile unsigned g_crosscheck = 0;
-unsigned lf_debug_crosscheck(unsigned mask) { const unsigned old = g_crosscheck; g_crosscheck = mask & 15u; return old; }
+lf_xc_hooks_t g_xc;
+void lf_xc_register(const lf_xc_hooks_t *h) { if (h) g_xc = *h; }
+/* the cross-check implementations live in liblfxcheck.so next to this library (tests / bench only): loaded the first time a non-zero mask is asked for */
+unsigned lf_debug_crosscheck(unsigned mask)
+{
+    const unsigned old = g_crosscheck;
+    mask &= 15u;
+    if (mask && !g_xc.vote_chain) {
+        Dl_info di; char path[4096];
+        if (dladdr((void *)lf_debug_crosscheck, &di) && di.dli_fname) {
+            snprintf(path, sizeof path, "%s", di.dli_fname);
+            char *sl = strrchr(path, '/'); if (sl) sl[1] = 0; else path[0] = 0;
+            strncat(path, "liblfxcheck.so", sizeof path - strlen(path) - 1);
+            void *h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+            if (h) { void (*inst)(void) = (void (*)(void))dlsym(h, "lf_xcheck_install"); if (inst) inst(); }
+        }
+        if (!g_xc.vote_chain) { lf_set_error("lf_debug_crosscheck: the cross-check library (liblfxcheck.so, a test artefact) is not beside liblfgpu.so"); return ~0u; }
+    }
+    g_crosscheck = mask;
+    return old;
+}
 double now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 arena_t g_arena[LF_MAX_LANES][260];
 const char *volatile g_lane_mark[LF_MAX_LANES];
@@ -390,7 +412,7 @@ static void *lane_main(void *arg_)
                 out_reserve(B, base, tot);
                 if (B->rc == LF_OK) {
                     cx.out_base = B->all.s + base; cx.out_off = ooff;
-                    parallel_for(&cx, cx.n_reads, phase_sam_print);
+                    parallel_for(&cx, cx.n_reads, g_xc.sam_print);
                 }
                 pthread_rwlock_unlock(&B->grow);
                 st->ms_sam += now_ms() - tch;

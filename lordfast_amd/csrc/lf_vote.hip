@@ -27,6 +27,7 @@
 #include "lf_gpu_common.h"
 #include "lf_scan.h"
 #include "lf_chain_kernel.h"
+#include "lf_reqsort.h"
 #include "lf_clasp_kernel.h"
 
 #define LF_STDSORT_FN static __device__
@@ -452,88 +453,7 @@ lf_req_gather_kernel(int n_req, const uint32_t *__restrict__ req_read, const uin
     if (!WRITE && lane == 0) { req_n[q] = cnt; if (skeys) atomicMax(reinterpret_cast<unsigned int *>(skeys) + (q & 255), cnt); }
 }
 
-/* ---- 5b: a request's seeds in key order -- qPos for dp-n2 (what std::sort(compare_seed) orders by, src/Chain.cpp:244), target
- * start for clasp (qsort(cmp_slmatch_qsort), src/Chain.cpp:94) -- STABLE, i.e. equal keys keep the gathered order (clasp's
- * qsort is glibc's stable merge sort; for dp-n2 the unstable std::sort is replayed afterwards on the requests that have ties).
- * A SEGMENTED sort: requests are independent and a few hundred seeds long, so every request is sorted by its own workgroup in
- * LDS -- a bitonic network over 64-bit words (key << 32 | place in the gathered order): the words are distinct, so the network's
- * result is THE stable order -- instead of one radix sort over (request, key) pairs of the whole chunk through HBM (round 3:
- * hipCUB, 14 launches and four passes over 1.3 M pairs per chunk). ---- */
-template <int THREADS>
-__global__ void __launch_bounds__(THREADS)
-lf_req_sort_kernel(int n_req, const uint64_t *__restrict__ req_off, const uint32_t *__restrict__ req_n, const uint2 *__restrict__ gathered,
-                   uint2 *__restrict__ sorted, uint64_t *__restrict__ skeys_sorted, int key_by_tpos, uint32_t n_lo, uint32_t n_hi)
-{
-    extern __shared__ uint64_t s_w[];
-    const int q = blockIdx.x, t = threadIdx.x;
-    if (q >= n_req) return;
-    const uint32_t n = req_n[q];
-    if (n < n_lo || n > n_hi) return;                       /* another launch's size class */
-    const uint64_t off = req_off[q];
-    uint32_t N = 1; while (N < n) N <<= 1;
-    for (uint32_t i = t; i < N; i += THREADS) {
-        uint64_t w = ~0ull;
-        if (i < n) { const uint2 sd = gathered[off + i]; w = ((uint64_t)(key_by_tpos ? sd.x : (sd.y & 0xFFFFFu)) << 32) | i; }
-        s_w[i] = w;
-    }
-    auto sync = [&]() { if (THREADS > 64) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } };
-    sync();
-    for (uint32_t k = 2; k <= N; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = t; i < N; i += THREADS) {
-                const uint32_t l = i ^ j;
-                if (l > i) {
-                    const uint64_t a = s_w[i], b = s_w[l];
-                    if ((a > b) == ((i & k) == 0)) { s_w[i] = b; s_w[l] = a; }
-                }
-            }
-            sync();
-        }
-    for (uint32_t i = t; i < n; i += THREADS) {
-        const uint2 sd = gathered[off + (uint32_t)s_w[i]];
-        sorted[off + i] = sd;
-        skeys_sorted[off + i] = key_by_tpos ? (((uint64_t)(uint32_t)q << 32) | sd.x) : (((uint64_t)(uint32_t)q << 20) | (sd.y & 0xFFFFFu));
-    }
-}
-
-/* ... and the requests above 8192 seeds (a window over a satellite array: every sample of the read hits it): the same network over a
- * scratch array in HBM (2 n words at 2 x the request's offset: the next power of two is below 2 n), one 1024-thread workgroup per
- * request.  Rare and L2-sized; replaces the chunk-wide hipCUB radix sort such a request used to switch the whole chunk to. */
-__global__ void __launch_bounds__(1024)
-lf_req_sort_big_kernel(int n_req, const uint64_t *__restrict__ req_off, const uint32_t *__restrict__ req_n, const uint2 *__restrict__ gathered,
-                       uint2 *__restrict__ sorted, uint64_t *__restrict__ skeys_sorted, uint64_t *__restrict__ scratch, int key_by_tpos, uint32_t n_lo)
-{
-    const int q = blockIdx.x, t = threadIdx.x;
-    if (q >= n_req) return;
-    const uint32_t n = req_n[q];
-    if (n < n_lo) return;
-    const uint64_t off = req_off[q];
-    uint64_t *w = scratch + 2 * off;
-    uint32_t N = 1; while (N < n) N <<= 1;
-    for (uint32_t i = t; i < N; i += 1024) {
-        uint64_t x = ~0ull;
-        if (i < n) { const uint2 sd = gathered[off + i]; x = ((uint64_t)(key_by_tpos ? sd.x : (sd.y & 0xFFFFFu)) << 32) | i; }
-        w[i] = x;
-    }
-    __syncthreads();
-    for (uint32_t k = 2; k <= N; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = t; i < N; i += 1024) {
-                const uint32_t l = i ^ j;
-                if (l > i) {
-                    const uint64_t a = w[i], b = w[l];
-                    if ((a > b) == ((i & k) == 0)) { w[i] = b; w[l] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    for (uint32_t i = t; i < n; i += 1024) {
-        const uint2 sd = gathered[off + (uint32_t)w[i]];
-        sorted[off + i] = sd;
-        skeys_sorted[off + i] = key_by_tpos ? (((uint64_t)(uint32_t)q << 32) | sd.x) : (((uint64_t)(uint32_t)q << 20) | (sd.y & 0xFFFFFu));
-    }
-}
-
+/* ---- 5b: a request's seeds in key order: the segmented LDS / HBM sorts of lf_reqsort.h ---- */
 /* ---- 6: equal qPos inside a request -> replay std::sort on the original order ---- */
 __global__ void lf_tie_flag_kernel(uint64_t n, const uint64_t *__restrict__ skeys_sorted, uint8_t *__restrict__ flag)
 {
@@ -809,26 +729,10 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
         hipLaunchKernelGGL(lf_req_gather_kernel<true>, dim3((unsigned)n_req), dim3(64), 0, s, (int)n_req, d_req_read, d_req_win, d_req_lo, d_req_hi, d_read_off,
                            d_tpos, d_qpl, d_strand, d_req_n, (const uint64_t *)d_req_off, d_gath, d_sk, clasp ? 1 : 0);
         {
-            /* segmented sort in LDS: one wavefront per request up to 512 seeds (4 KiB), a 256-thread workgroup up to 8192 (64 KiB); above that
-             * (LF_REQ_SORT_BIG_FROM lowers the bound: test hook) a 1024-thread workgroup over a scratch array in HBM */
-            const uint32_t big_from = (uint32_t)lf_env_long("LF_REQ_SORT_BIG_FROM", 8193);
-            const uint32_t lds_hi = big_from - 1u < 8192u ? big_from - 1u : 8192u;
-            const uint32_t small_hi = max_n < 512u ? max_n : 512u, hi1 = lds_hi < 512u ? lds_hi : 512u;
-            uint32_t cap1 = 64; while (cap1 < small_hi) cap1 <<= 1;
-            hipLaunchKernelGGL(lf_req_sort_kernel<64>, dim3((unsigned)n_req), dim3(64), (size_t)cap1 * 8, s, (int)n_req, (const uint64_t *)d_req_off, (const uint32_t *)d_req_n,
-                               (const uint2 *)d_gath, d_sorted, d_sk2, clasp ? 1 : 0, 0u, hi1);
-            if (max_n > 512u && lds_hi > 512u) {
-                const uint32_t top = max_n < lds_hi ? max_n : lds_hi;
-                uint32_t cap2 = 1024; while (cap2 < top) cap2 <<= 1;
-                hipLaunchKernelGGL(lf_req_sort_kernel<256>, dim3((unsigned)n_req), dim3(256), (size_t)cap2 * 8, s, (int)n_req, (const uint64_t *)d_req_off, (const uint32_t *)d_req_n,
-                                   (const uint2 *)d_gath, d_sorted, d_sk2, clasp ? 1 : 0, 513u, lds_hi);
-            }
-            if (max_n > lds_hi) {
-                uint64_t *d_big = (uint64_t *)VSLOT(17, 2 * S * 8 + 256);
-                if (!d_big) return LF_ERR_NOMEM;
-                hipLaunchKernelGGL(lf_req_sort_big_kernel, dim3((unsigned)n_req), dim3(1024), 0, s, (int)n_req, (const uint64_t *)d_req_off, (const uint32_t *)d_req_n,
-                                   (const uint2 *)d_gath, d_sorted, d_sk2, d_big, clasp ? 1 : 0, lds_hi + 1u);
-            }
+            /* (LF_REQ_SORT_BIG_FROM lowers the bound from which the HBM-scratch form is used: test hook) */
+            const int src_ = lf_req_sort_launch(dv, s, (int)n_req, (const uint64_t *)d_req_off, (const uint32_t *)d_req_n, (const uint2 *)d_gath, d_sorted, d_sk2, clasp ? 1 : 0, max_n,
+                                                (uint32_t)lf_env_long("LF_REQ_SORT_BIG_FROM", 8193), (uint64_t *)VSLOT(17, max_n > 8192u || lf_env_set("LF_REQ_SORT_BIG_FROM") ? 2 * S * 8 + 256 : 16));
+            if (src_ != LF_OK) return src_;
         }
         HIPCHK(hipMemsetAsync(d_flag, 0, Q, s));
         if (!clasp) {
