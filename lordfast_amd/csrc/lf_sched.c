@@ -134,7 +134,8 @@ void parallel_for_named(ctx_t *cx, int n, pf_fn fn, const char *name)
     pjob_t *J = &P->job[cx->lane];
     const int self = P->nw + cx->lane;
     const double w0 = g_phase_on ? now_ms() : 0;
-    if (n <= 4) {                                           /* a handful of items (the replay of a chunk's one or two rare chains): not worth waking the pool */
+    if (n == 1) {                                           /* ONE item (the replay of a chunk's one rare chain): nothing to spread; two to four items used to run here too, but an
+                                                             * item can be the replay of a 50 - 100 kb read with -n 30 chains (C4 / C5), and the lane driver holding a GPU lane was serialized behind them */
         const long long c0 = g_phase_on ? thread_cpu_ns() : 0;
         for (int i = 0; i < n; i++) fn(cx, self, i);
         if (g_phase_on) phase_account(name, (thread_cpu_ns() - c0) / 1e6, now_ms() - w0);

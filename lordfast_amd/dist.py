@@ -348,9 +348,14 @@ class PipelinedExchange:
                 lens = [int(own_len)] + [int(self._ctl_recv(1, r)[0]) for r in range(1, self.world)]
                 self.gather_lens[pb] = lens
                 off = lens[0]
+                need = sum(lens)
+                if need > self.sam[pb].numel():
+                    # grow instead of raising: the peers have already posted their sends -- a rank that leaves the loop here would leave them
+                    # blocked.  Rank 0's own records (complete: own_len is known) move to the new buffer, like the receive buffers grow.
+                    bigger = self.torch.empty(int(need * 1.25) + (1 << 20), dtype=self.sam[pb].dtype, device=self.sam[pb].device)
+                    bigger[:lens[0]].copy_(self.sam[pb][:lens[0]])
+                    self.sam[pb] = bigger
                 for r in range(1, self.world):
-                    if off + lens[r] > self.sam[pb].numel():
-                        raise RuntimeError("PipelinedExchange: gather buffer too small")
                     if lens[r]:
                         ops.append(dist.P2POp(dist.irecv, self.sam[pb][off:off + lens[r]], r))
                         self.bytes_in += lens[r]
