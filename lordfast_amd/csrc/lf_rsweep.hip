@@ -154,10 +154,12 @@ __device__ __forceinline__ void lf_rsweep_body(const lf_rsw_args &A)
             }
         }
     };
+    /* the lane's 16 target symbols of a group (stream position s - gl) are requested ONE GROUP AHEAD: the load right in front of its use was a stall per group */
+    uint32_t Vn = lf_pac16(A.pac, pr.tstart + (int64_t)dt * (0 - (int64_t)gl), dt, ct, A.pac_syms);
     for (int s0 = 0; s0 < steps_max; s0 += 16) {
-        /* the lane's next 16 target symbols: stream position s - gl */
         const int64_t p = (int64_t)s0 - gl;
-        const uint32_t V = lf_pac16(A.pac, pr.tstart + (int64_t)dt * p, dt, ct, A.pac_syms);
+        const uint32_t V = Vn;
+        Vn = lf_pac16(A.pac, pr.tstart + (int64_t)dt * (p + 16), dt, ct, A.pac_syms);
         /* a row starts: the state in front of it */
         if (any_ck && (s0 & 31) == 0) { lf_hist_t e; e.pv = Pv; e.ph = Mv; ck[(size_t)(s0 >> 5) * LF_RROW + lane] = e; }
         const bool partial = mine && (p < 0 || p + 15 >= (int64_t)m);       /* (lanes without a block compute on dead registers) */
