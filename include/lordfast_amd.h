@@ -218,6 +218,20 @@ int  lf_map_batch_into(const lf_index_t *idx, const lf_params_t *p, int n, const
 int  lf_map_batch_into_lens(const lf_index_t *idx, const lf_params_t *p, int n, const char *const *names,
                             const char *const *seqs, const char *const *quals, const uint32_t *seq_lens,
                             char *out, size_t out_cap, size_t *sam_len, lf_stats_t *stats);
+/* ---- a mapper-ready batch (the reference's readChunk leaves one outside its mapping timer: src/Reads.cpp:84-104, src/baseFAST.cpp:59-75).
+ * lf_batch_create takes the reads as the reader has them (pointers; the strings must outlive the batch) and makes, ONCE, what every mapping call of
+ * the other entry points makes per call: the lengths, and the bit planes the read batch crosses the host link as (code low bit, code high bit,
+ * "is upper-case ACGT": 3 / 8 of the bytes; bytes outside ACGT as an exception list) in pinned memory.  Reads shorter than min_read_len (-l) are not mapped
+ * and not packed: lf_map_batch_from uses the planes when its -l equals the batch's and packs per call otherwise.  Same records as lf_map_batch.  A batch
+ * can be mapped any number of times, from several threads at once; lf_batch_free releases the planes, not the caller's strings (for a batch of lf_reads_next it is
+ * lf_read_batch_free).  threads <= 0: all CPUs.  The object is the reader's lf_read_batch_t. ---- */
+lf_read_batch_t *lf_batch_create(int n, const char *const *names, const char *const *seqs, const char *const *quals,
+                                 const uint32_t *seq_lens /* NULL: strlen */, int min_read_len, int threads);
+int  lf_read_batch_prepack(lf_read_batch_t *b, int min_read_len, int threads);      /* the same for a batch of the library's reader (lf_reads_next); idempotent */
+void lf_batch_free(lf_read_batch_t *b);
+int  lf_batch_size(const lf_read_batch_t *b);
+/* output: a caller-owned buffer as in lf_map_batch_into (pinned: the SEQ-less egress) */
+int  lf_map_batch_from(const lf_index_t *idx, const lf_params_t *p, const lf_read_batch_t *b, char *out, size_t out_cap, size_t *sam_len, lf_stats_t *stats);
 /* Device-resident form of lf_map_batch_into_lens: the bases (and qualities) are already in HBM of idx's device and the
  * SAM text is left there (out_is_device) -- the bulk data never crosses PCIe.  This is what one rank of the N-GPU
  * deployment calls on the shard it received over xGMI (lordfast_amd/dist.py); the reference's equivalent is the chunk
