@@ -70,7 +70,7 @@ extern "C" int lfg_chain_n2(int device, const lf_params_t *p, int n_windows, con
     {
         uint32_t n_largest = 0; bool ws = false;
         for (const lf_chain_win &x : W) { if (x.n > n_largest) n_largest = x.n; if (x.n > LF_CHAIN_LDS_MAX) ws = true; }
-        const int lrc = lf_chain_n2_launch_classes(s, (const lf_chain_win *)d_w, (int)W.size(), (const uint32_t *)d_seeds, (const double *)d_pen, (uint32_t)pen.size(), reward, p->chain_penalty,
+        const int lrc = lf_chain_n2_launch_classes(device, s, (const lf_chain_win *)d_w, (int)W.size(), (const uint32_t *)d_seeds, (const double *)d_pen, (uint32_t)pen.size(), reward, p->chain_penalty,
                                                    (double *)d_dp, (int *)d_prev, ws, (uint32_t *)d_idx, (uint32_t *)d_len, (float *)d_sc, n_largest);
         if (lrc != LF_OK) return lrc;
     }

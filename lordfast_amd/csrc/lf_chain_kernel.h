@@ -187,7 +187,7 @@ static inline size_t lf_chain_big_smem(uint32_t cap, bool prev_lds) { return (si
 
 /* one launch per size class over ALL windows (a block outside its class exits): the one-wavefront kernel up to 512 seeds, the workgroup kernel up to
  * LF_CHAIN_BIG_MAX, the one-wavefront kernel with its state in the HBM workspace above that.  n_largest: the largest window if the caller knows it. */
-static inline int lf_chain_n2_launch_classes(hipStream_t s, const lf_chain_win *d_wins, int n_wins, const uint32_t *d_seeds, const double *d_pen, uint32_t pen_n, double reward, double chain_penalty,
+static inline int lf_chain_n2_launch_classes(int device, hipStream_t s, const lf_chain_win *d_wins, int n_wins, const uint32_t *d_seeds, const double *d_pen, uint32_t pen_n, double reward, double chain_penalty,
                                              double *d_dp, int *d_prev, bool have_ws, uint32_t *d_cidx, uint32_t *d_clen, float *d_cscore, uint32_t n_largest)
 {
     if (n_wins <= 0) return LF_OK;
@@ -198,10 +198,10 @@ static inline int lf_chain_n2_launch_classes(hipStream_t s, const lf_chain_win *
                            d_dp, d_prev, d_cidx, d_clen, d_cscore, lo, SMALL[c]);
         lo = SMALL[c] + 1;
     }
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = { false };          /* per device (and per translation unit: the kernel is a static function of each) */
+    if (!attr_done[device & 63]) {
         HIPCHK(hipFuncSetAttribute((const void *)lf_chain_n2_big_kernel<LF_CHAIN_BIG_W, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf_chain_big_smem(LF_CHAIN_BIG_MAX, false)));
-        attr_done = true;
+        attr_done[device & 63] = true;
     }
     static const uint32_t BIG[3] = { 2048, LF_CHAIN_LDS_MAX, LF_CHAIN_BIG_MAX };
     for (int c = 0; c < 3 && lo <= n_largest; c++) {

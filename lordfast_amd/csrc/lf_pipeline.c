@@ -279,9 +279,10 @@ int map_chunk(ctx_t *cx)
             } else {
             /* the lanes of a step all start with this copy: one at a time, with every pool thread on it, so that the first lane's
              * bases are ready (and on their way, see lfg_seed_src) after 1 / 8 of the time instead of all lanes' after all of it */
-            /* (process-wide on purpose: the turn is for the process-wide worker pool's CPU time, and it is never held across a GPU wait;
-             * the turn for the host LINK is per device, lfg_seed_any) */
-            static pthread_mutex_t concat_turn = PTHREAD_MUTEX_INITIALIZER;
+            /* (one turn per DEVICE since round 6, like the upload turn of lf_seed.hip: the lanes of different devices in one process -- lf_map_batch_multi -- do not
+             * wait for each other's packing; a turn is never held across a GPU wait) */
+            static pthread_mutex_t concat_turns[16] = { [0 ... 15] = PTHREAD_MUTEX_INITIALIZER };
+            pthread_mutex_t *concat_turn = &concat_turns[cx->ix->device & 15];
             /* Packed upload: the pool threads turn the reads into the three bit planes the alignment kernels work on anyway
              * (lo / hi / valid: 3 / 8 of the bytes; the device rebuilds the bytes for the seed search and the SAM writer) plus a
              * list of the bytes that are not upper-case ACGT -- the link carries 0.57 instead of 1.53 GB per 100 k reads, and the
@@ -313,7 +314,7 @@ int map_chunk(ctx_t *cx)
                 if (xpos && xbyte && 3 * qw * 8 <= bases + 64) {            /* the planes take the staging buffer's place */
                     uint64_t *planes = (uint64_t *)cat;
                     cx->pk_planes = planes; cx->pk_qw = qw; cx->pk_xpos = xpos; cx->pk_xbyte = xbyte; cx->pk_xcap = xcap; cx->pk_xn = 0; cx->pk_overflow = 0;
-                    pthread_mutex_lock(&concat_turn);
+                    pthread_mutex_lock(concat_turn);
                     /* the words that hold a read boundary (two reads OR their bits in) and the slack behind the last base */
                     for (int x = 0; x < 3; x++) {
                         uint64_t *P = planes + (size_t)x * qw;
@@ -321,7 +322,7 @@ int map_chunk(ctx_t *cx)
                         for (uint64_t w = off[m] >> 6; w < qw; w++) P[w] = 0;
                     }
                     parallel_for(cx, m, phase_pack);
-                    pthread_mutex_unlock(&concat_turn);
+                    pthread_mutex_unlock(concat_turn);
                     tmark(cx, "pack");
                     if (!cx->pk_overflow) {
                         lf_packed_src_t pk; memset(&pk, 0, sizeof pk); pk.planes = planes; pk.qw = qw; pk.exc_pos = xpos; pk.exc_byte = xbyte; pk.n_exc = cx->pk_xn;
@@ -333,7 +334,7 @@ int map_chunk(ctx_t *cx)
                 }
             }
             if (!packed) {
-            { pthread_mutex_lock(&concat_turn); parallel_for(cx, m, phase_concat); pthread_mutex_unlock(&concat_turn); }
+            { pthread_mutex_lock(concat_turn); parallel_for(cx, m, phase_concat); pthread_mutex_unlock(concat_turn); }
             tmark(cx, "concat");
             if (lf_env_set("LF_TIMING")) fprintf(stderr, "[lf] concat %.1f ms\n", now_ms() - tc0);
             tc0 = now_ms();

@@ -779,7 +779,7 @@ extern "C" int lfg_vote_chain(const struct lf_index *ix, const lf_params_t *p, i
             HIPCHK(hipStreamWaitEvent(s, ev[c], 0));
         }
     } else {
-        const int lrc = lf_chain_n2_launch_classes(s, (const lf_chain_win *)d_wins, (int)n_req, (const uint32_t *)d_sorted, d_pen, pen_n, reward, p->chain_penalty,
+        const int lrc = lf_chain_n2_launch_classes(dv, s, (const lf_chain_win *)d_wins, (int)n_req, (const uint32_t *)d_sorted, d_pen, pen_n, reward, p->chain_penalty,
                                                    d_dp, d_prev, WS != 0, d_cidx, d_clen, d_cscore, max_n);
         if (lrc != LF_OK) return lrc;
     }
