@@ -702,7 +702,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         HA.S.q = D->d_q; HA.S.t = D->d_t; HA.S.pac = D->d_pac; HA.pac_syms = D->pac_syms;
         lf_htrial_pick(HA.trial16);
         if (const char *e_ = lf_env("LF_HIRSCH_TRIAL")) { unsigned a_ = 0, b_ = 0; if (sscanf(e_, "%u,%u", &a_, &b_) == 2 && a_ <= 16 && b_ <= 16) { HA.trial16[0] = a_; HA.trial16[1] = b_; } }      /* test hook: fixed bounds "nw,shw" */
-        HA.no_band = lf_env_long("LF_HIRSCH_BAND", 1) == 0 ? 1u : 0u;      /* (read per call: the tests switch it) */
+        { const long hb_ = lf_env_long("LF_HIRSCH_BAND", 1); HA.no_band = hb_ == 0 ? 1u : hb_ == 64 ? 2u : hb_ == 3 ? 4u : 0u; }      /* (read per call: the tests switch it) */
         HA.qlo = D->d_planes; HA.qhi = D->d_planes + D->q_words; HA.qvalid = D->d_planes + 2 * D->q_words; HA.q_words = D->q_words;
         HA.q_cap = (uint32_t)q_cap; HA.ctl = d_ctl; HA.roots = d_roots; HA.segs = d_segs; HA.hdesc = d_hdesc; HA.hopsoff = d_hopsoff; HA.hleaf_cap = (uint32_t)hcap;
         HA.aux = d_haux; HA.aux_cap = aux_cap; HA.hcar = d_hcar; HA.hcar_cap = hcar_cap;
@@ -720,9 +720,9 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
             HIPCHK(hipStreamSynchronize(s));
             if (hdbg) {
                 const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
-                fprintf(stderr, "[lf]   level %d: unbanded %u / %u / %u (<= 4096 / <= 16384 / more rows), banded NW %u / %u / %u / %u (1 / 2 / 4 / 8 wavefronts per half), SHW %u / %u / %u / %u / %u (1 .. 16 wavefronts), trials %u failed %u, leaves so far %u, %.3f ms\n", level,
+                fprintf(stderr, "[lf]   level %d: unbanded %u / %u / %u (<= 4096 / <= 16384 / more rows), banded NW %u / %u / %u / %u (1 / 2 / 4 / 8 wavefronts per half), SHW %u / %u / %u / %u / %u (1 .. 16 wavefronts), sixteen-lane NW %u SHW %u, thirty-two-lane NW %u SHW %u, trials %u failed %u, leaves so far %u, %.3f ms\n", level,
                         h_ctl->q_n[par][0], h_ctl->q_n[par][1], h_ctl->q_n[par][2], h_ctl->q_n[par][3], h_ctl->q_n[par][4], h_ctl->q_n[par][5], h_ctl->q_n[par][6],
-                        h_ctl->q_n[par][7], h_ctl->q_n[par][8], h_ctl->q_n[par][9], h_ctl->q_n[par][10], h_ctl->q_n[par][11], h_ctl->n_trial, h_ctl->n_trial_failed, h_ctl->n_hleaf,
+                        h_ctl->q_n[par][7], h_ctl->q_n[par][8], h_ctl->q_n[par][9], h_ctl->q_n[par][10], h_ctl->q_n[par][11], h_ctl->q_n[par][12], h_ctl->q_n[par][13], h_ctl->q_n[par][14], h_ctl->q_n[par][15], h_ctl->n_trial, h_ctl->n_trial_failed, h_ctl->n_hleaf,
                         std::chrono::duration<double, std::milli>(t1 - hd_t0).count());
                 hd_t0 = t1;
             }
@@ -741,7 +741,7 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
             for (int k = 0; k < LF_HQ; k++) HA.q_out[k] = queue(par ^ 1, k);
             HA.out_par = (uint32_t)(par ^ 1);
             /* the classes with the longest sweeps first: wide bands, unbanded large queries, ... */
-            static const int order[LF_HQ] = { 2, 1, 11, 6, 10, 5, 9, 4, 8, 3, 7, 0 };
+            static const int order[LF_HQ] = { 2, 1, 11, 6, 10, 5, 9, 4, 8, 3, 7, 0, 14, 15, 12, 13 };
             /* A level's queues are independent, and each lasts as long as its longest node: one after the other on one stream a level cost the SUM of its
              * queues' longest sweeps (round 6 has twelve queues where round 5 had three).  They go out side by side on the lane's class streams -- idle
              * until the binning below -- and the level's stream waits for all of them. */

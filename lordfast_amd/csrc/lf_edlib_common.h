@@ -221,6 +221,6 @@ __device__ __forceinline__ uint64_t lf_brev64(uint64_t x) { return ((uint64_t)__
 
 /* lane l receives lane l-1's value (lane 0: 0): the horizontal carry of the anti-diagonal sweeps.  DPP wave_shr:1 is a
  * VALU move; __shfl_up goes through the LDS crossbar (ds_bpermute) and sits on the per-step dependency chain. */
-__device__ __forceinline__ uint32_t lf_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t lf_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true); }
 
 #endif

@@ -15,9 +15,9 @@ struct lf_hnode {
     uint32_t root;             /* index into the root table */
     uint8_t  flags, kind, is_root, pad;      /* pad: the root's target holds bytes other than ACGT (stage API) */
     uint32_t k0;               /* banded queues, distance not known: the node is swept inside the band of distance k0 (n + m: the whole matrix) and goes back to the
-                                * queue with the whole matrix if its distance turns out larger */
+                                * queue with the bound that sweep found if its distance turns out larger (lf_hrequeue_bound) */
 };
-#define LF_HQ 12
+#define LF_HQ 16
 struct lf_hroot { uint64_t ops_off; uint32_t desc, n, m, seg_off, seg_cap, count; };      /* count: pieces registered so far (atomic) */
 /* one finished piece of a root's path: its region inside the root's ops region and its length (bit 31 set: H-leaf j, whose
  * length the traceback kernels leave in out_len[n_desc + j]) */
@@ -34,7 +34,7 @@ struct lf_hargs {
     const lf_hnode *q_in; lf_hnode *q_out[LF_HQ];
     const uint64_t *qlo, *qhi, *qvalid; int64_t q_words;      /* bit planes of S.q (lf_pack_planes_kernel): the banded sweeps take a block's match masks from them */
     uint32_t n_in, q_cap, out_par;
-    uint32_t no_band;                     /* A / B and test hook (LF_HIRSCH_BAND=0): every node takes the unbanded sweep of its size */
+    uint32_t no_band;                     /* A / B and test hook: 1 (LF_HIRSCH_BAND=0): every node takes the unbanded sweep of its size; 2 (LF_HIRSCH_BAND=64): no sixteen-lane queues */
     uint32_t trial16[2];                  /* trial bound of the NW / SHW roots in sixteenths of their rows, 0 = none */
     lf_hctl *ctl; lf_hroot *roots; lf_hseg *segs;
     lf_aln_desc_t *hdesc; uint64_t *hopsoff; uint32_t hleaf_cap;
@@ -75,8 +75,10 @@ static inline __host__ __device__ bool lf_hband_fits(lf_hband B, uint32_t n, int
     return dhi - dlo <= 4096 * W + LF_HB_LAG(W) * W - 94;
 }
 /* trial bounds of the roots above 4096 rows, in sixteenths of the rows (trial16; 0 = none).  A root does not know its distance: it is swept inside the band of a
- * bound k0 -- min (F + R) <= k0, resp. the SHW minimum <= k0, proves the result exact -- and k0 = n + m is the whole matrix.  The levels are a chain of dependent
- * steps whose number a band does not change, so a trial that fails costs a whole level: lf_align.hip picks trial16 per mode from the distances of the roots the
+ * bound k0 -- min (F + R) <= k0, resp. the SHW minimum <= k0, proves the result exact -- and k0 = n + m is the whole matrix.  A trial that fails still
+ * says something: every value a banded sweep computes is the cost of a real path, so the minimum it found is an UPPER bound of the distance and the band of THAT bound
+ * holds an optimal path -- the root goes back to the queue with it (for unrelated strings ~0.55 of the rows: a third of the whole matrix).  The levels are a chain of
+ * dependent steps whose number a band does not change, so a trial that fails costs a whole level: lf_align.hip picks trial16 per mode from the distances of the roots the
  * process has seen so far (a batch is homogeneous: PacBio tails in the right place end at 0.16 - 0.2 of their rows, ONT ones at 0.1, tails in the wrong copy of a
  * duplication at 0.47).  Results do not depend on it. */
 static inline __host__ __device__ uint32_t lf_htrial_nw(uint32_t n, uint32_t m, uint32_t trial16) { const uint32_t d = n > m ? n - m : m - n, x = n > m ? n : m; return d + (uint32_t)((uint64_t)x * trial16 / 16) + 1; }
@@ -86,23 +88,43 @@ static inline __host__ __device__ uint32_t lf_htrial_shw(uint32_t n, uint32_t tr
  * above 32 768 rows).  *k0: the bound a node of unknown distance is swept with */
 #define LF_HQ_NW0 3
 #define LF_HQ_SHW0 7
-static inline __host__ __device__ int lf_hqueue_of(uint32_t n, uint32_t m, int best, int kind, unsigned pad, uint32_t trial16, uint32_t *k0)
+#define LF_HQ_NW16 12        /* NW nodes whose band fits SIXTEEN LANES: two nodes (four halves) per wavefront, lf_hband_group_kernel */
+#define LF_HQ_SHW16 13       /* SHW roots ... : four per wavefront */
+#define LF_HQ_NW32 14        /* ... THIRTY-TWO LANES: the two halves of a node in one wavefront */
+#define LF_HQ_SHW32 15       /* ... two SHW roots per wavefront */
+/* L lanes hold a band of 64 L + L - 94 diagonals (the same rule as lf_hband_fits with L lanes per "wavefront") */
+static inline __host__ __device__ bool lf_hband_fits_lanes(lf_hband B, uint32_t n, int mm, int L)
+{
+    const int nbk = (int)((n + 63) >> 6);
+    const int dhi = B.dhi < mm - 64 ? B.dhi : mm - 64, dlo = B.dlo > -64 * (nbk - 1) ? B.dlo : -64 * (nbk - 1);
+    return dhi - dlo <= 64 * L + L - 94;
+}
+/* t: the bound a node of unknown distance (best < 0) is swept with */
+static inline __host__ __device__ int lf_hqueue_of_bound(uint32_t n, uint32_t m, int best, int kind, unsigned pad, uint32_t t, uint32_t *k0)
 {
     *k0 = 0;
-    if (pad == 0 && (uint64_t)n + m < (1u << 30)) {
-        const bool trial = n > 4096 && trial16 != 0;
+    if ((pad & 1u) == 0 && (uint64_t)n + m < (1u << 30)) {      /* pad bit 0: no band; bit 1: no sixteen- / thirty-two-lane queues */
         if (kind == 1) {
-            const uint32_t t = trial ? lf_htrial_shw(n, trial16) : n + m;
             const lf_hband B = lf_hband_shw((int)t);
             const uint64_t me = (uint64_t)n + t; const int mm = (int)(me < m ? me : m);
+            if (!(pad & 2u) && lf_hband_fits_lanes(B, n, mm, 16)) { *k0 = t; return LF_HQ_SHW16; }
+            if (!(pad & 2u) && lf_hband_fits_lanes(B, n, mm, 32)) { *k0 = t; return LF_HQ_SHW32; }
             for (int c = 0, W = 1; c < 5; c++, W *= 2) if (lf_hband_fits(B, n, mm, W)) { *k0 = t; return LF_HQ_SHW0 + c; }
         } else {
-            const uint32_t t = best >= 0 ? 0u : trial ? lf_htrial_nw(n, m, trial16) : n + m;
+            if (best >= 0) t = 0;
             const lf_hband B = lf_hband_nw(n, m, best >= 0 ? best : (int)t);
+            if (!(pad & 2u) && lf_hband_fits_lanes(B, n, (int)(m - m / 2), 16)) { *k0 = t; return LF_HQ_NW16; }
+            if (!(pad & 2u) && lf_hband_fits_lanes(B, n, (int)(m - m / 2), 32)) { *k0 = t; return LF_HQ_NW32; }
             for (int c = 0, W = 1; c < 4; c++, W *= 2) if (lf_hband_fits(B, n, (int)(m - m / 2), W)) { *k0 = t; return LF_HQ_NW0 + c; }
         }
     }
     return lf_hkb_class(n);
+}
+static inline __host__ __device__ int lf_hqueue_of(uint32_t n, uint32_t m, int best, int kind, unsigned pad, uint32_t trial16, uint32_t *k0)
+{
+    const bool trial = n > 4096 && trial16 != 0;
+    const uint32_t t = !trial ? n + m : kind == 1 ? lf_htrial_shw(n, trial16) : lf_htrial_nw(n, m, trial16);
+    return lf_hqueue_of_bound(n, m, best, kind, pad, t, k0);
 }
 
 void lf_hirsch_launch_roots(hipStream_t s, bool pac_targets, const lf_aln_desc_t *d_desc, const uint64_t *d_opsoff, int n, lf_hargs A);

@@ -337,12 +337,15 @@ __device__ __forceinline__ void lf_hfinalize(const lf_hargs &A, const lf_hnode &
         A.q_out[kbc][idx] = c;
     }
 }
-/* a root whose trial bound was too small goes back to the queue with the whole matrix as its band */
-__device__ __forceinline__ void lf_hrequeue_full(const lf_hargs &A, const lf_hnode &P)
+/* a root whose trial bound was too small goes back to the queue.  `found` is what its sweep found inside the band -- the cost of a real path, an upper bound of the
+ * distance -- so the band of `found` holds an optimal path and the second sweep cannot fail; nothing connected inside the band (LF_HB_FAR): the whole matrix */
+__device__ __forceinline__ void lf_hrequeue_bound(const lf_hargs &A, const lf_hnode &P, int found)
 {
     if ((threadIdx.x & 63) == 0) {
         uint32_t k0;
-        const int kbc = lf_hqueue_of(P.n, P.m, -1, P.kind, P.pad, 0, &k0);
+        const uint64_t whole = (uint64_t)P.n + P.m;
+        const uint32_t t = found >= 0 && (uint64_t)found < whole ? (uint32_t)found : (uint32_t)whole;
+        const int kbc = lf_hqueue_of_bound(P.n, P.m, -1, P.kind, P.pad | (A.no_band & 2u), t, &k0);
         const uint32_t idx = atomicAdd(&A.ctl->q_n[A.out_par][kbc], 1u);
         atomicAdd(&A.ctl->n_trial_failed, 1u);
         if (idx >= A.q_cap) { atomicExch(&A.ctl->fail, 4u); return; }
@@ -362,6 +365,7 @@ lf_hirsch_level_kernel(lf_hargs A)
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     const int w = wave / W, wsub = wave % W;             /* w: the node's half; wsub: the wavefront's sub-band */
     if (blockIdx.x >= A.n_in) return;
+    if (W > 1 && !(A.no_band & 4u)) __builtin_amdgcn_s_setprio(3);
     const lf_hnode P = A.q_in[blockIdx.x];
     const uint32_t n = P.n, m = P.m, nbk = (n + 63) >> 6;
     const bool banded = nbk > 64u * KB * W;
@@ -459,7 +463,7 @@ lf_hirsch_level_kernel(lf_hargs A)
  * and go back to the queue for the unbanded sweep otherwise.  tests/models/hband_model.cpp is this schedule lane by lane on the host, checked against the
  * full matrix (tests/test_hband_model.py).
  * ================================================================================================ */
-__device__ __forceinline__ uint32_t lf_wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t lf_wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C /* wave_ror:1 */, 0xf, 0xf, true); }
 #define LF_HB_FAR (1 << 28)
 
 template <int W, bool TRACK>
@@ -610,6 +614,7 @@ lf_hband_level_kernel(lf_hargs A)
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     const int w = wave / W, wsub = wave % W;             /* w: the node's half; wsub: the wavefront inside it */
     if (blockIdx.x >= A.n_in) return;
+    if (W > 1 && !(A.no_band & 4u)) __builtin_amdgcn_s_setprio(W >= 8 ? 3 : W == 4 ? 2 : 1);
     const lf_hnode P = A.q_in[blockIdx.x];
     const uint32_t n = P.n, m = P.m, nbk = (n + 63) >> 6;
     const uint32_t lw = m / 2, rw = m - lw;
@@ -634,7 +639,7 @@ lf_hband_level_kernel(lf_hargs A)
         __syncthreads();
         if (wave != 0) return;
         const int ed = s_shw[0], tl = s_shw[1];
-        if (ed > k) { lf_hrequeue_full(A, P); return; }
+        if (ed > k) { lf_hrequeue_bound(A, P, ed); return; }
         if (lane == 0) { A.out_ed[desc] = ed; A.out_end[desc] = tl - 1; lf_hratio(A, 1, ed, n); }
         lf_hfinalize(A, P, 0, n, 0, (uint32_t)tl, ed, P.ops_off);
         return;
@@ -663,7 +668,7 @@ lf_hband_level_kernel(lf_hargs A)
         for (uint32_t base = 0; base <= n; base += 64) { const uint32_t r = base + (uint32_t)lane; if (r <= n) { const int v = F(r) + R(n - r); mn = v < mn ? v : mn; } }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(mn, o); mn = v < mn ? v : mn; }
-        if (mn > k) { lf_hrequeue_full(A, P); return; }
+        if (mn > k) { lf_hrequeue_bound(A, P, mn); return; }
         best = mn;
         if (lane == 0 && P.is_root) { A.out_ed[desc] = best; A.out_end[desc] = (int)m - 1; lf_hratio(A, 0, best, n); }
     }
@@ -682,6 +687,217 @@ lf_hband_level_kernel(lf_hargs A)
     const uint32_t ul = (uint32_t)(split + 1);
     lf_hfinalize(A, P, 0, ul, 0, lw, ls, P.ops_off);
     lf_hfinalize(A, P, ul, n - ul, lw, rw, rs, P.ops_off + ul + lw);
+}
+
+/* ---- SIXTEEN / THIRTY-TWO LANES PER HALF (round 6): most nodes of a batch are small -- C5's gaps between sparse anchors are 2 000 - 5 000 rows at 10 % error, tens of
+ * thousands per chunk and level, its roots 7 000 rows inside a trial band of 1 300 diagonals -- and their band needs a handful of blocks per column: a half of such a node on a whole
+ * wavefront leaves most of it idle, and with that many nodes a level is bound by VALU issue (a step is ~40 instructions, four cycles each on a SIMD), not by the longest chain.
+ * Here a half is a group of L = 16 or 32 lanes (block b on lane b mod L of the group; the carry round the group by DPP row_ror:1, resp. wave_ror:1 with lanes 0 and 32 set right by two
+ * v_readlane; everything else as in lf_hband_sweep with W = 1): a wavefront sweeps the two halves of 32 / L nodes, or 64 / L SHW roots, at once.  What is uniform per wavefront in
+ * lf_hband_sweep (the node's sizes, band, strings) is per lane here. ---- */
+template <int L>
+__device__ __forceinline__ uint32_t lf_group_ror1(uint32_t v)
+{
+    if constexpr (L == 16) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121 /* row_ror:1 */, 0xf, 0xf, true);
+    else {
+        const uint32_t r = lf_wave_ror1(v);                /* lane i <- lane i - 1, lane 0 <- lane 63 */
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+        const int lane = threadIdx.x & 63;
+        return lane == 0 ? a : lane == 32 ? b : r;
+    }
+}
+template <int L, bool TRACK>
+__device__ __forceinline__ void lf_hband_sweepL(const lf_hargs &A, const int64_t qstart, const int64_t tstart, const unsigned flags, const uint32_t n, const int mm, const lf_hband B,
+                                                 const bool idle, const int nG, uint64_t *peq, uint64_t *blk_out, int *s_shw)
+{
+    const int lane = threadIdx.x & 63, gl = lane & (L - 1);
+    const int dq = (flags & LF_F_QREV) ? -1 : 1, dt = (flags & LF_F_TREV) ? -1 : 1;
+    const bool cq = (flags & LF_F_QCOMP) != 0, ct = (flags & LF_F_TCOMP) != 0;
+    const int nbk = (int)((n + 63) >> 6), lastb = (int)((n - 1) >> 6), lastbit = (int)((n - 1) & 63);
+    int nbA = idle || mm <= 0 ? 0 : (mm - 1 - B.dlo) / 64 + 1; if (nbA > nbk) nbA = nbk;
+    auto jlo = [&](int b) { const int x = 64 * b + B.dlo; return x < 0 ? 0 : x; };
+    auto jhi = [&](int b) { const int x = 64 * b + 63 + B.dhi; return x > mm - 1 ? mm - 1 : x; };
+    auto planes = [&](int bb, uint64_t &lo, uint64_t &hi, uint64_t &valid) {
+        const int64_t r0 = (int64_t)bb * 64;
+        const int64_t p0 = dq > 0 ? qstart + r0 : qstart - r0 - 63;
+        lo = lf_bits64(A.qlo, p0, A.q_words); hi = lf_bits64(A.qhi, p0, A.q_words); valid = lf_bits64(A.qvalid, p0, A.q_words);
+        if (dq < 0) { lo = lf_brev64(lo); hi = lf_brev64(hi); valid = lf_brev64(valid); }
+        if (cq) { lo = ~lo; hi = ~hi; }
+        const int64_t rows = (int64_t)n - r0;
+        const uint64_t rmask = rows <= 0 ? 0ull : rows >= 64 ? ~0ull : ((1ull << rows) - 1);
+        valid &= rmask; lo &= valid; hi &= valid;
+    };
+    int b = -1, nbnext = gl, sc = 0;                       /* (skew(b) = b: L lanes, one "wavefront") */
+    uint32_t jend = 0, jtop = 0, hout = LF_HIN_PLUS1;
+    uint64_t Pv = ~0ull, Mv = 0, nlo = 0, nhi = 0, nvalid = 0;
+    int score = 0, best = 0x7fffffff, best_c = 0;
+    if (nbnext < nbA) planes(nbnext, nlo, nhi, nvalid);
+    uint64_t *peq_l = peq + lane;
+    auto finish = [&]() {
+        if (blk_out && jend == (uint32_t)mm) {
+            blk_out[3 * (size_t)b] = Pv; blk_out[3 * (size_t)b + 1] = Mv;
+            blk_out[3 * (size_t)b + 2] = (uint64_t)(int64_t)(sc - (__popcll(Pv) - __popcll(Mv)));
+        }
+        if (TRACK && b == lastb) { s_shw[0] = best; s_shw[1] = best_c; }
+        b = -1; jend = 0;
+    };
+    auto fetch = [&](int s, int sk) -> uint32_t { return lf_pac16(A.S.pac, tstart + (int64_t)dt * ((int64_t)s - sk), dt, ct, A.pac_syms); };
+    uint32_t Vn;
+    { const bool act0 = nbnext < nbA && 16 > jlo(nbnext) + nbnext; Vn = fetch(0, act0 ? nbnext : 0); }
+    for (int G = 0; G < nG; G++) {
+        const int s0 = 16 * G;
+        const int sc_left = (int)lf_group_ror1<L>((uint32_t)sc); const uint32_t h_left = lf_group_ror1<L>(hout);
+        if (b >= 0 && s0 > (int)jend - 1 + b) finish();
+        if (b < 0 && nbnext < nbA && s0 + 16 > jlo(nbnext) + nbnext) {
+            b = nbnext; nbnext += L;
+            jend = (uint32_t)(jhi(b) + 1);
+            { const int x = 64 * b + B.dhi; jtop = b == 0 ? 0u : (uint32_t)(x > mm ? mm : x); }
+            Pv = ~0ull; Mv = 0;
+            sc = s0 - b <= 0 ? 64 * (b + 1) : sc_left - ((int)(h_left & 1u) - (int)(h_left >> 1)) + 64;
+            if (TRACK && b == lastb) { score = sc - (63 - lastbit); best = (n & 63) ? (int)n : 0x7fffffff; best_c = 0; }
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                const uint64_t slo = 0ull - (uint64_t)(c & 1u), shi = 0ull - (uint64_t)(c >> 1);
+                peq_l[c * 64] = ~((nlo ^ slo) | (nhi ^ shi)) & nvalid;
+            }
+            if (nbnext < nbA) planes(nbnext, nlo, nhi, nvalid);
+        }
+        const uint32_t V = Vn;
+        const int skw = b >= 0 ? b : 0;
+        {
+            const int s1 = s0 + 16;
+            const bool done1 = b >= 0 && s1 > (int)jend - 1 + b;
+            const bool act1 = (b < 0 || done1) && nbnext < nbA && s1 + 16 > jlo(nbnext) + nbnext;
+            Vn = fetch(s1, act1 ? nbnext : skw);
+        }
+        uint32_t acc = 0;
+        if (lf_any(jend != 0u)) {
+            const int p0 = s0 - skw;
+            const bool is_last = TRACK && b == lastb;
+            uint64_t EQ[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) EQ[k] = peq_l[((V >> (2 * k)) & 3u) * 64];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t from_left = lf_group_ror1<L>(hout);
+                const uint32_t col0 = (uint32_t)(p0 + k);
+                if (col0 < jend) {
+                    const uint32_t hin = col0 < jtop ? from_left : LF_HIN_PLUS1;
+                    uint64_t ph, mh;
+                    hout = lf_myers_step(Pv, Mv, EQ[k], hin, ph, mh);
+                    acc |= hout << (2 * k);
+                    if (TRACK) {
+                        score += is_last ? lf_delta_at(ph, mh, lastbit) : 0;
+                        const bool upd = is_last && score < best; best = upd ? score : best; best_c = upd ? (int)col0 + 1 : best_c;
+                    }
+                }
+            }
+        }
+        sc += __popc(acc & 0x55555555u) - __popc(acc & 0xAAAAAAAAu);
+    }
+    if (b >= 0) finish();
+}
+__device__ __forceinline__ int lf_hband_groupsL(uint32_t n, int mm, lf_hband B)
+{
+    if (mm <= 0) return 0;
+    const int nbk = (int)((n + 63) >> 6);
+    int nbA = (mm - 1 - B.dlo) / 64 + 1; if (nbA > nbk) nbA = nbk;
+    const int bl = nbA - 1;
+    int jh = 64 * bl + 63 + B.dhi; if (jh > mm - 1) jh = mm - 1;
+    return (jh + bl) / 16 + 1;
+}
+
+/* one wavefront: SHW = false: the two halves of the nodes NPW blockIdx.x .. + NPW - 1 (L = 16: two nodes, L = 32: one); SHW = true: as many roots as the wavefront has groups */
+template <int L, bool SHW>
+__global__ void __launch_bounds__(64)
+lf_hband_group_kernel(lf_hargs A)
+{
+    constexpr int NGRP = 64 / L, NPW = SHW ? NGRP : NGRP / 2;      /* groups of lanes, nodes per wavefront */
+    __shared__ uint64_t s_peq[256];
+    __shared__ int s_shw[NGRP][2];
+    __shared__ unsigned long long s_base[NPW];
+    const int lane = (int)threadIdx.x, grp = lane / L;
+    const int slot = SHW ? grp : grp >> 1;                 /* the wavefront's node this lane works for */
+    const uint32_t idx = (uint32_t)blockIdx.x * NPW + (uint32_t)slot;
+    const bool live = idx < A.n_in;
+    const lf_hnode P = A.q_in[live ? idx : A.n_in - 1];
+    const uint32_t n = P.n, m = P.m, nbk = (n + 63) >> 6;
+    const uint32_t lw = m / 2, rw = m - lw;
+    if (!SHW && (lane & (2 * L - 1)) == 0 && live) s_base[slot] = atomicAdd(&A.ctl->aux_used, 6ull * nbk);
+    if ((lane & (L - 1)) == 0) { s_shw[grp][0] = (n & 63) ? (int)n : 0x7fffffff; s_shw[grp][1] = 0; }
+    __syncthreads();
+    const bool aux_ok = SHW || !live || s_base[slot] + 6ull * nbk <= A.aux_cap;
+    if (!SHW && live && !aux_ok && (lane & (2 * L - 1)) == 0) { atomicExch(&A.ctl->fail, 5u); A.out_ed[A.roots[P.root].desc] = -2; }
+    uint64_t *Fb = SHW ? nullptr : A.aux + s_base[slot], *Rb = SHW ? nullptr : Fb + 3 * (size_t)nbk;
+    const int64_t dq = (P.flags & LF_F_QREV) ? -1 : 1, dt = (P.flags & LF_F_TREV) ? -1 : 1;
+    if constexpr (SHW) {
+        const int k = (int)P.k0;
+        const lf_hband B = lf_hband_shw(k);
+        const int64_t mme64 = (int64_t)n + k; const int mme = (int)(mme64 < (int64_t)m ? mme64 : (int64_t)m);
+        const int nG = lf_wave_max_i32(live ? lf_hband_groupsL(n, mme, B) : 0);
+        lf_hband_sweepL<L, true>(A, P.qstart, P.tstart, P.flags, n, mme, B, !live, nG, s_peq, nullptr, s_shw[grp]);
+        __syncthreads();
+        for (int u = 0; u < NPW; u++) {                    /* the roots one after the other, with the whole wavefront */
+            const uint32_t iu = (uint32_t)blockIdx.x * NPW + (uint32_t)u;
+            if (iu >= A.n_in) break;
+            const lf_hnode Pu = A.q_in[iu];
+            const uint32_t desc = A.roots[Pu.root].desc;
+            const int ed = s_shw[u][0], tl = s_shw[u][1];
+            if (ed > (int)Pu.k0) { lf_hrequeue_bound(A, Pu, ed); continue; }
+            if (lane == 0) { A.out_ed[desc] = ed; A.out_end[desc] = tl - 1; lf_hratio(A, 1, ed, Pu.n); }
+            lf_hfinalize(A, Pu, 0, Pu.n, 0, (uint32_t)tl, ed, Pu.ops_off);
+        }
+        return;
+    } else {
+        const int k = P.best >= 0 ? P.best : (int)P.k0;
+        const lf_hband B = lf_hband_nw(n, m, k);
+        const bool rev = (grp & 1) != 0;                   /* the group's half: even groups forwards, odd groups backwards */
+        const int mm = rev ? (int)rw : (int)lw;
+        const bool ok = live && aux_ok;
+        const int nG = lf_wave_max_i32(ok ? lf_hband_groupsL(n, mm, B) : 0);
+        const unsigned fl = rev ? (P.flags ^ (LF_F_QREV | LF_F_TREV)) : P.flags;
+        const int64_t qs = rev ? P.qstart + dq * (int64_t)(n - 1) : P.qstart, ts = rev ? P.tstart + dt * (int64_t)(m - 1) : P.tstart;
+        lf_hband_sweepL<L, false>(A, qs, ts, fl, n, mm, B, !ok || mm == 0, nG, s_peq, rev ? Rb : Fb, s_shw[grp]);
+        __threadfence_block();
+        __syncthreads();
+        for (int u = 0; u < NPW; u++) {                    /* split row and children of the two nodes, one after the other, with the whole wavefront */
+            const uint32_t iu = (uint32_t)blockIdx.x * NPW + (uint32_t)u;
+            if (iu >= A.n_in) break;
+            const lf_hnode Pu = A.q_in[iu];
+            const uint32_t nu = Pu.n, mu = Pu.m, nbku = (nu + 63) >> 6, lwu = mu / 2, rwu = mu - lwu;
+            if (s_base[u] + 6ull * nbku > A.aux_cap) continue;
+            const uint64_t *Fu = A.aux + s_base[u], *Ru = Fu + 3 * (size_t)nbku;
+            const uint32_t desc = A.roots[Pu.root].desc;
+            const int ku = Pu.best >= 0 ? Pu.best : (int)Pu.k0;
+            const lf_hband Bu = lf_hband_nw(nu, mu, ku);
+            auto F = [&](uint32_t x) -> int { return lwu ? lf_hcol_band(Fu, x, (int)lwu, (int)lwu, Bu, (int)nbku) : (int)x; };
+            auto R = [&](uint32_t x) -> int { return lf_hcol_band(Ru, x, (int)rwu, (int)rwu, Bu, (int)nbku); };
+            int bestu = Pu.best;
+            if (bestu < 0) {
+                int mn = 0x7fffffff;
+                for (uint32_t base = 0; base <= nu; base += 64) { const uint32_t r = base + (uint32_t)lane; if (r <= nu) { const int v = F(r) + R(nu - r); mn = v < mn ? v : mn; } }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(mn, o); mn = v < mn ? v : mn; }
+                if (mn > ku) { lf_hrequeue_bound(A, Pu, mn); continue; }
+                bestu = mn;
+                if (lane == 0 && Pu.is_root) { A.out_ed[desc] = bestu; A.out_end[desc] = (int)mu - 1; lf_hratio(A, 0, bestu, nu); }
+            }
+            int split = -2, ls = 0, rs = 0;
+            for (uint32_t base = 0; base + 2 <= nu && split == -2; base += 64) {
+                const uint32_t qi = base + (uint32_t)lane;
+                const bool hit = qi + 2 <= nu && F(qi + 1) + R(nu - qi - 1) == bestu;
+                const uint64_t bm = lf_ballot(hit);
+                if (bm) split = (int)(base + (uint32_t)(__ffsll((long long)bm) - 1));
+            }
+            if (split >= 0) { ls = F((uint32_t)split + 1); rs = R(nu - (uint32_t)split - 1); }
+            else if ((int)lwu + R(nu) == bestu) { split = -1; ls = (int)lwu; rs = R(nu); }
+            else if (F(nu) + (int)rwu == bestu) { split = (int)nu - 1; ls = F(nu); rs = (int)rwu; }
+            else { if (lane == 0) { atomicExch(&A.ctl->fail, 1u); A.out_ed[desc] = -2; } continue; }
+            const uint32_t ul = (uint32_t)(split + 1);
+            lf_hfinalize(A, Pu, 0, ul, 0, lwu, ls, Pu.ops_off);
+            lf_hfinalize(A, Pu, ul, nu - ul, lwu, rwu, rs, Pu.ops_off + ul + lwu);
+        }
+    }
 }
 
 /* the problems above edlib's traceback switch become roots: a table entry + a node of level 0 */
@@ -750,6 +966,15 @@ void lf_hirsch_launch_roots(hipStream_t s, bool pac_targets, const lf_aln_desc_t
 void lf_hirsch_launch_level(hipStream_t s, bool pac, int kbc, lf_hargs A)
 {
     if (A.n_in == 0) return;
+    /* thirty-two lanes per half cost two v_readlane per step on the dependent chain: worth it when the level has more nodes than the GPU holds wavefronts at once (a
+     * level bound by VALU issue: half the wavefronts), not when all of them are resident anyway (a level bound by its longest chain: the one-wavefront kernel's
+     * step is shorter) */
+    if (kbc == LF_HQ_NW32 && A.n_in < 2500u) kbc = LF_HQ_NW0;
+    if (kbc == LF_HQ_SHW32 && A.n_in < 5000u) kbc = LF_HQ_SHW0;
+    if (kbc == LF_HQ_NW16) { hipLaunchKernelGGL((lf_hband_group_kernel<16, false>), dim3((A.n_in + 1) / 2), dim3(64), 0, s, A); return; }
+    if (kbc == LF_HQ_SHW16) { hipLaunchKernelGGL((lf_hband_group_kernel<16, true>), dim3((A.n_in + 3) / 4), dim3(64), 0, s, A); return; }
+    if (kbc == LF_HQ_NW32) { hipLaunchKernelGGL((lf_hband_group_kernel<32, false>), dim3(A.n_in), dim3(64), 0, s, A); return; }
+    if (kbc == LF_HQ_SHW32) { hipLaunchKernelGGL((lf_hband_group_kernel<32, true>), dim3((A.n_in + 1) / 2), dim3(64), 0, s, A); return; }
     if (kbc >= LF_HQ_NW0) {      /* banded sweeps, by the wavefronts the band needs */
         const dim3 gb(A.n_in);
         switch (kbc) {

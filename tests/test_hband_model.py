@@ -74,7 +74,7 @@ def ref_node(model, q, t):
     return out
 
 
-@pytest.mark.parametrize("L,Wmax,nmax,ncase", [(64, 1, 6500, 24), (8, 1, 1500, 150), (8, 4, 3000, 150), (4, 2, 900, 150), (4, 16, 3000, 100), (64, 2, 9000, 6)])
+@pytest.mark.parametrize("L,Wmax,nmax,ncase", [(64, 1, 6500, 24), (8, 1, 1500, 150), (8, 4, 3000, 150), (4, 2, 900, 150), (4, 16, 3000, 100), (64, 2, 9000, 6), (16, 1, 7000, 60), (32, 1, 7000, 30)])   # (16, 1), (32, 1): lf_hband_group_kernel's groups of sixteen / thirty-two lanes
 def test_banded_node_equals_full_matrix_node(model, L, Wmax, nmax, ncase):
     rng = np.random.default_rng(1000 * L + Wmax)
     done = fits = 0
@@ -106,7 +106,7 @@ def test_banded_node_equals_full_matrix_node(model, L, Wmax, nmax, ncase):
         assert len(ws) > 1, ws              # more than one wavefront class was exercised
 
 
-@pytest.mark.parametrize("L,Wmax,nmax,ncase", [(64, 2, 5000, 16), (8, 4, 1200, 150), (4, 4, 600, 150), (4, 16, 2500, 100)])
+@pytest.mark.parametrize("L,Wmax,nmax,ncase", [(64, 2, 5000, 16), (8, 4, 1200, 150), (4, 4, 600, 150), (4, 16, 2500, 100), (16, 1, 5000, 40), (32, 1, 5000, 20)])
 def test_banded_shw_equals_full_matrix_shw(model, L, Wmax, nmax, ncase):
     rng = np.random.default_rng(77 * L + Wmax)
     fits = 0
