@@ -701,7 +701,11 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
         HIPCHK(hipMemsetAsync(d_ctl, 0, sizeof(lf_hctl), s));
         HA.S.q = D->d_q; HA.S.t = D->d_t; HA.S.pac = D->d_pac; HA.pac_syms = D->pac_syms;
         lf_htrial_pick(HA.trial16);
-        if (const char *e_ = lf_env("LF_HIRSCH_TRIAL")) { unsigned a_ = 0, b_ = 0; if (sscanf(e_, "%u,%u", &a_, &b_) == 2 && a_ <= 16 && b_ <= 16) { HA.trial16[0] = a_; HA.trial16[1] = b_; } }      /* test hook: fixed bounds "nw,shw" */
+        HA.trial_min = LF_HTRIAL_MIN_ROWS;
+        if (const char *e_ = lf_env("LF_HIRSCH_TRIAL")) {      /* test hook: fixed bounds "nw,shw", optionally ",rows" (only roots above that many rows try) */
+            unsigned a_ = 0, b_ = 0, c_ = 0; const int got_ = sscanf(e_, "%u,%u,%u", &a_, &b_, &c_);
+            if (got_ >= 2 && a_ <= 16 && b_ <= 16) { HA.trial16[0] = a_; HA.trial16[1] = b_; if (got_ == 3) HA.trial_min = c_; }
+        }
         { const long hb_ = lf_env_long("LF_HIRSCH_BAND", 1); HA.no_band = hb_ == 0 ? 1u : hb_ == 64 ? 2u : hb_ == 3 ? 4u : 0u; }      /* (read per call: the tests switch it) */
         HA.qlo = D->d_planes; HA.qhi = D->d_planes + D->q_words; HA.qvalid = D->d_planes + 2 * D->q_words; HA.q_words = D->q_words;
         HA.q_cap = (uint32_t)q_cap; HA.ctl = d_ctl; HA.roots = d_roots; HA.segs = d_segs; HA.hdesc = d_hdesc; HA.hopsoff = d_hopsoff; HA.hleaf_cap = (uint32_t)hcap;

@@ -36,6 +36,7 @@ struct lf_hargs {
     uint32_t n_in, q_cap, out_par;
     uint32_t no_band;                     /* A / B and test hook: 1 (LF_HIRSCH_BAND=0): every node takes the unbanded sweep of its size; 2 (LF_HIRSCH_BAND=64): no sixteen-lane queues */
     uint32_t trial16[2];                  /* trial bound of the NW / SHW roots in sixteenths of their rows, 0 = none */
+    uint32_t trial_min;                   /* ... of the roots above this many rows (LF_HTRIAL_MIN_ROWS) */
     lf_hctl *ctl; lf_hroot *roots; lf_hseg *segs;
     lf_aln_desc_t *hdesc; uint64_t *hopsoff; uint32_t hleaf_cap;
     uint64_t *aux; uint64_t aux_cap; uint8_t *hcar; uint64_t hcar_cap;
@@ -74,7 +75,9 @@ static inline __host__ __device__ bool lf_hband_fits(lf_hband B, uint32_t n, int
     const int dhi = B.dhi < mm - 64 ? B.dhi : mm - 64, dlo = B.dlo > -64 * (nbk - 1) ? B.dlo : -64 * (nbk - 1);
     return dhi - dlo <= 4096 * W + LF_HB_LAG(W) * W - 94;
 }
-/* trial bounds of the roots above 4096 rows, in sixteenths of the rows (trial16; 0 = none).  A root does not know its distance: it is swept inside the band of a
+/* trial bounds of the roots, in sixteenths of the rows (trial16; 0 = none), chosen from the distances of the roots above 4096 rows -- the ones whose chain a failed trial
+ * makes longer -- and applied to every root above LF_HTRIAL_MIN_ROWS: the many roots just above edlib's traceback switch (2 000 - 4 000 rows: C5's gaps between sparse
+ * anchors) would otherwise be swept with the whole matrix as their band, forty blocks per column on two wavefronts per half where their distance needs seven on sixteen lanes.  A root does not know its distance: it is swept inside the band of a
  * bound k0 -- min (F + R) <= k0, resp. the SHW minimum <= k0, proves the result exact -- and k0 = n + m is the whole matrix.  A trial that fails still
  * says something: every value a banded sweep computes is the cost of a real path, so the minimum it found is an UPPER bound of the distance and the band of THAT bound
  * holds an optimal path -- the root goes back to the queue with it (for unrelated strings ~0.55 of the rows: a third of the whole matrix).  The levels are a chain of
@@ -86,6 +89,7 @@ static inline __host__ __device__ uint32_t lf_htrial_shw(uint32_t n, uint32_t tr
 /* the queue of a node.  Queues 3 .. 6: NW nodes on the banded sweep with 1 / 2 / 4 / 8 wavefronts per half; 7 .. 11: SHW roots (one half) on 1 .. 16 wavefronts;
  * 0 .. 2: what does not fit sixteen wavefronts, and targets with bytes other than ACGT (stage API), on the unbanded sweeps by rows (super-bands through HBM
  * above 32 768 rows).  *k0: the bound a node of unknown distance is swept with */
+#define LF_HTRIAL_MIN_ROWS 512
 #define LF_HQ_NW0 3
 #define LF_HQ_SHW0 7
 #define LF_HQ_NW16 12        /* NW nodes whose band fits SIXTEEN LANES: two nodes (four halves) per wavefront, lf_hband_group_kernel */
@@ -120,9 +124,9 @@ static inline __host__ __device__ int lf_hqueue_of_bound(uint32_t n, uint32_t m,
     }
     return lf_hkb_class(n);
 }
-static inline __host__ __device__ int lf_hqueue_of(uint32_t n, uint32_t m, int best, int kind, unsigned pad, uint32_t trial16, uint32_t *k0)
+static inline __host__ __device__ int lf_hqueue_of(uint32_t n, uint32_t m, int best, int kind, unsigned pad, uint32_t trial16, uint32_t trial_min, uint32_t *k0)
 {
-    const bool trial = n > 4096 && trial16 != 0;
+    const bool trial = n > trial_min && trial16 != 0;
     const uint32_t t = !trial ? n + m : kind == 1 ? lf_htrial_shw(n, trial16) : lf_htrial_nw(n, m, trial16);
     return lf_hqueue_of_bound(n, m, best, kind, pad, t, k0);
 }

@@ -328,7 +328,7 @@ __device__ __forceinline__ void lf_hfinalize(const lf_hargs &A, const lf_hnode &
     }
     if (lane == 0) {
         uint32_t k0;
-        const int kbc = lf_hqueue_of(cn, cm, best, 0, (P.pad & 1u) | A.no_band, 0, &k0);      /* (its distance is known: a band of exactly that width, no trial) */
+        const int kbc = lf_hqueue_of(cn, cm, best, 0, (P.pad & 1u) | A.no_band, 0, 0, &k0);      /* (its distance is known: a band of exactly that width, no trial) */
         const uint32_t idx = atomicAdd(&A.ctl->q_n[A.out_par][kbc], 1u);
         if (idx >= A.q_cap) { atomicExch(&A.ctl->fail, 4u); return; }
         lf_hnode c;
@@ -909,7 +909,7 @@ __global__ void lf_hirsch_roots_kernel(const lf_aln_desc_t *__restrict__ d, cons
     if (x.n == 0 || x.m == 0 || lf_leaf(x.n, x.m)) return;
     const uint32_t r = atomicAdd(&A.ctl->n_roots, 1u), cap = lf_hroot_cap(x.n, x.m), so = atomicAdd(&A.ctl->seg_used, cap);
     uint32_t k0;
-    const int kbc = lf_hqueue_of(x.n, x.m, -1, x.mode ? 1 : 0, (x.pad[0] != 0 ? 1u : 0u) | A.no_band, A.trial16[x.mode ? 1 : 0], &k0);
+    const int kbc = lf_hqueue_of(x.n, x.m, -1, x.mode ? 1 : 0, (x.pad[0] != 0 ? 1u : 0u) | A.no_band, A.trial16[x.mode ? 1 : 0], A.trial_min, &k0);
     const uint32_t idx = atomicAdd(&A.ctl->q_n[A.out_par][kbc], 1u);
     if (idx >= A.q_cap) { atomicExch(&A.ctl->fail, 4u); return; }
     if (k0 && k0 != x.n + x.m) atomicAdd(&A.ctl->n_trial, 1u);

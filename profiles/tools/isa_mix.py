@@ -22,7 +22,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "lordfast_amd", "csrc")
 KERNELS = ["lf_seed_search_kernel", "lf_edlib_rsweep_kernel", "lf_edlib_tb_kernel", "lf_render_kernel", "lf_vote_cell_kernel", "lf_seed_locate_kernel",
-           "lf_chain_n2_kernel", "lf_chain_n2_big_kernel", "lf_ksw_mw_kernel", "lf_ksw_r4_kernel", "lf_hirsch_level_kernel", "lf_hband_level_kernel", "lf_sam_write_kernel"]
+           "lf_chain_n2_kernel", "lf_chain_n2_big_kernel", "lf_ksw_mw_kernel", "lf_ksw_r4_kernel", "lf_hirsch_level_kernel", "lf_hband_level_kernel", "lf_hband_group_kernel", "lf_sam_write_kernel"]
 FOUR = re.compile(r"^v_(bfi|and_or|or3|alignbit|alignbyte|lshl_or|lshl_add|add3|xad|bfe|med3|perm|mad|mul_|fma|add_co|addc_co|sub_co|subb_co|subrev_co|subbrev_co|"
                   r"lshlrev_b64|lshrrev_b64|ashrrev_i64|lshl_add_u64|readlane|readfirstlane|writelane|mbcnt|cvt_|rcp|div_|sad|min3|max3|add_lshl|xor3|cndmask_b32_e64|"
                   r"cmp_\w+_e64|cmpx_\w+_e64|[a-z_0-9]+_f64|[a-z_0-9]+_dpp|pk_)")
