@@ -2,6 +2,7 @@
 # collect_r06.sh <part> -- round 6's profile sets, run on the GPU box from the repo root; results under gpurun_out/<dir>/ (copied into profiles/<dir>/)
 #   part c2      : profiles/tools/collect.sh r06_c2 (bench with the CPU baseline, kernel trace + stats, serialized stats, FETCH / WRITE / SQ counter passes)
 #   part configs : C4 (reads out of segmental duplications, clasp, -n 30, 10 x 100 k), C5 (ONT-like reads, T2T-like repeats), C2 on GRCh38-like repeats -- each with the CPU baseline
+#   part hirsch  : every Hirschberg launch of one C5 step in the exclusive pass's mode, in time order (profiles/r06_hirsch/)
 #   part shards  : the one-GPU proxy of strong scaling: 12.5 k / 25 k / 50 k-read steps alone and with 2 / 4 steps in flight
 set -u
 PART=${1:-c2}
@@ -26,6 +27,10 @@ configs)
   timeout 1500 python3 bench.py --config c4 --steps 10 --warmup 1 > $OUT/bench_c4_segdup_clasp_n30.json 2> $OUT/bench_c4.err; summ $OUT/bench_c4_segdup_clasp_n30.json
   timeout 1200 python3 bench.py --config c5 --steps 3 --warmup 1 > $OUT/bench_c5_ont50k_k17c2000_t2tlike.json 2> $OUT/bench_c5.err; summ $OUT/bench_c5_ont50k_k17c2000_t2tlike.json
   timeout 900 python3 bench.py --repeat-profile grch38like --steps 4 --warmup 1 > $OUT/bench_c2_grch38like.json 2> $OUT/bench_grch38like.err; summ $OUT/bench_c2_grch38like.json
+  ;;
+hirsch)
+  bash profiles/tools/r06_c5trace.sh
+  tail -1 gpurun_out/r06_hirsch/c5_last_step_launches_alone_on_the_gpu.txt
   ;;
 shards)
   OUT=$PWD/gpurun_out/r06_shard_sweep; mkdir -p $OUT
