@@ -29,8 +29,7 @@ configs)
   timeout 900 python3 bench.py --repeat-profile grch38like --steps 4 --warmup 1 > $OUT/bench_c2_grch38like.json 2> $OUT/bench_grch38like.err; summ $OUT/bench_c2_grch38like.json
   ;;
 hirsch)
-  bash profiles/tools/r06_c5trace.sh
-  tail -1 gpurun_out/r06_hirsch/c5_last_step_launches_alone_on_the_gpu.txt
+  for c in c5 c4; do bash profiles/tools/r06_c5trace.sh $c; tail -1 gpurun_out/r06_hirsch/${c}_last_step_launches_alone_on_the_gpu.txt; done
   ;;
 shards)
   OUT=$PWD/gpurun_out/r06_shard_sweep; mkdir -p $OUT
