@@ -706,7 +706,11 @@ static int run_edlib_desc_gpu(int device, int n, const lf_desc_src *D, int32_t *
             unsigned a_ = 0, b_ = 0, c_ = 0; const int got_ = sscanf(e_, "%u,%u,%u", &a_, &b_, &c_);
             if (got_ >= 2 && a_ <= 16 && b_ <= 16) { HA.trial16[0] = a_; HA.trial16[1] = b_; if (got_ == 3) HA.trial_min = c_; }
         }
-        { const long hb_ = lf_env_long("LF_HIRSCH_BAND", 1); HA.no_band = hb_ == 0 ? 1u : hb_ == 64 ? 2u : hb_ == 3 ? 4u : 0u; }      /* (read per call: the tests switch it) */
+        { const long hb_ = lf_env_long("LF_HIRSCH_BAND", 1); HA.no_band = hb_ == 0 ? 1u : hb_ == 64 ? 2u : hb_ == 3 ? 4u : 0u;      /* (read per call: the tests switch it) */
+          /* the lane-group queues (lf_hband_group_kernel) are for levels that are bound by VALU issue -- far more nodes than the GPU holds wavefronts; a call with few roots is
+           * bound by its longest chains and by the number of launches per level, and four more queues only add launches (C4, 11 k roots per call: 202 -> 213 ms per step with
+           * them).  LF_HIRSCH_BAND=16 keeps them on for any call (tests). */
+          if (hb_ != 16 && HC.roots < 16384) HA.no_band |= 2u; }
         HA.qlo = D->d_planes; HA.qhi = D->d_planes + D->q_words; HA.qvalid = D->d_planes + 2 * D->q_words; HA.q_words = D->q_words;
         HA.q_cap = (uint32_t)q_cap; HA.ctl = d_ctl; HA.roots = d_roots; HA.segs = d_segs; HA.hdesc = d_hdesc; HA.hopsoff = d_hopsoff; HA.hleaf_cap = (uint32_t)hcap;
         HA.aux = d_haux; HA.aux_cap = aux_cap; HA.hcar = d_hcar; HA.hcar_cap = hcar_cap;

@@ -95,7 +95,7 @@ def test_edlib_fuzz_vs_oracle(oracle_lib):
         assert np.array_equal(r[2], o[2]), (i, len(qs[i]), len(ts[i]), modes[i])
 
 
-@pytest.mark.parametrize("band", [1, 64, 0])
+@pytest.mark.parametrize("band", [16, 64, 0])
 def test_edlib_checkpoint_tiles_and_device_hirschberg(oracle_lib, monkeypatch, band):
     """shapes aimed at the recompute-from-checkpoint traceback and the breadth-first Hirschberg levels (lf_rsweep.hip,
     lf_align.hip, lf_hirsch.hip): tile boundaries (m around multiples of 8 / 16), paths that climb > 64 rows inside one
@@ -103,7 +103,8 @@ def test_edlib_checkpoint_tiles_and_device_hirschberg(oracle_lib, monkeypatch, b
     than the LDS ring of the level kernels, tall-and-thin / short-and-wide leaves, several recursion levels, SHW roots
     whose prefix is a leaf"""
     import lordfast_amd as la
-    # 1: nodes are swept inside the band of their distance (sixteen lanes, or one to eight wavefronts per half); 64: no sixteen-lane queues; 0: every block of every column
+    # 16: nodes are swept inside the band of their distance (sixteen / thirty-two lanes, or one to eight wavefronts per half; 1, the default, leaves the lane groups to calls of
+    # 16 384 roots and more); 64: whole wavefronts only; 0: every block of every column
     monkeypatch.setenv("LF_HIRSCH_BAND", str(band))
     orc = oracle_lib.Oracle()
     rng = np.random.default_rng(77)
@@ -149,7 +150,7 @@ def test_edlib_checkpoint_tiles_and_device_hirschberg(oracle_lib, monkeypatch, b
         assert np.array_equal(r[2], o[2]), (i, len(qs[i]), len(ts[i]), modes[i])
 
 
-@pytest.mark.parametrize("band", [1, 64, 0])
+@pytest.mark.parametrize("band", [16, 64, 0])
 def test_edlib_queries_above_32768_rows(oracle_lib, monkeypatch, band):
     """queries longer than one wavefront holds as register-resident blocks (64 lanes x 8 blocks x 64 rows = 32 768): the
     Hirschberg levels sweep them in row bands whose boundary carries go through HBM (lf_hirsch.hip); NW and SHW roots,
@@ -203,11 +204,14 @@ def test_edlib_banded_levels_on_low_complexity_strings(oracle_lib, monkeypatch):
     q = rseq(rng, 4200 + 64 * 3); add(q, q)                                                           # identical strings
     # the roots' trial bounds follow what the process has seen (lf_align.hip: lf_htrial_pick); fixed here: generous, tight (most trials fail), none
     runs = []
+    monkeypatch.setenv("LF_HIRSCH_BAND", "16")                                                      # lane-group queues for the narrow bands although the call is small
     for trial in ("4,4", "2,2", "0,0"):
         monkeypatch.setenv("LF_HIRSCH_TRIAL", trial)
         runs.append(la.edlib_batch(qs, ts, modes)[0])
     monkeypatch.delenv("LF_HIRSCH_TRIAL")
     runs.append(la.edlib_batch(qs, ts, modes)[0])                                                   # ... and chosen from the three runs above
+    monkeypatch.setenv("LF_HIRSCH_BAND", "1")
+    runs.append(la.edlib_batch(qs, ts, modes)[0])                                                   # the default: whole wavefronts for a call of a few roots
     res = runs[0]
     for other in runs[1:]:
         for i, (r, r0) in enumerate(zip(res, other)):
