@@ -723,7 +723,7 @@ def main():
             gbs = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
             traffic = None
             if pmc is not None:
-                prefix = kname.split(" ")[0].rstrip("*")
+                prefix = family_prefixes(kname)
                 fam = [v for k, v in pmc.items() if k.startswith(prefix) and isinstance(v, dict)]
                 if fam:      # the counter passes profile exactly ONE step (--no-exclusive --steps 1 --warmup 0): bytes per step
                     traffic = sum(v.get("fetch_kb", 0.0) + v.get("write_kb", 0.0) for v in fam) * 1024.0
@@ -1000,12 +1000,18 @@ def load_sq(args, world):
     return None, None, "no SQ counter pass + instruction mix of this source tree under profiles/ (profiles/tools/collect.sh, isa_mix.py)"
 
 
+def family_prefixes(kname):
+    """rocprof kernel-name prefixes of a by_kernel entry ("lf_x_* (...)" -> ("lf_x_",)); the Hirschberg levels are two families of kernels"""
+    p = kname.split(" ")[0].rstrip("*")
+    return ("lf_hirsch_", "lf_hband_") if p == "lf_hirsch_" else (p,)
+
+
 def alu_of(kname, kms, sq, isa, src, reads_now):
     """VALU-issue roofline of one kernel (family): sum over its instantiations of wave-level VALU instructions x cycles per instruction
     of the instantiation's loop mix, over 1024 SIMDs at the clock the counter pass saw"""
     if sq is None:
         return dict(frac=None, source=src)
-    prefix = kname.split(" ")[0].rstrip("*")
+    prefix = family_prefixes(kname)
     reads_sq = sq.get("_meta", {}).get("reads_per_step", 50000)
     scale = reads_now / float(reads_sq)
     n_valu = n_salu = cyc = 0.0
