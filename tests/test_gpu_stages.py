@@ -144,10 +144,20 @@ def test_edlib_checkpoint_tiles_and_device_hirschberg(oracle_lib, monkeypatch, b
     q = rseq(rng, 2100); t = b"AC" * 1200 + q[1000:] + b"GT" * 900                                  # low complexity: many co-optimal paths, tie rules decide
     add(q, t)
     res, ms = la.edlib_batch(qs, ts, modes)
+    want = []
     for i, r in enumerate(res):
         o = orc.edlib(qs[i], ts[i], modes[i])
+        want.append(o)
         assert (r[0], r[1]) == (o[0], o[1]), (i, len(qs[i]), len(ts[i]), modes[i])
         assert np.array_equal(r[2], o[2]), (i, len(qs[i]), len(ts[i]), modes[i])
+    if band == 16:
+        # roots of 1 800 - 6 000 rows inside tight trial bounds: SHW roots on sixteen / thirty-two lanes (two sixteenths of 3 700 rows fit 946 diagonals), most of
+        # the 20 - 45 % ones failing their trial and going back with the bound they found; one sixteenth: nearly every trial fails
+        for trial in ("2,2", "1,1"):
+            monkeypatch.setenv("LF_HIRSCH_TRIAL", trial)
+            res2, _ = la.edlib_batch(qs, ts, modes)
+            for i, (r, o) in enumerate(zip(res2, want)):
+                assert (r[0], r[1]) == (o[0], o[1]) and np.array_equal(r[2], o[2]), (trial, i, len(qs[i]), len(ts[i]), modes[i])
 
 
 @pytest.mark.parametrize("band", [16, 64, 0])
