@@ -130,3 +130,46 @@ def test_banded_shw_equals_full_matrix_shw(model, L, Wmax, nmax, ncase):
             else:
                 assert out[0] == 0, (it, n, len(t), k0, out, ref)
     assert fits >= ncase
+
+
+@pytest.mark.parametrize("L,Wmax", [(64, 4), (16, 1), (8, 4)])
+def test_failed_trial_returns_a_bound_whose_band_succeeds(model, L, Wmax):
+    """lf_hrequeue_bound (lf_hirsch.hip): a root whose trial bound was too small goes back to the queue with what its sweep FOUND inside the band -- the cost of a
+    real path, so an upper bound of the distance, so the band of that bound holds an optimal path: the second sweep must succeed and give the full matrix's node
+    (NW: min F + R; SHW: the last row's minimum)."""
+    rng = np.random.default_rng(4242 + L)
+    failed_nw = failed_shw = 0
+    for it in range(120):
+        n = int(rng.integers(70, 2500 if L >= 16 else 900))
+        q, t = make_pair(rng, n, it)
+        ref = ref_node(model, q, t)
+        best = int(ref[4])
+        if best >= 3:
+            k0 = int(rng.integers(max(1, abs(len(t) - n)), best)) if best > abs(len(t) - n) + 1 else best - 1      # a bound below the distance
+            got = run_node(model, q, t, k0, 1, L, Wmax)
+            if got[0] == 0:
+                failed_nw += 1
+                found = int(got[4])
+                assert found >= best, ("what a banded sweep finds is the cost of a real path", n, len(t), k0, found, best)
+                if found < n + len(t):
+                    again = run_node(model, q, t, found, 1, L, Wmax)
+                    if again[0] != -1:      # (-1: wider than the lanes hold -- the device takes the next class up)
+                        assert again[0] == 1 and list(again[1:5]) == list(ref[1:5]), (n, len(t), k0, found, list(again[:5]), list(ref[:5]))
+            elif got[0] == 1:
+                assert list(got[1:5]) == list(ref[1:5])
+        # SHW: the target goes on behind the alignment
+        t2 = np.ascontiguousarray(np.concatenate([t, rng.integers(0, 4, int(rng.integers(1, n // 2 + 2))).astype(np.int8)]))
+        r2 = np.zeros(8, dtype=np.int64); model.hbm_ref_shw(q, n, t2, len(t2), r2)
+        ed = int(r2[1])
+        if ed >= 3:
+            k0 = int(rng.integers(1, ed))
+            out = np.zeros(8, dtype=np.int64); model.hbm_shw(q, n, t2, len(t2), k0, L, Wmax, out)
+            if out[0] == 0:
+                failed_shw += 1
+                found = int(out[1])
+                assert found >= ed, (n, len(t2), k0, found, ed)
+                if found < n + len(t2):
+                    o2 = np.zeros(8, dtype=np.int64); model.hbm_shw(q, n, t2, len(t2), found, L, Wmax, o2)
+                    if o2[0] != -1:
+                        assert o2[0] == 1 and (int(o2[1]), int(o2[2])) == (ed, int(r2[2])), (n, len(t2), k0, found, list(o2[:3]), list(r2[:3]))
+    assert failed_nw > 20 and failed_shw > 20, (failed_nw, failed_shw)
