@@ -173,3 +173,19 @@ def test_failed_trial_returns_a_bound_whose_band_succeeds(model, L, Wmax):
                     if o2[0] != -1:
                         assert o2[0] == 1 and (int(o2[1]), int(o2[2])) == (ed, int(r2[2])), (n, len(t2), k0, found, list(o2[:3]), list(r2[:3]))
     assert failed_nw > 20 and failed_shw > 20, (failed_nw, failed_shw)
+
+
+def test_queue_choice_holds_the_band(tmp_path):
+    """lf_hqueue_of / lf_hqueue_of_bound (lordfast_amd/csrc/lf_hirsch.h, __host__ __device__): over 400 000 random nodes -- known distance, trial bound, a failed
+    trial's second bound, NW / SHW, lane groups on and off -- the queue chosen is one whose kernel holds the node's band, and the narrowest such one; every queue
+    is chosen at least once.  Built with hipcc for the host side only (no kernel is launched)."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "hqueue_check")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "lordfast_amd", "csrc"),
+                    "-Wno-unused-result", "-o", exe, os.path.join(HERE, "models", "hqueue_check.hip")], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
